@@ -1,0 +1,333 @@
+#!/usr/bin/env python
+"""Generate tests/golden/*.npz by running the REAL reference (dynesty 3.0.0
+from /root/reference/py, numpy/scipy of this image) on the seeded inputs of
+tests/inputs.py.  Run in the build container only:
+
+    python tools/make_golden.py
+
+The reference cannot travel to the GPU box, the fixtures can.  Nothing here is
+imported by the product.  Import shim per SURVEY.md appendix B.
+"""
+import os
+import sys
+import tempfile
+import warnings
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def import_reference():
+    shim = tempfile.mkdtemp(prefix="dynesty_shim_")
+    di = os.path.join(shim, "dynesty-3.0.0.dist-info")
+    os.makedirs(di)
+    with open(os.path.join(di, "METADATA"), "w") as f:
+        f.write("Metadata-Version: 2.1\nName: dynesty\nVersion: 3.0.0\n")
+    sys.path.insert(0, shim)
+    sys.path.insert(0, "/root/reference/py")
+    import dynesty  # noqa
+    return dynesty
+
+
+def ell_fields(e):
+    return dict(ctr=e.ctr, cov=e.cov, am=e.am, axes=e.axes, axlens=e.axlens,
+                logvol=np.float64(e.logvol))
+
+
+def gen_bounding(out):
+    from dynesty import bounding as db
+    import inputs
+    g = {}
+    for name in inputs.CLOUDS_SMALL:
+        pts = inputs.cloud(name)
+        n, d = pts.shape
+        e = db.bounding_ellipsoid(pts)
+        for k, v in ell_fields(e).items():
+            g[f"{name}/be/{k}"] = v
+        m = db.MultiEllipsoid(d)
+        m.update(pts, rstate=np.random.default_rng(5))
+        g[f"{name}/mu/nells"] = np.int64(m.nells)
+        g[f"{name}/mu/ctrs"] = m.ctrs
+        g[f"{name}/mu/covs"] = m.covs
+        g[f"{name}/mu/ams"] = m.ams
+        g[f"{name}/mu/logvol_ells"] = m.logvol_ells
+        g[f"{name}/mu/logvol"] = np.float64(m.logvol)
+        g[f"{name}/mu/axes"] = np.array([el.axes for el in m.ells])
+        g[f"{name}/mu/axlens"] = np.array([el.axlens for el in m.ells])
+        # which ellipsoid(s) each input point falls in: exact integer KAT
+        # (reference: tests/test_ellipsoid.py:106-133 test_overlap)
+        probe_rng = np.random.default_rng(11)
+        probes = pts[probe_rng.integers(n, size=64)] + \
+            0.3 * pts.std(axis=0) * probe_rng.standard_normal((64, d))
+        wl = [m.within(p) for p in probes]
+        g[f"{name}/kat/probes"] = probes
+        g[f"{name}/kat/within_flat"] = np.concatenate(wl).astype(np.int64) \
+            if len(wl) else np.zeros(0, np.int64)
+        g[f"{name}/kat/within_count"] = np.array([len(w) for w in wl],
+                                                 dtype=np.int64)
+        g[f"{name}/kat/contains"] = np.array([m.contains(p) for p in probes])
+        g[f"{name}/kat/overlap_skip0"] = np.array(
+            [m.overlap(p, j=0) for p in probes], dtype=np.int64)
+        # union samples, same seed (reference: bounding.py:592-606)
+        g[f"{name}/mu/samples"] = m.samples(40, rstate=np.random.default_rng(7))
+        # enlargement as applied by Sampler.update_bound (sampler.py:506-508)
+        m.scale_to_logvol(m.logvol + np.log(1.25))
+        g[f"{name}/sc/ctrs"] = m.ctrs
+        g[f"{name}/sc/covs"] = m.covs
+        g[f"{name}/sc/ams"] = m.ams
+        g[f"{name}/sc/logvol_ells"] = m.logvol_ells
+        g[f"{name}/sc/logvol"] = np.float64(m.logvol)
+        g[f"{name}/sc/axes"] = np.array([el.axes for el in m.ells])
+        g[f"{name}/sc/axlens"] = np.array([el.axlens for el in m.ells])
+        # single-ellipsoid bound
+        s = db.Ellipsoid(d)
+        s.update(pts, rstate=np.random.default_rng(5))
+        g[f"{name}/single/samples"] = s.samples(
+            40, rstate=np.random.default_rng(8))
+        g[f"{name}/single/contains"] = np.array(
+            [s.contains(p) for p in probes])
+        # anisotropic branch of scale_to_logvol (bounding.py:257-275):
+        # ask for a volume that forces axes against the sqrt(D)/2 cap
+        big = db.bounding_ellipsoid(pts)
+        target = big.logvol + d * np.log(
+            (np.sqrt(d) / 2) / big.axlens.max()) + 0.3 * d
+        maxlv = d * np.log(np.sqrt(d) / 2) + db.logvol_prefactor(d)
+        target = min(target, maxlv - 1e-3)
+        big.scale_to_logvol(target)
+        for k, v in ell_fields(big).items():
+            g[f"{name}/aniso/{k}"] = v
+        g[f"{name}/aniso/target"] = np.float64(target)
+        # bootstrap expansion factors (bounding.py:1619-1648)
+        seeds = np.random.SeedSequence(77).spawn(3)
+        g[f"{name}/boot/single"] = np.array([
+            db._ellipsoid_bootstrap_expand((False, pts, sd)) for sd in seeds])
+        seeds = np.random.SeedSequence(77).spawn(3)
+        g[f"{name}/boot/multi"] = np.array([
+            db._ellipsoid_bootstrap_expand((True, pts, sd)) for sd in seeds])
+    # improve_covar_mat on the reference's own edge cases
+    # (tests/test_ellipsoid.py:242-255 test_bounds)
+    for tag, mat in [("zero", np.zeros((4, 4))),
+                     ("rank1", np.outer(np.arange(1., 5.), np.arange(1., 5.))),
+                     ("neg", -np.eye(3))]:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            good, cov, am, axes = db.improve_covar_mat(mat)
+        g[f"icm/{tag}/in"] = mat
+        g[f"icm/{tag}/good"] = np.bool_(good)
+        g[f"icm/{tag}/cov"] = cov
+        g[f"icm/{tag}/am"] = am
+        g[f"icm/{tag}/axes"] = axes
+    for nd in (1, 2, 3, 25, 200):
+        g[f"prefactor/{nd}"] = np.float64(db.logvol_prefactor(nd))
+    np.savez_compressed(out, **g)
+    print("wrote", out, len(g), "arrays")
+
+
+def gen_proposals(out):
+    from dynesty import internal_samplers as dis
+    from dynesty import bounding as db
+    from dynesty.utils import get_nonbounded
+    import inputs
+    g = {}
+
+    def run(tag, cls, kwargs, case, nwalk, seedbase, scale=None, extra=None):
+        prob = case["problem"]
+        seeds = np.random.SeedSequence(seedbase).spawn(nwalk)
+        smp = cls(**kwargs)
+        kw = dict(smp.sampler_kwargs)
+        if extra:
+            kw.update(extra)
+        res = []
+        for i in range(nwalk):
+            arg = dis.SamplerArgument(
+                u=case["u0"][i].copy(), loglstar=case["loglstar"],
+                axes=case["axes"], scale=scale or case["scale"],
+                prior_transform=prob.prior_transform,
+                loglikelihood=prob.loglikelihood, rseed=seeds[i], kwargs=kw)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                res.append(cls.sample(arg))
+        g[f"{tag}/u"] = np.array([r.u for r in res])
+        g[f"{tag}/v"] = np.array([r.v for r in res])
+        g[f"{tag}/logl"] = np.array([float(r.logl) for r in res])
+        g[f"{tag}/ncalls"] = np.array([r.ncalls for r in res], dtype=np.int64)
+        ti = [r.tuning_info for r in res]
+        if ti[0] is not None:
+            for key in ti[0]:
+                g[f"{tag}/ti_{key}"] = np.array([t[key] for t in ti])
+        g[f"{tag}/seedbase"] = np.int64(seedbase)
+        g[f"{tag}/nwalk"] = np.int64(nwalk)
+
+    # ---- rwalk (internal_samplers.py:866-986) ----
+    for pname, nw, walks in (("C2", 8, 45), ("G5", 16, 25), ("C1", 8, 23),
+                             ("C3", 8, 22), ("N6", 8, 26)):
+        case = inputs.walker_case(pname, 64, 900 + walks)
+        d = case["problem"].ndim
+        run(f"rwalk/{pname}", dis.RWalkSampler,
+            dict(ndim=d, ncdim=d, walks=walks, nonbounded=None, periodic=None,
+                 reflective=None), case, nw, 4000 + walks)
+    # periodic + reflective dims
+    case = inputs.walker_case("G5", 64, 931, shrink=3.0)
+    per, ref = np.array([0, 3]), np.array([1])
+    run("rwalk/G5_pr", dis.RWalkSampler,
+        dict(ndim=5, ncdim=5, walks=30,
+             nonbounded=get_nonbounded(5, per, ref), periodic=per,
+             reflective=ref), case, 16, 4100, scale=2.5)
+    # ncdim < ndim: last two dims are redrawn U(0,1) at every step
+    case = inputs.walker_case("G5", 64, 932, shrink=2.0)
+    case3 = dict(case)
+    case3["axes"] = case["axes"][:3, :3].copy()
+    run("rwalk/G5_nc3", dis.RWalkSampler,
+        dict(ndim=5, ncdim=3, walks=20, nonbounded=None, periodic=None,
+             reflective=None), case3, 16, 4200)
+
+    # ---- rslice / slice (internal_samplers.py:745-855, 593-709, 1075-1206) --
+    for pname, nw, slices in (("C3", 12, 5), ("G5", 12, 4), ("N6", 8, 3),
+                              ("C2", 4, 3)):
+        case = inputs.walker_case(pname, 64, 950 + slices)
+        d = case["problem"].ndim
+        run(f"rslice/{pname}", dis.RSliceSampler,
+            dict(ndim=d, ncdim=d, slices=slices, nonbounded=None,
+                 periodic=None, reflective=None), case, nw, 5000 + slices)
+    case = inputs.walker_case("G5", 64, 961)
+    run("rslice/G5_dbl", dis.RSliceSampler,
+        dict(ndim=5, ncdim=5, slices=4, nonbounded=None, periodic=None,
+             reflective=None), case, 12, 5100,
+        extra=dict(slice_doubling=True))
+    # tiny scale forces many expansions
+    run("rslice/G5_tiny", dis.RSliceSampler,
+        dict(ndim=5, ncdim=5, slices=2, nonbounded=None, periodic=None,
+             reflective=None), case, 8, 5200, scale=0.02)
+    for pname, nw, slices in (("G5", 8, 2), ("E3", 8, 2)):
+        case = inputs.walker_case(pname, 64, 970 + slices)
+        d = case["problem"].ndim
+        run(f"slice/{pname}", dis.SliceSampler,
+            dict(ndim=d, ncdim=d, slices=slices, nonbounded=None,
+                 periodic=None, reflective=None), case, nw, 6000 + slices)
+    case = inputs.walker_case("G5", 64, 981)
+    run("slice/G5_dbl", dis.SliceSampler,
+        dict(ndim=5, ncdim=5, slices=2, nonbounded=None, periodic=None,
+             reflective=None), case, 8, 6100, extra=dict(slice_doubling=True))
+
+    # ---- unif inside a bound (internal_samplers.py:243-340) ----
+    def run_unif(tag, prob, bound, nwalk, seedbase, loglstar, ndim, ncdim):
+        seeds = np.random.SeedSequence(seedbase).spawn(nwalk)
+        kw = dict(bound=bound, ndim=ndim, n_cluster=ncdim, nonbounded=None)
+        res = []
+        for i in range(nwalk):
+            arg = dis.SamplerArgument(
+                u=np.zeros(ndim), loglstar=loglstar, axes=None, scale=1.,
+                prior_transform=prob.prior_transform,
+                loglikelihood=prob.loglikelihood, rseed=seeds[i], kwargs=kw)
+            res.append(dis.UniformBoundSampler.sample(arg))
+        g[f"{tag}/u"] = np.array([r.u for r in res])
+        g[f"{tag}/v"] = np.array([r.v for r in res])
+        g[f"{tag}/logl"] = np.array([float(r.logl) for r in res])
+        g[f"{tag}/ncalls"] = np.array([r.ncalls for r in res], dtype=np.int64)
+        g[f"{tag}/loglstar"] = np.float64(loglstar)
+        g[f"{tag}/seedbase"] = np.int64(seedbase)
+
+    prob = inputs.problem("C1")
+    pts = inputs.cloud("g3")
+    single = db.Ellipsoid(3)
+    single.update(pts, rstate=np.random.default_rng(5))
+    lstar = float(np.quantile(
+        prob.loglikelihood_many(prob.prior_transform_many(pts)), 0.3))
+    run_unif("unif/C1_single", prob, single, 16, 7000, lstar, 3, 3)
+    prob = inputs.problem("G5")
+    pts = inputs.cloud("two5")
+    multi = db.MultiEllipsoid(5)
+    multi.update(pts, rstate=np.random.default_rng(5))
+    multi.scale_to_logvol(multi.logvol + 5 * np.log(3.0))  # make them overlap
+    lstar = float(np.quantile(
+        prob.loglikelihood_many(prob.prior_transform_many(pts)), 0.3))
+    run_unif("unif/G5_multi", prob, multi, 16, 7100, lstar, 5, 5)
+    g["unif/G5_multi/nells"] = np.int64(multi.nells)
+    # ncdim < ndim with a 3-D bound on a 5-D problem
+    b3 = db.Ellipsoid(3)
+    b3.update(pts[:, :3].copy(), rstate=np.random.default_rng(5))
+    run_unif("unif/G5_nc3", prob, b3, 8, 7200, lstar - 30.0, 5, 3)
+
+    # ---- unit cube (internal_samplers.py:364-441) ----
+    prob = inputs.problem("C1")
+    seeds = np.random.SeedSequence(7300).spawn(8)
+    res = []
+    for i in range(8):
+        arg = dis.SamplerArgument(
+            u=np.zeros(3), loglstar=-60.0, axes=None, scale=1.,
+            prior_transform=prob.prior_transform,
+            loglikelihood=prob.loglikelihood, rseed=seeds[i],
+            kwargs=dict(ndim=3))
+        res.append(dis.UnitCubeSampler.sample(arg))
+    g["unitcube/C1/u"] = np.array([r.u for r in res])
+    g["unitcube/C1/logl"] = np.array([float(r.logl) for r in res])
+    g["unitcube/C1/ncalls"] = np.array([r.ncalls for r in res], dtype=np.int64)
+
+    np.savez_compressed(out, **g)
+    print("wrote", out, len(g), "arrays")
+
+
+def gen_rng(out):
+    """PCG64 / SeedSequence / ziggurat known answers from NumPy itself (the
+    reference's RNG: utils.py:993-1009)."""
+    g = {}
+    ss = np.random.SeedSequence([11, 22, 33, 44])
+    kids = ss.spawn(5)
+    g["ss/entropy"] = np.array([11, 22, 33, 44], dtype=np.uint64)
+    g["ss/child_state4"] = np.array(
+        [k.generate_state(4, np.uint64) for k in kids])
+    st = []
+    for k in kids:
+        s = np.random.PCG64(k).state["state"]
+        st.append([s["state"] >> 64, s["state"] & (2**64 - 1),
+                   s["inc"] >> 64, s["inc"] & (2**64 - 1)])
+    g["ss/pcg_state"] = np.array(st, dtype=np.uint64)
+    rng = np.random.Generator(np.random.PCG64(kids[2]))
+    g["stream/normals"] = rng.standard_normal(5000)
+    g["stream/uniforms"] = rng.random(100)
+    g["stream/normals2"] = rng.standard_normal(7)
+    s = rng.bit_generator.state["state"]
+    g["stream/final_state"] = np.array(
+        [s["state"] >> 64, s["state"] & (2**64 - 1), s["inc"] >> 64,
+         s["inc"] & (2**64 - 1)], dtype=np.uint64)
+    np.savez_compressed(out, **g)
+    print("wrote", out, len(g), "arrays")
+
+
+def gen_runs(out):
+    """Short end-to-end reference runs (static NestedSampler) for the logZ
+    gate.  C1 full run; C2/C3 are too slow to regenerate casually, their
+    same-seed values are recorded in SURVEY.md section 8c."""
+    import dynesty
+    import inputs
+    g = {}
+    prob = inputs.problem("C1")
+    s = dynesty.NestedSampler(prob.loglikelihood, prob.prior_transform, 3,
+                              nlive=500, bound='single', sample='unif',
+                              rstate=np.random.default_rng(21))
+    s.run_nested(dlogz=0.01, print_progress=False, add_live=False)
+    r = s.results
+    g["C1/logz"] = np.float64(r.logz[-1])
+    g["C1/logzerr"] = np.float64(r.logzerr[-1])
+    g["C1/niter"] = np.int64(r.niter)
+    g["C1/ncall"] = np.int64(np.sum(r.ncall))
+    np.savez_compressed(out, **g)
+    print("wrote", out, dict((k, float(v)) for k, v in g.items()))
+
+
+if __name__ == "__main__":
+    import_reference()
+    gdir = os.path.join(ROOT, "tests", "golden")
+    os.makedirs(gdir, exist_ok=True)
+    which = sys.argv[1:] or ["bounding", "proposals", "rng", "runs"]
+    if "bounding" in which:
+        gen_bounding(os.path.join(gdir, "bounding.npz"))
+    if "proposals" in which:
+        gen_proposals(os.path.join(gdir, "proposals.npz"))
+    if "rng" in which:
+        gen_rng(os.path.join(gdir, "rng.npz"))
+    if "runs" in which:
+        gen_runs(os.path.join(gdir, "runs.npz"))
