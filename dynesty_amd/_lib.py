@@ -1,0 +1,309 @@
+"""ctypes binding of libdynhip.so (C ABI: include/dynhip.h).
+
+There is deliberately **no CPU fallback**: if the shared library is missing or
+no HIP device is visible, importing the backend raises.  Build the library
+with ``python -c "import __graft_entry__ as g; g.build()"`` or
+``make -C dynesty_amd/csrc``.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_ENV = "DYNHIP_LIB"
+
+DH_OK = 0
+ERR_VALUE, ERR_CONTAIN, ERR_REGION, ERR_SLICE = -1, -2, -3, -4
+ERR_HIP, ERR_ARG, ERR_QZERO, ERR_NOMEM = -5, -6, -7, -8
+
+BC_HARD, BC_PERIODIC, BC_REFLECT = 0, 1, 2
+
+
+class DynHipError(RuntimeError):
+    """HIP runtime / argument failures of libdynhip (no reference analogue)."""
+
+
+def lib_path():
+    p = os.environ.get(LIB_ENV)
+    if p:
+        return p
+    return os.path.join(_HERE, "libdynhip.so")
+
+
+_lib = None
+
+_vp, _i, _u32, _u64, _dbl = C.c_void_p, C.c_int, C.c_uint32, C.c_uint64, C.c_double
+_pd = C.POINTER(C.c_double)
+
+# name -> (restype, argtypes); kept in step with include/dynhip.h (checked by
+# tests/test_abi.py, which parses the header).
+SIGNATURES = {
+    "dh_version": (_i, []),
+    "dh_device_count": (_i, []),
+    "dh_create": (_vp, [_i]),
+    "dh_destroy": (None, [_vp]),
+    "dh_last_error": (C.c_char_p, [_vp]),
+    "dh_sync": (_i, [_vp]),
+    "dh_stream": (_vp, [_vp]),
+    "dh_malloc": (_vp, [_vp, _u64]),
+    "dh_free": (_i, [_vp, _vp]),
+    "dh_memcpy_h2d": (_i, [_vp, _vp, _vp, _u64]),
+    "dh_memcpy_d2h": (_i, [_vp, _vp, _vp, _u64]),
+    "dh_memset": (_i, [_vp, _vp, _i, _u64]),
+    "dh_event_create": (_vp, [_vp]),
+    "dh_event_destroy": (_i, [_vp, _vp]),
+    "dh_event_record": (_i, [_vp, _vp]),
+    "dh_event_elapsed_ms": (_i, [_vp, _vp, _vp, _pd]),
+    "dh_problem_create": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _i]),
+    "dh_problem_destroy": (_i, [_vp, _i]),
+    "dh_problem_eval": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
+    "dh_seed_children": (_i, [_vp, _vp, _i, _u32, _i, _vp]),
+    "dh_rng_stream": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
+    "dh_contains": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _vp]),
+    "dh_rwalk_batch": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _dbl, _dbl,
+                            _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dh_rwalk_batch_dev": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _dbl,
+                                _dbl, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                _vp]),
+}
+
+
+def load():
+    """Load libdynhip.so (once) and declare every prototype."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise ImportError(
+            f"libdynhip.so not found at {path}: the HIP extension is required "
+            "(no CPU fallback). Build it with `make -C dynesty_amd/csrc` or "
+            "__graft_entry__.build().")
+    lib = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _f64(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None:
+        a = a.reshape(shape)
+    return a
+
+
+def entropy_words(entropy):
+    """numpy's SeedSequence coercion of a sequence of ints to uint32 words
+    (bit_generator.pyx _coerce_to_uint32_array)."""
+    out = []
+    for n in np.atleast_1d(entropy).tolist():
+        n = int(n)
+        if n < 0:
+            raise ValueError("entropy must be non-negative")
+        if n == 0:
+            out.append(0)
+        while n > 0:
+            out.append(n & 0xFFFFFFFF)
+            n >>= 32
+    return np.array(out, dtype=np.uint32)
+
+
+def pcg_state_words(bitgen):
+    """(4,) uint64 {state_hi, state_lo, inc_hi, inc_lo} of a numpy PCG64."""
+    st = bitgen.state
+    if st["bit_generator"] != "PCG64":
+        raise TypeError("only numpy PCG64 streams are supported")
+    s, inc = st["state"]["state"], st["state"]["inc"]
+    m = (1 << 64) - 1
+    return np.array([s >> 64, s & m, inc >> 64, inc & m], dtype=np.uint64)
+
+
+def set_pcg_state_words(bitgen, words):
+    """Write a device-advanced state back into a numpy PCG64 (keeps the
+    buffered uint32 half exactly as numpy would: see SURVEY.md appendix A)."""
+    st = bitgen.state
+    w = [int(x) for x in words]
+    st["state"]["state"] = (w[0] << 64) | w[1]
+    st["state"]["inc"] = (w[2] << 64) | w[3]
+    bitgen.state = st
+
+
+class Context:
+    """One device + stream (dh_ctx).  Methods take/return NumPy arrays."""
+
+    def __init__(self, device=0):
+        self.lib = load()
+        self.handle = self.lib.dh_create(int(device))
+        if not self.handle:
+            msg = self.lib.dh_last_error(None).decode()
+            raise DynHipError(f"dh_create({device}) failed: {msg}")
+        self.device = int(device)
+        self._problems = {}
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.dh_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- errors -------------------------------------------------------------
+    def _check(self, rc):
+        if rc >= 0:
+            return rc
+        msg = self.lib.dh_last_error(self.handle).decode()
+        if rc == ERR_VALUE:
+            raise ValueError(msg)
+        if rc in (ERR_CONTAIN, ERR_REGION, ERR_SLICE, ERR_QZERO):
+            raise RuntimeError(msg)
+        raise DynHipError(f"libdynhip error {rc}: {msg}")
+
+    def sync(self):
+        self._check(self.lib.dh_sync(self.handle))
+
+    # -- device memory --------------------------------------------------------
+    def malloc(self, nbytes):
+        p = self.lib.dh_malloc(self.handle, int(nbytes))
+        if not p:
+            self._check(ERR_NOMEM)
+        return p
+
+    def free(self, dptr):
+        self._check(self.lib.dh_free(self.handle, dptr))
+
+    def to_device(self, arr):
+        arr = np.ascontiguousarray(arr)
+        p = self.malloc(arr.nbytes)
+        self._check(self.lib.dh_memcpy_h2d(self.handle, p, _ptr(arr),
+                                           arr.nbytes))
+        return p
+
+    def from_device(self, dptr, shape, dtype):
+        out = np.empty(shape, dtype=dtype)
+        self._check(self.lib.dh_memcpy_d2h(self.handle, _ptr(out), dptr,
+                                           out.nbytes))
+        return out
+
+    def event(self):
+        return self.lib.dh_event_create(self.handle)
+
+    def record(self, ev):
+        self._check(self.lib.dh_event_record(self.handle, ev))
+
+    def elapsed_ms(self, ev0, ev1):
+        ms = C.c_double(0.0)
+        self._check(self.lib.dh_event_elapsed_ms(self.handle, ev0, ev1,
+                                                 C.byref(ms)))
+        return ms.value
+
+    # -- problems -------------------------------------------------------------
+    def problem(self, prob):
+        """Upload (once) a dynesty_amd.problems.Problem; returns the handle."""
+        key = id(prob)
+        if key in self._problems:
+            return self._problems[key][0]
+        like_id, like_par, prior_id, prior_par = prob.device_spec()
+        lp, pp = _f64(like_par), _f64(prior_par)
+        h = self._check(self.lib.dh_problem_create(
+            self.handle, prob.ndim, like_id, _ptr(lp), lp.size, prior_id,
+            _ptr(pp) if pp.size else None, pp.size))
+        self._problems[key] = (h, prob)  # keep prob alive: id() stays unique
+        return h
+
+    def problem_eval(self, prob, u):
+        u = _f64(u).reshape(-1, prob.ndim)
+        k = u.shape[0]
+        v = np.empty_like(u)
+        logl = np.empty(k)
+        self._check(self.lib.dh_problem_eval(self.handle, self.problem(prob),
+                                             k, _ptr(u), _ptr(v), _ptr(logl)))
+        return v, logl
+
+    # -- RNG ------------------------------------------------------------------
+    def seed_children(self, entropy, first, k):
+        words = entropy_words(entropy)
+        out = np.empty((k, 4), dtype=np.uint64)
+        self._check(self.lib.dh_seed_children(self.handle, _ptr(words),
+                                              words.size, int(first), int(k),
+                                              _ptr(out)))
+        return out
+
+    def rng_stream(self, state4, n_normal, n_unif):
+        st = np.ascontiguousarray(state4, dtype=np.uint64)
+        nrm = np.empty(max(n_normal, 1))
+        unf = np.empty(max(n_unif, 1))
+        out = np.empty(4, dtype=np.uint64)
+        self._check(self.lib.dh_rng_stream(self.handle, _ptr(st), n_normal,
+                                           n_unif, _ptr(nrm), _ptr(unf),
+                                           _ptr(out)))
+        return nrm[:n_normal], unf[:n_unif], out
+
+    # -- membership -------------------------------------------------------------
+    def contains(self, x, ctrs, ams, mode=0, want_mask=False, want_quad=False):
+        x = _f64(x)
+        if x.ndim == 1:
+            x = x[None, :]
+        k, d = x.shape
+        ctrs = _f64(ctrs).reshape(-1, d)
+        m = ctrs.shape[0]
+        ams = _f64(ams).reshape(m, d, d)
+        count = np.empty(k, dtype=np.int32)
+        nw = (k + 63) // 64
+        mask = np.empty((m, nw), dtype=np.uint64) if want_mask else None
+        quad = np.empty((k, m)) if want_quad else None
+        self._check(self.lib.dh_contains(self.handle, _ptr(x), k, d,
+                                         _ptr(ctrs), _ptr(ams), m, mode,
+                                         _ptr(count), _ptr(mask), _ptr(quad)))
+        return count, mask, quad
+
+    # -- proposals ----------------------------------------------------------------
+    def rwalk_batch(self, prob, u0, axes, scale, loglstar, walks, rng_states,
+                    axes_idx=None, ncdim=None, bc=None):
+        """Batched RWalkSampler.sample (see dh_rwalk_batch)."""
+        ndim = prob.ndim
+        u0 = _f64(u0).reshape(-1, ndim)
+        k = u0.shape[0]
+        ncdim = ndim if ncdim is None else int(ncdim)
+        axes = _f64(axes).reshape(-1, ncdim, ncdim)
+        m = axes.shape[0]
+        idx = None if axes_idx is None else np.ascontiguousarray(
+            axes_idx, dtype=np.int32)
+        bcarr = None if bc is None else np.ascontiguousarray(bc, dtype=np.int8)
+        rng = np.ascontiguousarray(rng_states, dtype=np.uint64).reshape(k, 4)
+        u = np.empty((k, ndim))
+        v = np.empty((k, ndim))
+        logl = np.empty(k)
+        nacc = np.empty(k, dtype=np.int32)
+        nrej = np.empty(k, dtype=np.int32)
+        rng_out = np.empty((k, 4), dtype=np.uint64)
+        self._check(self.lib.dh_rwalk_batch(
+            self.handle, self.problem(prob), k, ndim, ncdim, _ptr(u0),
+            _ptr(axes), m, _ptr(idx), float(scale), float(loglstar),
+            int(walks), _ptr(bcarr), _ptr(rng), _ptr(u), _ptr(v), _ptr(logl),
+            _ptr(nacc), _ptr(nrej), _ptr(rng_out)))
+        return dict(u=u, v=v, logl=logl, accept=nacc, reject=nrej,
+                    rng_out=rng_out)
+
+
+_default_ctx = {}
+
+
+def default_context(device=0):
+    """Process-wide context per device (created lazily)."""
+    ctx = _default_ctx.get(device)
+    if ctx is None or ctx.handle is None:
+        ctx = Context(device)
+        _default_ctx[device] = ctx
+    return ctx

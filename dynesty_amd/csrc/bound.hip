@@ -1,0 +1,95 @@
+// Bounding kernels: ellipsoid membership (K5).  Rebuild kernels follow below.
+#include "ctx.h"
+
+using namespace dh;
+
+namespace {
+
+#define DH_DIM_LIST(X) X(1) X(2) X(3) X(4) X(5) X(6) X(8) X(10) X(12) X(16) X(20) X(25) X(32)
+constexpr int kMaxRegDim = 32;
+
+// MultiEllipsoid.within / contains (bounding.py:502-523): lane = candidate point,
+// the loop runs over ellipsoids so centre and precision matrix are wave-uniform
+// (scalar loads); each ellipsoid's verdict for 64 candidates is one ballot word.
+template <int N>
+__global__ void __launch_bounds__(64)
+    contains_kernel(const double* __restrict__ x, int k, int d, const double* __restrict__ ctrs,
+                    const double* __restrict__ ams, int m, int mode, int32_t* count, uint64_t* mask,
+                    double* quad) {
+  const int w = blockIdx.x * 64 + threadIdx.x;
+  const bool live = w < k;
+  const int wi = live ? w : k - 1;
+  double xx[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) xx[i] = (i < d) ? x[(size_t)wi * d + i] : 0.0;
+  int cnt = 0;
+  const int nwords = (k + 63) / 64;
+  for (int a = 0; a < m; ++a) {
+    const double* __restrict__ c = ctrs + (size_t)a * d;
+    const double* __restrict__ A = ams + (size_t)a * d * d;
+    double dl[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) dl[i] = (i < d) ? xx[i] - c[i] : 0.0;
+    double q = 0.0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      if (i < d) {
+        double r = 0.0;
+#pragma unroll
+        for (int j = 0; j < N; ++j)
+          if (j < d) r = fma(A[i * d + j], dl[j], r);
+        q = fma(dl[i], r, q);
+      }
+    }
+    const bool in = live && (mode == 0 ? (q < 1.0) : (sqrt(q) <= 1.0));
+    cnt += in ? 1 : 0;
+    const unsigned long long b = __ballot(in);
+    if (mask && threadIdx.x == 0) mask[(size_t)a * nwords + blockIdx.x] = b;
+    if (quad && live) quad[(size_t)w * m + a] = q;
+  }
+  if (live) count[w] = cnt;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dh_contains(dh_ctx* ctx, const double* x, int k, int d, const double* ctrs, const double* ams,
+                int m, int mode, int32_t* count, uint64_t* mask, double* quad) {
+  DH_CHECK_CTX(ctx);
+  if (k <= 0) return DH_OK;
+  if (!x || !ctrs || !ams || !count || d < 1 || m < 1 || (mode != 0 && mode != 1))
+    return fail(ctx, DH_ERR_ARG, "contains: bad arguments (d=%d m=%d mode=%d)", d, m, mode);
+  if (d > kMaxRegDim)
+    return fail(ctx, DH_ERR_ARG, "contains: d=%d > %d needs the wide-D path (not built yet)", d,
+                kMaxRegDim);
+  arena_reset(ctx);
+  const size_t nwords = (size_t)(k + 63) / 64;
+  int rc = arena_reserve(ctx, ((size_t)k * d + (size_t)m * d + (size_t)m * d * d + (size_t)k * m) * 8 +
+                                  (size_t)k * 4 + nwords * m * 8 + 8192);
+  if (rc) return rc;
+  const double* d_x = arena_up(ctx, x, (size_t)k * d);
+  const double* d_c = arena_up(ctx, ctrs, (size_t)m * d);
+  const double* d_a = arena_up(ctx, ams, (size_t)m * d * d);
+  int32_t* d_cnt = (int32_t*)arena_get(ctx, (size_t)k * 4);
+  uint64_t* d_mask = mask ? (uint64_t*)arena_get(ctx, nwords * m * 8) : nullptr;
+  double* d_q = quad ? (double*)arena_get(ctx, (size_t)k * m * 8) : nullptr;
+  if (!d_x || !d_c || !d_a || !d_cnt || (mask && !d_mask) || (quad && !d_q)) return DH_ERR_NOMEM;
+  const dim3 grid((k + 63) / 64), block(64);
+  bool hit = false;
+#define X(NN)                                                                                   \
+  if (!hit && d <= NN) {                                                                        \
+    hit = true;                                                                                 \
+    hipLaunchKernelGGL(contains_kernel<NN>, grid, block, 0, ctx->stream, d_x, k, d, d_c, d_a, m, \
+                       mode, d_cnt, d_mask, d_q);                                               \
+  }
+  DH_DIM_LIST(X)
+#undef X
+  if (!hip_ok(ctx, hipGetLastError(), "contains launch")) return DH_ERR_HIP;
+  if (!down(ctx, count, d_cnt, (size_t)k) || !down(ctx, mask, d_mask, nwords * m) ||
+      !down(ctx, quad, d_q, (size_t)k * m))
+    return DH_ERR_HIP;
+  return dh_sync(ctx);
+}
+
+}  // extern "C"

@@ -1,0 +1,75 @@
+// Internal: the context object behind dh_ctx* and small launch helpers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/dynhip.h"
+#include "problem.h"
+
+struct dh_problem_rec {
+  bool live = false;
+  int ndim = 0;
+  int like_id = 0, prior_id = 0;
+  double* like_par = nullptr;   // device
+  double* prior_par = nullptr;  // device
+  int n_like = 0, n_prior = 0;
+};
+
+struct dh_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  std::vector<dh_problem_rec> problems;
+  // ziggurat tables in device memory (bit patterns)
+  uint64_t* zig = nullptr;  // [ki | wi | fi] 3*256
+  // grow-only staging arena for the host-pointer entry points
+  char* arena = nullptr;
+  size_t arena_cap = 0;
+  size_t arena_top = 0;
+  // transposed/padded proposal frames for the walk kernels
+  double* axes_t = nullptr;
+  size_t axes_t_cap = 0;
+
+  const uint64_t* zki() const { return zig; }
+  const uint64_t* zwi() const { return zig + 256; }
+  const uint64_t* zfi() const { return zig + 512; }
+};
+
+namespace dh {
+
+int fail(dh_ctx* ctx, int code, const char* fmt, ...);
+bool hip_ok(dh_ctx* ctx, hipError_t e, const char* what);
+
+// bump allocator over the context arena (256-byte aligned); reset per call
+void arena_reset(dh_ctx* ctx);
+void* arena_get(dh_ctx* ctx, size_t bytes);  // nullptr + error set on failure
+int arena_reserve(dh_ctx* ctx, size_t bytes);
+
+template <typename T>
+inline T* arena_up(dh_ctx* ctx, const T* host, size_t count) {
+  T* d = (T*)arena_get(ctx, count * sizeof(T));
+  if (!d) return nullptr;
+  if (host && count) {
+    if (!hip_ok(ctx, hipMemcpyAsync(d, host, count * sizeof(T), hipMemcpyHostToDevice, ctx->stream),
+                "H2D"))
+      return nullptr;
+  }
+  return d;
+}
+
+template <typename T>
+inline bool down(dh_ctx* ctx, T* host, const T* dev, size_t count) {
+  if (!host || !count) return true;
+  return hip_ok(ctx, hipMemcpyAsync(host, dev, count * sizeof(T), hipMemcpyDeviceToHost, ctx->stream),
+                "D2H");
+}
+
+bool get_problem(dh_ctx* ctx, int handle, ProblemDev* out);
+
+}  // namespace dh
+
+#define DH_CHECK_CTX(ctx) \
+  if (!(ctx)) return DH_ERR_ARG;

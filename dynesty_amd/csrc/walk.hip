@@ -1,0 +1,415 @@
+// Proposal kernels: one walker per lane, walker state in registers.
+//
+// Mapping (DESIGN.md "proposal kernels"): a walker's whole chain -- `walks`
+// steps of {D normals + 1 uniform, D x D frame mat-vec, wrap/reflect, cube
+// check, prior transform, log-likelihood, accept} -- is sequential, and walkers
+// are independent, so each lane owns one walker and keeps u / dr / u' in
+// VGPRs (kernels are instantiated per padded dimension so every array index
+// is static).  The proposal frame (`axes`) and the likelihood parameters are
+// wave-uniform and are fetched through the scalar cache into SGPRs; the only
+// LDS traffic is the 6 KiB ziggurat table.  HBM traffic is one read of u0 and
+// one write of (u, v, logl) per walker per launch -- the kernel is fp64-VALU
+// bound, not bandwidth bound.
+#include "ctx.h"
+#include "rng_pcg64.h"
+
+using namespace dh;
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// small helpers
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double wrap01(double x) { return x - floor(x); }  // np.mod(x, 1)
+
+// utils.py:1053-1078 apply_reflect for one coordinate
+__device__ __forceinline__ double reflect01(double x) {
+  double m2 = x - 2.0 * floor(x * 0.5);  // np.mod(x, 2)
+  double m1 = wrap01(x);
+  return (m2 < 1.0) ? m1 : 1.0 - m1;
+}
+
+struct RwalkArgs {
+  ProblemDev prob;
+  int k, ndim, ncdim, walks, m;
+  double scale, loglstar;
+  const double* u0;
+  const double* axes_t;  // m x N x N, transposed + zero padded (prep_axes_kernel)
+  const int32_t* axes_idx;
+  const int8_t* bc;
+  const uint64_t* rng_in;
+  double* u;
+  double* v;
+  double* logl;
+  int32_t* nacc;
+  int32_t* nrej;
+  uint64_t* rng_out;
+  const uint64_t* zki;
+  const uint64_t* zwi;
+  const uint64_t* zfi;
+};
+
+// frames arrive row-major with column i = axis i (bounding.py:225-229); the walk
+// kernel wants, for a fixed input index j, the N outputs contiguous so one
+// s_load_dwordx16 feeds 8 FMAs: AT[f][j][i] = axes[f][i][j], zero padded to N.
+__global__ void prep_axes_kernel(const double* __restrict__ axes, int m, int nc, int N,
+                                 double* __restrict__ at) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int tot = m * N * N;
+  if (t >= tot) return;
+  const int f = t / (N * N), r = t % (N * N), j = r / N, i = r % N;
+  at[t] = (i < nc && j < nc) ? axes[(size_t)f * nc * nc + i * nc + j] : 0.0;
+}
+
+// generic_random_walk (internal_samplers.py:866-986), one walker per lane.
+// FULL: ndim == ncdim == N (all guards fold away).
+template <int N, bool FULL>
+__global__ void __launch_bounds__(64, 2) rwalk_kernel(RwalkArgs a) {
+  __shared__ ZigLds zig;
+  __shared__ double sdr[N * 64];  // per-lane column scratch: dr, then v staging
+  zig_stage(&zig, a.zki, a.zwi, a.zfi);
+  const int lane = threadIdx.x;
+  const int w = blockIdx.x * 64 + lane;
+  const bool live = w < a.k;
+  const int wi = live ? w : a.k - 1;  // dead lanes shadow the last walker (no stores)
+  const int n = FULL ? N : a.ndim, nc = FULL ? N : a.ncdim;
+
+  double u[N], up[N], v[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) u[i] = (FULL || i < n) ? a.u0[(size_t)wi * n + i] : 0.5;
+  Pcg64 g;
+  g.load(a.rng_in + (size_t)wi * 4);
+  const int my_frame = a.axes_idx ? a.axes_idx[wi] : 0;
+
+  int nacc = 0, nrej = 0;
+  double logl_cur = 0.0;
+  const double inv_nc = 1.0 / (double)nc;
+
+#pragma unroll 1
+  for (int step = 0; step < a.walks; ++step) {
+    // propose_ball_point (internal_samplers.py:989-1035): non-cluster dims are
+    // redrawn first (rstate.random(n - n_cluster)) ...
+    if (!FULL) {
+#pragma unroll 1
+      for (int i = nc; i < n; ++i) sdr[i * 64 + lane] = g.next_double();
+    }
+    // ... then randsphere (bounding.py:1288-1297): nc normals, one uniform
+    double ss = 0.0;
+#pragma unroll 1
+    for (int i = 0; i < nc; ++i) {
+      const double x = std_normal(g, &zig);
+      sdr[i * 64 + lane] = x;
+      ss = fma(x, x, ss);
+    }
+    const double fac = a.scale * (pow(g.next_double(), inv_nc) / sqrt(ss));
+    // du = axes @ dr, frame wave-uniform: waterfall over the distinct frames
+#pragma unroll
+    for (int i = 0; i < N; ++i) up[i] = 0.0;
+    bool done = false;
+    while (!done) {
+      const int cur = __builtin_amdgcn_readfirstlane(my_frame);
+      if (cur == my_frame) {
+        cdptr AT = as_const(a.axes_t + (size_t)cur * N * N);
+#pragma unroll 1
+        for (int j = 0; j < nc; ++j) {
+          const double d = sdr[j * 64 + lane];
+#pragma unroll
+          for (int i = 0; i < N; ++i) up[i] = fma(AT[j * N + i], d, up[i]);
+        }
+        done = true;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      if (FULL || i < nc)
+        up[i] = fma(fac, up[i], u[i]);
+      else
+        up[i] = (i < n) ? sdr[i * 64 + lane] : 0.5;
+    }
+    // periodic wrap / reflection, then unitcheck (utils.py:1036-1050)
+    bool inside = true;
+    if (a.bc) {
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        if (FULL || i < n) {
+          const int b = a.bc[i];
+          double x = up[i];
+          if (b == DH_BC_PERIODIC) x = wrap01(x);
+          if (b == DH_BC_REFLECT) x = reflect01(x);
+          up[i] = x;
+          if (b == DH_BC_HARD)
+            inside = inside && (x > 0.0) && (x < 1.0);
+          else
+            inside = inside && (x > -0.5) && (x < 1.5);
+        }
+      }
+    } else {
+      double lo = up[0], hi = up[0];
+#pragma unroll
+      for (int i = 1; i < N; ++i) {
+        lo = fmin(lo, up[i]);
+        hi = fmax(hi, up[i]);
+      }
+      inside = (lo > 0.0) && (hi < 1.0);  // padded entries sit at 0.5
+    }
+    if (!inside) {  // counted as a call and a reject, no likelihood evaluated
+      ++nrej;
+      continue;
+    }
+    prior_transform<N, FULL>(a.prob, up, v, n, sdr);
+    const double ll = loglike<N, FULL>(a.prob, v, n, sdr);
+    if (ll > a.loglstar) {
+#pragma unroll
+      for (int i = 0; i < N; ++i) u[i] = up[i];
+      logl_cur = ll;
+      ++nacc;
+    } else {
+      ++nrej;
+    }
+  }
+  // v of the returned point; logl is re-evaluated when nothing was accepted
+  // (internal_samplers.py:970-975)
+  prior_transform<N, FULL>(a.prob, u, v, n, sdr);
+  if (nacc == 0) logl_cur = loglike<N, FULL>(a.prob, v, n, sdr);
+  if (live) {
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+      if (FULL || i < n) {
+        a.u[(size_t)w * n + i] = u[i];
+        a.v[(size_t)w * n + i] = v[i];
+      }
+    a.logl[w] = logl_cur;
+    a.nacc[w] = nacc;
+    a.nrej[w] = nrej;
+    if (a.rng_out) g.store(a.rng_out + (size_t)w * 4);
+  }
+}
+
+// ---------------------------------------------------------------------------
+template <int N>
+__global__ void __launch_bounds__(64)
+    eval_kernel(ProblemDev prob, int k, const double* __restrict__ u, double* v, double* logl) {
+  __shared__ double tmp[N * 64];
+  const int w = blockIdx.x * 64 + threadIdx.x;
+  const int wi = w < k ? w : k - 1;
+  const int n = prob.ndim;
+  double uu[N], vv[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) uu[i] = (i < n) ? u[(size_t)wi * n + i] : 0.5;
+  prior_transform<N, false>(prob, uu, vv, n, tmp);
+  const double ll = loglike<N, false>(prob, vv, n, tmp);
+  if (w >= k) return;
+  logl[w] = ll;
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+    if (i < n) v[(size_t)w * n + i] = vv[i];
+}
+
+__global__ void seed_kernel(const uint32_t* __restrict__ entropy, int nwords, uint32_t first, int k,
+                            uint64_t* states) {
+  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= k) return;
+  Pcg64 g;
+  seed_from_child(g, entropy, nwords, first + (uint32_t)w);
+  g.store(states + (size_t)w * 4);
+}
+
+__global__ void __launch_bounds__(64)
+    stream_kernel(const uint64_t* state_in, int n_normal, int n_unif, double* normals, double* unifs,
+                  uint64_t* state_out, const uint64_t* zki, const uint64_t* zwi, const uint64_t* zfi) {
+  __shared__ ZigLds zig;
+  zig_stage(&zig, zki, zwi, zfi);
+  if (threadIdx.x != 0) return;
+  Pcg64 g;
+  g.load(state_in);
+  for (int i = 0; i < n_normal; ++i) normals[i] = std_normal(g, &zig);
+  for (int i = 0; i < n_unif; ++i) unifs[i] = g.next_double();
+  g.store(state_out);
+}
+
+// runtime dimension -> padded compile-time dimension
+#define DH_DIM_LIST(X) X(1) X(2) X(3) X(4) X(5) X(6) X(8) X(10) X(12) X(16) X(20) X(25) X(32)
+constexpr int kMaxRegDim = 32;
+
+}  // namespace
+
+extern "C" {
+
+int dh_rwalk_batch_dev(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, const double* u0,
+                       const double* axes, int m, const int32_t* axes_idx, double scale,
+                       double loglstar, int walks, const int8_t* bc, const uint64_t* rng, double* u,
+                       double* v, double* logl, int32_t* naccept, int32_t* nreject,
+                       uint64_t* rng_out) {
+  DH_CHECK_CTX(ctx);
+  RwalkArgs a;
+  if (!get_problem(ctx, problem, &a.prob)) return DH_ERR_ARG;
+  if (a.prob.ndim != ndim) return fail(ctx, DH_ERR_ARG, "problem ndim %d != %d", a.prob.ndim, ndim);
+  if (k <= 0) return DH_OK;
+  if (ncdim < 1 || ncdim > ndim || m < 1 || walks < 1)
+    return fail(ctx, DH_ERR_ARG, "rwalk: ncdim=%d ndim=%d m=%d walks=%d", ncdim, ndim, m, walks);
+  if (ndim > kMaxRegDim)
+    return fail(ctx, DH_ERR_ARG, "rwalk: ndim=%d > %d needs the wide-D path (not built yet)", ndim,
+                kMaxRegDim);
+  a.k = k;
+  a.ndim = ndim;
+  a.ncdim = ncdim;
+  a.walks = walks;
+  a.m = m;
+  a.scale = scale;
+  a.loglstar = loglstar;
+  a.u0 = u0;
+  a.axes_idx = axes_idx;
+  a.bc = bc;
+  a.rng_in = rng;
+  a.u = u;
+  a.v = v;
+  a.logl = logl;
+  a.nacc = naccept;
+  a.nrej = nreject;
+  a.rng_out = rng_out;
+  a.zki = ctx->zki();
+  a.zwi = ctx->zwi();
+  a.zfi = ctx->zfi();
+  int N = 0;
+#define X(NN) \
+  if (!N && ndim <= NN) N = NN;
+  DH_DIM_LIST(X)
+#undef X
+  // transposed + padded copy of the frames (stream ordered, context scratch)
+  const size_t at_bytes = (size_t)m * N * N * sizeof(double);
+  if (at_bytes > ctx->axes_t_cap) {
+    if (!hip_ok(ctx, hipStreamSynchronize(ctx->stream), "sync")) return DH_ERR_HIP;
+    if (ctx->axes_t) (void)hipFree(ctx->axes_t);
+    ctx->axes_t = nullptr;
+    ctx->axes_t_cap = 0;
+    if (!hip_ok(ctx, hipMalloc((void**)&ctx->axes_t, at_bytes * 2), "hipMalloc(axes_t)"))
+      return DH_ERR_NOMEM;
+    ctx->axes_t_cap = at_bytes * 2;
+  }
+  hipLaunchKernelGGL(prep_axes_kernel, dim3((m * N * N + 255) / 256), dim3(256), 0, ctx->stream, axes, m,
+                     ncdim, N, ctx->axes_t);
+  a.axes_t = ctx->axes_t;
+  const dim3 grid((k + 63) / 64), block(64);
+  const bool full = (ndim == N && ncdim == N);
+#define X(NN)                                                                      \
+  if (N == NN) {                                                                   \
+    if (full)                                                                      \
+      hipLaunchKernelGGL((rwalk_kernel<NN, true>), grid, block, 0, ctx->stream, a);  \
+    else                                                                           \
+      hipLaunchKernelGGL((rwalk_kernel<NN, false>), grid, block, 0, ctx->stream, a); \
+  }
+  DH_DIM_LIST(X)
+#undef X
+  return hip_ok(ctx, hipGetLastError(), "rwalk launch") ? DH_OK : DH_ERR_HIP;
+}
+
+int dh_rwalk_batch(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, const double* u0,
+                   const double* axes, int m, const int32_t* axes_idx, double scale, double loglstar,
+                   int walks, const int8_t* bc, const uint64_t* rng, double* u, double* v,
+                   double* logl, int32_t* naccept, int32_t* nreject, uint64_t* rng_out) {
+  DH_CHECK_CTX(ctx);
+  if (k <= 0) return DH_OK;
+  if (!u0 || !axes || !rng || !u || !v || !logl || !naccept || !nreject)
+    return fail(ctx, DH_ERR_ARG, "rwalk: null pointer");
+  arena_reset(ctx);
+  const size_t kd = (size_t)k * ndim;
+  size_t need = 3 * kd * 8 + (size_t)m * ncdim * ncdim * 8 + (size_t)k * (4 + 8 + 4 + 4 + 64) +
+                (size_t)ndim + 16 * 256;
+  int rc = arena_reserve(ctx, need);
+  if (rc) return rc;
+  const double* d_u0 = arena_up(ctx, u0, kd);
+  const double* d_axes = arena_up(ctx, axes, (size_t)m * ncdim * ncdim);
+  const int32_t* d_idx = axes_idx ? arena_up(ctx, axes_idx, (size_t)k) : nullptr;
+  const int8_t* d_bc = bc ? arena_up(ctx, bc, (size_t)ndim) : nullptr;
+  const uint64_t* d_rng = arena_up(ctx, rng, (size_t)k * 4);
+  double* d_u = (double*)arena_get(ctx, kd * 8);
+  double* d_v = (double*)arena_get(ctx, kd * 8);
+  double* d_logl = (double*)arena_get(ctx, (size_t)k * 8);
+  int32_t* d_na = (int32_t*)arena_get(ctx, (size_t)k * 4);
+  int32_t* d_nr = (int32_t*)arena_get(ctx, (size_t)k * 4);
+  uint64_t* d_ro = (uint64_t*)arena_get(ctx, (size_t)k * 32);
+  if (!d_u0 || !d_axes || !d_rng || !d_u || !d_v || !d_logl || !d_na || !d_nr || !d_ro ||
+      (axes_idx && !d_idx) || (bc && !d_bc))
+    return DH_ERR_NOMEM;
+  rc = dh_rwalk_batch_dev(ctx, problem, k, ndim, ncdim, d_u0, d_axes, m, d_idx, scale, loglstar, walks,
+                          d_bc, d_rng, d_u, d_v, d_logl, d_na, d_nr, d_ro);
+  if (rc) return rc;
+  if (!down(ctx, u, d_u, kd) || !down(ctx, v, d_v, kd) || !down(ctx, logl, d_logl, (size_t)k) ||
+      !down(ctx, naccept, d_na, (size_t)k) || !down(ctx, nreject, d_nr, (size_t)k) ||
+      !down(ctx, rng_out, d_ro, (size_t)k * 4))
+    return DH_ERR_HIP;
+  return dh_sync(ctx);
+}
+
+int dh_problem_eval(dh_ctx* ctx, int problem, int k, const double* u, double* v, double* logl) {
+  DH_CHECK_CTX(ctx);
+  ProblemDev p;
+  if (!get_problem(ctx, problem, &p)) return DH_ERR_ARG;
+  if (k <= 0) return DH_OK;
+  const int ndim = p.ndim;
+  if (ndim > kMaxRegDim)
+    return fail(ctx, DH_ERR_ARG, "eval: ndim=%d > %d needs the wide-D path (not built yet)", ndim,
+                kMaxRegDim);
+  arena_reset(ctx);
+  const size_t kd = (size_t)k * ndim;
+  int rc = arena_reserve(ctx, 2 * kd * 8 + (size_t)k * 8 + 4096);
+  if (rc) return rc;
+  const double* d_u = arena_up(ctx, u, kd);
+  double* d_v = (double*)arena_get(ctx, kd * 8);
+  double* d_l = (double*)arena_get(ctx, (size_t)k * 8);
+  if (!d_u || !d_v || !d_l) return DH_ERR_NOMEM;
+  const dim3 grid((k + 63) / 64), block(64);
+  bool hit = false;
+#define X(NN)                                                                      \
+  if (!hit && ndim <= NN) {                                                        \
+    hit = true;                                                                    \
+    hipLaunchKernelGGL(eval_kernel<NN>, grid, block, 0, ctx->stream, p, k, d_u, d_v, d_l); \
+  }
+  DH_DIM_LIST(X)
+#undef X
+  if (!hip_ok(ctx, hipGetLastError(), "eval launch")) return DH_ERR_HIP;
+  if (!down(ctx, v, d_v, kd) || !down(ctx, logl, d_l, (size_t)k)) return DH_ERR_HIP;
+  return dh_sync(ctx);
+}
+
+int dh_seed_children(dh_ctx* ctx, const uint32_t* entropy_words, int n_words, uint32_t first_child,
+                     int k, uint64_t* states) {
+  DH_CHECK_CTX(ctx);
+  if (k <= 0) return DH_OK;
+  if (!entropy_words || n_words < 1 || n_words > 64 || !states)
+    return fail(ctx, DH_ERR_ARG, "seed_children: n_words=%d", n_words);
+  arena_reset(ctx);
+  int rc = arena_reserve(ctx, (size_t)k * 32 + 1024);
+  if (rc) return rc;
+  const uint32_t* d_e = arena_up(ctx, entropy_words, (size_t)n_words);
+  uint64_t* d_s = (uint64_t*)arena_get(ctx, (size_t)k * 32);
+  if (!d_e || !d_s) return DH_ERR_NOMEM;
+  hipLaunchKernelGGL(seed_kernel, dim3((k + 255) / 256), dim3(256), 0, ctx->stream, d_e, n_words,
+                     first_child, k, d_s);
+  if (!hip_ok(ctx, hipGetLastError(), "seed launch")) return DH_ERR_HIP;
+  if (!down(ctx, states, d_s, (size_t)k * 4)) return DH_ERR_HIP;
+  return dh_sync(ctx);
+}
+
+int dh_rng_stream(dh_ctx* ctx, const uint64_t* state4, int n_normal, int n_unif, double* normals,
+                  double* unifs, uint64_t* state4_out) {
+  DH_CHECK_CTX(ctx);
+  if (!state4 || n_normal < 0 || n_unif < 0) return fail(ctx, DH_ERR_ARG, "rng_stream: bad args");
+  arena_reset(ctx);
+  int rc = arena_reserve(ctx, (size_t)(n_normal + n_unif) * 8 + 4096);
+  if (rc) return rc;
+  const uint64_t* d_s = arena_up(ctx, state4, 4);
+  double* d_n = (double*)arena_get(ctx, (size_t)(n_normal + 1) * 8);
+  double* d_u = (double*)arena_get(ctx, (size_t)(n_unif + 1) * 8);
+  uint64_t* d_o = (uint64_t*)arena_get(ctx, 32);
+  if (!d_s || !d_n || !d_u || !d_o) return DH_ERR_NOMEM;
+  hipLaunchKernelGGL(stream_kernel, dim3(1), dim3(64), 0, ctx->stream, d_s, n_normal, n_unif, d_n, d_u,
+                     d_o, ctx->zki(), ctx->zwi(), ctx->zfi());
+  if (!hip_ok(ctx, hipGetLastError(), "stream launch")) return DH_ERR_HIP;
+  if (!down(ctx, normals, d_n, (size_t)n_normal) || !down(ctx, unifs, d_u, (size_t)n_unif) ||
+      !down(ctx, state4_out, d_o, 4))
+    return DH_ERR_HIP;
+  return dh_sync(ctx);
+}
+
+}  // extern "C"

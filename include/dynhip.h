@@ -1,0 +1,146 @@
+/* dynhip.h -- C ABI of libdynhip.so, the MI355X (gfx950) implementation of
+ * dynesty's bounding + proposal hot path.
+ *
+ * The reference (joshspeagle/dynesty 3.0.0) is pure Python and has no FFI of
+ * its own; the entry points below are what a ctypes binding for this path
+ * binds to.  Each one names the reference function(s) it replaces
+ * (file:line relative to /root/reference/py/dynesty/).  INTEGRATION.md shows
+ * the reference-side stubs; dynesty_amd/_lib.py is the binding used here.
+ *
+ * Conventions
+ *   - plain C types only; all matrices are C-contiguous row-major float64.
+ *   - every function returns DH_OK (0) or a negative DH_ERR_* code; the
+ *     message is available from dh_last_error(ctx).  The Python shim maps the
+ *     codes back to the exception types the reference raises.
+ *   - host-pointer entry points copy in, launch on the context's stream, copy
+ *     out and synchronise before returning; the library never keeps a host
+ *     pointer.  `*_dev` entry points take device pointers (from dh_malloc),
+ *     only enqueue work on the context's stream and do NOT synchronise.
+ *   - a dh_ctx is bound to one device and one stream; calls on one context are
+ *     serialised.  No global state: fork/spawn-safe until the first dh_create.
+ *   - RNG: one numpy-compatible PCG64 stream per walker, 4 x uint64 words
+ *     {state_hi, state_lo, inc_hi, inc_lo} (numpy PCG64().state['state']).
+ */
+#ifndef DYNHIP_H
+#define DYNHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DH_VERSION 100
+
+#define DH_OK 0
+#define DH_ERR_VALUE (-1)   /* ValueError: single point / singular covariance (bounding.py:1405-1407, 220-224) */
+#define DH_ERR_CONTAIN (-2) /* RuntimeError: failed to contain all the points (bounding.py:1451-1453) */
+#define DH_ERR_REGION (-3)  /* RuntimeError: Rejecting invalid MultiEllipsoid region (bounding.py:683-685) */
+#define DH_ERR_SLICE (-4)   /* RuntimeError: slice sampler failed, x == 0 (internal_samplers.py:1188-1199) */
+#define DH_ERR_HIP (-5)     /* HIP runtime failure */
+#define DH_ERR_ARG (-6)     /* bad argument (unsupported dimension, null pointer, bad handle) */
+#define DH_ERR_QZERO (-7)   /* RuntimeError: Ellipsoid check failed q=0 (bounding.py:565-572) */
+#define DH_ERR_NOMEM (-8)
+
+/* likelihood / prior ids -- twins of dynesty_amd/problems.py */
+#define DH_LIKE_GAUSS_IID 0  /* -0.5 sum v^2 + c                par = [c]        */
+#define DH_LIKE_GAUSS_PREC 1 /* -0.5 v^T P v + c                par = [c, P]     */
+#define DH_LIKE_EGGBOX 2     /* (2 + prod cos((2 tmax v - tmax)/2))^5  par = [tmax] */
+#define DH_PRIOR_IDENTITY 0  /* v = u                                            */
+#define DH_PRIOR_AFFINE 1    /* v = a (2u - 1) + b              par = [a, b]     */
+#define DH_PRIOR_NORMAL 2    /* v = mu + sigma ndtri(u)         par = [mu, sigma]*/
+
+/* per-dimension boundary flags (reference kwargs periodic / reflective,
+ * utils.py:950-976 get_nonbounded) */
+#define DH_BC_HARD 0
+#define DH_BC_PERIODIC 1
+#define DH_BC_REFLECT 2
+
+typedef struct dh_ctx dh_ctx;
+
+/* ---- context ----------------------------------------------------------- */
+int dh_version(void);
+int dh_device_count(void);
+/* NULL on failure (no HIP device / bad ordinal): the message is in
+ * dh_last_error(NULL).  There is no CPU fallback. */
+dh_ctx* dh_create(int device);
+void dh_destroy(dh_ctx* ctx);
+const char* dh_last_error(dh_ctx* ctx);
+int dh_sync(dh_ctx* ctx);
+/* the hipStream_t every launch of this context goes to */
+void* dh_stream(dh_ctx* ctx);
+
+/* ---- device memory + events (for resident data and on-stream timing) --- */
+void* dh_malloc(dh_ctx* ctx, uint64_t bytes);
+int dh_free(dh_ctx* ctx, void* dptr);
+int dh_memcpy_h2d(dh_ctx* ctx, void* dst_dev, const void* src_host, uint64_t bytes);
+int dh_memcpy_d2h(dh_ctx* ctx, void* dst_host, const void* src_dev, uint64_t bytes);
+int dh_memset(dh_ctx* ctx, void* dst_dev, int value, uint64_t bytes);
+void* dh_event_create(dh_ctx* ctx);
+int dh_event_destroy(dh_ctx* ctx, void* ev);
+int dh_event_record(dh_ctx* ctx, void* ev);                     /* on dh_stream(ctx) */
+int dh_event_elapsed_ms(dh_ctx* ctx, void* ev0, void* ev1, double* ms); /* syncs ev1 */
+
+/* ---- problems: device twins of the user's loglikelihood/prior_transform --
+ * callbacks (internal_samplers.py:957-958; dynesty.py:529-557).  Returns a
+ * handle >= 0 or a DH_ERR_* code. */
+int dh_problem_create(dh_ctx* ctx, int ndim, int like_id, const double* like_par,
+                      int n_like_par, int prior_id, const double* prior_par,
+                      int n_prior_par);
+int dh_problem_destroy(dh_ctx* ctx, int problem);
+/* logl/v for k points: the batched form of loglikelihood(prior_transform(u)) */
+int dh_problem_eval(dh_ctx* ctx, int problem, int k, const double* u, double* v,
+                    double* logl);
+
+/* ---- RNG ---------------------------------------------------------------- */
+/* numpy: [PCG64(c).state for c in SeedSequence(entropy).spawn(first+k)[first:]]
+ * (utils.py:1002-1009 get_seed_sequence + :993-999 get_random_generator).
+ * entropy_words = the entropy ints coerced to little-endian uint32 words. */
+int dh_seed_children(dh_ctx* ctx, const uint32_t* entropy_words, int n_words,
+                     uint32_t first_child, int k, uint64_t* states /* k*4 */);
+/* test hook: from one state draw n_normal standard_normal() then n_unif
+ * random(); returns the advanced state. */
+int dh_rng_stream(dh_ctx* ctx, const uint64_t* state4, int n_normal, int n_unif,
+                  double* normals, double* unifs, uint64_t* state4_out);
+
+/* ---- membership ---------------------------------------------------------
+ * MultiEllipsoid.contains/within/overlap (bounding.py:502-523) and
+ * Ellipsoid.contains (bounding.py:286-305) for k points against m ellipsoids.
+ *   mode 0: (x-c)^T A (x-c) < 1          (MultiEllipsoid, strict)
+ *   mode 1: sqrt((x-c)^T A (x-c)) <= 1   (Ellipsoid)
+ * count[i]  = number of ellipsoids containing x_i
+ * mask      = bit matrix, word (a * ceil(k/64) + i/64), bit i%64 set iff x_i is
+ *             inside ellipsoid a  (one 64-lane ballot per word); may be NULL
+ * quad      = k*m quadratic forms (row i = point i); may be NULL */
+int dh_contains(dh_ctx* ctx, const double* x, int k, int d, const double* ctrs,
+                const double* ams, int m, int mode, int32_t* count,
+                uint64_t* mask, double* quad);
+
+/* ---- proposals ----------------------------------------------------------
+ * RWalkSampler.sample over a batch of k walkers = generic_random_walk +
+ * propose_ball_point + randsphere (internal_samplers.py:866-1035,
+ * bounding.py:1288-1297), prior/likelihood evaluated in-kernel.
+ *   u0        k*ndim   start points (copies of live points)
+ *   axes      m*ncdim*ncdim proposal frames, column i = axis i
+ *   axes_idx  k        frame per walker (NULL: all use frame 0)
+ *   bc        ndim     DH_BC_* flags or NULL (all hard)
+ *   rng       k*4      PCG64 states in
+ *   outputs   u,v k*ndim; logl k; naccept,nreject k; rng_out k*4 (may be NULL)
+ * ncalls == walks for every walker (internal_samplers.py:925-944). */
+int dh_rwalk_batch(dh_ctx* ctx, int problem, int k, int ndim, int ncdim,
+                   const double* u0, const double* axes, int m,
+                   const int32_t* axes_idx, double scale, double loglstar,
+                   int walks, const int8_t* bc, const uint64_t* rng, double* u,
+                   double* v, double* logl, int32_t* naccept, int32_t* nreject,
+                   uint64_t* rng_out);
+int dh_rwalk_batch_dev(dh_ctx* ctx, int problem, int k, int ndim, int ncdim,
+                       const double* u0, const double* axes, int m,
+                       const int32_t* axes_idx, double scale, double loglstar,
+                       int walks, const int8_t* bc, const uint64_t* rng,
+                       double* u, double* v, double* logl, int32_t* naccept,
+                       int32_t* nreject, uint64_t* rng_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DYNHIP_H */

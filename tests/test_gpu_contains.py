@@ -1,0 +1,85 @@
+"""K5 membership kernel vs the oracle and the reference's golden index lists
+(reference tests/test_ellipsoid.py:106-133 test_overlap is the model)."""
+import numpy as np
+import pytest
+
+import inputs
+from oracle import bounding_ref as B
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from dynesty_amd import _lib
+    return _lib.Context(0)
+
+
+def unpack(mask, k):
+    m = mask.shape[0]
+    bits = np.unpackbits(mask.view(np.uint8).reshape(m, -1), axis=1,
+                         bitorder="little")[:, :k]
+    return bits.astype(bool)
+
+
+@pytest.mark.parametrize("name", inputs.CLOUDS_SMALL)
+def test_within_golden(ctx, name, golden_bounding):
+    g = golden_bounding
+    ctrs, ams = g[f"{name}/mu/ctrs"], g[f"{name}/mu/ams"]
+    probes = g[f"{name}/kat/probes"]
+    k = probes.shape[0]
+    count, mask, quad = ctx.contains(probes, ctrs, ams, mode=0, want_mask=True,
+                                     want_quad=True)
+    inside = unpack(mask, k)  # (m, k)
+    within = [np.nonzero(inside[:, i])[0] for i in range(k)]
+    np.testing.assert_array_equal(np.concatenate(within),
+                                  g[f"{name}/kat/within_flat"])
+    np.testing.assert_array_equal(count, g[f"{name}/kat/within_count"])
+    np.testing.assert_array_equal(count > 0, g[f"{name}/kat/contains"])
+    skip0 = count - inside[0].astype(np.int32)
+    np.testing.assert_array_equal(skip0, g[f"{name}/kat/overlap_skip0"])
+    want_q = np.array([B.multi_quadforms(p, ctrs, ams) for p in probes])
+    np.testing.assert_allclose(quad, want_q, rtol=1e-12, atol=1e-13)
+
+
+def test_two_spheres_brute_force(ctx):
+    """1e4 points against two unit spheres, exact index lists
+    (reference tests/test_ellipsoid.py:106-133)."""
+    rng = np.random.default_rng(3)
+    for ndim in (2, 10):
+        ctrs = np.zeros((2, ndim))
+        ctrs[0, 0] = -0.7
+        ctrs[1, 0] = 0.7
+        ams = np.array([np.eye(ndim), np.eye(ndim)])
+        x = rng.uniform(-2, 2, size=(10000, ndim))
+        count, mask, _ = ctx.contains(x, ctrs, ams, mode=0, want_mask=True)
+        inside = unpack(mask, x.shape[0])
+        brute = np.stack([((x - c)**2).sum(1) < 1 for c in ctrs])
+        np.testing.assert_array_equal(inside, brute)
+        np.testing.assert_array_equal(count, brute.sum(0))
+
+
+@pytest.mark.parametrize("name", ["g3", "c2"])
+def test_single_mode(ctx, name, golden_bounding):
+    """Ellipsoid.contains uses sqrt(q) <= 1 (bounding.py:302-305)."""
+    g = golden_bounding
+    e = B.bounding_ellipsoid(inputs.cloud(name))
+    probes = g[f"{name}/kat/probes"]
+    count, _, _ = ctx.contains(probes, e.ctr[None], e.am[None], mode=1)
+    np.testing.assert_array_equal(count > 0, g[f"{name}/single/contains"])
+
+
+def test_ragged_sizes(ctx):
+    rng = np.random.default_rng(4)
+    for k in (1, 63, 64, 65, 1000):
+        d, m = 3, 5
+        ctrs = rng.uniform(0.3, 0.7, size=(m, d))
+        a = rng.standard_normal((m, d, d))
+        ams = np.einsum('mij,mkj->mik', a, a) * 4 + np.eye(d)
+        x = rng.uniform(0, 1, size=(k, d))
+        count, mask, quad = ctx.contains(x, ctrs, ams, want_mask=True,
+                                         want_quad=True)
+        want = np.array([B.multi_quadforms(p, ctrs, ams) for p in x])
+        np.testing.assert_allclose(quad, want, rtol=1e-12)
+        np.testing.assert_array_equal(count, (want < 1).sum(1))
+        np.testing.assert_array_equal(unpack(mask, k), (want < 1).T)
