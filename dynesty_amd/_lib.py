@@ -61,6 +61,10 @@ SIGNATURES = {
     "dh_seed_children": (_i, [_vp, _vp, _i, _u32, _i, _vp]),
     "dh_rng_stream": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
     "dh_contains": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _vp]),
+    "dh_rebuild": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp,
+                        _vp, _vp, _vp]),
+    "dh_rebuild_batch_dev": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp,
+                                  _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dh_rwalk_batch": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _dbl, _dbl,
                             _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dh_rwalk_batch_dev": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _dbl,
@@ -267,6 +271,33 @@ class Context:
                                          _ptr(ctrs), _ptr(ams), m, mode,
                                          _ptr(count), _ptr(mask), _ptr(quad)))
         return count, mask, quad
+
+    # -- rebuild ------------------------------------------------------------------
+    def rebuild(self, points, multi=True, max_ells=None, want_labels=False):
+        """MultiEllipsoid.update / Ellipsoid.update (see dh_rebuild).  Returns a
+        dict of stacked arrays for the resulting ellipsoids."""
+        pts = _f64(points)
+        n, d = pts.shape
+        if max_ells is None:
+            max_ells = max(1, n // (2 * d)) if multi else 1
+        nells = C.c_int32(0)
+        nnodes = C.c_int32(0)
+        ctrs = np.empty((max_ells, d))
+        covs = np.empty((max_ells, d, d))
+        ams = np.empty((max_ells, d, d))
+        axes = np.empty((max_ells, d, d))
+        axlens = np.empty((max_ells, d))
+        logvols = np.empty(max_ells)
+        lop = np.empty(n, dtype=np.int32) if want_labels else None
+        self._check(self.lib.dh_rebuild(
+            self.handle, _ptr(pts), n, d, 0 if multi else 1, max_ells,
+            C.byref(nells), _ptr(ctrs), _ptr(covs), _ptr(ams), _ptr(axes),
+            _ptr(axlens), _ptr(logvols), _ptr(lop), C.byref(nnodes)))
+        m = nells.value
+        return dict(nells=m, ctrs=ctrs[:m].copy(), covs=covs[:m].copy(),
+                    ams=ams[:m].copy(), axes=axes[:m].copy(),
+                    axlens=axlens[:m].copy(), logvol_ells=logvols[:m].copy(),
+                    labels=lop, nnodes=nnodes.value)
 
     # -- proposals ----------------------------------------------------------------
     def rwalk_batch(self, prob, u0, axes, scale, loglstar, walks, rng_states,

@@ -68,6 +68,7 @@ bool get_problem(dh_ctx* ctx, int handle, ProblemDev* out) {
   out->ndim = r.ndim;
   out->like_par = r.like_par;
   out->prior_par = r.prior_par;
+  out->prec_t = r.prec_t;
   return true;
 }
 
@@ -124,10 +125,12 @@ void dh_destroy(dh_ctx* ctx) {
   for (auto& p : ctx->problems) {
     if (p.like_par) (void)hipFree(p.like_par);
     if (p.prior_par) (void)hipFree(p.prior_par);
+    if (p.prec_t) (void)hipFree(p.prec_t);
   }
   if (ctx->zig) (void)hipFree(ctx->zig);
   if (ctx->arena) (void)hipFree(ctx->arena);
   if (ctx->axes_t) (void)hipFree(ctx->axes_t);
+  if (ctx->rebuild_ws) (void)hipFree(ctx->rebuild_ws);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -233,6 +236,18 @@ int dh_problem_create(dh_ctx* ctx, int ndim, int like_id, const double* like_par
       !hip_ok(ctx, hipMemcpy(r.prior_par, prior_par, sizeof(double) * n_prior_par, hipMemcpyHostToDevice),
               "H2D prior_par"))
     return DH_ERR_HIP;
+  if (like_id == DH_LIKE_GAUSS_PREC && ndim <= kMaxRegDim) {
+    // transposed + zero-padded copy for the column-sweep mat-vec of the walk
+    // kernels (P is symmetric in exact arithmetic; transpose anyway)
+    const int N = pad_dim(ndim);
+    std::vector<double> pt((size_t)N * N, 0.0);
+    for (int i = 0; i < ndim; ++i)
+      for (int j = 0; j < ndim; ++j) pt[(size_t)j * N + i] = like_par[1 + (size_t)i * ndim + j];
+    if (!hip_ok(ctx, hipMalloc((void**)&r.prec_t, sizeof(double) * N * N), "hipMalloc") ||
+        !hip_ok(ctx, hipMemcpy(r.prec_t, pt.data(), sizeof(double) * N * N, hipMemcpyHostToDevice),
+                "H2D prec_t"))
+      return DH_ERR_HIP;
+  }
   for (size_t i = 0; i < ctx->problems.size(); ++i)
     if (!ctx->problems[i].live) {
       ctx->problems[i] = r;
@@ -250,6 +265,7 @@ int dh_problem_destroy(dh_ctx* ctx, int problem) {
   dh_problem_rec& r = ctx->problems[problem];
   (void)hipFree(r.like_par);
   (void)hipFree(r.prior_par);
+  if (r.prec_t) (void)hipFree(r.prec_t);
   r = dh_problem_rec();
   return DH_OK;
 }

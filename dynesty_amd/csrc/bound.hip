@@ -5,8 +5,6 @@ using namespace dh;
 
 namespace {
 
-#define DH_DIM_LIST(X) X(1) X(2) X(3) X(4) X(5) X(6) X(8) X(10) X(12) X(16) X(20) X(25) X(32)
-constexpr int kMaxRegDim = 32;
 
 // MultiEllipsoid.within / contains (bounding.py:502-523): lane = candidate point,
 // the loop runs over ellipsoids so centre and precision matrix are wave-uniform

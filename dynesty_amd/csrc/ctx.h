@@ -9,12 +9,25 @@
 #include "../../include/dynhip.h"
 #include "problem.h"
 
+// Walker / candidate state lives in registers, so the per-lane kernels are
+// instantiated for a fixed list of padded dimensions.
+#define DH_DIM_LIST(X) X(1) X(2) X(3) X(4) X(5) X(6) X(8) X(10) X(12) X(16) X(20) X(25) X(32)
+constexpr int kMaxRegDim = 32;
+inline int pad_dim(int n) {
+#define X(NN) \
+  if (n <= NN) return NN;
+  DH_DIM_LIST(X)
+#undef X
+  return 0;
+}
+
 struct dh_problem_rec {
   bool live = false;
   int ndim = 0;
   int like_id = 0, prior_id = 0;
   double* like_par = nullptr;   // device
   double* prior_par = nullptr;  // device
+  double* prec_t = nullptr;     // device: padded precision matrix (GAUSS_PREC)
   int n_like = 0, n_prior = 0;
 };
 
@@ -32,6 +45,9 @@ struct dh_ctx {
   // transposed/padded proposal frames for the walk kernels
   double* axes_t = nullptr;
   size_t axes_t_cap = 0;
+  // scratch of the rebuild kernel (permutations, node table, per-node ellipsoids)
+  char* rebuild_ws = nullptr;
+  size_t rebuild_ws_cap = 0;
 
   const uint64_t* zki() const { return zig; }
   const uint64_t* zwi() const { return zig + 256; }

@@ -1,0 +1,1087 @@
+// MultiEllipsoid / Ellipsoid rebuild on the device (kernels K1-K4 of SURVEY.md).
+//
+// One workgroup owns one live set ("run") and executes the whole rebuild --
+// bounding ellipsoid of the root, the recursive k=2 split
+// (reference bounding.py:1464-1563) as a level-ordered worklist, the bottom-up
+// BIC-style accept test, and the coverage check of MultiEllipsoid.update
+// (bounding.py:632-686) -- in ONE launch: no host round trips, no inter-
+// workgroup synchronisation.  An ensemble of runs is a grid of workgroups.
+//
+// Data layout: points stay row-major (N x D, fp64) in HBM/L2; a permutation
+// array keeps every tree node a contiguous segment (stable partition = the
+// order of `points[labels == k]`).  Node tiles of TP points are gathered
+// (coalesced along D) into LDS, centred or rescaled on the way in; covariance
+// entries / centroid sums are accumulated from LDS by a fixed thread->entry
+// map so results are deterministic.  D x D eigenproblems are solved by one
+// wavefront with a parallel-order cyclic Jacobi in LDS.
+#include <math.h>
+
+#include "ctx.h"
+
+using namespace dh;
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr double kRoundDelta = 1e-3;  // bounding.py:1420
+constexpr double kMaxCond = 1e12;     // bounding.py:1311
+constexpr double kEigMult = 10.0;     // bounding.py:1326
+constexpr int kNTries = 100;          // bounding.py:1311
+
+// per-node record in global scratch
+struct Node {
+  int start, count;
+  int parent, child0, child1;
+  int depth;
+  int split;        // 1 if children were created
+  int res_start, res_len;  // result list (indices of nodes) after the accept test
+  double logvol;
+};
+
+struct RebuildArgs {
+  const double* pts;  // runs x n x d
+  int n, d, runs;
+  int mode;           // 0: MultiEllipsoid.update, 1: Ellipsoid.update (no split)
+  int max_nodes, max_ells;
+  double prefactor;   // logvol_prefactor(d), bounding.py:1271-1285
+  // per-run scratch (strided by run)
+  int* perm;          // runs x n
+  int* perm2;         // runs x n
+  unsigned char* lab; // runs x n
+  Node* nodes;        // runs x max_nodes
+  double* estore;     // runs x max_nodes x ES   (ctr D | cov D^2 | am D^2 | axes D^2 | axlens D)
+  int* reslist;       // runs x (max_nodes * 2 + ...) result-list arena
+  int reslist_cap;
+  // outputs (strided by run)
+  int* nells;         // runs
+  int* status;        // runs
+  double* ctrs;       // runs x max_ells x D
+  double* covs;       // runs x max_ells x D^2
+  double* ams;
+  double* axes;
+  double* axlens;     // runs x max_ells x D
+  double* logvols;    // runs x max_ells
+  int* leaf_of_point; // runs x n (index into the output list) or null
+  int* nnodes_out;    // runs or null
+};
+
+// ---- LDS carve-up ----------------------------------------------------------
+struct Lds {
+  double* tile;   // TP x LD
+  double* A;      // D x LD   (cov / Jacobi work)
+  double* V;      // D x LD
+  double* AM;     // D x LD
+  double* AX;     // D x LD   (axes)
+  double* mean;   // D
+  double* scale;  // D
+  double* lam;    // D
+  double* cen;    // 2 x D
+  double* sums;   // 2 x D
+  double* red;    // kThreads
+  double* rc;     // 64 (rotation c)
+  double* rs;     // 64
+  int* ri;        // 256 ints (pair indices, scan scratch, ...)
+  int* perm_sort; // D
+  int TP, LD;
+};
+
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ double block_reduce_max(double v, double* red) {
+  const int t = threadIdx.x;
+  red[t] = v;
+  __syncthreads();
+  for (int s = kThreads / 2; s > 0; s >>= 1) {
+    if (t < s) red[t] = fmax(red[t], red[t + s]);
+    __syncthreads();
+  }
+  double r = red[0];
+  __syncthreads();
+  return r;
+}
+
+__device__ __forceinline__ int block_reduce_sum_int(int v, int* red) {
+  const int t = threadIdx.x;
+  red[t] = v;
+  __syncthreads();
+  for (int s = kThreads / 2; s > 0; s >>= 1) {
+    if (t < s) red[t] += red[t + s];
+    __syncthreads();
+  }
+  int r = red[0];
+  __syncthreads();
+  return r;
+}
+
+// ---- symmetric eigen-decomposition by one wavefront -------------------------
+// A (D x LD, symmetric, destroyed: diagonal -> eigenvalues), V -> eigenvectors
+// in columns.  Parallel-order cyclic Jacobi: every round rotates ceil(D/2)
+// disjoint (p,q) pairs at once (round-robin tournament), so a sweep is D-1 (D)
+// rounds of three LDS passes.  Called by wave 0 only; caller barriers after.
+// Returns false if the matrix contains non-finite entries.
+__device__ bool jacobi_wave(double* A, double* V, int D, int LD, double* rc, double* rs, int* rp) {
+  const int lane = threadIdx.x & 63;
+  // V = I ; finiteness check
+  bool ok = true;
+  for (int e = lane; e < D * D; e += 64) {
+    const int i = e / D, j = e % D;
+    V[i * LD + j] = (i == j) ? 1.0 : 0.0;
+    if (!isfinite(A[i * LD + j])) ok = false;
+  }
+  ok = __all(ok);
+  wave_sync();
+  if (!ok) return false;
+  if (D == 1) return true;
+  const int m = (D + 1) / 2;  // pairs per round
+  const int P = 2 * m;        // players (last one is a bye when D is odd)
+  const int rounds = P - 1;
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    // convergence: off-diagonal mass vs diagonal mass
+    double off = 0.0, dia = 0.0;
+    for (int e = lane; e < D * D; e += 64) {
+      const int i = e / D, j = e % D;
+      const double a = A[i * LD + j];
+      if (i == j)
+        dia = fma(a, a, dia);
+      else
+        off = fma(a, a, off);
+    }
+    for (int s = 32; s > 0; s >>= 1) {
+      off += __shfl_xor(off, s);
+      dia += __shfl_xor(dia, s);
+    }
+    if (!(off > 1e-33 * dia)) break;  // also exits on off == 0
+    for (int r = 0; r < rounds; ++r) {
+      // pair k of round r (circle method)
+      if (lane < m) {
+        int p, q;
+        if (lane == 0) {
+          p = P - 1;
+          q = r;
+        } else {
+          p = (r + lane) % (P - 1);
+          q = (r - lane + (P - 1)) % (P - 1);
+        }
+        if (p > q) {
+          const int tmp = p;
+          p = q;
+          q = tmp;
+        }
+        double c = 1.0, s = 0.0;
+        if (q < D) {
+          const double apq = A[p * LD + q];
+          if (apq != 0.0) {
+            const double app = A[p * LD + p], aqq = A[q * LD + q];
+            const double tau = (aqq - app) / (2.0 * apq);
+            const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(fma(tau, tau, 1.0)));
+            c = 1.0 / sqrt(fma(t, t, 1.0));
+            s = t * c;
+          }
+        } else {
+          p = -1;  // bye
+        }
+        rc[lane] = c;
+        rs[lane] = s;
+        rp[lane] = p;
+        rp[64 + lane] = q;
+      }
+      wave_sync();
+      // columns: A <- A J, V <- V J
+      for (int e = lane; e < D * m; e += 64) {
+        const int i = e / m, k = e % m;
+        const int p = rp[k], q = rp[64 + k];
+        if (p >= 0) {
+          const double c = rc[k], s = rs[k];
+          const double aip = A[i * LD + p], aiq = A[i * LD + q];
+          A[i * LD + p] = c * aip - s * aiq;
+          A[i * LD + q] = s * aip + c * aiq;
+          const double vip = V[i * LD + p], viq = V[i * LD + q];
+          V[i * LD + p] = c * vip - s * viq;
+          V[i * LD + q] = s * vip + c * viq;
+        }
+      }
+      wave_sync();
+      // rows: A <- J^T A
+      for (int e = lane; e < D * m; e += 64) {
+        const int k = e / D, j = e % D;
+        const int p = rp[k], q = rp[64 + k];
+        if (p >= 0) {
+          const double c = rc[k], s = rs[k];
+          const double apj = A[p * LD + j], aqj = A[q * LD + j];
+          A[p * LD + j] = c * apj - s * aqj;
+          A[q * LD + j] = s * apj + c * aqj;
+        }
+      }
+      wave_sync();
+      if (lane < m && rp[lane] >= 0) {
+        const int p = rp[lane], q = rp[64 + lane];
+        A[p * LD + q] = 0.0;
+        A[q * LD + p] = 0.0;
+      }
+      wave_sync();
+    }
+  }
+  return true;
+}
+
+// Sort eigenpairs ascending (LAPACK order), fix the sign of every eigenvector so
+// its largest-magnitude component is positive (our canonical choice: LAPACK's
+// sign is arbitrary).  lam[k], V[:,k] <- sorted; uses AX as scratch.  Wave 0.
+__device__ void sort_eigs_wave(const double* A, double* V, double* lam, int* order, double* scratch,
+                               int D, int LD) {
+  const int lane = threadIdx.x & 63;
+  for (int k = lane; k < D; k += 64) {
+    const double mine = A[k * LD + k];
+    int rank = 0;
+    for (int j = 0; j < D; ++j) {
+      const double other = A[j * LD + j];
+      if (other < mine || (other == mine && j < k)) ++rank;
+    }
+    order[rank] = k;  // NaNs compare false everywhere: caught by the caller
+  }
+  wave_sync();
+  for (int e = lane; e < D * D; e += 64) {
+    const int i = e / D, k = e % D;
+    scratch[i * LD + k] = V[i * LD + order[k]];
+  }
+  for (int k = lane; k < D; k += 64) lam[k] = A[order[k] * LD + order[k]];
+  wave_sync();
+  for (int k = lane; k < D; k += 64) {
+    double best = 0.0;
+    int bi = 0;
+    for (int i = 0; i < D; ++i) {
+      const double a = fabs(scratch[i * LD + k]);
+      if (a > best) {
+        best = a;
+        bi = i;
+      }
+    }
+    const double sg = scratch[bi * LD + k] < 0.0 ? -1.0 : 1.0;
+    for (int i = 0; i < D; ++i) V[i * LD + k] = sg * scratch[i * LD + k];
+  }
+  wave_sync();
+}
+
+// ---- tile staging -----------------------------------------------------------
+// tile[p][j] = f(pts[perm[start+p]][j]) for p < cnt ; f: 0 raw, 1 minus mean, 2 / scale
+__device__ __forceinline__ void stage_tile(const Lds& L, const double* __restrict__ pts,
+                                           const int* __restrict__ perm, int start, int cnt, int D,
+                                           int how) {
+  const int tot = cnt * D;
+  for (int e = threadIdx.x; e < tot; e += kThreads) {
+    const int p = e / D, j = e - p * D;
+    double x = pts[(size_t)perm[start + p] * D + j];
+    if (how == 1) x -= L.mean[j];
+    if (how == 2) x = x / L.scale[j];
+    L.tile[p * L.LD + j] = x;
+  }
+  __syncthreads();
+}
+
+// mean of a node -> L.mean (np.mean(points, axis=0), bounding.py:1410)
+__device__ void node_mean(const Lds& L, const double* pts, const int* perm, int start, int count, int D) {
+  const int t = threadIdx.x;
+  const int G = kThreads / D > 0 ? kThreads / D : 1;  // point groups per dim
+  const int j = t % D, g = t / D;
+  double acc = 0.0;
+  for (int base = 0; base < count; base += L.TP) {
+    const int cnt = min(L.TP, count - base);
+    stage_tile(L, pts, perm, start + base, cnt, D, 0);
+    if (g < G && t < G * D)
+      for (int p = g; p < cnt; p += G) acc += L.tile[p * L.LD + j];
+    __syncthreads();
+  }
+  L.red[t] = acc;
+  __syncthreads();
+  if (t < D) {
+    double s = 0.0;
+    for (int gg = 0; gg < G; ++gg) s += L.red[gg * D + t];
+    L.mean[t] = s / (double)count;
+  }
+  __syncthreads();
+}
+
+// population std of a node -> L.scale (points.std(axis=0), bounding.py:1503-1504)
+__device__ void node_std(const Lds& L, const double* pts, const int* perm, int start, int count, int D) {
+  node_mean(L, pts, perm, start, count, D);
+  const int t = threadIdx.x;
+  const int G = kThreads / D > 0 ? kThreads / D : 1;
+  const int j = t % D, g = t / D;
+  double acc = 0.0;
+  for (int base = 0; base < count; base += L.TP) {
+    const int cnt = min(L.TP, count - base);
+    stage_tile(L, pts, perm, start + base, cnt, D, 1);
+    if (g < G && t < G * D)
+      for (int p = g; p < cnt; p += G) {
+        const double x = L.tile[p * L.LD + j];
+        acc = fma(x, x, acc);
+      }
+    __syncthreads();
+  }
+  L.red[t] = acc;
+  __syncthreads();
+  if (t < D) {
+    double s = 0.0;
+    for (int gg = 0; gg < G; ++gg) s += L.red[gg * D + t];
+    L.scale[t] = sqrt(s / (double)count);
+  }
+  __syncthreads();
+}
+
+// sample covariance (ddof=1) of a node about L.mean -> L.A (np.cov, bounding.py:1411)
+__device__ void node_cov(const Lds& L, const double* pts, const int* perm, int start, int count, int D) {
+  const int t = threadIdx.x;
+  const int nent = D * (D + 1) / 2;
+  // each thread owns entries e = t, t+256, ...; at most 4 per thread kept in registers
+  // (D <= 44); larger D loops in chunks of entries.
+  for (int e0 = 0; e0 < nent; e0 += kThreads * 4) {
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    int ea[4], eb[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int e = e0 + r * kThreads + t;
+      // unrank e -> (a <= b), row-major upper triangle
+      int a = 0, rem = e;
+      if (e < nent) {
+        // a = largest with a*D - a(a-1)/2 <= e
+        a = (int)floor(((2.0 * D + 1.0) - sqrt((2.0 * D + 1.0) * (2.0 * D + 1.0) - 8.0 * e)) * 0.5);
+        while (a > 0 && a * D - a * (a - 1) / 2 > e) --a;
+        while ((a + 1) * D - (a + 1) * a / 2 <= e) ++a;
+        rem = e - (a * D - a * (a - 1) / 2);
+      }
+      ea[r] = a;
+      eb[r] = a + rem;
+    }
+    for (int base = 0; base < count; base += L.TP) {
+      const int cnt = min(L.TP, count - base);
+      stage_tile(L, pts, perm, start + base, cnt, D, 1);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (e0 + r * kThreads + t < nent) {
+          const int a = ea[r], b = eb[r];
+          double s = acc[r];
+          for (int p = 0; p < cnt; ++p) s = fma(L.tile[p * L.LD + a], L.tile[p * L.LD + b], s);
+          acc[r] = s;
+        }
+      }
+      __syncthreads();
+    }
+    const double inv = 1.0 / (double)(count - 1);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (e0 + r * kThreads + t < nent) {
+        const double c = acc[r] * inv;
+        L.A[ea[r] * L.LD + eb[r]] = c;
+        L.A[eb[r] * L.LD + ea[r]] = c;
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// max_i delta_i^T AM delta_i over a node (bounding.py:1438), delta about L.mean
+__device__ double node_fmax(const Lds& L, const double* pts, const int* perm, int start, int count, int D) {
+  const int t = threadIdx.x;
+  double best = -INFINITY;
+  for (int base = 0; base < count; base += L.TP) {
+    const int cnt = min(L.TP, count - base);
+    stage_tile(L, pts, perm, start + base, cnt, D, 1);
+    for (int p = t; p < cnt; p += kThreads) {
+      const double* x = L.tile + p * L.LD;
+      double q = 0.0;
+      for (int i = 0; i < D; ++i) {
+        double r = 0.0;
+        const double* row = L.AM + i * L.LD;
+        for (int j = 0; j < D; ++j) r = fma(row[j], x[j], r);
+        q = fma(x[i], r, q);
+      }
+      best = fmax(best, q);
+    }
+    __syncthreads();
+  }
+  return block_reduce_max(best, L.red);
+}
+
+// helpers on D x D LDS matrices (all threads)
+__device__ __forceinline__ void mat_from_eig(const Lds& L, double* out, const double* lamv, int D,
+                                             bool inverse) {
+  // out = (V * w) V^T with w = lam or 1/lam   ((eigvec * x) @ eigvec.T)
+  for (int e = threadIdx.x; e < D * D; e += kThreads) {
+    const int i = e / D, j = e % D;
+    double s = 0.0;
+    for (int k = 0; k < D; ++k) {
+      const double w = inverse ? 1.0 / lamv[k] : lamv[k];
+      s = fma(L.V[i * L.LD + k] * w, L.V[j * L.LD + k], s);
+    }
+    out[i * L.LD + j] = s;
+  }
+  __syncthreads();
+}
+
+// improve_covar_mat (bounding.py:1311-1384) on L.A (the covariance, kept in
+// L.AX-independent copy `cov`), producing L.AM (precision), L.AX (axes), L.lam
+// (eigenvalues of the returned covariance).  `cov` is a D x LD global/LDS buffer
+// holding the matrix to regularise; it is updated in place.  Returns good_mat.
+__device__ bool regularize(const Lds& L, double* cov, int D) {
+  const int t = threadIdx.x;
+  int failed = 0;
+  int trial = 0;
+  for (trial = 0; trial < kNTries; ++trial) {
+    failed = 0;
+    // eigh(cov): copy into A, solve with wave 0
+    for (int e = t; e < D * D; e += kThreads) L.A[(e / D) * L.LD + e % D] = cov[(e / D) * L.LD + e % D];
+    __syncthreads();
+    if (t < 64) {
+      bool fin = jacobi_wave(L.A, L.V, D, L.LD, L.rc, L.rs, L.ri);
+      if (fin) sort_eigs_wave(L.A, L.V, L.lam, L.perm_sort, L.AX, D, L.LD);
+      if (t == 0) L.ri[300] = fin ? 1 : 0;
+    }
+    __syncthreads();
+    const bool fin = L.ri[300] != 0;
+    double top = -INFINITY, bot = INFINITY;
+    bool allfin = fin;
+    if (fin) {
+      for (int k = 0; k < D; ++k) {
+        const double l = L.lam[k];
+        if (!isfinite(l)) allfin = false;
+        top = fmax(top, l);
+        bot = fmin(bot, l);
+      }
+    }
+    if (allfin) {
+      if (top <= 0.0)
+        failed = 2;
+      else if (bot < top / kMaxCond)
+        failed = 1;
+      else {
+        // axes = eigvec * eigval**.5
+        for (int e = t; e < D * D; e += kThreads) {
+          const int i = e / D, k = e % D;
+          L.AX[i * L.LD + k] = L.V[i * L.LD + k] * sqrt(L.lam[k]);
+        }
+        __syncthreads();
+        break;
+      }
+    } else {
+      failed = 2;
+    }
+    if (failed == 1) {
+      // eigval_fix = max(eigval, eig_mult * maxval / max_condition_number)
+      __syncthreads();
+      if (t < D) L.lam[t] = fmax(L.lam[t], kEigMult * top / kMaxCond);
+      __syncthreads();
+      mat_from_eig(L, cov, L.lam, D, false);
+    } else {
+      const double coeffmin = 1e-10;
+      const double coeff = coeffmin * pow(1.0 / coeffmin, (double)trial / (double)(kNTries - 1));
+      for (int e = t; e < D * D; e += kThreads) {
+        const int i = e / D, j = e % D;
+        cov[i * L.LD + j] = (1.0 - coeff) * cov[i * L.LD + j] + coeff * (i == j ? 1.0 : 0.0);
+      }
+      __syncthreads();
+    }
+  }
+  if (failed > 0) {
+    // identity fallback (bounding.py:1374-1378)
+    for (int e = t; e < D * D; e += kThreads) {
+      const int i = e / D, j = e % D;
+      const double v = (i == j) ? 1.0 : 0.0;
+      cov[i * L.LD + j] = v;
+      L.AM[i * L.LD + j] = v;
+      L.AX[i * L.LD + j] = v;
+    }
+    if (t < D) L.lam[t] = 1.0;
+    __syncthreads();
+    return false;  // trial == ntries-1 != 0
+  }
+  mat_from_eig(L, L.AM, L.lam, D, true);
+  return trial == 0;
+}
+
+// bounding_ellipsoid (bounding.py:1387-1461) of the node segment; writes the
+// ellipsoid record to `es` (global).  Returns 0 or a DH_ERR code (uniform).
+__device__ int node_ellipsoid(const Lds& L, const RebuildArgs& a, const double* pts, const int* perm,
+                              int start, int count, double* es, double* cov_g, double* logvol_out) {
+  const int D = a.d, t = threadIdx.x, LD = L.LD;
+  if (count == 1) return DH_ERR_VALUE;
+  node_mean(L, pts, perm, start, count, D);
+  node_cov(L, pts, perm, start, count, D);
+  // cov_g: this node's D x LD working covariance (global scratch, L2 resident)
+  for (int e = t; e < D * D; e += kThreads) cov_g[(e / D) * LD + e % D] = L.A[(e / D) * LD + e % D];
+  __syncthreads();
+  const double lim = 1.0 - kRoundDelta;
+  for (int pass = 0; pass < 2; ++pass) {
+    const bool good = regularize(L, cov_g, D);
+    const double fmx = node_fmax(L, pts, perm, start, count, D);
+    if (pass == 0 && fmx > lim) {
+      const double mult = fmx / lim;
+      const double rt = sqrt(mult);
+      for (int e = t; e < D * D; e += kThreads) {
+        const int i = e / D, j = e % D;
+        cov_g[i * LD + j] *= mult;
+        L.AM[i * LD + j] /= mult;
+        L.AX[i * LD + j] *= rt;
+      }
+      __syncthreads();
+      if (t < D) L.lam[t] *= mult;
+      __syncthreads();
+    }
+    if (pass == 1 && fmx >= 1.0) return DH_ERR_CONTAIN;
+    if (good) break;
+  }
+  // Ellipsoid.__init__ (bounding.py:201-240): eigenvalues must be positive
+  bool ok = true;
+  double slog = 0.0;
+  for (int k = 0; k < D; ++k) {
+    const double l = L.lam[k];
+    if (!(l > 0.0) || !isfinite(l)) ok = false;
+    slog += log(l);
+  }
+  if (!ok) return DH_ERR_VALUE;
+  const double logvol = a.prefactor + 0.5 * slog;
+  // store: ctr | cov | am | axes | axlens
+  const int DD = D * D;
+  if (t < D) {
+    es[t] = L.mean[t];
+    es[D + 3 * DD + t] = sqrt(L.lam[t]);
+  }
+  for (int e = t; e < DD; e += kThreads) {
+    const int i = e / D, j = e % D;
+    es[D + e] = cov_g[i * LD + j];
+    es[D + DD + e] = L.AM[i * LD + j];
+    es[D + 2 * DD + e] = L.AX[i * LD + j];
+  }
+  __syncthreads();
+  *logvol_out = logvol;
+  return DH_OK;
+}
+
+// kmeans2(points/scale, seeds/scale, iter=10, minit='matrix') on a node
+// (bounding.py:1510-1514; scipy.cluster.vq.kmeans2 loop).  Labels -> lab[].
+// Returns the size of cluster 0 (uniform).
+__device__ int node_kmeans(const Lds& L, const double* pts, const int* perm, unsigned char* lab,
+                           int start, int count, int D, const double* es) {
+  const int t = threadIdx.x;
+  const int DD = D * D;
+  // seeds: major-axis endpoints ctr -/+ axes[:, argmax(axlens)] (bounding.py:278-284)
+  if (t == 0) {
+    int best = 0;
+    double bl = es[D + 3 * DD];
+    for (int k = 1; k < D; ++k)
+      if (es[D + 3 * DD + k] > bl) {
+        bl = es[D + 3 * DD + k];
+        best = k;
+      }
+    L.ri[301] = best;
+  }
+  __syncthreads();
+  const int kbest = L.ri[301];
+  if (t < D) {
+    const double v = es[D + 2 * DD + t * D + kbest];
+    L.cen[t] = (es[t] - v) / L.scale[t];
+    L.cen[D + t] = (es[t] + v) / L.scale[t];
+  }
+  __syncthreads();
+  const int G = kThreads / D > 0 ? kThreads / D : 1;
+  const int j = t % D, g = t / D;
+  int n0_last = 0;
+  for (int it = 0; it < 10; ++it) {
+    double s0 = 0.0, s1 = 0.0;
+    int myc0 = 0;
+    for (int base = 0; base < count; base += L.TP) {
+      const int cnt = min(L.TP, count - base);
+      stage_tile(L, pts, perm, start + base, cnt, D, 2);
+      // vq: nearest centroid, strict '<' so the lower index wins ties
+      for (int p = t; p < cnt; p += kThreads) {
+        const double* x = L.tile + p * L.LD;
+        double d0 = 0.0, d1 = 0.0;
+        for (int jj = 0; jj < D; ++jj) {
+          const double e0 = x[jj] - L.cen[jj], e1 = x[jj] - L.cen[D + jj];
+          d0 = fma(e0, e0, d0);
+          d1 = fma(e1, e1, d1);
+        }
+        const unsigned char lb = d1 < d0 ? 1 : 0;
+        lab[start + base + p] = lb;
+        L.ri[p] = lb;  // TP <= 256 == kThreads: one label slot per tile point
+        myc0 += lb ? 0 : 1;
+      }
+      __syncthreads();
+      // update_cluster_means: per-dimension sums, fixed point->group map
+      if (t < G * D) {
+        for (int p = g; p < cnt; p += G) {
+          const double x = L.tile[p * L.LD + j];
+          if (L.ri[p])
+            s1 += x;
+          else
+            s0 += x;
+        }
+      }
+      __syncthreads();
+    }
+    const int c0 = block_reduce_sum_int(myc0, L.ri);
+    // reduce groups (fixed order)
+    L.red[t] = s0;
+    __syncthreads();
+    double sum0 = 0.0;
+    if (t < D)
+      for (int gg = 0; gg < G; ++gg) sum0 += L.red[gg * D + t];
+    __syncthreads();
+    L.red[t] = s1;
+    __syncthreads();
+    double sum1 = 0.0;
+    if (t < D)
+      for (int gg = 0; gg < G; ++gg) sum1 += L.red[gg * D + t];
+    __syncthreads();
+    const int n0 = c0, n1 = count - n0;
+    n0_last = n0;
+    if (t < D) {
+      if (n0 > 0) L.cen[t] = sum0 / (double)n0;       // empty cluster keeps its centroid
+      if (n1 > 0) L.cen[D + t] = sum1 / (double)n1;
+    }
+    __syncthreads();
+  }
+  return n0_last;
+}
+
+// stable partition of perm[start, start+count) by lab: label 0 first
+__device__ void node_partition(const Lds& L, int* perm, int* perm2, const unsigned char* lab, int start,
+                               int count, int n0) {
+  const int t = threadIdx.x;
+  int run0 = 0, run1 = 0;  // running counts before this tile (uniform)
+  for (int base = 0; base < count; base += kThreads) {
+    const int p = base + t;
+    const int flag = (p < count) ? (lab[start + p] ? 0 : 1) : 0;  // 1 for label 0
+    const int live = (p < count) ? 1 : 0;
+    // inclusive scan of flag over the block (Hillis-Steele in LDS)
+    L.ri[t] = flag;
+    __syncthreads();
+    for (int s = 1; s < kThreads; s <<= 1) {
+      int v = L.ri[t];
+      if (t >= s) v += L.ri[t - s];
+      __syncthreads();
+      L.ri[t] = v;
+      __syncthreads();
+    }
+    const int incl = L.ri[t];
+    const int tile0 = L.ri[kThreads - 1];
+    __syncthreads();
+    if (live) {
+      int pos;
+      if (flag)
+        pos = run0 + incl - 1;
+      else
+        pos = n0 + run1 + (t + 1 - incl) - 1;
+      perm2[start + pos] = perm[start + p];
+    }
+    const int tile_live = min(kThreads, count - base);
+    run0 += tile0;
+    run1 += tile_live - tile0;
+    __syncthreads();
+  }
+  for (int p = t; p < count; p += kThreads) perm[start + p] = perm2[start + p];
+  __threadfence_block();
+  __syncthreads();
+}
+
+__device__ __forceinline__ double logaddexp_d(double x, double y) {
+  // np.logaddexp
+  if (x == y) return x + 0.6931471805599453;
+  const double d = x - y;
+  if (d > 0) return x + log1p(exp(-d));
+  if (d <= 0) return y + log1p(exp(d));
+  return x + y;  // NaN
+}
+
+__global__ void __launch_bounds__(kThreads) rebuild_kernel(RebuildArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int D = a.d, n = a.n, t = threadIdx.x;
+  const int run = blockIdx.x;
+  // ---- LDS carve ----
+  Lds L;
+  L.LD = D | 1;  // odd leading dimension: conflict-free column walks
+  L.TP = kThreads;
+  {
+    double* p = (double*)smem;
+    L.tile = p;
+    p += (size_t)L.TP * L.LD;
+    L.A = p;
+    p += D * L.LD;
+    L.V = p;
+    p += D * L.LD;
+    L.AM = p;
+    p += D * L.LD;
+    L.AX = p;
+    p += D * L.LD;
+    L.mean = p;
+    p += D;
+    L.scale = p;
+    p += D;
+    L.lam = p;
+    p += D;
+    L.cen = p;
+    p += 2 * D;
+    L.sums = p;
+    p += 2 * D;
+    L.red = p;
+    p += kThreads;
+    L.rc = p;
+    p += 64;
+    L.rs = p;
+    p += 64;
+    L.ri = (int*)p;
+    L.perm_sort = L.ri + 320;
+  }
+  const double* pts = a.pts + (size_t)run * n * D;
+  int* perm = a.perm + (size_t)run * n;
+  int* perm2 = a.perm2 + (size_t)run * n;
+  unsigned char* lab = a.lab + (size_t)run * n;
+  Node* nodes = a.nodes + (size_t)run * a.max_nodes;
+  const int DD = D * D;
+  const int ES = D + 3 * DD + D;            // ellipsoid record
+  const int NS = ES + D * L.LD;             // + working covariance
+  double* estore = a.estore + (size_t)run * a.max_nodes * NS;
+  int* reslist = a.reslist + (size_t)run * a.reslist_cap;
+
+  for (int p = t; p < n; p += kThreads) perm[p] = p;
+  __threadfence_block();
+  __syncthreads();
+
+  int status = DH_OK;
+  int nnodes = 1;
+  if (n <= 1) status = (a.mode == 0) ? DH_ERR_REGION : DH_ERR_VALUE;  // single point
+
+  // ---- root ----
+  double lv = 0.0;
+  if (status == DH_OK) {
+    status = node_ellipsoid(L, a, pts, perm, 0, n, estore, estore + ES, &lv);
+    if (t == 0) {
+      Node r;
+      r.start = 0;
+      r.count = n;
+      r.parent = -1;
+      r.child0 = r.child1 = -1;
+      r.depth = 0;
+      r.split = 0;
+      r.res_start = 0;
+      r.res_len = 0;
+      r.logvol = lv;
+      nodes[0] = r;
+    }
+    __syncthreads();
+  }
+
+  // ---- level-ordered split worklist (bounding.py:1464-1563) ----
+  if (status == DH_OK && a.mode == 0) {
+    const int min_size = 2 * D;
+    if (n >= 2 * min_size) node_std(L, pts, perm, 0, n, D);  // scale, root only (:1503)
+    for (int cur = 0; cur < nnodes && status == DH_OK; ++cur) {
+      const int start = nodes[cur].start, count = nodes[cur].count, depth = nodes[cur].depth;
+      if (count < 2 * min_size) continue;  // too small to try a split (:1492-1496)
+      const double* es = estore + (size_t)cur * NS;
+      const int n0 = node_kmeans(L, pts, perm, lab, start, count, D, es);
+      const int n1 = count - n0;
+      if (min(n0, n1) < min_size) continue;  // reject the split (:1521-1522)
+      if (nnodes + 2 > a.max_nodes) {
+        status = DH_ERR_NOMEM;
+        break;
+      }
+      node_partition(L, perm, perm2, lab, start, count, n0);
+      const int c0 = nnodes, c1 = nnodes + 1;
+      double lv0 = 0.0, lv1 = 0.0;
+      int rc = node_ellipsoid(L, a, pts, perm, start, n0, estore + (size_t)c0 * NS,
+                              estore + (size_t)c0 * NS + ES, &lv0);
+      if (rc == DH_OK)
+        rc = node_ellipsoid(L, a, pts, perm, start + n0, n1, estore + (size_t)c1 * NS,
+                            estore + (size_t)c1 * NS + ES, &lv1);
+      if (rc != DH_OK) {
+        status = rc;
+        break;
+      }
+      if (t == 0) {
+        Node k0, k1;
+        k0.start = start;
+        k0.count = n0;
+        k1.start = start + n0;
+        k1.count = n1;
+        k0.parent = k1.parent = cur;
+        k0.child0 = k0.child1 = k1.child0 = k1.child1 = -1;
+        k0.depth = k1.depth = depth + 1;
+        k0.split = k1.split = 0;
+        k0.res_start = k1.res_start = 0;
+        k0.res_len = k1.res_len = 0;
+        k0.logvol = lv0;
+        k1.logvol = lv1;
+        nodes[c0] = k0;
+        nodes[c1] = k1;
+        nodes[cur].child0 = c0;
+        nodes[cur].child1 = c1;
+        nodes[cur].split = 1;
+      }
+      nnodes += 2;
+      __threadfence_block();
+      __syncthreads();
+    }
+  }
+
+  // ---- bottom-up accept test (bounding.py:1541-1563), thread 0 ----
+  if (status == DH_OK) {
+    if (t == 0) {
+      L.ri[303] = 0;
+      int top = 0;  // arena cursor
+      for (int i = nnodes - 1; i >= 0; --i) {
+        Node nd = nodes[i];
+        if (!nd.split) {
+          nd.res_start = top;
+          nd.res_len = 1;
+          reslist[top++] = i;
+        } else {
+          const Node& k0 = nodes[nd.child0];
+          const Node& k1 = nodes[nd.child1];
+          const int len = k0.res_len + k1.res_len;
+          const int nparam = (D * (D + 3)) / 2;
+          const double dec = nparam * log((double)nd.count) / (double)nd.count;
+          bool accept = (logaddexp_d(k0.logvol, k1.logvol) - nd.logvol) < -dec;
+          if (!accept) {
+            // logsumexp over the leaves of both subtrees, in list order
+            double mx = -INFINITY;
+            for (int q = 0; q < k0.res_len; ++q) mx = fmax(mx, nodes[reslist[k0.res_start + q]].logvol);
+            for (int q = 0; q < k1.res_len; ++q) mx = fmax(mx, nodes[reslist[k1.res_start + q]].logvol);
+            double s = 0.0;
+            for (int q = 0; q < k0.res_len; ++q) s += exp(nodes[reslist[k0.res_start + q]].logvol - mx);
+            for (int q = 0; q < k1.res_len; ++q) s += exp(nodes[reslist[k1.res_start + q]].logvol - mx);
+            const double lse = log(s) + mx;
+            accept = (lse - nd.logvol) < -dec * (len - 1);
+          }
+          if (accept) {
+            if (top + len > a.reslist_cap) {
+              L.ri[303] = DH_ERR_NOMEM;
+              break;
+            }
+            nd.res_start = top;
+            nd.res_len = len;
+            for (int q = 0; q < k0.res_len; ++q) reslist[top++] = reslist[k0.res_start + q];
+            for (int q = 0; q < k1.res_len; ++q) reslist[top++] = reslist[k1.res_start + q];
+          } else {
+            nd.res_start = top;
+            nd.res_len = 1;
+            reslist[top++] = i;
+          }
+        }
+        nodes[i] = nd;
+      }
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (L.ri[303] != 0) status = DH_ERR_NOMEM;
+  }
+
+  // ---- emit the ellipsoid list ----
+  int M = 0;
+  if (status == DH_OK) {
+    M = nodes[0].res_len;
+    if (M > a.max_ells) status = DH_ERR_NOMEM;
+  }
+  if (status == DH_OK) {
+    const int rs0 = nodes[0].res_start;
+    double* o_ctr = a.ctrs + (size_t)run * a.max_ells * D;
+    double* o_cov = a.covs + (size_t)run * a.max_ells * DD;
+    double* o_am = a.ams + (size_t)run * a.max_ells * DD;
+    double* o_ax = a.axes + (size_t)run * a.max_ells * DD;
+    double* o_al = a.axlens + (size_t)run * a.max_ells * D;
+    double* o_lv = a.logvols + (size_t)run * a.max_ells;
+    for (int m = 0; m < M; ++m) {
+      const int ni = reslist[rs0 + m];
+      const double* es = estore + (size_t)ni * NS;
+      for (int e = t; e < D; e += kThreads) {
+        o_ctr[m * D + e] = es[e];
+        o_al[m * D + e] = es[D + 3 * DD + e];
+      }
+      for (int e = t; e < DD; e += kThreads) {
+        o_cov[(size_t)m * DD + e] = es[D + e];
+        o_am[(size_t)m * DD + e] = es[D + DD + e];
+        o_ax[(size_t)m * DD + e] = es[D + 2 * DD + e];
+      }
+      if (t == 0) o_lv[m] = nodes[ni].logvol;
+      if (a.leaf_of_point) {
+        int* lop = a.leaf_of_point + (size_t)run * n;
+        const int s = nodes[ni].start, c = nodes[ni].count;
+        for (int p = t; p < c; p += kThreads) lop[perm[s + p]] = m;
+      }
+    }
+    __threadfence_block();
+    __syncthreads();
+    // ---- coverage check: every point inside some ellipsoid, strict < 1
+    //      (MultiEllipsoid.update, bounding.py:683-685).  mode 1 has no check.
+    if (a.mode == 0) {
+      int uncovered = 0;
+      for (int base = 0; base < n; base += L.TP) {
+        const int cnt = min(L.TP, n - base);
+        stage_tile(L, pts, perm, base, cnt, D, 0);
+        bool inside = false;
+        for (int m = 0; m < M; ++m) {
+          // stage this ellipsoid's centre and precision matrix
+          for (int e = t; e < DD; e += kThreads) L.AM[(e / D) * L.LD + e % D] = o_am[(size_t)m * DD + e];
+          if (t < D) L.mean[t] = o_ctr[m * D + t];
+          __syncthreads();
+          if (t < cnt && !inside) {
+            const double* x = L.tile + t * L.LD;
+            double q = 0.0;
+            for (int i = 0; i < D; ++i) {
+              double r = 0.0;
+              const double* row = L.AM + i * L.LD;
+              for (int jj = 0; jj < D; ++jj) r = fma(row[jj], x[jj] - L.mean[jj], r);
+              q = fma(x[i] - L.mean[i], r, q);
+            }
+            if (q < 1.0) inside = true;
+          }
+          __syncthreads();
+        }
+        if (t < cnt && !inside) uncovered = 1;
+      }
+      const int tot = block_reduce_sum_int(uncovered, L.ri);
+      if (tot > 0) status = DH_ERR_REGION;
+    }
+  }
+  if (t == 0) {
+    a.nells[run] = (status == DH_OK) ? M : 0;
+    a.status[run] = status;
+    if (a.nnodes_out) a.nnodes_out[run] = nnodes;
+  }
+}
+
+size_t rebuild_lds_bytes(int D) {
+  const int LD = D | 1;
+  size_t dbl = (size_t)kThreads * LD + 4 * (size_t)D * LD + 7 * (size_t)D + kThreads + 128;
+  return dbl * 8 + (320 + (size_t)D + 8) * 4;
+}
+
+}  // namespace
+
+extern "C" {
+
+// see include/dynhip.h
+int dh_rebuild_batch_dev(dh_ctx* ctx, int runs, const double* pts, int n, int d, int mode, int max_ells,
+                         int32_t* nells, int32_t* status, double* ctrs, double* covs, double* ams,
+                         double* axes, double* axlens, double* logvols, int32_t* leaf_of_point,
+                         int32_t* nnodes) {
+  DH_CHECK_CTX(ctx);
+  if (runs <= 0) return DH_OK;
+  if (!pts || n < 1 || d < 1 || max_ells < 1 || (mode != 0 && mode != 1))
+    return fail(ctx, DH_ERR_ARG, "rebuild: bad arguments (n=%d d=%d mode=%d)", n, d, mode);
+  const size_t lds = rebuild_lds_bytes(d);
+  if (lds > 160 * 1024)
+    return fail(ctx, DH_ERR_ARG, "rebuild: d=%d needs %zu B of LDS (> 160 KiB): wide-D path not built yet",
+                d, lds);
+  RebuildArgs a;
+  a.pts = pts;
+  a.n = n;
+  a.d = d;
+  a.runs = runs;
+  a.mode = mode;
+  // every split creates two children of >= 2d points each: <= n/d nodes + root
+  a.max_nodes = mode == 1 ? 1 : (n / d + 3);
+  a.max_ells = max_ells;
+  a.prefactor = d * log(2.0) + d * lgamma(1.5) - lgamma(d / 2.0 + 1.0);
+  const int LD = d | 1;
+  const size_t NS = (size_t)d + 3 * (size_t)d * d + d + (size_t)d * LD;
+  a.reslist_cap = a.max_nodes * 24 + 64;
+  // scratch: reuse a context-owned buffer (grown on demand)
+  const size_t b_perm = (size_t)runs * n * 4, b_lab = (size_t)runs * n;
+  const size_t b_nodes = (size_t)runs * a.max_nodes * sizeof(Node);
+  const size_t b_es = (size_t)runs * a.max_nodes * NS * 8;
+  const size_t b_res = (size_t)runs * a.reslist_cap * 4;
+  auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  const size_t total = al(b_perm) * 2 + al(b_lab) + al(b_nodes) + al(b_es) + al(b_res);
+  if (total > ctx->rebuild_ws_cap) {
+    if (!hip_ok(ctx, hipStreamSynchronize(ctx->stream), "sync")) return DH_ERR_HIP;
+    if (ctx->rebuild_ws) (void)hipFree(ctx->rebuild_ws);
+    ctx->rebuild_ws = nullptr;
+    ctx->rebuild_ws_cap = 0;
+    if (!hip_ok(ctx, hipMalloc((void**)&ctx->rebuild_ws, total), "hipMalloc(rebuild scratch)"))
+      return DH_ERR_NOMEM;
+    ctx->rebuild_ws_cap = total;
+  }
+  char* w = ctx->rebuild_ws;
+  a.perm = (int*)w;
+  w += al(b_perm);
+  a.perm2 = (int*)w;
+  w += al(b_perm);
+  a.lab = (unsigned char*)w;
+  w += al(b_lab);
+  a.nodes = (Node*)w;
+  w += al(b_nodes);
+  a.estore = (double*)w;
+  w += al(b_es);
+  a.reslist = (int*)w;
+  a.nells = nells;
+  a.status = status;
+  a.ctrs = ctrs;
+  a.covs = covs;
+  a.ams = ams;
+  a.axes = axes;
+  a.axlens = axlens;
+  a.logvols = logvols;
+  a.leaf_of_point = leaf_of_point;
+  a.nnodes_out = nnodes;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)rebuild_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(rebuild_kernel, dim3(runs), dim3(kThreads), lds, ctx->stream, a);
+  return hip_ok(ctx, hipGetLastError(), "rebuild launch") ? DH_OK : DH_ERR_HIP;
+}
+
+int dh_rebuild(dh_ctx* ctx, const double* pts, int n, int d, int mode, int max_ells, int32_t* nells,
+               double* ctrs, double* covs, double* ams, double* axes, double* axlens, double* logvols,
+               int32_t* leaf_of_point, int32_t* nnodes) {
+  DH_CHECK_CTX(ctx);
+  if (!pts || !nells || !ctrs || !covs || !ams || !axes || !axlens || !logvols)
+    return fail(ctx, DH_ERR_ARG, "rebuild: null pointer");
+  arena_reset(ctx);
+  const size_t dd = (size_t)d * d;
+  const size_t need = ((size_t)n * d + (size_t)max_ells * (3 * dd + 2 * d + 1)) * 8 + (size_t)n * 4 + 8192;
+  int rc = arena_reserve(ctx, need);
+  if (rc) return rc;
+  const double* d_pts = arena_up(ctx, pts, (size_t)n * d);
+  int32_t* d_nells = (int32_t*)arena_get(ctx, 4);
+  int32_t* d_status = (int32_t*)arena_get(ctx, 4);
+  int32_t* d_nn = (int32_t*)arena_get(ctx, 4);
+  double* d_ctrs = (double*)arena_get(ctx, (size_t)max_ells * d * 8);
+  double* d_covs = (double*)arena_get(ctx, (size_t)max_ells * dd * 8);
+  double* d_ams = (double*)arena_get(ctx, (size_t)max_ells * dd * 8);
+  double* d_axes = (double*)arena_get(ctx, (size_t)max_ells * dd * 8);
+  double* d_axl = (double*)arena_get(ctx, (size_t)max_ells * d * 8);
+  double* d_lv = (double*)arena_get(ctx, (size_t)max_ells * 8);
+  int32_t* d_lop = leaf_of_point ? (int32_t*)arena_get(ctx, (size_t)n * 4) : nullptr;
+  if (!d_pts || !d_nells || !d_status || !d_nn || !d_ctrs || !d_covs || !d_ams || !d_axes || !d_axl ||
+      !d_lv || (leaf_of_point && !d_lop))
+    return DH_ERR_NOMEM;
+  rc = dh_rebuild_batch_dev(ctx, 1, d_pts, n, d, mode, max_ells, d_nells, d_status, d_ctrs, d_covs, d_ams,
+                            d_axes, d_axl, d_lv, d_lop, d_nn);
+  if (rc) return rc;
+  int32_t h_status = 0, h_nells = 0;
+  if (!down(ctx, &h_status, d_status, 1) || !down(ctx, &h_nells, d_nells, 1)) return DH_ERR_HIP;
+  if ((rc = dh_sync(ctx))) return rc;
+  if (h_status != DH_OK) {
+    const char* msg = h_status == DH_ERR_VALUE     ? "Cannot compute a bounding ellipsoid (single point or singular covariance)"
+                      : h_status == DH_ERR_CONTAIN ? "Failed to initialize the ellipsoid to contain all the points"
+                      : h_status == DH_ERR_REGION  ? "Rejecting invalid MultiEllipsoid region"
+                      : h_status == DH_ERR_NOMEM   ? "rebuild: more ellipsoids/nodes than the output buffers hold"
+                                                   : "rebuild failed";
+    return fail(ctx, h_status, "%s", msg);
+  }
+  *nells = h_nells;
+  const size_t m = (size_t)h_nells;
+  if (!down(ctx, ctrs, d_ctrs, m * d) || !down(ctx, covs, d_covs, m * dd) || !down(ctx, ams, d_ams, m * dd) ||
+      !down(ctx, axes, d_axes, m * dd) || !down(ctx, axlens, d_axl, m * d) || !down(ctx, logvols, d_lv, m) ||
+      !down(ctx, leaf_of_point, d_lop, (size_t)n) || !down(ctx, nnodes, d_nn, 1))
+    return DH_ERR_HIP;
+  return dh_sync(ctx);
+}
+
+}  // extern "C"

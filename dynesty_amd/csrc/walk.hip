@@ -10,10 +10,15 @@
 // LDS traffic is the 6 KiB ziggurat table.  HBM traffic is one read of u0 and
 // one write of (u, v, logl) per walker per launch -- the kernel is fp64-VALU
 // bound, not bandwidth bound.
+#include <stdlib.h>
+
 #include "ctx.h"
 #include "rng_pcg64.h"
 
 using namespace dh;
+#ifndef DH_RW_OCC
+#define DH_RW_OCC 2
+#endif
 
 namespace {
 
@@ -47,6 +52,7 @@ struct RwalkArgs {
   const uint64_t* zki;
   const uint64_t* zwi;
   const uint64_t* zfi;
+  int ablate;  // profiling aid (env DH_ABLATE): 1 no normals, 2 no frame mat-vec, 4 no likelihood, 8 no pow
 };
 
 // frames arrive row-major with column i = axis i (bounding.py:225-229); the walk
@@ -62,11 +68,11 @@ __global__ void prep_axes_kernel(const double* __restrict__ axes, int m, int nc,
 }
 
 // generic_random_walk (internal_samplers.py:866-986), one walker per lane.
-// FULL: ndim == ncdim == N (all guards fold away).
-template <int N, bool FULL>
-__global__ void __launch_bounds__(64, 2) rwalk_kernel(RwalkArgs a) {
+// FULL: ndim == ncdim == N (all guards fold away).  KIND: problem.h.
+template <int N, bool FULL, int KIND>
+__global__ void __launch_bounds__(64, DH_RW_OCC) rwalk_kernel(RwalkArgs a) {
   __shared__ ZigLds zig;
-  __shared__ double sdr[N * 64];  // per-lane column scratch: dr, then v staging
+  __shared__ double sx[N * 64];  // per-lane column: dr, then v = prior(u')
   zig_stage(&zig, a.zki, a.zwi, a.zfi);
   const int lane = threadIdx.x;
   const int w = blockIdx.x * 64 + lane;
@@ -74,7 +80,7 @@ __global__ void __launch_bounds__(64, 2) rwalk_kernel(RwalkArgs a) {
   const int wi = live ? w : a.k - 1;  // dead lanes shadow the last walker (no stores)
   const int n = FULL ? N : a.ndim, nc = FULL ? N : a.ncdim;
 
-  double u[N], up[N], v[N];
+  double u[N], up[N], acc[N];
 #pragma unroll
   for (int i = 0; i < N; ++i) u[i] = (FULL || i < n) ? a.u0[(size_t)wi * n + i] : 0.5;
   Pcg64 g;
@@ -91,40 +97,35 @@ __global__ void __launch_bounds__(64, 2) rwalk_kernel(RwalkArgs a) {
     // redrawn first (rstate.random(n - n_cluster)) ...
     if (!FULL) {
 #pragma unroll 1
-      for (int i = nc; i < n; ++i) sdr[i * 64 + lane] = g.next_double();
+      for (int i = nc; i < n; ++i) sx[i * 64 + lane] = g.next_double();
     }
     // ... then randsphere (bounding.py:1288-1297): nc normals, one uniform
     double ss = 0.0;
 #pragma unroll 1
     for (int i = 0; i < nc; ++i) {
-      const double x = std_normal(g, &zig);
-      sdr[i * 64 + lane] = x;
+      const double x = (a.ablate & 1) ? 0.1 * (i + 1) : std_normal(g, &zig);
+      sx[i * 64 + lane] = x;
       ss = fma(x, x, ss);
     }
-    const double fac = a.scale * (pow(g.next_double(), inv_nc) / sqrt(ss));
+    const double ur = g.next_double();
+    const double fac = a.scale * (((a.ablate & 8) ? ur : pow(ur, inv_nc)) / sqrt(ss));
     // du = axes @ dr, frame wave-uniform: waterfall over the distinct frames
 #pragma unroll
-    for (int i = 0; i < N; ++i) up[i] = 0.0;
+    for (int i = 0; i < N; ++i) acc[i] = 0.0;
     bool done = false;
     while (!done) {
       const int cur = __builtin_amdgcn_readfirstlane(my_frame);
       if (cur == my_frame) {
-        cdptr AT = as_const(a.axes_t + (size_t)cur * N * N);
-#pragma unroll 1
-        for (int j = 0; j < nc; ++j) {
-          const double d = sdr[j * 64 + lane];
-#pragma unroll
-          for (int i = 0; i < N; ++i) up[i] = fma(AT[j * N + i], d, up[i]);
-        }
+        if (!(a.ablate & 2)) matvec_sgpr<N>(as_const(a.axes_t + (size_t)cur * N * N), sx, lane, nc, acc);
         done = true;
       }
     }
 #pragma unroll
     for (int i = 0; i < N; ++i) {
       if (FULL || i < nc)
-        up[i] = fma(fac, up[i], u[i]);
+        up[i] = fma(fac, acc[i], u[i]);
       else
-        up[i] = (i < n) ? sdr[i * 64 + lane] : 0.5;
+        up[i] = (i < n) ? sx[i * 64 + lane] : 0.5;
     }
     // periodic wrap / reflection, then unitcheck (utils.py:1036-1050)
     bool inside = true;
@@ -156,8 +157,9 @@ __global__ void __launch_bounds__(64, 2) rwalk_kernel(RwalkArgs a) {
       ++nrej;
       continue;
     }
-    prior_transform<N, FULL>(a.prob, up, v, n, sdr);
-    const double ll = loglike<N, FULL>(a.prob, v, n, sdr);
+    prior_to_lds<N, FULL, KIND>(a.prob, up, n, sx, lane);
+    const double ll = (a.ablate & 4) ? a.loglstar + ur - 0.6
+                                     : loglike_lds<N, FULL, KIND>(a.prob, n, sx, lane, acc);
     if (ll > a.loglstar) {
 #pragma unroll
       for (int i = 0; i < N; ++i) u[i] = up[i];
@@ -169,14 +171,14 @@ __global__ void __launch_bounds__(64, 2) rwalk_kernel(RwalkArgs a) {
   }
   // v of the returned point; logl is re-evaluated when nothing was accepted
   // (internal_samplers.py:970-975)
-  prior_transform<N, FULL>(a.prob, u, v, n, sdr);
-  if (nacc == 0) logl_cur = loglike<N, FULL>(a.prob, v, n, sdr);
+  prior_to_lds<N, FULL, KIND>(a.prob, u, n, sx, lane);
+  if (nacc == 0) logl_cur = loglike_lds<N, FULL, KIND>(a.prob, n, sx, lane, acc);
   if (live) {
 #pragma unroll
     for (int i = 0; i < N; ++i)
       if (FULL || i < n) {
         a.u[(size_t)w * n + i] = u[i];
-        a.v[(size_t)w * n + i] = v[i];
+        a.v[(size_t)w * n + i] = sx[i * 64 + lane];
       }
     a.logl[w] = logl_cur;
     a.nacc[w] = nacc;
@@ -189,20 +191,21 @@ __global__ void __launch_bounds__(64, 2) rwalk_kernel(RwalkArgs a) {
 template <int N>
 __global__ void __launch_bounds__(64)
     eval_kernel(ProblemDev prob, int k, const double* __restrict__ u, double* v, double* logl) {
-  __shared__ double tmp[N * 64];
-  const int w = blockIdx.x * 64 + threadIdx.x;
+  __shared__ double sx[N * 64];
+  const int lane = threadIdx.x;
+  const int w = blockIdx.x * 64 + lane;
   const int wi = w < k ? w : k - 1;
   const int n = prob.ndim;
-  double uu[N], vv[N];
+  double uu[N], acc[N];
 #pragma unroll
   for (int i = 0; i < N; ++i) uu[i] = (i < n) ? u[(size_t)wi * n + i] : 0.5;
-  prior_transform<N, false>(prob, uu, vv, n, tmp);
-  const double ll = loglike<N, false>(prob, vv, n, tmp);
+  prior_to_lds<N, false, KIND_GENERIC>(prob, uu, n, sx, lane);
+  const double ll = loglike_lds<N, false, KIND_GENERIC>(prob, n, sx, lane, acc);
   if (w >= k) return;
   logl[w] = ll;
 #pragma unroll
   for (int i = 0; i < N; ++i)
-    if (i < n) v[(size_t)w * n + i] = vv[i];
+    if (i < n) v[(size_t)w * n + i] = sx[i * 64 + lane];
 }
 
 __global__ void seed_kernel(const uint32_t* __restrict__ entropy, int nwords, uint32_t first, int k,
@@ -227,9 +230,6 @@ __global__ void __launch_bounds__(64)
   g.store(state_out);
 }
 
-// runtime dimension -> padded compile-time dimension
-#define DH_DIM_LIST(X) X(1) X(2) X(3) X(4) X(5) X(6) X(8) X(10) X(12) X(16) X(20) X(25) X(32)
-constexpr int kMaxRegDim = 32;
 
 }  // namespace
 
@@ -270,11 +270,11 @@ int dh_rwalk_batch_dev(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, con
   a.zki = ctx->zki();
   a.zwi = ctx->zwi();
   a.zfi = ctx->zfi();
-  int N = 0;
-#define X(NN) \
-  if (!N && ndim <= NN) N = NN;
-  DH_DIM_LIST(X)
-#undef X
+  {
+    const char* e = getenv("DH_ABLATE");
+    a.ablate = e ? atoi(e) : 0;
+  }
+  const int N = pad_dim(ndim);
   // transposed + padded copy of the frames (stream ordered, context scratch)
   const size_t at_bytes = (size_t)m * N * N * sizeof(double);
   if (at_bytes > ctx->axes_t_cap) {
@@ -291,15 +291,26 @@ int dh_rwalk_batch_dev(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, con
   a.axes_t = ctx->axes_t;
   const dim3 grid((k + 63) / 64), block(64);
   const bool full = (ndim == N && ncdim == N);
-#define X(NN)                                                                      \
-  if (N == NN) {                                                                   \
-    if (full)                                                                      \
-      hipLaunchKernelGGL((rwalk_kernel<NN, true>), grid, block, 0, ctx->stream, a);  \
-    else                                                                           \
-      hipLaunchKernelGGL((rwalk_kernel<NN, false>), grid, block, 0, ctx->stream, a); \
+  const int kind = full ? problem_kind(a.prob.like_id, a.prob.prior_id) : KIND_GENERIC;
+#define L(NN, FF, KK) hipLaunchKernelGGL((rwalk_kernel<NN, FF, KK>), grid, block, 0, ctx->stream, a)
+#define X(NN)                                       \
+  if (N == NN) {                                    \
+    if (!full)                                      \
+      L(NN, false, KIND_GENERIC);                   \
+    else if (kind == KIND_PREC_AFFINE)              \
+      L(NN, true, KIND_PREC_AFFINE);                \
+    else if (kind == KIND_IID_AFFINE)               \
+      L(NN, true, KIND_IID_AFFINE);                 \
+    else if (kind == KIND_EGGBOX_IDENTITY)          \
+      L(NN, true, KIND_EGGBOX_IDENTITY);            \
+    else if (kind == KIND_IID_NORMAL)               \
+      L(NN, true, KIND_IID_NORMAL);                 \
+    else                                            \
+      L(NN, true, KIND_GENERIC);                    \
   }
   DH_DIM_LIST(X)
 #undef X
+#undef L
   return hip_ok(ctx, hipGetLastError(), "rwalk launch") ? DH_OK : DH_ERR_HIP;
 }
 

@@ -116,6 +116,32 @@ int dh_contains(dh_ctx* ctx, const double* x, int k, int d, const double* ctrs,
                 const double* ams, int m, int mode, int32_t* count,
                 uint64_t* mask, double* quad);
 
+/* ---- rebuild -------------------------------------------------------------
+ * mode 0: MultiEllipsoid.update(points) without bootstrap (bounding.py:632-686)
+ *         = bounding_ellipsoid (:1387-1461) + _bounding_ellipsoids (:1464-1563,
+ *         incl. scipy kmeans2 k=2 iter=10) + improve_covar_mat (:1311-1384)
+ *         + the all-points-covered check (:683-685).
+ * mode 1: Ellipsoid.update(points) without bootstrap (bounding.py:345-375).
+ * Outputs for the nells ellipsoids, in the reference's list order (left subtree
+ * first): ctrs nells*d, covs/ams/axes nells*d*d (axes: column i = axis i, sorted
+ * by ascending eigenvalue, sign fixed so the largest component is positive),
+ * axlens nells*d, logvols nells; leaf_of_point[n] = index of the ellipsoid whose
+ * cluster owns each point (may be NULL); nnodes = visited tree nodes (may be
+ * NULL).  Errors: DH_ERR_VALUE / DH_ERR_CONTAIN / DH_ERR_REGION as the
+ * reference raises; DH_ERR_NOMEM if more than max_ells ellipsoids result. */
+int dh_rebuild(dh_ctx* ctx, const double* pts, int n, int d, int mode, int max_ells,
+               int32_t* nells, double* ctrs, double* covs, double* ams, double* axes,
+               double* axlens, double* logvols, int32_t* leaf_of_point,
+               int32_t* nnodes);
+/* `runs` independent live sets (pts: runs*n*d) in one launch, one workgroup per
+ * run; outputs strided by max_ells per run; status[run] holds the per-run
+ * DH_ERR code (the call itself only fails on launch errors). */
+int dh_rebuild_batch_dev(dh_ctx* ctx, int runs, const double* pts, int n, int d,
+                         int mode, int max_ells, int32_t* nells, int32_t* status,
+                         double* ctrs, double* covs, double* ams, double* axes,
+                         double* axlens, double* logvols, int32_t* leaf_of_point,
+                         int32_t* nnodes);
+
 /* ---- proposals ----------------------------------------------------------
  * RWalkSampler.sample over a batch of k walkers = generic_random_walk +
  * propose_ball_point + randsphere (internal_samplers.py:866-1035,

