@@ -70,6 +70,19 @@ SIGNATURES = {
     "dh_rwalk_batch_dev": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _dbl,
                                 _dbl, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                 _vp]),
+    "dh_slice_batch": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _dbl, _dbl,
+                            _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                            _vp]),
+    "dh_slice_batch_dev": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _dbl,
+                                _dbl, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp,
+                                _vp, _vp, _vp]),
+    "dh_unif_batch": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _dbl,
+                           _vp, _vp, C.c_int64, _vp, _vp, _vp, _vp, _vp]),
+    "dh_unif_batch_dev": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp,
+                               _dbl, _vp, _vp, C.c_int64, _vp, _vp, _vp, _vp,
+                               _vp, _vp]),
+    "dh_bound_draw": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp,
+                           _vp, _vp, _vp]),
 }
 
 
@@ -326,6 +339,98 @@ class Context:
             _ptr(nacc), _ptr(nrej), _ptr(rng_out)))
         return dict(u=u, v=v, logl=logl, accept=nacc, reject=nrej,
                     rng_out=rng_out)
+
+
+    def slice_batch(self, prob, u0, axes, scale, loglstar, slices, rng_states,
+                    principal=False, doubling=False, axes_idx=None):
+        """Batched RSliceSampler.sample / SliceSampler.sample (dh_slice_batch)."""
+        ndim = prob.ndim
+        u0 = _f64(u0).reshape(-1, ndim)
+        k = u0.shape[0]
+        axes = _f64(axes).reshape(-1, ndim, ndim)
+        idx = None if axes_idx is None else np.ascontiguousarray(
+            axes_idx, dtype=np.int32)
+        rng = np.ascontiguousarray(rng_states, dtype=np.uint64).reshape(k, 4)
+        u = np.empty((k, ndim))
+        v = np.empty((k, ndim))
+        logl = np.empty(k)
+        nc = np.empty(k, dtype=np.int32)
+        ne = np.empty(k, dtype=np.int32)
+        nt = np.empty(k, dtype=np.int32)
+        fl = np.empty(k, dtype=np.int32)
+        rng_out = np.empty((k, 4), dtype=np.uint64)
+        self._check(self.lib.dh_slice_batch(
+            self.handle, self.problem(prob), k, ndim, 1 if principal else 0,
+            _ptr(u0), _ptr(axes), axes.shape[0], _ptr(idx), float(scale),
+            float(loglstar), int(slices), 1 if doubling else 0, _ptr(rng),
+            _ptr(u), _ptr(v), _ptr(logl), _ptr(nc), _ptr(ne), _ptr(nt),
+            _ptr(fl), _ptr(rng_out)))
+        return dict(u=u, v=v, logl=logl, ncalls=nc, n_expand=ne, n_contract=nt,
+                    expansion_warning_set=(fl & 1).astype(bool),
+                    rng_out=rng_out)
+
+    def unif_batch(self, prob, loglstar, rng_states, ctrs=None, axes=None,
+                   ams=None, logvol_ells=None, ncdim=None, bc=None,
+                   max_tries=0):
+        """Batched UniformBoundSampler.sample (ellipsoid bound given by
+        ctrs/axes[/ams/logvol_ells]) or UnitCubeSampler.sample (ctrs=None)."""
+        ndim = prob.ndim
+        rng = np.ascontiguousarray(rng_states, dtype=np.uint64).reshape(-1, 4)
+        k = rng.shape[0]
+        ncdim = ndim if ncdim is None else int(ncdim)
+        if ctrs is None:
+            m, c, ax, am, cp = 0, None, None, None, None
+        else:
+            c = _f64(ctrs).reshape(-1, ncdim)
+            m = c.shape[0]
+            ax = _f64(axes).reshape(m, ncdim, ncdim)
+            am = cp = None
+            if m > 1:
+                am = _f64(ams).reshape(m, ncdim, ncdim)
+                cp = cumprob_of(logvol_ells)
+        bcarr = None if bc is None else np.ascontiguousarray(bc, dtype=np.int8)
+        u = np.empty((k, ndim))
+        v = np.empty((k, ndim))
+        logl = np.empty(k)
+        nc = np.empty(k, dtype=np.int32)
+        rng_out = np.empty((k, 4), dtype=np.uint64)
+        self._check(self.lib.dh_unif_batch(
+            self.handle, self.problem(prob), k, ndim, ncdim, m, _ptr(c),
+            _ptr(ax), _ptr(am), _ptr(cp), float(loglstar), _ptr(bcarr),
+            _ptr(rng), int(max_tries), _ptr(u), _ptr(v), _ptr(logl), _ptr(nc),
+            _ptr(rng_out)))
+        return dict(u=u, v=v, logl=logl, ncalls=nc, rng_out=rng_out)
+
+    def bound_draw(self, state4, nsamp, ctrs, axes, ams=None, logvol_ells=None,
+                   return_q=False):
+        """Bound.samples from one generator state (dh_bound_draw)."""
+        c = _f64(ctrs)
+        if c.ndim == 1:
+            c = c[None, :]
+        m, d = c.shape
+        ax = _f64(axes).reshape(m, d, d)
+        am = cp = None
+        if m > 1:
+            am = _f64(ams).reshape(m, d, d)
+            cp = cumprob_of(logvol_ells)
+        st = np.ascontiguousarray(state4, dtype=np.uint64)
+        xs = np.empty((nsamp, d))
+        idxs = np.empty(nsamp, dtype=np.int32)
+        qs = np.empty(nsamp, dtype=np.int32)
+        out = np.empty(4, dtype=np.uint64)
+        self._check(self.lib.dh_bound_draw(
+            self.handle, _ptr(st), int(nsamp), d, m, _ptr(c), _ptr(ax),
+            _ptr(am), _ptr(cp), 1 if return_q else 0, _ptr(xs), _ptr(idxs),
+            _ptr(qs), _ptr(out)))
+        return xs, idxs, qs, out
+
+
+def cumprob_of(logvol_ells):
+    """cumsum(exp(logvol_ells - logsumexp(logvol_ells))) exactly as
+    rand_choice sees it (bounding.py:543, 1300-1308)."""
+    from scipy.special import logsumexp
+    lv = np.asarray(logvol_ells, dtype=np.float64)
+    return np.ascontiguousarray(np.cumsum(np.exp(lv - logsumexp(lv))))
 
 
 _default_ctx = {}

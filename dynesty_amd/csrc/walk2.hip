@@ -1,0 +1,893 @@
+// Proposal kernels, part 2: slice samplers (rslice / slice), uniform sampling
+// inside the bound (unif), unit-cube sampling, and the sequential draw used by
+// Bound.sample(s).  Same mapping as walk.hip: one walker per lane, state in
+// registers, wave-uniform matrices through the scalar cache.
+#include <stdlib.h>
+
+#include "ctx.h"
+#include "rng_pcg64.h"
+
+using namespace dh;
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// Slice sampling (internal_samplers.py:745-855 RSliceSampler.sample, :593-709
+// SliceSampler.sample, :1075-1206 generic_slice_step, :1038-1072 doubling
+// acceptance).  The walkers of a wave are at different points of Neal's
+// procedure, but every transition needs exactly one evaluation of
+//    F(x) = logl(prior_transform(u + x * dir))   (-inf outside the unit cube)
+// so the step is written as a per-lane state machine around ONE shared F site.
+// ---------------------------------------------------------------------------
+enum : int {
+  PH_LEFT0 = 0,   // evaluate F(left)  (initial)
+  PH_RIGHT0 = 1,  // evaluate F(right) (initial)
+  PH_OUT_L = 2,   // stepping out, left edge
+  PH_OUT_R = 3,   // stepping out, right edge
+  PH_DBL = 4,     // doubling expansion
+  PH_SHRINK = 5,  // propose inside [left, right]
+  PH_ACC = 6,     // doubling acceptance test (Neal 2003, alg. 6)
+  PH_DONE = 7
+};
+
+struct SliceArgs {
+  ProblemDev prob;
+  int k, ndim, slices, m, mode;  // mode 0: rslice, 1: slice (principal axes)
+  int doubling0;                 // kwargs['slice_doubling']
+  double scale, loglstar;
+  const double* u0;
+  const double* axes_t;
+  const int32_t* axes_idx;
+  const uint64_t* rng_in;
+  double* u;
+  double* v;
+  double* logl;
+  int32_t* ncalls;
+  int32_t* nexpand;
+  int32_t* ncontract;
+  int32_t* flags;  // bit0: expansion_warning_set, bit1: x == 0 failure
+  uint64_t* rng_out;
+  const uint64_t* zki;
+  const uint64_t* zwi;
+  const uint64_t* zfi;
+};
+
+template <int N, int KIND>
+__global__ void __launch_bounds__(64, 2) slice_kernel(SliceArgs a) {
+  __shared__ ZigLds zig;
+  __shared__ double sx[N * 64];
+  __shared__ int sperm[N * 64];
+  zig_stage(&zig, a.zki, a.zwi, a.zfi);
+  const int lane = threadIdx.x;
+  const int w = blockIdx.x * 64 + lane;
+  const bool live = w < a.k;
+  const int wi = live ? w : a.k - 1;
+  constexpr int n = N;  // slice samplers require ncdim == ndim (dynesty.py:507-509)
+
+  double u[N], dir[N], acc[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) u[i] = a.u0[(size_t)wi * n + i];
+  Pcg64 g;
+  g.load(a.rng_in + (size_t)wi * 4);
+  const int my_frame = a.axes_idx ? a.axes_idx[wi] : 0;
+
+  bool doubling = a.doubling0 != 0;
+  bool warn_set = false, failed = false;
+  int nc = 0, n_expand = 0, n_contract = 0;
+  double logl_cur = 0.0;
+  const double maxlen = sqrt((double)n) / 2.0;
+  const int nsub = a.mode == 0 ? 1 : n;  // slice: one step per principal axis
+
+#pragma unroll 1
+  for (int s = 0; s < a.slices; ++s) {
+    if (a.mode == 1) {
+      // rstate.shuffle(arange(n)): Fisher-Yates from the top (numpy _shuffle_raw)
+#pragma unroll 1
+      for (int i = 0; i < n; ++i) sperm[i * 64 + lane] = i;
+#pragma unroll 1
+      for (int i = n - 1; i >= 1; --i) {
+        const int j = (int)g.interval((uint64_t)i);
+        const int tmp = sperm[i * 64 + lane];
+        sperm[i * 64 + lane] = sperm[j * 64 + lane];
+        sperm[j * 64 + lane] = tmp;
+      }
+    }
+#pragma unroll 1
+    for (int sub = 0; sub < nsub; ++sub) {
+      // ---- direction ----
+      if (a.mode == 0) {
+        double ss = 0.0;
+#pragma unroll 1
+        for (int i = 0; i < n; ++i) {
+          const double x = std_normal(g, &zig);
+          sx[i * 64 + lane] = x;
+          ss = fma(x, x, ss);
+        }
+        const double inv = 1.0 / sqrt(ss);  // drhat /= norm(drhat)
+#pragma unroll 1
+        for (int i = 0; i < n; ++i) sx[i * 64 + lane] = sx[i * 64 + lane] * inv;
+#pragma unroll
+        for (int i = 0; i < N; ++i) acc[i] = 0.0;
+        bool done = false;
+        while (!done) {
+          const int cur = __builtin_amdgcn_readfirstlane(my_frame);
+          if (cur == my_frame) {
+            matvec_sgpr<N>(as_const(a.axes_t + (size_t)cur * N * N), sx, lane, n, acc);
+            done = true;
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < N; ++i) dir[i] = acc[i] * a.scale;  // np.dot(axes, drhat) * scale
+      } else {
+        // axis = (scale * axes.T)[idx] = scale * axes[:, idx]
+        const int idx = sperm[sub * 64 + lane];
+        const double* col = a.axes_t + (size_t)my_frame * N * N + (size_t)idx * N;
+#pragma unroll
+        for (int i = 0; i < N; ++i) dir[i] = a.scale * col[i];
+      }
+      // ---- generic_slice_step ----
+      const double rand0 = g.next_double();
+      double dl = 0.0;
+#pragma unroll
+      for (int i = 0; i < N; ++i) dl = fma(dir[i], dir[i], dl);
+      dl = sqrt(dl);
+      const double dirnorm = dl > maxlen ? dl / maxlen : 1.0;
+#pragma unroll
+      for (int i = 0; i < N; ++i) dir[i] = dir[i] / dirnorm;
+
+      double left = -rand0, right = 1.0 - rand0;
+      double f_l = 0.0, f_r = 0.0;
+      double Lw = 0.0, Rw = 0.0, fLw = 0.0, fRw = 0.0;  // doubling window
+      double lhat = 0.0, rhat = 0.0, f_lhat = 0.0, f_rhat = 0.0, x1 = 0.0, logl_x1 = 0.0;
+      bool Dflag = false, acc_right = false;
+      int Kdbl = 1, nexp_step = 0;
+      int phase = failed ? PH_DONE : PH_LEFT0;
+      double xq = left;  // abscissa being evaluated
+
+      while (__any(phase != PH_DONE)) {
+        const bool act = phase != PH_DONE;
+        // F(xq): u_new = u + xq * dir ; unit-cube check ; prior ; likelihood
+        double lo = 2.0, hi = -1.0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+          acc[i] = fma(xq, dir[i], u[i]);
+          lo = fmin(lo, acc[i]);
+          hi = fmax(hi, acc[i]);
+        }
+        const bool inside = (lo > 0.0) && (hi < 1.0);
+        double f = -INFINITY;
+        if (__any(act && inside)) {
+          prior_to_lds<N, true, KIND>(a.prob, acc, n, sx, lane);
+          const double ll = loglike_lds<N, true, KIND>(a.prob, n, sx, lane, acc);
+          if (inside) f = ll;
+        }
+        if (act) {
+          ++nc;
+          switch (phase) {
+            case PH_LEFT0:
+              f_l = f;
+              phase = PH_RIGHT0;
+              xq = right;
+              break;
+            case PH_RIGHT0:
+              f_r = f;
+              if (!doubling) {
+                if (f_l > a.loglstar) {
+                  phase = PH_OUT_L;
+                  left -= 1.0;
+                  xq = left;
+                } else if (f_r > a.loglstar) {
+                  phase = PH_OUT_R;
+                  right += 1.0;
+                  xq = right;
+                } else {
+                  phase = PH_SHRINK;
+                }
+              } else {
+                phase = PH_DBL;
+              }
+              break;
+            case PH_OUT_L:
+              f_l = f;
+              ++nexp_step;
+              if (f_l > a.loglstar) {
+                left -= 1.0;
+                xq = left;
+              } else if (f_r > a.loglstar) {
+                phase = PH_OUT_R;
+                right += 1.0;
+                xq = right;
+              } else {
+                phase = PH_SHRINK;
+              }
+              break;
+            case PH_OUT_R:
+              f_r = f;
+              ++nexp_step;
+              if (f_r > a.loglstar) {
+                right += 1.0;
+                xq = right;
+              } else {
+                phase = PH_SHRINK;
+              }
+              break;
+            case PH_DBL:
+              if (acc_right)
+                f_r = f;
+              else
+                f_l = f;
+              nexp_step += Kdbl;
+              Kdbl *= 2;
+              break;
+            case PH_SHRINK: {
+              ++n_contract;
+              bool ok = f > a.loglstar;
+              if (ok && doubling) {
+                // start the acceptance test for x1 = xq
+                x1 = xq;
+                logl_x1 = f;
+                lhat = Lw;
+                rhat = Rw;
+                f_lhat = fLw;
+                f_rhat = fRw;
+                Dflag = false;
+                phase = PH_ACC;
+                ok = false;
+              }
+              if (ok) {
+                logl_cur = f;
+#pragma unroll
+                for (int i = 0; i < N; ++i) u[i] = fma(xq, dir[i], u[i]);
+                phase = PH_DONE;
+              } else if (phase == PH_SHRINK) {
+                if (xq < 0.0)
+                  left = xq;
+                else if (xq > 0.0)
+                  right = xq;
+                else {
+                  failed = true;
+                  phase = PH_DONE;
+                }
+              }
+              break;
+            }
+            case PH_ACC:
+              if (acc_right)
+                f_rhat = f;
+              else
+                f_lhat = f;
+              if (Dflag && a.loglstar >= f_lhat && a.loglstar >= f_rhat) {
+                // rejected: shrink towards the origin as for any failed proposal
+                phase = PH_SHRINK;
+                if (x1 < 0.0)
+                  left = x1;
+                else if (x1 > 0.0)
+                  right = x1;
+                else {
+                  failed = true;
+                  phase = PH_DONE;
+                }
+              }
+              break;
+            default:
+              break;
+          }
+          // ---- phases that decide their next abscissa after the switch ----
+          if (phase == PH_DBL) {
+            if (f_l > a.loglstar || f_r > a.loglstar) {
+              const double V = g.next_double();
+              if (V < 0.5) {
+                left -= (right - left);
+                xq = left;
+                acc_right = false;
+              } else {
+                right += (right - left);
+                xq = right;
+                acc_right = true;
+              }
+            } else {
+              Lw = left;
+              Rw = right;
+              fLw = f_l;
+              fRw = f_r;
+              phase = PH_SHRINK;
+            }
+          }
+          if (phase == PH_ACC) {
+            if (rhat - lhat > 1.1) {
+              const double M = (lhat + rhat) / 2.0;
+              if ((0.0 < M && M <= x1) || (x1 < M && M <= 0.0)) Dflag = true;
+              if (x1 < M) {
+                rhat = M;
+                xq = rhat;
+                acc_right = true;
+              } else {
+                lhat = M;
+                xq = lhat;
+                acc_right = false;
+              }
+            } else {
+              // accepted
+              logl_cur = logl_x1;
+#pragma unroll
+              for (int i = 0; i < N; ++i) u[i] = fma(x1, dir[i], u[i]);
+              phase = PH_DONE;
+            }
+          }
+          if (phase == PH_SHRINK) {
+            const double width = right - left;
+            xq = left + g.next_double() * width;
+          }
+        }
+      }
+      n_expand += nexp_step;
+      if (!doubling && nexp_step > 1000) {  // n_expand_threshold (:1096, 1142-1145)
+        doubling = true;
+        warn_set = true;
+      }
+    }
+  }
+  prior_to_lds<N, true, KIND>(a.prob, u, n, sx, lane);
+  if (live) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      a.u[(size_t)w * n + i] = u[i];
+      a.v[(size_t)w * n + i] = sx[i * 64 + lane];
+    }
+    a.logl[w] = logl_cur;
+    a.ncalls[w] = nc;
+    a.nexpand[w] = n_expand;
+    a.ncontract[w] = n_contract;
+    a.flags[w] = (warn_set ? 1 : 0) | (failed ? 2 : 0);
+    if (a.rng_out) g.store(a.rng_out + (size_t)w * 4);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// UniformBoundSampler.sample (internal_samplers.py:243-340) with the bound's
+// sample() inlined: Ellipsoid.sample (bounding.py:307-319) for m == 1,
+// MultiEllipsoid.sample (bounding.py:525-590) otherwise; UnitCubeSampler
+// (internal_samplers.py:364-441) for m == 0.
+// ---------------------------------------------------------------------------
+struct UnifArgs {
+  ProblemDev prob;
+  int k, ndim, ncdim, m;
+  double loglstar;
+  const double* ctrs;      // m x ncdim
+  const double* axes_t;    // m x N x N (padded, transposed)
+  const double* ams_p;     // m x N x N (padded precision matrices)
+  const double* cumprob;   // m   cumsum(exp(logvol_ells - logvol))
+  const int8_t* bc;        // ndim or null (nonbounded mask semantics)
+  const uint64_t* rng_in;
+  int64_t max_tries;     // guard against a bound that cannot reach loglstar
+  double* u;
+  double* v;
+  double* logl;
+  int32_t* ncalls;
+  int32_t* flags;  // bit0: q == 0 failure (RuntimeError), bit1: max_tries hit
+  uint64_t* rng_out;
+  const uint64_t* zki;
+  const uint64_t* zwi;
+  const uint64_t* zfi;
+};
+
+template <int N, bool FULL, int KIND>
+__global__ void __launch_bounds__(64, 2) unif_kernel(UnifArgs a) {
+  __shared__ ZigLds zig;
+  __shared__ double sx[N * 64];
+  zig_stage(&zig, a.zki, a.zwi, a.zfi);
+  const int lane = threadIdx.x;
+  const int w = blockIdx.x * 64 + lane;
+  const bool live = w < a.k;
+  const int wi = live ? w : a.k - 1;
+  const int n = FULL ? N : a.ndim, nc = FULL ? N : a.ncdim;
+  Pcg64 g;
+  g.load(a.rng_in + (size_t)wi * 4);
+  double x[N], acc[N];
+  int ncall = 0, flags = 0;
+  double logl_cur = 0.0;
+  bool done = false;
+  int64_t tries = 0;
+  const double inv_nc = 1.0 / (double)nc;
+  while (__any(!done)) {
+    bool cand = false;  // x holds a candidate inside the cube
+    if (!done) {
+      ++tries;
+      if (a.m == 0) {
+        // unit cube: rstate.uniform(size=ndim)
+#pragma unroll 1
+        for (int i = 0; i < n; ++i) sx[i * 64 + lane] = g.next_double();
+#pragma unroll
+        for (int i = 0; i < N; ++i) x[i] = (FULL || i < n) ? sx[i * 64 + lane] : 0.5;
+        cand = true;
+      } else {
+        int idx = 0;
+        if (a.m > 1) {
+          // rand_choice (bounding.py:1300-1308): searchsorted(cumsum(pb), U)
+          const double xr = g.next_double();
+          while (idx < a.m - 1 && a.cumprob[idx] < xr) ++idx;
+        }
+        // randsphere: nc normals then one uniform
+        double ss = 0.0;
+#pragma unroll 1
+        for (int i = 0; i < nc; ++i) {
+          const double z = std_normal(g, &zig);
+          sx[i * 64 + lane] = z;
+          ss = fma(z, z, ss);
+        }
+        const double fac = pow(g.next_double(), inv_nc) / sqrt(ss);
+#pragma unroll
+        for (int i = 0; i < N; ++i) acc[i] = 0.0;
+        bool mv = false;
+        while (!mv) {
+          const int cur = __builtin_amdgcn_readfirstlane(idx);
+          if (cur == idx) {
+            matvec_sgpr<N>(as_const(a.axes_t + (size_t)cur * N * N), sx, lane, nc, acc);
+            mv = true;
+          }
+        }
+        const double* c = a.ctrs + (size_t)idx * nc;
+#pragma unroll
+        for (int i = 0; i < N; ++i) x[i] = (FULL || i < nc) ? fma(fac, acc[i], c[i]) : 0.5;
+        bool accept = true;
+        if (a.m > 1) {
+          // q = number of ellipsoids containing x (strict), 1/q acceptance
+          int q = 0, qloose = 0;
+          for (int e = 0; e < a.m; ++e) {
+            cdptr ce = as_const(a.ctrs + (size_t)e * nc);
+            cdptr A = as_const(a.ams_p + (size_t)e * N * N);
+            double quad = 0.0;
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+              if (FULL || i < nc) {
+                double r = 0.0;
+#pragma unroll
+                for (int j = 0; j < N; ++j)
+                  if (FULL || j < nc) r = fma(A[i * N + j], x[j] - ce[j], r);
+                quad = fma(x[i] - ce[i], r, quad);
+              }
+            }
+            q += quad < 1.0 ? 1 : 0;
+            qloose += quad <= 1.0 + 1e-3 ? 1 : 0;
+          }
+          if (q == 0) {
+            q = qloose;
+            if (q == 0) {
+              flags |= 1;
+              done = true;
+              accept = false;
+            }
+          }
+          if (accept && q > 1) accept = g.next_double() < (1.0 / (double)q);
+        }
+        if (accept) {
+          // unitcheck(u, nonbounded[:n_cluster])
+          bool inside = true;
+#pragma unroll
+          for (int i = 0; i < N; ++i) {
+            if (FULL || i < nc) {
+              const int b = a.bc ? a.bc[i] : 0;
+              if (b == DH_BC_HARD)
+                inside = inside && (x[i] > 0.0) && (x[i] < 1.0);
+              else
+                inside = inside && (x[i] > -0.5) && (x[i] < 1.5);
+            }
+          }
+          if (inside) {
+            if (!FULL) {
+              // non-cluster dims: rstate.uniform(size=ndim - n_cluster)
+#pragma unroll 1
+              for (int i = nc; i < n; ++i) sx[i * 64 + lane] = g.next_double();
+#pragma unroll
+              for (int i = 0; i < N; ++i)
+                if (i >= nc && i < n) x[i] = sx[i * 64 + lane];
+            }
+            cand = true;
+          }
+        }
+      }
+    }
+    if (__any(cand)) {
+      prior_to_lds<N, FULL, KIND>(a.prob, x, n, sx, lane);
+      const double ll = loglike_lds<N, FULL, KIND>(a.prob, n, sx, lane, acc);
+      if (cand) {
+        ++ncall;
+        if (ll > a.loglstar) {
+          logl_cur = ll;
+          done = true;
+          if (live) {
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+              if (FULL || i < n) {
+                a.u[(size_t)w * n + i] = x[i];
+                a.v[(size_t)w * n + i] = sx[i * 64 + lane];
+              }
+          }
+        }
+      }
+    }
+    if (!done && tries >= a.max_tries) {
+      flags |= 2;
+      done = true;
+    }
+  }
+  if (live) {
+    a.logl[w] = logl_cur;
+    a.ncalls[w] = ncall;
+    a.flags[w] = flags;
+    if (a.rng_out) g.store(a.rng_out + (size_t)w * 4);
+  }
+}
+
+// pad + transpose m matrices (row-major nc x nc) to m x N x N; transpose=0 keeps
+// the orientation (precision matrices), 1 transposes (frames)
+__global__ void pad_mats_kernel(const double* __restrict__ in, int m, int nc, int N, int transpose,
+                                double* __restrict__ out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int tot = m * N * N;
+  if (t >= tot) return;
+  const int f = t / (N * N), r = t % (N * N), a = r / N, b = r % N;
+  const int i = transpose ? b : a, j = transpose ? a : b;
+  out[t] = (a < nc && b < nc) ? in[(size_t)f * nc * nc + i * nc + j] : 0.0;
+}
+
+// ---------------------------------------------------------------------------
+// Bound.sample / samples from ONE generator (Ellipsoid.sample bounding.py:307-
+// 334, MultiEllipsoid.sample :525-606): sequential by construction, run by a
+// single lane; runtime dimension, operands in global memory.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(64)
+    bound_draw_kernel(const uint64_t* state_in, int nsamp, int d, int m, const double* ctrs,
+                      const double* axes, const double* ams, const double* cumprob, int return_q,
+                      double* xs, int32_t* idxs, int32_t* qs, int32_t* status, uint64_t* state_out,
+                      double* work, const uint64_t* zki, const uint64_t* zwi, const uint64_t* zfi) {
+  __shared__ ZigLds zig;
+  zig_stage(&zig, zki, zwi, zfi);
+  if (threadIdx.x != 0) return;
+  Pcg64 g;
+  g.load(state_in);
+  double* z = work;      // d
+  double* x = work + d;  // d
+  int st = 0;
+  for (int s = 0; s < nsamp && st == 0; ++s) {
+    for (;;) {
+      int idx = 0;
+      if (m > 1) {
+        const double xr = g.next_double();
+        while (idx < m - 1 && cumprob[idx] < xr) ++idx;
+      }
+      double ss = 0.0;
+      for (int i = 0; i < d; ++i) {
+        z[i] = std_normal(g, &zig);
+        ss = fma(z[i], z[i], ss);
+      }
+      const double fac = pow(g.next_double(), 1.0 / (double)d) / sqrt(ss);
+      const double* A = axes + (size_t)idx * d * d;
+      for (int i = 0; i < d; ++i) {
+        double r = 0.0;
+        for (int j = 0; j < d; ++j) r = fma(A[i * d + j], z[j], r);
+        x[i] = fma(fac, r, ctrs[(size_t)idx * d + i]);
+      }
+      int q = 1;
+      if (m > 1) {
+        q = 0;
+        int qloose = 0;
+        for (int e = 0; e < m; ++e) {
+          const double* P = ams + (size_t)e * d * d;
+          const double* c = ctrs + (size_t)e * d;
+          double quad = 0.0;
+          for (int i = 0; i < d; ++i) {
+            double r = 0.0;
+            for (int j = 0; j < d; ++j) r = fma(P[i * d + j], x[j] - c[j], r);
+            quad = fma(x[i] - c[i], r, quad);
+          }
+          q += quad < 1.0 ? 1 : 0;
+          qloose += quad <= 1.0 + 1e-3 ? 1 : 0;
+        }
+        if (q == 0) {
+          q = qloose;
+          if (q == 0) {
+            st = DH_ERR_QZERO;
+            break;
+          }
+        }
+      }
+      bool take = true;
+      if (m > 1 && !return_q) take = (q == 1) || (g.next_double() < (1.0 / (double)q));
+      if (take) {
+        for (int i = 0; i < d; ++i) xs[(size_t)s * d + i] = x[i];
+        idxs[s] = idx;
+        qs[s] = q;
+        break;
+      }
+    }
+  }
+  *status = st;
+  g.store(state_out);
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+namespace {
+
+int ensure_axes_t(dh_ctx* ctx, size_t bytes) {
+  if (bytes <= ctx->axes_t_cap) return DH_OK;
+  if (!hip_ok(ctx, hipStreamSynchronize(ctx->stream), "sync")) return DH_ERR_HIP;
+  if (ctx->axes_t) (void)hipFree(ctx->axes_t);
+  ctx->axes_t = nullptr;
+  ctx->axes_t_cap = 0;
+  if (!hip_ok(ctx, hipMalloc((void**)&ctx->axes_t, bytes * 2), "hipMalloc(axes_t)")) return DH_ERR_NOMEM;
+  ctx->axes_t_cap = bytes * 2;
+  return DH_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dh_slice_batch_dev(dh_ctx* ctx, int problem, int k, int ndim, int mode, const double* u0,
+                       const double* axes, int m, const int32_t* axes_idx, double scale,
+                       double loglstar, int slices, int doubling, const uint64_t* rng, double* u,
+                       double* v, double* logl, int32_t* ncalls, int32_t* nexpand, int32_t* ncontract,
+                       int32_t* flags, uint64_t* rng_out) {
+  DH_CHECK_CTX(ctx);
+  SliceArgs a;
+  if (!get_problem(ctx, problem, &a.prob)) return DH_ERR_ARG;
+  if (a.prob.ndim != ndim) return fail(ctx, DH_ERR_ARG, "problem ndim %d != %d", a.prob.ndim, ndim);
+  if (k <= 0) return DH_OK;
+  if (m < 1 || slices < 1 || (mode != 0 && mode != 1))
+    return fail(ctx, DH_ERR_ARG, "slice: m=%d slices=%d mode=%d", m, slices, mode);
+  const int N = pad_dim(ndim);
+  if (N != ndim)
+    return fail(ctx, DH_ERR_ARG,
+                "slice: ndim=%d has no register-resident instantiation (supported: 1-6,8,10,12,16,20,25,32)",
+                ndim);
+  int rc = ensure_axes_t(ctx, (size_t)m * N * N * 8);
+  if (rc) return rc;
+  hipLaunchKernelGGL(pad_mats_kernel, dim3((m * N * N + 255) / 256), dim3(256), 0, ctx->stream, axes, m,
+                     ndim, N, 1, ctx->axes_t);
+  a.k = k;
+  a.ndim = ndim;
+  a.slices = slices;
+  a.m = m;
+  a.mode = mode;
+  a.doubling0 = doubling;
+  a.scale = scale;
+  a.loglstar = loglstar;
+  a.u0 = u0;
+  a.axes_t = ctx->axes_t;
+  a.axes_idx = axes_idx;
+  a.rng_in = rng;
+  a.u = u;
+  a.v = v;
+  a.logl = logl;
+  a.ncalls = ncalls;
+  a.nexpand = nexpand;
+  a.ncontract = ncontract;
+  a.flags = flags;
+  a.rng_out = rng_out;
+  a.zki = ctx->zki();
+  a.zwi = ctx->zwi();
+  a.zfi = ctx->zfi();
+  const dim3 grid((k + 63) / 64), block(64);
+  const int kind = problem_kind(a.prob.like_id, a.prob.prior_id);
+#define L(NN, KK) hipLaunchKernelGGL((slice_kernel<NN, KK>), grid, block, 0, ctx->stream, a)
+#define X(NN)                              \
+  if (N == NN) {                           \
+    if (kind == KIND_PREC_AFFINE)          \
+      L(NN, KIND_PREC_AFFINE);             \
+    else if (kind == KIND_IID_AFFINE)      \
+      L(NN, KIND_IID_AFFINE);              \
+    else if (kind == KIND_EGGBOX_IDENTITY) \
+      L(NN, KIND_EGGBOX_IDENTITY);         \
+    else if (kind == KIND_IID_NORMAL)      \
+      L(NN, KIND_IID_NORMAL);              \
+    else                                   \
+      L(NN, KIND_GENERIC);                 \
+  }
+  DH_DIM_LIST(X)
+#undef X
+#undef L
+  return hip_ok(ctx, hipGetLastError(), "slice launch") ? DH_OK : DH_ERR_HIP;
+}
+
+int dh_slice_batch(dh_ctx* ctx, int problem, int k, int ndim, int mode, const double* u0,
+                   const double* axes, int m, const int32_t* axes_idx, double scale, double loglstar,
+                   int slices, int doubling, const uint64_t* rng, double* u, double* v, double* logl,
+                   int32_t* ncalls, int32_t* nexpand, int32_t* ncontract, int32_t* flags,
+                   uint64_t* rng_out) {
+  DH_CHECK_CTX(ctx);
+  if (k <= 0) return DH_OK;
+  if (!u0 || !axes || !rng || !u || !v || !logl || !ncalls || !nexpand || !ncontract || !flags)
+    return fail(ctx, DH_ERR_ARG, "slice: null pointer");
+  arena_reset(ctx);
+  const size_t kd = (size_t)k * ndim;
+  int rc = arena_reserve(ctx, 3 * kd * 8 + (size_t)m * ndim * ndim * 8 + (size_t)k * (8 + 20 + 64) + 8192);
+  if (rc) return rc;
+  const double* d_u0 = arena_up(ctx, u0, kd);
+  const double* d_axes = arena_up(ctx, axes, (size_t)m * ndim * ndim);
+  const int32_t* d_idx = axes_idx ? arena_up(ctx, axes_idx, (size_t)k) : nullptr;
+  const uint64_t* d_rng = arena_up(ctx, rng, (size_t)k * 4);
+  double* d_u = (double*)arena_get(ctx, kd * 8);
+  double* d_v = (double*)arena_get(ctx, kd * 8);
+  double* d_l = (double*)arena_get(ctx, (size_t)k * 8);
+  int32_t* d_nc = (int32_t*)arena_get(ctx, (size_t)k * 4);
+  int32_t* d_ne = (int32_t*)arena_get(ctx, (size_t)k * 4);
+  int32_t* d_nt = (int32_t*)arena_get(ctx, (size_t)k * 4);
+  int32_t* d_fl = (int32_t*)arena_get(ctx, (size_t)k * 4);
+  uint64_t* d_ro = (uint64_t*)arena_get(ctx, (size_t)k * 32);
+  if (!d_u0 || !d_axes || !d_rng || !d_u || !d_v || !d_l || !d_nc || !d_ne || !d_nt || !d_fl || !d_ro ||
+      (axes_idx && !d_idx))
+    return DH_ERR_NOMEM;
+  rc = dh_slice_batch_dev(ctx, problem, k, ndim, mode, d_u0, d_axes, m, d_idx, scale, loglstar, slices,
+                          doubling, d_rng, d_u, d_v, d_l, d_nc, d_ne, d_nt, d_fl, d_ro);
+  if (rc) return rc;
+  if (!down(ctx, u, d_u, kd) || !down(ctx, v, d_v, kd) || !down(ctx, logl, d_l, (size_t)k) ||
+      !down(ctx, ncalls, d_nc, (size_t)k) || !down(ctx, nexpand, d_ne, (size_t)k) ||
+      !down(ctx, ncontract, d_nt, (size_t)k) || !down(ctx, flags, d_fl, (size_t)k) ||
+      !down(ctx, rng_out, d_ro, (size_t)k * 4))
+    return DH_ERR_HIP;
+  if ((rc = dh_sync(ctx))) return rc;
+  for (int i = 0; i < k; ++i)
+    if (flags[i] & 2)
+      return fail(ctx, DH_ERR_SLICE, "Slice sampler has failed to find a valid point (walker %d)", i);
+  return DH_OK;
+}
+
+int dh_unif_batch_dev(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, int m, const double* ctrs,
+                      const double* axes, const double* ams, const double* cumprob, double loglstar,
+                      const int8_t* bc, const uint64_t* rng, int64_t max_tries, double* u, double* v,
+                      double* logl, int32_t* ncalls, int32_t* flags, uint64_t* rng_out) {
+  DH_CHECK_CTX(ctx);
+  UnifArgs a;
+  if (!get_problem(ctx, problem, &a.prob)) return DH_ERR_ARG;
+  if (a.prob.ndim != ndim) return fail(ctx, DH_ERR_ARG, "problem ndim %d != %d", a.prob.ndim, ndim);
+  if (k <= 0) return DH_OK;
+  if (m < 0 || ncdim < 1 || ncdim > ndim) return fail(ctx, DH_ERR_ARG, "unif: m=%d ncdim=%d", m, ncdim);
+  if (ndim > kMaxRegDim)
+    return fail(ctx, DH_ERR_ARG, "unif: ndim=%d > %d needs the wide-D path (not built yet)", ndim,
+                kMaxRegDim);
+  const int N = pad_dim(ndim);
+  const size_t mats = (size_t)(m > 0 ? m : 1) * N * N * 8;
+  int rc = ensure_axes_t(ctx, 2 * mats);
+  if (rc) return rc;
+  double* at = ctx->axes_t;
+  double* ap = ctx->axes_t + (size_t)(m > 0 ? m : 1) * N * N;
+  if (m > 0) {
+    hipLaunchKernelGGL(pad_mats_kernel, dim3((m * N * N + 255) / 256), dim3(256), 0, ctx->stream, axes, m,
+                       ncdim, N, 1, at);
+    if (m > 1)
+      hipLaunchKernelGGL(pad_mats_kernel, dim3((m * N * N + 255) / 256), dim3(256), 0, ctx->stream, ams,
+                         m, ncdim, N, 0, ap);
+  }
+  a.k = k;
+  a.ndim = ndim;
+  a.ncdim = ncdim;
+  a.m = m;
+  a.loglstar = loglstar;
+  a.ctrs = ctrs;
+  a.axes_t = at;
+  a.ams_p = ap;
+  a.cumprob = cumprob;
+  a.bc = bc;
+  a.rng_in = rng;
+  a.max_tries = max_tries > 0 ? max_tries : ((int64_t)1 << 40);
+  a.u = u;
+  a.v = v;
+  a.logl = logl;
+  a.ncalls = ncalls;
+  a.flags = flags;
+  a.rng_out = rng_out;
+  a.zki = ctx->zki();
+  a.zwi = ctx->zwi();
+  a.zfi = ctx->zfi();
+  const dim3 grid((k + 63) / 64), block(64);
+  const bool full = (ndim == N && ncdim == N);
+  const int kind = full ? problem_kind(a.prob.like_id, a.prob.prior_id) : KIND_GENERIC;
+#define L(NN, FF, KK) hipLaunchKernelGGL((unif_kernel<NN, FF, KK>), grid, block, 0, ctx->stream, a)
+#define X(NN)                              \
+  if (N == NN) {                           \
+    if (!full)                             \
+      L(NN, false, KIND_GENERIC);          \
+    else if (kind == KIND_PREC_AFFINE)     \
+      L(NN, true, KIND_PREC_AFFINE);       \
+    else if (kind == KIND_IID_AFFINE)      \
+      L(NN, true, KIND_IID_AFFINE);        \
+    else if (kind == KIND_EGGBOX_IDENTITY) \
+      L(NN, true, KIND_EGGBOX_IDENTITY);   \
+    else if (kind == KIND_IID_NORMAL)      \
+      L(NN, true, KIND_IID_NORMAL);        \
+    else                                   \
+      L(NN, true, KIND_GENERIC);           \
+  }
+  DH_DIM_LIST(X)
+#undef X
+#undef L
+  return hip_ok(ctx, hipGetLastError(), "unif launch") ? DH_OK : DH_ERR_HIP;
+}
+
+int dh_unif_batch(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, int m, const double* ctrs,
+                  const double* axes, const double* ams, const double* cumprob, double loglstar,
+                  const int8_t* bc, const uint64_t* rng, int64_t max_tries, double* u, double* v,
+                  double* logl, int32_t* ncalls, uint64_t* rng_out) {
+  DH_CHECK_CTX(ctx);
+  if (k <= 0) return DH_OK;
+  if (!rng || !u || !v || !logl || !ncalls || (m > 0 && (!ctrs || !axes)) || (m > 1 && (!ams || !cumprob)))
+    return fail(ctx, DH_ERR_ARG, "unif: null pointer");
+  arena_reset(ctx);
+  const size_t kd = (size_t)k * ndim, mm = (size_t)(m > 0 ? m : 1);
+  int rc = arena_reserve(ctx, 2 * kd * 8 + mm * ((size_t)2 * ncdim * ncdim + ncdim + 1) * 8 +
+                                  (size_t)k * (8 + 8 + 64) + (size_t)ndim + 8192);
+  if (rc) return rc;
+  const double* d_c = m > 0 ? arena_up(ctx, ctrs, (size_t)m * ncdim) : nullptr;
+  const double* d_ax = m > 0 ? arena_up(ctx, axes, (size_t)m * ncdim * ncdim) : nullptr;
+  const double* d_am = m > 1 ? arena_up(ctx, ams, (size_t)m * ncdim * ncdim) : nullptr;
+  const double* d_cp = m > 1 ? arena_up(ctx, cumprob, (size_t)m) : nullptr;
+  const int8_t* d_bc = bc ? arena_up(ctx, bc, (size_t)ndim) : nullptr;
+  const uint64_t* d_rng = arena_up(ctx, rng, (size_t)k * 4);
+  double* d_u = (double*)arena_get(ctx, kd * 8);
+  double* d_v = (double*)arena_get(ctx, kd * 8);
+  double* d_l = (double*)arena_get(ctx, (size_t)k * 8);
+  int32_t* d_nc = (int32_t*)arena_get(ctx, (size_t)k * 4);
+  int32_t* d_fl = (int32_t*)arena_get(ctx, (size_t)k * 4);
+  uint64_t* d_ro = (uint64_t*)arena_get(ctx, (size_t)k * 32);
+  if (!d_rng || !d_u || !d_v || !d_l || !d_nc || !d_fl || !d_ro) return DH_ERR_NOMEM;
+  rc = dh_unif_batch_dev(ctx, problem, k, ndim, ncdim, m, d_c, d_ax, d_am, d_cp, loglstar, d_bc, d_rng,
+                         max_tries, d_u, d_v, d_l, d_nc, d_fl, d_ro);
+  if (rc) return rc;
+  std::vector<int32_t> fl((size_t)k);
+  if (!down(ctx, u, d_u, kd) || !down(ctx, v, d_v, kd) || !down(ctx, logl, d_l, (size_t)k) ||
+      !down(ctx, ncalls, d_nc, (size_t)k) || !down(ctx, fl.data(), d_fl, (size_t)k) ||
+      !down(ctx, rng_out, d_ro, (size_t)k * 4))
+    return DH_ERR_HIP;
+  if ((rc = dh_sync(ctx))) return rc;
+  for (int i = 0; i < k; ++i) {
+    if (fl[i] & 1) return fail(ctx, DH_ERR_QZERO, "Ellipsoid check failed q=0 (walker %d)", i);
+    if (fl[i] & 2)
+      return fail(ctx, DH_ERR_ARG, "unif: walker %d exceeded max_tries without reaching loglstar", i);
+  }
+  return DH_OK;
+}
+
+int dh_bound_draw(dh_ctx* ctx, const uint64_t* state4, int nsamp, int d, int m, const double* ctrs,
+                  const double* axes, const double* ams, const double* cumprob, int return_q, double* xs,
+                  int32_t* idxs, int32_t* qs, uint64_t* state4_out) {
+  DH_CHECK_CTX(ctx);
+  if (nsamp <= 0) return DH_OK;
+  if (!state4 || !ctrs || !axes || !xs || !idxs || !qs || !state4_out || m < 1 || d < 1 ||
+      (m > 1 && (!ams || !cumprob)))
+    return fail(ctx, DH_ERR_ARG, "bound_draw: bad arguments");
+  arena_reset(ctx);
+  const size_t dd = (size_t)d * d;
+  int rc = arena_reserve(ctx, ((size_t)m * (2 * dd + d + 1) + (size_t)nsamp * d + 2 * d) * 8 +
+                                  (size_t)nsamp * 8 + 8192);
+  if (rc) return rc;
+  const uint64_t* d_s = arena_up(ctx, state4, 4);
+  const double* d_c = arena_up(ctx, ctrs, (size_t)m * d);
+  const double* d_ax = arena_up(ctx, axes, (size_t)m * dd);
+  const double* d_am = m > 1 ? arena_up(ctx, ams, (size_t)m * dd) : nullptr;
+  const double* d_cp = m > 1 ? arena_up(ctx, cumprob, (size_t)m) : nullptr;
+  double* d_x = (double*)arena_get(ctx, (size_t)nsamp * d * 8);
+  int32_t* d_i = (int32_t*)arena_get(ctx, (size_t)nsamp * 4);
+  int32_t* d_q = (int32_t*)arena_get(ctx, (size_t)nsamp * 4);
+  int32_t* d_st = (int32_t*)arena_get(ctx, 4);
+  uint64_t* d_o = (uint64_t*)arena_get(ctx, 32);
+  double* d_w = (double*)arena_get(ctx, (size_t)2 * d * 8);
+  if (!d_s || !d_c || !d_ax || !d_x || !d_i || !d_q || !d_st || !d_o || !d_w) return DH_ERR_NOMEM;
+  hipLaunchKernelGGL(bound_draw_kernel, dim3(1), dim3(64), 0, ctx->stream, d_s, nsamp, d, m, d_c, d_ax,
+                     d_am, d_cp, return_q, d_x, d_i, d_q, d_st, d_o, d_w, ctx->zki(), ctx->zwi(),
+                     ctx->zfi());
+  if (!hip_ok(ctx, hipGetLastError(), "bound_draw launch")) return DH_ERR_HIP;
+  int32_t st = 0;
+  if (!down(ctx, xs, d_x, (size_t)nsamp * d) || !down(ctx, idxs, d_i, (size_t)nsamp) ||
+      !down(ctx, qs, d_q, (size_t)nsamp) || !down(ctx, &st, d_st, 1) || !down(ctx, state4_out, d_o, 4))
+    return DH_ERR_HIP;
+  if ((rc = dh_sync(ctx))) return rc;
+  if (st == DH_ERR_QZERO) return fail(ctx, DH_ERR_QZERO, "Ellipsoid check failed q=0");
+  return DH_OK;
+}
+
+}  // extern "C"

@@ -166,6 +166,54 @@ int dh_rwalk_batch_dev(dh_ctx* ctx, int problem, int k, int ndim, int ncdim,
                        double* u, double* v, double* logl, int32_t* naccept,
                        int32_t* nreject, uint64_t* rng_out);
 
+/* RSliceSampler.sample (mode 0, internal_samplers.py:745-855) / SliceSampler.sample
+ * (mode 1, :593-709) over k walkers; generic_slice_step + Neal's doubling
+ * (:1038-1206) run as a per-lane state machine.  ncdim == ndim (dynesty.py:507-509).
+ *   doubling   kwargs['slice_doubling'] on entry
+ *   outputs    u,v k*ndim; logl, ncalls, nexpand, ncontract k;
+ *              flags k: bit0 expansion_warning_set, bit1 x == 0 failure
+ * The host-pointer form returns DH_ERR_SLICE if any walker failed. */
+int dh_slice_batch(dh_ctx* ctx, int problem, int k, int ndim, int mode,
+                   const double* u0, const double* axes, int m,
+                   const int32_t* axes_idx, double scale, double loglstar,
+                   int slices, int doubling, const uint64_t* rng, double* u,
+                   double* v, double* logl, int32_t* ncalls, int32_t* nexpand,
+                   int32_t* ncontract, int32_t* flags, uint64_t* rng_out);
+int dh_slice_batch_dev(dh_ctx* ctx, int problem, int k, int ndim, int mode,
+                       const double* u0, const double* axes, int m,
+                       const int32_t* axes_idx, double scale, double loglstar,
+                       int slices, int doubling, const uint64_t* rng, double* u,
+                       double* v, double* logl, int32_t* ncalls, int32_t* nexpand,
+                       int32_t* ncontract, int32_t* flags, uint64_t* rng_out);
+
+/* UniformBoundSampler.sample (internal_samplers.py:243-340) with the bound's
+ * sample() inlined: m == 1 Ellipsoid.sample (bounding.py:307-319), m > 1
+ * MultiEllipsoid.sample incl. the 1/q overlap rejection (bounding.py:525-590),
+ * m == 0 UnitCubeSampler.sample (internal_samplers.py:364-441).
+ *   ctrs m*ncdim, axes/ams m*ncdim*ncdim, cumprob m = cumsum(exp(logvol_ells -
+ *   logvol)) (rand_choice, bounding.py:1300-1308); bc: DH_BC_* per dim or NULL
+ *   max_tries: per-walker guard (<= 0: 2^40); ncalls = likelihood calls. */
+int dh_unif_batch(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, int m,
+                  const double* ctrs, const double* axes, const double* ams,
+                  const double* cumprob, double loglstar, const int8_t* bc,
+                  const uint64_t* rng, int64_t max_tries, double* u, double* v,
+                  double* logl, int32_t* ncalls, uint64_t* rng_out);
+int dh_unif_batch_dev(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, int m,
+                      const double* ctrs, const double* axes, const double* ams,
+                      const double* cumprob, double loglstar, const int8_t* bc,
+                      const uint64_t* rng, int64_t max_tries, double* u, double* v,
+                      double* logl, int32_t* ncalls, int32_t* flags,
+                      uint64_t* rng_out);
+
+/* Bound.sample / samples from ONE generator: Ellipsoid.sample(s)
+ * (bounding.py:307-334) for m == 1, MultiEllipsoid.sample(s)
+ * (bounding.py:525-606) for m > 1 (return_q != 0: no internal 1/q rejection).
+ * xs nsamp*d, idxs/qs nsamp, state4_out = the generator after the draws. */
+int dh_bound_draw(dh_ctx* ctx, const uint64_t* state4, int nsamp, int d, int m,
+                  const double* ctrs, const double* axes, const double* ams,
+                  const double* cumprob, int return_q, double* xs, int32_t* idxs,
+                  int32_t* qs, uint64_t* state4_out);
+
 #ifdef __cplusplus
 }
 #endif

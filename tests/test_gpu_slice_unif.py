@@ -1,0 +1,171 @@
+"""K7 (rslice / slice incl. doubling), K8 (unif, unit cube) and the sequential
+Bound.samples draw vs golden vectors from the real reference (same seeds).
+Tolerances as in test_gpu_rwalk.py; every counter (ncalls, n_expand,
+n_contract) must match exactly."""
+import numpy as np
+import pytest
+
+import inputs
+from oracle import bounding_ref as B
+
+pytestmark = pytest.mark.gpu
+
+ATOL_U = 1e-12
+RTOL_L = 1e-11
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from dynesty_amd import _lib
+    return _lib.Context(0)
+
+
+def states_for(ctx, g, tag):
+    return ctx.seed_children([int(g[f"{tag}/seedbase"])], 0,
+                             int(g[f"{tag}/nwalk"]))
+
+
+def check(out, g, tag, counters=True):
+    np.testing.assert_array_equal(out["ncalls"], g[f"{tag}/ncalls"])
+    if counters:
+        np.testing.assert_array_equal(out["n_expand"], g[f"{tag}/ti_n_expand"])
+        np.testing.assert_array_equal(out["n_contract"],
+                                      g[f"{tag}/ti_n_contract"])
+    np.testing.assert_allclose(out["u"], g[f"{tag}/u"], rtol=0, atol=ATOL_U)
+    scale_v = max(1.0, np.abs(g[f"{tag}/v"]).max())
+    np.testing.assert_allclose(out["v"], g[f"{tag}/v"], rtol=0,
+                               atol=ATOL_U * 20 * scale_v)
+    np.testing.assert_allclose(out["logl"], g[f"{tag}/logl"], rtol=RTOL_L,
+                               atol=1e-11)
+
+
+@pytest.mark.parametrize("pname,slices,cseed", [("C3", 5, 955), ("G5", 4, 954),
+                                                ("N6", 3, 953), ("C2", 3, 953)])
+def test_rslice_golden(ctx, pname, slices, cseed, golden_proposals):
+    g = golden_proposals
+    tag = f"rslice/{pname}"
+    case = inputs.walker_case(pname, 64, cseed)
+    nw = int(g[f"{tag}/nwalk"])
+    out = ctx.slice_batch(case["problem"], case["u0"][:nw], case["axes"],
+                          case["scale"], case["loglstar"], slices,
+                          states_for(ctx, g, tag))
+    check(out, g, tag)
+    assert not out["expansion_warning_set"].any()
+
+
+@pytest.mark.parametrize("tag,slices,scale,dbl", [
+    ("rslice/G5_dbl", 4, None, True), ("rslice/G5_tiny", 2, 0.02, False)])
+def test_rslice_variants_golden(ctx, tag, slices, scale, dbl, golden_proposals):
+    g = golden_proposals
+    case = inputs.walker_case("G5", 64, 961)
+    nw = int(g[f"{tag}/nwalk"])
+    out = ctx.slice_batch(case["problem"], case["u0"][:nw], case["axes"],
+                          scale or case["scale"], case["loglstar"], slices,
+                          states_for(ctx, g, tag), doubling=dbl)
+    check(out, g, tag)
+
+
+@pytest.mark.parametrize("tag,pname,cseed,dbl", [
+    ("slice/G5", "G5", 972, False), ("slice/E3", "E3", 972, False),
+    ("slice/G5_dbl", "G5", 981, True)])
+def test_pslice_golden(ctx, tag, pname, cseed, dbl, golden_proposals):
+    g = golden_proposals
+    case = inputs.walker_case(pname, 64, cseed)
+    nw = int(g[f"{tag}/nwalk"])
+    out = ctx.slice_batch(case["problem"], case["u0"][:nw], case["axes"],
+                          case["scale"], case["loglstar"], 2,
+                          states_for(ctx, g, tag), principal=True,
+                          doubling=dbl)
+    check(out, g, tag)
+
+
+def test_rslice_many_vs_oracle(ctx):
+    """Ragged batch, two frames, advanced generator state returned."""
+    from dynesty_amd import _lib
+    from oracle import proposals_ref as P
+    case = inputs.walker_case("G5", 300, 78)
+    prob = case["problem"]
+    u0 = case["u0"][:150]
+    k = u0.shape[0]
+    axes2 = np.stack([case["axes"], 0.7 * case["axes"][::-1, ::-1].copy()])
+    idx = (np.arange(k) % 2).astype(np.int32)
+    ent = [9, 9, 9]
+    st = ctx.seed_children(ent, 0, k)
+    out = ctx.slice_batch(prob, u0, axes2, case["scale"], case["loglstar"], 3,
+                          st, axes_idx=idx)
+    kids = np.random.SeedSequence(ent).spawn(k)
+    for i in range(k):
+        bg = np.random.PCG64(kids[i])
+        ref = P.rslice(u0[i].copy(), case["loglstar"], axes2[idx[i]],
+                       case["scale"], prob.prior_transform, prob.loglikelihood,
+                       np.random.Generator(bg), 3)
+        assert ref["ncalls"] == out["ncalls"][i]
+        assert ref["n_expand"] == out["n_expand"][i]
+        np.testing.assert_allclose(out["u"][i], ref["u"], rtol=0, atol=ATOL_U)
+        np.testing.assert_array_equal(out["rng_out"][i],
+                                      _lib.pcg_state_words(bg))
+
+
+def test_unif_golden(ctx, golden_proposals):
+    g = golden_proposals
+    # single ellipsoid, C1
+    prob = inputs.problem("C1")
+    e = B.bounding_ellipsoid(inputs.cloud("g3"))
+    tag = "unif/C1_single"
+    st = ctx.seed_children([7000], 0, 16)
+    out = ctx.unif_batch(prob, float(g[f"{tag}/loglstar"]), st, ctrs=e.ctr,
+                         axes=e.axes)
+    check(out, g, tag, counters=False)
+    # overlapping union of ellipsoids, 1/q rejection
+    prob = inputs.problem("G5")
+    pts = inputs.cloud("two5")
+    m = B.multi_update(pts)
+    m = B.scale_multi_to_logvol(m, m.logvol + 5 * np.log(3.0))
+    tag = "unif/G5_multi"
+    st = ctx.seed_children([7100], 0, 16)
+    out = ctx.unif_batch(prob, float(g[f"{tag}/loglstar"]), st, ctrs=m.ctrs,
+                         axes=np.array([el.axes for el in m.ells]), ams=m.ams,
+                         logvol_ells=m.logvol_ells)
+    check(out, g, tag, counters=False)
+    # 3-D bound on a 5-D problem: the last two dims are U(0,1)
+    b3 = B.bounding_ellipsoid(pts[:, :3].copy())
+    tag = "unif/G5_nc3"
+    st = ctx.seed_children([7200], 0, 8)
+    out = ctx.unif_batch(prob, float(g[f"{tag}/loglstar"]), st, ctrs=b3.ctr,
+                         axes=b3.axes, ncdim=3)
+    check(out, g, tag, counters=False)
+    # unit cube
+    prob = inputs.problem("C1")
+    st = ctx.seed_children([7300], 0, 8)
+    out = ctx.unif_batch(prob, -60.0, st)
+    np.testing.assert_array_equal(out["ncalls"], g["unitcube/C1/ncalls"])
+    np.testing.assert_allclose(out["u"], g["unitcube/C1/u"], rtol=0, atol=0)
+    np.testing.assert_allclose(out["logl"], g["unitcube/C1/logl"], rtol=RTOL_L)
+
+
+@pytest.mark.parametrize("name", ["c2", "c3", "two5", "g3"])
+def test_bound_draw_golden(ctx, name, golden_bounding):
+    """MultiEllipsoid.samples / Ellipsoid.samples from one generator; uses the
+    reference's own ellipsoids (axes included) so coordinates are comparable."""
+    from dynesty_amd import _lib
+    g = golden_bounding
+    ctrs, ams = g[f"{name}/mu/ctrs"], g[f"{name}/mu/ams"]
+    axes, lvs = g[f"{name}/mu/axes"], g[f"{name}/mu/logvol_ells"]
+    bg = np.random.PCG64(7)
+    st = _lib.pcg_state_words(bg)
+    xs, idxs, qs, out = ctx.bound_draw(st, 40, ctrs, axes, ams, lvs)
+    np.testing.assert_allclose(xs, g[f"{name}/mu/samples"], rtol=0, atol=1e-13)
+    # the generator must have advanced exactly as numpy's did
+    m = B.stack_ells([B.Ell(ctrs[i], g[f"{name}/mu/covs"][i], ams[i], axes[i],
+                            g[f"{name}/mu/axlens"][i], float(lvs[i]))
+                      for i in range(len(lvs))])
+    rng = np.random.Generator(bg)
+    for _ in range(40):
+        B.multi_sample(m, rng)
+    np.testing.assert_array_equal(out, _lib.pcg_state_words(bg))
+    # single-ellipsoid bound
+    e = B.bounding_ellipsoid(inputs.cloud(name))
+    bg = np.random.PCG64(8)
+    xs, _, _, _ = ctx.bound_draw(_lib.pcg_state_words(bg), 40, e.ctr, e.axes)
+    np.testing.assert_allclose(xs, g[f"{name}/single/samples"], rtol=0,
+                               atol=1e-13)
