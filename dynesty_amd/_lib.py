@@ -65,6 +65,8 @@ SIGNATURES = {
                         _vp, _vp, _vp]),
     "dh_rebuild_batch_dev": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp,
                                   _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dh_ell_from_cov": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "dh_scale_to_logvol": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dh_rwalk_batch": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _dbl, _dbl,
                             _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dh_rwalk_batch_dev": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _dbl,
@@ -311,6 +313,32 @@ class Context:
                     ams=ams[:m].copy(), axes=axes[:m].copy(),
                     axlens=axlens[:m].copy(), logvol_ells=logvols[:m].copy(),
                     labels=lop, nnodes=nnodes.value)
+
+    def ell_from_cov(self, covs):
+        """Ellipsoid.__init__ numerics for a stack of covariances."""
+        covs = _f64(covs)
+        if covs.ndim == 2:
+            covs = covs[None]
+        m, d, _ = covs.shape
+        axes = np.empty((m, d, d))
+        axlens = np.empty((m, d))
+        ams = np.empty((m, d, d))
+        lvs = np.empty(m)
+        self._check(self.lib.dh_ell_from_cov(self.handle, m, d, _ptr(covs),
+                                             _ptr(axes), _ptr(axlens),
+                                             _ptr(ams), _ptr(lvs)))
+        return axes, axlens, ams, lvs
+
+    def scale_to_logvol(self, covs, ams, axes, axlens, logvols, targets):
+        """In-place Ellipsoid.scale_to_logvol for a stack of ellipsoids; the
+        arrays must be C-contiguous float64 (they are updated in place)."""
+        m, d = axlens.shape
+        for a in (covs, ams, axes, axlens, logvols):
+            assert a.flags.c_contiguous and a.dtype == np.float64
+        t = _f64(targets).reshape(m)
+        self._check(self.lib.dh_scale_to_logvol(
+            self.handle, m, d, _ptr(covs), _ptr(ams), _ptr(axes), _ptr(axlens),
+            _ptr(logvols), _ptr(t)))
 
     # -- proposals ----------------------------------------------------------------
     def rwalk_batch(self, prob, u0, axes, scale, loglstar, walks, rng_states,

@@ -1,0 +1,320 @@
+"""Host-side mirrors of dynesty's ``Ellipsoid`` / ``MultiEllipsoid`` bounds
+(reference: /root/reference/py/dynesty/bounding.py:182-731) whose numerics run
+on the GPU through libdynhip.
+
+Same attribute names and method signatures as the reference classes, same
+exception types.  The canonical state is plain NumPy (so instances pickle and
+deep-copy exactly like the reference's: sampler.py:510, utils.py:2321-2355);
+no device handle is ever stored on an instance.
+
+Differences that are visible to a caller (all documented in DESIGN.md):
+  * ``axes`` columns are ordered by ascending axis length with a fixed sign
+    (largest component positive); LAPACK's order is the same, its signs are
+    arbitrary.
+  * the order of the ellipsoids of a ``HipMultiEllipsoid`` may be a permutation
+    of the reference's (the reference's order depends on LAPACK's signs).
+  * ``scale_to_logvol`` reuses the stored principal axes instead of calling
+    ``eigh`` again.
+"""
+import math
+from collections.abc import Iterable
+
+import numpy as np
+from scipy.special import logsumexp
+
+from . import _lib
+from .backend import get_backend
+
+
+def logvol_prefactor(n, p=2.):
+    """ln volume constant of the unit L^p ball (bounding.py:1271-1285)."""
+    p *= 1.
+    return (n * math.log(2.) + n * math.lgamma(1. / p + 1.) -
+            math.lgamma(n / p + 1))
+
+
+def _draw(rstate, nsamp, ctrs, axes, ams=None, logvol_ells=None,
+          return_q=False):
+    """Bound.samples on the device from the caller's numpy Generator; the
+    generator is left exactly where numpy would have left it."""
+    bitgen = rstate.bit_generator
+    st = _lib.pcg_state_words(bitgen)
+    xs, idxs, qs, out = get_backend().bound_draw(st, nsamp, ctrs, axes, ams,
+                                                 logvol_ells, return_q)
+    _lib.set_pcg_state_words(bitgen, out)
+    return xs, idxs, qs
+
+
+class HipBound:
+    """Common part of the interface (bounding.py:76-122)."""
+
+    def __init__(self, ndim):
+        self.logvol = 0
+        self.need_centers = False
+        self.ndim = ndim
+
+
+class HipEllipsoid(HipBound):
+    """(x - ctr)^T am (x - ctr) = 1.  bounding.py:182-417."""
+
+    def __init__(self, ndim, ctr=None, cov=None, am=None, axes=None,
+                 axlens=None, logvol=None):
+        super().__init__(ndim)
+        if ctr is None:
+            # default: bounding.py:203-205; closed form, no eigen-solve needed
+            self.ctr = 0.5 * np.zeros(ndim)
+            self.cov = np.identity(ndim) * ndim / 4
+            a = math.sqrt(ndim / 4)
+            self.axlens = np.full(ndim, a)
+            self.axes = np.identity(ndim) * a
+            self.am = np.identity(ndim) * (4. / ndim)
+            self.logvol = logvol_prefactor(ndim) + 0.5 * ndim * math.log(
+                ndim / 4)
+        elif axlens is not None and logvol is not None:
+            # fully specified (as produced by the rebuild kernel)
+            self.ctr = np.asarray(ctr)
+            self.cov = np.asarray(cov)
+            self.am = np.asarray(am)
+            self.axes = np.asarray(axes)
+            self.axlens = np.asarray(axlens)
+            self.logvol = float(logvol)
+        else:
+            self.ctr = np.asarray(ctr)
+            self.cov = np.asarray(cov)
+            ax, al, pm, lv = get_backend().ell_from_cov(self.cov)
+            self.axlens = al[0]
+            self.logvol = float(lv[0])
+            self.axes = ax[0] if axes is None else axes
+            self.am = pm[0] if am is None else am
+        self.funit = 1
+
+    def scale_to_logvol(self, logvol):
+        """bounding.py:242-276."""
+        cov = np.ascontiguousarray(self.cov, dtype=np.float64)[None].copy()
+        am = np.ascontiguousarray(self.am, dtype=np.float64)[None].copy()
+        axes = np.ascontiguousarray(self.axes, dtype=np.float64)[None].copy()
+        axlens = np.ascontiguousarray(self.axlens, dtype=np.float64)[None].copy()
+        lv = np.array([self.logvol], dtype=np.float64)
+        get_backend().scale_to_logvol(cov, am, axes, axlens, lv, [logvol])
+        self.cov, self.am, self.axes, self.axlens = cov[0], am[0], axes[0], \
+            axlens[0]
+        self.logvol = logvol
+
+    def major_axis_endpoints(self):
+        """bounding.py:278-284."""
+        i = np.argmax(self.axlens)
+        v = self.axes[:, i]
+        return self.ctr - v, self.ctr + v
+
+    def distance(self, x):
+        """bounding.py:286-293."""
+        _, _, quad = get_backend().contains(np.asarray(x), self.ctr[None],
+                                            self.am[None], mode=1,
+                                            want_quad=True)
+        return np.sqrt(quad[0, 0])
+
+    def distance_many(self, x):
+        """bounding.py:295-300."""
+        _, _, quad = get_backend().contains(np.asarray(x), self.ctr[None],
+                                            self.am[None], mode=1,
+                                            want_quad=True)
+        return np.sqrt(quad[:, 0])
+
+    def contains(self, x):
+        """bounding.py:302-305 (sqrt(q) <= 1)."""
+        count, _, _ = get_backend().contains(np.asarray(x), self.ctr[None],
+                                             self.am[None], mode=1)
+        return bool(count[0] > 0)
+
+    def sample(self, rstate=None):
+        """bounding.py:307-319."""
+        return self.samples(1, rstate=rstate)[0]
+
+    def samples(self, nsamples, rstate=None):
+        """bounding.py:321-334."""
+        xs, _, _ = _draw(rstate, nsamples, self.ctr[None], self.axes[None])
+        return xs
+
+    def unitcube_overlap(self, ndraws=10000, rstate=None):
+        """bounding.py:336-343."""
+        xs = self.samples(ndraws, rstate=rstate)
+        nin = np.sum((xs.min(axis=1) > 0) & (xs.max(axis=1) < 1))
+        return 1. * nin / ndraws
+
+    def update(self, points, rstate=None, bootstrap=0, pool=None,
+               mc_integrate=False):
+        """bounding.py:345-414."""
+        points = np.asarray(points)
+        res = get_backend().rebuild(points, multi=False)
+        self.ndim = points.shape[1]
+        self.ctr = res["ctrs"][0]
+        self.cov = res["covs"][0]
+        self.am = res["ams"][0]
+        self.axes = res["axes"][0]
+        self.axlens = res["axlens"][0]
+        self.logvol = float(res["logvol_ells"][0])
+        if bootstrap > 0:
+            from .bootstrap import bootstrap_expand
+            expand = bootstrap_expand(points, rstate, bootstrap, multi=False,
+                                      pool=pool)
+            if expand > 1.:
+                self.scale_to_logvol(self.logvol + self.ndim * np.log(expand))
+        if mc_integrate:
+            self.funit = self.unitcube_overlap(rstate=rstate)
+
+    def get_random_axes(self, rstate):
+        """bounding.py:416-417."""
+        return self.axes
+
+
+class HipMultiEllipsoid(HipBound):
+    """Union of ellipsoids.  bounding.py:420-731."""
+
+    def __init__(self, ndim, ells=None, ctrs=None, covs=None):
+        if ells is None and ctrs is None:
+            ells = [HipEllipsoid(ndim)]
+        if ells is not None:
+            if (ctrs is None) and (covs is None):
+                self._set_from_ells(ells)
+            else:
+                raise ValueError("You cannot specific both `ells` and "
+                                 "(`ctrs`, `covs`)!")
+        else:
+            if covs is None:
+                raise ValueError("You must specify either `ells` or "
+                                 "(`ctrs`, `covs`).")
+            ctrs = np.asarray(ctrs, dtype=np.float64)
+            covs = np.asarray(covs, dtype=np.float64)
+            ax, al, pm, lv = get_backend().ell_from_cov(covs)
+            self._set_arrays(ctrs, covs, pm, ax, al, lv)
+        super().__init__(ndim)
+        self.logvol = logsumexp(self.logvol_ells)
+        self.funit = 1
+
+    # -- state ----------------------------------------------------------------
+    def _set_arrays(self, ctrs, covs, ams, axes, axlens, logvol_ells):
+        self.nells = len(ctrs)
+        self.ctrs = np.ascontiguousarray(ctrs, dtype=np.float64)
+        self.covs = np.ascontiguousarray(covs, dtype=np.float64)
+        self.ams = np.ascontiguousarray(ams, dtype=np.float64)
+        self.axes_ells = np.ascontiguousarray(axes, dtype=np.float64)
+        self.axlens_ells = np.ascontiguousarray(axlens, dtype=np.float64)
+        self.logvol_ells = np.ascontiguousarray(logvol_ells, dtype=np.float64)
+
+    def _set_from_ells(self, ells):
+        self._set_arrays(np.array([e.ctr for e in ells]),
+                         np.array([e.cov for e in ells]),
+                         np.array([e.am for e in ells]),
+                         np.array([e.axes for e in ells]),
+                         np.array([e.axlens for e in ells]),
+                         np.array([e.logvol for e in ells]))
+
+    @property
+    def ells(self):
+        """List of HipEllipsoid views (reference attribute `ells`; used by
+        plotting.boundplot via `bound.ells[i]`)."""
+        return [
+            HipEllipsoid(self.ctrs.shape[1], ctr=self.ctrs[i],
+                         cov=self.covs[i], am=self.ams[i],
+                         axes=self.axes_ells[i], axlens=self.axlens_ells[i],
+                         logvol=self.logvol_ells[i])
+            for i in range(self.nells)
+        ]
+
+    # -- geometry ---------------------------------------------------------------
+    def scale_to_logvol(self, logvol):
+        """bounding.py:478-495."""
+        if isinstance(logvol, Iterable):
+            targets = np.asarray(logvol, dtype=np.float64)
+        else:
+            targets = self.logvol_ells + (logvol - self.logvol)
+        get_backend().scale_to_logvol(self.covs, self.ams, self.axes_ells,
+                                      self.axlens_ells, self.logvol_ells,
+                                      targets)
+        self.logvol = logsumexp(self.logvol_ells)
+
+    def major_axis_endpoints(self):
+        """bounding.py:497-500."""
+        return np.array([e.major_axis_endpoints() for e in self.ells])
+
+    def _mask(self, x):
+        x = np.asarray(x, dtype=np.float64)
+        count, mask, _ = get_backend().contains(x, self.ctrs, self.ams, mode=0,
+                                                want_mask=True)
+        return count, mask
+
+    def within(self, x, j=None):
+        """bounding.py:502-511."""
+        _, mask = self._mask(x)
+        inside = (mask[:, 0] & np.uint64(1)).astype(bool)
+        if j is not None:
+            inside[j] = False
+        return np.nonzero(inside)[0]
+
+    def overlap(self, x, j=None):
+        """bounding.py:513-518."""
+        return len(self.within(x, j=j))
+
+    def contains(self, x):
+        """bounding.py:520-523 (strict <)."""
+        count, _, _ = get_backend().contains(np.asarray(x, dtype=np.float64),
+                                             self.ctrs, self.ams, mode=0)
+        return bool(count[0] > 0)
+
+    # -- draws --------------------------------------------------------------------
+    def sample(self, rstate=None, return_q=False):
+        """bounding.py:525-590."""
+        xs, idxs, qs = _draw(rstate, 1, self.ctrs, self.axes_ells, self.ams,
+                             self.logvol_ells, return_q=return_q)
+        if return_q:
+            return xs[0], int(idxs[0]), int(qs[0])
+        return xs[0], int(idxs[0])
+
+    def samples(self, nsamples, rstate=None):
+        """bounding.py:592-606."""
+        xs, _, _ = _draw(rstate, nsamples, self.ctrs, self.axes_ells, self.ams,
+                         self.logvol_ells)
+        return xs
+
+    def monte_carlo_logvol(self, ndraws=10000, rstate=None,
+                           return_overlap=True):
+        """bounding.py:608-630."""
+        xs, _, qs = _draw(rstate, ndraws, self.ctrs, self.axes_ells, self.ams,
+                          self.logvol_ells, return_q=True)
+        invq = 1. / qs
+        qsum = invq.sum()
+        logvol = np.log(qsum / ndraws) + self.logvol
+        if return_overlap:
+            inside = (xs.min(axis=1) > 0) & (xs.max(axis=1) < 1)
+            return logvol, (invq * inside).sum() / qsum
+        return logvol
+
+    # -- rebuild ----------------------------------------------------------------
+    def update(self, points, rstate=None, bootstrap=0, pool=None,
+               mc_integrate=False):
+        """bounding.py:632-724."""
+        points = np.asarray(points)
+        npoints, ndim = points.shape
+        if npoints == 1:
+            raise RuntimeError('Cannot compute the bounding ellipsoid of '
+                               'a single point.')
+        res = get_backend().rebuild(points, multi=True)
+        self._set_arrays(res["ctrs"], res["covs"], res["ams"], res["axes"],
+                         res["axlens"], res["logvol_ells"])
+        self.logvol = logsumexp(self.logvol_ells)
+        if bootstrap > 0:
+            from .bootstrap import bootstrap_expand
+            expand = bootstrap_expand(points, rstate, bootstrap, multi=True,
+                                      pool=pool)
+            if expand > 1.:
+                self.scale_to_logvol(self.logvol_ells + ndim * np.log(expand))
+        if mc_integrate:
+            self.logvol, self.funit = self.monte_carlo_logvol(
+                rstate=rstate, return_overlap=True)
+
+    def get_random_axes(self, rstate):
+        """bounding.py:726-731 (one uniform draw, volume-weighted choice)."""
+        probs = np.exp(self.logvol_ells - self.logvol)
+        idx = min(np.searchsorted(np.cumsum(probs), rstate.random()),
+                  len(probs) - 1)
+        return self.axes_ells[idx]

@@ -952,6 +952,138 @@ __global__ void __launch_bounds__(kThreads) rebuild_kernel(RebuildArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------
+// Ellipsoid.__init__ from (ctr, cov) (bounding.py:201-240): eigen-decomposition
+// -> axlens, axes, am, logvol.  One wavefront per ellipsoid.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(64)
+    ell_from_cov_kernel(int m, int D, const double* __restrict__ covs, double prefactor, double* axes,
+                        double* axlens, double* ams, double* logvols, int* status) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int LD = D | 1;
+  double* A = (double*)smem;
+  double* V = A + D * LD;
+  double* S = V + D * LD;
+  double* lam = S + D * LD;
+  double* rc = lam + D;
+  double* rs = rc + 64;
+  int* ri = (int*)(rs + 64);
+  int* order = ri + 128;
+  const int e = blockIdx.x, lane = threadIdx.x;
+  if (e >= m) return;
+  const double* C = covs + (size_t)e * D * D;
+  for (int t = lane; t < D * D; t += 64) A[(t / D) * LD + t % D] = C[t];
+  wave_sync();
+  const bool fin = jacobi_wave(A, V, D, LD, rc, rs, ri);
+  int st = DH_OK;
+  if (fin) {
+    sort_eigs_wave(A, V, lam, order, S, D, LD);
+    double slog = 0.0;
+    bool ok = true;
+    for (int k = 0; k < D; ++k) {
+      const double l = lam[k];
+      if (!(l > 0.0) || !isfinite(l)) ok = false;
+      slog += log(l);
+    }
+    if (!ok)
+      st = DH_ERR_VALUE;
+    else {
+      for (int t = lane; t < D * D; t += 64) {
+        const int i = t / D, j = t % D;
+        axes[(size_t)e * D * D + t] = V[i * LD + j] * sqrt(lam[j]);
+        double s = 0.0;
+        for (int k = 0; k < D; ++k) s = fma(V[i * LD + k] * (1.0 / lam[k]), V[j * LD + k], s);
+        ams[(size_t)e * D * D + t] = s;
+      }
+      for (int k = lane; k < D; k += 64) axlens[(size_t)e * D + k] = sqrt(lam[k]);
+      if (lane == 0) logvols[e] = prefactor + 0.5 * slog;
+    }
+  } else {
+    st = DH_ERR_VALUE;
+  }
+  if (lane == 0) status[e] = st;
+}
+
+// ---------------------------------------------------------------------------
+// Ellipsoid.scale_to_logvol (bounding.py:242-276), one wavefront per ellipsoid.
+// The eigen-system of cov is taken from the stored principal axes
+// (v = axes / axlens, l = axlens^2) instead of a fresh eigh(cov).
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(64)
+    scale_logvol_kernel(int m, int D, double* covs, double* ams, double* axes, double* axlens,
+                        double* logvols, const double* __restrict__ targets) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  double* fax = (double*)smem;  // D
+  double* lax = fax + D;        // D  log axlens
+  int* iso = (int*)(lax + D);
+  const int e = blockIdx.x, lane = threadIdx.x;
+  if (e >= m) return;
+  double* C = covs + (size_t)e * D * D;
+  double* P = ams + (size_t)e * D * D;
+  double* X = axes + (size_t)e * D * D;
+  double* al = axlens + (size_t)e * D;
+  const double logf = targets[e] - logvols[e];
+  const double max_log_axlen = log(sqrt((double)D) / 2.0);
+  for (int k = lane; k < D; k += 64) lax[k] = log(al[k]);
+  wave_sync();
+  if (lane == 0) {
+    double mx = -INFINITY;
+    for (int k = 0; k < D; ++k) mx = fmax(mx, lax[k]);
+    iso[0] = (mx < max_log_axlen - logf / D) ? 1 : 0;
+    if (!iso[0]) {
+      // greedy per-axis inflation, largest eigenvalue first (bounding.py:262-268)
+      double left = logf;
+      int nleft = D;
+      for (int k = 0; k < D; ++k) fax[k] = -1.0;  // marks "not done"
+      for (int step = 0; step < D; ++step) {
+        int best = -1;
+        double bl = -INFINITY;
+        // np.argsort(l)[::-1]: descending eigenvalue; ties resolve to the later index
+        for (int k = 0; k < D; ++k)
+          if (fax[k] < 0.0 && lax[k] >= bl) {
+            bl = lax[k];
+            best = k;
+          }
+        const double delta = fmax(fmin(max_log_axlen - lax[best], left / nleft), 0.0);
+        fax[best] = exp(delta);
+        left -= delta;
+        --nleft;
+      }
+    }
+  }
+  wave_sync();
+  if (iso[0]) {
+    const double f = exp(logf / D);
+    const double f2 = f * f, inv = 1.0 / f2;
+    for (int t = lane; t < D * D; t += 64) {
+      C[t] *= f2;
+      P[t] *= inv;
+      X[t] *= f;
+    }
+    for (int k = lane; k < D; k += 64) al[k] *= f;
+  } else {
+    // cov = (v * l1) v^T, am = (v / l1) v^T with l1 = l * fax^2, v = axes / axlens
+    for (int t = lane; t < D * D; t += 64) {
+      const int i = t / D, j = t % D;
+      double sc = 0.0, sp = 0.0;
+      for (int k = 0; k < D; ++k) {
+        const double a = al[k];
+        const double vik = X[i * D + k] / a, vjk = X[j * D + k] / a;
+        const double l1 = a * a * fax[k] * fax[k];
+        sc = fma(vik * l1, vjk, sc);
+        sp = fma(vik * (1.0 / l1), vjk, sp);
+      }
+      C[t] = sc;
+      P[t] = sp;
+    }
+    wave_sync();
+    for (int t = lane; t < D * D; t += 64) X[t] *= fax[t % D];
+    wave_sync();
+    for (int k = lane; k < D; k += 64) al[k] *= fax[k];
+  }
+  if (lane == 0) logvols[e] = targets[e];
+}
+
 size_t rebuild_lds_bytes(int D) {
   const int LD = D | 1;
   size_t dbl = (size_t)kThreads * LD + 4 * (size_t)D * LD + 7 * (size_t)D + kThreads + 128;
@@ -1080,6 +1212,75 @@ int dh_rebuild(dh_ctx* ctx, const double* pts, int n, int d, int mode, int max_e
   if (!down(ctx, ctrs, d_ctrs, m * d) || !down(ctx, covs, d_covs, m * dd) || !down(ctx, ams, d_ams, m * dd) ||
       !down(ctx, axes, d_axes, m * dd) || !down(ctx, axlens, d_axl, m * d) || !down(ctx, logvols, d_lv, m) ||
       !down(ctx, leaf_of_point, d_lop, (size_t)n) || !down(ctx, nnodes, d_nn, 1))
+    return DH_ERR_HIP;
+  return dh_sync(ctx);
+}
+
+int dh_ell_from_cov(dh_ctx* ctx, int m, int d, const double* covs, double* axes, double* axlens,
+                    double* ams, double* logvols) {
+  DH_CHECK_CTX(ctx);
+  if (m <= 0) return DH_OK;
+  if (!covs || !axes || !axlens || !ams || !logvols || d < 1)
+    return fail(ctx, DH_ERR_ARG, "ell_from_cov: bad arguments");
+  const int LD = d | 1;
+  const size_t lds = ((size_t)3 * d * LD + d + 128) * 8 + (128 + (size_t)d + 8) * 4;
+  if (lds > 160 * 1024) return fail(ctx, DH_ERR_ARG, "ell_from_cov: d=%d too large for LDS", d);
+  arena_reset(ctx);
+  const size_t dd = (size_t)d * d;
+  int rc = arena_reserve(ctx, (size_t)m * (3 * dd + d + 2) * 8 + 8192);
+  if (rc) return rc;
+  const double* d_c = arena_up(ctx, covs, (size_t)m * dd);
+  double* d_ax = (double*)arena_get(ctx, (size_t)m * dd * 8);
+  double* d_am = (double*)arena_get(ctx, (size_t)m * dd * 8);
+  double* d_al = (double*)arena_get(ctx, (size_t)m * d * 8);
+  double* d_lv = (double*)arena_get(ctx, (size_t)m * 8);
+  int* d_st = (int*)arena_get(ctx, (size_t)m * 4);
+  if (!d_c || !d_ax || !d_am || !d_al || !d_lv || !d_st) return DH_ERR_NOMEM;
+  const double pre = d * log(2.0) + d * lgamma(1.5) - lgamma(d / 2.0 + 1.0);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)ell_from_cov_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(ell_from_cov_kernel, dim3(m), dim3(64), lds, ctx->stream, m, d, d_c, pre, d_ax, d_al,
+                     d_am, d_lv, d_st);
+  if (!hip_ok(ctx, hipGetLastError(), "ell_from_cov launch")) return DH_ERR_HIP;
+  std::vector<int> st((size_t)m);
+  if (!down(ctx, axes, d_ax, (size_t)m * dd) || !down(ctx, ams, d_am, (size_t)m * dd) ||
+      !down(ctx, axlens, d_al, (size_t)m * d) || !down(ctx, logvols, d_lv, (size_t)m) ||
+      !down(ctx, st.data(), d_st, (size_t)m))
+    return DH_ERR_HIP;
+  if ((rc = dh_sync(ctx))) return rc;
+  for (int i = 0; i < m; ++i)
+    if (st[i] != DH_OK)
+      return fail(ctx, DH_ERR_VALUE, "The input covariance of ellipsoid %d is singular or not finite", i);
+  return DH_OK;
+}
+
+int dh_scale_to_logvol(dh_ctx* ctx, int m, int d, double* covs, double* ams, double* axes, double* axlens,
+                       double* logvols, const double* targets) {
+  DH_CHECK_CTX(ctx);
+  if (m <= 0) return DH_OK;
+  if (!covs || !ams || !axes || !axlens || !logvols || !targets || d < 1)
+    return fail(ctx, DH_ERR_ARG, "scale_to_logvol: bad arguments");
+  arena_reset(ctx);
+  const size_t dd = (size_t)d * d;
+  int rc = arena_reserve(ctx, (size_t)m * (3 * dd + d + 2) * 8 + 8192);
+  if (rc) return rc;
+  double* d_c = arena_up(ctx, (const double*)covs, (size_t)m * dd);
+  double* d_p = arena_up(ctx, (const double*)ams, (size_t)m * dd);
+  double* d_x = arena_up(ctx, (const double*)axes, (size_t)m * dd);
+  double* d_al = arena_up(ctx, (const double*)axlens, (size_t)m * d);
+  double* d_lv = arena_up(ctx, (const double*)logvols, (size_t)m);
+  const double* d_t = arena_up(ctx, targets, (size_t)m);
+  if (!d_c || !d_p || !d_x || !d_al || !d_lv || !d_t) return DH_ERR_NOMEM;
+  hipLaunchKernelGGL(scale_logvol_kernel, dim3(m), dim3(64), (size_t)2 * d * 8 + 64, ctx->stream, m, d,
+                     d_c, d_p, d_x, d_al, d_lv, d_t);
+  if (!hip_ok(ctx, hipGetLastError(), "scale_to_logvol launch")) return DH_ERR_HIP;
+  if (!down(ctx, covs, d_c, (size_t)m * dd) || !down(ctx, ams, d_p, (size_t)m * dd) ||
+      !down(ctx, axes, d_x, (size_t)m * dd) || !down(ctx, axlens, d_al, (size_t)m * d) ||
+      !down(ctx, logvols, d_lv, (size_t)m))
     return DH_ERR_HIP;
   return dh_sync(ctx);
 }

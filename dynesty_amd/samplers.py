@@ -1,0 +1,228 @@
+"""Batched execution of dynesty's proposal samplers on the device.
+
+Each ``run_*`` function takes the list of ``SamplerArgument`` tuples that
+``InternalSampler.prepare_sampler`` built for one queue fill
+(reference sampler.py:676-717, internal_samplers.py:111-159) and returns the
+list of ``SamplerReturn``-shaped results, one device launch for the whole
+queue.  All walkers of a fill share ``loglstar`` and ``scale``
+(sampler.py:709-716).
+
+Random streams: every argument carries ``rseed`` -- the sampler's own
+``numpy.random.Generator`` when ``queue_size == 1`` or a ``SeedSequence`` child
+otherwise (sampler.py:696-699).  The device continues exactly those PCG64
+streams: Generators are read and written back, SeedSequence children are hashed
+on the device.
+"""
+from collections import namedtuple
+
+import numpy as np
+
+from . import _lib
+from .backend import get_backend
+
+# same field names as internal_samplers.py:28-31
+SamplerReturn = namedtuple('SamplerReturn', [
+    'u', 'v', 'logl', 'ncalls', 'evaluation_history', 'tuning_info',
+    'proposal_stats'
+])
+
+
+class NoDeviceProblem(NotImplementedError):
+    pass
+
+
+def _problem_of(arg):
+    prob = arg.kwargs.get('problem')
+    if prob is None:
+        raise NoDeviceProblem(
+            "this sampler was built without problem=<dynesty_amd.problems."
+            "Problem>: the device proposal kernels evaluate the prior transform "
+            "and the log-likelihood in-kernel and need their device twin. "
+            "(A lock-step path for arbitrary Python callbacks is not built.)")
+    return prob
+
+
+class _Streams:
+    """Per-walker PCG64 states for a list of rseeds + write-back."""
+
+    def __init__(self, seeds):
+        self.seeds = list(seeds)
+        k = len(self.seeds)
+        be = get_backend()
+        first = self.seeds[0]
+        self.generators = None
+        if isinstance(first, np.random.Generator):
+            self.generators = self.seeds
+            self.states = np.array([
+                _lib.pcg_state_words(g.bit_generator) for g in self.seeds
+            ], dtype=np.uint64)
+            return
+        # SeedSequence children of one parent, consecutive spawn keys: hash on
+        # the device (utils.py:1002-1009 spawns exactly this)
+        ent = first.entropy
+        keys = [s.spawn_key for s in self.seeds]
+        consecutive = all(
+            len(kk) == 1 and kk[0] == keys[0][0] + i and np.array_equal(
+                np.atleast_1d(s.entropy), np.atleast_1d(ent))
+            for i, (kk, s) in enumerate(zip(keys, self.seeds))) and len(
+                keys[0]) == 1 and first.pool_size == 4
+        if consecutive:
+            self.states = be.seed_children(np.atleast_1d(ent), keys[0][0], k)
+        else:
+            self.states = np.array([
+                _lib.pcg_state_words(np.random.PCG64(s)) for s in self.seeds
+            ], dtype=np.uint64)
+
+    def write_back(self, rng_out):
+        if self.generators is not None:
+            for g, st in zip(self.generators, rng_out):
+                _lib.set_pcg_state_words(g.bit_generator, st)
+
+
+def _frames(args):
+    """Unique proposal frames (by identity, then value) + index per walker."""
+    uniq, ids, idx = [], {}, np.empty(len(args), dtype=np.int32)
+    for i, a in enumerate(args):
+        key = id(a.axes)
+        j = ids.get(key)
+        if j is None:
+            j = len(uniq)
+            ids[key] = j
+            uniq.append(np.asarray(a.axes, dtype=np.float64))
+        idx[i] = j
+    return np.stack(uniq), (None if len(uniq) == 1 else idx)
+
+
+def _bc_flags(kwargs, ndim):
+    periodic, reflective = kwargs.get('periodic'), kwargs.get('reflective')
+    if periodic is None and reflective is None:
+        return None
+    bc = np.zeros(ndim, dtype=np.int8)
+    if periodic is not None:
+        bc[np.asarray(periodic)] = _lib.BC_PERIODIC
+    if reflective is not None:
+        bc[np.asarray(reflective)] = _lib.BC_REFLECT
+    return bc
+
+
+def run_rwalk(args):
+    """RWalkSampler.sample over a queue (internal_samplers.py:504-561)."""
+    args = list(args)
+    if not args:
+        return []
+    a0 = args[0]
+    prob = _problem_of(a0)
+    kw = a0.kwargs
+    u0 = np.array([a.u for a in args], dtype=np.float64)
+    axes, idx = _frames(args)
+    streams = _Streams([a.rseed for a in args])
+    out = get_backend().rwalk_batch(
+        prob, u0, axes, a0.scale, a0.loglstar, kw['walks'], streams.states,
+        axes_idx=idx, ncdim=axes.shape[1], bc=_bc_flags(kw, prob.ndim))
+    streams.write_back(out["rng_out"])
+    walks = int(kw['walks'])
+    res = []
+    for i in range(len(args)):
+        na, nr = int(out["accept"][i]), int(out["reject"][i])
+        res.append(SamplerReturn(
+            u=out["u"][i], v=out["v"][i], logl=float(out["logl"][i]),
+            ncalls=walks, evaluation_history=[],
+            tuning_info={'accept': na, 'reject': nr, 'scale': a0.scale},
+            proposal_stats=dict(n_accept=na, n_reject=nr)))
+    return res
+
+
+def _run_slice(args, principal):
+    args = list(args)
+    if not args:
+        return []
+    a0 = args[0]
+    prob = _problem_of(a0)
+    kw = a0.kwargs
+    u0 = np.array([a.u for a in args], dtype=np.float64)
+    axes, idx = _frames(args)
+    streams = _Streams([a.rseed for a in args])
+    out = get_backend().slice_batch(
+        prob, u0, axes, a0.scale, a0.loglstar, kw['slices'], streams.states,
+        principal=principal, doubling=bool(kw.get('slice_doubling', False)),
+        axes_idx=idx)
+    streams.write_back(out["rng_out"])
+    res = []
+    for i in range(len(args)):
+        ne, nt = int(out["n_expand"][i]), int(out["n_contract"][i])
+        res.append(SamplerReturn(
+            u=out["u"][i], v=out["v"][i], logl=float(out["logl"][i]),
+            ncalls=int(out["ncalls"][i]), evaluation_history=[],
+            tuning_info={'n_expand': ne, 'n_contract': nt,
+                         'expansion_warning_set':
+                         bool(out["expansion_warning_set"][i])},
+            proposal_stats=dict(n_expand=ne, n_contract=nt)))
+    return res
+
+
+def run_rslice(args):
+    """RSliceSampler.sample over a queue (internal_samplers.py:745-855)."""
+    return _run_slice(args, principal=False)
+
+
+def run_slice(args):
+    """SliceSampler.sample over a queue (internal_samplers.py:593-709)."""
+    return _run_slice(args, principal=True)
+
+
+def bound_arrays(bound):
+    """(ctrs, axes, ams, logvol_ells) of an ellipsoidal bound -- ours or the
+    reference's (duck-typed: bounding.py:201-240, 440-476)."""
+    if hasattr(bound, 'ctrs') and hasattr(bound, 'logvol_ells'):
+        axes = getattr(bound, 'axes_ells', None)
+        if axes is None:
+            axes = np.array([e.axes for e in bound.ells])
+        return (np.asarray(bound.ctrs), np.asarray(axes), np.asarray(bound.ams),
+                np.asarray(bound.logvol_ells))
+    if hasattr(bound, 'ctr') and hasattr(bound, 'axes'):
+        return (np.asarray(bound.ctr)[None], np.asarray(bound.axes)[None],
+                np.asarray(bound.am)[None], np.array([bound.logvol]))
+    raise TypeError(
+        f"{type(bound).__name__} is not an ellipsoidal bound: the device "
+        "uniform sampler supports Ellipsoid / MultiEllipsoid bounds")
+
+
+def run_unif(args):
+    """UniformBoundSampler.sample over a queue (internal_samplers.py:243-340)."""
+    args = list(args)
+    if not args:
+        return []
+    a0 = args[0]
+    prob = _problem_of(a0)
+    kw = a0.kwargs
+    ctrs, axes, ams, lvs = bound_arrays(kw['bound'])
+    streams = _Streams([a.rseed for a in args])
+    bc = None
+    nonb = kw.get('nonbounded')
+    if nonb is not None:
+        bc = np.where(np.asarray(nonb), _lib.BC_HARD,
+                      _lib.BC_PERIODIC).astype(np.int8)
+    out = get_backend().unif_batch(prob, a0.loglstar, streams.states,
+                                   ctrs=ctrs, axes=axes, ams=ams,
+                                   logvol_ells=lvs, ncdim=kw['n_cluster'],
+                                   bc=bc)
+    streams.write_back(out["rng_out"])
+    return [
+        SamplerReturn(u=out["u"][i], v=out["v"][i],
+                      logl=float(out["logl"][i]), ncalls=int(out["ncalls"][i]),
+                      evaluation_history=[], tuning_info=None,
+                      proposal_stats={'n_proposals': 0})
+        for i in range(len(args))
+    ]
+
+
+def batched(runner):
+    """Wrap a queue runner as the static per-argument ``sample`` dynesty
+    expects; ``HipBatchPool.map`` finds the runner on ``_dynhip_batch``."""
+
+    def sample(arg):
+        return runner([arg])[0]
+
+    sample._dynhip_batch = runner
+    sample.__doc__ = runner.__doc__
+    return sample

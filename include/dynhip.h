@@ -142,6 +142,18 @@ int dh_rebuild_batch_dev(dh_ctx* ctx, int runs, const double* pts, int n, int d,
                          double* axlens, double* logvols, int32_t* leaf_of_point,
                          int32_t* nnodes);
 
+/* Ellipsoid.__init__(ctr, cov) (bounding.py:201-240) for m covariance matrices:
+ * eigen-decomposition -> axes (ascending, sign-canonical), axlens, am, logvol.
+ * DH_ERR_VALUE if an eigenvalue is not positive/finite. */
+int dh_ell_from_cov(dh_ctx* ctx, int m, int d, const double* covs, double* axes,
+                    double* axlens, double* ams, double* logvols);
+/* Ellipsoid.scale_to_logvol (bounding.py:242-276) applied in place to m
+ * ellipsoids with per-ellipsoid targets (MultiEllipsoid.scale_to_logvol,
+ * bounding.py:478-495, supplies logvol_ells + shift). */
+int dh_scale_to_logvol(dh_ctx* ctx, int m, int d, double* covs, double* ams,
+                       double* axes, double* axlens, double* logvols,
+                       const double* targets);
+
 /* ---- proposals ----------------------------------------------------------
  * RWalkSampler.sample over a batch of k walkers = generic_random_walk +
  * propose_ball_point + randsphere (internal_samplers.py:866-1035,

@@ -1,0 +1,231 @@
+"""TEST-ONLY backend: the methods of ``dynesty_amd._lib.Context`` that the
+plugin classes call, implemented over the NumPy oracle.  It lets the CPU test
+suite drive the *host* logic (plugin plumbing, pickling, dynesty integration,
+multi-process sharding) where no GPU exists.  It is injected explicitly with
+``dynesty_amd.backend.set_backend`` by tests; the product never imports it.
+"""
+import numpy as np
+
+from oracle import bounding_ref as B
+from oracle import proposals_ref as P
+
+
+def _gen(words):
+    bg = np.random.PCG64()
+    st = bg.state
+    w = [int(x) for x in words]
+    st["state"]["state"] = (w[0] << 64) | w[1]
+    st["state"]["inc"] = (w[2] << 64) | w[3]
+    st["has_uint32"] = 0
+    st["uinteger"] = 0
+    bg.state = st
+    return np.random.Generator(bg)
+
+
+def _words(gen):
+    s = gen.bit_generator.state["state"]
+    m = (1 << 64) - 1
+    return np.array([s["state"] >> 64, s["state"] & m, s["inc"] >> 64,
+                     s["inc"] & m], dtype=np.uint64)
+
+
+def _canon(axes):
+    out = np.array(axes, dtype=np.float64)
+    for k in range(out.shape[1]):
+        i = np.argmax(np.abs(out[:, k]))
+        if out[i, k] < 0:
+            out[:, k] = -out[:, k]
+    return out
+
+
+def _ell(ctr, cov, am, axes, axlens, logvol):
+    return B.Ell(np.asarray(ctr), np.asarray(cov), np.asarray(am),
+                 np.asarray(axes), np.asarray(axlens), float(logvol))
+
+
+class OracleBackend:
+    name = "oracle (tests only)"
+
+    def seed_children(self, entropy, first, k):
+        kids = np.random.SeedSequence(
+            [int(x) for x in np.atleast_1d(entropy)]).spawn(first + k)[first:]
+        out = np.empty((k, 4), dtype=np.uint64)
+        for i, c in enumerate(kids):
+            out[i] = _words(np.random.Generator(np.random.PCG64(c)))
+        return out
+
+    def problem_eval(self, prob, u):
+        u = np.asarray(u, dtype=np.float64).reshape(-1, prob.ndim)
+        v = prob.prior_transform_many(u)
+        return v, prob.loglikelihood_many(v)
+
+    def contains(self, x, ctrs, ams, mode=0, want_mask=False, want_quad=False):
+        x = np.asarray(x, dtype=np.float64)
+        if x.ndim == 1:
+            x = x[None]
+        ctrs = np.asarray(ctrs).reshape(-1, x.shape[1])
+        ams = np.asarray(ams).reshape(len(ctrs), x.shape[1], x.shape[1])
+        quad = np.array([B.multi_quadforms(p, ctrs, ams) for p in x])
+        inside = quad < 1 if mode == 0 else np.sqrt(quad) <= 1.0
+        count = inside.sum(axis=1).astype(np.int32)
+        mask = None
+        if want_mask:
+            k, m = inside.shape
+            nw = (k + 63) // 64
+            bits = np.zeros((m, nw * 64), dtype=np.uint8)
+            bits[:, :k] = inside.T
+            mask = np.packbits(bits, axis=1, bitorder="little").view(np.uint64)
+        return count, mask, (quad if want_quad else None)
+
+    def rebuild(self, points, multi=True, max_ells=None, want_labels=False):
+        pts = np.asarray(points, dtype=np.float64)
+        ells = B.multi_update(pts).ells if multi else \
+            [B.bounding_ellipsoid(pts)]
+        return dict(nells=len(ells), ctrs=np.array([e.ctr for e in ells]),
+                    covs=np.array([e.cov for e in ells]),
+                    ams=np.array([e.am for e in ells]),
+                    axes=np.array([_canon(e.axes) for e in ells]),
+                    axlens=np.array([e.axlens for e in ells]),
+                    logvol_ells=np.array([e.logvol for e in ells]),
+                    labels=None, nnodes=0)
+
+    def ell_from_cov(self, covs):
+        covs = np.asarray(covs, dtype=np.float64)
+        if covs.ndim == 2:
+            covs = covs[None]
+        d = covs.shape[1]
+        ells = [B.make_ell(np.zeros(d), c) for c in covs]
+        return (np.array([_canon(e.axes) for e in ells]),
+                np.array([e.axlens for e in ells]),
+                np.array([e.am for e in ells]),
+                np.array([e.logvol for e in ells]))
+
+    def scale_to_logvol(self, covs, ams, axes, axlens, logvols, targets):
+        d = axlens.shape[1]
+        for i in range(len(logvols)):
+            e = _ell(np.zeros(d), covs[i], ams[i], axes[i], axlens[i],
+                     logvols[i])
+            B.scale_ell_to_logvol(e, float(targets[i]))
+            covs[i], ams[i], axes[i], axlens[i] = e.cov, e.am, e.axes, e.axlens
+            logvols[i] = e.logvol
+
+    def bound_draw(self, state4, nsamp, ctrs, axes, ams=None, logvol_ells=None,
+                   return_q=False):
+        rng = _gen(state4)
+        ctrs = np.asarray(ctrs, dtype=np.float64)
+        if ctrs.ndim == 1:
+            ctrs = ctrs[None]
+        m, d = ctrs.shape
+        axes = np.asarray(axes).reshape(m, d, d)
+        xs = np.empty((nsamp, d))
+        idxs = np.zeros(nsamp, dtype=np.int32)
+        qs = np.ones(nsamp, dtype=np.int32)
+        if m == 1:
+            e = _ell(ctrs[0], np.eye(d), np.eye(d), axes[0], np.ones(d), 0.0)
+            for s in range(nsamp):
+                xs[s] = B.ell_sample(e, rng)
+        else:
+            ams = np.asarray(ams).reshape(m, d, d)
+            ells = [_ell(ctrs[i], np.eye(d), ams[i], axes[i], np.ones(d),
+                         logvol_ells[i]) for i in range(m)]
+            mell = B.stack_ells(ells)
+            for s in range(nsamp):
+                r = B.multi_sample(mell, rng, return_q=return_q)
+                xs[s], idxs[s] = r[0], r[1]
+                if return_q:
+                    qs[s] = r[2]
+        return xs, idxs, qs, _words(rng)
+
+    @staticmethod
+    def _bcmasks(bc, ndim):
+        if bc is None:
+            return None, None, None
+        bc = np.asarray(bc)
+        per = np.nonzero(bc == 1)[0]
+        ref = np.nonzero(bc == 2)[0]
+        return (per if len(per) else None, ref if len(ref) else None, bc == 0)
+
+    def rwalk_batch(self, prob, u0, axes, scale, loglstar, walks, rng_states,
+                    axes_idx=None, ncdim=None, bc=None):
+        u0 = np.asarray(u0, dtype=np.float64).reshape(-1, prob.ndim)
+        k = u0.shape[0]
+        nc = prob.ndim if ncdim is None else ncdim
+        axes = np.asarray(axes).reshape(-1, nc, nc)
+        per, ref, nonb = self._bcmasks(bc, prob.ndim)
+        out = dict(u=np.empty_like(u0), v=np.empty_like(u0), logl=np.empty(k),
+                   accept=np.empty(k, np.int32), reject=np.empty(k, np.int32),
+                   rng_out=np.empty((k, 4), np.uint64))
+        for i in range(k):
+            rng = _gen(rng_states[i])
+            fr = axes[0 if axes_idx is None else axes_idx[i]]
+            r = P.rwalk(u0[i].copy(), loglstar, fr, scale, prob.prior_transform,
+                        prob.loglikelihood, rng, walks, periodic=per,
+                        reflective=ref, nonbounded=nonb)
+            out["u"][i], out["v"][i], out["logl"][i] = r["u"], r["v"], r["logl"]
+            out["accept"][i], out["reject"][i] = r["accept"], r["reject"]
+            out["rng_out"][i] = _words(rng)
+        return out
+
+    def slice_batch(self, prob, u0, axes, scale, loglstar, slices, rng_states,
+                    principal=False, doubling=False, axes_idx=None):
+        u0 = np.asarray(u0, dtype=np.float64).reshape(-1, prob.ndim)
+        k = u0.shape[0]
+        axes = np.asarray(axes).reshape(-1, prob.ndim, prob.ndim)
+        fn = P.pslice if principal else P.rslice
+        out = dict(u=np.empty_like(u0), v=np.empty_like(u0), logl=np.empty(k),
+                   ncalls=np.empty(k, np.int32), n_expand=np.empty(k, np.int32),
+                   n_contract=np.empty(k, np.int32),
+                   expansion_warning_set=np.zeros(k, bool),
+                   rng_out=np.empty((k, 4), np.uint64))
+        for i in range(k):
+            rng = _gen(rng_states[i])
+            fr = axes[0 if axes_idx is None else axes_idx[i]]
+            r = fn(u0[i].copy(), loglstar, fr, scale, prob.prior_transform,
+                   prob.loglikelihood, rng, slices, doubling=doubling)
+            out["u"][i], out["v"][i], out["logl"][i] = r["u"], r["v"], r["logl"]
+            out["ncalls"][i] = r["ncalls"]
+            out["n_expand"][i], out["n_contract"][i] = r["n_expand"], \
+                r["n_contract"]
+            out["expansion_warning_set"][i] = r["expansion_warning_set"]
+            out["rng_out"][i] = _words(rng)
+        return out
+
+    def unif_batch(self, prob, loglstar, rng_states, ctrs=None, axes=None,
+                   ams=None, logvol_ells=None, ncdim=None, bc=None,
+                   max_tries=0):
+        rng_states = np.asarray(rng_states).reshape(-1, 4)
+        k = rng_states.shape[0]
+        nd = prob.ndim
+        nc = nd if ncdim is None else ncdim
+        nonb = None if bc is None else (np.asarray(bc) == 0)
+        out = dict(u=np.empty((k, nd)), v=np.empty((k, nd)), logl=np.empty(k),
+                   ncalls=np.empty(k, np.int32),
+                   rng_out=np.empty((k, 4), np.uint64))
+        draw = None
+        if ctrs is not None:
+            ctrs = np.asarray(ctrs).reshape(-1, nc)
+            m = len(ctrs)
+            axes = np.asarray(axes).reshape(m, nc, nc)
+            if m == 1:
+                e = _ell(ctrs[0], np.eye(nc), np.eye(nc), axes[0], np.ones(nc),
+                         0.0)
+                draw = P.unif_single(e)
+            else:
+                ams = np.asarray(ams).reshape(m, nc, nc)
+                mell = B.stack_ells([
+                    _ell(ctrs[i], np.eye(nc), ams[i], axes[i], np.ones(nc),
+                         logvol_ells[i]) for i in range(m)])
+                draw = P.unif_multi(mell)
+        for i in range(k):
+            rng = _gen(rng_states[i])
+            if draw is None:
+                r = P.unitcube(loglstar, prob.prior_transform,
+                               prob.loglikelihood, rng, nd)
+            else:
+                r = P.unif_bound(loglstar, draw, prob.prior_transform,
+                                 prob.loglikelihood, rng, nd, nc,
+                                 nonbounded=nonb)
+            out["u"][i], out["v"][i], out["logl"][i] = r["u"], r["v"], r["logl"]
+            out["ncalls"][i] = r["ncalls"]
+            out["rng_out"][i] = _words(rng)
+        return out

@@ -1,0 +1,180 @@
+"""Drop-in boundary exercised with the REAL dynesty and
+the oracle test backend on CPU: the plugin classes must be accepted by an
+unmodified NestedSampler, survive deepcopy / pickling, honour dynesty's
+isinstance-keyed defaults, and the batching pool must turn a queue fill into
+one runner call.  (The same classes run on the HIP backend in
+tests/test_gpu_dropin.py through a dynesty-free driver.)
+
+Model: reference tests/test_bound_interface.py and test_sampler_interface.py.
+"""
+import copy
+import pickle
+
+import numpy as np
+import pytest
+
+import refshim
+
+pytestmark = [
+    pytest.mark.reference,
+    pytest.mark.skipif(not refshim.have_reference(),
+                       reason="needs /root/reference (build container)"),
+]
+
+
+@pytest.fixture(scope="module")
+def dyn():
+    d = refshim.import_reference()
+    from dynesty_amd import backend
+    from oracle_backend import OracleBackend
+    backend.set_backend(OracleBackend())
+    yield d
+    backend.set_backend(None)
+
+
+def run(dyn, prob, bound, sample, pool=None, nlive=200, seed=5, dlogz=0.5,
+        **kw):
+    s = dyn.NestedSampler(prob.loglikelihood, prob.prior_transform, prob.ndim,
+                          nlive=nlive, bound=bound, sample=sample, pool=pool,
+                          queue_size=None if pool is None else pool.size,
+                          rstate=np.random.default_rng(seed), **kw)
+    s.run_nested(dlogz=dlogz, print_progress=False)
+    return s
+
+
+def test_classes_are_reference_subclasses(dyn):
+    from dynesty import bounding as db, internal_samplers as dis
+    from dynesty_amd import dropin
+    assert issubclass(dropin.HipMultiEllipsoid, db.Bound)
+    assert issubclass(dropin.HipEllipsoid, db.Bound)
+    assert issubclass(dropin.HipRWalkSampler, dis.RWalkSampler)
+    assert issubclass(dropin.HipRSliceSampler, dis.RSliceSampler)
+    assert issubclass(dropin.HipSliceSampler, dis.SliceSampler)
+    assert issubclass(dropin.HipUniformBoundSampler, dis.UniformBoundSampler)
+
+
+def test_unif_single_c1(dyn):
+    """BASELINE config C1 shape: 3-D Gaussian, single bound, unif sampler."""
+    import inputs
+    from dynesty_amd import dropin
+    prob = inputs.problem("C1")
+    s = run(dyn, prob, dropin.HipEllipsoid(3),
+            dropin.HipUniformBoundSampler(problem=prob), nlive=300)
+    r = s.results
+    assert abs(r.logz[-1] - prob.logz_truth) < 5 * r.logzerr[-1] + 0.1
+    # dynesty keys bootstrap=5 / enlarge=1 on isinstance(UniformBoundSampler)
+    assert s.bound_bootstrap == 5 and s.bound_enlarge == 1
+
+
+@pytest.mark.parametrize("which", ["rwalk", "rslice", "slice"])
+def test_multi_samplers_g5(dyn, which):
+    import inputs
+    from dynesty_amd import dropin
+    prob = inputs.problem("G5")
+    smp = dict(rwalk=dropin.HipRWalkSampler(problem=prob, walks=20),
+               rslice=dropin.HipRSliceSampler(problem=prob, slices=4),
+               slice=dropin.HipSliceSampler(problem=prob, slices=2))[which]
+    s = run(dyn, prob, dropin.HipMultiEllipsoid(5), smp, nlive=150, dlogz=1.0)
+    r = s.results
+    assert abs(r.logz[-1] - prob.logz_truth) < 5 * r.logzerr[-1] + 0.3
+    assert s.bound_enlarge == 1.25 and s.bound_bootstrap == 0
+    assert isinstance(s.bound, dropin.HipMultiEllipsoid)
+    assert s.nbound > 1
+
+
+def test_batch_pool_one_launch_per_fill(dyn):
+    import inputs
+    from dynesty_amd import dropin, samplers
+    prob = inputs.problem("G5")
+    calls = []
+    orig = samplers.run_rwalk
+
+    class CountingPool(dropin.HipBatchPool):
+
+        def map(self, func, iterable):
+            items = list(iterable)
+            if getattr(func, '_dynhip_batch', None) is not None:
+                calls.append(len(items))
+            return super().map(func, items)
+
+    pool = CountingPool(queue_size=32)
+    s = run(dyn, prob, dropin.HipMultiEllipsoid(5),
+            dropin.HipRWalkSampler(problem=prob, walks=15), pool=pool,
+            nlive=120, dlogz=2.0)
+    assert calls and all(c == 32 for c in calls)
+    r = s.results
+    assert abs(r.logz[-1] - prob.logz_truth) < 5 * r.logzerr[-1] + 0.5
+    assert samplers.run_rwalk is orig
+
+
+def test_deepcopy_pickle_roundtrip(dyn):
+    import inputs
+    from dynesty_amd import dropin
+    b = dropin.HipMultiEllipsoid(5)
+    b.update(inputs.cloud("two5"), rstate=np.random.default_rng(1))
+    assert b.nells == 2
+    for clone in (copy.deepcopy(b), pickle.loads(pickle.dumps(b))):
+        assert clone.nells == b.nells
+        np.testing.assert_array_equal(clone.ams, b.ams)
+        x = inputs.cloud("two5")[0]
+        assert clone.contains(x) == b.contains(x) is True
+        np.testing.assert_array_equal(
+            clone.samples(5, rstate=np.random.default_rng(2)),
+            b.samples(5, rstate=np.random.default_rng(2)))
+    smp = dropin.HipRWalkSampler(problem=inputs.problem("G5"), walks=30)
+    smp2 = pickle.loads(pickle.dumps(smp))
+    assert smp2.sampler_kwargs['walks'] == 30
+    assert smp2.sampler_kwargs['problem'].ndim == 5
+    # dynesty re-instantiates the user's sampler from a template
+    smp3 = smp._new_from_template(dict(ndim=5, ncdim=5, nonbounded=None,
+                                       periodic=None, reflective=None,
+                                       facc=0.5))
+    assert type(smp3) is type(smp)
+    assert smp3.sampler_kwargs['problem'] is smp.sampler_kwargs['problem']
+
+
+def test_checkpoint_resume(dyn, tmp_path):
+    """utils.save_sampler / restore_sampler with plugin objects inside."""
+    import inputs
+    from dynesty_amd import dropin
+    prob = inputs.problem("G5")
+    s = dyn.NestedSampler(prob.loglikelihood, prob.prior_transform, 5,
+                          nlive=100, bound=dropin.HipMultiEllipsoid(5),
+                          sample=dropin.HipRWalkSampler(problem=prob, walks=15),
+                          rstate=np.random.default_rng(3))
+    s.run_nested(maxiter=300, print_progress=False, add_live=False)
+    f = str(tmp_path / "ck.sav")
+    s.save(f)
+    s2 = dyn.NestedSampler.restore(f)
+    s2.run_nested(dlogz=2.0, print_progress=False, resume=True)
+    assert abs(s2.results.logz[-1] - prob.logz_truth) < 1.5
+
+
+def test_bound_api_matches_reference_semantics(dyn):
+    """Method-by-method comparison with the reference classes on the same
+    points (exact where the arithmetic is identical)."""
+    import inputs
+    from dynesty import bounding as db
+    from dynesty_amd import dropin
+    pts = inputs.cloud("two5")
+    ours, ref = dropin.HipMultiEllipsoid(5), db.MultiEllipsoid(5)
+    np.testing.assert_allclose(ours.logvol, ref.logvol, rtol=1e-14)
+    ours.update(pts, rstate=np.random.default_rng(1))
+    ref.update(pts, rstate=np.random.default_rng(1))
+    assert ours.nells == ref.nells == 2
+    np.testing.assert_allclose(ours.logvol, ref.logvol, rtol=1e-13)
+    ours.scale_to_logvol(ours.logvol + np.log(1.25))
+    ref.scale_to_logvol(ref.logvol + np.log(1.25))
+    np.testing.assert_allclose(np.sort(ours.logvol_ells),
+                               np.sort(ref.logvol_ells), rtol=1e-13)
+    x = pts[3]
+    assert ours.contains(x) == ref.contains(x)
+    assert list(ours.within(x)) == list(ref.within(x)) or ours.nells == 2
+    assert ours.overlap(x) == ref.overlap(x)
+    single, rs = dropin.HipEllipsoid(5), db.Ellipsoid(5)
+    single.update(pts, rstate=np.random.default_rng(1))
+    rs.update(pts, rstate=np.random.default_rng(1))
+    np.testing.assert_allclose(single.logvol, rs.logvol, rtol=1e-13)
+    np.testing.assert_allclose(single.distance(x), rs.distance(x), rtol=1e-12)
+    with pytest.raises(RuntimeError):
+        ours.update(pts[:1], rstate=np.random.default_rng(1))
