@@ -4,14 +4,21 @@ on MI355X (contract: see the round prompt; metric from BASELINE.json).
 
 Workload (config.workload): BASELINE config C2 -- 25-D rho=0.4 correlated
 Normal, nlive=2000, bound='multi', sample='rwalk' (walks = 45) -- as `runs`
-independent runs per GPU (the per-GPU shard of the C5 ensemble; 64 by default).
-One *step* = one pass of the hot path for every run of the shard with all
-inputs resident in HBM:  K = nlive walkers x `walks` rwalk proposals each
-(in-kernel PCG64/ziggurat draws, frame mat-vec, prior transform, Gaussian
-log-likelihood, accept test) = one bound-update interval of the reference
-(update_interval = walks * nlive calls, dynesty.py:213-232).
+independent runs per GPU (64 = one GPU's shard of the C5 ensemble of 512 runs
+on 8 GPUs).  One *step* = one pass of the hot path for every run of the shard,
+all inputs resident in HBM:
 
-value = proposals/s over all GPUs (weak scaling: per-GPU work fixed).
+  1. MultiEllipsoid.update on each run's live set        (rebuild kernel)
+  2. scale_to_logvol(logvol + ln 1.25)                   (enlarge kernel)
+  3. K = nlive walkers x `walks` rwalk proposals per run against the rebuilt,
+     enlarged ellipsoid frame (in-kernel PCG64/ziggurat draws, frame mat-vec,
+     prior transform, Gaussian log-likelihood, accept test)
+
+i.e. exactly one bound-update interval of the reference
+(update_interval = walks * nlive = 90 000 calls, dynesty.py:213-232).
+
+value = proposals/s over all GPUs (weak scaling: per-GPU work fixed);
+config.rebuilds_per_s is the second half of BASELINE.json's metric.
 Tap point: (A) kernel boundary.
 """
 import argparse
@@ -28,43 +35,42 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 FP64_PEAK_TFLOPS = 78.6  # vector fp64 (datasheet)
+MAX_ELLS = 8
 
 
 def make_shard(prob, runs, nlive, seed):
-    """Synthetic live sets: points of a C2 posterior shell, their frame, and a
-    likelihood threshold at the 10% quantile (so proposals are genuinely
-    accepted/rejected)."""
+    """Synthetic live sets: `runs` clouds of nlive points drawn from a C2
+    posterior shell (N(0, s^2 Sigma) in parameter space, mapped to the unit
+    cube) and a likelihood threshold at their 10% quantile, so proposals are
+    genuinely accepted and rejected."""
     d = prob.ndim
     rng = np.random.default_rng(seed)
     cov = np.full((d, d), 0.4)
     np.fill_diagonal(cov, 1.0)
     lam, vec = np.linalg.eigh(cov)
     hw = prob.prior_par[0]
-    # live points ~ N(0, s^2 cov) in v, mapped to the unit cube
     s = 0.6
     z = rng.standard_normal((runs * nlive, d))
     v = s * (z * np.sqrt(lam)) @ vec.T
     u0 = 0.5 + v / (2 * hw)
     logl = prob.loglikelihood_many(prob.prior_transform_many(u0))
-    logl = logl.reshape(runs, nlive)
     loglstar = float(np.quantile(logl, 0.10))
-    # bounding-ellipsoid-like frame in cube units: axes = V sqrt(lam) * r
-    radius = s * math.sqrt(d + 2 * math.sqrt(2 * d)) / (2 * hw) * 1.08
-    axes = (vec * np.sqrt(lam)) * radius
-    return u0, axes, loglstar
+    return u0, loglstar
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--runs", type=int, default=64,
                     help="independent C2 runs per GPU (C5 shard = 64)")
     ap.add_argument("--nlive", type=int, default=2000)
     ap.add_argument("--walks", type=int, default=45)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-rebuild", action="store_true",
+                    help="time the proposal kernel alone (diagnostic)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -72,42 +78,73 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
     dist = None
+    torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl",
+                                device_id=torch.device("cuda", local_rank))
 
     from dynesty_amd import _lib, problems
     ctx = _lib.Context(local_rank)
-    lib = ctx.lib
+    lib, h = ctx.lib, ctx.handle
     prob = problems.gauss_corr(25, 0.4, 5.0, "C2")
     d = prob.ndim
-    k = args.runs * args.nlive
-    u0, axes, loglstar = make_shard(prob, args.runs, args.nlive, 1000 + rank)
+    runs, nlive = args.runs, args.nlive
+    k = runs * nlive
+    u0, loglstar = make_shard(prob, runs, nlive, 1000 + rank)
     scale = 0.35
+    log_enlarge = math.log(1.25)
 
-    # resident device buffers
-    h = ctx.handle
-    d_u0 = ctx.to_device(u0)
-    d_axes = ctx.to_device(axes)
-    ent = [21, rank, 0, 0]
-    states = ctx.seed_children(ent, 0, k)
+    # ---- resident device buffers ----
+    d_u0 = ctx.to_device(u0)  # live sets == walker start points
+    idx = (np.arange(k, dtype=np.int32) // nlive) * MAX_ELLS
+    d_idx = ctx.to_device(idx)
+    states = ctx.seed_children([21, rank, 0, 0], 0, k)
     d_rng = ctx.to_device(states)
-    d_u = ctx.malloc(k * d * 8)
-    d_v = ctx.malloc(k * d * 8)
+    d_rng2 = ctx.malloc(k * 32)
+    d_u, d_v = ctx.malloc(k * d * 8), ctx.malloc(k * d * 8)
     d_logl = ctx.malloc(k * 8)
-    d_na = ctx.malloc(k * 4)
-    d_nr = ctx.malloc(k * 4)
-    d_rng_out = ctx.malloc(k * 32)
+    d_na, d_nr = ctx.malloc(k * 4), ctx.malloc(k * 4)
+    me = MAX_ELLS
+    d_nells, d_status = ctx.malloc(runs * 4), ctx.malloc(runs * 4)
+    d_ctrs = ctx.malloc(runs * me * d * 8)
+    d_covs = ctx.malloc(runs * me * d * d * 8)
+    d_ams = ctx.malloc(runs * me * d * d * 8)
+    d_axes = ctx.malloc(runs * me * d * d * 8)
+    d_axl = ctx.malloc(runs * me * d * 8)
+    d_lv = ctx.malloc(runs * me * 8)
     ph = ctx.problem(prob)
 
-    def step(rng_in, rng_out):
-        rc = lib.dh_rwalk_batch_dev(h, ph, k, d, d, d_u0, d_axes, 1, None,
-                                    scale, loglstar, args.walks, None, rng_in,
-                                    d_u, d_v, d_logl, d_na, d_nr, rng_out)
-        ctx._check(rc)
+    ev = [ctx.event() for _ in range(4)]
+    t_rb = t_wk = 0.0
+
+    def rebuild():
+        ctx._check(lib.dh_rebuild_batch_dev(h, runs, d_u0, nlive, d, 0, me,
+                                            d_nells, d_status, d_ctrs, d_covs,
+                                            d_ams, d_axes, d_axl, d_lv, None,
+                                            None))
+        ctx._check(lib.dh_enlarge_batch_dev(h, runs, me, d_nells, d, d_covs,
+                                            d_ams, d_axes, d_axl, d_lv,
+                                            log_enlarge))
+
+    def walk(i):
+        a, b = (d_rng, d_rng2) if i % 2 == 0 else (d_rng2, d_rng)
+        ctx._check(lib.dh_rwalk_batch_dev(h, ph, k, d, d, d_u0, d_axes,
+                                          runs * me, d_idx, scale, loglstar,
+                                          args.walks, None, a, d_u, d_v,
+                                          d_logl, d_na, d_nr, b))
+
+    def step(i, timed=False):
+        nonlocal t_rb, t_wk
+        if timed:
+            ctx.record(ev[0])
+        if not args.no_rebuild:
+            rebuild()
+        if timed:
+            ctx.record(ev[1])
+        walk(i)
+        if timed:
+            ctx.record(ev[2])
 
     def barrier():
         if dist is not None:
@@ -115,43 +152,56 @@ def main():
         torch.cuda.synchronize()
         ctx.sync()
 
+    rebuild()  # frames must exist even with --no-rebuild
     for i in range(args.warmup):
-        step(d_rng if i % 2 == 0 else d_rng_out, d_rng_out if i % 2 == 0 else d_rng)
+        step(i)
     barrier()
-    ev0, ev1 = ctx.event(), ctx.event()
     t0 = time.perf_counter()
-    ctx.record(ev0)
+    ctx.record(ev[3])
     for i in range(args.steps):
-        # streams continue from step to step (ping-pong the state buffers)
-        step(d_rng if i % 2 == 0 else d_rng_out, d_rng_out if i % 2 == 0 else d_rng)
-    ctx.record(ev1)
+        step(i)
+    ctx.record(ev[0])
     barrier()
-    t1 = time.perf_counter()
-    wall = t1 - t0
-    kern_ms = ctx.elapsed_ms(ev0, ev1) / args.steps
+    wall = time.perf_counter() - t0
+    dev_ms = ctx.elapsed_ms(ev[3], ev[0]) / args.steps
     if dist is not None:
         t = torch.tensor([wall], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
 
+    # per-kernel durations (HIP events on the launch stream), outside the
+    # timed region so the event records do not perturb it
+    nrep = 3
+    for i in range(nrep):
+        step(i, timed=True)
+        ctx.sync()
+        t_rb += ctx.elapsed_ms(ev[0], ev[1])
+        t_wk += ctx.elapsed_ms(ev[1], ev[2])
+    t_rb /= nrep
+    t_wk /= nrep
+
     nacc = ctx.from_device(d_na, (k,), np.int32)
     nrej = ctx.from_device(d_nr, (k,), np.int32)
+    status = ctx.from_device(d_status, (runs,), np.int32)
+    nells = ctx.from_device(d_nells, (runs,), np.int32)
     assert np.all(nacc + nrej == args.walks)
+    assert np.all(status == 0), status
     props_per_step_rank = k * args.walks
     value = world * props_per_step_rank * args.steps / wall
 
-    # ensemble exchange step (C5): gather one record per run over RCCL
+    # ensemble exchange step (C5): one record per run gathered over RCCL
     if dist is not None:
-        rec = torch.tensor(nacc.reshape(args.runs, -1).mean(1), device="cuda")
+        rec = torch.tensor(nacc.reshape(runs, -1).mean(1), device="cuda")
         out = [torch.empty_like(rec) for _ in range(world)]
         dist.all_gather(out, rec)
 
     if rank == 0:
         alg_bytes = 8 * (2 * d + 1)  # read u, write u', write logl
         flops = 2 * d * d + 8 * d + (d * d + 3 * d)  # frame mat-vec + sym. quad form
-        achieved = props_per_step_rank * alg_bytes / (kern_ms * 1e-3) / 1e9
+        achieved = props_per_step_rank * alg_bytes / (t_wk * 1e-3) / 1e9
         line = {
-            "metric": "proposals/sec (25-D corr-Normal nlive=2000 multi/rwalk)",
+            "metric": "proposals/sec + ellipsoid-rebuilds/sec, 25-D corr-Normal "
+                      "nlive=2000 (multi/rwalk)",
             "value": value,
             "unit": "proposals/s",
             "n_gpus": world,
@@ -164,48 +214,78 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"C2 x {args.runs} independent runs per GPU "
-                            f"(C5 shard): K={args.nlive} walkers x "
-                            f"{args.walks} rwalk steps per run per step",
-                "ndim": d, "nlive": args.nlive, "walks": args.walks,
-                "runs_per_gpu": args.runs, "tap_point": "A (kernel boundary)",
+                "workload": f"C2 x {runs} independent runs per GPU (C5 shard); "
+                            f"per step and run: 1 MultiEllipsoid rebuild + "
+                            f"enlarge 1.25 + K={nlive} walkers x {args.walks} "
+                            f"rwalk steps (= one bound-update interval)",
+                "ndim": d, "nlive": nlive, "walks": args.walks,
+                "runs_per_gpu": runs, "tap_point": "A (kernel boundary)",
+                "rebuild_in_step": not args.no_rebuild,
+                "rebuilds_per_s": (0.0 if args.no_rebuild else
+                                   world * runs * args.steps / wall),
+                "rebuild_kernel_ms": t_rb, "rwalk_kernel_ms": t_wk,
+                "device_ms_per_step": dev_ms,
+                "proposals_per_s_rwalk_kernel_only":
+                    world * props_per_step_rank / (t_wk * 1e-3),
+                "rebuilds_per_s_rebuild_kernel_only":
+                    world * runs / (t_rb * 1e-3) if t_rb > 0 else None,
+                "nells_per_run": float(nells.mean()),
                 "accept_frac": float(nacc.sum() / (k * args.walks)),
             },
             "roofline": {
-                "bound": "hbm", "kernel": "rwalk_kernel<25,true>",
+                "bound": "hbm", "kernel": "rwalk_kernel<25,true,PREC_AFFINE>",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "kernel_ms": kern_ms,
+                "kernel_ms": t_wk,
+                "note": "algorithmic bytes = 408 B/proposal (SURVEY 8d); walker "
+                        "state stays in registers for all 45 steps, so the "
+                        "binding roof is fp64 VALU, reported below",
                 "fp64_valu": {
-                    "achieved": props_per_step_rank * flops / (kern_ms * 1e-3) / 1e12,
+                    "achieved": props_per_step_rank * flops / (t_wk * 1e-3) / 1e12,
                     "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s"},
             },
         }
         if not args.no_cpu:
-            line["cpu_baseline"] = cpu_baseline(prob, u0, axes, scale, loglstar,
-                                                args.walks, args.cpu_seconds)
+            line["cpu_baseline"] = cpu_baseline(prob, u0, nlive, scale,
+                                                loglstar, args.walks,
+                                                args.cpu_seconds)
         print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()
 
 
-def cpu_baseline(prob, u0, axes, scale, loglstar, walks, budget_s):
-    """The oracle (NumPy restatement of the reference's RWalkSampler.sample)
-    timed on one host core on a bounded sample of the same workload."""
+def cpu_baseline(prob, u0, nlive, scale, loglstar, walks, budget_s):
+    """The oracle (NumPy restatement of the reference's MultiEllipsoid.update +
+    RWalkSampler.sample) timed on one host core on a bounded sample of the same
+    workload: one rebuild of run 0's live set, then walkers until the budget is
+    spent; proposals/s is scaled to the reference cadence of one rebuild per
+    nlive*walks proposals."""
+    from oracle import bounding_ref as B
     from oracle import proposals_ref as P
+    pts = u0[:nlive]
+    t0 = time.perf_counter()
+    mell = B.multi_update(pts)
+    mell = B.scale_multi_to_logvol(mell, mell.logvol + math.log(1.25))
+    t_rebuild = time.perf_counter() - t0
+    axes = mell.ells[0].axes
     kids = np.random.SeedSequence(99).spawn(100000)
     t0 = time.perf_counter()
     n = 0
     while time.perf_counter() - t0 < budget_s:
         rng = np.random.Generator(np.random.PCG64(kids[n]))
-        P.rwalk(u0[n].copy(), loglstar, axes, scale, prob.prior_transform,
-                prob.loglikelihood, rng, walks)
+        P.rwalk(u0[n % len(u0)].copy(), loglstar, axes, scale,
+                prob.prior_transform, prob.loglikelihood, rng, walks)
         n += 1
     dt = time.perf_counter() - t0
-    return {"value": n * walks / dt, "unit": "proposals/s", "cores": 1,
+    per_prop = dt / (n * walks)
+    combined = 1.0 / (per_prop + t_rebuild / (nlive * walks))
+    return {"value": combined, "unit": "proposals/s", "cores": 1,
             "kind": "port",
-            "sample": f"{n} walkers x {walks} steps of the same C2 shard "
-                      f"({dt:.1f} s, oracle/proposals_ref.rwalk, 1 thread)"}
+            "rebuilds_per_s": 1.0 / t_rebuild,
+            "proposals_per_s_walk_only": 1.0 / per_prop,
+            "sample": f"1 rebuild of a {nlive}x{prob.ndim} live set "
+                      f"({t_rebuild * 1e3:.0f} ms) + {n} walkers x {walks} steps "
+                      f"({dt:.1f} s), oracle/ (NumPy/SciPy restatement), 1 thread"}
 
 
 if __name__ == "__main__":

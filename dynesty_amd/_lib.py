@@ -67,6 +67,8 @@ SIGNATURES = {
                                   _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dh_ell_from_cov": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "dh_scale_to_logvol": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dh_enlarge_batch_dev": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp,
+                                  _dbl]),
     "dh_rwalk_batch": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _dbl, _dbl,
                             _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dh_rwalk_batch_dev": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _dbl,

@@ -65,6 +65,22 @@ struct RebuildArgs {
   int* nnodes_out;    // runs or null
 };
 
+#ifdef DH_REBUILD_TIMING
+__device__ long long g_phase_cycles[16];
+#define PH_T0() long long t0_ = clock64()
+#define PH_ADD(i)                                                      \
+  do {                                                                 \
+    if (threadIdx.x == 0 && blockIdx.x == 0) {                         \
+      long long t1_ = clock64();                                       \
+      g_phase_cycles[i] += t1_ - t0_;                                  \
+      t0_ = t1_;                                                       \
+    }                                                                  \
+  } while (0)
+#else
+#define PH_T0()
+#define PH_ADD(i)
+#endif
+
 // ---- LDS carve-up ----------------------------------------------------------
 struct Lds {
   double* tile;   // TP x LD
@@ -82,7 +98,7 @@ struct Lds {
   double* rs;     // 64
   int* ri;        // 256 ints (pair indices, scan scratch, ...)
   int* perm_sort; // D
-  int TP, LD;
+  int TP, LD, DP, DPlog;
 };
 
 __device__ __forceinline__ void wave_sync() {
@@ -124,31 +140,40 @@ __device__ __forceinline__ int block_reduce_sum_int(int v, int* red) {
 // Returns false if the matrix contains non-finite entries.
 __device__ bool jacobi_wave(double* A, double* V, int D, int LD, double* rc, double* rs, int* rp) {
   const int lane = threadIdx.x & 63;
+  // power-of-two lane maps (no integer division in the hot loops):
+  //   (row i, column j): j = lane & (JW-1), i strides by 64/JW
+  //   (row i, pair k):   k = lane & (KW-1), i strides by 64/KW
+  const int m = (D + 1) / 2;  // pairs per round
+  int JW = 1;
+  while (JW < D) JW <<= 1;  // <= 64
+  int KW = 1;
+  while (KW < m) KW <<= 1;  // <= 32
+  const int jj = lane & (JW - 1), i0j = lane / JW, istepj = 64 / JW;
+  const int kk = lane & (KW - 1), i0k = lane / KW, istepk = 64 / KW;
   // V = I ; finiteness check
   bool ok = true;
-  for (int e = lane; e < D * D; e += 64) {
-    const int i = e / D, j = e % D;
-    V[i * LD + j] = (i == j) ? 1.0 : 0.0;
-    if (!isfinite(A[i * LD + j])) ok = false;
-  }
+  if (jj < D)
+    for (int i = i0j; i < D; i += istepj) {
+      V[i * LD + jj] = (i == jj) ? 1.0 : 0.0;
+      if (!isfinite(A[i * LD + jj])) ok = false;
+    }
   ok = __all(ok);
   wave_sync();
   if (!ok) return false;
   if (D == 1) return true;
-  const int m = (D + 1) / 2;  // pairs per round
   const int P = 2 * m;        // players (last one is a bye when D is odd)
   const int rounds = P - 1;
   for (int sweep = 0; sweep < 60; ++sweep) {
     // convergence: off-diagonal mass vs diagonal mass
     double off = 0.0, dia = 0.0;
-    for (int e = lane; e < D * D; e += 64) {
-      const int i = e / D, j = e % D;
-      const double a = A[i * LD + j];
-      if (i == j)
-        dia = fma(a, a, dia);
-      else
-        off = fma(a, a, off);
-    }
+    if (jj < D)
+      for (int i = i0j; i < D; i += istepj) {
+        const double a = A[i * LD + jj];
+        if (i == jj)
+          dia = fma(a, a, dia);
+        else
+          off = fma(a, a, off);
+      }
     for (int s = 32; s > 0; s >>= 1) {
       off += __shfl_xor(off, s);
       dia += __shfl_xor(dia, s);
@@ -162,8 +187,10 @@ __device__ bool jacobi_wave(double* A, double* V, int D, int LD, double* rc, dou
           p = P - 1;
           q = r;
         } else {
-          p = (r + lane) % (P - 1);
-          q = (r - lane + (P - 1)) % (P - 1);
+          p = r + lane;
+          if (p >= P - 1) p -= P - 1;
+          q = r - lane;
+          if (q < 0) q += P - 1;
         }
         if (p > q) {
           const int tmp = p;
@@ -189,32 +216,33 @@ __device__ bool jacobi_wave(double* A, double* V, int D, int LD, double* rc, dou
         rp[64 + lane] = q;
       }
       wave_sync();
-      // columns: A <- A J, V <- V J
-      for (int e = lane; e < D * m; e += 64) {
-        const int i = e / m, k = e % m;
-        const int p = rp[k], q = rp[64 + k];
+      // columns: A <- A J, V <- V J      items (i, k)
+      if (kk < m) {
+        const int p = rp[kk], q = rp[64 + kk];
         if (p >= 0) {
-          const double c = rc[k], s = rs[k];
-          const double aip = A[i * LD + p], aiq = A[i * LD + q];
-          A[i * LD + p] = c * aip - s * aiq;
-          A[i * LD + q] = s * aip + c * aiq;
-          const double vip = V[i * LD + p], viq = V[i * LD + q];
-          V[i * LD + p] = c * vip - s * viq;
-          V[i * LD + q] = s * vip + c * viq;
+          const double c = rc[kk], s = rs[kk];
+          for (int i = i0k; i < D; i += istepk) {
+            const double aip = A[i * LD + p], aiq = A[i * LD + q];
+            A[i * LD + p] = c * aip - s * aiq;
+            A[i * LD + q] = s * aip + c * aiq;
+            const double vip = V[i * LD + p], viq = V[i * LD + q];
+            V[i * LD + p] = c * vip - s * viq;
+            V[i * LD + q] = s * vip + c * viq;
+          }
         }
       }
       wave_sync();
-      // rows: A <- J^T A
-      for (int e = lane; e < D * m; e += 64) {
-        const int k = e / D, j = e % D;
-        const int p = rp[k], q = rp[64 + k];
-        if (p >= 0) {
-          const double c = rc[k], s = rs[k];
-          const double apj = A[p * LD + j], aqj = A[q * LD + j];
-          A[p * LD + j] = c * apj - s * aqj;
-          A[q * LD + j] = s * apj + c * aqj;
+      // rows: A <- J^T A                 items (k, j)
+      if (jj < D)
+        for (int k = i0j; k < m; k += istepj) {
+          const int p = rp[k], q = rp[64 + k];
+          if (p >= 0) {
+            const double c = rc[k], s = rs[k];
+            const double apj = A[p * LD + jj], aqj = A[q * LD + jj];
+            A[p * LD + jj] = c * apj - s * aqj;
+            A[q * LD + jj] = s * apj + c * aqj;
+          }
         }
-      }
       wave_sync();
       if (lane < m && rp[lane] >= 0) {
         const int p = rp[lane], q = rp[64 + lane];
@@ -222,6 +250,127 @@ __device__ bool jacobi_wave(double* A, double* V, int D, int LD, double* rc, dou
         A[q * LD + p] = 0.0;
       }
       wave_sync();
+    }
+  }
+  return true;
+}
+
+// Whole-workgroup form of the same solver (all kThreads threads, 3 barriers per
+// round): used inside the rebuild kernel where the eigenproblem is on the
+// critical path of every tree node.
+__device__ bool jacobi_block(double* A, double* V, int D, int LD, double* rc, double* rs, int* rp,
+                             double* red) {
+  const int t = threadIdx.x;
+  const int m = (D + 1) / 2;
+  int JW = 1, JWl = 0;
+  while (JW < D) {
+    JW <<= 1;
+    ++JWl;
+  }
+  int KW = 1, KWl = 0;
+  while (KW < m) {
+    KW <<= 1;
+    ++KWl;
+  }
+  const int jj = t & (JW - 1), i0j = t >> JWl, istepj = kThreads >> JWl;
+  const int kk = t & (KW - 1), i0k = t >> KWl, istepk = kThreads >> KWl;
+  bool bad = false;
+  if (jj < D)
+    for (int i = i0j; i < D; i += istepj) {
+      V[i * LD + jj] = (i == jj) ? 1.0 : 0.0;
+      if (!isfinite(A[i * LD + jj])) bad = true;
+    }
+  if (__syncthreads_or(bad ? 1 : 0)) return false;
+  if (D == 1) return true;
+  const int P = 2 * m;
+  const int rounds = P - 1;
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    double off = 0.0, dia = 0.0;
+    if (jj < D)
+      for (int i = i0j; i < D; i += istepj) {
+        const double a = A[i * LD + jj];
+        if (i == jj)
+          dia = fma(a, a, dia);
+        else
+          off = fma(a, a, off);
+      }
+    for (int s = 32; s > 0; s >>= 1) {
+      off += __shfl_xor(off, s);
+      dia += __shfl_xor(dia, s);
+    }
+    if ((t & 63) == 0) {
+      red[t >> 6] = off;
+      red[8 + (t >> 6)] = dia;
+    }
+    __syncthreads();
+    off = red[0] + red[1] + red[2] + red[3];
+    dia = red[8] + red[9] + red[10] + red[11];
+    __syncthreads();
+    if (!(off > 1e-31 * dia)) break;
+    for (int r = 0; r < rounds; ++r) {
+      if (t < m) {
+        int p, q;
+        if (t == 0) {
+          p = P - 1;
+          q = r;
+        } else {
+          p = r + t;
+          if (p >= P - 1) p -= P - 1;
+          q = r - t;
+          if (q < 0) q += P - 1;
+        }
+        if (p > q) {
+          const int tmp = p;
+          p = q;
+          q = tmp;
+        }
+        double c = 1.0, sn = 0.0;
+        if (q < D) {
+          const double apq = A[p * LD + q];
+          if (apq != 0.0) {
+            const double app = A[p * LD + p], aqq = A[q * LD + q];
+            const double tau = (aqq - app) / (2.0 * apq);
+            const double tt = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(fma(tau, tau, 1.0)));
+            c = 1.0 / sqrt(fma(tt, tt, 1.0));
+            sn = tt * c;
+          }
+        } else {
+          p = -1;
+        }
+        rc[t] = c;
+        rs[t] = sn;
+        rp[t] = p;
+        rp[64 + t] = q;
+      }
+      __syncthreads();
+      // columns: A <- A J, V <- V J
+      if (kk < m) {
+        const int p = rp[kk], q = rp[64 + kk];
+        if (p >= 0) {
+          const double c = rc[kk], sn = rs[kk];
+          for (int i = i0k; i < D; i += istepk) {
+            const double aip = A[i * LD + p], aiq = A[i * LD + q];
+            A[i * LD + p] = c * aip - sn * aiq;
+            A[i * LD + q] = sn * aip + c * aiq;
+            const double vip = V[i * LD + p], viq = V[i * LD + q];
+            V[i * LD + p] = c * vip - sn * viq;
+            V[i * LD + q] = sn * vip + c * viq;
+          }
+        }
+      }
+      __syncthreads();
+      // rows: A <- J^T A ; the rotated (p,q) element is set to exactly zero
+      if (jj < D)
+        for (int k = i0j; k < m; k += istepj) {
+          const int p = rp[k], q = rp[64 + k];
+          if (p >= 0) {
+            const double c = rc[k], sn = rs[k];
+            const double apj = A[p * LD + jj], aqj = A[q * LD + jj];
+            A[p * LD + jj] = (jj == q) ? 0.0 : c * apj - sn * aqj;
+            A[q * LD + jj] = (jj == p) ? 0.0 : sn * apj + c * aqj;
+          }
+        }
+      __syncthreads();
     }
   }
   return true;
@@ -270,13 +419,19 @@ __device__ void sort_eigs_wave(const double* A, double* V, double* lam, int* ord
 __device__ __forceinline__ void stage_tile(const Lds& L, const double* __restrict__ pts,
                                            const int* __restrict__ perm, int start, int cnt, int D,
                                            int how) {
-  const int tot = cnt * D;
-  for (int e = threadIdx.x; e < tot; e += kThreads) {
-    const int p = e / D, j = e - p * D;
-    double x = pts[(size_t)perm[start + p] * D + j];
-    if (how == 1) x -= L.mean[j];
-    if (how == 2) x = x / L.scale[j];
-    L.tile[p * L.LD + j] = x;
+  // column j = t & (DP-1) (DP = pow2 >= D), rows stride by kThreads/DP: consecutive lanes
+  // read consecutive doubles of one point (coalesced), no integer division.
+  const int j = threadIdx.x & (L.DP - 1);
+  const int p0 = threadIdx.x >> L.DPlog, pstep = kThreads >> L.DPlog;
+  if (j < D) {
+    const double mj = how == 1 ? L.mean[j] : 0.0;
+    const double sj = how == 2 ? L.scale[j] : 1.0;
+    for (int p = p0; p < cnt; p += pstep) {
+      double x = pts[(size_t)perm[start + p] * D + j];
+      if (how == 1) x -= mj;
+      if (how == 2) x = x / sj;
+      L.tile[p * L.LD + j] = x;
+    }
   }
   __syncthreads();
 }
@@ -409,13 +564,12 @@ __device__ double node_fmax(const Lds& L, const double* pts, const int* perm, in
 __device__ __forceinline__ void mat_from_eig(const Lds& L, double* out, const double* lamv, int D,
                                              bool inverse) {
   // out = (V * w) V^T with w = lam or 1/lam   ((eigvec * x) @ eigvec.T)
+  if (threadIdx.x < D) L.red[threadIdx.x] = inverse ? 1.0 / lamv[threadIdx.x] : lamv[threadIdx.x];
+  __syncthreads();
   for (int e = threadIdx.x; e < D * D; e += kThreads) {
     const int i = e / D, j = e % D;
     double s = 0.0;
-    for (int k = 0; k < D; ++k) {
-      const double w = inverse ? 1.0 / lamv[k] : lamv[k];
-      s = fma(L.V[i * L.LD + k] * w, L.V[j * L.LD + k], s);
-    }
+    for (int k = 0; k < D; ++k) s = fma(L.V[i * L.LD + k] * L.red[k], L.V[j * L.LD + k], s);
     out[i * L.LD + j] = s;
   }
   __syncthreads();
@@ -434,13 +588,9 @@ __device__ bool regularize(const Lds& L, double* cov, int D) {
     // eigh(cov): copy into A, solve with wave 0
     for (int e = t; e < D * D; e += kThreads) L.A[(e / D) * L.LD + e % D] = cov[(e / D) * L.LD + e % D];
     __syncthreads();
-    if (t < 64) {
-      bool fin = jacobi_wave(L.A, L.V, D, L.LD, L.rc, L.rs, L.ri);
-      if (fin) sort_eigs_wave(L.A, L.V, L.lam, L.perm_sort, L.AX, D, L.LD);
-      if (t == 0) L.ri[300] = fin ? 1 : 0;
-    }
+    const bool fin = jacobi_block(L.A, L.V, D, L.LD, L.rc, L.rs, L.ri, L.red);
+    if (fin && t < 64) sort_eigs_wave(L.A, L.V, L.lam, L.perm_sort, L.AX, D, L.LD);
     __syncthreads();
-    const bool fin = L.ri[300] != 0;
     double top = -INFINITY, bot = INFINITY;
     bool allfin = fin;
     if (fin) {
@@ -507,15 +657,20 @@ __device__ int node_ellipsoid(const Lds& L, const RebuildArgs& a, const double* 
                               int start, int count, double* es, double* cov_g, double* logvol_out) {
   const int D = a.d, t = threadIdx.x, LD = L.LD;
   if (count == 1) return DH_ERR_VALUE;
+  PH_T0();
   node_mean(L, pts, perm, start, count, D);
+  PH_ADD(0);
   node_cov(L, pts, perm, start, count, D);
+  PH_ADD(1);
   // cov_g: this node's D x LD working covariance (global scratch, L2 resident)
   for (int e = t; e < D * D; e += kThreads) cov_g[(e / D) * LD + e % D] = L.A[(e / D) * LD + e % D];
   __syncthreads();
   const double lim = 1.0 - kRoundDelta;
   for (int pass = 0; pass < 2; ++pass) {
     const bool good = regularize(L, cov_g, D);
+    PH_ADD(2);
     const double fmx = node_fmax(L, pts, perm, start, count, D);
+    PH_ADD(3);
     if (pass == 0 && fmx > lim) {
       const double mult = fmx / lim;
       const double rt = sqrt(mult);
@@ -703,6 +858,12 @@ __global__ void __launch_bounds__(kThreads) rebuild_kernel(RebuildArgs a) {
   Lds L;
   L.LD = D | 1;  // odd leading dimension: conflict-free column walks
   L.TP = kThreads;
+  L.DP = 1;
+  L.DPlog = 0;
+  while (L.DP < D) {
+    L.DP <<= 1;
+    ++L.DPlog;
+  }
   {
     double* p = (double*)smem;
     L.tile = p;
@@ -781,7 +942,9 @@ __global__ void __launch_bounds__(kThreads) rebuild_kernel(RebuildArgs a) {
       const int start = nodes[cur].start, count = nodes[cur].count, depth = nodes[cur].depth;
       if (count < 2 * min_size) continue;  // too small to try a split (:1492-1496)
       const double* es = estore + (size_t)cur * NS;
+      PH_T0();
       const int n0 = node_kmeans(L, pts, perm, lab, start, count, D, es);
+      PH_ADD(4);
       const int n1 = count - n0;
       if (min(n0, n1) < min_size) continue;  // reject the split (:1521-1522)
       if (nnodes + 2 > a.max_nodes) {
@@ -789,6 +952,7 @@ __global__ void __launch_bounds__(kThreads) rebuild_kernel(RebuildArgs a) {
         break;
       }
       node_partition(L, perm, perm2, lab, start, count, n0);
+      PH_ADD(5);
       const int c0 = nnodes, c1 = nnodes + 1;
       double lv0 = 0.0, lv1 = 0.0;
       int rc = node_ellipsoid(L, a, pts, perm, start, n0, estore + (size_t)c0 * NS,
@@ -1011,18 +1175,23 @@ __global__ void __launch_bounds__(64)
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(64)
     scale_logvol_kernel(int m, int D, double* covs, double* ams, double* axes, double* axlens,
-                        double* logvols, const double* __restrict__ targets) {
+                        double* logvols, const double* __restrict__ targets, double shift,
+                        const int* __restrict__ nells, int stride) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double* fax = (double*)smem;  // D
   double* lax = fax + D;        // D  log axlens
   int* iso = (int*)(lax + D);
   const int e = blockIdx.x, lane = threadIdx.x;
   if (e >= m) return;
+  // batched form: slot e belongs to run e / stride and is live iff its index
+  // within the run is below that run's ellipsoid count
+  if (nells && (e % stride) >= nells[e / stride]) return;
   double* C = covs + (size_t)e * D * D;
   double* P = ams + (size_t)e * D * D;
   double* X = axes + (size_t)e * D * D;
   double* al = axlens + (size_t)e * D;
-  const double logf = targets[e] - logvols[e];
+  const double target = targets ? targets[e] : logvols[e] + shift;
+  const double logf = target - logvols[e];
   const double max_log_axlen = log(sqrt((double)D) / 2.0);
   for (int k = lane; k < D; k += 64) lax[k] = log(al[k]);
   wave_sync();
@@ -1081,7 +1250,7 @@ __global__ void __launch_bounds__(64)
     wave_sync();
     for (int k = lane; k < D; k += 64) al[k] *= fax[k];
   }
-  if (lane == 0) logvols[e] = targets[e];
+  if (lane == 0) logvols[e] = target;
 }
 
 size_t rebuild_lds_bytes(int D) {
@@ -1094,6 +1263,16 @@ size_t rebuild_lds_bytes(int D) {
 
 extern "C" {
 
+#ifdef DH_REBUILD_TIMING
+void dh_rebuild_timing(long long* out16, int reset) {
+  (void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_phase_cycles), 16 * sizeof(long long));
+  if (reset) {
+    long long z[16] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), z, sizeof z);
+  }
+}
+#endif
+
 // see include/dynhip.h
 int dh_rebuild_batch_dev(dh_ctx* ctx, int runs, const double* pts, int n, int d, int mode, int max_ells,
                          int32_t* nells, int32_t* status, double* ctrs, double* covs, double* ams,
@@ -1104,8 +1283,8 @@ int dh_rebuild_batch_dev(dh_ctx* ctx, int runs, const double* pts, int n, int d,
   if (!pts || n < 1 || d < 1 || max_ells < 1 || (mode != 0 && mode != 1))
     return fail(ctx, DH_ERR_ARG, "rebuild: bad arguments (n=%d d=%d mode=%d)", n, d, mode);
   const size_t lds = rebuild_lds_bytes(d);
-  if (lds > 160 * 1024)
-    return fail(ctx, DH_ERR_ARG, "rebuild: d=%d needs %zu B of LDS (> 160 KiB): wide-D path not built yet",
+  if (lds > 159 * 1024)
+    return fail(ctx, DH_ERR_ARG, "rebuild: d=%d needs %zu B of LDS (> 159 KiB): wide-D path not built yet",
                 d, lds);
   RebuildArgs a;
   a.pts = pts;
@@ -1158,11 +1337,14 @@ int dh_rebuild_batch_dev(dh_ctx* ctx, int runs, const double* pts, int n, int d,
   a.logvols = logvols;
   a.leaf_of_point = leaf_of_point;
   a.nnodes_out = nnodes;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)rebuild_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              160 * 1024);
-    attr_set = true;
+  static size_t attr_lds = 0;
+  if (lds > attr_lds) {
+    if (!hip_ok(ctx,
+                hipFuncSetAttribute((const void*)rebuild_kernel,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+                "hipFuncSetAttribute(rebuild LDS)"))
+      return DH_ERR_HIP;
+    attr_lds = lds;
   }
   hipLaunchKernelGGL(rebuild_kernel, dim3(runs), dim3(kThreads), lds, ctx->stream, a);
   return hip_ok(ctx, hipGetLastError(), "rebuild launch") ? DH_OK : DH_ERR_HIP;
@@ -1237,11 +1419,14 @@ int dh_ell_from_cov(dh_ctx* ctx, int m, int d, const double* covs, double* axes,
   int* d_st = (int*)arena_get(ctx, (size_t)m * 4);
   if (!d_c || !d_ax || !d_am || !d_al || !d_lv || !d_st) return DH_ERR_NOMEM;
   const double pre = d * log(2.0) + d * lgamma(1.5) - lgamma(d / 2.0 + 1.0);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)ell_from_cov_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              160 * 1024);
-    attr_set = true;
+  static size_t attr_lds = 0;
+  if (lds > attr_lds) {
+    if (!hip_ok(ctx,
+                hipFuncSetAttribute((const void*)ell_from_cov_kernel,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+                "hipFuncSetAttribute(ell_from_cov LDS)"))
+      return DH_ERR_HIP;
+    attr_lds = lds;
   }
   hipLaunchKernelGGL(ell_from_cov_kernel, dim3(m), dim3(64), lds, ctx->stream, m, d, d_c, pre, d_ax, d_al,
                      d_am, d_lv, d_st);
@@ -1256,6 +1441,19 @@ int dh_ell_from_cov(dh_ctx* ctx, int m, int d, const double* covs, double* axes,
     if (st[i] != DH_OK)
       return fail(ctx, DH_ERR_VALUE, "The input covariance of ellipsoid %d is singular or not finite", i);
   return DH_OK;
+}
+
+int dh_enlarge_batch_dev(dh_ctx* ctx, int runs, int max_ells, const int32_t* nells, int d, double* covs,
+                         double* ams, double* axes, double* axlens, double* logvols, double log_enlarge) {
+  DH_CHECK_CTX(ctx);
+  if (runs <= 0) return DH_OK;
+  if (!nells || !covs || !ams || !axes || !axlens || !logvols || d < 1 || max_ells < 1)
+    return fail(ctx, DH_ERR_ARG, "enlarge: bad arguments");
+  const int m = runs * max_ells;
+  hipLaunchKernelGGL(scale_logvol_kernel, dim3(m), dim3(64), (size_t)2 * d * 8 + 64, ctx->stream, m, d,
+                     covs, ams, axes, axlens, logvols, (const double*)nullptr, log_enlarge, nells,
+                     max_ells);
+  return hip_ok(ctx, hipGetLastError(), "enlarge launch") ? DH_OK : DH_ERR_HIP;
 }
 
 int dh_scale_to_logvol(dh_ctx* ctx, int m, int d, double* covs, double* ams, double* axes, double* axlens,
@@ -1276,7 +1474,7 @@ int dh_scale_to_logvol(dh_ctx* ctx, int m, int d, double* covs, double* ams, dou
   const double* d_t = arena_up(ctx, targets, (size_t)m);
   if (!d_c || !d_p || !d_x || !d_al || !d_lv || !d_t) return DH_ERR_NOMEM;
   hipLaunchKernelGGL(scale_logvol_kernel, dim3(m), dim3(64), (size_t)2 * d * 8 + 64, ctx->stream, m, d,
-                     d_c, d_p, d_x, d_al, d_lv, d_t);
+                     d_c, d_p, d_x, d_al, d_lv, d_t, 0.0, (const int*)nullptr, 1);
   if (!hip_ok(ctx, hipGetLastError(), "scale_to_logvol launch")) return DH_ERR_HIP;
   if (!down(ctx, covs, d_c, (size_t)m * dd) || !down(ctx, ams, d_p, (size_t)m * dd) ||
       !down(ctx, axes, d_x, (size_t)m * dd) || !down(ctx, axlens, d_al, (size_t)m * d) ||

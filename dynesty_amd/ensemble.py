@@ -1,0 +1,120 @@
+"""Many independent runs sharded over the GPUs of one node (BASELINE config C5).
+
+Runs share nothing: rank r -- one process per GPU,
+launched by torchrun / torch.distributed.run -- owns a contiguous block of run
+ids and executes them on its own device with no communication.  Seeds are
+derived from the *global* run id (``SeedSequence(base).spawn(total)[run]``), so
+results do not depend on the number of GPUs.  The only exchange step is at the
+end: one fixed-size record per run, all-gathered with RCCL over xGMI (backend
+"nccl" on ROCm; "gloo" in the CPU tests).  At 512 x 5 doubles = 20 KB the
+collective is latency bound; posterior samples stay sharded (they can be merged
+on the host with the reference's ``utils.merge_runs``) unless ``gather_ragged``
+is asked for them.
+"""
+import numpy as np
+
+RECORD_FIELDS = ("run", "logz", "logzerr", "niter", "ncall", "h")
+
+
+def shard_runs(total, world, rank):
+    """Contiguous block of run ids owned by `rank` (sizes differ by <= 1)."""
+    base, extra = divmod(int(total), int(world))
+    start = rank * base + min(rank, extra)
+    return range(start, start + base + (1 if rank < extra else 0))
+
+
+def run_seeds(base_seed, total):
+    """One SeedSequence child per global run id."""
+    return np.random.SeedSequence(base_seed).spawn(int(total))
+
+
+def gather_records(local, total, world, rank, dist=None, device=None):
+    """All-gather the per-run records (n_local x len(RECORD_FIELDS), float64;
+    column 0 is the global run id).  Returns the (total x nfield) table ordered
+    by run id on every rank.  With dist=None (single process) it is a sort."""
+    local = np.ascontiguousarray(local, dtype=np.float64).reshape(
+        -1, len(RECORD_FIELDS))
+    if dist is None or world == 1:
+        out = local
+    else:
+        import torch
+        nmax = -(-int(total) // int(world))  # ceil: equal-sized buffers
+        buf = np.full((nmax, local.shape[1]), np.nan)
+        buf[:len(local)] = local
+        t = torch.from_numpy(buf)
+        if device is not None:
+            t = t.to(device)
+        parts = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(parts, t)
+        out = np.concatenate([p.cpu().numpy() for p in parts])
+        out = out[~np.isnan(out[:, 0])]
+    out = out[np.argsort(out[:, 0], kind="stable")]
+    assert len(out) == total, (len(out), total)
+    return out
+
+
+def gather_ragged(arrays, world, rank, dist=None, device=None):
+    """Optional second exchange: gather variable-length (n_i, d) float64 arrays
+    (e.g. weighted posterior samples) as [counts all-gather, padded
+    all-gather].  Returns the list of arrays of every rank, in rank order."""
+    arrays = [np.ascontiguousarray(a, dtype=np.float64) for a in arrays]
+    if dist is None or world == 1:
+        return arrays
+    import torch
+    d = arrays[0].shape[1] if arrays else 0
+    flat = np.concatenate(arrays) if arrays else np.zeros((0, d))
+    counts = torch.tensor([len(a) for a in arrays] or [0], dtype=torch.int64)
+    meta = torch.tensor([len(arrays), len(flat), d], dtype=torch.int64)
+    if device is not None:
+        meta = meta.to(device)
+    metas = [torch.empty_like(meta) for _ in range(world)]
+    dist.all_gather(metas, meta)
+    metas = [m.cpu().numpy() for m in metas]
+    max_runs = max(int(m[0]) for m in metas) or 1
+    max_rows = max(int(m[1]) for m in metas) or 1
+    d = max(int(m[2]) for m in metas)
+    cbuf = torch.zeros(max_runs, dtype=torch.int64)
+    cbuf[:len(arrays)] = counts[:len(arrays)]
+    fbuf = torch.zeros((max_rows, d), dtype=torch.float64)
+    if len(flat):
+        fbuf[:len(flat)] = torch.from_numpy(flat)
+    if device is not None:
+        cbuf, fbuf = cbuf.to(device), fbuf.to(device)
+    call = [torch.empty_like(cbuf) for _ in range(world)]
+    fall = [torch.empty_like(fbuf) for _ in range(world)]
+    dist.all_gather(call, cbuf)
+    dist.all_gather(fall, fbuf)
+    out = []
+    for r in range(world):
+        c = call[r].cpu().numpy()[:int(metas[r][0])]
+        f = fall[r].cpu().numpy()
+        off = 0
+        for n in c:
+            out.append(f[off:off + int(n)].copy())
+            off += int(n)
+    return out
+
+
+def run_ensemble(prob, total_runs, base_seed=21, world=1, rank=0, dist=None,
+                 device=None, **run_kw):
+    """Run this rank's shard with ``nested.run_static`` and gather the records.
+    Returns (table, local_results)."""
+    from . import nested
+    seeds = run_seeds(base_seed, total_runs)
+    mine = shard_runs(total_runs, world, rank)
+    local, results = [], []
+    for rid in mine:
+        rng = np.random.Generator(np.random.PCG64(seeds[rid]))
+        r = nested.run_static(prob, rstate=rng, **run_kw)
+        results.append(r)
+        local.append([rid, r.logz, r.logzerr, r.niter, r.ncall, r.h])
+    table = gather_records(np.array(local).reshape(-1, len(RECORD_FIELDS)),
+                           total_runs, world, rank, dist=dist, device=device)
+    return table, results
+
+
+def combine_logz(table):
+    """Ensemble estimate: mean of ln Z over runs and its standard error."""
+    lz = table[:, RECORD_FIELDS.index("logz")]
+    return float(lz.mean()), float(lz.std(ddof=1) / np.sqrt(len(lz))) \
+        if len(lz) > 1 else float("nan")

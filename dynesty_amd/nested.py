@@ -1,0 +1,214 @@
+"""A compact static nested-sampling driver over the device hot path.
+
+This is the *caller* of the hot path, written so that end-to-end runs (logZ
+checks, ensemble benchmark) are possible where dynesty itself is not installed
+(the GPU box).  It follows the semantics of dynesty's static sampler with a
+proposal queue (reference sampler.py:932-1212 main loop, :676-778 queue
+handling, :625-674 bound-update policy, utils.py:1411-1492 evidence
+integration) but is an independent, much smaller implementation: static runs
+only, device problems only, no checkpointing, no dynamic batches.  With
+dynesty installed, use the drop-in classes of ``dynesty_amd.dropin`` instead.
+
+Semantics kept from the reference because they decide the statistics:
+  * K = queue_size proposals are generated against the same loglstar and
+    consumed one per iteration; a proposal whose logl no longer beats the
+    current loglstar is discarded (sampler.py:741-776);
+  * the run starts in the unit cube and switches to the bound once the
+    efficiency drops below 10% after 2*nlive calls (dynesty.py first_update
+    defaults); the bound is rebuilt every update_interval calls and enlarged by
+    1.25 in volume (sampler.py:493-510);
+  * rwalk scale tuning: scale *= exp((facc_obs - facc)/ncdim/facc) per queue
+    fill (internal_samplers.py:460-493); slice tuning per tune_slice (:1209-1239);
+  * ln X decreases by ln((N+1)/N) per iteration; trapezoid weights; the final
+    live points are appended (sampler.py:780-930).
+"""
+import math
+
+import numpy as np
+from scipy.special import logsumexp
+
+from . import bounding
+from .backend import get_backend
+
+
+class RunResult(dict):
+    __getattr__ = dict.get
+
+
+def _integrate(logl, logvol):
+    """ln Z and information from ordered (logl, logvol) with the trapezoid rule
+    (the arithmetic of utils.compute_integrals, utils.py:1411-1467)."""
+    logl = np.asarray(logl)
+    logvol = np.asarray(logvol)
+    lpad = np.concatenate([[-1.e300], logl])
+    vpad = np.concatenate([[0.], logvol])
+    # ln(X_{i-1} - X_i) and the trapezoid factor 1/2
+    logdvol = vpad[:-1] + np.log1p(-np.exp(vpad[1:] - vpad[:-1])) + math.log(.5)
+    logwt = np.logaddexp(lpad[1:], lpad[:-1]) + logdvol
+    logz = np.logaddexp.accumulate(logwt)
+    # information H (for the logz error estimate sqrt(H/N))
+    lz = logz[-1]
+    w0 = np.exp(lpad[:-1] - lz + logdvol)
+    w1 = np.exp(lpad[1:] - lz + logdvol)
+    with np.errstate(invalid='ignore'):
+        h = np.nansum(w0 * np.where(w0 > 0, lpad[:-1], 0.) +
+                      w1 * np.where(w1 > 0, lpad[1:], 0.)) - lz
+    return logwt, logz, float(h)
+
+
+def run_static(prob, nlive=500, bound='multi', sample='rwalk', queue_size=None,
+               walks=None, slices=None, rstate=None, dlogz=0.01, enlarge=1.25,
+               maxiter=None, first_update_min_ncall=None,
+               first_update_min_eff=10., verbose=False):
+    """One static nested-sampling run on the device.  Returns a RunResult with
+    logz, logzerr, niter, ncall, samples_u, samples_logl, logwt, nbound."""
+    be = get_backend()
+    if rstate is None:
+        rstate = np.random.default_rng()
+    nd = prob.ndim
+    K = int(queue_size or max(1, nlive // 4))
+    if walks is None:
+        walks = nd + 20  # dynesty.py:128
+    if slices is None:
+        slices = 3 + nd if sample == 'rslice' else 3
+    if first_update_min_ncall is None:
+        first_update_min_ncall = 2 * nlive
+    ratio = dict(unif=1, rwalk=walks, rslice=slices, slice=slices * nd)[sample]
+    update_interval = max(1, round(ratio * nlive))
+    facc = min(1., max(1. / max(2, walks), 0.5))
+
+    def spawn_states(k):
+        # utils.get_seed_sequence: 4 ints below 2**63-1 -> SeedSequence children
+        ent = rstate.integers(0, 2**63 - 1, size=4)
+        return be.seed_children(ent, 0, k)
+
+    # ---- initial live points: uniform in the cube ----
+    live_u = rstate.random((nlive, nd))
+    live_v, live_logl = be.problem_eval(prob, live_u)
+    ncall = nlive
+    it = 0
+    bnd = None
+    unit_cube = True
+    scale = 1.0
+    doubling = False
+    ncall_last_update = 0
+    nbound = 0
+    logvol = 0.
+    dlv = math.log((nlive + 1.) / nlive)
+    dead_u, dead_logl, dead_logvol = [], [], []
+    logz = -1.e300
+    hist = dict(acc=0, rej=0, nexp=0, ncon=0)
+
+    def rebuild():
+        nonlocal bnd, nbound
+        if bnd is None:
+            bnd = (bounding.HipMultiEllipsoid(nd) if bound == 'multi' else
+                   bounding.HipEllipsoid(nd))
+        bnd.update(live_u, rstate=rstate)
+        if enlarge != 1.:
+            bnd.scale_to_logvol(bnd.logvol + math.log(enlarge))
+        nbound += 1
+
+    def fill(loglstar):
+        """One queue fill: K proposals against loglstar (one launch)."""
+        nonlocal scale, doubling
+        states = spawn_states(K)
+        if unit_cube:
+            out = be.unif_batch(prob, loglstar, states)
+            return out, None
+        if sample == 'unif':
+            if bound == 'multi':
+                out = be.unif_batch(prob, loglstar, states, ctrs=bnd.ctrs,
+                                    axes=bnd.axes_ells, ams=bnd.ams,
+                                    logvol_ells=bnd.logvol_ells)
+            else:
+                out = be.unif_batch(prob, loglstar, states, ctrs=bnd.ctr,
+                                    axes=bnd.axes)
+            return out, None
+        above = np.nonzero(live_logl > loglstar)[0]
+        if len(above) == 0:
+            raise RuntimeError('No live points are above loglstar.')
+        start = rstate.choice(above, size=K)
+        if bound == 'multi':
+            probs = np.exp(bnd.logvol_ells - bnd.logvol)
+            fidx = np.minimum(np.searchsorted(np.cumsum(probs),
+                                              rstate.random(K)),
+                              bnd.nells - 1).astype(np.int32)
+            frames = bnd.axes_ells
+        else:
+            fidx, frames = None, bnd.axes[None]
+        if sample == 'rwalk':
+            out = be.rwalk_batch(prob, live_u[start], frames, scale, loglstar,
+                                 walks, states, axes_idx=fidx)
+            out["ncalls"] = np.full(K, walks)
+            hist["acc"] += int(out["accept"].sum())
+            hist["rej"] += int(out["reject"].sum())
+            tot = hist["acc"] + hist["rej"]
+            scale *= math.exp((hist["acc"] / tot - facc) / nd / facc)
+            hist["acc"] = hist["rej"] = 0
+        else:
+            out = be.slice_batch(prob, live_u[start], frames, scale, loglstar,
+                                 slices, states, principal=(sample == 'slice'),
+                                 doubling=doubling, axes_idx=fidx)
+            hist["nexp"] += int(out["n_expand"].sum())
+            hist["ncon"] += int(out["n_contract"].sum())
+            if out["expansion_warning_set"].any():
+                doubling = True
+            ne, nc_ = max(hist["nexp"], 1), hist["ncon"]
+            scale *= float(np.clip(ne * 2. / (ne + nc_), 0.5, 2))
+            hist["nexp"] = hist["ncon"] = 0
+        return out, start
+
+    done = False
+    while not done:
+        loglstar = float(live_logl.min())
+        # bound-update policy, evaluated when the queue is empty
+        eff = 100. * max(it, 1) / ncall
+        if unit_cube:
+            if ncall >= first_update_min_ncall and eff < first_update_min_eff:
+                unit_cube = False
+                rebuild()
+                ncall_last_update = ncall
+        elif ncall >= ncall_last_update + update_interval:
+            rebuild()
+            ncall_last_update = ncall
+        out, _ = fill(loglstar)
+        for j in range(K):
+            ncall += int(out["ncalls"][j])
+            worst = int(np.argmin(live_logl))
+            cur = float(live_logl[worst])
+            if not out["logl"][j] > cur:
+                continue  # stale proposal: discarded (sampler.py:774-776)
+            logvol -= dlv
+            dead_u.append(live_u[worst].copy())
+            dead_logl.append(cur)
+            dead_logvol.append(logvol)
+            lw = cur + logvol  # coarse running evidence for the stop rule
+            logz = np.logaddexp(logz, lw - math.log(nlive))
+            live_u[worst] = out["u"][j]
+            live_v[worst] = out["v"][j]
+            live_logl[worst] = out["logl"][j]
+            it += 1
+            if maxiter is not None and it >= maxiter:
+                done = True
+                break
+            if it % 64 == 0 or j == K - 1:
+                dz = np.logaddexp(0., float(live_logl.max()) + logvol - logz)
+                if dz < dlogz:
+                    done = True
+                    break
+        if verbose:
+            print(f"it={it} ncall={ncall} logz~{logz:.3f} nbound={nbound} "
+                  f"scale={scale:.3f}")
+    # ---- add the remaining live points (sampler.py:780-930) ----
+    order = np.argsort(live_logl)
+    lv_live = logvol + np.log(1. - (np.arange(nlive) + 1.) / (nlive + 1.))
+    all_logl = np.concatenate([dead_logl, live_logl[order]])
+    all_logvol = np.concatenate([dead_logvol, lv_live])
+    all_u = np.concatenate([np.array(dead_u).reshape(-1, nd), live_u[order]])
+    logwt, logz_arr, h = _integrate(all_logl, all_logvol)
+    return RunResult(logz=float(logz_arr[-1]),
+                     logzerr=math.sqrt(max(h, 0.) / nlive), niter=it,
+                     ncall=ncall, h=h, nbound=nbound, samples_u=all_u,
+                     samples_logl=all_logl, logwt=logwt, scale=scale,
+                     eff=100. * it / ncall)

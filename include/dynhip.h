@@ -154,6 +154,14 @@ int dh_scale_to_logvol(dh_ctx* ctx, int m, int d, double* covs, double* ams,
                        double* axes, double* axlens, double* logvols,
                        const double* targets);
 
+/* Sampler.update_bound's enlargement (sampler.py:506-508):
+ * bound.scale_to_logvol(bound.logvol + log(enlarge)) for `runs` bounds laid out
+ * as by dh_rebuild_batch_dev (max_ells slots per run, nells[run] live): every
+ * live ellipsoid's target is its own logvol + log_enlarge (bounding.py:485-490). */
+int dh_enlarge_batch_dev(dh_ctx* ctx, int runs, int max_ells, const int32_t* nells,
+                         int d, double* covs, double* ams, double* axes,
+                         double* axlens, double* logvols, double log_enlarge);
+
 /* ---- proposals ----------------------------------------------------------
  * RWalkSampler.sample over a batch of k walkers = generic_random_walk +
  * propose_ball_point + randsphere (internal_samplers.py:866-1035,
