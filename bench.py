@@ -199,6 +199,14 @@ def main():
         alg_bytes = 8 * (2 * d + 1)  # read u, write u', write logl
         flops = 2 * d * d + 8 * d + (d * d + 3 * d)  # frame mat-vec + sym. quad form
         achieved = props_per_step_rank * alg_bytes / (t_wk * 1e-3) / 1e9
+        traffic, traffic_src = None, None
+        pmc = os.path.join(ROOT, "profiles", "r01", "pmc_rwalk_traffic.json")
+        if os.path.exists(pmc) and runs == 64 and nlive == 2000 and args.walks == 45:
+            # PMC counters cannot be read from inside this process; the value is
+            # the committed rocprofv3 measurement of this same launch shape
+            with open(pmc) as f:
+                traffic = json.load(f)["traffic_bytes_per_launch"]
+            traffic_src = "profiles/r01/pmc_rwalk_traffic.json (2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes)"
         line = {
             "metric": "proposals/sec + ellipsoid-rebuilds/sec, 25-D corr-Normal "
                       "nlive=2000 (multi/rwalk)",
@@ -235,7 +243,9 @@ def main():
             "roofline": {
                 "bound": "hbm", "kernel": "rwalk_kernel<25,true,PREC_AFFINE>",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
+                "algorithmic_bytes_per_launch": props_per_step_rank * alg_bytes,
                 "kernel_ms": t_wk,
                 "note": "algorithmic bytes = 408 B/proposal (SURVEY 8d); walker "
                         "state stays in registers for all 45 steps, so the "

@@ -63,6 +63,15 @@ struct RebuildArgs {
   double* logvols;    // runs x max_ells
   int* leaf_of_point; // runs x n (index into the output list) or null
   int* nnodes_out;    // runs or null
+  // level pipeline
+  int maxw;           // max splittable nodes of one run at one level: n / (4d) + 1
+  int levels;         // number of (k_split, k_ell) level steps launched
+  int* nnodes_dev;    // runs
+  int* nsplit;        // (levels+1) x runs
+  int* nell;          // levels x runs
+  int* split_list;    // 2 x runs x maxw   (by level parity)
+  int* ell_list;      // runs x 2 maxw
+  double* scale_g;    // runs x d
 };
 
 #ifdef DH_REBUILD_TIMING
@@ -850,12 +859,18 @@ __device__ __forceinline__ double logaddexp_d(double x, double y) {
   return x + y;  // NaN
 }
 
-__global__ void __launch_bounds__(kThreads) rebuild_kernel(RebuildArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int D = a.d, n = a.n, t = threadIdx.x;
-  const int run = blockIdx.x;
-  // ---- LDS carve ----
-  Lds L;
+// ---- the rebuild as a level-synchronous kernel pipeline ----------------------
+//   k_root   (grid = runs)            root ellipsoid, per-run scale, worklist seed
+//   k_split  (grid = runs * maxw)     one workgroup per splittable node of the
+//                                     level: k-means (k=2) + stable partition
+//   k_ell    (grid = runs * 2 maxw)   one workgroup per new child: bounding
+//                                     ellipsoid; queues it for the next level
+//   ... repeated for `levels` levels (idle workgroups exit immediately) ...
+//   k_finish (grid = runs)            bottom-up accept test, emit, coverage check
+// All nodes of a level -- of every run -- are processed concurrently, so a
+// single run is no longer confined to one CU and nothing returns to the host.
+
+__device__ __forceinline__ void carve(Lds& L, unsigned char* smem, int D) {
   L.LD = D | 1;  // odd leading dimension: conflict-free column walks
   L.TP = kThreads;
   L.DP = 1;
@@ -864,131 +879,201 @@ __global__ void __launch_bounds__(kThreads) rebuild_kernel(RebuildArgs a) {
     L.DP <<= 1;
     ++L.DPlog;
   }
-  {
-    double* p = (double*)smem;
-    L.tile = p;
-    p += (size_t)L.TP * L.LD;
-    L.A = p;
-    p += D * L.LD;
-    L.V = p;
-    p += D * L.LD;
-    L.AM = p;
-    p += D * L.LD;
-    L.AX = p;
-    p += D * L.LD;
-    L.mean = p;
-    p += D;
-    L.scale = p;
-    p += D;
-    L.lam = p;
-    p += D;
-    L.cen = p;
-    p += 2 * D;
-    L.sums = p;
-    p += 2 * D;
-    L.red = p;
-    p += kThreads;
-    L.rc = p;
-    p += 64;
-    L.rs = p;
-    p += 64;
-    L.ri = (int*)p;
-    L.perm_sort = L.ri + 320;
-  }
-  const double* pts = a.pts + (size_t)run * n * D;
-  int* perm = a.perm + (size_t)run * n;
-  int* perm2 = a.perm2 + (size_t)run * n;
-  unsigned char* lab = a.lab + (size_t)run * n;
-  Node* nodes = a.nodes + (size_t)run * a.max_nodes;
-  const int DD = D * D;
-  const int ES = D + 3 * DD + D;            // ellipsoid record
-  const int NS = ES + D * L.LD;             // + working covariance
-  double* estore = a.estore + (size_t)run * a.max_nodes * NS;
-  int* reslist = a.reslist + (size_t)run * a.reslist_cap;
+  double* p = (double*)smem;
+  L.tile = p;
+  p += (size_t)L.TP * L.LD;
+  L.A = p;
+  p += D * L.LD;
+  L.V = p;
+  p += D * L.LD;
+  L.AM = p;
+  p += D * L.LD;
+  L.AX = p;
+  p += D * L.LD;
+  L.mean = p;
+  p += D;
+  L.scale = p;
+  p += D;
+  L.lam = p;
+  p += D;
+  L.cen = p;
+  p += 2 * D;
+  L.sums = p;
+  p += 2 * D;
+  L.red = p;
+  p += kThreads;
+  L.rc = p;
+  p += 64;
+  L.rs = p;
+  p += 64;
+  L.ri = (int*)p;
+  L.perm_sort = L.ri + 320;
+}
 
-  for (int p = t; p < n; p += kThreads) perm[p] = p;
+struct RunView {
+  const double* pts;
+  int* perm;
+  int* perm2;
+  unsigned char* lab;
+  Node* nodes;
+  double* estore;
+  int* reslist;
+  int NS, ES;
+};
+
+__device__ __forceinline__ RunView view_of(const RebuildArgs& a, int run, int LD) {
+  RunView v;
+  const int D = a.d;
+  v.pts = a.pts + (size_t)run * a.n * D;
+  v.perm = a.perm + (size_t)run * a.n;
+  v.perm2 = a.perm2 + (size_t)run * a.n;
+  v.lab = a.lab + (size_t)run * a.n;
+  v.nodes = a.nodes + (size_t)run * a.max_nodes;
+  v.ES = D + 3 * D * D + D;
+  v.NS = v.ES + D * LD;
+  v.estore = a.estore + (size_t)run * a.max_nodes * v.NS;
+  v.reslist = a.reslist + (size_t)run * a.reslist_cap;
+  return v;
+}
+
+__device__ __forceinline__ void set_status(const RebuildArgs& a, int run, int rc) {
+  // first error wins is not needed: any error code marks the run failed
+  if (threadIdx.x == 0 && rc != DH_OK) atomicMin(&a.status[run], rc);
+}
+
+__global__ void __launch_bounds__(kThreads) k_root(RebuildArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int D = a.d, n = a.n, t = threadIdx.x, run = blockIdx.x;
+  Lds L;
+  carve(L, smem, D);
+  const RunView v = view_of(a, run, L.LD);
+  for (int p = t; p < n; p += kThreads) v.perm[p] = p;
   __threadfence_block();
   __syncthreads();
-
   int status = DH_OK;
-  int nnodes = 1;
   if (n <= 1) status = (a.mode == 0) ? DH_ERR_REGION : DH_ERR_VALUE;  // single point
-
-  // ---- root ----
   double lv = 0.0;
-  if (status == DH_OK) {
-    status = node_ellipsoid(L, a, pts, perm, 0, n, estore, estore + ES, &lv);
+  if (status == DH_OK) status = node_ellipsoid(L, a, v.pts, v.perm, 0, n, v.estore, v.estore + v.ES, &lv);
+  if (t == 0) {
+    Node r;
+    r.start = 0;
+    r.count = n;
+    r.parent = -1;
+    r.child0 = r.child1 = -1;
+    r.depth = 0;
+    r.split = 0;
+    r.res_start = 0;
+    r.res_len = 0;
+    r.logvol = lv;
+    v.nodes[0] = r;
+    a.nnodes_dev[run] = 1;
+    a.status[run] = status;
+  }
+  // root std -> per-run scale (bounding.py:1503-1504), seed of the level-0 worklist
+  if (status == DH_OK && a.mode == 0 && n >= 4 * D) {
+    node_std(L, v.pts, v.perm, 0, n, D);
+    if (t < D) a.scale_g[(size_t)run * D + t] = L.scale[t];
     if (t == 0) {
-      Node r;
-      r.start = 0;
-      r.count = n;
-      r.parent = -1;
-      r.child0 = r.child1 = -1;
-      r.depth = 0;
-      r.split = 0;
-      r.res_start = 0;
-      r.res_len = 0;
-      r.logvol = lv;
-      nodes[0] = r;
+      a.split_list[((size_t)0 * a.runs + run) * a.maxw] = 0;
+      a.nsplit[(size_t)0 * a.runs + run] = 1;
     }
-    __syncthreads();
   }
+}
 
-  // ---- level-ordered split worklist (bounding.py:1464-1563) ----
-  if (status == DH_OK && a.mode == 0) {
-    const int min_size = 2 * D;
-    if (n >= 2 * min_size) node_std(L, pts, perm, 0, n, D);  // scale, root only (:1503)
-    for (int cur = 0; cur < nnodes && status == DH_OK; ++cur) {
-      const int start = nodes[cur].start, count = nodes[cur].count, depth = nodes[cur].depth;
-      if (count < 2 * min_size) continue;  // too small to try a split (:1492-1496)
-      const double* es = estore + (size_t)cur * NS;
-      PH_T0();
-      const int n0 = node_kmeans(L, pts, perm, lab, start, count, D, es);
-      PH_ADD(4);
-      const int n1 = count - n0;
-      if (min(n0, n1) < min_size) continue;  // reject the split (:1521-1522)
-      if (nnodes + 2 > a.max_nodes) {
-        status = DH_ERR_NOMEM;
-        break;
-      }
-      node_partition(L, perm, perm2, lab, start, count, n0);
-      PH_ADD(5);
-      const int c0 = nnodes, c1 = nnodes + 1;
-      double lv0 = 0.0, lv1 = 0.0;
-      int rc = node_ellipsoid(L, a, pts, perm, start, n0, estore + (size_t)c0 * NS,
-                              estore + (size_t)c0 * NS + ES, &lv0);
-      if (rc == DH_OK)
-        rc = node_ellipsoid(L, a, pts, perm, start + n0, n1, estore + (size_t)c1 * NS,
-                            estore + (size_t)c1 * NS + ES, &lv1);
-      if (rc != DH_OK) {
-        status = rc;
-        break;
-      }
-      if (t == 0) {
-        Node k0, k1;
-        k0.start = start;
-        k0.count = n0;
-        k1.start = start + n0;
-        k1.count = n1;
-        k0.parent = k1.parent = cur;
-        k0.child0 = k0.child1 = k1.child0 = k1.child1 = -1;
-        k0.depth = k1.depth = depth + 1;
-        k0.split = k1.split = 0;
-        k0.res_start = k1.res_start = 0;
-        k0.res_len = k1.res_len = 0;
-        k0.logvol = lv0;
-        k1.logvol = lv1;
-        nodes[c0] = k0;
-        nodes[c1] = k1;
-        nodes[cur].child0 = c0;
-        nodes[cur].child1 = c1;
-        nodes[cur].split = 1;
-      }
-      nnodes += 2;
-      __threadfence_block();
-      __syncthreads();
+__global__ void __launch_bounds__(kThreads) k_split(RebuildArgs a, int level) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int run = blockIdx.x / a.maxw, slot = blockIdx.x % a.maxw;
+  if (slot >= a.nsplit[(size_t)level * a.runs + run]) return;
+  if (a.status[run] != DH_OK) return;
+  const int D = a.d, t = threadIdx.x;
+  Lds L;
+  carve(L, smem, D);
+  const RunView v = view_of(a, run, L.LD);
+  if (t < D) L.scale[t] = a.scale_g[(size_t)run * D + t];
+  __syncthreads();
+  const int cur = a.split_list[((size_t)(level & 1) * a.runs + run) * a.maxw + slot];
+  const int start = v.nodes[cur].start, count = v.nodes[cur].count, depth = v.nodes[cur].depth;
+  const int min_size = 2 * D;
+  PH_T0();
+  const int n0 = node_kmeans(L, v.pts, v.perm, v.lab, start, count, D, v.estore + (size_t)cur * v.NS);
+  PH_ADD(4);
+  const int n1 = count - n0;
+  if (min(n0, n1) < min_size) return;  // reject the split (:1521-1522): node stays a leaf
+  node_partition(L, v.perm, v.perm2, v.lab, start, count, n0);
+  PH_ADD(5);
+  if (t == 0) {
+    const int c0 = atomicAdd(&a.nnodes_dev[run], 2);
+    if (c0 + 2 > a.max_nodes) {
+      atomicMin(&a.status[run], DH_ERR_NOMEM);
+    } else {
+      Node k0, k1;
+      k0.start = start;
+      k0.count = n0;
+      k1.start = start + n0;
+      k1.count = n1;
+      k0.parent = k1.parent = cur;
+      k0.child0 = k0.child1 = k1.child0 = k1.child1 = -1;
+      k0.depth = k1.depth = depth + 1;
+      k0.split = k1.split = 0;
+      k0.res_start = k1.res_start = 0;
+      k0.res_len = k1.res_len = 0;
+      k0.logvol = k1.logvol = 0.0;
+      v.nodes[c0] = k0;
+      v.nodes[c0 + 1] = k1;
+      v.nodes[cur].child0 = c0;
+      v.nodes[cur].child1 = c0 + 1;
+      v.nodes[cur].split = 1;
+      const int e = atomicAdd(&a.nell[(size_t)level * a.runs + run], 2);
+      a.ell_list[(size_t)run * 2 * a.maxw + e] = c0;
+      a.ell_list[(size_t)run * 2 * a.maxw + e + 1] = c0 + 1;
     }
   }
+}
+
+__global__ void __launch_bounds__(kThreads) k_ell(RebuildArgs a, int level) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int run = blockIdx.x / (2 * a.maxw), slot = blockIdx.x % (2 * a.maxw);
+  if (slot >= a.nell[(size_t)level * a.runs + run]) return;
+  if (a.status[run] != DH_OK) return;
+  const int D = a.d, t = threadIdx.x;
+  Lds L;
+  carve(L, smem, D);
+  const RunView v = view_of(a, run, L.LD);
+  const int node = a.ell_list[(size_t)run * 2 * a.maxw + slot];
+  const int start = v.nodes[node].start, count = v.nodes[node].count;
+  double lv = 0.0;
+  const int rc = node_ellipsoid(L, a, v.pts, v.perm, start, count, v.estore + (size_t)node * v.NS,
+                                v.estore + (size_t)node * v.NS + v.ES, &lv);
+  if (rc != DH_OK) {
+    set_status(a, run, rc);
+    return;
+  }
+  if (t == 0) {
+    v.nodes[node].logvol = lv;
+    if (count >= 4 * D) {  // big enough to try a split at the next level (:1492-1496)
+      if (level + 1 >= a.levels) {
+        atomicMin(&a.status[run], DH_ERR_NOMEM);  // deeper than the launch plan
+      } else {
+        const int sidx = atomicAdd(&a.nsplit[(size_t)(level + 1) * a.runs + run], 1);
+        a.split_list[((size_t)((level + 1) & 1) * a.runs + run) * a.maxw + sidx] = node;
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(kThreads) k_finish(RebuildArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int D = a.d, n = a.n, t = threadIdx.x, run = blockIdx.x;
+  Lds L;
+  carve(L, smem, D);
+  const RunView v = view_of(a, run, L.LD);
+  Node* nodes = v.nodes;
+  int* reslist = v.reslist;
+  const double* estore = v.estore;
+  const int NS = v.NS, DD = D * D;
+  int status = a.status[run];
+  const int nnodes = min(a.nnodes_dev[run], a.max_nodes);
+  __syncthreads();
 
   // ---- bottom-up accept test (bounding.py:1541-1563), thread 0 ----
   if (status == DH_OK) {
@@ -1013,10 +1098,10 @@ __global__ void __launch_bounds__(kThreads) rebuild_kernel(RebuildArgs a) {
             double mx = -INFINITY;
             for (int q = 0; q < k0.res_len; ++q) mx = fmax(mx, nodes[reslist[k0.res_start + q]].logvol);
             for (int q = 0; q < k1.res_len; ++q) mx = fmax(mx, nodes[reslist[k1.res_start + q]].logvol);
-            double s = 0.0;
-            for (int q = 0; q < k0.res_len; ++q) s += exp(nodes[reslist[k0.res_start + q]].logvol - mx);
-            for (int q = 0; q < k1.res_len; ++q) s += exp(nodes[reslist[k1.res_start + q]].logvol - mx);
-            const double lse = log(s) + mx;
+            double sm = 0.0;
+            for (int q = 0; q < k0.res_len; ++q) sm += exp(nodes[reslist[k0.res_start + q]].logvol - mx);
+            for (int q = 0; q < k1.res_len; ++q) sm += exp(nodes[reslist[k1.res_start + q]].logvol - mx);
+            const double lse = log(sm) + mx;
             accept = (lse - nd.logvol) < -dec * (len - 1);
           }
           if (accept) {
@@ -1071,8 +1156,8 @@ __global__ void __launch_bounds__(kThreads) rebuild_kernel(RebuildArgs a) {
       if (t == 0) o_lv[m] = nodes[ni].logvol;
       if (a.leaf_of_point) {
         int* lop = a.leaf_of_point + (size_t)run * n;
-        const int s = nodes[ni].start, c = nodes[ni].count;
-        for (int p = t; p < c; p += kThreads) lop[perm[s + p]] = m;
+        const int s0 = nodes[ni].start, c = nodes[ni].count;
+        for (int p = t; p < c; p += kThreads) lop[v.perm[s0 + p]] = m;
       }
     }
     __threadfence_block();
@@ -1083,10 +1168,9 @@ __global__ void __launch_bounds__(kThreads) rebuild_kernel(RebuildArgs a) {
       int uncovered = 0;
       for (int base = 0; base < n; base += L.TP) {
         const int cnt = min(L.TP, n - base);
-        stage_tile(L, pts, perm, base, cnt, D, 0);
+        stage_tile(L, v.pts, v.perm, base, cnt, D, 0);
         bool inside = false;
         for (int m = 0; m < M; ++m) {
-          // stage this ellipsoid's centre and precision matrix
           for (int e = t; e < DD; e += kThreads) L.AM[(e / D) * L.LD + e % D] = o_am[(size_t)m * DD + e];
           if (t < D) L.mean[t] = o_ctr[m * D + t];
           __syncthreads();
@@ -1304,8 +1388,18 @@ int dh_rebuild_batch_dev(dh_ctx* ctx, int runs, const double* pts, int n, int d,
   const size_t b_nodes = (size_t)runs * a.max_nodes * sizeof(Node);
   const size_t b_es = (size_t)runs * a.max_nodes * NS * 8;
   const size_t b_res = (size_t)runs * a.reslist_cap * 4;
+  a.maxw = n / (4 * d) + 1;
+  // depth: a balanced tree needs log2(n / 2d) levels; unbalanced splits need more.
+  // Idle level launches cost ~2 us each, a run that is deeper still fails loudly.
+  int lv = 4;
+  while ((1 << lv) < n / (2 * d) + 1) ++lv;
+  a.levels = mode == 1 ? 0 : (2 * lv + 8);
+  const size_t b_cnt = (size_t)runs * ((size_t)2 * a.levels + 3) * 4;
+  const size_t b_sl = (size_t)2 * runs * a.maxw * 4, b_el = (size_t)runs * 2 * a.maxw * 4;
+  const size_t b_sc = (size_t)runs * d * 8;
   auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-  const size_t total = al(b_perm) * 2 + al(b_lab) + al(b_nodes) + al(b_es) + al(b_res);
+  const size_t total = al(b_perm) * 2 + al(b_lab) + al(b_nodes) + al(b_es) + al(b_res) + al(b_cnt) +
+                       al(b_sl) + al(b_el) + al(b_sc);
   if (total > ctx->rebuild_ws_cap) {
     if (!hip_ok(ctx, hipStreamSynchronize(ctx->stream), "sync")) return DH_ERR_HIP;
     if (ctx->rebuild_ws) (void)hipFree(ctx->rebuild_ws);
@@ -1327,6 +1421,17 @@ int dh_rebuild_batch_dev(dh_ctx* ctx, int runs, const double* pts, int n, int d,
   a.estore = (double*)w;
   w += al(b_es);
   a.reslist = (int*)w;
+  w += al(b_res);
+  int* cnt = (int*)w;
+  w += al(b_cnt);
+  a.nnodes_dev = cnt;
+  a.nsplit = cnt + runs;
+  a.nell = a.nsplit + (size_t)(a.levels + 1) * runs;
+  a.split_list = (int*)w;
+  w += al(b_sl);
+  a.ell_list = (int*)w;
+  w += al(b_el);
+  a.scale_g = (double*)w;
   a.nells = nells;
   a.status = status;
   a.ctrs = ctrs;
@@ -1339,14 +1444,21 @@ int dh_rebuild_batch_dev(dh_ctx* ctx, int runs, const double* pts, int n, int d,
   a.nnodes_out = nnodes;
   static size_t attr_lds = 0;
   if (lds > attr_lds) {
-    if (!hip_ok(ctx,
-                hipFuncSetAttribute((const void*)rebuild_kernel,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
-                "hipFuncSetAttribute(rebuild LDS)"))
-      return DH_ERR_HIP;
+    const void* ks[4] = {(const void*)k_root, (const void*)k_split, (const void*)k_ell,
+                         (const void*)k_finish};
+    for (const void* kf : ks)
+      if (!hip_ok(ctx, hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+                  "hipFuncSetAttribute(rebuild LDS)"))
+        return DH_ERR_HIP;
     attr_lds = lds;
   }
-  hipLaunchKernelGGL(rebuild_kernel, dim3(runs), dim3(kThreads), lds, ctx->stream, a);
+  if (!hip_ok(ctx, hipMemsetAsync(cnt, 0, b_cnt, ctx->stream), "memset(rebuild counters)")) return DH_ERR_HIP;
+  hipLaunchKernelGGL(k_root, dim3(runs), dim3(kThreads), lds, ctx->stream, a);
+  for (int L = 0; L < a.levels; ++L) {
+    hipLaunchKernelGGL(k_split, dim3(runs * a.maxw), dim3(kThreads), lds, ctx->stream, a, L);
+    hipLaunchKernelGGL(k_ell, dim3(runs * 2 * a.maxw), dim3(kThreads), lds, ctx->stream, a, L);
+  }
+  hipLaunchKernelGGL(k_finish, dim3(runs), dim3(kThreads), lds, ctx->stream, a);
   return hip_ok(ctx, hipGetLastError(), "rebuild launch") ? DH_OK : DH_ERR_HIP;
 }
 
