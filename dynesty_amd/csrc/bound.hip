@@ -58,9 +58,6 @@ int dh_contains(dh_ctx* ctx, const double* x, int k, int d, const double* ctrs, 
   if (k <= 0) return DH_OK;
   if (!x || !ctrs || !ams || !count || d < 1 || m < 1 || (mode != 0 && mode != 1))
     return fail(ctx, DH_ERR_ARG, "contains: bad arguments (d=%d m=%d mode=%d)", d, m, mode);
-  if (d > kMaxRegDim)
-    return fail(ctx, DH_ERR_ARG, "contains: d=%d > %d needs the wide-D path (not built yet)", d,
-                kMaxRegDim);
   arena_reset(ctx);
   const size_t nwords = (size_t)(k + 63) / 64;
   int rc = arena_reserve(ctx, ((size_t)k * d + (size_t)m * d + (size_t)m * d * d + (size_t)k * m) * 8 +
@@ -75,6 +72,11 @@ int dh_contains(dh_ctx* ctx, const double* x, int k, int d, const double* ctrs, 
   if (!d_x || !d_c || !d_a || !d_cnt || (mask && !d_mask) || (quad && !d_q)) return DH_ERR_NOMEM;
   const dim3 grid((k + 63) / 64), block(64);
   bool hit = false;
+  if (d > kMaxRegDim) {
+    hit = true;
+    rc = wide_contains_launch(ctx, d_x, k, d, d_c, d_a, m, mode, d_cnt, d_mask, d_q);
+    if (rc) return rc;
+  }
 #define X(NN)                                                                                   \
   if (!hit && d <= NN) {                                                                        \
     hit = true;                                                                                 \

@@ -85,6 +85,20 @@ inline bool down(dh_ctx* ctx, T* host, const T* dev, size_t count) {
 
 bool get_problem(dh_ctx* ctx, int handle, ProblemDev* out);
 
+// wide-D path (wide.hip): used by the dispatchers when the dimension exceeds the
+// register-resident limits.  kind: 0 rwalk, 1 rslice, 2 slice, 3 unit cube.
+int wide_walk_launch(dh_ctx* ctx, int kind, int problem, int k, int ndim, int ncdim, const double* u0,
+                     const double* axes, int m, const int32_t* axes_idx, double scale, double loglstar,
+                     int iters, int doubling, const int8_t* bc, const uint64_t* rng, double* u, double* v,
+                     double* logl, int32_t* c0, int32_t* c1, int32_t* c2, int32_t* flags,
+                     uint64_t* rng_out);
+int wide_eval_launch(dh_ctx* ctx, const ProblemDev& p, int k, const double* u, double* v, double* logl);
+int wide_contains_launch(dh_ctx* ctx, const double* x, int k, int d, const double* ctrs, const double* ams,
+                         int m, int mode, int32_t* count, uint64_t* mask, double* quad);
+int wide_single_launch(dh_ctx* ctx, int runs, const double* pts, int n, int d, int32_t* nells,
+                       int32_t* status, double* ctrs, double* covs, double* ams, double* axes,
+                       double* axlens, double* logvols);
+
 }  // namespace dh
 
 #define DH_CHECK_CTX(ctx) \

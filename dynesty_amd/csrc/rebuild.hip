@@ -1367,9 +1367,13 @@ int dh_rebuild_batch_dev(dh_ctx* ctx, int runs, const double* pts, int n, int d,
   if (!pts || n < 1 || d < 1 || max_ells < 1 || (mode != 0 && mode != 1))
     return fail(ctx, DH_ERR_ARG, "rebuild: bad arguments (n=%d d=%d mode=%d)", n, d, mode);
   const size_t lds = rebuild_lds_bytes(d);
-  if (lds > 159 * 1024)
-    return fail(ctx, DH_ERR_ARG, "rebuild: d=%d needs %zu B of LDS (> 159 KiB): wide-D path not built yet",
-                d, lds);
+  if (lds > 159 * 1024) {
+    if (mode == 1)
+      return wide_single_launch(ctx, runs, pts, n, d, nells, status, ctrs, covs, ams, axes, axlens,
+                                logvols);
+    return fail(ctx, DH_ERR_ARG,
+                "rebuild: MultiEllipsoid.update for d=%d (> 44) is not built (Ellipsoid.update is)", d);
+  }
   RebuildArgs a;
   a.pts = pts;
   a.n = n;

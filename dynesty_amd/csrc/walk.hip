@@ -248,8 +248,8 @@ int dh_rwalk_batch_dev(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, con
   if (ncdim < 1 || ncdim > ndim || m < 1 || walks < 1)
     return fail(ctx, DH_ERR_ARG, "rwalk: ncdim=%d ndim=%d m=%d walks=%d", ncdim, ndim, m, walks);
   if (ndim > kMaxRegDim)
-    return fail(ctx, DH_ERR_ARG, "rwalk: ndim=%d > %d needs the wide-D path (not built yet)", ndim,
-                kMaxRegDim);
+    return wide_walk_launch(ctx, 0, problem, k, ndim, ncdim, u0, axes, m, axes_idx, scale, loglstar, walks,
+                            0, bc, rng, u, v, logl, naccept, nreject, nullptr, nullptr, rng_out);
   a.k = k;
   a.ndim = ndim;
   a.ncdim = ncdim;
@@ -358,9 +358,6 @@ int dh_problem_eval(dh_ctx* ctx, int problem, int k, const double* u, double* v,
   if (!get_problem(ctx, problem, &p)) return DH_ERR_ARG;
   if (k <= 0) return DH_OK;
   const int ndim = p.ndim;
-  if (ndim > kMaxRegDim)
-    return fail(ctx, DH_ERR_ARG, "eval: ndim=%d > %d needs the wide-D path (not built yet)", ndim,
-                kMaxRegDim);
   arena_reset(ctx);
   const size_t kd = (size_t)k * ndim;
   int rc = arena_reserve(ctx, 2 * kd * 8 + (size_t)k * 8 + 4096);
@@ -371,6 +368,11 @@ int dh_problem_eval(dh_ctx* ctx, int problem, int k, const double* u, double* v,
   if (!d_u || !d_v || !d_l) return DH_ERR_NOMEM;
   const dim3 grid((k + 63) / 64), block(64);
   bool hit = false;
+  if (ndim > kMaxRegDim) {
+    hit = true;
+    rc = wide_eval_launch(ctx, p, k, d_u, d_v, d_l);
+    if (rc) return rc;
+  }
 #define X(NN)                                                                      \
   if (!hit && ndim <= NN) {                                                        \
     hit = true;                                                                    \

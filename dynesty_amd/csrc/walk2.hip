@@ -641,10 +641,10 @@ int dh_slice_batch_dev(dh_ctx* ctx, int problem, int k, int ndim, int mode, cons
   if (m < 1 || slices < 1 || (mode != 0 && mode != 1))
     return fail(ctx, DH_ERR_ARG, "slice: m=%d slices=%d mode=%d", m, slices, mode);
   const int N = pad_dim(ndim);
-  if (N != ndim)
-    return fail(ctx, DH_ERR_ARG,
-                "slice: ndim=%d has no register-resident instantiation (supported: 1-6,8,10,12,16,20,25,32)",
-                ndim);
+  if (N != ndim)  // no register-resident instantiation for this dimension: wave-per-walker path
+    return wide_walk_launch(ctx, mode + 1, problem, k, ndim, ndim, u0, axes, m, axes_idx, scale, loglstar,
+                            slices, doubling, nullptr, rng, u, v, logl, ncalls, nexpand, ncontract, flags,
+                            rng_out);
   int rc = ensure_axes_t(ctx, (size_t)m * N * N * 8);
   if (rc) return rc;
   hipLaunchKernelGGL(pad_mats_kernel, dim3((m * N * N + 255) / 256), dim3(256), 0, ctx->stream, axes, m,
@@ -747,9 +747,15 @@ int dh_unif_batch_dev(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, int 
   if (a.prob.ndim != ndim) return fail(ctx, DH_ERR_ARG, "problem ndim %d != %d", a.prob.ndim, ndim);
   if (k <= 0) return DH_OK;
   if (m < 0 || ncdim < 1 || ncdim > ndim) return fail(ctx, DH_ERR_ARG, "unif: m=%d ncdim=%d", m, ncdim);
-  if (ndim > kMaxRegDim)
-    return fail(ctx, DH_ERR_ARG, "unif: ndim=%d > %d needs the wide-D path (not built yet)", ndim,
-                kMaxRegDim);
+  if (ndim > kMaxRegDim) {
+    if (m != 0)
+      return fail(ctx, DH_ERR_ARG,
+                  "unif: uniform sampling inside an ellipsoid is not built for ndim=%d > %d", ndim,
+                  kMaxRegDim);
+    return wide_walk_launch(ctx, 3, problem, k, ndim, ndim, nullptr, nullptr, 1,
+                            nullptr, 1.0, loglstar, 0, 0, bc, rng, u, v, logl, ncalls, nullptr, nullptr,
+                            flags, rng_out);
+  }
   const int N = pad_dim(ndim);
   const size_t mats = (size_t)(m > 0 ? m : 1) * N * N * 8;
   int rc = ensure_axes_t(ctx, 2 * mats);

@@ -1,0 +1,1035 @@
+// Wide-D path (D up to 512): BASELINE config C4 is 200-D, where neither a
+// walker (3 x 200 doubles) nor a D x D matrix (320 KB) fits a lane's registers
+// or one CU's LDS.  Mapping changes accordingly:
+//   * proposals: one WAVEFRONT per walker, lanes stride over the dimensions;
+//     the proposal frame is read transposed from L2 (coalesced along outputs),
+//     reductions are wave shuffles; the walker's PCG64 stream is advanced by
+//     all lanes redundantly (it is inherently sequential) and every lane keeps
+//     the normals of its own dimensions.
+//   * single-ellipsoid rebuild (Ellipsoid.update): one 1024-thread workgroup
+//     per run; covariance accumulated from 64-point LDS tiles with ~20 entries
+//     per thread in registers; the eigenproblem is a parallel-order Jacobi on
+//     matrices kept in global memory (L2 resident); the Mahalanobis maximum
+//     streams the precision matrix through the scalar cache (lane = point).
+//   * membership: one workgroup per candidate point.
+// Semantics and citations are those of the register-resident kernels
+// (walk.hip / walk2.hip / rebuild.hip / bound.hip).
+#include <math.h>
+
+#include "ctx.h"
+#include "rng_pcg64.h"
+
+using namespace dh;
+
+namespace {
+
+constexpr int kWideMaxD = 512;
+constexpr int kRT = 1024;  // threads of the wide rebuild workgroup
+constexpr int kTP = 64;    // points per LDS tile
+
+__device__ __forceinline__ double wave_sum(double v) {
+  for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s);
+  return v;
+}
+__device__ __forceinline__ double wave_min(double v) {
+  for (int s = 32; s > 0; s >>= 1) v = fmin(v, __shfl_xor(v, s));
+  return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+  for (int s = 32; s > 0; s >>= 1) v = fmax(v, __shfl_xor(v, s));
+  return v;
+}
+
+// prior_transform + loglikelihood for one walker spread over a wave:
+// lane owns dims lane, lane+64, ...; u in LDS row `su` (D), v written to `sv`.
+// For LIKE_GAUSS_PREC the precision matrix is read from global memory.
+__device__ double wide_logl(const ProblemDev& P, int D, const double* su, double* sv, int lane) {
+  // prior
+  if (P.prior_id == PRIOR_AFFINE) {
+    const double a = P.prior_par[0], b = P.prior_par[1];
+    for (int i = lane; i < D; i += 64) sv[i] = a * (2.0 * su[i] - 1.0) + b;
+  } else if (P.prior_id == PRIOR_NORMAL) {
+    const double mu = P.prior_par[0], sg = P.prior_par[1];
+    for (int i = lane; i < D; i += 64) sv[i] = mu + sg * ndtri_dev(su[i]);
+  } else {
+    for (int i = lane; i < D; i += 64) sv[i] = su[i];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  if (P.like_id == LIKE_GAUSS_PREC) {
+    const double* A = P.like_par + 1;
+    double q = 0.0;
+    for (int i = lane; i < D; i += 64) {
+      double r = 0.0;
+      const double* row = A + (size_t)i * D;
+      for (int j = 0; j < D; ++j) r = fma(row[j], sv[j], r);
+      q = fma(sv[i], r, q);
+    }
+    return P.like_par[0] - 0.5 * wave_sum(q);
+  } else if (P.like_id == LIKE_EGGBOX) {
+    const double tmax = P.like_par[0];
+    // product over dims in index order (lane 0 only: D is small for eggbox)
+    double prod = 1.0;
+    for (int i = 0; i < D; ++i) prod *= cos((2.0 * tmax * sv[i] - tmax) / 2.0);
+    const double b = 2.0 + prod, b2 = b * b;
+    return b2 * b2 * b;
+  } else {
+    double q = 0.0;
+    for (int i = lane; i < D; i += 64) q = fma(sv[i], sv[i], q);
+    return P.like_par[0] - 0.5 * wave_sum(q);
+  }
+}
+
+struct WideWalkArgs {
+  ProblemDev prob;
+  int k, ndim, ncdim, m, iters;  // iters = walks or slices
+  int kind;                      // 0 rwalk, 1 rslice, 2 slice
+  int doubling0;
+  double scale, loglstar;
+  const double* u0;
+  const double* axes_t;  // m x D x D, transposed (prep): AT[j*D + i] = axes[i][j]
+  const int32_t* axes_idx;
+  const int8_t* bc;
+  const uint64_t* rng_in;
+  double* u;
+  double* v;
+  double* logl;
+  int32_t* c0;  // rwalk: naccept ; slice: ncalls
+  int32_t* c1;  // rwalk: nreject ; slice: nexpand
+  int32_t* c2;  // slice: ncontract
+  int32_t* flags;
+  uint64_t* rng_out;
+  const uint64_t* zki;
+  const uint64_t* zwi;
+  const uint64_t* zfi;
+};
+
+__device__ __forceinline__ void lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// out[i] = sum_j AT[j*D + i] * x[j]   for i = lane, lane+64, ... ; x in LDS.
+// acc registers: up to 8 outputs per lane (D <= 512).
+__device__ __forceinline__ void wide_matvec(const double* __restrict__ AT, const double* x, int D,
+                                            int nj, int lane, double (&acc)[8]) {
+#pragma unroll
+  for (int r = 0; r < 8; ++r) acc[r] = 0.0;
+  for (int j = 0; j < nj; ++j) {
+    const double xj = x[j];
+    const double* row = AT + (size_t)j * D;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int i = lane + 64 * r;
+      if (i < D) acc[r] = fma(row[i], xj, acc[r]);
+    }
+  }
+}
+
+// one wavefront per walker; blockDim = 64.
+__global__ void __launch_bounds__(64) wide_walk_kernel(WideWalkArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ ZigLds zig;
+  zig_stage(&zig, a.zki, a.zwi, a.zfi);
+  const int lane = threadIdx.x;
+  const int w = blockIdx.x;
+  const int D = a.ndim, nc = a.ncdim;
+  double* su = (double*)smem;  // current point
+  double* sp = su + D;         // proposal / u_new
+  double* sd = sp + D;         // dr / direction
+  double* sv = sd + D;         // v
+  int* sperm = (int*)(sv + D);
+  if (a.u0)
+    for (int i = lane; i < D; i += 64) su[i] = a.u0[(size_t)w * D + i];
+  Pcg64 g;
+  g.load(a.rng_in + (size_t)w * 4);
+  const int frame = a.axes_idx ? a.axes_idx[w] : 0;
+  const double* AT = a.axes_t ? a.axes_t + (size_t)frame * nc * nc : nullptr;
+  double acc[8];
+  lds_sync();
+
+  if (a.kind == 3) {
+    // ---- UnitCubeSampler.sample (internal_samplers.py:364-441) ----
+    int ncall = 0;
+    double ll = -INFINITY;
+    for (;;) {
+      for (int i = 0; i < D; ++i) {
+        const double x = g.next_double();
+        if ((i & 63) == lane) su[i] = x;
+      }
+      lds_sync();
+      ll = wide_logl(a.prob, D, su, sv, lane);
+      ++ncall;
+      lds_sync();
+      if (ll > a.loglstar) break;
+    }
+    for (int i = lane; i < D; i += 64) {
+      a.u[(size_t)w * D + i] = su[i];
+      a.v[(size_t)w * D + i] = sv[i];
+    }
+    if (lane == 0) {
+      a.logl[w] = ll;
+      a.c0[w] = ncall;
+      a.flags[w] = 0;
+      if (a.rng_out) g.store(a.rng_out + (size_t)w * 4);
+    }
+    return;
+  }
+  if (a.kind == 0) {
+    // ---- rwalk (internal_samplers.py:866-1035) ----
+    int nacc = 0, nrej = 0;
+    double logl_cur = 0.0;
+    for (int step = 0; step < a.iters; ++step) {
+      for (int i = nc; i < D; ++i) {
+        const double x = g.next_double();
+        if ((i & 63) == lane) sp[i] = x;
+      }
+      double ss = 0.0;
+      for (int i = 0; i < nc; ++i) {
+        const double x = std_normal(g, &zig);
+        if ((i & 63) == lane) sd[i] = x;
+        ss = fma(x, x, ss);
+      }
+      const double fac = a.scale * (pow(g.next_double(), 1.0 / (double)nc) / sqrt(ss));
+      lds_sync();
+      wide_matvec(AT, sd, nc, nc, lane, acc);
+      bool inside = true;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int i = lane + 64 * r;
+        if (i < nc) sp[i] = fma(fac, acc[r], su[i]);
+      }
+      lds_sync();
+      for (int i = lane; i < D; i += 64) {
+        const int b = a.bc ? a.bc[i] : 0;
+        double x = sp[i];
+        if (b == DH_BC_PERIODIC) x = x - floor(x);
+        if (b == DH_BC_REFLECT) {
+          const double m2 = x - 2.0 * floor(x * 0.5), m1 = x - floor(x);
+          x = (m2 < 1.0) ? m1 : 1.0 - m1;
+        }
+        sp[i] = x;
+        if (b == DH_BC_HARD)
+          inside = inside && (x > 0.0) && (x < 1.0);
+        else
+          inside = inside && (x > -0.5) && (x < 1.5);
+      }
+      inside = __all(inside);
+      lds_sync();
+      if (!inside) {
+        ++nrej;
+        continue;
+      }
+      const double ll = wide_logl(a.prob, D, sp, sv, lane);
+      if (ll > a.loglstar) {
+        for (int i = lane; i < D; i += 64) su[i] = sp[i];
+        logl_cur = ll;
+        ++nacc;
+      } else {
+        ++nrej;
+      }
+      lds_sync();
+    }
+    const double ll0 = wide_logl(a.prob, D, su, sv, lane);
+    if (nacc == 0) logl_cur = ll0;
+    lds_sync();
+    for (int i = lane; i < D; i += 64) {
+      a.u[(size_t)w * D + i] = su[i];
+      a.v[(size_t)w * D + i] = sv[i];
+    }
+    if (lane == 0) {
+      a.logl[w] = logl_cur;
+      a.c0[w] = nacc;
+      a.c1[w] = nrej;
+      if (a.rng_out) g.store(a.rng_out + (size_t)w * 4);
+    }
+    return;
+  }
+
+  // ---- rslice / slice (internal_samplers.py:593-855, 1038-1206) ----
+  bool doubling = a.doubling0 != 0, warn_set = false, failed = false;
+  int ncall = 0, n_expand = 0, n_contract = 0;
+  double logl_cur = 0.0;
+  const double maxlen = sqrt((double)D) / 2.0;
+  const int nsub = a.kind == 1 ? 1 : D;
+  for (int s = 0; s < a.iters && !failed; ++s) {
+    if (a.kind == 2) {
+      // rstate.shuffle(arange(D)) -- sequential, every lane mirrors it
+      for (int i = lane; i < D; i += 64) sperm[i] = i;
+      lds_sync();
+      for (int i = D - 1; i >= 1; --i) {
+        const int j = (int)g.interval((uint64_t)i);
+        if (lane == 0) {
+          const int tmp = sperm[i];
+          sperm[i] = sperm[j];
+          sperm[j] = tmp;
+        }
+      }
+      lds_sync();
+    }
+    for (int sub = 0; sub < nsub && !failed; ++sub) {
+      if (a.kind == 1) {
+        double ss = 0.0;
+        for (int i = 0; i < D; ++i) {
+          const double x = std_normal(g, &zig);
+          if ((i & 63) == lane) sv[i] = x;  // sv as scratch for drhat
+          ss = fma(x, x, ss);
+        }
+        const double inv = 1.0 / sqrt(ss);
+        lds_sync();
+        for (int i = lane; i < D; i += 64) sv[i] = sv[i] * inv;
+        lds_sync();
+        wide_matvec(AT, sv, D, D, lane, acc);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          const int i = lane + 64 * r;
+          if (i < D) sd[i] = acc[r] * a.scale;
+        }
+      } else {
+        const int idx = sperm[sub];
+        const double* col = AT + (size_t)idx * D;
+        for (int i = lane; i < D; i += 64) sd[i] = a.scale * col[i];
+      }
+      lds_sync();
+      const double rand0 = g.next_double();
+      double dl = 0.0;
+      for (int i = lane; i < D; i += 64) dl = fma(sd[i], sd[i], dl);
+      dl = sqrt(wave_sum(dl));
+      const double dirnorm = dl > maxlen ? dl / maxlen : 1.0;
+      for (int i = lane; i < D; i += 64) sd[i] = sd[i] / dirnorm;
+      lds_sync();
+      // F(x): wave-uniform control flow (one walker per wave): plain code
+      auto F = [&](double x) -> double {
+        double lo = 2.0, hi = -1.0;
+        for (int i = lane; i < D; i += 64) {
+          const double un = fma(x, sd[i], su[i]);
+          sp[i] = un;
+          lo = fmin(lo, un);
+          hi = fmax(hi, un);
+        }
+        lo = wave_min(lo);
+        hi = wave_max(hi);
+        lds_sync();
+        ++ncall;
+        if (!(lo > 0.0 && hi < 1.0)) return -INFINITY;
+        const double ll = wide_logl(a.prob, D, sp, sv, lane);
+        lds_sync();
+        return ll;
+      };
+      double left = -rand0, right = 1.0 - rand0;
+      double f_l = F(left), f_r = F(right);
+      int nexp_step = 0;
+      double Lw = 0, Rw = 0, fLw = 0, fRw = 0;
+      if (!doubling) {
+        while (f_l > a.loglstar) {
+          left -= 1.0;
+          f_l = F(left);
+          ++nexp_step;
+        }
+        while (f_r > a.loglstar) {
+          right += 1.0;
+          f_r = F(right);
+          ++nexp_step;
+        }
+      } else {
+        int K = 1;
+        while (f_l > a.loglstar || f_r > a.loglstar) {
+          if (g.next_double() < 0.5) {
+            left -= (right - left);
+            f_l = F(left);
+          } else {
+            right += (right - left);
+            f_r = F(right);
+          }
+          nexp_step += K;
+          K *= 2;
+        }
+        Lw = left;
+        Rw = right;
+        fLw = f_l;
+        fRw = f_r;
+      }
+      for (;;) {
+        const double x = left + g.next_double() * (right - left);
+        const double f = F(x);
+        ++n_contract;
+        bool ok = f > a.loglstar;
+        if (ok && doubling) {
+          double lhat = Lw, rhat = Rw, f_lhat = fLw, f_rhat = fRw;
+          bool Df = false;
+          while (rhat - lhat > 1.1) {
+            const double M = (lhat + rhat) / 2.0;
+            if ((0.0 < M && M <= x) || (x < M && M <= 0.0)) Df = true;
+            if (x < M) {
+              rhat = M;
+              f_rhat = F(rhat);
+            } else {
+              lhat = M;
+              f_lhat = F(lhat);
+            }
+            if (Df && a.loglstar >= f_lhat && a.loglstar >= f_rhat) {
+              ok = false;
+              break;
+            }
+          }
+        }
+        if (ok) {
+          for (int i = lane; i < D; i += 64) su[i] = fma(x, sd[i], su[i]);
+          logl_cur = f;
+          lds_sync();
+          break;
+        }
+        if (x < 0.0)
+          left = x;
+        else if (x > 0.0)
+          right = x;
+        else {
+          failed = true;
+          break;
+        }
+      }
+      n_expand += nexp_step;
+      if (!doubling && nexp_step > 1000) {
+        doubling = true;
+        warn_set = true;
+      }
+    }
+  }
+  (void)wide_logl(a.prob, D, su, sv, lane);  // v of the returned point
+  lds_sync();
+  for (int i = lane; i < D; i += 64) {
+    a.u[(size_t)w * D + i] = su[i];
+    a.v[(size_t)w * D + i] = sv[i];
+  }
+  if (lane == 0) {
+    a.logl[w] = logl_cur;
+    a.c0[w] = ncall;
+    a.c1[w] = n_expand;
+    a.c2[w] = n_contract;
+    a.flags[w] = (warn_set ? 1 : 0) | (failed ? 2 : 0);
+    if (a.rng_out) g.store(a.rng_out + (size_t)w * 4);
+  }
+}
+
+__global__ void __launch_bounds__(64)
+    wide_eval_kernel(ProblemDev prob, int k, const double* __restrict__ u, double* v, double* logl) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int D = prob.ndim, lane = threadIdx.x, w = blockIdx.x;
+  double* su = (double*)smem;
+  double* sv = su + D;
+  for (int i = lane; i < D; i += 64) su[i] = u[(size_t)w * D + i];
+  lds_sync();
+  const double ll = wide_logl(prob, D, su, sv, lane);
+  lds_sync();
+  for (int i = lane; i < D; i += 64) v[(size_t)w * D + i] = sv[i];
+  if (lane == 0) logl[w] = ll;
+}
+
+__global__ void wide_transpose_kernel(const double* __restrict__ in, int m, int d, double* __restrict__ out) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t tot = (size_t)m * d * d;
+  if (t >= tot) return;
+  const size_t f = t / ((size_t)d * d), r = t % ((size_t)d * d);
+  const int j = (int)(r / d), i = (int)(r % d);
+  out[t] = in[f * d * d + (size_t)i * d + j];
+}
+
+// ---------------------------------------------------------------------------
+// membership, one workgroup (256 threads) per candidate point
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+    wide_contains_kernel(const double* __restrict__ x, int k, int d, const double* __restrict__ ctrs,
+                         const double* __restrict__ ams, int m, int mode, int32_t* count, uint64_t* mask,
+                         double* quad) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  double* dl = (double*)smem;  // d
+  double* red = dl + d;        // 256
+  const int p = blockIdx.x, t = threadIdx.x;
+  int cnt = 0;
+  const int nwords = (k + 63) / 64;
+  for (int e = 0; e < m; ++e) {
+    for (int i = t; i < d; i += 256) dl[i] = x[(size_t)p * d + i] - ctrs[(size_t)e * d + i];
+    __syncthreads();
+    const double* A = ams + (size_t)e * d * d;
+    double q = 0.0;
+    for (int i = t; i < d; i += 256) {
+      double r = 0.0;
+      const double* row = A + (size_t)i * d;
+      for (int j = 0; j < d; ++j) r = fma(row[j], dl[j], r);
+      q = fma(dl[i], r, q);
+    }
+    red[t] = q;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+      if (t < s) red[t] += red[t + s];
+      __syncthreads();
+    }
+    q = red[0];
+    __syncthreads();
+    const bool in = mode == 0 ? (q < 1.0) : (sqrt(q) <= 1.0);
+    cnt += in ? 1 : 0;
+    if (t == 0) {
+      if (quad) quad[(size_t)p * m + e] = q;
+      if (mask && in) atomicOr((unsigned long long*)&mask[(size_t)e * nwords + p / 64], 1ull << (p & 63));
+    }
+  }
+  if (t == 0) count[p] = cnt;
+}
+
+// ---------------------------------------------------------------------------
+// Ellipsoid.update (bounding_ellipsoid, bounding.py:1387-1461) for wide D:
+// one 1024-thread workgroup per run.
+// ---------------------------------------------------------------------------
+struct WideRebuildArgs {
+  const double* pts;
+  int n, d, runs;
+  double prefactor;
+  double* wsA;   // runs x d x d   Jacobi work
+  double* wsV;   // runs x d x d
+  double* wscov; // runs x d x d   working covariance
+  int* status;
+  double* ctrs;
+  double* covs;
+  double* ams;
+  double* axes;
+  double* axlens;
+  double* logvols;
+};
+
+__device__ double block_max_1024(double v, double* red) {
+  const int t = threadIdx.x;
+  v = wave_max(v);
+  if ((t & 63) == 0) red[t >> 6] = v;
+  __syncthreads();
+  double r = red[0];
+  for (int i = 1; i < kRT / 64; ++i) r = fmax(r, red[i]);
+  __syncthreads();
+  return r;
+}
+
+// parallel-order cyclic Jacobi on global-memory matrices (row-major d x d).
+__device__ bool jacobi_global(double* A, double* V, int D, double* rc, double* rs, int* rp, double* red) {
+  const int t = threadIdx.x;
+  const int m = (D + 1) / 2;
+  bool bad = false;
+  for (int e = t; e < D * D; e += kRT) {
+    const int i = e / D, j = e - i * D;
+    V[e] = (i == j) ? 1.0 : 0.0;
+    if (!isfinite(A[e])) bad = true;
+  }
+  if (__syncthreads_or(bad ? 1 : 0)) return false;
+  if (D == 1) return true;
+  const int P = 2 * m, rounds = P - 1;
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    double off = 0.0, dia = 0.0;
+    for (int e = t; e < D * D; e += kRT) {
+      const int i = e / D, j = e - i * D;
+      const double v = A[e];
+      if (i == j)
+        dia = fma(v, v, dia);
+      else
+        off = fma(v, v, off);
+    }
+    off = wave_sum(off);
+    dia = wave_sum(dia);
+    if ((t & 63) == 0) {
+      red[t >> 6] = off;
+      red[16 + (t >> 6)] = dia;
+    }
+    __syncthreads();
+    off = dia = 0.0;
+    for (int i = 0; i < kRT / 64; ++i) {
+      off += red[i];
+      dia += red[16 + i];
+    }
+    __syncthreads();
+    if (!(off > 1e-31 * dia)) break;
+    for (int r = 0; r < rounds; ++r) {
+      for (int k = t; k < m; k += kRT) {
+        int p, q;
+        if (k == 0) {
+          p = P - 1;
+          q = r;
+        } else {
+          p = r + k;
+          if (p >= P - 1) p -= P - 1;
+          q = r - k;
+          if (q < 0) q += P - 1;
+        }
+        if (p > q) {
+          const int tmp = p;
+          p = q;
+          q = tmp;
+        }
+        double c = 1.0, sn = 0.0;
+        if (q < D) {
+          const double apq = A[(size_t)p * D + q];
+          if (apq != 0.0) {
+            const double app = A[(size_t)p * D + p], aqq = A[(size_t)q * D + q];
+            const double tau = (aqq - app) / (2.0 * apq);
+            const double tt = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(fma(tau, tau, 1.0)));
+            c = 1.0 / sqrt(fma(tt, tt, 1.0));
+            sn = tt * c;
+          }
+        } else {
+          p = -1;
+        }
+        rc[k] = c;
+        rs[k] = sn;
+        rp[k] = p;
+        rp[kWideMaxD / 2 + 1 + k] = q;
+      }
+      __threadfence_block();
+      __syncthreads();
+      // columns: A <- A J, V <- V J      items (i, k), k fastest
+      for (int e = t; e < D * m; e += kRT) {
+        const int i = e / m, k = e - i * m;
+        const int p = rp[k], q = rp[kWideMaxD / 2 + 1 + k];
+        if (p >= 0) {
+          const double c = rc[k], sn = rs[k];
+          double* ar = A + (size_t)i * D;
+          const double aip = ar[p], aiq = ar[q];
+          ar[p] = c * aip - sn * aiq;
+          ar[q] = sn * aip + c * aiq;
+          double* vr = V + (size_t)i * D;
+          const double vip = vr[p], viq = vr[q];
+          vr[p] = c * vip - sn * viq;
+          vr[q] = sn * vip + c * viq;
+        }
+      }
+      __threadfence_block();
+      __syncthreads();
+      // rows: A <- J^T A                 items (k, j), j fastest (coalesced)
+      for (int e = t; e < m * D; e += kRT) {
+        const int k = e / D, j = e - k * D;
+        const int p = rp[k], q = rp[kWideMaxD / 2 + 1 + k];
+        if (p >= 0) {
+          const double c = rc[k], sn = rs[k];
+          const double apj = A[(size_t)p * D + j], aqj = A[(size_t)q * D + j];
+          A[(size_t)p * D + j] = (j == q) ? 0.0 : c * apj - sn * aqj;
+          A[(size_t)q * D + j] = (j == p) ? 0.0 : sn * apj + c * aqj;
+        }
+      }
+      __threadfence_block();
+      __syncthreads();
+    }
+  }
+  return true;
+}
+
+__global__ void __launch_bounds__(kRT) wide_single_kernel(WideRebuildArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int D = a.d, n = a.n, t = threadIdx.x, run = blockIdx.x;
+  const int LD = D | 1;
+  double* tile = (double*)smem;            // kTP x LD
+  double* mean = tile + (size_t)kTP * LD;  // D
+  double* lam = mean + D;                  // D
+  double* red = lam + D;                   // 64
+  double* rc = red + 64;                   // D/2+1
+  double* rs = rc + (kWideMaxD / 2 + 1);
+  int* rp = (int*)(rs + (kWideMaxD / 2 + 1));  // 2*(kWideMaxD/2+1)
+  int* order = rp + 2 * (kWideMaxD / 2 + 1);   // D
+  const double* pts = a.pts + (size_t)run * n * D;
+  double* A = a.wsA + (size_t)run * D * D;
+  double* V = a.wsV + (size_t)run * D * D;
+  double* cov = a.wscov + (size_t)run * D * D;
+  double* o_am = a.ams + (size_t)run * D * D;
+  double* o_ax = a.axes + (size_t)run * D * D;
+  int status = DH_OK;
+  if (n <= 1) status = DH_ERR_VALUE;
+
+  auto stage = [&](int base, int cnt, bool centre) {
+    for (int e = t; e < cnt * D; e += kRT) {
+      const int p = e / D, j = e - p * D;
+      double x = pts[(size_t)(base + p) * D + j];
+      if (centre) x -= mean[j];
+      tile[p * LD + j] = x;
+    }
+    __syncthreads();
+  };
+
+  if (status == DH_OK) {
+    // ---- mean (np.mean axis 0) ----
+    {
+      // thread (j, g): dims j = t % DP..., use simple map: each thread sums a strided set of points
+      const int G = kRT / D > 0 ? kRT / D : 1;
+      const int j = t % D, g = t / D;
+      double acc = 0.0;
+      if (g < G)
+        for (int p = g; p < n; p += G) acc += pts[(size_t)p * D + j];
+      // reduce the G partials per dimension through global scratch (A reused)
+      if (g < G) A[(size_t)g * D + j] = acc;
+      __threadfence_block();
+      __syncthreads();
+      if (t < D) {
+        double s = 0.0;
+        for (int gg = 0; gg < G; ++gg) s += A[(size_t)gg * D + t];
+        mean[t] = s / (double)n;
+      }
+      __syncthreads();
+    }
+    // ---- covariance (np.cov ddof=1): entries (a<=b) distributed over threads ----
+    {
+      const int nent = D * (D + 1) / 2;
+      constexpr int EPT = 24;  // entries per thread per pass (registers)
+      for (int e0 = 0; e0 < nent; e0 += kRT * EPT) {
+        double acc[EPT];
+        int ea[EPT], eb[EPT];
+#pragma unroll
+        for (int r = 0; r < EPT; ++r) {
+          acc[r] = 0.0;
+          const int e = e0 + r * kRT + t;
+          int aa = 0, rem = 0;
+          if (e < nent) {
+            aa = (int)floor(((2.0 * D + 1.0) - sqrt((2.0 * D + 1.0) * (2.0 * D + 1.0) - 8.0 * e)) * 0.5);
+            while (aa > 0 && aa * D - aa * (aa - 1) / 2 > e) --aa;
+            while ((aa + 1) * D - (aa + 1) * aa / 2 <= e) ++aa;
+            rem = e - (aa * D - aa * (aa - 1) / 2);
+          }
+          ea[r] = aa;
+          eb[r] = aa + rem;
+        }
+        for (int base = 0; base < n; base += kTP) {
+          const int cnt = min(kTP, n - base);
+          stage(base, cnt, true);
+#pragma unroll
+          for (int r = 0; r < EPT; ++r) {
+            if (e0 + r * kRT + t < nent) {
+              const int aa = ea[r], bb = eb[r];
+              double s = acc[r];
+              for (int p = 0; p < cnt; ++p) s = fma(tile[p * LD + aa], tile[p * LD + bb], s);
+              acc[r] = s;
+            }
+          }
+          __syncthreads();
+        }
+        const double inv = 1.0 / (double)(n - 1);
+#pragma unroll
+        for (int r = 0; r < EPT; ++r) {
+          if (e0 + r * kRT + t < nent) {
+            const double c = acc[r] * inv;
+            cov[(size_t)ea[r] * D + eb[r]] = c;
+            cov[(size_t)eb[r] * D + ea[r]] = c;
+          }
+        }
+      }
+      __threadfence_block();
+      __syncthreads();
+    }
+    // ---- improve_covar_mat + fmax passes (bounding.py:1311-1384, 1423-1457) ----
+    const double lim = 1.0 - 1e-3;
+    for (int pass = 0; pass < 2 && status == DH_OK; ++pass) {
+      bool good = false;
+      int failed = 0, trial = 0;
+      for (trial = 0; trial < 100; ++trial) {
+        failed = 0;
+        for (int e = t; e < D * D; e += kRT) A[e] = cov[e];
+        __threadfence_block();
+        __syncthreads();
+        const bool fin = jacobi_global(A, V, D, rc, rs, rp, red);
+        double top = -INFINITY, bot = INFINITY;
+        bool allfin = fin;
+        if (fin) {
+          for (int k = t; k < D; k += kRT) lam[k] = A[(size_t)k * D + k];
+          __syncthreads();
+          for (int k = 0; k < D; ++k) {
+            const double l = lam[k];
+            if (!isfinite(l)) allfin = false;
+            top = fmax(top, l);
+            bot = fmin(bot, l);
+          }
+        }
+        if (allfin) {
+          if (top <= 0.0)
+            failed = 2;
+          else if (bot < top / 1e12)
+            failed = 1;
+          else
+            break;
+        } else {
+          failed = 2;
+        }
+        if (failed == 1) {
+          __syncthreads();
+          if (t < D) lam[t] = fmax(lam[t], 10.0 * top / 1e12);
+          __syncthreads();
+          for (int e = t; e < D * D; e += kRT) {
+            const int i = e / D, j = e - i * D;
+            double s = 0.0;
+            for (int k = 0; k < D; ++k) s = fma(V[(size_t)i * D + k] * lam[k], V[(size_t)j * D + k], s);
+            cov[e] = s;
+          }
+        } else {
+          const double coeff = 1e-10 * pow(1e10, (double)trial / 99.0);
+          for (int e = t; e < D * D; e += kRT) {
+            const int i = e / D, j = e - i * D;
+            cov[e] = (1.0 - coeff) * cov[e] + coeff * (i == j ? 1.0 : 0.0);
+          }
+        }
+        __threadfence_block();
+        __syncthreads();
+      }
+      if (failed > 0) {
+        for (int e = t; e < D * D; e += kRT) {
+          const int i = e / D, j = e - i * D;
+          const double v = (i == j) ? 1.0 : 0.0;
+          cov[e] = v;
+          V[e] = v;
+        }
+        if (t < D) lam[t] = 1.0;
+        __threadfence_block();
+        __syncthreads();
+      } else {
+        good = trial == 0;
+      }
+      // sort ascending + canonical signs: order[] by rank; AX/AM from (V, lam)
+      for (int k = t; k < D; k += kRT) {
+        const double mine = lam[k];
+        int rank = 0;
+        for (int j = 0; j < D; ++j) {
+          const double o = lam[j];
+          if (o < mine || (o == mine && j < k)) ++rank;
+        }
+        order[rank] = k;
+      }
+      __syncthreads();
+      // sign of each sorted eigenvector (largest |component| positive) -> rc[] reused as sign
+      for (int k = t; k < D; k += kRT) {
+        const int src = order[k];
+        double best = 0.0, val = 1.0;
+        for (int i = 0; i < D; ++i) {
+          const double vv = V[(size_t)i * D + src];
+          if (fabs(vv) > best) {
+            best = fabs(vv);
+            val = vv;
+          }
+        }
+        // store the sign in the A work matrix diagonal slot k (A is dead here)
+        A[(size_t)k * D + k] = val < 0.0 ? -1.0 : 1.0;
+      }
+      __threadfence_block();
+      __syncthreads();
+      for (int e = t; e < D * D; e += kRT) {
+        const int i = e / D, k = e - i * D;
+        const int src = order[k];
+        o_ax[e] = A[(size_t)k * D + k] * V[(size_t)i * D + src] * sqrt(lam[src]);
+      }
+      for (int e = t; e < D * D; e += kRT) {
+        const int i = e / D, j = e - i * D;
+        double s = 0.0;
+        for (int k = 0; k < D; ++k) s = fma(V[(size_t)i * D + k] * (1.0 / lam[k]), V[(size_t)j * D + k], s);
+        o_am[e] = s;
+      }
+      __threadfence_block();
+      __syncthreads();
+      // ---- fmax = max_p delta^T am delta : lane = point, am through the scalar cache
+      double best = -INFINITY;
+      for (int base = 0; base < n; base += kTP) {
+        const int cnt = min(kTP, n - base);
+        stage(base, cnt, true);
+        // 16 waves x 64 lanes: wave wv handles rows wv, wv+16, ... for the tile's 64 points
+        const int lane = t & 63, wv = t >> 6;
+        double q = 0.0;
+        if (lane < cnt) {
+          const double* x = tile + lane * LD;
+          for (int i = wv; i < D; i += kRT / 64) {
+            const double* row = o_am + (size_t)i * D;  // written above: not via the scalar cache
+            double r = 0.0;
+            for (int j = 0; j < D; ++j) r = fma(row[j], x[j], r);
+            q = fma(x[i], r, q);
+          }
+        }
+        // reduce the 16 partial sums per point through LDS
+        __syncthreads();
+        double* part = tile;  // reuse (tile is dead after the barrier)
+        part[wv * 64 + lane] = q;
+        __syncthreads();
+        if (t < cnt) {
+          double s = 0.0;
+          for (int ww = 0; ww < kRT / 64; ++ww) s += part[ww * 64 + t];
+          best = fmax(best, s);
+        }
+        __syncthreads();
+      }
+      const double fmx = block_max_1024(best, red);
+      if (pass == 0 && fmx > lim) {
+        const double mult = fmx / lim, rt = sqrt(mult);
+        for (int e = t; e < D * D; e += kRT) {
+          cov[e] *= mult;
+          o_am[e] /= mult;
+          o_ax[e] *= rt;
+        }
+        __syncthreads();
+        if (t < D) lam[t] *= mult;
+        __threadfence_block();
+        __syncthreads();
+      }
+      if (pass == 1 && fmx >= 1.0) status = DH_ERR_CONTAIN;
+      if (good) break;
+    }
+  }
+  if (status == DH_OK) {
+    bool ok = true;
+    double slog = 0.0;
+    for (int k = 0; k < D; ++k) {
+      const double l = lam[k];
+      if (!(l > 0.0) || !isfinite(l)) ok = false;
+      slog += log(l);
+    }
+    if (!ok)
+      status = DH_ERR_VALUE;
+    else {
+      for (int e = t; e < D * D; e += kRT) a.covs[(size_t)run * D * D + e] = cov[e];
+      for (int k = t; k < D; k += kRT) {
+        a.ctrs[(size_t)run * D + k] = mean[k];
+        a.axlens[(size_t)run * D + k] = sqrt(lam[order[k]]);
+      }
+      if (t == 0) a.logvols[run] = a.prefactor + 0.5 * slog;
+    }
+  }
+  if (t == 0) a.status[run] = status;
+}
+
+size_t wide_single_lds(int D) {
+  const int LD = D | 1;
+  size_t dbl = (size_t)kTP * LD + 2 * (size_t)D + 64 + 2 * (kWideMaxD / 2 + 1);
+  size_t part = (size_t)(kRT / 64) * 64;  // fmax partials alias the tile
+  if (dbl < part) dbl = part;
+  return dbl * 8 + (2 * (kWideMaxD / 2 + 1) + kWideMaxD + 8) * 4;
+}
+
+int ensure_ws(dh_ctx* ctx, size_t bytes) {
+  if (bytes <= ctx->rebuild_ws_cap) return DH_OK;
+  if (!hip_ok(ctx, hipStreamSynchronize(ctx->stream), "sync")) return DH_ERR_HIP;
+  if (ctx->rebuild_ws) (void)hipFree(ctx->rebuild_ws);
+  ctx->rebuild_ws = nullptr;
+  ctx->rebuild_ws_cap = 0;
+  if (!hip_ok(ctx, hipMalloc((void**)&ctx->rebuild_ws, bytes), "hipMalloc(wide scratch)")) return DH_ERR_NOMEM;
+  ctx->rebuild_ws_cap = bytes;
+  return DH_OK;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// entry points used by the dispatchers in walk.hip / walk2.hip / bound.hip /
+// rebuild.hip when the dimension exceeds the register-resident limits
+// ---------------------------------------------------------------------------
+namespace dh {
+
+int wide_walk_launch(dh_ctx* ctx, int kind, int problem, int k, int ndim, int ncdim, const double* u0,
+                     const double* axes, int m, const int32_t* axes_idx, double scale, double loglstar,
+                     int iters, int doubling, const int8_t* bc, const uint64_t* rng, double* u, double* v,
+                     double* logl, int32_t* c0, int32_t* c1, int32_t* c2, int32_t* flags,
+                     uint64_t* rng_out) {
+  WideWalkArgs a;
+  if (!get_problem(ctx, problem, &a.prob)) return DH_ERR_ARG;
+  if (ndim > kWideMaxD) return fail(ctx, DH_ERR_ARG, "ndim=%d exceeds the wide-D limit %d", ndim, kWideMaxD);
+  // transposed frames in the context scratch
+  const size_t at_bytes = axes ? (size_t)m * ncdim * ncdim * 8 : 0;
+  if (at_bytes > ctx->axes_t_cap) {
+    if (!hip_ok(ctx, hipStreamSynchronize(ctx->stream), "sync")) return DH_ERR_HIP;
+    if (ctx->axes_t) (void)hipFree(ctx->axes_t);
+    ctx->axes_t = nullptr;
+    ctx->axes_t_cap = 0;
+    if (!hip_ok(ctx, hipMalloc((void**)&ctx->axes_t, at_bytes * 2), "hipMalloc(axes_t)")) return DH_ERR_NOMEM;
+    ctx->axes_t_cap = at_bytes * 2;
+  }
+  const size_t tot = axes ? (size_t)m * ncdim * ncdim : 0;
+  if (tot)
+    hipLaunchKernelGGL(wide_transpose_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream,
+                     axes, m, ncdim, ctx->axes_t);
+  a.k = k;
+  a.ndim = ndim;
+  a.ncdim = ncdim;
+  a.m = m;
+  a.iters = iters;
+  a.kind = kind;
+  a.doubling0 = doubling;
+  a.scale = scale;
+  a.loglstar = loglstar;
+  a.u0 = u0;
+  a.axes_t = ctx->axes_t;
+  a.axes_idx = axes_idx;
+  a.bc = bc;
+  a.rng_in = rng;
+  a.u = u;
+  a.v = v;
+  a.logl = logl;
+  a.c0 = c0;
+  a.c1 = c1;
+  a.c2 = c2;
+  a.flags = flags;
+  a.rng_out = rng_out;
+  a.zki = ctx->zki();
+  a.zwi = ctx->zwi();
+  a.zfi = ctx->zfi();
+  const size_t lds = (size_t)4 * ndim * 8 + (size_t)ndim * 4 + 64;
+  hipLaunchKernelGGL(wide_walk_kernel, dim3(k), dim3(64), lds, ctx->stream, a);
+  return hip_ok(ctx, hipGetLastError(), "wide walk launch") ? DH_OK : DH_ERR_HIP;
+}
+
+int wide_eval_launch(dh_ctx* ctx, const ProblemDev& p, int k, const double* u, double* v, double* logl) {
+  if (p.ndim > kWideMaxD) return fail(ctx, DH_ERR_ARG, "ndim=%d exceeds the wide-D limit %d", p.ndim, kWideMaxD);
+  hipLaunchKernelGGL(wide_eval_kernel, dim3(k), dim3(64), (size_t)2 * p.ndim * 8, ctx->stream, p, k, u, v,
+                     logl);
+  return hip_ok(ctx, hipGetLastError(), "wide eval launch") ? DH_OK : DH_ERR_HIP;
+}
+
+int wide_contains_launch(dh_ctx* ctx, const double* x, int k, int d, const double* ctrs, const double* ams,
+                         int m, int mode, int32_t* count, uint64_t* mask, double* quad) {
+  if (d > 4096) return fail(ctx, DH_ERR_ARG, "contains: d=%d too large", d);
+  if (mask) {
+    const size_t nw = (size_t)(k + 63) / 64 * m;
+    if (!hip_ok(ctx, hipMemsetAsync(mask, 0, nw * 8, ctx->stream), "memset(mask)")) return DH_ERR_HIP;
+  }
+  hipLaunchKernelGGL(wide_contains_kernel, dim3(k), dim3(256), (size_t)(d + 256) * 8, ctx->stream, x, k, d,
+                     ctrs, ams, m, mode, count, mask, quad);
+  return hip_ok(ctx, hipGetLastError(), "wide contains launch") ? DH_OK : DH_ERR_HIP;
+}
+
+int wide_single_launch(dh_ctx* ctx, int runs, const double* pts, int n, int d, int32_t* nells,
+                       int32_t* status, double* ctrs, double* covs, double* ams, double* axes,
+                       double* axlens, double* logvols) {
+  if (d > kWideMaxD) return fail(ctx, DH_ERR_ARG, "rebuild: d=%d exceeds the wide-D limit %d", d, kWideMaxD);
+  const size_t lds = wide_single_lds(d);
+  if (lds > 159 * 1024) return fail(ctx, DH_ERR_ARG, "rebuild: d=%d needs %zu B of LDS", d, lds);
+  const size_t dd = (size_t)d * d * 8;
+  int rc = ensure_ws(ctx, 3 * dd * runs + 4096);
+  if (rc) return rc;
+  WideRebuildArgs a;
+  a.pts = pts;
+  a.n = n;
+  a.d = d;
+  a.runs = runs;
+  a.prefactor = d * log(2.0) + d * lgamma(1.5) - lgamma(d / 2.0 + 1.0);
+  a.wsA = (double*)ctx->rebuild_ws;
+  a.wsV = a.wsA + (size_t)runs * d * d;
+  a.wscov = a.wsV + (size_t)runs * d * d;
+  a.status = status;
+  a.ctrs = ctrs;
+  a.covs = covs;
+  a.ams = ams;
+  a.axes = axes;
+  a.axlens = axlens;
+  a.logvols = logvols;
+  static size_t attr_lds = 0;
+  if (lds > attr_lds) {
+    if (!hip_ok(ctx,
+                hipFuncSetAttribute((const void*)wide_single_kernel,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+                "hipFuncSetAttribute(wide LDS)"))
+      return DH_ERR_HIP;
+    attr_lds = lds;
+  }
+  hipLaunchKernelGGL(wide_single_kernel, dim3(runs), dim3(kRT), lds, ctx->stream, a);
+  if (!hip_ok(ctx, hipGetLastError(), "wide rebuild launch")) return DH_ERR_HIP;
+  // nells = 1 per run (status decides validity)
+  std::vector<int32_t> ones((size_t)runs, 1);
+  if (!hip_ok(ctx, hipMemcpyAsync(nells, ones.data(), (size_t)runs * 4, hipMemcpyHostToDevice, ctx->stream),
+              "H2D nells"))
+    return DH_ERR_HIP;
+  return hip_ok(ctx, hipStreamSynchronize(ctx->stream), "sync") ? DH_OK : DH_ERR_HIP;
+}
+
+}  // namespace dh

@@ -1,0 +1,130 @@
+"""Wide-D path (wave-per-walker proposals, 1024-thread single-ellipsoid
+rebuild, workgroup-per-point membership): BASELINE config C4 shapes (200-D,
+N=4000, single/rslice) and dimensions without a register-resident
+instantiation, against the oracle on the same seeds."""
+import numpy as np
+import pytest
+
+import inputs
+from oracle import bounding_ref as B
+from oracle import proposals_ref as P
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from dynesty_amd import _lib
+    return _lib.Context(0)
+
+
+def test_eval_and_contains_200d(ctx):
+    prob = inputs.problem("C4")
+    rng = np.random.default_rng(2)
+    u = rng.uniform(0.01, 0.99, size=(70, 200))
+    v, logl = ctx.problem_eval(prob, u)
+    np.testing.assert_allclose(v, prob.prior_transform_many(u), rtol=1e-11,
+                               atol=1e-12)
+    np.testing.assert_allclose(
+        logl, prob.loglikelihood_many(prob.prior_transform_many(u)), rtol=1e-11)
+    d, m = 200, 2
+    ctrs = rng.uniform(0.4, 0.6, size=(m, d))
+    a = rng.standard_normal((m, d, d)) * 0.05
+    ams = np.einsum('mij,mkj->mik', a, a) + 3 * np.eye(d)
+    x = ctrs[0] + 0.05 * rng.standard_normal((130, d))
+    count, mask, quad = ctx.contains(x, ctrs, ams, want_mask=True,
+                                     want_quad=True)
+    want = np.array([B.multi_quadforms(p, ctrs, ams) for p in x])
+    np.testing.assert_allclose(quad, want, rtol=1e-11)
+    np.testing.assert_array_equal(count, (want < 1).sum(1))
+    bits = np.unpackbits(mask.view(np.uint8).reshape(m, -1), axis=1,
+                         bitorder="little")[:, :130].astype(bool)
+    np.testing.assert_array_equal(bits, (want < 1).T)
+
+
+def test_single_rebuild_200d(ctx):
+    """Ellipsoid.update on the C4-shaped live set (4000 x 200)."""
+    pts = inputs.cloud("g200")
+    got = ctx.rebuild(pts, multi=False)
+    ref = B.bounding_ellipsoid(pts)
+    np.testing.assert_allclose(got["ctrs"][0], ref.ctr, rtol=0, atol=1e-13)
+    np.testing.assert_allclose(got["covs"][0], ref.cov, rtol=1e-9,
+                               atol=1e-9 * np.abs(ref.cov).max())
+    np.testing.assert_allclose(got["ams"][0], ref.am, rtol=0,
+                               atol=1e-8 * np.abs(ref.am).max())
+    np.testing.assert_allclose(got["logvol_ells"][0], ref.logvol, atol=1e-8)
+    np.testing.assert_allclose(got["axlens"][0], np.sort(ref.axlens),
+                               rtol=1e-9)
+    ax = got["axes"][0]
+    np.testing.assert_allclose(ax @ ax.T, ref.cov, rtol=0,
+                               atol=1e-9 * np.abs(ref.cov).max())
+    d = pts - got["ctrs"][0]
+    q = np.einsum('ij,jk,ik->i', d, got["ams"][0], d)
+    np.testing.assert_allclose(q.max(), 1 - 1e-3, rtol=1e-8)
+    with pytest.raises(Exception):
+        ctx.rebuild(pts, multi=True)  # MultiEllipsoid for d > 44: loud, not silent
+
+
+@pytest.mark.parametrize("pname,d", [("C4", 200), ("N7", 7)])
+def test_rslice_wide_vs_oracle(ctx, pname, d):
+    from dynesty_amd import _lib, problems
+    prob = inputs.problem("C4") if pname == "C4" else \
+        problems.gauss_normal_prior(7, "N7")
+    rng = np.random.default_rng(4)
+    k = 6
+    u0 = np.clip(0.5 + 0.08 * rng.standard_normal((k, d)), 0.02, 0.98)
+    logl0 = prob.loglikelihood_many(prob.prior_transform_many(u0))
+    loglstar = float(logl0.min() - 5.0)
+    q, _ = np.linalg.qr(rng.standard_normal((d, d)))
+    axes = q * (0.08 * np.sqrt(d) * rng.uniform(0.8, 1.4, size=d))
+    ent = [31, 32]
+    st = ctx.seed_children(ent, 0, k)
+    slices = 3
+    out = ctx.slice_batch(prob, u0, axes, 0.8, loglstar, slices, st)
+    kids = np.random.SeedSequence(ent).spawn(k)
+    for i in range(k):
+        bg = np.random.PCG64(kids[i])
+        ref = P.rslice(u0[i].copy(), loglstar, axes, 0.8, prob.prior_transform,
+                       prob.loglikelihood, np.random.Generator(bg), slices)
+        assert ref["ncalls"] == out["ncalls"][i]
+        assert ref["n_expand"] == out["n_expand"][i]
+        assert ref["n_contract"] == out["n_contract"][i]
+        np.testing.assert_allclose(out["u"][i], ref["u"], rtol=0, atol=1e-11)
+        np.testing.assert_allclose(out["logl"][i], ref["logl"], rtol=1e-10)
+        np.testing.assert_array_equal(out["rng_out"][i],
+                                      _lib.pcg_state_words(bg))
+
+
+def test_rwalk_and_unitcube_wide_vs_oracle(ctx):
+    from dynesty_amd import _lib, problems
+    prob = problems.gauss_corr(40, 0.3, 5.0, "G40")  # precision-matrix path, D > 32
+    d = 40
+    rng = np.random.default_rng(6)
+    k = 5
+    u0 = np.clip(0.5 + 0.05 * rng.standard_normal((k, d)), 0.02, 0.98)
+    loglstar = float(prob.loglikelihood_many(
+        prob.prior_transform_many(u0)).min() - 8.0)
+    q, _ = np.linalg.qr(rng.standard_normal((d, d)))
+    axes = q * (0.05 * np.sqrt(d))
+    ent = [41]
+    st = ctx.seed_children(ent, 0, k)
+    out = ctx.rwalk_batch(prob, u0, axes, 0.6, loglstar, 30, st)
+    kids = np.random.SeedSequence(ent).spawn(k)
+    for i in range(k):
+        bg = np.random.PCG64(kids[i])
+        ref = P.rwalk(u0[i].copy(), loglstar, axes, 0.6, prob.prior_transform,
+                      prob.loglikelihood, np.random.Generator(bg), 30)
+        assert ref["accept"] == out["accept"][i]
+        np.testing.assert_allclose(out["u"][i], ref["u"], rtol=0, atol=1e-11)
+        np.testing.assert_allclose(out["logl"][i], ref["logl"], rtol=1e-10)
+        np.testing.assert_array_equal(out["rng_out"][i],
+                                      _lib.pcg_state_words(bg))
+    # unit cube in 40-D with a very low threshold
+    st = ctx.seed_children([43], 0, 4)
+    out = ctx.unif_batch(prob, -1e6, st)
+    kids = np.random.SeedSequence([43]).spawn(4)
+    for i in range(4):
+        ref = P.unitcube(-1e6, prob.prior_transform, prob.loglikelihood,
+                         np.random.Generator(np.random.PCG64(kids[i])), d)
+        np.testing.assert_allclose(out["u"][i], ref["u"], rtol=0, atol=0)
+        assert out["ncalls"][i] == ref["ncalls"]
