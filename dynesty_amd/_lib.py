@@ -85,6 +85,9 @@ SIGNATURES = {
     "dh_unif_batch_dev": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp,
                                _dbl, _vp, _vp, C.c_int64, _vp, _vp, _vp, _vp,
                                _vp, _vp]),
+    "dh_ns_ensemble": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _dbl, _dbl,
+                            C.c_int64, C.c_int64, _vp, _i, _u32, _vp, _vp,
+                            _vp]),
     "dh_bound_draw": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp,
                            _vp, _vp, _vp]),
 }
@@ -430,6 +433,34 @@ class Context:
             _ptr(rng), int(max_tries), _ptr(u), _ptr(v), _ptr(logl), _ptr(nc),
             _ptr(rng_out)))
         return dict(u=u, v=v, logl=logl, ncalls=nc, rng_out=rng_out)
+
+    def ns_ensemble(self, prob, runs, nlive, queue_size, walks=None,
+                    bound='multi', dlogz=0.01, enlarge=1.25, entropy=(21,),
+                    first_run=0, max_fills=0, max_iter=400000,
+                    want_dead_logl=False):
+        """Device-resident ensemble of static NS runs (dh_ns_ensemble)."""
+        nd = prob.ndim
+        if walks is None:
+            walks = nd + 20
+        words = entropy_words(entropy)
+        rec = np.empty((runs, 8))
+        dead = np.empty((runs, max_iter)) if want_dead_logl else None
+        nf = C.c_int64(0)
+        self._check(self.lib.dh_ns_ensemble(
+            self.handle, self.problem(prob), int(runs), int(nlive), nd,
+            int(queue_size), int(walks), 1 if bound == 'multi' else 0,
+            float(dlogz), float(enlarge), int(max_fills), int(max_iter),
+            _ptr(words), words.size, int(first_run), _ptr(rec), _ptr(dead),
+            C.byref(nf)))
+        out = dict(logz=rec[:, 0], logzerr=rec[:, 1],
+                   niter=rec[:, 2].astype(np.int64),
+                   ncall=rec[:, 3].astype(np.int64), h=rec[:, 4],
+                   nbound=rec[:, 5].astype(np.int64),
+                   status=rec[:, 6].astype(np.int64), eff=rec[:, 7],
+                   nfills=nf.value)
+        if want_dead_logl:
+            out["dead_logl"] = dead
+        return out
 
     def bound_draw(self, state4, nsamp, ctrs, axes, ams=None, logvol_ells=None,
                    return_q=False):

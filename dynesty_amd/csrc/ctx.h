@@ -85,6 +85,31 @@ inline bool down(dh_ctx* ctx, T* host, const T* dev, size_t count) {
 
 bool get_problem(dh_ctx* ctx, int handle, ProblemDev* out);
 
+// ensemble forms used by ns.hip: per-run loglstar / scale arrays, walkers of
+// runs whose run_mode != my_mode are skipped (run = walker / wpr)
+int rwalk_launch_runs(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, const double* u0,
+                      const double* axes, int m, const int32_t* axes_idx, double scale, double loglstar,
+                      int walks, const int8_t* bc, const uint64_t* rng, double* u, double* v, double* logl,
+                      int32_t* naccept, int32_t* nreject, uint64_t* rng_out, const double* run_loglstar,
+                      const double* run_scale, const int* run_mode, int wpr, int my_mode);
+int unif_launch_runs(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, int m, const double* ctrs,
+                     const double* axes, const double* ams, const double* cumprob, double loglstar,
+                     const int8_t* bc, const uint64_t* rng, int64_t max_tries, double* u, double* v,
+                     double* logl, int32_t* ncalls, int32_t* flags, uint64_t* rng_out,
+                     const double* run_loglstar, const int* run_mode, int wpr, int my_mode);
+
+int rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int d, int mode, int max_ells,
+                        int32_t* nells, int32_t* status, double* ctrs, double* covs, double* ams,
+                        double* axes, double* axlens, double* logvols, int32_t* leaf_of_point,
+                        int32_t* nnodes, const int* active);
+int rebuild_launch_masked(dh_ctx* ctx, int runs, const double* pts, int n, int d, int mode, int max_ells,
+                          int32_t* nells, int32_t* status, double* ctrs, double* covs, double* ams,
+                          double* axes, double* axlens, double* logvols, const int* active);
+int enlarge_launch_masked(dh_ctx* ctx, int runs, int max_ells, const int32_t* nells, int d, double* covs,
+                          double* ams, double* axes, double* axlens, double* logvols, double log_enlarge,
+                          const int* active);
+int eval_launch_dev(dh_ctx* ctx, int problem, int k, const double* u, double* v, double* logl);
+
 // wide-D path (wide.hip): used by the dispatchers when the dimension exceeds the
 // register-resident limits.  kind: 0 rwalk, 1 rslice, 2 slice, 3 unit cube.
 int wide_walk_launch(dh_ctx* ctx, int kind, int problem, int k, int ndim, int ncdim, const double* u0,

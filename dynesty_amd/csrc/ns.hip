@@ -1,0 +1,628 @@
+// Device-resident ensemble of static nested-sampling runs (SURVEY.md section 8f-1,
+// BASELINE config C5).  The run loop of the reference (sampler.py:932-1212:
+// pop the worst live point, replace it by a proposal that beats it, integrate
+// ln Z; :676-778 queue semantics; :625-674 bound-update policy) is executed on
+// the GPU for `runs` independent runs at once; the host only enqueues a fixed
+// kernel sequence per queue fill and polls a done-counter every few fills.
+//
+//   per fill:  ns_prepare  (policy: switch unit cube -> bound, schedule rebuilds)
+//              rebuild pipeline + enlarge        (only runs that asked for it)
+//              ns_select   (K start points, proposal frames, walker RNG streams)
+//              unit-cube / rwalk walk kernels    (all runs x K walkers, one launch each)
+//              ns_consume  (sequential queue consumption per run on a min-heap in
+//                           LDS, dead-point record, evidence integration, tuning)
+//   at the end: ns_finish  (append the final live points, write the record)
+//
+// All state (live points, heap, dead points, integrals, RNG) stays in HBM; with
+// 288 GB there is room for the full dead-point history of thousands of runs.
+#include <math.h>
+
+#include "ctx.h"
+#include "rng_pcg64.h"
+
+using namespace dh;
+
+
+namespace {
+
+constexpr int kT = 256;
+enum : int { MODE_CUBE = 0, MODE_BOUND = 1, MODE_DONE = 2, MODE_FAILED = 3 };
+
+struct NsRun {
+  double logvol, logz, h, lmax, scale, loglstar, dead_prev;
+  long long it, ncall, ncall_last_update;
+  int mode, need_rebuild, nbound, nfill;
+  int acc, rej, pad0, pad1;
+  uint64_t rng[4];
+};
+
+struct NsArgs {
+  int runs, nlive, ndim, K, walks, bound_multi, max_ells;
+  long long cap;  // dead-point capacity per run
+  double dlogz, enlarge_log, facc, first_eff;
+  long long first_ncall, update_interval;
+  int store_samples;
+  NsRun* st;
+  double* live_u;
+  double* live_v;
+  double* live_logl;
+  double* heap_key;
+  int* heap_slot;
+  double* dead_logl;
+  double* dead_u;      // optional
+  // queue
+  double* q_u0;
+  int* q_frame;
+  uint64_t* q_rng;
+  uint64_t* q_rng_out;
+  double* r_u;
+  double* r_v;
+  double* r_logl;
+  int* r_a;  // naccept | ncalls (unit cube)
+  int* r_b;  // nreject | flags
+  // per-run walk parameters
+  double* run_loglstar;
+  double* run_scale;
+  int* run_mode;
+  int* rebuild_mask;
+  int* ndone;
+  // bound (rebuild outputs)
+  int* nells;
+  int* bstatus;
+  double* b_ctrs;
+  double* b_covs;
+  double* b_ams;
+  double* b_axes;
+  double* b_axl;
+  double* b_lv;
+  // results
+  double* records;  // runs x 8: logz, logzerr, niter, ncall, h, nbound, status, eff
+};
+
+__device__ __forceinline__ double logaddexp_dev(double x, double y) {
+  if (x == y) return x + 0.6931471805599453;
+  const double d = x - y;
+  if (d > 0) return x + log1p(exp(-d));
+  if (d <= 0) return y + log1p(exp(d));
+  return x + y;
+}
+
+// progress_integration (utils.py:1470-1492), one dead point
+__device__ __forceinline__ void integrate_step(double& logz, double& h, double lprev, double lnew,
+                                               double logvol, double dlv) {
+  const double logdvol = logvol + log(0.5 * expm1(dlv));
+  const double logwt = logaddexp_dev(lnew, lprev) + logdvol;
+  const double logz_new = logaddexp_dev(logz, logwt);
+  const double t0 = exp(lprev - logz_new + logdvol), t1 = exp(lnew - logz_new + logdvol);
+  const double lzterm = (t0 > 0.0 ? t0 * lprev : 0.0) + (t1 > 0.0 ? t1 * lnew : 0.0);
+  const double w = exp(logz - logz_new);
+  h = lzterm + (w > 0.0 ? w * (h + logz) : 0.0) - logz_new;
+  logz = logz_new;
+}
+
+// ---- init: RNG, uniform live points --------------------------------------
+__global__ void __launch_bounds__(kT)
+    ns_init(NsArgs a, const uint32_t* __restrict__ entropy, int nwords, uint32_t first_run) {
+  const int run = blockIdx.x, t = threadIdx.x;
+  const int N = a.nlive, D = a.ndim;
+  // every live point gets its own stream: child (first_run + run) * N + i of the entropy
+  for (int i = t; i < N; i += kT) {
+    Pcg64 g;
+    seed_from_child(g, entropy, nwords, (uint32_t)((first_run + run) * (uint32_t)N + i));
+    double* u = a.live_u + ((size_t)run * N + i) * D;
+    for (int j = 0; j < D; ++j) u[j] = g.next_double();
+  }
+  if (t == 0) {
+    NsRun r;
+    r.logvol = 0.0;
+    r.logz = -1e300;
+    r.h = 0.0;
+    r.lmax = -1e300;
+    r.scale = 1.0;
+    r.loglstar = -1e300;
+    r.dead_prev = -1e300;
+    r.it = 0;
+    r.ncall = N;
+    r.ncall_last_update = 0;
+    r.mode = MODE_CUBE;
+    r.need_rebuild = 0;
+    r.nbound = 0;
+    r.nfill = 0;
+    r.acc = r.rej = r.pad0 = r.pad1 = 0;
+    Pcg64 g;
+    seed_from_child(g, entropy, nwords, 0x80000000u + first_run + (uint32_t)run);
+    g.store(r.rng);
+    a.st[run] = r;
+  }
+}
+
+// ---- heapify after the initial evaluation ------------------------------------
+__global__ void __launch_bounds__(kT) ns_heapify(NsArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int run = blockIdx.x, t = threadIdx.x, N = a.nlive;
+  double* key = (double*)smem;
+  int* slot = (int*)(key + N);
+  __shared__ double red[kT];
+  double mx = -1e300;
+  for (int i = t; i < N; i += kT) {
+    key[i] = a.live_logl[(size_t)run * N + i];
+    slot[i] = i;
+    mx = fmax(mx, key[i]);
+  }
+  red[t] = mx;
+  __syncthreads();
+  for (int s = kT / 2; s > 0; s >>= 1) {
+    if (t < s) red[t] = fmax(red[t], red[t + s]);
+    __syncthreads();
+  }
+  if (t == 0) {
+    for (int start = N / 2 - 1; start >= 0; --start) {  // Floyd
+      int i = start;
+      const double k0 = key[i];
+      const int s0 = slot[i];
+      for (;;) {
+        int c = 2 * i + 1;
+        if (c >= N) break;
+        if (c + 1 < N && key[c + 1] < key[c]) ++c;
+        if (!(key[c] < k0)) break;
+        key[i] = key[c];
+        slot[i] = slot[c];
+        i = c;
+      }
+      key[i] = k0;
+      slot[i] = s0;
+    }
+    a.st[run].lmax = red[0];
+    a.st[run].loglstar = key[0];
+  }
+  __syncthreads();
+  for (int i = t; i < N; i += kT) {
+    a.heap_key[(size_t)run * N + i] = key[i];
+    a.heap_slot[(size_t)run * N + i] = slot[i];
+  }
+}
+
+// ---- policy (sampler.py:625-674 update_bound_if_needed) ------------------------
+__global__ void ns_prepare(NsArgs a) {
+  const int run = blockIdx.x * blockDim.x + threadIdx.x;
+  if (run >= a.runs) return;
+  NsRun& r = a.st[run];
+  int need = 0;
+  if (r.mode == MODE_CUBE || r.mode == MODE_BOUND) {
+    if (r.mode == MODE_BOUND && a.bstatus[run] != DH_OK) {
+      r.mode = MODE_FAILED;
+      atomicAdd(a.ndone, 1);
+    } else {
+      const double eff = 100.0 * (double)(r.it > 0 ? r.it : 1) / (double)r.ncall;
+      if (r.mode == MODE_CUBE) {
+        if (r.ncall >= a.first_ncall && eff < a.first_eff) {
+          r.mode = MODE_BOUND;
+          need = 1;
+        }
+      } else if (r.ncall >= r.ncall_last_update + a.update_interval) {
+        need = 1;
+      }
+      if (need) {
+        r.ncall_last_update = r.ncall;
+        r.nbound += 1;
+      }
+    }
+  }
+  r.need_rebuild = need;
+  a.rebuild_mask[run] = need;
+  a.run_mode[run] = r.mode;
+  a.run_loglstar[run] = r.loglstar;
+  a.run_scale[run] = r.scale;
+}
+
+// ---- queue fill: start points, frames, walker streams ---------------------------
+__global__ void __launch_bounds__(kT) ns_select(NsArgs a) {
+  __shared__ uint64_t ent[4];
+  __shared__ double cum[64];
+  __shared__ int Msh;
+  const int run = blockIdx.x, t = threadIdx.x;
+  const int N = a.nlive, D = a.ndim, K = a.K;
+  NsRun& r = a.st[run];
+  const int mode = r.mode;
+  if (mode != MODE_CUBE && mode != MODE_BOUND) return;
+  if (mode == MODE_BOUND && a.bstatus[run] != DH_OK) return;  // ns_prepare fails the run next fill
+  int M = 1;
+  if (t == 0) {
+    Pcg64 g;
+    g.load(r.rng);
+    for (int i = 0; i < 4; ++i) ent[i] = g.next64();
+    g.store(r.rng);
+    if (mode == MODE_BOUND && a.bound_multi) {
+      M = a.nells[run];
+      if (M > 64) M = 64;
+      // rand_choice weights: cumsum(exp(logvol_ells - logsumexp))
+      double mx = -INFINITY;
+      for (int e = 0; e < M; ++e) mx = fmax(mx, a.b_lv[(size_t)run * a.max_ells + e]);
+      double s = 0.0;
+      for (int e = 0; e < M; ++e) s += exp(a.b_lv[(size_t)run * a.max_ells + e] - mx);
+      double c = 0.0;
+      for (int e = 0; e < M; ++e) {
+        c += exp(a.b_lv[(size_t)run * a.max_ells + e] - mx) / s;
+        cum[e] = c;
+      }
+    }
+    Msh = M;
+  }
+  __syncthreads();
+  M = Msh;
+  const double loglstar = r.loglstar;
+  for (int w = t; w < K; w += kT) {
+    Pcg64 g;
+    U128 is = {ent[0], ent[1] + (uint64_t)w};
+    U128 iq = {ent[2], ent[3] + 2ull * (uint64_t)w};
+    g.seed(is, iq);
+    const size_t q = (size_t)run * K + w;
+    int frame = 0;
+    if (mode == MODE_BOUND) {
+      // a live point with logl > loglstar, uniformly (sampler.py:469-474)
+      int i;
+      int guard = 0;
+      do {
+        i = (int)g.interval((uint64_t)(N - 1));
+      } while (!(a.live_logl[(size_t)run * N + i] > loglstar) && ++guard < 100000);
+      const double* src = a.live_u + ((size_t)run * N + i) * D;
+      double* dst = a.q_u0 + q * D;
+      for (int j = 0; j < D; ++j) dst[j] = src[j];
+      if (M > 1) {
+        const double xr = g.next_double();
+        while (frame < M - 1 && cum[frame] < xr) ++frame;
+      }
+    }
+    a.q_frame[q] = run * a.max_ells + frame;
+    g.store(a.q_rng + q * 4);
+  }
+}
+
+// ---- consume the queue (sampler.py:732-778 + 1105-1185), one workgroup per run ----
+__global__ void __launch_bounds__(kT) ns_consume(NsArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int run = blockIdx.x, t = threadIdx.x;
+  const int N = a.nlive, D = a.ndim, K = a.K;
+  NsRun& r = a.st[run];
+  const int mode = r.mode;
+  if (mode != MODE_CUBE && mode != MODE_BOUND) return;
+  if (mode == MODE_BOUND && a.bstatus[run] != DH_OK) return;
+  double* key = (double*)smem;      // N
+  double* ql = key + N;             // K   proposal logl
+  int* slot = (int*)(ql + K);       // N
+  int* src = slot + N;              // N   queue index now living in the slot, -1 = original
+  int* qc = src + N;                // K   calls
+  int* dslot = qc + K;              // K   death list: slot
+  int* dsrc = dslot + K;            // K               content source at death
+  int* misc = dsrc + K;             // 8
+  for (int i = t; i < N; i += kT) {
+    key[i] = a.heap_key[(size_t)run * N + i];
+    slot[i] = a.heap_slot[(size_t)run * N + i];
+    src[i] = -1;
+  }
+  int acc = 0, rej = 0;
+  for (int j = t; j < K; j += kT) {
+    const size_t q = (size_t)run * K + j;
+    ql[j] = a.r_logl[q];
+    if (mode == MODE_CUBE) {
+      qc[j] = a.r_a[q];
+    } else {
+      qc[j] = a.walks;
+      acc += a.r_a[q];
+      rej += a.r_b[q];
+    }
+  }
+  // block sums of accept / reject for the scale tuning
+  __shared__ int racc[kT], rrej[kT];
+  racc[t] = acc;
+  rrej[t] = rej;
+  __syncthreads();
+  for (int s = kT / 2; s > 0; s >>= 1) {
+    if (t < s) {
+      racc[t] += racc[t + s];
+      rrej[t] += rrej[t + s];
+    }
+    __syncthreads();
+  }
+  if (t == 0) {
+    double logvol = r.logvol, logz = r.logz, h = r.h, lmax = r.lmax, dead_prev = r.dead_prev;
+    long long it = r.it, ncall = r.ncall;
+    const double dlv = log(((double)N + 1.0) / (double)N);
+    int ndead = 0, done = 0;
+    for (int j = 0; j < K; ++j) {
+      ncall += qc[j];
+      const double cur = key[0];
+      const double lj = ql[j];
+      if (!(lj > cur)) continue;  // stale proposal (sampler.py:774-776)
+      const int s = slot[0];
+      if (it >= a.cap) {
+        done = 2;  // dead-point store exhausted
+        break;
+      }
+      logvol -= dlv;
+      integrate_step(logz, h, dead_prev, cur, logvol, dlv);
+      dead_prev = cur;
+      a.dead_logl[(size_t)run * a.cap + it] = cur;
+      dslot[ndead] = s;
+      dsrc[ndead] = src[s];
+      ++ndead;
+      src[s] = j;
+      // heap: replace the root by (lj, s), sift down
+      int i = 0;
+      for (;;) {
+        int c = 2 * i + 1;
+        if (c >= N) break;
+        if (c + 1 < N && key[c + 1] < key[c]) ++c;
+        if (!(key[c] < lj)) break;
+        key[i] = key[c];
+        slot[i] = slot[c];
+        i = c;
+      }
+      key[i] = lj;
+      slot[i] = s;
+      if (lj > lmax) lmax = lj;
+      ++it;
+      const double dz = logaddexp_dev(0.0, lmax + logvol - logz);
+      if (dz < a.dlogz) {
+        done = 1;
+        break;
+      }
+    }
+    misc[0] = ndead;
+    misc[1] = done;
+    r.logvol = logvol;
+    r.logz = logz;
+    r.h = h;
+    r.lmax = lmax;
+    r.dead_prev = dead_prev;
+    misc[2] = (int)r.it;  // first death index of this fill
+    r.it = it;
+    r.ncall = ncall;
+    r.loglstar = key[0];
+    r.nfill += 1;
+    if (mode == MODE_BOUND) {
+      // RWalkSampler.tune (internal_samplers.py:460-493), once per queue fill
+      const int ta = racc[0], tr = rrej[0];
+      if (ta + tr > 0) r.scale *= exp(((double)ta / (double)(ta + tr) - a.facc) / (double)D / a.facc);
+    }
+    if (done) {
+      r.mode = done == 1 ? MODE_DONE : MODE_FAILED;
+      atomicAdd(a.ndone, 1);
+    }
+  }
+  __syncthreads();
+  const int ndead = misc[0];
+  const long long it0 = misc[2];
+  // dead-point coordinates (optional), in death order
+  if (a.store_samples) {
+    for (int e = 0; e < ndead; ++e) {
+      const int s = dslot[e], sj = dsrc[e];
+      const double* from = sj < 0 ? a.live_u + ((size_t)run * N + s) * D
+                                  : a.r_u + ((size_t)run * K + sj) * D;
+      double* to = a.dead_u + ((size_t)run * a.cap + it0 + e) * D;
+      for (int j = t; j < D; j += kT) to[j] = from[j];
+    }
+  }
+  __syncthreads();
+  // apply the surviving replacements to the live set
+  for (int s = t; s < N; s += kT) {
+    const int sj = src[s];
+    if (sj >= 0) {
+      const size_t q = (size_t)run * K + sj;
+      a.live_logl[(size_t)run * N + s] = ql[sj];
+      double* lu = a.live_u + ((size_t)run * N + s) * D;
+      double* lv = a.live_v + ((size_t)run * N + s) * D;
+      for (int j = 0; j < D; ++j) {
+        lu[j] = a.r_u[q * D + j];
+        lv[j] = a.r_v[q * D + j];
+      }
+    }
+  }
+  for (int i = t; i < N; i += kT) {
+    a.heap_key[(size_t)run * N + i] = key[i];
+    a.heap_slot[(size_t)run * N + i] = slot[i];
+  }
+}
+
+// ---- final live points (sampler.py:780-930) + record -----------------------------
+__global__ void __launch_bounds__(kT) ns_finish(NsArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int run = blockIdx.x, t = threadIdx.x, N = a.nlive;
+  double* key = (double*)smem;
+  for (int i = t; i < N; i += kT) key[i] = a.heap_key[(size_t)run * N + i];
+  __syncthreads();
+  if (t == 0) {
+    NsRun& r = a.st[run];
+    double logz = r.logz, h = r.h, prev = r.dead_prev;
+    const double lv0 = r.logvol;
+    double lvprev = lv0;
+    int n = N;
+    for (int i = 1; i <= N; ++i) {
+      // pop the minimum
+      const double cur = key[0];
+      --n;
+      const double last = key[n];
+      int p = 0;
+      for (;;) {
+        int c = 2 * p + 1;
+        if (c >= n) break;
+        if (c + 1 < n && key[c + 1] < key[c]) ++c;
+        if (!(key[c] < last)) break;
+        key[p] = key[c];
+        p = c;
+      }
+      if (n > 0) key[p] = last;
+      const double lv = lv0 + log(1.0 - (double)i / ((double)N + 1.0));
+      integrate_step(logz, h, prev, cur, lv, lvprev - lv);
+      prev = cur;
+      lvprev = lv;
+    }
+    double* rec = a.records + (size_t)run * 8;
+    rec[0] = logz;
+    rec[1] = sqrt(fmax(h, 0.0) / (double)N);
+    rec[2] = (double)r.it;
+    rec[3] = (double)r.ncall;
+    rec[4] = h;
+    rec[5] = (double)r.nbound;
+    rec[6] = (double)(r.mode == MODE_DONE ? 0 : (r.mode == MODE_FAILED ? -1 : 1));  // 1: hit maxfills
+    rec[7] = 100.0 * (double)r.it / (double)r.ncall;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int queue_size, int walks,
+                   int bound_multi, double dlogz, double enlarge, int64_t max_fills, int64_t max_iter,
+                   const uint32_t* entropy_words, int n_words, uint32_t first_run, double* records,
+                   double* dead_logl_out, int64_t* n_fills_out) {
+  DH_CHECK_CTX(ctx);
+  ProblemDev pd;
+  if (!get_problem(ctx, problem, &pd)) return DH_ERR_ARG;
+  if (pd.ndim != ndim) return fail(ctx, DH_ERR_ARG, "problem ndim %d != %d", pd.ndim, ndim);
+  if (runs < 1 || nlive < 4 || queue_size < 1 || walks < 2 || !entropy_words || n_words < 1 || !records)
+    return fail(ctx, DH_ERR_ARG, "ns_ensemble: bad arguments");
+  if (ndim > kMaxRegDim) return fail(ctx, DH_ERR_ARG, "ns_ensemble: ndim=%d > %d not built", ndim, kMaxRegDim);
+  const int N = nlive, D = ndim, K = queue_size, R = runs;
+  const int me = bound_multi ? (N / (2 * D) > 0 ? N / (2 * D) : 1) : 1;
+  NsArgs a;
+  a.runs = R;
+  a.nlive = N;
+  a.ndim = D;
+  a.K = K;
+  a.walks = walks;
+  a.bound_multi = bound_multi;
+  a.max_ells = me;
+  a.cap = max_iter > 0 ? max_iter : 400000;
+  a.dlogz = dlogz;
+  a.enlarge_log = log(enlarge);
+  a.facc = fmin(1.0, fmax(1.0 / (double)walks, 0.5));
+  a.first_eff = 10.0;
+  a.first_ncall = 2ll * N;
+  a.update_interval = (long long)walks * N;
+  a.store_samples = 0;
+  // ---- one allocation for all state ----
+  auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  const size_t dd = (size_t)D * D;
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    size_t o = off;
+    off += al(bytes);
+    return o;
+  };
+  const size_t o_st = take(sizeof(NsRun) * R), o_lu = take((size_t)R * N * D * 8), o_lv = take((size_t)R * N * D * 8),
+               o_ll = take((size_t)R * N * 8), o_hk = take((size_t)R * N * 8), o_hs = take((size_t)R * N * 4),
+               o_dl = take((size_t)R * a.cap * 8), o_qu = take((size_t)R * K * D * 8),
+               o_qf = take((size_t)R * K * 4), o_qr = take((size_t)R * K * 32), o_qo = take((size_t)R * K * 32),
+               o_ru = take((size_t)R * K * D * 8), o_rv = take((size_t)R * K * D * 8),
+               o_rl = take((size_t)R * K * 8), o_ra = take((size_t)R * K * 4), o_rb = take((size_t)R * K * 4),
+               o_pl = take((size_t)R * 8), o_ps = take((size_t)R * 8), o_pm = take((size_t)R * 4),
+               o_rm = take((size_t)R * 4), o_nd = take(64), o_ne = take((size_t)R * 4),
+               o_bs = take((size_t)R * 4), o_bc = take((size_t)R * me * D * 8), o_bv = take((size_t)R * me * dd * 8),
+               o_ba = take((size_t)R * me * dd * 8), o_bx = take((size_t)R * me * dd * 8),
+               o_bl = take((size_t)R * me * D * 8), o_bg = take((size_t)R * me * 8),
+               o_rec = take((size_t)R * 8 * 8), o_ent = take((size_t)n_words * 4);
+  char* base = nullptr;
+  (void)hipSetDevice(ctx->device);
+  if (!hip_ok(ctx, hipMalloc((void**)&base, off), "hipMalloc(ns state)")) return DH_ERR_NOMEM;
+  auto cleanup = [&](int rc) {
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(base);
+    return rc;
+  };
+  a.st = (NsRun*)(base + o_st);
+  a.live_u = (double*)(base + o_lu);
+  a.live_v = (double*)(base + o_lv);
+  a.live_logl = (double*)(base + o_ll);
+  a.heap_key = (double*)(base + o_hk);
+  a.heap_slot = (int*)(base + o_hs);
+  a.dead_logl = (double*)(base + o_dl);
+  a.dead_u = nullptr;
+  a.q_u0 = (double*)(base + o_qu);
+  a.q_frame = (int*)(base + o_qf);
+  a.q_rng = (uint64_t*)(base + o_qr);
+  a.q_rng_out = (uint64_t*)(base + o_qo);
+  a.r_u = (double*)(base + o_ru);
+  a.r_v = (double*)(base + o_rv);
+  a.r_logl = (double*)(base + o_rl);
+  a.r_a = (int*)(base + o_ra);
+  a.r_b = (int*)(base + o_rb);
+  a.run_loglstar = (double*)(base + o_pl);
+  a.run_scale = (double*)(base + o_ps);
+  a.run_mode = (int*)(base + o_pm);
+  a.rebuild_mask = (int*)(base + o_rm);
+  a.ndone = (int*)(base + o_nd);
+  a.nells = (int*)(base + o_ne);
+  a.bstatus = (int*)(base + o_bs);
+  a.b_ctrs = (double*)(base + o_bc);
+  a.b_covs = (double*)(base + o_bv);
+  a.b_ams = (double*)(base + o_ba);
+  a.b_axes = (double*)(base + o_bx);
+  a.b_axl = (double*)(base + o_bl);
+  a.b_lv = (double*)(base + o_bg);
+  a.records = (double*)(base + o_rec);
+  uint32_t* d_ent = (uint32_t*)(base + o_ent);
+  hipStream_t s = ctx->stream;
+  if (!hip_ok(ctx, hipMemsetAsync(base + o_nd, 0, 64, s), "memset") ||
+      !hip_ok(ctx, hipMemsetAsync(base + o_bs, 0, (size_t)R * 4, s), "memset") ||
+      !hip_ok(ctx, hipMemsetAsync(base + o_ne, 0, (size_t)R * 4, s), "memset") ||
+      !hip_ok(ctx, hipMemcpyAsync(d_ent, entropy_words, (size_t)n_words * 4, hipMemcpyHostToDevice, s), "H2D"))
+    return cleanup(DH_ERR_HIP);
+
+  hipLaunchKernelGGL(ns_init, dim3(R), dim3(kT), 0, s, a, d_ent, n_words, first_run);
+  int rc = eval_launch_dev(ctx, problem, R * N, a.live_u, a.live_v, a.live_logl);
+  if (rc) return cleanup(rc);
+  const size_t lds_heap = (size_t)N * 12 + 64;
+  hipLaunchKernelGGL(ns_heapify, dim3(R), dim3(kT), lds_heap, s, a);
+  const size_t lds_cons = (size_t)N * 8 + (size_t)K * 8 + (size_t)N * 8 + (size_t)K * 12 + 64;
+  if (lds_cons > 150 * 1024) return cleanup(fail(ctx, DH_ERR_ARG, "ns_ensemble: nlive/queue too large for LDS"));
+  static size_t attr = 0;
+  if (lds_cons > attr) {
+    (void)hipFuncSetAttribute((const void*)ns_consume, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cons);
+    (void)hipFuncSetAttribute((const void*)ns_heapify, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cons);
+    (void)hipFuncSetAttribute((const void*)ns_finish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cons);
+    attr = lds_cons;
+  }
+  const int64_t fills_cap = max_fills > 0 ? max_fills : 1000000;
+  int64_t fill = 0;
+  int ndone = 0;
+  while (fill < fills_cap && ndone < R) {
+    for (int burst = 0; burst < 8 && fill < fills_cap; ++burst, ++fill) {
+      hipLaunchKernelGGL(ns_prepare, dim3((R + 63) / 64), dim3(64), 0, s, a);
+      rc = rebuild_launch_masked(ctx, R, a.live_u, N, D, bound_multi ? 0 : 1, me, a.nells, a.bstatus, a.b_ctrs,
+                                 a.b_covs, a.b_ams, a.b_axes, a.b_axl, a.b_lv, a.rebuild_mask);
+      if (rc) return cleanup(rc);
+      rc = enlarge_launch_masked(ctx, R, me, a.nells, D, a.b_covs, a.b_ams, a.b_axes, a.b_axl, a.b_lv,
+                                 a.enlarge_log, a.rebuild_mask);
+      if (rc) return cleanup(rc);
+      hipLaunchKernelGGL(ns_select, dim3(R), dim3(kT), 0, s, a);
+      rc = unif_launch_runs(ctx, problem, R * K, D, D, 0, nullptr, nullptr, nullptr, nullptr, 0.0, nullptr,
+                            a.q_rng, 0, a.r_u, a.r_v, a.r_logl, a.r_a, a.r_b, a.q_rng_out, a.run_loglstar,
+                            a.run_mode, K, MODE_CUBE);
+      if (rc) return cleanup(rc);
+      rc = rwalk_launch_runs(ctx, problem, R * K, D, D, a.q_u0, a.b_axes, R * me, a.q_frame, 1.0, 0.0, walks,
+                             nullptr, a.q_rng, a.r_u, a.r_v, a.r_logl, a.r_a, a.r_b, a.q_rng_out,
+                             a.run_loglstar, a.run_scale, a.run_mode, K, MODE_BOUND);
+      if (rc) return cleanup(rc);
+      hipLaunchKernelGGL(ns_consume, dim3(R), dim3(kT), lds_cons, s, a);
+    }
+    if (!hip_ok(ctx, hipMemcpyAsync(&ndone, a.ndone, 4, hipMemcpyDeviceToHost, s), "D2H ndone") ||
+        !hip_ok(ctx, hipStreamSynchronize(s), "sync"))
+      return cleanup(DH_ERR_HIP);
+  }
+  hipLaunchKernelGGL(ns_finish, dim3(R), dim3(kT), lds_heap, s, a);
+  if (!hip_ok(ctx, hipGetLastError(), "ns launch") ||
+      !hip_ok(ctx, hipMemcpyAsync(records, a.records, (size_t)R * 64, hipMemcpyDeviceToHost, s), "D2H records"))
+    return cleanup(DH_ERR_HIP);
+  if (dead_logl_out) {
+    // first max_iter entries per run (caller allocates runs * cap doubles)
+    if (!hip_ok(ctx, hipMemcpyAsync(dead_logl_out, a.dead_logl, (size_t)R * a.cap * 8, hipMemcpyDeviceToHost, s),
+                "D2H dead"))
+      return cleanup(DH_ERR_HIP);
+  }
+  if (n_fills_out) *n_fills_out = fill;
+  return cleanup(DH_OK);
+}
+
+}  // extern "C"

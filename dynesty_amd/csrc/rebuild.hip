@@ -72,6 +72,7 @@ struct RebuildArgs {
   int* split_list;    // 2 x runs x maxw   (by level parity)
   int* ell_list;      // runs x 2 maxw
   double* scale_g;    // runs x d
+  const int* active;  // runs or null: only runs with active[run] != 0 are rebuilt
 };
 
 #ifdef DH_REBUILD_TIMING
@@ -944,6 +945,7 @@ __device__ __forceinline__ void set_status(const RebuildArgs& a, int run, int rc
 __global__ void __launch_bounds__(kThreads) k_root(RebuildArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int D = a.d, n = a.n, t = threadIdx.x, run = blockIdx.x;
+  if (a.active && !a.active[run]) return;
   Lds L;
   carve(L, smem, D);
   const RunView v = view_of(a, run, L.LD);
@@ -1064,6 +1066,7 @@ __global__ void __launch_bounds__(kThreads) k_ell(RebuildArgs a, int level) {
 __global__ void __launch_bounds__(kThreads) k_finish(RebuildArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int D = a.d, n = a.n, t = threadIdx.x, run = blockIdx.x;
+  if (a.active && !a.active[run]) return;
   Lds L;
   carve(L, smem, D);
   const RunView v = view_of(a, run, L.LD);
@@ -1260,7 +1263,7 @@ __global__ void __launch_bounds__(64)
 __global__ void __launch_bounds__(64)
     scale_logvol_kernel(int m, int D, double* covs, double* ams, double* axes, double* axlens,
                         double* logvols, const double* __restrict__ targets, double shift,
-                        const int* __restrict__ nells, int stride) {
+                        const int* __restrict__ nells, int stride, const int* __restrict__ active) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double* fax = (double*)smem;  // D
   double* lax = fax + D;        // D  log axlens
@@ -1270,6 +1273,7 @@ __global__ void __launch_bounds__(64)
   // batched form: slot e belongs to run e / stride and is live iff its index
   // within the run is below that run's ellipsoid count
   if (nells && (e % stride) >= nells[e / stride]) return;
+  if (active && !active[e / stride]) return;
   double* C = covs + (size_t)e * D * D;
   double* P = ams + (size_t)e * D * D;
   double* X = axes + (size_t)e * D * D;
@@ -1362,13 +1366,40 @@ int dh_rebuild_batch_dev(dh_ctx* ctx, int runs, const double* pts, int n, int d,
                          int32_t* nells, int32_t* status, double* ctrs, double* covs, double* ams,
                          double* axes, double* axlens, double* logvols, int32_t* leaf_of_point,
                          int32_t* nnodes) {
+  return dh::rebuild_launch_full(ctx, runs, pts, n, d, mode, max_ells, nells, status, ctrs, covs, ams, axes,
+                                 axlens, logvols, leaf_of_point, nnodes, nullptr);
+}
+
+}  // extern "C"
+
+int dh::rebuild_launch_masked(dh_ctx* ctx, int runs, const double* pts, int n, int d, int mode, int max_ells,
+                              int32_t* nells, int32_t* status, double* ctrs, double* covs, double* ams,
+                              double* axes, double* axlens, double* logvols, const int* active) {
+  return rebuild_launch_full(ctx, runs, pts, n, d, mode, max_ells, nells, status, ctrs, covs, ams, axes,
+                             axlens, logvols, nullptr, nullptr, active);
+}
+
+int dh::enlarge_launch_masked(dh_ctx* ctx, int runs, int max_ells, const int32_t* nells, int d, double* covs,
+                              double* ams, double* axes, double* axlens, double* logvols,
+                              double log_enlarge, const int* active) {
+  const int m = runs * max_ells;
+  hipLaunchKernelGGL(scale_logvol_kernel, dim3(m), dim3(64), (size_t)2 * d * 8 + 64, ctx->stream, m, d,
+                     covs, ams, axes, axlens, logvols, (const double*)nullptr, log_enlarge, nells, max_ells,
+                     active);
+  return hip_ok(ctx, hipGetLastError(), "enlarge launch") ? DH_OK : DH_ERR_HIP;
+}
+
+int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int d, int mode, int max_ells,
+                            int32_t* nells, int32_t* status, double* ctrs, double* covs, double* ams,
+                            double* axes, double* axlens, double* logvols, int32_t* leaf_of_point,
+                            int32_t* nnodes, const int* active) {
   DH_CHECK_CTX(ctx);
   if (runs <= 0) return DH_OK;
   if (!pts || n < 1 || d < 1 || max_ells < 1 || (mode != 0 && mode != 1))
     return fail(ctx, DH_ERR_ARG, "rebuild: bad arguments (n=%d d=%d mode=%d)", n, d, mode);
   const size_t lds = rebuild_lds_bytes(d);
   if (lds > 159 * 1024) {
-    if (mode == 1)
+    if (mode == 1 && !active)
       return wide_single_launch(ctx, runs, pts, n, d, nells, status, ctrs, covs, ams, axes, axlens,
                                 logvols);
     return fail(ctx, DH_ERR_ARG,
@@ -1446,6 +1477,7 @@ int dh_rebuild_batch_dev(dh_ctx* ctx, int runs, const double* pts, int n, int d,
   a.logvols = logvols;
   a.leaf_of_point = leaf_of_point;
   a.nnodes_out = nnodes;
+  a.active = active;
   static size_t attr_lds = 0;
   if (lds > attr_lds) {
     const void* ks[4] = {(const void*)k_root, (const void*)k_split, (const void*)k_ell,
@@ -1465,6 +1497,8 @@ int dh_rebuild_batch_dev(dh_ctx* ctx, int runs, const double* pts, int n, int d,
   hipLaunchKernelGGL(k_finish, dim3(runs), dim3(kThreads), lds, ctx->stream, a);
   return hip_ok(ctx, hipGetLastError(), "rebuild launch") ? DH_OK : DH_ERR_HIP;
 }
+
+extern "C" {
 
 int dh_rebuild(dh_ctx* ctx, const double* pts, int n, int d, int mode, int max_ells, int32_t* nells,
                double* ctrs, double* covs, double* ams, double* axes, double* axlens, double* logvols,
@@ -1568,7 +1602,7 @@ int dh_enlarge_batch_dev(dh_ctx* ctx, int runs, int max_ells, const int32_t* nel
   const int m = runs * max_ells;
   hipLaunchKernelGGL(scale_logvol_kernel, dim3(m), dim3(64), (size_t)2 * d * 8 + 64, ctx->stream, m, d,
                      covs, ams, axes, axlens, logvols, (const double*)nullptr, log_enlarge, nells,
-                     max_ells);
+                     max_ells, (const int*)nullptr);
   return hip_ok(ctx, hipGetLastError(), "enlarge launch") ? DH_OK : DH_ERR_HIP;
 }
 
@@ -1590,7 +1624,7 @@ int dh_scale_to_logvol(dh_ctx* ctx, int m, int d, double* covs, double* ams, dou
   const double* d_t = arena_up(ctx, targets, (size_t)m);
   if (!d_c || !d_p || !d_x || !d_al || !d_lv || !d_t) return DH_ERR_NOMEM;
   hipLaunchKernelGGL(scale_logvol_kernel, dim3(m), dim3(64), (size_t)2 * d * 8 + 64, ctx->stream, m, d,
-                     d_c, d_p, d_x, d_al, d_lv, d_t, 0.0, (const int*)nullptr, 1);
+                     d_c, d_p, d_x, d_al, d_lv, d_t, 0.0, (const int*)nullptr, 1, (const int*)nullptr);
   if (!hip_ok(ctx, hipGetLastError(), "scale_to_logvol launch")) return DH_ERR_HIP;
   if (!down(ctx, covs, d_c, (size_t)m * dd) || !down(ctx, ams, d_p, (size_t)m * dd) ||
       !down(ctx, axes, d_x, (size_t)m * dd) || !down(ctx, axlens, d_al, (size_t)m * d) ||

@@ -52,6 +52,12 @@ struct RwalkArgs {
   const uint64_t* zki;
   const uint64_t* zwi;
   const uint64_t* zfi;
+  // ensemble form (ns.hip): walker w belongs to run w / wpr; per-run threshold and
+  // scale; walkers of runs whose mode differs from my_mode do nothing
+  const double* run_loglstar;
+  const double* run_scale;
+  const int* run_mode;
+  int wpr, my_mode;
   int ablate;  // profiling aid (env DH_ABLATE): 1 no normals, 2 no frame mat-vec, 4 no likelihood, 8 no pow
 };
 
@@ -79,6 +85,13 @@ __global__ void __launch_bounds__(64, DH_RW_OCC) rwalk_kernel(RwalkArgs a) {
   const bool live = w < a.k;
   const int wi = live ? w : a.k - 1;  // dead lanes shadow the last walker (no stores)
   const int n = FULL ? N : a.ndim, nc = FULL ? N : a.ncdim;
+  double loglstar = a.loglstar, scale = a.scale;
+  if (a.run_mode) {
+    const int run = wi / a.wpr;
+    if (a.run_mode[run] != a.my_mode) return;
+    loglstar = a.run_loglstar[run];
+    scale = a.run_scale[run];
+  }
 
   double u[N], up[N], acc[N];
 #pragma unroll
@@ -108,7 +121,7 @@ __global__ void __launch_bounds__(64, DH_RW_OCC) rwalk_kernel(RwalkArgs a) {
       ss = fma(x, x, ss);
     }
     const double ur = g.next_double();
-    const double fac = a.scale * (((a.ablate & 8) ? ur : pow(ur, inv_nc)) / sqrt(ss));
+    const double fac = scale * (((a.ablate & 8) ? ur : pow(ur, inv_nc)) / sqrt(ss));
     // du = axes @ dr, frame wave-uniform: waterfall over the distinct frames
 #pragma unroll
     for (int i = 0; i < N; ++i) acc[i] = 0.0;
@@ -158,9 +171,9 @@ __global__ void __launch_bounds__(64, DH_RW_OCC) rwalk_kernel(RwalkArgs a) {
       continue;
     }
     prior_to_lds<N, FULL, KIND>(a.prob, up, n, sx, lane);
-    const double ll = (a.ablate & 4) ? a.loglstar + ur - 0.6
+    const double ll = (a.ablate & 4) ? loglstar + ur - 0.6
                                      : loglike_lds<N, FULL, KIND>(a.prob, n, sx, lane, acc);
-    if (ll > a.loglstar) {
+    if (ll > loglstar) {
 #pragma unroll
       for (int i = 0; i < N; ++i) u[i] = up[i];
       logl_cur = ll;
@@ -240,16 +253,36 @@ int dh_rwalk_batch_dev(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, con
                        double loglstar, int walks, const int8_t* bc, const uint64_t* rng, double* u,
                        double* v, double* logl, int32_t* naccept, int32_t* nreject,
                        uint64_t* rng_out) {
+  return dh::rwalk_launch_runs(ctx, problem, k, ndim, ncdim, u0, axes, m, axes_idx, scale, loglstar, walks,
+                               bc, rng, u, v, logl, naccept, nreject, rng_out, nullptr, nullptr, nullptr, 1,
+                               0);
+}
+
+}  // extern "C"
+
+int dh::rwalk_launch_runs(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, const double* u0,
+                          const double* axes, int m, const int32_t* axes_idx, double scale,
+                          double loglstar, int walks, const int8_t* bc, const uint64_t* rng, double* u,
+                          double* v, double* logl, int32_t* naccept, int32_t* nreject, uint64_t* rng_out,
+                          const double* run_loglstar, const double* run_scale, const int* run_mode,
+                          int wpr, int my_mode) {
   DH_CHECK_CTX(ctx);
   RwalkArgs a;
+  a.run_loglstar = run_loglstar;
+  a.run_scale = run_scale;
+  a.run_mode = run_mode;
+  a.wpr = wpr;
+  a.my_mode = my_mode;
   if (!get_problem(ctx, problem, &a.prob)) return DH_ERR_ARG;
   if (a.prob.ndim != ndim) return fail(ctx, DH_ERR_ARG, "problem ndim %d != %d", a.prob.ndim, ndim);
   if (k <= 0) return DH_OK;
   if (ncdim < 1 || ncdim > ndim || m < 1 || walks < 1)
     return fail(ctx, DH_ERR_ARG, "rwalk: ncdim=%d ndim=%d m=%d walks=%d", ncdim, ndim, m, walks);
-  if (ndim > kMaxRegDim)
+  if (ndim > kMaxRegDim) {
+    if (run_mode) return fail(ctx, DH_ERR_ARG, "ensemble rwalk: ndim=%d > %d not built", ndim, kMaxRegDim);
     return wide_walk_launch(ctx, 0, problem, k, ndim, ncdim, u0, axes, m, axes_idx, scale, loglstar, walks,
                             0, bc, rng, u, v, logl, naccept, nreject, nullptr, nullptr, rng_out);
+  }
   a.k = k;
   a.ndim = ndim;
   a.ncdim = ncdim;
@@ -314,6 +347,9 @@ int dh_rwalk_batch_dev(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, con
   return hip_ok(ctx, hipGetLastError(), "rwalk launch") ? DH_OK : DH_ERR_HIP;
 }
 
+extern "C" {
+
+
 int dh_rwalk_batch(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, const double* u0,
                    const double* axes, int m, const int32_t* axes_idx, double scale, double loglstar,
                    int walks, const int8_t* bc, const uint64_t* rng, double* u, double* v,
@@ -351,6 +387,28 @@ int dh_rwalk_batch(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, const d
     return DH_ERR_HIP;
   return dh_sync(ctx);
 }
+
+}  // extern "C"
+
+int dh::eval_launch_dev(dh_ctx* ctx, int problem, int k, const double* u, double* v, double* logl) {
+  ProblemDev p;
+  if (!get_problem(ctx, problem, &p)) return DH_ERR_ARG;
+  if (k <= 0) return DH_OK;
+  if (p.ndim > kMaxRegDim) return wide_eval_launch(ctx, p, k, u, v, logl);
+  const dim3 grid((k + 63) / 64), block(64);
+  const int ndim = p.ndim;
+  bool hit = false;
+#define X(NN)                                                                  \
+  if (!hit && ndim <= NN) {                                                    \
+    hit = true;                                                                \
+    hipLaunchKernelGGL(eval_kernel<NN>, grid, block, 0, ctx->stream, p, k, u, v, logl); \
+  }
+  DH_DIM_LIST(X)
+#undef X
+  return hip_ok(ctx, hipGetLastError(), "eval launch") ? DH_OK : DH_ERR_HIP;
+}
+
+extern "C" {
 
 int dh_problem_eval(dh_ctx* ctx, int problem, int k, const double* u, double* v, double* logl) {
   DH_CHECK_CTX(ctx);

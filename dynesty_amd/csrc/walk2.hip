@@ -369,6 +369,10 @@ struct UnifArgs {
   const uint64_t* zki;
   const uint64_t* zwi;
   const uint64_t* zfi;
+  // ensemble form (ns.hip), as in RwalkArgs
+  const double* run_loglstar;
+  const int* run_mode;
+  int wpr, my_mode;
 };
 
 template <int N, bool FULL, int KIND>
@@ -381,12 +385,19 @@ __global__ void __launch_bounds__(64, 2) unif_kernel(UnifArgs a) {
   const bool live = w < a.k;
   const int wi = live ? w : a.k - 1;
   const int n = FULL ? N : a.ndim, nc = FULL ? N : a.ncdim;
+  double loglstar = a.loglstar;
+  bool done = false;
+  if (a.run_mode) {
+    const int run = wi / a.wpr;
+    if (a.run_mode[run] != a.my_mode) done = true;  // idle lane (keeps wave-level votes valid)
+    loglstar = a.run_loglstar[run];
+  }
+  const bool idle = done;
   Pcg64 g;
   g.load(a.rng_in + (size_t)wi * 4);
   double x[N], acc[N];
   int ncall = 0, flags = 0;
   double logl_cur = 0.0;
-  bool done = false;
   int64_t tries = 0;
   const double inv_nc = 1.0 / (double)nc;
   while (__any(!done)) {
@@ -492,7 +503,7 @@ __global__ void __launch_bounds__(64, 2) unif_kernel(UnifArgs a) {
       const double ll = loglike_lds<N, FULL, KIND>(a.prob, n, sx, lane, acc);
       if (cand) {
         ++ncall;
-        if (ll > a.loglstar) {
+        if (ll > loglstar) {
           logl_cur = ll;
           done = true;
           if (live) {
@@ -511,7 +522,7 @@ __global__ void __launch_bounds__(64, 2) unif_kernel(UnifArgs a) {
       done = true;
     }
   }
-  if (live) {
+  if (live && !idle) {
     a.logl[w] = logl_cur;
     a.ncalls[w] = ncall;
     a.flags[w] = flags;
@@ -741,8 +752,23 @@ int dh_unif_batch_dev(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, int 
                       const double* axes, const double* ams, const double* cumprob, double loglstar,
                       const int8_t* bc, const uint64_t* rng, int64_t max_tries, double* u, double* v,
                       double* logl, int32_t* ncalls, int32_t* flags, uint64_t* rng_out) {
+  return dh::unif_launch_runs(ctx, problem, k, ndim, ncdim, m, ctrs, axes, ams, cumprob, loglstar, bc, rng,
+                              max_tries, u, v, logl, ncalls, flags, rng_out, nullptr, nullptr, 1, 0);
+}
+
+}  // extern "C"
+
+int dh::unif_launch_runs(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, int m, const double* ctrs,
+                         const double* axes, const double* ams, const double* cumprob, double loglstar,
+                         const int8_t* bc, const uint64_t* rng, int64_t max_tries, double* u, double* v,
+                         double* logl, int32_t* ncalls, int32_t* flags, uint64_t* rng_out,
+                         const double* run_loglstar, const int* run_mode, int wpr, int my_mode) {
   DH_CHECK_CTX(ctx);
   UnifArgs a;
+  a.run_loglstar = run_loglstar;
+  a.run_mode = run_mode;
+  a.wpr = wpr;
+  a.my_mode = my_mode;
   if (!get_problem(ctx, problem, &a.prob)) return DH_ERR_ARG;
   if (a.prob.ndim != ndim) return fail(ctx, DH_ERR_ARG, "problem ndim %d != %d", a.prob.ndim, ndim);
   if (k <= 0) return DH_OK;
@@ -814,6 +840,9 @@ int dh_unif_batch_dev(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, int 
 #undef L
   return hip_ok(ctx, hipGetLastError(), "unif launch") ? DH_OK : DH_ERR_HIP;
 }
+
+extern "C" {
+
 
 int dh_unif_batch(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, int m, const double* ctrs,
                   const double* axes, const double* ams, const double* cumprob, double loglstar,

@@ -22,6 +22,7 @@ Semantics kept from the reference because they decide the statistics:
   * ln X decreases by ln((N+1)/N) per iteration; trapezoid weights; the final
     live points are appended (sampler.py:780-930).
 """
+import heapq
 import math
 
 import numpy as np
@@ -160,8 +161,12 @@ def run_static(prob, nlive=500, bound='multi', sample='rwalk', queue_size=None,
         return out, start
 
     done = False
+    # min-heap over (logl, slot): the worst live point in O(log N) per iteration
+    heap = [(float(l), i) for i, l in enumerate(live_logl)]
+    heapq.heapify(heap)
+    lmax = float(live_logl.max())
     while not done:
-        loglstar = float(live_logl.min())
+        loglstar = heap[0][0]
         # bound-update policy, evaluated when the queue is empty
         eff = 100. * max(it, 1) / ncall
         if unit_cube:
@@ -173,11 +178,12 @@ def run_static(prob, nlive=500, bound='multi', sample='rwalk', queue_size=None,
             rebuild()
             ncall_last_update = ncall
         out, _ = fill(loglstar)
+        o_logl = out["logl"].tolist()
+        o_nc = [int(x) for x in out["ncalls"]]
         for j in range(K):
-            ncall += int(out["ncalls"][j])
-            worst = int(np.argmin(live_logl))
-            cur = float(live_logl[worst])
-            if not out["logl"][j] > cur:
+            ncall += o_nc[j]
+            cur, worst = heap[0]
+            if not o_logl[j] > cur:
                 continue  # stale proposal: discarded (sampler.py:774-776)
             logvol -= dlv
             dead_u.append(live_u[worst].copy())
@@ -187,13 +193,16 @@ def run_static(prob, nlive=500, bound='multi', sample='rwalk', queue_size=None,
             logz = np.logaddexp(logz, lw - math.log(nlive))
             live_u[worst] = out["u"][j]
             live_v[worst] = out["v"][j]
-            live_logl[worst] = out["logl"][j]
+            live_logl[worst] = o_logl[j]
+            heapq.heapreplace(heap, (o_logl[j], worst))
+            if o_logl[j] > lmax:
+                lmax = o_logl[j]
             it += 1
             if maxiter is not None and it >= maxiter:
                 done = True
                 break
             if it % 64 == 0 or j == K - 1:
-                dz = np.logaddexp(0., float(live_logl.max()) + logvol - logz)
+                dz = np.logaddexp(0., lmax + logvol - logz)
                 if dz < dlogz:
                     done = True
                     break

@@ -234,6 +234,23 @@ int dh_bound_draw(dh_ctx* ctx, const uint64_t* state4, int nsamp, int d, int m,
                   const double* cumprob, int return_q, double* xs, int32_t* idxs,
                   int32_t* qs, uint64_t* state4_out);
 
+/* ---- device-resident ensemble of static nested-sampling runs (BASELINE config
+ * C5): the loop of Sampler.sample (sampler.py:932-1212) with a
+ * proposal queue of `queue_size` rwalk walkers per run (sampler.py:676-778),
+ * unit-cube start, MultiEllipsoid (bound_multi=1) or Ellipsoid bound rebuilt
+ * every walks*nlive calls and enlarged by `enlarge`, RWalkSampler.tune, evidence
+ * integration (utils.py:1470-1492) and the final live points -- all on the
+ * device for `runs` independent runs at once.  Run r seeds from
+ * SeedSequence(entropy) children keyed on first_run + r (independent of how the
+ * ensemble is sharded).  records: runs x 8 doubles {logz, logzerr, niter, ncall,
+ * h, nbound, status (0 ok, 1 max_fills hit, -1 failed), eff%}.
+ * dead_logl_out (optional): runs x max_iter dead-point log-likelihoods. */
+int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim,
+                   int queue_size, int walks, int bound_multi, double dlogz,
+                   double enlarge, int64_t max_fills, int64_t max_iter,
+                   const uint32_t* entropy_words, int n_words, uint32_t first_run,
+                   double* records, double* dead_logl_out, int64_t* n_fills_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,59 @@
+"""Device-resident ensemble of nested-sampling runs (dh_ns_ensemble, SURVEY.md
+8f-1 / BASELINE config C5): statistics vs the analytic evidence, determinism,
+and independence of the way the ensemble is sharded."""
+import numpy as np
+import pytest
+
+import inputs
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from dynesty_amd import _lib
+    return _lib.Context(0)
+
+
+@pytest.mark.parametrize("pname,bound,nlive,K,walks", [
+    ("G5", "multi", 400, 64, 25), ("C1", "single", 400, 64, 23),
+    ("C3", "multi", 600, 128, 22)])
+def test_ensemble_logz(ctx, pname, bound, nlive, K, walks):
+    prob = inputs.problem(pname)
+    r = ctx.ns_ensemble(prob, 16, nlive, K, walks=walks, bound=bound,
+                        entropy=[7, 7], dlogz=0.05)
+    assert np.all(r["status"] == 0)
+    assert np.all(r["nbound"] >= 2)
+    lz = r["logz"]
+    se = lz.std(ddof=1) / np.sqrt(len(lz))
+    # ensemble mean within 5 standard errors (+ the dlogz truncation) of the truth
+    assert abs(lz.mean() - prob.logz_truth) < 5 * se + 0.08, (lz.mean(), se)
+    # the per-run error estimate sqrt(H/N) describes the scatter
+    assert 0.4 < lz.std(ddof=1) / r["logzerr"].mean() < 2.5
+
+
+def test_deterministic_and_sharding_independent(ctx):
+    prob = inputs.problem("G5")
+    kw = dict(nlive=200, queue_size=64, walks=20, bound="multi",
+              entropy=[3, 1, 4], dlogz=0.5)
+    a = ctx.ns_ensemble(prob, 6, **kw)
+    b = ctx.ns_ensemble(prob, 6, **kw)
+    np.testing.assert_array_equal(a["logz"], b["logz"])
+    np.testing.assert_array_equal(a["ncall"], b["ncall"])
+    lo = ctx.ns_ensemble(prob, 3, first_run=0, **kw)
+    hi = ctx.ns_ensemble(prob, 3, first_run=3, **kw)
+    np.testing.assert_array_equal(np.concatenate([lo["logz"], hi["logz"]]),
+                                  a["logz"])
+    np.testing.assert_array_equal(np.concatenate([lo["niter"], hi["niter"]]),
+                                  a["niter"])
+
+
+def test_dead_points_ordered(ctx):
+    prob = inputs.problem("C1")
+    r = ctx.ns_ensemble(prob, 2, 200, 32, walks=23, bound="single",
+                        entropy=[5], dlogz=0.5, max_iter=20000,
+                        want_dead_logl=True)
+    for i in range(2):
+        n = int(r["niter"][i])
+        d = r["dead_logl"][i, :n]
+        assert np.all(np.diff(d) >= 0)  # worst-first: non-decreasing
