@@ -69,6 +69,8 @@ SIGNATURES = {
     "dh_scale_to_logvol": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dh_enlarge_batch_dev": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp,
                                   _dbl]),
+    "dh_rwalk_propose": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _vp, _dbl, _vp, _vp,
+                              _vp, _vp, _vp]),
     "dh_rwalk_batch": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _dbl, _dbl,
                             _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dh_rwalk_batch_dev": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _dbl,
@@ -373,6 +375,26 @@ class Context:
         return dict(u=u, v=v, logl=logl, accept=nacc, reject=nrej,
                     rng_out=rng_out)
 
+
+    def rwalk_propose(self, u0, axes, scale, rng_states, axes_idx=None,
+                      ncdim=None, bc=None):
+        """One propose_ball_point per walker (dh_rwalk_propose)."""
+        u0 = _f64(u0)
+        k, ndim = u0.shape
+        ncdim = ndim if ncdim is None else int(ncdim)
+        axes = _f64(axes).reshape(-1, ncdim, ncdim)
+        idx = None if axes_idx is None else np.ascontiguousarray(
+            axes_idx, dtype=np.int32)
+        bcarr = None if bc is None else np.ascontiguousarray(bc, dtype=np.int8)
+        rng = np.ascontiguousarray(rng_states, dtype=np.uint64).reshape(k, 4)
+        up = np.empty((k, ndim))
+        inside = np.empty(k, dtype=np.int32)
+        rng_out = np.empty((k, 4), dtype=np.uint64)
+        self._check(self.lib.dh_rwalk_propose(
+            self.handle, k, ndim, ncdim, _ptr(u0), _ptr(axes), axes.shape[0],
+            _ptr(idx), float(scale), _ptr(bcarr), _ptr(rng), _ptr(up),
+            _ptr(inside), _ptr(rng_out)))
+        return up, inside.astype(bool), rng_out
 
     def slice_batch(self, prob, u0, axes, scale, loglstar, slices, rng_states,
                     principal=False, doubling=False, axes_idx=None):

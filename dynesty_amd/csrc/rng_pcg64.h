@@ -242,6 +242,77 @@ __device__ __forceinline__ double std_normal(Pcg64& g, const ZigLds* z) {
     }
   }
 }
+// nc standard normals -> column dst[i * 64 + lane] (LDS), returns sum of squares.
+// Same stream consumption as nc calls of std_normal(), but software-pipelined:
+// the PCG step and the ziggurat table lookups of the NEXT candidate are issued
+// before the current one is classified, so the LDS latency of the lookup and the
+// 128-bit multiply overlap; a rejected candidate consumes the prefetched draw
+// as its wedge/tail uniform exactly as the sequential algorithm would, and a
+// lane that is finished hands its unconsumed candidate back (state rewind).
+__device__ __forceinline__ double normals_to_lds(Pcg64& g, const ZigLds* z, double* dst, int lane,
+                                                 int nc) {
+#pragma clang fp contract(off)
+  double ss = 0.0;
+  int i = 0;
+  U128 sb = g.state;  // generator state before `cand` was drawn
+  uint64_t cand = g.next64();
+  uint64_t cki = z->ki[cand & 0xff];
+  double cwi = z->wi[cand & 0xff];
+  while (__any(i < nc)) {
+    const bool active = i < nc;
+    const U128 sn = g.state;  // state before `nxt`
+    const uint64_t nxt = g.next64();
+    const uint64_t nki = z->ki[nxt & 0xff];
+    const double nwi = z->wi[nxt & 0xff];
+    if (active) {
+      const int idx = (int)(cand & 0xff);
+      const uint64_t r = cand >> 8;
+      const uint64_t rabs = (r >> 1) & 0x000fffffffffffffull;
+      double x = (double)rabs * cwi;
+      if (r & 1) x = -x;
+      bool take = rabs < cki;
+      bool used_next = false;
+      if (!take) {
+        used_next = true;
+        double u1 = (double)(nxt >> 11) * (1.0 / 9007199254740992.0);
+        if (idx == 0) {
+          for (;;) {
+            const double xx = -DH_ZIG_INV_R * log1p(-u1);
+            const double yy = -log1p(-g.next_double());
+            if (yy + yy > xx * xx) {
+              x = ((rabs >> 8) & 1) ? -(DH_ZIG_R + xx) : DH_ZIG_R + xx;
+              break;
+            }
+            u1 = g.next_double();
+          }
+          take = true;
+        } else {
+          take = (z->fi[idx - 1] - z->fi[idx]) * u1 + z->fi[idx] < exp(-0.5 * x * x);
+        }
+      }
+      if (take) {
+        dst[i * 64 + lane] = x;
+        ss = fma(x, x, ss);
+        ++i;
+      }
+      if (used_next) {
+        sb = g.state;
+        cand = g.next64();
+        cki = z->ki[cand & 0xff];
+        cwi = z->wi[cand & 0xff];
+      } else {
+        sb = sn;
+        cand = nxt;
+        cki = nki;
+        cwi = nwi;
+      }
+      if (i >= nc) g.state = sb;  // done: give the unconsumed candidate back
+    } else {
+      g.state = sn;  // idle lane: undo the speculative step
+    }
+  }
+  return ss;
+}
 #endif  // __HIPCC__
 
 }  // namespace dh

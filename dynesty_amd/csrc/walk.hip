@@ -58,6 +58,9 @@ struct RwalkArgs {
   const double* run_scale;
   const int* run_mode;
   int wpr, my_mode;
+  // lock-step form for host-evaluated likelihoods: do ONE proposal, write it to u,
+  // its in-cube flag to nacc, the advanced stream to rng_out, and stop
+  int propose_only;
   int ablate;  // profiling aid (env DH_ABLATE): 1 no normals, 2 no frame mat-vec, 4 no likelihood, 8 no pow
 };
 
@@ -114,11 +117,15 @@ __global__ void __launch_bounds__(64, DH_RW_OCC) rwalk_kernel(RwalkArgs a) {
     }
     // ... then randsphere (bounding.py:1288-1297): nc normals, one uniform
     double ss = 0.0;
+    if (a.ablate & 1) {
 #pragma unroll 1
-    for (int i = 0; i < nc; ++i) {
-      const double x = (a.ablate & 1) ? 0.1 * (i + 1) : std_normal(g, &zig);
-      sx[i * 64 + lane] = x;
-      ss = fma(x, x, ss);
+      for (int i = 0; i < nc; ++i) {
+        const double x = 0.1 * (i + 1);
+        sx[i * 64 + lane] = x;
+        ss = fma(x, x, ss);
+      }
+    } else {
+      ss = normals_to_lds(g, &zig, sx, lane, nc);
     }
     const double ur = g.next_double();
     const double fac = scale * (((a.ablate & 8) ? ur : pow(ur, inv_nc)) / sqrt(ss));
@@ -165,6 +172,16 @@ __global__ void __launch_bounds__(64, DH_RW_OCC) rwalk_kernel(RwalkArgs a) {
         hi = fmax(hi, up[i]);
       }
       inside = (lo > 0.0) && (hi < 1.0);  // padded entries sit at 0.5
+    }
+    if (a.propose_only) {
+      if (live) {
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+          if (FULL || i < n) a.u[(size_t)w * n + i] = up[i];
+        a.nacc[w] = inside ? 1 : 0;
+        if (a.rng_out) g.store(a.rng_out + (size_t)w * 4);
+      }
+      return;
     }
     if (!inside) {  // counted as a call and a reject, no likelihood evaluated
       ++nrej;
@@ -273,8 +290,16 @@ int dh::rwalk_launch_runs(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, 
   a.run_mode = run_mode;
   a.wpr = wpr;
   a.my_mode = my_mode;
-  if (!get_problem(ctx, problem, &a.prob)) return DH_ERR_ARG;
-  if (a.prob.ndim != ndim) return fail(ctx, DH_ERR_ARG, "problem ndim %d != %d", a.prob.ndim, ndim);
+  a.propose_only = problem == -1 ? 1 : 0;
+  if (a.propose_only) {
+    a.prob = ProblemDev();
+    a.prob.ndim = ndim;
+    a.prob.like_id = 99;   // never evaluated
+    a.prob.prior_id = 99;
+  } else {
+    if (!get_problem(ctx, problem, &a.prob)) return DH_ERR_ARG;
+    if (a.prob.ndim != ndim) return fail(ctx, DH_ERR_ARG, "problem ndim %d != %d", a.prob.ndim, ndim);
+  }
   if (k <= 0) return DH_OK;
   if (ncdim < 1 || ncdim > ndim || m < 1 || walks < 1)
     return fail(ctx, DH_ERR_ARG, "rwalk: ncdim=%d ndim=%d m=%d walks=%d", ncdim, ndim, m, walks);
@@ -323,7 +348,7 @@ int dh::rwalk_launch_runs(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, 
                      ncdim, N, ctx->axes_t);
   a.axes_t = ctx->axes_t;
   const dim3 grid((k + 63) / 64), block(64);
-  const bool full = (ndim == N && ncdim == N);
+  const bool full = (ndim == N && ncdim == N) && !a.propose_only;
   const int kind = full ? problem_kind(a.prob.like_id, a.prob.prior_id) : KIND_GENERIC;
 #define L(NN, FF, KK) hipLaunchKernelGGL((rwalk_kernel<NN, FF, KK>), grid, block, 0, ctx->stream, a)
 #define X(NN)                                       \
@@ -349,6 +374,39 @@ int dh::rwalk_launch_runs(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, 
 
 extern "C" {
 
+
+int dh_rwalk_propose(dh_ctx* ctx, int k, int ndim, int ncdim, const double* u0, const double* axes, int m,
+                     const int32_t* axes_idx, double scale, const int8_t* bc, const uint64_t* rng,
+                     double* u_prop, int32_t* inside, uint64_t* rng_out) {
+  DH_CHECK_CTX(ctx);
+  if (k <= 0) return DH_OK;
+  if (!u0 || !axes || !rng || !u_prop || !inside || !rng_out)
+    return fail(ctx, DH_ERR_ARG, "rwalk_propose: null pointer");
+  if (ndim > kMaxRegDim)
+    return fail(ctx, DH_ERR_ARG, "rwalk_propose: ndim=%d > %d not built", ndim, kMaxRegDim);
+  arena_reset(ctx);
+  const size_t kd = (size_t)k * ndim;
+  int rc = arena_reserve(ctx, 2 * kd * 8 + (size_t)m * ncdim * ncdim * 8 + (size_t)k * (4 + 4 + 64) +
+                                  (size_t)ndim + 8192);
+  if (rc) return rc;
+  const double* d_u0 = arena_up(ctx, u0, kd);
+  const double* d_axes = arena_up(ctx, axes, (size_t)m * ncdim * ncdim);
+  const int32_t* d_idx = axes_idx ? arena_up(ctx, axes_idx, (size_t)k) : nullptr;
+  const int8_t* d_bc = bc ? arena_up(ctx, bc, (size_t)ndim) : nullptr;
+  const uint64_t* d_rng = arena_up(ctx, rng, (size_t)k * 4);
+  double* d_u = (double*)arena_get(ctx, kd * 8);
+  int32_t* d_in = (int32_t*)arena_get(ctx, (size_t)k * 4);
+  uint64_t* d_ro = (uint64_t*)arena_get(ctx, (size_t)k * 32);
+  if (!d_u0 || !d_axes || !d_rng || !d_u || !d_in || !d_ro || (axes_idx && !d_idx) || (bc && !d_bc))
+    return DH_ERR_NOMEM;
+  rc = dh::rwalk_launch_runs(ctx, -1, k, ndim, ncdim, d_u0, d_axes, m, d_idx, scale, 0.0, 1, d_bc, d_rng, d_u,
+                             nullptr, nullptr, d_in, nullptr, d_ro, nullptr, nullptr, nullptr, 1, 0);
+  if (rc) return rc;
+  if (!down(ctx, u_prop, d_u, kd) || !down(ctx, inside, d_in, (size_t)k) ||
+      !down(ctx, rng_out, d_ro, (size_t)k * 4))
+    return DH_ERR_HIP;
+  return dh_sync(ctx);
+}
 
 int dh_rwalk_batch(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, const double* u0,
                    const double* axes, int m, const int32_t* axes_idx, double scale, double loglstar,

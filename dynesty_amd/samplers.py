@@ -105,12 +105,64 @@ def _bc_flags(kwargs, ndim):
     return bc
 
 
+def _run_rwalk_lockstep(args):
+    """rwalk with an arbitrary Python likelihood: the device proposes one
+    propose_ball_point per walker per step (dh_rwalk_propose), the host
+    evaluates the user's callbacks and applies generic_random_walk's accept
+    rule (internal_samplers.py:925-975).  Same streams, same counters."""
+    a0 = args[0]
+    kw = a0.kwargs
+    k = len(args)
+    u = np.array([a.u for a in args], dtype=np.float64)
+    ndim = u.shape[1]
+    axes, idx = _frames(args)
+    streams = _Streams([a.rseed for a in args])
+    states = streams.states
+    be = get_backend()
+    bc = _bc_flags(kw, ndim)
+    walks = int(kw['walks'])
+    nacc = np.zeros(k, dtype=np.int64)
+    nrej = np.zeros(k, dtype=np.int64)
+    v = [None] * k
+    logl = [None] * k
+    for _ in range(walks):
+        up, inside, states = be.rwalk_propose(u, axes, a0.scale, states,
+                                              axes_idx=idx,
+                                              ncdim=axes.shape[1], bc=bc)
+        for i in range(k):
+            if not inside[i]:
+                nrej[i] += 1
+                continue
+            vi = a0.prior_transform(np.array(up[i]))
+            li = a0.loglikelihood(np.asarray(vi))
+            if li > a0.loglstar:
+                u[i], v[i], logl[i] = up[i], vi, li
+                nacc[i] += 1
+            else:
+                nrej[i] += 1
+    streams.write_back(states)
+    res = []
+    for i in range(k):
+        if nacc[i] == 0:
+            v[i] = a0.prior_transform(np.array(u[i]))
+            logl[i] = a0.loglikelihood(np.asarray(v[i]))
+        res.append(SamplerReturn(
+            u=u[i].copy(), v=v[i], logl=logl[i], ncalls=walks,
+            evaluation_history=[],
+            tuning_info={'accept': int(nacc[i]), 'reject': int(nrej[i]),
+                         'scale': a0.scale},
+            proposal_stats=dict(n_accept=int(nacc[i]), n_reject=int(nrej[i]))))
+    return res
+
+
 def run_rwalk(args):
     """RWalkSampler.sample over a queue (internal_samplers.py:504-561)."""
     args = list(args)
     if not args:
         return []
     a0 = args[0]
+    if a0.kwargs.get('problem') is None:
+        return _run_rwalk_lockstep(args)
     prob = _problem_of(a0)
     kw = a0.kwargs
     u0 = np.array([a.u for a in args], dtype=np.float64)

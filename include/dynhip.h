@@ -186,6 +186,16 @@ int dh_rwalk_batch_dev(dh_ctx* ctx, int problem, int k, int ndim, int ncdim,
                        double* u, double* v, double* logl, int32_t* naccept,
                        int32_t* nreject, uint64_t* rng_out);
 
+/* Lock-step form for an arbitrary host likelihood: ONE propose_ball_point
+ * (internal_samplers.py:989-1035) per walker -- draws, frame mat-vec,
+ * wrap/reflect, unitcheck -- returning the proposals, their in-cube flags and the
+ * advanced streams; the caller evaluates prior_transform/loglikelihood on the
+ * host, applies the accept rule (internal_samplers.py:946-968) and calls again. */
+int dh_rwalk_propose(dh_ctx* ctx, int k, int ndim, int ncdim, const double* u0,
+                     const double* axes, int m, const int32_t* axes_idx, double scale,
+                     const int8_t* bc, const uint64_t* rng, double* u_prop,
+                     int32_t* inside, uint64_t* rng_out);
+
 /* RSliceSampler.sample (mode 0, internal_samplers.py:745-855) / SliceSampler.sample
  * (mode 1, :593-709) over k walkers; generic_slice_step + Neal's doubling
  * (:1038-1206) run as a per-lane state machine.  ncdim == ndim (dynesty.py:507-509).

@@ -166,6 +166,26 @@ class OracleBackend:
             out["rng_out"][i] = _words(rng)
         return out
 
+    def rwalk_propose(self, u0, axes, scale, rng_states, axes_idx=None,
+                      ncdim=None, bc=None):
+        u0 = np.asarray(u0, dtype=np.float64)
+        k, nd = u0.shape
+        nc = nd if ncdim is None else ncdim
+        axes = np.asarray(axes).reshape(-1, nc, nc)
+        per, ref, nonb = self._bcmasks(bc, nd)
+        up = np.array(u0)
+        inside = np.zeros(k, dtype=bool)
+        out = np.empty((k, 4), np.uint64)
+        for i in range(k):
+            rng = _gen(rng_states[i])
+            fr = axes[0 if axes_idx is None else axes_idx[i]]
+            p, fail = P.propose_ball(u0[i], scale, fr, nc, rng, per, ref, nonb)
+            if not fail:
+                up[i] = p
+                inside[i] = True
+            out[i] = _words(rng)
+        return up, inside, out
+
     def slice_batch(self, prob, u0, axes, scale, loglstar, slices, rng_states,
                     principal=False, doubling=False, axes_idx=None):
         u0 = np.asarray(u0, dtype=np.float64).reshape(-1, prob.ndim)

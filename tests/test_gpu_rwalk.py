@@ -117,3 +117,54 @@ def test_problem_eval(ctx):
                                    atol=1e-13)
         np.testing.assert_allclose(logl, prob.loglikelihood_many(
             prob.prior_transform_many(u)), rtol=1e-11, atol=1e-11)
+
+
+def test_rwalk_propose_lockstep(ctx):
+    """dh_rwalk_propose (device half of the lock-step path for arbitrary Python
+    likelihoods) vs propose_ball_point of the oracle, stream for stream; then a
+    full lock-step walk reproduces the fused kernel exactly."""
+    from dynesty_amd import _lib
+    case = inputs.walker_case("G5", 200, 55, shrink=3.0)
+    prob = case["problem"]
+    u0 = case["u0"][:100]
+    k = len(u0)
+    bc = np.zeros(5, dtype=np.int8)
+    bc[0] = _lib.BC_PERIODIC
+    bc[2] = _lib.BC_REFLECT
+    st = ctx.seed_children([77], 0, k)
+    up, inside, out = ctx.rwalk_propose(u0, case["axes"], 2.0, st, bc=bc)
+    kids = np.random.SeedSequence([77]).spawn(k)
+    nonb = bc == 0
+    for i in range(k):
+        bg = np.random.PCG64(kids[i])
+        p, fail = P.propose_ball(u0[i], 2.0, case["axes"], 5,
+                                 np.random.Generator(bg), np.array([0]),
+                                 np.array([2]), nonb)
+        assert inside[i] == (not fail)
+        if not fail:
+            np.testing.assert_allclose(up[i], p, rtol=0, atol=1e-13)
+        np.testing.assert_array_equal(out[i], _lib.pcg_state_words(bg))
+    assert inside.any() and (~inside).any()
+    # lock-step walk == fused walk
+    from dynesty_amd import samplers
+    from dynesty_amd.samplers import SamplerReturn  # noqa: F401
+    from collections import namedtuple
+    Arg = namedtuple("Arg", "u loglstar axes scale prior_transform "
+                     "loglikelihood rseed kwargs")
+    seeds = np.random.SeedSequence([78]).spawn(16)
+    args = [Arg(u0[i].copy(), case["loglstar"], case["axes"], case["scale"],
+                prob.prior_transform, prob.loglikelihood, seeds[i],
+                dict(walks=20, problem=None, periodic=None, reflective=None))
+            for i in range(16)]
+    from dynesty_amd import backend
+    backend.set_backend(ctx)
+    try:
+        lock = samplers.run_rwalk(args)
+    finally:
+        backend.set_backend(None)
+    fused = ctx.rwalk_batch(prob, u0[:16], case["axes"], case["scale"],
+                            case["loglstar"], 20,
+                            ctx.seed_children([78], 0, 16))
+    for i in range(16):
+        np.testing.assert_allclose(lock[i].u, fused["u"][i], rtol=0, atol=1e-12)
+        assert lock[i].tuning_info["accept"] == fused["accept"][i]

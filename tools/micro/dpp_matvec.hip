@@ -68,6 +68,30 @@ __global__ void __launch_bounds__(64) kA(const double* MT, const double* __restr
   for (int i = 0; i < N; ++i) out[(size_t)blockIdx.x * N * 64 + i * 64 + lane] = acc[i];
 }
 
+__global__ void __launch_bounds__(64) kL(const double* __restrict__ MT, const double* __restrict__ x,
+                                         double* out, int iters) {
+  __shared__ double xs[N * 64];
+  __shared__ __attribute__((aligned(16))) double ms[N * NP];
+  const int lane = threadIdx.x;
+  for (int j = 0; j < N; ++j) xs[j * 64 + lane] = x[(size_t)blockIdx.x * N * 64 + j * 64 + lane];
+  for (int e = lane; e < N * NP; e += 64) ms[e] = MT[e];
+  __syncthreads();
+  double acc[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) acc[i] = 0;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll 5
+    for (int j = 0; j < N; ++j) {
+      double d = xs[j * 64 + lane];
+#pragma unroll
+      for (int i = 0; i < N; ++i) acc[i] = fma(ms[j * NP + i], d, acc[i]);
+    }
+    xs[(it % N) * 64 + lane] = acc[it % N] * 1e-3;
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i) out[(size_t)blockIdx.x * N * 64 + i * 64 + lane] = acc[i];
+}
+
 int main(int argc, char** argv) {
   int blocks = argc > 1 ? atoi(argv[1]) : 2048, iters = argc > 2 ? atoi(argv[2]) : 90;
   std::vector<double> MT(N * NP, 0.0), x((size_t)blocks * N * 64);
@@ -87,6 +111,11 @@ int main(int argc, char** argv) {
     hipEventElapsedTime(&ma, e0, e1);
     hipEventRecord(e0); kB<<<blocks, 64>>>(dM, dx, dB, iters); hipEventRecord(e1); hipEventSynchronize(e1);
     hipEventElapsedTime(&mb, e0, e1);
+    float ml;
+    hipEventRecord(e0); kL<<<blocks, 64>>>(dM, dx, dB, iters); hipEventRecord(e1); hipEventSynchronize(e1);
+    hipEventElapsedTime(&ml, e0, e1);
+    printf("lds-bcast: %.3f ms %.2f TFLOP/s | ", ml, (double)blocks * 64 * iters * N * N * 2 / ml / 1e9);
+    hipEventRecord(e0); kB<<<blocks, 64>>>(dM, dx, dB, iters); hipEventRecord(e1); hipEventSynchronize(e1);
     double fl = (double)blocks * 64 * iters * N * N * 2;
     printf("sgpr: %.3f ms %.2f TFLOP/s | dpp: %.3f ms %.2f TFLOP/s\n", ma, fl / ma / 1e9, mb, fl / mb / 1e9);
   }
