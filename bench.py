@@ -71,6 +71,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-rebuild", action="store_true",
                     help="time the proposal kernel alone (diagnostic)")
+    ap.add_argument("--no-e2e", action="store_true",
+                    help="skip the end-to-end device-loop leg (tap C)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -195,6 +197,32 @@ def main():
         out = [torch.empty_like(rec) for _ in range(world)]
         dist.all_gather(out, rec)
 
+    # ---- tap C (outside the timed region): the same shard run END TO END by the
+    # device-resident nested-sampling loop, every run to dlogz = 0.01
+    e2e = None
+    if not args.no_e2e:
+        from dynesty_amd import ensemble
+        t0 = time.perf_counter()
+        table = ensemble.run_ensemble_device(
+            prob, runs * world, base_seed=21, world=world, rank=rank,
+            dist=dist, device=torch.device("cuda", local_rank) if dist else None,
+            nlive=nlive, queue_size=512, walks=args.walks)
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        lz = table[:, 1]
+        e2e = {"tap_point": "C (device-resident NS loop, dh_ns_ensemble)",
+               "runs": int(len(table)), "seconds": dt,
+               "likelihood_calls_per_s": float(table[:, 4].sum() / dt),
+               "ns_iterations_per_s": float(table[:, 3].sum() / dt),
+               "logz_mean": float(lz.mean()),
+               "logz_se": float(lz.std(ddof=1) / math.sqrt(len(lz))),
+               "logz_reference_seed21": -57.4541, "logz_truth": -57.5646,
+               "gather": "RCCL all_gather of 6 doubles per run" if dist else
+                         "single process"}
+
     if rank == 0:
         alg_bytes = 8 * (2 * d + 1)  # read u, write u', write logl
         flops = 2 * d * d + 8 * d + (d * d + 3 * d)  # frame mat-vec + sym. quad form
@@ -255,6 +283,8 @@ def main():
                     "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s"},
             },
         }
+        if e2e is not None:
+            line["config"]["end_to_end"] = e2e
         if not args.no_cpu:
             line["cpu_baseline"] = cpu_baseline(prob, u0, nlive, scale,
                                                 loglstar, args.walks,

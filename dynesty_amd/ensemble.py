@@ -113,6 +113,28 @@ def run_ensemble(prob, total_runs, base_seed=21, world=1, rank=0, dist=None,
     return table, results
 
 
+def run_ensemble_device(prob, total_runs, base_seed=21, world=1, rank=0,
+                        dist=None, device=None, nlive=2000, queue_size=512,
+                        walks=None, bound='multi', dlogz=0.01, **kw):
+    """BASELINE config C5: this rank's shard of `total_runs` static runs executed
+    by the device-resident loop (`dh_ns_ensemble`, one launch sequence for the
+    whole shard), then the RCCL all-gather of the per-run records.  Seeds are
+    keyed on the global run id, so the table does not depend on `world`."""
+    from .backend import get_backend
+    mine = shard_runs(total_runs, world, rank)
+    local = np.zeros((0, len(RECORD_FIELDS)))
+    if len(mine):
+        r = get_backend().ns_ensemble(prob, len(mine), nlive, queue_size,
+                                      walks=walks, bound=bound, dlogz=dlogz,
+                                      entropy=np.atleast_1d(base_seed),
+                                      first_run=mine.start, **kw)
+        local = np.stack([np.arange(mine.start, mine.stop, dtype=np.float64),
+                          r["logz"], r["logzerr"], r["niter"].astype(float),
+                          r["ncall"].astype(float), r["h"]], axis=1)
+    return gather_records(local, total_runs, world, rank, dist=dist,
+                          device=device)
+
+
 def combine_logz(table):
     """Ensemble estimate: mean of ln Z over runs and its standard error."""
     lz = table[:, RECORD_FIELDS.index("logz")]
