@@ -87,7 +87,7 @@ SIGNATURES = {
     "dh_unif_batch_dev": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp,
                                _dbl, _vp, _vp, C.c_int64, _vp, _vp, _vp, _vp,
                                _vp, _vp]),
-    "dh_ns_ensemble": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _dbl, _dbl,
+    "dh_ns_ensemble": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _dbl, _dbl,
                             C.c_int64, C.c_int64, _vp, _i, _u32, _vp, _vp,
                             _vp]),
     "dh_bound_draw": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp,
@@ -459,18 +459,23 @@ class Context:
     def ns_ensemble(self, prob, runs, nlive, queue_size, walks=None,
                     bound='multi', dlogz=0.01, enlarge=1.25, entropy=(21,),
                     first_run=0, max_fills=0, max_iter=400000,
-                    want_dead_logl=False):
+                    want_dead_logl=False, sample='rwalk', slices=None):
         """Device-resident ensemble of static NS runs (dh_ns_ensemble)."""
         nd = prob.ndim
-        if walks is None:
-            walks = nd + 20
+        kind = dict(rwalk=0, rslice=1, slice=2)[sample]
+        if kind == 0:
+            if walks is None:
+                walks = nd + 20  # dynesty.py:128
+        else:
+            walks = slices if slices is not None else \
+                (3 + nd if kind == 1 else 3)
         words = entropy_words(entropy)
         rec = np.empty((runs, 8))
         dead = np.empty((runs, max_iter)) if want_dead_logl else None
         nf = C.c_int64(0)
         self._check(self.lib.dh_ns_ensemble(
             self.handle, self.problem(prob), int(runs), int(nlive), nd,
-            int(queue_size), int(walks), 1 if bound == 'multi' else 0,
+            int(queue_size), kind, int(walks), 1 if bound == 'multi' else 0,
             float(dlogz), float(enlarge), int(max_fills), int(max_iter),
             _ptr(words), words.size, int(first_run), _ptr(rec), _ptr(dead),
             C.byref(nf)))

@@ -92,6 +92,12 @@ int rwalk_launch_runs(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, cons
                       int walks, const int8_t* bc, const uint64_t* rng, double* u, double* v, double* logl,
                       int32_t* naccept, int32_t* nreject, uint64_t* rng_out, const double* run_loglstar,
                       const double* run_scale, const int* run_mode, int wpr, int my_mode);
+int slice_launch_runs(dh_ctx* ctx, int problem, int k, int ndim, int mode, const double* u0,
+                      const double* axes, int m, const int32_t* axes_idx, double scale, double loglstar,
+                      int slices, int doubling, const uint64_t* rng, double* u, double* v, double* logl,
+                      int32_t* ncalls, int32_t* nexpand, int32_t* ncontract, int32_t* flags,
+                      uint64_t* rng_out, const double* run_loglstar, const double* run_scale,
+                      const int* run_mode, const int* run_doubling, int wpr, int my_mode);
 int unif_launch_runs(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, int m, const double* ctrs,
                      const double* axes, const double* ams, const double* cumprob, double loglstar,
                      const int8_t* bc, const uint64_t* rng, int64_t max_tries, double* u, double* v,

@@ -32,12 +32,13 @@ struct NsRun {
   double logvol, logz, h, lmax, scale, loglstar, dead_prev;
   long long it, ncall, ncall_last_update;
   int mode, need_rebuild, nbound, nfill;
-  int acc, rej, pad0, pad1;
+  int acc, rej, doubling, pad1;
   uint64_t rng[4];
 };
 
 struct NsArgs {
   int runs, nlive, ndim, K, walks, bound_multi, max_ells;
+  int sampler;  // 0 rwalk, 1 rslice, 2 slice ; `walks` holds the slice count for 1, 2
   long long cap;  // dead-point capacity per run
   double dlogz, enlarge_log, facc, first_eff;
   long long first_ncall, update_interval;
@@ -58,8 +59,11 @@ struct NsArgs {
   double* r_u;
   double* r_v;
   double* r_logl;
-  int* r_a;  // naccept | ncalls (unit cube)
-  int* r_b;  // nreject | flags
+  int* r_a;  // naccept | ncalls (unit cube, slice)
+  int* r_b;  // nreject | flags (unit cube) | nexpand (slice)
+  int* r_c;  // ncontract (slice)
+  int* r_d;  // flags (slice)
+  int* run_doubling;
   // per-run walk parameters
   double* run_loglstar;
   double* run_scale;
@@ -128,7 +132,7 @@ __global__ void __launch_bounds__(kT)
     r.need_rebuild = 0;
     r.nbound = 0;
     r.nfill = 0;
-    r.acc = r.rej = r.pad0 = r.pad1 = 0;
+    r.acc = r.rej = r.doubling = r.pad1 = 0;
     Pcg64 g;
     seed_from_child(g, entropy, nwords, 0x80000000u + first_run + (uint32_t)run);
     g.store(r.rng);
@@ -213,6 +217,7 @@ __global__ void ns_prepare(NsArgs a) {
   a.run_mode[run] = r.mode;
   a.run_loglstar[run] = r.loglstar;
   a.run_scale[run] = r.scale;
+  a.run_doubling[run] = r.doubling;
 }
 
 // ---- queue fill: start points, frames, walker streams ---------------------------
@@ -306,10 +311,16 @@ __global__ void __launch_bounds__(kT) ns_consume(NsArgs a) {
     ql[j] = a.r_logl[q];
     if (mode == MODE_CUBE) {
       qc[j] = a.r_a[q];
-    } else {
+    } else if (a.sampler == 0) {
       qc[j] = a.walks;
       acc += a.r_a[q];
       rej += a.r_b[q];
+    } else {
+      qc[j] = a.r_a[q];
+      acc += a.r_b[q];                      // n_expand
+      rej += a.r_c[q];                      // n_contract
+      if (a.r_d[q] & 1) atomicOr(&r.doubling, 1);  // expansion_warning_set -> slice_doubling
+      if (a.r_d[q] & 2) ql[j] = -INFINITY;         // failed slice: never accepted
     }
   }
   // block sums of accept / reject for the scale tuning
@@ -381,9 +392,17 @@ __global__ void __launch_bounds__(kT) ns_consume(NsArgs a) {
     r.loglstar = key[0];
     r.nfill += 1;
     if (mode == MODE_BOUND) {
-      // RWalkSampler.tune (internal_samplers.py:460-493), once per queue fill
       const int ta = racc[0], tr = rrej[0];
-      if (ta + tr > 0) r.scale *= exp(((double)ta / (double)(ta + tr) - a.facc) / (double)D / a.facc);
+      if (a.sampler == 0) {
+        // RWalkSampler.tune (internal_samplers.py:460-493), once per queue fill
+        if (ta + tr > 0) r.scale *= exp(((double)ta / (double)(ta + tr) - a.facc) / (double)D / a.facc);
+      } else {
+        // tune_slice (internal_samplers.py:1209-1239)
+        const double ne = ta > 1 ? (double)ta : 1.0, nt = (double)tr;
+        double mult = ne * 2.0 / (ne + nt);
+        mult = fmin(fmax(mult, 0.5), 2.0);
+        r.scale *= mult;
+      }
     }
     if (done) {
       r.mode = done == 1 ? MODE_DONE : MODE_FAILED;
@@ -473,16 +492,19 @@ __global__ void __launch_bounds__(kT) ns_finish(NsArgs a) {
 
 extern "C" {
 
-int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int queue_size, int walks,
-                   int bound_multi, double dlogz, double enlarge, int64_t max_fills, int64_t max_iter,
+int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int queue_size, int sampler,
+                   int walks, int bound_multi, double dlogz, double enlarge, int64_t max_fills, int64_t max_iter,
                    const uint32_t* entropy_words, int n_words, uint32_t first_run, double* records,
                    double* dead_logl_out, int64_t* n_fills_out) {
   DH_CHECK_CTX(ctx);
   ProblemDev pd;
   if (!get_problem(ctx, problem, &pd)) return DH_ERR_ARG;
   if (pd.ndim != ndim) return fail(ctx, DH_ERR_ARG, "problem ndim %d != %d", pd.ndim, ndim);
-  if (runs < 1 || nlive < 4 || queue_size < 1 || walks < 2 || !entropy_words || n_words < 1 || !records)
+  if (runs < 1 || nlive < 4 || queue_size < 1 || walks < 1 || sampler < 0 || sampler > 2 || !entropy_words ||
+      n_words < 1 || !records)
     return fail(ctx, DH_ERR_ARG, "ns_ensemble: bad arguments");
+  if (sampler != 0 && pad_dim(ndim) != ndim)
+    return fail(ctx, DH_ERR_ARG, "ns_ensemble: slice samplers need ndim in {1-6,8,10,12,16,20,25,32}");
   if (ndim > kMaxRegDim) return fail(ctx, DH_ERR_ARG, "ns_ensemble: ndim=%d > %d not built", ndim, kMaxRegDim);
   const int N = nlive, D = ndim, K = queue_size, R = runs;
   const int me = bound_multi ? (N / (2 * D) > 0 ? N / (2 * D) : 1) : 1;
@@ -492,15 +514,17 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
   a.ndim = D;
   a.K = K;
   a.walks = walks;
+  a.sampler = sampler;
   a.bound_multi = bound_multi;
   a.max_ells = me;
   a.cap = max_iter > 0 ? max_iter : 400000;
   a.dlogz = dlogz;
   a.enlarge_log = log(enlarge);
-  a.facc = fmin(1.0, fmax(1.0 / (double)walks, 0.5));
+  a.facc = fmin(1.0, fmax(1.0 / (double)(walks > 2 ? walks : 2), 0.5));
   a.first_eff = 10.0;
   a.first_ncall = 2ll * N;
-  a.update_interval = (long long)walks * N;
+  // update_bound_interval_ratio (internal_samplers.py:495-502, 581-588, 737-744) * nlive
+  a.update_interval = (long long)(sampler == 2 ? walks * D : walks) * N;
   a.store_samples = 0;
   // ---- one allocation for all state ----
   auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
@@ -517,6 +541,7 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
                o_qf = take((size_t)R * K * 4), o_qr = take((size_t)R * K * 32), o_qo = take((size_t)R * K * 32),
                o_ru = take((size_t)R * K * D * 8), o_rv = take((size_t)R * K * D * 8),
                o_rl = take((size_t)R * K * 8), o_ra = take((size_t)R * K * 4), o_rb = take((size_t)R * K * 4),
+               o_rc = take((size_t)R * K * 4), o_rd = take((size_t)R * K * 4), o_dbl = take((size_t)R * 4),
                o_pl = take((size_t)R * 8), o_ps = take((size_t)R * 8), o_pm = take((size_t)R * 4),
                o_rm = take((size_t)R * 4), o_nd = take(64), o_ne = take((size_t)R * 4),
                o_bs = take((size_t)R * 4), o_bc = take((size_t)R * me * D * 8), o_bv = take((size_t)R * me * dd * 8),
@@ -548,6 +573,9 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
   a.r_logl = (double*)(base + o_rl);
   a.r_a = (int*)(base + o_ra);
   a.r_b = (int*)(base + o_rb);
+  a.r_c = (int*)(base + o_rc);
+  a.r_d = (int*)(base + o_rd);
+  a.run_doubling = (int*)(base + o_dbl);
   a.run_loglstar = (double*)(base + o_pl);
   a.run_scale = (double*)(base + o_ps);
   a.run_mode = (int*)(base + o_pm);
@@ -601,9 +629,15 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
                             a.q_rng, 0, a.r_u, a.r_v, a.r_logl, a.r_a, a.r_b, a.q_rng_out, a.run_loglstar,
                             a.run_mode, K, MODE_CUBE);
       if (rc) return cleanup(rc);
-      rc = rwalk_launch_runs(ctx, problem, R * K, D, D, a.q_u0, a.b_axes, R * me, a.q_frame, 1.0, 0.0, walks,
-                             nullptr, a.q_rng, a.r_u, a.r_v, a.r_logl, a.r_a, a.r_b, a.q_rng_out,
-                             a.run_loglstar, a.run_scale, a.run_mode, K, MODE_BOUND);
+      if (sampler == 0)
+        rc = rwalk_launch_runs(ctx, problem, R * K, D, D, a.q_u0, a.b_axes, R * me, a.q_frame, 1.0, 0.0, walks,
+                               nullptr, a.q_rng, a.r_u, a.r_v, a.r_logl, a.r_a, a.r_b, a.q_rng_out,
+                               a.run_loglstar, a.run_scale, a.run_mode, K, MODE_BOUND);
+      else
+        rc = slice_launch_runs(ctx, problem, R * K, D, sampler - 1, a.q_u0, a.b_axes, R * me, a.q_frame, 1.0,
+                               0.0, walks, 0, a.q_rng, a.r_u, a.r_v, a.r_logl, a.r_a, a.r_b, a.r_c, a.r_d,
+                               a.q_rng_out, a.run_loglstar, a.run_scale, a.run_mode, a.run_doubling, K,
+                               MODE_BOUND);
       if (rc) return cleanup(rc);
       hipLaunchKernelGGL(ns_consume, dim3(R), dim3(kT), lds_cons, s, a);
     }

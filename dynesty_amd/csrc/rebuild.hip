@@ -72,6 +72,7 @@ struct RebuildArgs {
   int* split_list;    // 2 x runs x maxw   (by level parity)
   int* ell_list;      // runs x 2 maxw
   double* scale_g;    // runs x d
+  double* pts_scaled; // runs x n x d : points / root std, written once by k_root (k-means input)
   const int* active;  // runs or null: only runs with active[run] != 0 are rebuilt
 };
 
@@ -116,28 +117,27 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_wave_barrier();
 }
 
+// block reductions: wave shuffles, then one LDS exchange across the 4 waves
 __device__ __forceinline__ double block_reduce_max(double v, double* red) {
+  for (int s = 32; s > 0; s >>= 1) v = fmax(v, __shfl_xor(v, s));
   const int t = threadIdx.x;
-  red[t] = v;
+  __syncthreads();  // red may still be read by a previous user
+  if ((t & 63) == 0) red[t >> 6] = v;
   __syncthreads();
-  for (int s = kThreads / 2; s > 0; s >>= 1) {
-    if (t < s) red[t] = fmax(red[t], red[t + s]);
-    __syncthreads();
-  }
   double r = red[0];
+  for (int i = 1; i < kThreads / 64; ++i) r = fmax(r, red[i]);
   __syncthreads();
   return r;
 }
 
 __device__ __forceinline__ int block_reduce_sum_int(int v, int* red) {
+  for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s);
   const int t = threadIdx.x;
-  red[t] = v;
   __syncthreads();
-  for (int s = kThreads / 2; s > 0; s >>= 1) {
-    if (t < s) red[t] += red[t + s];
-    __syncthreads();
-  }
-  int r = red[0];
+  if ((t & 63) == 0) red[t >> 6] = v;
+  __syncthreads();
+  int r = 0;
+  for (int i = 0; i < kThreads / 64; ++i) r += red[i];
   __syncthreads();
   return r;
 }
@@ -758,7 +758,7 @@ __device__ int node_kmeans(const Lds& L, const double* pts, const int* perm, uns
     int myc0 = 0;
     for (int base = 0; base < count; base += L.TP) {
       const int cnt = min(L.TP, count - base);
-      stage_tile(L, pts, perm, start + base, cnt, D, 2);
+      stage_tile(L, pts, perm, start + base, cnt, D, 0);  // pts = points / scale (pre-divided)
       // vq: nearest centroid, strict '<' so the lower index wins ties
       for (int p = t; p < cnt; p += kThreads) {
         const double* x = L.tile + p * L.LD;
@@ -975,6 +975,15 @@ __global__ void __launch_bounds__(kThreads) k_root(RebuildArgs a) {
   if (status == DH_OK && a.mode == 0 && n >= 4 * D) {
     node_std(L, v.pts, v.perm, 0, n, D);
     if (t < D) a.scale_g[(size_t)run * D + t] = L.scale[t];
+    {
+      // points / scale once (the reference divides the whole array before kmeans2, :1510)
+      double* ps = a.pts_scaled + (size_t)run * n * D;
+      const int j = t & (L.DP - 1), p0 = t >> L.DPlog, pstep = kThreads >> L.DPlog;
+      if (j < D) {
+        const double sj = L.scale[j];
+        for (int p = p0; p < n; p += pstep) ps[(size_t)p * D + j] = v.pts[(size_t)p * D + j] / sj;
+      }
+    }
     if (t == 0) {
       a.split_list[((size_t)0 * a.runs + run) * a.maxw] = 0;
       a.nsplit[(size_t)0 * a.runs + run] = 1;
@@ -997,7 +1006,8 @@ __global__ void __launch_bounds__(kThreads) k_split(RebuildArgs a, int level) {
   const int start = v.nodes[cur].start, count = v.nodes[cur].count, depth = v.nodes[cur].depth;
   const int min_size = 2 * D;
   PH_T0();
-  const int n0 = node_kmeans(L, v.pts, v.perm, v.lab, start, count, D, v.estore + (size_t)cur * v.NS);
+  const int n0 = node_kmeans(L, a.pts_scaled + (size_t)run * a.n * D, v.perm, v.lab, start, count, D,
+                             v.estore + (size_t)cur * v.NS);
   PH_ADD(4);
   const int n1 = count - n0;
   if (min(n0, n1) < min_size) return;  // reject the split (:1521-1522): node stays a leaf
@@ -1432,9 +1442,10 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
   const size_t b_cnt = (size_t)runs * ((size_t)2 * a.levels + 3) * 4;
   const size_t b_sl = (size_t)2 * runs * a.maxw * 4, b_el = (size_t)runs * 2 * a.maxw * 4;
   const size_t b_sc = (size_t)runs * d * 8;
+  const size_t b_ps = mode == 1 ? 0 : (size_t)runs * n * d * 8;
   auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
   const size_t total = al(b_perm) * 2 + al(b_lab) + al(b_nodes) + al(b_es) + al(b_res) + al(b_cnt) +
-                       al(b_sl) + al(b_el) + al(b_sc);
+                       al(b_sl) + al(b_el) + al(b_sc) + al(b_ps);
   if (total > ctx->rebuild_ws_cap) {
     if (!hip_ok(ctx, hipStreamSynchronize(ctx->stream), "sync")) return DH_ERR_HIP;
     if (ctx->rebuild_ws) (void)hipFree(ctx->rebuild_ws);
@@ -1467,6 +1478,8 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
   a.ell_list = (int*)w;
   w += al(b_el);
   a.scale_g = (double*)w;
+  w += al(b_sc);
+  a.pts_scaled = (double*)w;
   a.nells = nells;
   a.status = status;
   a.ctrs = ctrs;

@@ -50,6 +50,12 @@ struct SliceArgs {
   const uint64_t* zki;
   const uint64_t* zwi;
   const uint64_t* zfi;
+  // ensemble form (ns.hip), as in RwalkArgs; run_doubling = per-run slice_doubling
+  const double* run_loglstar;
+  const double* run_scale;
+  const int* run_mode;
+  const int* run_doubling;
+  int wpr, my_mode;
 };
 
 template <int N, int KIND>
@@ -71,8 +77,18 @@ __global__ void __launch_bounds__(64, 2) slice_kernel(SliceArgs a) {
   g.load(a.rng_in + (size_t)wi * 4);
   const int my_frame = a.axes_idx ? a.axes_idx[wi] : 0;
 
+  double loglstar = a.loglstar, scale = a.scale;
   bool doubling = a.doubling0 != 0;
   bool warn_set = false, failed = false;
+  bool idle = false;
+  if (a.run_mode) {
+    const int run = wi / a.wpr;
+    idle = a.run_mode[run] != a.my_mode;
+    loglstar = a.run_loglstar[run];
+    scale = a.run_scale[run];
+    doubling = a.run_doubling[run] != 0;
+  }
+  failed = idle;  // idle lanes never enter the state machine
   int nc = 0, n_expand = 0, n_contract = 0;
   double logl_cur = 0.0;
   const double maxlen = sqrt((double)n) / 2.0;
@@ -117,13 +133,13 @@ __global__ void __launch_bounds__(64, 2) slice_kernel(SliceArgs a) {
           }
         }
 #pragma unroll
-        for (int i = 0; i < N; ++i) dir[i] = acc[i] * a.scale;  // np.dot(axes, drhat) * scale
+        for (int i = 0; i < N; ++i) dir[i] = acc[i] * scale;  // np.dot(axes, drhat) * scale
       } else {
         // axis = (scale * axes.T)[idx] = scale * axes[:, idx]
         const int idx = sperm[sub * 64 + lane];
         const double* col = a.axes_t + (size_t)my_frame * N * N + (size_t)idx * N;
 #pragma unroll
-        for (int i = 0; i < N; ++i) dir[i] = a.scale * col[i];
+        for (int i = 0; i < N; ++i) dir[i] = scale * col[i];
       }
       // ---- generic_slice_step ----
       const double rand0 = g.next_double();
@@ -172,11 +188,11 @@ __global__ void __launch_bounds__(64, 2) slice_kernel(SliceArgs a) {
             case PH_RIGHT0:
               f_r = f;
               if (!doubling) {
-                if (f_l > a.loglstar) {
+                if (f_l > loglstar) {
                   phase = PH_OUT_L;
                   left -= 1.0;
                   xq = left;
-                } else if (f_r > a.loglstar) {
+                } else if (f_r > loglstar) {
                   phase = PH_OUT_R;
                   right += 1.0;
                   xq = right;
@@ -190,10 +206,10 @@ __global__ void __launch_bounds__(64, 2) slice_kernel(SliceArgs a) {
             case PH_OUT_L:
               f_l = f;
               ++nexp_step;
-              if (f_l > a.loglstar) {
+              if (f_l > loglstar) {
                 left -= 1.0;
                 xq = left;
-              } else if (f_r > a.loglstar) {
+              } else if (f_r > loglstar) {
                 phase = PH_OUT_R;
                 right += 1.0;
                 xq = right;
@@ -204,7 +220,7 @@ __global__ void __launch_bounds__(64, 2) slice_kernel(SliceArgs a) {
             case PH_OUT_R:
               f_r = f;
               ++nexp_step;
-              if (f_r > a.loglstar) {
+              if (f_r > loglstar) {
                 right += 1.0;
                 xq = right;
               } else {
@@ -221,7 +237,7 @@ __global__ void __launch_bounds__(64, 2) slice_kernel(SliceArgs a) {
               break;
             case PH_SHRINK: {
               ++n_contract;
-              bool ok = f > a.loglstar;
+              bool ok = f > loglstar;
               if (ok && doubling) {
                 // start the acceptance test for x1 = xq
                 x1 = xq;
@@ -256,7 +272,7 @@ __global__ void __launch_bounds__(64, 2) slice_kernel(SliceArgs a) {
                 f_rhat = f;
               else
                 f_lhat = f;
-              if (Dflag && a.loglstar >= f_lhat && a.loglstar >= f_rhat) {
+              if (Dflag && loglstar >= f_lhat && loglstar >= f_rhat) {
                 // rejected: shrink towards the origin as for any failed proposal
                 phase = PH_SHRINK;
                 if (x1 < 0.0)
@@ -274,7 +290,7 @@ __global__ void __launch_bounds__(64, 2) slice_kernel(SliceArgs a) {
           }
           // ---- phases that decide their next abscissa after the switch ----
           if (phase == PH_DBL) {
-            if (f_l > a.loglstar || f_r > a.loglstar) {
+            if (f_l > loglstar || f_r > loglstar) {
               const double V = g.next_double();
               if (V < 0.5) {
                 left -= (right - left);
@@ -328,7 +344,8 @@ __global__ void __launch_bounds__(64, 2) slice_kernel(SliceArgs a) {
     }
   }
   prior_to_lds<N, true, KIND>(a.prob, u, n, sx, lane);
-  if (live) {
+  if (idle) failed = false;
+  if (live && !idle) {
 #pragma unroll
     for (int i = 0; i < N; ++i) {
       a.u[(size_t)w * n + i] = u[i];
@@ -644,14 +661,36 @@ int dh_slice_batch_dev(dh_ctx* ctx, int problem, int k, int ndim, int mode, cons
                        double loglstar, int slices, int doubling, const uint64_t* rng, double* u,
                        double* v, double* logl, int32_t* ncalls, int32_t* nexpand, int32_t* ncontract,
                        int32_t* flags, uint64_t* rng_out) {
+  return dh::slice_launch_runs(ctx, problem, k, ndim, mode, u0, axes, m, axes_idx, scale, loglstar, slices,
+                               doubling, rng, u, v, logl, ncalls, nexpand, ncontract, flags, rng_out, nullptr,
+                               nullptr, nullptr, nullptr, 1, 0);
+}
+
+}  // extern "C"
+
+int dh::slice_launch_runs(dh_ctx* ctx, int problem, int k, int ndim, int mode, const double* u0,
+                          const double* axes, int m, const int32_t* axes_idx, double scale,
+                          double loglstar, int slices, int doubling, const uint64_t* rng, double* u,
+                          double* v, double* logl, int32_t* ncalls, int32_t* nexpand, int32_t* ncontract,
+                          int32_t* flags, uint64_t* rng_out, const double* run_loglstar,
+                          const double* run_scale, const int* run_mode, const int* run_doubling, int wpr,
+                          int my_mode) {
   DH_CHECK_CTX(ctx);
   SliceArgs a;
+  a.run_loglstar = run_loglstar;
+  a.run_scale = run_scale;
+  a.run_mode = run_mode;
+  a.run_doubling = run_doubling;
+  a.wpr = wpr;
+  a.my_mode = my_mode;
   if (!get_problem(ctx, problem, &a.prob)) return DH_ERR_ARG;
   if (a.prob.ndim != ndim) return fail(ctx, DH_ERR_ARG, "problem ndim %d != %d", a.prob.ndim, ndim);
   if (k <= 0) return DH_OK;
   if (m < 1 || slices < 1 || (mode != 0 && mode != 1))
     return fail(ctx, DH_ERR_ARG, "slice: m=%d slices=%d mode=%d", m, slices, mode);
   const int N = pad_dim(ndim);
+  if (N != ndim && run_mode)
+    return fail(ctx, DH_ERR_ARG, "ensemble slice: ndim=%d has no register-resident instantiation", ndim);
   if (N != ndim)  // no register-resident instantiation for this dimension: wave-per-walker path
     return wide_walk_launch(ctx, mode + 1, problem, k, ndim, ndim, u0, axes, m, axes_idx, scale, loglstar,
                             slices, doubling, nullptr, rng, u, v, logl, ncalls, nexpand, ncontract, flags,
@@ -704,6 +743,9 @@ int dh_slice_batch_dev(dh_ctx* ctx, int problem, int k, int ndim, int mode, cons
 #undef L
   return hip_ok(ctx, hipGetLastError(), "slice launch") ? DH_OK : DH_ERR_HIP;
 }
+
+extern "C" {
+
 
 int dh_slice_batch(dh_ctx* ctx, int problem, int k, int ndim, int mode, const double* u0,
                    const double* axes, int m, const int32_t* axes_idx, double scale, double loglstar,

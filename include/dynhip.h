@@ -246,7 +246,8 @@ int dh_bound_draw(dh_ctx* ctx, const uint64_t* state4, int nsamp, int d, int m,
 
 /* ---- device-resident ensemble of static nested-sampling runs (BASELINE config
  * C5): the loop of Sampler.sample (sampler.py:932-1212) with a
- * proposal queue of `queue_size` rwalk walkers per run (sampler.py:676-778),
+ * proposal queue of `queue_size` rwalk / rslice / slice walkers per run
+ * (sampler.py:676-778; tune / tune_slice once per fill),
  * unit-cube start, MultiEllipsoid (bound_multi=1) or Ellipsoid bound rebuilt
  * every walks*nlive calls and enlarged by `enlarge`, RWalkSampler.tune, evidence
  * integration (utils.py:1470-1492) and the final live points -- all on the
@@ -256,7 +257,8 @@ int dh_bound_draw(dh_ctx* ctx, const uint64_t* state4, int nsamp, int d, int m,
  * h, nbound, status (0 ok, 1 max_fills hit, -1 failed), eff%}.
  * dead_logl_out (optional): runs x max_iter dead-point log-likelihoods. */
 int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim,
-                   int queue_size, int walks, int bound_multi, double dlogz,
+                   int queue_size, int sampler /* 0 rwalk, 1 rslice, 2 slice */,
+                   int walks /* or slices */, int bound_multi, double dlogz,
                    double enlarge, int64_t max_fills, int64_t max_iter,
                    const uint32_t* entropy_words, int n_words, uint32_t first_run,
                    double* records, double* dead_logl_out, int64_t* n_fills_out);

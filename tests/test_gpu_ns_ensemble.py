@@ -32,6 +32,21 @@ def test_ensemble_logz(ctx, pname, bound, nlive, K, walks):
     assert 0.4 < lz.std(ddof=1) / r["logzerr"].mean() < 2.5
 
 
+@pytest.mark.parametrize("pname,sample,slices,nlive,K", [
+    ("G5", "rslice", 5, 400, 64), ("G5", "slice", 3, 400, 64),
+    ("C3", "rslice", 5, 1000, 256)])
+def test_ensemble_slice_samplers(ctx, pname, sample, slices, nlive, K):
+    """BASELINE config C3 shape (eggbox, multi/rslice) and the slice samplers in
+    the device-resident loop (tune_slice, per-run doubling flag)."""
+    prob = inputs.problem(pname)
+    r = ctx.ns_ensemble(prob, 16, nlive, K, bound="multi", sample=sample,
+                        slices=slices, entropy=[11], dlogz=0.05)
+    assert np.all(r["status"] == 0)
+    lz = r["logz"]
+    se = lz.std(ddof=1) / np.sqrt(len(lz))
+    assert abs(lz.mean() - prob.logz_truth) < 5 * se + 0.08, (lz.mean(), se)
+
+
 def test_deterministic_and_sharding_independent(ctx):
     prob = inputs.problem("G5")
     kw = dict(nlive=200, queue_size=64, walks=20, bound="multi",
