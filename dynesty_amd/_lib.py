@@ -89,7 +89,7 @@ SIGNATURES = {
                                _vp, _vp]),
     "dh_ns_ensemble": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _dbl, _dbl,
                             C.c_int64, C.c_int64, _vp, _i, _u32, _vp, _vp,
-                            _vp]),
+                            _vp, _vp]),
     "dh_bound_draw": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp,
                            _vp, _vp, _vp]),
 }
@@ -472,13 +472,14 @@ class Context:
         words = entropy_words(entropy)
         rec = np.empty((runs, 8))
         dead = np.empty((runs, max_iter)) if want_dead_logl else None
+        livel = np.empty((runs, nlive)) if want_dead_logl else None
         nf = C.c_int64(0)
         self._check(self.lib.dh_ns_ensemble(
             self.handle, self.problem(prob), int(runs), int(nlive), nd,
             int(queue_size), kind, int(walks), 1 if bound == 'multi' else 0,
             float(dlogz), float(enlarge), int(max_fills), int(max_iter),
             _ptr(words), words.size, int(first_run), _ptr(rec), _ptr(dead),
-            C.byref(nf)))
+            _ptr(livel), C.byref(nf)))
         out = dict(logz=rec[:, 0], logzerr=rec[:, 1],
                    niter=rec[:, 2].astype(np.int64),
                    ncall=rec[:, 3].astype(np.int64), h=rec[:, 4],
@@ -487,6 +488,7 @@ class Context:
                    nfills=nf.value)
         if want_dead_logl:
             out["dead_logl"] = dead
+            out["live_logl"] = livel
         return out
 
     def bound_draw(self, state4, nsamp, ctrs, axes, ams=None, logvol_ells=None,

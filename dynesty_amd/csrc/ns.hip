@@ -33,6 +33,7 @@ struct NsRun {
   long long it, ncall, ncall_last_update;
   int mode, need_rebuild, nbound, nfill;
   int acc, rej, doubling, pad1;
+  double logzvar;
   uint64_t rng[4];
 };
 
@@ -92,15 +93,17 @@ __device__ __forceinline__ double logaddexp_dev(double x, double y) {
 }
 
 // progress_integration (utils.py:1470-1492), one dead point
-__device__ __forceinline__ void integrate_step(double& logz, double& h, double lprev, double lnew,
-                                               double logvol, double dlv) {
+__device__ __forceinline__ void integrate_step(double& logz, double& h, double& logzvar, double lprev,
+                                               double lnew, double logvol, double dlv) {
   const double logdvol = logvol + log(0.5 * expm1(dlv));
   const double logwt = logaddexp_dev(lnew, lprev) + logdvol;
   const double logz_new = logaddexp_dev(logz, logwt);
   const double t0 = exp(lprev - logz_new + logdvol), t1 = exp(lnew - logz_new + logdvol);
   const double lzterm = (t0 > 0.0 ? t0 * lprev : 0.0) + (t1 > 0.0 ? t1 * lnew : 0.0);
   const double w = exp(logz - logz_new);
-  h = lzterm + (w > 0.0 ? w * (h + logz) : 0.0) - logz_new;
+  const double h_new = lzterm + (w > 0.0 ? w * (h + logz) : 0.0) - logz_new;
+  logzvar += (h_new - h) * dlv;  // logzvar_new = logzvar + dh * dlogvol
+  h = h_new;
   logz = logz_new;
 }
 
@@ -133,6 +136,7 @@ __global__ void __launch_bounds__(kT)
     r.nbound = 0;
     r.nfill = 0;
     r.acc = r.rej = r.doubling = r.pad1 = 0;
+    r.logzvar = 0.0;
     Pcg64 g;
     seed_from_child(g, entropy, nwords, 0x80000000u + first_run + (uint32_t)run);
     g.store(r.rng);
@@ -337,6 +341,7 @@ __global__ void __launch_bounds__(kT) ns_consume(NsArgs a) {
   }
   if (t == 0) {
     double logvol = r.logvol, logz = r.logz, h = r.h, lmax = r.lmax, dead_prev = r.dead_prev;
+    double logzvar = r.logzvar;
     long long it = r.it, ncall = r.ncall;
     const double dlv = log(((double)N + 1.0) / (double)N);
     int ndead = 0, done = 0;
@@ -351,7 +356,7 @@ __global__ void __launch_bounds__(kT) ns_consume(NsArgs a) {
         break;
       }
       logvol -= dlv;
-      integrate_step(logz, h, dead_prev, cur, logvol, dlv);
+      integrate_step(logz, h, logzvar, dead_prev, cur, logvol, dlv);
       dead_prev = cur;
       a.dead_logl[(size_t)run * a.cap + it] = cur;
       dslot[ndead] = s;
@@ -384,6 +389,7 @@ __global__ void __launch_bounds__(kT) ns_consume(NsArgs a) {
     r.logvol = logvol;
     r.logz = logz;
     r.h = h;
+    r.logzvar = logzvar;
     r.lmax = lmax;
     r.dead_prev = dead_prev;
     misc[2] = (int)r.it;  // first death index of this fill
@@ -452,7 +458,7 @@ __global__ void __launch_bounds__(kT) ns_finish(NsArgs a) {
   __syncthreads();
   if (t == 0) {
     NsRun& r = a.st[run];
-    double logz = r.logz, h = r.h, prev = r.dead_prev;
+    double logz = r.logz, h = r.h, prev = r.dead_prev, logzvar = r.logzvar;
     const double lv0 = r.logvol;
     double lvprev = lv0;
     int n = N;
@@ -472,13 +478,13 @@ __global__ void __launch_bounds__(kT) ns_finish(NsArgs a) {
       }
       if (n > 0) key[p] = last;
       const double lv = lv0 + log(1.0 - (double)i / ((double)N + 1.0));
-      integrate_step(logz, h, prev, cur, lv, lvprev - lv);
+      integrate_step(logz, h, logzvar, prev, cur, lv, lvprev - lv);
       prev = cur;
       lvprev = lv;
     }
     double* rec = a.records + (size_t)run * 8;
     rec[0] = logz;
-    rec[1] = sqrt(fmax(h, 0.0) / (double)N);
+    rec[1] = sqrt(fabs(logzvar));
     rec[2] = (double)r.it;
     rec[3] = (double)r.ncall;
     rec[4] = h;
@@ -495,7 +501,7 @@ extern "C" {
 int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int queue_size, int sampler,
                    int walks, int bound_multi, double dlogz, double enlarge, int64_t max_fills, int64_t max_iter,
                    const uint32_t* entropy_words, int n_words, uint32_t first_run, double* records,
-                   double* dead_logl_out, int64_t* n_fills_out) {
+                   double* dead_logl_out, double* live_logl_out, int64_t* n_fills_out) {
   DH_CHECK_CTX(ctx);
   ProblemDev pd;
   if (!get_problem(ctx, problem, &pd)) return DH_ERR_ARG;
@@ -655,6 +661,10 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
                 "D2H dead"))
       return cleanup(DH_ERR_HIP);
   }
+  if (live_logl_out &&
+      !hip_ok(ctx, hipMemcpyAsync(live_logl_out, a.live_logl, (size_t)R * N * 8, hipMemcpyDeviceToHost, s),
+              "D2H live"))
+    return cleanup(DH_ERR_HIP);
   if (n_fills_out) *n_fills_out = fill;
   return cleanup(DH_OK);
 }

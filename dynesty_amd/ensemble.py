@@ -135,6 +135,36 @@ def run_ensemble_device(prob, total_runs, base_seed=21, world=1, rank=0,
                           device=device)
 
 
+def merge_logz(dead_logl, niter, live_logl):
+    """Combine R static runs into ONE run with R*nlive live points and return
+    (logz, logzerr) of the merged run -- the evidence part of the reference's
+    utils.merge_runs / _merge_two (utils.py:1817-1900, 2000-2226) for runs of
+    equal, constant nlive.  Every point (dead points, then each run's final
+    live points in ascending order) is given the number of live points its own
+    run had when it died (N for dead points, N, N-1, ..., 1 for the final
+    ones); the merged sequence is ordered by log-likelihood and each point
+    shrinks the prior volume by n/(n+1) with n the summed live count."""
+    dead_logl = np.asarray(dead_logl)
+    live_logl = np.asarray(live_logl)
+    R, N = live_logl.shape
+    ls, ns = [], []
+    for r in range(R):
+        d = dead_logl[r, :int(niter[r])]
+        fl = np.sort(live_logl[r])
+        ls.append(np.concatenate([d, fl]))
+        # change of this run's live count AFTER each of its points dies
+        ns.append(np.concatenate([np.zeros(len(d)), -np.ones(N)]))
+    logl = np.concatenate(ls)
+    dn = np.concatenate(ns)
+    order = np.argsort(logl, kind="stable")
+    logl, dn = logl[order], dn[order]
+    nlive_at = R * N + np.concatenate([[0.], np.cumsum(dn)[:-1]])
+    logvol = -np.cumsum(np.log((nlive_at + 1.) / nlive_at))
+    from .nested import _integrate
+    logwt, logz, h, logzvar = _integrate(logl, logvol)
+    return float(logz[-1]), float(np.sqrt(logzvar))
+
+
 def combine_logz(table):
     """Ensemble estimate: mean of ln Z over runs and its standard error."""
     lz = table[:, RECORD_FIELDS.index("logz")]

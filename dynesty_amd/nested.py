@@ -47,14 +47,18 @@ def _integrate(logl, logvol):
     logdvol = vpad[:-1] + np.log1p(-np.exp(vpad[1:] - vpad[:-1])) + math.log(.5)
     logwt = np.logaddexp(lpad[1:], lpad[:-1]) + logdvol
     logz = np.logaddexp.accumulate(logwt)
-    # information H (for the logz error estimate sqrt(H/N))
+    # information H and var[ln Z] = |sum dH * dlnX| (utils.py:1451-1466)
     lz = logz[-1]
     w0 = np.exp(lpad[:-1] - lz + logdvol)
     w1 = np.exp(lpad[1:] - lz + logdvol)
     with np.errstate(invalid='ignore'):
-        h = np.nansum(w0 * np.where(w0 > 0, lpad[:-1], 0.) +
-                      w1 * np.where(w1 > 0, lpad[1:], 0.)) - lz
-    return logwt, logz, float(h)
+        part = np.cumsum(np.where(w0 > 0, w0 * lpad[:-1], 0.) +
+                         np.where(w1 > 0, w1 * lpad[1:], 0.))
+    saved_h = part - lz * np.exp(logz - lz)
+    dh = np.diff(saved_h, prepend=0)
+    dlogvol = -np.diff(vpad)
+    logzvar = float(np.abs(np.sum(dh * dlogvol)))
+    return logwt, logz, float(saved_h[-1]), logzvar
 
 
 def run_static(prob, nlive=500, bound='multi', sample='rwalk', queue_size=None,
@@ -215,9 +219,9 @@ def run_static(prob, nlive=500, bound='multi', sample='rwalk', queue_size=None,
     all_logl = np.concatenate([dead_logl, live_logl[order]])
     all_logvol = np.concatenate([dead_logvol, lv_live])
     all_u = np.concatenate([np.array(dead_u).reshape(-1, nd), live_u[order]])
-    logwt, logz_arr, h = _integrate(all_logl, all_logvol)
+    logwt, logz_arr, h, logzvar = _integrate(all_logl, all_logvol)
     return RunResult(logz=float(logz_arr[-1]),
-                     logzerr=math.sqrt(max(h, 0.) / nlive), niter=it,
+                     logzerr=math.sqrt(logzvar), niter=it,
                      ncall=ncall, h=h, nbound=nbound, samples_u=all_u,
                      samples_logl=all_logl, logwt=logwt, scale=scale,
                      eff=100. * it / ncall)

@@ -255,13 +255,16 @@ int dh_bound_draw(dh_ctx* ctx, const uint64_t* state4, int nsamp, int d, int m,
  * SeedSequence(entropy) children keyed on first_run + r (independent of how the
  * ensemble is sharded).  records: runs x 8 doubles {logz, logzerr, niter, ncall,
  * h, nbound, status (0 ok, 1 max_fills hit, -1 failed), eff%}.
- * dead_logl_out (optional): runs x max_iter dead-point log-likelihoods. */
+ * dead_logl_out (optional): runs x max_iter dead-point log-likelihoods;
+ * live_logl_out (optional): runs x nlive log-likelihoods of the final live points
+ * (together they are what utils.merge_runs needs to combine the ensemble). */
 int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim,
                    int queue_size, int sampler /* 0 rwalk, 1 rslice, 2 slice */,
                    int walks /* or slices */, int bound_multi, double dlogz,
                    double enlarge, int64_t max_fills, int64_t max_iter,
                    const uint32_t* entropy_words, int n_words, uint32_t first_run,
-                   double* records, double* dead_logl_out, int64_t* n_fills_out);
+                   double* records, double* dead_logl_out, double* live_logl_out,
+                   int64_t* n_fills_out);
 
 #ifdef __cplusplus
 }

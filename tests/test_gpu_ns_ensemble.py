@@ -72,3 +72,18 @@ def test_dead_points_ordered(ctx):
         n = int(r["niter"][i])
         d = r["dead_logl"][i, :n]
         assert np.all(np.diff(d) >= 0)  # worst-first: non-decreasing
+
+
+def test_merge_runs_logz(ctx):
+    """Ensemble combiner (the evidence part of utils.merge_runs): 16 runs of 200
+    live points merged into one 3200-point run."""
+    from dynesty_amd import ensemble
+    prob = inputs.problem("G5")
+    r = ctx.ns_ensemble(prob, 16, 200, 64, walks=25, bound="multi",
+                        entropy=[13], dlogz=0.01, max_iter=50000,
+                        want_dead_logl=True)
+    lz, err = ensemble.merge_logz(r["dead_logl"], r["niter"], r["live_logl"])
+    # merged estimate: much tighter than a single run, consistent with the mean
+    assert err < 0.6 * r["logzerr"].mean()
+    assert abs(lz - prob.logz_truth) < 5 * err + 0.1
+    assert abs(lz - r["logz"].mean()) < 0.15

@@ -92,6 +92,53 @@ __global__ void __launch_bounds__(64) kL(const double* __restrict__ MT, const do
   for (int i = 0; i < N; ++i) out[(size_t)blockIdx.x * N * 64 + i * 64 + lane] = acc[i];
 }
 
+// explicit double-buffered scalar loads (inline asm: the compiler cannot sink them)
+typedef double d8v __attribute__((ext_vector_type(8)));
+typedef double d4v __attribute__((ext_vector_type(4)));
+struct Half { d8v a; d4v b; double c; };   // 13 doubles = 26 SGPRs
+__device__ __forceinline__ void load_half(Half& h, const double* p) {
+  asm volatile("s_load_dwordx16 %0, %3, 0x0\n\ts_load_dwordx8 %1, %3, 0x40\n\ts_load_dwordx2 %2, %3, 0x60"
+               : "=&s"(h.a), "=&s"(h.b), "=&s"(h.c) : "s"(p));
+}
+__device__ __forceinline__ void wait_half(Half& h) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(h.a), "+s"(h.b), "+s"(h.c));
+}
+__device__ __forceinline__ void fma_half(const Half& h, double d, double* acc) {
+  acc[0] = fma(h.a[0], d, acc[0]); acc[1] = fma(h.a[1], d, acc[1]); acc[2] = fma(h.a[2], d, acc[2]);
+  acc[3] = fma(h.a[3], d, acc[3]); acc[4] = fma(h.a[4], d, acc[4]); acc[5] = fma(h.a[5], d, acc[5]);
+  acc[6] = fma(h.a[6], d, acc[6]); acc[7] = fma(h.a[7], d, acc[7]); acc[8] = fma(h.b[0], d, acc[8]);
+  acc[9] = fma(h.b[1], d, acc[9]); acc[10] = fma(h.b[2], d, acc[10]); acc[11] = fma(h.b[3], d, acc[11]);
+  acc[12] = fma(h.c, d, acc[12]);
+}
+__global__ void __launch_bounds__(64) kP(const double* MT, const double* __restrict__ x, double* out,
+                                         int iters) {
+  __shared__ double xs[N * 64];
+  const int lane = threadIdx.x;
+  for (int j = 0; j < N; ++j) xs[j * 64 + lane] = x[(size_t)blockIdx.x * N * 64 + j * 64 + lane];
+  __syncthreads();
+  double acc[26];
+#pragma unroll
+  for (int i = 0; i < 26; ++i) acc[i] = 0;
+  for (int it = 0; it < iters; ++it) {
+    Half h0, h1;
+    load_half(h0, MT);
+#pragma unroll 1
+    for (int j = 0; j < N; ++j) {
+      const double d = xs[j * 64 + lane];
+      wait_half(h0);                             // h0 landed; nothing else outstanding
+      load_half(h1, MT + j * NP + 13);           // flies during the 13 FMAs below
+      fma_half(h0, d, acc);
+      const int jn = j + 1 < N ? j + 1 : j;
+      wait_half(h1);
+      load_half(h0, MT + jn * NP);               // flies during the next 13 FMAs
+      fma_half(h1, d, acc + 13);
+    }
+    xs[(it % N) * 64 + lane] = acc[it % N] * 1e-3;
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i) out[(size_t)blockIdx.x * N * 64 + i * 64 + lane] = acc[i];
+}
+
 int main(int argc, char** argv) {
   int blocks = argc > 1 ? atoi(argv[1]) : 2048, iters = argc > 2 ? atoi(argv[2]) : 90;
   std::vector<double> MT(N * NP, 0.0), x((size_t)blocks * N * 64);
@@ -111,6 +158,10 @@ int main(int argc, char** argv) {
     hipEventElapsedTime(&ma, e0, e1);
     hipEventRecord(e0); kB<<<blocks, 64>>>(dM, dx, dB, iters); hipEventRecord(e1); hipEventSynchronize(e1);
     hipEventElapsedTime(&mb, e0, e1);
+    float mp;
+    hipEventRecord(e0); kP<<<blocks, 64>>>(dM, dx, dA, iters); hipEventRecord(e1); hipEventSynchronize(e1);
+    hipEventElapsedTime(&mp, e0, e1);
+    printf("asm-prefetch: %.3f ms %.2f TFLOP/s | ", mp, (double)blocks * 64 * iters * N * N * 2 / mp / 1e9);
     float ml;
     hipEventRecord(e0); kL<<<blocks, 64>>>(dM, dx, dB, iters); hipEventRecord(e1); hipEventSynchronize(e1);
     hipEventElapsedTime(&ml, e0, e1);
