@@ -65,6 +65,8 @@ SIGNATURES = {
                         _vp, _vp, _vp]),
     "dh_rebuild_batch_dev": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp,
                                   _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dh_rebuild_ragged_dev": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _vp,
+                                   _vp, _vp, _vp, _vp, _vp, _vp]),
     "dh_ell_from_cov": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "dh_scale_to_logvol": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dh_enlarge_batch_dev": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp,
@@ -320,6 +322,52 @@ class Context:
                     ams=ams[:m].copy(), axes=axes[:m].copy(),
                     axlens=axlens[:m].copy(), logvol_ells=logvols[:m].copy(),
                     labels=lop, nnodes=nnodes.value)
+
+    def rebuild_many(self, point_sets, multi=True):
+        """One launch for several point sets of different sizes (bootstrap
+        replicas): returns a list of rebuild() dicts."""
+        sets = [_f64(p) for p in point_sets]
+        B = len(sets)
+        d = sets[0].shape[1]
+        n_arr = np.array([len(p) for p in sets], dtype=np.int32)
+        n_max = int(n_arr.max())
+        pad = np.zeros((B, n_max, d))
+        for i, p in enumerate(sets):
+            pad[i, :len(p)] = p
+        me = max(1, n_max // (2 * d)) if multi else 1
+        d_pts = self.to_device(pad)
+        d_n = self.to_device(n_arr)
+        sizes = dict(nells=B * 4, status=B * 4, ctrs=B * me * d * 8,
+                     covs=B * me * d * d * 8, ams=B * me * d * d * 8,
+                     axes=B * me * d * d * 8, axl=B * me * d * 8, lv=B * me * 8)
+        buf = {k: self.malloc(v) for k, v in sizes.items()}
+        try:
+            self._check(self.lib.dh_rebuild_ragged_dev(
+                self.handle, B, d_pts, n_max, d_n, d, 0 if multi else 1, me,
+                buf["nells"], buf["status"], buf["ctrs"], buf["covs"],
+                buf["ams"], buf["axes"], buf["axl"], buf["lv"]))
+            nells = self.from_device(buf["nells"], (B,), np.int32)
+            status = self.from_device(buf["status"], (B,), np.int32)
+            ctrs = self.from_device(buf["ctrs"], (B, me, d), np.float64)
+            covs = self.from_device(buf["covs"], (B, me, d, d), np.float64)
+            ams = self.from_device(buf["ams"], (B, me, d, d), np.float64)
+            axes = self.from_device(buf["axes"], (B, me, d, d), np.float64)
+            axl = self.from_device(buf["axl"], (B, me, d), np.float64)
+            lv = self.from_device(buf["lv"], (B, me), np.float64)
+        finally:
+            for p in list(buf.values()) + [d_pts, d_n]:
+                self.free(p)
+        out = []
+        for i in range(B):
+            if status[i] != 0:
+                self.lib.dh_last_error(self.handle)
+                raise RuntimeError(f"bootstrap replica {i}: rebuild failed "
+                                   f"with code {int(status[i])}")
+            m = int(nells[i])
+            out.append(dict(nells=m, ctrs=ctrs[i, :m], covs=covs[i, :m],
+                            ams=ams[i, :m], axes=axes[i, :m],
+                            axlens=axl[i, :m], logvol_ells=lv[i, :m]))
+        return out
 
     def ell_from_cov(self, covs):
         """Ellipsoid.__init__ numerics for a stack of covariances."""

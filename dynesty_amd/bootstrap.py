@@ -36,7 +36,19 @@ def expand_one(multi, points, seed):
 
 def bootstrap_expand(points, rstate, bootstrap, multi, pool=None):
     """max over `bootstrap` replicas (bounding.py:381-400 / 688-703); seeds as
-    utils.get_seed_sequence (utils.py:1002-1009)."""
+    utils.get_seed_sequence (utils.py:1002-1009).  All replicas are rebuilt by
+    ONE ragged batched launch when the backend offers it."""
     seeds = np.random.SeedSequence(rstate.integers(0, 2**63 - 1,
                                                    size=4)).spawn(bootstrap)
-    return max(expand_one(multi, points, s) for s in seeds)
+    be = get_backend()
+    if not hasattr(be, "rebuild_many"):
+        return max(expand_one(multi, points, s) for s in seeds)
+    splits = [_split(points, s) for s in seeds]
+    results = be.rebuild_many([np.ascontiguousarray(pin) for pin, _ in splits],
+                              multi=multi)
+    expand = 1.
+    for (pin, pout), res in zip(splits, results):
+        _, _, quad = be.contains(np.ascontiguousarray(pout), res["ctrs"],
+                                 res["ams"], mode=0, want_quad=True)
+        expand = max(expand, float(np.sqrt(quad.min(axis=1)).max()))
+    return expand

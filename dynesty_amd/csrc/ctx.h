@@ -107,7 +107,7 @@ int unif_launch_runs(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, int m
 int rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int d, int mode, int max_ells,
                         int32_t* nells, int32_t* status, double* ctrs, double* covs, double* ams,
                         double* axes, double* axlens, double* logvols, int32_t* leaf_of_point,
-                        int32_t* nnodes, const int* active);
+                        int32_t* nnodes, const int* active, const int* n_arr);
 int rebuild_launch_masked(dh_ctx* ctx, int runs, const double* pts, int n, int d, int mode, int max_ells,
                           int32_t* nells, int32_t* status, double* ctrs, double* covs, double* ams,
                           double* axes, double* axlens, double* logvols, const int* active);

@@ -74,6 +74,7 @@ struct RebuildArgs {
   double* scale_g;    // runs x d
   double* pts_scaled; // runs x n x d : points / root std, written once by k_root (k-means input)
   const int* active;  // runs or null: only runs with active[run] != 0 are rebuilt
+  const int* n_arr;   // runs or null: per-run point count (<= n; rows beyond it are padding)
 };
 
 #ifdef DH_REBUILD_TIMING
@@ -944,7 +945,8 @@ __device__ __forceinline__ void set_status(const RebuildArgs& a, int run, int rc
 
 __global__ void __launch_bounds__(kThreads) k_root(RebuildArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int D = a.d, n = a.n, t = threadIdx.x, run = blockIdx.x;
+  const int D = a.d, t = threadIdx.x, run = blockIdx.x;
+  const int n = a.n_arr ? a.n_arr[run] : a.n;
   if (a.active && !a.active[run]) return;
   Lds L;
   carve(L, smem, D);
@@ -977,7 +979,7 @@ __global__ void __launch_bounds__(kThreads) k_root(RebuildArgs a) {
     if (t < D) a.scale_g[(size_t)run * D + t] = L.scale[t];
     {
       // points / scale once (the reference divides the whole array before kmeans2, :1510)
-      double* ps = a.pts_scaled + (size_t)run * n * D;
+      double* ps = a.pts_scaled + (size_t)run * a.n * D;
       const int j = t & (L.DP - 1), p0 = t >> L.DPlog, pstep = kThreads >> L.DPlog;
       if (j < D) {
         const double sj = L.scale[j];
@@ -1075,7 +1077,8 @@ __global__ void __launch_bounds__(kThreads) k_ell(RebuildArgs a, int level) {
 
 __global__ void __launch_bounds__(kThreads) k_finish(RebuildArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int D = a.d, n = a.n, t = threadIdx.x, run = blockIdx.x;
+  const int D = a.d, t = threadIdx.x, run = blockIdx.x;
+  const int n = a.n_arr ? a.n_arr[run] : a.n;
   if (a.active && !a.active[run]) return;
   Lds L;
   carve(L, smem, D);
@@ -1168,7 +1171,7 @@ __global__ void __launch_bounds__(kThreads) k_finish(RebuildArgs a) {
       }
       if (t == 0) o_lv[m] = nodes[ni].logvol;
       if (a.leaf_of_point) {
-        int* lop = a.leaf_of_point + (size_t)run * n;
+        int* lop = a.leaf_of_point + (size_t)run * a.n;
         const int s0 = nodes[ni].start, c = nodes[ni].count;
         for (int p = t; p < c; p += kThreads) lop[v.perm[s0 + p]] = m;
       }
@@ -1377,7 +1380,14 @@ int dh_rebuild_batch_dev(dh_ctx* ctx, int runs, const double* pts, int n, int d,
                          double* axes, double* axlens, double* logvols, int32_t* leaf_of_point,
                          int32_t* nnodes) {
   return dh::rebuild_launch_full(ctx, runs, pts, n, d, mode, max_ells, nells, status, ctrs, covs, ams, axes,
-                                 axlens, logvols, leaf_of_point, nnodes, nullptr);
+                                 axlens, logvols, leaf_of_point, nnodes, nullptr, nullptr);
+}
+
+int dh_rebuild_ragged_dev(dh_ctx* ctx, int runs, const double* pts, int n_max, const int32_t* n_arr, int d,
+                          int mode, int max_ells, int32_t* nells, int32_t* status, double* ctrs,
+                          double* covs, double* ams, double* axes, double* axlens, double* logvols) {
+  return dh::rebuild_launch_full(ctx, runs, pts, n_max, d, mode, max_ells, nells, status, ctrs, covs, ams,
+                                 axes, axlens, logvols, nullptr, nullptr, nullptr, n_arr);
 }
 
 }  // extern "C"
@@ -1386,7 +1396,7 @@ int dh::rebuild_launch_masked(dh_ctx* ctx, int runs, const double* pts, int n, i
                               int32_t* nells, int32_t* status, double* ctrs, double* covs, double* ams,
                               double* axes, double* axlens, double* logvols, const int* active) {
   return rebuild_launch_full(ctx, runs, pts, n, d, mode, max_ells, nells, status, ctrs, covs, ams, axes,
-                             axlens, logvols, nullptr, nullptr, active);
+                             axlens, logvols, nullptr, nullptr, active, nullptr);
 }
 
 int dh::enlarge_launch_masked(dh_ctx* ctx, int runs, int max_ells, const int32_t* nells, int d, double* covs,
@@ -1402,14 +1412,14 @@ int dh::enlarge_launch_masked(dh_ctx* ctx, int runs, int max_ells, const int32_t
 int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int d, int mode, int max_ells,
                             int32_t* nells, int32_t* status, double* ctrs, double* covs, double* ams,
                             double* axes, double* axlens, double* logvols, int32_t* leaf_of_point,
-                            int32_t* nnodes, const int* active) {
+                            int32_t* nnodes, const int* active, const int* n_arr) {
   DH_CHECK_CTX(ctx);
   if (runs <= 0) return DH_OK;
   if (!pts || n < 1 || d < 1 || max_ells < 1 || (mode != 0 && mode != 1))
     return fail(ctx, DH_ERR_ARG, "rebuild: bad arguments (n=%d d=%d mode=%d)", n, d, mode);
   const size_t lds = rebuild_lds_bytes(d);
   if (lds > 159 * 1024) {
-    if (mode == 1 && !active)
+    if (mode == 1 && !active && !n_arr)
       return wide_single_launch(ctx, runs, pts, n, d, nells, status, ctrs, covs, ams, axes, axlens,
                                 logvols);
     return fail(ctx, DH_ERR_ARG,
@@ -1491,6 +1501,7 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
   a.leaf_of_point = leaf_of_point;
   a.nnodes_out = nnodes;
   a.active = active;
+  a.n_arr = n_arr;
   static size_t attr_lds = 0;
   if (lds > attr_lds) {
     const void* ks[4] = {(const void*)k_root, (const void*)k_split, (const void*)k_ell,

@@ -142,6 +142,14 @@ int dh_rebuild_batch_dev(dh_ctx* ctx, int runs, const double* pts, int n, int d,
                          double* axlens, double* logvols, int32_t* leaf_of_point,
                          int32_t* nnodes);
 
+/* Ragged batch: run r bounds the first n_arr[r] (<= n_max) rows of its
+ * n_max x d block -- the B bootstrap replicas of _ellipsoid_bootstrap_expand
+ * (bounding.py:1619-1648) in one launch. */
+int dh_rebuild_ragged_dev(dh_ctx* ctx, int runs, const double* pts, int n_max,
+                          const int32_t* n_arr, int d, int mode, int max_ells,
+                          int32_t* nells, int32_t* status, double* ctrs, double* covs,
+                          double* ams, double* axes, double* axlens, double* logvols);
+
 /* Ellipsoid.__init__(ctr, cov) (bounding.py:201-240) for m covariance matrices:
  * eigen-decomposition -> axes (ascending, sign-canonical), axlens, am, logvol.
  * DH_ERR_VALUE if an eigenvalue is not positive/finite. */

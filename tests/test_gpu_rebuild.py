@@ -172,3 +172,28 @@ def test_number_of_clusters(ctx):
     want = len(B.multi_update(pts).ells)
     assert got["nells"] == want
     assert abs(got["nells"] - len(centres)) <= 0.1 * len(centres)
+
+
+def test_ragged_batch_bootstrap(ctx, golden_bounding):
+    """All bootstrap replicas in one ragged launch (dh_rebuild_ragged_dev) and
+    the resulting expansion factors vs the reference's golden values
+    (_ellipsoid_bootstrap_expand, bounding.py:1619-1648)."""
+    from dynesty_amd import backend, bootstrap
+    g = golden_bounding
+    backend.set_backend(ctx)
+    try:
+        for name in ("g3", "two5", "c3"):
+            pts = inputs.cloud(name)
+            for multi, key in ((False, "single"), (True, "multi")):
+                seeds = np.random.SeedSequence(77).spawn(3)
+                splits = [bootstrap._split(pts, s) for s in seeds]
+                res = ctx.rebuild_many([p for p, _ in splits], multi=multi)
+                got = []
+                for (pin, pout), r in zip(splits, res):
+                    _, _, quad = ctx.contains(pout, r["ctrs"], r["ams"],
+                                              want_quad=True)
+                    got.append(max(1., float(np.sqrt(quad.min(axis=1)).max())))
+                np.testing.assert_allclose(got, g[f"{name}/boot/{key}"],
+                                           rtol=1e-8)
+    finally:
+        backend.set_backend(None)
