@@ -319,15 +319,19 @@ __device__ bool jacobi_block(double* A, double* V, int D, int LD, double* rc, do
     __syncthreads();
     if (!(off > 1e-31 * dia)) break;
     for (int r = 0; r < rounds; ++r) {
-      if (t < m) {
-        int p, q;
-        if (t == 0) {
+      // every thread derives the rotation of ITS pair kk (redundantly across the
+      // rows it serves): no serial "few threads compute, all wait" phase and one
+      // barrier less per round.  Pair kk of round r by the circle method.
+      int p = -1, q = 0;
+      double c = 1.0, sn = 0.0;
+      if (kk < m) {
+        if (kk == 0) {
           p = P - 1;
           q = r;
         } else {
-          p = r + t;
+          p = r + kk;
           if (p >= P - 1) p -= P - 1;
-          q = r - t;
+          q = r - kk;
           if (q < 0) q += P - 1;
         }
         if (p > q) {
@@ -335,7 +339,6 @@ __device__ bool jacobi_block(double* A, double* V, int D, int LD, double* rc, do
           p = q;
           q = tmp;
         }
-        double c = 1.0, sn = 0.0;
         if (q < D) {
           const double apq = A[p * LD + q];
           if (apq != 0.0) {
@@ -348,25 +351,23 @@ __device__ bool jacobi_block(double* A, double* V, int D, int LD, double* rc, do
         } else {
           p = -1;
         }
-        rc[t] = c;
-        rs[t] = sn;
-        rp[t] = p;
-        rp[64 + t] = q;
+        if (i0k == 0) {  // one writer per pair publishes it for the row phase
+          rc[kk] = c;
+          rs[kk] = sn;
+          rp[kk] = p;
+          rp[64 + kk] = q;
+        }
       }
-      __syncthreads();
+      __syncthreads();  // all rotation inputs read before any column is modified
       // columns: A <- A J, V <- V J
-      if (kk < m) {
-        const int p = rp[kk], q = rp[64 + kk];
-        if (p >= 0) {
-          const double c = rc[kk], sn = rs[kk];
-          for (int i = i0k; i < D; i += istepk) {
-            const double aip = A[i * LD + p], aiq = A[i * LD + q];
-            A[i * LD + p] = c * aip - sn * aiq;
-            A[i * LD + q] = sn * aip + c * aiq;
-            const double vip = V[i * LD + p], viq = V[i * LD + q];
-            V[i * LD + p] = c * vip - sn * viq;
-            V[i * LD + q] = sn * vip + c * viq;
-          }
+      if (kk < m && p >= 0) {
+        for (int i = i0k; i < D; i += istepk) {
+          const double aip = A[i * LD + p], aiq = A[i * LD + q];
+          A[i * LD + p] = c * aip - sn * aiq;
+          A[i * LD + q] = sn * aip + c * aiq;
+          const double vip = V[i * LD + p], viq = V[i * LD + q];
+          V[i * LD + p] = c * vip - sn * viq;
+          V[i * LD + q] = sn * vip + c * viq;
         }
       }
       __syncthreads();
