@@ -111,6 +111,13 @@ struct Lds {
   int* ri;        // 256 ints (pair indices, scan scratch, ...)
   int* perm_sort; // D
   int TP, LD, DP, DPlog;
+  double* JA[2];  // Jacobi work buffers, P x JLD (P = D rounded up to even)
+  double* JV[2];
+  int JLD;
+  bool j_alias;   // true: JA/JV overlay the tile (D too large for separate buffers)
+  // what the tile currently holds (see stage_tile)
+  mutable const double* c_pts;
+  mutable int c_start, c_cnt, c_how;
 };
 
 __device__ __forceinline__ void wave_sync() {
@@ -266,125 +273,208 @@ __device__ bool jacobi_wave(double* A, double* V, int D, int LD, double* rc, dou
   return true;
 }
 
-// Whole-workgroup form of the same solver (all kThreads threads, 3 barriers per
-// round): used inside the rebuild kernel where the eigenproblem is on the
-// critical path of every tree node.
-__device__ bool jacobi_block(double* A, double* V, int D, int LD, double* rc, double* rs, int* rp,
-                             double* red) {
+// ---- whole-workgroup Jacobi: one barrier per round ---------------------------
+// The eigenproblem sits on the critical path of every tree node, and a round of
+// the textbook formulation costs ~3000 cycles here: a dependent div/sqrt/div/
+// sqrt/div chain for (c, s), then three barrier-separated phases (rotation
+// parameters, columns, rows).  This form removes all three costs:
+//   * position-based tournament: the pair of "table" k always sits at matrix
+//     positions (2k, 2k+1); after a round the rotated rows/columns are WRITTEN to
+//     the positions the circle method moves them to, into a second buffer, so
+//     every index is loop-invariant and read/write hazards need ONE barrier;
+//   * every thread owns one 2x2 block (row pair kr, column pair kc) of A and of V
+//     and derives the two rotations it needs itself from the three entries of
+//     each pair (redundant, but no "few compute, all wait" phase);
+//   * (c, s) from two reciprocal square roots (v_rsq_f64 + Newton) and no
+//     division:  d = aqq-app, b = 2apq, h = hypot(d, b), cos(2t) = |d|/h,
+//     c = sqrt((1+cos 2t)/2), s = sign(d) b / (2 h c)   (|t| <= pi/4, the same
+//     rotation as the classical tau/t formula).
+typedef __attribute__((address_space(3))) double lds_double;
+
+__device__ __forceinline__ double rsqrt_nr(double x) {
+  // v_rsq_f64 is good to 2^-24 (measured, tools/micro/rsq_acc.hip); two Newton steps reach 2^-52
+  double y = __builtin_amdgcn_rsq(x);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const double xy = x * y;
+    const double e = fma(-xy, y, 1.0);
+    y = fma(0.5 * y, e, y);
+  }
+  return y;
+}
+
+// (c, s) of the Jacobi rotation annihilating apq.  Branch-free; the matrix is pre-scaled
+// to max|a_ij| < 1, so d^2 + b^2 cannot overflow, and a pair whose d^2 + b^2 underflows
+// is below any convergence threshold and is left alone.
+__device__ __forceinline__ void jacobi_rotation(double app, double aqq, double apq, double& c, double& s) {
+  const double d = aqq - app, b = 2.0 * apq;
+  double q = fma(d, d, b * b);
+  const bool none = (apq == 0.0) || !(q > 0.0);  // also the padding index of odd D
+  q = none ? 1.0 : q;
+  const double rh = rsqrt_nr(q);
+  const double cc = fma(0.5 * fabs(d), rh, 0.5);  // cos^2 in [1/2, 1]
+  const double rcc = rsqrt_nr(cc);
+  c = none ? 1.0 : cc * rcc;
+  s = none ? 0.0 : (d >= 0.0 ? 0.5 : -0.5) * b * rh * rcc;
+}
+
+// where the circle method moves the occupant of position `pos` (top row = even
+// positions T[k] = 2k, bottom row = odd positions B[k] = 2k+1; T[0] is fixed)
+__device__ __forceinline__ int jacobi_dest(int pos, int m) {
+  const int k = pos >> 1;
+  if (pos & 1) {
+    if (k == 0) return m > 1 ? 2 : 1;  // B[0] -> T[1]
+    return 2 * (k - 1) + 1;            // B[k] -> B[k-1]
+  }
+  if (k == 0) return 0;
+  if (k == m - 1) return 2 * (m - 1) + 1;  // T[m-1] -> B[m-1]
+  return 2 * (k + 1);                      // T[k] -> T[k+1]
+}
+
+// eigh of the symmetric D x D matrix in L.A: on return the diagonal of L.A holds
+// the (unsorted) eigenvalues and the columns of L.V the eigenvectors.  Returns
+// false if the input is not finite.  All kThreads threads.
+__device__ bool jacobi_block(const Lds& L, int D) {
   const int t = threadIdx.x;
-  const int m = (D + 1) / 2;
-  int JW = 1, JWl = 0;
-  while (JW < D) {
-    JW <<= 1;
-    ++JWl;
-  }
-  int KW = 1, KWl = 0;
-  while (KW < m) {
-    KW <<= 1;
-    ++KWl;
-  }
-  const int jj = t & (JW - 1), i0j = t >> JWl, istepj = kThreads >> JWl;
-  const int kk = t & (KW - 1), i0k = t >> KWl, istepk = kThreads >> KWl;
-  bool bad = false;
-  if (jj < D)
-    for (int i = i0j; i < D; i += istepj) {
-      V[i * LD + jj] = (i == jj) ? 1.0 : 0.0;
-      if (!isfinite(A[i * LD + jj])) bad = true;
+  const int LD = L.LD, JLD = L.JLD;
+  if (L.j_alias) L.c_pts = nullptr;  // the work buffers overlay the point tile
+  if (D == 1) {
+    bool bad1 = false;
+    if (t == 0) {
+      L.V[0] = 1.0;
+      bad1 = !isfinite(L.A[0]);
     }
+    return !__syncthreads_or(bad1 ? 1 : 0);
+  }
+  const int m = (D + 1) / 2, P = 2 * m;
+  // explicit LDS address space: through the struct the pointers are generic and the
+  // round loop would be compiled to FLAT loads (several times the ds_read latency)
+  lds_double* const ja0 = (lds_double*)L.JA[0];
+  lds_double* const ja1 = (lds_double*)L.JA[1];
+  lds_double* const jv0 = (lds_double*)L.JV[0];
+  lds_double* const jv1 = (lds_double*)L.JV[1];
+  // power-of-two pre-scaling to max|a_ij| in [1/2, 1): exact, undone on the eigenvalues
+  bool bad = false;
+  double amax = 0.0;
+  for (int e = t; e < D * D; e += kThreads) {
+    const int i = e / D, j = e - i * D;
+    const double v = L.A[i * LD + j];
+    if (!isfinite(v)) bad = true;
+    amax = fmax(amax, fabs(v));
+  }
   if (__syncthreads_or(bad ? 1 : 0)) return false;
-  if (D == 1) return true;
-  const int P = 2 * m;
-  const int rounds = P - 1;
+  amax = block_reduce_max(amax, L.red);
+  const int ex = amax > 0.0 ? ilogb(amax) + 1 : 0;
+  for (int e = t; e < P * P; e += kThreads) {
+    const int i = e / P, j = e - i * P;
+    ja0[i * JLD + j] = (i < D && j < D) ? ldexp(L.A[i * LD + j], -ex) : 0.0;
+    jv0[i * JLD + j] = (i == j && i < D) ? 1.0 : 0.0;
+  }
+  __syncthreads();
+  // block ownership: slot 0 = block t, slot 1 = block t + kThreads (m <= 22 -> m^2 <= 2 kThreads).
+  // EVERY lane derives the rotation of column pair (block index mod m) -- active block or
+  // not -- so that the 64 consecutive block indices of a wave cover all pairs and the row
+  // rotation can be fetched from a lane of the same wave (no LDS round trip, no barrier).
+  const int nslots = m * m > kThreads ? 2 : 1;
+  int ra[2], ca[2], dra[2], drb[2], dca[2], dcb[2], srcl[2];
+  bool on[2];
+#pragma unroll
+  for (int sl = 0; sl < 2; ++sl) {
+    const int blk = t + sl * kThreads;
+    on[sl] = blk < m * m;
+    const int kr = blk / m, kc = blk - kr * m;
+    const int wave_base = blk & ~63;
+    int l = (on[sl] ? kr : 0) - wave_base % m;  // lane of this wave whose column pair is kr
+    if (l < 0) l += m;
+    srcl[sl] = l;
+    ra[sl] = on[sl] ? 2 * kr : 0;
+    ca[sl] = 2 * kc;
+    dra[sl] = jacobi_dest(ra[sl], m);
+    drb[sl] = jacobi_dest(ra[sl] + 1, m);
+    dca[sl] = jacobi_dest(2 * kc, m);
+    dcb[sl] = jacobi_dest(2 * kc + 1, m);
+  }
+  int cur = 0;
+  int dpos = (D & 1) ? D : -1;  // position of the padding index (odd D)
   for (int sweep = 0; sweep < 60; ++sweep) {
+    const lds_double* Ac = cur ? ja1 : ja0;
     double off = 0.0, dia = 0.0;
-    if (jj < D)
-      for (int i = i0j; i < D; i += istepj) {
-        const double a = A[i * LD + jj];
-        if (i == jj)
-          dia = fma(a, a, dia);
-        else
-          off = fma(a, a, off);
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl)
+      if (on[sl]) {
+        const int r0 = ra[sl], c0 = ca[sl];
+        const double x00 = Ac[r0 * JLD + c0], x01 = Ac[r0 * JLD + c0 + 1];
+        const double x10 = Ac[(r0 + 1) * JLD + c0], x11 = Ac[(r0 + 1) * JLD + c0 + 1];
+        if (r0 == c0) {
+          dia = fma(x00, x00, fma(x11, x11, dia));
+          off = fma(x01, x01, fma(x10, x10, off));
+        } else {
+          off = fma(x00, x00, fma(x01, x01, fma(x10, x10, fma(x11, x11, off))));
+        }
       }
-    for (int s = 32; s > 0; s >>= 1) {
-      off += __shfl_xor(off, s);
-      dia += __shfl_xor(dia, s);
+    for (int sh = 32; sh > 0; sh >>= 1) {
+      off += __shfl_xor(off, sh);
+      dia += __shfl_xor(dia, sh);
     }
     if ((t & 63) == 0) {
-      red[t >> 6] = off;
-      red[8 + (t >> 6)] = dia;
+      L.red[t >> 6] = off;
+      L.red[8 + (t >> 6)] = dia;
     }
     __syncthreads();
-    off = red[0] + red[1] + red[2] + red[3];
-    dia = red[8] + red[9] + red[10] + red[11];
+    off = L.red[0] + L.red[1] + L.red[2] + L.red[3];
+    dia = L.red[8] + L.red[9] + L.red[10] + L.red[11];
     __syncthreads();
     if (!(off > 1e-31 * dia)) break;
-    for (int r = 0; r < rounds; ++r) {
-      // every thread derives the rotation of ITS pair kk (redundantly across the
-      // rows it serves): no serial "few threads compute, all wait" phase and one
-      // barrier less per round.  Pair kk of round r by the circle method.
-      int p = -1, q = 0;
-      double c = 1.0, sn = 0.0;
-      if (kk < m) {
-        if (kk == 0) {
-          p = P - 1;
-          q = r;
-        } else {
-          p = r + kk;
-          if (p >= P - 1) p -= P - 1;
-          q = r - kk;
-          if (q < 0) q += P - 1;
-        }
-        if (p > q) {
-          const int tmp = p;
-          p = q;
-          q = tmp;
-        }
-        if (q < D) {
-          const double apq = A[p * LD + q];
-          if (apq != 0.0) {
-            const double app = A[p * LD + p], aqq = A[q * LD + q];
-            const double tau = (aqq - app) / (2.0 * apq);
-            const double tt = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(fma(tau, tau, 1.0)));
-            c = 1.0 / sqrt(fma(tt, tt, 1.0));
-            sn = tt * c;
-          }
-        } else {
-          p = -1;
-        }
-        if (i0k == 0) {  // one writer per pair publishes it for the row phase
-          rc[kk] = c;
-          rs[kk] = sn;
-          rp[kk] = p;
-          rp[64 + kk] = q;
+    for (int r = 0; r < P - 1; ++r) {
+      const lds_double* As = cur ? ja1 : ja0;
+      const lds_double* Vs = cur ? jv1 : jv0;
+      lds_double* Ad = cur ? ja0 : ja1;
+      lds_double* Vd = cur ? jv0 : jv1;
+#pragma unroll
+      for (int sl = 0; sl < 2; ++sl) {
+        if (sl >= nslots) break;
+        const int c0 = ca[sl], c1 = c0 + 1;
+        double cc, sc;
+        jacobi_rotation(As[c0 * JLD + c0], As[c1 * JLD + c1], As[c0 * JLD + c1], cc, sc);
+        const double cr = __shfl(cc, srcl[sl]), sr = __shfl(sc, srcl[sl]);
+        if (on[sl]) {
+          const int r0 = ra[sl], r1 = r0 + 1;
+          const double x00 = As[r0 * JLD + c0], x01 = As[r0 * JLD + c1];
+          const double x10 = As[r1 * JLD + c0], x11 = As[r1 * JLD + c1];
+          const double v00 = Vs[r0 * JLD + c0], v01 = Vs[r0 * JLD + c1];
+          const double v10 = Vs[r1 * JLD + c0], v11 = Vs[r1 * JLD + c1];
+          // rows: J_r^T x ; columns: (.) J_c      J = [[c, s], [-s, c]]
+          const double y00 = cr * x00 - sr * x10, y01 = cr * x01 - sr * x11;
+          const double y10 = sr * x00 + cr * x10, y11 = sr * x01 + cr * x11;
+          double z00 = cc * y00 - sc * y01, z01 = sc * y00 + cc * y01;
+          double z10 = cc * y10 - sc * y11, z11 = sc * y10 + cc * y11;
+          if (r0 == c0) z01 = z10 = 0.0;  // the annihilated pair is exactly zero
+          Ad[dra[sl] * JLD + dca[sl]] = z00;
+          Ad[dra[sl] * JLD + dcb[sl]] = z01;
+          Ad[drb[sl] * JLD + dca[sl]] = z10;
+          Ad[drb[sl] * JLD + dcb[sl]] = z11;
+          Vd[r0 * JLD + dca[sl]] = cc * v00 - sc * v01;
+          Vd[r0 * JLD + dcb[sl]] = sc * v00 + cc * v01;
+          Vd[r1 * JLD + dca[sl]] = cc * v10 - sc * v11;
+          Vd[r1 * JLD + dcb[sl]] = sc * v10 + cc * v11;
         }
       }
-      __syncthreads();  // all rotation inputs read before any column is modified
-      // columns: A <- A J, V <- V J
-      if (kk < m && p >= 0) {
-        for (int i = i0k; i < D; i += istepk) {
-          const double aip = A[i * LD + p], aiq = A[i * LD + q];
-          A[i * LD + p] = c * aip - sn * aiq;
-          A[i * LD + q] = sn * aip + c * aiq;
-          const double vip = V[i * LD + p], viq = V[i * LD + q];
-          V[i * LD + p] = c * vip - sn * viq;
-          V[i * LD + q] = sn * vip + c * viq;
-        }
-      }
-      __syncthreads();
-      // rows: A <- J^T A ; the rotated (p,q) element is set to exactly zero
-      if (jj < D)
-        for (int k = i0j; k < m; k += istepj) {
-          const int p = rp[k], q = rp[64 + k];
-          if (p >= 0) {
-            const double c = rc[k], sn = rs[k];
-            const double apj = A[p * LD + jj], aqj = A[q * LD + jj];
-            A[p * LD + jj] = (jj == q) ? 0.0 : c * apj - sn * aqj;
-            A[q * LD + jj] = (jj == p) ? 0.0 : sn * apj + c * aqj;
-          }
-        }
+      if (dpos >= 0) dpos = jacobi_dest(dpos, m);
+      cur ^= 1;
       __syncthreads();
     }
   }
+  // copy out: position a (skipping the padding) -> column a' of L.V, diagonal of L.A
+  const lds_double* Af = cur ? ja1 : ja0;
+  const lds_double* Vf = cur ? jv1 : jv0;
+  for (int e = t; e < P * P; e += kThreads) {
+    const int i = e / P, a = e - i * P;
+    if (a == dpos || i >= D) continue;
+    const int col = a - ((dpos >= 0 && a > dpos) ? 1 : 0);
+    L.V[i * LD + col] = Vf[i * JLD + a];
+    if (i == 0) L.A[col * LD + col] = ldexp(Af[a * JLD + a], ex);
+  }
+  __syncthreads();
   return true;
 }
 
@@ -428,6 +518,13 @@ __device__ void sort_eigs_wave(const double* A, double* V, double* lam, int* ord
 
 // ---- tile staging -----------------------------------------------------------
 // tile[p][j] = f(pts[perm[start+p]][j]) for p < cnt ; f: 0 raw, 1 minus mean, 2 / scale
+//
+// The gather is latency-bound (one workgroup per CU, perm -> row -> LDS is a chain of two
+// dependent global loads), so the loads are issued in batches of kStageBatch independent
+// rows per thread before any of them is consumed.  The Lds struct remembers what the tile
+// holds: a node that fits one tile is staged ONCE per kernel and reused by the mean / cov /
+// fmax / k-means passes (raw -> centred is done in place).
+constexpr int kStageBatch = 8;
 __device__ __forceinline__ void stage_tile(const Lds& L, const double* __restrict__ pts,
                                            const int* __restrict__ perm, int start, int cnt, int D,
                                            int how) {
@@ -435,16 +532,47 @@ __device__ __forceinline__ void stage_tile(const Lds& L, const double* __restric
   // read consecutive doubles of one point (coalesced), no integer division.
   const int j = threadIdx.x & (L.DP - 1);
   const int p0 = threadIdx.x >> L.DPlog, pstep = kThreads >> L.DPlog;
+  if (L.c_pts == pts && L.c_start == start && L.c_cnt == cnt) {
+    if (L.c_how == how) return;  // the tile already holds exactly this (callers barrier after use)
+    if (L.c_how == 0 && how == 1) {
+      if (j < D) {
+        const double mj = L.mean[j];
+        for (int p = p0; p < cnt; p += pstep) L.tile[p * L.LD + j] -= mj;
+      }
+      L.c_how = 1;
+      __syncthreads();
+      return;
+    }
+  }
   if (j < D) {
     const double mj = how == 1 ? L.mean[j] : 0.0;
     const double sj = how == 2 ? L.scale[j] : 1.0;
-    for (int p = p0; p < cnt; p += pstep) {
-      double x = pts[(size_t)perm[start + p] * D + j];
-      if (how == 1) x -= mj;
-      if (how == 2) x = x / sj;
-      L.tile[p * L.LD + j] = x;
+    for (int pb = p0; pb < cnt; pb += kStageBatch * pstep) {
+      int idx[kStageBatch];
+      double x[kStageBatch];
+#pragma unroll
+      for (int k = 0; k < kStageBatch; ++k) {
+        const int p = pb + k * pstep;
+        idx[k] = p < cnt ? perm[start + p] : -1;
+      }
+#pragma unroll
+      for (int k = 0; k < kStageBatch; ++k) x[k] = idx[k] >= 0 ? pts[(size_t)idx[k] * D + j] : 0.0;
+#pragma unroll
+      for (int k = 0; k < kStageBatch; ++k) {
+        const int p = pb + k * pstep;
+        if (p < cnt) {
+          double v = x[k];
+          if (how == 1) v -= mj;
+          if (how == 2) v = v / sj;
+          L.tile[p * L.LD + j] = v;
+        }
+      }
     }
   }
+  L.c_pts = pts;
+  L.c_start = start;
+  L.c_cnt = cnt;
+  L.c_how = how;
   __syncthreads();
 }
 
@@ -498,74 +626,154 @@ __device__ void node_std(const Lds& L, const double* pts, const int* perm, int s
   __syncthreads();
 }
 
-// sample covariance (ddof=1) of a node about L.mean -> L.A (np.cov, bounding.py:1411)
+// ---- the two GEMM-shaped passes run on the fp64 matrix cores -------------------
+// v_mfma_f64_16x16x4_f64: lane l supplies A[i = l&15][k = l>>4] and B[k = l>>4][j = l&15]
+// (one double each); the 16x16 result sits 4 per lane at row = (l>>4) + 4*reg, col = l&15.
+// The point is not the FLOP rate (VALU fp64 is as fast) but operand traffic: the VALU forms
+// of these loops read two LDS operands per FMA (~1250 ds_reads per point for the quadratic
+// form), the MFMA forms read one operand pair per 1024 FMAs.
+typedef double mfma_acc __attribute__((ext_vector_type(4)));
+constexpr int kMfmaMinDim = 10;  // below this the quadratic form stays on the VALU
+#define DH_MFMA_F64(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
+
+// sample covariance (ddof=1) of a node about L.mean -> L.A (np.cov, bounding.py:1411):
+// C = Xc^T Xc.  Each wave contracts its own 64 points of every tile (K = points, 16 MFMA
+// steps of 4), upper 16x16 blocks only; the four partial sums are folded in wave order.
 __device__ void node_cov(const Lds& L, const double* pts, const int* perm, int start, int count, int D) {
-  const int t = threadIdx.x;
-  const int nent = D * (D + 1) / 2;
-  // each thread owns entries e = t, t+256, ...; at most 4 per thread kept in registers
-  // (D <= 44); larger D loops in chunks of entries.
-  for (int e0 = 0; e0 < nent; e0 += kThreads * 4) {
-    double acc[4] = {0.0, 0.0, 0.0, 0.0};
-    int ea[4], eb[4];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, LD = L.LD;
+  const int nb = (D + 15) >> 4;  // 16-wide dimension blocks: 1..3 (D <= 44)
+  const int lj = lane & 15, lk = lane >> 4;
+  mfma_acc acc[6];  // (0,0) (0,1) (1,1) (0,2) (1,2) (2,2)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int e = e0 + r * kThreads + t;
-      // unrank e -> (a <= b), row-major upper triangle
-      int a = 0, rem = e;
-      if (e < nent) {
-        // a = largest with a*D - a(a-1)/2 <= e
-        a = (int)floor(((2.0 * D + 1.0) - sqrt((2.0 * D + 1.0) * (2.0 * D + 1.0) - 8.0 * e)) * 0.5);
-        while (a > 0 && a * D - a * (a - 1) / 2 > e) --a;
-        while ((a + 1) * D - (a + 1) * a / 2 <= e) ++a;
-        rem = e - (a * D - a * (a - 1) / 2);
-      }
-      ea[r] = a;
-      eb[r] = a + rem;
-    }
-    for (int base = 0; base < count; base += L.TP) {
-      const int cnt = min(L.TP, count - base);
-      stage_tile(L, pts, perm, start + base, cnt, D, 1);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        if (e0 + r * kThreads + t < nent) {
-          const int a = ea[r], b = eb[r];
-          double s = acc[r];
-          for (int p = 0; p < cnt; ++p) s = fma(L.tile[p * L.LD + a], L.tile[p * L.LD + b], s);
-          acc[r] = s;
+  for (int b = 0; b < 6; ++b) acc[b] = (mfma_acc){0.0, 0.0, 0.0, 0.0};
+  const bool v0 = lj < D, v1 = 16 + lj < D, v2 = 32 + lj < D;
+  for (int base = 0; base < count; base += L.TP) {
+    const int cnt = min(L.TP, count - base);
+    stage_tile(L, pts, perm, start + base, cnt, D, 1);
+    const int pend = min(cnt, w * 64 + 64);
+    for (int p0 = w * 64; p0 < pend; p0 += 4) {
+      const int p = p0 + lk;
+      const bool pv = p < cnt;
+      const double* row = L.tile + p * LD + lj;
+      const double f0 = (pv && v0) ? row[0] : 0.0;
+      acc[0] = DH_MFMA_F64(f0, f0, acc[0]);
+      if (nb > 1) {
+        const double f1 = (pv && v1) ? row[16] : 0.0;
+        acc[1] = DH_MFMA_F64(f0, f1, acc[1]);
+        acc[2] = DH_MFMA_F64(f1, f1, acc[2]);
+        if (nb > 2) {
+          const double f2 = (pv && v2) ? row[32] : 0.0;
+          acc[3] = DH_MFMA_F64(f0, f2, acc[3]);
+          acc[4] = DH_MFMA_F64(f1, f2, acc[4]);
+          acc[5] = DH_MFMA_F64(f2, f2, acc[5]);
         }
       }
-      __syncthreads();
     }
-    const double inv = 1.0 / (double)(count - 1);
+    __syncthreads();
+  }
+  // fold the four wave partials into L.A in wave order (deterministic)
+  for (int wv = 0; wv < kThreads / 64; ++wv) {
+    if (w == wv) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      if (e0 + r * kThreads + t < nent) {
-        const double c = acc[r] * inv;
-        L.A[ea[r] * L.LD + eb[r]] = c;
-        L.A[eb[r] * L.LD + ea[r]] = c;
+      for (int b = 0; b < 6; ++b) {
+        const int ib = b == 0 ? 0 : b == 1 ? 0 : b == 2 ? 1 : b == 3 ? 0 : b == 4 ? 1 : 2;
+        const int jb = b == 0 ? 0 : b == 1 ? 1 : b == 2 ? 1 : 2;
+        if (jb < nb) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int i = ib * 16 + lk + 4 * r, j = jb * 16 + lj;
+            if (i < D && j < D) {
+              double v = acc[b][r];
+              if (wv > 0) v += L.A[i * LD + j];
+              L.A[i * LD + j] = v;
+            }
+          }
+        }
       }
+    }
+    __syncthreads();
+  }
+  // 1/(n-1) and mirror the upper triangle
+  const double inv = 1.0 / (double)(count - 1);
+  for (int e = t; e < D * D; e += kThreads) {
+    const int i = e / D, j = e - i * D;
+    if (i <= j) {
+      const double c = L.A[i * LD + j] * inv;
+      L.A[i * LD + j] = c;
+      L.A[j * LD + i] = c;
     }
   }
   __syncthreads();
 }
 
+// max over the staged tile of x^T AM x (AM: D x LD in LDS, symmetric; x = tile rows):
+// Z = X AM on the matrix cores (M = 16 points per block, N = dimension blocks, K = D in
+// steps of 4), then the row-wise dot Z.x and a 16-lane reduction.  Returns the per-thread
+// running maximum (callers reduce over the block).
+__device__ __forceinline__ double tile_quadform_max(const Lds& L, const double* AM, int cnt, int D, double best) {
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, LD = L.LD;
+  const int nb = (D + 15) >> 4, ksteps = (D + 3) >> 2;
+  const int lj = lane & 15, lk = lane >> 4;
+  for (int mb = w; mb * 16 < cnt; mb += kThreads / 64) {
+    const int p0 = mb * 16;
+    mfma_acc z0 = {0.0, 0.0, 0.0, 0.0}, z1 = z0, z2 = z0;
+    const bool pa = p0 + lj < cnt;
+    const double* xrow = L.tile + (p0 + lj) * LD + lk;
+    const double* brow = AM + lk * LD + lj;
+    for (int ks = 0; ks < ksteps; ++ks) {
+      const int k = ks * 4 + lk;
+      const bool kv = k < D;
+      const double a = (pa && kv) ? xrow[ks * 4] : 0.0;
+      const double b0 = (kv && lj < D) ? brow[ks * 4 * LD] : 0.0;
+      z0 = DH_MFMA_F64(a, b0, z0);
+      if (nb > 1) {
+        const double b1 = (kv && 16 + lj < D) ? brow[ks * 4 * LD + 16] : 0.0;
+        z1 = DH_MFMA_F64(a, b1, z1);
+        if (nb > 2) {
+          const double b2 = (kv && 32 + lj < D) ? brow[ks * 4 * LD + 32] : 0.0;
+          z2 = DH_MFMA_F64(a, b2, z2);
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int p = p0 + lk + 4 * r;
+      const bool pv = p < cnt;
+      const double* x = L.tile + p * LD + lj;
+      double sacc = (pv && lj < D) ? z0[r] * x[0] : 0.0;
+      if (nb > 1 && pv && 16 + lj < D) sacc = fma(z1[r], x[16], sacc);
+      if (nb > 2 && pv && 32 + lj < D) sacc = fma(z2[r], x[32], sacc);
+      sacc += __shfl_xor(sacc, 1);
+      sacc += __shfl_xor(sacc, 2);
+      sacc += __shfl_xor(sacc, 4);
+      sacc += __shfl_xor(sacc, 8);
+      if (pv) best = fmax(best, sacc);
+    }
+  }
+  return best;
+}
+
 // max_i delta_i^T AM delta_i over a node (bounding.py:1438), delta about L.mean
 __device__ double node_fmax(const Lds& L, const double* pts, const int* perm, int start, int count, int D) {
-  const int t = threadIdx.x;
   double best = -INFINITY;
   for (int base = 0; base < count; base += L.TP) {
     const int cnt = min(L.TP, count - base);
     stage_tile(L, pts, perm, start + base, cnt, D, 1);
-    for (int p = t; p < cnt; p += kThreads) {
-      const double* x = L.tile + p * L.LD;
-      double q = 0.0;
-      for (int i = 0; i < D; ++i) {
-        double r = 0.0;
-        const double* row = L.AM + i * L.LD;
-        for (int j = 0; j < D; ++j) r = fma(row[j], x[j], r);
-        q = fma(x[i], r, q);
+    if (D >= kMfmaMinDim) {
+      best = tile_quadform_max(L, L.AM, cnt, D, best);
+    } else {
+      // small D: a point's D^2 FMAs are cheaper than the 16-lane reductions of the MFMA form
+      for (int p = threadIdx.x; p < cnt; p += kThreads) {
+        const double* x = L.tile + p * L.LD;
+        double q = 0.0;
+        for (int i = 0; i < D; ++i) {
+          double r = 0.0;
+          const double* row = L.AM + i * L.LD;
+          for (int j = 0; j < D; ++j) r = fma(row[j], x[j], r);
+          q = fma(x[i], r, q);
+        }
+        best = fmax(best, q);
       }
-      best = fmax(best, q);
     }
     __syncthreads();
   }
@@ -595,14 +803,18 @@ __device__ bool regularize(const Lds& L, double* cov, int D) {
   const int t = threadIdx.x;
   int failed = 0;
   int trial = 0;
+  PH_T0();
   for (trial = 0; trial < kNTries; ++trial) {
     failed = 0;
     // eigh(cov): copy into A, solve with wave 0
     for (int e = t; e < D * D; e += kThreads) L.A[(e / D) * L.LD + e % D] = cov[(e / D) * L.LD + e % D];
     __syncthreads();
-    const bool fin = jacobi_block(L.A, L.V, D, L.LD, L.rc, L.rs, L.ri, L.red);
+    PH_ADD(8);
+    const bool fin = jacobi_block(L, D);
+    PH_ADD(6);
     if (fin && t < 64) sort_eigs_wave(L.A, L.V, L.lam, L.perm_sort, L.AX, D, L.LD);
     __syncthreads();
+    PH_ADD(7);
     double top = -INFINITY, bot = INFINITY;
     bool allfin = fin;
     if (fin) {
@@ -659,7 +871,9 @@ __device__ bool regularize(const Lds& L, double* cov, int D) {
     __syncthreads();
     return false;  // trial == ntries-1 != 0
   }
+  PH_ADD(8);
   mat_from_eig(L, L.AM, L.lam, D, true);
+  PH_ADD(9);
   return trial == 0;
 }
 
@@ -873,9 +1087,22 @@ __device__ __forceinline__ double logaddexp_d(double x, double y) {
 // All nodes of a level -- of every run -- are processed concurrently, so a
 // single run is no longer confined to one CU and nothing returns to the host.
 
+// LDS without the Jacobi work buffers (16-byte multiple); they follow at this offset
+// when everything fits kLdsLimit, else they overlay the point tile.
+constexpr size_t kLdsLimit = 159 * 1024;
+// separate Jacobi buffers only while two workgroups still fit one CU's 160 KB
+constexpr size_t kLdsSeparate = 79 * 1024;
+__host__ __device__ inline size_t rebuild_lds_base_bytes(int D) {
+  const int LD = D | 1;
+  const size_t dbl = (size_t)kThreads * LD + 4 * (size_t)D * LD + 7 * (size_t)D + kThreads + 128;
+  return (dbl * 8 + (320 + (size_t)D + 8) * 4 + 15) & ~(size_t)15;
+}
+
 __device__ __forceinline__ void carve(Lds& L, unsigned char* smem, int D) {
   L.LD = D | 1;  // odd leading dimension: conflict-free column walks
   L.TP = kThreads;
+  L.c_pts = nullptr;
+  L.c_start = L.c_cnt = L.c_how = -1;
   L.DP = 1;
   L.DPlog = 0;
   while (L.DP < D) {
@@ -911,6 +1138,15 @@ __device__ __forceinline__ void carve(Lds& L, unsigned char* smem, int D) {
   p += 64;
   L.ri = (int*)p;
   L.perm_sort = L.ri + 320;
+  const int P = (D + 1) & ~1;
+  L.JLD = P | 1;
+  const size_t jdbl = 4 * (size_t)P * L.JLD;
+  L.j_alias = rebuild_lds_base_bytes(D) + jdbl * 8 > kLdsSeparate;
+  double* jb = L.j_alias ? L.tile : (double*)(smem + rebuild_lds_base_bytes(D));
+  L.JA[0] = jb;
+  L.JA[1] = jb + (size_t)P * L.JLD;
+  L.JV[0] = jb + 2 * (size_t)P * L.JLD;
+  L.JV[1] = jb + 3 * (size_t)P * L.JLD;
 }
 
 struct RunView {
@@ -1356,9 +1592,10 @@ __global__ void __launch_bounds__(64)
 }
 
 size_t rebuild_lds_bytes(int D) {
-  const int LD = D | 1;
-  size_t dbl = (size_t)kThreads * LD + 4 * (size_t)D * LD + 7 * (size_t)D + kThreads + 128;
-  return dbl * 8 + (320 + (size_t)D + 8) * 4;
+  const size_t base = rebuild_lds_base_bytes(D);
+  const int P = (D + 1) & ~1;
+  const size_t jb = 4 * (size_t)P * (P | 1) * 8;
+  return base + jb > kLdsSeparate ? base : base + jb;  // else the Jacobi buffers overlay the tile
 }
 
 }  // namespace
@@ -1419,7 +1656,7 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
   if (!pts || n < 1 || d < 1 || max_ells < 1 || (mode != 0 && mode != 1))
     return fail(ctx, DH_ERR_ARG, "rebuild: bad arguments (n=%d d=%d mode=%d)", n, d, mode);
   const size_t lds = rebuild_lds_bytes(d);
-  if (lds > 159 * 1024) {
+  if (lds > kLdsLimit) {
     if (mode == 1 && !active && !n_arr)
       return wide_single_launch(ctx, runs, pts, n, d, nells, status, ctrs, covs, ams, axes, axlens,
                                 logvols);

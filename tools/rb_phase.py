@@ -4,7 +4,7 @@ sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests')
 import inputs
 from dynesty_amd import _lib
 ctx=_lib.Context(0)
-names=["mean","cov","regularize(eig)","fmax","kmeans","partition"]
+names=["mean","cov","regularize(all)","fmax","kmeans","partition","  jacobi","  sort_eigs","  copy/axes","  am"]
 for cloud,multi in (("c2",True),("c2",False),("c3",True)):
     pts=inputs.cloud(cloud)
     ctx.rebuild(pts,multi=multi)
@@ -12,5 +12,5 @@ for cloud,multi in (("c2",True),("c2",False),("c3",True)):
     ctx.lib.dh_rebuild_timing(out,1)
     ctx.rebuild(pts,multi=multi)
     ctx.lib.dh_rebuild_timing(out,1)
-    tot=sum(out)
+    tot=sum(out[:6])
     print(cloud,"multi" if multi else "single",{n:f"{out[i]/1e5:.1f}" for i,n in enumerate(names)},"total(1e5 ticks)",tot/1e5)
