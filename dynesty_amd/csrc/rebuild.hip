@@ -71,6 +71,18 @@ struct RebuildArgs {
   int* nell;          // levels x runs
   int* split_list;    // 2 x runs x maxw   (by level parity)
   int* ell_list;      // runs x 2 maxw
+  // k-means parts: a splittable node of c points is worked on by ceil(c / TP) workgroups
+  // ("parts"), each keeping its TP points resident in LDS for all ten iterations
+  int fin_extra_off;  // k_finish: byte offset of the LDS node/result-list copies (0: keep them in global memory)
+  int fin_res_lds;    // 1: the result-list arena is in LDS too
+  int ell_tp_small;   // 1: k_ell of levels >= kSmallTileLevel is launched with the small-tile LDS layout
+  int maxp;           // max parts of one run at one level: n / TP + maxw + 1
+  int* nparts;        // (levels+1) x runs
+  int* part_list;     // 2 x runs x maxp x 2   (by level parity): (slot in split_list, part index)
+  int* part_base;     // 2 x runs x maxw       first part slot of the node in split_list slot
+  int* kbar;          // levels x runs x maxw  arrive counters of the part barriers
+  int* kerr;          // runs: error raised inside k_split (folded into status by the next kernel)
+  double* kpart;      // 2 x runs x maxp x (2d + 2): per-part partial sums, by iteration parity
   double* scale_g;    // runs x d
   double* pts_scaled; // runs x n x d : points / root std, written once by k_root (k-means input)
   const int* active;  // runs or null: only runs with active[run] != 0 are rebuilt
@@ -108,6 +120,7 @@ struct Lds {
   double* red;    // kThreads
   double* rc;     // 64 (rotation c)
   double* rs;     // 64
+  double* kred;   // 4 waves x 2 clusters x 48: k-means partial sums
   int* ri;        // 256 ints (pair indices, scan scratch, ...)
   int* perm_sort; // D
   int TP, LD, DP, DPlog;
@@ -633,7 +646,12 @@ __device__ void node_std(const Lds& L, const double* pts, const int* perm, int s
 // of these loops read two LDS operands per FMA (~1250 ds_reads per point for the quadratic
 // form), the MFMA forms read one operand pair per 1024 FMAs.
 typedef double mfma_acc __attribute__((ext_vector_type(4)));
-constexpr int kMfmaMinDim = 10;  // below this the quadratic form stays on the VALU
+constexpr int kBarStride = 16;  // ints between part-barrier counters (one per 64-byte line)
+constexpr int kMfmaMinDim = 10;
+// deep levels hold small nodes: k_ell runs there with a 128-point tile so that three
+// workgroups (instead of two) share a CU and overlap their latency-bound Jacobi phases
+constexpr int kSmallTile = 128;
+constexpr int kSmallTileLevel = 3;  // below this the quadratic form stays on the VALU
 #define DH_MFMA_F64(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
 
 // sample covariance (ddof=1) of a node about L.mean -> L.A (np.cov, bounding.py:1411):
@@ -940,13 +958,59 @@ __device__ int node_ellipsoid(const Lds& L, const RebuildArgs& a, const double* 
   return DH_OK;
 }
 
-// kmeans2(points/scale, seeds/scale, iter=10, minit='matrix') on a node
-// (bounding.py:1510-1514; scipy.cluster.vq.kmeans2 loop).  Labels -> lab[].
-// Returns the size of cluster 0 (uniform).
-__device__ int node_kmeans(const Lds& L, const double* pts, const int* perm, unsigned char* lab,
-                           int start, int count, int D, const double* es) {
-  const int t = threadIdx.x;
-  const int DD = D * D;
+// ---- k-means (k = 2) + stable partition of a node, cooperatively by its parts -----------
+// kmeans2(points/scale, seeds/scale, iter=10, minit='matrix') (bounding.py:1510-1514; the
+// scipy.cluster.vq.kmeans2 loop).  A node of c points is handled by np = ceil(c / TP)
+// workgroups; part q keeps points [q TP, (q+1) TP) of the node resident in LDS for all
+// ten iterations (the old form re-gathered every tile from HBM/L2 in every iteration).
+// Per iteration a part assigns its points (same distance arithmetic as vq), reduces the
+// per-cluster sums on the matrix cores (sums = Labels^T X), publishes them, meets the
+// other parts at a device-scope barrier, and every part forms the new centroids from the
+// partials in part order (deterministic).
+
+// device-scope barrier among the np parts of one node; returns false on timeout.
+// No cache-wide release/acquire fences (an agent-scope fence writes back / invalidates the
+// whole XCD L2, and with hundreds of parts doing that 11 times each the L2 never holds
+// anything): everything the parts exchange is written with agent-scope stores (write-through)
+// and read with agent-scope loads (bypass), so the barrier only has to order, not to flush --
+// __syncthreads() drains every wave's stores (s_waitcnt vmcnt(0)) before thread 0 arrives.
+__device__ __forceinline__ bool parts_barrier(int* bar, int target) {
+  __shared__ int ok_flag;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(bar, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int ok = 1;
+    long long spins = 0;
+    while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(4);
+      if (++spins > (1ll << 20)) {  // partners never arrived (would otherwise hang the device)
+        ok = 0;
+        break;
+      }
+    }
+    ok_flag = ok;
+  }
+  __syncthreads();
+  return ok_flag != 0;
+}
+
+__device__ __forceinline__ double ld_agent(const double* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent(double* p, double v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// One part's share of the k-means + partition of node [start, start+count).  q = part
+// index, np = number of parts, kp = this node's partial-sum slots (2 parities x np x KP),
+// bar = its barrier counter.  Returns n0 (size of cluster 0) or -1 on a barrier timeout;
+// on return perm[start + q TP ...] holds the partitioned order if the split is viable.
+__device__ int node_kmeans_part(const Lds& L, const double* pts, int* perm, int* perm2, int start, int count,
+                                int D, const double* es, int q, int np, double* kp0, double* kp1, int* bar,
+                                int min_size) {
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, LD = L.LD;
+  const int DD = D * D, KP = 2 * D + 2;
+  const int s0 = start + q * L.TP, cnt = min(L.TP, count - q * L.TP);
   // seeds: major-axis endpoints ctr -/+ axes[:, argmax(axlens)] (bounding.py:278-284)
   if (t == 0) {
     int best = 0;
@@ -958,7 +1022,7 @@ __device__ int node_kmeans(const Lds& L, const double* pts, const int* perm, uns
       }
     L.ri[301] = best;
   }
-  __syncthreads();
+  stage_tile(L, pts, perm, s0, cnt, D, 0);  // pts = points / scale (pre-divided); resident from here on
   const int kbest = L.ri[301];
   if (t < D) {
     const double v = es[D + 2 * DD + t * D + kbest];
@@ -966,105 +1030,110 @@ __device__ int node_kmeans(const Lds& L, const double* pts, const int* perm, uns
     L.cen[D + t] = (es[t] + v) / L.scale[t];
   }
   __syncthreads();
-  const int G = kThreads / D > 0 ? kThreads / D : 1;
-  const int j = t % D, g = t / D;
-  int n0_last = 0;
+  const int nb = (D + 15) >> 4;
+  const int lj = lane & 15, lk = lane >> 4;
+  int lb = 0, n0 = 0, c0_tile = 0;
   for (int it = 0; it < 10; ++it) {
-    double s0 = 0.0, s1 = 0.0;
-    int myc0 = 0;
-    for (int base = 0; base < count; base += L.TP) {
-      const int cnt = min(L.TP, count - base);
-      stage_tile(L, pts, perm, start + base, cnt, D, 0);  // pts = points / scale (pre-divided)
-      // vq: nearest centroid, strict '<' so the lower index wins ties
-      for (int p = t; p < cnt; p += kThreads) {
-        const double* x = L.tile + p * L.LD;
-        double d0 = 0.0, d1 = 0.0;
-        for (int jj = 0; jj < D; ++jj) {
-          const double e0 = x[jj] - L.cen[jj], e1 = x[jj] - L.cen[D + jj];
-          d0 = fma(e0, e0, d0);
-          d1 = fma(e1, e1, d1);
-        }
-        const unsigned char lb = d1 < d0 ? 1 : 0;
-        lab[start + base + p] = lb;
-        L.ri[p] = lb;  // TP <= 256 == kThreads: one label slot per tile point
-        myc0 += lb ? 0 : 1;
+    // vq: nearest centroid, strict '<' so the lower index wins ties
+    if (t < cnt) {
+      const double* x = L.tile + t * LD;
+      double d0 = 0.0, d1 = 0.0;
+      for (int jj = 0; jj < D; ++jj) {
+        const double xv = x[jj];
+        const double e0 = xv - L.cen[jj], e1 = xv - L.cen[D + jj];
+        d0 = fma(e0, e0, d0);
+        d1 = fma(e1, e1, d1);
       }
-      __syncthreads();
-      // update_cluster_means: per-dimension sums, fixed point->group map
-      if (t < G * D) {
-        for (int p = g; p < cnt; p += G) {
-          const double x = L.tile[p * L.LD + j];
-          if (L.ri[p])
-            s1 += x;
-          else
-            s0 += x;
-        }
-      }
-      __syncthreads();
+      lb = d1 < d0 ? 1 : 0;
+      L.ri[t] = lb;
     }
-    const int c0 = block_reduce_sum_int(myc0, L.ri);
-    // reduce groups (fixed order)
-    L.red[t] = s0;
+    c0_tile = __syncthreads_count(t < cnt && lb == 0);  // also publishes the labels
+    // update_cluster_means: per-cluster sums = Labels^T X on the matrix cores; wave w
+    // contracts its 64 points (rows 0/1 of the 16-row A operand are the two indicators)
+    mfma_acc a0 = {0.0, 0.0, 0.0, 0.0}, a1 = a0, a2 = a0;
+    const int pend = min(cnt, w * 64 + 64);
+    for (int p0 = w * 64; p0 < pend; p0 += 4) {
+      const int p = p0 + lk;
+      const bool pv = p < cnt;
+      const double ind = (pv && lj < 2 && L.ri[pv ? p : 0] == lj) ? 1.0 : 0.0;
+      const double* row = L.tile + p * LD + lj;
+      a0 = DH_MFMA_F64(ind, (pv && lj < D) ? row[0] : 0.0, a0);
+      if (nb > 1) a1 = DH_MFMA_F64(ind, (pv && 16 + lj < D) ? row[16] : 0.0, a1);
+      if (nb > 2) a2 = DH_MFMA_F64(ind, (pv && 32 + lj < D) ? row[32] : 0.0, a2);
+    }
+    // result rows 0 and 1 sit in register 0 of lanes 0..15 and 16..31
+    if (lane < 32) {
+      double* o = L.kred + (w * 2 + lk) * 48;
+      o[lj] = a0[0];
+      if (nb > 1) o[16 + lj] = a1[0];
+      if (nb > 2) o[32 + lj] = a2[0];
+    }
     __syncthreads();
-    double sum0 = 0.0;
-    if (t < D)
-      for (int gg = 0; gg < G; ++gg) sum0 += L.red[gg * D + t];
+    double* kp = (it & 1) ? kp1 : kp0;
+    if (t < 2 * D) {
+      const int c = t >= D ? 1 : 0, j = t - c * D;
+      double sum = 0.0;
+      for (int wv = 0; wv < kThreads / 64; ++wv) sum += L.kred[(wv * 2 + c) * 48 + j];
+      if (np > 1) st_agent(kp + (size_t)q * KP + c * D + j, sum);
+      L.sums[c * D + j] = sum;
+    }
+    n0 = c0_tile;
+    if (np > 1) {
+      if (t == 0) st_agent(kp + (size_t)q * KP + 2 * D, (double)c0_tile);
+      if (!parts_barrier(bar, np * (it + 1))) return -1;
+      if (t < 2 * D) {
+        double sum = 0.0;
+        for (int pp = 0; pp < np; ++pp) sum += ld_agent(kp + (size_t)pp * KP + t);
+        L.sums[t] = sum;
+      }
+      double cc = 0.0;
+      for (int pp = 0; pp < np; ++pp) cc += ld_agent(kp + (size_t)pp * KP + 2 * D);
+      n0 = (int)cc;
+    }
     __syncthreads();
-    L.red[t] = s1;
-    __syncthreads();
-    double sum1 = 0.0;
-    if (t < D)
-      for (int gg = 0; gg < G; ++gg) sum1 += L.red[gg * D + t];
-    __syncthreads();
-    const int n0 = c0, n1 = count - n0;
-    n0_last = n0;
+    const int n1 = count - n0;
     if (t < D) {
-      if (n0 > 0) L.cen[t] = sum0 / (double)n0;       // empty cluster keeps its centroid
-      if (n1 > 0) L.cen[D + t] = sum1 / (double)n1;
+      if (n0 > 0) L.cen[t] = L.sums[t] / (double)n0;  // empty cluster keeps its centroid
+      if (n1 > 0) L.cen[D + t] = L.sums[D + t] / (double)n1;
     }
     __syncthreads();
   }
-  return n0_last;
-}
-
-// stable partition of perm[start, start+count) by lab: label 0 first
-__device__ void node_partition(const Lds& L, int* perm, int* perm2, const unsigned char* lab, int start,
-                               int count, int n0) {
-  const int t = threadIdx.x;
-  int run0 = 0, run1 = 0;  // running counts before this tile (uniform)
-  for (int base = 0; base < count; base += kThreads) {
-    const int p = base + t;
-    const int flag = (p < count) ? (lab[start + p] ? 0 : 1) : 0;  // 1 for label 0
-    const int live = (p < count) ? 1 : 0;
-    // inclusive scan of flag over the block (Hillis-Steele in LDS)
-    L.ri[t] = flag;
-    __syncthreads();
-    for (int s = 1; s < kThreads; s <<= 1) {
-      int v = L.ri[t];
-      if (t >= s) v += L.ri[t - s];
-      __syncthreads();
-      L.ri[t] = v;
-      __syncthreads();
-    }
-    const int incl = L.ri[t];
-    const int tile0 = L.ri[kThreads - 1];
-    __syncthreads();
-    if (live) {
-      int pos;
-      if (flag)
-        pos = run0 + incl - 1;
-      else
-        pos = n0 + run1 + (t + 1 - incl) - 1;
-      perm2[start + pos] = perm[start + p];
-    }
-    const int tile_live = min(kThreads, count - base);
-    run0 += tile0;
-    run1 += tile_live - tile0;
-    __syncthreads();
-  }
-  for (int p = t; p < count; p += kThreads) perm[start + p] = perm2[start + p];
-  __threadfence_block();
+  if (min(n0, count - n0) < min_size) return n0;  // split rejected (:1521-1522): no partition needed
+  // ---- stable partition by label (label 0 first) ----
+  // ranks inside the tile from wave ballots; offsets of this part from the partners' counts
+  const bool valid = t < cnt;
+  const unsigned long long m0 = __ballot(valid && lb == 0);
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  if (lane == 0) L.ri[256 + w] = __popcll(m0);
   __syncthreads();
+  int before0 = 0;
+  for (int wv = 0; wv < w; ++wv) before0 += L.ri[256 + wv];
+  const int rank0 = before0 + __popcll(m0 & lt);
+  int off0 = 0, off1 = n0;
+  if (np > 1) {
+    const double* kp = kp1;  // the last iteration (it = 9) used parity 1
+    for (int pp = 0; pp < q; ++pp) {
+      const int c0p = (int)ld_agent(kp + (size_t)pp * KP + 2 * D);
+      off0 += c0p;
+      off1 += L.TP - c0p;  // parts before q are full tiles
+    }
+  }
+  if (valid) {
+    const int pos = lb == 0 ? off0 + rank0 : off1 + (t - rank0);
+    if (np > 1)
+      __hip_atomic_store(perm2 + start + pos, perm[s0 + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else
+      perm2[start + pos] = perm[s0 + t];
+  }
+  if (np > 1) {
+    if (!parts_barrier(bar, np * 11)) return -1;
+    if (valid) perm[s0 + t] = __hip_atomic_load(perm2 + s0 + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+    __threadfence_block();
+    __syncthreads();
+    if (valid) perm[s0 + t] = perm2[s0 + t];
+  }
+  return n0;
 }
 
 __device__ __forceinline__ double logaddexp_d(double x, double y) {
@@ -1092,15 +1161,21 @@ __device__ __forceinline__ double logaddexp_d(double x, double y) {
 constexpr size_t kLdsLimit = 159 * 1024;
 // separate Jacobi buffers only while two workgroups still fit one CU's 160 KB
 constexpr size_t kLdsSeparate = 79 * 1024;
-__host__ __device__ inline size_t rebuild_lds_base_bytes(int D) {
+__host__ __device__ inline size_t rebuild_lds_base_bytes(int D, int TP) {
   const int LD = D | 1;
-  const size_t dbl = (size_t)kThreads * LD + 4 * (size_t)D * LD + 7 * (size_t)D + kThreads + 128;
+  const size_t dbl = (size_t)TP * LD + 4 * (size_t)D * LD + 7 * (size_t)D + kThreads + 128 + 384;
   return (dbl * 8 + (320 + (size_t)D + 8) * 4 + 15) & ~(size_t)15;
 }
 
-__device__ __forceinline__ void carve(Lds& L, unsigned char* smem, int D) {
+// does the (small) tile of the deep-level configuration hold the Jacobi overlay?
+__host__ __device__ inline bool rebuild_small_tile_ok(int D) {
+  const int P = (D + 1) & ~1;
+  return (size_t)kSmallTile * (D | 1) >= 4 * (size_t)P * (P | 1);
+}
+
+__device__ __forceinline__ void carve(Lds& L, unsigned char* smem, int D, int TP = kThreads) {
   L.LD = D | 1;  // odd leading dimension: conflict-free column walks
-  L.TP = kThreads;
+  L.TP = TP;
   L.c_pts = nullptr;
   L.c_start = L.c_cnt = L.c_how = -1;
   L.DP = 1;
@@ -1136,13 +1211,15 @@ __device__ __forceinline__ void carve(Lds& L, unsigned char* smem, int D) {
   p += 64;
   L.rs = p;
   p += 64;
+  L.kred = p;
+  p += 4 * 2 * 48;
   L.ri = (int*)p;
   L.perm_sort = L.ri + 320;
   const int P = (D + 1) & ~1;
   L.JLD = P | 1;
   const size_t jdbl = 4 * (size_t)P * L.JLD;
-  L.j_alias = rebuild_lds_base_bytes(D) + jdbl * 8 > kLdsSeparate;
-  double* jb = L.j_alias ? L.tile : (double*)(smem + rebuild_lds_base_bytes(D));
+  L.j_alias = rebuild_lds_base_bytes(D, TP) + jdbl * 8 > kLdsSeparate;
+  double* jb = L.j_alias ? L.tile : (double*)(smem + rebuild_lds_base_bytes(D, TP));
   L.JA[0] = jb;
   L.JA[1] = jb + (size_t)P * L.JLD;
   L.JV[0] = jb + 2 * (size_t)P * L.JLD;
@@ -1178,6 +1255,24 @@ __device__ __forceinline__ RunView view_of(const RebuildArgs& a, int run, int LD
 __device__ __forceinline__ void set_status(const RebuildArgs& a, int run, int rc) {
   // first error wins is not needed: any error code marks the run failed
   if (threadIdx.x == 0 && rc != DH_OK) atomicMin(&a.status[run], rc);
+}
+
+// queue `node` (count points) for splitting at `level`: one split_list slot + its parts
+__device__ __forceinline__ void queue_split(const RebuildArgs& a, int run, int level, int node, int count, int TP) {
+  const size_t lp = (size_t)(level & 1) * a.runs + run;
+  const int sidx = atomicAdd(&a.nsplit[(size_t)level * a.runs + run], 1);
+  const int np = (count + TP - 1) / TP;
+  const int pb = atomicAdd(&a.nparts[(size_t)level * a.runs + run], np);
+  if (sidx >= a.maxw || pb + np > a.maxp) {
+    atomicMin(&a.status[run], DH_ERR_NOMEM);
+    return;
+  }
+  a.split_list[lp * a.maxw + sidx] = node;
+  a.part_base[lp * a.maxw + sidx] = pb;
+  for (int qq = 0; qq < np; ++qq) {
+    a.part_list[(lp * a.maxp + pb + qq) * 2] = sidx;
+    a.part_list[(lp * a.maxp + pb + qq) * 2 + 1] = qq;
+  }
 }
 
 __global__ void __launch_bounds__(kThreads) k_root(RebuildArgs a) {
@@ -1223,17 +1318,16 @@ __global__ void __launch_bounds__(kThreads) k_root(RebuildArgs a) {
         for (int p = p0; p < n; p += pstep) ps[(size_t)p * D + j] = v.pts[(size_t)p * D + j] / sj;
       }
     }
-    if (t == 0) {
-      a.split_list[((size_t)0 * a.runs + run) * a.maxw] = 0;
-      a.nsplit[(size_t)0 * a.runs + run] = 1;
-    }
+    if (t == 0) queue_split(a, run, 0, 0, n, kThreads);
   }
 }
 
 __global__ void __launch_bounds__(kThreads) k_split(RebuildArgs a, int level) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int run = blockIdx.x / a.maxw, slot = blockIdx.x % a.maxw;
-  if (slot >= a.nsplit[(size_t)level * a.runs + run]) return;
+  const int run = blockIdx.x / a.maxp, ps = blockIdx.x % a.maxp;
+  if (ps >= a.nparts[(size_t)level * a.runs + run]) return;
+  // status is only written by the other kernels of the pipeline (errors of THIS kernel go
+  // to kerr): all parts of a node take the same decision here
   if (a.status[run] != DH_OK) return;
   const int D = a.d, t = threadIdx.x;
   Lds L;
@@ -1241,21 +1335,31 @@ __global__ void __launch_bounds__(kThreads) k_split(RebuildArgs a, int level) {
   const RunView v = view_of(a, run, L.LD);
   if (t < D) L.scale[t] = a.scale_g[(size_t)run * D + t];
   __syncthreads();
-  const int cur = a.split_list[((size_t)(level & 1) * a.runs + run) * a.maxw + slot];
+  const size_t lp = (size_t)(level & 1) * a.runs + run;
+  const int slot = a.part_list[(lp * a.maxp + ps) * 2], q = a.part_list[(lp * a.maxp + ps) * 2 + 1];
+  const int pb = a.part_base[lp * a.maxw + slot];
+  const int cur = a.split_list[lp * a.maxw + slot];
   const int start = v.nodes[cur].start, count = v.nodes[cur].count, depth = v.nodes[cur].depth;
+  const int np = (count + L.TP - 1) / L.TP;
   const int min_size = 2 * D;
+  const int KP = 2 * D + 2;
+  double* kp0 = a.kpart + ((size_t)run * a.maxp + pb) * KP;
+  double* kp1 = kp0 + (size_t)a.runs * a.maxp * KP;
+  int* bar = a.kbar + (((size_t)level * a.runs + run) * a.maxw + slot) * kBarStride;
   PH_T0();
-  const int n0 = node_kmeans(L, a.pts_scaled + (size_t)run * a.n * D, v.perm, v.lab, start, count, D,
-                             v.estore + (size_t)cur * v.NS);
+  const int n0 = node_kmeans_part(L, a.pts_scaled + (size_t)run * a.n * D, v.perm, v.perm2, start, count, D,
+                                  v.estore + (size_t)cur * v.NS, q, np, kp0, kp1, bar, min_size);
   PH_ADD(4);
+  if (n0 < 0) {
+    if (t == 0) atomicMin(&a.kerr[run], DH_ERR_HIP);
+    return;
+  }
   const int n1 = count - n0;
   if (min(n0, n1) < min_size) return;  // reject the split (:1521-1522): node stays a leaf
-  node_partition(L, v.perm, v.perm2, v.lab, start, count, n0);
-  PH_ADD(5);
-  if (t == 0) {
+  if (q == 0 && t == 0) {
     const int c0 = atomicAdd(&a.nnodes_dev[run], 2);
     if (c0 + 2 > a.max_nodes) {
-      atomicMin(&a.status[run], DH_ERR_NOMEM);
+      atomicMin(&a.kerr[run], DH_ERR_NOMEM);
     } else {
       Node k0, k1;
       k0.start = start;
@@ -1285,10 +1389,14 @@ __global__ void __launch_bounds__(kThreads) k_ell(RebuildArgs a, int level) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int run = blockIdx.x / (2 * a.maxw), slot = blockIdx.x % (2 * a.maxw);
   if (slot >= a.nell[(size_t)level * a.runs + run]) return;
+  if (a.kerr[run] != DH_OK) {  // raised by a k_split workgroup of this level
+    if (threadIdx.x == 0) atomicMin(&a.status[run], a.kerr[run]);
+    return;
+  }
   if (a.status[run] != DH_OK) return;
   const int D = a.d, t = threadIdx.x;
   Lds L;
-  carve(L, smem, D);
+  carve(L, smem, D, a.ell_tp_small && level >= kSmallTileLevel ? kSmallTile : kThreads);
   const RunView v = view_of(a, run, L.LD);
   const int node = a.ell_list[(size_t)run * 2 * a.maxw + slot];
   const int start = v.nodes[node].start, count = v.nodes[node].count;
@@ -1305,8 +1413,7 @@ __global__ void __launch_bounds__(kThreads) k_ell(RebuildArgs a, int level) {
       if (level + 1 >= a.levels) {
         atomicMin(&a.status[run], DH_ERR_NOMEM);  // deeper than the launch plan
       } else {
-        const int sidx = atomicAdd(&a.nsplit[(size_t)(level + 1) * a.runs + run], 1);
-        a.split_list[((size_t)((level + 1) & 1) * a.runs + run) * a.maxw + sidx] = node;
+        queue_split(a, run, level + 1, node, count, kThreads);
       }
     }
   }
@@ -1324,8 +1431,17 @@ __global__ void __launch_bounds__(kThreads) k_finish(RebuildArgs a) {
   int* reslist = v.reslist;
   const double* estore = v.estore;
   const int NS = v.NS, DD = D * D;
-  int status = a.status[run];
+  int status = min(a.status[run], a.kerr[run]);  // k_split errors of the last level are folded here
   const int nnodes = min(a.nnodes_dev[run], a.max_nodes);
+  // the accept test below is a serial walk over the tree by one thread: every access to a
+  // node in global memory is a dependent ~1 us load, so the tree (and, when it fits, the
+  // result-list arena) is copied to LDS first
+  if (a.fin_extra_off) {
+    Node* nl = (Node*)(smem + a.fin_extra_off);
+    for (int i = t; i < nnodes; i += kThreads) nl[i] = nodes[i];
+    nodes = nl;
+    if (a.fin_res_lds) reslist = (int*)(nl + a.max_nodes);
+  }
   __syncthreads();
 
   // ---- bottom-up accept test (bounding.py:1541-1563), thread 0 ----
@@ -1418,32 +1534,48 @@ __global__ void __launch_bounds__(kThreads) k_finish(RebuildArgs a) {
     // ---- coverage check: every point inside some ellipsoid, strict < 1
     //      (MultiEllipsoid.update, bounding.py:683-685).  mode 1 has no check.
     if (a.mode == 0) {
-      int uncovered = 0;
-      for (int base = 0; base < n; base += L.TP) {
-        const int cnt = min(L.TP, n - base);
-        stage_tile(L, v.pts, v.perm, base, cnt, D, 0);
-        bool inside = false;
-        for (int m = 0; m < M; ++m) {
-          for (int e = t; e < DD; e += kThreads) L.AM[(e / D) * L.LD + e % D] = o_am[(size_t)m * DD + e];
-          if (t < D) L.mean[t] = o_ctr[m * D + t];
-          __syncthreads();
-          if (t < cnt && !inside) {
-            const double* x = L.tile + t * L.LD;
-            double q = 0.0;
-            for (int i = 0; i < D; ++i) {
-              double r = 0.0;
-              const double* row = L.AM + i * L.LD;
-              for (int jj = 0; jj < D; ++jj) r = fma(row[jj], x[jj] - L.mean[jj], r);
-              q = fma(x[i] - L.mean[i], r, q);
-            }
-            if (q < 1.0) inside = true;
-          }
-          __syncthreads();
-        }
-        if (t < cnt && !inside) uncovered = 1;
+      // fast path: the leaves partition the points, so "every point lies in its own leaf's
+      // ellipsoid" (max of the quadratic form over the leaf < 1, the matrix-core pass of
+      // node_fmax) already proves coverage with n instead of n x M quadratic forms
+      double worst = -INFINITY;
+      for (int m = 0; m < M; ++m) {
+        const int ni = reslist[rs0 + m];
+        __syncthreads();
+        for (int e = t; e < DD; e += kThreads) L.AM[(e / D) * L.LD + e % D] = o_am[(size_t)m * DD + e];
+        if (t < D) L.mean[t] = o_ctr[m * D + t];
+        __syncthreads();
+        L.c_pts = nullptr;  // L.mean changed: a cached centred tile is stale
+        worst = fmax(worst, node_fmax(L, v.pts, v.perm, nodes[ni].start, nodes[ni].count, D));
       }
-      const int tot = block_reduce_sum_int(uncovered, L.ri);
-      if (tot > 0) status = DH_ERR_REGION;
+      if (!(worst < 1.0)) {
+        // some point is outside its own leaf: the reference's full test (any ellipsoid)
+        int uncovered = 0;
+        for (int base = 0; base < n; base += L.TP) {
+          const int cnt = min(L.TP, n - base);
+          stage_tile(L, v.pts, v.perm, base, cnt, D, 0);
+          bool inside = false;
+          for (int m = 0; m < M; ++m) {
+            for (int e = t; e < DD; e += kThreads) L.AM[(e / D) * L.LD + e % D] = o_am[(size_t)m * DD + e];
+            if (t < D) L.mean[t] = o_ctr[m * D + t];
+            __syncthreads();
+            if (t < cnt && !inside) {
+              const double* x = L.tile + t * L.LD;
+              double q = 0.0;
+              for (int i = 0; i < D; ++i) {
+                double r = 0.0;
+                const double* row = L.AM + i * L.LD;
+                for (int jj = 0; jj < D; ++jj) r = fma(row[jj], x[jj] - L.mean[jj], r);
+                q = fma(x[i] - L.mean[i], r, q);
+              }
+              if (q < 1.0) inside = true;
+            }
+            __syncthreads();
+          }
+          if (t < cnt && !inside) uncovered = 1;
+        }
+        const int tot = block_reduce_sum_int(uncovered, L.ri);
+        if (tot > 0) status = DH_ERR_REGION;
+      }
     }
   }
   if (t == 0) {
@@ -1591,8 +1723,8 @@ __global__ void __launch_bounds__(64)
   if (lane == 0) logvols[e] = target;
 }
 
-size_t rebuild_lds_bytes(int D) {
-  const size_t base = rebuild_lds_base_bytes(D);
+size_t rebuild_lds_bytes(int D, int TP = kThreads) {
+  const size_t base = rebuild_lds_base_bytes(D, TP);
   const int P = (D + 1) & ~1;
   const size_t jb = 4 * (size_t)P * (P | 1) * 8;
   return base + jb > kLdsSeparate ? base : base + jb;  // else the Jacobi buffers overlay the tile
@@ -1687,13 +1819,35 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
   int lv = 4;
   while ((1 << lv) < n / (2 * d) + 1) ++lv;
   a.levels = mode == 1 ? 0 : (2 * lv + 8);
-  const size_t b_cnt = (size_t)runs * ((size_t)2 * a.levels + 3) * 4;
+  a.maxp = n / kThreads + a.maxw + 1;
+  a.ell_tp_small = rebuild_small_tile_ok(d) ? 1 : 0;
+  const size_t lds_small = rebuild_lds_bytes(d, kSmallTile);
+  // k_finish: tree (and result list) in LDS when they fit behind the standard layout
+  size_t lds_fin = lds;
+  a.fin_extra_off = 0;
+  a.fin_res_lds = 0;
+  {
+    const size_t off = (lds + 15) & ~(size_t)15;
+    const size_t nb_nodes = (size_t)a.max_nodes * sizeof(Node), nb_res = (size_t)a.reslist_cap * 4;
+    if (off + nb_nodes <= kLdsLimit) {
+      a.fin_extra_off = (int)off;
+      lds_fin = off + nb_nodes;
+      if (lds_fin + nb_res <= kLdsLimit) {
+        a.fin_res_lds = 1;
+        lds_fin += nb_res;
+      }
+    }
+  }
+  // zeroed counters: nnodes | nsplit (levels+1) | nell (levels) | nparts (levels+1) | kerr | kbar (levels x maxw)
+  const size_t b_cnt = (size_t)runs * ((size_t)3 * a.levels + 5 + (size_t)a.levels * a.maxw * kBarStride) * 4;
+  const size_t b_pl = (size_t)2 * runs * a.maxp * 2 * 4, b_pb = (size_t)2 * runs * a.maxw * 4;
+  const size_t b_kp = mode == 1 ? 0 : (size_t)2 * runs * a.maxp * (2 * (size_t)d + 2) * 8;
   const size_t b_sl = (size_t)2 * runs * a.maxw * 4, b_el = (size_t)runs * 2 * a.maxw * 4;
   const size_t b_sc = (size_t)runs * d * 8;
   const size_t b_ps = mode == 1 ? 0 : (size_t)runs * n * d * 8;
   auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
   const size_t total = al(b_perm) * 2 + al(b_lab) + al(b_nodes) + al(b_es) + al(b_res) + al(b_cnt) +
-                       al(b_sl) + al(b_el) + al(b_sc) + al(b_ps);
+                       al(b_sl) + al(b_el) + al(b_sc) + al(b_ps) + al(b_pl) + al(b_pb) + al(b_kp);
   if (total > ctx->rebuild_ws_cap) {
     if (!hip_ok(ctx, hipStreamSynchronize(ctx->stream), "sync")) return DH_ERR_HIP;
     if (ctx->rebuild_ws) (void)hipFree(ctx->rebuild_ws);
@@ -1721,6 +1875,9 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
   a.nnodes_dev = cnt;
   a.nsplit = cnt + runs;
   a.nell = a.nsplit + (size_t)(a.levels + 1) * runs;
+  a.nparts = a.nell + (size_t)a.levels * runs;
+  a.kerr = a.nparts + (size_t)(a.levels + 1) * runs;
+  a.kbar = a.kerr + runs;
   a.split_list = (int*)w;
   w += al(b_sl);
   a.ell_list = (int*)w;
@@ -1728,6 +1885,12 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
   a.scale_g = (double*)w;
   w += al(b_sc);
   a.pts_scaled = (double*)w;
+  w += al(b_ps);
+  a.part_list = (int*)w;
+  w += al(b_pl);
+  a.part_base = (int*)w;
+  w += al(b_pb);
+  a.kpart = (double*)w;
   a.nells = nells;
   a.status = status;
   a.ctrs = ctrs;
@@ -1742,21 +1905,28 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
   a.n_arr = n_arr;
   static size_t attr_lds = 0;
   if (lds > attr_lds) {
-    const void* ks[4] = {(const void*)k_root, (const void*)k_split, (const void*)k_ell,
-                         (const void*)k_finish};
+    const void* ks[3] = {(const void*)k_root, (const void*)k_split, (const void*)k_ell};
     for (const void* kf : ks)
       if (!hip_ok(ctx, hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
                   "hipFuncSetAttribute(rebuild LDS)"))
         return DH_ERR_HIP;
     attr_lds = lds;
   }
+  static size_t attr_fin = 0;
+  if (lds_fin > attr_fin) {
+    if (!hip_ok(ctx, hipFuncSetAttribute((const void*)k_finish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fin),
+                "hipFuncSetAttribute(k_finish LDS)"))
+      return DH_ERR_HIP;
+    attr_fin = lds_fin;
+  }
   if (!hip_ok(ctx, hipMemsetAsync(cnt, 0, b_cnt, ctx->stream), "memset(rebuild counters)")) return DH_ERR_HIP;
   hipLaunchKernelGGL(k_root, dim3(runs), dim3(kThreads), lds, ctx->stream, a);
   for (int L = 0; L < a.levels; ++L) {
-    hipLaunchKernelGGL(k_split, dim3(runs * a.maxw), dim3(kThreads), lds, ctx->stream, a, L);
-    hipLaunchKernelGGL(k_ell, dim3(runs * 2 * a.maxw), dim3(kThreads), lds, ctx->stream, a, L);
+    hipLaunchKernelGGL(k_split, dim3(runs * a.maxp), dim3(kThreads), lds, ctx->stream, a, L);
+    hipLaunchKernelGGL(k_ell, dim3(runs * 2 * a.maxw), dim3(kThreads),
+                       a.ell_tp_small && L >= kSmallTileLevel ? lds_small : lds, ctx->stream, a, L);
   }
-  hipLaunchKernelGGL(k_finish, dim3(runs), dim3(kThreads), lds, ctx->stream, a);
+  hipLaunchKernelGGL(k_finish, dim3(runs), dim3(kThreads), lds_fin, ctx->stream, a);
   return hip_ok(ctx, hipGetLastError(), "rebuild launch") ? DH_OK : DH_ERR_HIP;
 }
 
