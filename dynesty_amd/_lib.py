@@ -89,7 +89,7 @@ SIGNATURES = {
     "dh_unif_batch_dev": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp,
                                _dbl, _vp, _vp, C.c_int64, _vp, _vp, _vp, _vp,
                                _vp, _vp]),
-    "dh_ns_ensemble": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _dbl, _dbl,
+    "dh_ns_ensemble": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _dbl, _dbl,
                             C.c_int64, C.c_int64, _vp, _i, _u32, _vp, _vp,
                             _vp, _vp]),
     "dh_bound_draw": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp,
@@ -507,8 +507,16 @@ class Context:
     def ns_ensemble(self, prob, runs, nlive, queue_size, walks=None,
                     bound='multi', dlogz=0.01, enlarge=1.25, entropy=(21,),
                     first_run=0, max_fills=0, max_iter=400000,
-                    want_dead_logl=False, sample='rwalk', slices=None):
-        """Device-resident ensemble of static NS runs (dh_ns_ensemble)."""
+                    want_dead_logl=False, sample='rwalk', slices=None,
+                    rebuild_sync=False):
+        """Device-resident ensemble of static NS runs (dh_ns_ensemble).
+
+        rebuild_sync=False keeps the reference's per-run update schedule
+        (sampler.py:625-674): a run's result then depends only on its own seed,
+        not on how the ensemble is sharded.  rebuild_sync=True lets all runs
+        that already have a bound rebuild it together whenever any run is due
+        (early, never late): fewer, fuller rebuild launches, but a run's
+        schedule then depends on its shard mates."""
         nd = prob.ndim
         kind = dict(rwalk=0, rslice=1, slice=2)[sample]
         if kind == 0:
@@ -525,7 +533,7 @@ class Context:
         self._check(self.lib.dh_ns_ensemble(
             self.handle, self.problem(prob), int(runs), int(nlive), nd,
             int(queue_size), kind, int(walks), 1 if bound == 'multi' else 0,
-            float(dlogz), float(enlarge), int(max_fills), int(max_iter),
+            1 if rebuild_sync else 0, float(dlogz), float(enlarge), int(max_fills), int(max_iter),
             _ptr(words), words.size, int(first_run), _ptr(rec), _ptr(dead),
             _ptr(livel), C.byref(nf)))
         out = dict(logz=rec[:, 0], logzerr=rec[:, 1],

@@ -16,6 +16,8 @@
 // All state (live points, heap, dead points, integrals, RNG) stays in HBM; with
 // 288 GB there is room for the full dead-point history of thousands of runs.
 #include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
 
 #include "ctx.h"
 #include "rng_pcg64.h"
@@ -44,6 +46,8 @@ struct NsArgs {
   double dlogz, enlarge_log, facc, first_eff;
   long long first_ncall, update_interval;
   int store_samples;
+  long long* prof;   // optional (DH_NS_PROF=1): cycle counters of ns_consume's phases, run 0
+  int rebuild_sync;  // 1: all bound-mode runs rebuild whenever any run is due (see ns_prepare)
   NsRun* st;
   double* live_u;
   double* live_v;
@@ -191,37 +195,53 @@ __global__ void __launch_bounds__(kT) ns_heapify(NsArgs a) {
 }
 
 // ---- policy (sampler.py:625-674 update_bound_if_needed) ------------------------
-__global__ void ns_prepare(NsArgs a) {
-  const int run = blockIdx.x * blockDim.x + threadIdx.x;
-  if (run >= a.runs) return;
-  NsRun& r = a.st[run];
-  int need = 0;
-  if (r.mode == MODE_CUBE || r.mode == MODE_BOUND) {
-    if (r.mode == MODE_BOUND && a.bstatus[run] != DH_OK) {
-      r.mode = MODE_FAILED;
-      atomicAdd(a.ndone, 1);
-    } else {
-      const double eff = 100.0 * (double)(r.it > 0 ? r.it : 1) / (double)r.ncall;
-      if (r.mode == MODE_CUBE) {
-        if (r.ncall >= a.first_ncall && eff < a.first_eff) {
-          r.mode = MODE_BOUND;
+// One workgroup looks at all runs.  With rebuild_sync the runs of the ensemble rebuild
+// TOGETHER: as soon as any run is due, every run that already samples from a bound joins
+// (its rebuild comes early, never late).  A rebuild is a latency-bound tree construction
+// that costs about the same for 1 or 64 runs; with rwalk every run spends exactly
+// K * walks calls per fill, so after the first joint rebuild all runs are due in the same
+// fill and the ensemble pays one rebuild per update interval instead of one per fill.
+__global__ void __launch_bounds__(kT) ns_prepare(NsArgs a) {
+  const int t = threadIdx.x;
+  int any = 0;
+  for (int run = t; run < a.runs; run += kT) {
+    NsRun& r = a.st[run];
+    int need = 0;
+    if (r.mode == MODE_CUBE || r.mode == MODE_BOUND) {
+      if (r.mode == MODE_BOUND && a.bstatus[run] != DH_OK) {
+        r.mode = MODE_FAILED;
+        atomicAdd(a.ndone, 1);
+      } else {
+        const double eff = 100.0 * (double)(r.it > 0 ? r.it : 1) / (double)r.ncall;
+        if (r.mode == MODE_CUBE) {
+          if (r.ncall >= a.first_ncall && eff < a.first_eff) {
+            r.mode = MODE_BOUND;
+            need = 1;
+          }
+        } else if (r.ncall >= r.ncall_last_update + a.update_interval) {
           need = 1;
         }
-      } else if (r.ncall >= r.ncall_last_update + a.update_interval) {
-        need = 1;
-      }
-      if (need) {
-        r.ncall_last_update = r.ncall;
-        r.nbound += 1;
       }
     }
+    r.need_rebuild = need;
+    any |= need;
   }
-  r.need_rebuild = need;
-  a.rebuild_mask[run] = need;
-  a.run_mode[run] = r.mode;
-  a.run_loglstar[run] = r.loglstar;
-  a.run_scale[run] = r.scale;
-  a.run_doubling[run] = r.doubling;
+  any = __syncthreads_or(any);
+  for (int run = t; run < a.runs; run += kT) {
+    NsRun& r = a.st[run];
+    int need = r.need_rebuild;
+    if (a.rebuild_sync && any && r.mode == MODE_BOUND) need = 1;
+    if (need) {
+      r.ncall_last_update = r.ncall;
+      r.nbound += 1;
+    }
+    r.need_rebuild = need;
+    a.rebuild_mask[run] = need;
+    a.run_mode[run] = r.mode;
+    a.run_loglstar[run] = r.loglstar;
+    a.run_scale[run] = r.scale;
+    a.run_doubling[run] = r.doubling;
+  }
 }
 
 // ---- queue fill: start points, frames, walker streams ---------------------------
@@ -288,26 +308,119 @@ __global__ void __launch_bounds__(kT) ns_select(NsArgs a) {
 }
 
 // ---- consume the queue (sampler.py:732-778 + 1105-1185), one workgroup per run ----
+// Only the heap walk is inherently serial (which proposal kills which live point depends
+// on every earlier one).  It is done by one lane and touches nothing but LDS integers and
+// keys; everything transcendental -- the evidence integration of progress_integration
+// (utils.py:1470-1492) and the dlogz stopping rule, ~10 exp/log per dead point -- is a
+// prefix scan over the deaths of the fill and runs on all lanes afterwards:
+//   ln Z_e   = logaddexp-scan of the trapezoid weights,
+//   lmax_e   = running maximum of the inserted log-likelihoods,
+//   stop     = first e with ln(1 + exp(lmax_e + lnX_e - lnZ_e)) < dlogz,
+//   H_E      = e^{-lnZ_E} [ G_0 + sum_{e<=E} dX_e (L e^L terms) ] - lnZ_E   (G = e^{lnZ}(H + lnZ) is additive),
+//   var lnZ += dlnX (H_E - H_0)                         (the per-step sum telescopes: dlnX is constant).
+// If the stop index falls inside the fill, the heap walk is replayed up to it from the
+// untouched copy in HBM (once per run).
+#define NS_PROF(i)                                              \
+  do {                                                          \
+    if (a.prof && run == 0 && t == 0) {                          \
+      const long long now_ = clock64();                          \
+      a.prof[i] += now_ - pt_;                                   \
+      pt_ = now_;                                                \
+    }                                                            \
+  } while (0)
+
+constexpr int kEPT = 8;  // deaths per lane in the scan phase: K <= kEPT * kT
+
+// heap node = one 16-byte LDS entry {logl, slot}: x = key, y = slot (integer bits)
+typedef double HeapEnt __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ HeapEnt heap_ent(double key, int slot) {
+  HeapEnt e;
+  e.x = key;
+  e.y = __longlong_as_double((long long)slot);
+  return e;
+}
+__device__ __forceinline__ int heap_slot_of(HeapEnt e) { return (int)__double_as_longlong(e.y); }
+
+// The walk is a chain of dependent LDS accesses (~150 cycles per round trip for a lone
+// lane), so its speed is (round trips per sift level) x (levels).  Key and slot share one
+// 128-bit entry, and every step fetches the two children AND the four grandchildren
+// (contiguous at 4i+3) in one volley: TWO levels per round trip, ~6 round trips per
+// replacement at nlive = 2000 instead of ~33 with separate key / slot arrays.
+// hp[N .. N+3] are +inf sentinels, so partial child groups need no special cases.
+__device__ __forceinline__ int consume_heap(HeapEnt* hp, int* src, const double* ql, double* dcur, int* dj,
+                                            int* dslot, int* dsrc, int N, int K, long long room, int limit,
+                                            int* jcap) {
+  int ndead = 0;
+  *jcap = -1;
+  for (int j = 0; j < K; ++j) {
+    const HeapEnt root = hp[0];
+    const double lj = ql[j];
+    if (!(lj > root.x)) continue;  // stale proposal (sampler.py:774-776)
+    if (ndead >= room) {           // dead-point store exhausted
+      *jcap = j;
+      break;
+    }
+    const int s = heap_slot_of(root);
+    dcur[ndead] = root.x;
+    dj[ndead] = j;
+    dslot[ndead] = s;
+    dsrc[ndead] = src[s];
+    ++ndead;
+    src[s] = j;
+    // heap: replace the root by (lj, s), sift down two levels per step
+    int i = 0;
+    for (;;) {
+      const int c = 2 * i + 1;
+      if (c >= N) break;
+      const int g = 4 * i + 3, gi = g < N ? g : N;
+      HeapEnt e0 = hp[c], e1 = hp[c + 1];
+      HeapEnt g0 = hp[gi], g1 = hp[gi + 1], g2 = hp[gi + 2], g3 = hp[gi + 3];
+      // keep the six reads in ONE volley: without this the compiler sinks the grandchild
+      // reads below the first comparison (no speculative loads) and pays a second round trip
+      asm volatile("" : "+v"(e0), "+v"(e1), "+v"(g0), "+v"(g1), "+v"(g2), "+v"(g3));
+      const bool r1 = e1.x < e0.x;
+      const HeapEnt ec = r1 ? e1 : e0;
+      if (!(ec.x < lj)) break;
+      hp[i] = ec;
+      i = c + (r1 ? 1 : 0);
+      const HeapEnt ga = r1 ? g2 : g0, gb = r1 ? g3 : g1;
+      const bool r2 = gb.x < ga.x;
+      const HeapEnt gc = r2 ? gb : ga;
+      if (!(gc.x < lj)) break;
+      hp[i] = gc;
+      i = g + (r1 ? 2 : 0) + (r2 ? 1 : 0);
+    }
+    hp[i] = heap_ent(lj, s);
+    if (ndead == limit) break;
+  }
+  return ndead;
+}
+
 __global__ void __launch_bounds__(kT) ns_consume(NsArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int run = blockIdx.x, t = threadIdx.x;
+  const int run = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
   const int N = a.nlive, D = a.ndim, K = a.K;
   NsRun& r = a.st[run];
   const int mode = r.mode;
   if (mode != MODE_CUBE && mode != MODE_BOUND) return;
   if (mode == MODE_BOUND && a.bstatus[run] != DH_OK) return;
-  double* key = (double*)smem;      // N
-  double* ql = key + N;             // K   proposal logl
-  int* slot = (int*)(ql + K);       // N
-  int* src = slot + N;              // N   queue index now living in the slot, -1 = original
+  long long pt_ = a.prof ? clock64() : 0;
+  HeapEnt* hp = (HeapEnt*)smem;            // N + 4  min-heap over (logl, slot), hp[N..N+3] = +inf sentinels
+  double* ql = (double*)(hp + N + 4);      // K   proposal logl
+  double* dcur = ql + K;                   // K   death list: logl of the dead point
+  int* src = (int*)(dcur + K);             // N   queue index now living in the slot, -1 = original
   int* qc = src + N;                // K   calls
-  int* dslot = qc + K;              // K   death list: slot
+  int* dj = qc + K;                 // K   death list: queue index of the replacement
+  int* dslot = dj + K;              // K               slot
   int* dsrc = dslot + K;            // K               content source at death
-  int* misc = dsrc + K;             // 8
-  for (int i = t; i < N; i += kT) {
-    key[i] = a.heap_key[(size_t)run * N + i];
-    slot[i] = a.heap_slot[(size_t)run * N + i];
-    src[i] = -1;
+  __shared__ int misc[8];
+  __shared__ double wred[2][4];
+  __shared__ double bcast[4];
+  __shared__ long long lred[4];
+  for (int i = t; i < N + 4; i += kT) {
+    hp[i] = i < N ? heap_ent(a.heap_key[(size_t)run * N + i], a.heap_slot[(size_t)run * N + i])
+                  : heap_ent(INFINITY, 0);
+    if (i < N) src[i] = -1;
   }
   int acc = 0, rej = 0;
   for (int j = t; j < K; j += kT) {
@@ -331,71 +444,154 @@ __global__ void __launch_bounds__(kT) ns_consume(NsArgs a) {
   __shared__ int racc[kT], rrej[kT];
   racc[t] = acc;
   rrej[t] = rej;
+  if (t == 0) misc[3] = 0x7fffffff;  // first stop index
   __syncthreads();
-  for (int s = kT / 2; s > 0; s >>= 1) {
-    if (t < s) {
-      racc[t] += racc[t + s];
-      rrej[t] += rrej[t + s];
+  for (int sft = kT / 2; sft > 0; sft >>= 1) {
+    if (t < sft) {
+      racc[t] += racc[t + sft];
+      rrej[t] += rrej[t + sft];
     }
     __syncthreads();
   }
+  const long long it0 = r.it;
+  const double logvol0 = r.logvol, logz0 = r.logz, h0 = r.h, lmax0 = r.lmax, dead_prev0 = r.dead_prev;
+  const double dlv = log(((double)N + 1.0) / (double)N);
+  const double ldv_c = log(0.5 * expm1(dlv));  // ln(dX_e / X_e) of the trapezoid rule
+  NS_PROF(0);
+  // ---- phase A: the heap walk (one lane) ----
   if (t == 0) {
-    double logvol = r.logvol, logz = r.logz, h = r.h, lmax = r.lmax, dead_prev = r.dead_prev;
-    double logzvar = r.logzvar;
-    long long it = r.it, ncall = r.ncall;
-    const double dlv = log(((double)N + 1.0) / (double)N);
-    int ndead = 0, done = 0;
-    for (int j = 0; j < K; ++j) {
-      ncall += qc[j];
-      const double cur = key[0];
-      const double lj = ql[j];
-      if (!(lj > cur)) continue;  // stale proposal (sampler.py:774-776)
-      const int s = slot[0];
-      if (it >= a.cap) {
-        done = 2;  // dead-point store exhausted
-        break;
-      }
-      logvol -= dlv;
-      integrate_step(logz, h, logzvar, dead_prev, cur, logvol, dlv);
-      dead_prev = cur;
-      a.dead_logl[(size_t)run * a.cap + it] = cur;
-      dslot[ndead] = s;
-      dsrc[ndead] = src[s];
-      ++ndead;
-      src[s] = j;
-      // heap: replace the root by (lj, s), sift down
-      int i = 0;
-      for (;;) {
-        int c = 2 * i + 1;
-        if (c >= N) break;
-        if (c + 1 < N && key[c + 1] < key[c]) ++c;
-        if (!(key[c] < lj)) break;
-        key[i] = key[c];
-        slot[i] = slot[c];
-        i = c;
-      }
-      key[i] = lj;
-      slot[i] = s;
-      if (lj > lmax) lmax = lj;
-      ++it;
-      const double dz = logaddexp_dev(0.0, lmax + logvol - logz);
-      if (dz < a.dlogz) {
-        done = 1;
-        break;
-      }
+    int jcap;
+    misc[0] = consume_heap(hp, src, ql, dcur, dj, dslot, dsrc, N, K, a.cap - it0, K + 1, &jcap);
+    misc[1] = jcap;
+  }
+  __syncthreads();
+  const int ndead = misc[0], jcap = misc[1];
+  NS_PROF(1);
+  // ---- phase B: integration + stopping rule as prefix scans over the deaths ----
+  const int EPT = (K + kT - 1) / kT;
+  double lw[kEPT], nl[kEPT];
+  double tz = -INFINITY, tm = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < kEPT; ++i) {
+    lw[i] = -INFINITY;
+    nl[i] = -INFINITY;
+    const int e = t * EPT + i;
+    if (i < EPT && e < ndead) {
+      const double lnew = dcur[e], lprev = e ? dcur[e - 1] : dead_prev0;
+      const double logvol_e = logvol0 - (double)(e + 1) * dlv;
+      lw[i] = logaddexp_dev(lnew, lprev) + logvol_e + ldv_c;
+      nl[i] = ql[dj[e]];
     }
-    misc[0] = ndead;
-    misc[1] = done;
-    r.logvol = logvol;
-    r.logz = logz;
-    r.h = h;
-    r.logzvar = logzvar;
-    r.lmax = lmax;
-    r.dead_prev = dead_prev;
-    misc[2] = (int)r.it;  // first death index of this fill
-    r.it = it;
-    r.ncall = ncall;
-    r.loglstar = key[0];
+    tz = logaddexp_dev(tz, lw[i]);  // running (inclusive) values of this lane's segment
+    tm = fmax(tm, nl[i]);
+    lw[i] = tz;
+    nl[i] = tm;
+  }
+  // inclusive scan of the lane totals across the wave, then across the 4 waves
+  double sz = tz, sm = tm;
+  for (int off = 1; off < 64; off <<= 1) {
+    const double yz = __shfl_up(sz, off), ym = __shfl_up(sm, off);
+    if (lane >= off) {
+      sz = logaddexp_dev(yz, sz);
+      sm = fmax(ym, sm);
+    }
+  }
+  if (lane == 63) {
+    wred[0][wv] = sz;
+    wred[1][wv] = sm;
+  }
+  double ez = __shfl_up(sz, 1), em = __shfl_up(sm, 1);  // exclusive prefix inside the wave
+  if (lane == 0) {
+    ez = -INFINITY;
+    em = -INFINITY;
+  }
+  __syncthreads();
+  double pz = logz0, pm = lmax0;  // everything before this lane's segment
+  for (int w2 = 0; w2 < wv; ++w2) {
+    pz = logaddexp_dev(pz, wred[0][w2]);
+    pm = fmax(pm, wred[1][w2]);
+  }
+  pz = logaddexp_dev(pz, ez);
+  pm = fmax(pm, em);
+  int mystop = 0x7fffffff;
+#pragma unroll
+  for (int i = 0; i < kEPT; ++i) {
+    const int e = t * EPT + i;
+    if (i < EPT && e < ndead) {
+      lw[i] = logaddexp_dev(pz, lw[i]);  // ln Z after death e
+      nl[i] = fmax(pm, nl[i]);           // lmax after death e
+      const double logvol_e = logvol0 - (double)(e + 1) * dlv;
+      const double dz = logaddexp_dev(0.0, nl[i] + logvol_e - lw[i]);
+      if (dz < a.dlogz && e < mystop) mystop = e;
+    }
+  }
+  if (mystop != 0x7fffffff) atomicMin(&misc[3], mystop);
+  __syncthreads();
+  const int estop = misc[3];
+  const bool stopped = estop != 0x7fffffff;
+  const int nkeep = stopped ? estop + 1 : ndead;
+  const int E = nkeep - 1;
+#pragma unroll
+  for (int i = 0; i < kEPT; ++i)
+    if (i < EPT && t * EPT + i == E) {
+      bcast[0] = lw[i];
+      bcast[1] = nl[i];
+    }
+  __syncthreads();
+  const double logz_E = E >= 0 ? bcast[0] : logz0, lmax_E = E >= 0 ? bcast[1] : lmax0;
+  // information: sum of the L e^L dX terms relative to e^{lnZ_E}
+  double hs = 0.0;
+  long long calls = 0;
+  const int jlast = stopped ? dj[E] : (jcap >= 0 ? jcap : K - 1);
+#pragma unroll
+  for (int i = 0; i < kEPT; ++i) {
+    const int e = t * EPT + i;
+    if (i < EPT && e <= E) {
+      const double lnew = dcur[e], lprev = e ? dcur[e - 1] : dead_prev0;
+      const double ldv = logvol0 - (double)(e + 1) * dlv + ldv_c;
+      const double t0 = exp(lprev - logz_E + ldv), t1 = exp(lnew - logz_E + ldv);
+      hs += (t0 > 0.0 ? t0 * lprev : 0.0) + (t1 > 0.0 ? t1 * lnew : 0.0);
+    }
+  }
+  for (int j = t; j <= jlast; j += kT) calls += qc[j];
+  for (int off = 32; off > 0; off >>= 1) {
+    hs += __shfl_xor(hs, off);
+    calls += __shfl_xor(calls, off);
+  }
+  if (lane == 0) {
+    wred[0][wv] = hs;
+    lred[wv] = calls;
+  }
+  NS_PROF(2);
+  // ---- replay the heap walk up to the stop index (once per run) ----
+  if (nkeep < ndead) {
+    __syncthreads();
+    for (int i = t; i < N; i += kT) {
+      hp[i] = heap_ent(a.heap_key[(size_t)run * N + i], a.heap_slot[(size_t)run * N + i]);
+      src[i] = -1;
+    }
+    __syncthreads();
+    if (t == 0) {
+      int jc;
+      consume_heap(hp, src, ql, dcur, dj, dslot, dsrc, N, K, a.cap - it0, nkeep, &jc);
+    }
+  }
+  __syncthreads();
+  if (t == 0) {
+    const double hsum = wred[0][0] + wred[0][1] + wred[0][2] + wred[0][3];
+    r.ncall += lred[0] + lred[1] + lred[2] + lred[3];
+    if (nkeep > 0) {
+      const double w = exp(logz0 - logz_E);
+      const double h_E = hsum + (w > 0.0 ? w * (h0 + logz0) : 0.0) - logz_E;
+      r.logzvar += (h_E - h0) * dlv;
+      r.h = h_E;
+      r.logz = logz_E;
+      r.lmax = lmax_E;
+      r.dead_prev = dcur[E];
+      r.logvol = logvol0 - (double)nkeep * dlv;
+      r.it = it0 + nkeep;
+    }
+    r.loglstar = hp[0].x;
     r.nfill += 1;
     if (mode == MODE_BOUND) {
       const int ta = racc[0], tr = rrej[0];
@@ -410,17 +606,18 @@ __global__ void __launch_bounds__(kT) ns_consume(NsArgs a) {
         r.scale *= mult;
       }
     }
+    const int done = stopped ? 1 : (jcap >= 0 ? 2 : 0);
     if (done) {
       r.mode = done == 1 ? MODE_DONE : MODE_FAILED;
       atomicAdd(a.ndone, 1);
     }
   }
-  __syncthreads();
-  const int ndead = misc[0];
-  const long long it0 = misc[2];
+  NS_PROF(3);
+  // dead-point log-likelihoods, in death order
+  for (int e = t; e < nkeep; e += kT) a.dead_logl[(size_t)run * a.cap + it0 + e] = dcur[e];
   // dead-point coordinates (optional), in death order
   if (a.store_samples) {
-    for (int e = 0; e < ndead; ++e) {
+    for (int e = 0; e < nkeep; ++e) {
       const int s = dslot[e], sj = dsrc[e];
       const double* from = sj < 0 ? a.live_u + ((size_t)run * N + s) * D
                                   : a.r_u + ((size_t)run * K + sj) * D;
@@ -429,6 +626,7 @@ __global__ void __launch_bounds__(kT) ns_consume(NsArgs a) {
     }
   }
   __syncthreads();
+  NS_PROF(4);
   // apply the surviving replacements to the live set
   for (int s = t; s < N; s += kT) {
     const int sj = src[s];
@@ -444,9 +642,10 @@ __global__ void __launch_bounds__(kT) ns_consume(NsArgs a) {
     }
   }
   for (int i = t; i < N; i += kT) {
-    a.heap_key[(size_t)run * N + i] = key[i];
-    a.heap_slot[(size_t)run * N + i] = slot[i];
+    a.heap_key[(size_t)run * N + i] = hp[i].x;
+    a.heap_slot[(size_t)run * N + i] = heap_slot_of(hp[i]);
   }
+  NS_PROF(5);
 }
 
 // ---- final live points (sampler.py:780-930) + record -----------------------------
@@ -499,7 +698,8 @@ __global__ void __launch_bounds__(kT) ns_finish(NsArgs a) {
 extern "C" {
 
 int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int queue_size, int sampler,
-                   int walks, int bound_multi, double dlogz, double enlarge, int64_t max_fills, int64_t max_iter,
+                   int walks, int bound_multi, int rebuild_sync, double dlogz, double enlarge, int64_t max_fills,
+                   int64_t max_iter,
                    const uint32_t* entropy_words, int n_words, uint32_t first_run, double* records,
                    double* dead_logl_out, double* live_logl_out, int64_t* n_fills_out) {
   DH_CHECK_CTX(ctx);
@@ -532,6 +732,12 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
   // update_bound_interval_ratio (internal_samplers.py:495-502, 581-588, 737-744) * nlive
   a.update_interval = (long long)(sampler == 2 ? walks * D : walks) * N;
   a.store_samples = 0;
+  a.rebuild_sync = rebuild_sync ? 1 : 0;
+  a.prof = nullptr;
+  if (getenv("DH_NS_PROF")) {
+    if (hipMalloc((void**)&a.prof, 16 * sizeof(long long)) != hipSuccess) a.prof = nullptr;
+    if (a.prof) (void)hipMemset(a.prof, 0, 16 * sizeof(long long));
+  }
   // ---- one allocation for all state ----
   auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
   const size_t dd = (size_t)D * D;
@@ -609,7 +815,8 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
   if (rc) return cleanup(rc);
   const size_t lds_heap = (size_t)N * 12 + 64;
   hipLaunchKernelGGL(ns_heapify, dim3(R), dim3(kT), lds_heap, s, a);
-  const size_t lds_cons = (size_t)N * 8 + (size_t)K * 8 + (size_t)N * 8 + (size_t)K * 12 + 64;
+  const size_t lds_cons = (size_t)(N + 4) * 16 + (size_t)N * 4 + (size_t)K * 32 + 64;
+  if (K > kEPT * kT) return cleanup(fail(ctx, DH_ERR_ARG, "ns_ensemble: queue_size %d > %d", K, kEPT * kT));
   if (lds_cons > 150 * 1024) return cleanup(fail(ctx, DH_ERR_ARG, "ns_ensemble: nlive/queue too large for LDS"));
   static size_t attr = 0;
   if (lds_cons > attr) {
@@ -623,7 +830,7 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
   int ndone = 0;
   while (fill < fills_cap && ndone < R) {
     for (int burst = 0; burst < 8 && fill < fills_cap; ++burst, ++fill) {
-      hipLaunchKernelGGL(ns_prepare, dim3((R + 63) / 64), dim3(64), 0, s, a);
+      hipLaunchKernelGGL(ns_prepare, dim3(1), dim3(kT), 0, s, a);
       rc = rebuild_launch_masked(ctx, R, a.live_u, N, D, bound_multi ? 0 : 1, me, a.nells, a.bstatus, a.b_ctrs,
                                  a.b_covs, a.b_ams, a.b_axes, a.b_axl, a.b_lv, a.rebuild_mask);
       if (rc) return cleanup(rc);
@@ -666,6 +873,14 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
               "D2H live"))
     return cleanup(DH_ERR_HIP);
   if (n_fills_out) *n_fills_out = fill;
+  if (a.prof) {
+    long long h[16];
+    (void)hipStreamSynchronize(s);
+    (void)hipMemcpy(h, a.prof, sizeof h, hipMemcpyDeviceToHost);
+    fprintf(stderr, "ns_consume cycles (run 0, %lld fills): load %lld | heap %lld | scan %lld | replay+state %lld | dead %lld | live+heap store %lld\n",
+            (long long)fill, h[0], h[1], h[2], h[3], h[4], h[5]);
+    (void)hipFree(a.prof);
+  }
   return cleanup(DH_OK);
 }
 

@@ -265,10 +265,16 @@ int dh_bound_draw(dh_ctx* ctx, const uint64_t* state4, int nsamp, int d, int m,
  * h, nbound, status (0 ok, 1 max_fills hit, -1 failed), eff%}.
  * dead_logl_out (optional): runs x max_iter dead-point log-likelihoods;
  * live_logl_out (optional): runs x nlive log-likelihoods of the final live points
- * (together they are what utils.merge_runs needs to combine the ensemble). */
+ * (together they are what utils.merge_runs needs to combine the ensemble).
+ * rebuild_sync = 0 keeps the reference's schedule per run (rebuild when ncall has
+ * advanced by update_interval, sampler.py:625-674); rebuild_sync = 1 lets every run
+ * that already has a bound rebuild whenever ANY run of the ensemble is due (its
+ * rebuild comes early, never late): a rebuild is a latency-bound tree construction
+ * that costs about the same for one run or the whole ensemble. */
 int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim,
                    int queue_size, int sampler /* 0 rwalk, 1 rslice, 2 slice */,
-                   int walks /* or slices */, int bound_multi, double dlogz,
+                   int walks /* or slices */, int bound_multi,
+                   int rebuild_sync /* 1: all runs rebuild together, see below */, double dlogz,
                    double enlarge, int64_t max_fills, int64_t max_iter,
                    const uint32_t* entropy_words, int n_words, uint32_t first_run,
                    double* records, double* dead_logl_out, double* live_logl_out,
