@@ -91,7 +91,7 @@ SIGNATURES = {
                                _vp, _vp]),
     "dh_ns_ensemble": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _dbl, _dbl,
                             C.c_int64, C.c_int64, _vp, _i, _u32, _vp, _vp,
-                            _vp, _vp]),
+                            _vp, _vp, _vp, _vp]),
     "dh_bound_draw": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp,
                            _vp, _vp, _vp]),
 }
@@ -508,7 +508,7 @@ class Context:
                     bound='multi', dlogz=0.01, enlarge=1.25, entropy=(21,),
                     first_run=0, max_fills=0, max_iter=400000,
                     want_dead_logl=False, sample='rwalk', slices=None,
-                    rebuild_sync=False):
+                    rebuild_sync=False, want_samples=False):
         """Device-resident ensemble of static NS runs (dh_ns_ensemble).
 
         rebuild_sync=False keeps the reference's per-run update schedule
@@ -527,15 +527,19 @@ class Context:
                 (3 + nd if kind == 1 else 3)
         words = entropy_words(entropy)
         rec = np.empty((runs, 8))
+        want_dead_logl = want_dead_logl or want_samples
         dead = np.empty((runs, max_iter)) if want_dead_logl else None
         livel = np.empty((runs, nlive)) if want_dead_logl else None
+        # runs x max_iter x ndim: only the niter rows a run produced are touched
+        dead_u = np.empty((runs, max_iter, nd)) if want_samples else None
+        live_u = np.empty((runs, nlive, nd)) if want_samples else None
         nf = C.c_int64(0)
         self._check(self.lib.dh_ns_ensemble(
             self.handle, self.problem(prob), int(runs), int(nlive), nd,
             int(queue_size), kind, int(walks), 1 if bound == 'multi' else 0,
             1 if rebuild_sync else 0, float(dlogz), float(enlarge), int(max_fills), int(max_iter),
             _ptr(words), words.size, int(first_run), _ptr(rec), _ptr(dead),
-            _ptr(livel), C.byref(nf)))
+            _ptr(livel), _ptr(dead_u), _ptr(live_u), C.byref(nf)))
         out = dict(logz=rec[:, 0], logzerr=rec[:, 1],
                    niter=rec[:, 2].astype(np.int64),
                    ncall=rec[:, 3].astype(np.int64), h=rec[:, 4],
@@ -545,6 +549,9 @@ class Context:
         if want_dead_logl:
             out["dead_logl"] = dead
             out["live_logl"] = livel
+        if want_samples:
+            out["dead_u"] = dead_u
+            out["live_u"] = live_u
         return out
 
     def bound_draw(self, state4, nsamp, ctrs, axes, ams=None, logvol_ells=None,

@@ -701,7 +701,8 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
                    int walks, int bound_multi, int rebuild_sync, double dlogz, double enlarge, int64_t max_fills,
                    int64_t max_iter,
                    const uint32_t* entropy_words, int n_words, uint32_t first_run, double* records,
-                   double* dead_logl_out, double* live_logl_out, int64_t* n_fills_out) {
+                   double* dead_logl_out, double* live_logl_out, double* dead_u_out, double* live_u_out,
+                   int64_t* n_fills_out) {
   DH_CHECK_CTX(ctx);
   ProblemDev pd;
   if (!get_problem(ctx, problem, &pd)) return DH_ERR_ARG;
@@ -731,7 +732,7 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
   a.first_ncall = 2ll * N;
   // update_bound_interval_ratio (internal_samplers.py:495-502, 581-588, 737-744) * nlive
   a.update_interval = (long long)(sampler == 2 ? walks * D : walks) * N;
-  a.store_samples = 0;
+  a.store_samples = dead_u_out ? 1 : 0;
   a.rebuild_sync = rebuild_sync ? 1 : 0;
   a.prof = nullptr;
   if (getenv("DH_NS_PROF")) {
@@ -749,7 +750,7 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
   };
   const size_t o_st = take(sizeof(NsRun) * R), o_lu = take((size_t)R * N * D * 8), o_lv = take((size_t)R * N * D * 8),
                o_ll = take((size_t)R * N * 8), o_hk = take((size_t)R * N * 8), o_hs = take((size_t)R * N * 4),
-               o_dl = take((size_t)R * a.cap * 8), o_qu = take((size_t)R * K * D * 8),
+               o_dl = take((size_t)R * a.cap * 8), o_du = take(dead_u_out ? (size_t)R * a.cap * D * 8 : 8), o_qu = take((size_t)R * K * D * 8),
                o_qf = take((size_t)R * K * 4), o_qr = take((size_t)R * K * 32), o_qo = take((size_t)R * K * 32),
                o_ru = take((size_t)R * K * D * 8), o_rv = take((size_t)R * K * D * 8),
                o_rl = take((size_t)R * K * 8), o_ra = take((size_t)R * K * 4), o_rb = take((size_t)R * K * 4),
@@ -775,7 +776,7 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
   a.heap_key = (double*)(base + o_hk);
   a.heap_slot = (int*)(base + o_hs);
   a.dead_logl = (double*)(base + o_dl);
-  a.dead_u = nullptr;
+  a.dead_u = dead_u_out ? (double*)(base + o_du) : nullptr;
   a.q_u0 = (double*)(base + o_qu);
   a.q_frame = (int*)(base + o_qf);
   a.q_rng = (uint64_t*)(base + o_qr);
@@ -872,6 +873,23 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
       !hip_ok(ctx, hipMemcpyAsync(live_logl_out, a.live_logl, (size_t)R * N * 8, hipMemcpyDeviceToHost, s),
               "D2H live"))
     return cleanup(DH_ERR_HIP);
+  if (live_u_out &&
+      !hip_ok(ctx, hipMemcpyAsync(live_u_out, a.live_u, (size_t)R * N * D * 8, hipMemcpyDeviceToHost, s),
+              "D2H live u"))
+    return cleanup(DH_ERR_HIP);
+  if (dead_u_out) {
+    // only the niter rows each run produced (the caller's runs x max_iter x ndim buffer may be
+    // far larger than what is touched here)
+    if (!hip_ok(ctx, hipStreamSynchronize(s), "sync")) return cleanup(DH_ERR_HIP);
+    for (int r = 0; r < R; ++r) {
+      long long nit = (long long)records[(size_t)r * 8 + 2];
+      if (nit > a.cap) nit = a.cap;
+      if (nit > 0 &&
+          !hip_ok(ctx, hipMemcpyAsync(dead_u_out + (size_t)r * a.cap * D, a.dead_u + (size_t)r * a.cap * D,
+                                      (size_t)nit * D * 8, hipMemcpyDeviceToHost, s), "D2H dead u"))
+        return cleanup(DH_ERR_HIP);
+    }
+  }
   if (n_fills_out) *n_fills_out = fill;
   if (a.prof) {
     long long h[16];

@@ -135,34 +135,107 @@ def run_ensemble_device(prob, total_runs, base_seed=21, world=1, rank=0,
                           device=device)
 
 
-def merge_logz(dead_logl, niter, live_logl):
-    """Combine R static runs into ONE run with R*nlive live points and return
-    (logz, logzerr) of the merged run -- the evidence part of the reference's
-    utils.merge_runs / _merge_two (utils.py:1817-1900, 2000-2226) for runs of
-    equal, constant nlive.  Every point (dead points, then each run's final
-    live points in ascending order) is given the number of live points its own
-    run had when it died (N for dead points, N, N-1, ..., 1 for the final
-    ones); the merged sequence is ordered by log-likelihood and each point
-    shrinks the prior volume by n/(n+1) with n the summed live count."""
+class MergedRun(dict):
+    """Result of `merge_static_runs`: the fields of the reference's merged
+    `Results` (utils.merge_runs) that are defined for an ensemble of static
+    runs, with attribute access."""
+    __getattr__ = dict.get
+
+    def importance_weights(self):
+        """Normalised posterior weights exp(logwt - logz[-1])."""
+        w = np.exp(self["logwt"] - self["logz"][-1])
+        return w / w.sum()
+
+
+def merge_static_runs(dead_logl, niter, live_logl, dead_u=None, live_u=None,
+                      prior_transform=None, ncall=None):
+    """Combine R static runs of equal, constant nlive into ONE run with R*nlive
+    live points -- what the reference's utils.merge_runs / _merge_two
+    (utils.py:1817-1900, 2000-2226) produce for such runs.
+
+    Every point (a run's dead points in death order, then its final live points
+    in ascending log-likelihood) carries the number of live points its own run
+    had when it died (N for dead points; N, N-1, ..., 1 for the final ones);
+    the merged sequence is ordered by log-likelihood (stable) and each point
+    shrinks the prior volume by n/(n+1) with n the summed live count; weights,
+    ln Z, information and var[ln Z] follow utils.compute_integrals
+    (utils.py:1411-1467).
+
+    dead_logl: (R, >=max niter), niter: (R,), live_logl: (R, N) in slot order;
+    dead_u: (R, >=max niter, D) and live_u: (R, N, D) optional (posterior
+    samples); prior_transform: optional callable mapping an (n, D) array of
+    unit-cube points to parameters (gives `samples`).
+
+    Returns a MergedRun with niter, logl, logvol, logwt, logz, logzerr,
+    information (all per point, cumulative where the reference's are),
+    samples_n, samples_run (run index of each point), samples_it (index within
+    its run's own sequence) and, with coordinates given, samples_u / samples."""
+    from .nested import _integrate_full
     dead_logl = np.asarray(dead_logl)
     live_logl = np.asarray(live_logl)
     R, N = live_logl.shape
-    ls, ns = [], []
+    ls, ns, rs, its, us = [], [], [], [], []
     for r in range(R):
-        d = dead_logl[r, :int(niter[r])]
-        fl = np.sort(live_logl[r])
-        ls.append(np.concatenate([d, fl]))
+        k = int(niter[r])
+        d = dead_logl[r, :k]
+        lo = np.argsort(live_logl[r], kind="stable")
+        ls.append(np.concatenate([d, live_logl[r][lo]]))
         # change of this run's live count AFTER each of its points dies
-        ns.append(np.concatenate([np.zeros(len(d)), -np.ones(N)]))
+        ns.append(np.concatenate([np.zeros(k), -np.ones(N)]))
+        rs.append(np.full(k + N, r, dtype=np.int64))
+        its.append(np.arange(k + N, dtype=np.int64))
+        if dead_u is not None:
+            us.append(np.concatenate([np.asarray(dead_u[r][:k]),
+                                      np.asarray(live_u[r])[lo]]))
     logl = np.concatenate(ls)
     dn = np.concatenate(ns)
     order = np.argsort(logl, kind="stable")
     logl, dn = logl[order], dn[order]
     nlive_at = R * N + np.concatenate([[0.], np.cumsum(dn)[:-1]])
     logvol = -np.cumsum(np.log((nlive_at + 1.) / nlive_at))
-    from .nested import _integrate
-    logwt, logz, h, logzvar = _integrate(logl, logvol)
-    return float(logz[-1]), float(np.sqrt(logzvar))
+    logwt, logz, h, logzvar = _integrate_full(logl, logvol)
+    out = MergedRun(niter=len(logl), logl=logl, logvol=logvol, logwt=logwt,
+                    logz=logz, logzerr=np.sqrt(logzvar), information=h,
+                    samples_n=nlive_at.astype(np.int64),
+                    samples_run=np.concatenate(rs)[order],
+                    samples_it=np.concatenate(its)[order])
+    if ncall is not None:
+        out["ncall"] = int(np.sum(ncall))
+        out["eff"] = 100. * len(logl) / out["ncall"]
+    if us:
+        out["samples_u"] = np.concatenate(us)[order]
+        if prior_transform is not None:
+            out["samples"] = np.asarray(prior_transform(out["samples_u"]))
+    return out
+
+
+def merge_logz(dead_logl, niter, live_logl):
+    """(logz, logzerr) of the merged run (see merge_static_runs)."""
+    m = merge_static_runs(dead_logl, niter, live_logl)
+    return float(m["logz"][-1]), float(m["logzerr"][-1])
+
+
+def run_ensemble_merged(prob, runs, nlive=2000, queue_size=512, entropy=(21,),
+                        max_iter=None, **kw):
+    """`runs` static runs on the device (dh_ns_ensemble) merged into one
+    MergedRun with posterior samples: the single-process form of BASELINE C5's
+    "gather of logZ / posterior samples"."""
+    from .backend import get_backend
+    be = get_backend()
+    if max_iter is None:
+        max_iter = 80 * nlive  # > nlive * (H + ln(1/dlogz)) for the benchmark problems
+    r = be.ns_ensemble(prob, runs, nlive, queue_size, entropy=entropy,
+                       max_iter=max_iter, want_samples=True, **kw)
+    if (r["status"] != 0).any():
+        raise RuntimeError(f"ns_ensemble: runs failed, status {r['status']}")
+
+    def ptform(u):
+        return be.problem_eval(prob, u)[0]
+    m = merge_static_runs(r["dead_logl"], r["niter"], r["live_logl"],
+                          r["dead_u"], r["live_u"], prior_transform=ptform,
+                          ncall=r["ncall"])
+    m["runs"] = r
+    return m
 
 
 def combine_logz(table):

@@ -36,9 +36,10 @@ class RunResult(dict):
     __getattr__ = dict.get
 
 
-def _integrate(logl, logvol):
-    """ln Z and information from ordered (logl, logvol) with the trapezoid rule
-    (the arithmetic of utils.compute_integrals, utils.py:1411-1467)."""
+def _integrate_full(logl, logvol):
+    """Per-point ln weights, cumulative ln Z, information and var[ln Z] from
+    ordered (logl, logvol) with the trapezoid rule (the arithmetic of
+    utils.compute_integrals, utils.py:1411-1467)."""
     logl = np.asarray(logl)
     logvol = np.asarray(logvol)
     lpad = np.concatenate([[-1.e300], logl])
@@ -47,7 +48,8 @@ def _integrate(logl, logvol):
     logdvol = vpad[:-1] + np.log1p(-np.exp(vpad[1:] - vpad[:-1])) + math.log(.5)
     logwt = np.logaddexp(lpad[1:], lpad[:-1]) + logdvol
     logz = np.logaddexp.accumulate(logwt)
-    # information H and var[ln Z] = |sum dH * dlnX| (utils.py:1451-1466)
+    # incomplete information H_x = int_0^x L/Z ln L dX - Z_x/Z ln Z, normalised by the FINAL
+    # Z, and var[ln Z] = |cumsum dH * dlnX| (utils.py:1451-1466)
     lz = logz[-1]
     w0 = np.exp(lpad[:-1] - lz + logdvol)
     w1 = np.exp(lpad[1:] - lz + logdvol)
@@ -57,8 +59,14 @@ def _integrate(logl, logvol):
     saved_h = part - lz * np.exp(logz - lz)
     dh = np.diff(saved_h, prepend=0)
     dlogvol = -np.diff(vpad)
-    logzvar = float(np.abs(np.sum(dh * dlogvol)))
-    return logwt, logz, float(saved_h[-1]), logzvar
+    logzvar = np.abs(np.cumsum(dh * dlogvol))
+    return logwt, logz, saved_h, logzvar
+
+
+def _integrate(logl, logvol):
+    """ln weights, cumulative ln Z, final information and final var[ln Z]."""
+    logwt, logz, h, logzvar = _integrate_full(logl, logvol)
+    return logwt, logz, float(h[-1]), float(logzvar[-1])
 
 
 def run_static(prob, nlive=500, bound='multi', sample='rwalk', queue_size=None,

@@ -265,7 +265,11 @@ int dh_bound_draw(dh_ctx* ctx, const uint64_t* state4, int nsamp, int d, int m,
  * h, nbound, status (0 ok, 1 max_fills hit, -1 failed), eff%}.
  * dead_logl_out (optional): runs x max_iter dead-point log-likelihoods;
  * live_logl_out (optional): runs x nlive log-likelihoods of the final live points
- * (together they are what utils.merge_runs needs to combine the ensemble).
+ * (together they are what utils.merge_runs needs to combine the ensemble);
+ * dead_u_out (optional): runs x max_iter x ndim unit-cube coordinates of the dead
+ * points in death order (only the first niter rows of a run are written);
+ * live_u_out (optional): runs x nlive x ndim final live points (slot order, matching
+ * live_logl_out) -- the posterior samples of the runs.
  * rebuild_sync = 0 keeps the reference's schedule per run (rebuild when ncall has
  * advanced by update_interval, sampler.py:625-674); rebuild_sync = 1 lets every run
  * that already has a bound rebuild whenever ANY run of the ensemble is due (its
@@ -278,7 +282,7 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim,
                    double enlarge, int64_t max_fills, int64_t max_iter,
                    const uint32_t* entropy_words, int n_words, uint32_t first_run,
                    double* records, double* dead_logl_out, double* live_logl_out,
-                   int64_t* n_fills_out);
+                   double* dead_u_out, double* live_u_out, int64_t* n_fills_out);
 
 #ifdef __cplusplus
 }

@@ -106,3 +106,33 @@ def test_rebuild_sync_mode(ctx):
     # deterministic for a fixed ensemble
     again = ctx.ns_ensemble(prob, 16, rebuild_sync=True, **kw)
     np.testing.assert_array_equal(again["logz"], syn["logz"])
+
+
+def test_samples_and_merged_run(ctx):
+    """want_samples: the stored dead / live coordinates reproduce the stored
+    log-likelihoods, and the merged run (ensemble.merge_static_runs) gives the
+    analytic posterior moments and ln Z of the Gaussian test problem."""
+    from dynesty_amd import ensemble
+    prob = inputs.problem("G5")
+    m = ensemble.run_ensemble_merged(prob, 8, nlive=300, queue_size=64,
+                                     entropy=[9], walks=25, bound="multi",
+                                     dlogz=0.1, max_iter=20000)
+    r = m["runs"]
+    for run in range(8):
+        k = int(r["niter"][run])
+        _, ll = ctx.problem_eval(prob, r["dead_u"][run, :k])
+        np.testing.assert_allclose(ll, r["dead_logl"][run, :k], rtol=0, atol=1e-10)
+        _, ll = ctx.problem_eval(prob, r["live_u"][run])
+        np.testing.assert_allclose(ll, r["live_logl"][run], rtol=0, atol=1e-10)
+        assert (np.diff(r["dead_logl"][run, :k]) >= 0).all()
+    assert m.niter == int(r["niter"].sum()) + 8 * 300
+    assert (np.diff(m.logl) >= 0).all()
+    assert abs(m.logz[-1] - prob.logz_truth) < 5 * m.logzerr[-1] + 0.05
+    w = m.importance_weights()
+    mean = (w[:, None] * m.samples).sum(0)
+    var = (w[:, None] * (m.samples - mean) ** 2).sum(0)
+    # G5: unit-variance Gaussian posterior centred on 0 (prior is wide)
+    assert np.abs(mean).max() < 0.15
+    assert np.abs(var - 1.0).max() < 0.25
+    # the merged evidence is at least as tight as a single run's
+    assert m.logzerr[-1] < r["logzerr"].mean()

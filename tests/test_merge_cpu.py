@@ -37,3 +37,55 @@ def test_merge_logz_matches_reference_merge_runs():
     lz, err = ensemble.merge_logz(d, nit, np.array(live))
     np.testing.assert_allclose(lz, merged.logz[-1], rtol=0, atol=1e-10)
     np.testing.assert_allclose(err, merged.logzerr[-1], rtol=1e-9)
+
+
+def test_merge_static_runs_matches_reference_fields():
+    """Every per-point field of the merged run (order, live counts, volumes,
+    weights, cumulative ln Z / information / error, samples) equals the
+    reference's utils.merge_runs on static runs."""
+    dynesty = refshim.import_reference()
+    from dynesty import utils as dyu
+    import inputs
+    from dynesty_amd import ensemble
+    prob = inputs.problem("C1")
+    R, N = 3, 60
+    res = []
+    for s in range(R):
+        sm = dynesty.NestedSampler(prob.loglikelihood, prob.prior_transform, 3,
+                                   nlive=N, bound='single', sample='unif',
+                                   rstate=np.random.default_rng(100 + s))
+        sm.run_nested(dlogz=0.3, print_progress=False)
+        res.append(sm.results)
+    ref = dyu.merge_runs(res, print_progress=False)
+    nit = [r.niter for r in res]
+    dead_l = np.zeros((R, max(nit)))
+    dead_u = np.zeros((R, max(nit), 3))
+    live_l = np.zeros((R, N))
+    live_u = np.zeros((R, N, 3))
+    rng = np.random.default_rng(0)
+    for i, r in enumerate(res):
+        dead_l[i, :nit[i]] = r.logl[:nit[i]]
+        dead_u[i, :nit[i]] = r.samples_u[:nit[i]]
+        # the device hands the final live points over in SLOT order, not sorted
+        sl = rng.permutation(N)
+        live_l[i] = np.asarray(r.logl[nit[i]:])[sl]
+        live_u[i] = np.asarray(r.samples_u[nit[i]:])[sl]
+
+    def ptform(u):
+        return np.array([prob.prior_transform(x) for x in u])
+    m = ensemble.merge_static_runs(dead_l, nit, live_l, dead_u, live_u,
+                                   prior_transform=ptform,
+                                   ncall=[r.ncall.sum() for r in res])
+    assert m.niter == ref.niter
+    np.testing.assert_array_equal(m.logl, ref.logl)
+    np.testing.assert_array_equal(m.samples_n, ref.samples_n)
+    np.testing.assert_array_equal(m.samples_u, ref.samples_u)
+    np.testing.assert_allclose(m.samples, ref.samples, rtol=0, atol=1e-14)
+    np.testing.assert_allclose(m.logvol, ref.logvol, rtol=0, atol=1e-11)
+    np.testing.assert_allclose(m.logwt, ref.logwt, rtol=0, atol=1e-10)
+    np.testing.assert_allclose(m.logz, ref.logz, rtol=0, atol=1e-10)
+    np.testing.assert_allclose(m.information, ref.information, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(m.logzerr, ref.logzerr, rtol=1e-7, atol=1e-10)
+    w = m.importance_weights()
+    np.testing.assert_allclose(w, ref.importance_weights(), rtol=1e-9, atol=1e-300)
+    assert abs(m.eff - ref.eff) < 1e-9
