@@ -49,6 +49,10 @@ def cloud(name):
     if name == "small4":  # fewer than 4*ndim points: no split attempted
         rng = np.random.default_rng(107)
         return rng.uniform(0.2, 0.8, size=(12, 4))
+    if name == "egg13":  # c3 thinned: 13 well separated modes, N=1300
+        return cloud("c3")[::4][:1300]
+    if name == "c2s":  # c2 thinned to N=600 (25-D)
+        return cloud("c2")[:600]
     if name == "g200":  # 200-D, N=4000 (C4 rebuild input)
         rng = np.random.default_rng(108)
         return 0.5 + 0.05 * rng.standard_normal((4000, 200))
@@ -56,6 +60,9 @@ def cloud(name):
 
 
 CLOUDS_SMALL = ["c2", "c3", "g3", "two5", "ring2", "flat10", "small4"]
+# RadFriends / SupFriends fixtures: a blob, two separated blobs (clustering path), a ring
+# (one chained cluster), the 13-mode eggbox-like cloud thinned to 1300 points, C2-like 25-D
+CLOUDS_FRIENDS = ["g3", "two5", "ring2", "egg13", "c2s"]
 
 
 def problem(name):

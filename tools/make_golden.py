@@ -297,6 +297,69 @@ def gen_rng(out):
     print("wrote", out, len(g), "arrays")
 
 
+def gen_friends(out):
+    """RadFriends ('balls') / SupFriends ('cubes'): two successive updates (the
+    second clusters in the metric of the first), a bootstrap update, membership
+    index lists, scale_to_logvol and same-seed draws."""
+    from dynesty import bounding as db
+    from dynesty.utils import get_seed_sequence
+    import inputs
+    g = {}
+    for kind, cls in (("balls", db.RadFriends), ("cubes", db.SupFriends)):
+        for name in inputs.CLOUDS_FRIENDS:
+            if kind == "cubes" and name == "c2s":
+                # 25-D: the max-norm radius is far below the 2-norm linkage length, the second
+                # update finds 600 singleton clusters and the reference divides by hsmax = 0
+                continue
+            pts = inputs.cloud(name)
+            n, d = pts.shape
+            b = cls(d)
+            key = f"{kind}/{name}"
+            for step in (1, 2):
+                b.update(pts, rstate=np.random.default_rng(7), bootstrap=0)
+                for k in ("cov", "am", "axes", "axes_inv"):
+                    g[f"{key}/u{step}/{k}"] = np.array(getattr(b, k)).real
+                g[f"{key}/u{step}/logvol"] = np.float64(b.logvol)
+            b.ctrs = pts  # what Sampler.propose_live does (sampler.py:483-484); SupFriends.update leaves it unset
+            # membership of probe points: exact integer KAT
+            rng = np.random.default_rng(11)
+            probes = np.concatenate([pts[rng.integers(n, size=6)] + 0.3 * rng.standard_normal((6, d)) @ b.axes,
+                                     rng.uniform(size=(4, d))])
+            g[f"{key}/probes"] = probes
+            w = [b.within(x) for x in probes]
+            g[f"{key}/within_counts"] = np.array([len(x) for x in w], dtype=np.int64)
+            g[f"{key}/within_idx"] = np.concatenate(w).astype(np.int64) if sum(map(len, w)) else np.zeros(0, np.int64)
+            # draws from ONE generator
+            rs = np.random.default_rng(13)
+            g[f"{key}/samples"] = b.samples(12, rstate=rs)
+            g[f"{key}/samples_state_after"] = np.array(
+                [rs.bit_generator.state["state"]["state"] >> 64, rs.bit_generator.state["state"]["state"] & (2**64 - 1),
+                 rs.bit_generator.state["has_uint32"], rs.bit_generator.state["uinteger"]], dtype=np.uint64)
+            rs = np.random.default_rng(14)
+            xq = [b.sample(rstate=rs, return_q=True) for _ in range(8)]
+            g[f"{key}/sample_q_x"] = np.array([x for x, q in xq])
+            g[f"{key}/sample_q_q"] = np.array([q for x, q in xq], dtype=np.int64)
+            # enlarge
+            lv = b.logvol + np.log(1.25)
+            b.scale_to_logvol(lv)
+            for k in ("cov", "am", "axes", "axes_inv"):
+                g[f"{key}/scaled/{k}"] = np.array(getattr(b, k)).real
+            # bootstrap radius (3 replicas) from a fresh bound of the same kind
+            b2 = cls(d)
+            b2.update(pts, rstate=np.random.default_rng(7), bootstrap=0)
+            b2.update(pts, rstate=np.random.default_rng(9), bootstrap=3)
+            for k in ("cov", "am", "axes", "axes_inv"):
+                g[f"{key}/boot/{k}"] = np.array(getattr(b2, k)).real
+            g[f"{key}/boot/logvol"] = np.float64(b2.logvol)
+            # no-clustering variant
+            b3 = cls(d)
+            b3.update(pts, rstate=np.random.default_rng(7), bootstrap=0, use_clustering=False)
+            g[f"{key}/noclust/cov"] = np.array(b3.cov).real
+            g[f"{key}/noclust/logvol"] = np.float64(b3.logvol)
+    np.savez_compressed(out, **g)
+    print("wrote", out, len(g), "arrays")
+
+
 def gen_runs(out):
     """Short end-to-end reference runs (static NestedSampler) for the logZ
     gate.  C1 full run; C2/C3 are too slow to regenerate casually, their
@@ -322,7 +385,7 @@ if __name__ == "__main__":
     import_reference()
     gdir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(gdir, exist_ok=True)
-    which = sys.argv[1:] or ["bounding", "proposals", "rng", "runs"]
+    which = sys.argv[1:] or ["bounding", "proposals", "rng", "runs", "friends"]
     if "bounding" in which:
         gen_bounding(os.path.join(gdir, "bounding.npz"))
     if "proposals" in which:
@@ -331,3 +394,5 @@ if __name__ == "__main__":
         gen_rng(os.path.join(gdir, "rng.npz"))
     if "runs" in which:
         gen_runs(os.path.join(gdir, "runs.npz"))
+    if "friends" in which:
+        gen_friends(os.path.join(gdir, "friends.npz"))
