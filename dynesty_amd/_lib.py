@@ -92,6 +92,11 @@ SIGNATURES = {
     "dh_ns_ensemble": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _dbl, _dbl,
                             C.c_int64, C.c_int64, _vp, _i, _u32, _vp, _vp,
                             _vp, _vp, _vp, _vp]),
+    "dh_friends_update": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp,
+                               _vp, _vp, _vp, _vp]),
+    "dh_friends_within": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp]),
+    "dh_friends_draw": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp, _i, _vp,
+                             _vp, _vp]),
     "dh_bound_draw": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp,
                            _vp, _vp, _vp]),
 }
@@ -152,6 +157,25 @@ def pcg_state_words(bitgen):
     s, inc = st["state"]["state"], st["state"]["inc"]
     m = (1 << 64) - 1
     return np.array([s >> 64, s & m, inc >> 64, inc & m], dtype=np.uint64)
+
+
+def pcg_state6(bitgen):
+    """(6,) uint64: pcg_state_words + {has_uint32, uinteger} (the buffered half
+    of numpy's 32-bit draws, which Generator.integers(n) consumes)."""
+    st = bitgen.state
+    return np.concatenate([pcg_state_words(bitgen),
+                           np.array([st["has_uint32"], st["uinteger"]],
+                                    dtype=np.uint64)])
+
+
+def set_pcg_state6(bitgen, words):
+    st = bitgen.state
+    w = [int(x) for x in words]
+    st["state"]["state"] = (w[0] << 64) | w[1]
+    st["state"]["inc"] = (w[2] << 64) | w[3]
+    st["has_uint32"] = w[4]
+    st["uinteger"] = w[5]
+    bitgen.state = st
 
 
 def set_pcg_state_words(bitgen, words):
@@ -553,6 +577,59 @@ class Context:
             out["dead_u"] = dead_u
             out["live_u"] = live_u
         return out
+
+    # ---- RadFriends / SupFriends ------------------------------------------
+    def friends_update(self, points, kind, am_prev=None, in_masks=None):
+        """RadFriends.update / SupFriends.update (dh_friends_update).
+        kind 'balls' | 'cubes'; am_prev = previous metric (None: no
+        clustering); in_masks = (B, n) bool resampling masks or None (LOO)."""
+        pts = _f64(points)
+        n, d = pts.shape
+        prev = None if am_prev is None else _f64(am_prev)
+        nb, mk = 0, None
+        if in_masks is not None and len(in_masks):
+            mk = np.ascontiguousarray(in_masks, dtype=np.uint8)
+            nb = mk.shape[0]
+        cov = np.empty((d, d)); am = np.empty((d, d))
+        axes = np.empty((d, d)); axes_inv = np.empty((d, d))
+        lv = C.c_double(0.); rmax = C.c_double(0.); ncl = C.c_int32(0)
+        self._check(self.lib.dh_friends_update(
+            self.handle, _ptr(pts), n, d, 0 if kind == 'balls' else 1,
+            _ptr(prev), nb, _ptr(mk), _ptr(cov), _ptr(am), _ptr(axes),
+            _ptr(axes_inv), C.byref(lv), C.byref(rmax), C.byref(ncl)))
+        return dict(cov=cov, am=am, axes=axes, axes_inv=axes_inv,
+                    logvol=lv.value, rmax=rmax.value, nclusters=ncl.value)
+
+    def friends_within(self, ctrs, kind, axes_inv, x, want_bits=False):
+        """Counts (and optionally index bit rows) of the balls / cubes that
+        contain each row of x (dh_friends_within)."""
+        c = _f64(ctrs)
+        n, d = c.shape
+        xs = _f64(x).reshape(-1, d)
+        m = xs.shape[0]
+        counts = np.empty(m, dtype=np.int32)
+        bits = np.empty((m, (n + 63) // 64), dtype=np.uint64) if want_bits \
+            else None
+        self._check(self.lib.dh_friends_within(
+            self.handle, _ptr(c), n, d, 0 if kind == 'balls' else 1,
+            _ptr(_f64(axes_inv)), _ptr(xs), m, _ptr(counts), _ptr(bits)))
+        return counts, bits
+
+    def friends_draw(self, state6, nsamp, ctrs, kind, axes, axes_inv,
+                     return_q=False):
+        """Bound.samples from one generator state (dh_friends_draw)."""
+        c = _f64(ctrs)
+        n, d = c.shape
+        st = np.ascontiguousarray(state6, dtype=np.uint64)
+        xs = np.empty((nsamp, d))
+        qs = np.empty(nsamp, dtype=np.int32)
+        out = np.empty(6, dtype=np.uint64)
+        self._check(self.lib.dh_friends_draw(
+            self.handle, _ptr(st), int(nsamp), _ptr(c), n, d,
+            0 if kind == 'balls' else 1, _ptr(_f64(axes)),
+            _ptr(_f64(axes_inv)), 1 if return_q else 0, _ptr(xs), _ptr(qs),
+            _ptr(out)))
+        return xs, qs, out
 
     def bound_draw(self, state4, nsamp, ctrs, axes, ams=None, logvol_ells=None,
                    return_q=False):

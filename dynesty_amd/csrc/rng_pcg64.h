@@ -87,6 +87,22 @@ struct Pcg64 {
     buf32 = (uint32_t)(v >> 32);
     return (uint32_t)v;
   }
+  // Generator.integers(n) for n <= 2^32 (rng = n - 1 < 0xFFFFFFFF): numpy distributions.c
+  // bounded_lemire_uint32 on the buffered 32-bit stream
+  __host__ __device__ __forceinline__ uint32_t bounded_lemire32(uint32_t rng) {
+    if (rng == 0) return 0;
+    const uint32_t rng_excl = rng + 1u;
+    uint64_t m = (uint64_t)next32() * rng_excl;
+    uint32_t leftover = (uint32_t)m;
+    if (leftover < rng_excl) {
+      const uint32_t threshold = (0xFFFFFFFFu - rng) % rng_excl;
+      while (leftover < threshold) {
+        m = (uint64_t)next32() * rng_excl;
+        leftover = (uint32_t)m;
+      }
+    }
+    return (uint32_t)(m >> 32);
+  }
   // random_interval(max): uniform integer in [0, max], numpy distributions.c
   __host__ __device__ __forceinline__ uint64_t interval(uint64_t mx) {
     if (mx == 0) return 0;

@@ -284,6 +284,42 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim,
                    double* records, double* dead_logl_out, double* live_logl_out,
                    double* dead_u_out, double* live_u_out, int64_t* n_fills_out);
 
+/* ---- RadFriends / SupFriends (bounding.py:734-1263, 1651-1702) ----------------
+ * kind: 0 = 'balls' (RadFriends, Euclidean norm), 1 = 'cubes' (SupFriends, max norm).
+ * All matrices are d x d row-major host arrays; axes = sqrtm(cov) and axes_inv = pinvh(axes)
+ * are symmetric, am = pinvh(cov).
+ *
+ * dh_friends_update = RadFriends.update / SupFriends.update (bounding.py:876-957, 1141-1222):
+ * covariance of the points after re-centring every single-linkage cluster (cut at Mahalanobis
+ * distance 1 in the PREVIOUS metric am_prev, evaluated with the arithmetic of scipy's pdist so
+ * that the knife-edge pair -- the radius puts the loneliest point exactly at distance 1 -- falls
+ * the reference's way; NULL = use_clustering=False), its symmetric square root and pseudo-inverses, the points in
+ * the whitened frame, and the radius / half-side = max nearest-neighbour distance: leave-one-out
+ * (nboot = 0) or, per bootstrap replica b, from the left-out points to the resampled ones
+ * (in_mask[b*n + i] != 0 iff point i was resampled; the index bookkeeping of
+ * _bootstrap_points, bounding.py:1593-1616, stays on the host).  Outputs are already scaled by
+ * the radius (cov r^2, am / r^2, axes r, axes_inv / r); logvol = ln volume of ONE shape.
+ * DH_ERR_VALUE: non-finite or singular covariance, or zero radius (the reference divides by 0). */
+int dh_friends_update(dh_ctx* ctx, const double* pts, int n, int d, int kind,
+                      const double* am_prev, int nboot, const uint8_t* in_mask,
+                      double* cov, double* am, double* axes, double* axes_inv,
+                      double* logvol, double* rmax, int32_t* nclusters);
+
+/* RadFriends.within / overlap / contains for m candidate points (bounding.py:777-793,
+ * 1043-1064): counts[c] = number of balls / cubes containing x_c; bits (optional,
+ * m x ceil(n/64) words) = which ones (bit j of word j/64). */
+int dh_friends_within(dh_ctx* ctx, const double* ctrs, int n, int d, int kind,
+                      const double* axes_inv, const double* x, int m, int32_t* counts,
+                      uint64_t* bits);
+
+/* RadFriends.sample(s) / SupFriends.sample(s) from ONE generator (bounding.py:795-847,
+ * 1066-1117), same draw order as the reference (balls: d normals + 1 uniform; cubes: d uniforms;
+ * then integers(n) on the buffered 32-bit stream when n > 1; then 1 uniform iff q > 1 and not
+ * return_q).  state6 = {state hi, state lo, inc hi, inc lo, has_uint32, uinteger}. */
+int dh_friends_draw(dh_ctx* ctx, const uint64_t* state6, int nsamp, const double* ctrs, int n,
+                    int d, int kind, const double* axes, const double* axes_inv, int return_q,
+                    double* xs, int32_t* qs, uint64_t* state6_out);
+
 #ifdef __cplusplus
 }
 #endif
