@@ -97,6 +97,9 @@ SIGNATURES = {
     "dh_friends_within": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp]),
     "dh_friends_draw": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp, _i, _vp,
                              _vp, _vp]),
+    "dh_unif_friends_batch": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _dbl,
+                                   _vp, _vp, C.c_int64, _vp, _vp, _vp, _vp,
+                                   _vp]),
     "dh_bound_draw": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp,
                            _vp, _vp, _vp]),
 }
@@ -526,6 +529,28 @@ class Context:
             _ptr(ax), _ptr(am), _ptr(cp), float(loglstar), _ptr(bcarr),
             _ptr(rng), int(max_tries), _ptr(u), _ptr(v), _ptr(logl), _ptr(nc),
             _ptr(rng_out)))
+        return dict(u=u, v=v, logl=logl, ncalls=nc, rng_out=rng_out)
+
+    def unif_friends_batch(self, prob, loglstar, rng_states, ctrs, kind, axes,
+                           axes_inv, bc=None, max_tries=0):
+        """Batched UniformBoundSampler.sample inside a RadFriends ('balls') /
+        SupFriends ('cubes') bound (dh_unif_friends_batch)."""
+        ndim = prob.ndim
+        rng = np.ascontiguousarray(rng_states, dtype=np.uint64).reshape(-1, 4)
+        k = rng.shape[0]
+        c = _f64(ctrs).reshape(-1, ndim)
+        bcarr = None if bc is None else np.ascontiguousarray(bc, dtype=np.int8)
+        u = np.empty((k, ndim))
+        v = np.empty((k, ndim))
+        logl = np.empty(k)
+        nc = np.empty(k, dtype=np.int32)
+        rng_out = np.empty((k, 4), dtype=np.uint64)
+        self._check(self.lib.dh_unif_friends_batch(
+            self.handle, self.problem(prob), k, ndim,
+            0 if kind == 'balls' else 1, _ptr(c), c.shape[0],
+            _ptr(_f64(axes)), _ptr(_f64(axes_inv)), float(loglstar),
+            _ptr(bcarr), _ptr(rng), int(max_tries), _ptr(u), _ptr(v),
+            _ptr(logl), _ptr(nc), _ptr(rng_out)))
         return dict(u=u, v=v, logl=logl, ncalls=nc, rng_out=rng_out)
 
     def ns_ensemble(self, prob, runs, nlive, queue_size, walks=None,

@@ -23,6 +23,29 @@ def _split(points, seed):
     return points[sel], points[~sel]
 
 
+def resample_mask(n, seed):
+    """The `sel_in` mask of bounding.py:1593-1616 for n points."""
+    rstate = seed if isinstance(seed, np.random.Generator) else \
+        np.random.Generator(np.random.PCG64(seed))
+    idxs = rstate.integers(n, size=n)
+    sel = np.zeros(n, dtype=bool)
+    sel[np.unique(idxs)] = True
+    n_in = sel.sum()
+    if n_in < 2:
+        sel[:2] = True
+    if n_in > n - 1:
+        sel[0] = False
+    return sel
+
+
+def resample_masks(n, rstate, bootstrap):
+    """(bootstrap, n) masks from get_seed_sequence(rstate, bootstrap)
+    (utils.py:1002-1009)."""
+    seeds = np.random.SeedSequence(rstate.integers(0, 2**63 - 1,
+                                                   size=4)).spawn(bootstrap)
+    return np.array([resample_mask(n, s) for s in seeds])
+
+
 def expand_one(multi, points, seed):
     """bounding.py:1619-1648."""
     be = get_backend()

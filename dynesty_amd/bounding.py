@@ -318,3 +318,145 @@ class HipMultiEllipsoid(HipBound):
         idx = min(np.searchsorted(np.cumsum(probs), rstate.random()),
                   len(probs) - 1)
         return self.axes_ells[idx]
+
+
+# ---------------------------------------------------------------------------
+# RadFriends / SupFriends (bounding.py:734-1263)
+# ---------------------------------------------------------------------------
+def _sym_funcs(cov):
+    """(pinvh(cov), sqrtm(cov), pinvh(sqrtm(cov))) of a symmetric PSD matrix from
+    one eigendecomposition (what the reference gets from three LAPACK calls,
+    bounding.py:755-758)."""
+    lam, vec = np.linalg.eigh(np.asarray(cov, dtype=np.float64))
+    d = len(lam)
+    eps = np.finfo(float).eps
+    top = np.abs(lam).max()
+    rt = np.sqrt(np.clip(lam, 0., None))
+    inv = np.where(np.abs(lam) > d * eps * top, 1. / np.where(lam == 0, 1., lam), 0.)
+    rinv = np.where(rt > d * eps * np.sqrt(top), 1. / np.where(rt == 0, 1., rt), 0.)
+    return (vec * inv) @ vec.T, (vec * rt) @ vec.T, (vec * rinv) @ vec.T
+
+
+class _HipFriends(HipBound):
+    """A collection of N-balls / N-cubes of one common shape centred on every
+    live point; the centres must be set in ``.ctrs`` (the sampler does it,
+    sampler.py:483-484)."""
+    kind = None
+
+    def __init__(self, ndim, cov=None):
+        super().__init__(ndim)
+        self.need_centers = True
+        if cov is None:
+            cov = np.identity(self.ndim)
+        self.cov = np.array(cov, dtype=np.float64)
+        self.am, self.axes, self.axes_inv = _sym_funcs(self.cov)
+        self.logvol = self._shape_logvol()
+        self.funit = 1
+        self.ctrs = []  # placeholder
+
+    def _shape_logvol(self):
+        sign, detln = np.linalg.slogdet(self.am)
+        if not sign > 0:
+            raise ValueError('Singular matrix')  # bounding.py _slogdet_checked
+        pref = logvol_prefactor(self.ndim) if self.kind == 'balls' else \
+            self.ndim * math.log(2.)
+        return pref - 0.5 * detln
+
+    def scale_to_logvol(self, logvol):
+        """bounding.py:766-775, 1032-1041."""
+        f = np.exp((logvol - self.logvol) * (1.0 / self.ndim))
+        self.cov = self.cov * f**2
+        self.am = self.am / f**2
+        self.axes = self.axes * f
+        self.axes_inv = self.axes_inv / f
+        self.logvol = logvol
+
+    # -- membership ---------------------------------------------------------------
+    def within(self, x):
+        """Indices of the shapes containing x (bounding.py:777-784, 1043-1051)."""
+        ctrs = np.asarray(self.ctrs, dtype=np.float64)
+        _, bits = get_backend().friends_within(ctrs, self.kind, self.axes_inv,
+                                               np.asarray(x)[None],
+                                               want_bits=True)
+        b = np.unpackbits(bits[0].view(np.uint8), bitorder="little")[:len(ctrs)]
+        return np.nonzero(b)[0]
+
+    def overlap(self, x):
+        """bounding.py:786-791, 1053-1059."""
+        counts, _ = get_backend().friends_within(
+            np.asarray(self.ctrs, dtype=np.float64), self.kind, self.axes_inv,
+            np.asarray(x)[None])
+        return int(counts[0])
+
+    def contains(self, x):
+        """bounding.py:793-796, 1061-1064."""
+        return self.overlap(x) > 0
+
+    # -- draws ------------------------------------------------------------------
+    def _draw(self, rstate, nsamp, return_q=False):
+        bitgen = rstate.bit_generator
+        xs, qs, out = get_backend().friends_draw(
+            _lib.pcg_state6(bitgen), nsamp, np.asarray(self.ctrs, dtype=np.float64),
+            self.kind, self.axes, self.axes_inv, return_q)
+        _lib.set_pcg_state6(bitgen, out)
+        return xs, qs
+
+    def sample(self, rstate=None, return_q=False):
+        """bounding.py:798-831, 1066-1101."""
+        xs, qs = self._draw(rstate, 1, return_q)
+        return (xs[0], int(qs[0])) if return_q else xs[0]
+
+    def samples(self, nsamples, rstate=None):
+        """bounding.py:833-847, 1103-1117."""
+        return self._draw(rstate, nsamples)[0]
+
+    def monte_carlo_logvol(self, ndraws=10000, rstate=None,
+                           return_overlap=True):
+        """bounding.py:849-874, 1119-1139."""
+        xs, qs = self._draw(rstate, ndraws, return_q=True)
+        invq = 1. / qs
+        qsum = invq.sum()
+        logvol = np.log(1. / ndraws * qsum * len(self.ctrs)) + self.logvol
+        if return_overlap:
+            inside = (xs.min(axis=1) > 0) & (xs.max(axis=1) < 1)
+            return logvol, (invq * inside).sum() / qsum
+        return logvol
+
+    # -- rebuild ----------------------------------------------------------------
+    def update(self, points, rstate=None, bootstrap=0, pool=None,
+               mc_integrate=False, use_clustering=True):
+        """bounding.py:876-957, 1141-1222: covariance from the re-centred
+        single-linkage clusters (in the metric of the previous update), its
+        square root / pseudo-inverses, radius = largest nearest-neighbour
+        distance in the whitened frame (leave-one-out, or from the left-out to the
+        resampled points of `bootstrap` replicas) -- one device call."""
+        points = np.asarray(points, dtype=np.float64)
+        masks = None
+        if bootstrap > 0:
+            from .bootstrap import resample_masks
+            masks = resample_masks(len(points), rstate, bootstrap)
+        res = get_backend().friends_update(
+            points, self.kind, am_prev=self.am if use_clustering else None,
+            in_masks=masks)
+        self.ndim = points.shape[1]
+        self.cov, self.am = res["cov"], res["am"]
+        self.axes, self.axes_inv = res["axes"], res["axes_inv"]
+        self.logvol = float(res["logvol"])
+        self.ctrs = points
+        if mc_integrate:
+            self.funit = self.monte_carlo_logvol(return_overlap=True,
+                                                 rstate=rstate)[1]
+
+    def get_random_axes(self, rstate):
+        """bounding.py:995-996."""
+        return self.axes
+
+
+class HipRadFriends(_HipFriends):
+    """N-balls (Euclidean norm).  bounding.py:734-996."""
+    kind = 'balls'
+
+
+class HipSupFriends(_HipFriends):
+    """N-cubes (max norm).  bounding.py:999-1263."""
+    kind = 'cubes'

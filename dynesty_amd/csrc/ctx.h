@@ -115,6 +115,8 @@ int enlarge_launch_masked(dh_ctx* ctx, int runs, int max_ells, const int32_t* ne
                           double* ams, double* axes, double* axlens, double* logvols, double log_enlarge,
                           const int* active);
 int eval_launch_dev(dh_ctx* ctx, int problem, int k, const double* u, double* v, double* logl);
+// friends.hip: Y = X M (n x d times d x d) on the context's stream, device pointers
+int friends_whiten_launch(dh_ctx* ctx, const double* X, const double* M, int n, int d, double* Y);
 
 // wide-D path (wide.hip): used by the dispatchers when the dimension exceeds the
 // register-resident limits.  kind: 0 rwalk, 1 rslice, 2 slice, 3 unit cube.

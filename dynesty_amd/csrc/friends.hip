@@ -446,6 +446,12 @@ int launch_ok(dh_ctx* ctx, const char* what) {
 
 }  // namespace
 
+int dh::friends_whiten_launch(dh_ctx* ctx, const double* X, const double* M, int n, int d, double* Y) {
+  const size_t nd = (size_t)n * d;
+  hipLaunchKernelGGL(fr_matmul, dim3((int)((nd + kT - 1) / kT)), dim3(kT), (size_t)d * d * 8, ctx->stream, X, M, n, d, Y);
+  return hip_ok(ctx, hipGetLastError(), "friends whiten launch") ? DH_OK : DH_ERR_HIP;
+}
+
 extern "C" {
 
 // see include/dynhip.h

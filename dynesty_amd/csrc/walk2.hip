@@ -374,6 +374,11 @@ struct UnifArgs {
   const double* axes_t;    // m x N x N (padded, transposed)
   const double* ams_p;     // m x N x N (padded precision matrices)
   const double* cumprob;   // m   cumsum(exp(logvol_ells - logvol))
+  // RadFriends / SupFriends bound (fr_kind 0 balls, 1 cubes, -1: ellipsoids): m == 1, axes_t =
+  // the common shape sqrtm(cov), ams_p = its pseudo-inverse axes_inv (both symmetric, padded)
+  int fr_kind, fr_n;
+  const double* fr_ctrs;   // fr_n x ncdim centres (the live points)
+  const double* fr_ct;     // fr_n x ncdim centres in the whitened frame (ctrs . axes_inv)
   const int8_t* bc;        // ndim or null (nonbounded mask semantics)
   const uint64_t* rng_in;
   int64_t max_tries;     // guard against a bound that cannot reach loglstar
@@ -429,6 +434,64 @@ __global__ void __launch_bounds__(64, 2) unif_kernel(UnifArgs a) {
         for (int i = 0; i < N; ++i) x[i] = (FULL || i < n) ? sx[i * 64 + lane] : 0.5;
         cand = true;
       } else {
+        bool accept = true;
+        if (a.fr_kind >= 0) {
+          // RadFriends.sample / SupFriends.sample (bounding.py:795-831, 1066-1101): a point of the
+          // common shape around a random centre, kept with probability 1/q, q = number of shapes
+          // that contain it.  Draw order: balls nc normals + 1 uniform, cubes nc uniforms; then
+          // integers(n) (buffered 32-bit Lemire) when n > 1; then 1 uniform iff q > 1.
+          double fac = 1.0;
+          if (a.fr_kind == 0) {
+            double ss = 0.0;
+#pragma unroll 1
+            for (int i = 0; i < nc; ++i) {
+              const double z = std_normal(g, &zig);
+              sx[i * 64 + lane] = z;
+              ss = fma(z, z, ss);
+            }
+            fac = pow(g.next_double(), inv_nc) / sqrt(ss);
+          } else {
+#pragma unroll 1
+            for (int i = 0; i < nc; ++i) sx[i * 64 + lane] = -1.0 + 2.0 * g.next_double();
+          }
+          int idx = 0;
+          if (a.fr_n > 1) idx = (int)g.bounded_lemire32((uint32_t)(a.fr_n - 1));
+#pragma unroll
+          for (int i = 0; i < N; ++i) acc[i] = 0.0;
+          matvec_sgpr<N>(as_const(a.axes_t), sx, lane, nc, acc);
+          const double* c = a.fr_ctrs + (size_t)idx * nc;
+#pragma unroll
+          for (int i = 0; i < N; ++i) x[i] = (FULL || i < nc) ? fma(fac, acc[i], c[i]) : 0.5;
+          if (a.fr_n > 1) {
+            // whitened candidate y = x . axes_inv, then brute force over the centres
+            // (wave-uniform rows through the scalar cache)
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+              if (FULL || i < nc) sx[i * 64 + lane] = x[i];
+#pragma unroll
+            for (int i = 0; i < N; ++i) acc[i] = 0.0;
+            matvec_sgpr<N>(as_const(a.ams_p), sx, lane, nc, acc);
+            int q = 0;
+            for (int j = 0; j < a.fr_n; ++j) {
+              cdptr cj = as_const(a.fr_ct + (size_t)j * nc);
+              double sd = 0.0;
+#pragma unroll
+              for (int i = 0; i < N; ++i) {
+                if (FULL || i < nc) {
+                  const double e = cj[i] - acc[i];
+                  sd = a.fr_kind == 0 ? fma(e, e, sd) : fmax(sd, fabs(e));
+                }
+              }
+              q += (a.fr_kind == 0 ? sqrt(sd) : sd) <= 1.0 ? 1 : 0;
+            }
+            // q == 0: rounding put the draw outside its own shape (the reference divides by
+            // zero there); it is simply redrawn
+            if (q == 0)
+              accept = false;
+            else if (q > 1)
+              accept = g.next_double() < (1.0 / (double)q);
+          }
+        } else {
         int idx = 0;
         if (a.m > 1) {
           // rand_choice (bounding.py:1300-1308): searchsorted(cumsum(pb), U)
@@ -457,7 +520,6 @@ __global__ void __launch_bounds__(64, 2) unif_kernel(UnifArgs a) {
         const double* c = a.ctrs + (size_t)idx * nc;
 #pragma unroll
         for (int i = 0; i < N; ++i) x[i] = (FULL || i < nc) ? fma(fac, acc[i], c[i]) : 0.5;
-        bool accept = true;
         if (a.m > 1) {
           // q = number of ellipsoids containing x (strict), 1/q acceptance
           int q = 0, qloose = 0;
@@ -487,6 +549,7 @@ __global__ void __launch_bounds__(64, 2) unif_kernel(UnifArgs a) {
             }
           }
           if (accept && q > 1) accept = g.next_double() < (1.0 / (double)q);
+        }
         }
         if (accept) {
           // unitcheck(u, nonbounded[:n_cluster])
@@ -800,6 +863,37 @@ int dh_unif_batch_dev(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, int 
 
 }  // extern "C"
 
+namespace {
+
+int unif_dispatch(dh_ctx* ctx, const UnifArgs& a, int N) {
+  const int k = a.k, ndim = a.ndim, ncdim = a.ncdim;
+  const dim3 grid((k + 63) / 64), block(64);
+  const bool full = (ndim == N && ncdim == N);
+  const int kind = full ? problem_kind(a.prob.like_id, a.prob.prior_id) : KIND_GENERIC;
+#define L(NN, FF, KK) hipLaunchKernelGGL((unif_kernel<NN, FF, KK>), grid, block, 0, ctx->stream, a)
+#define X(NN)                              \
+  if (N == NN) {                           \
+    if (!full)                             \
+      L(NN, false, KIND_GENERIC);          \
+    else if (kind == KIND_PREC_AFFINE)     \
+      L(NN, true, KIND_PREC_AFFINE);       \
+    else if (kind == KIND_IID_AFFINE)      \
+      L(NN, true, KIND_IID_AFFINE);        \
+    else if (kind == KIND_EGGBOX_IDENTITY) \
+      L(NN, true, KIND_EGGBOX_IDENTITY);   \
+    else if (kind == KIND_IID_NORMAL)      \
+      L(NN, true, KIND_IID_NORMAL);        \
+    else                                   \
+      L(NN, true, KIND_GENERIC);           \
+  }
+  DH_DIM_LIST(X)
+#undef X
+#undef L
+  return hip_ok(ctx, hipGetLastError(), "unif launch") ? DH_OK : DH_ERR_HIP;
+}
+
+}  // namespace
+
 int dh::unif_launch_runs(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, int m, const double* ctrs,
                          const double* axes, const double* ams, const double* cumprob, double loglstar,
                          const int8_t* bc, const uint64_t* rng, int64_t max_tries, double* u, double* v,
@@ -846,6 +940,9 @@ int dh::unif_launch_runs(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, i
   a.axes_t = at;
   a.ams_p = ap;
   a.cumprob = cumprob;
+  a.fr_kind = -1;
+  a.fr_n = 0;
+  a.fr_ctrs = a.fr_ct = nullptr;
   a.bc = bc;
   a.rng_in = rng;
   a.max_tries = max_tries > 0 ? max_tries : ((int64_t)1 << 40);
@@ -858,29 +955,7 @@ int dh::unif_launch_runs(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, i
   a.zki = ctx->zki();
   a.zwi = ctx->zwi();
   a.zfi = ctx->zfi();
-  const dim3 grid((k + 63) / 64), block(64);
-  const bool full = (ndim == N && ncdim == N);
-  const int kind = full ? problem_kind(a.prob.like_id, a.prob.prior_id) : KIND_GENERIC;
-#define L(NN, FF, KK) hipLaunchKernelGGL((unif_kernel<NN, FF, KK>), grid, block, 0, ctx->stream, a)
-#define X(NN)                              \
-  if (N == NN) {                           \
-    if (!full)                             \
-      L(NN, false, KIND_GENERIC);          \
-    else if (kind == KIND_PREC_AFFINE)     \
-      L(NN, true, KIND_PREC_AFFINE);       \
-    else if (kind == KIND_IID_AFFINE)      \
-      L(NN, true, KIND_IID_AFFINE);        \
-    else if (kind == KIND_EGGBOX_IDENTITY) \
-      L(NN, true, KIND_EGGBOX_IDENTITY);   \
-    else if (kind == KIND_IID_NORMAL)      \
-      L(NN, true, KIND_IID_NORMAL);        \
-    else                                   \
-      L(NN, true, KIND_GENERIC);           \
-  }
-  DH_DIM_LIST(X)
-#undef X
-#undef L
-  return hip_ok(ctx, hipGetLastError(), "unif launch") ? DH_OK : DH_ERR_HIP;
+  return unif_dispatch(ctx, a, N);
 }
 
 extern "C" {
@@ -926,6 +1001,87 @@ int dh_unif_batch(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, int m, c
     if (fl[i] & 2)
       return fail(ctx, DH_ERR_ARG, "unif: walker %d exceeded max_tries without reaching loglstar", i);
   }
+  return DH_OK;
+}
+
+// UniformBoundSampler.sample over a queue with a RadFriends / SupFriends bound
+// (internal_samplers.py:243-340 + bounding.py:795-831, 1066-1101); see include/dynhip.h
+int dh_unif_friends_batch(dh_ctx* ctx, int problem, int k, int ndim, int kind, const double* ctrs, int n,
+                          const double* axes, const double* axes_inv, double loglstar, const int8_t* bc,
+                          const uint64_t* rng, int64_t max_tries, double* u, double* v, double* logl,
+                          int32_t* ncalls, uint64_t* rng_out) {
+  DH_CHECK_CTX(ctx);
+  if (k <= 0) return DH_OK;
+  if (!rng || !u || !v || !logl || !ncalls || !ctrs || !axes || !axes_inv || n < 1 || (kind != 0 && kind != 1))
+    return fail(ctx, DH_ERR_ARG, "unif_friends: bad arguments");
+  UnifArgs a;
+  if (!get_problem(ctx, problem, &a.prob)) return DH_ERR_ARG;
+  if (a.prob.ndim != ndim) return fail(ctx, DH_ERR_ARG, "problem ndim %d != %d", a.prob.ndim, ndim);
+  if (ndim > kMaxRegDim) return fail(ctx, DH_ERR_ARG, "unif_friends: ndim=%d > %d not built", ndim, kMaxRegDim);
+  arena_reset(ctx);
+  const size_t kd = (size_t)k * ndim, nd = (size_t)n * ndim, dd = (size_t)ndim * ndim;
+  int rc = arena_reserve(ctx, 2 * kd * 8 + 2 * nd * 8 + 2 * dd * 8 + (size_t)k * (8 + 8 + 64) + (size_t)ndim + 8192);
+  if (rc) return rc;
+  const double* d_c = arena_up(ctx, ctrs, nd);
+  const double* d_ax = arena_up(ctx, axes, dd);
+  const double* d_ai = arena_up(ctx, axes_inv, dd);
+  double* d_ct = (double*)arena_get(ctx, nd * 8);
+  const int8_t* d_bc = bc ? arena_up(ctx, bc, (size_t)ndim) : nullptr;
+  const uint64_t* d_rng = arena_up(ctx, rng, (size_t)k * 4);
+  double* d_u = (double*)arena_get(ctx, kd * 8);
+  double* d_v = (double*)arena_get(ctx, kd * 8);
+  double* d_l = (double*)arena_get(ctx, (size_t)k * 8);
+  int32_t* d_nc = (int32_t*)arena_get(ctx, (size_t)k * 4);
+  int32_t* d_fl = (int32_t*)arena_get(ctx, (size_t)k * 4);
+  uint64_t* d_ro = (uint64_t*)arena_get(ctx, (size_t)k * 32);
+  if (!d_c || !d_ax || !d_ai || !d_ct || !d_rng || !d_u || !d_v || !d_l || !d_nc || !d_fl || !d_ro)
+    return DH_ERR_NOMEM;
+  if ((rc = friends_whiten_launch(ctx, d_c, d_ai, n, ndim, d_ct))) return rc;
+  const int N = pad_dim(ndim);
+  if ((rc = ensure_axes_t(ctx, (size_t)2 * N * N * 8))) return rc;
+  double* at = ctx->axes_t;
+  double* ap = ctx->axes_t + (size_t)N * N;
+  hipLaunchKernelGGL(pad_mats_kernel, dim3((N * N + 255) / 256), dim3(256), 0, ctx->stream, d_ax, 1, ndim, N, 1, at);
+  hipLaunchKernelGGL(pad_mats_kernel, dim3((N * N + 255) / 256), dim3(256), 0, ctx->stream, d_ai, 1, ndim, N, 1, ap);
+  a.run_loglstar = nullptr;
+  a.run_mode = nullptr;
+  a.wpr = 1;
+  a.my_mode = 0;
+  a.k = k;
+  a.ndim = ndim;
+  a.ncdim = ndim;
+  a.m = 1;
+  a.loglstar = loglstar;
+  a.ctrs = d_c;
+  a.axes_t = at;
+  a.ams_p = ap;
+  a.cumprob = nullptr;
+  a.fr_kind = kind;
+  a.fr_n = n;
+  a.fr_ctrs = d_c;
+  a.fr_ct = d_ct;
+  a.bc = d_bc;
+  a.rng_in = d_rng;
+  a.max_tries = max_tries > 0 ? max_tries : ((int64_t)1 << 40);
+  a.u = d_u;
+  a.v = d_v;
+  a.logl = d_l;
+  a.ncalls = d_nc;
+  a.flags = d_fl;
+  a.rng_out = d_ro;
+  a.zki = ctx->zki();
+  a.zwi = ctx->zwi();
+  a.zfi = ctx->zfi();
+  if ((rc = unif_dispatch(ctx, a, N))) return rc;
+  std::vector<int32_t> fl((size_t)k);
+  if (!down(ctx, u, d_u, kd) || !down(ctx, v, d_v, kd) || !down(ctx, logl, d_l, (size_t)k) ||
+      !down(ctx, ncalls, d_nc, (size_t)k) || !down(ctx, fl.data(), d_fl, (size_t)k) ||
+      !down(ctx, rng_out, d_ro, (size_t)k * 4))
+    return DH_ERR_HIP;
+  if ((rc = dh_sync(ctx))) return rc;
+  for (int i = 0; i < k; ++i)
+    if (fl[i] & 2)
+      return fail(ctx, DH_ERR_ARG, "unif_friends: walker %d exceeded max_tries without reaching loglstar", i);
   return DH_OK;
 }
 

@@ -31,6 +31,16 @@ class HipMultiEllipsoid(_hb.HipMultiEllipsoid, _db.Bound):
     dynesty.bounding.MultiEllipsoid."""
 
 
+class HipRadFriends(_hb.HipRadFriends, _db.Bound):
+    """bound=HipRadFriends(ndim): device twin of dynesty.bounding.RadFriends
+    (bound='balls')."""
+
+
+class HipSupFriends(_hb.HipSupFriends, _db.Bound):
+    """bound=HipSupFriends(ndim): device twin of dynesty.bounding.SupFriends
+    (bound='cubes')."""
+
+
 class _ProblemMixin:
 
     def _attach_problem(self, kwargs):
@@ -71,7 +81,8 @@ class HipSliceSampler(_ProblemMixin, _dis.SliceSampler):
 
 class HipUniformBoundSampler(_ProblemMixin, _dis.UniformBoundSampler):
     """sample=HipUniformBoundSampler(problem=...); works with an ellipsoidal
-    bound (ours or the reference's 'single' / 'multi')."""
+    bound (ours or the reference's 'single' / 'multi') and with balls / cubes
+    (HipRadFriends / HipSupFriends or the reference's 'balls' / 'cubes')."""
 
     def __init__(self, **kwargs):
         super().__init__(**kwargs)

@@ -70,7 +70,8 @@ def _integrate(logl, logvol):
 
 
 def run_static(prob, nlive=500, bound='multi', sample='rwalk', queue_size=None,
-               walks=None, slices=None, rstate=None, dlogz=0.01, enlarge=1.25,
+               walks=None, slices=None, rstate=None, dlogz=0.01, enlarge=None,
+               bootstrap=None,
                maxiter=None, first_update_min_ncall=None,
                first_update_min_eff=10., verbose=False):
     """One static nested-sampling run on the device.  Returns a RunResult with
@@ -78,6 +79,12 @@ def run_static(prob, nlive=500, bound='multi', sample='rwalk', queue_size=None,
     be = get_backend()
     if rstate is None:
         rstate = np.random.default_rng()
+    # dynesty.py:186-193: uniform sampling bootstraps the bound (5 replicas) instead of
+    # enlarging it; everything else enlarges by 1.25 in volume
+    if bootstrap is None:
+        bootstrap = 5 if sample == 'unif' else 0
+    if enlarge is None:
+        enlarge = 1.0 if sample == 'unif' else 1.25
     nd = prob.ndim
     K = int(queue_size or max(1, nlive // 4))
     if walks is None:
@@ -115,9 +122,11 @@ def run_static(prob, nlive=500, bound='multi', sample='rwalk', queue_size=None,
     def rebuild():
         nonlocal bnd, nbound
         if bnd is None:
-            bnd = (bounding.HipMultiEllipsoid(nd) if bound == 'multi' else
-                   bounding.HipEllipsoid(nd))
-        bnd.update(live_u, rstate=rstate)
+            bnd = dict(multi=bounding.HipMultiEllipsoid,
+                       single=bounding.HipEllipsoid,
+                       balls=bounding.HipRadFriends,
+                       cubes=bounding.HipSupFriends)[bound](nd)
+        bnd.update(live_u, rstate=rstate, bootstrap=bootstrap)
         if enlarge != 1.:
             bnd.scale_to_logvol(bnd.logvol + math.log(enlarge))
         nbound += 1
@@ -130,7 +139,11 @@ def run_static(prob, nlive=500, bound='multi', sample='rwalk', queue_size=None,
             out = be.unif_batch(prob, loglstar, states)
             return out, None
         if sample == 'unif':
-            if bound == 'multi':
+            if bound in ('balls', 'cubes'):
+                # the shapes sit on the CURRENT live points (sampler.py:483-484)
+                out = be.unif_friends_batch(prob, loglstar, states, live_u,
+                                            bound, bnd.axes, bnd.axes_inv)
+            elif bound == 'multi':
                 out = be.unif_batch(prob, loglstar, states, ctrs=bnd.ctrs,
                                     axes=bnd.axes_ells, ams=bnd.ams,
                                     logvol_ells=bnd.logvol_ells)

@@ -239,6 +239,18 @@ def bound_arrays(bound):
         "uniform sampler supports Ellipsoid / MultiEllipsoid bounds")
 
 
+def friends_kind(bound):
+    """'balls' / 'cubes' for a RadFriends / SupFriends bound -- ours or the
+    reference's (duck-typed on axes_inv + need_centers; the reference's two
+    classes differ in their `within` norm, told apart by name)."""
+    if not (hasattr(bound, 'axes_inv') and getattr(bound, 'need_centers', False)):
+        return None
+    kind = getattr(bound, 'kind', None)
+    if kind is None:
+        kind = 'cubes' if 'Sup' in type(bound).__name__ else 'balls'
+    return kind
+
+
 def run_unif(args):
     """UniformBoundSampler.sample over a queue (internal_samplers.py:243-340)."""
     args = list(args)
@@ -247,17 +259,27 @@ def run_unif(args):
     a0 = args[0]
     prob = _problem_of(a0)
     kw = a0.kwargs
-    ctrs, axes, ams, lvs = bound_arrays(kw['bound'])
+    bound = kw['bound']
     streams = _Streams([a.rseed for a in args])
     bc = None
     nonb = kw.get('nonbounded')
     if nonb is not None:
         bc = np.where(np.asarray(nonb), _lib.BC_HARD,
                       _lib.BC_PERIODIC).astype(np.int8)
-    out = get_backend().unif_batch(prob, a0.loglstar, streams.states,
-                                   ctrs=ctrs, axes=axes, ams=ams,
-                                   logvol_ells=lvs, ncdim=kw['n_cluster'],
-                                   bc=bc)
+    fkind = friends_kind(bound)
+    if fkind is not None:
+        if kw['n_cluster'] != kw['ndim']:
+            raise ValueError("balls / cubes bounds need ncdim == ndim (their "
+                             "centres are the full live points)")
+        out = get_backend().unif_friends_batch(
+            prob, a0.loglstar, streams.states, np.asarray(bound.ctrs), fkind,
+            np.real(bound.axes), np.real(bound.axes_inv), bc=bc)
+    else:
+        ctrs, axes, ams, lvs = bound_arrays(bound)
+        out = get_backend().unif_batch(prob, a0.loglstar, streams.states,
+                                       ctrs=ctrs, axes=axes, ams=ams,
+                                       logvol_ells=lvs, ncdim=kw['n_cluster'],
+                                       bc=bc)
     streams.write_back(out["rng_out"])
     return [
         SamplerReturn(u=out["u"][i], v=out["v"][i],

@@ -320,6 +320,17 @@ int dh_friends_draw(dh_ctx* ctx, const uint64_t* state6, int nsamp, const double
                     int d, int kind, const double* axes, const double* axes_inv, int return_q,
                     double* xs, int32_t* qs, uint64_t* state6_out);
 
+/* UniformBoundSampler.sample over a queue of k walkers with a RadFriends / SupFriends bound
+ * (internal_samplers.py:243-340 with bounding.py:795-831 / 1066-1101 as bound.samples(1)):
+ * per try one draw from the union of shapes (1/q rule, brute-force overlap over the n centres),
+ * unitcheck, prior transform and likelihood of the device problem, until logl > loglstar.
+ * Same arguments and outputs as dh_unif_batch; ncdim == ndim (the reference's friends bounds
+ * need it too: their centres are the full live points). */
+int dh_unif_friends_batch(dh_ctx* ctx, int problem, int k, int ndim, int kind, const double* ctrs,
+                          int n, const double* axes, const double* axes_inv, double loglstar,
+                          const int8_t* bc, const uint64_t* rng, int64_t max_tries, double* u,
+                          double* v, double* logl, int32_t* ncalls, uint64_t* rng_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -7,6 +7,7 @@ multi-process sharding) where no GPU exists.  It is injected explicitly with
 import numpy as np
 
 from oracle import bounding_ref as B
+from oracle import friends_ref as F
 from oracle import proposals_ref as P
 
 
@@ -245,6 +246,96 @@ class OracleBackend:
                 r = P.unif_bound(loglstar, draw, prob.prior_transform,
                                  prob.loglikelihood, rng, nd, nc,
                                  nonbounded=nonb)
+            out["u"][i], out["v"][i], out["logl"][i] = r["u"], r["v"], r["logl"]
+            out["ncalls"][i] = r["ncalls"]
+            out["rng_out"][i] = _words(rng)
+        return out
+
+    # ---- RadFriends / SupFriends ---------------------------------------------------
+    @staticmethod
+    def _friends(kind, ctrs, axes, axes_inv):
+        ctrs = np.asarray(ctrs, dtype=np.float64)
+        d = ctrs.shape[1]
+        return F.Friends(kind, np.eye(d), np.asarray(axes_inv) @ np.asarray(axes_inv),
+                         np.asarray(axes), np.asarray(axes_inv), 0.0, ctrs)
+
+    def friends_update(self, points, kind, am_prev=None, in_masks=None):
+        points = np.asarray(points, dtype=np.float64)
+        d = points.shape[1]
+        fr = F.friends_init(kind, d)
+        if am_prev is not None:
+            fr.am = np.asarray(am_prev)
+        if in_masks is None or not len(in_masks):
+            out, info = F.friends_update(fr, points, use_clustering=am_prev is not None)
+        else:
+            # the oracle resamples from seeds; here the masks are given: same steps by hand
+            if am_prev is not None:
+                cov, ncl = F.covariance_from_clusters(points, fr.am)
+            else:
+                cov, ncl = np.cov(points, rowvar=False), 1
+            from scipy import linalg as sla
+            from scipy import spatial
+            am, axes = sla.pinvh(cov), sla.sqrtm(cov)
+            axes_inv = sla.pinvh(axes)
+            pt = points @ axes_inv
+            p = 2 if kind == 'balls' else np.inf
+            r = max(max(spatial.KDTree(pt[m]).query(pt[~m], k=1, eps=0, p=p)[0])
+                    for m in np.asarray(in_masks, dtype=bool))
+            am2 = am / r**2
+            out = F.Friends(kind, cov * r**2, am2, axes * r, axes_inv / r,
+                            F.shape_logvol(kind, d, am2), points)
+            info = dict(nclusters=ncl, rmax=float(r))
+        return dict(cov=np.real(out.cov), am=np.real(out.am), axes=np.real(out.axes),
+                    axes_inv=np.real(out.axes_inv), logvol=float(out.logvol),
+                    rmax=info["rmax"], nclusters=info["nclusters"])
+
+    def friends_within(self, ctrs, kind, axes_inv, x, want_bits=False):
+        ctrs = np.asarray(ctrs, dtype=np.float64)
+        n, d = ctrs.shape
+        xs = np.asarray(x, dtype=np.float64).reshape(-1, d)
+        fr = self._friends(kind, ctrs, np.eye(d), axes_inv)
+        counts = np.zeros(len(xs), dtype=np.int32)
+        bits = np.zeros((len(xs), (n + 63) // 64), dtype=np.uint64) if want_bits else None
+        for i, xi in enumerate(xs):
+            idx = F.friends_within(fr, xi)
+            counts[i] = len(idx)
+            if want_bits:
+                b = np.zeros(bits.shape[1] * 64, dtype=np.uint8)
+                b[idx] = 1
+                bits[i] = np.packbits(b, bitorder="little").view(np.uint64)
+        return counts, bits
+
+    def friends_draw(self, state6, nsamp, ctrs, kind, axes, axes_inv, return_q=False):
+        gen = _gen(state6[:4])
+        st = gen.bit_generator.state
+        st["has_uint32"], st["uinteger"] = int(state6[4]), int(state6[5])
+        gen.bit_generator.state = st
+        fr = self._friends(kind, ctrs, axes, axes_inv)
+        xs = np.empty((nsamp, fr.ndim))
+        qs = np.ones(nsamp, dtype=np.int32)
+        for i in range(nsamp):
+            if return_q:
+                xs[i], qs[i] = F.friends_sample(fr, gen, return_q=True)
+            else:
+                xs[i] = F.friends_sample(fr, gen)
+        st = gen.bit_generator.state
+        out = np.concatenate([_words(gen), np.array([st["has_uint32"], st["uinteger"]],
+                                                    dtype=np.uint64)])
+        return xs, qs, out
+
+    def unif_friends_batch(self, prob, loglstar, rng_states, ctrs, kind, axes,
+                           axes_inv, bc=None, max_tries=0):
+        rng_states = np.asarray(rng_states).reshape(-1, 4)
+        k, nd = rng_states.shape[0], prob.ndim
+        nonb = None if bc is None else (np.asarray(bc) == 0)
+        fr = self._friends(kind, ctrs, axes, axes_inv)
+        out = dict(u=np.empty((k, nd)), v=np.empty((k, nd)), logl=np.empty(k),
+                   ncalls=np.empty(k, np.int32), rng_out=np.empty((k, 4), np.uint64))
+        for i in range(k):
+            rng = _gen(rng_states[i])
+            r = P.unif_bound(loglstar, lambda g: F.friends_sample(fr, g),
+                             prob.prior_transform, prob.loglikelihood, rng, nd, nd,
+                             nonbounded=nonb)
             out["u"][i], out["v"][i], out["logl"][i] = r["u"], r["v"], r["logl"]
             out["ncalls"][i] = r["ncalls"]
             out["rng_out"][i] = _words(rng)

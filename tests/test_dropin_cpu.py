@@ -199,3 +199,64 @@ def test_rwalk_arbitrary_python_likelihood(dyn):
     s.run_nested(dlogz=1.0, print_progress=False)
     r = s.results
     assert abs(r.logz[-1] - (-3 * np.log(20.0))) < 5 * r.logzerr[-1] + 0.4
+
+
+@pytest.mark.parametrize("kind", ["balls", "cubes"])
+def test_friends_bounds_dropin(dyn, kind):
+    """bound=HipRadFriends / HipSupFriends in an unmodified NestedSampler, with
+    the batched uniform sampler (1/q rule over the live-point shapes) and with
+    rwalk (get_random_axes = the common shape)."""
+    import inputs
+    from dynesty import bounding as db
+    from dynesty_amd import dropin
+    prob = inputs.problem("C1")
+    cls = dict(balls=dropin.HipRadFriends, cubes=dropin.HipSupFriends)[kind]
+    assert issubclass(cls, db.Bound)
+    pool = dropin.HipBatchPool(queue_size=8)
+    s = run(dyn, prob, cls(3), dropin.HipUniformBoundSampler(problem=prob), pool=pool, nlive=120, dlogz=0.5)
+    r = s.results
+    assert abs(r.logz[-1] - prob.logz_truth) < 5 * r.logzerr[-1] + 0.15
+    assert isinstance(s.bound, cls) and s.nbound > 1
+    assert s.bound_bootstrap == 5  # dynesty's default for the uniform sampler
+    s2 = run(dyn, prob, cls(3), dropin.HipRWalkSampler(problem=prob, walks=15), nlive=100, dlogz=1.0)
+    r2 = s2.results
+    assert abs(r2.logz[-1] - prob.logz_truth) < 5 * r2.logzerr[-1] + 0.3
+
+
+@pytest.mark.parametrize("kind", ["balls", "cubes"])
+def test_friends_api_matches_reference(dyn, kind):
+    """Same attributes / method results as the reference classes on the same
+    inputs (update, scale_to_logvol, within / overlap / contains, same-seed
+    sample(s), monte_carlo_logvol, pickling)."""
+    import inputs
+    from dynesty import bounding as db
+    from dynesty_amd import dropin
+    pts = inputs.cloud("two5")
+    ours = dict(balls=dropin.HipRadFriends, cubes=dropin.HipSupFriends)[kind](5)
+    ref = dict(balls=db.RadFriends, cubes=db.SupFriends)[kind](5)
+    for b in (ours, ref):
+        b.update(pts, rstate=np.random.default_rng(1), bootstrap=0)
+        b.update(pts, rstate=np.random.default_rng(1), bootstrap=2)
+        b.scale_to_logvol(b.logvol + np.log(1.3))
+        b.ctrs = pts
+    for k in ("cov", "am", "axes", "axes_inv"):
+        np.testing.assert_allclose(getattr(ours, k), np.real(getattr(ref, k)), rtol=0,
+                                   atol=1e-12 * np.abs(getattr(ref, k)).max())
+    assert abs(ours.logvol - ref.logvol) < 1e-10
+    x = pts[3] + 0.01
+    np.testing.assert_array_equal(ours.within(x), ref.within(x))
+    assert ours.overlap(x) == ref.overlap(x) and ours.contains(x) == ref.contains(x)
+    assert not ours.contains(np.full(5, 5.0))
+    a, b = np.random.default_rng(3), np.random.default_rng(3)
+    np.testing.assert_allclose(ours.samples(5, rstate=a), ref.samples(5, rstate=b), atol=1e-13)
+    xa, qa = ours.sample(rstate=a, return_q=True)
+    xb, qb = ref.sample(rstate=b, return_q=True)
+    np.testing.assert_allclose(xa, xb, atol=1e-13)
+    assert qa == qb and a.random() == b.random()  # generators left in the same state
+    la, fa = ours.monte_carlo_logvol(200, rstate=np.random.default_rng(4))
+    lb, fb = ref.monte_carlo_logvol(200, rstate=np.random.default_rng(4))
+    assert abs(la - lb) < 1e-10 and abs(fa - fb) < 1e-12
+    assert ours.get_random_axes(a) is ours.axes
+    c = pickle.loads(pickle.dumps(copy.deepcopy(ours)))
+    np.testing.assert_array_equal(c.axes_inv, ours.axes_inv)
+    assert c.need_centers and c.kind == kind

@@ -120,3 +120,60 @@ def test_draws_same_seed(ctx, kind, name):
     xs, qs, _ = ctx.friends_draw(_lib.pcg_state6(rs.bit_generator), 8, pts, kind, axes, axes_inv, return_q=True)
     np.testing.assert_allclose(xs, GOLD[f"{key}/sample_q_x"], rtol=0, atol=1e-13)
     np.testing.assert_array_equal(qs, GOLD[f"{key}/sample_q_q"])
+
+
+@pytest.mark.parametrize("kind", ["balls", "cubes"])
+def test_unif_friends_batch_same_seed(ctx, kind):
+    """Batched UniformBoundSampler inside a friends bound: same streams as the
+    oracle (draw order incl. the buffered 32-bit integers and the 1/q uniform),
+    same accepted points and call counts."""
+    from oracle_backend import OracleBackend
+    prob = inputs.problem("C1")
+    rng = np.random.default_rng(2)
+    live = 0.5 + 0.06 * rng.standard_normal((300, 3))
+    fr = F.friends_init(kind, 3)
+    fr, _ = F.friends_update(fr, live)
+    fr = F.friends_scale_to_logvol(fr, fr.logvol + np.log(1.2))
+    _, ll = ctx.problem_eval(prob, live)
+    loglstar = float(np.sort(ll)[60])
+    states = ctx.seed_children(np.array([5, 6, 7, 8]), 0, 200)
+    dev = ctx.unif_friends_batch(prob, loglstar, states, live, kind, fr.axes, fr.axes_inv)
+    ref = OracleBackend().unif_friends_batch(prob, loglstar, states, live, kind, fr.axes, fr.axes_inv)
+    np.testing.assert_array_equal(dev["ncalls"], ref["ncalls"])
+    np.testing.assert_array_equal(dev["rng_out"], ref["rng_out"])
+    np.testing.assert_allclose(dev["u"], ref["u"], rtol=0, atol=1e-13)
+    np.testing.assert_allclose(dev["logl"], ref["logl"], rtol=1e-11, atol=1e-11)
+    assert (dev["logl"] > loglstar).all()
+
+
+@pytest.mark.parametrize("kind", ["balls", "cubes"])
+def test_host_classes_on_device(ctx, kind):
+    from dynesty_amd import bounding
+    pts = inputs.cloud("egg13")
+    b = dict(balls=bounding.HipRadFriends, cubes=bounding.HipSupFriends)[kind](2)
+    key = f"{kind}/egg13"
+    b.update(pts, rstate=np.random.default_rng(7))
+    close(b.cov, GOLD[f"{key}/u1/cov"])
+    b.am = GOLD[f"{key}/u1/am"]  # the reference's metric for the knife-edge linkage (see above)
+    b.update(pts, rstate=np.random.default_rng(7))
+    for k in ("cov", "am", "axes", "axes_inv"):
+        close(getattr(b, k), GOLD[f"{key}/u2/{k}"])
+    assert abs(b.logvol - GOLD[f"{key}/u2/logvol"]) < 1e-9
+    probes = GOLD[f"{key}/probes"]
+    assert [b.overlap(x) for x in probes] == list(GOLD[f"{key}/within_counts"])
+    assert b.contains(pts[0]) and not b.contains(np.array([5.0, 5.0]))
+    xs = b.samples(12, rstate=np.random.default_rng(13))
+    np.testing.assert_allclose(xs, GOLD[f"{key}/samples"], rtol=0, atol=1e-12)
+    lv, fu = b.monte_carlo_logvol(2000, rstate=np.random.default_rng(1))
+    assert lv < np.log(len(pts)) + b.logvol + 1e-9 and 0.0 < fu <= 1.0
+
+
+@pytest.mark.parametrize("kind,sample", [("balls", "unif"), ("cubes", "unif"), ("balls", "rwalk"), ("cubes", "rslice")])
+def test_end_to_end_c1(ctx, kind, sample):
+    """Full static run with bound='balls' / 'cubes' through the dynesty-free driver."""
+    from dynesty_amd import nested
+    prob = inputs.problem("C1")
+    r = nested.run_static(prob, nlive=300, bound=kind, sample=sample, queue_size=32,
+                          rstate=np.random.default_rng(17), dlogz=0.1)
+    assert abs(r.logz - prob.logz_truth) < 5 * r.logzerr + 0.1
+    assert r.nbound > 1
