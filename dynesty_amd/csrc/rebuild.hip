@@ -1658,6 +1658,11 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
   while ((1 << lv) < n / (2 * d) + 1) ++lv;
   a.levels = mode == 1 ? 0 : (2 * lv + 8);
   a.maxp = n / kThreads + a.maxw + 1;
+  // the parts of one node meet at a device-scope barrier, so they must all be resident at the
+  // same time: 256 parts (65 536 points per run) fit the 256 CUs with room to spare
+  if (mode == 0 && n > 256 * kThreads)
+    return fail(ctx, DH_ERR_ARG, "rebuild: MultiEllipsoid.update supports at most %d points per run (n = %d)",
+                256 * kThreads, n);
   a.ell_tp_small = rebuild_small_tile_ok(d) ? 1 : 0;
   const size_t lds_small = rebuild_lds_bytes(d, kSmallTile);
   // k_finish: tree (and result list) in LDS when they fit behind the standard layout
