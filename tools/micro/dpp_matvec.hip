@@ -194,6 +194,62 @@ __global__ void __launch_bounds__(64) kQ(const double* MT, const double* __restr
   for (int i = 0; i < N; ++i) out[(size_t)blockIdx.x * N * 64 + i * 64 + lane] = acc[i];
 }
 
+// M: the mat-vec of all 64 lanes as ONE GEMM on the fp64 matrix cores: C[i][n] = sum_k A[i][k] B[k][n],
+// A = the (wave-uniform) matrix held in registers for the whole kernel (no scalar loads per step),
+// B[k][n] = component k of lane n's vector read from the [dim][lane] LDS columns, C transposed back to
+// "lane n holds all components" through LDS.
+typedef double mfma4 __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(64) kM(const double* __restrict__ MT, const double* __restrict__ x,
+                                         double* out, int iters) {
+  __shared__ double xs[N * 64];
+  __shared__ double ys[NP * 64];
+  const int lane = threadIdx.x;
+  const int lj = lane & 15, lk = lane >> 4;
+  for (int j = 0; j < N; ++j) xs[j * 64 + lane] = x[(size_t)blockIdx.x * N * 64 + j * 64 + lane];
+  constexpr int KS = (N + 3) / 4;  // 7
+  double afr[2][KS];
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int k = ks * 4 + lk;
+      afr[mb][ks] = k < N ? MT[k * NP + mb * 16 + lj] : 0.0;
+    }
+  double acc[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) acc[i] = 0;
+  for (int it = 0; it < iters; ++it) {
+    mfma4 c[2][4];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) c[mb][nb] = (mfma4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int k = ks * 4 + lk;
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) {
+        const double b = k < N ? xs[k * 64 + nb * 16 + lj] : 0.0;
+        c[0][nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[0][ks], b, c[0][nb], 0, 0, 0);
+        c[1][nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[1][ks], b, c[1][nb], 0, 0, 0);
+      }
+    }
+    // C[row = lk + 4 r (+16 mb)][col = lj (+16 nb)] -> ys[row][lane = col]
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ys[(mb * 16 + lk + 4 * r) * 64 + nb * 16 + lj] = c[mb][nb][r];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < N; ++i) acc[i] += ys[i * 64 + lane];
+    xs[(it % N) * 64 + lane] = acc[it % N] * 1e-3;
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i) out[(size_t)blockIdx.x * N * 64 + i * 64 + lane] = acc[i];
+}
+
 int main(int argc, char** argv) {
   int blocks = argc > 1 ? atoi(argv[1]) : 2048, iters = argc > 2 ? atoi(argv[2]) : 90;
   std::vector<double> MT(N * NP, 0.0), x((size_t)blocks * N * 64);
@@ -222,17 +278,21 @@ int main(int argc, char** argv) {
     hipEventElapsedTime(&ml, e0, e1);
     printf("lds-bcast: %.3f ms %.2f TFLOP/s | ", ml, (double)blocks * 64 * iters * N * N * 2 / ml / 1e9);
     hipEventRecord(e0); kB<<<blocks, 64>>>(dM, dx, dB, iters); hipEventRecord(e1); hipEventSynchronize(e1);
+    float mm;
+    hipEventRecord(e0); kM<<<blocks, 64>>>(dM, dx, dB, iters); hipEventRecord(e1); hipEventSynchronize(e1);
+    hipEventElapsedTime(&mm, e0, e1);
+    printf("mfma: %.3f ms %.2f TFLOP/s | ", mm, (double)blocks * 64 * iters * N * N * 2 / mm / 1e9);
     double fl = (double)blocks * 64 * iters * N * N * 2;
     printf("sgpr: %.3f ms %.2f TFLOP/s | dpp: %.3f ms %.2f TFLOP/s\n", ma, fl / ma / 1e9, mb, fl / mb / 1e9);
   }
   kA<<<blocks, 64>>>(dM, dx, dA, iters);
-  kQ<<<blocks, 64>>>(dM, dx, dB, iters);
+  kM<<<blocks, 64>>>(dM, dx, dB, iters);
   hipDeviceSynchronize();
   std::vector<double> a(x.size()), b(x.size());
   hipMemcpy(a.data(), dA, a.size() * 8, hipMemcpyDeviceToHost);
   hipMemcpy(b.data(), dB, b.size() * 8, hipMemcpyDeviceToHost);
   double md = 0, mx = 0;
   for (size_t i = 0; i < a.size(); ++i) { md = fmax(md, fabs(a[i] - b[i])); mx = fmax(mx, fabs(a[i])); }
-  printf("max |sgpr - asm-block| = %.3e (max |val| %.3e) -> %s\n", md, mx, md <= 1e-12 * fmax(1.0, mx) ? "MATCH" : "MISMATCH");
+  printf("max |sgpr - mfma| = %.3e (max |val| %.3e) -> %s\n", md, mx, md <= 1e-12 * fmax(1.0, mx) ? "MATCH" : "MISMATCH");
   return 0;
 }
