@@ -79,7 +79,6 @@ struct RebuildArgs {
   // ("parts"), each keeping its TP points resident in LDS for all ten iterations
   int fin_extra_off;  // k_finish: byte offset of the LDS node/result-list copies (0: keep them in global memory)
   int fin_res_lds;    // 1: the result-list arena is in LDS too
-  int ell_tp_small;   // 1: k_ell of levels >= kSmallTileLevel is launched with the small-tile LDS layout
   int maxp;           // max parts of one run at one level: n / TP + maxw + 1
   int* nparts;        // (levels+1) x runs
   int* part_list;     // 2 x runs x maxp x 2   (by level parity): (slot in split_list, part index)
@@ -485,11 +484,7 @@ __device__ void node_std(const Lds& L, const double* pts, const int* perm, int s
 // form), the MFMA forms read one operand pair per 1024 FMAs.
 typedef double mfma_acc __attribute__((ext_vector_type(4)));
 constexpr int kBarStride = 16;  // ints between part-barrier counters (one per 64-byte line)
-constexpr int kMfmaMinDim = 10;
-// deep levels hold small nodes: k_ell runs there with a 128-point tile so that three
-// workgroups (instead of two) share a CU and overlap their latency-bound Jacobi phases
-constexpr int kSmallTile = 128;
-constexpr int kSmallTileLevel = 3;  // below this the quadratic form stays on the VALU
+constexpr int kMfmaMinDim = 10;  // below this the quadratic form stays on the VALU
 #define DH_MFMA_F64(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
 
 // sample covariance (ddof=1) of a node about L.mean -> L.A (np.cov, bounding.py:1411):
@@ -1005,12 +1000,6 @@ __host__ __device__ inline size_t rebuild_lds_base_bytes(int D, int TP) {
   return (dbl * 8 + (320 + (size_t)D + 8) * 4 + 15) & ~(size_t)15;
 }
 
-// does the (small) tile of the deep-level configuration hold the Jacobi overlay?
-__host__ __device__ inline bool rebuild_small_tile_ok(int D) {
-  const int P = (D + 1) & ~1;
-  return (size_t)kSmallTile * (D | 1) >= 4 * (size_t)P * (P | 1);
-}
-
 __device__ __forceinline__ void carve(Lds& L, unsigned char* smem, int D, int TP = kThreads) {
   L.LD = D | 1;  // odd leading dimension: conflict-free column walks
   L.TP = TP;
@@ -1234,7 +1223,7 @@ __global__ void __launch_bounds__(kThreads) k_ell(RebuildArgs a, int level) {
   if (a.status[run] != DH_OK) return;
   const int D = a.d, t = threadIdx.x;
   Lds L;
-  carve(L, smem, D, a.ell_tp_small && level >= kSmallTileLevel ? kSmallTile : kThreads);
+  carve(L, smem, D);
   const RunView v = view_of(a, run, L.LD);
   const int node = a.ell_list[(size_t)run * 2 * a.maxw + slot];
   const int start = v.nodes[node].start, count = v.nodes[node].count;
@@ -1663,8 +1652,6 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
   if (mode == 0 && n > 256 * kThreads)
     return fail(ctx, DH_ERR_ARG, "rebuild: MultiEllipsoid.update supports at most %d points per run (n = %d)",
                 256 * kThreads, n);
-  a.ell_tp_small = rebuild_small_tile_ok(d) ? 1 : 0;
-  const size_t lds_small = rebuild_lds_bytes(d, kSmallTile);
   // k_finish: tree (and result list) in LDS when they fit behind the standard layout
   size_t lds_fin = lds;
   a.fin_extra_off = 0;
@@ -1766,8 +1753,7 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
   hipLaunchKernelGGL(k_root, dim3(runs), dim3(kThreads), lds, ctx->stream, a);
   for (int L = 0; L < a.levels; ++L) {
     hipLaunchKernelGGL(k_split, dim3(runs * a.maxp), dim3(kThreads), lds, ctx->stream, a, L);
-    hipLaunchKernelGGL(k_ell, dim3(runs * 2 * a.maxw), dim3(kThreads),
-                       a.ell_tp_small && L >= kSmallTileLevel ? lds_small : lds, ctx->stream, a, L);
+    hipLaunchKernelGGL(k_ell, dim3(runs * 2 * a.maxw), dim3(kThreads), lds, ctx->stream, a, L);
   }
   hipLaunchKernelGGL(k_finish, dim3(runs), dim3(kThreads), lds_fin, ctx->stream, a);
   return hip_ok(ctx, hipGetLastError(), "rebuild launch") ? DH_OK : DH_ERR_HIP;
