@@ -235,14 +235,18 @@ def main():
         alg_bytes = 8 * (2 * d + 1)  # read u, write u', write logl
         flops = 2 * d * d + 8 * d + (d * d + 3 * d)  # frame mat-vec + sym. quad form
         achieved = props_per_step_rank * alg_bytes / (t_wk * 1e-3) / 1e9
-        traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", "r01", "pmc_rwalk_traffic.json")
+        traffic, traffic_src, traffic_rb = None, None, None
+        pmc = os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")
         if os.path.exists(pmc) and runs == 64 and nlive == 2000 and args.walks == 45:
-            # PMC counters cannot be read from inside this process; the value is
+            # PMC counters cannot be read from inside this process; the values are
             # the committed rocprofv3 measurement of this same launch shape
+            # (tools/pmc_traffic.py: 2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes)
             with open(pmc) as f:
-                traffic = json.load(f)["traffic_bytes_per_launch"]
-            traffic_src = "profiles/r01/pmc_rwalk_traffic.json (2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes)"
+                pj = json.load(f)
+            traffic = pj["kernels"]["rwalk_kernel<25, true, 1>"]["traffic_bytes_per_launch"]
+            traffic_rb = pj["rebuild_pipeline_bytes_per_launch_sequence"]
+            traffic_src = ("profiles/r01/pmc_traffic.json (2*FETCH_SIZE + WRITE_SIZE, "
+                           "separate --pmc passes)")
         line = {
             "metric": "proposals/sec + ellipsoid-rebuilds/sec, 25-D corr-Normal "
                       "nlive=2000 (multi/rwalk)",
@@ -301,7 +305,9 @@ def main():
             line["roofline_rebuild"] = {
                 "bound": "hbm", "kernel": "k_root + 20 x (k_split, k_ell) + k_finish",
                 "achieved": rb_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": rb_gbs / HBM_PEAK_GBS, "traffic": None,
+                "frac": rb_gbs / HBM_PEAK_GBS, "traffic": traffic_rb,
+                "traffic_unit": "bytes per launch sequence (64 runs)",
+                "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": rb_bytes, "kernel_ms": t_rb,
                 "note": "a tree of ~49 nodes per run built level by level (critical path: "
                         "6 levels x [k-means, covariance, 25x25 Jacobi eigensolve, "
