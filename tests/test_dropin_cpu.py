@@ -260,3 +260,27 @@ def test_friends_api_matches_reference(dyn, kind):
     c = pickle.loads(pickle.dumps(copy.deepcopy(ours)))
     np.testing.assert_array_equal(c.axes_inv, ours.axes_inv)
     assert c.need_centers and c.kind == kind
+
+
+def test_dynamic_nested_sampler_dropin(dyn):
+    """The same plugin objects under an unmodified DynamicNestedSampler (baseline
+    run + one posterior-weighted batch): bound re-instantiation from the template
+    (_new_from_template), batch-wise bound updates and the merged result."""
+    import inputs
+    from dynesty_amd import dropin
+    prob = inputs.problem("G5")
+    pool = dropin.HipBatchPool(queue_size=8)
+    s = dyn.DynamicNestedSampler(prob.loglikelihood, prob.prior_transform, prob.ndim,
+                                 bound=dropin.HipMultiEllipsoid(5),
+                                 sample=dropin.HipRWalkSampler(problem=prob, walks=15),
+                                 pool=pool, queue_size=pool.size,
+                                 rstate=np.random.default_rng(11))
+    s.run_nested(nlive_init=100, nlive_batch=50, maxbatch=1, dlogz_init=0.5, print_progress=False)
+    r = s.results
+    assert abs(r.logz[-1] - prob.logz_truth) < 5 * r.logzerr[-1] + 0.3
+    assert len(np.unique(r.samples_batch)) == 2  # baseline + one batch
+    assert isinstance(s.sampler.bound, dropin.HipMultiEllipsoid)
+    # posterior moments from the weighted samples: unit variance, zero mean
+    w = r.importance_weights()
+    mean = (w[:, None] * r.samples).sum(0)
+    assert np.abs(mean).max() < 0.3
