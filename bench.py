@@ -149,10 +149,13 @@ def main():
             ctx.record(ev[2])
 
     def barrier():
+        # own work first (the kernels run on the context's stream, which torch does not
+        # see), then the cross-rank barrier, then a device-wide synchronize
+        ctx.sync()
+        torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
-        ctx.sync()
+            torch.cuda.synchronize()
 
     rebuild()  # frames must exist even with --no-rebuild
     for i in range(args.warmup):
