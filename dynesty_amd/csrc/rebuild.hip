@@ -119,7 +119,7 @@ struct Lds {
   double* scale;  // D
   double* lam;    // D
   double* cen;    // 2 x D
-  double* sums;   // 2 x D
+  double* sums;   // 2 x D + 2
   double* red;    // kThreads
   double* rc;     // 64 (rotation c)
   double* rs;     // 64
@@ -914,14 +914,25 @@ __device__ int node_kmeans_part(const Lds& L, const double* pts, int* perm, int*
     if (np > 1) {
       if (t == 0) st_agent(kp + (size_t)q * KP + 2 * D, (double)c0_tile);
       if (!parts_barrier(bar, np * (it + 1))) return -1;
-      if (t < 2 * D) {
+      // the partners' partials: 8 independent bypassing loads in flight per round trip (a plain
+      // loop serialises np ~2 us memory-side round trips), summed in part order.  Column 2D is
+      // the label-0 count, read by every thread.
+      {
+        const int col = t < 2 * D ? t : 2 * D;
         double sum = 0.0;
-        for (int pp = 0; pp < np; ++pp) sum += ld_agent(kp + (size_t)pp * KP + t);
-        L.sums[t] = sum;
+        for (int pp0 = 0; pp0 < np; pp0 += 8) {
+          double part[8];
+#pragma unroll
+          for (int uu = 0; uu < 8; ++uu)
+            part[uu] = pp0 + uu < np ? ld_agent(kp + (size_t)(pp0 + uu) * KP + col) : 0.0;
+#pragma unroll
+          for (int uu = 0; uu < 8; ++uu) sum += part[uu];
+        }
+        if (t < 2 * D) L.sums[t] = sum;
+        if (t == 2 * D) L.sums[2 * D] = sum;
       }
-      double cc = 0.0;
-      for (int pp = 0; pp < np; ++pp) cc += ld_agent(kp + (size_t)pp * KP + 2 * D);
-      n0 = (int)cc;
+      __syncthreads();
+      n0 = (int)L.sums[2 * D];
     }
     __syncthreads();
     const int n1 = count - n0;
@@ -945,10 +956,17 @@ __device__ int node_kmeans_part(const Lds& L, const double* pts, int* perm, int*
   int off0 = 0, off1 = n0;
   if (np > 1) {
     const double* kp = kp1;  // the last iteration (it = 9) used parity 1
-    for (int pp = 0; pp < q; ++pp) {
-      const int c0p = (int)ld_agent(kp + (size_t)pp * KP + 2 * D);
-      off0 += c0p;
-      off1 += L.TP - c0p;  // parts before q are full tiles
+    for (int pp0 = 0; pp0 < q; pp0 += 8) {
+      double part[8];
+#pragma unroll
+      for (int uu = 0; uu < 8; ++uu)
+        part[uu] = pp0 + uu < q ? ld_agent(kp + (size_t)(pp0 + uu) * KP + 2 * D) : 0.0;
+#pragma unroll
+      for (int uu = 0; uu < 8; ++uu)
+        if (pp0 + uu < q) {
+          off0 += (int)part[uu];
+          off1 += L.TP - (int)part[uu];  // parts before q are full tiles
+        }
     }
   }
   if (valid) {
@@ -996,7 +1014,7 @@ constexpr size_t kLdsLimit = 159 * 1024;
 constexpr size_t kLdsSeparate = 79 * 1024;
 __host__ __device__ inline size_t rebuild_lds_base_bytes(int D, int TP) {
   const int LD = D | 1;
-  const size_t dbl = (size_t)TP * LD + 4 * (size_t)D * LD + 7 * (size_t)D + kThreads + 128 + 384;
+  const size_t dbl = (size_t)TP * LD + 4 * (size_t)D * LD + 7 * (size_t)D + 2 + kThreads + 128 + 384;
   return (dbl * 8 + (320 + (size_t)D + 8) * 4 + 15) & ~(size_t)15;
 }
 
@@ -1031,7 +1049,7 @@ __device__ __forceinline__ void carve(Lds& L, unsigned char* smem, int D, int TP
   L.cen = p;
   p += 2 * D;
   L.sums = p;
-  p += 2 * D;
+  p += 2 * D + 2;
   L.red = p;
   p += kThreads;
   L.rc = p;
