@@ -123,7 +123,7 @@ struct Lds {
   double* red;    // kThreads
   double* rc;     // 64 (rotation c)
   double* rs;     // 64
-  double* kred;   // 4 waves x 2 clusters x 48: k-means partial sums
+  double* kred;   // 4 waves x 2 clusters x 48: k-means partial sums (overlays red | rc | rs)
   int* ri;        // 256 ints (pair indices, scan scratch, ...)
   int* perm_sort; // D
   int TP, LD, DP, DPlog;
@@ -1014,7 +1014,7 @@ constexpr size_t kLdsLimit = 159 * 1024;
 constexpr size_t kLdsSeparate = 79 * 1024;
 __host__ __device__ inline size_t rebuild_lds_base_bytes(int D, int TP) {
   const int LD = D | 1;
-  const size_t dbl = (size_t)TP * LD + 4 * (size_t)D * LD + 7 * (size_t)D + 2 + kThreads + 128 + 384;
+  const size_t dbl = (size_t)TP * LD + 4 * (size_t)D * LD + 7 * (size_t)D + 2 + kThreads + 128;
   return (dbl * 8 + (320 + (size_t)D + 8) * 4 + 15) & ~(size_t)15;
 }
 
@@ -1056,8 +1056,7 @@ __device__ __forceinline__ void carve(Lds& L, unsigned char* smem, int D, int TP
   p += 64;
   L.rs = p;
   p += 64;
-  L.kred = p;
-  p += 4 * 2 * 48;
+  L.kred = L.red;  // 384 doubles = red | rc | rs, none of which the k-means parts use
   L.ri = (int*)p;
   L.perm_sort = L.ri + 320;
   const int P = (D + 1) & ~1;

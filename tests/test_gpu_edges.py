@@ -1,0 +1,122 @@
+"""Edge cases and size-independent properties of the device hot path:
+determinism, batch == single, largest supported dimensions, degenerate inputs,
+odd batch sizes, and the BASELINE full sizes."""
+import numpy as np
+import pytest
+
+import inputs
+from oracle import bounding_ref as B
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from dynesty_amd import _lib
+    return _lib.Context(0)
+
+
+FIELDS = ("ctrs", "covs", "ams", "axes", "axlens", "logvol_ells")
+
+
+def test_rebuild_is_deterministic_and_batch_equals_single(ctx):
+    """The k-means parts of a node cooperate through a device-scope barrier and
+    node ids come from an atomic counter: the RESULT must not depend on any of
+    that -- bit-identical across repetitions, and a run inside a 40-run batch
+    equals the same run alone."""
+    pts = inputs.cloud("c2")
+    a = ctx.rebuild(pts, multi=True)
+    for _ in range(3):
+        b = ctx.rebuild(pts, multi=True)
+        assert a["nells"] == b["nells"]
+        for k in FIELDS:
+            np.testing.assert_array_equal(a[k], b[k])
+    rng = np.random.default_rng(0)
+    sets = [inputs.cloud("c3")[rng.permutation(5000)[:n]] for n in (5000, 1234, 257, 256, 4999)] * 8
+    many = ctx.rebuild_many(sets, multi=True)
+    for s, r in list(zip(sets, many))[::7]:
+        one = ctx.rebuild(s, multi=True)
+        assert one["nells"] == r["nells"]
+        for k in FIELDS:
+            np.testing.assert_array_equal(one[k], r[k][:one["nells"]] if r[k].shape[0] != one[k].shape[0] else r[k])
+
+
+@pytest.mark.parametrize("d,n", [(32, 900), (44, 1200), (1, 300), (2, 9)])
+def test_dimension_limits_vs_oracle(ctx, d, n):
+    """Largest LDS-resident dimensions (32 = last register-resident walker
+    dimension, 44 = last LDS rebuild dimension), D = 1, and a node too small to
+    split."""
+    rng = np.random.default_rng(d)
+    a = rng.standard_normal((d, d)) * 0.2 + np.eye(d)
+    pts = 0.5 + 0.03 * rng.standard_normal((n, d)) @ a
+    if d <= 2:
+        pts[: n // 2] += 0.3  # two separated groups
+    got = ctx.rebuild(pts, multi=True)
+    ref = B.multi_update(pts)
+    assert got["nells"] == len(ref.ells)
+    order = np.argsort([e.ctr[0] for e in ref.ells])
+    mine = np.argsort(got["ctrs"][:, 0])
+    for i, j in zip(mine, order):
+        e = ref.ells[j]
+        np.testing.assert_allclose(got["ctrs"][i], e.ctr, atol=1e-12)
+        np.testing.assert_allclose(got["covs"][i], e.cov, rtol=0, atol=1e-8 * np.abs(e.cov).max())
+        assert abs(got["logvol_ells"][i] - e.logvol) < 1e-8
+
+
+def test_degenerate_clouds(ctx):
+    """Duplicated points and a cloud confined to a line: improve_covar_mat's
+    regularisation path, same ellipsoid volume as the oracle."""
+    rng = np.random.default_rng(5)
+    base = 0.5 + 0.05 * rng.standard_normal((50, 4))
+    dup = np.repeat(base, 6, axis=0)
+    line = 0.5 + np.outer(rng.uniform(-0.2, 0.2, 200), np.array([1.0, 2.0, -1.0]) / 3)
+    for pts in (dup, line):
+        got = ctx.rebuild(pts, multi=False)
+        ref = B.bounding_ellipsoid(pts)
+        assert abs(got["logvol_ells"][0] - ref.logvol) < 1e-4
+        dd = pts - got["ctrs"][0]
+        assert np.einsum('ij,jk,ik->i', dd, got["ams"][0], dd).max() < 1.0
+
+
+@pytest.mark.parametrize("k,walks", [(1, 1), (63, 7), (65, 45), (1000, 3)])
+def test_rwalk_odd_batches(ctx, k, walks):
+    """Batch sizes that are not multiples of the wavefront, single walker,
+    single step: same result as the oracle, walker by walker."""
+    from oracle import proposals_ref as P
+    case = inputs.walker_case("G5", 64, 3)
+    prob = case["problem"]
+    u0 = case["u0"][np.arange(k) % len(case["u0"])]
+    ent = [9, 9, k, walks]
+    states = ctx.seed_children(ent, 0, k)
+    out = ctx.rwalk_batch(prob, u0, case["axes"], case["scale"], case["loglstar"], walks, states)
+    kids = np.random.SeedSequence(ent).spawn(k)
+    for i in list(range(min(k, 8))) + [k - 1]:
+        ref = P.rwalk(u0[i].copy(), case["loglstar"], case["axes"], case["scale"], prob.prior_transform,
+                      prob.loglikelihood, np.random.Generator(np.random.PCG64(kids[i])), walks)
+        assert ref["accept"] == out["accept"][i] and ref["reject"] == out["reject"][i]
+        np.testing.assert_allclose(out["u"][i], ref["u"], rtol=0, atol=1e-12)
+    assert (out["accept"] + out["reject"] == walks).all()
+
+
+def test_full_size_properties_c3_and_c5_shard(ctx):
+    """BASELINE full sizes through size-independent properties: every live point
+    inside the union (strictly), union volume below the single bounding
+    ellipsoid, a permutation of the points gives the same set of ellipsoids; 512
+    C2 live sets in one launch all succeed."""
+    pts = inputs.cloud("c3")
+    got = ctx.rebuild(pts, multi=True)
+    single = ctx.rebuild(pts, multi=False)
+    assert np.logaddexp.reduce(got["logvol_ells"]) < single["logvol_ells"][0]
+    count, _, _ = ctx.contains(pts, got["ctrs"], got["ams"], mode=0)
+    assert (count >= 1).all()
+    perm = np.random.default_rng(1).permutation(len(pts))
+    got2 = ctx.rebuild(pts[perm], multi=True)
+    assert got2["nells"] == got["nells"]
+    np.testing.assert_allclose(np.sort(got2["logvol_ells"]), np.sort(got["logvol_ells"]), atol=1e-7)
+    c2 = inputs.cloud("c2")
+    rng = np.random.default_rng(2)
+    sets = [c2[rng.permutation(2000)] for _ in range(512)]
+    many = ctx.rebuild_many(sets, multi=True)
+    assert len(many) == 512
+    lv = np.array([np.logaddexp.reduce(r["logvol_ells"]) for r in many])
+    assert np.ptp(lv) < 1e-6  # the same cloud, permuted: the same bound
