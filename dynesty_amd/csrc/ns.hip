@@ -148,18 +148,101 @@ __global__ void __launch_bounds__(kT)
   }
 }
 
+// heap node = one 16-byte LDS entry {logl, slot}: x = key, y = slot (integer bits)
+typedef double HeapEnt __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ HeapEnt heap_ent(double key, int slot) {
+  HeapEnt e;
+  e.x = key;
+  e.y = __longlong_as_double((long long)slot);
+  return e;
+}
+__device__ __forceinline__ int heap_slot_of(HeapEnt e) { return (int)__double_as_longlong(e.y); }
+
+// ---- wave-cooperative 64-ary min-heap -----------------------------------------------------
+// The queue walk is a chain of dependent LDS accesses; a lone lane pays ~150-250 cycles per
+// round trip and a binary heap over 2000 live points needs 11 levels.  Here the heap has
+// fan-out 64: the children of node i are the 64 contiguous entries 64 i + 1 ..., fetched by
+// ONE wave-wide 128-bit read (lane = child), the smallest child is found with two DPP
+// min-reductions on the order-preserving integer image of the key (high then low word, ties
+// to the lowest lane), and 2000 points are TWO levels deep.  Entries past the heap size are
+// +inf sentinels, so partial child groups need no special cases.
+constexpr int kFan = 64;
+__host__ __device__ inline int heap_cap(int n) {  // entries including the sentinel padding
+  return n < 2 ? kFan + 1 : ((n - 2) / kFan) * kFan + kFan + 1;
+}
+
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
+  // butterflies inside each row of 16 lanes, then row_bcast15 / row_bcast31: lane 63 holds the minimum
+#define DH_DPP_MIN(ctrl, rmask) \
+  v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, ctrl, rmask, 0xF, false))
+  DH_DPP_MIN(0xB1, 0xF);   // quad_perm [1,0,3,2]
+  DH_DPP_MIN(0x4E, 0xF);   // quad_perm [2,3,0,1]
+  DH_DPP_MIN(0x141, 0xF);  // row_half_mirror
+  DH_DPP_MIN(0x140, 0xF);  // row_mirror
+  DH_DPP_MIN(0x142, 0xA);  // row_bcast:15 -> rows 1, 3
+  DH_DPP_MIN(0x143, 0xC);  // row_bcast:31 -> rows 2, 3
+#undef DH_DPP_MIN
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// lane holding the smallest of the wave's 64 keys (lowest lane on ties) and that key
+__device__ __forceinline__ int wave_argmin(double key, double* kmin) {
+  unsigned long long bits = (unsigned long long)__double_as_longlong(key);
+  bits = (bits >> 63) ? ~bits : (bits | 0x8000000000000000ull);  // order-preserving image
+  const unsigned hi = (unsigned)(bits >> 32), lo = (unsigned)bits;
+  const unsigned mh = wave_min_u32(hi);
+  const unsigned ml = wave_min_u32(hi == mh ? lo : 0xFFFFFFFFu);
+  const unsigned long long win = __ballot(hi == mh && lo == ml);
+  const int l = __ffsll((long long)win) - 1;
+  const int klo = __builtin_amdgcn_readlane((int)(unsigned)__double_as_longlong(key), l);
+  const int khi = __builtin_amdgcn_readlane((int)(unsigned)(__double_as_longlong(key) >> 32), l);
+  *kmin = __longlong_as_double(((long long)khi << 32) | (unsigned)klo);
+  return l;
+}
+
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// place (key, slot) at node i of a heap of n entries and sift it down.  All 64 lanes of ONE
+// wave call this with identical (wave-uniform) arguments.
+__device__ __forceinline__ void heap64_sift(HeapEnt* hp, int n, int i, double key, int slot, int lane) {
+  for (;;) {
+    const int c0 = kFan * i + 1;
+    if (c0 >= n) break;
+    const HeapEnt e = hp[c0 + lane];
+    double kmin;
+    const int lmin = wave_argmin(e.x, &kmin);
+    if (!(kmin < key)) break;
+    if (lane == lmin) hp[i] = e;
+    i = c0 + lmin;
+  }
+  if (lane == 0) hp[i] = heap_ent(key, slot);
+  wave_lds_fence();
+}
+
+// Floyd heapify of hp[0 .. n) (sentinels beyond n already in place); one wave
+__device__ __forceinline__ void heap64_build(HeapEnt* hp, int n, int lane) {
+  if (n < 2) return;
+  for (int p = (n - 2) / kFan; p >= 0; --p) {
+    const HeapEnt e = hp[p];
+    heap64_sift(hp, n, p, e.x, heap_slot_of(e), lane);
+  }
+}
+
 // ---- heapify after the initial evaluation ------------------------------------
 __global__ void __launch_bounds__(kT) ns_heapify(NsArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int run = blockIdx.x, t = threadIdx.x, N = a.nlive;
-  double* key = (double*)smem;
-  int* slot = (int*)(key + N);
+  const int HC = heap_cap(N);
+  HeapEnt* hp = (HeapEnt*)smem;
   __shared__ double red[kT];
   double mx = -1e300;
-  for (int i = t; i < N; i += kT) {
-    key[i] = a.live_logl[(size_t)run * N + i];
-    slot[i] = i;
-    mx = fmax(mx, key[i]);
+  for (int i = t; i < HC; i += kT) {
+    const double k = i < N ? a.live_logl[(size_t)run * N + i] : INFINITY;
+    hp[i] = heap_ent(k, i < N ? i : 0);
+    if (i < N) mx = fmax(mx, k);
   }
   red[t] = mx;
   __syncthreads();
@@ -167,30 +250,15 @@ __global__ void __launch_bounds__(kT) ns_heapify(NsArgs a) {
     if (t < s) red[t] = fmax(red[t], red[t + s]);
     __syncthreads();
   }
-  if (t == 0) {
-    for (int start = N / 2 - 1; start >= 0; --start) {  // Floyd
-      int i = start;
-      const double k0 = key[i];
-      const int s0 = slot[i];
-      for (;;) {
-        int c = 2 * i + 1;
-        if (c >= N) break;
-        if (c + 1 < N && key[c + 1] < key[c]) ++c;
-        if (!(key[c] < k0)) break;
-        key[i] = key[c];
-        slot[i] = slot[c];
-        i = c;
-      }
-      key[i] = k0;
-      slot[i] = s0;
-    }
-    a.st[run].lmax = red[0];
-    a.st[run].loglstar = key[0];
-  }
+  if (t < 64) heap64_build(hp, N, t);
   __syncthreads();
+  if (t == 0) {
+    a.st[run].lmax = red[0];
+    a.st[run].loglstar = hp[0].x;
+  }
   for (int i = t; i < N; i += kT) {
-    a.heap_key[(size_t)run * N + i] = key[i];
-    a.heap_slot[(size_t)run * N + i] = slot[i];
+    a.heap_key[(size_t)run * N + i] = hp[i].x;
+    a.heap_slot[(size_t)run * N + i] = heap_slot_of(hp[i]);
   }
 }
 
@@ -331,25 +399,11 @@ __global__ void __launch_bounds__(kT) ns_select(NsArgs a) {
 
 constexpr int kEPT = 8;  // deaths per lane in the scan phase: K <= kEPT * kT
 
-// heap node = one 16-byte LDS entry {logl, slot}: x = key, y = slot (integer bits)
-typedef double HeapEnt __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ HeapEnt heap_ent(double key, int slot) {
-  HeapEnt e;
-  e.x = key;
-  e.y = __longlong_as_double((long long)slot);
-  return e;
-}
-__device__ __forceinline__ int heap_slot_of(HeapEnt e) { return (int)__double_as_longlong(e.y); }
-
-// The walk is a chain of dependent LDS accesses (~150 cycles per round trip for a lone
-// lane), so its speed is (round trips per sift level) x (levels).  Key and slot share one
-// 128-bit entry, and every step fetches the two children AND the four grandchildren
-// (contiguous at 4i+3) in one volley: TWO levels per round trip, ~6 round trips per
-// replacement at nlive = 2000 instead of ~33 with separate key / slot arrays.
-// hp[N .. N+3] are +inf sentinels, so partial child groups need no special cases.
+// The serial part of the queue consumption (sampler.py:741-776), run by wave 0: stale test,
+// death record, heap update.  Returns the number of deaths (wave-uniform).
 __device__ __forceinline__ int consume_heap(HeapEnt* hp, int* src, const double* ql, double* dcur, int* dj,
                                             int* dslot, int* dsrc, int N, int K, long long room, int limit,
-                                            int* jcap) {
+                                            int* jcap, int lane) {
   int ndead = 0;
   *jcap = -1;
   for (int j = 0; j < K; ++j) {
@@ -361,36 +415,15 @@ __device__ __forceinline__ int consume_heap(HeapEnt* hp, int* src, const double*
       break;
     }
     const int s = heap_slot_of(root);
-    dcur[ndead] = root.x;
-    dj[ndead] = j;
-    dslot[ndead] = s;
-    dsrc[ndead] = src[s];
-    ++ndead;
-    src[s] = j;
-    // heap: replace the root by (lj, s), sift down two levels per step
-    int i = 0;
-    for (;;) {
-      const int c = 2 * i + 1;
-      if (c >= N) break;
-      const int g = 4 * i + 3, gi = g < N ? g : N;
-      HeapEnt e0 = hp[c], e1 = hp[c + 1];
-      HeapEnt g0 = hp[gi], g1 = hp[gi + 1], g2 = hp[gi + 2], g3 = hp[gi + 3];
-      // keep the six reads in ONE volley: without this the compiler sinks the grandchild
-      // reads below the first comparison (no speculative loads) and pays a second round trip
-      asm volatile("" : "+v"(e0), "+v"(e1), "+v"(g0), "+v"(g1), "+v"(g2), "+v"(g3));
-      const bool r1 = e1.x < e0.x;
-      const HeapEnt ec = r1 ? e1 : e0;
-      if (!(ec.x < lj)) break;
-      hp[i] = ec;
-      i = c + (r1 ? 1 : 0);
-      const HeapEnt ga = r1 ? g2 : g0, gb = r1 ? g3 : g1;
-      const bool r2 = gb.x < ga.x;
-      const HeapEnt gc = r2 ? gb : ga;
-      if (!(gc.x < lj)) break;
-      hp[i] = gc;
-      i = g + (r1 ? 2 : 0) + (r2 ? 1 : 0);
+    if (lane == 0) {
+      dcur[ndead] = root.x;
+      dj[ndead] = j;
+      dslot[ndead] = s;
+      dsrc[ndead] = src[s];
+      src[s] = j;
     }
-    hp[i] = heap_ent(lj, s);
+    ++ndead;
+    heap64_sift(hp, N, 0, lj, s, lane);
     if (ndead == limit) break;
   }
   return ndead;
@@ -405,8 +438,9 @@ __global__ void __launch_bounds__(kT) ns_consume(NsArgs a) {
   if (mode != MODE_CUBE && mode != MODE_BOUND) return;
   if (mode == MODE_BOUND && a.bstatus[run] != DH_OK) return;
   long long pt_ = a.prof ? clock64() : 0;
-  HeapEnt* hp = (HeapEnt*)smem;            // N + 4  min-heap over (logl, slot), hp[N..N+3] = +inf sentinels
-  double* ql = (double*)(hp + N + 4);      // K   proposal logl
+  const int HC = heap_cap(N);
+  HeapEnt* hp = (HeapEnt*)smem;            // HC  64-ary min-heap over (logl, slot), entries >= N are +inf sentinels
+  double* ql = (double*)(hp + HC);         // K   proposal logl
   double* dcur = ql + K;                   // K   death list: logl of the dead point
   int* src = (int*)(dcur + K);             // N   queue index now living in the slot, -1 = original
   int* qc = src + N;                // K   calls
@@ -417,7 +451,7 @@ __global__ void __launch_bounds__(kT) ns_consume(NsArgs a) {
   __shared__ double wred[2][4];
   __shared__ double bcast[4];
   __shared__ long long lred[4];
-  for (int i = t; i < N + 4; i += kT) {
+  for (int i = t; i < HC; i += kT) {
     hp[i] = i < N ? heap_ent(a.heap_key[(size_t)run * N + i], a.heap_slot[(size_t)run * N + i])
                   : heap_ent(INFINITY, 0);
     if (i < N) src[i] = -1;
@@ -458,11 +492,14 @@ __global__ void __launch_bounds__(kT) ns_consume(NsArgs a) {
   const double dlv = log(((double)N + 1.0) / (double)N);
   const double ldv_c = log(0.5 * expm1(dlv));  // ln(dX_e / X_e) of the trapezoid rule
   NS_PROF(0);
-  // ---- phase A: the heap walk (one lane) ----
-  if (t == 0) {
+  // ---- phase A: the heap walk (wave 0, lanes cooperating on every sift level) ----
+  if (t < 64) {
     int jcap;
-    misc[0] = consume_heap(hp, src, ql, dcur, dj, dslot, dsrc, N, K, a.cap - it0, K + 1, &jcap);
-    misc[1] = jcap;
+    const int nd = consume_heap(hp, src, ql, dcur, dj, dslot, dsrc, N, K, a.cap - it0, K + 1, &jcap, t);
+    if (t == 0) {
+      misc[0] = nd;
+      misc[1] = jcap;
+    }
   }
   __syncthreads();
   const int ndead = misc[0], jcap = misc[1];
@@ -571,9 +608,9 @@ __global__ void __launch_bounds__(kT) ns_consume(NsArgs a) {
       src[i] = -1;
     }
     __syncthreads();
-    if (t == 0) {
+    if (t < 64) {
       int jc;
-      consume_heap(hp, src, ql, dcur, dj, dslot, dsrc, N, K, a.cap - it0, nkeep, &jc);
+      consume_heap(hp, src, ql, dcur, dj, dslot, dsrc, N, K, a.cap - it0, nkeep, &jc, t);
     }
   }
   __syncthreads();
@@ -652,30 +689,36 @@ __global__ void __launch_bounds__(kT) ns_consume(NsArgs a) {
 __global__ void __launch_bounds__(kT) ns_finish(NsArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int run = blockIdx.x, t = threadIdx.x, N = a.nlive;
-  double* key = (double*)smem;
-  for (int i = t; i < N; i += kT) key[i] = a.heap_key[(size_t)run * N + i];
+  const int HC = heap_cap(N);
+  HeapEnt* hp = (HeapEnt*)smem;
+  double* sorted = (double*)(hp + HC);  // N  the final live log-likelihoods, ascending
+  for (int i = t; i < HC; i += kT)
+    hp[i] = i < N ? heap_ent(a.heap_key[(size_t)run * N + i], a.heap_slot[(size_t)run * N + i])
+                  : heap_ent(INFINITY, 0);
+  __syncthreads();
+  if (t < 64) {
+    // heap sort by wave 0: N pops of the 64-ary heap (two levels each)
+    int n = N;
+    for (int i = 0; i < N; ++i) {
+      const HeapEnt root = hp[0];
+      --n;
+      const HeapEnt last = hp[n];
+      if (t == 0) {
+        sorted[i] = root.x;
+        hp[n] = heap_ent(INFINITY, 0);
+      }
+      wave_lds_fence();
+      if (n > 0) heap64_sift(hp, n, 0, last.x, heap_slot_of(last), t);
+    }
+  }
   __syncthreads();
   if (t == 0) {
     NsRun& r = a.st[run];
     double logz = r.logz, h = r.h, prev = r.dead_prev, logzvar = r.logzvar;
     const double lv0 = r.logvol;
     double lvprev = lv0;
-    int n = N;
     for (int i = 1; i <= N; ++i) {
-      // pop the minimum
-      const double cur = key[0];
-      --n;
-      const double last = key[n];
-      int p = 0;
-      for (;;) {
-        int c = 2 * p + 1;
-        if (c >= n) break;
-        if (c + 1 < n && key[c + 1] < key[c]) ++c;
-        if (!(key[c] < last)) break;
-        key[p] = key[c];
-        p = c;
-      }
-      if (n > 0) key[p] = last;
+      const double cur = sorted[i - 1];
       const double lv = lv0 + log(1.0 - (double)i / ((double)N + 1.0));
       integrate_step(logz, h, logzvar, prev, cur, lv, lvprev - lv);
       prev = cur;
@@ -814,18 +857,20 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
   hipLaunchKernelGGL(ns_init, dim3(R), dim3(kT), 0, s, a, d_ent, n_words, first_run);
   int rc = eval_launch_dev(ctx, problem, R * N, a.live_u, a.live_v, a.live_logl);
   if (rc) return cleanup(rc);
-  const size_t lds_heap = (size_t)N * 12 + 64;
-  hipLaunchKernelGGL(ns_heapify, dim3(R), dim3(kT), lds_heap, s, a);
-  const size_t lds_cons = (size_t)(N + 4) * 16 + (size_t)N * 4 + (size_t)K * 32 + 64;
+  const size_t lds_heap = (size_t)heap_cap(N) * 16 + (size_t)N * 8 + 64;
+  const size_t lds_cons = (size_t)heap_cap(N) * 16 + (size_t)N * 4 + (size_t)K * 32 + 64;
   if (K > kEPT * kT) return cleanup(fail(ctx, DH_ERR_ARG, "ns_ensemble: queue_size %d > %d", K, kEPT * kT));
   if (lds_cons > 150 * 1024) return cleanup(fail(ctx, DH_ERR_ARG, "ns_ensemble: nlive/queue too large for LDS"));
   static size_t attr = 0;
-  if (lds_cons > attr) {
-    (void)hipFuncSetAttribute((const void*)ns_consume, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cons);
-    (void)hipFuncSetAttribute((const void*)ns_heapify, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cons);
-    (void)hipFuncSetAttribute((const void*)ns_finish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cons);
-    attr = lds_cons;
+  const size_t lds_max = lds_cons > lds_heap ? lds_cons : lds_heap;
+  if (lds_max > 150 * 1024) return cleanup(fail(ctx, DH_ERR_ARG, "ns_ensemble: nlive/queue too large for LDS"));
+  if (lds_max > attr) {
+    (void)hipFuncSetAttribute((const void*)ns_consume, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
+    (void)hipFuncSetAttribute((const void*)ns_heapify, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
+    (void)hipFuncSetAttribute((const void*)ns_finish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
+    attr = lds_max;
   }
+  hipLaunchKernelGGL(ns_heapify, dim3(R), dim3(kT), lds_heap, s, a);
   const int64_t fills_cap = max_fills > 0 ? max_fills : 1000000;
   int64_t fill = 0;
   int ndone = 0;
