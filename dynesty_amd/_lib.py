@@ -99,7 +99,7 @@ SIGNATURES = {
                              _vp, _vp]),
     "dh_unif_friends_batch": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _dbl,
                                    _vp, _vp, C.c_int64, _vp, _vp, _vp, _vp,
-                                   _vp]),
+                                   _vp, _vp, _vp]),
     "dh_bound_draw": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp,
                            _vp, _vp, _vp]),
 }
@@ -531,6 +531,50 @@ class Context:
             _ptr(rng_out)))
         return dict(u=u, v=v, logl=logl, ncalls=nc, rng_out=rng_out)
 
+    def unif_propose(self, ndim, rng_states, ctrs=None, axes=None, ams=None,
+                     logvol_ells=None, ncdim=None, bc=None, friends=None):
+        """Lock-step half of UniformBoundSampler for an arbitrary host
+        likelihood: per walker the next candidate of its stream that lies in
+        the bound and passes unitcheck (dh_unif_batch / dh_unif_friends_batch
+        with problem = -1).  friends = (kind, ctrs, axes, axes_inv) selects a
+        balls / cubes bound; rng_states then has 6 columns (the last two carry
+        NumPy's buffered 32-bit half, which integers(n) consumes) and so has
+        the returned state.  Returns (u (k, ndim), rng_out)."""
+        rs = np.ascontiguousarray(rng_states, dtype=np.uint64)
+        rs = rs.reshape(-1, 6 if friends is not None else 4)
+        rng = np.ascontiguousarray(rs[:, :4])
+        k = rng.shape[0]
+        ncdim = ndim if ncdim is None else int(ncdim)
+        bcarr = None if bc is None else np.ascontiguousarray(bc, dtype=np.int8)
+        u = np.empty((k, ndim))
+        rng_out = np.empty((k, 4), dtype=np.uint64)
+        if friends is not None:
+            kind, fc, fax, fai = friends
+            c = _f64(fc).reshape(-1, ndim)
+            r32 = np.ascontiguousarray(rs[:, 4:])
+            r32o = np.empty((k, 2), dtype=np.uint64)
+            self._check(self.lib.dh_unif_friends_batch(
+                self.handle, -1, k, ndim, 0 if kind == 'balls' else 1, _ptr(c),
+                c.shape[0], _ptr(_f64(fax)), _ptr(_f64(fai)), 0.0, _ptr(bcarr),
+                _ptr(rng), 0, _ptr(u), None, None, None, _ptr(rng_out),
+                _ptr(r32), _ptr(r32o)))
+            return u, np.concatenate([rng_out, r32o], axis=1)
+        if ctrs is None:
+            m, c, ax, am, cp = 0, None, None, None, None
+        else:
+            c = _f64(ctrs).reshape(-1, ncdim)
+            m = c.shape[0]
+            ax = _f64(axes).reshape(m, ncdim, ncdim)
+            am = cp = None
+            if m > 1:
+                am = _f64(ams).reshape(m, ncdim, ncdim)
+                cp = cumprob_of(logvol_ells)
+        self._check(self.lib.dh_unif_batch(
+            self.handle, -1, k, ndim, ncdim, m, _ptr(c), _ptr(ax), _ptr(am),
+            _ptr(cp), 0.0, _ptr(bcarr), _ptr(rng), 0, _ptr(u), None, None,
+            None, _ptr(rng_out)))
+        return u, rng_out
+
     def unif_friends_batch(self, prob, loglstar, rng_states, ctrs, kind, axes,
                            axes_inv, bc=None, max_tries=0):
         """Batched UniformBoundSampler.sample inside a RadFriends ('balls') /
@@ -550,7 +594,7 @@ class Context:
             0 if kind == 'balls' else 1, _ptr(c), c.shape[0],
             _ptr(_f64(axes)), _ptr(_f64(axes_inv)), float(loglstar),
             _ptr(bcarr), _ptr(rng), int(max_tries), _ptr(u), _ptr(v),
-            _ptr(logl), _ptr(nc), _ptr(rng_out)))
+            _ptr(logl), _ptr(nc), _ptr(rng_out), None, None))
         return dict(u=u, v=v, logl=logl, ncalls=nc, rng_out=rng_out)
 
     def ns_ensemble(self, prob, runs, nlive, queue_size, walks=None,

@@ -377,6 +377,9 @@ struct UnifArgs {
   // RadFriends / SupFriends bound (fr_kind 0 balls, 1 cubes, -1: ellipsoids): m == 1, axes_t =
   // the common shape sqrtm(cov), ams_p = its pseudo-inverse axes_inv (both symmetric, padded)
   int fr_kind, fr_n;
+  const uint64_t* rng32_in;  // optional k x 2 {has_uint32, uinteger}: NumPy's buffered half of the 32-bit draws
+  uint64_t* rng32_out;       // (integers(n) of the friends bounds consumes it); carried across lock-step rounds
+  int propose_only;        // 1: stop at the first candidate inside the cube, no prior / likelihood (lock-step path)
   const double* fr_ctrs;   // fr_n x ncdim centres (the live points)
   const double* fr_ct;     // fr_n x ncdim centres in the whitened frame (ctrs . axes_inv)
   const int8_t* bc;        // ndim or null (nonbounded mask semantics)
@@ -417,6 +420,10 @@ __global__ void __launch_bounds__(64, 2) unif_kernel(UnifArgs a) {
   const bool idle = done;
   Pcg64 g;
   g.load(a.rng_in + (size_t)wi * 4);
+  if (a.rng32_in) {
+    g.has32 = (uint32_t)a.rng32_in[(size_t)wi * 2];
+    g.buf32 = (uint32_t)a.rng32_in[(size_t)wi * 2 + 1];
+  }
   double x[N], acc[N];
   int ncall = 0, flags = 0;
   double logl_cur = 0.0;
@@ -578,7 +585,17 @@ __global__ void __launch_bounds__(64, 2) unif_kernel(UnifArgs a) {
         }
       }
     }
-    if (__any(cand)) {
+    if (a.propose_only) {
+      // lock-step path (arbitrary host likelihood): hand the candidate back
+      if (cand) {
+        done = true;
+        if (live) {
+#pragma unroll
+          for (int i = 0; i < N; ++i)
+            if (FULL || i < n) a.u[(size_t)w * n + i] = x[i];
+        }
+      }
+    } else if (__any(cand)) {
       prior_to_lds<N, FULL, KIND>(a.prob, x, n, sx, lane);
       const double ll = loglike_lds<N, FULL, KIND>(a.prob, n, sx, lane, acc);
       if (cand) {
@@ -603,10 +620,16 @@ __global__ void __launch_bounds__(64, 2) unif_kernel(UnifArgs a) {
     }
   }
   if (live && !idle) {
-    a.logl[w] = logl_cur;
-    a.ncalls[w] = ncall;
+    if (!a.propose_only) {
+      a.logl[w] = logl_cur;
+      a.ncalls[w] = ncall;
+    }
     a.flags[w] = flags;
     if (a.rng_out) g.store(a.rng_out + (size_t)w * 4);
+    if (a.rng32_out) {
+      a.rng32_out[(size_t)w * 2] = g.has32;
+      a.rng32_out[(size_t)w * 2 + 1] = g.buf32;
+    }
   }
 }
 
@@ -869,7 +892,7 @@ int unif_dispatch(dh_ctx* ctx, const UnifArgs& a, int N) {
   const int k = a.k, ndim = a.ndim, ncdim = a.ncdim;
   const dim3 grid((k + 63) / 64), block(64);
   const bool full = (ndim == N && ncdim == N);
-  const int kind = full ? problem_kind(a.prob.like_id, a.prob.prior_id) : KIND_GENERIC;
+  const int kind = (full && !a.propose_only) ? problem_kind(a.prob.like_id, a.prob.prior_id) : KIND_GENERIC;
 #define L(NN, FF, KK) hipLaunchKernelGGL((unif_kernel<NN, FF, KK>), grid, block, 0, ctx->stream, a)
 #define X(NN)                              \
   if (N == NN) {                           \
@@ -905,8 +928,17 @@ int dh::unif_launch_runs(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, i
   a.run_mode = run_mode;
   a.wpr = wpr;
   a.my_mode = my_mode;
-  if (!get_problem(ctx, problem, &a.prob)) return DH_ERR_ARG;
-  if (a.prob.ndim != ndim) return fail(ctx, DH_ERR_ARG, "problem ndim %d != %d", a.prob.ndim, ndim);
+  a.propose_only = problem == -1 ? 1 : 0;
+  if (a.propose_only) {
+    a.prob = ProblemDev();
+    a.prob.ndim = ndim;
+    a.prob.like_id = 99;  // never evaluated
+    a.prob.prior_id = 99;
+    if (ndim > kMaxRegDim) return fail(ctx, DH_ERR_ARG, "unif_propose: ndim=%d > %d not built", ndim, kMaxRegDim);
+  } else {
+    if (!get_problem(ctx, problem, &a.prob)) return DH_ERR_ARG;
+    if (a.prob.ndim != ndim) return fail(ctx, DH_ERR_ARG, "problem ndim %d != %d", a.prob.ndim, ndim);
+  }
   if (k <= 0) return DH_OK;
   if (m < 0 || ncdim < 1 || ncdim > ndim) return fail(ctx, DH_ERR_ARG, "unif: m=%d ncdim=%d", m, ncdim);
   if (ndim > kMaxRegDim) {
@@ -943,6 +975,8 @@ int dh::unif_launch_runs(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, i
   a.fr_kind = -1;
   a.fr_n = 0;
   a.fr_ctrs = a.fr_ct = nullptr;
+  a.rng32_in = nullptr;
+  a.rng32_out = nullptr;
   a.bc = bc;
   a.rng_in = rng;
   a.max_tries = max_tries > 0 ? max_tries : ((int64_t)1 << 40);
@@ -967,7 +1001,8 @@ int dh_unif_batch(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, int m, c
                   double* logl, int32_t* ncalls, uint64_t* rng_out) {
   DH_CHECK_CTX(ctx);
   if (k <= 0) return DH_OK;
-  if (!rng || !u || !v || !logl || !ncalls || (m > 0 && (!ctrs || !axes)) || (m > 1 && (!ams || !cumprob)))
+  if (!rng || !u || (problem != -1 && (!v || !logl || !ncalls)) || (m > 0 && (!ctrs || !axes)) ||
+      (m > 1 && (!ams || !cumprob)))
     return fail(ctx, DH_ERR_ARG, "unif: null pointer");
   arena_reset(ctx);
   const size_t kd = (size_t)k * ndim, mm = (size_t)(m > 0 ? m : 1);
@@ -991,9 +1026,10 @@ int dh_unif_batch(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, int m, c
                          max_tries, d_u, d_v, d_l, d_nc, d_fl, d_ro);
   if (rc) return rc;
   std::vector<int32_t> fl((size_t)k);
-  if (!down(ctx, u, d_u, kd) || !down(ctx, v, d_v, kd) || !down(ctx, logl, d_l, (size_t)k) ||
-      !down(ctx, ncalls, d_nc, (size_t)k) || !down(ctx, fl.data(), d_fl, (size_t)k) ||
-      !down(ctx, rng_out, d_ro, (size_t)k * 4))
+  if (!down(ctx, u, d_u, kd) || !down(ctx, fl.data(), d_fl, (size_t)k) || !down(ctx, rng_out, d_ro, (size_t)k * 4))
+    return DH_ERR_HIP;
+  if (problem != -1 && (!down(ctx, v, d_v, kd) || !down(ctx, logl, d_l, (size_t)k) ||
+                        !down(ctx, ncalls, d_nc, (size_t)k)))
     return DH_ERR_HIP;
   if ((rc = dh_sync(ctx))) return rc;
   for (int i = 0; i < k; ++i) {
@@ -1009,18 +1045,27 @@ int dh_unif_batch(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, int m, c
 int dh_unif_friends_batch(dh_ctx* ctx, int problem, int k, int ndim, int kind, const double* ctrs, int n,
                           const double* axes, const double* axes_inv, double loglstar, const int8_t* bc,
                           const uint64_t* rng, int64_t max_tries, double* u, double* v, double* logl,
-                          int32_t* ncalls, uint64_t* rng_out) {
+                          int32_t* ncalls, uint64_t* rng_out, const uint64_t* rng32, uint64_t* rng32_out) {
   DH_CHECK_CTX(ctx);
   if (k <= 0) return DH_OK;
-  if (!rng || !u || !v || !logl || !ncalls || !ctrs || !axes || !axes_inv || n < 1 || (kind != 0 && kind != 1))
+  if (!rng || !u || !ctrs || !axes || !axes_inv || n < 1 || (kind != 0 && kind != 1) ||
+      (problem != -1 && (!v || !logl || !ncalls)))
     return fail(ctx, DH_ERR_ARG, "unif_friends: bad arguments");
   UnifArgs a;
-  if (!get_problem(ctx, problem, &a.prob)) return DH_ERR_ARG;
-  if (a.prob.ndim != ndim) return fail(ctx, DH_ERR_ARG, "problem ndim %d != %d", a.prob.ndim, ndim);
+  a.propose_only = problem == -1 ? 1 : 0;
+  if (a.propose_only) {
+    a.prob = ProblemDev();
+    a.prob.ndim = ndim;
+    a.prob.like_id = 99;
+    a.prob.prior_id = 99;
+  } else {
+    if (!get_problem(ctx, problem, &a.prob)) return DH_ERR_ARG;
+    if (a.prob.ndim != ndim) return fail(ctx, DH_ERR_ARG, "problem ndim %d != %d", a.prob.ndim, ndim);
+  }
   if (ndim > kMaxRegDim) return fail(ctx, DH_ERR_ARG, "unif_friends: ndim=%d > %d not built", ndim, kMaxRegDim);
   arena_reset(ctx);
   const size_t kd = (size_t)k * ndim, nd = (size_t)n * ndim, dd = (size_t)ndim * ndim;
-  int rc = arena_reserve(ctx, 2 * kd * 8 + 2 * nd * 8 + 2 * dd * 8 + (size_t)k * (8 + 8 + 64) + (size_t)ndim + 8192);
+  int rc = arena_reserve(ctx, 2 * kd * 8 + 2 * nd * 8 + 2 * dd * 8 + (size_t)k * (8 + 8 + 64 + 32) + (size_t)ndim + 8192);
   if (rc) return rc;
   const double* d_c = arena_up(ctx, ctrs, nd);
   const double* d_ax = arena_up(ctx, axes, dd);
@@ -1034,7 +1079,10 @@ int dh_unif_friends_batch(dh_ctx* ctx, int problem, int k, int ndim, int kind, c
   int32_t* d_nc = (int32_t*)arena_get(ctx, (size_t)k * 4);
   int32_t* d_fl = (int32_t*)arena_get(ctx, (size_t)k * 4);
   uint64_t* d_ro = (uint64_t*)arena_get(ctx, (size_t)k * 32);
-  if (!d_c || !d_ax || !d_ai || !d_ct || !d_rng || !d_u || !d_v || !d_l || !d_nc || !d_fl || !d_ro)
+  const uint64_t* d_r32 = rng32 ? arena_up(ctx, rng32, (size_t)k * 2) : nullptr;
+  uint64_t* d_r32o = rng32_out ? (uint64_t*)arena_get(ctx, (size_t)k * 16) : nullptr;
+  if (!d_c || !d_ax || !d_ai || !d_ct || !d_rng || !d_u || !d_v || !d_l || !d_nc || !d_fl || !d_ro ||
+      (rng32 && !d_r32) || (rng32_out && !d_r32o))
     return DH_ERR_NOMEM;
   if ((rc = friends_whiten_launch(ctx, d_c, d_ai, n, ndim, d_ct))) return rc;
   const int N = pad_dim(ndim);
@@ -1060,6 +1108,8 @@ int dh_unif_friends_batch(dh_ctx* ctx, int problem, int k, int ndim, int kind, c
   a.fr_n = n;
   a.fr_ctrs = d_c;
   a.fr_ct = d_ct;
+  a.rng32_in = d_r32;
+  a.rng32_out = d_r32o;
   a.bc = d_bc;
   a.rng_in = d_rng;
   a.max_tries = max_tries > 0 ? max_tries : ((int64_t)1 << 40);
@@ -1074,9 +1124,11 @@ int dh_unif_friends_batch(dh_ctx* ctx, int problem, int k, int ndim, int kind, c
   a.zfi = ctx->zfi();
   if ((rc = unif_dispatch(ctx, a, N))) return rc;
   std::vector<int32_t> fl((size_t)k);
-  if (!down(ctx, u, d_u, kd) || !down(ctx, v, d_v, kd) || !down(ctx, logl, d_l, (size_t)k) ||
-      !down(ctx, ncalls, d_nc, (size_t)k) || !down(ctx, fl.data(), d_fl, (size_t)k) ||
-      !down(ctx, rng_out, d_ro, (size_t)k * 4))
+  if (!down(ctx, u, d_u, kd) || !down(ctx, fl.data(), d_fl, (size_t)k) || !down(ctx, rng_out, d_ro, (size_t)k * 4) ||
+      (rng32_out && !down(ctx, rng32_out, d_r32o, (size_t)k * 2)))
+    return DH_ERR_HIP;
+  if (problem != -1 && (!down(ctx, v, d_v, kd) || !down(ctx, logl, d_l, (size_t)k) ||
+                        !down(ctx, ncalls, d_nc, (size_t)k)))
     return DH_ERR_HIP;
   if ((rc = dh_sync(ctx))) return rc;
   for (int i = 0; i < k; ++i)

@@ -251,12 +251,71 @@ def friends_kind(bound):
     return kind
 
 
+def _run_unif_lockstep(args):
+    """UniformBoundSampler / UnitCubeSampler semantics with an arbitrary Python
+    likelihood: per round the device hands every unfinished walker the next
+    candidate of its stream that lies in the bound and passes unitcheck
+    (dh_unif_batch with problem = -1); the host evaluates the user's callbacks
+    and keeps the first candidate with logl > loglstar
+    (internal_samplers.py:304-333).  Same streams and call counts as the fused
+    kernel."""
+    a0 = args[0]
+    kw = a0.kwargs
+    k = len(args)
+    ndim = int(kw['ndim'])
+    bound = kw['bound']
+    streams = _Streams([a.rseed for a in args])
+    states = np.array(streams.states, dtype=np.uint64).reshape(k, 4)
+    bc = None
+    nonb = kw.get('nonbounded')
+    if nonb is not None:
+        bc = np.where(np.asarray(nonb), _lib.BC_HARD,
+                      _lib.BC_PERIODIC).astype(np.int8)
+    fkind = friends_kind(bound)
+    pk = {}
+    if fkind is not None:
+        if kw['n_cluster'] != ndim:
+            raise ValueError("balls / cubes bounds need ncdim == ndim")
+        pk = dict(friends=(fkind, np.asarray(bound.ctrs), np.real(bound.axes),
+                           np.real(bound.axes_inv)))
+        # + {has_uint32, uinteger}: integers(n) draws from the buffered 32-bit half
+        states = np.concatenate([states, np.zeros((k, 2), dtype=np.uint64)], axis=1)
+    else:
+        ctrs, axes, ams, lvs = bound_arrays(bound)
+        pk = dict(ctrs=ctrs, axes=axes, ams=ams, logvol_ells=lvs,
+                  ncdim=kw['n_cluster'])
+    be = get_backend()
+    todo = np.arange(k)
+    res = [None] * k
+    nc = np.zeros(k, dtype=np.int64)
+    while len(todo):
+        up, out = be.unif_propose(ndim, states[todo], bc=bc, **pk)
+        states[todo] = out
+        keep = []
+        for j, i in enumerate(todo):
+            vi = a0.prior_transform(np.array(up[j]))
+            li = a0.loglikelihood(np.asarray(vi))
+            nc[i] += 1
+            if li > a0.loglstar:
+                res[i] = SamplerReturn(u=up[j].copy(), v=vi, logl=li,
+                                       ncalls=int(nc[i]),
+                                       evaluation_history=[], tuning_info=None,
+                                       proposal_stats={'n_proposals': 0})
+            else:
+                keep.append(i)
+        todo = np.array(keep, dtype=np.int64)
+    streams.write_back(states[:, :4])
+    return res
+
+
 def run_unif(args):
     """UniformBoundSampler.sample over a queue (internal_samplers.py:243-340)."""
     args = list(args)
     if not args:
         return []
     a0 = args[0]
+    if a0.kwargs.get('problem') is None:
+        return _run_unif_lockstep(args)
     prob = _problem_of(a0)
     kw = a0.kwargs
     bound = kw['bound']

@@ -325,11 +325,17 @@ int dh_friends_draw(dh_ctx* ctx, const uint64_t* state6, int nsamp, const double
  * per try one draw from the union of shapes (1/q rule, brute-force overlap over the n centres),
  * unitcheck, prior transform and likelihood of the device problem, until logl > loglstar.
  * Same arguments and outputs as dh_unif_batch; ncdim == ndim (the reference's friends bounds
- * need it too: their centres are the full live points). */
+ * need it too: their centres are the full live points).
+ * problem = -1 (also accepted by dh_unif_batch) selects the lock-step form for an arbitrary
+ * host likelihood: every walker returns the next candidate of its stream that lies in the bound
+ * and passes unitcheck (u, rng_out; v / logl / ncalls may be NULL) and the caller evaluates it.
+ * rng32 / rng32_out (optional, k x 2 {has_uint32, uinteger}) carry NumPy's buffered 32-bit half,
+ * which integers(n) consumes, from one lock-step round to the next. */
 int dh_unif_friends_batch(dh_ctx* ctx, int problem, int k, int ndim, int kind, const double* ctrs,
                           int n, const double* axes, const double* axes_inv, double loglstar,
                           const int8_t* bc, const uint64_t* rng, int64_t max_tries, double* u,
-                          double* v, double* logl, int32_t* ncalls, uint64_t* rng_out);
+                          double* v, double* logl, int32_t* ncalls, uint64_t* rng_out,
+                          const uint64_t* rng32, uint64_t* rng32_out);
 
 #ifdef __cplusplus
 }

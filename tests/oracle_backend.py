@@ -340,3 +340,44 @@ class OracleBackend:
             out["ncalls"][i] = r["ncalls"]
             out["rng_out"][i] = _words(rng)
         return out
+
+    def unif_propose(self, ndim, rng_states, ctrs=None, axes=None, ams=None,
+                     logvol_ells=None, ncdim=None, bc=None, friends=None):
+        rng_states = np.asarray(rng_states).reshape(-1, 6 if friends is not None else 4)
+        k = rng_states.shape[0]
+        nc = ndim if ncdim is None else ncdim
+        nonb = None if bc is None else (np.asarray(bc) == 0)
+        if friends is not None:
+            kind, fc, fax, fai = friends
+            fr = self._friends(kind, fc, fax, fai)
+            draw = lambda g: F.friends_sample(fr, g)
+        else:
+            ctrs = np.asarray(ctrs).reshape(-1, nc)
+            m = len(ctrs)
+            axes = np.asarray(axes).reshape(m, nc, nc)
+            if m == 1:
+                draw = P.unif_single(_ell(ctrs[0], np.eye(nc), np.eye(nc), axes[0], np.ones(nc), 0.0))
+            else:
+                ams = np.asarray(ams).reshape(m, nc, nc)
+                draw = P.unif_multi(B.stack_ells([
+                    _ell(ctrs[i], np.eye(nc), ams[i], axes[i], np.ones(nc), logvol_ells[i]) for i in range(m)]))
+        u = np.empty((k, ndim))
+        out = np.empty((k, rng_states.shape[1]), np.uint64)
+        for i in range(k):
+            rng = _gen(rng_states[i][:4])
+            if friends is not None:
+                st = rng.bit_generator.state
+                st["has_uint32"], st["uinteger"] = int(rng_states[i][4]), int(rng_states[i][5])
+                rng.bit_generator.state = st
+            while True:
+                x = draw(rng)
+                if P.unitcheck(x, None if nonb is None else nonb[:nc]):
+                    break
+            if nc != ndim:
+                x = np.concatenate((x, rng.uniform(size=(ndim - nc))))
+            u[i] = x
+            out[i, :4] = _words(rng)
+            if friends is not None:
+                st = rng.bit_generator.state
+                out[i, 4], out[i, 5] = st["has_uint32"], st["uinteger"]
+        return u, out

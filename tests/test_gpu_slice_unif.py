@@ -169,3 +169,71 @@ def test_bound_draw_golden(ctx, name, golden_bounding):
     xs, _, _, _ = ctx.bound_draw(_lib.pcg_state_words(bg), 40, e.ctr, e.axes)
     np.testing.assert_allclose(xs, g[f"{name}/single/samples"], rtol=0,
                                atol=1e-13)
+
+
+@pytest.mark.parametrize("kind", ["multi", "single", "cube", "balls"])
+def test_unif_lockstep_equals_fused(ctx, kind):
+    """The lock-step path for arbitrary Python likelihoods (candidates from
+    dh_unif_batch with problem = -1, callbacks on the host) reproduces the fused
+    kernel: same accepted points, same call counts, same final streams."""
+    from dynesty_amd import samplers, backend, bounding
+    from dynesty_amd.samplers import SamplerReturn  # noqa: F401
+    import types
+    prob = inputs.problem("G5")
+    rng = np.random.default_rng(4)
+    live = 0.5 + 0.05 * rng.standard_normal((400, 5))
+    _, ll = ctx.problem_eval(prob, live)
+    loglstar = float(np.sort(ll)[80])
+    backend.set_backend(ctx)
+    try:
+        if kind == "multi":
+            b = bounding.HipMultiEllipsoid(5)
+            b.update(np.vstack([live[:200], live[200:] + 0.2]))
+        elif kind == "single":
+            b = bounding.HipEllipsoid(5)
+            b.update(live)
+        elif kind == "balls":
+            b = bounding.HipRadFriends(5)
+            b.update(live)
+            b.ctrs = live
+        else:
+            b = None
+        kids = np.random.SeedSequence(77).spawn(40)
+
+        def mk(problem):
+            kw = dict(bound=b, ndim=5, n_cluster=5, nonbounded=None, problem=problem)
+            return [types.SimpleNamespace(u=None, loglstar=loglstar, axes=None, scale=1.0,
+                                          prior_transform=prob.prior_transform,
+                                          loglikelihood=prob.loglikelihood,
+                                          rseed=np.random.Generator(np.random.PCG64(s)), kwargs=kw)
+                    for s in kids]
+        if kind == "cube":
+            st = ctx.seed_children([1, 2, 3, 4], 0, 40)
+            fused = ctx.unif_batch(prob, loglstar - 50.0, st)
+            u, out = st.copy(), None
+            todo = np.arange(40); states = np.array(st).reshape(40, 4); nc = np.zeros(40, int); got = np.zeros((40, 5))
+            while len(todo):
+                up, so = ctx.unif_propose(5, states[todo])
+                states[todo] = so
+                keep = []
+                for j, i in enumerate(todo):
+                    nc[i] += 1
+                    if prob.loglikelihood(prob.prior_transform(up[j])) > loglstar - 50.0:
+                        got[i] = up[j]
+                    else:
+                        keep.append(i)
+                todo = np.array(keep, dtype=int)
+            np.testing.assert_array_equal(got, fused["u"])
+            np.testing.assert_array_equal(nc, fused["ncalls"])
+            np.testing.assert_array_equal(states, fused["rng_out"])
+            return
+        a_f, a_l = mk(prob), mk(None)
+        fused = samplers.run_unif(a_f)
+        lock = samplers.run_unif(a_l)
+        for f, l, af, al in zip(fused, lock, a_f, a_l):
+            np.testing.assert_array_equal(f.u, l.u)
+            assert f.ncalls == l.ncalls
+            assert abs(f.logl - l.logl) < 1e-10
+            assert af.rseed.random() == al.rseed.random()
+    finally:
+        backend.set_backend(None)
