@@ -15,6 +15,7 @@
 // map so results are deterministic.  D x D eigenproblems are solved by one
 // wavefront with a parallel-order cyclic Jacobi in LDS.
 #include <math.h>
+#include <stdlib.h>
 
 #include "ctx.h"
 #include "eig_wave.h"
@@ -85,6 +86,9 @@ struct RebuildArgs {
   int* part_base;     // 2 x runs x maxw       first part slot of the node in split_list slot
   int* kbar;          // levels x runs x maxw  arrive counters of the part barriers
   int* kerr;          // runs: error raised inside k_split (folded into status by the next kernel)
+  int* rbar;          // runs x kBarStride: barrier counters of the cooperative root
+  double* rootbuf;    // runs x rootbuf_stride: partials exchanged by the root's parts
+  size_t rootbuf_stride;
   double* kpart;      // 2 x runs x maxp x (2d + 2): per-part partial sums, by iteration parity
   double* scale_g;    // runs x d
   double* pts_scaled; // runs x n x d : points / root std, written once by k_root (k-means input)
@@ -490,39 +494,38 @@ constexpr int kMfmaMinDim = 10;  // below this the quadratic form stays on the V
 // sample covariance (ddof=1) of a node about L.mean -> L.A (np.cov, bounding.py:1411):
 // C = Xc^T Xc.  Each wave contracts its own 64 points of every tile (K = points, 16 MFMA
 // steps of 4), upper 16x16 blocks only; the four partial sums are folded in wave order.
-__device__ void node_cov(const Lds& L, const double* pts, const int* perm, int start, int count, int D) {
+// accumulate Xc^T Xc of the staged (centred) tile: each wave contracts its own 64 points
+__device__ __forceinline__ void tile_cov_accumulate(const Lds& L, int cnt, int D, mfma_acc (&acc)[6]) {
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, LD = L.LD;
   const int nb = (D + 15) >> 4;  // 16-wide dimension blocks: 1..3 (D <= 44)
   const int lj = lane & 15, lk = lane >> 4;
-  mfma_acc acc[6];  // (0,0) (0,1) (1,1) (0,2) (1,2) (2,2)
-#pragma unroll
-  for (int b = 0; b < 6; ++b) acc[b] = (mfma_acc){0.0, 0.0, 0.0, 0.0};
   const bool v0 = lj < D, v1 = 16 + lj < D, v2 = 32 + lj < D;
-  for (int base = 0; base < count; base += L.TP) {
-    const int cnt = min(L.TP, count - base);
-    stage_tile(L, pts, perm, start + base, cnt, D, 1);
-    const int pend = min(cnt, w * 64 + 64);
-    for (int p0 = w * 64; p0 < pend; p0 += 4) {
-      const int p = p0 + lk;
-      const bool pv = p < cnt;
-      const double* row = L.tile + p * LD + lj;
-      const double f0 = (pv && v0) ? row[0] : 0.0;
-      acc[0] = DH_MFMA_F64(f0, f0, acc[0]);
-      if (nb > 1) {
-        const double f1 = (pv && v1) ? row[16] : 0.0;
-        acc[1] = DH_MFMA_F64(f0, f1, acc[1]);
-        acc[2] = DH_MFMA_F64(f1, f1, acc[2]);
-        if (nb > 2) {
-          const double f2 = (pv && v2) ? row[32] : 0.0;
-          acc[3] = DH_MFMA_F64(f0, f2, acc[3]);
-          acc[4] = DH_MFMA_F64(f1, f2, acc[4]);
-          acc[5] = DH_MFMA_F64(f2, f2, acc[5]);
-        }
+  const int pend = min(cnt, w * 64 + 64);
+  for (int p0 = w * 64; p0 < pend; p0 += 4) {
+    const int p = p0 + lk;
+    const bool pv = p < cnt;
+    const double* row = L.tile + p * LD + lj;
+    const double f0 = (pv && v0) ? row[0] : 0.0;
+    acc[0] = DH_MFMA_F64(f0, f0, acc[0]);
+    if (nb > 1) {
+      const double f1 = (pv && v1) ? row[16] : 0.0;
+      acc[1] = DH_MFMA_F64(f0, f1, acc[1]);
+      acc[2] = DH_MFMA_F64(f1, f1, acc[2]);
+      if (nb > 2) {
+        const double f2 = (pv && v2) ? row[32] : 0.0;
+        acc[3] = DH_MFMA_F64(f0, f2, acc[3]);
+        acc[4] = DH_MFMA_F64(f1, f2, acc[4]);
+        acc[5] = DH_MFMA_F64(f2, f2, acc[5]);
       }
     }
-    __syncthreads();
   }
-  // fold the four wave partials into L.A in wave order (deterministic)
+}
+
+// fold the four wave partials into the upper triangle of L.A in wave order (deterministic)
+__device__ __forceinline__ void cov_fold_waves(const Lds& L, int D, const mfma_acc (&acc)[6]) {
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, LD = L.LD;
+  const int nb = (D + 15) >> 4;
+  const int lj = lane & 15, lk = lane >> 4;
   for (int wv = 0; wv < kThreads / 64; ++wv) {
     if (w == wv) {
 #pragma unroll
@@ -544,17 +547,33 @@ __device__ void node_cov(const Lds& L, const double* pts, const int* perm, int s
     }
     __syncthreads();
   }
-  // 1/(n-1) and mirror the upper triangle
-  const double inv = 1.0 / (double)(count - 1);
-  for (int e = t; e < D * D; e += kThreads) {
+}
+
+// upper triangle of L.A times inv, mirrored
+__device__ __forceinline__ void cov_finalize(const Lds& L, int D, double inv) {
+  for (int e = threadIdx.x; e < D * D; e += kThreads) {
     const int i = e / D, j = e - i * D;
     if (i <= j) {
-      const double c = L.A[i * LD + j] * inv;
-      L.A[i * LD + j] = c;
-      L.A[j * LD + i] = c;
+      const double c = L.A[i * L.LD + j] * inv;
+      L.A[i * L.LD + j] = c;
+      L.A[j * L.LD + i] = c;
     }
   }
   __syncthreads();
+}
+
+__device__ void node_cov(const Lds& L, const double* pts, const int* perm, int start, int count, int D) {
+  mfma_acc acc[6];  // (0,0) (0,1) (1,1) (0,2) (1,2) (2,2)
+#pragma unroll
+  for (int b = 0; b < 6; ++b) acc[b] = (mfma_acc){0.0, 0.0, 0.0, 0.0};
+  for (int base = 0; base < count; base += L.TP) {
+    const int cnt = min(L.TP, count - base);
+    stage_tile(L, pts, perm, start + base, cnt, D, 1);
+    tile_cov_accumulate(L, cnt, D, acc);
+    __syncthreads();
+  }
+  cov_fold_waves(L, D, acc);
+  cov_finalize(L, D, 1.0 / (double)(count - 1));
 }
 
 // max over the staged tile of x^T AM x (AM: D x LD in LDS, symmetric; x = tile rows):
@@ -728,43 +747,30 @@ __device__ bool regularize(const Lds& L, double* cov, int D) {
   return trial == 0;
 }
 
-// bounding_ellipsoid (bounding.py:1387-1461) of the node segment; writes the
-// ellipsoid record to `es` (global).  Returns 0 or a DH_ERR code (uniform).
-__device__ int node_ellipsoid(const Lds& L, const RebuildArgs& a, const double* pts, const int* perm,
-                              int start, int count, double* es, double* cov_g, double* logvol_out) {
-  const int D = a.d, t = threadIdx.x, LD = L.LD;
-  if (count == 1) return DH_ERR_VALUE;
-  PH_T0();
-  node_mean(L, pts, perm, start, count, D);
-  PH_ADD(0);
-  node_cov(L, pts, perm, start, count, D);
-  PH_ADD(1);
-  // cov_g: this node's D x LD working covariance (global scratch, L2 resident)
-  for (int e = t; e < D * D; e += kThreads) cov_g[(e / D) * LD + e % D] = L.A[(e / D) * LD + e % D];
-  __syncthreads();
+// enlarge the ellipsoid so that the outermost point sits at 1 - ROUND_DELTA (bounding.py:1438-1448)
+__device__ __forceinline__ void ellipsoid_rescale(const Lds& L, double* cov_g, int D, double fmx) {
+  const int t = threadIdx.x, LD = L.LD;
   const double lim = 1.0 - kRoundDelta;
-  for (int pass = 0; pass < 2; ++pass) {
-    const bool good = regularize(L, cov_g, D);
-    PH_ADD(2);
-    const double fmx = node_fmax(L, pts, perm, start, count, D);
-    PH_ADD(3);
-    if (pass == 0 && fmx > lim) {
-      const double mult = fmx / lim;
-      const double rt = sqrt(mult);
-      for (int e = t; e < D * D; e += kThreads) {
-        const int i = e / D, j = e % D;
-        cov_g[i * LD + j] *= mult;
-        L.AM[i * LD + j] /= mult;
-        L.AX[i * LD + j] *= rt;
-      }
-      __syncthreads();
-      if (t < D) L.lam[t] *= mult;
-      __syncthreads();
+  if (fmx > lim) {
+    const double mult = fmx / lim;
+    const double rt = sqrt(mult);
+    for (int e = t; e < D * D; e += kThreads) {
+      const int i = e / D, j = e % D;
+      cov_g[i * LD + j] *= mult;
+      L.AM[i * LD + j] /= mult;
+      L.AX[i * LD + j] *= rt;
     }
-    if (pass == 1 && fmx >= 1.0) return DH_ERR_CONTAIN;
-    if (good) break;
+    __syncthreads();
+    if (t < D) L.lam[t] *= mult;
+    __syncthreads();
   }
-  // Ellipsoid.__init__ (bounding.py:201-240): eigenvalues must be positive
+}
+
+// Ellipsoid.__init__ (bounding.py:201-240): eigenvalues must be positive; log-volume; the
+// record ctr | cov | am | axes | axlens -> es
+__device__ __forceinline__ int ellipsoid_store(const Lds& L, const RebuildArgs& a, double* es, const double* cov_g,
+                                               double* logvol_out) {
+  const int D = a.d, t = threadIdx.x, LD = L.LD;
   bool ok = true;
   double slog = 0.0;
   for (int k = 0; k < D; ++k) {
@@ -774,7 +780,6 @@ __device__ int node_ellipsoid(const Lds& L, const RebuildArgs& a, const double* 
   }
   if (!ok) return DH_ERR_VALUE;
   const double logvol = a.prefactor + 0.5 * slog;
-  // store: ctr | cov | am | axes | axlens
   const int DD = D * D;
   if (t < D) {
     es[t] = L.mean[t];
@@ -789,6 +794,32 @@ __device__ int node_ellipsoid(const Lds& L, const RebuildArgs& a, const double* 
   __syncthreads();
   *logvol_out = logvol;
   return DH_OK;
+}
+
+// bounding_ellipsoid (bounding.py:1387-1461) of the node segment; writes the
+// ellipsoid record to `es` (global).  Returns 0 or a DH_ERR code (uniform).
+__device__ int node_ellipsoid(const Lds& L, const RebuildArgs& a, const double* pts, const int* perm,
+                              int start, int count, double* es, double* cov_g, double* logvol_out) {
+  const int D = a.d, t = threadIdx.x, LD = L.LD;
+  if (count == 1) return DH_ERR_VALUE;
+  PH_T0();
+  node_mean(L, pts, perm, start, count, D);
+  PH_ADD(0);
+  node_cov(L, pts, perm, start, count, D);
+  PH_ADD(1);
+  // cov_g: this node's D x LD working covariance (global scratch, L2 resident)
+  for (int e = t; e < D * D; e += kThreads) cov_g[(e / D) * LD + e % D] = L.A[(e / D) * LD + e % D];
+  __syncthreads();
+  for (int pass = 0; pass < 2; ++pass) {
+    const bool good = regularize(L, cov_g, D);
+    PH_ADD(2);
+    const double fmx = node_fmax(L, pts, perm, start, count, D);
+    PH_ADD(3);
+    if (pass == 0) ellipsoid_rescale(L, cov_g, D, fmx);
+    if (pass == 1 && fmx >= 1.0) return DH_ERR_CONTAIN;
+    if (good) break;
+  }
+  return ellipsoid_store(L, a, es, cov_g, logvol_out);
 }
 
 // ---- k-means (k = 2) + stable partition of a node, cooperatively by its parts -----------
@@ -997,7 +1028,7 @@ __device__ __forceinline__ double logaddexp_d(double x, double y) {
 }
 
 // ---- the rebuild as a level-synchronous kernel pipeline ----------------------
-//   k_root   (grid = runs)            root ellipsoid, per-run scale, worklist seed
+//   k_root_parts (grid = runs x ceil(n/TP))  root ellipsoid by cooperating resident parts, per-run scale, worklist seed
 //   k_split  (grid = runs * maxw)     one workgroup per splittable node of the
 //                                     level: k-means (k=2) + stable partition
 //   k_ell    (grid = runs * 2 maxw)   one workgroup per new child: bounding
@@ -1119,22 +1150,223 @@ __device__ __forceinline__ void queue_split(const RebuildArgs& a, int run, int l
   }
 }
 
-__global__ void __launch_bounds__(kThreads) k_root(RebuildArgs a) {
+// ---- the root, cooperatively -----------------------------------------------------------------
+// k_root spends most of its time gathering the 8 tiles of a 2000-point live set three times (mean,
+// covariance, Mahalanobis maximum) and a fourth and fifth time for std and the scaled copy.
+// Here the root is worked on by np = ceil(n / TP) workgroups, each keeping ITS tile resident in LDS
+// for the whole kernel: partial column sums -> mean, centred in place, partial Xc^T Xc on the
+// matrix cores, Mahalanobis maximum and sum of squares over the own tile; the parts meet at the
+// fence-free device-scope barrier of the k-means parts (five times) and exchange their partials
+// with agent-scope stores / loads.  Part 0 alone runs the eigensolver (improve_covar_mat) and
+// writes the node; if the covariance needed regularising it falls back to the single-workgroup
+// routine for the rest (rare path, same code as k_root).
+// rootbuf per run: [np x D sums | np x D^2 cov partials | np fmax | np x D squares | D^2 am | 8 flags]
+__global__ void __launch_bounds__(kThreads) k_root_parts(RebuildArgs a, int rp) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int D = a.d, t = threadIdx.x, run = blockIdx.x;
+  const int D = a.d, DD = D * D, t = threadIdx.x, run = blockIdx.x / rp, q = blockIdx.x % rp;
   const int n = a.n_arr ? a.n_arr[run] : a.n;
   if (a.active && !a.active[run]) return;
   Lds L;
   carve(L, smem, D);
+  const int np = (n > 1 && rp > 1) ? (n + L.TP - 1) / L.TP : 1;  // rp == 1: the single-workgroup routine for any n
+  if (q >= np) return;
   const RunView v = view_of(a, run, L.LD);
-  for (int p = t; p < n; p += kThreads) v.perm[p] = p;
+  const int LD = L.LD;
+  const int s0 = q * L.TP, cnt = min(L.TP, n - s0);
+  // identity permutation: every part its own range (the only part: everything)
+  for (int p = s0 + t; p < (np == 1 ? n : s0 + cnt); p += kThreads) v.perm[p] = p;
   __threadfence_block();
   __syncthreads();
+  double* es = v.estore;
+  double* cov_g = v.estore + v.ES;
   int status = DH_OK;
-  if (n <= 1) status = (a.mode == 0) ? DH_ERR_REGION : DH_ERR_VALUE;  // single point
   double lv = 0.0;
-  if (status == DH_OK) status = node_ellipsoid(L, a, v.pts, v.perm, 0, n, v.estore, v.estore + v.ES, &lv);
-  if (t == 0) {
+  if (np == 1) {
+    // small live set: the single-workgroup routine
+    if (n <= 1) status = (a.mode == 0) ? DH_ERR_REGION : DH_ERR_VALUE;  // single point
+    if (status == DH_OK) status = node_ellipsoid(L, a, v.pts, v.perm, 0, n, es, cov_g, &lv);
+  } else {
+    double* rb = a.rootbuf + (size_t)run * a.rootbuf_stride;
+    double* b_sum = rb;
+    double* b_cov = b_sum + (size_t)rp * D;
+    double* b_fmx = b_cov + (size_t)rp * DD;
+    double* b_sq = b_fmx + rp;
+    double* b_am = b_sq + (size_t)rp * D;
+    double* b_flag = b_am + DD;
+    int* bar = a.rbar + (size_t)run * kBarStride;
+    int phase = 0;
+    const int G = kThreads / D > 0 ? kThreads / D : 1;
+    const int j = t % D, g = t / D;
+    // ---- mean ----
+    stage_tile(L, v.pts, v.perm, s0, cnt, D, 0);
+    {
+      double acc = 0.0;
+      if (t < G * D)
+        for (int p = g; p < cnt; p += G) acc += L.tile[p * LD + j];
+      L.red[t] = acc;
+      __syncthreads();
+      if (t < D) {
+        double sum = 0.0;
+        for (int gg = 0; gg < G; ++gg) sum += L.red[gg * D + t];
+        st_agent(b_sum + (size_t)q * D + t, sum);
+      }
+    }
+    if (!parts_barrier(bar, np * ++phase)) status = DH_ERR_HIP;
+    if (t < D) {
+      double sum = 0.0;
+      for (int pp0 = 0; pp0 < np; pp0 += 8) {
+        double part[8];
+#pragma unroll
+        for (int uu = 0; uu < 8; ++uu) part[uu] = pp0 + uu < np ? ld_agent(b_sum + (size_t)(pp0 + uu) * D + t) : 0.0;
+#pragma unroll
+        for (int uu = 0; uu < 8; ++uu) sum += part[uu];
+      }
+      L.mean[t] = sum / (double)n;
+    }
+    __syncthreads();
+    // ---- covariance: partial Xc^T Xc of the own tile ----
+    stage_tile(L, v.pts, v.perm, s0, cnt, D, 1);  // centred in place
+    {
+      mfma_acc acc[6];
+#pragma unroll
+      for (int b = 0; b < 6; ++b) acc[b] = (mfma_acc){0.0, 0.0, 0.0, 0.0};
+      tile_cov_accumulate(L, cnt, D, acc);
+      __syncthreads();
+      cov_fold_waves(L, D, acc);
+      for (int e = t; e < DD; e += kThreads) {
+        const int i = e / D, k = e - i * D;
+        if (i <= k) st_agent(b_cov + (size_t)q * DD + e, L.A[i * LD + k]);
+      }
+    }
+    if (!parts_barrier(bar, np * ++phase)) status = DH_ERR_HIP;
+    // ---- part 0: eigensolver; publishes the precision matrix (flag 1) or falls back (flag 2) ----
+    if (q == 0) {
+      for (int e = t; e < DD; e += kThreads) {
+        const int i = e / D, k = e - i * D;
+        if (i <= k) {
+          double sum = 0.0;
+          for (int pp0 = 0; pp0 < np; pp0 += 8) {
+            double part[8];
+#pragma unroll
+            for (int uu = 0; uu < 8; ++uu)
+              part[uu] = pp0 + uu < np ? ld_agent(b_cov + (size_t)(pp0 + uu) * DD + e) : 0.0;
+#pragma unroll
+            for (int uu = 0; uu < 8; ++uu) sum += part[uu];
+          }
+          L.A[i * LD + k] = sum;
+        }
+      }
+      __syncthreads();
+      cov_finalize(L, D, 1.0 / (double)(n - 1));
+      for (int e = t; e < DD; e += kThreads) cov_g[(e / D) * LD + e % D] = L.A[(e / D) * LD + e % D];
+      __syncthreads();
+      const bool good = regularize(L, cov_g, D);  // may overlay the tile with the Jacobi buffers
+      if (good) {
+        for (int e = t; e < DD; e += kThreads) st_agent(b_am + e, L.AM[(e / D) * LD + e % D]);
+        if (t == 0) st_agent(b_flag, 1.0);
+      } else {
+        if (t == 0) st_agent(b_flag, 2.0);
+      }
+    }
+    if (!parts_barrier(bar, np * ++phase)) status = DH_ERR_HIP;
+    const int flag = (int)ld_agent(b_flag);
+    if (flag == 1) {
+      if (q > 0) {
+        for (int e = t; e < DD; e += kThreads) L.AM[(e / D) * LD + e % D] = ld_agent(b_am + e);
+        __syncthreads();
+      }
+      // ---- Mahalanobis maximum over the own tile ----
+      stage_tile(L, v.pts, v.perm, s0, cnt, D, 1);  // still resident unless the Jacobi buffers overlaid it
+      double best = -INFINITY;
+      if (D >= kMfmaMinDim) {
+        best = tile_quadform_max(L, L.AM, cnt, D, best);
+      } else {
+        for (int p = t; p < cnt; p += kThreads) {
+          const double* x = L.tile + p * LD;
+          double qf = 0.0;
+          for (int i = 0; i < D; ++i) {
+            double r = 0.0;
+            const double* row = L.AM + i * LD;
+            for (int k = 0; k < D; ++k) r = fma(row[k], x[k], r);
+            qf = fma(x[i], r, qf);
+          }
+          best = fmax(best, qf);
+        }
+      }
+      __syncthreads();
+      best = block_reduce_max(best, L.red);
+      if (t == 0) st_agent(b_fmx + q, best);
+      if (!parts_barrier(bar, np * ++phase)) status = DH_ERR_HIP;
+      if (q == 0) {
+        double fmx = -INFINITY;
+        for (int pp = 0; pp < np; ++pp) fmx = fmax(fmx, ld_agent(b_fmx + pp));
+        ellipsoid_rescale(L, cov_g, D, fmx);
+        if (status == DH_OK) status = ellipsoid_store(L, a, es, cov_g, &lv);
+      }
+    } else {
+      // regularised covariance: the reference's second pass (bounding.py:1449-1453) by the
+      // single-workgroup routine, from scratch
+      if (q == 0 && status == DH_OK) {
+        // the other parts' ranges of the identity permutation were written by other CUs with
+        // plain stores (not visible across XCDs inside this kernel): write them here as well
+        for (int p = t; p < n; p += kThreads) v.perm[p] = p;
+        __threadfence_block();
+        __syncthreads();
+        status = node_ellipsoid(L, a, v.pts, v.perm, 0, n, es, cov_g, &lv);
+      }
+      if (!parts_barrier(bar, np * ++phase)) status = DH_ERR_HIP;
+    }
+    // ---- status to all parts ----
+    if (q == 0 && t == 0) st_agent(b_flag + 1, (double)status);
+    if (!parts_barrier(bar, np * ++phase)) status = DH_ERR_HIP;
+    if (status == DH_OK) status = (int)ld_agent(b_flag + 1);
+    // ---- std and the scaled copy for the k-means (bounding.py:1503-1510) ----
+    if (status == DH_OK && a.mode == 0 && n >= 4 * D) {
+      if (q == 0 && flag != 1) {
+        // the fallback recomputed the mean into L.mean: identical values, nothing to do
+      }
+      stage_tile(L, v.pts, v.perm, s0, cnt, D, 1);
+      double acc = 0.0;
+      if (t < G * D)
+        for (int p = g; p < cnt; p += G) {
+          const double x = L.tile[p * LD + j];
+          acc = fma(x, x, acc);
+        }
+      L.red[t] = acc;
+      __syncthreads();
+      if (t < D) {
+        double sum = 0.0;
+        for (int gg = 0; gg < G; ++gg) sum += L.red[gg * D + t];
+        st_agent(b_sq + (size_t)q * D + t, sum);
+      }
+      if (!parts_barrier(bar, np * ++phase)) status = DH_ERR_HIP;
+      if (t < D) {
+        double sum = 0.0;
+        for (int pp0 = 0; pp0 < np; pp0 += 8) {
+          double part[8];
+#pragma unroll
+          for (int uu = 0; uu < 8; ++uu) part[uu] = pp0 + uu < np ? ld_agent(b_sq + (size_t)(pp0 + uu) * D + t) : 0.0;
+#pragma unroll
+          for (int uu = 0; uu < 8; ++uu) sum += part[uu];
+        }
+        L.scale[t] = sqrt(sum / (double)n);
+      }
+      __syncthreads();
+      {
+        double* ps = a.pts_scaled + (size_t)run * a.n * D;
+        const int jj = t & (L.DP - 1), p0 = t >> L.DPlog, pstep = kThreads >> L.DPlog;
+        if (jj < D) {
+          const double sj = L.scale[jj];
+          for (int p = s0 + p0; p < s0 + cnt; p += pstep) ps[(size_t)p * D + jj] = v.pts[(size_t)p * D + jj] / sj;
+        }
+      }
+      if (q == 0) {
+        if (t < D) a.scale_g[(size_t)run * D + t] = L.scale[t];
+        if (t == 0 && status == DH_OK) queue_split(a, run, 0, 0, n, kThreads);
+      }
+    }
+  }
+  if (q == 0 && t == 0) {
     Node r;
     r.start = 0;
     r.count = n;
@@ -1149,18 +1381,14 @@ __global__ void __launch_bounds__(kThreads) k_root(RebuildArgs a) {
     a.nnodes_dev[run] = 1;
     a.status[run] = status;
   }
-  // root std -> per-run scale (bounding.py:1503-1504), seed of the level-0 worklist
-  if (status == DH_OK && a.mode == 0 && n >= 4 * D) {
+  if (np == 1 && status == DH_OK && a.mode == 0 && n >= 4 * D) {
     node_std(L, v.pts, v.perm, 0, n, D);
     if (t < D) a.scale_g[(size_t)run * D + t] = L.scale[t];
-    {
-      // points / scale once (the reference divides the whole array before kmeans2, :1510)
-      double* ps = a.pts_scaled + (size_t)run * a.n * D;
-      const int j = t & (L.DP - 1), p0 = t >> L.DPlog, pstep = kThreads >> L.DPlog;
-      if (j < D) {
-        const double sj = L.scale[j];
-        for (int p = p0; p < n; p += pstep) ps[(size_t)p * D + j] = v.pts[(size_t)p * D + j] / sj;
-      }
+    double* ps = a.pts_scaled + (size_t)run * a.n * D;
+    const int jj = t & (L.DP - 1), p0 = t >> L.DPlog, pstep = kThreads >> L.DPlog;
+    if (jj < D) {
+      const double sj = L.scale[jj];
+      for (int p = p0; p < n; p += pstep) ps[(size_t)p * D + jj] = v.pts[(size_t)p * D + jj] / sj;
     }
     if (t == 0) queue_split(a, run, 0, 0, n, kThreads);
   }
@@ -1685,8 +1913,15 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
       }
     }
   }
-  // zeroed counters: nnodes | nsplit (levels+1) | nell (levels) | nparts (levels+1) | kerr | kbar (levels x maxw)
-  const size_t b_cnt = (size_t)runs * ((size_t)3 * a.levels + 5 + (size_t)a.levels * a.maxw * kBarStride) * 4;
+  // parts of the root: cooperative only while all parts of all runs are resident with room to spare
+  // (a part idles at a barrier while part 0 runs the eigensolver, so on a full chip it only costs slots)
+  int rp = n > 1 ? (n + kThreads - 1) / kThreads : 1;
+  if ((long long)runs * rp > 512) rp = 1;
+  if (getenv("DH_ROOT_PARTS") && atoi(getenv("DH_ROOT_PARTS")) == 0) rp = 1;  // diagnostic
+  // zeroed counters: nnodes | nsplit (levels+1) | nell (levels) | nparts (levels+1) | kerr | rbar | kbar (levels x maxw)
+  const size_t b_cnt = (size_t)runs * ((size_t)3 * a.levels + 5 + kBarStride + (size_t)a.levels * a.maxw * kBarStride) * 4;
+  a.rootbuf_stride = (size_t)rp * (2 * (size_t)d + (size_t)d * d + 1) + (size_t)d * d + 8;
+  const size_t b_rb = (size_t)runs * a.rootbuf_stride * 8;
   const size_t b_pl = (size_t)2 * runs * a.maxp * 2 * 4, b_pb = (size_t)2 * runs * a.maxw * 4;
   const size_t b_kp = mode == 1 ? 0 : (size_t)2 * runs * a.maxp * (2 * (size_t)d + 2) * 8;
   const size_t b_sl = (size_t)2 * runs * a.maxw * 4, b_el = (size_t)runs * 2 * a.maxw * 4;
@@ -1694,7 +1929,7 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
   const size_t b_ps = mode == 1 ? 0 : (size_t)runs * n * d * 8;
   auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
   const size_t total = al(b_perm) * 2 + al(b_lab) + al(b_nodes) + al(b_es) + al(b_res) + al(b_cnt) +
-                       al(b_sl) + al(b_el) + al(b_sc) + al(b_ps) + al(b_pl) + al(b_pb) + al(b_kp);
+                       al(b_sl) + al(b_el) + al(b_sc) + al(b_ps) + al(b_pl) + al(b_pb) + al(b_kp) + al(b_rb);
   if (total > ctx->rebuild_ws_cap) {
     if (!hip_ok(ctx, hipStreamSynchronize(ctx->stream), "sync")) return DH_ERR_HIP;
     if (ctx->rebuild_ws) (void)hipFree(ctx->rebuild_ws);
@@ -1724,7 +1959,8 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
   a.nell = a.nsplit + (size_t)(a.levels + 1) * runs;
   a.nparts = a.nell + (size_t)a.levels * runs;
   a.kerr = a.nparts + (size_t)(a.levels + 1) * runs;
-  a.kbar = a.kerr + runs;
+  a.rbar = a.kerr + runs;
+  a.kbar = a.rbar + (size_t)runs * kBarStride;
   a.split_list = (int*)w;
   w += al(b_sl);
   a.ell_list = (int*)w;
@@ -1738,6 +1974,8 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
   a.part_base = (int*)w;
   w += al(b_pb);
   a.kpart = (double*)w;
+  w += al(b_kp);
+  a.rootbuf = (double*)w;
   a.nells = nells;
   a.status = status;
   a.ctrs = ctrs;
@@ -1752,7 +1990,7 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
   a.n_arr = n_arr;
   static size_t attr_lds = 0;
   if (lds > attr_lds) {
-    const void* ks[3] = {(const void*)k_root, (const void*)k_split, (const void*)k_ell};
+    const void* ks[3] = {(const void*)k_root_parts, (const void*)k_split, (const void*)k_ell};
     for (const void* kf : ks)
       if (!hip_ok(ctx, hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
                   "hipFuncSetAttribute(rebuild LDS)"))
@@ -1767,7 +2005,7 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
     attr_fin = lds_fin;
   }
   if (!hip_ok(ctx, hipMemsetAsync(cnt, 0, b_cnt, ctx->stream), "memset(rebuild counters)")) return DH_ERR_HIP;
-  hipLaunchKernelGGL(k_root, dim3(runs), dim3(kThreads), lds, ctx->stream, a);
+  hipLaunchKernelGGL(k_root_parts, dim3(runs * rp), dim3(kThreads), lds, ctx->stream, a, rp);
   for (int L = 0; L < a.levels; ++L) {
     hipLaunchKernelGGL(k_split, dim3(runs * a.maxp), dim3(kThreads), lds, ctx->stream, a, L);
     hipLaunchKernelGGL(k_ell, dim3(runs * 2 * a.maxw), dim3(kThreads), lds, ctx->stream, a, L);
