@@ -876,12 +876,14 @@ __device__ int node_kmeans_part(const Lds& L, const double* pts, int* perm, int*
   const int DD = D * D, KP = 2 * D + 2;
   const int s0 = start + q * L.TP, cnt = min(L.TP, count - q * L.TP);
   // seeds: major-axis endpoints ctr -/+ axes[:, argmax(axlens)] (bounding.py:278-284)
+  if (t < D) L.sums[t] = es[D + 3 * DD + t];  // axis lengths: one parallel fetch, then a scan in LDS
+  __syncthreads();
   if (t == 0) {
     int best = 0;
-    double bl = es[D + 3 * DD];
+    double bl = L.sums[0];
     for (int k = 1; k < D; ++k)
-      if (es[D + 3 * DD + k] > bl) {
-        bl = es[D + 3 * DD + k];
+      if (L.sums[k] > bl) {
+        bl = L.sums[k];
         best = k;
       }
     L.ri[301] = best;
@@ -902,6 +904,8 @@ __device__ int node_kmeans_part(const Lds& L, const double* pts, int* perm, int*
     if (t < cnt) {
       const double* x = L.tile + t * LD;
       double d0 = 0.0, d1 = 0.0;
+      // loads of four dimensions in flight per LDS round trip (same summation order)
+#pragma unroll 4
       for (int jj = 0; jj < D; ++jj) {
         const double xv = x[jj];
         const double e0 = xv - L.cen[jj], e1 = xv - L.cen[D + jj];
