@@ -319,7 +319,7 @@ def main():
                         "set is read ~3 times per level, not 12"}
         if e2e is not None:
             line["config"]["end_to_end"] = e2e
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:  # the CPU baseline is timed on rank 0 at N = 1 only
             line["cpu_baseline"] = cpu_baseline(prob, u0, nlive, scale,
                                                 loglstar, args.walks,
                                                 args.cpu_seconds)
