@@ -899,6 +899,7 @@ __device__ int node_kmeans_part(const Lds& L, const double* pts, int* perm, int*
   const int nb = (D + 15) >> 4;
   const int lj = lane & 15, lk = lane >> 4;
   int lb = 0, n0 = 0, c0_tile = 0;
+  PH_T0();
   for (int it = 0; it < 10; ++it) {
     // vq: nearest centroid, strict '<' so the lower index wins ties
     if (t < cnt) {
@@ -916,6 +917,7 @@ __device__ int node_kmeans_part(const Lds& L, const double* pts, int* perm, int*
       L.ri[t] = lb;
     }
     c0_tile = __syncthreads_count(t < cnt && lb == 0);  // also publishes the labels
+    PH_ADD(10);
     // update_cluster_means: per-cluster sums = Labels^T X on the matrix cores; wave w
     // contracts its 64 points (rows 0/1 of the 16-row A operand are the two indicators)
     mfma_acc a0 = {0.0, 0.0, 0.0, 0.0}, a1 = a0, a2 = a0;
@@ -937,6 +939,7 @@ __device__ int node_kmeans_part(const Lds& L, const double* pts, int* perm, int*
       if (nb > 2) o[32 + lj] = a2[0];
     }
     __syncthreads();
+    PH_ADD(11);
     double* kp = (it & 1) ? kp1 : kp0;
     if (t < 2 * D) {
       const int c = t >= D ? 1 : 0, j = t - c * D;
@@ -976,6 +979,7 @@ __device__ int node_kmeans_part(const Lds& L, const double* pts, int* perm, int*
       if (n1 > 0) L.cen[D + t] = L.sums[D + t] / (double)n1;
     }
     __syncthreads();
+    PH_ADD(12);
   }
   if (min(n0, count - n0) < min_size) return n0;  // split rejected (:1521-1522): no partition needed
   // ---- stable partition by label (label 0 first) ----
