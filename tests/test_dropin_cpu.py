@@ -2,8 +2,9 @@
 the oracle test backend on CPU: the plugin classes must be accepted by an
 unmodified NestedSampler, survive deepcopy / pickling, honour dynesty's
 isinstance-keyed defaults, and the batching pool must turn a queue fill into
-one runner call.  (The same classes run on the HIP backend in
-tests/test_gpu_dropin.py through a dynesty-free driver.)
+one runner call.  (The same bound classes and samplers run on the HIP backend
+in tests/test_gpu_endtoend.py / test_gpu_friends.py through the dynesty-free
+driver, dynesty not being installed on the GPU box.)
 
 Model: reference tests/test_bound_interface.py and test_sampler_interface.py.
 """
