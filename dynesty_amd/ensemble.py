@@ -238,6 +238,79 @@ def run_ensemble_merged(prob, runs, nlive=2000, queue_size=512, entropy=(21,),
     return m
 
 
+def gather_and_merge(points_per_run, nlive, world=1, rank=0, dist=None,
+                     device=None, prior_transform=None, ncall=None):
+    """The sharded form of the combiner (north star: "gather of logZ / posterior
+    samples"): every rank contributes, per local run, ONE array of rows
+    [logl, is_final_live, u_0 .. u_{D-1}] (dead points in death order, then the
+    final live points in any order); the rows travel in the ragged all-gather
+    (`gather_ragged`: counts + padded rows, RCCL on GPUs, gloo on CPU) and every
+    rank merges all runs with `merge_static_runs`.  Returns the MergedRun."""
+    allruns = gather_ragged(points_per_run, world, rank, dist=dist, device=device)
+    R = len(allruns)
+    d = allruns[0].shape[1] - 2
+    nit = np.array([int((a[:, 1] == 0).sum()) for a in allruns])
+    dead_l = np.zeros((R, max(1, nit.max())))
+    dead_u = np.zeros((R, max(1, nit.max()), d))
+    live_l = np.zeros((R, nlive))
+    live_u = np.zeros((R, nlive, d))
+    for i, a in enumerate(allruns):
+        dmask = a[:, 1] == 0
+        dead_l[i, :nit[i]] = a[dmask, 0]
+        dead_u[i, :nit[i]] = a[dmask, 2:]
+        live_l[i] = a[~dmask, 0]
+        live_u[i] = a[~dmask, 2:]
+    if ncall is not None and dist is not None and world > 1:
+        import torch
+        t = torch.tensor([float(np.sum(ncall))], dtype=torch.float64)
+        if device is not None:
+            t = t.to(device)
+        dist.all_reduce(t)
+        ncall = [float(t.item())]
+    return merge_static_runs(dead_l, nit, live_l, dead_u, live_u,
+                             prior_transform=prior_transform, ncall=ncall)
+
+
+def run_rows(dead_logl, dead_u, live_logl, live_u):
+    """One run as the row block `gather_and_merge` expects."""
+    k, n = len(dead_logl), len(live_logl)
+    out = np.empty((k + n, 2 + np.shape(live_u)[1]))
+    out[:k, 0], out[k:, 0] = dead_logl, live_logl
+    out[:k, 1], out[k:, 1] = 0., 1.
+    out[:k, 2:], out[k:, 2:] = dead_u, live_u
+    return out
+
+
+def run_ensemble_merged_sharded(prob, total_runs, base_seed=21, world=1, rank=0,
+                                dist=None, device=None, nlive=2000,
+                                queue_size=512, max_iter=None, **kw):
+    """BASELINE C5 end to end: this rank's shard of `total_runs` device-resident
+    runs (dh_ns_ensemble with coordinates), the ragged gather of every run's
+    points, and the merged posterior / evidence on every rank."""
+    from .backend import get_backend
+    be = get_backend()
+    mine = shard_runs(total_runs, world, rank)
+    if max_iter is None:
+        max_iter = 80 * nlive
+    rows, ncall = [], 0
+    if len(mine):
+        r = be.ns_ensemble(prob, len(mine), nlive, queue_size,
+                           entropy=np.atleast_1d(base_seed), first_run=mine.start,
+                           max_iter=max_iter, want_samples=True, **kw)
+        if (r["status"] != 0).any():
+            raise RuntimeError(f"ns_ensemble: runs failed, status {r['status']}")
+        ncall = int(r["ncall"].sum())
+        for i in range(len(mine)):
+            k = int(r["niter"][i])
+            rows.append(run_rows(r["dead_logl"][i, :k], r["dead_u"][i, :k],
+                                 r["live_logl"][i], r["live_u"][i]))
+
+    def ptform(u):
+        return be.problem_eval(prob, u)[0]
+    return gather_and_merge(rows, nlive, world, rank, dist=dist, device=device,
+                            prior_transform=ptform, ncall=[ncall])
+
+
 def combine_logz(table):
     """Ensemble estimate: mean of ln Z over runs and its standard error."""
     lz = table[:, RECORD_FIELDS.index("logz")]

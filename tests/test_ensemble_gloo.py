@@ -30,8 +30,15 @@ table, results = ensemble.run_ensemble(
 mine = ensemble.shard_runs(5, world, rank)
 rag = ensemble.gather_ragged([r.samples_u[:3 + rid] for rid, r in zip(mine, results)],
                              world, rank, dist=dist if world > 1 else None)
+rows = []
+for r in results:
+    k = r.niter
+    rows.append(ensemble.run_rows(r.samples_logl[:k], r.samples_u[:k], r.samples_logl[k:], r.samples_u[k:]))
+merged = ensemble.gather_and_merge(rows, 60, world, rank, dist=dist if world > 1 else None,
+                                   ncall=[sum(r.ncall for r in results)])
 out = dict(table=table.tolist(), nrag=[len(a) for a in rag],
-           rag0=rag[0].tolist())
+           rag0=rag[0].tolist(), mlogz=float(merged.logz[-1]), mlogzerr=float(merged.logzerr[-1]),
+           mniter=int(merged.niter), mncall=int(merged.ncall), mu0=merged.samples_u[:5].tolist())
 with open(os.path.join(%(out)r, "r%%d_of_%%d.json" %% (rank, world)), "w") as f:
     json.dump(out, f)
 if world > 1:
@@ -82,3 +89,11 @@ def test_two_process_gather(tmp_path):
     np.testing.assert_array_equal(np.array(one["rag0"]), np.array(two0["rag0"]))
     # sanity of the physics: C1 truth -8.987
     assert abs(t1[:, 1].mean() + 8.987) < 1.0
+    # the merged run (ragged gather of every run's points + merge on each rank) is the same
+    # on both ranks and for both world sizes, and tighter than a single run
+    for k in ("mlogz", "mlogzerr", "mniter", "mncall"):
+        assert one[k] == two0[k] == two1[k], k
+    np.testing.assert_array_equal(np.array(one["mu0"]), np.array(two1["mu0"]))
+    assert one["mniter"] == int(t1[:, 3].sum()) + 5 * 60
+    assert abs(one["mlogz"] + 8.987) < 5 * one["mlogzerr"] + 0.2
+    assert one["mlogzerr"] < np.mean(t1[:, 2])

@@ -136,3 +136,17 @@ def test_samples_and_merged_run(ctx):
     assert np.abs(var - 1.0).max() < 0.25
     # the merged evidence is at least as tight as a single run's
     assert m.logzerr[-1] < r["logzerr"].mean()
+
+
+def test_sharded_merge_equals_single_process(ctx):
+    """run_ensemble_merged_sharded (row blocks through the ragged gather) gives
+    the same merged run as the single-process combiner."""
+    from dynesty_amd import ensemble
+    prob = inputs.problem("C1")
+    kw = dict(nlive=200, queue_size=32, walks=23, bound="single", dlogz=0.3, max_iter=20000)
+    a = ensemble.run_ensemble_merged(prob, 5, entropy=[12], **kw)
+    b = ensemble.run_ensemble_merged_sharded(prob, 5, base_seed=12, **kw)
+    assert a.niter == b.niter and a.ncall == b.ncall
+    np.testing.assert_array_equal(a.logl, b.logl)
+    np.testing.assert_array_equal(a.samples_u, b.samples_u)
+    np.testing.assert_array_equal(a.logz, b.logz)
