@@ -86,6 +86,8 @@ struct RebuildArgs {
   int* part_base;     // 2 x runs x maxw       first part slot of the node in split_list slot
   int* kbar;          // levels x runs x maxw  arrive counters of the part barriers
   int* kerr;          // runs: error raised inside k_split (folded into status by the next kernel)
+  double* fin_lse;    // runs x max_nodes: k_finish scratch (logsumexp of a node's result list)
+  int* fin_int;       // runs x max_nodes x 2: k_finish scratch (accepted split / on the output path)
   int* rbar;          // runs x kBarStride: barrier counters of the cooperative root
   double* rootbuf;    // runs x rootbuf_stride: partials exchanged by the root's parts
   size_t rootbuf_stride;
@@ -1524,56 +1526,77 @@ __global__ void __launch_bounds__(kThreads) k_finish(RebuildArgs a) {
   }
   __syncthreads();
 
-  // ---- bottom-up accept test (bounding.py:1541-1563), thread 0 ----
+  // ---- bottom-up accept test (bounding.py:1541-1563), level-parallel ----
+  // A node's verdict needs only its children's (list length, logsumexp of the list's volumes),
+  // so the tree is reduced depth by depth with all threads (the eggbox-like C3 tree has 1 719
+  // nodes: a serial walk cost 1.3 ms); a top-down pass then hands every surviving leaf its
+  // position in the output list (child-0 subtree first: the reference's concatenation order).
   if (status == DH_OK) {
-    if (t == 0) {
-      L.ri[303] = 0;
-      int top = 0;  // arena cursor
-      for (int i = nnodes - 1; i >= 0; --i) {
-        Node nd = nodes[i];
-        if (!nd.split) {
-          nd.res_start = top;
-          nd.res_len = 1;
-          reslist[top++] = i;
-        } else {
+    double* lse = a.fin_lse + (size_t)run * a.max_nodes;
+    int* acc = a.fin_int + (size_t)run * a.max_nodes * 2;  // accepted split?
+    int* act = acc + a.max_nodes;                           // on the output path?
+    int md = 0;
+    for (int i = t; i < nnodes; i += kThreads) act[i] = 0;
+    __syncthreads();
+    {
+      int mine = 0;
+      for (int i = t; i < nnodes; i += kThreads) mine = max(mine, nodes[i].depth);
+      for (int sft = 32; sft > 0; sft >>= 1) mine = max(mine, __shfl_xor(mine, sft));
+      if ((t & 63) == 0) L.ri[t >> 6] = mine;
+      __syncthreads();
+      md = max(max(L.ri[0], L.ri[1]), max(L.ri[2], L.ri[3]));
+      __syncthreads();
+    }
+    const int nparam = (D * (D + 3)) / 2;
+    for (int dpt = md; dpt >= 0; --dpt) {
+      for (int i = t; i < nnodes; i += kThreads) {
+        const Node nd = nodes[i];
+        if (nd.depth != dpt) continue;
+        int rl = 1, ac = 0;
+        double ls = nd.logvol;
+        if (nd.split) {
           const Node& k0 = nodes[nd.child0];
           const Node& k1 = nodes[nd.child1];
           const int len = k0.res_len + k1.res_len;
-          const int nparam = (D * (D + 3)) / 2;
           const double dec = nparam * log((double)nd.count) / (double)nd.count;
-          bool accept = (logaddexp_d(k0.logvol, k1.logvol) - nd.logvol) < -dec;
-          if (!accept) {
-            // logsumexp over the leaves of both subtrees, in list order
-            double mx = -INFINITY;
-            for (int q = 0; q < k0.res_len; ++q) mx = fmax(mx, nodes[reslist[k0.res_start + q]].logvol);
-            for (int q = 0; q < k1.res_len; ++q) mx = fmax(mx, nodes[reslist[k1.res_start + q]].logvol);
-            double sm = 0.0;
-            for (int q = 0; q < k0.res_len; ++q) sm += exp(nodes[reslist[k0.res_start + q]].logvol - mx);
-            for (int q = 0; q < k1.res_len; ++q) sm += exp(nodes[reslist[k1.res_start + q]].logvol - mx);
-            const double lse = log(sm) + mx;
-            accept = (lse - nd.logvol) < -dec * (len - 1);
-          }
+          const double both = logaddexp_d(lse[nd.child0], lse[nd.child1]);
+          const bool accept = ((logaddexp_d(k0.logvol, k1.logvol) - nd.logvol) < -dec) ||
+                              ((both - nd.logvol) < -dec * (len - 1));
           if (accept) {
-            if (top + len > a.reslist_cap) {
-              L.ri[303] = DH_ERR_NOMEM;
-              break;
-            }
-            nd.res_start = top;
-            nd.res_len = len;
-            for (int q = 0; q < k0.res_len; ++q) reslist[top++] = reslist[k0.res_start + q];
-            for (int q = 0; q < k1.res_len; ++q) reslist[top++] = reslist[k1.res_start + q];
-          } else {
-            nd.res_start = top;
-            nd.res_len = 1;
-            reslist[top++] = i;
+            rl = len;
+            ls = both;
+            ac = 1;
           }
         }
-        nodes[i] = nd;
+        nodes[i].res_len = rl;
+        lse[i] = ls;
+        acc[i] = ac;
       }
+      __threadfence_block();
+      __syncthreads();
+    }
+    if (t == 0) {
+      nodes[0].res_start = 0;
+      act[0] = 1;
     }
     __threadfence_block();
     __syncthreads();
-    if (L.ri[303] != 0) status = DH_ERR_NOMEM;
+    for (int dpt = 0; dpt <= md; ++dpt) {
+      for (int i = t; i < nnodes; i += kThreads) {
+        const Node nd = nodes[i];
+        if (nd.depth != dpt || !act[i]) continue;
+        if (acc[i]) {
+          nodes[nd.child0].res_start = nd.res_start;
+          nodes[nd.child1].res_start = nd.res_start + nodes[nd.child0].res_len;
+          act[nd.child0] = 1;
+          act[nd.child1] = 1;
+        } else if (nd.res_start < a.reslist_cap) {
+          reslist[nd.res_start] = i;
+        }
+      }
+      __threadfence_block();
+      __syncthreads();
+    }
   }
 
   // ---- emit the ellipsoid list ----
@@ -1583,7 +1606,7 @@ __global__ void __launch_bounds__(kThreads) k_finish(RebuildArgs a) {
     if (M > a.max_ells) status = DH_ERR_NOMEM;
   }
   if (status == DH_OK) {
-    const int rs0 = nodes[0].res_start;
+    const int rs0 = 0;
     double* o_ctr = a.ctrs + (size_t)run * a.max_ells * D;
     double* o_cov = a.covs + (size_t)run * a.max_ells * DD;
     double* o_am = a.ams + (size_t)run * a.max_ells * DD;
@@ -1930,6 +1953,7 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
   const size_t b_cnt = (size_t)runs * ((size_t)3 * a.levels + 5 + kBarStride + (size_t)a.levels * a.maxw * kBarStride) * 4;
   a.rootbuf_stride = (size_t)rp * (2 * (size_t)d + (size_t)d * d + 1) + (size_t)d * d + 8;
   const size_t b_rb = (size_t)runs * a.rootbuf_stride * 8;
+  const size_t b_fl = (size_t)runs * a.max_nodes * 8, b_fi = (size_t)runs * a.max_nodes * 2 * 4;
   const size_t b_pl = (size_t)2 * runs * a.maxp * 2 * 4, b_pb = (size_t)2 * runs * a.maxw * 4;
   const size_t b_kp = mode == 1 ? 0 : (size_t)2 * runs * a.maxp * (2 * (size_t)d + 2) * 8;
   const size_t b_sl = (size_t)2 * runs * a.maxw * 4, b_el = (size_t)runs * 2 * a.maxw * 4;
@@ -1937,7 +1961,7 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
   const size_t b_ps = mode == 1 ? 0 : (size_t)runs * n * d * 8;
   auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
   const size_t total = al(b_perm) * 2 + al(b_lab) + al(b_nodes) + al(b_es) + al(b_res) + al(b_cnt) +
-                       al(b_sl) + al(b_el) + al(b_sc) + al(b_ps) + al(b_pl) + al(b_pb) + al(b_kp) + al(b_rb);
+                       al(b_sl) + al(b_el) + al(b_sc) + al(b_ps) + al(b_pl) + al(b_pb) + al(b_kp) + al(b_rb) + al(b_fl) + al(b_fi);
   if (total > ctx->rebuild_ws_cap) {
     if (!hip_ok(ctx, hipStreamSynchronize(ctx->stream), "sync")) return DH_ERR_HIP;
     if (ctx->rebuild_ws) (void)hipFree(ctx->rebuild_ws);
@@ -1984,6 +2008,10 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
   a.kpart = (double*)w;
   w += al(b_kp);
   a.rootbuf = (double*)w;
+  w += al(b_rb);
+  a.fin_lse = (double*)w;
+  w += al(b_fl);
+  a.fin_int = (int*)w;
   a.nells = nells;
   a.status = status;
   a.ctrs = ctrs;
