@@ -68,6 +68,34 @@ __global__ void __launch_bounds__(64) kA(const double* MT, const double* __restr
   for (int i = 0; i < N; ++i) out[(size_t)blockIdx.x * N * 64 + i * 64 + lane] = acc[i];
 }
 
+// A5: as A, the 25 input components fetched five at a time (five LDS reads in flight)
+__global__ void __launch_bounds__(64) kA5(const double* MT, const double* __restrict__ x, double* out,
+                                          int iters) {
+  __shared__ double xs[N * 64];
+  const int lane = threadIdx.x;
+  for (int j = 0; j < N; ++j) xs[j * 64 + lane] = x[(size_t)blockIdx.x * N * 64 + j * 64 + lane];
+  double acc[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) acc[i] = 0;
+  cdptr M = (cdptr)(unsigned long long)MT;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll 1
+    for (int j0 = 0; j0 < N; j0 += 5) {
+      double d[5];
+#pragma unroll
+      for (int u = 0; u < 5; ++u) d[u] = xs[(j0 + u) * 64 + lane];
+#pragma unroll
+      for (int u = 0; u < 5; ++u) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) acc[i] = fma(M[(j0 + u) * NP + i], d[u], acc[i]);
+      }
+    }
+    xs[(it % N) * 64 + lane] = acc[it % N] * 1e-3;
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i) out[(size_t)blockIdx.x * N * 64 + i * 64 + lane] = acc[i];
+}
+
 __global__ void __launch_bounds__(64) kL(const double* __restrict__ MT, const double* __restrict__ x,
                                          double* out, int iters) {
   __shared__ double xs[N * 64];
@@ -250,6 +278,62 @@ __global__ void __launch_bounds__(64) kM(const double* __restrict__ MT, const do
   for (int i = 0; i < N; ++i) out[(size_t)blockIdx.x * N * 64 + i * 64 + lane] = acc[i];
 }
 
+// H: hybrid operand feed -- of each matrix row (one input component j, 25 outputs) the first LH outputs come
+// through LDS broadcast reads, the rest through the scalar cache: two independent per-CU data paths.
+template <int LH>
+__global__ void __launch_bounds__(64) kH(const double* MT, const double* __restrict__ x, double* out, int iters) {
+  __shared__ double xs[N * 64];
+  __shared__ __attribute__((aligned(16))) double ms[N * NP];
+  const int lane = threadIdx.x;
+  for (int j = 0; j < N; ++j) xs[j * 64 + lane] = x[(size_t)blockIdx.x * N * 64 + j * 64 + lane];
+  for (int e = lane; e < N * NP; e += 64) ms[e] = MT[e];
+  __syncthreads();
+  double acc[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) acc[i] = 0;
+  cdptr M = (cdptr)(unsigned long long)MT;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll 1
+    for (int j = 0; j < N; ++j) {
+      double d = xs[j * 64 + lane];
+#pragma unroll
+      for (int i = 0; i < LH; ++i) acc[i] = fma(ms[j * NP + i], d, acc[i]);
+#pragma unroll
+      for (int i = LH; i < N; ++i) acc[i] = fma(M[j * NP + i], d, acc[i]);
+    }
+    xs[(it % N) * 64 + lane] = acc[it % N] * 1e-3;
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i) out[(size_t)blockIdx.x * N * 64 + i * 64 + lane] = acc[i];
+}
+
+// R: ceiling of the loop shape -- the same 25 FMAs per input component, matrix row held in VGPRs / SGPRs for the
+// whole kernel (wrong mathematics, right instruction mix): what the mat-vec would do with free operand delivery.
+template <bool SG, int UN>
+__global__ void __launch_bounds__(64) kR(const double* MT, const double* __restrict__ x, double* out, int iters) {
+  __shared__ double xs[N * 64];
+  const int lane = threadIdx.x;
+  for (int j = 0; j < N; ++j) xs[j * 64 + lane] = x[(size_t)blockIdx.x * N * 64 + j * 64 + lane];
+  double acc[N], row[N];
+  cdptr M = (cdptr)(unsigned long long)MT;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    acc[i] = 0;
+    row[i] = SG ? M[i] : MT[i + (lane & 1)];
+  }
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll UN
+    for (int j = 0; j < N; ++j) {
+      double d = xs[j * 64 + lane];
+#pragma unroll
+      for (int i = 0; i < N; ++i) acc[i] = fma(row[i], d, acc[i]);
+    }
+    xs[(it % N) * 64 + lane] = acc[it % N] * 1e-3;
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i) out[(size_t)blockIdx.x * N * 64 + i * 64 + lane] = acc[i];
+}
+
 int main(int argc, char** argv) {
   int blocks = argc > 1 ? atoi(argv[1]) : 2048, iters = argc > 2 ? atoi(argv[2]) : 90;
   std::vector<double> MT(N * NP, 0.0), x((size_t)blocks * N * 64);
@@ -278,6 +362,30 @@ int main(int argc, char** argv) {
     hipEventElapsedTime(&ml, e0, e1);
     printf("lds-bcast: %.3f ms %.2f TFLOP/s | ", ml, (double)blocks * 64 * iters * N * N * 2 / ml / 1e9);
     hipEventRecord(e0); kB<<<blocks, 64>>>(dM, dx, dB, iters); hipEventRecord(e1); hipEventSynchronize(e1);
+    {
+      float mh;
+      hipEventRecord(e0); kH<8><<<blocks, 64>>>(dM, dx, dB, iters); hipEventRecord(e1); hipEventSynchronize(e1);
+      hipEventElapsedTime(&mh, e0, e1);
+      printf("hybrid8: %.2f TF | ", (double)blocks * 64 * iters * N * N * 2 / mh / 1e9);
+      hipEventRecord(e0); kH<12><<<blocks, 64>>>(dM, dx, dB, iters); hipEventRecord(e1); hipEventSynchronize(e1);
+      hipEventElapsedTime(&mh, e0, e1);
+      printf("hybrid12: %.2f TF | ", (double)blocks * 64 * iters * N * N * 2 / mh / 1e9);
+    }
+    {
+      float mr;
+      hipEventRecord(e0); kR<false, 1><<<blocks, 64>>>(dM, dx, dB, iters); hipEventRecord(e1); hipEventSynchronize(e1);
+      hipEventElapsedTime(&mr, e0, e1);
+      printf("ceiling(vgpr row): %.2f TF | ", (double)blocks * 64 * iters * N * N * 2 / mr / 1e9);
+      hipEventRecord(e0); kR<true, 5><<<blocks, 64>>>(dM, dx, dB, iters); hipEventRecord(e1); hipEventSynchronize(e1);
+      hipEventElapsedTime(&mr, e0, e1);
+      printf("ceiling(sgpr row, unroll 5): %.2f TF | ", (double)blocks * 64 * iters * N * N * 2 / mr / 1e9);
+    }
+    {
+      float m5;
+      hipEventRecord(e0); kA5<<<blocks, 64>>>(dM, dx, dB, iters); hipEventRecord(e1); hipEventSynchronize(e1);
+      hipEventElapsedTime(&m5, e0, e1);
+      printf("sgpr x5: %.2f TF | ", (double)blocks * 64 * iters * N * N * 2 / m5 / 1e9);
+    }
     float mm;
     hipEventRecord(e0); kM<<<blocks, 64>>>(dM, dx, dB, iters); hipEventRecord(e1); hipEventSynchronize(e1);
     hipEventElapsedTime(&mm, e0, e1);
