@@ -172,4 +172,45 @@ static __device__ void sort_eigs_wave(const double* A, double* V, double* lam, i
   wave_sync();
 }
 
+// ---- rotation helpers of the one-barrier-per-round Jacobi (rebuild.hip, wide.hip) -----------
+static __device__ __forceinline__ double rsqrt_nr(double x) {
+  // v_rsq_f64 is good to 2^-24 (measured, tools/micro/rsq_acc.hip); two Newton steps reach 2^-52
+  double y = __builtin_amdgcn_rsq(x);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const double xy = x * y;
+    const double e = fma(-xy, y, 1.0);
+    y = fma(0.5 * y, e, y);
+  }
+  return y;
+}
+
+// (c, s) of the Jacobi rotation annihilating apq.  Branch-free; the matrix is pre-scaled
+// to max|a_ij| < 1, so d^2 + b^2 cannot overflow, and a pair whose d^2 + b^2 underflows
+// is below any convergence threshold and is left alone.
+static __device__ __forceinline__ void jacobi_rotation(double app, double aqq, double apq, double& c, double& s) {
+  const double d = aqq - app, b = 2.0 * apq;
+  double q = fma(d, d, b * b);
+  const bool none = (apq == 0.0) || !(q > 0.0);  // also the padding index of odd D
+  q = none ? 1.0 : q;
+  const double rh = rsqrt_nr(q);
+  const double cc = fma(0.5 * fabs(d), rh, 0.5);  // cos^2 in [1/2, 1]
+  const double rcc = rsqrt_nr(cc);
+  c = none ? 1.0 : cc * rcc;
+  s = none ? 0.0 : (d >= 0.0 ? 0.5 : -0.5) * b * rh * rcc;
+}
+
+// where the circle method moves the occupant of position `pos` (top row = even
+// positions T[k] = 2k, bottom row = odd positions B[k] = 2k+1; T[0] is fixed)
+static __device__ __forceinline__ int jacobi_dest(int pos, int m) {
+  const int k = pos >> 1;
+  if (pos & 1) {
+    if (k == 0) return m > 1 ? 2 : 1;  // B[0] -> T[1]
+    return 2 * (k - 1) + 1;            // B[k] -> B[k-1]
+  }
+  if (k == 0) return 0;
+  if (k == m - 1) return 2 * (m - 1) + 1;  // T[m-1] -> B[m-1]
+  return 2 * (k + 1);                      // T[k] -> T[k+1]
+}
+
 }  // namespace dh_eig

@@ -184,46 +184,9 @@ __device__ __forceinline__ int block_reduce_sum_int(int v, int* red) {
 //     c = sqrt((1+cos 2t)/2), s = sign(d) b / (2 h c)   (|t| <= pi/4, the same
 //     rotation as the classical tau/t formula).
 typedef __attribute__((address_space(3))) double lds_double;
-
-__device__ __forceinline__ double rsqrt_nr(double x) {
-  // v_rsq_f64 is good to 2^-24 (measured, tools/micro/rsq_acc.hip); two Newton steps reach 2^-52
-  double y = __builtin_amdgcn_rsq(x);
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const double xy = x * y;
-    const double e = fma(-xy, y, 1.0);
-    y = fma(0.5 * y, e, y);
-  }
-  return y;
-}
-
-// (c, s) of the Jacobi rotation annihilating apq.  Branch-free; the matrix is pre-scaled
-// to max|a_ij| < 1, so d^2 + b^2 cannot overflow, and a pair whose d^2 + b^2 underflows
-// is below any convergence threshold and is left alone.
-__device__ __forceinline__ void jacobi_rotation(double app, double aqq, double apq, double& c, double& s) {
-  const double d = aqq - app, b = 2.0 * apq;
-  double q = fma(d, d, b * b);
-  const bool none = (apq == 0.0) || !(q > 0.0);  // also the padding index of odd D
-  q = none ? 1.0 : q;
-  const double rh = rsqrt_nr(q);
-  const double cc = fma(0.5 * fabs(d), rh, 0.5);  // cos^2 in [1/2, 1]
-  const double rcc = rsqrt_nr(cc);
-  c = none ? 1.0 : cc * rcc;
-  s = none ? 0.0 : (d >= 0.0 ? 0.5 : -0.5) * b * rh * rcc;
-}
-
-// where the circle method moves the occupant of position `pos` (top row = even
-// positions T[k] = 2k, bottom row = odd positions B[k] = 2k+1; T[0] is fixed)
-__device__ __forceinline__ int jacobi_dest(int pos, int m) {
-  const int k = pos >> 1;
-  if (pos & 1) {
-    if (k == 0) return m > 1 ? 2 : 1;  // B[0] -> T[1]
-    return 2 * (k - 1) + 1;            // B[k] -> B[k-1]
-  }
-  if (k == 0) return 0;
-  if (k == m - 1) return 2 * (m - 1) + 1;  // T[m-1] -> B[m-1]
-  return 2 * (k + 1);                      // T[k] -> T[k+1]
-}
+using dh_eig::rsqrt_nr;
+using dh_eig::jacobi_rotation;
+using dh_eig::jacobi_dest;
 
 // eigh of the symmetric D x D matrix in L.A: on return the diagonal of L.A holds
 // the (unsorted) eigenvalues and the columns of L.V the eigenvectors.  Returns

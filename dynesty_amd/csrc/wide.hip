@@ -15,8 +15,11 @@
 // Semantics and citations are those of the register-resident kernels
 // (walk.hip / walk2.hip / rebuild.hip / bound.hip).
 #include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
 
 #include "ctx.h"
+#include "eig_wave.h"
 #include "rng_pcg64.h"
 
 using namespace dh;
@@ -26,6 +29,8 @@ namespace {
 constexpr int kWideMaxD = 512;
 constexpr int kRT = 1024;  // threads of the wide rebuild workgroup
 constexpr int kTP = 64;    // points per LDS tile
+typedef double wacc __attribute__((ext_vector_type(4)));
+#define W_MFMA(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
 
 __device__ __forceinline__ double wave_sum(double v) {
   for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s);
@@ -487,6 +492,8 @@ struct WideRebuildArgs {
   double* wsA;   // runs x d x d   Jacobi work
   double* wsV;   // runs x d x d
   double* wscov; // runs x d x d   working covariance
+  int dbg;       // DH_WIDE_PROF=1: thread 0 of run 0 prints the cycle count of every phase
+  double* wsW;   // runs x 4 x P x P  double-buffered Jacobi work (P = d rounded up to even)
   int* status;
   double* ctrs;
   double* covs;
@@ -507,24 +514,55 @@ __device__ double block_max_1024(double v, double* red) {
   return r;
 }
 
-// parallel-order cyclic Jacobi on global-memory matrices (row-major d x d).
-__device__ bool jacobi_global(double* A, double* V, int D, double* rc, double* rs, int* rp, double* red) {
+// Parallel-order cyclic Jacobi on global-memory (L2-resident) matrices, the formulation of
+// rebuild.hip's jacobi_block for D up to 512: position-based tournament (pair k always sits at
+// positions 2k, 2k+1; a round WRITES the rotated 2x2 blocks to where the circle method moves
+// them, into the second buffer), so every index is loop-invariant, the block loads are
+// coalesced pairs, and a round costs two workgroup barriers -- one after the m rotations are
+// derived (by m threads, shared through LDS), one after the blocks are written.  The previous
+// three-phase form (columns strided by D, integer divisions in the inner loops) cost ~39 us
+// per round at D = 200; 10 sweeps x 199 rounds made the eigensolver 95 % of the 78 ms rebuild.
+// Work buffers: W = 4 matrices of P x P (P = D rounded up to even): A0 | A1 | V0 | V1.
+// On return the diagonal of A holds the eigenvalues (unsorted), the columns of V the vectors.
+__device__ bool jacobi_global(double* A, double* V, double* W, int D, double* rc, double* rs, double* red) {
   const int t = threadIdx.x;
-  const int m = (D + 1) / 2;
+  const int m = (D + 1) / 2, P = 2 * m;
+  const size_t PP = (size_t)P * P;
+  double* wa[2] = {W, W + PP};
+  double* wv[2] = {W + 2 * PP, W + 3 * PP};
   bool bad = false;
+  double amax = 0.0;
   for (int e = t; e < D * D; e += kRT) {
-    const int i = e / D, j = e - i * D;
-    V[e] = (i == j) ? 1.0 : 0.0;
-    if (!isfinite(A[e])) bad = true;
+    const double v = A[e];
+    if (!isfinite(v)) bad = true;
+    amax = fmax(amax, fabs(v));
   }
   if (__syncthreads_or(bad ? 1 : 0)) return false;
-  if (D == 1) return true;
-  const int P = 2 * m, rounds = P - 1;
+  if (D == 1) {
+    if (t == 0) V[0] = 1.0;
+    __syncthreads();
+    return true;
+  }
+  amax = block_max_1024(amax, red);
+  const int ex = amax > 0.0 ? ilogb(amax) + 1 : 0;  // power-of-two pre-scaling (see jacobi_rotation)
+  for (int e = t; e < P * P; e += kRT) {
+    const int i = e / P, j = e - i * P;
+    wa[0][e] = (i < D && j < D) ? ldexp(A[(size_t)i * D + j], -ex) : 0.0;
+    wv[0][e] = (i == j && i < D) ? 1.0 : 0.0;
+  }
+  __threadfence_block();
+  __syncthreads();
+  // block ownership: blocks blk = t + s * kRT, s < NS (m^2 <= 65 536 -> NS <= 64); the (row pair,
+  // column pair) of a slot is recomputed each round from two running counters instead of a division
+  const int nblk = m * m;
+  int cur = 0;
+  int dpos = (D & 1) ? D : -1;
   for (int sweep = 0; sweep < 60; ++sweep) {
+    const double* Ac = wa[cur];
     double off = 0.0, dia = 0.0;
-    for (int e = t; e < D * D; e += kRT) {
-      const int i = e / D, j = e - i * D;
-      const double v = A[e];
+    for (int e = t; e < P * P; e += kRT) {
+      const int i = e / P, j = e - i * P;
+      const double v = Ac[e];
       if (i == j)
         dia = fma(v, v, dia);
       else
@@ -544,76 +582,80 @@ __device__ bool jacobi_global(double* A, double* V, int D, double* rc, double* r
     }
     __syncthreads();
     if (!(off > 1e-31 * dia)) break;
-    for (int r = 0; r < rounds; ++r) {
+    for (int r = 0; r < P - 1; ++r) {
+      const double* As = wa[cur];
+      const double* Vs = wv[cur];
+      double* Ad = wa[cur ^ 1];
+      double* Vd = wv[cur ^ 1];
+      // the m rotations of this round
       for (int k = t; k < m; k += kRT) {
-        int p, q;
-        if (k == 0) {
-          p = P - 1;
-          q = r;
-        } else {
-          p = r + k;
-          if (p >= P - 1) p -= P - 1;
-          q = r - k;
-          if (q < 0) q += P - 1;
-        }
-        if (p > q) {
-          const int tmp = p;
-          p = q;
-          q = tmp;
-        }
-        double c = 1.0, sn = 0.0;
-        if (q < D) {
-          const double apq = A[(size_t)p * D + q];
-          if (apq != 0.0) {
-            const double app = A[(size_t)p * D + p], aqq = A[(size_t)q * D + q];
-            const double tau = (aqq - app) / (2.0 * apq);
-            const double tt = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(fma(tau, tau, 1.0)));
-            c = 1.0 / sqrt(fma(tt, tt, 1.0));
-            sn = tt * c;
-          }
-        } else {
-          p = -1;
-        }
+        const size_t p0 = (size_t)(2 * k) * P + 2 * k;
+        double c, sn;
+        dh_eig::jacobi_rotation(As[p0], As[p0 + P + 1], As[p0 + 1], c, sn);
         rc[k] = c;
         rs[k] = sn;
-        rp[k] = p;
-        rp[kWideMaxD / 2 + 1 + k] = q;
       }
-      __threadfence_block();
       __syncthreads();
-      // columns: A <- A J, V <- V J      items (i, k), k fastest
-      for (int e = t; e < D * m; e += kRT) {
-        const int i = e / m, k = e - i * m;
-        const int p = rp[k], q = rp[kWideMaxD / 2 + 1 + k];
-        if (p >= 0) {
-          const double c = rc[k], sn = rs[k];
-          double* ar = A + (size_t)i * D;
-          const double aip = ar[p], aiq = ar[q];
-          ar[p] = c * aip - sn * aiq;
-          ar[q] = sn * aip + c * aiq;
-          double* vr = V + (size_t)i * D;
-          const double vip = vr[p], viq = vr[q];
-          vr[p] = c * vip - sn * viq;
-          vr[q] = sn * vip + c * viq;
+      // all 2x2 blocks: rows J_r^T ., columns . J_c, written to the positions of the next round.
+      // Four blocks per thread are loaded before any is stored (source and destination buffers
+      // are distinct, but the compiler cannot know: without the batching every block waited
+      // a full L2 round trip behind the stores of the previous one -- 14 us per round).
+      constexpr int kBB = 4;
+      for (int blk0 = t; blk0 < nblk; blk0 += kBB * kRT) {
+        double2 xa[kBB], xb[kBB], va[kBB], vb[kBB];
+        int kr[kBB], kc[kBB];
+#pragma unroll
+        for (int u = 0; u < kBB; ++u) {
+          const int blk = blk0 + u * kRT;
+          const int b2 = blk < nblk ? blk : 0;
+          kr[u] = b2 / m;
+          kc[u] = b2 - kr[u] * m;
+          const size_t o0 = (size_t)(2 * kr[u]) * P + 2 * kc[u];
+          xa[u] = *(const double2*)(As + o0);
+          xb[u] = *(const double2*)(As + o0 + P);
+          va[u] = *(const double2*)(Vs + o0);
+          vb[u] = *(const double2*)(Vs + o0 + P);
+        }
+#pragma unroll
+        for (int u = 0; u < kBB; ++u) {
+          if (blk0 + u * kRT >= nblk) continue;
+          const int r0 = 2 * kr[u], c0 = 2 * kc[u];
+          const double cr = rc[kr[u]], sr = rs[kr[u]], cc = rc[kc[u]], sc = rs[kc[u]];
+          const double y00 = cr * xa[u].x - sr * xb[u].x, y01 = cr * xa[u].y - sr * xb[u].y;
+          const double y10 = sr * xa[u].x + cr * xb[u].x, y11 = sr * xa[u].y + cr * xb[u].y;
+          double z00 = cc * y00 - sc * y01, z01 = sc * y00 + cc * y01;
+          double z10 = cc * y10 - sc * y11, z11 = sc * y10 + cc * y11;
+          if (r0 == c0) z01 = z10 = 0.0;  // the annihilated pair is exactly zero
+          const int dra = dh_eig::jacobi_dest(r0, m), drb = dh_eig::jacobi_dest(r0 + 1, m);
+          const int dca = dh_eig::jacobi_dest(c0, m), dcb = dh_eig::jacobi_dest(c0 + 1, m);
+          Ad[(size_t)dra * P + dca] = z00;
+          Ad[(size_t)dra * P + dcb] = z01;
+          Ad[(size_t)drb * P + dca] = z10;
+          Ad[(size_t)drb * P + dcb] = z11;
+          Vd[(size_t)r0 * P + dca] = cc * va[u].x - sc * va[u].y;
+          Vd[(size_t)r0 * P + dcb] = sc * va[u].x + cc * va[u].y;
+          Vd[(size_t)(r0 + 1) * P + dca] = cc * vb[u].x - sc * vb[u].y;
+          Vd[(size_t)(r0 + 1) * P + dcb] = sc * vb[u].x + cc * vb[u].y;
         }
       }
-      __threadfence_block();
-      __syncthreads();
-      // rows: A <- J^T A                 items (k, j), j fastest (coalesced)
-      for (int e = t; e < m * D; e += kRT) {
-        const int k = e / D, j = e - k * D;
-        const int p = rp[k], q = rp[kWideMaxD / 2 + 1 + k];
-        if (p >= 0) {
-          const double c = rc[k], sn = rs[k];
-          const double apj = A[(size_t)p * D + j], aqj = A[(size_t)q * D + j];
-          A[(size_t)p * D + j] = (j == q) ? 0.0 : c * apj - sn * aqj;
-          A[(size_t)q * D + j] = (j == p) ? 0.0 : sn * apj + c * aqj;
-        }
-      }
+      if (dpos >= 0) dpos = dh_eig::jacobi_dest(dpos, m);
+      cur ^= 1;
       __threadfence_block();
       __syncthreads();
     }
   }
+  // copy out: position a (skipping the padding) -> column a' of V, diagonal of A
+  const double* Af = wa[cur];
+  const double* Vf = wv[cur];
+  for (int e = t; e < P * P; e += kRT) {
+    const int i = e / P, a2 = e - i * P;
+    if (a2 == dpos || i >= D) continue;
+    const int col = a2 - ((dpos >= 0 && a2 > dpos) ? 1 : 0);
+    V[(size_t)i * D + col] = Vf[e];
+    if (i == 0) A[(size_t)col * D + col] = ldexp(Af[(size_t)a2 * P + a2], ex);
+  }
+  __threadfence_block();
+  __syncthreads();
   return true;
 }
 
@@ -627,7 +669,8 @@ __global__ void __launch_bounds__(kRT) wide_single_kernel(WideRebuildArgs a) {
   double* red = lam + D;                   // 64
   double* rc = red + 64;                   // D/2+1
   double* rs = rc + (kWideMaxD / 2 + 1);
-  int* rp = (int*)(rs + (kWideMaxD / 2 + 1));  // 2*(kWideMaxD/2+1)
+  double* part = rs + (kWideMaxD / 2 + 1);     // ceil(D/16) x 64 partial quadratic forms (fmax)
+  int* rp = (int*)(part + (size_t)((D + 15) / 16) * 64);  // 2*(kWideMaxD/2+1)
   int* order = rp + 2 * (kWideMaxD / 2 + 1);   // D
   const double* pts = a.pts + (size_t)run * n * D;
   double* A = a.wsA + (size_t)run * D * D;
@@ -637,6 +680,15 @@ __global__ void __launch_bounds__(kRT) wide_single_kernel(WideRebuildArgs a) {
   double* o_ax = a.axes + (size_t)run * D * D;
   int status = DH_OK;
   if (n <= 1) status = DH_ERR_VALUE;
+  long long tp_ = clock64();
+#define WPH(name)                                                                   \
+  do {                                                                              \
+    if (a.dbg && t == 0 && run == 0) {                                              \
+      const long long now_ = clock64();                                             \
+      printf("wide_single %s %lld\n", name, (long long)(now_ - tp_)); \
+      tp_ = now_;                                                                   \
+    }                                                                               \
+  } while (0)
 
   auto stage = [&](int base, int cnt, bool centre) {
     for (int e = t; e < cnt * D; e += kRT) {
@@ -668,54 +720,68 @@ __global__ void __launch_bounds__(kRT) wide_single_kernel(WideRebuildArgs a) {
       }
       __syncthreads();
     }
-    // ---- covariance (np.cov ddof=1): entries (a<=b) distributed over threads ----
+    WPH("mean");
+    // ---- covariance (np.cov ddof=1) on the matrix cores: C = Xc^T Xc, upper 16x16 blocks ----
+    // Block pairs (ib <= jb) are dealt round-robin to the 16 waves, kCovPairs per wave and pass
+    // (accumulators stay in registers across all tiles of the pass); K = points, 16 MFMA steps
+    // of 4 per 64-point tile.  The VALU form read two LDS operands per FMA (3.9 ms at 4000x200).
     {
-      const int nent = D * (D + 1) / 2;
-      constexpr int EPT = 24;  // entries per thread per pass (registers)
-      for (int e0 = 0; e0 < nent; e0 += kRT * EPT) {
-        double acc[EPT];
-        int ea[EPT], eb[EPT];
+      const int lane = t & 63, wv = t >> 6, lj = lane & 15, lk = lane >> 4;
+      const int nbk = (D + 15) >> 4;
+      const int npairs = nbk * (nbk + 1) / 2;
+      constexpr int kCovPairs = 6;
+      const double inv = 1.0 / (double)(n - 1);
+      for (int pass0 = 0; pass0 < npairs; pass0 += kCovPairs * (kRT / 64)) {
+        wacc acc[kCovPairs];
+        int pib[kCovPairs], pjb[kCovPairs];
 #pragma unroll
-        for (int r = 0; r < EPT; ++r) {
-          acc[r] = 0.0;
-          const int e = e0 + r * kRT + t;
-          int aa = 0, rem = 0;
-          if (e < nent) {
-            aa = (int)floor(((2.0 * D + 1.0) - sqrt((2.0 * D + 1.0) * (2.0 * D + 1.0) - 8.0 * e)) * 0.5);
-            while (aa > 0 && aa * D - aa * (aa - 1) / 2 > e) --aa;
-            while ((aa + 1) * D - (aa + 1) * aa / 2 <= e) ++aa;
-            rem = e - (aa * D - aa * (aa - 1) / 2);
+        for (int r = 0; r < kCovPairs; ++r) {
+          acc[r] = (wacc){0.0, 0.0, 0.0, 0.0};
+          const int pr = pass0 + r * (kRT / 64) + wv;
+          // unrank pr -> (ib <= jb), row-major over the upper triangle of an nbk x nbk grid
+          int ib = 0, rem = pr;
+          while (ib < nbk && rem >= nbk - ib) {
+            rem -= nbk - ib;
+            ++ib;
           }
-          ea[r] = aa;
-          eb[r] = aa + rem;
+          pib[r] = pr < npairs ? ib : -1;
+          pjb[r] = ib + rem;
         }
         for (int base = 0; base < n; base += kTP) {
           const int cnt = min(kTP, n - base);
           stage(base, cnt, true);
 #pragma unroll
-          for (int r = 0; r < EPT; ++r) {
-            if (e0 + r * kRT + t < nent) {
-              const int aa = ea[r], bb = eb[r];
-              double s = acc[r];
-              for (int p = 0; p < cnt; ++p) s = fma(tile[p * LD + aa], tile[p * LD + bb], s);
-              acc[r] = s;
+          for (int r = 0; r < kCovPairs; ++r) {
+            if (pib[r] < 0) continue;
+            const int ca = pib[r] * 16 + lj, cb = pjb[r] * 16 + lj;
+            for (int p0 = 0; p0 < cnt; p0 += 4) {
+              const int pp = p0 + lk;
+              const bool pv = pp < cnt;
+              const double fa = (pv && ca < D) ? tile[pp * LD + ca] : 0.0;
+              const double fb = (pv && cb < D) ? tile[pp * LD + cb] : 0.0;
+              acc[r] = W_MFMA(fa, fb, acc[r]);
             }
           }
           __syncthreads();
         }
-        const double inv = 1.0 / (double)(n - 1);
 #pragma unroll
-        for (int r = 0; r < EPT; ++r) {
-          if (e0 + r * kRT + t < nent) {
-            const double c = acc[r] * inv;
-            cov[(size_t)ea[r] * D + eb[r]] = c;
-            cov[(size_t)eb[r] * D + ea[r]] = c;
+        for (int r = 0; r < kCovPairs; ++r) {
+          if (pib[r] < 0) continue;
+#pragma unroll
+          for (int q4 = 0; q4 < 4; ++q4) {
+            const int i = pib[r] * 16 + lk + 4 * q4, j = pjb[r] * 16 + lj;
+            if (i < D && j < D) {
+              const double c = acc[r][q4] * inv;
+              cov[(size_t)i * D + j] = c;
+              cov[(size_t)j * D + i] = c;
+            }
           }
         }
       }
       __threadfence_block();
       __syncthreads();
     }
+    WPH("cov");
     // ---- improve_covar_mat + fmax passes (bounding.py:1311-1384, 1423-1457) ----
     const double lim = 1.0 - 1e-3;
     for (int pass = 0; pass < 2 && status == DH_OK; ++pass) {
@@ -726,7 +792,9 @@ __global__ void __launch_bounds__(kRT) wide_single_kernel(WideRebuildArgs a) {
         for (int e = t; e < D * D; e += kRT) A[e] = cov[e];
         __threadfence_block();
         __syncthreads();
-        const bool fin = jacobi_global(A, V, D, rc, rs, rp, red);
+        WPH("copy");
+        const bool fin = jacobi_global(A, V, a.wsW + (size_t)run * 4 * (size_t)((D + 1) & ~1) * ((D + 1) & ~1), D, rc, rs, red);
+        WPH("jacobi");
         double top = -INFINITY, bot = INFINITY;
         bool allfin = fin;
         if (fin) {
@@ -782,6 +850,7 @@ __global__ void __launch_bounds__(kRT) wide_single_kernel(WideRebuildArgs a) {
       } else {
         good = trial == 0;
       }
+      WPH("regularize");
       // sort ascending + canonical signs: order[] by rank; AX/AM from (V, lam)
       for (int k = t; k < D; k += kRT) {
         const double mine = lam[k];
@@ -814,44 +883,91 @@ __global__ void __launch_bounds__(kRT) wide_single_kernel(WideRebuildArgs a) {
         const int src = order[k];
         o_ax[e] = A[(size_t)k * D + k] * V[(size_t)i * D + src] * sqrt(lam[src]);
       }
-      for (int e = t; e < D * D; e += kRT) {
-        const int i = e / D, j = e - i * D;
-        double s = 0.0;
-        for (int k = 0; k < D; ++k) s = fma(V[(size_t)i * D + k] * (1.0 / lam[k]), V[(size_t)j * D + k], s);
-        o_am[e] = s;
+      // am = (V / lam) V^T on the matrix cores: block (ib <= jb) per wave step, K = D in steps of 4
+      {
+        const int lane = t & 63, wv = t >> 6, lj = lane & 15, lk = lane >> 4;
+        const int nbk = (D + 15) >> 4, npairs = nbk * (nbk + 1) / 2, ksteps = (D + 3) >> 2;
+        for (int pr = wv; pr < npairs; pr += kRT / 64) {
+          int ib = 0, rem = pr;
+          while (rem >= nbk - ib) {
+            rem -= nbk - ib;
+            ++ib;
+          }
+          const int jb = ib + rem;
+          const int ia = ib * 16 + lj, ja = jb * 16 + lj;
+          wacc acc = {0.0, 0.0, 0.0, 0.0};
+          for (int ks = 0; ks < ksteps; ++ks) {
+            const int k = ks * 4 + lk;
+            const bool kv = k < D;
+            const double fa = (kv && ia < D) ? V[(size_t)ia * D + k] / lam[k] : 0.0;
+            const double fb = (kv && ja < D) ? V[(size_t)ja * D + k] : 0.0;
+            acc = W_MFMA(fa, fb, acc);
+          }
+#pragma unroll
+          for (int q4 = 0; q4 < 4; ++q4) {
+            const int i = ib * 16 + lk + 4 * q4, j = jb * 16 + lj;
+            if (i < D && j < D) {
+              o_am[(size_t)i * D + j] = acc[q4];
+              o_am[(size_t)j * D + i] = acc[q4];
+            }
+          }
+        }
       }
       __threadfence_block();
       __syncthreads();
-      // ---- fmax = max_p delta^T am delta : lane = point, am through the scalar cache
+      WPH("sort+ax+am");
+      // ---- fmax = max_p delta^T am delta on the matrix cores: Z = Xc AM per 64-point tile
+      // (M = 4 point blocks, N = column blocks dealt to the waves, K = D in steps of 4), then the
+      // row-wise dot Z . x, a 16-lane reduction and a fixed-order sum over the column blocks.
+      // The VALU form issued one global load per FMA (17.5 ms at 4000 x 200).
       double best = -INFINITY;
-      for (int base = 0; base < n; base += kTP) {
-        const int cnt = min(kTP, n - base);
-        stage(base, cnt, true);
-        // 16 waves x 64 lanes: wave wv handles rows wv, wv+16, ... for the tile's 64 points
-        const int lane = t & 63, wv = t >> 6;
-        double q = 0.0;
-        if (lane < cnt) {
-          const double* x = tile + lane * LD;
-          for (int i = wv; i < D; i += kRT / 64) {
-            const double* row = o_am + (size_t)i * D;  // written above: not via the scalar cache
-            double r = 0.0;
-            for (int j = 0; j < D; ++j) r = fma(row[j], x[j], r);
-            q = fma(x[i], r, q);
+      {
+        const int lane = t & 63, wv = t >> 6, lj = lane & 15, lk = lane >> 4;
+        const int nbk = (D + 15) >> 4, ksteps = (D + 3) >> 2;
+        for (int base = 0; base < n; base += kTP) {
+          const int cnt = min(kTP, n - base);
+          stage(base, cnt, true);
+          for (int jb = wv; jb < nbk; jb += kRT / 64) {
+            const int jc = jb * 16 + lj;
+            wacc z[4];
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) z[mb] = (wacc){0.0, 0.0, 0.0, 0.0};
+            for (int ks = 0; ks < ksteps; ++ks) {
+              const int k = ks * 4 + lk;
+              const bool kv = k < D;
+              const double fb = (kv && jc < D) ? o_am[(size_t)k * D + jc] : 0.0;
+#pragma unroll
+              for (int mb = 0; mb < 4; ++mb) {
+                const int pp = mb * 16 + lj;
+                const double fa = (kv && pp < cnt) ? tile[pp * LD + k] : 0.0;
+                z[mb] = W_MFMA(fa, fb, z[mb]);
+              }
+            }
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+#pragma unroll
+              for (int q4 = 0; q4 < 4; ++q4) {
+                const int pp = mb * 16 + lk + 4 * q4;
+                double sacc = (pp < cnt && jc < D) ? z[mb][q4] * tile[pp * LD + jc] : 0.0;
+                sacc += __shfl_xor(sacc, 1);
+                sacc += __shfl_xor(sacc, 2);
+                sacc += __shfl_xor(sacc, 4);
+                sacc += __shfl_xor(sacc, 8);
+                if (lj == 0) part[jb * 64 + pp] = sacc;
+              }
+            }
           }
+          __syncthreads();
+          if (t < cnt) {
+            double sacc = 0.0;
+            for (int jb = 0; jb < nbk; ++jb) sacc += part[jb * 64 + t];
+            best = fmax(best, sacc);
+          }
+          __syncthreads();
         }
-        // reduce the 16 partial sums per point through LDS
-        __syncthreads();
-        double* part = tile;  // reuse (tile is dead after the barrier)
-        part[wv * 64 + lane] = q;
-        __syncthreads();
-        if (t < cnt) {
-          double s = 0.0;
-          for (int ww = 0; ww < kRT / 64; ++ww) s += part[ww * 64 + t];
-          best = fmax(best, s);
-        }
-        __syncthreads();
       }
       const double fmx = block_max_1024(best, red);
+      WPH("fmax");
       if (pass == 0 && fmx > lim) {
         const double mult = fmx / lim, rt = sqrt(mult);
         for (int e = t; e < D * D; e += kRT) {
@@ -892,7 +1008,7 @@ __global__ void __launch_bounds__(kRT) wide_single_kernel(WideRebuildArgs a) {
 
 size_t wide_single_lds(int D) {
   const int LD = D | 1;
-  size_t dbl = (size_t)kTP * LD + 2 * (size_t)D + 64 + 2 * (kWideMaxD / 2 + 1);
+  size_t dbl = (size_t)kTP * LD + 2 * (size_t)D + 64 + 2 * (kWideMaxD / 2 + 1) + (size_t)((D + 15) / 16) * 64;
   size_t part = (size_t)(kRT / 64) * 64;  // fmax partials alias the tile
   if (dbl < part) dbl = part;
   return dbl * 8 + (2 * (kWideMaxD / 2 + 1) + kWideMaxD + 8) * 4;
@@ -995,7 +1111,9 @@ int wide_single_launch(dh_ctx* ctx, int runs, const double* pts, int n, int d, i
   const size_t lds = wide_single_lds(d);
   if (lds > 159 * 1024) return fail(ctx, DH_ERR_ARG, "rebuild: d=%d needs %zu B of LDS", d, lds);
   const size_t dd = (size_t)d * d * 8;
-  int rc = ensure_ws(ctx, 3 * dd * runs + 4096);
+  const size_t pw = (size_t)((d + 1) & ~1);
+  const size_t ww = 4 * pw * pw * 8;  // double-buffered Jacobi work per run
+  int rc = ensure_ws(ctx, (3 * dd + ww) * runs + 4096);
   if (rc) return rc;
   WideRebuildArgs a;
   a.pts = pts;
@@ -1006,6 +1124,8 @@ int wide_single_launch(dh_ctx* ctx, int runs, const double* pts, int n, int d, i
   a.wsA = (double*)ctx->rebuild_ws;
   a.wsV = a.wsA + (size_t)runs * d * d;
   a.wscov = a.wsV + (size_t)runs * d * d;
+  a.wsW = a.wscov + (size_t)runs * d * d;
+  a.dbg = getenv("DH_WIDE_PROF") ? 1 : 0;
   a.status = status;
   a.ctrs = ctrs;
   a.covs = covs;
