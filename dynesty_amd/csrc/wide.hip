@@ -32,17 +32,59 @@ constexpr int kTP = 64;    // points per LDS tile
 typedef double wacc __attribute__((ext_vector_type(4)));
 #define W_MFMA(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
 
+// Wave reductions through DPP (quad_perm / row mirrors inside each row of 16 lanes, row_bcast15/31
+// across rows, readlane 63): ~20 VALU instructions instead of six ds_bpermute round trips.  The
+// combination order is fixed, the result wave-uniform.
+__device__ __forceinline__ double dpp_move(double v, const int ctrl_sel) {
+  const long long b = __double_as_longlong(v);
+  int lo = (int)b, hi = (int)(b >> 32);
+  switch (ctrl_sel) {  // literal controls: the builtin needs immediates
+    case 0: lo = __builtin_amdgcn_update_dpp(lo, lo, 0xB1, 0xF, 0xF, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0xB1, 0xF, 0xF, false); break;
+    case 1: lo = __builtin_amdgcn_update_dpp(lo, lo, 0x4E, 0xF, 0xF, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x4E, 0xF, 0xF, false); break;
+    case 2: lo = __builtin_amdgcn_update_dpp(lo, lo, 0x141, 0xF, 0xF, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x141, 0xF, 0xF, false); break;
+    case 3: lo = __builtin_amdgcn_update_dpp(lo, lo, 0x140, 0xF, 0xF, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x140, 0xF, 0xF, false); break;
+    case 4: lo = __builtin_amdgcn_update_dpp(lo, lo, 0x142, 0xA, 0xF, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x142, 0xA, 0xF, false); break;
+    default: lo = __builtin_amdgcn_update_dpp(lo, lo, 0x143, 0xC, 0xF, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x143, 0xC, 0xF, false); break;
+  }
+  return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ double wave_bcast63(double v) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readlane((int)b, 63), hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+// rows 0/2 are masked out of the row_bcast steps (update_dpp returns the old value = v there): for
+// sums the masked lanes must contribute 0 in those steps, so the partner value is taken only in the
+// rows the mask enables
 __device__ __forceinline__ double wave_sum(double v) {
-  for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s);
-  return v;
+  v += dpp_move(v, 0);
+  v += dpp_move(v, 1);
+  v += dpp_move(v, 2);
+  v += dpp_move(v, 3);  // every lane of a row: the row sum
+  const int row = (threadIdx.x & 63) >> 4;
+  const double b15 = dpp_move(v, 4);
+  if (row & 1) v += b15;  // rows 1, 3: + previous row
+  const double b31 = dpp_move(v, 5);
+  if (row >= 2) v += b31;  // rows 2, 3: + (row 0 + row 1)
+  return wave_bcast63(v);
 }
 __device__ __forceinline__ double wave_min(double v) {
-  for (int s = 32; s > 0; s >>= 1) v = fmin(v, __shfl_xor(v, s));
-  return v;
+  v = fmin(v, dpp_move(v, 0));
+  v = fmin(v, dpp_move(v, 1));
+  v = fmin(v, dpp_move(v, 2));
+  v = fmin(v, dpp_move(v, 3));
+  v = fmin(v, dpp_move(v, 4));
+  v = fmin(v, dpp_move(v, 5));
+  return wave_bcast63(v);
 }
 __device__ __forceinline__ double wave_max(double v) {
-  for (int s = 32; s > 0; s >>= 1) v = fmax(v, __shfl_xor(v, s));
-  return v;
+  v = fmax(v, dpp_move(v, 0));
+  v = fmax(v, dpp_move(v, 1));
+  v = fmax(v, dpp_move(v, 2));
+  v = fmax(v, dpp_move(v, 3));
+  v = fmax(v, dpp_move(v, 4));
+  v = fmax(v, dpp_move(v, 5));
+  return wave_bcast63(v);
 }
 
 // prior_transform + loglikelihood for one walker spread over a wave:
