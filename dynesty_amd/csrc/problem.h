@@ -71,6 +71,57 @@ __device__ __forceinline__ int prior_of(const ProblemDev& P) {
 // near p = 1/2 (1.5e-11 relative) and doubles the cost.
 __device__ __forceinline__ double ndtri_dev(double p) { return -1.4142135623730951 * erfcinv(2.0 * p); }
 
+// The same function for kernels where it is the critical path (one wavefront per walker at wide D:
+// a lane owns a few coordinates and ocml's erfcinv is a long dependent chain behind divergent
+// branches).  Wichura's AS 241 (PPND16, Appl. Statist. 37 (1988) 477): rational approximations in
+// r = 0.180625 - q^2 for |p - 1/2| <= 0.425 and in sqrt(-ln min(p, 1-p)) - 1.6 beyond; both are
+// evaluated branch-free (straight-line code: N independent chains for the scheduler to
+// interleave) and selected.  Measured against scipy.special.ndtri: <= 1.1e-15 relative
+// (tools/ndtri_as241_check.py).  p < exp(-25) (or p outside (0, 1)) takes ndtri_dev.
+__device__ __forceinline__ double ndtri_as241_core(double p, bool* far) {
+  const double q = p - 0.5;
+  double r = 0.180625 - q * q;
+  const double cn =
+      (((((((r * 2509.0809287301226727 + 33430.575583588128105) * r + 67265.770927008700853) * r +
+           45921.953931549871457) * r + 13731.693765509461125) * r + 1971.5909503065514427) * r +
+        133.14166789178437745) * r + 3.387132872796366608);
+  const double cd =
+      (((((((r * 5226.495278852545925 + 28729.085735721942674) * r + 39307.89580009271061) * r +
+           21213.794301586595867) * r + 5394.1960214247511077) * r + 687.1870074920579083) * r +
+        42.313330701600911252) * r + 1.0);
+  const double pm = q < 0.0 ? p : 1.0 - p;
+  const double rt = sqrt(-log(pm));
+  *far = !(rt <= 5.0);
+  r = rt - 1.6;
+  const double tn =
+      (((((((r * 7.7454501427834140764e-4 + .0227238449892691845833) * r + .24178072517745061177) * r +
+           1.27045825245236838258) * r + 3.64784832476320460504) * r + 5.7694972214606914055) * r +
+        4.6303378461565452959) * r + 1.42343711074968357734);
+  const double td =
+      (((((((r * 1.05075007164441684324e-9 + 5.475938084995344946e-4) * r + .0151986665636164571966) * r +
+           .14810397642748007459) * r + .68976733498510000455) * r + 1.6763848301838038494) * r +
+        2.05319162663775882187) * r + 1.0);
+  const bool central = fabs(q) <= 0.425;
+  const double num = central ? q * cn : (q < 0.0 ? -tn : tn);
+  const double den = central ? cd : td;
+  return num / den;
+}
+
+template <int N>
+__device__ __forceinline__ void ndtri_n(const double (&p)[N], double (&out)[N]) {
+  bool far[N], any_far = false;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    out[i] = ndtri_as241_core(p[i], &far[i]);
+    any_far = any_far || far[i];
+  }
+  if (__builtin_expect(any_far, 0)) {
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+      if (far[i]) out[i] = ndtri_dev(p[i]);
+  }
+}
+
 // acc[i] += sum_j MT[j*N + i] * xs[j*64 + lane]   for i in [I0, I0+NI), j < nj.
 // MT is wave-uniform (scalar loads); the row for j+1 is requested before the
 // FMAs of row j are issued so the scalar-cache latency overlaps the math.

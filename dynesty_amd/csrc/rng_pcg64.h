@@ -258,6 +258,109 @@ __device__ __forceinline__ double std_normal(Pcg64& g, const ZigLds* z) {
     }
   }
 }
+// ---- one generator, 64 lanes ------------------------------------------------
+// A wavefront that serves ONE walker holds the walker's generator replicated in every lane.
+// Drawing n values one after the other leaves 63 lanes idle behind a 128-bit multiply and an LDS
+// lookup per value.  The LCG behind PCG64 jumps: the state after j steps is A_j * s + G_j * inc
+// (A_j = mult^j, G_j = 1 + mult + ... + mult^(j-1)), so lane l evaluates the (l+1)-th NEXT output
+// directly and the wave classifies 64 ziggurat candidates at once.  The stream is consumed exactly
+// as the sequential algorithm would: candidates up to the first one that misses the fast accept
+// are taken; that one is finished by the sequential wedge / tail code (wave-uniform) and the next
+// round starts from the state it left.
+struct PcgLanes {
+  U128 A, C;  // lane l: state after l + 1 steps = A * state + C
+};
+
+__device__ __forceinline__ PcgLanes pcg_lanes_init(const Pcg64& g, int lane) {
+  const U128 m = {DH_PCG_MULT_HI, DH_PCG_MULT_LO}, one = {0ull, 1ull};
+  U128 A = one, G = {0ull, 0ull}, Al = one, Gl = G;
+  for (int j = 1; j <= 64; ++j) {
+    A = mul128(A, m);
+    G = add128(mul128(G, m), one);
+    if (j == lane + 1) {
+      Al = A;
+      Gl = G;
+    }
+  }
+  PcgLanes L;
+  L.A = Al;
+  L.C = mul128(Gl, g.inc);
+  return L;
+}
+
+__device__ __forceinline__ uint64_t readlane64(uint64_t v, int l) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l);
+  return ((uint64_t)hi << 32) | lo;
+}
+
+__device__ __forceinline__ uint64_t pcg_output(const U128& st) {
+  const uint64_t x = st.hi ^ st.lo;
+  const unsigned r = (unsigned)(st.hi >> 58);
+  return (x >> r) | (x << ((64u - r) & 63u));
+}
+
+// n doubles of Generator.random() -> dst[0..n) (LDS); g advances by n.
+__device__ __forceinline__ void wave_doubles(Pcg64& g, const PcgLanes& L, double* dst, int n, int lane) {
+  for (int i = 0; i < n; i += 64) {
+    const int m = n - i < 64 ? n - i : 64;
+    const U128 st = add128(mul128(g.state, L.A), L.C);
+    if (lane < m) dst[i + lane] = (double)(pcg_output(st) >> 11) * (1.0 / 9007199254740992.0);
+    g.state.hi = readlane64(st.hi, m - 1);
+    g.state.lo = readlane64(st.lo, m - 1);
+  }
+}
+
+// n draws of random_standard_normal() -> dst[0..n) (LDS); same stream consumption as n calls of
+// std_normal().  The caller synchronises LDS before reading dst.
+__device__ __forceinline__ void wave_normals(Pcg64& g, const PcgLanes& L, const ZigLds* z, double* dst, int n,
+                                             int lane) {
+#pragma clang fp contract(off)
+  int i = 0;
+  while (i < n) {
+    const int m = n - i < 64 ? n - i : 64;
+    const U128 st = add128(mul128(g.state, L.A), L.C);
+    uint64_t r = pcg_output(st);
+    const int idx = (int)(r & 0xff);
+    r >>= 8;
+    const uint64_t rabs = (r >> 1) & 0x000fffffffffffffull;
+    double x = (double)rabs * z->wi[idx];
+    if (r & 1) x = -x;
+    const bool fast = rabs < z->ki[idx];
+    const uint64_t miss = __ballot(!fast && lane < m);
+    const int f = miss ? __ffsll((long long)miss) - 1 : m;  // candidates 0..f-1 are accepted as they are
+    if (lane < f) dst[i + lane] = x;
+    i += f;
+    const int last = miss ? f : m - 1;
+    g.state.hi = readlane64(st.hi, last);
+    g.state.lo = readlane64(st.lo, last);
+    if (miss) {
+      // candidate f: wedge or tail, with the uniforms that follow it in the stream
+      const int idf = __builtin_amdgcn_readlane(idx, f);
+      const uint64_t rabsf = readlane64(rabs, f);
+      double xf = __longlong_as_double((long long)readlane64((uint64_t)__double_as_longlong(x), f));
+      bool take;
+      if (idf == 0) {
+        for (;;) {
+          const double xx = -DH_ZIG_INV_R * log1p(-g.next_double());
+          const double yy = -log1p(-g.next_double());
+          if (yy + yy > xx * xx) {
+            xf = ((rabsf >> 8) & 1) ? -(DH_ZIG_R + xx) : DH_ZIG_R + xx;
+            break;
+          }
+        }
+        take = true;
+      } else {
+        take = (z->fi[idf - 1] - z->fi[idf]) * g.next_double() + z->fi[idf] < exp(-0.5 * xf * xf);
+      }
+      if (take) {
+        if (lane == 0) dst[i] = xf;
+        ++i;
+      }
+    }
+  }
+}
+
 // nc standard normals -> column dst[i * 64 + lane] (LDS), returns sum of squares.
 // Same stream consumption as nc calls of std_normal(), but software-pipelined:
 // the PCG step and the ziggurat table lookups of the NEXT candidate are issued

@@ -97,7 +97,15 @@ __device__ double wide_logl(const ProblemDev& P, int D, const double* su, double
     for (int i = lane; i < D; i += 64) sv[i] = a * (2.0 * su[i] - 1.0) + b;
   } else if (P.prior_id == PRIOR_NORMAL) {
     const double mu = P.prior_par[0], sg = P.prior_par[1];
-    for (int i = lane; i < D; i += 64) sv[i] = mu + sg * ndtri_dev(su[i]);
+    for (int i0 = lane; i0 < D; i0 += 256) {  // 4 coordinates per lane at a time: independent chains
+      double p[4], o[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) p[q] = (i0 + 64 * q < D) ? su[i0 + 64 * q] : 0.5;
+      ndtri_n<4>(p, o);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (i0 + 64 * q < D) sv[i0 + 64 * q] = mu + sg * o[q];
+    }
   } else {
     for (int i = lane; i < D; i += 64) sv[i] = su[i];
   }
@@ -149,6 +157,8 @@ struct WideWalkArgs {
   const uint64_t* zki;
   const uint64_t* zwi;
   const uint64_t* zfi;
+  int dbg;  // DH_WIDE_PROF=1: wave 0 prints its cycle split (normals / mat-vec / F evaluations)
+  int lds_ws;  // doubles per wave region in LDS (4 D rounded up to odd)
 };
 
 __device__ __forceinline__ void lds_sync() {
@@ -173,26 +183,99 @@ __device__ __forceinline__ void wide_matvec(const double* __restrict__ AT, const
   }
 }
 
-// one wavefront per walker; blockDim = 64.
-__global__ void __launch_bounds__(64) wide_walk_kernel(WideWalkArgs a) {
+// The proposal frame applied to the vectors of ALL walkers of the workgroup at once:
+// out_w[i] = scale * sum_k AT[k*n + i] * in_w[k]  =  one (n x n)(n x wpw) GEMM on the matrix cores.
+// One wavefront per walker alone re-read the whole frame (320 KB at D = 200) from L2 for every
+// direction: 57 % of the C4 kernel.  Here the frame is read once per workgroup and direction
+// round; the walkers of a workgroup meet at two barriers per round (they need their directions at
+// the same point of the algorithm: once per rwalk step / rslice slice).
+//   lds: per-wave regions of `ws` doubles; in/out = offsets of the vectors inside a region.
+//   ncols walkers (columns) starting at region `lds`, worked on by `nw` wavefronts (this one = `wv`).
+// A lone wavefront uses it on its own region (ncols = nw = 1) when the walkers of a workgroup sit on
+// different frames: the arithmetic per column is the same, so a walker's path does not depend on
+// the company it keeps.
+constexpr int kGemmBatch = 10;
+__device__ __forceinline__ void wg_frame_gemm(const double* __restrict__ AT, int n, double* lds, int ws, int off_in,
+                                              int off_out, double scale, int ncols, int wv, int nw) {
+  const int lane = threadIdx.x & 63, lj = lane & 15, lk = lane >> 4;
+  typedef const __attribute__((address_space(1))) double* gptr;
+  const int nbk = __builtin_amdgcn_readfirstlane((n + 15) >> 4), kfull = __builtin_amdgcn_readfirstlane(n >> 2);
+  const bool cv = lj < ncols;
+  const double* inw = lds + (size_t)(cv ? lj : 0) * ws + off_in + lk;
+  const size_t step = (size_t)4 * n;
+  for (int ib = wv; ib < nbk; ib += nw) {
+    const int ia = ib * 16 + lj;
+    const bool iv = ia < n;
+    gptr ap = (gptr)AT + (size_t)lk * n + (iv ? ia : 0);
+    const double* bp = inw;
+    wacc acc = {0.0, 0.0, 0.0, 0.0};
+    int ks = 0;
+    for (; ks + kGemmBatch <= kfull; ks += kGemmBatch) {  // kGemmBatch loads in flight per lane
+      double fa[kGemmBatch], fb[kGemmBatch];
+#pragma unroll
+      for (int q = 0; q < kGemmBatch; ++q) fa[q] = ap[(size_t)q * step];
+#pragma unroll
+      for (int q = 0; q < kGemmBatch; ++q) fb[q] = bp[4 * q];
+      ap += kGemmBatch * step;
+      bp += 4 * kGemmBatch;
+#pragma unroll
+      for (int q = 0; q < kGemmBatch; ++q) acc = W_MFMA(iv ? fa[q] : 0.0, cv ? fb[q] : 0.0, acc);
+    }
+    for (; ks < kfull; ++ks) {
+      const double fa = *ap;
+      const double fb = *bp;
+      ap += step;
+      bp += 4;
+      acc = W_MFMA(iv ? fa : 0.0, cv ? fb : 0.0, acc);
+    }
+    if (n & 3) {
+      const bool kv = kfull * 4 + lk < n;
+      const double fa = (kv && iv) ? *ap : 0.0;
+      const double fb = (kv && cv) ? *bp : 0.0;
+      acc = W_MFMA(fa, fb, acc);
+    }
+    if (cv) {
+      double* outw = lds + (size_t)lj * ws + off_out;
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        const int row = ib * 16 + lk + 4 * q4;
+        if (row < n) outw[row] = acc[q4] * scale;
+      }
+    }
+  }
+}
+
+// one wavefront per walker, wpw = blockDim / 64 walkers per workgroup.
+constexpr int kWalkMaxWaves = 4;  // walkers per workgroup: one wavefront per SIMD keeps the full register file per walker
+__global__ void __launch_bounds__(64 * kWalkMaxWaves) wide_walk_kernel(WideWalkArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ ZigLds zig;
+  __shared__ int sframe[16];
   zig_stage(&zig, a.zki, a.zwi, a.zfi);
-  const int lane = threadIdx.x;
-  const int w = blockIdx.x;
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wpw = blockDim.x >> 6;
+  const int wq = blockIdx.x * wpw + wv;
+  const bool ghost = wq >= a.k;  // padding wavefront of the last workgroup: barriers only
+  const int w = ghost ? a.k - 1 : wq;
   const int D = a.ndim, nc = a.ncdim;
-  double* su = (double*)smem;  // current point
-  double* sp = su + D;         // proposal / u_new
-  double* sd = sp + D;         // dr / direction
-  double* sv = sd + D;         // v
-  int* sperm = (int*)(sv + D);
+  const int ws = a.lds_ws;  // doubles per wave region (odd: conflict-free column reads in the GEMM)
+  double* wbase = (double*)smem;
+  double* su = wbase + (size_t)wv * ws;  // current point
+  double* sp = su + D;                   // proposal / u_new
+  double* sd = sp + D;                   // dr / direction
+  double* sv = sd + D;                   // v
+  int* sperm = (int*)(wbase + (size_t)wpw * ws) + (size_t)wv * ((D + 1) & ~1);
   if (a.u0)
     for (int i = lane; i < D; i += 64) su[i] = a.u0[(size_t)w * D + i];
   Pcg64 g;
   g.load(a.rng_in + (size_t)w * 4);
-  const int frame = a.axes_idx ? a.axes_idx[w] : 0;
-  const double* AT = a.axes_t ? a.axes_t + (size_t)frame * nc * nc : nullptr;
-  double acc[8];
+  const PcgLanes PL = pcg_lanes_init(g, lane);
+  const int frame = __builtin_amdgcn_readfirstlane(a.axes_idx ? a.axes_idx[w] : 0);
+  const double* AT = a.axes_t + (size_t)frame * nc * nc;  // unused when there are no frames (kind 3)
+  if (lane == 0) sframe[wv] = frame;
+  __syncthreads();
+  bool coop = a.axes_t != nullptr;  // all walkers of the workgroup on one frame: GEMM path
+  for (int q = 0; q < wpw; ++q) coop = coop && sframe[q] == sframe[0];
+  coop = __builtin_amdgcn_readfirstlane((int)coop) != 0;
   lds_sync();
 
   if (a.kind == 3) {
@@ -200,16 +283,14 @@ __global__ void __launch_bounds__(64) wide_walk_kernel(WideWalkArgs a) {
     int ncall = 0;
     double ll = -INFINITY;
     for (;;) {
-      for (int i = 0; i < D; ++i) {
-        const double x = g.next_double();
-        if ((i & 63) == lane) su[i] = x;
-      }
+      wave_doubles(g, PL, su, D, lane);
       lds_sync();
       ll = wide_logl(a.prob, D, su, sv, lane);
       ++ncall;
       lds_sync();
       if (ll > a.loglstar) break;
     }
+    if (ghost) return;
     for (int i = lane; i < D; i += 64) {
       a.u[(size_t)w * D + i] = su[i];
       a.v[(size_t)w * D + i] = sv[i];
@@ -227,25 +308,24 @@ __global__ void __launch_bounds__(64) wide_walk_kernel(WideWalkArgs a) {
     int nacc = 0, nrej = 0;
     double logl_cur = 0.0;
     for (int step = 0; step < a.iters; ++step) {
-      for (int i = nc; i < D; ++i) {
-        const double x = g.next_double();
-        if ((i & 63) == lane) sp[i] = x;
-      }
+      if (nc < D) wave_doubles(g, PL, sp + nc, D - nc, lane);
+      wave_normals(g, PL, &zig, sd, nc, lane);
+      lds_sync();
       double ss = 0.0;
-      for (int i = 0; i < nc; ++i) {
-        const double x = std_normal(g, &zig);
-        if ((i & 63) == lane) sd[i] = x;
-        ss = fma(x, x, ss);
-      }
+      for (int i = lane; i < nc; i += 64) ss = fma(sd[i], sd[i], ss);
+      ss = wave_sum(ss);
       const double fac = a.scale * (pow(g.next_double(), 1.0 / (double)nc) / sqrt(ss));
       lds_sync();
-      wide_matvec(AT, sd, nc, nc, lane, acc);
-      bool inside = true;
-#pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        const int i = lane + 64 * r;
-        if (i < nc) sp[i] = fma(fac, acc[r], su[i]);
+      if (coop) {
+        __syncthreads();
+        wg_frame_gemm(AT, nc, wbase, ws, 2 * D, 3 * D, 1.0, wpw, wv, wpw);
+        __syncthreads();
+      } else {
+        wg_frame_gemm(AT, nc, su, ws, 2 * D, 3 * D, 1.0, 1, 0, 1);
+        lds_sync();
       }
+      bool inside = true;
+      for (int i = lane; i < nc; i += 64) sp[i] = fma(fac, sv[i], su[i]);
       lds_sync();
       for (int i = lane; i < D; i += 64) {
         const int b = a.bc ? a.bc[i] : 0;
@@ -280,6 +360,7 @@ __global__ void __launch_bounds__(64) wide_walk_kernel(WideWalkArgs a) {
     const double ll0 = wide_logl(a.prob, D, su, sv, lane);
     if (nacc == 0) logl_cur = ll0;
     lds_sync();
+    if (ghost) return;
     for (int i = lane; i < D; i += 64) {
       a.u[(size_t)w * D + i] = su[i];
       a.v[(size_t)w * D + i] = sv[i];
@@ -294,12 +375,13 @@ __global__ void __launch_bounds__(64) wide_walk_kernel(WideWalkArgs a) {
   }
 
   // ---- rslice / slice (internal_samplers.py:593-855, 1038-1206) ----
+  long long cy_n = 0, cy_m = 0, cy_f = 0, cy_t0 = clock64();
   bool doubling = a.doubling0 != 0, warn_set = false, failed = false;
   int ncall = 0, n_expand = 0, n_contract = 0;
   double logl_cur = 0.0;
   const double maxlen = sqrt((double)D) / 2.0;
   const int nsub = a.kind == 1 ? 1 : D;
-  for (int s = 0; s < a.iters && !failed; ++s) {
+  for (int s = 0; s < a.iters && (!failed || a.kind == 1); ++s) {
     if (a.kind == 2) {
       // rstate.shuffle(arange(D)) -- sequential, every lane mirrors it
       for (int i = lane; i < D; i += 64) sperm[i] = i;
@@ -314,24 +396,32 @@ __global__ void __launch_bounds__(64) wide_walk_kernel(WideWalkArgs a) {
       }
       lds_sync();
     }
-    for (int sub = 0; sub < nsub && !failed; ++sub) {
+    for (int sub = 0; sub < nsub && (!failed || a.kind == 1); ++sub) {
       if (a.kind == 1) {
-        double ss = 0.0;
-        for (int i = 0; i < D; ++i) {
-          const double x = std_normal(g, &zig);
-          if ((i & 63) == lane) sv[i] = x;  // sv as scratch for drhat
-          ss = fma(x, x, ss);
+        // a failed walker keeps the workgroup's barriers company and does nothing else
+        const long long c0_ = clock64();
+        if (!failed) {
+          wave_normals(g, PL, &zig, sv, D, lane);  // sv as scratch for drhat
+          lds_sync();
+          double ss = 0.0;
+          for (int i = lane; i < D; i += 64) ss = fma(sv[i], sv[i], ss);
+          ss = wave_sum(ss);
+          const double inv = 1.0 / sqrt(ss);
+          lds_sync();
+          for (int i = lane; i < D; i += 64) sv[i] = sv[i] * inv;
+          lds_sync();
         }
-        const double inv = 1.0 / sqrt(ss);
-        lds_sync();
-        for (int i = lane; i < D; i += 64) sv[i] = sv[i] * inv;
-        lds_sync();
-        wide_matvec(AT, sv, D, D, lane, acc);
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-          const int i = lane + 64 * r;
-          if (i < D) sd[i] = acc[r] * a.scale;
+        const long long c1_ = clock64();
+        cy_n += c1_ - c0_;
+        if (coop) {
+          __syncthreads();
+          wg_frame_gemm(AT, D, wbase, ws, 3 * D, 2 * D, a.scale, wpw, wv, wpw);
+          __syncthreads();
+        } else if (!failed) {
+          wg_frame_gemm(AT, D, su, ws, 3 * D, 2 * D, a.scale, 1, 0, 1);
         }
+        cy_m += clock64() - c1_;
+        if (failed) continue;
       } else {
         const int idx = sperm[sub];
         const double* col = AT + (size_t)idx * D;
@@ -347,6 +437,7 @@ __global__ void __launch_bounds__(64) wide_walk_kernel(WideWalkArgs a) {
       lds_sync();
       // F(x): wave-uniform control flow (one walker per wave): plain code
       auto F = [&](double x) -> double {
+        const long long cf_ = clock64();
         double lo = 2.0, hi = -1.0;
         for (int i = lane; i < D; i += 64) {
           const double un = fma(x, sd[i], su[i]);
@@ -358,9 +449,13 @@ __global__ void __launch_bounds__(64) wide_walk_kernel(WideWalkArgs a) {
         hi = wave_max(hi);
         lds_sync();
         ++ncall;
-        if (!(lo > 0.0 && hi < 1.0)) return -INFINITY;
+        if (!(lo > 0.0 && hi < 1.0)) {
+          cy_f += clock64() - cf_;
+          return -INFINITY;
+        }
         const double ll = wide_logl(a.prob, D, sp, sv, lane);
         lds_sync();
+        cy_f += clock64() - cf_;
         return ll;
       };
       double left = -rand0, right = 1.0 - rand0;
@@ -442,8 +537,12 @@ __global__ void __launch_bounds__(64) wide_walk_kernel(WideWalkArgs a) {
       }
     }
   }
+  if (a.dbg && w == 0 && lane == 0)
+    printf("wide_walk wave 0: total %lld | normals %lld | matvec %lld | F %lld (ncall %d)\n",
+           (long long)(clock64() - cy_t0), cy_n, cy_m, cy_f, ncall);
   (void)wide_logl(a.prob, D, su, sv, lane);  // v of the returned point
   lds_sync();
+  if (ghost) return;
   for (int i = lane; i < D; i += 64) {
     a.u[(size_t)w * D + i] = su[i];
     a.v[(size_t)w * D + i] = sv[i];
@@ -1122,8 +1221,22 @@ int wide_walk_launch(dh_ctx* ctx, int kind, int problem, int k, int ndim, int nc
   a.zki = ctx->zki();
   a.zwi = ctx->zwi();
   a.zfi = ctx->zfi();
-  const size_t lds = (size_t)4 * ndim * 8 + (size_t)ndim * 4 + 64;
-  hipLaunchKernelGGL(wide_walk_kernel, dim3(k), dim3(64), lds, ctx->stream, a);
+  a.dbg = getenv("DH_WIDE_PROF") ? 1 : 0;
+  // walkers per workgroup: as many as LDS allows up to the 16 columns of one MFMA tile
+  a.lds_ws = (4 * ndim) | 1;
+  const size_t per_wave = (size_t)a.lds_ws * 8 + (size_t)((ndim + 1) & ~1) * 4;
+  int wpw = (int)std::min<size_t>(kWalkMaxWaves, (150 * 1024) / per_wave);
+  if (const char* e = getenv("DH_WIDE_WPW")) wpw = std::max(1, std::min(wpw, atoi(e)));
+  wpw = std::max(1, std::min(wpw, k));
+  const size_t lds = per_wave * wpw;
+  static size_t lds_attr = 0;
+  if (lds > lds_attr) {
+    if (!hip_ok(ctx, hipFuncSetAttribute((const void*)wide_walk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)lds), "hipFuncSetAttribute(wide_walk)"))
+      return DH_ERR_HIP;
+    lds_attr = lds;
+  }
+  hipLaunchKernelGGL(wide_walk_kernel, dim3((k + wpw - 1) / wpw), dim3(64 * wpw), lds, ctx->stream, a);
   return hip_ok(ctx, hipGetLastError(), "wide walk launch") ? DH_OK : DH_ERR_HIP;
 }
 
