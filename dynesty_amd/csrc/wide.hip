@@ -90,7 +90,7 @@ __device__ __forceinline__ double wave_max(double v) {
 // prior_transform + loglikelihood for one walker spread over a wave:
 // lane owns dims lane, lane+64, ...; u in LDS row `su` (D), v written to `sv`.
 // For LIKE_GAUSS_PREC the precision matrix is read from global memory.
-__device__ double wide_logl(const ProblemDev& P, int D, const double* su, double* sv, int lane) {
+__device__ __forceinline__ double wide_logl(const ProblemDev& P, int D, const double* su, double* sv, int lane) {
   // prior
   if (P.prior_id == PRIOR_AFFINE) {
     const double a = P.prior_par[0], b = P.prior_par[1];
@@ -194,58 +194,92 @@ __device__ __forceinline__ void wide_matvec(const double* __restrict__ AT, const
 // A lone wavefront uses it on its own region (ncols = nw = 1) when the walkers of a workgroup sit on
 // different frames: the arithmetic per column is the same, so a walker's path does not depend on
 // the company it keeps.
-constexpr int kGemmBatch = 10;
+// A lane loads TWO neighbouring rows of the frame per request (16 B): rows 2 lj and 2 lj + 1 of a
+// 32-row span feed two MFMA tiles (even rows / odd rows of the span), and up to 16 requests are in
+// flight per lane -- the product is bound by the latency of the L2 reads, not by their volume.
+typedef double dv2 __attribute__((ext_vector_type(2)));
+template <int NB>
+__device__ __forceinline__ void gemm_batch(const __attribute__((address_space(1))) double*& ap, const double*& bp,
+                                           size_t step, bool iv0, bool iv1, bool cv, wacc& acc0, wacc& acc1) {
+  typedef const __attribute__((address_space(1))) dv2* g2ptr;
+  dv2 fa[NB];
+  double fb[NB];
+#pragma unroll
+  for (int q = 0; q < NB; ++q) fa[q] = *(g2ptr)(ap + (size_t)q * step);
+#pragma unroll
+  for (int q = 0; q < NB; ++q) fb[q] = bp[4 * q];
+  ap += NB * step;
+  bp += 4 * NB;
+#pragma unroll
+  for (int q = 0; q < NB; ++q) {
+    const double b = cv ? fb[q] : 0.0;
+    acc0 = W_MFMA(iv0 ? fa[q].x : 0.0, b, acc0);
+    acc1 = W_MFMA(iv1 ? fa[q].y : 0.0, b, acc1);
+  }
+}
+
 __device__ __forceinline__ void wg_frame_gemm(const double* __restrict__ AT, int n, double* lds, int ws, int off_in,
                                               int off_out, double scale, int ncols, int wv, int nw) {
-  const int lane = threadIdx.x & 63, lj = lane & 15, lk = lane >> 4;
   typedef const __attribute__((address_space(1))) double* gptr;
-  const int nbk = __builtin_amdgcn_readfirstlane((n + 15) >> 4), kfull = __builtin_amdgcn_readfirstlane(n >> 2);
+  const int lane = threadIdx.x & 63, lj = lane & 15, lk = lane >> 4;
+  const int nsp = __builtin_amdgcn_readfirstlane((n + 31) >> 5), kfull = __builtin_amdgcn_readfirstlane(n >> 2);
   const bool cv = lj < ncols;
+  const bool even = (n & 1) == 0;  // 16-byte requests need 16-byte aligned rows
   const double* inw = lds + (size_t)(cv ? lj : 0) * ws + off_in + lk;
   const size_t step = (size_t)4 * n;
-  for (int ib = wv; ib < nbk; ib += nw) {
-    const int ia = ib * 16 + lj;
-    const bool iv = ia < n;
-    gptr ap = (gptr)AT + (size_t)lk * n + (iv ? ia : 0);
+  for (int sp = wv; sp < nsp; sp += nw) {
+    const int i0 = sp * 32 + 2 * lj;
+    const bool iv0 = i0 < n, iv1 = i0 + 1 < n;
+    wacc acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
     const double* bp = inw;
-    wacc acc = {0.0, 0.0, 0.0, 0.0};
-    int ks = 0;
-    for (; ks + kGemmBatch <= kfull; ks += kGemmBatch) {  // kGemmBatch loads in flight per lane
-      double fa[kGemmBatch], fb[kGemmBatch];
-#pragma unroll
-      for (int q = 0; q < kGemmBatch; ++q) fa[q] = ap[(size_t)q * step];
-#pragma unroll
-      for (int q = 0; q < kGemmBatch; ++q) fb[q] = bp[4 * q];
-      ap += kGemmBatch * step;
-      bp += 4 * kGemmBatch;
-#pragma unroll
-      for (int q = 0; q < kGemmBatch; ++q) acc = W_MFMA(iv ? fa[q] : 0.0, cv ? fb[q] : 0.0, acc);
-    }
-    for (; ks < kfull; ++ks) {
-      const double fa = *ap;
-      const double fb = *bp;
-      ap += step;
-      bp += 4;
-      acc = W_MFMA(iv ? fa : 0.0, cv ? fb : 0.0, acc);
-    }
-    if (n & 3) {
-      const bool kv = kfull * 4 + lk < n;
-      const double fa = (kv && iv) ? *ap : 0.0;
-      const double fb = (kv && cv) ? *bp : 0.0;
-      acc = W_MFMA(fa, fb, acc);
+    if (even) {
+      gptr ap = (gptr)AT + (size_t)lk * n + (iv0 ? i0 : 0);
+      int ks = 0;
+      for (; ks + 16 <= kfull; ks += 16) gemm_batch<16>(ap, bp, step, iv0, iv1, cv, acc0, acc1);
+      if (ks + 8 <= kfull) {
+        gemm_batch<8>(ap, bp, step, iv0, iv1, cv, acc0, acc1);
+        ks += 8;
+      }
+      if (ks + 4 <= kfull) {
+        gemm_batch<4>(ap, bp, step, iv0, iv1, cv, acc0, acc1);
+        ks += 4;
+      }
+      for (; ks < kfull; ++ks) gemm_batch<1>(ap, bp, step, iv0, iv1, cv, acc0, acc1);
+      if (n & 3) {
+        const bool kv = kfull * 4 + lk < n;
+        typedef const __attribute__((address_space(1))) dv2* g2ptr;
+        dv2 fa = {0.0, 0.0};
+        if (kv) fa = *(g2ptr)ap;
+        const double b = (kv && cv) ? *bp : 0.0;
+        acc0 = W_MFMA(iv0 ? fa.x : 0.0, b, acc0);
+        acc1 = W_MFMA(iv1 ? fa.y : 0.0, b, acc1);
+      }
+    } else {
+      gptr a0 = (gptr)AT + (size_t)lk * n + (iv0 ? i0 : 0);
+      gptr a1 = (gptr)AT + (size_t)lk * n + (iv1 ? i0 + 1 : 0);
+      for (int ks = 0; ks * 4 < n; ++ks) {
+        const bool kv = ks * 4 + lk < n;
+        const double f0 = (kv && iv0) ? *a0 : 0.0, f1 = (kv && iv1) ? *a1 : 0.0;
+        const double b = (kv && cv) ? *bp : 0.0;
+        a0 += step;
+        a1 += step;
+        bp += 4;
+        acc0 = W_MFMA(f0, b, acc0);
+        acc1 = W_MFMA(f1, b, acc1);
+      }
     }
     if (cv) {
       double* outw = lds + (size_t)lj * ws + off_out;
 #pragma unroll
       for (int q4 = 0; q4 < 4; ++q4) {
-        const int row = ib * 16 + lk + 4 * q4;
-        if (row < n) outw[row] = acc[q4] * scale;
+        const int row = sp * 32 + 2 * (lk + 4 * q4);
+        if (row < n) outw[row] = acc0[q4] * scale;
+        if (row + 1 < n) outw[row + 1] = acc1[q4] * scale;
       }
     }
   }
 }
 
-// one wavefront per walker, wpw = blockDim / 64 walkers per workgroup.
 constexpr int kWalkMaxWaves = 4;  // walkers per workgroup: one wavefront per SIMD keeps the full register file per walker
 __global__ void __launch_bounds__(64 * kWalkMaxWaves) wide_walk_kernel(WideWalkArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -375,7 +409,7 @@ __global__ void __launch_bounds__(64 * kWalkMaxWaves) wide_walk_kernel(WideWalkA
   }
 
   // ---- rslice / slice (internal_samplers.py:593-855, 1038-1206) ----
-  long long cy_n = 0, cy_m = 0, cy_f = 0, cy_t0 = clock64();
+  long long cy_n = 0, cy_m = 0, cy_f = 0, cy_g = 0, cy_t0 = clock64();
   bool doubling = a.doubling0 != 0, warn_set = false, failed = false;
   int ncall = 0, n_expand = 0, n_contract = 0;
   double logl_cur = 0.0;
@@ -415,7 +449,9 @@ __global__ void __launch_bounds__(64 * kWalkMaxWaves) wide_walk_kernel(WideWalkA
         cy_n += c1_ - c0_;
         if (coop) {
           __syncthreads();
+          const long long cg_ = clock64();
           wg_frame_gemm(AT, D, wbase, ws, 3 * D, 2 * D, a.scale, wpw, wv, wpw);
+          cy_g += clock64() - cg_;
           __syncthreads();
         } else if (!failed) {
           wg_frame_gemm(AT, D, su, ws, 3 * D, 2 * D, a.scale, 1, 0, 1);
@@ -538,8 +574,8 @@ __global__ void __launch_bounds__(64 * kWalkMaxWaves) wide_walk_kernel(WideWalkA
     }
   }
   if (a.dbg && w == 0 && lane == 0)
-    printf("wide_walk wave 0: total %lld | normals %lld | matvec %lld | F %lld (ncall %d)\n",
-           (long long)(clock64() - cy_t0), cy_n, cy_m, cy_f, ncall);
+    printf("wide_walk wave 0: total %lld | normals %lld | frame product %lld (GEMM itself %lld) | F %lld (ncall %d)\n",
+           (long long)(clock64() - cy_t0), cy_n, cy_m, cy_g, cy_f, ncall);
   (void)wide_logl(a.prob, D, su, sv, lane);  // v of the returned point
   lds_sync();
   if (ghost) return;
@@ -635,6 +671,10 @@ struct WideRebuildArgs {
   double* wscov; // runs x d x d   working covariance
   int dbg;       // DH_WIDE_PROF=1: thread 0 of run 0 prints the cycle count of every phase
   double* wsW;   // runs x 4 x P x P  double-buffered Jacobi work (P = d rounded up to even)
+  int phase;     // 0: whole rebuild in one launch; 1: mean + covariance only; 2: the rest, taking the
+                 // eigen-decomposition of the covariance from wide_eig_kernel when eig_ok says so
+  const double* lam_pre;  // runs x d   eigenvalues from wide_eig_kernel (vectors are in wsV)
+  const int* eig_ok;      // runs
   int* status;
   double* ctrs;
   double* covs;
@@ -800,6 +840,240 @@ __device__ bool jacobi_global(double* A, double* V, double* W, int D, double* rc
   return true;
 }
 
+// ---------------------------------------------------------------------------
+// Eigen-decomposition of the covariance by ONE-SIDED block Jacobi over several workgroups.
+//
+// jacobi_global above is two-sided: every round rewrites A and V (1.3 MB at D = 200) through ONE
+// compute unit's memory pipeline -- 30 ms of the 37 ms rebuild at 4000 x 200.  Hestenes' form
+// rotates COLUMNS only: with G = A (symmetric), right rotations that make the columns of G J
+// mutually orthogonal give J = V (A V = V L has orthogonal columns), and a rotation needs just the
+// two columns it touches: three dot products and two axpys.  So the columns are dealt in 2B blocks
+// of b (<= 16) to B workgroups, each keeps its two blocks [G column | V column] in LDS and
+// orthogonalises their pairs there (one wavefront per pair, b pairs at a time); between block
+// rounds the blocks move to their next partner through global memory (agent-scope stores / loads,
+// the barrier of rebuild.hip's parts -- workgroups may sit on different XCDs).  Block pairing is
+// the circle method; pairs inside a block are met in the first round of every sweep.  A sweep
+// without a rotation ends the iteration.  lam_k = v_k . (A v_k) (Rayleigh quotient of the final
+// column), V is orthogonal by construction (it only ever sees rotations).
+// LDS: 2b columns of 2D doubles.  Grid = runs x B, all resident (launch checks B * runs <= CUs).
+struct WideEigArgs {
+  const double* cov;  // runs x D x D
+  double* lam;        // runs x D
+  double* V;          // runs x D x D : V[i*D + k] = component i of vector k
+  double* xbuf;       // runs x 2 x M x b x 2D   block exchange (two parities)
+  int* bar;           // runs  (zeroed before launch)
+  int* rot;           // runs x kEigMaxSweeps rotation counters (zeroed)
+  int* ok;            // runs
+  int D, B, b;
+  int dbg;
+};
+constexpr int kEigMaxSweeps = 30;
+
+__device__ __forceinline__ bool eig_barrier(int* bar, int target, int* ok_flag) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(bar, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int ok = 1;
+    long long spins = 0;
+    while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(2);
+      if (++spins > (1ll << 20)) {  // partners never arrived (would otherwise hang the device)
+        ok = 0;
+        break;
+      }
+    }
+    *ok_flag = ok;
+  }
+  __syncthreads();
+  return *ok_flag != 0;
+}
+
+__global__ void __launch_bounds__(kRT) wide_eig_kernel(WideEigArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ int s_rot, s_ok;
+  const int D = a.D, B = a.B, b = a.b, M = 2 * B, CL = 2 * D;
+  const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6), nwv = kRT / 64;
+  const int run = blockIdx.x / B, w = blockIdx.x - run * B;
+  double* col = (double*)smem;  // 2b columns x CL
+  const double* cov = a.cov + (size_t)run * D * D;
+  double* xb = a.xbuf + (size_t)run * 2 * M * b * CL;
+  int* bar = a.bar + run;
+  int* rot = a.rot + (size_t)run * kEigMaxSweeps;
+  const double tol2 = (double)D * (2.220446049250313e-16 * 2.220446049250313e-16);
+  int nbar = 0;
+  long long tp_ = clock64(), cy_rot = 0, cy_st = 0, cy_bar = 0, cy_ld = 0;
+
+  // circle method: the pair of blocks workgroup w holds in round r
+  auto pair_of = [&](int r, int& top, int& bot) {
+    if (w == 0) {
+      top = M - 1;
+      bot = r % (M - 1);
+    } else {
+      top = (r + w) % (M - 1);
+      bot = (r - w + 2 * (M - 1)) % (M - 1);
+    }
+  };
+  // one rotation: columns p, q of the LDS tile (wave-uniform p, q)
+  auto rotate = [&](int p, int q) -> int {
+    double* P = col + (size_t)p * CL;
+    double* Q = col + (size_t)q * CL;
+    double al = 0.0, be = 0.0, ga = 0.0;
+    for (int i = lane; i < D; i += 64) {
+      const double x = P[i], y = Q[i];
+      al = fma(x, x, al);
+      be = fma(y, y, be);
+      ga = fma(x, y, ga);
+    }
+    al = wave_sum(al);
+    be = wave_sum(be);
+    ga = wave_sum(ga);
+    if (!(ga * ga > tol2 * (al * be))) return 0;  // orthogonal already (or a zero / padding column)
+    double c, sn;  // the 2x2 problem [[al, ga], [ga, be]]: same rotation as the two-sided form
+    dh_eig::jacobi_rotation(al, be, ga, c, sn);
+    for (int i = lane; i < CL; i += 64) {
+      const double x = P[i], y = Q[i];
+      P[i] = c * x - sn * y;
+      Q[i] = sn * x + c * y;
+    }
+    return 1;
+  };
+
+  // scale to max |cov_ij| = 1 (the rotation formula squares squared column norms)
+  __shared__ double s_red[kRT / 64];
+  double amax = 0.0;
+  for (int e = t; e < D * D; e += kRT) amax = fmax(amax, fabs(cov[e]));
+  amax = block_max_1024(amax, s_red);
+  const double scale = (amax > 0.0 && isfinite(amax)) ? 1.0 / amax : 1.0;
+  // initial blocks: G column g = column g of the covariance, V column = e_g; padding columns zero
+  {
+    int top, bot;
+    pair_of(0, top, bot);
+    for (int e = t; e < 2 * b * CL; e += kRT) {
+      const int c = e / CL, i = e - c * CL;
+      const int g = (c < b ? top : bot) * b + (c < b ? c : c - b);
+      double v = 0.0;
+      if (g < D) v = i < D ? cov[(size_t)g * D + i] * scale : (i - D == g ? 1.0 : 0.0);
+      col[e] = v;
+    }
+    if (t == 0) s_rot = 0;
+    __syncthreads();
+  }
+  bool ok = true, converged = false;
+  int parity = 0, sweep = 0;
+  for (sweep = 0; sweep < kEigMaxSweeps && ok && !converged; ++sweep) {
+    for (int r = 0; r < M - 1 && ok; ++r) {
+      int nrot = 0;
+      long long c0_ = clock64();
+      if (r == 0) {
+        // all pairs among the 2b columns: circle method inside the tile (2b - 1 steps of b pairs)
+        const int m2 = 2 * b;
+        for (int st = 0; st < m2 - 1; ++st) {
+          for (int k = wv; k < b; k += nwv) {
+            int p, q;
+            if (k == 0) {
+              p = m2 - 1;
+              q = st;
+            } else {
+              p = (st + k) % (m2 - 1);
+              q = (st - k + 2 * (m2 - 1)) % (m2 - 1);
+            }
+            nrot += rotate(p, q);
+          }
+          __syncthreads();
+        }
+      } else {
+        // pairs across the two blocks: step st pairs column i with column b + (i + st) % b
+        for (int st = 0; st < b; ++st) {
+          for (int k = wv; k < b; k += nwv) nrot += rotate(k, b + (k + st) % b);
+          __syncthreads();
+        }
+      }
+      if (lane == 0 && nrot) atomicAdd(&s_rot, nrot);
+      __syncthreads();
+      cy_rot += clock64() - c0_;
+      c0_ = clock64();
+      const bool last_round = r == M - 2;
+      if (M > 2) {
+        // hand the blocks on
+        int top, bot;
+        pair_of(r, top, bot);
+        double* dst = xb + (size_t)parity * M * b * CL;
+        double* d_top = dst + (size_t)top * b * CL;
+        double* d_bot = dst + (size_t)bot * b * CL - (size_t)b * CL;
+        const int half = b * CL;
+        for (int e = t; e < 2 * half; e += kRT)
+          __hip_atomic_store((e < half ? d_top : d_bot) + e, col[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (last_round && t == 0) {
+        if (s_rot) __hip_atomic_fetch_add(rot + sweep, s_rot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_rot = 0;
+      }
+      __syncthreads();  // (stores drained)
+      cy_st += clock64() - c0_;
+      c0_ = clock64();
+      if (B > 1) {
+        ++nbar;
+        ok = eig_barrier(bar, B * nbar, &s_ok);
+      } else {
+        __syncthreads();
+      }
+      cy_bar += clock64() - c0_;
+      c0_ = clock64();
+      if (last_round) {
+        const int total = __hip_atomic_load(rot + sweep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        converged = total == 0;
+      }
+      if (M > 2 && ok && !(last_round && converged)) {
+        int top, bot;
+        pair_of((r + 1) % (M - 1), top, bot);
+        const double* src = xb + (size_t)parity * M * b * CL;
+        const double* s_top = src + (size_t)top * b * CL;
+        const double* s_bot = src + (size_t)bot * b * CL - (size_t)b * CL;
+        const int half = b * CL, tot = 2 * half;
+        for (int e0 = t; e0 < tot; e0 += 8 * kRT) {  // eight requests in flight per thread
+          double tmp[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const int e = e0 + q * kRT;
+            tmp[q] = e < tot ? __hip_atomic_load((e < half ? s_top : s_bot) + e, __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_AGENT)
+                             : 0.0;
+          }
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const int e = e0 + q * kRT;
+            if (e < tot) col[e] = tmp[q];
+          }
+        }
+        parity ^= 1;
+        __syncthreads();
+      }
+      cy_ld += clock64() - c0_;
+    }
+  }
+  if (a.dbg && t == 0 && blockIdx.x == 0)
+    printf("wide_eig: D %d, %d workgroups x %d columns, %d sweeps, %lld cycles (rotations %lld, hand-on %lld, barrier %lld, pick-up %lld)\n",
+           D, B, 2 * b, sweep, (long long)(clock64() - tp_), cy_rot, cy_st, cy_bar, cy_ld);
+  // results: the blocks this workgroup holds now (those of the last round it worked on)
+  if (ok && converged) {
+    int top, bot;
+    pair_of(M - 2, top, bot);
+    double* lam = a.lam + (size_t)run * D;
+    double* V = a.V + (size_t)run * D * D;
+    for (int c = wv; c < 2 * b; c += nwv) {
+      const int g = (c < b ? top : bot) * b + (c < b ? c : c - b);
+      if (g >= D) continue;
+      const double* P = col + (size_t)c * CL;
+      double dot = 0.0;
+      for (int i = lane; i < D; i += 64) dot = fma(P[D + i], P[i], dot);
+      dot = wave_sum(dot);
+      if (lane == 0) lam[g] = dot * amax;
+      for (int i = lane; i < D; i += 64) V[(size_t)i * D + g] = P[D + i];
+    }
+  }
+  if (t == 0 && w == 0) a.ok[run] = (ok && converged) ? 1 : 0;
+}
+
 __global__ void __launch_bounds__(kRT) wide_single_kernel(WideRebuildArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int D = a.d, n = a.n, t = threadIdx.x, run = blockIdx.x;
@@ -821,6 +1095,7 @@ __global__ void __launch_bounds__(kRT) wide_single_kernel(WideRebuildArgs a) {
   double* o_ax = a.axes + (size_t)run * D * D;
   int status = DH_OK;
   if (n <= 1) status = DH_ERR_VALUE;
+  if (a.phase == 2 && a.status[run] != DH_OK) return;  // phase 1 already said why
   long long tp_ = clock64();
 #define WPH(name)                                                                   \
   do {                                                                              \
@@ -841,7 +1116,11 @@ __global__ void __launch_bounds__(kRT) wide_single_kernel(WideRebuildArgs a) {
     __syncthreads();
   };
 
-  if (status == DH_OK) {
+  if (status == DH_OK && a.phase == 2) {
+    for (int k = t; k < D; k += kRT) mean[k] = a.ctrs[(size_t)run * D + k];
+    __syncthreads();
+  }
+  if (status == DH_OK && a.phase != 2) {
     // ---- mean (np.mean axis 0) ----
     {
       // thread (j, g): dims j = t % DP..., use simple map: each thread sums a strided set of points
@@ -923,6 +1202,15 @@ __global__ void __launch_bounds__(kRT) wide_single_kernel(WideRebuildArgs a) {
       __syncthreads();
     }
     WPH("cov");
+  }
+  if (a.phase == 1) {
+    // the eigen-decomposition runs on several workgroups (wide_eig_kernel); phase 2 picks up here
+    if (status == DH_OK)
+      for (int k = t; k < D; k += kRT) a.ctrs[(size_t)run * D + k] = mean[k];
+    if (t == 0) a.status[run] = status;
+    return;
+  }
+  if (status == DH_OK) {
     // ---- improve_covar_mat + fmax passes (bounding.py:1311-1384, 1423-1457) ----
     const double lim = 1.0 - 1e-3;
     for (int pass = 0; pass < 2 && status == DH_OK; ++pass) {
@@ -930,16 +1218,20 @@ __global__ void __launch_bounds__(kRT) wide_single_kernel(WideRebuildArgs a) {
       int failed = 0, trial = 0;
       for (trial = 0; trial < 100; ++trial) {
         failed = 0;
-        for (int e = t; e < D * D; e += kRT) A[e] = cov[e];
-        __threadfence_block();
-        __syncthreads();
-        WPH("copy");
-        const bool fin = jacobi_global(A, V, a.wsW + (size_t)run * 4 * (size_t)((D + 1) & ~1) * ((D + 1) & ~1), D, rc, rs, red);
-        WPH("jacobi");
+        const bool pre = a.phase == 2 && pass == 0 && trial == 0 && a.eig_ok[run] == 1;
+        bool fin = true;
+        if (!pre) {
+          for (int e = t; e < D * D; e += kRT) A[e] = cov[e];
+          __threadfence_block();
+          __syncthreads();
+          WPH("copy");
+          fin = jacobi_global(A, V, a.wsW + (size_t)run * 4 * (size_t)((D + 1) & ~1) * ((D + 1) & ~1), D, rc, rs, red);
+          WPH("jacobi");
+        }
         double top = -INFINITY, bot = INFINITY;
         bool allfin = fin;
         if (fin) {
-          for (int k = t; k < D; k += kRT) lam[k] = A[(size_t)k * D + k];
+          for (int k = t; k < D; k += kRT) lam[k] = pre ? a.lam_pre[(size_t)run * D + k] : A[(size_t)k * D + k];
           __syncthreads();
           for (int k = 0; k < D; ++k) {
             const double l = lam[k];
@@ -1268,7 +1560,24 @@ int wide_single_launch(dh_ctx* ctx, int runs, const double* pts, int n, int d, i
   const size_t dd = (size_t)d * d * 8;
   const size_t pw = (size_t)((d + 1) & ~1);
   const size_t ww = 4 * pw * pw * 8;  // double-buffered Jacobi work per run
-  int rc = ensure_ws(ctx, (3 * dd + ww) * runs + 4096);
+  // multi-workgroup eigensolver: blocks of b <= 16 columns, two per workgroup
+  const int bmax = std::max(1, std::min(16, 4608 / d));
+  const int M = 2 * ((d + 2 * bmax - 1) / (2 * bmax)), B = M / 2, b = (d + M - 1) / M;
+  const size_t xb = (size_t)2 * M * b * 2 * d * 8;
+  const size_t eig_lds = (size_t)2 * b * 2 * d * 8;
+  const size_t ints = (size_t)(kEigMaxSweeps + 2) * 4;
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+      n_cu = prop.multiProcessorCount;
+    else
+      n_cu = 1;
+  }
+  const char* e_eig = getenv("DH_WIDE_EIG");
+  const bool split = !(e_eig && atoi(e_eig) == 0) && (long long)B * runs <= n_cu;
+  int rc = ensure_ws(ctx, (3 * dd + ww + xb + (size_t)d * 8 + ints) * runs + 4096);
   if (rc) return rc;
   WideRebuildArgs a;
   a.pts = pts;
@@ -1280,7 +1589,13 @@ int wide_single_launch(dh_ctx* ctx, int runs, const double* pts, int n, int d, i
   a.wsV = a.wsA + (size_t)runs * d * d;
   a.wscov = a.wsV + (size_t)runs * d * d;
   a.wsW = a.wscov + (size_t)runs * d * d;
+  double* x_buf = a.wsW + (size_t)runs * 4 * pw * pw;
+  double* lam_pre = x_buf + (size_t)runs * 2 * M * b * 2 * d;
+  int* eig_int = (int*)(lam_pre + (size_t)runs * d);  // bar[runs] | rot[runs x kEigMaxSweeps] | ok[runs]
   a.dbg = getenv("DH_WIDE_PROF") ? 1 : 0;
+  a.phase = 0;
+  a.lam_pre = lam_pre;
+  a.eig_ok = eig_int + (size_t)runs * (1 + kEigMaxSweeps);
   a.status = status;
   a.ctrs = ctrs;
   a.covs = covs;
@@ -1288,7 +1603,7 @@ int wide_single_launch(dh_ctx* ctx, int runs, const double* pts, int n, int d, i
   a.axes = axes;
   a.axlens = axlens;
   a.logvols = logvols;
-  static size_t attr_lds = 0;
+  static size_t attr_lds = 0, attr_eig = 0;
   if (lds > attr_lds) {
     if (!hip_ok(ctx,
                 hipFuncSetAttribute((const void*)wide_single_kernel,
@@ -1297,7 +1612,36 @@ int wide_single_launch(dh_ctx* ctx, int runs, const double* pts, int n, int d, i
       return DH_ERR_HIP;
     attr_lds = lds;
   }
-  hipLaunchKernelGGL(wide_single_kernel, dim3(runs), dim3(kRT), lds, ctx->stream, a);
+  if (!split) {
+    hipLaunchKernelGGL(wide_single_kernel, dim3(runs), dim3(kRT), lds, ctx->stream, a);
+  } else {
+    if (eig_lds > attr_eig) {
+      if (!hip_ok(ctx,
+                  hipFuncSetAttribute((const void*)wide_eig_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)eig_lds),
+                  "hipFuncSetAttribute(wide eig LDS)"))
+        return DH_ERR_HIP;
+      attr_eig = eig_lds;
+    }
+    if (!hip_ok(ctx, hipMemsetAsync(eig_int, 0, ints * runs, ctx->stream), "memset(eig counters)")) return DH_ERR_HIP;
+    a.phase = 1;
+    hipLaunchKernelGGL(wide_single_kernel, dim3(runs), dim3(kRT), lds, ctx->stream, a);
+    WideEigArgs g;
+    g.cov = a.wscov;
+    g.lam = lam_pre;
+    g.V = a.wsV;
+    g.xbuf = x_buf;
+    g.bar = eig_int;
+    g.rot = eig_int + runs;
+    g.ok = eig_int + (size_t)runs * (1 + kEigMaxSweeps);
+    g.D = d;
+    g.B = B;
+    g.b = b;
+    g.dbg = a.dbg;
+    hipLaunchKernelGGL(wide_eig_kernel, dim3(runs * B), dim3(kRT), eig_lds, ctx->stream, g);
+    a.phase = 2;
+    hipLaunchKernelGGL(wide_single_kernel, dim3(runs), dim3(kRT), lds, ctx->stream, a);
+  }
   if (!hip_ok(ctx, hipGetLastError(), "wide rebuild launch")) return DH_ERR_HIP;
   // nells = 1 per run (status decides validity)
   std::vector<int32_t> ones((size_t)runs, 1);
