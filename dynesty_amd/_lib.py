@@ -102,6 +102,8 @@ SIGNATURES = {
                                    _vp, _vp, _vp]),
     "dh_bound_draw": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp,
                            _vp, _vp, _vp]),
+    "dh_slice_feed": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _dbl, _vp, _vp, _i, _vp,
+                           _vp, _vp]),
 }
 
 
@@ -470,6 +472,34 @@ class Context:
             _ptr(idx), float(scale), _ptr(bcarr), _ptr(rng), _ptr(up),
             _ptr(inside), _ptr(rng_out)))
         return up, inside.astype(bool), rng_out
+
+    def slice_feed(self, kind, ndim, states6, consumed=None, nlook=0, axes=None,
+                   axes_idx=None, scale=1.0):
+        """Direction / axis order + uncommitted uniform lookahead of every
+        walker's stream for one slice (dh_slice_feed).  kind: 'direction'
+        (rslice), 'shuffle' (slice) or 'advance'.  Returns
+        (states6, dirs | perm | None, look)."""
+        kd = {'direction': 0, 'shuffle': 1, 'advance': 2}[kind]
+        st = np.array(states6, dtype=np.uint64).reshape(-1, 6)
+        k = st.shape[0]
+        cons = None if consumed is None else np.ascontiguousarray(
+            consumed, dtype=np.int32)
+        ax = idx = dirs = perm = None
+        m = 0
+        if kd == 0:
+            ax = _f64(axes).reshape(-1, ndim, ndim)
+            m = ax.shape[0]
+            idx = None if axes_idx is None else np.ascontiguousarray(
+                axes_idx, dtype=np.int32)
+            dirs = np.empty((k, ndim))
+        elif kd == 1:
+            perm = np.empty((k, ndim), dtype=np.int32)
+        look = np.empty((k, int(nlook)))
+        self._check(self.lib.dh_slice_feed(
+            self.handle, k, int(ndim), kd, _ptr(ax), m, _ptr(idx), float(scale),
+            _ptr(st), _ptr(cons), int(nlook), _ptr(dirs), _ptr(perm),
+            _ptr(look) if nlook else None))
+        return st, (dirs if kd == 0 else perm), look
 
     def slice_batch(self, prob, u0, axes, scale, loglstar, slices, rng_states,
                     principal=False, doubling=False, axes_idx=None):

@@ -1176,3 +1176,137 @@ int dh_bound_draw(dh_ctx* ctx, const uint64_t* state4, int nsamp, int d, int m, 
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------
+// Slice sampling in lock step with a HOST likelihood (dh_slice_feed).
+// With an arbitrary Python likelihood every F(x) of generic_slice_step
+// (internal_samplers.py:1076-1206) is a host call, so the host drives the stepping-out /
+// shrinking state machine and the device supplies what the walker's stream produces: the
+// slice direction (rslice: standard_normal(n), normalised, times the frame and the scale,
+// :818-823; slice: the shuffled axis order, :667-669) and then the uniforms the step will
+// consume (rand0, one per doubling expansion, one per shrink) as a LOOKAHEAD of `nlook`
+// values that is not committed -- the next call first advances the stream by the number
+// the host actually used.  One wavefront per walker.
+namespace {
+
+struct SliceFeedArgs {
+  int k, ndim, kind, m, nlook;
+  double scale;
+  const double* axes;  // m x ndim x ndim (row-major, as passed to the samplers)
+  const int32_t* axes_idx;
+  uint64_t* st6;  // k x 6: PCG64 state hi, lo, inc hi, lo, has_uint32, uinteger
+  const int32_t* consumed;
+  double* dirs;   // kind 0: k x ndim
+  int32_t* perm;  // kind 1: k x ndim
+  double* look;   // k x nlook
+  const uint64_t* zki;
+  const uint64_t* zwi;
+  const uint64_t* zfi;
+};
+
+__global__ void __launch_bounds__(64) slice_feed_kernel(SliceFeedArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ ZigLds zig;
+  double* dr = (double*)smem;        // ndim
+  int* sperm = (int*)(dr + a.ndim);  // ndim
+  if (a.kind == 0) zig_stage(&zig, a.zki, a.zwi, a.zfi);
+  const int w = blockIdx.x, lane = threadIdx.x, D = a.ndim;
+  uint64_t* st = a.st6 + (size_t)w * 6;
+  Pcg64 g;
+  g.load(st);
+  g.has32 = (uint32_t)st[4];
+  g.buf32 = (uint32_t)st[5];
+  const int adv = a.consumed ? a.consumed[w] : 0;
+  for (int i = 0; i < adv; ++i) g.step();
+  PcgLanes PL = pcg_lanes_init(g, lane);
+  if (a.kind == 0) {
+    wave_normals(g, PL, &zig, dr, D, lane);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    double ss = 0.0;
+    for (int i = 0; i < D; ++i) ss = fma(dr[i], dr[i], ss);  // index order, every lane the same
+    const double nrm = sqrt(ss);
+    __builtin_amdgcn_wave_barrier();
+    for (int i = lane; i < D; i += 64) dr[i] = dr[i] / nrm;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    const double* A = a.axes + (size_t)(a.axes_idx ? a.axes_idx[w] : 0) * D * D;
+    for (int i = lane; i < D; i += 64) {
+      double acc = 0.0;
+      for (int j = 0; j < D; ++j) acc = fma(A[(size_t)i * D + j], dr[j], acc);
+      a.dirs[(size_t)w * D + i] = acc * a.scale;
+    }
+  } else if (a.kind == 1) {
+    for (int i = lane; i < D; i += 64) sperm[i] = i;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    for (int i = D - 1; i >= 1; --i) {  // Generator.shuffle: Fisher-Yates from the top
+      const int j = (int)g.interval((uint64_t)i);
+      if (lane == 0) {
+        const int tmp = sperm[i];
+        sperm[i] = sperm[j];
+        sperm[j] = tmp;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    for (int i = lane; i < D; i += 64) a.perm[(size_t)w * D + i] = sperm[i];
+  }
+  if (lane == 0) {
+    g.store(st);
+    st[4] = g.has32;
+    st[5] = g.buf32;
+  }
+  if (a.nlook > 0) {
+    Pcg64 g2 = g;
+    wave_doubles(g2, PL, a.look + (size_t)w * a.nlook, a.nlook, lane);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int dh_slice_feed(dh_ctx* ctx, int k, int ndim, int kind, const double* axes, int m, const int32_t* axes_idx,
+                  double scale, uint64_t* state6, const int32_t* consumed, int nlook, double* dirs,
+                  int32_t* perm, double* look) {
+  DH_CHECK_CTX(ctx);
+  if (k <= 0) return DH_OK;
+  if (!state6 || kind < 0 || kind > 2 || ndim < 1 || nlook < 0 || (nlook > 0 && !look) ||
+      (kind == 0 && (!axes || !dirs || m < 1)) || (kind == 1 && !perm))
+    return fail(ctx, DH_ERR_ARG, "slice_feed: bad argument (kind=%d ndim=%d nlook=%d)", kind, ndim, nlook);
+  arena_reset(ctx);
+  const size_t kd = (size_t)k * ndim;
+  int rc = arena_reserve(ctx, (kind == 0 ? (size_t)m * ndim * ndim * 8 + kd * 8 : 0) + kd * 4 +
+                                  (size_t)k * (48 + 4 + 4 + (size_t)nlook * 8) + 8192);
+  if (rc) return rc;
+  SliceFeedArgs a;
+  a.k = k;
+  a.ndim = ndim;
+  a.kind = kind;
+  a.m = m;
+  a.nlook = nlook;
+  a.scale = scale;
+  a.axes = kind == 0 ? arena_up(ctx, axes, (size_t)m * ndim * ndim) : nullptr;
+  a.axes_idx = (kind == 0 && axes_idx) ? arena_up(ctx, axes_idx, (size_t)k) : nullptr;
+  a.st6 = arena_up(ctx, state6, (size_t)k * 6);
+  a.consumed = consumed ? arena_up(ctx, consumed, (size_t)k) : nullptr;
+  a.dirs = kind == 0 ? (double*)arena_get(ctx, kd * 8) : nullptr;
+  a.perm = kind == 1 ? (int32_t*)arena_get(ctx, kd * 4) : nullptr;
+  a.look = nlook ? (double*)arena_get(ctx, (size_t)k * nlook * 8) : nullptr;
+  a.zki = ctx->zki();
+  a.zwi = ctx->zwi();
+  a.zfi = ctx->zfi();
+  if (!a.st6 || (kind == 0 && (!a.axes || !a.dirs)) || (kind == 1 && !a.perm) || (nlook && !a.look) ||
+      (consumed && !a.consumed) || (kind == 0 && axes_idx && !a.axes_idx))
+    return DH_ERR_NOMEM;
+  hipLaunchKernelGGL(slice_feed_kernel, dim3(k), dim3(64), (size_t)ndim * 12 + 16, ctx->stream, a);
+  if (!hip_ok(ctx, hipGetLastError(), "slice feed launch")) return DH_ERR_HIP;
+  if (!down(ctx, state6, (const uint64_t*)a.st6, (size_t)k * 6)) return DH_ERR_HIP;
+  if (kind == 0 && !down(ctx, dirs, (const double*)a.dirs, kd)) return DH_ERR_HIP;
+  if (kind == 1 && !down(ctx, perm, (const int32_t*)a.perm, kd)) return DH_ERR_HIP;
+  if (nlook && !down(ctx, look, (const double*)a.look, (size_t)k * nlook)) return DH_ERR_HIP;
+  return dh_sync(ctx);
+}
+
+}  // extern "C"

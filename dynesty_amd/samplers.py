@@ -13,6 +13,7 @@ otherwise (sampler.py:696-699).  The device continues exactly those PCG64
 streams: Generators are read and written back, SeedSequence children are hashed
 on the device.
 """
+import warnings
 from collections import namedtuple
 
 import numpy as np
@@ -184,11 +185,214 @@ def run_rwalk(args):
     return res
 
 
+class _UniformFeed:
+    """Generator.random() of k walker streams, served from the device's
+    uncommitted lookahead (dh_slice_feed); `begin` commits what was used."""
+
+    def __init__(self, be, ndim, states6, nlook):
+        self.be, self.ndim, self.nlook = be, ndim, int(nlook)
+        self.states = np.array(states6, dtype=np.uint64).reshape(-1, 6)
+        k = self.states.shape[0]
+        self.pos = np.zeros(k, dtype=np.int32)
+        self.look = np.empty((k, 0))
+
+    def begin(self, kind, **kw):
+        self.states, out, self.look = self.be.slice_feed(
+            kind, self.ndim, self.states, consumed=self.pos, nlook=self.nlook,
+            **kw)
+        self.pos[:] = 0
+        return out
+
+    def random(self, i):
+        if self.pos[i] == self.look.shape[1]:  # lookahead used up: refill walker i
+            st, _, lk = self.be.slice_feed(
+                'advance', self.ndim, self.states[i:i + 1],
+                consumed=self.pos[i:i + 1], nlook=self.nlook)
+            self.states[i] = st[0]
+            self.look[i] = lk[0]
+            self.pos[i] = 0
+        x = self.look[i, self.pos[i]]
+        self.pos[i] += 1
+        return float(x)
+
+    def commit(self):
+        self.states, _, _ = self.be.slice_feed('advance', self.ndim, self.states,
+                                               consumed=self.pos, nlook=0)
+        self.pos[:] = 0
+        return self.states
+
+
+def _unitcheck(u, nonperiodic):
+    # utils.unitcheck: periodic coordinates may leave the cube by half a period
+    if nonperiodic is None:
+        return bool(np.all(u > 0.) and np.all(u < 1.))
+    nonp = np.asarray(nonperiodic, dtype=bool)
+    return bool(np.all(u[nonp] > 0.) and np.all(u[nonp] < 1.)
+                and np.all(u[~nonp] > -0.5) and np.all(u[~nonp] < 1.5))
+
+
+def _slice_step_host(u, direction, nonperiodic, loglstar, ptform, loglike,
+                     doubling, rand):
+    """generic_slice_step (internal_samplers.py:1076-1206) with the uniforms
+    of the walker's stream handed in by `rand()`.  Returns (u, v, logl, nc,
+    n_expand, n_contract, expansion_warning)."""
+    n = len(u)
+    nc = n_expand = n_contract = 0
+    rand0 = rand()
+    dirlen = np.linalg.norm(direction)
+    maxlen = np.sqrt(n) / 2.
+    direction = direction / (dirlen / maxlen if dirlen > maxlen else 1)
+
+    def F(x):
+        nonlocal nc
+        u_new = u + x * direction
+        nc += 1
+        if _unitcheck(u_new, nonperiodic):
+            v_new = ptform(u_new)
+            return u_new, v_new, loglike(v_new)
+        return u_new, None, -np.inf
+
+    left, right = -rand0, 1 - rand0
+    f_l, f_r = F(left)[2], F(right)[2]
+    warn = False
+    if not doubling:
+        while f_l > loglstar:
+            left -= 1
+            f_l = F(left)[2]
+            n_expand += 1
+        while f_r > loglstar:
+            right += 1
+            f_r = F(right)[2]
+            n_expand += 1
+        if n_expand > 1000:
+            warn = True
+            warnings.warn('The slice sample interval was expanded more '
+                          'than 1000 times')
+    else:
+        K = 1
+        while f_l > loglstar or f_r > loglstar:
+            if rand() < 0.5:
+                left -= (right - left)
+                f_l = F(left)[2]
+            else:
+                right += (right - left)
+                f_r = F(right)[2]
+            n_expand += K
+            K *= 2
+        L, R, fL, fR = left, right, f_l, f_r
+    while True:
+        x = left + rand() * (right - left)
+        u_prop, v_prop, f = F(x)
+        n_contract += 1
+        ok = f > loglstar
+        if ok and doubling:  # Neal (2003) algorithm 6, w = 1, x0 = 0
+            lhat, rhat, f_lhat, f_rhat, far = L, R, fL, fR, False
+            while rhat - lhat > 1.1:
+                M = (lhat + rhat) / 2.
+                if (0 < M <= x) or (x < M <= 0):
+                    far = True
+                if x < M:
+                    rhat = M
+                    f_rhat = F(rhat)[2]
+                else:
+                    lhat = M
+                    f_lhat = F(lhat)[2]
+                if far and loglstar >= f_lhat and loglstar >= f_rhat:
+                    ok = False
+                    break
+        if ok:
+            return u_prop, v_prop, f, nc, n_expand, n_contract, warn
+        if x < 0:
+            left = x
+        elif x > 0:
+            right = x
+        else:
+            raise RuntimeError(
+                "Slice sampler has failed to find a valid point. Some useful "
+                f"output quantities:\nu: {u}\nnstep_left: {left}\n"
+                f"nstep_right: {right}\nu_prop: {u_prop}\nloglstar: {loglstar}\n"
+                f"logl_prop: {f}\ndirection: {direction}\n")
+
+
+def _run_slice_lockstep(args, principal):
+    """RSliceSampler / SliceSampler with an arbitrary Python likelihood: per
+    slice ONE device call hands every walker its direction (or shuffled axis
+    order) and the uniforms that follow in its stream; the host runs
+    generic_slice_step's state machine around the user's callbacks
+    (internal_samplers.py:593-855).  Same streams, same counters."""
+    a0 = args[0]
+    kw = a0.kwargs
+    k = len(args)
+    u = np.array([a.u for a in args], dtype=np.float64)
+    ndim = u.shape[1]
+    nonperiodic = kw.get('nonperiodic', None)
+    doubling = [bool(kw.get('slice_doubling', False))] * k
+    slices = int(kw['slices'])
+    axes, idx = _frames(args)
+    streams = _Streams([a.rseed for a in args])
+    st6 = np.concatenate([np.array(streams.states, dtype=np.uint64).reshape(k, 4),
+                          np.zeros((k, 2), dtype=np.uint64)], axis=1)
+    if streams.generators is not None:
+        st6 = np.array([_lib.pcg_state6(g.bit_generator)
+                        for g in streams.generators], dtype=np.uint64)
+    feed = _UniformFeed(get_backend(), ndim, st6,
+                        nlook=(max(64, 8 * ndim) if principal else 64))
+    nc = np.zeros(k, dtype=np.int64)
+    ne = np.zeros(k, dtype=np.int64)
+    nt = np.zeros(k, dtype=np.int64)
+    warn_set = [False] * k
+    v = [None] * k
+    logl = [None] * k
+    # axes[:, i] is the i-th principal axis (internal_samplers.py:660-663)
+    scaled = [a0.scale * np.asarray(fr).T for fr in axes] if principal else None
+    for _ in range(slices):
+        if principal:
+            lead = feed.begin('shuffle')
+        else:
+            lead = feed.begin('direction', axes=axes, axes_idx=idx,
+                              scale=a0.scale)
+        for i in range(k):
+            rand = (lambda i=i: feed.random(i))
+            steps = ([scaled[0 if idx is None else idx[i]][j] for j in lead[i]]
+                     if principal else [lead[i]])
+            for direction in steps:
+                (u[i], v[i], logl[i], c1, e1, t1, w1) = _slice_step_host(
+                    u[i], direction, nonperiodic, a0.loglstar,
+                    a0.prior_transform, a0.loglikelihood, doubling[i], rand)
+                nc[i] += c1
+                ne[i] += e1
+                nt[i] += t1
+                if w1 and not doubling[i]:
+                    doubling[i] = True
+                    warn_set[i] = True
+                    warnings.warn('Enabling doubling strategy of slice '
+                                  'sampling from Neal(2003)')
+    st6 = feed.commit()
+    if streams.generators is not None:
+        for g, st in zip(streams.generators, st6):
+            _lib.set_pcg_state6(g.bit_generator, st)
+    res = []
+    for i in range(k):
+        res.append(SamplerReturn(
+            u=u[i].copy(), v=v[i], logl=logl[i], ncalls=int(nc[i]),
+            evaluation_history=[],
+            tuning_info={'n_expand': int(ne[i]), 'n_contract': int(nt[i]),
+                         'expansion_warning_set': warn_set[i]},
+            proposal_stats=dict(n_expand=int(ne[i]), n_contract=int(nt[i]))))
+    return res
+
+
 def _run_slice(args, principal):
     args = list(args)
     if not args:
         return []
     a0 = args[0]
+    nonp = a0.kwargs.get('nonperiodic', None)
+    if a0.kwargs.get('problem') is None or (nonp is not None
+                                            and not np.all(nonp)):
+        # arbitrary Python likelihood, or periodic coordinates (the fused slice
+        # kernels implement the plain unit-cube check only)
+        return _run_slice_lockstep(args, principal)
     prob = _problem_of(a0)
     kw = a0.kwargs
     u0 = np.array([a.u for a in args], dtype=np.float64)

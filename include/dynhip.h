@@ -204,6 +204,26 @@ int dh_rwalk_propose(dh_ctx* ctx, int k, int ndim, int ncdim, const double* u0,
                      const int8_t* bc, const uint64_t* rng, double* u_prop,
                      int32_t* inside, uint64_t* rng_out);
 
+/* Slice sampling in lock step with a HOST likelihood.  generic_slice_step
+ * (internal_samplers.py:1076-1206) evaluates F(x) = loglikelihood(prior_transform(u + x d)) at
+ * every stepping-out / shrinking move; with an arbitrary Python likelihood the host runs that
+ * state machine and this call supplies what each walker's random stream produces:
+ *   kind 0  rslice: drhat = standard_normal(ndim) / |.|, dirs = axes . drhat * scale (:818-823)
+ *   kind 1  slice : perm = the shuffled axis order of one sweep (:667-669)
+ *   kind 2  nothing (advance / refill / commit only)
+ * followed by a LOOKAHEAD of the next `nlook` Generator.random() values (rand0, doubling
+ * draws, shrink draws) that is NOT committed to the stream.
+ *   state6    k x 6 in/out: PCG64 state hi, lo, increment hi, lo, has_uint32, uinteger; on
+ *             entry the stream is first advanced by consumed[i] draws (the part of the previous
+ *             lookahead the host used; NULL = 0), on return it stands after the direction /
+ *             shuffle draws and before the lookahead.
+ *   axes      m x ndim x ndim (kind 0), axes_idx k or NULL
+ *   dirs      k x ndim (kind 0); perm k x ndim (kind 1); look k x nlook */
+int dh_slice_feed(dh_ctx* ctx, int k, int ndim, int kind, const double* axes, int m,
+                  const int32_t* axes_idx, double scale, uint64_t* state6,
+                  const int32_t* consumed, int nlook, double* dirs, int32_t* perm,
+                  double* look);
+
 /* RSliceSampler.sample (mode 0, internal_samplers.py:745-855) / SliceSampler.sample
  * (mode 1, :593-709) over k walkers; generic_slice_step + Neal's doubling
  * (:1038-1206) run as a per-lane state machine.  ncdim == ndim (dynesty.py:507-509).

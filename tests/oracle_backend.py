@@ -381,3 +381,35 @@ class OracleBackend:
                 st = rng.bit_generator.state
                 out[i, 4], out[i, 5] = st["has_uint32"], st["uinteger"]
         return u, out
+
+    def slice_feed(self, kind, ndim, states6, consumed=None, nlook=0, axes=None,
+                   axes_idx=None, scale=1.0):
+        from dynesty_amd import _lib
+        st = np.array(states6, dtype=np.uint64).reshape(-1, 6)
+        k = st.shape[0]
+        out = None
+        if kind == 'direction':
+            axes = np.asarray(axes, dtype=np.float64).reshape(-1, ndim, ndim)
+            out = np.empty((k, ndim))
+        elif kind == 'shuffle':
+            out = np.empty((k, ndim), dtype=np.int32)
+        look = np.empty((k, int(nlook)))
+        for i in range(k):
+            bg = np.random.PCG64()
+            _lib.set_pcg_state6(bg, st[i])
+            gen = np.random.Generator(bg)
+            if consumed is not None and consumed[i]:
+                gen.random(int(consumed[i]))
+            if kind == 'direction':
+                drhat = gen.standard_normal(size=ndim)
+                drhat /= np.linalg.norm(drhat)
+                fr = axes[0 if axes_idx is None else axes_idx[i]]
+                out[i] = np.dot(fr, drhat) * scale
+            elif kind == 'shuffle':
+                idxs = np.arange(ndim)
+                gen.shuffle(idxs)
+                out[i] = idxs
+            st[i] = _lib.pcg_state6(bg)
+            if nlook:
+                look[i] = gen.random(int(nlook))
+        return st, out, look

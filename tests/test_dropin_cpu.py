@@ -313,3 +313,71 @@ def test_unif_arbitrary_python_likelihood(dyn, bound):
     # every likelihood call went through the user's callback (the proposals of the last,
     # partly consumed queue fill are evaluated but not recorded)
     assert 0 <= len(calls) - int(np.sum(r.ncall)) <= 8 * 20
+
+
+@pytest.mark.parametrize("which,doubling,periodic", [
+    ("rslice", False, False), ("rslice", True, False), ("slice", False, False),
+    ("slice", True, False), ("rslice", False, True), ("slice", False, True)])
+def test_slice_lockstep_equals_reference_samplers(dyn, which, doubling, periodic):
+    """Arbitrary Python likelihood with sample='rslice' / 'slice': the lock-step path (directions,
+    axis orders and uniforms from the backend -- dh_slice_feed on the device, its NumPy twin
+    here -- and generic_slice_step's state machine on the host) against the reference's own
+    RSliceSampler.sample / SliceSampler.sample on the same arguments: same points, same
+    likelihoods, same call / expansion / contraction counters, same final stream."""
+    from dynesty_amd import samplers
+    IS = dyn.internal_samplers
+    nd = 4
+    rng = np.random.default_rng(12)
+    A = rng.standard_normal((nd, nd))
+    prec = A @ A.T + nd * np.eye(nd)
+
+    def loglike(v):
+        d = v - 0.3
+        return -0.5 * float(d @ prec @ d)
+
+    def ptform(u):
+        return 4.0 * u - 2.0
+    axes = [0.15 * (np.eye(nd) + 0.3 * rng.standard_normal((nd, nd))) for _ in range(2)]
+    us = 0.5 + 0.05 * rng.standard_normal((6, nd))
+    lls = [loglike(ptform(x)) for x in us]
+    loglstar = min(lls) - 0.5
+    nonp = np.array([True, False, True, True]) if periodic else None
+    kw = dict(slices=3, slice_doubling=doubling, nonperiodic=nonp)
+
+    def mk(seed_objs, cls):
+        return [cls(u=us[i].copy(), loglstar=loglstar, axes=axes[i % 2], scale=0.9,
+                    prior_transform=ptform, loglikelihood=loglike, rseed=s, kwargs=dict(kw))
+                for i, s in enumerate(seed_objs)]
+    gens_a = [np.random.Generator(np.random.PCG64(100 + i)) for i in range(6)]
+    gens_b = [np.random.Generator(np.random.PCG64(100 + i)) for i in range(6)]
+    for g in gens_a + gens_b:
+        g.integers(10)  # leave a buffered 32-bit half in the stream (has_uint32 = 1)
+    ref_cls = IS.RSliceSampler if which == "rslice" else IS.SliceSampler
+    ref = [ref_cls.sample(a) for a in mk(gens_a, IS.SamplerArgument)]
+    run = samplers.run_rslice if which == "rslice" else samplers.run_slice
+    got = run(mk(gens_b, IS.SamplerArgument))
+    for r, g in zip(ref, got):
+        np.testing.assert_array_equal(g.u, r.u)
+        np.testing.assert_array_equal(g.v, r.v)
+        assert g.logl == r.logl and g.ncalls == r.ncalls
+        assert g.tuning_info == r.tuning_info
+        assert g.proposal_stats == r.proposal_stats
+    for a, b in zip(gens_a, gens_b):
+        assert a.bit_generator.state == b.bit_generator.state
+
+
+def test_rslice_arbitrary_python_likelihood_run(dyn):
+    """A whole NestedSampler run with a Python likelihood and the drop-in rslice sampler."""
+    from dynesty_amd import dropin
+
+    def loglike(v):
+        return -0.5 * float(np.sum(v**2)) - 1.5 * np.log(2 * np.pi)
+
+    def ptform(u):
+        return 10. * (2. * u - 1.)
+    s = dyn.NestedSampler(loglike, ptform, 3, nlive=100, bound=dropin.HipMultiEllipsoid(3),
+                          sample=dropin.HipRSliceSampler(), pool=dropin.HipBatchPool(queue_size=8),
+                          queue_size=8, rstate=np.random.default_rng(4))
+    s.run_nested(dlogz=0.5, print_progress=False)
+    r = s.results
+    assert abs(r.logz[-1] - (-3 * np.log(20.))) < 5 * r.logzerr[-1] + 0.2

@@ -237,3 +237,69 @@ def test_unif_lockstep_equals_fused(ctx, kind):
             assert af.rseed.random() == al.rseed.random()
     finally:
         backend.set_backend(None)
+
+
+def test_slice_feed_equals_numpy_streams(ctx):
+    """dh_slice_feed (directions / axis orders / uncommitted uniform lookahead for the lock-step
+    slice path) against NumPy Generators on the same 6-word states: streams, permutations and
+    uniforms bit-exact, directions to rounding (norm and dot-product order differ)."""
+    from oracle_backend import OracleBackend
+    from dynesty_amd import _lib
+    ob = OracleBackend()
+    for nd in (3, 25, 70):
+        k = 9
+        gens = [np.random.Generator(np.random.PCG64(500 + i)) for i in range(k)]
+        for i, g in enumerate(gens):
+            if i % 2:
+                g.integers(7)  # buffered 32-bit half
+        st = np.array([_lib.pcg_state6(g.bit_generator) for g in gens], dtype=np.uint64)
+        rng = np.random.default_rng(nd)
+        axes = rng.standard_normal((2, nd, nd))
+        idx = (np.arange(k) % 2).astype(np.int32)
+        cons = (np.arange(k) * 3).astype(np.int32)
+        for kind, kw in (("direction", dict(axes=axes, axes_idx=idx, scale=0.7)), ("shuffle", {}),
+                         ("advance", {})):
+            s1, o1, l1 = ctx.slice_feed(kind, nd, st, consumed=cons, nlook=70, **kw)
+            s2, o2, l2 = ob.slice_feed(kind, nd, st, consumed=cons, nlook=70, **kw)
+            np.testing.assert_array_equal(s1, s2)
+            np.testing.assert_array_equal(l1, l2)
+            if kind == "direction":
+                np.testing.assert_allclose(o1, o2, rtol=1e-12, atol=1e-14)
+            elif kind == "shuffle":
+                np.testing.assert_array_equal(o1, o2)
+            st = s1
+
+
+@pytest.mark.parametrize("which", ["rslice", "slice"])
+def test_slice_lockstep_on_device_feed(ctx, which):
+    """run_rslice / run_slice without a device problem (arbitrary Python likelihood) on the HIP
+    backend against the same host state machine fed by NumPy streams."""
+    import types
+    from oracle_backend import OracleBackend
+    from dynesty_amd import samplers, backend
+    prob = inputs.problem("G5")
+    rng = np.random.default_rng(8)
+    us = 0.5 + 0.04 * rng.standard_normal((12, 5))
+    _, ll = ctx.problem_eval(prob, us)
+    loglstar = float(np.min(ll)) - 1.0
+    axes = 0.1 * (np.eye(5) + 0.2 * rng.standard_normal((5, 5)))
+
+    def mk():
+        kids = np.random.SeedSequence(31).spawn(12)
+        return [types.SimpleNamespace(u=us[i].copy(), loglstar=loglstar, axes=axes, scale=1.1,
+                                      prior_transform=prob.prior_transform,
+                                      loglikelihood=prob.loglikelihood, rseed=kids[i],
+                                      kwargs=dict(slices=4, slice_doubling=False, nonperiodic=None))
+                for i in range(12)]
+    run = samplers.run_rslice if which == "rslice" else samplers.run_slice
+    backend.set_backend(ctx)
+    try:
+        got = run(mk())
+        backend.set_backend(OracleBackend())
+        ref = run(mk())
+    finally:
+        backend.set_backend(None)
+    for g, r in zip(got, ref):
+        assert g.ncalls == r.ncalls and g.tuning_info == r.tuning_info
+        np.testing.assert_allclose(g.u, r.u, rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(g.logl, r.logl, rtol=1e-9, atol=1e-9)
