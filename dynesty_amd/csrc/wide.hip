@@ -675,6 +675,15 @@ struct WideRebuildArgs {
                  // eigen-decomposition of the covariance from wide_eig_kernel when eig_ok says so
   const double* lam_pre;  // runs x d   eigenvalues from wide_eig_kernel (vectors are in wsV)
   const int* eig_ok;      // runs
+  // phase 2 with split_tail: stop before the Mahalanobis maximum (wide_fmax_part_kernel /
+  // wide_finish_kernel take over) unless the covariance had to be regularised
+  int split_tail, P, chunk;  // P chunks of `chunk` points per run
+  double* meanpart;          // runs x P x d
+  double* covpart;           // runs x P x d x d
+  double* fmaxpart;          // runs x P
+  int* fast;                 // runs: 1 = phase 2 left the tail to the split kernels
+  double* lam_ws;            // runs x d
+  int* order_ws;             // runs x d
   int* status;
   double* ctrs;
   double* covs;
@@ -838,6 +847,141 @@ __device__ bool jacobi_global(double* A, double* V, double* W, int D, double* rc
   __threadfence_block();
   __syncthreads();
   return true;
+}
+
+// stage points [base, base+cnt) of the run, centred on `mean`, into the LDS tile (row stride D|1)
+__device__ __forceinline__ void wide_stage(const double* pts, int D, int base, int cnt, const double* mean,
+                                           double* tile) {
+  const int LD = D | 1;
+  for (int e = threadIdx.x; e < cnt * D; e += kRT) {
+    const int p = e / D, j = e - p * D;
+    tile[p * LD + j] = pts[(size_t)(base + p) * D + j] - mean[j];
+  }
+  __syncthreads();
+}
+
+// out = inv * Xc^T Xc over the points [pbeg, pend) (one 1024-thread workgroup); with `mirror` both
+// triangles are written, without only the 16x16 blocks (ib <= jb) -- the form the partial sums of the
+// multi-workgroup path use.
+__device__ void wide_cov_range(const double* pts, int D, int pbeg, int pend, const double* mean, double* tile,
+                               double* out, double inv, bool mirror) {
+  const int t = threadIdx.x, LD = D | 1;
+    // ---- covariance (np.cov ddof=1) on the matrix cores: C = Xc^T Xc, upper 16x16 blocks ----
+    // Block pairs (ib <= jb) are dealt round-robin to the 16 waves, kCovPairs per wave and pass
+    // (accumulators stay in registers across all tiles of the pass); K = points, 16 MFMA steps
+    // of 4 per 64-point tile.  The VALU form read two LDS operands per FMA (3.9 ms at 4000x200).
+    {
+      const int lane = t & 63, wv = t >> 6, lj = lane & 15, lk = lane >> 4;
+      const int nbk = (D + 15) >> 4;
+      const int npairs = nbk * (nbk + 1) / 2;
+      constexpr int kCovPairs = 6;
+      for (int pass0 = 0; pass0 < npairs; pass0 += kCovPairs * (kRT / 64)) {
+        wacc acc[kCovPairs];
+        int pib[kCovPairs], pjb[kCovPairs];
+#pragma unroll
+        for (int r = 0; r < kCovPairs; ++r) {
+          acc[r] = (wacc){0.0, 0.0, 0.0, 0.0};
+          const int pr = pass0 + r * (kRT / 64) + wv;
+          // unrank pr -> (ib <= jb), row-major over the upper triangle of an nbk x nbk grid
+          int ib = 0, rem = pr;
+          while (ib < nbk && rem >= nbk - ib) {
+            rem -= nbk - ib;
+            ++ib;
+          }
+          pib[r] = pr < npairs ? ib : -1;
+          pjb[r] = ib + rem;
+        }
+        for (int base = pbeg; base < pend; base += kTP) {
+          const int cnt = min(kTP, pend - base);
+          wide_stage(pts, D, base, cnt, mean, tile);
+#pragma unroll
+          for (int r = 0; r < kCovPairs; ++r) {
+            if (pib[r] < 0) continue;
+            const int ca = pib[r] * 16 + lj, cb = pjb[r] * 16 + lj;
+            for (int p0 = 0; p0 < cnt; p0 += 4) {
+              const int pp = p0 + lk;
+              const bool pv = pp < cnt;
+              const double fa = (pv && ca < D) ? tile[pp * LD + ca] : 0.0;
+              const double fb = (pv && cb < D) ? tile[pp * LD + cb] : 0.0;
+              acc[r] = W_MFMA(fa, fb, acc[r]);
+            }
+          }
+          __syncthreads();
+        }
+#pragma unroll
+        for (int r = 0; r < kCovPairs; ++r) {
+          if (pib[r] < 0) continue;
+#pragma unroll
+          for (int q4 = 0; q4 < 4; ++q4) {
+            const int i = pib[r] * 16 + lk + 4 * q4, j = pjb[r] * 16 + lj;
+            if (i < D && j < D) {
+              const double c = acc[r][q4] * inv;
+              out[(size_t)i * D + j] = c;
+              if (mirror) out[(size_t)j * D + i] = c;
+            }
+          }
+        }
+      }
+      __threadfence_block();
+      __syncthreads();
+    }
+}
+
+// max over the points [pbeg, pend) of delta^T am delta (per-thread partial maxima; the caller reduces)
+__device__ double wide_fmax_range(const double* pts, int D, int pbeg, int pend, const double* mean, double* tile,
+                                  double* part, const double* o_am) {
+  const int t = threadIdx.x, LD = D | 1;
+      // ---- fmax = max_p delta^T am delta on the matrix cores: Z = Xc AM per 64-point tile
+      // (M = 4 point blocks, N = column blocks dealt to the waves, K = D in steps of 4), then the
+      // row-wise dot Z . x, a 16-lane reduction and a fixed-order sum over the column blocks.
+      // The VALU form issued one global load per FMA (17.5 ms at 4000 x 200).
+      double best = -INFINITY;
+      {
+        const int lane = t & 63, wv = t >> 6, lj = lane & 15, lk = lane >> 4;
+        const int nbk = (D + 15) >> 4, ksteps = (D + 3) >> 2;
+        for (int base = pbeg; base < pend; base += kTP) {
+          const int cnt = min(kTP, pend - base);
+          wide_stage(pts, D, base, cnt, mean, tile);
+          for (int jb = wv; jb < nbk; jb += kRT / 64) {
+            const int jc = jb * 16 + lj;
+            wacc z[4];
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) z[mb] = (wacc){0.0, 0.0, 0.0, 0.0};
+            for (int ks = 0; ks < ksteps; ++ks) {
+              const int k = ks * 4 + lk;
+              const bool kv = k < D;
+              const double fb = (kv && jc < D) ? o_am[(size_t)k * D + jc] : 0.0;
+#pragma unroll
+              for (int mb = 0; mb < 4; ++mb) {
+                const int pp = mb * 16 + lj;
+                const double fa = (kv && pp < cnt) ? tile[pp * LD + k] : 0.0;
+                z[mb] = W_MFMA(fa, fb, z[mb]);
+              }
+            }
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+#pragma unroll
+              for (int q4 = 0; q4 < 4; ++q4) {
+                const int pp = mb * 16 + lk + 4 * q4;
+                double sacc = (pp < cnt && jc < D) ? z[mb][q4] * tile[pp * LD + jc] : 0.0;
+                sacc += __shfl_xor(sacc, 1);
+                sacc += __shfl_xor(sacc, 2);
+                sacc += __shfl_xor(sacc, 4);
+                sacc += __shfl_xor(sacc, 8);
+                if (lj == 0) part[jb * 64 + pp] = sacc;
+              }
+            }
+          }
+          __syncthreads();
+          if (t < cnt) {
+            double sacc = 0.0;
+            for (int jb = 0; jb < nbk; ++jb) sacc += part[jb * 64 + t];
+            best = fmax(best, sacc);
+          }
+          __syncthreads();
+        }
+      }
+  return best;
 }
 
 // ---------------------------------------------------------------------------
@@ -1106,16 +1250,6 @@ __global__ void __launch_bounds__(kRT) wide_single_kernel(WideRebuildArgs a) {
     }                                                                               \
   } while (0)
 
-  auto stage = [&](int base, int cnt, bool centre) {
-    for (int e = t; e < cnt * D; e += kRT) {
-      const int p = e / D, j = e - p * D;
-      double x = pts[(size_t)(base + p) * D + j];
-      if (centre) x -= mean[j];
-      tile[p * LD + j] = x;
-    }
-    __syncthreads();
-  };
-
   if (status == DH_OK && a.phase == 2) {
     for (int k = t; k < D; k += kRT) mean[k] = a.ctrs[(size_t)run * D + k];
     __syncthreads();
@@ -1141,66 +1275,7 @@ __global__ void __launch_bounds__(kRT) wide_single_kernel(WideRebuildArgs a) {
       __syncthreads();
     }
     WPH("mean");
-    // ---- covariance (np.cov ddof=1) on the matrix cores: C = Xc^T Xc, upper 16x16 blocks ----
-    // Block pairs (ib <= jb) are dealt round-robin to the 16 waves, kCovPairs per wave and pass
-    // (accumulators stay in registers across all tiles of the pass); K = points, 16 MFMA steps
-    // of 4 per 64-point tile.  The VALU form read two LDS operands per FMA (3.9 ms at 4000x200).
-    {
-      const int lane = t & 63, wv = t >> 6, lj = lane & 15, lk = lane >> 4;
-      const int nbk = (D + 15) >> 4;
-      const int npairs = nbk * (nbk + 1) / 2;
-      constexpr int kCovPairs = 6;
-      const double inv = 1.0 / (double)(n - 1);
-      for (int pass0 = 0; pass0 < npairs; pass0 += kCovPairs * (kRT / 64)) {
-        wacc acc[kCovPairs];
-        int pib[kCovPairs], pjb[kCovPairs];
-#pragma unroll
-        for (int r = 0; r < kCovPairs; ++r) {
-          acc[r] = (wacc){0.0, 0.0, 0.0, 0.0};
-          const int pr = pass0 + r * (kRT / 64) + wv;
-          // unrank pr -> (ib <= jb), row-major over the upper triangle of an nbk x nbk grid
-          int ib = 0, rem = pr;
-          while (ib < nbk && rem >= nbk - ib) {
-            rem -= nbk - ib;
-            ++ib;
-          }
-          pib[r] = pr < npairs ? ib : -1;
-          pjb[r] = ib + rem;
-        }
-        for (int base = 0; base < n; base += kTP) {
-          const int cnt = min(kTP, n - base);
-          stage(base, cnt, true);
-#pragma unroll
-          for (int r = 0; r < kCovPairs; ++r) {
-            if (pib[r] < 0) continue;
-            const int ca = pib[r] * 16 + lj, cb = pjb[r] * 16 + lj;
-            for (int p0 = 0; p0 < cnt; p0 += 4) {
-              const int pp = p0 + lk;
-              const bool pv = pp < cnt;
-              const double fa = (pv && ca < D) ? tile[pp * LD + ca] : 0.0;
-              const double fb = (pv && cb < D) ? tile[pp * LD + cb] : 0.0;
-              acc[r] = W_MFMA(fa, fb, acc[r]);
-            }
-          }
-          __syncthreads();
-        }
-#pragma unroll
-        for (int r = 0; r < kCovPairs; ++r) {
-          if (pib[r] < 0) continue;
-#pragma unroll
-          for (int q4 = 0; q4 < 4; ++q4) {
-            const int i = pib[r] * 16 + lk + 4 * q4, j = pjb[r] * 16 + lj;
-            if (i < D && j < D) {
-              const double c = acc[r][q4] * inv;
-              cov[(size_t)i * D + j] = c;
-              cov[(size_t)j * D + i] = c;
-            }
-          }
-        }
-      }
-      __threadfence_block();
-      __syncthreads();
-    }
+    wide_cov_range(pts, D, 0, n, mean, tile, cov, 1.0 / (double)(n - 1), true);
     WPH("cov");
   }
   if (a.phase == 1) {
@@ -1349,56 +1424,15 @@ __global__ void __launch_bounds__(kRT) wide_single_kernel(WideRebuildArgs a) {
       __threadfence_block();
       __syncthreads();
       WPH("sort+ax+am");
-      // ---- fmax = max_p delta^T am delta on the matrix cores: Z = Xc AM per 64-point tile
-      // (M = 4 point blocks, N = column blocks dealt to the waves, K = D in steps of 4), then the
-      // row-wise dot Z . x, a 16-lane reduction and a fixed-order sum over the column blocks.
-      // The VALU form issued one global load per FMA (17.5 ms at 4000 x 200).
-      double best = -INFINITY;
-      {
-        const int lane = t & 63, wv = t >> 6, lj = lane & 15, lk = lane >> 4;
-        const int nbk = (D + 15) >> 4, ksteps = (D + 3) >> 2;
-        for (int base = 0; base < n; base += kTP) {
-          const int cnt = min(kTP, n - base);
-          stage(base, cnt, true);
-          for (int jb = wv; jb < nbk; jb += kRT / 64) {
-            const int jc = jb * 16 + lj;
-            wacc z[4];
-#pragma unroll
-            for (int mb = 0; mb < 4; ++mb) z[mb] = (wacc){0.0, 0.0, 0.0, 0.0};
-            for (int ks = 0; ks < ksteps; ++ks) {
-              const int k = ks * 4 + lk;
-              const bool kv = k < D;
-              const double fb = (kv && jc < D) ? o_am[(size_t)k * D + jc] : 0.0;
-#pragma unroll
-              for (int mb = 0; mb < 4; ++mb) {
-                const int pp = mb * 16 + lj;
-                const double fa = (kv && pp < cnt) ? tile[pp * LD + k] : 0.0;
-                z[mb] = W_MFMA(fa, fb, z[mb]);
-              }
-            }
-#pragma unroll
-            for (int mb = 0; mb < 4; ++mb) {
-#pragma unroll
-              for (int q4 = 0; q4 < 4; ++q4) {
-                const int pp = mb * 16 + lk + 4 * q4;
-                double sacc = (pp < cnt && jc < D) ? z[mb][q4] * tile[pp * LD + jc] : 0.0;
-                sacc += __shfl_xor(sacc, 1);
-                sacc += __shfl_xor(sacc, 2);
-                sacc += __shfl_xor(sacc, 4);
-                sacc += __shfl_xor(sacc, 8);
-                if (lj == 0) part[jb * 64 + pp] = sacc;
-              }
-            }
-          }
-          __syncthreads();
-          if (t < cnt) {
-            double sacc = 0.0;
-            for (int jb = 0; jb < nbk; ++jb) sacc += part[jb * 64 + t];
-            best = fmax(best, sacc);
-          }
-          __syncthreads();
+      if (a.phase == 2 && a.split_tail && pass == 0 && good) {
+        for (int k = t; k < D; k += kRT) {
+          a.lam_ws[(size_t)run * D + k] = lam[k];
+          a.order_ws[(size_t)run * D + k] = order[k];
         }
+        if (t == 0) a.fast[run] = 1;
+        return;
       }
+      const double best = wide_fmax_range(pts, D, 0, n, mean, tile, part, o_am);
       const double fmx = block_max_1024(best, red);
       WPH("fmax");
       if (pass == 0 && fmx > lim) {
@@ -1437,6 +1471,129 @@ __global__ void __launch_bounds__(kRT) wide_single_kernel(WideRebuildArgs a) {
     }
   }
   if (t == 0) a.status[run] = status;
+}
+
+// ---- the data-parallel parts of the rebuild over P workgroups per run -------------------------
+// mean: partial sums per chunk; covariance: partial Gram matrices per chunk (mean re-derived from
+// the partials in chunk order by every workgroup), reduced in chunk order; Mahalanobis maximum:
+// partial maxima.  Everything is summed in a fixed order: results do not depend on scheduling.
+__global__ void __launch_bounds__(kRT) wide_mean_part_kernel(WideRebuildArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  double* sacc = (double*)smem;  // G x D
+  const int D = a.d, t = threadIdx.x, run = blockIdx.x / a.P, q = blockIdx.x - run * a.P;
+  const int pbeg = min(a.n, q * a.chunk), pend = min(a.n, pbeg + a.chunk);
+  const double* pts = a.pts + (size_t)run * a.n * D;
+  const int G = kRT / D > 0 ? kRT / D : 1;
+  const int j = t % D, g = t / D;
+  double acc = 0.0;
+  if (g < G)
+    for (int p = pbeg + g; p < pend; p += G) acc += pts[(size_t)p * D + j];
+  if (g < G) sacc[(size_t)g * D + j] = acc;
+  __syncthreads();
+  if (t < D) {
+    double sum = 0.0;
+    for (int gg = 0; gg < G; ++gg) sum += sacc[(size_t)gg * D + t];
+    a.meanpart[((size_t)run * a.P + q) * D + t] = sum;
+  }
+}
+
+__device__ __forceinline__ void wide_mean_from_parts(const WideRebuildArgs& a, int run, double* mean) {
+  for (int k = threadIdx.x; k < a.d; k += kRT) {
+    double sum = 0.0;
+    for (int q = 0; q < a.P; ++q) sum += a.meanpart[((size_t)run * a.P + q) * a.d + k];
+    mean[k] = sum / (double)a.n;
+  }
+  __syncthreads();
+}
+
+__global__ void __launch_bounds__(kRT) wide_cov_part_kernel(WideRebuildArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int D = a.d, LD = D | 1, run = blockIdx.x / a.P, q = blockIdx.x - run * a.P;
+  double* tile = (double*)smem;
+  double* mean = tile + (size_t)kTP * LD;
+  const int pbeg = min(a.n, q * a.chunk), pend = min(a.n, pbeg + a.chunk);
+  wide_mean_from_parts(a, run, mean);
+  wide_cov_range(a.pts + (size_t)run * a.n * D, D, pbeg, pend, mean, tile,
+                 a.covpart + ((size_t)run * a.P + q) * D * D, 1.0, false);
+}
+
+__global__ void __launch_bounds__(256) wide_cov_reduce_kernel(WideRebuildArgs a) {
+  const int D = a.d, run = blockIdx.y, e = blockIdx.x * 256 + threadIdx.x;
+  if (e < D * D) {
+    const int i = e / D, j = e - i * D;
+    const size_t src = (i >> 4) <= (j >> 4) ? (size_t)i * D + j : (size_t)j * D + i;
+    double sum = 0.0;
+    for (int q = 0; q < a.P; ++q) sum += a.covpart[((size_t)run * a.P + q) * D * D + src];
+    a.wscov[(size_t)run * D * D + e] = sum * (1.0 / (double)(a.n - 1));
+  }
+  if (blockIdx.x == 0) {
+    for (int k = threadIdx.x; k < D; k += 256) {
+      double sum = 0.0;
+      for (int q = 0; q < a.P; ++q) sum += a.meanpart[((size_t)run * a.P + q) * D + k];
+      a.ctrs[(size_t)run * D + k] = sum / (double)a.n;
+    }
+    if (threadIdx.x == 0) a.status[run] = DH_OK;
+  }
+}
+
+__global__ void __launch_bounds__(kRT) wide_fmax_part_kernel(WideRebuildArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int D = a.d, LD = D | 1, t = threadIdx.x, run = blockIdx.x / a.P, q = blockIdx.x - run * a.P;
+  if (!a.fast[run]) return;
+  double* tile = (double*)smem;
+  double* mean = tile + (size_t)kTP * LD;
+  double* red = mean + D;
+  double* part = red + 64;
+  const int pbeg = min(a.n, q * a.chunk), pend = min(a.n, pbeg + a.chunk);
+  for (int k = t; k < D; k += kRT) mean[k] = a.ctrs[(size_t)run * D + k];
+  __syncthreads();
+  const double best = wide_fmax_range(a.pts + (size_t)run * a.n * D, D, pbeg, pend, mean, tile, part,
+                                      a.ams + (size_t)run * D * D);
+  const double fm = block_max_1024(best, red);
+  if (t == 0) a.fmaxpart[(size_t)run * a.P + q] = fm;
+}
+
+// the tail of wide_single_kernel after the Mahalanobis maximum, for the runs phase 2 left to us
+__global__ void __launch_bounds__(kRT) wide_finish_kernel(WideRebuildArgs a) {
+  const int D = a.d, t = threadIdx.x, run = blockIdx.x;
+  if (!a.fast[run]) return;
+  double fmx = -INFINITY;
+  for (int q = 0; q < a.P; ++q) fmx = fmax(fmx, a.fmaxpart[(size_t)run * a.P + q]);
+  const double lim = 1.0 - 1e-3;
+  double* cov = a.wscov + (size_t)run * D * D;
+  double* o_am = a.ams + (size_t)run * D * D;
+  double* o_ax = a.axes + (size_t)run * D * D;
+  const double* lam = a.lam_ws + (size_t)run * D;
+  const int* order = a.order_ws + (size_t)run * D;
+  const double mult = fmx > lim ? fmx / lim : 1.0, rt = sqrt(mult);
+  bool ok = true;
+  double slog = 0.0;
+  for (int k = 0; k < D; ++k) {
+    const double l = fmx > lim ? lam[k] * mult : lam[k];
+    if (!(l > 0.0) || !isfinite(l)) ok = false;
+    slog += log(l);
+  }
+  if (!ok) {
+    if (t == 0) a.status[run] = DH_ERR_VALUE;
+    return;
+  }
+  for (int e = t; e < D * D; e += kRT) {
+    double c = cov[e];
+    if (fmx > lim) {
+      c *= mult;
+      o_am[e] /= mult;
+      o_ax[e] *= rt;
+    }
+    a.covs[(size_t)run * D * D + e] = c;
+  }
+  for (int k = t; k < D; k += kRT) {
+    const double l = fmx > lim ? lam[order[k]] * mult : lam[order[k]];
+    a.axlens[(size_t)run * D + k] = sqrt(l);
+  }
+  if (t == 0) {
+    a.logvols[run] = a.prefactor + 0.5 * slog;
+    a.status[run] = DH_OK;
+  }
 }
 
 size_t wide_single_lds(int D) {
@@ -1565,7 +1722,6 @@ int wide_single_launch(dh_ctx* ctx, int runs, const double* pts, int n, int d, i
   const int M = 2 * ((d + 2 * bmax - 1) / (2 * bmax)), B = M / 2, b = (d + M - 1) / M;
   const size_t xb = (size_t)2 * M * b * 2 * d * 8;
   const size_t eig_lds = (size_t)2 * b * 2 * d * 8;
-  const size_t ints = (size_t)(kEigMaxSweeps + 2) * 4;
   static int n_cu = 0;
   if (!n_cu) {
     int dev = 0;
@@ -1576,8 +1732,13 @@ int wide_single_launch(dh_ctx* ctx, int runs, const double* pts, int n, int d, i
       n_cu = 1;
   }
   const char* e_eig = getenv("DH_WIDE_EIG");
-  const bool split = !(e_eig && atoi(e_eig) == 0) && (long long)B * runs <= n_cu;
-  int rc = ensure_ws(ctx, (3 * dd + ww + xb + (size_t)d * 8 + ints) * runs + 4096);
+  const bool split = !(e_eig && atoi(e_eig) == 0) && (long long)B * runs <= n_cu && n > 1;
+  // chunks of whole 64-point tiles for the data-parallel kernels
+  const int ntiles = (n + kTP - 1) / kTP;
+  const int ct = std::max(1, (ntiles + 31) / 32), P = (ntiles + ct - 1) / ct, chunk = ct * kTP;
+  const size_t part_bytes = ((size_t)P * d + (size_t)P * d * d + P + d) * 8 + (size_t)d * 4 + 64;
+  const size_t ints = (size_t)(kEigMaxSweeps + 3) * 4;
+  int rc = ensure_ws(ctx, (3 * dd + ww + xb + (size_t)d * 8 + ints + part_bytes) * runs + 4096);
   if (rc) return rc;
   WideRebuildArgs a;
   a.pts = pts;
@@ -1591,11 +1752,21 @@ int wide_single_launch(dh_ctx* ctx, int runs, const double* pts, int n, int d, i
   a.wsW = a.wscov + (size_t)runs * d * d;
   double* x_buf = a.wsW + (size_t)runs * 4 * pw * pw;
   double* lam_pre = x_buf + (size_t)runs * 2 * M * b * 2 * d;
-  int* eig_int = (int*)(lam_pre + (size_t)runs * d);  // bar[runs] | rot[runs x kEigMaxSweeps] | ok[runs]
+  a.meanpart = lam_pre + (size_t)runs * d;
+  a.covpart = a.meanpart + (size_t)runs * P * d;
+  a.fmaxpart = a.covpart + (size_t)runs * P * d * d;
+  a.lam_ws = a.fmaxpart + (size_t)runs * P;
+  a.order_ws = (int*)(a.lam_ws + (size_t)runs * d);
+  // bar[runs] | rot[runs x kEigMaxSweeps] | ok[runs] | fast[runs]
+  int* eig_int = a.order_ws + (size_t)runs * d + 2;
   a.dbg = getenv("DH_WIDE_PROF") ? 1 : 0;
   a.phase = 0;
   a.lam_pre = lam_pre;
   a.eig_ok = eig_int + (size_t)runs * (1 + kEigMaxSweeps);
+  a.fast = eig_int + (size_t)runs * (2 + kEigMaxSweeps);
+  a.split_tail = 0;
+  a.P = P;
+  a.chunk = chunk;
   a.status = status;
   a.ctrs = ctrs;
   a.covs = covs;
@@ -1603,7 +1774,10 @@ int wide_single_launch(dh_ctx* ctx, int runs, const double* pts, int n, int d, i
   a.axes = axes;
   a.axlens = axlens;
   a.logvols = logvols;
-  static size_t attr_lds = 0, attr_eig = 0;
+  const int LD = d | 1;
+  const size_t lds_part = ((size_t)kTP * LD + d + 64 + (size_t)((d + 15) / 16) * 64) * 8;
+  const size_t lds_mean = (size_t)std::max(1, kRT / d) * d * 8;
+  static size_t attr_lds = 0, attr_eig = 0, attr_part = 0;
   if (lds > attr_lds) {
     if (!hip_ok(ctx,
                 hipFuncSetAttribute((const void*)wide_single_kernel,
@@ -1623,9 +1797,22 @@ int wide_single_launch(dh_ctx* ctx, int runs, const double* pts, int n, int d, i
         return DH_ERR_HIP;
       attr_eig = eig_lds;
     }
+    if (std::max(lds_part, lds_mean) > attr_part) {
+      const int want = (int)std::max(lds_part, lds_mean);
+      if (!hip_ok(ctx, hipFuncSetAttribute((const void*)wide_cov_part_kernel,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, want), "attr(cov part)") ||
+          !hip_ok(ctx, hipFuncSetAttribute((const void*)wide_fmax_part_kernel,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, want), "attr(fmax part)") ||
+          !hip_ok(ctx, hipFuncSetAttribute((const void*)wide_mean_part_kernel,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, want), "attr(mean part)"))
+        return DH_ERR_HIP;
+      attr_part = (size_t)want;
+    }
     if (!hip_ok(ctx, hipMemsetAsync(eig_int, 0, ints * runs, ctx->stream), "memset(eig counters)")) return DH_ERR_HIP;
-    a.phase = 1;
-    hipLaunchKernelGGL(wide_single_kernel, dim3(runs), dim3(kRT), lds, ctx->stream, a);
+    a.split_tail = 1;
+    hipLaunchKernelGGL(wide_mean_part_kernel, dim3(runs * P), dim3(kRT), lds_mean, ctx->stream, a);
+    hipLaunchKernelGGL(wide_cov_part_kernel, dim3(runs * P), dim3(kRT), lds_part, ctx->stream, a);
+    hipLaunchKernelGGL(wide_cov_reduce_kernel, dim3((d * d + 255) / 256, runs), dim3(256), 0, ctx->stream, a);
     WideEigArgs g;
     g.cov = a.wscov;
     g.lam = lam_pre;
@@ -1641,6 +1828,8 @@ int wide_single_launch(dh_ctx* ctx, int runs, const double* pts, int n, int d, i
     hipLaunchKernelGGL(wide_eig_kernel, dim3(runs * B), dim3(kRT), eig_lds, ctx->stream, g);
     a.phase = 2;
     hipLaunchKernelGGL(wide_single_kernel, dim3(runs), dim3(kRT), lds, ctx->stream, a);
+    hipLaunchKernelGGL(wide_fmax_part_kernel, dim3(runs * P), dim3(kRT), lds_part, ctx->stream, a);
+    hipLaunchKernelGGL(wide_finish_kernel, dim3(runs), dim3(kRT), 0, ctx->stream, a);
   }
   if (!hip_ok(ctx, hipGetLastError(), "wide rebuild launch")) return DH_ERR_HIP;
   // nells = 1 per run (status decides validity)
