@@ -358,6 +358,8 @@ class Context:
         sets = [_f64(p) for p in point_sets]
         B = len(sets)
         d = sets[0].shape[1]
+        if d > 44:  # wide-D path: one rebuild per set (the ragged batch is a narrow-D kernel)
+            return [self.rebuild(p, multi=multi) for p in sets]
         n_arr = np.array([len(p) for p in sets], dtype=np.int32)
         n_max = int(n_arr.max())
         pad = np.zeros((B, n_max, d))

@@ -126,11 +126,20 @@ int wide_walk_launch(dh_ctx* ctx, int kind, int problem, int k, int ndim, int nc
                      double* logl, int32_t* c0, int32_t* c1, int32_t* c2, int32_t* flags,
                      uint64_t* rng_out);
 int wide_eval_launch(dh_ctx* ctx, const ProblemDev& p, int k, const double* u, double* v, double* logl);
+// UniformBoundSampler inside a (multi-)ellipsoid at wide D; problem = -1: propose only (lock-step)
+int wide_unif_launch(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, int m, const double* ctrs,
+                     const double* axes, const double* ams, const double* cumprob, double loglstar,
+                     const int8_t* bc, const uint64_t* rng, int64_t max_tries, double* u, double* v, double* logl,
+                     int32_t* ncalls, int32_t* flags, uint64_t* rng_out);
 int wide_contains_launch(dh_ctx* ctx, const double* x, int k, int d, const double* ctrs, const double* ams,
                          int m, int mode, int32_t* count, uint64_t* mask, double* quad);
 int wide_single_launch(dh_ctx* ctx, int runs, const double* pts, int n, int d, int32_t* nells,
                        int32_t* status, double* ctrs, double* covs, double* ams, double* axes,
                        double* axlens, double* logvols);
+// MultiEllipsoid.update at wide D: host recursion over device node work (wide.hip)
+int wide_multi_launch(dh_ctx* ctx, int runs, const double* pts, int n, int d, int max_ells, int32_t* nells,
+                      int32_t* status, double* ctrs, double* covs, double* ams, double* axes, double* axlens,
+                      double* logvols, int32_t* leaf_of_point, int32_t* nnodes);
 
 }  // namespace dh
 

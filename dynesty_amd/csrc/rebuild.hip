@@ -1858,8 +1858,10 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
     if (mode == 1 && !active && !n_arr)
       return wide_single_launch(ctx, runs, pts, n, d, nells, status, ctrs, covs, ams, axes, axlens,
                                 logvols);
-    return fail(ctx, DH_ERR_ARG,
-                "rebuild: MultiEllipsoid.update for d=%d (> 44) is not built (Ellipsoid.update is)", d);
+    if (mode == 0 && !active && !n_arr)
+      return wide_multi_launch(ctx, runs, pts, n, d, max_ells, nells, status, ctrs, covs, ams, axes, axlens,
+                               logvols, leaf_of_point, nnodes);
+    return fail(ctx, DH_ERR_ARG, "rebuild: ragged / masked batches for d=%d (> 44) are not built", d);
   }
   RebuildArgs a;
   a.pts = pts;

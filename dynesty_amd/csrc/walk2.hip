@@ -934,7 +934,6 @@ int dh::unif_launch_runs(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, i
     a.prob.ndim = ndim;
     a.prob.like_id = 99;  // never evaluated
     a.prob.prior_id = 99;
-    if (ndim > kMaxRegDim) return fail(ctx, DH_ERR_ARG, "unif_propose: ndim=%d > %d not built", ndim, kMaxRegDim);
   } else {
     if (!get_problem(ctx, problem, &a.prob)) return DH_ERR_ARG;
     if (a.prob.ndim != ndim) return fail(ctx, DH_ERR_ARG, "problem ndim %d != %d", a.prob.ndim, ndim);
@@ -942,10 +941,10 @@ int dh::unif_launch_runs(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, i
   if (k <= 0) return DH_OK;
   if (m < 0 || ncdim < 1 || ncdim > ndim) return fail(ctx, DH_ERR_ARG, "unif: m=%d ncdim=%d", m, ncdim);
   if (ndim > kMaxRegDim) {
-    if (m != 0)
-      return fail(ctx, DH_ERR_ARG,
-                  "unif: uniform sampling inside an ellipsoid is not built for ndim=%d > %d", ndim,
-                  kMaxRegDim);
+    if (run_mode) return fail(ctx, DH_ERR_ARG, "ensemble unif: ndim=%d > %d not built", ndim, kMaxRegDim);
+    if (m != 0 || a.propose_only)
+      return wide_unif_launch(ctx, problem, k, ndim, ncdim, m, ctrs, axes, ams, cumprob, loglstar, bc, rng,
+                              max_tries, u, v, logl, ncalls, flags, rng_out);
     return wide_walk_launch(ctx, 3, problem, k, ndim, ndim, nullptr, nullptr, 1,
                             nullptr, 1.0, loglstar, 0, 0, bc, rng, u, v, logl, ncalls, nullptr, nullptr,
                             flags, rng_out);

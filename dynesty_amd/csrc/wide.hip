@@ -593,6 +593,151 @@ __global__ void __launch_bounds__(64 * kWalkMaxWaves) wide_walk_kernel(WideWalkA
   }
 }
 
+// ---- UniformBoundSampler.sample at wide D (internal_samplers.py:243-340) ----------------------
+// One wavefront per walker: rand_choice over the ellipsoids, randsphere (lane-parallel normals),
+// frame product, membership count q over all ellipsoids (strict, as MultiEllipsoid.within) with the
+// 1/q acceptance, unitcheck, uniforms for the non-clustered coordinates, prior + likelihood -- the
+// draw order of the narrow unif_kernel.  propose_only = the lock-step form (problem = -1).
+struct WideUnifArgs {
+  ProblemDev prob;
+  int k, ndim, ncdim, m, propose_only;
+  double loglstar;
+  const double* ctrs;     // m x nc
+  const double* axes_t;   // m x nc x nc transposed: AT[j*nc + i] = axes[i][j]
+  const double* ams;      // m x nc x nc (symmetric)
+  const double* cumprob;  // m
+  const int8_t* bc;
+  const uint64_t* rng_in;
+  int64_t max_tries;
+  double* u;
+  double* v;
+  double* logl;
+  int32_t* ncalls;
+  int32_t* flags;
+  uint64_t* rng_out;
+  const uint64_t* zki;
+  const uint64_t* zwi;
+  const uint64_t* zfi;
+};
+
+__global__ void __launch_bounds__(64) wide_unif_kernel(WideUnifArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ ZigLds zig;
+  zig_stage(&zig, a.zki, a.zwi, a.zfi);
+  const int lane = threadIdx.x, w = blockIdx.x, D = a.ndim, nc = a.ncdim;
+  double* sz = (double*)smem;  // nc: normals, then x - c
+  double* sx = sz + nc;        // D : candidate
+  double* sv = sx + D;         // D : v
+  Pcg64 g;
+  g.load(a.rng_in + (size_t)w * 4);
+  const PcgLanes PL = pcg_lanes_init(g, lane);
+  int ncall = 0, flags = 0;
+  double logl_cur = 0.0;
+  int64_t tries = 0;
+  for (;;) {
+    if (tries >= a.max_tries) {
+      flags |= 2;
+      break;
+    }
+    ++tries;
+    if (a.m == 0) {  // unit cube: rstate.uniform(size=ndim)
+      wave_doubles(g, PL, sx, D, lane);
+      lds_sync();
+      if (a.propose_only) break;
+      const double ll0 = wide_logl(a.prob, D, sx, sv, lane);
+      lds_sync();
+      ++ncall;
+      if (ll0 > a.loglstar) {
+        logl_cur = ll0;
+        break;
+      }
+      continue;
+    }
+    int idx = 0;
+    if (a.m > 1) {  // rand_choice (bounding.py:1300-1308)
+      const double xr = g.next_double();
+      while (idx < a.m - 1 && a.cumprob[idx] < xr) ++idx;
+    }
+    wave_normals(g, PL, &zig, sz, nc, lane);
+    lds_sync();
+    double ss = 0.0;
+    for (int i = 0; i < nc; ++i) ss = fma(sz[i], sz[i], ss);  // index order, as the narrow kernel
+    const double fac = pow(g.next_double(), 1.0 / (double)nc) / sqrt(ss);
+    const double* AT = a.axes_t + (size_t)idx * nc * nc;
+    const double* c = a.ctrs + (size_t)idx * nc;
+    for (int i = lane; i < nc; i += 64) {
+      double r = 0.0;
+      for (int j = 0; j < nc; ++j) r = fma(AT[(size_t)j * nc + i], sz[j], r);
+      sx[i] = fma(fac, r, c[i]);
+    }
+    lds_sync();
+    bool accept = true;
+    if (a.m > 1) {
+      int q = 0, qloose = 0;
+      for (int e = 0; e < a.m; ++e) {
+        const double* ce = a.ctrs + (size_t)e * nc;
+        const double* A = a.ams + (size_t)e * nc * nc;
+        for (int i = lane; i < nc; i += 64) sz[i] = sx[i] - ce[i];
+        lds_sync();
+        double part = 0.0;
+        for (int i = lane; i < nc; i += 64) {
+          double r = 0.0;
+          for (int j = 0; j < nc; ++j) r = fma(A[(size_t)j * nc + i], sz[j], r);
+          part = fma(sz[i], r, part);
+        }
+        const double quad = wave_sum(part);
+        lds_sync();
+        q += quad < 1.0 ? 1 : 0;
+        qloose += quad <= 1.0 + 1e-3 ? 1 : 0;
+      }
+      if (q == 0) {
+        q = qloose;
+        if (q == 0) {
+          flags |= 1;
+          break;
+        }
+      }
+      if (q > 1) accept = g.next_double() < (1.0 / (double)q);
+    }
+    if (!accept) continue;
+    bool inside = true;
+    for (int i = lane; i < nc; i += 64) {
+      const int b = a.bc ? a.bc[i] : 0;
+      const double x = sx[i];
+      if (b == DH_BC_HARD)
+        inside = inside && (x > 0.0) && (x < 1.0);
+      else
+        inside = inside && (x > -0.5) && (x < 1.5);
+    }
+    inside = __all(inside);
+    if (!inside) continue;
+    if (nc < D) {
+      wave_doubles(g, PL, sx + nc, D - nc, lane);
+      lds_sync();
+    }
+    if (a.propose_only) break;
+    const double ll = wide_logl(a.prob, D, sx, sv, lane);
+    lds_sync();
+    ++ncall;
+    if (ll > a.loglstar) {
+      logl_cur = ll;
+      break;
+    }
+  }
+  for (int i = lane; i < D; i += 64) {
+    a.u[(size_t)w * D + i] = sx[i];
+    if (!a.propose_only) a.v[(size_t)w * D + i] = sv[i];
+  }
+  if (lane == 0) {
+    if (!a.propose_only) {
+      a.logl[w] = logl_cur;
+      a.ncalls[w] = ncall;
+    }
+    a.flags[w] = flags;
+    if (a.rng_out) g.store(a.rng_out + (size_t)w * 4);
+  }
+}
+
 __global__ void __launch_bounds__(64)
     wide_eval_kernel(ProblemDev prob, int k, const double* __restrict__ u, double* v, double* logl) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1689,6 +1834,58 @@ int wide_walk_launch(dh_ctx* ctx, int kind, int problem, int k, int ndim, int nc
   return hip_ok(ctx, hipGetLastError(), "wide walk launch") ? DH_OK : DH_ERR_HIP;
 }
 
+int wide_unif_launch(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, int m, const double* ctrs,
+                     const double* axes, const double* ams, const double* cumprob, double loglstar,
+                     const int8_t* bc, const uint64_t* rng, int64_t max_tries, double* u, double* v, double* logl,
+                     int32_t* ncalls, int32_t* flags, uint64_t* rng_out) {
+  WideUnifArgs a;
+  a.propose_only = problem == -1 ? 1 : 0;
+  if (a.propose_only) {
+    a.prob = ProblemDev();
+    a.prob.ndim = ndim;
+  } else if (!get_problem(ctx, problem, &a.prob)) {
+    return DH_ERR_ARG;
+  }
+  if (ndim > kWideMaxD) return fail(ctx, DH_ERR_ARG, "ndim=%d exceeds the wide-D limit %d", ndim, kWideMaxD);
+  if (m < 0 || (m > 0 && (!ctrs || !axes)) || (m > 1 && (!ams || !cumprob)))
+    return fail(ctx, DH_ERR_ARG, "unif (wide): m=%d needs centres, axes and (m > 1) precision matrices", m);
+  const size_t tot = (size_t)m * ncdim * ncdim;
+  if (tot * 8 > ctx->axes_t_cap) {
+    if (!hip_ok(ctx, hipStreamSynchronize(ctx->stream), "sync")) return DH_ERR_HIP;
+    if (ctx->axes_t) (void)hipFree(ctx->axes_t);
+    ctx->axes_t = nullptr;
+    ctx->axes_t_cap = 0;
+    if (!hip_ok(ctx, hipMalloc((void**)&ctx->axes_t, tot * 16), "hipMalloc(axes_t)")) return DH_ERR_NOMEM;
+    ctx->axes_t_cap = tot * 16;
+  }
+  if (tot)
+    hipLaunchKernelGGL(wide_transpose_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, axes,
+                       m, ncdim, ctx->axes_t);
+  a.k = k;
+  a.ndim = ndim;
+  a.ncdim = ncdim;
+  a.m = m;
+  a.loglstar = loglstar;
+  a.ctrs = ctrs;
+  a.axes_t = ctx->axes_t;
+  a.ams = ams;
+  a.cumprob = cumprob;
+  a.bc = bc;
+  a.rng_in = rng;
+  a.max_tries = max_tries > 0 ? max_tries : ((int64_t)1 << 40);
+  a.u = u;
+  a.v = v;
+  a.logl = logl;
+  a.ncalls = ncalls;
+  a.flags = flags;
+  a.rng_out = rng_out;
+  a.zki = ctx->zki();
+  a.zwi = ctx->zwi();
+  a.zfi = ctx->zfi();
+  hipLaunchKernelGGL(wide_unif_kernel, dim3(k), dim3(64), (size_t)(ncdim + 2 * ndim) * 8, ctx->stream, a);
+  return hip_ok(ctx, hipGetLastError(), "wide unif launch") ? DH_OK : DH_ERR_HIP;
+}
+
 int wide_eval_launch(dh_ctx* ctx, const ProblemDev& p, int k, const double* u, double* v, double* logl) {
   if (p.ndim > kWideMaxD) return fail(ctx, DH_ERR_ARG, "ndim=%d exceeds the wide-D limit %d", p.ndim, kWideMaxD);
   hipLaunchKernelGGL(wide_eval_kernel, dim3(k), dim3(64), (size_t)2 * p.ndim * 8, ctx->stream, p, k, u, v,
@@ -1708,9 +1905,9 @@ int wide_contains_launch(dh_ctx* ctx, const double* x, int k, int d, const doubl
   return hip_ok(ctx, hipGetLastError(), "wide contains launch") ? DH_OK : DH_ERR_HIP;
 }
 
-int wide_single_launch(dh_ctx* ctx, int runs, const double* pts, int n, int d, int32_t* nells,
-                       int32_t* status, double* ctrs, double* covs, double* ams, double* axes,
-                       double* axlens, double* logvols) {
+static int wide_single_enqueue(dh_ctx* ctx, int runs, const double* pts, int n, int d, int32_t* status,
+                               double* ctrs, double* covs, double* ams, double* axes, double* axlens,
+                               double* logvols) {
   if (d > kWideMaxD) return fail(ctx, DH_ERR_ARG, "rebuild: d=%d exceeds the wide-D limit %d", d, kWideMaxD);
   const size_t lds = wide_single_lds(d);
   if (lds > 159 * 1024) return fail(ctx, DH_ERR_ARG, "rebuild: d=%d needs %zu B of LDS", d, lds);
@@ -1831,13 +2028,386 @@ int wide_single_launch(dh_ctx* ctx, int runs, const double* pts, int n, int d, i
     hipLaunchKernelGGL(wide_fmax_part_kernel, dim3(runs * P), dim3(kRT), lds_part, ctx->stream, a);
     hipLaunchKernelGGL(wide_finish_kernel, dim3(runs), dim3(kRT), 0, ctx->stream, a);
   }
-  if (!hip_ok(ctx, hipGetLastError(), "wide rebuild launch")) return DH_ERR_HIP;
+  return hip_ok(ctx, hipGetLastError(), "wide rebuild launch") ? DH_OK : DH_ERR_HIP;
+}
+
+int wide_single_launch(dh_ctx* ctx, int runs, const double* pts, int n, int d, int32_t* nells,
+                       int32_t* status, double* ctrs, double* covs, double* ams, double* axes,
+                       double* axlens, double* logvols) {
+  const int rc0 = wide_single_enqueue(ctx, runs, pts, n, d, status, ctrs, covs, ams, axes, axlens, logvols);
+  if (rc0) return rc0;
   // nells = 1 per run (status decides validity)
   std::vector<int32_t> ones((size_t)runs, 1);
   if (!hip_ok(ctx, hipMemcpyAsync(nells, ones.data(), (size_t)runs * 4, hipMemcpyHostToDevice, ctx->stream),
               "H2D nells"))
     return DH_ERR_HIP;
   return hip_ok(ctx, hipStreamSynchronize(ctx->stream), "sync") ? DH_OK : DH_ERR_HIP;
+}
+
+
+// ---------------------------------------------------------------------------
+// MultiEllipsoid.update at wide D (bounding.py:632-686, 1464-1563).  Nodes are big here (a split
+// needs 2 x 2D points per side), so the tree has a handful of nodes: the recursion runs on the host
+// exactly as the reference writes it, every node's work on the device -- the ellipsoid of a point
+// subset is the multi-workgroup rebuild above on a gathered copy, k-means is one workgroup.
+
+// points.std(axis=0) (ddof = 0): one thread per dimension, two passes in point order
+__global__ void wide_std_kernel(const double* __restrict__ pts, int n, int D, double* __restrict__ scale) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= D) return;
+  double m = 0.0;
+  for (int p = 0; p < n; ++p) m += pts[(size_t)p * D + j];
+  m /= (double)n;
+  double v = 0.0;
+  for (int p = 0; p < n; ++p) {
+    const double e = pts[(size_t)p * D + j] - m;
+    v = fma(e, e, v);
+  }
+  scale[j] = sqrt(v / (double)n);
+}
+
+__global__ void wide_gather_kernel(const double* __restrict__ pts, const int32_t* __restrict__ idx, int cnt, int D,
+                                   double* __restrict__ out) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (size_t)cnt * D) return;
+  const int p = (int)(e / D), j = (int)(e - (size_t)p * D);
+  out[e] = pts[(size_t)idx[p] * D + j];
+}
+
+// scipy.cluster.vq.kmeans2(points / scale, k = seeds / scale, iter = 10, minit = 'matrix') with the
+// major-axis endpoints of the node's ellipsoid as seeds (bounding.py:1500-1514): vq = nearest
+// centroid (distance summed in dimension order, strict '<': the lower index wins ties), then
+// update_cluster_means = per-cluster sums IN POINT ORDER / counts, an empty cluster keeping its
+// centroid.  The labels returned are those of the last vq.  One workgroup.
+__global__ void __launch_bounds__(kRT) wide_kmeans_kernel(const double* __restrict__ pts, int cnt, int D,
+                                                         const double* __restrict__ scale,
+                                                         const double* __restrict__ ctr,
+                                                         const double* __restrict__ axes,
+                                                         const double* __restrict__ axlens, int32_t* labels,
+                                                         int32_t* n0_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  double* cen = (double*)smem;  // 2 x D
+  double* isc = cen + 2 * D;    // D : the scale
+  __shared__ int s_best, s_cnt[kRT / 64];
+  const int t = threadIdx.x;
+  if (t == 0) {
+    int best = 0;
+    double bl = axlens[0];
+    for (int k = 1; k < D; ++k)
+      if (axlens[k] > bl) {
+        bl = axlens[k];
+        best = k;
+      }
+    s_best = best;
+  }
+  for (int j = t; j < D; j += kRT) isc[j] = scale[j];
+  __syncthreads();
+  for (int j = t; j < D; j += kRT) {
+    const double v = axes[(size_t)j * D + s_best];
+    cen[j] = (ctr[j] - v) / isc[j];
+    cen[D + j] = (ctr[j] + v) / isc[j];
+  }
+  __syncthreads();
+  int n0 = 0;
+  for (int it = 0; it < 10; ++it) {
+    int mine0 = 0;
+    for (int p = t; p < cnt; p += kRT) {
+      const double* x = pts + (size_t)p * D;
+      double d0 = 0.0, d1 = 0.0;
+      for (int j = 0; j < D; ++j) {
+        const double xv = x[j] / isc[j];
+        const double e0 = xv - cen[j], e1 = xv - cen[D + j];
+        d0 = fma(e0, e0, d0);
+        d1 = fma(e1, e1, d1);
+      }
+      const int lb = d1 < d0 ? 1 : 0;
+      labels[p] = lb;
+      mine0 += lb == 0;
+    }
+    // count of label 0
+    for (int o = 32; o > 0; o >>= 1) mine0 += __shfl_xor(mine0, o);
+    if ((t & 63) == 0) s_cnt[t >> 6] = mine0;
+    __threadfence_block();
+    __syncthreads();
+    n0 = 0;
+    for (int w = 0; w < kRT / 64; ++w) n0 += s_cnt[w];
+    const int n1 = cnt - n0;
+    // cluster sums in point order: thread (c, j)
+    double sum = 0.0;
+    const int c = t >= D ? 1 : 0, j = t - c * D;
+    if (t < 2 * D) {
+      const double sc = isc[j];
+      for (int p0 = 0; p0 < cnt; p0 += 8) {
+        int lb[8];
+        double xv[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int p = p0 + q;
+          lb[q] = p < cnt ? labels[p] : -1;
+          xv[q] = p < cnt ? pts[(size_t)p * D + j] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+          if (lb[q] == c) sum += xv[q] / sc;
+      }
+    }
+    __syncthreads();
+    if (t < 2 * D) {
+      const int nc = c == 0 ? n0 : n1;
+      if (nc > 0) cen[c * D + j] = sum / (double)nc;
+    }
+    __syncthreads();
+  }
+  if (t == 0) *n0_out = n0;
+}
+
+namespace {
+
+struct WideSlots {  // device arrays of node ellipsoids
+  double *ctrs, *covs, *ams, *axes, *axlens, *logvols;
+  int32_t* status;
+  int cap, used;
+};
+
+struct WideTree {
+  dh_ctx* ctx;
+  const double* pts;  // all points of the run (device)
+  int n, d;
+  const double* scale;  // device, d
+  WideSlots sl;
+  int32_t* d_labels;  // n
+  int32_t* d_n0;
+  int32_t* d_idx;     // n
+  std::vector<double> logvol;  // host copy per slot
+  int nnodes = 0;
+  int err = DH_OK;
+};
+
+// bounding ellipsoid of `cnt` contiguous points -> a fresh slot; returns the slot or -1
+int wide_node_ell(WideTree& T, const double* p, int cnt) {
+  WideSlots& S = T.sl;
+  if (S.used >= S.cap) {
+    T.err = DH_ERR_NOMEM;
+    return -1;
+  }
+  const int s = S.used++;
+  const size_t d = T.d, dd = d * d;
+  int rc = wide_single_enqueue(T.ctx, 1, p, cnt, T.d, S.status + s, S.ctrs + s * d, S.covs + s * dd, S.ams + s * dd,
+                               S.axes + s * dd, S.axlens + s * d, S.logvols + s);
+  if (rc) {
+    T.err = rc;
+    return -1;
+  }
+  int32_t st = DH_OK;
+  double lv = 0.0;
+  if (!hip_ok(T.ctx, hipMemcpyAsync(&st, S.status + s, 4, hipMemcpyDeviceToHost, T.ctx->stream), "D2H status") ||
+      !hip_ok(T.ctx, hipMemcpyAsync(&lv, S.logvols + s, 8, hipMemcpyDeviceToHost, T.ctx->stream), "D2H logvol") ||
+      !hip_ok(T.ctx, hipStreamSynchronize(T.ctx->stream), "sync")) {
+    T.err = DH_ERR_HIP;
+    return -1;
+  }
+  if (st != DH_OK) {
+    T.err = st;
+    return -1;
+  }
+  if ((int)T.logvol.size() <= s) T.logvol.resize(s + 1);
+  T.logvol[s] = lv;
+  return s;
+}
+
+double host_logaddexp(double x, double y) {
+  if (x == y) return x + 0.6931471805599453;
+  const double dlt = x - y;
+  if (dlt > 0) return x + log1p(exp(-dlt));
+  if (dlt <= 0) return y + log1p(exp(dlt));
+  return x + y;
+}
+
+// _bounding_ellipsoids (bounding.py:1464-1563): node = global indices `idx`, its points gathered in
+// `p` (device), its ellipsoid in slot `s`.  Appends the leaves (slot, indices) in list order.
+void wide_split(WideTree& T, const std::vector<int32_t>& idx, const double* p, int s,
+                std::vector<std::pair<int, std::vector<int32_t>>>& out) {
+  ++T.nnodes;
+  const int cnt = (int)idx.size(), d = T.d, min_size = 2 * d;
+  if (T.err || cnt < 2 * min_size) {
+    out.emplace_back(s, idx);
+    return;
+  }
+  const size_t dd = (size_t)d * d;
+  hipLaunchKernelGGL(wide_kmeans_kernel, dim3(1), dim3(kRT), (size_t)3 * d * 8, T.ctx->stream, p, cnt, d, T.scale,
+                     T.sl.ctrs + (size_t)s * d, T.sl.axes + (size_t)s * dd, T.sl.axlens + (size_t)s * d, T.d_labels,
+                     T.d_n0);
+  std::vector<int32_t> lab((size_t)cnt);
+  if (!hip_ok(T.ctx, hipGetLastError(), "wide kmeans launch") ||
+      !hip_ok(T.ctx, hipMemcpyAsync(lab.data(), T.d_labels, (size_t)cnt * 4, hipMemcpyDeviceToHost, T.ctx->stream),
+              "D2H labels") ||
+      !hip_ok(T.ctx, hipStreamSynchronize(T.ctx->stream), "sync")) {
+    T.err = DH_ERR_HIP;
+    return;
+  }
+  std::vector<int32_t> kid[2];
+  for (int i = 0; i < cnt; ++i) kid[lab[i] ? 1 : 0].push_back(idx[i]);
+  if ((int)std::min(kid[0].size(), kid[1].size()) < min_size) {
+    out.emplace_back(s, idx);
+    return;
+  }
+  double* buf[2] = {nullptr, nullptr};
+  int ks[2] = {-1, -1};
+  for (int c = 0; c < 2 && !T.err; ++c) {
+    const size_t m = kid[c].size();
+    if (!hip_ok(T.ctx, hipMalloc((void**)&buf[c], m * d * 8), "hipMalloc(child points)")) {
+      T.err = DH_ERR_NOMEM;
+      break;
+    }
+    if (!hip_ok(T.ctx, hipMemcpyAsync(T.d_idx, kid[c].data(), m * 4, hipMemcpyHostToDevice, T.ctx->stream),
+                "H2D child indices")) {
+      T.err = DH_ERR_HIP;
+      break;
+    }
+    const size_t tot = m * d;
+    hipLaunchKernelGGL(wide_gather_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, T.ctx->stream, T.pts,
+                       T.d_idx, (int)m, d, buf[c]);
+    // (the index staging buffer is reused by the sibling: finish this gather first)
+    if (!hip_ok(T.ctx, hipStreamSynchronize(T.ctx->stream), "sync")) {
+      T.err = DH_ERR_HIP;
+      break;
+    }
+    ks[c] = wide_node_ell(T, buf[c], (int)m);
+  }
+  if (!T.err) {
+    const int nparam = (d * (d + 3)) / 2;
+    const double dec = nparam * log((double)cnt) / (double)cnt;
+    std::vector<std::pair<int, std::vector<int32_t>>> sub;
+    wide_split(T, kid[0], buf[0], ks[0], sub);
+    wide_split(T, kid[1], buf[1], ks[1], sub);
+    if (!T.err) {
+      bool accept = (host_logaddexp(T.logvol[ks[0]], T.logvol[ks[1]]) - T.logvol[s]) < -dec;
+      if (!accept) {
+        // scipy.special.logsumexp over the leaves
+        double mx = -INFINITY;
+        for (auto& e : sub) mx = std::max(mx, T.logvol[e.first]);
+        double acc = 0.0;
+        for (auto& e : sub) acc += exp(T.logvol[e.first] - mx);
+        accept = (log(acc) + mx - T.logvol[s]) < -dec * ((double)sub.size() - 1.0);
+      }
+      if (accept)
+        for (auto& e : sub) out.push_back(std::move(e));
+      else
+        out.emplace_back(s, idx);
+    }
+  }
+  for (int c = 0; c < 2; ++c)
+    if (buf[c]) (void)hipFree(buf[c]);
+}
+
+}  // namespace
+
+int wide_multi_launch(dh_ctx* ctx, int runs, const double* pts, int n, int d, int max_ells, int32_t* nells,
+                      int32_t* status, double* ctrs, double* covs, double* ams, double* axes, double* axlens,
+                      double* logvols, int32_t* leaf_of_point, int32_t* nnodes) {
+  if (d > kWideMaxD) return fail(ctx, DH_ERR_ARG, "rebuild: d=%d exceeds the wide-D limit %d", d, kWideMaxD);
+  const size_t dd = (size_t)d * d;
+  const int cap = std::max(3, n / d + 3);  // every split makes two children of >= 2d points
+  char* pool = nullptr;
+  const size_t per = (3 * dd + 2 * (size_t)d + 1) * 8 + 4;
+  const size_t bytes = per * cap + (size_t)d * 8 + (size_t)n * 8 + 64 + 4096;
+  if (!hip_ok(ctx, hipMalloc((void**)&pool, bytes), "hipMalloc(wide multi scratch)")) return DH_ERR_NOMEM;
+  int rc = DH_OK;
+  for (int run = 0; run < runs && rc == DH_OK; ++run) {
+    WideTree T;
+    T.ctx = ctx;
+    T.pts = pts + (size_t)run * n * d;
+    T.n = n;
+    T.d = d;
+    double* w = (double*)pool;
+    T.sl.ctrs = w;
+    w += (size_t)cap * d;
+    T.sl.covs = w;
+    w += (size_t)cap * dd;
+    T.sl.ams = w;
+    w += (size_t)cap * dd;
+    T.sl.axes = w;
+    w += (size_t)cap * dd;
+    T.sl.axlens = w;
+    w += (size_t)cap * d;
+    T.sl.logvols = w;
+    w += cap;
+    double* d_scale = w;
+    w += d;
+    T.scale = d_scale;
+    T.sl.status = (int32_t*)w;
+    T.d_labels = T.sl.status + cap;
+    T.d_idx = T.d_labels + n;
+    T.d_n0 = T.d_idx + n;
+    T.sl.cap = cap;
+    T.sl.used = 0;
+    int32_t st = DH_OK, m = 0;
+    std::vector<std::pair<int, std::vector<int32_t>>> leaves;
+    if (n <= 1) {
+      st = DH_ERR_VALUE;
+    } else {
+      const int root = wide_node_ell(T, T.pts, n);
+      if (root >= 0) {
+        hipLaunchKernelGGL(wide_std_kernel, dim3((d + 63) / 64), dim3(64), 0, ctx->stream, T.pts, n, d, d_scale);
+        std::vector<int32_t> all((size_t)n);
+        for (int i = 0; i < n; ++i) all[i] = i;
+        wide_split(T, all, T.pts, root, leaves);
+      }
+      st = T.err;
+      if (st == DH_ERR_HIP || st == DH_ERR_ARG) {
+        rc = st;
+        break;
+      }
+    }
+    if (st == DH_OK && (int)leaves.size() > max_ells) st = DH_ERR_NOMEM;
+    if (st == DH_OK) {
+      m = (int)leaves.size();
+      std::vector<int32_t> lop((size_t)n, 0);
+      for (int e = 0; e < m; ++e) {
+        const size_t s = (size_t)leaves[e].first, o = (size_t)run * max_ells + e;
+        bool ok = hip_ok(ctx, hipMemcpyAsync(ctrs + o * d, T.sl.ctrs + s * d, (size_t)d * 8, hipMemcpyDeviceToDevice, ctx->stream), "D2D") &&
+                  hip_ok(ctx, hipMemcpyAsync(covs + o * dd, T.sl.covs + s * dd, dd * 8, hipMemcpyDeviceToDevice, ctx->stream), "D2D") &&
+                  hip_ok(ctx, hipMemcpyAsync(ams + o * dd, T.sl.ams + s * dd, dd * 8, hipMemcpyDeviceToDevice, ctx->stream), "D2D") &&
+                  hip_ok(ctx, hipMemcpyAsync(axes + o * dd, T.sl.axes + s * dd, dd * 8, hipMemcpyDeviceToDevice, ctx->stream), "D2D") &&
+                  hip_ok(ctx, hipMemcpyAsync(axlens + o * d, T.sl.axlens + s * d, (size_t)d * 8, hipMemcpyDeviceToDevice, ctx->stream), "D2D") &&
+                  hip_ok(ctx, hipMemcpyAsync(logvols + o, T.sl.logvols + s, 8, hipMemcpyDeviceToDevice, ctx->stream), "D2D");
+        if (!ok) {
+          rc = DH_ERR_HIP;
+          break;
+        }
+        for (int32_t i : leaves[e].second) lop[(size_t)i] = e;
+      }
+      if (rc) break;
+      // every point inside some ellipsoid (bounding.py:683-685)
+      int32_t* d_count = T.d_labels;
+      rc = wide_contains_launch(ctx, T.pts, n, d, ctrs + (size_t)run * max_ells * d, ams + (size_t)run * max_ells * dd, m,
+                                0, d_count, nullptr, nullptr);
+      if (rc) break;
+      std::vector<int32_t> cntv((size_t)n);
+      if (!hip_ok(ctx, hipMemcpyAsync(cntv.data(), d_count, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream), "D2H") ||
+          !hip_ok(ctx, hipStreamSynchronize(ctx->stream), "sync")) {
+        rc = DH_ERR_HIP;
+        break;
+      }
+      for (int i = 0; i < n; ++i)
+        if (cntv[i] < 1) st = DH_ERR_REGION;
+      if (leaf_of_point &&
+          !hip_ok(ctx, hipMemcpyAsync(leaf_of_point + (size_t)run * n, lop.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream), "H2D")) {
+        rc = DH_ERR_HIP;
+        break;
+      }
+    }
+    const int32_t nn = T.nnodes;
+    if (!hip_ok(ctx, hipMemcpyAsync(nells + run, &m, 4, hipMemcpyHostToDevice, ctx->stream), "H2D") ||
+        !hip_ok(ctx, hipMemcpyAsync(status + run, &st, 4, hipMemcpyHostToDevice, ctx->stream), "H2D") ||
+        (nnodes && !hip_ok(ctx, hipMemcpyAsync(nnodes + run, &nn, 4, hipMemcpyHostToDevice, ctx->stream), "H2D")) ||
+        !hip_ok(ctx, hipStreamSynchronize(ctx->stream), "sync")) {
+      rc = DH_ERR_HIP;
+      break;
+    }
+  }
+  (void)hipFree(pool);
+  return rc;
 }
 
 }  // namespace dh
