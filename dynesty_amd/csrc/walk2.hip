@@ -978,7 +978,7 @@ int dh::unif_launch_runs(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, i
   a.rng32_out = nullptr;
   a.bc = bc;
   a.rng_in = rng;
-  a.max_tries = max_tries > 0 ? max_tries : ((int64_t)1 << 40);
+  a.max_tries = max_tries > 0 ? max_tries : ((int64_t)1 << 32);
   a.u = u;
   a.v = v;
   a.logl = logl;
@@ -1111,7 +1111,7 @@ int dh_unif_friends_batch(dh_ctx* ctx, int problem, int k, int ndim, int kind, c
   a.rng32_out = d_r32o;
   a.bc = d_bc;
   a.rng_in = d_rng;
-  a.max_tries = max_tries > 0 ? max_tries : ((int64_t)1 << 40);
+  a.max_tries = max_tries > 0 ? max_tries : ((int64_t)1 << 32);
   a.u = d_u;
   a.v = d_v;
   a.logl = d_l;

@@ -1872,7 +1872,7 @@ int wide_unif_launch(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, int m
   a.cumprob = cumprob;
   a.bc = bc;
   a.rng_in = rng;
-  a.max_tries = max_tries > 0 ? max_tries : ((int64_t)1 << 40);
+  a.max_tries = max_tries > 0 ? max_tries : ((int64_t)1 << 32);
   a.u = u;
   a.v = v;
   a.logl = logl;

@@ -250,7 +250,7 @@ int dh_slice_batch_dev(dh_ctx* ctx, int problem, int k, int ndim, int mode,
  * m == 0 UnitCubeSampler.sample (internal_samplers.py:364-441).
  *   ctrs m*ncdim, axes/ams m*ncdim*ncdim, cumprob m = cumsum(exp(logvol_ells -
  *   logvol)) (rand_choice, bounding.py:1300-1308); bc: DH_BC_* per dim or NULL
- *   max_tries: per-walker guard (<= 0: 2^40); ncalls = likelihood calls. */
+ *   max_tries: per-walker guard (<= 0: 2^32 tries, then DH_ERR with "exceeded max_tries"); ncalls = likelihood calls. */
 int dh_unif_batch(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, int m,
                   const double* ctrs, const double* axes, const double* ams,
                   const double* cumprob, double loglstar, const int8_t* bc,
