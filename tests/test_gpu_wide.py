@@ -237,3 +237,42 @@ def test_unif_wide_vs_oracle(ctx, case):
         up2, out2 = OracleBackend().unif_propose(d, st, **pk)
         np.testing.assert_array_equal(out, out2)
         np.testing.assert_allclose(up, up2, rtol=1e-10, atol=1e-13)
+
+
+@pytest.mark.parametrize("which", ["rslice", "slice", "rwalk", "rwalk_nc"])
+def test_wide_walkers_on_different_frames(ctx, which):
+    """Walkers of one workgroup on DIFFERENT proposal frames (multi-ellipsoid bound: axes_idx) take
+    the per-wavefront form of the frame product instead of the workgroup GEMM; principal-axes
+    slice sampling and ncdim < ndim at wide D.  Against the oracle, walker by walker."""
+    from oracle_backend import OracleBackend
+    from dynesty_amd import problems
+    d = 50
+    prob = problems.gauss_normal_prior(d, "C4")
+    rng = np.random.default_rng(10)
+    k = 7
+    u0 = np.clip(0.5 + 0.06 * rng.standard_normal((k, d)), 0.02, 0.98)
+    loglstar = float(prob.loglikelihood_many(prob.prior_transform_many(u0)).min() - 6.0)
+    nc = 44 if which == "rwalk_nc" else d
+    frames = []
+    for s in (0.05, 0.08):
+        q, _ = np.linalg.qr(rng.standard_normal((nc, nc)))
+        frames.append(q * (s * np.sqrt(nc) * rng.uniform(0.8, 1.3, size=nc)))
+    frames = np.array(frames)
+    idx = np.array([0, 1, 1, 0, 1, 0, 0], dtype=np.int32)
+    st = ctx.seed_children([77, 1], 0, k)
+    ob = OracleBackend()
+    if which in ("rslice", "slice"):
+        kw = dict(principal=(which == "slice"), axes_idx=idx)
+        nsl = 2 if which == "rslice" else 1
+        got = ctx.slice_batch(prob, u0, frames, 0.9, loglstar, nsl, st, **kw)
+        ref = ob.slice_batch(prob, u0, frames, 0.9, loglstar, nsl, st, **kw)
+        for key in ("ncalls", "n_expand", "n_contract"):
+            np.testing.assert_array_equal(got[key], ref[key])
+    else:
+        kw = dict(axes_idx=idx, ncdim=nc)
+        got = ctx.rwalk_batch(prob, u0, frames, 0.7, loglstar, 20, st, **kw)
+        ref = ob.rwalk_batch(prob, u0, frames, 0.7, loglstar, 20, st, **kw)
+        np.testing.assert_array_equal(got["accept"], ref["accept"])
+    np.testing.assert_array_equal(got["rng_out"], ref["rng_out"])
+    np.testing.assert_allclose(got["u"], ref["u"], rtol=0, atol=1e-11)
+    np.testing.assert_allclose(got["logl"], ref["logl"], rtol=1e-10)
