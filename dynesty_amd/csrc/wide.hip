@@ -816,8 +816,8 @@ struct WideRebuildArgs {
   double* wscov; // runs x d x d   working covariance
   int dbg;       // DH_WIDE_PROF=1: thread 0 of run 0 prints the cycle count of every phase
   double* wsW;   // runs x 4 x P x P  double-buffered Jacobi work (P = d rounded up to even)
-  int phase;     // 0: whole rebuild in one launch; 1: mean + covariance only; 2: the rest, taking the
-                 // eigen-decomposition of the covariance from wide_eig_kernel when eig_ok says so
+  int phase;     // 0: whole rebuild in one launch; 2: everything after the covariance (centre in ctrs,
+                 // covariance in wscov), taking its eigen-decomposition from wide_eig_kernel when eig_ok says so
   const double* lam_pre;  // runs x d   eigenvalues from wide_eig_kernel (vectors are in wsV)
   const int* eig_ok;      // runs
   // phase 2 with split_tail: stop before the Mahalanobis maximum (wide_fmax_part_kernel /
@@ -1384,7 +1384,7 @@ __global__ void __launch_bounds__(kRT) wide_single_kernel(WideRebuildArgs a) {
   double* o_ax = a.axes + (size_t)run * D * D;
   int status = DH_OK;
   if (n <= 1) status = DH_ERR_VALUE;
-  if (a.phase == 2 && a.status[run] != DH_OK) return;  // phase 1 already said why
+  if (a.phase == 2 && a.status[run] != DH_OK) return;  // the covariance kernels already said why
   long long tp_ = clock64();
 #define WPH(name)                                                                   \
   do {                                                                              \
@@ -1422,13 +1422,6 @@ __global__ void __launch_bounds__(kRT) wide_single_kernel(WideRebuildArgs a) {
     WPH("mean");
     wide_cov_range(pts, D, 0, n, mean, tile, cov, 1.0 / (double)(n - 1), true);
     WPH("cov");
-  }
-  if (a.phase == 1) {
-    // the eigen-decomposition runs on several workgroups (wide_eig_kernel); phase 2 picks up here
-    if (status == DH_OK)
-      for (int k = t; k < D; k += kRT) a.ctrs[(size_t)run * D + k] = mean[k];
-    if (t == 0) a.status[run] = status;
-    return;
   }
   if (status == DH_OK) {
     // ---- improve_covar_mat + fmax passes (bounding.py:1311-1384, 1423-1457) ----

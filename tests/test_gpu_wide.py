@@ -42,8 +42,14 @@ def test_eval_and_contains_200d(ctx):
     np.testing.assert_array_equal(bits, (want < 1).T)
 
 
-def test_single_rebuild_200d(ctx):
-    """Ellipsoid.update on the C4-shaped live set (4000 x 200)."""
+@pytest.mark.parametrize("split", [True, False])
+def test_single_rebuild_200d(ctx, split, monkeypatch):
+    """Ellipsoid.update on the C4-shaped live set (4000 x 200): the multi-workgroup sequence
+    (partial covariances, one-sided block Jacobi, partial Mahalanobis maxima) and the single-launch
+    form with the two-sided solver (DH_WIDE_EIG=0; also the fallback when the eigensolver's
+    workgroups cannot all be resident)."""
+    if not split:
+        monkeypatch.setenv("DH_WIDE_EIG", "0")
     pts = inputs.cloud("g200")
     got = ctx.rebuild(pts, multi=False)
     ref = B.bounding_ellipsoid(pts)
