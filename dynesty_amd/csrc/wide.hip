@@ -1,16 +1,18 @@
 // Wide-D path (D up to 512): BASELINE config C4 is 200-D, where neither a
 // walker (3 x 200 doubles) nor a D x D matrix (320 KB) fits a lane's registers
-// or one CU's LDS.  Mapping changes accordingly:
-//   * proposals: one WAVEFRONT per walker, lanes stride over the dimensions;
-//     the proposal frame is read transposed from L2 (coalesced along outputs),
-//     reductions are wave shuffles; the walker's PCG64 stream is advanced by
-//     all lanes redundantly (it is inherently sequential) and every lane keeps
-//     the normals of its own dimensions.
-//   * single-ellipsoid rebuild (Ellipsoid.update): one 1024-thread workgroup
-//     per run; covariance accumulated from 64-point LDS tiles with ~20 entries
-//     per thread in registers; the eigenproblem is a parallel-order Jacobi on
-//     matrices kept in global memory (L2 resident); the Mahalanobis maximum
-//     streams the precision matrix through the scalar cache (lane = point).
+// or one CU's LDS.  Mapping changes accordingly (DESIGN.md section 3.5):
+//   * proposals: one WAVEFRONT per walker, lanes stride over the dimensions,
+//     reductions are DPP wave reductions; the walker's PCG64 stream is drawn
+//     lane-parallel (rng_pcg64.h: wave_normals / wave_doubles); the frame
+//     products of the walkers of a workgroup are one GEMM on the matrix cores
+//     (wg_frame_gemm); uniform sampling inside ellipsoids: wide_unif_kernel.
+//   * Ellipsoid.update: partial sums / Gram matrices / Mahalanobis maxima over
+//     up to 32 workgroups per run, the eigen-decomposition by one-sided block
+//     Jacobi over several workgroups (wide_eig_kernel), the sequential rest on
+//     one 1024-thread workgroup; a single-launch form with a two-sided Jacobi
+//     on L2-resident matrices remains as the fallback (wide_single_kernel).
+//   * MultiEllipsoid.update: the recursion of _bounding_ellipsoids on the host,
+//     every node's work on the device (wide_multi_launch).
 //   * membership: one workgroup per candidate point.
 // Semantics and citations are those of the register-resident kernels
 // (walk.hip / walk2.hip / rebuild.hip / bound.hip).
@@ -164,23 +166,6 @@ struct WideWalkArgs {
 __device__ __forceinline__ void lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
   __builtin_amdgcn_wave_barrier();
-}
-
-// out[i] = sum_j AT[j*D + i] * x[j]   for i = lane, lane+64, ... ; x in LDS.
-// acc registers: up to 8 outputs per lane (D <= 512).
-__device__ __forceinline__ void wide_matvec(const double* __restrict__ AT, const double* x, int D,
-                                            int nj, int lane, double (&acc)[8]) {
-#pragma unroll
-  for (int r = 0; r < 8; ++r) acc[r] = 0.0;
-  for (int j = 0; j < nj; ++j) {
-    const double xj = x[j];
-    const double* row = AT + (size_t)j * D;
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      const int i = lane + 64 * r;
-      if (i < D) acc[r] = fma(row[i], xj, acc[r]);
-    }
-  }
 }
 
 // The proposal frame applied to the vectors of ALL walkers of the workgroup at once:
