@@ -30,7 +30,7 @@ namespace {
 
 constexpr int kWideMaxD = 512;
 constexpr int kRT = 1024;  // threads of the wide rebuild workgroup
-constexpr int kTP = 64;    // points per LDS tile
+constexpr int kTPMax = 64;  // points per LDS tile (32 / 16 where 64 rows of D | 1 doubles do not fit LDS)
 typedef double wacc __attribute__((ext_vector_type(4)));
 #define W_MFMA(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
 
@@ -807,6 +807,7 @@ struct WideRebuildArgs {
   const int* eig_ok;      // runs
   // phase 2 with split_tail: stop before the Mahalanobis maximum (wide_fmax_part_kernel /
   // wide_finish_kernel take over) unless the covariance had to be regularised
+  int tp;                    // points per LDS tile
   int split_tail, P, chunk;  // P chunks of `chunk` points per run
   double* meanpart;          // runs x P x d
   double* covpart;           // runs x P x d x d
@@ -993,8 +994,8 @@ __device__ __forceinline__ void wide_stage(const double* pts, int D, int base, i
 // out = inv * Xc^T Xc over the points [pbeg, pend) (one 1024-thread workgroup); with `mirror` both
 // triangles are written, without only the 16x16 blocks (ib <= jb) -- the form the partial sums of the
 // multi-workgroup path use.
-__device__ void wide_cov_range(const double* pts, int D, int pbeg, int pend, const double* mean, double* tile,
-                               double* out, double inv, bool mirror) {
+__device__ void wide_cov_range(const double* pts, int D, int tp, int pbeg, int pend, const double* mean,
+                               double* tile, double* out, double inv, bool mirror) {
   const int t = threadIdx.x, LD = D | 1;
     // ---- covariance (np.cov ddof=1) on the matrix cores: C = Xc^T Xc, upper 16x16 blocks ----
     // Block pairs (ib <= jb) are dealt round-robin to the 16 waves, kCovPairs per wave and pass
@@ -1021,8 +1022,8 @@ __device__ void wide_cov_range(const double* pts, int D, int pbeg, int pend, con
           pib[r] = pr < npairs ? ib : -1;
           pjb[r] = ib + rem;
         }
-        for (int base = pbeg; base < pend; base += kTP) {
-          const int cnt = min(kTP, pend - base);
+        for (int base = pbeg; base < pend; base += tp) {
+          const int cnt = min(tp, pend - base);
           wide_stage(pts, D, base, cnt, mean, tile);
 #pragma unroll
           for (int r = 0; r < kCovPairs; ++r) {
@@ -1058,8 +1059,8 @@ __device__ void wide_cov_range(const double* pts, int D, int pbeg, int pend, con
 }
 
 // max over the points [pbeg, pend) of delta^T am delta (per-thread partial maxima; the caller reduces)
-__device__ double wide_fmax_range(const double* pts, int D, int pbeg, int pend, const double* mean, double* tile,
-                                  double* part, const double* o_am) {
+__device__ double wide_fmax_range(const double* pts, int D, int tp, int pbeg, int pend, const double* mean,
+                                  double* tile, double* part, const double* o_am) {
   const int t = threadIdx.x, LD = D | 1;
       // ---- fmax = max_p delta^T am delta on the matrix cores: Z = Xc AM per 64-point tile
       // (M = 4 point blocks, N = column blocks dealt to the waves, K = D in steps of 4), then the
@@ -1069,8 +1070,8 @@ __device__ double wide_fmax_range(const double* pts, int D, int pbeg, int pend, 
       {
         const int lane = t & 63, wv = t >> 6, lj = lane & 15, lk = lane >> 4;
         const int nbk = (D + 15) >> 4, ksteps = (D + 3) >> 2;
-        for (int base = pbeg; base < pend; base += kTP) {
-          const int cnt = min(kTP, pend - base);
+        for (int base = pbeg; base < pend; base += tp) {
+          const int cnt = min(tp, pend - base);
           wide_stage(pts, D, base, cnt, mean, tile);
           for (int jb = wv; jb < nbk; jb += kRT / 64) {
             const int jc = jb * 16 + lj;
@@ -1352,8 +1353,8 @@ __global__ void __launch_bounds__(kRT) wide_single_kernel(WideRebuildArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int D = a.d, n = a.n, t = threadIdx.x, run = blockIdx.x;
   const int LD = D | 1;
-  double* tile = (double*)smem;            // kTP x LD
-  double* mean = tile + (size_t)kTP * LD;  // D
+  double* tile = (double*)smem;            // tp x LD
+  double* mean = tile + (size_t)a.tp * LD;  // D
   double* lam = mean + D;                  // D
   double* red = lam + D;                   // 64
   double* rc = red + 64;                   // D/2+1
@@ -1405,7 +1406,7 @@ __global__ void __launch_bounds__(kRT) wide_single_kernel(WideRebuildArgs a) {
       __syncthreads();
     }
     WPH("mean");
-    wide_cov_range(pts, D, 0, n, mean, tile, cov, 1.0 / (double)(n - 1), true);
+    wide_cov_range(pts, D, a.tp, 0, n, mean, tile, cov, 1.0 / (double)(n - 1), true);
     WPH("cov");
   }
   if (status == DH_OK) {
@@ -1555,7 +1556,7 @@ __global__ void __launch_bounds__(kRT) wide_single_kernel(WideRebuildArgs a) {
         if (t == 0) a.fast[run] = 1;
         return;
       }
-      const double best = wide_fmax_range(pts, D, 0, n, mean, tile, part, o_am);
+      const double best = wide_fmax_range(pts, D, a.tp, 0, n, mean, tile, part, o_am);
       const double fmx = block_max_1024(best, red);
       WPH("fmax");
       if (pass == 0 && fmx > lim) {
@@ -1633,10 +1634,10 @@ __global__ void __launch_bounds__(kRT) wide_cov_part_kernel(WideRebuildArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int D = a.d, LD = D | 1, run = blockIdx.x / a.P, q = blockIdx.x - run * a.P;
   double* tile = (double*)smem;
-  double* mean = tile + (size_t)kTP * LD;
+  double* mean = tile + (size_t)a.tp * LD;
   const int pbeg = min(a.n, q * a.chunk), pend = min(a.n, pbeg + a.chunk);
   wide_mean_from_parts(a, run, mean);
-  wide_cov_range(a.pts + (size_t)run * a.n * D, D, pbeg, pend, mean, tile,
+  wide_cov_range(a.pts + (size_t)run * a.n * D, D, a.tp, pbeg, pend, mean, tile,
                  a.covpart + ((size_t)run * a.P + q) * D * D, 1.0, false);
 }
 
@@ -1664,13 +1665,13 @@ __global__ void __launch_bounds__(kRT) wide_fmax_part_kernel(WideRebuildArgs a) 
   const int D = a.d, LD = D | 1, t = threadIdx.x, run = blockIdx.x / a.P, q = blockIdx.x - run * a.P;
   if (!a.fast[run]) return;
   double* tile = (double*)smem;
-  double* mean = tile + (size_t)kTP * LD;
+  double* mean = tile + (size_t)a.tp * LD;
   double* red = mean + D;
   double* part = red + 64;
   const int pbeg = min(a.n, q * a.chunk), pend = min(a.n, pbeg + a.chunk);
   for (int k = t; k < D; k += kRT) mean[k] = a.ctrs[(size_t)run * D + k];
   __syncthreads();
-  const double best = wide_fmax_range(a.pts + (size_t)run * a.n * D, D, pbeg, pend, mean, tile, part,
+  const double best = wide_fmax_range(a.pts + (size_t)run * a.n * D, D, a.tp, pbeg, pend, mean, tile, part,
                                       a.ams + (size_t)run * D * D);
   const double fm = block_max_1024(best, red);
   if (t == 0) a.fmaxpart[(size_t)run * a.P + q] = fm;
@@ -1719,9 +1720,18 @@ __global__ void __launch_bounds__(kRT) wide_finish_kernel(WideRebuildArgs a) {
   }
 }
 
+// points per LDS tile for dimension D: the largest of 64 / 32 / 16 whose tile fits
+int wide_tile_points(int D) {
+  const int LD = D | 1;
+  const size_t other = (2 * (size_t)D + 64 + 2 * (kWideMaxD / 2 + 1) + (size_t)((D + 15) / 16) * 64) * 8 +
+                       (2 * (kWideMaxD / 2 + 1) + kWideMaxD + 8) * 4;
+  for (int tp = kTPMax; tp > 16; tp >>= 1)
+    if ((size_t)tp * LD * 8 + other <= 159 * 1024) return tp;
+  return 16;
+}
 size_t wide_single_lds(int D) {
   const int LD = D | 1;
-  size_t dbl = (size_t)kTP * LD + 2 * (size_t)D + 64 + 2 * (kWideMaxD / 2 + 1) + (size_t)((D + 15) / 16) * 64;
+  size_t dbl = (size_t)wide_tile_points(D) * LD + 2 * (size_t)D + 64 + 2 * (kWideMaxD / 2 + 1) + (size_t)((D + 15) / 16) * 64;
   size_t part = (size_t)(kRT / 64) * 64;  // fmax partials alias the tile
   if (dbl < part) dbl = part;
   return dbl * 8 + (2 * (kWideMaxD / 2 + 1) + kWideMaxD + 8) * 4;
@@ -1909,8 +1919,9 @@ static int wide_single_enqueue(dh_ctx* ctx, int runs, const double* pts, int n, 
   const char* e_eig = getenv("DH_WIDE_EIG");
   const bool split = !(e_eig && atoi(e_eig) == 0) && (long long)B * runs <= n_cu && n > 1;
   // chunks of whole 64-point tiles for the data-parallel kernels
-  const int ntiles = (n + kTP - 1) / kTP;
-  const int ct = std::max(1, (ntiles + 31) / 32), P = (ntiles + ct - 1) / ct, chunk = ct * kTP;
+  const int tp = wide_tile_points(d);
+  const int ntiles = (n + tp - 1) / tp;
+  const int ct = std::max(1, (ntiles + 31) / 32), P = (ntiles + ct - 1) / ct, chunk = ct * tp;
   const size_t part_bytes = ((size_t)P * d + (size_t)P * d * d + P + d) * 8 + (size_t)d * 4 + 64;
   const size_t ints = (size_t)(kEigMaxSweeps + 3) * 4;
   int rc = ensure_ws(ctx, (3 * dd + ww + xb + (size_t)d * 8 + ints + part_bytes) * runs + 4096);
@@ -1940,6 +1951,7 @@ static int wide_single_enqueue(dh_ctx* ctx, int runs, const double* pts, int n, 
   a.eig_ok = eig_int + (size_t)runs * (1 + kEigMaxSweeps);
   a.fast = eig_int + (size_t)runs * (2 + kEigMaxSweeps);
   a.split_tail = 0;
+  a.tp = tp;
   a.P = P;
   a.chunk = chunk;
   a.status = status;
@@ -1950,7 +1962,7 @@ static int wide_single_enqueue(dh_ctx* ctx, int runs, const double* pts, int n, 
   a.axlens = axlens;
   a.logvols = logvols;
   const int LD = d | 1;
-  const size_t lds_part = ((size_t)kTP * LD + d + 64 + (size_t)((d + 15) / 16) * 64) * 8;
+  const size_t lds_part = ((size_t)tp * LD + d + 64 + (size_t)((d + 15) / 16) * 64) * 8;
   const size_t lds_mean = (size_t)std::max(1, kRT / d) * d * 8;
   static size_t attr_lds = 0, attr_eig = 0, attr_part = 0;
   if (lds > attr_lds) {

@@ -282,3 +282,42 @@ def test_wide_walkers_on_different_frames(ctx, which):
     np.testing.assert_array_equal(got["rng_out"], ref["rng_out"])
     np.testing.assert_allclose(got["u"], ref["u"], rtol=0, atol=1e-11)
     np.testing.assert_allclose(got["logl"], ref["logl"], rtol=1e-10)
+
+
+@pytest.mark.parametrize("d,n,kind", [(45, 300, "gauss"), (77, 400, "gauss"), (128, 700, "corr"), (333, 1200, "gauss"),
+                                      (512, 1600, "corr"), (60, 400, "tiny"), (64, 500, "flat"), (50, 40, "few")])
+def test_single_rebuild_wide_dimensions(ctx, d, n, kind):
+    """Ellipsoid.update across the wide range (block sizes / workgroup counts of the eigensolver
+    change with D), strongly correlated clouds, a cloud of scale 1e-12 (the eigensolver works on
+    the matrix scaled to max |a_ij| = 1), a rank-deficient cloud and one with fewer points than
+    dimensions (both take improve_covar_mat's regularisation loop, i.e. the single-workgroup
+    continuation with the two-sided solver)."""
+    rng = np.random.default_rng(d + n)
+    if kind == "gauss":
+        pts = 0.5 + 0.03 * rng.standard_normal((n, d))
+    elif kind == "corr":
+        L = rng.standard_normal((d, d)) * 0.3 + np.eye(d)
+        pts = 0.5 + 0.01 * rng.standard_normal((n, d)) @ L
+    elif kind == "tiny":
+        pts = 0.5 + 1e-12 * rng.standard_normal((n, d))
+    elif kind == "flat":
+        pts = 0.5 + 0.03 * rng.standard_normal((n, 20)) @ rng.standard_normal((20, d))
+    else:
+        pts = 0.5 + 0.03 * rng.standard_normal((n, d))
+    got = ctx.rebuild(pts, multi=False)
+    ref = B.bounding_ellipsoid(pts)
+    loose = kind in ("flat", "few")
+    np.testing.assert_allclose(got["ctrs"][0], ref.ctr, rtol=0, atol=1e-13)
+    scale = np.abs(ref.cov).max()
+    # 'tiny': deviations of 1e-12 around 0.5 carry four digits; the covariance is determined to ~1e-3
+    ctol = 5e-3 if kind == "tiny" else (1e-5 if loose else 1e-9)
+    np.testing.assert_allclose(got["covs"][0], ref.cov, rtol=0, atol=ctol * scale)
+    np.testing.assert_allclose(got["logvol_ells"][0], ref.logvol, rtol=0,
+                               atol=0.2 if kind == "tiny" else (1e-2 if loose else 1e-7))
+    ax = got["axes"][0]
+    np.testing.assert_allclose(ax @ ax.T, got["covs"][0], rtol=0, atol=(1e-6 if loose else 1e-10) * scale)
+    if not loose:
+        np.testing.assert_allclose(got["ams"][0] @ got["covs"][0], np.eye(d), rtol=0, atol=1e-7)
+    dlt = pts - got["ctrs"][0]
+    q = np.einsum('ij,jk,ik->i', dlt, got["ams"][0], dlt)
+    assert q.max() <= 1.0
