@@ -128,7 +128,11 @@ int dh_contains(dh_ctx* ctx, const double* x, int k, int d, const double* ctrs,
  * axlens nells*d, logvols nells; leaf_of_point[n] = index of the ellipsoid whose
  * cluster owns each point (may be NULL); nnodes = visited tree nodes (may be
  * NULL).  Errors: DH_ERR_VALUE / DH_ERR_CONTAIN / DH_ERR_REGION as the
- * reference raises; DH_ERR_NOMEM if more than max_ells ellipsoids result. */
+ * reference raises; DH_ERR_NOMEM if more than max_ells ellipsoids result.
+ * Dimensions: d <= 44 runs the LDS-resident kernel pipeline (rebuild.hip);
+ * 44 < d <= 512 the wide path (wide.hip: multi-workgroup covariance /
+ * eigensolver / Mahalanobis maximum; mode 0 as a host recursion over device node
+ * work).  The batched / ragged forms below are d <= 44 for mode 0. */
 int dh_rebuild(dh_ctx* ctx, const double* pts, int n, int d, int mode, int max_ells,
                int32_t* nells, double* ctrs, double* covs, double* ams, double* axes,
                double* axlens, double* logvols, int32_t* leaf_of_point,
