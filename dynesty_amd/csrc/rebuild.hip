@@ -1708,7 +1708,7 @@ __global__ void __launch_bounds__(64)
 // The eigen-system of cov is taken from the stored principal axes
 // (v = axes / axlens, l = axlens^2) instead of a fresh eigh(cov).
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(1024)
     scale_logvol_kernel(int m, int D, double* covs, double* ams, double* axes, double* axlens,
                         double* logvols, const double* __restrict__ targets, double shift,
                         const int* __restrict__ nells, int stride, const int* __restrict__ active) {
@@ -1716,7 +1716,13 @@ __global__ void __launch_bounds__(64)
   double* fax = (double*)smem;  // D
   double* lax = fax + D;        // D  log axlens
   int* iso = (int*)(lax + D);
-  const int e = blockIdx.x, lane = threadIdx.x;
+  const int e = blockIdx.x, lane = threadIdx.x, nt = blockDim.x;  // nt = 64 (one wavefront) or more at wide D
+  auto sync = [&]() {
+    if (nt > 64)
+      __syncthreads();
+    else
+      wave_sync();
+  };
   if (e >= m) return;
   // batched form: slot e belongs to run e / stride and is live iff its index
   // within the run is below that run's ellipsoid count
@@ -1729,8 +1735,8 @@ __global__ void __launch_bounds__(64)
   const double target = targets ? targets[e] : logvols[e] + shift;
   const double logf = target - logvols[e];
   const double max_log_axlen = log(sqrt((double)D) / 2.0);
-  for (int k = lane; k < D; k += 64) lax[k] = log(al[k]);
-  wave_sync();
+  for (int k = lane; k < D; k += nt) lax[k] = log(al[k]);
+  sync();
   if (lane == 0) {
     double mx = -INFINITY;
     for (int k = 0; k < D; ++k) mx = fmax(mx, lax[k]);
@@ -1756,19 +1762,19 @@ __global__ void __launch_bounds__(64)
       }
     }
   }
-  wave_sync();
+  sync();
   if (iso[0]) {
     const double f = exp(logf / D);
     const double f2 = f * f, inv = 1.0 / f2;
-    for (int t = lane; t < D * D; t += 64) {
+    for (int t = lane; t < D * D; t += nt) {
       C[t] *= f2;
       P[t] *= inv;
       X[t] *= f;
     }
-    for (int k = lane; k < D; k += 64) al[k] *= f;
+    for (int k = lane; k < D; k += nt) al[k] *= f;
   } else {
     // cov = (v * l1) v^T, am = (v / l1) v^T with l1 = l * fax^2, v = axes / axlens
-    for (int t = lane; t < D * D; t += 64) {
+    for (int t = lane; t < D * D; t += nt) {
       const int i = t / D, j = t % D;
       double sc = 0.0, sp = 0.0;
       for (int k = 0; k < D; ++k) {
@@ -1781,10 +1787,10 @@ __global__ void __launch_bounds__(64)
       C[t] = sc;
       P[t] = sp;
     }
-    wave_sync();
-    for (int t = lane; t < D * D; t += 64) X[t] *= fax[t % D];
-    wave_sync();
-    for (int k = lane; k < D; k += 64) al[k] *= fax[k];
+    sync();
+    for (int t = lane; t < D * D; t += nt) X[t] *= fax[t % D];
+    sync();
+    for (int k = lane; k < D; k += nt) al[k] *= fax[k];
   }
   if (lane == 0) logvols[e] = target;
 }
@@ -1839,7 +1845,7 @@ int dh::enlarge_launch_masked(dh_ctx* ctx, int runs, int max_ells, const int32_t
                               double* ams, double* axes, double* axlens, double* logvols,
                               double log_enlarge, const int* active) {
   const int m = runs * max_ells;
-  hipLaunchKernelGGL(scale_logvol_kernel, dim3(m), dim3(64), (size_t)2 * d * 8 + 64, ctx->stream, m, d,
+  hipLaunchKernelGGL(scale_logvol_kernel, dim3(m), dim3(d > 64 ? 1024 : 64), (size_t)2 * d * 8 + 64, ctx->stream, m, d,
                      covs, ams, axes, axlens, logvols, (const double*)nullptr, log_enlarge, nells, max_ells,
                      active);
   return hip_ok(ctx, hipGetLastError(), "enlarge launch") ? DH_OK : DH_ERR_HIP;
@@ -2117,7 +2123,7 @@ int dh_enlarge_batch_dev(dh_ctx* ctx, int runs, int max_ells, const int32_t* nel
   if (!nells || !covs || !ams || !axes || !axlens || !logvols || d < 1 || max_ells < 1)
     return fail(ctx, DH_ERR_ARG, "enlarge: bad arguments");
   const int m = runs * max_ells;
-  hipLaunchKernelGGL(scale_logvol_kernel, dim3(m), dim3(64), (size_t)2 * d * 8 + 64, ctx->stream, m, d,
+  hipLaunchKernelGGL(scale_logvol_kernel, dim3(m), dim3(d > 64 ? 1024 : 64), (size_t)2 * d * 8 + 64, ctx->stream, m, d,
                      covs, ams, axes, axlens, logvols, (const double*)nullptr, log_enlarge, nells,
                      max_ells, (const int*)nullptr);
   return hip_ok(ctx, hipGetLastError(), "enlarge launch") ? DH_OK : DH_ERR_HIP;
@@ -2140,7 +2146,7 @@ int dh_scale_to_logvol(dh_ctx* ctx, int m, int d, double* covs, double* ams, dou
   double* d_lv = arena_up(ctx, (const double*)logvols, (size_t)m);
   const double* d_t = arena_up(ctx, targets, (size_t)m);
   if (!d_c || !d_p || !d_x || !d_al || !d_lv || !d_t) return DH_ERR_NOMEM;
-  hipLaunchKernelGGL(scale_logvol_kernel, dim3(m), dim3(64), (size_t)2 * d * 8 + 64, ctx->stream, m, d,
+  hipLaunchKernelGGL(scale_logvol_kernel, dim3(m), dim3(d > 64 ? 1024 : 64), (size_t)2 * d * 8 + 64, ctx->stream, m, d,
                      d_c, d_p, d_x, d_al, d_lv, d_t, 0.0, (const int*)nullptr, 1, (const int*)nullptr);
   if (!hip_ok(ctx, hipGetLastError(), "scale_to_logvol launch")) return DH_ERR_HIP;
   if (!down(ctx, covs, d_c, (size_t)m * dd) || !down(ctx, ams, d_p, (size_t)m * dd) ||
