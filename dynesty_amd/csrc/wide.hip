@@ -169,7 +169,7 @@ __device__ __forceinline__ void lds_sync() {
 }
 
 // The proposal frame applied to the vectors of ALL walkers of the workgroup at once:
-// out_w[i] = scale * sum_k AT[k*n + i] * in_w[k]  =  one (n x n)(n x wpw) GEMM on the matrix cores.
+// out_w[i] = scale * sum_k AT[k*n + i] * in_w[k]  =  one (n x n)(n x wpw) product on the matrix cores.
 // One wavefront per walker alone re-read the whole frame (320 KB at D = 200) from L2 for every
 // direction: 57 % of the C4 kernel.  Here the frame is read once per workgroup and direction
 // round; the walkers of a workgroup meet at two barriers per round (they need their directions at
@@ -179,13 +179,21 @@ __device__ __forceinline__ void lds_sync() {
 // A lone wavefront uses it on its own region (ncols = nw = 1) when the walkers of a workgroup sit on
 // different frames: the arithmetic per column is the same, so a walker's path does not depend on
 // the company it keeps.
-// A lane loads TWO neighbouring rows of the frame per request (16 B): rows 2 lj and 2 lj + 1 of a
-// 32-row span feed two MFMA tiles (even rows / odd rows of the span), and up to 16 requests are in
-// flight per lane -- the product is bound by the latency of the L2 reads, not by their volume.
+// On gfx950 the fp64 matrix rate equals the vector rate (a 16x16x4 instruction takes 64+ cycles),
+// and a workgroup has at most 4 walkers -- 4 of the 16 columns of that tile.  The 4x4x4 form
+// (v_mfma_f64_4x4x4_4b_f64: four independent 4x4x4 products, 17-24 cycles) fits exactly: the four
+// blocks are four groups of 4 frame rows, all multiplied by the same 4 (k) x 4 (walker) block.
+// Operand lanes (measured, tools/micro/mfma_f64_shapes.hip): A: block (l>>2)&3, i = l&3, k = l>>4
+// -- i.e. frame row l&15, k = l>>4, as for the 16x16x4 form; B: k = l>>4, walker l&3 (any block);
+// D: block (l>>2)&3, i = l>>4, walker l&3 -- one value per lane.
+// A lane loads TWO neighbouring rows of the frame per request (16 B): rows 2 (l&15) and 2 (l&15) + 1
+// of a 32-row span feed two tiles (even rows / odd rows of the span); 16 requests are in flight per
+// lane and four accumulator chains (tile x k-step parity) keep the matrix pipe busy.
+#define W_MFMA4(a, b, c) __builtin_amdgcn_mfma_f64_4x4x4f64((a), (b), (c), 0, 0, 0)
 typedef double dv2 __attribute__((ext_vector_type(2)));
 template <int NB>
 __device__ __forceinline__ void gemm_batch(const __attribute__((address_space(1))) double*& ap, const double*& bp,
-                                           size_t step, bool iv0, bool iv1, bool cv, wacc& acc0, wacc& acc1) {
+                                           size_t step, bool iv0, bool iv1, bool cv, double (&acc)[4]) {
   typedef const __attribute__((address_space(1))) dv2* g2ptr;
   dv2 fa[NB];
   double fb[NB];
@@ -197,47 +205,42 @@ __device__ __forceinline__ void gemm_batch(const __attribute__((address_space(1)
   bp += 4 * NB;
 #pragma unroll
   for (int q = 0; q < NB; ++q) {
-    const double b = cv ? fb[q] : 0.0;
-    acc0 = W_MFMA(iv0 ? fa[q].x : 0.0, b, acc0);
-    acc1 = W_MFMA(iv1 ? fa[q].y : 0.0, b, acc1);
+    // rows past n and walkers past ncols read clamped (finite) operands; their results are never stored
+    acc[2 * (q & 1)] = W_MFMA4(fa[q].x, fb[q], acc[2 * (q & 1)]);
+    acc[2 * (q & 1) + 1] = W_MFMA4(fa[q].y, fb[q], acc[2 * (q & 1) + 1]);
   }
 }
 
 __device__ __forceinline__ void wg_frame_gemm(const double* __restrict__ AT, int n, double* lds, int ws, int off_in,
-                                              int off_out, double scale, int ncols, int wv, int nw) {
+                                          int off_out, double scale, int ncols, int wv, int nw) {
   typedef const __attribute__((address_space(1))) double* gptr;
-  const int lane = threadIdx.x & 63, lj = lane & 15, lk = lane >> 4;
+  const int lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4, lw = lane & 3;
   const int nsp = __builtin_amdgcn_readfirstlane((n + 31) >> 5), kfull = __builtin_amdgcn_readfirstlane(n >> 2);
-  const bool cv = lj < ncols;
+  const bool cv = lw < ncols;
   const bool even = (n & 1) == 0;  // 16-byte requests need 16-byte aligned rows
-  const double* inw = lds + (size_t)(cv ? lj : 0) * ws + off_in + lk;
+  const double* inw = lds + (size_t)(cv ? lw : 0) * ws + off_in + lk;
   const size_t step = (size_t)4 * n;
   for (int sp = wv; sp < nsp; sp += nw) {
-    const int i0 = sp * 32 + 2 * lj;
+    const int i0 = sp * 32 + 2 * lr;
     const bool iv0 = i0 < n, iv1 = i0 + 1 < n;
-    wacc acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
     const double* bp = inw;
     if (even) {
       gptr ap = (gptr)AT + (size_t)lk * n + (iv0 ? i0 : 0);
       int ks = 0;
-      for (; ks + 16 <= kfull; ks += 16) gemm_batch<16>(ap, bp, step, iv0, iv1, cv, acc0, acc1);
-      if (ks + 8 <= kfull) {
-        gemm_batch<8>(ap, bp, step, iv0, iv1, cv, acc0, acc1);
-        ks += 8;
-      }
-      if (ks + 4 <= kfull) {
-        gemm_batch<4>(ap, bp, step, iv0, iv1, cv, acc0, acc1);
-        ks += 4;
-      }
-      for (; ks < kfull; ++ks) gemm_batch<1>(ap, bp, step, iv0, iv1, cv, acc0, acc1);
+#pragma unroll 1
+      for (; ks + 16 <= kfull; ks += 16) gemm_batch<16>(ap, bp, step, iv0, iv1, cv, acc);
+#pragma unroll 1
+      for (; ks + 2 <= kfull; ks += 2) gemm_batch<2>(ap, bp, step, iv0, iv1, cv, acc);
+      if (ks < kfull) gemm_batch<1>(ap, bp, step, iv0, iv1, cv, acc);
       if (n & 3) {
         const bool kv = kfull * 4 + lk < n;
         typedef const __attribute__((address_space(1))) dv2* g2ptr;
         dv2 fa = {0.0, 0.0};
         if (kv) fa = *(g2ptr)ap;
         const double b = (kv && cv) ? *bp : 0.0;
-        acc0 = W_MFMA(iv0 ? fa.x : 0.0, b, acc0);
-        acc1 = W_MFMA(iv1 ? fa.y : 0.0, b, acc1);
+        acc[0] = W_MFMA4(iv0 ? fa.x : 0.0, b, acc[0]);
+        acc[1] = W_MFMA4(iv1 ? fa.y : 0.0, b, acc[1]);
       }
     } else {
       gptr a0 = (gptr)AT + (size_t)lk * n + (iv0 ? i0 : 0);
@@ -249,22 +252,21 @@ __device__ __forceinline__ void wg_frame_gemm(const double* __restrict__ AT, int
         a0 += step;
         a1 += step;
         bp += 4;
-        acc0 = W_MFMA(f0, b, acc0);
-        acc1 = W_MFMA(f1, b, acc1);
+        acc[0] = W_MFMA4(f0, b, acc[0]);
+        acc[1] = W_MFMA4(f1, b, acc[1]);
       }
     }
     if (cv) {
-      double* outw = lds + (size_t)lj * ws + off_out;
-#pragma unroll
-      for (int q4 = 0; q4 < 4; ++q4) {
-        const int row = sp * 32 + 2 * (lk + 4 * q4);
-        if (row < n) outw[row] = acc0[q4] * scale;
-        if (row + 1 < n) outw[row + 1] = acc1[q4] * scale;
-      }
+      // D: frame row 4 * ((l>>2)&3) + (l>>4) of the tile, walker l&3
+      double* outw = lds + (size_t)lw * ws + off_out;
+      const int row = sp * 32 + 2 * (4 * ((lane >> 2) & 3) + lk);
+      if (row < n) outw[row] = (acc[0] + acc[2]) * scale;
+      if (row + 1 < n) outw[row + 1] = (acc[1] + acc[3]) * scale;
     }
   }
 }
 
+enum SlicePhase { SL_LEFT0, SL_RIGHT0, SL_OUT_L, SL_OUT_R, SL_DBL, SL_SHRINK, SL_ACC, SL_DONE };
 constexpr int kWalkMaxWaves = 4;  // walkers per workgroup: one wavefront per SIMD keeps the full register file per walker
 __global__ void __launch_bounds__(64 * kWalkMaxWaves) wide_walk_kernel(WideWalkArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -456,12 +458,24 @@ __global__ void __launch_bounds__(64 * kWalkMaxWaves) wide_walk_kernel(WideWalkA
       const double dirnorm = dl > maxlen ? dl / maxlen : 1.0;
       for (int i = lane; i < D; i += 64) sd[i] = sd[i] / dirnorm;
       lds_sync();
-      // F(x): wave-uniform control flow (one walker per wave): plain code
-      auto F = [&](double x) -> double {
+      // generic_slice_step as a state machine around ONE evaluation site of F(x) (the phases of
+      // walk2.hip's slice_kernel; control flow is wave-uniform here).  Eight inlined copies of F --
+      // each with the prior and likelihood code -- made the kernel 570 KB of instructions: every
+      // wavefront missed in the instruction cache all the time.
+      double left = -rand0, right = 1.0 - rand0;
+      double f_l = 0.0, f_r = 0.0;
+      double Lw = 0.0, Rw = 0.0, fLw = 0.0, fRw = 0.0;
+      double lhat = 0.0, rhat = 0.0, f_lhat = 0.0, f_rhat = 0.0, x1 = 0.0, logl_x1 = 0.0;
+      bool Dflag = false, acc_right = false;
+      int Kdbl = 1, nexp_step = 0;
+      int phase = SL_LEFT0;
+      double xq = left;
+      while (phase != SL_DONE) {
+        // F(xq): u_new = u + xq * direction; unitcheck; prior; likelihood
         const long long cf_ = clock64();
         double lo = 2.0, hi = -1.0;
         for (int i = lane; i < D; i += 64) {
-          const double un = fma(x, sd[i], su[i]);
+          const double un = fma(xq, sd[i], su[i]);
           sp[i] = un;
           lo = fmin(lo, un);
           hi = fmax(hi, un);
@@ -470,86 +484,160 @@ __global__ void __launch_bounds__(64 * kWalkMaxWaves) wide_walk_kernel(WideWalkA
         hi = wave_max(hi);
         lds_sync();
         ++ncall;
-        if (!(lo > 0.0 && hi < 1.0)) {
-          cy_f += clock64() - cf_;
-          return -INFINITY;
+        double f = -INFINITY;
+        if (lo > 0.0 && hi < 1.0) {
+          f = wide_logl(a.prob, D, sp, sv, lane);
+          lds_sync();
         }
-        const double ll = wide_logl(a.prob, D, sp, sv, lane);
-        lds_sync();
         cy_f += clock64() - cf_;
-        return ll;
-      };
-      double left = -rand0, right = 1.0 - rand0;
-      double f_l = F(left), f_r = F(right);
-      int nexp_step = 0;
-      double Lw = 0, Rw = 0, fLw = 0, fRw = 0;
-      if (!doubling) {
-        while (f_l > a.loglstar) {
-          left -= 1.0;
-          f_l = F(left);
-          ++nexp_step;
-        }
-        while (f_r > a.loglstar) {
-          right += 1.0;
-          f_r = F(right);
-          ++nexp_step;
-        }
-      } else {
-        int K = 1;
-        while (f_l > a.loglstar || f_r > a.loglstar) {
-          if (g.next_double() < 0.5) {
-            left -= (right - left);
-            f_l = F(left);
-          } else {
-            right += (right - left);
-            f_r = F(right);
+        switch (phase) {
+          case SL_LEFT0:
+            f_l = f;
+            phase = SL_RIGHT0;
+            xq = right;
+            break;
+          case SL_RIGHT0:
+            f_r = f;
+            if (!doubling) {
+              if (f_l > a.loglstar) {
+                phase = SL_OUT_L;
+                left -= 1.0;
+                xq = left;
+              } else if (f_r > a.loglstar) {
+                phase = SL_OUT_R;
+                right += 1.0;
+                xq = right;
+              } else {
+                phase = SL_SHRINK;
+              }
+            } else {
+              phase = SL_DBL;
+            }
+            break;
+          case SL_OUT_L:
+            f_l = f;
+            ++nexp_step;
+            if (f_l > a.loglstar) {
+              left -= 1.0;
+              xq = left;
+            } else if (f_r > a.loglstar) {
+              phase = SL_OUT_R;
+              right += 1.0;
+              xq = right;
+            } else {
+              phase = SL_SHRINK;
+            }
+            break;
+          case SL_OUT_R:
+            f_r = f;
+            ++nexp_step;
+            if (f_r > a.loglstar) {
+              right += 1.0;
+              xq = right;
+            } else {
+              phase = SL_SHRINK;
+            }
+            break;
+          case SL_DBL:
+            if (acc_right)
+              f_r = f;
+            else
+              f_l = f;
+            nexp_step += Kdbl;
+            Kdbl *= 2;
+            break;
+          case SL_SHRINK: {
+            ++n_contract;
+            bool ok = f > a.loglstar;
+            if (ok && doubling) {  // start Neal's acceptance test for x1 = xq
+              x1 = xq;
+              logl_x1 = f;
+              lhat = Lw;
+              rhat = Rw;
+              f_lhat = fLw;
+              f_rhat = fRw;
+              Dflag = false;
+              phase = SL_ACC;
+              ok = false;
+            }
+            if (ok) {
+              logl_cur = f;
+              for (int i = lane; i < D; i += 64) su[i] = fma(xq, sd[i], su[i]);
+              lds_sync();
+              phase = SL_DONE;
+            } else if (phase == SL_SHRINK) {
+              if (xq < 0.0)
+                left = xq;
+              else if (xq > 0.0)
+                right = xq;
+              else {
+                failed = true;
+                phase = SL_DONE;
+              }
+            }
+            break;
           }
-          nexp_step += K;
-          K *= 2;
+          case SL_ACC:
+            if (acc_right)
+              f_rhat = f;
+            else
+              f_lhat = f;
+            if (Dflag && a.loglstar >= f_lhat && a.loglstar >= f_rhat) {
+              phase = SL_SHRINK;  // rejected: shrink towards the origin as for any failed proposal
+              if (x1 < 0.0)
+                left = x1;
+              else if (x1 > 0.0)
+                right = x1;
+              else {
+                failed = true;
+                phase = SL_DONE;
+              }
+            }
+            break;
+          default:
+            break;
         }
-        Lw = left;
-        Rw = right;
-        fLw = f_l;
-        fRw = f_r;
-      }
-      for (;;) {
-        const double x = left + g.next_double() * (right - left);
-        const double f = F(x);
-        ++n_contract;
-        bool ok = f > a.loglstar;
-        if (ok && doubling) {
-          double lhat = Lw, rhat = Rw, f_lhat = fLw, f_rhat = fRw;
-          bool Df = false;
-          while (rhat - lhat > 1.1) {
+        // phases that choose their next abscissa after the switch
+        if (phase == SL_DBL) {
+          if (f_l > a.loglstar || f_r > a.loglstar) {
+            if (g.next_double() < 0.5) {
+              left -= (right - left);
+              xq = left;
+              acc_right = false;
+            } else {
+              right += (right - left);
+              xq = right;
+              acc_right = true;
+            }
+          } else {
+            Lw = left;
+            Rw = right;
+            fLw = f_l;
+            fRw = f_r;
+            phase = SL_SHRINK;
+          }
+        }
+        if (phase == SL_ACC) {
+          if (rhat - lhat > 1.1) {
             const double M = (lhat + rhat) / 2.0;
-            if ((0.0 < M && M <= x) || (x < M && M <= 0.0)) Df = true;
-            if (x < M) {
+            if ((0.0 < M && M <= x1) || (x1 < M && M <= 0.0)) Dflag = true;
+            if (x1 < M) {
               rhat = M;
-              f_rhat = F(rhat);
+              xq = rhat;
+              acc_right = true;
             } else {
               lhat = M;
-              f_lhat = F(lhat);
+              xq = lhat;
+              acc_right = false;
             }
-            if (Df && a.loglstar >= f_lhat && a.loglstar >= f_rhat) {
-              ok = false;
-              break;
-            }
+          } else {  // accepted
+            logl_cur = logl_x1;
+            for (int i = lane; i < D; i += 64) su[i] = fma(x1, sd[i], su[i]);
+            lds_sync();
+            phase = SL_DONE;
           }
         }
-        if (ok) {
-          for (int i = lane; i < D; i += 64) su[i] = fma(x, sd[i], su[i]);
-          logl_cur = f;
-          lds_sync();
-          break;
-        }
-        if (x < 0.0)
-          left = x;
-        else if (x > 0.0)
-          right = x;
-        else {
-          failed = true;
-          break;
-        }
+        if (phase == SL_SHRINK) xq = left + g.next_double() * (right - left);
       }
       n_expand += nexp_step;
       if (!doubling && nexp_step > 1000) {
