@@ -455,6 +455,7 @@ typedef double mfma_acc __attribute__((ext_vector_type(4)));
 constexpr int kBarStride = 16;  // ints between part-barrier counters (one per 64-byte line)
 constexpr int kMfmaMinDim = 10;  // below this the quadratic form stays on the VALU
 #define DH_MFMA_F64(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
+#define DH_MFMA_F64_4X4(a, b, c) __builtin_amdgcn_mfma_f64_4x4x4f64((a), (b), (c), 0, 0, 0)
 
 // sample covariance (ddof=1) of a node about L.mean -> L.A (np.cov, bounding.py:1411):
 // C = Xc^T Xc.  Each wave contracts its own 64 points of every tile (K = points, 16 MFMA
@@ -885,23 +886,29 @@ __device__ int node_kmeans_part(const Lds& L, const double* pts, int* perm, int*
     PH_ADD(10);
     // update_cluster_means: per-cluster sums = Labels^T X on the matrix cores; wave w
     // contracts its 64 points (rows 0/1 of the 16-row A operand are the two indicators)
-    mfma_acc a0 = {0.0, 0.0, 0.0, 0.0}, a1 = a0, a2 = a0;
+    // Only two of a 16x16x4 tile's sixteen rows would carry indicators, and on gfx950 that
+    // instruction costs 64 cycles (tools/micro/mfma_f64_shapes.hip); the 4x4x4 form (17-24 cycles:
+    // four independent 4x4x4 products) takes the indicators as its 4 rows and 4 x 4 dimensions as the
+    // columns of its four blocks.  Operand lanes: A row = lane & 3, k = lane >> 4 (any block);
+    // B column = dimension lane & 15, k = lane >> 4; D row = lane >> 4, dimension lane & 15.
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
     const int pend = min(cnt, w * 64 + 64);
+    const int li = lane & 3;
     for (int p0 = w * 64; p0 < pend; p0 += 4) {
       const int p = p0 + lk;
       const bool pv = p < cnt;
-      const double ind = (pv && lj < 2 && L.ri[pv ? p : 0] == lj) ? 1.0 : 0.0;
+      const double ind = (pv && li < 2 && L.ri[pv ? p : 0] == li) ? 1.0 : 0.0;
       const double* row = L.tile + p * LD + lj;
-      a0 = DH_MFMA_F64(ind, (pv && lj < D) ? row[0] : 0.0, a0);
-      if (nb > 1) a1 = DH_MFMA_F64(ind, (pv && 16 + lj < D) ? row[16] : 0.0, a1);
-      if (nb > 2) a2 = DH_MFMA_F64(ind, (pv && 32 + lj < D) ? row[32] : 0.0, a2);
+      a0 = DH_MFMA_F64_4X4(ind, (pv && lj < D) ? row[0] : 0.0, a0);
+      if (nb > 1) a1 = DH_MFMA_F64_4X4(ind, (pv && 16 + lj < D) ? row[16] : 0.0, a1);
+      if (nb > 2) a2 = DH_MFMA_F64_4X4(ind, (pv && 32 + lj < D) ? row[32] : 0.0, a2);
     }
-    // result rows 0 and 1 sit in register 0 of lanes 0..15 and 16..31
+    // result rows 0 and 1 (the two clusters) sit in lanes 0..15 and 16..31
     if (lane < 32) {
       double* o = L.kred + (w * 2 + lk) * 48;
-      o[lj] = a0[0];
-      if (nb > 1) o[16 + lj] = a1[0];
-      if (nb > 2) o[32 + lj] = a2[0];
+      o[lj] = a0;
+      if (nb > 1) o[16 + lj] = a1;
+      if (nb > 2) o[32 + lj] = a2;
     }
     __syncthreads();
     PH_ADD(11);
