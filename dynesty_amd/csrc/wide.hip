@@ -268,7 +268,12 @@ __device__ __forceinline__ void wg_frame_gemm(const double* __restrict__ AT, int
 
 enum SlicePhase { SL_LEFT0, SL_RIGHT0, SL_OUT_L, SL_OUT_R, SL_DBL, SL_SHRINK, SL_ACC, SL_DONE };
 constexpr int kWalkMaxWaves = 4;  // walkers per workgroup: one wavefront per SIMD keeps the full register file per walker
-__global__ void __launch_bounds__(64 * kWalkMaxWaves) wide_walk_kernel(WideWalkArgs a) {
+// KIND: 0 rwalk, 1 rslice, 2 slice, 3 unit cube -- one instantiation each.  Two workgroups per CU
+// (256 VGPRs): a lone wavefront issues a v_fma_f64 only every 8.5 cycles (tools/micro/
+// mfma_f64_shapes.hip), so a second wavefront per SIMD nearly doubles the fp64 throughput of the F
+// evaluations once there are more than 1024 walkers; the spills this costs are outside the hot loops.
+template <int KIND>
+__global__ void __launch_bounds__(64 * kWalkMaxWaves, 2) wide_walk_kernel(WideWalkArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ ZigLds zig;
   __shared__ int sframe[16];
@@ -299,7 +304,7 @@ __global__ void __launch_bounds__(64 * kWalkMaxWaves) wide_walk_kernel(WideWalkA
   coop = __builtin_amdgcn_readfirstlane((int)coop) != 0;
   lds_sync();
 
-  if (a.kind == 3) {
+  if (KIND == 3) {
     // ---- UnitCubeSampler.sample (internal_samplers.py:364-441) ----
     int ncall = 0;
     double ll = -INFINITY;
@@ -324,7 +329,7 @@ __global__ void __launch_bounds__(64 * kWalkMaxWaves) wide_walk_kernel(WideWalkA
     }
     return;
   }
-  if (a.kind == 0) {
+  if (KIND == 0) {
     // ---- rwalk (internal_samplers.py:866-1035) ----
     int nacc = 0, nrej = 0;
     double logl_cur = 0.0;
@@ -401,9 +406,9 @@ __global__ void __launch_bounds__(64 * kWalkMaxWaves) wide_walk_kernel(WideWalkA
   int ncall = 0, n_expand = 0, n_contract = 0;
   double logl_cur = 0.0;
   const double maxlen = sqrt((double)D) / 2.0;
-  const int nsub = a.kind == 1 ? 1 : D;
-  for (int s = 0; s < a.iters && (!failed || a.kind == 1); ++s) {
-    if (a.kind == 2) {
+  const int nsub = KIND == 1 ? 1 : D;
+  for (int s = 0; s < a.iters && (!failed || KIND == 1); ++s) {
+    if (KIND == 2) {
       // rstate.shuffle(arange(D)) -- sequential, every lane mirrors it
       for (int i = lane; i < D; i += 64) sperm[i] = i;
       lds_sync();
@@ -417,8 +422,8 @@ __global__ void __launch_bounds__(64 * kWalkMaxWaves) wide_walk_kernel(WideWalkA
       }
       lds_sync();
     }
-    for (int sub = 0; sub < nsub && (!failed || a.kind == 1); ++sub) {
-      if (a.kind == 1) {
+    for (int sub = 0; sub < nsub && (!failed || KIND == 1); ++sub) {
+      if (KIND == 1) {
         // a failed walker keeps the workgroup's barriers company and does nothing else
         const long long c0_ = clock64();
         if (!failed) {
@@ -1899,14 +1904,27 @@ int wide_walk_launch(dh_ctx* ctx, int kind, int problem, int k, int ndim, int nc
   if (const char* e = getenv("DH_WIDE_WPW")) wpw = std::max(1, std::min(wpw, atoi(e)));
   wpw = std::max(1, std::min(wpw, k));
   const size_t lds = per_wave * wpw;
-  static size_t lds_attr = 0;
-  if (lds > lds_attr) {
-    if (!hip_ok(ctx, hipFuncSetAttribute((const void*)wide_walk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         (int)lds), "hipFuncSetAttribute(wide_walk)"))
+  static size_t lds_attr[4] = {0, 0, 0, 0};
+  const int kk = kind < 0 || kind > 3 ? 3 : kind;
+  if (lds > lds_attr[kk]) {
+    const void* fn = kk == 0   ? (const void*)wide_walk_kernel<0>
+                     : kk == 1 ? (const void*)wide_walk_kernel<1>
+                     : kk == 2 ? (const void*)wide_walk_kernel<2>
+                               : (const void*)wide_walk_kernel<3>;
+    if (!hip_ok(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+                "hipFuncSetAttribute(wide_walk)"))
       return DH_ERR_HIP;
-    lds_attr = lds;
+    lds_attr[kk] = lds;
   }
-  hipLaunchKernelGGL(wide_walk_kernel, dim3((k + wpw - 1) / wpw), dim3(64 * wpw), lds, ctx->stream, a);
+  const dim3 grid((k + wpw - 1) / wpw), block(64 * wpw);
+  if (kind == 0)
+    hipLaunchKernelGGL(wide_walk_kernel<0>, grid, block, lds, ctx->stream, a);
+  else if (kind == 1)
+    hipLaunchKernelGGL(wide_walk_kernel<1>, grid, block, lds, ctx->stream, a);
+  else if (kind == 2)
+    hipLaunchKernelGGL(wide_walk_kernel<2>, grid, block, lds, ctx->stream, a);
+  else
+    hipLaunchKernelGGL(wide_walk_kernel<3>, grid, block, lds, ctx->stream, a);
   return hip_ok(ctx, hipGetLastError(), "wide walk launch") ? DH_OK : DH_ERR_HIP;
 }
 
