@@ -69,6 +69,17 @@ def _integrate(logl, logvol):
     return logwt, logz, float(h[-1]), float(logzvar[-1])
 
 
+def _logaddexp(x, y):
+    # np.logaddexp's formula on Python floats (a NumPy scalar call per iteration was a third of the
+    # host loop's time)
+    if x == y:
+        return x + 0.6931471805599453
+    d = x - y
+    if d > 0:
+        return x + math.log1p(math.exp(-d))
+    return y + math.log1p(math.exp(d))
+
+
 def run_static(prob, nlive=500, bound='multi', sample='rwalk', queue_size=None,
                walks=None, slices=None, rstate=None, dlogz=0.01, enlarge=None,
                bootstrap=None,
@@ -186,6 +197,7 @@ def run_static(prob, nlive=500, bound='multi', sample='rwalk', queue_size=None,
         return out, start
 
     done = False
+    log_nlive = math.log(nlive)
     # min-heap over (logl, slot): the worst live point in O(log N) per iteration
     heap = [(float(l), i) for i, l in enumerate(live_logl)]
     heapq.heapify(heap)
@@ -215,7 +227,7 @@ def run_static(prob, nlive=500, bound='multi', sample='rwalk', queue_size=None,
             dead_logl.append(cur)
             dead_logvol.append(logvol)
             lw = cur + logvol  # coarse running evidence for the stop rule
-            logz = np.logaddexp(logz, lw - math.log(nlive))
+            logz = _logaddexp(logz, lw - log_nlive)
             live_u[worst] = out["u"][j]
             live_v[worst] = out["v"][j]
             live_logl[worst] = o_logl[j]
@@ -227,7 +239,7 @@ def run_static(prob, nlive=500, bound='multi', sample='rwalk', queue_size=None,
                 done = True
                 break
             if it % 64 == 0 or j == K - 1:
-                dz = np.logaddexp(0., lmax + logvol - logz)
+                dz = _logaddexp(0., lmax + logvol - logz)
                 if dz < dlogz:
                     done = True
                     break
