@@ -381,3 +381,40 @@ def test_rslice_arbitrary_python_likelihood_run(dyn):
     s.run_nested(dlogz=0.5, print_progress=False)
     r = s.results
     assert abs(r.logz[-1] - (-3 * np.log(20.))) < 5 * r.logzerr[-1] + 0.2
+
+
+def test_slice_lockstep_lookahead_refill(dyn, monkeypatch):
+    """The uniform lookahead of the lock-step slice path running dry (here: 2 values per call) is
+    refilled per walker without disturbing the stream: results still equal the reference's."""
+    from dynesty_amd import samplers
+    IS = dyn.internal_samplers
+    orig = samplers._UniformFeed.__init__
+
+    def tiny(self, be, ndim, states6, nlook):
+        orig(self, be, ndim, states6, 2)
+    monkeypatch.setattr(samplers._UniformFeed, "__init__", tiny)
+
+    def loglike(v):
+        return -0.5 * float(np.sum((v - 0.2)**2) / 0.3**2)
+
+    def ptform(u):
+        return 6.0 * u - 3.0
+    rng = np.random.default_rng(5)
+    us = 0.5 + 0.03 * rng.standard_normal((4, 3))
+    loglstar = min(loglike(ptform(x)) for x in us) - 0.3
+    axes = 0.2 * np.eye(3)
+    for cls, run in ((IS.RSliceSampler, samplers.run_rslice), (IS.SliceSampler, samplers.run_slice)):
+        def mk(gens):
+            return [IS.SamplerArgument(u=us[i].copy(), loglstar=loglstar, axes=axes, scale=1.0,
+                                       prior_transform=ptform, loglikelihood=loglike, rseed=g,
+                                       kwargs=dict(slices=4, slice_doubling=False, nonperiodic=None))
+                    for i, g in enumerate(gens)]
+        ga = [np.random.Generator(np.random.PCG64(40 + i)) for i in range(4)]
+        gb = [np.random.Generator(np.random.PCG64(40 + i)) for i in range(4)]
+        ref = [cls.sample(a) for a in mk(ga)]
+        got = run(mk(gb))
+        for r, g in zip(ref, got):
+            np.testing.assert_array_equal(g.u, r.u)
+            assert g.logl == r.logl and g.ncalls == r.ncalls
+        for a, b in zip(ga, gb):
+            assert a.bit_generator.state == b.bit_generator.state
