@@ -1442,6 +1442,276 @@ __global__ void __launch_bounds__(kRT) wide_eig_kernel(WideEigArgs a) {
   if (t == 0 && w == 0) a.ok[run] = (ok && converged) ? 1 : 0;
 }
 
+constexpr int kGS = 33;  // row stride of the 32 x 32 Gram / rotation matrices
+__global__ void __launch_bounds__(kRT) wide_eig2_kernel(WideEigArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ int s_rot, s_ok;
+  const int D = a.D, B = a.B, b = a.b, M = 2 * B, CL = 2 * D + 1;  // CL odd: conflict-free writes across columns
+  const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6), nwv = kRT / 64;
+  const int run = blockIdx.x / B, w = blockIdx.x - run * B;
+  double* col = (double*)smem;              // 2b columns x CL: [G (D) | V (D) | pad]
+  double* gm0 = col + (size_t)2 * b * CL;   // Gram matrix of the G parts, two buffers of 32 x kGS
+  double* jm0 = gm0 + 2 * 32 * kGS;         // accumulated rotations of the round, two buffers
+  double* gpart = jm0 + 2 * 32 * kGS;       // 12 partial Gram tiles of 256
+  double* coefa = gpart + 12 * 256;         // per column: new = coefa * own + coefb * partner
+  double* coefb = coefa + 32;
+  int* partner = (int*)(coefb + 32);        // 32
+  const double* cov = a.cov + (size_t)run * D * D;
+  double* xb = a.xbuf + (size_t)run * 2 * M * b * CL;
+  int* bar = a.bar + run;
+  int* rot = a.rot + (size_t)run * kEigMaxSweeps;
+  const double tol2 = (double)D * (2.220446049250313e-16 * 2.220446049250313e-16);
+  int nbar = 0;
+  long long tp_ = clock64(), cy_rot = 0, cy_st = 0, cy_bar = 0, cy_ld = 0;
+
+  // circle method: the pair of blocks workgroup w holds in round r
+  auto pair_of = [&](int r, int& top, int& bot) {
+    if (w == 0) {
+      top = M - 1;
+      bot = r % (M - 1);
+    } else {
+      top = (r + w) % (M - 1);
+      bot = (r - w + 2 * (M - 1)) % (M - 1);
+    }
+  };
+  // scale to max |cov_ij| = 1 (the rotation formula squares squared column norms)
+  __shared__ double s_red[kRT / 64];
+  double amax = 0.0;
+  for (int e = t; e < D * D; e += kRT) amax = fmax(amax, fabs(cov[e]));
+  amax = block_max_1024(amax, s_red);
+  const double scale = (amax > 0.0 && isfinite(amax)) ? 1.0 / amax : 1.0;
+  // initial blocks: G column g = column g of the covariance, V column = e_g; padding columns zero
+  {
+    int top, bot;
+    pair_of(0, top, bot);
+    for (int e = t; e < 2 * b * CL; e += kRT) {
+      const int c = e / CL, i = e - c * CL;
+      const int g = (c < b ? top : bot) * b + (c < b ? c : c - b);
+      double v = 0.0;
+      if (g < D && i < 2 * D) v = i < D ? cov[(size_t)g * D + i] * scale : (i - D == g ? 1.0 : 0.0);
+      col[e] = v;
+    }
+    if (t == 0) s_rot = 0;
+    __syncthreads();
+  }
+  bool ok = true, converged = false;
+  int parity = 0, sweep = 0;
+  for (sweep = 0; sweep < kEigMaxSweeps && ok && !converged; ++sweep) {
+    for (int r = 0; r < M - 1 && ok; ++r) {
+      int nrot = 0;
+      long long c0_ = clock64();
+      const int m2 = 2 * b, nt = (m2 + 15) >> 4;
+      // (a) Gram matrix of the G parts on the matrix cores: tiles (0,0) (0,1) (1,1) x four slices of
+      // the rows, partial tiles summed in slice order
+      if (wv < 12) {
+        const int tt = wv % 3, kq = wv / 3;
+        const int ib = tt == 2 ? 1 : 0, jb = tt == 0 ? 0 : 1;
+        wacc acc = {0.0, 0.0, 0.0, 0.0};
+        if (jb < nt) {
+          const int ca = ib * 16 + (lane & 15), cb = jb * 16 + (lane & 15);
+          const int ksteps = (D + 3) >> 2, per = (ksteps + 3) >> 2;
+          const int k1 = min(ksteps, (kq + 1) * per);
+          for (int ks = kq * per; ks < k1; ++ks) {
+            const int i = 4 * ks + (lane >> 4);
+            const double fa = (ca < m2 && i < D) ? col[(size_t)ca * CL + i] : 0.0;
+            const double fb = (cb < m2 && i < D) ? col[(size_t)cb * CL + i] : 0.0;
+            acc = W_MFMA(fa, fb, acc);
+          }
+        }
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) gpart[(kq * 3 + tt) * 256 + ((lane >> 4) + 4 * q4) * 16 + (lane & 15)] = acc[q4];
+      }
+      __syncthreads();
+      if (t < 3 * 256) {
+        const int tt = t >> 8, e = t & 255, ib = tt == 2 ? 1 : 0, jb = tt == 0 ? 0 : 1;
+        const double v = ((gpart[tt * 256 + e] + gpart[(3 + tt) * 256 + e]) + gpart[(6 + tt) * 256 + e]) +
+                         gpart[(9 + tt) * 256 + e];
+        const int i = ib * 16 + (e >> 4), j = jb * 16 + (e & 15);
+        gm0[i * kGS + j] = v;
+        if (tt == 1) gm0[j * kGS + i] = v;
+      }
+      {
+        const int i = t >> 5, j = t & 31;
+        jm0[i * kGS + j] = i == j ? 1.0 : 0.0;
+      }
+      __syncthreads();
+      // (b) the round's rotations on the small matrices: angles from the Gram matrix, Gm <- R^T Gm R,
+      // J <- J R (element-wise with the partner map: new column = coefa * own + coefb * partner)
+      int cur = 0;
+      const int nsteps = r == 0 ? m2 - 1 : b;
+      for (int st = 0; st < nsteps; ++st) {
+        const double* Gs = gm0 + cur * 32 * kGS;
+        const double* Js = jm0 + cur * 32 * kGS;
+        double* Gd = gm0 + (cur ^ 1) * 32 * kGS;
+        double* Jd = jm0 + (cur ^ 1) * 32 * kGS;
+        if (t < b) {
+          int p, q;
+          if (r == 0) {
+            if (t == 0) {
+              p = m2 - 1;
+              q = st;
+            } else {
+              p = (st + t) % (m2 - 1);
+              q = (st - t + 2 * (m2 - 1)) % (m2 - 1);
+            }
+          } else {
+            p = t;
+            q = b + (t + st) % b;
+          }
+          const double al = Gs[p * kGS + p], be = Gs[q * kGS + q], ga = Gs[p * kGS + q];
+          double c = 1.0, sn = 0.0;
+          if (ga * ga > tol2 * (al * be)) {  // else orthogonal already (or a zero / padding column)
+            dh_eig::jacobi_rotation(al, be, ga, c, sn);
+            ++nrot;
+          }
+          partner[p] = q;
+          partner[q] = p;
+          coefa[p] = c;
+          coefb[p] = -sn;
+          coefa[q] = c;
+          coefb[q] = sn;
+        }
+        __syncthreads();
+        {
+          const int i = t >> 5, j = t & 31;
+          if (i < m2 && j < m2) {
+            const int pi = partner[i], pj = partner[j];
+            const double ai = coefa[i], bi = coefb[i], aj = coefa[j], bj = coefb[j];
+            const double g00 = Gs[i * kGS + j], g01 = Gs[i * kGS + pj], g10 = Gs[pi * kGS + j],
+                         g11 = Gs[pi * kGS + pj];
+            Gd[i * kGS + j] = ai * (aj * g00 + bj * g01) + bi * (aj * g10 + bj * g11);
+            Jd[i * kGS + j] = aj * Js[i * kGS + j] + bj * Js[i * kGS + pj];
+          }
+        }
+        __syncthreads();
+        cur ^= 1;
+      }
+      // (c) the columns (G and V parts) times the accumulated rotation, on the matrix cores; a wave
+      // owns 16 rows at a time: all of their operands are in registers before the first write
+      {
+        const double* Jf = jm0 + cur * 32 * kGS;
+        const int lj = lane & 15, lk = lane >> 4;
+        for (int rt = wv; rt * 16 < CL; rt += nwv) {
+          const int i = rt * 16 + lj;
+          double fa[8];
+#pragma unroll
+          for (int ks = 0; ks < 8; ++ks) {
+            const int kc = 4 * ks + lk;
+            fa[ks] = (kc < m2 && i < CL) ? col[(size_t)kc * CL + i] : 0.0;
+          }
+          wacc acc[2];
+#pragma unroll
+          for (int jb = 0; jb < 2; ++jb) {
+            acc[jb] = (wacc){0.0, 0.0, 0.0, 0.0};
+            if (jb < nt) {
+#pragma unroll
+              for (int ks = 0; ks < 8; ++ks) {
+                const int kc = 4 * ks + lk, jc = jb * 16 + lj;
+                const double fb = (kc < m2 && jc < m2) ? Jf[kc * kGS + jc] : 0.0;
+                acc[jb] = W_MFMA(fa[ks], fb, acc[jb]);
+              }
+            }
+          }
+#pragma unroll
+          for (int jb = 0; jb < 2; ++jb) {
+            const int jc = jb * 16 + lj;
+            if (jb < nt && jc < m2) {
+#pragma unroll
+              for (int q4 = 0; q4 < 4; ++q4) {
+                const int row = rt * 16 + lk + 4 * q4;
+                if (row < CL) col[(size_t)jc * CL + row] = acc[jb][q4];
+              }
+            }
+          }
+        }
+      }
+      __syncthreads();
+      if (nrot) atomicAdd(&s_rot, nrot);
+      __syncthreads();
+      cy_rot += clock64() - c0_;
+      c0_ = clock64();
+      const bool last_round = r == M - 2;
+      if (M > 2) {
+        // hand the blocks on
+        int top, bot;
+        pair_of(r, top, bot);
+        double* dst = xb + (size_t)parity * M * b * CL;
+        double* d_top = dst + (size_t)top * b * CL;
+        double* d_bot = dst + (size_t)bot * b * CL - (size_t)b * CL;
+        const int half = b * CL;
+        for (int e = t; e < 2 * half; e += kRT)
+          __hip_atomic_store((e < half ? d_top : d_bot) + e, col[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (last_round && t == 0) {
+        if (s_rot) __hip_atomic_fetch_add(rot + sweep, s_rot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_rot = 0;
+      }
+      __syncthreads();  // (stores drained)
+      cy_st += clock64() - c0_;
+      c0_ = clock64();
+      if (B > 1) {
+        ++nbar;
+        ok = eig_barrier(bar, B * nbar, &s_ok);
+      } else {
+        __syncthreads();
+      }
+      cy_bar += clock64() - c0_;
+      c0_ = clock64();
+      if (last_round) {
+        const int total = __hip_atomic_load(rot + sweep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        converged = total == 0;
+      }
+      if (M > 2 && ok && !(last_round && converged)) {
+        int top, bot;
+        pair_of((r + 1) % (M - 1), top, bot);
+        const double* src = xb + (size_t)parity * M * b * CL;
+        const double* s_top = src + (size_t)top * b * CL;
+        const double* s_bot = src + (size_t)bot * b * CL - (size_t)b * CL;
+        const int half = b * CL, tot = 2 * half;
+        for (int e0 = t; e0 < tot; e0 += 8 * kRT) {  // eight requests in flight per thread
+          double tmp[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const int e = e0 + q * kRT;
+            tmp[q] = e < tot ? __hip_atomic_load((e < half ? s_top : s_bot) + e, __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_AGENT)
+                             : 0.0;
+          }
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const int e = e0 + q * kRT;
+            if (e < tot) col[e] = tmp[q];
+          }
+        }
+        parity ^= 1;
+        __syncthreads();
+      }
+      cy_ld += clock64() - c0_;
+    }
+  }
+  if (a.dbg && t == 0 && blockIdx.x == 0)
+    printf("wide_eig2: D %d, %d workgroups x %d columns, %d sweeps, %lld cycles (rotations %lld, hand-on %lld, barrier %lld, pick-up %lld)\n",
+           D, B, 2 * b, sweep, (long long)(clock64() - tp_), cy_rot, cy_st, cy_bar, cy_ld);
+  // results: the blocks this workgroup holds now (those of the last round it worked on)
+  if (ok && converged) {
+    int top, bot;
+    pair_of(M - 2, top, bot);
+    double* lam = a.lam + (size_t)run * D;
+    double* V = a.V + (size_t)run * D * D;
+    for (int c = wv; c < 2 * b; c += nwv) {
+      const int g = (c < b ? top : bot) * b + (c < b ? c : c - b);
+      if (g >= D) continue;
+      const double* P = col + (size_t)c * CL;
+      double dot = 0.0;
+      for (int i = lane; i < D; i += 64) dot = fma(P[D + i], P[i], dot);
+      dot = wave_sum(dot);
+      if (lane == 0) lam[g] = dot * amax;
+      for (int i = lane; i < D; i += 64) V[(size_t)i * D + g] = P[D + i];
+    }
+  }
+  if (t == 0 && w == 0) a.ok[run] = (ok && converged) ? 1 : 0;
+}
+
 __global__ void __launch_bounds__(kRT) wide_single_kernel(WideRebuildArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int D = a.d, n = a.n, t = threadIdx.x, run = blockIdx.x;
@@ -2009,10 +2279,17 @@ static int wide_single_enqueue(dh_ctx* ctx, int runs, const double* pts, int n, 
   const size_t pw = (size_t)((d + 1) & ~1);
   const size_t ww = 4 * pw * pw * 8;  // double-buffered Jacobi work per run
   // multi-workgroup eigensolver: blocks of b <= 16 columns, two per workgroup
-  const int bmax = std::max(1, std::min(16, 4608 / d));
+  // (form 2, the default: the round's rotations on the Gram matrix, applied to the columns by one
+  // product -- column stride 2d + 1 and 59 KB of small matrices beside the columns; DH_WIDE_EIG=1
+  // selects the pairwise form)
+  const char* e_form = getenv("DH_WIDE_EIG");
+  const bool gram = !(e_form && atoi(e_form) == 1);
+  const size_t clen = gram ? 2 * (size_t)d + 1 : 2 * (size_t)d;
+  const size_t eig_other = gram ? ((size_t)4 * 32 * kGS + 12 * 256 + 64) * 8 + 128 : 0;
+  const int bmax = std::max(1, std::min(16, (int)(((gram ? 159 : 144) * 1024 - eig_other) / (2 * clen * 8))));
   const int M = 2 * ((d + 2 * bmax - 1) / (2 * bmax)), B = M / 2, b = (d + M - 1) / M;
-  const size_t xb = (size_t)2 * M * b * 2 * d * 8;
-  const size_t eig_lds = (size_t)2 * b * 2 * d * 8;
+  const size_t xb = (size_t)2 * M * b * clen * 8;
+  const size_t eig_lds = (size_t)2 * b * clen * 8 + eig_other;
   static int n_cu = 0;
   if (!n_cu) {
     int dev = 0;
@@ -2043,7 +2320,7 @@ static int wide_single_enqueue(dh_ctx* ctx, int runs, const double* pts, int n, 
   a.wscov = a.wsV + (size_t)runs * d * d;
   a.wsW = a.wscov + (size_t)runs * d * d;
   double* x_buf = a.wsW + (size_t)runs * 4 * pw * pw;
-  double* lam_pre = x_buf + (size_t)runs * 2 * M * b * 2 * d;
+  double* lam_pre = x_buf + (size_t)runs * 2 * M * b * clen;
   a.meanpart = lam_pre + (size_t)runs * d;
   a.covpart = a.meanpart + (size_t)runs * P * d;
   a.fmaxpart = a.covpart + (size_t)runs * P * d * d;
@@ -2086,7 +2363,11 @@ static int wide_single_enqueue(dh_ctx* ctx, int runs, const double* pts, int n, 
       if (!hip_ok(ctx,
                   hipFuncSetAttribute((const void*)wide_eig_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)eig_lds),
-                  "hipFuncSetAttribute(wide eig LDS)"))
+                  "hipFuncSetAttribute(wide eig LDS)") ||
+          !hip_ok(ctx,
+                  hipFuncSetAttribute((const void*)wide_eig2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)eig_lds),
+                  "hipFuncSetAttribute(wide eig2 LDS)"))
         return DH_ERR_HIP;
       attr_eig = eig_lds;
     }
@@ -2118,7 +2399,10 @@ static int wide_single_enqueue(dh_ctx* ctx, int runs, const double* pts, int n, 
     g.B = B;
     g.b = b;
     g.dbg = a.dbg;
-    hipLaunchKernelGGL(wide_eig_kernel, dim3(runs * B), dim3(kRT), eig_lds, ctx->stream, g);
+    if (gram)
+      hipLaunchKernelGGL(wide_eig2_kernel, dim3(runs * B), dim3(kRT), eig_lds, ctx->stream, g);
+    else
+      hipLaunchKernelGGL(wide_eig_kernel, dim3(runs * B), dim3(kRT), eig_lds, ctx->stream, g);
     a.phase = 2;
     hipLaunchKernelGGL(wide_single_kernel, dim3(runs), dim3(kRT), lds, ctx->stream, a);
     hipLaunchKernelGGL(wide_fmax_part_kernel, dim3(runs * P), dim3(kRT), lds_part, ctx->stream, a);
