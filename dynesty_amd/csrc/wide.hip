@@ -1462,7 +1462,7 @@ __global__ void __launch_bounds__(kRT) wide_eig2_kernel(WideEigArgs a) {
   int* rot = a.rot + (size_t)run * kEigMaxSweeps;
   const double tol2 = (double)D * (2.220446049250313e-16 * 2.220446049250313e-16);
   int nbar = 0;
-  long long tp_ = clock64(), cy_rot = 0, cy_st = 0, cy_bar = 0, cy_ld = 0;
+  long long tp_ = clock64(), cy_rot = 0, cy_st = 0, cy_bar = 0, cy_ld = 0, cy_a = 0, cy_b = 0, cy_c = 0;
 
   // circle method: the pair of blocks workgroup w holds in round r
   auto pair_of = [&](int r, int& top, int& bot) {
@@ -1535,6 +1535,8 @@ __global__ void __launch_bounds__(kRT) wide_eig2_kernel(WideEigArgs a) {
         jm0[i * kGS + j] = i == j ? 1.0 : 0.0;
       }
       __syncthreads();
+      cy_a += clock64() - c0_;
+      long long c1_ = clock64();
       // (b) the round's rotations on the small matrices: angles from the Gram matrix, Gm <- R^T Gm R,
       // J <- J R (element-wise with the partner map: new column = coefa * own + coefb * partner)
       int cur = 0;
@@ -1586,6 +1588,8 @@ __global__ void __launch_bounds__(kRT) wide_eig2_kernel(WideEigArgs a) {
         __syncthreads();
         cur ^= 1;
       }
+      cy_b += clock64() - c1_;
+      c1_ = clock64();
       // (c) the columns (G and V parts) times the accumulated rotation, on the matrix cores; a wave
       // owns 16 rows at a time: all of their operands are in registers before the first write
       {
@@ -1626,6 +1630,7 @@ __global__ void __launch_bounds__(kRT) wide_eig2_kernel(WideEigArgs a) {
         }
       }
       __syncthreads();
+      cy_c += clock64() - c1_;
       if (nrot) atomicAdd(&s_rot, nrot);
       __syncthreads();
       cy_rot += clock64() - c0_;
@@ -1690,8 +1695,8 @@ __global__ void __launch_bounds__(kRT) wide_eig2_kernel(WideEigArgs a) {
     }
   }
   if (a.dbg && t == 0 && blockIdx.x == 0)
-    printf("wide_eig2: D %d, %d workgroups x %d columns, %d sweeps, %lld cycles (rotations %lld, hand-on %lld, barrier %lld, pick-up %lld)\n",
-           D, B, 2 * b, sweep, (long long)(clock64() - tp_), cy_rot, cy_st, cy_bar, cy_ld);
+    printf("wide_eig2: D %d, %d workgroups x %d columns, %d sweeps, %lld cycles (rotations %lld = Gram %lld + steps %lld + apply %lld, hand-on %lld, barrier %lld, pick-up %lld)\n",
+           D, B, 2 * b, sweep, (long long)(clock64() - tp_), cy_rot, cy_a, cy_b, cy_c, cy_st, cy_bar, cy_ld);
   // results: the blocks this workgroup holds now (those of the last round it worked on)
   if (ok && converged) {
     int top, bot;
