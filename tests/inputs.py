@@ -106,3 +106,30 @@ def walker_case(pname, nwalk, seed, shrink=0.5):
     keep = logl > loglstar
     return dict(u0=u0[keep], loglstar=loglstar, axes=axes, scale=0.7,
                 problem=prob)
+
+
+def blobs(d, sizes, sep, seed, sigma=0.001):
+    rng = np.random.default_rng(seed)
+    out = []
+    for k, m in enumerate(sizes):
+        c = np.full(d, 0.5)
+        c[k % d] += sep * (1 if k % 2 == 0 else -1)
+        c[(k + 3) % d] += 0.5 * sep * k
+        A = rng.standard_normal((d, d)) * 0.4 * sigma
+        out.append(c + rng.standard_normal((m, d)) * sigma + rng.standard_normal((m, d)) @ A)
+    pts = np.vstack(out)
+    return pts[rng.permutation(len(pts))]
+
+
+def wide_walker_case(d, k, seed):
+    """Start points, threshold and frame of the wide-D walker tests (iid Normal likelihood, Normal
+    prior via ndtri): shared by tools/make_golden.py (the real reference) and the tests."""
+    from dynesty_amd import problems
+    prob = problems.gauss_normal_prior(d, "C4")
+    rng = np.random.default_rng(seed)
+    u0 = np.clip(0.5 + 0.08 * rng.standard_normal((k, d)), 0.02, 0.98)
+    logl0 = prob.loglikelihood_many(prob.prior_transform_many(u0))
+    loglstar = float(logl0.min() - 5.0)
+    q, _ = np.linalg.qr(rng.standard_normal((d, d)))
+    axes = q * (0.08 * np.sqrt(d) * rng.uniform(0.8, 1.4, size=d))
+    return dict(problem=prob, u0=u0, loglstar=loglstar, axes=axes)

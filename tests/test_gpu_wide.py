@@ -159,25 +159,12 @@ def test_rslice_logz_matches_the_reference_runs(ctx):
     assert abs(np.mean([r.logzerr for r in ours]) - err) < 0.02
 
 
-def _blobs(d, sizes, sep, seed, sigma=0.001):
-    rng = np.random.default_rng(seed)
-    out = []
-    for k, m in enumerate(sizes):
-        c = np.full(d, 0.5)
-        c[k % d] += sep * (1 if k % 2 == 0 else -1)
-        c[(k + 3) % d] += 0.5 * sep * k
-        A = rng.standard_normal((d, d)) * 0.4 * sigma
-        out.append(c + rng.standard_normal((m, d)) * sigma + rng.standard_normal((m, d)) @ A)
-    pts = np.vstack(out)
-    return pts[rng.permutation(len(pts))]
-
-
 @pytest.mark.parametrize("d,sizes", [(48, (2000, 2000)), (64, (2000, 1800, 2200)), (50, (900,)), (96, (2500, 2400))])
 def test_multi_rebuild_wide_vs_oracle(ctx, d, sizes):
     """MultiEllipsoid.update above the register-resident limit (D > 44): host recursion over device
     node work (k-means in one workgroup, ellipsoids by the multi-workgroup rebuild).  Against the
     oracle's split tree: same number of ellipsoids, the same point partition, the same ellipsoids."""
-    pts = _blobs(d, sizes, 0.3, d)
+    pts = inputs.blobs(d, sizes, 0.3, d)
     trace = []
     first = B.bounding_ellipsoid(pts)
     ells = B.split_tree(pts, first, trace=trace)
@@ -321,3 +308,55 @@ def test_single_rebuild_wide_dimensions(ctx, d, n, kind):
     dlt = pts - got["ctrs"][0]
     q = np.einsum('ij,jk,ik->i', dlt, got["ams"][0], dlt)
     assert q.max() <= 1.0
+
+
+def _wide_golden():
+    import os
+    return np.load(os.path.join(os.path.dirname(__file__), "golden", "wide.npz"))
+
+
+@pytest.mark.parametrize("d,sizes", [(48, (2000, 2000)), (64, (2000, 1800, 2200))])
+def test_multi_rebuild_wide_golden(ctx, d, sizes):
+    """Device MultiEllipsoid.update above D = 44 against the REAL reference's ellipsoids
+    (tests/golden/wide.npz), matched by centre."""
+    g = _wide_golden()
+    got = ctx.rebuild(inputs.blobs(d, sizes, 0.3, d), multi=True)
+    assert got["nells"] == int(g[f"multi{d}/nells"])
+    rc = g[f"multi{d}/ctrs"]
+    for i in range(got["nells"]):
+        j = int(np.argmin(np.linalg.norm(rc - got["ctrs"][i], axis=1)))
+        np.testing.assert_allclose(got["ctrs"][i], rc[j], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(got["logvol_ells"][i], g[f"multi{d}/logvol_ells"][j], rtol=0, atol=1e-8)
+        cov = g[f"multi{d}/covs"][j]
+        np.testing.assert_allclose(got["covs"][i], cov, rtol=0, atol=1e-9 * np.abs(cov).max())
+
+
+def test_single_rebuild_200d_golden(ctx):
+    g = _wide_golden()
+    got = ctx.rebuild(inputs.cloud("g200"), multi=False)
+    np.testing.assert_allclose(got["ctrs"][0], g["single200/ctr"], rtol=0, atol=1e-13)
+    np.testing.assert_allclose(got["logvol_ells"][0], float(g["single200/logvol"]), rtol=0, atol=1e-7)
+    np.testing.assert_allclose(np.sort(got["axlens"][0]), g["single200/axlens_sorted"], rtol=1e-9)
+    rows = g["single200/cov_rows"]
+    np.testing.assert_allclose(got["covs"][0][[0, 17]], rows, rtol=0, atol=1e-9 * np.abs(rows).max())
+    np.testing.assert_allclose(np.trace(got["covs"][0]), float(g["single200/cov_trace"]), rtol=1e-10)
+
+
+@pytest.mark.parametrize("tag,d", [("rslice64", 64), ("rwalk50", 50)])
+def test_wide_walkers_golden(ctx, tag, d):
+    """Wide walk kernels against the REAL reference's RSliceSampler.sample / RWalkSampler.sample on
+    the same child streams: counters exact, coordinates to 1e-11 (frame product and norm are summed
+    in a different order)."""
+    g = _wide_golden()
+    case = inputs.wide_walker_case(d, 6, d)
+    st = ctx.seed_children([int(g[f"{tag}/seedbase"])], 0, 6)
+    if tag.startswith("rslice"):
+        out = ctx.slice_batch(case["problem"], case["u0"], case["axes"], 0.8, case["loglstar"], 3, st)
+        np.testing.assert_array_equal(out["ncalls"], g[f"{tag}/ncalls"])
+        np.testing.assert_array_equal(out["n_expand"], g[f"{tag}/ti_n_expand"])
+        np.testing.assert_array_equal(out["n_contract"], g[f"{tag}/ti_n_contract"])
+    else:
+        out = ctx.rwalk_batch(case["problem"], case["u0"], case["axes"], 0.8, case["loglstar"], 30, st)
+        np.testing.assert_array_equal(out["accept"], g[f"{tag}/ti_accept"])
+    np.testing.assert_allclose(out["u"], g[f"{tag}/u"], rtol=0, atol=1e-11)
+    np.testing.assert_allclose(out["logl"], g[f"{tag}/logl"], rtol=1e-10)

@@ -381,11 +381,58 @@ def gen_runs(out):
     print("wrote", out, dict((k, float(v)) for k, v in g.items()))
 
 
+def gen_wide(out):
+    """Wide-D shapes (D > 44) from the real reference: MultiEllipsoid on two / three clusters in
+    48 / 64-D, Ellipsoid on the 4000 x 200 cloud (compact: centre, axis lengths, logvol, two rows of
+    the covariance), RSliceSampler in 64-D and RWalkSampler in 50-D on child streams."""
+    from dynesty import bounding as db
+    from dynesty import internal_samplers as dis
+    import inputs
+    g = {}
+    for d, sizes in ((48, (2000, 2000)), (64, (2000, 1800, 2200))):
+        pts = inputs.blobs(d, sizes, 0.3, d)
+        m = db.bounding_ellipsoids(pts)
+        g[f"multi{d}/nells"] = np.int64(m.nells)
+        g[f"multi{d}/ctrs"] = np.array(m.ctrs)
+        g[f"multi{d}/logvol_ells"] = np.array(m.logvol_ells)
+        g[f"multi{d}/covs"] = np.array(m.covs)
+    pts = inputs.cloud("g200")
+    e = db.bounding_ellipsoid(pts)
+    g["single200/ctr"] = e.ctr
+    g["single200/logvol"] = np.float64(e.logvol)
+    g["single200/axlens_sorted"] = np.sort(e.axlens)
+    g["single200/cov_rows"] = e.cov[[0, 17]]
+    g["single200/cov_trace"] = np.float64(np.trace(e.cov))
+    for tag, cls, d, kw, seedbase in (("rslice64", dis.RSliceSampler, 64, dict(slices=3), 6400),
+                                       ("rwalk50", dis.RWalkSampler, 50, dict(walks=30), 5000)):
+        case = inputs.wide_walker_case(d, 6, d)
+        prob = case["problem"]
+        smp = cls(ndim=d, ncdim=d, nonbounded=None, periodic=None, reflective=None, **kw)
+        seeds = np.random.SeedSequence(seedbase).spawn(6)
+        res = []
+        for i in range(6):
+            arg = dis.SamplerArgument(u=case["u0"][i].copy(), loglstar=case["loglstar"], axes=case["axes"],
+                                      scale=0.8, prior_transform=prob.prior_transform,
+                                      loglikelihood=prob.loglikelihood, rseed=seeds[i],
+                                      kwargs=dict(smp.sampler_kwargs))
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                res.append(cls.sample(arg))
+        g[f"{tag}/u"] = np.array([r.u for r in res])
+        g[f"{tag}/logl"] = np.array([float(r.logl) for r in res])
+        g[f"{tag}/ncalls"] = np.array([r.ncalls for r in res], dtype=np.int64)
+        for key in res[0].tuning_info:
+            g[f"{tag}/ti_{key}"] = np.array([r.tuning_info[key] for r in res])
+        g[f"{tag}/seedbase"] = np.int64(seedbase)
+    np.savez_compressed(out, **g)
+    print("wrote", out, len(g), "arrays")
+
+
 if __name__ == "__main__":
     import_reference()
     gdir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(gdir, exist_ok=True)
-    which = sys.argv[1:] or ["bounding", "proposals", "rng", "runs", "friends"]
+    which = sys.argv[1:] or ["bounding", "proposals", "rng", "runs", "friends", "wide"]
     if "bounding" in which:
         gen_bounding(os.path.join(gdir, "bounding.npz"))
     if "proposals" in which:
@@ -396,3 +443,5 @@ if __name__ == "__main__":
         gen_runs(os.path.join(gdir, "runs.npz"))
     if "friends" in which:
         gen_friends(os.path.join(gdir, "friends.npz"))
+    if "wide" in which:
+        gen_wide(os.path.join(gdir, "wide.npz"))
