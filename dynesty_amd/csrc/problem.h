@@ -78,6 +78,25 @@ __device__ __forceinline__ double ndtri_dev(double p) { return -1.41421356237309
 // evaluated branch-free (straight-line code: N independent chains for the scheduler to
 // interleave) and selected.  Measured against scipy.special.ndtri: <= 1.1e-15 relative
 // (tools/ndtri_as241_check.py).  p < exp(-25) (or p outside (0, 1)) takes ndtri_dev.
+// ln x for x > 0 in plain fp64 (fdlibm's e_log.c scheme: x = 2^k (1 + f), s = f / (2 + f), a degree-7
+// polynomial in s^2, k ln2 in two parts): <= 1 ulp against NumPy's log over (e^-30, 1)
+// (tools/ndtri_as241_check.py), a third of the instructions of ocml's double-double log -- the
+// logarithm was the largest part of the tail branch below.
+__device__ __forceinline__ double log_pos(double x) {
+  int e;
+  double m = frexp(x, &e);  // [0.5, 1)
+  const bool lo = m < 0.7071067811865476;
+  m = lo ? m + m : m;
+  const double k = (double)(lo ? e - 1 : e);
+  const double f = m - 1.0;
+  const double s = f / (2.0 + f), z = s * s, w = z * z;
+  const double t1 = w * (3.999999999940941908e-01 + w * (2.222219843214978396e-01 + w * 1.531383769920937332e-01));
+  const double t2 = z * (6.666666666666735130e-01 +
+                         w * (2.857142874366239149e-01 + w * (1.818357216161805012e-01 + w * 1.479819860511658591e-01)));
+  const double R = t2 + t1, hfsq = 0.5 * f * f;
+  return k * 6.93147180369123816490e-01 - ((hfsq - (s * (hfsq + R) + k * 1.90821492927058770002e-10)) - f);
+}
+
 __device__ __forceinline__ double ndtri_as241_core(double p, bool* far) {
   const double q = p - 0.5;
   double r = 0.180625 - q * q;
@@ -90,8 +109,8 @@ __device__ __forceinline__ double ndtri_as241_core(double p, bool* far) {
            21213.794301586595867) * r + 5394.1960214247511077) * r + 687.1870074920579083) * r +
         42.313330701600911252) * r + 1.0);
   const double pm = q < 0.0 ? p : 1.0 - p;
-  const double rt = sqrt(-log(pm));
-  *far = !(rt <= 5.0);
+  const double rt = sqrt(-log_pos(pm));
+  *far = !(rt <= 5.0) || !(pm > 0.0);
   r = rt - 1.6;
   const double tn =
       (((((((r * 7.7454501427834140764e-4 + .0227238449892691845833) * r + .24178072517745061177) * r +
