@@ -8,7 +8,7 @@ independent runs per GPU (64 = one GPU's shard of the C5 ensemble of 512 runs
 on 8 GPUs).  One *step* = one pass of the hot path for every run of the shard,
 all inputs resident in HBM:
 
-  1. MultiEllipsoid.update on each run's live set        (rebuild kernel)
+  1. MultiEllipsoid.update on each run's live set        (rebuild kernels)
   2. scale_to_logvol(logvol + ln 1.25)                   (enlarge kernel)
   3. K = nlive walkers x `walks` rwalk proposals per run against the rebuilt,
      enlarged ellipsoid frame (in-kernel PCG64/ziggurat draws, frame mat-vec,
@@ -17,14 +17,28 @@ all inputs resident in HBM:
 i.e. exactly one bound-update interval of the reference
 (update_interval = walks * nlive = 90 000 calls, dynesty.py:213-232).
 
+Live sets are uniform-in-contour shells: a run's live points are distributed
+uniformly inside {logl > loglstar} (here an ellipsoid well inside the prior
+box), which is exactly the distribution of the live points of a real run
+(SURVEY.md section 8d), not a Gaussian cloud.
+
 value = proposals/s over all GPUs (weak scaling: per-GPU work fixed);
 config.rebuilds_per_s is the second half of BASELINE.json's metric.
 Tap point: (A) kernel boundary.
+
+`python bench.py --gpus N` (N > 1, no torchrun) launches the N ranks itself;
+under torchrun (WORLD_SIZE set) it is one rank of the job.
+
+After the timed region the very entry points that were timed are run once
+more from known generator states and compared with the oracle
+(config.verified); a mismatch fails the benchmark.
 """
 import argparse
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -36,117 +50,313 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 FP64_PEAK_TFLOPS = 78.6  # vector fp64 (datasheet)
 MAX_ELLS = 8
+# the REAL dynesty 3.0.0 on C2, one core of the build container (it cannot
+# travel to the GPU box: /root/reference does not exist there)
+REFERENCE_C2_PROPOSALS_PER_S_1CORE = 44.0e3
+REFERENCE_C2_REBUILDS_PER_S_1CORE = 15.0
 
 
-def make_shard(prob, runs, nlive, seed):
-    """Synthetic live sets: `runs` clouds of nlive points drawn from a C2
-    posterior shell (N(0, s^2 Sigma) in parameter space, mapped to the unit
-    cube) and a likelihood threshold at their 10% quantile, so proposals are
-    genuinely accepted and rejected."""
+def c2_problem():
+    from dynesty_amd import problems
+    return problems.gauss_corr(25, 0.4, 5.0, "C2")
+
+
+def make_shard(prob, runs, nlive, seed, radius=4.0):
+    """`runs` live sets of nlive points, uniform inside the likelihood contour
+    v^T Sigma^-1 v < radius^2 (u = 0.5 + v / 10): the distribution of a real run's
+    live points at the iteration whose threshold is that contour.  Returns
+    (u0 (runs*nlive, d), loglstar)."""
     d = prob.ndim
     rng = np.random.default_rng(seed)
     cov = np.full((d, d), 0.4)
     np.fill_diagonal(cov, 1.0)
-    lam, vec = np.linalg.eigh(cov)
+    chol = np.linalg.cholesky(cov)
     hw = prob.prior_par[0]
-    s = 0.6
     z = rng.standard_normal((runs * nlive, d))
-    v = s * (z * np.sqrt(lam)) @ vec.T
+    z /= np.linalg.norm(z, axis=1)[:, None]
+    rad = radius * rng.random(runs * nlive)**(1.0 / d)
+    v = (z * rad[:, None]) @ chol.T
     u0 = 0.5 + v / (2 * hw)
-    logl = prob.loglikelihood_many(prob.prior_transform_many(u0))
-    loglstar = float(np.quantile(logl, 0.10))
+    loglstar = float(prob.like_par[0] - 0.5 * radius * radius)
     return u0, loglstar
+
+
+class Shard:
+    """The device-resident state of one rank's benchmark shard and the three
+    timed entry points (dh_rebuild_batch_dev, dh_enlarge_batch_dev,
+    dh_rwalk_batch_dev).  tests/test_gpu_bench_shape.py drives the same object."""
+
+    def __init__(self, ctx, prob, runs=64, nlive=2000, walks=45, seed=1000,
+                 scale=0.27, entropy=(21, 0, 0, 0)):
+        self.ctx, self.prob = ctx, prob
+        self.runs, self.nlive, self.walks, self.scale = runs, nlive, walks, scale
+        self.d = d = prob.ndim
+        self.k = k = runs * nlive
+        self.u0, self.loglstar = make_shard(prob, runs, nlive, seed)
+        self.log_enlarge = math.log(1.25)
+        self.entropy = list(entropy)
+        me = self.me = MAX_ELLS
+        self.d_u0 = ctx.to_device(self.u0)  # live sets == walker start points
+        self.idx = (np.arange(k, dtype=np.int32) // nlive) * me
+        self.d_idx = ctx.to_device(self.idx)
+        self.states0 = ctx.seed_children(self.entropy, 0, k)
+        self.d_rng = ctx.to_device(self.states0)
+        self.d_rng2 = ctx.malloc(k * 32)
+        self.d_u, self.d_v = ctx.malloc(k * d * 8), ctx.malloc(k * d * 8)
+        self.d_logl = ctx.malloc(k * 8)
+        self.d_na, self.d_nr = ctx.malloc(k * 4), ctx.malloc(k * 4)
+        self.d_nells, self.d_status = ctx.malloc(runs * 4), ctx.malloc(runs * 4)
+        self.d_ctrs = ctx.malloc(runs * me * d * 8)
+        self.d_covs = ctx.malloc(runs * me * d * d * 8)
+        self.d_ams = ctx.malloc(runs * me * d * d * 8)
+        self.d_axes = ctx.malloc(runs * me * d * d * 8)
+        self.d_axl = ctx.malloc(runs * me * d * 8)
+        self.d_lv = ctx.malloc(runs * me * 8)
+        self.ph = ctx.problem(prob)
+
+    # ---- the timed entry points ------------------------------------------
+    def rebuild(self, enlarge=True):
+        c, lib, h = self.ctx, self.ctx.lib, self.ctx.handle
+        c._check(lib.dh_rebuild_batch_dev(h, self.runs, self.d_u0, self.nlive, self.d, 0,
+                                          self.me, self.d_nells, self.d_status, self.d_ctrs,
+                                          self.d_covs, self.d_ams, self.d_axes, self.d_axl,
+                                          self.d_lv, None, None))
+        if enlarge:
+            c._check(lib.dh_enlarge_batch_dev(h, self.runs, self.me, self.d_nells, self.d,
+                                              self.d_covs, self.d_ams, self.d_axes, self.d_axl,
+                                              self.d_lv, self.log_enlarge))
+
+    def walk(self, i=0, first=0, count=None):
+        """One rwalk launch over walkers [first, first + count) of the shard."""
+        c, lib, h = self.ctx, self.ctx.lib, self.ctx.handle
+        a, b = (self.d_rng, self.d_rng2) if i % 2 == 0 else (self.d_rng2, self.d_rng)
+        count = self.k if count is None else count
+        d = self.d
+
+        def off(p, stride):
+            return p + first * stride
+        c._check(lib.dh_rwalk_batch_dev(h, self.ph, count, d, d, off(self.d_u0, d * 8),
+                                        self.d_axes, self.runs * self.me,
+                                        off(self.d_idx, 4), self.scale, self.loglstar,
+                                        self.walks, None, off(a, 32), off(self.d_u, d * 8),
+                                        off(self.d_v, d * 8), off(self.d_logl, 8),
+                                        off(self.d_na, 4), off(self.d_nr, 4), off(b, 32)))
+
+    def step(self, i=0, rebuild=True):
+        if rebuild:
+            self.rebuild()
+        self.walk(i)
+
+    # ---- results -------------------------------------------------------------
+    def fetch_bound(self):
+        c, r, me, d = self.ctx, self.runs, self.me, self.d
+        return dict(nells=c.from_device(self.d_nells, (r,), np.int32),
+                    status=c.from_device(self.d_status, (r,), np.int32),
+                    ctrs=c.from_device(self.d_ctrs, (r, me, d), np.float64),
+                    covs=c.from_device(self.d_covs, (r, me, d, d), np.float64),
+                    ams=c.from_device(self.d_ams, (r, me, d, d), np.float64),
+                    axes=c.from_device(self.d_axes, (r, me, d, d), np.float64),
+                    axlens=c.from_device(self.d_axl, (r, me, d), np.float64),
+                    logvols=c.from_device(self.d_lv, (r, me), np.float64))
+
+    def fetch_walk(self):
+        c, k, d = self.ctx, self.k, self.d
+        return dict(u=c.from_device(self.d_u, (k, d), np.float64),
+                    v=c.from_device(self.d_v, (k, d), np.float64),
+                    logl=c.from_device(self.d_logl, (k,), np.float64),
+                    accept=c.from_device(self.d_na, (k,), np.int32),
+                    reject=c.from_device(self.d_nr, (k,), np.int32))
+
+    def reset_rng(self):
+        c = self.ctx
+        c._check(c.lib.dh_memcpy_h2d(c.handle, self.d_rng, self.states0.ctypes.data,
+                                     self.states0.nbytes))
+
+    # ---- the check of what was timed (the oracle is the checker only) -------------
+    def verify(self, check_runs=None, walkers_per_run=64, rtol=1e-9):
+        """Run the timed entry points once from the initial generator states and hold
+        `check_runs` to the oracle: the rebuilt + enlarged MultiEllipsoid against
+        oracle.multi_update + scale_multi_to_logvol (nells exact, centres 1e-13, cov /
+        logvol / axis lengths `rtol`), and the first `walkers_per_run` walkers of each
+        of those runs against oracle.rwalk on the same child streams (accept / reject
+        counts exact, u within 1e-12, logl 1e-11 relative).  Raises AssertionError."""
+        from oracle import bounding_ref as B
+        from oracle import proposals_ref as P
+        runs, nlive, d = self.runs, self.nlive, self.d
+        if check_runs is None:
+            check_runs = sorted({0, runs // 2 - 1 if runs > 2 else 0, runs - 1})
+        self.reset_rng()
+        self.rebuild(enlarge=False)
+        self.ctx.sync()
+        plain = self.fetch_bound()
+        self.rebuild(enlarge=True)
+        self.walk(0)
+        self.ctx.sync()
+        bnd, wk = self.fetch_bound(), self.fetch_walk()
+        assert np.all(bnd["status"] == 0), bnd["status"]
+        assert np.all(wk["accept"] + wk["reject"] == self.walks)
+        kids = np.random.SeedSequence(self.entropy).spawn(self.k)
+        nwalk = 0
+        for r in check_runs:
+            pts = self.u0[r * nlive:(r + 1) * nlive]
+            m0 = B.multi_update(pts)
+            m1 = B.scale_multi_to_logvol(m0, m0.logvol + self.log_enlarge)
+            for got, ref in ((plain, m0), (bnd, m1)):
+                assert int(got["nells"][r]) == ref.nells, (r, got["nells"][r], ref.nells)
+                order = [int(np.argmin(np.linalg.norm(got["ctrs"][r, :ref.nells] - e.ctr, axis=1)))
+                         for e in ref.ells]
+                assert sorted(order) == list(range(ref.nells))
+                for e, j in zip(ref.ells, order):
+                    np.testing.assert_allclose(got["ctrs"][r, j], e.ctr, rtol=0, atol=1e-13)
+                    np.testing.assert_allclose(got["covs"][r, j], e.cov, rtol=rtol,
+                                               atol=rtol * np.abs(e.cov).max())
+                    np.testing.assert_allclose(got["ams"][r, j], e.am, rtol=0,
+                                               atol=1e-8 * np.abs(e.am).max())
+                    np.testing.assert_allclose(got["logvols"][r, j], e.logvol, rtol=0, atol=1e-9)
+                    np.testing.assert_allclose(np.sort(got["axlens"][r, j]), np.sort(e.axlens),
+                                               rtol=rtol)
+                    ax = got["axes"][r, j]
+                    np.testing.assert_allclose(ax @ ax.T, e.cov, rtol=0,
+                                               atol=1e-10 * np.abs(e.cov).max())
+            # walkers of run r use frame r * MAX_ELLS (ellipsoid 0 of the run); the oracle walks
+            # in the device's frame (its columns equal the oracle's up to LAPACK's arbitrary signs,
+            # checked through axes @ axes.T above)
+            frame = bnd["axes"][r, 0]
+            for w in range(r * nlive, r * nlive + min(walkers_per_run, nlive)):
+                rng = np.random.Generator(np.random.PCG64(kids[w]))
+                ref = P.rwalk(self.u0[w].copy(), self.loglstar, frame, self.scale,
+                              self.prob.prior_transform, self.prob.loglikelihood, rng, self.walks)
+                assert ref["accept"] == wk["accept"][w], (w, ref["accept"], wk["accept"][w])
+                assert ref["reject"] == wk["reject"][w], (w, ref["reject"], wk["reject"][w])
+                np.testing.assert_allclose(wk["u"][w], ref["u"], rtol=0, atol=1e-12)
+                np.testing.assert_allclose(wk["logl"][w], ref["logl"], rtol=1e-11)
+                nwalk += 1
+        return {"checker": "oracle/ (NumPy restatement pinned to the reference's golden vectors)",
+                "runs_checked": [int(r) for r in check_runs],
+                "ellipsoids": "nells exact; ctr 1e-13; cov/axlens/logvol 1e-9 (before and after "
+                              "the 1.25 enlargement)",
+                "walkers_checked": nwalk,
+                "walkers": "accept/reject counts exact; u 1e-12 abs; logl 1e-11 rel",
+                "ok": True}
+
+
+# --------------------------------------------------------------------------------------
+# self-launch: `python bench.py --gpus N` without torchrun
+# --------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n, argv, extra_env=None):
+    """Start n copies of this script, one per GPU (RANK = LOCAL_RANK = 0..n-1,
+    rendezvous on 127.0.0.1), wait for all of them; rank 0's stdout (the JSON line) is
+    passed through.  Returns the worst exit code."""
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n),
+                    "LOCAL_WORLD_SIZE": str(n), "MASTER_ADDR": "127.0.0.1",
+                    "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+        if extra_env:
+            env.update(extra_env)
+        out = None if r == 0 else subprocess.DEVNULL
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv,
+                                      env=env, stdout=out))
+    rc = 0
+    try:
+        for p in procs:
+            rc = max(rc, abs(p.wait()))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+def _gather_ranks(dist, torch, rank, world, device):
+    """The ensemble's exchange primitive: an all_gather across the ranks; returns the
+    number of distinct ranks that answered."""
+    t = torch.tensor([float(rank)], dtype=torch.float64, device=device)
+    out = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(out, t)
+    return len({int(x.item()) for x in out})
+
+
+def launch_selftest(args):
+    """No device work: rendezvous, barrier / max-over-ranks timing and the record gather over
+    gloo.  Exercises the multi-rank plumbing of this file on a CPU box (tests/test_bench_launch.py);
+    the line it prints says so."""
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist.init_process_group("gloo")
+    dist.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.01 * (rank + 1))
+    dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    n = _gather_ranks(dist, torch, rank, world, "cpu")
+    if rank == 0:
+        print(json.dumps({"selftest": "launch plumbing only, NO device work", "n_gpus": world,
+                          "rccl_ranks": n, "backend": "gloo", "seconds": float(t.item()),
+                          "value": None}), flush=True)
+    dist.destroy_process_group()
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--runs", type=int, default=64,
                     help="independent C2 runs per GPU (C5 shard = 64)")
     ap.add_argument("--nlive", type=int, default=2000)
     ap.add_argument("--walks", type=int, default=45)
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-rebuild", action="store_true",
                     help="time the proposal kernel alone (diagnostic)")
     ap.add_argument("--no-e2e", action="store_true",
                     help="skip the end-to-end device-loop leg (tap C)")
+    ap.add_argument("--no-verify", action="store_true",
+                    help="skip the oracle check of the timed entry points (diagnostic)")
+    ap.add_argument("--launch-selftest", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    if args.launch_selftest:
+        return launch_selftest(args)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     import torch
     dist = None
     torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl",
-                                device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
 
-    from dynesty_amd import _lib, problems
+    from dynesty_amd import _lib
     ctx = _lib.Context(local_rank)
-    lib, h = ctx.lib, ctx.handle
-    prob = problems.gauss_corr(25, 0.4, 5.0, "C2")
+    prob = c2_problem()
     d = prob.ndim
     runs, nlive = args.runs, args.nlive
-    k = runs * nlive
-    u0, loglstar = make_shard(prob, runs, nlive, 1000 + rank)
-    scale = 0.35
-    log_enlarge = math.log(1.25)
-
-    # ---- resident device buffers ----
-    d_u0 = ctx.to_device(u0)  # live sets == walker start points
-    idx = (np.arange(k, dtype=np.int32) // nlive) * MAX_ELLS
-    d_idx = ctx.to_device(idx)
-    states = ctx.seed_children([21, rank, 0, 0], 0, k)
-    d_rng = ctx.to_device(states)
-    d_rng2 = ctx.malloc(k * 32)
-    d_u, d_v = ctx.malloc(k * d * 8), ctx.malloc(k * d * 8)
-    d_logl = ctx.malloc(k * 8)
-    d_na, d_nr = ctx.malloc(k * 4), ctx.malloc(k * 4)
-    me = MAX_ELLS
-    d_nells, d_status = ctx.malloc(runs * 4), ctx.malloc(runs * 4)
-    d_ctrs = ctx.malloc(runs * me * d * 8)
-    d_covs = ctx.malloc(runs * me * d * d * 8)
-    d_ams = ctx.malloc(runs * me * d * d * 8)
-    d_axes = ctx.malloc(runs * me * d * d * 8)
-    d_axl = ctx.malloc(runs * me * d * 8)
-    d_lv = ctx.malloc(runs * me * 8)
-    ph = ctx.problem(prob)
+    sh = Shard(ctx, prob, runs, nlive, args.walks, seed=1000 + rank, entropy=(21, rank, 0, 0))
+    k = sh.k
 
     ev = [ctx.event() for _ in range(4)]
-    t_rb = t_wk = 0.0
-
-    def rebuild():
-        ctx._check(lib.dh_rebuild_batch_dev(h, runs, d_u0, nlive, d, 0, me,
-                                            d_nells, d_status, d_ctrs, d_covs,
-                                            d_ams, d_axes, d_axl, d_lv, None,
-                                            None))
-        ctx._check(lib.dh_enlarge_batch_dev(h, runs, me, d_nells, d, d_covs,
-                                            d_ams, d_axes, d_axl, d_lv,
-                                            log_enlarge))
-
-    def walk(i):
-        a, b = (d_rng, d_rng2) if i % 2 == 0 else (d_rng2, d_rng)
-        ctx._check(lib.dh_rwalk_batch_dev(h, ph, k, d, d, d_u0, d_axes,
-                                          runs * me, d_idx, scale, loglstar,
-                                          args.walks, None, a, d_u, d_v,
-                                          d_logl, d_na, d_nr, b))
-
-    def step(i, timed=False):
-        nonlocal t_rb, t_wk
-        if timed:
-            ctx.record(ev[0])
-        if not args.no_rebuild:
-            rebuild()
-        if timed:
-            ctx.record(ev[1])
-        walk(i)
-        if timed:
-            ctx.record(ev[2])
 
     def barrier():
         # own work first (the kernels run on the context's stream, which torch does not
@@ -157,14 +367,14 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    rebuild()  # frames must exist even with --no-rebuild
+    sh.rebuild()  # frames must exist even with --no-rebuild
     for i in range(args.warmup):
-        step(i)
+        sh.step(i, rebuild=not args.no_rebuild)
     barrier()
     t0 = time.perf_counter()
     ctx.record(ev[3])
     for i in range(args.steps):
-        step(i)
+        sh.step(i, rebuild=not args.no_rebuild)
     ctx.record(ev[0])
     barrier()
     wall = time.perf_counter() - t0
@@ -176,29 +386,61 @@ def main():
 
     # per-kernel durations (HIP events on the launch stream), outside the
     # timed region so the event records do not perturb it
-    nrep = 3
+    nrep = 5
+    t_rb = t_wk = 0.0
     for i in range(nrep):
-        step(i, timed=True)
+        ctx.record(ev[0])
+        if not args.no_rebuild:
+            sh.rebuild()
+        ctx.record(ev[1])
+        sh.walk(i)
+        ctx.record(ev[2])
         ctx.sync()
         t_rb += ctx.elapsed_ms(ev[0], ev[1])
         t_wk += ctx.elapsed_ms(ev[1], ev[2])
     t_rb /= nrep
     t_wk /= nrep
 
-    nacc = ctx.from_device(d_na, (k,), np.int32)
-    nrej = ctx.from_device(d_nr, (k,), np.int32)
-    status = ctx.from_device(d_status, (runs,), np.int32)
-    nells = ctx.from_device(d_nells, (runs,), np.int32)
+    wkr = sh.fetch_walk()
+    bnd = sh.fetch_bound()
+    nacc, nrej, status, nells = wkr["accept"], wkr["reject"], bnd["status"], bnd["nells"]
     assert np.all(nacc + nrej == args.walks)
     assert np.all(status == 0), status
     props_per_step_rank = k * args.walks
     value = world * props_per_step_rank * args.steps / wall
 
+    # the same interval at the queue size of the end-to-end leg (K = 512 walkers in flight per
+    # run: ceil(nlive / 512) launches of runs x 512 walkers after one rebuild) -- outside the
+    # timed region, reported beside the headline
+    kq = 512
+    nq = (nlive + kq - 1) // kq
+    tq = None
+    if not args.no_rebuild and nlive >= kq:
+        idxq = (np.arange(runs * kq, dtype=np.int32) // kq) * MAX_ELLS
+        ctx._check(ctx.lib.dh_memcpy_h2d(ctx.handle, sh.d_idx, idxq.ctypes.data, idxq.nbytes))
+        for rep in range(3):
+            if rep == 1:
+                ctx.record(ev[0])
+            for _ in range(2 if rep else 1):
+                sh.rebuild()
+                for j in range(nq):
+                    sh.walk(j, 0, runs * kq)
+        ctx.record(ev[1])
+        ctx.sync()
+        tq = ctx.elapsed_ms(ev[0], ev[1]) / 4
+        ctx._check(ctx.lib.dh_memcpy_h2d(ctx.handle, sh.d_idx, sh.idx.ctypes.data, sh.idx.nbytes))
+
+    verified = None
+    if not args.no_verify and not args.no_rebuild:
+        verified = sh.verify()  # raises on any mismatch
+
     # ensemble exchange step (C5): one record per run gathered over RCCL
+    rccl_ranks = 1
     if dist is not None:
         rec = torch.tensor(nacc.reshape(runs, -1).mean(1), device="cuda")
         out = [torch.empty_like(rec) for _ in range(world)]
         dist.all_gather(out, rec)
+        rccl_ranks = _gather_ranks(dist, torch, rank, world, dev)
 
     # ---- tap C (outside the timed region): the same shard run END TO END by the
     # device-resident nested-sampling loop, every run to dlogz = 0.01
@@ -210,7 +452,7 @@ def main():
             t0 = time.perf_counter()
             table = ensemble.run_ensemble_device(
                 prob, runs * world, base_seed=21, world=world, rank=rank,
-                dist=dist, device=torch.device("cuda", local_rank) if dist else None,
+                dist=dist, device=dev if dist else None,
                 nlive=nlive, queue_size=512, walks=args.walks,
                 rebuild_sync=rebuild_sync)
             dt = time.perf_counter() - t0
@@ -226,9 +468,10 @@ def main():
                     "logz_se": float(lz.std(ddof=1) / math.sqrt(len(lz)))}
 
         # reference bound-update schedule per run (results independent of the sharding) ...
-        e2e = {"tap_point": "C (device-resident NS loop, dh_ns_ensemble)"}
+        e2e = {"tap_point": "C (device-resident NS loop, dh_ns_ensemble)", "queue_size": 512}
         e2e.update(e2e_leg(False))
-        e2e.update({"logz_reference_seed21": -57.4541, "logz_truth": -57.5646,
+        e2e.update(reference_logz_gate())
+        e2e.update({"logz_truth": -57.5646,
                     "gather": "RCCL all_gather of 6 doubles per run" if dist else
                               "single process"})
         # ... and with the ensemble's rebuilds synchronised (early, never late)
@@ -239,17 +482,21 @@ def main():
         flops = 2 * d * d + 8 * d + (d * d + 3 * d)  # frame mat-vec + sym. quad form
         achieved = props_per_step_rank * alg_bytes / (t_wk * 1e-3) / 1e9
         traffic, traffic_src, traffic_rb = None, None, None
-        pmc = os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")
-        if os.path.exists(pmc) and runs == 64 and nlive == 2000 and args.walks == 45:
-            # PMC counters cannot be read from inside this process; the values are
-            # the committed rocprofv3 measurement of this same launch shape
-            # (tools/pmc_traffic.py: 2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes)
-            with open(pmc) as f:
-                pj = json.load(f)
-            traffic = pj["kernels"]["rwalk_kernel<25, true, 1>"]["traffic_bytes_per_launch"]
-            traffic_rb = pj["rebuild_pipeline_bytes_per_launch_sequence"]
-            traffic_src = ("profiles/r01/pmc_traffic.json (2*FETCH_SIZE + WRITE_SIZE, "
-                           "separate --pmc passes)")
+        for rnd in ("r02", "r01"):
+            pmc = os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json")
+            if os.path.exists(pmc) and runs == 64 and nlive == 2000 and args.walks == 45:
+                # PMC counters cannot be read from inside this process; the values are
+                # the committed rocprofv3 measurement of this same launch shape
+                # (tools/pmc_traffic.py: 2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes)
+                with open(pmc) as f:
+                    pj = json.load(f)
+                kk = [x for x in pj["kernels"] if x.startswith("rwalk_kernel<25")]
+                if kk:
+                    traffic = pj["kernels"][kk[0]]["traffic_bytes_per_launch"]
+                traffic_rb = pj.get("rebuild_pipeline_bytes_per_launch_sequence")
+                traffic_src = (f"profiles/{rnd}/pmc_traffic.json (2*FETCH_SIZE + WRITE_SIZE, "
+                               "separate --pmc passes)")
+                break
         line = {
             "metric": "proposals/sec + ellipsoid-rebuilds/sec, 25-D corr-Normal "
                       "nlive=2000 (multi/rwalk)",
@@ -264,11 +511,13 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
+            "rccl_ranks": rccl_ranks,
             "config": {
                 "workload": f"C2 x {runs} independent runs per GPU (C5 shard); "
                             f"per step and run: 1 MultiEllipsoid rebuild + "
                             f"enlarge 1.25 + K={nlive} walkers x {args.walks} "
-                            f"rwalk steps (= one bound-update interval)",
+                            f"rwalk steps (= one bound-update interval); live sets "
+                            f"uniform inside the likelihood contour",
                 "ndim": d, "nlive": nlive, "walks": args.walks,
                 "runs_per_gpu": runs, "tap_point": "A (kernel boundary)",
                 "rebuild_in_step": not args.no_rebuild,
@@ -282,6 +531,8 @@ def main():
                     world * runs / (t_rb * 1e-3) if t_rb > 0 else None,
                 "nells_per_run": float(nells.mean()),
                 "accept_frac": float(nacc.sum() / (k * args.walks)),
+                "rng": "PCG64 + ziggurat, stream-identical to numpy.random.Generator (parity mode)",
+                "verified": verified,
             },
             "roofline": {
                 "bound": "hbm", "kernel": "rwalk_kernel<25,true,PREC_AFFINE>",
@@ -298,6 +549,11 @@ def main():
                     "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s"},
             },
         }
+        if tq is not None:
+            line["config"]["interval_at_queue_512"] = {
+                "what": f"the same bound-update interval flown as {nq} launches of {runs} x {kq} "
+                        f"walkers after one rebuild (queue size of the end-to-end leg)",
+                "ms": tq, "proposals_per_s": world * runs * kq * nq * args.walks / (tq * 1e-3)}
         if not args.no_rebuild and t_rb > 0:
             # the rebuild pipeline (k_root / k_split / k_ell / k_finish) takes most of the
             # step; SURVEY 8d prices it at 8*N*D*P bytes with P = 62 dependency-ordered
@@ -306,13 +562,13 @@ def main():
             rb_bytes = 8.0 * nlive * d * 62 * runs
             rb_gbs = rb_bytes / (t_rb * 1e-3) / 1e9
             line["roofline_rebuild"] = {
-                "bound": "hbm", "kernel": "k_root + 20 x (k_split, k_ell) + k_finish",
+                "bound": "hbm", "kernel": "k_root + levels x (k_split, k_ell) + k_finish",
                 "achieved": rb_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": rb_gbs / HBM_PEAK_GBS, "traffic": traffic_rb,
                 "traffic_unit": "bytes per launch sequence (64 runs)",
                 "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": rb_bytes, "kernel_ms": t_rb,
-                "note": "a tree of ~49 nodes per run built level by level (critical path: "
+                "note": "a tree of ~55 nodes per run built level by level (critical path: "
                         "6 levels x [k-means, covariance, 25x25 Jacobi eigensolve, "
                         "Mahalanobis max]); latency-bound, not bandwidth-bound: the "
                         "k-means parts keep their points resident in LDS, so the live "
@@ -320,46 +576,98 @@ def main():
         if e2e is not None:
             line["config"]["end_to_end"] = e2e
         if not args.no_cpu and world == 1:  # the CPU baseline is timed on rank 0 at N = 1 only
-            line["cpu_baseline"] = cpu_baseline(prob, u0, nlive, scale,
-                                                loglstar, args.walks,
-                                                args.cpu_seconds)
-        print(json.dumps(line))
+            line["cpu_baseline"] = cpu_baseline(prob, sh.u0, nlive, sh.scale, sh.loglstar,
+                                                args.walks, args.cpu_seconds)
+        print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 
 
+def reference_logz_gate():
+    """The real reference's C2 ensembles (tests/golden/c2_logz_ref.json, generated in the build
+    container by tools/ref_c2_runs.py) at the queue size of the end-to-end leg."""
+    p = os.path.join(ROOT, "tests", "golden", "c2_logz_ref.json")
+    if not os.path.exists(p):
+        return {"logz_reference_seed21": -57.4541}
+    with open(p) as f:
+        g = json.load(f)
+    out = {"logz_reference_seed21_K1": -57.4541}
+    for key, e in g.get("ensembles", {}).items():
+        out[f"logz_reference_{key}"] = {"mean": e["mean"], "se": e["se"], "n": e["n"]}
+    return out
+
+
+def _cpu_walk_worker(job):
+    """One host core: oracle rwalk walkers for `budget_s` seconds (spawned process)."""
+    seed, u0, loglstar, axes, scale, walks, budget_s = job
+    sys.path.insert(0, ROOT)
+    from oracle import proposals_ref as P
+    prob = c2_problem()
+    kids = np.random.SeedSequence(seed).spawn(200000)
+    t0 = time.perf_counter()
+    n = 0
+    while time.perf_counter() - t0 < budget_s:
+        rng = np.random.Generator(np.random.PCG64(kids[n]))
+        P.rwalk(u0[n % len(u0)].copy(), loglstar, axes, scale, prob.prior_transform,
+                prob.loglikelihood, rng, walks)
+        n += 1
+    return n, time.perf_counter() - t0
+
+
 def cpu_baseline(prob, u0, nlive, scale, loglstar, walks, budget_s):
     """The oracle (NumPy restatement of the reference's MultiEllipsoid.update +
-    RWalkSampler.sample) timed on one host core on a bounded sample of the same
+    RWalkSampler.sample) timed on the host cores on a bounded sample of the same
     workload: one rebuild of run 0's live set, then walkers until the budget is
     spent; proposals/s is scaled to the reference cadence of one rebuild per
-    nlive*walks proposals."""
+    nlive*walks proposals.  First on one core (the reference's serial path, the
+    primary figure), then on all host cores as independent single-core workers
+    (the ensemble mode of SURVEY.md section 8d)."""
+    import multiprocessing as mp
     from oracle import bounding_ref as B
-    from oracle import proposals_ref as P
+    os.environ.setdefault("OMP_NUM_THREADS", "1")
     pts = u0[:nlive]
     t0 = time.perf_counter()
     mell = B.multi_update(pts)
     mell = B.scale_multi_to_logvol(mell, mell.logvol + math.log(1.25))
     t_rebuild = time.perf_counter() - t0
     axes = mell.ells[0].axes
-    kids = np.random.SeedSequence(99).spawn(100000)
-    t0 = time.perf_counter()
-    n = 0
-    while time.perf_counter() - t0 < budget_s:
-        rng = np.random.Generator(np.random.PCG64(kids[n]))
-        P.rwalk(u0[n % len(u0)].copy(), loglstar, axes, scale,
-                prob.prior_transform, prob.loglikelihood, rng, walks)
-        n += 1
-    dt = time.perf_counter() - t0
+    sample = u0[:4096]
+    n, dt = _cpu_walk_worker((99, sample, loglstar, axes, scale, walks, budget_s * 0.6))
     per_prop = dt / (n * walks)
     combined = 1.0 / (per_prop + t_rebuild / (nlive * walks))
-    return {"value": combined, "unit": "proposals/s", "cores": 1,
-            "kind": "port",
-            "rebuilds_per_s": 1.0 / t_rebuild,
-            "proposals_per_s_walk_only": 1.0 / per_prop,
-            "sample": f"1 rebuild of a {nlive}x{prob.ndim} live set "
-                      f"({t_rebuild * 1e3:.0f} ms) + {n} walkers x {walks} steps "
-                      f"({dt:.1f} s), oracle/ (NumPy/SciPy restatement), 1 thread"}
+    out = {"value": combined, "unit": "proposals/s", "cores": 1,
+           "kind": "port",
+           "rebuilds_per_s": 1.0 / t_rebuild,
+           "proposals_per_s_walk_only": 1.0 / per_prop,
+           "sample": f"1 rebuild of a {nlive}x{prob.ndim} live set "
+                     f"({t_rebuild * 1e3:.0f} ms) + {n} walkers x {walks} steps "
+                     f"({dt:.1f} s), oracle/ (NumPy/SciPy restatement), 1 thread",
+           "reference_figure": {
+               "proposals_per_s": REFERENCE_C2_PROPOSALS_PER_S_1CORE,
+               "rebuilds_per_s": REFERENCE_C2_REBUILDS_PER_S_1CORE, "cores": 1,
+               "note": "the real dynesty 3.0.0 on C2, measured in the build container (SURVEY.md "
+                       "section 6); it cannot travel to the GPU box, so the port above is what "
+                       "is timed here -- the port is the faster of the two"}}
+    ncores = os.cpu_count() or 1
+    if ncores > 1:
+        try:
+            mpc = mp.get_context("spawn")
+            with mpc.Pool(ncores) as pool:
+                t0 = time.perf_counter()
+                res = pool.map(_cpu_walk_worker,
+                               [(1000 + i, sample, loglstar, axes, scale, walks, budget_s * 0.4)
+                                for i in range(ncores)])
+                wall = time.perf_counter() - t0
+            rate = sum(r[0] for r in res) * walks / max(r[1] for r in res)
+            out["all_cores"] = {
+                "value": 1.0 / (1.0 / rate + t_rebuild / (nlive * walks) / ncores),
+                "unit": "proposals/s", "cores": ncores,
+                "sample": f"{ncores} independent single-core workers x {budget_s * 0.4:.1f} s of "
+                          f"oracle rwalk walkers ({sum(r[0] for r in res)} walkers, pool wall "
+                          f"{wall:.1f} s incl. start-up); rebuild cost spread over the cores"}
+        except Exception as exc:  # the all-cores leg is auxiliary: never lose the line
+            out["all_cores"] = {"error": repr(exc)}
+    return out
 
 
 if __name__ == "__main__":

@@ -643,6 +643,12 @@ class Context:
         (early, never late): fewer, fuller rebuild launches, but a run's
         schedule then depends on its shard mates."""
         nd = prob.ndim
+        if bound not in ('multi', 'single'):
+            raise ValueError(f"ns_ensemble: bound={bound!r} is not supported by the device-resident "
+                             "loop ('multi' or 'single'; balls / cubes: nested.run_static)")
+        if sample not in ('rwalk', 'rslice', 'slice'):
+            raise ValueError(f"ns_ensemble: sample={sample!r} is not supported by the "
+                             "device-resident loop ('rwalk', 'rslice' or 'slice')")
         kind = dict(rwalk=0, rslice=1, slice=2)[sample]
         if kind == 0:
             if walks is None:

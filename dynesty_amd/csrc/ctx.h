@@ -13,6 +13,10 @@
 // instantiated for a fixed list of padded dimensions.
 #define DH_DIM_LIST(X) X(1) X(2) X(3) X(4) X(5) X(6) X(8) X(10) X(12) X(16) X(20) X(25) X(32)
 constexpr int kMaxRegDim = 32;
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute: the memo of what was already
+// set is kept per device ordinal (a process may hold contexts on several GPUs)
+constexpr int kMaxDev = 64;
+#define DH_DEV_MEMO(name) static size_t name##_dev[kMaxDev] = {}; size_t& name = name##_dev[ctx->device & (kMaxDev - 1)]
 inline int pad_dim(int n) {
 #define X(NN) \
   if (n <= NN) return NN;

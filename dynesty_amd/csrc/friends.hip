@@ -498,7 +498,7 @@ int dh_friends_update(dh_ctx* ctx, const double* pts, int n, int d, int kind, co
     // clusters: single linkage cut at Mahalanobis distance 1 in the previous metric
     const size_t lds_adj = (dd + 4 * ((size_t)d + (size_t)d * 64)) * 8;
     if (lds_adj > 159 * 1024) return fail(ctx, DH_ERR_ARG, "friends_update: clustering needs d <= 60 (d = %d)", d);
-    static size_t attr_adj = 0;
+    DH_DEV_MEMO(attr_adj);
     if (lds_adj > attr_adj) {
       if (!hip_ok(ctx, hipFuncSetAttribute((const void*)fr_adjacency, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)lds_adj), "hipFuncSetAttribute(fr_adjacency)"))

@@ -313,10 +313,12 @@ __global__ void __launch_bounds__(kT) ns_prepare(NsArgs a) {
 }
 
 // ---- queue fill: start points, frames, walker streams ---------------------------
+constexpr int kMaxCum = 4096;  // ellipsoids per run the frame choice can weigh (32 KB of LDS)
 __global__ void __launch_bounds__(kT) ns_select(NsArgs a) {
   __shared__ uint64_t ent[4];
-  __shared__ double cum[64];
+  __shared__ double cum[kMaxCum];  // rand_choice weights of ALL ellipsoids of the run (bounding.py:726-731)
   __shared__ int Msh;
+  __shared__ double mxs;
   const int run = blockIdx.x, t = threadIdx.x;
   const int N = a.nlive, D = a.ndim, K = a.K;
   NsRun& r = a.st[run];
@@ -331,22 +333,30 @@ __global__ void __launch_bounds__(kT) ns_select(NsArgs a) {
     g.store(r.rng);
     if (mode == MODE_BOUND && a.bound_multi) {
       M = a.nells[run];
-      if (M > 64) M = 64;
-      // rand_choice weights: cumsum(exp(logvol_ells - logsumexp))
+      if (M > kMaxCum) M = kMaxCum;  // unreachable: dh_ns_ensemble refuses max_ells > kMaxCum
       double mx = -INFINITY;
       for (int e = 0; e < M; ++e) mx = fmax(mx, a.b_lv[(size_t)run * a.max_ells + e]);
-      double s = 0.0;
-      for (int e = 0; e < M; ++e) s += exp(a.b_lv[(size_t)run * a.max_ells + e] - mx);
-      double c = 0.0;
-      for (int e = 0; e < M; ++e) {
-        c += exp(a.b_lv[(size_t)run * a.max_ells + e] - mx) / s;
-        cum[e] = c;
-      }
+      mxs = mx;
     }
     Msh = M;
   }
   __syncthreads();
   M = Msh;
+  if (M > 1) {
+    // cumsum(exp(logvol_ells - logsumexp)): the exponentials on all threads, the running sum by one
+    for (int e = t; e < M; e += kT) cum[e] = exp(a.b_lv[(size_t)run * a.max_ells + e] - mxs);
+    __syncthreads();
+    if (t == 0) {
+      double c = 0.0;
+      for (int e = 0; e < M; ++e) {
+        c += cum[e];
+        cum[e] = c;
+      }
+      const double inv = 1.0 / c;
+      for (int e = 0; e < M; ++e) cum[e] *= inv;
+    }
+    __syncthreads();
+  }
   const double loglstar = r.loglstar;
   for (int w = t; w < K; w += kT) {
     Pcg64 g;
@@ -366,8 +376,14 @@ __global__ void __launch_bounds__(kT) ns_select(NsArgs a) {
       double* dst = a.q_u0 + q * D;
       for (int j = 0; j < D; ++j) dst[j] = src[j];
       if (M > 1) {
+        // min(searchsorted(cum, xr), M - 1): first index with cum[i] >= xr
         const double xr = g.next_double();
-        while (frame < M - 1 && cum[frame] < xr) ++frame;
+        int lo = 0, hi = M - 1;
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          if (cum[mid] < xr) lo = mid + 1; else hi = mid;
+        }
+        frame = lo;
       }
     }
     a.q_frame[q] = run * a.max_ells + frame;
@@ -861,16 +877,16 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
   const size_t lds_cons = (size_t)heap_cap(N) * 16 + (size_t)N * 4 + (size_t)K * 32 + 64;
   if (K > kEPT * kT) return cleanup(fail(ctx, DH_ERR_ARG, "ns_ensemble: queue_size %d > %d", K, kEPT * kT));
   if (lds_cons > 150 * 1024) return cleanup(fail(ctx, DH_ERR_ARG, "ns_ensemble: nlive/queue too large for LDS"));
-  static size_t attr = 0;
   const size_t lds_max = lds_cons > lds_heap ? lds_cons : lds_heap;
   if (lds_max > 150 * 1024) return cleanup(fail(ctx, DH_ERR_ARG, "ns_ensemble: nlive/queue too large for LDS"));
-  if (lds_max > attr) {
-    (void)hipFuncSetAttribute((const void*)ns_consume, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
-    (void)hipFuncSetAttribute((const void*)ns_heapify, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
-    (void)hipFuncSetAttribute((const void*)ns_finish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
-    attr = lds_max;
-  }
+  if (me > kMaxCum) return cleanup(fail(ctx, DH_ERR_ARG, "ns_ensemble: nlive/(2 ndim) = %d ellipsoids > %d", me, kMaxCum));
+  // the attribute is per device (and the call is cheap): set it on every call, on this context's device
+  if (!hip_ok(ctx, hipFuncSetAttribute((const void*)ns_consume, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max), "hipFuncSetAttribute(ns_consume)") ||
+      !hip_ok(ctx, hipFuncSetAttribute((const void*)ns_heapify, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max), "hipFuncSetAttribute(ns_heapify)") ||
+      !hip_ok(ctx, hipFuncSetAttribute((const void*)ns_finish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max), "hipFuncSetAttribute(ns_finish)"))
+    return cleanup(DH_ERR_HIP);
   hipLaunchKernelGGL(ns_heapify, dim3(R), dim3(kT), lds_heap, s, a);
+  if (!hip_ok(ctx, hipGetLastError(), "ns_heapify launch")) return cleanup(DH_ERR_HIP);
   const int64_t fills_cap = max_fills > 0 ? max_fills : 1000000;
   int64_t fill = 0;
   int ndone = 0;

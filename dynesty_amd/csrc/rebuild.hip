@@ -2002,7 +2002,7 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
   a.nnodes_out = nnodes;
   a.active = active;
   a.n_arr = n_arr;
-  static size_t attr_lds = 0;
+  DH_DEV_MEMO(attr_lds);
   if (lds > attr_lds) {
     const void* ks[3] = {(const void*)k_root_parts, (const void*)k_split, (const void*)k_ell};
     for (const void* kf : ks)
@@ -2011,7 +2011,7 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
         return DH_ERR_HIP;
     attr_lds = lds;
   }
-  static size_t attr_fin = 0;
+  DH_DEV_MEMO(attr_fin);
   if (lds_fin > attr_fin) {
     if (!hip_ok(ctx, hipFuncSetAttribute((const void*)k_finish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fin),
                 "hipFuncSetAttribute(k_finish LDS)"))
@@ -2099,7 +2099,7 @@ int dh_ell_from_cov(dh_ctx* ctx, int m, int d, const double* covs, double* axes,
   int* d_st = (int*)arena_get(ctx, (size_t)m * 4);
   if (!d_c || !d_ax || !d_am || !d_al || !d_lv || !d_st) return DH_ERR_NOMEM;
   const double pre = d * log(2.0) + d * lgamma(1.5) - lgamma(d / 2.0 + 1.0);
-  static size_t attr_lds = 0;
+  DH_DEV_MEMO(attr_lds);
   if (lds > attr_lds) {
     if (!hip_ok(ctx,
                 hipFuncSetAttribute((const void*)ell_from_cov_kernel,

@@ -2179,7 +2179,8 @@ int wide_walk_launch(dh_ctx* ctx, int kind, int problem, int k, int ndim, int nc
   if (const char* e = getenv("DH_WIDE_WPW")) wpw = std::max(1, std::min(wpw, atoi(e)));
   wpw = std::max(1, std::min(wpw, k));
   const size_t lds = per_wave * wpw;
-  static size_t lds_attr[4] = {0, 0, 0, 0};
+  static size_t lds_attr_dev[kMaxDev][4] = {};
+  size_t* lds_attr = lds_attr_dev[ctx->device & (kMaxDev - 1)];
   const int kk = kind < 0 || kind > 3 ? 3 : kind;
   if (lds > lds_attr[kk]) {
     const void* fn = kk == 0   ? (const void*)wide_walk_kernel<0>
@@ -2352,7 +2353,9 @@ static int wide_single_enqueue(dh_ctx* ctx, int runs, const double* pts, int n, 
   const int LD = d | 1;
   const size_t lds_part = ((size_t)tp * LD + d + 64 + (size_t)((d + 15) / 16) * 64) * 8;
   const size_t lds_mean = (size_t)std::max(1, kRT / d) * d * 8;
-  static size_t attr_lds = 0, attr_eig = 0, attr_part = 0;
+  DH_DEV_MEMO(attr_lds);
+  DH_DEV_MEMO(attr_eig);
+  DH_DEV_MEMO(attr_part);
   if (lds > attr_lds) {
     if (!hip_ok(ctx,
                 hipFuncSetAttribute((const void*)wide_single_kernel,

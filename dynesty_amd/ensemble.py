@@ -115,11 +115,16 @@ def run_ensemble(prob, total_runs, base_seed=21, world=1, rank=0, dist=None,
 
 def run_ensemble_device(prob, total_runs, base_seed=21, world=1, rank=0,
                         dist=None, device=None, nlive=2000, queue_size=512,
-                        walks=None, bound='multi', dlogz=0.01, **kw):
+                        walks=None, bound='multi', dlogz=0.01, on_failure='raise', **kw):
     """BASELINE config C5: this rank's shard of `total_runs` static runs executed
     by the device-resident loop (`dh_ns_ensemble`, one launch sequence for the
     whole shard), then the RCCL all-gather of the per-run records.  Seeds are
-    keyed on the global run id, so the table does not depend on `world`."""
+    keyed on the global run id, so the table does not depend on `world`.
+    on_failure: 'raise' (default) or 'nan' -- what to do with a run whose status is
+    not 0; with 'nan' its ln Z / error / information are NaN in the table and
+    `combine_logz` leaves it out."""
+    if on_failure not in ('raise', 'nan'):
+        raise ValueError("on_failure must be 'raise' or 'nan'")
     from .backend import get_backend
     mine = shard_runs(total_runs, world, rank)
     local = np.zeros((0, len(RECORD_FIELDS)))
@@ -128,11 +133,36 @@ def run_ensemble_device(prob, total_runs, base_seed=21, world=1, rank=0,
                                       walks=walks, bound=bound, dlogz=dlogz,
                                       entropy=np.atleast_1d(base_seed),
                                       first_run=mine.start, **kw)
+        bad = np.flatnonzero(np.asarray(r["status"]) != 0)
+        if len(bad):
+            # a failed run (bound rebuild error, dead-point capacity) or one that hit max_fills
+            # before dlogz must never enter the table as a valid ln Z estimate
+            if on_failure == 'raise':
+                raise RuntimeError(
+                    f"ns_ensemble: runs {[int(mine.start + b) for b in bad]} ended with status "
+                    f"{[int(r['status'][b]) for b in bad]} (1 = not converged within max_fills, "
+                    f"< 0 = failed)")
+            for key in ("logz", "logzerr", "h"):
+                r[key] = np.array(r[key], dtype=np.float64)
+                r[key][bad] = np.nan
         local = np.stack([np.arange(mine.start, mine.stop, dtype=np.float64),
                           r["logz"], r["logzerr"], r["niter"].astype(float),
                           r["ncall"].astype(float), r["h"]], axis=1)
     return gather_records(local, total_runs, world, rank, dist=dist,
                           device=device)
+
+
+def combine_logz(table):
+    """Ensemble estimate from the gathered record table: mean and standard error of the
+    per-run ln Z over the runs that completed (failed runs carry NaN, see
+    run_ensemble_device(on_failure='nan')).  Returns (mean, se, n_used)."""
+    lz = np.asarray(table)[:, RECORD_FIELDS.index("logz")]
+    ok = np.isfinite(lz)
+    n = int(ok.sum())
+    if n == 0:
+        raise RuntimeError("combine_logz: no completed run in the table")
+    se = float(lz[ok].std(ddof=1) / np.sqrt(n)) if n > 1 else float('nan')
+    return float(lz[ok].mean()), se, n
 
 
 class MergedRun(dict):
@@ -309,10 +339,3 @@ def run_ensemble_merged_sharded(prob, total_runs, base_seed=21, world=1, rank=0,
         return be.problem_eval(prob, u)[0]
     return gather_and_merge(rows, nlive, world, rank, dist=dist, device=device,
                             prior_transform=ptform, ncall=[ncall])
-
-
-def combine_logz(table):
-    """Ensemble estimate: mean of ln Z over runs and its standard error."""
-    lz = table[:, RECORD_FIELDS.index("logz")]
-    return float(lz.mean()), float(lz.std(ddof=1) / np.sqrt(len(lz))) \
-        if len(lz) > 1 else float("nan")

@@ -81,15 +81,28 @@ class _Streams:
 
 
 def _frames(args):
-    """Unique proposal frames (by identity, then value) + index per walker."""
-    uniq, ids, idx = [], {}, np.empty(len(args), dtype=np.int32)
+    """Unique proposal frames + index per walker.  Frames are deduplicated first by
+    the memory they view (HipMultiEllipsoid.get_random_axes hands out a fresh ndarray
+    view of `axes_ells[i]` per call: same data pointer, different `id`), then by value,
+    so a fill uploads one frame per ellipsoid, not one per walker."""
+    uniq, by_mem, by_val = [], {}, {}
+    idx = np.empty(len(args), dtype=np.int32)
     for i, a in enumerate(args):
-        key = id(a.axes)
-        j = ids.get(key)
+        ax = a.axes
+        if isinstance(ax, np.ndarray):
+            key = (ax.__array_interface__['data'][0], ax.shape, ax.strides, ax.dtype.str)
+        else:
+            key = ('id', id(ax))
+        j = by_mem.get(key)
         if j is None:
-            j = len(uniq)
-            ids[key] = j
-            uniq.append(np.asarray(a.axes, dtype=np.float64))
+            arr = np.ascontiguousarray(ax, dtype=np.float64)
+            vkey = (arr.shape, arr.tobytes())
+            j = by_val.get(vkey)
+            if j is None:
+                j = len(uniq)
+                by_val[vkey] = j
+                uniq.append(arr)
+            by_mem[key] = j
         idx[i] = j
     return np.stack(uniq), (None if len(uniq) == 1 else idx)
 

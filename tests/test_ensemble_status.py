@@ -1,0 +1,52 @@
+"""run_ensemble_device must not average failed / unconverged runs into the ensemble ln Z
+(records carry the device loop's status)."""
+import numpy as np
+import pytest
+
+from dynesty_amd import backend, ensemble, _lib
+
+
+class FakeBackend:
+    """Stands in for the HIP context: returns a canned dh_ns_ensemble result."""
+
+    def __init__(self, status):
+        self.status = np.asarray(status)
+
+    def ns_ensemble(self, prob, runs, nlive, queue_size, **kw):
+        assert runs == len(self.status)
+        return dict(logz=np.linspace(-57.6, -57.4, runs), logzerr=np.full(runs, 0.1),
+                    niter=np.full(runs, 80000), ncall=np.full(runs, 3500000),
+                    h=np.full(runs, 28.0), status=self.status)
+
+
+def test_failed_runs_raise_or_are_masked():
+    backend.set_backend(FakeBackend([0, 0, -2, 1]))
+    try:
+        with pytest.raises(RuntimeError, match="status"):
+            ensemble.run_ensemble_device(None, 4)
+        table = ensemble.run_ensemble_device(None, 4, on_failure='nan')
+        assert np.isnan(table[2:, 1]).all() and np.isfinite(table[:2, 1]).all()
+        mean, se, n = ensemble.combine_logz(table)
+        assert n == 2 and np.isclose(mean, table[:2, 1].mean())
+        with pytest.raises(ValueError):
+            ensemble.run_ensemble_device(None, 4, on_failure='ignore')
+    finally:
+        backend.set_backend(None)
+    backend.set_backend(FakeBackend([0, 0, 0]))
+    try:
+        table = ensemble.run_ensemble_device(None, 3)
+        assert ensemble.combine_logz(table)[2] == 3
+    finally:
+        backend.set_backend(None)
+
+
+def test_ns_ensemble_rejects_unsupported_bound_and_sampler():
+    """The device-resident loop knows 'multi' / 'single' and rwalk / rslice / slice only; anything
+    else must raise instead of silently running a single ellipsoid."""
+    ctx = _lib.Context.__new__(_lib.Context)  # no device needed: validation comes first
+
+    class P:
+        ndim = 3
+    for kw in (dict(bound='balls'), dict(bound='cubes'), dict(sample='unif'), dict(bound='none')):
+        with pytest.raises(ValueError, match="not supported"):
+            _lib.Context.ns_ensemble(ctx, P(), 2, 100, 16, **kw)

@@ -155,3 +155,32 @@ def test_ziggurat_tail_vs_numpy():
     got = np.array([normal(p, ki, wi, fi) for _ in range(120000)])
     assert np.abs(want).max() > R  # the tail branch was exercised
     np.testing.assert_array_equal(got, want)
+
+
+def test_frames_dedupe_by_memory_and_value():
+    """samplers._frames: HipMultiEllipsoid.get_random_axes returns a fresh view of
+    axes_ells[i] per call -- a fill over nells ellipsoids must upload <= nells frames."""
+    from types import SimpleNamespace
+    from dynesty_amd import samplers
+    from dynesty_amd.bounding import HipMultiEllipsoid
+    rng = np.random.default_rng(3)
+    nells, d = 3, 4
+    covs = np.array([np.eye(d) * (0.01 * (i + 1)) for i in range(nells)])
+    ctrs = np.full((nells, d), 0.5) + 0.1 * np.arange(nells)[:, None]
+    m = HipMultiEllipsoid.__new__(HipMultiEllipsoid)
+    m.axes_ells = np.array([np.linalg.cholesky(c) for c in covs])
+    m.logvol_ells = np.log(np.arange(1., nells + 1))
+    m.logvol = float(np.log(np.exp(m.logvol_ells).sum()))
+    args = [SimpleNamespace(axes=m.get_random_axes(rng)) for _ in range(200)]
+    assert len({id(a.axes) for a in args}) == 200  # fresh views: identity is useless
+    frames, idx = samplers._frames(args)
+    assert len(frames) <= nells and idx is not None
+    for a, j in zip(args, idx):
+        np.testing.assert_array_equal(frames[j], a.axes)
+    # equal by value only (separate copies) also collapses
+    args = [SimpleNamespace(axes=m.axes_ells[i % nells].copy()) for i in range(50)]
+    frames, idx = samplers._frames(args)
+    assert len(frames) == nells
+    # a single frame -> no index array
+    frames, idx = samplers._frames([SimpleNamespace(axes=m.axes_ells[0])] * 5)
+    assert len(frames) == 1 and idx is None

@@ -428,6 +428,61 @@ def gen_wide(out):
     print("wrote", out, len(g), "arrays")
 
 
+class _Enough(Exception):
+    pass
+
+
+def gen_livesets(out):
+    """Live sets captured from REAL reference runs ("live sets captured from
+    the oracle at fixed iterations, so shapes and distributions are real"), together with what the
+    reference's own MultiEllipsoid.update made of them.  C2 (25-D, nlive 2000, multi/rwalk): bound
+    updates number 1, 8 and 24 of the seed-21 run; C3 (eggbox, nlive 5000, multi/rslice): updates
+    1, 6 and 16.  Uniform-in-contour shells, not Gaussian clouds: different fmax / k-means behaviour."""
+    import dynesty
+    from dynesty import bounding as db
+    import inputs
+    g = {}
+    for tag, pname, nlive, sample, picks in (("C2", "C2", 2000, "rwalk", (1, 8, 24)),
+                                             ("C3", "C3", 5000, "rslice", (1, 6, 16))):
+        prob = inputs.problem(pname)
+        taken = []
+        orig = db.MultiEllipsoid.update
+
+        def spy(self, points, *a, **kw):
+            spy.n += 1
+            pts = np.array(points)
+            r = orig(self, points, *a, **kw)
+            if spy.n in picks:
+                taken.append((spy.n, pts, np.array(self.ctrs), np.array(self.covs),
+                              np.array(self.logvol_ells), float(self.logvol)))
+            if spy.n >= max(picks):
+                raise _Enough
+            return r
+        spy.n = 0
+        db.MultiEllipsoid.update = spy
+        try:
+            s = dynesty.NestedSampler(prob.loglikelihood, prob.prior_transform, prob.ndim,
+                                      nlive=nlive, bound='multi', sample=sample,
+                                      rstate=np.random.default_rng(21))
+            try:
+                s.run_nested(dlogz=0.01, print_progress=False)
+            except _Enough:
+                pass
+        finally:
+            db.MultiEllipsoid.update = orig
+        for i, (n, pts, ctrs, covs, lve, lv) in enumerate(taken):
+            g[f"{tag}/{i}/update_no"] = np.int64(n)
+            g[f"{tag}/{i}/live_u"] = pts
+            g[f"{tag}/{i}/nells"] = np.int64(len(ctrs))
+            g[f"{tag}/{i}/ctrs"] = ctrs
+            g[f"{tag}/{i}/covs"] = covs
+            g[f"{tag}/{i}/logvol_ells"] = lve
+            g[f"{tag}/{i}/logvol"] = np.float64(lv)
+            print(tag, i, "update", n, "nells", len(ctrs), "logvol", lv, flush=True)
+    np.savez_compressed(out, **g)
+    print("wrote", out, len(g), "arrays")
+
+
 if __name__ == "__main__":
     import_reference()
     gdir = os.path.join(ROOT, "tests", "golden")
@@ -445,3 +500,5 @@ if __name__ == "__main__":
         gen_friends(os.path.join(gdir, "friends.npz"))
     if "wide" in which:
         gen_wide(os.path.join(gdir, "wide.npz"))
+    if "livesets" in which:  # not in the default list: two partial reference runs (minutes)
+        gen_livesets(os.path.join(gdir, "livesets.npz"))
