@@ -50,6 +50,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 FP64_PEAK_TFLOPS = 78.6  # vector fp64 (datasheet)
 MAX_ELLS = 8
+RWALK_SCALE = 0.27  # acceptance ~0.5 on the contour shells: the reference's tuned state (facc = 0.5)
 # the REAL dynesty 3.0.0 on C2, one core of the build container (it cannot
 # travel to the GPU box: /root/reference does not exist there)
 REFERENCE_C2_PROPOSALS_PER_S_1CORE = 44.0e3
@@ -87,7 +88,7 @@ class Shard:
     dh_rwalk_batch_dev).  tests/test_gpu_bench_shape.py drives the same object."""
 
     def __init__(self, ctx, prob, runs=64, nlive=2000, walks=45, seed=1000,
-                 scale=0.27, entropy=(21, 0, 0, 0)):
+                 scale=RWALK_SCALE, entropy=(21, 0, 0, 0)):
         self.ctx, self.prob = ctx, prob
         self.runs, self.nlive, self.walks, self.scale = runs, nlive, walks, scale
         self.d = d = prob.ndim
@@ -200,7 +201,9 @@ class Shard:
         for r in check_runs:
             pts = self.u0[r * nlive:(r + 1) * nlive]
             m0 = B.multi_update(pts)
-            m1 = B.scale_multi_to_logvol(m0, m0.logvol + self.log_enlarge)
+            # scale_multi_to_logvol works in place on the Ell records: scale a copy
+            m1 = B.scale_multi_to_logvol(B.stack_ells([e.copy() for e in m0.ells]),
+                                         m0.logvol + self.log_enlarge)
             for got, ref in ((plain, m0), (bnd, m1)):
                 assert int(got["nells"][r]) == ref.nells, (r, got["nells"][r], ref.nells)
                 order = [int(np.argmin(np.linalg.norm(got["ctrs"][r, :ref.nells] - e.ctr, axis=1)))
@@ -340,6 +343,14 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    prob = c2_problem()
+    # CPU baseline first, while this process holds no HIP / torch state: the all-cores leg forks
+    # its workers (256 spawned interpreters took 30 s to start on the GPU box's host)
+    cpu = None
+    if not args.no_cpu and world == 1 and rank == 0:
+        u0c, loglstar_c = make_shard(prob, args.runs, args.nlive, 1000 + rank)
+        cpu = cpu_baseline(prob, u0c, args.nlive, RWALK_SCALE, loglstar_c, args.walks, args.cpu_seconds)
+        del u0c
     import torch
     dist = None
     torch.cuda.set_device(local_rank)
@@ -350,7 +361,6 @@ def main():
 
     from dynesty_amd import _lib
     ctx = _lib.Context(local_rank)
-    prob = c2_problem()
     d = prob.ndim
     runs, nlive = args.runs, args.nlive
     sh = Shard(ctx, prob, runs, nlive, args.walks, seed=1000 + rank, entropy=(21, rank, 0, 0))
@@ -575,9 +585,8 @@ def main():
                         "set is read ~3 times per level, not 12"}
         if e2e is not None:
             line["config"]["end_to_end"] = e2e
-        if not args.no_cpu and world == 1:  # the CPU baseline is timed on rank 0 at N = 1 only
-            line["cpu_baseline"] = cpu_baseline(prob, sh.u0, nlive, sh.scale, sh.loglstar,
-                                                args.walks, args.cpu_seconds)
+        if cpu is not None:  # the CPU baseline is timed on rank 0 at N = 1 only
+            line["cpu_baseline"] = cpu
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()
@@ -598,7 +607,7 @@ def reference_logz_gate():
 
 
 def _cpu_walk_worker(job):
-    """One host core: oracle rwalk walkers for `budget_s` seconds (spawned process)."""
+    """One host core: oracle rwalk walkers for `budget_s` seconds."""
     seed, u0, loglstar, axes, scale, walks, budget_s = job
     sys.path.insert(0, ROOT)
     from oracle import proposals_ref as P
@@ -651,7 +660,7 @@ def cpu_baseline(prob, u0, nlive, scale, loglstar, walks, budget_s):
     ncores = os.cpu_count() or 1
     if ncores > 1:
         try:
-            mpc = mp.get_context("spawn")
+            mpc = mp.get_context("fork")  # safe: called before any HIP / torch initialisation
             with mpc.Pool(ncores) as pool:
                 t0 = time.perf_counter()
                 res = pool.map(_cpu_walk_worker,

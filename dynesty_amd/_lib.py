@@ -68,6 +68,7 @@ SIGNATURES = {
     "dh_rebuild_ragged_dev": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _vp,
                                    _vp, _vp, _vp, _vp, _vp, _vp]),
     "dh_ell_from_cov": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "dh_improve_covar_mat": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "dh_scale_to_logvol": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dh_enlarge_batch_dev": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp,
                                   _dbl]),
@@ -89,6 +90,7 @@ SIGNATURES = {
     "dh_unif_batch_dev": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp,
                                _dbl, _vp, _vp, C.c_int64, _vp, _vp, _vp, _vp,
                                _vp, _vp]),
+    "dh_ns_consume": (_i, [_vp, _i, _i, _i, _dbl, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dh_ns_ensemble": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _dbl, _dbl,
                             C.c_int64, C.c_int64, _vp, _i, _u32, _vp, _vp,
                             _vp, _vp, _vp, _vp]),
@@ -415,6 +417,19 @@ class Context:
                                              _ptr(ams), _ptr(lvs)))
         return axes, axlens, ams, lvs
 
+    def improve_covar_mat(self, covs):
+        """improve_covar_mat (bounding.py:1311-1384) for a stack of matrices:
+        returns (good (m,) bool, cov, am, axes)."""
+        covs = _f64(covs)
+        if covs.ndim == 2:
+            covs = covs[None]
+        m, d, _ = covs.shape
+        good = np.empty(m, dtype=np.int32)
+        out = np.empty((m, d, d)); am = np.empty((m, d, d)); axes = np.empty((m, d, d))
+        self._check(self.lib.dh_improve_covar_mat(self.handle, m, d, _ptr(covs), _ptr(good),
+                                                  _ptr(out), _ptr(am), _ptr(axes)))
+        return good.astype(bool), out, am, axes
+
     def scale_to_logvol(self, covs, ams, axes, axlens, logvols, targets):
         """In-place Ellipsoid.scale_to_logvol for a stack of ellipsoids; the
         arrays must be C-contiguous float64 (they are updated in place)."""
@@ -628,6 +643,27 @@ class Context:
             _ptr(bcarr), _ptr(rng), int(max_tries), _ptr(u), _ptr(v),
             _ptr(logl), _ptr(nc), _ptr(rng_out), None, None))
         return dict(u=u, v=v, logl=logl, ncalls=nc, rng_out=rng_out)
+
+    def ns_consume(self, live_logl, q_logl, q_ncalls, state, dlogz):
+        """One queue consumption per run (dh_ns_consume).  live_logl (R, N) and
+        state (R, 8) are updated in place; returns dict(dead_logl, dead_slot,
+        dead_src (lists per run), stopped (R,) bool)."""
+        live = np.ascontiguousarray(live_logl, dtype=np.float64)
+        assert live is live_logl and live.ndim == 2
+        R, N = live.shape
+        ql = _f64(q_logl).reshape(R, -1)
+        K = ql.shape[1]
+        qn = np.ascontiguousarray(q_ncalls, dtype=np.int32).reshape(R, K)
+        assert state.dtype == np.float64 and state.shape == (R, 8) and state.flags.c_contiguous
+        dl = np.empty((R, K)); ds = np.empty((R, K), dtype=np.int32); dj = np.empty((R, K), dtype=np.int32)
+        nd = np.empty(R, dtype=np.int32); stp = np.empty(R, dtype=np.int32)
+        self._check(self.lib.dh_ns_consume(self.handle, R, N, K, float(dlogz), _ptr(live), _ptr(ql),
+                                           _ptr(qn), _ptr(state), _ptr(dl), _ptr(ds), _ptr(dj),
+                                           _ptr(nd), _ptr(stp)))
+        return dict(dead_logl=[dl[r, :nd[r]].copy() for r in range(R)],
+                    dead_slot=[ds[r, :nd[r]].copy() for r in range(R)],
+                    dead_src=[dj[r, :nd[r]].copy() for r in range(R)],
+                    stopped=stp.astype(bool))
 
     def ns_ensemble(self, prob, runs, nlive, queue_size, walks=None,
                     bound='multi', dlogz=0.01, enlarge=1.25, entropy=(21,),

@@ -33,6 +33,17 @@ def logvol_prefactor(n, p=2.):
             math.lgamma(n / p + 1))
 
 
+def improve_covar_mat(covar0, ntries=100, max_condition_number=1e12):
+    """bounding.py:1311-1384 on the device (dh_improve_covar_mat): returns
+    (good_mat, covar, am, axes).  The loop constants are compiled into the
+    kernels, so only the reference's defaults are accepted."""
+    if ntries != 100 or max_condition_number != 1e12:
+        raise ValueError("improve_covar_mat: the device routine is built for the reference's "
+                         "defaults (ntries=100, max_condition_number=1e12)")
+    good, cov, am, axes = get_backend().improve_covar_mat(np.asarray(covar0, dtype=np.float64))
+    return bool(good[0]), cov[0], am[0], axes[0]
+
+
 def _draw(rstate, nsamp, ctrs, axes, ams=None, logvol_ells=None,
           return_q=False):
     """Bound.samples on the device from the caller's numpy Generator; the

@@ -18,6 +18,9 @@
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
+
+#include <vector>
 
 #include "ctx.h"
 #include "rng_pcg64.h"
@@ -86,6 +89,11 @@ struct NsArgs {
   double* b_lv;
   // results
   double* records;  // runs x 8: logz, logzerr, niter, ncall, h, nbound, status, eff
+  // dh_ns_consume (one queue consumption as an operator of its own): death list of THIS call
+  int dead_rel;     // 1: dead_logl rows are K wide and hold this call's deaths from index 0
+  int* trace_slot;  // runs x K or null: slot of every death
+  int* trace_src;   // runs x K or null: queue index of its replacement
+  int* trace_n;     // runs x 2 or null: number of deaths kept, stopped flag
 };
 
 __device__ __forceinline__ double logaddexp_dev(double x, double y) {
@@ -511,7 +519,8 @@ __global__ void __launch_bounds__(kT) ns_consume(NsArgs a) {
   // ---- phase A: the heap walk (wave 0, lanes cooperating on every sift level) ----
   if (t < 64) {
     int jcap;
-    const int nd = consume_heap(hp, src, ql, dcur, dj, dslot, dsrc, N, K, a.cap - it0, K + 1, &jcap, t);
+    const int nd = consume_heap(hp, src, ql, dcur, dj, dslot, dsrc, N, K, a.dead_rel ? (long long)K + 1 : a.cap - it0,
+                                K + 1, &jcap, t);
     if (t == 0) {
       misc[0] = nd;
       misc[1] = jcap;
@@ -626,7 +635,7 @@ __global__ void __launch_bounds__(kT) ns_consume(NsArgs a) {
     __syncthreads();
     if (t < 64) {
       int jc;
-      consume_heap(hp, src, ql, dcur, dj, dslot, dsrc, N, K, a.cap - it0, nkeep, &jc, t);
+      consume_heap(hp, src, ql, dcur, dj, dslot, dsrc, N, K, a.dead_rel ? (long long)K + 1 : a.cap - it0, nkeep, &jc, t);
     }
   }
   __syncthreads();
@@ -667,7 +676,17 @@ __global__ void __launch_bounds__(kT) ns_consume(NsArgs a) {
   }
   NS_PROF(3);
   // dead-point log-likelihoods, in death order
-  for (int e = t; e < nkeep; e += kT) a.dead_logl[(size_t)run * a.cap + it0 + e] = dcur[e];
+  const size_t dbase = a.dead_rel ? (size_t)run * K : (size_t)run * a.cap + it0;
+  for (int e = t; e < nkeep; e += kT) a.dead_logl[dbase + e] = dcur[e];
+  if (a.trace_slot)
+    for (int e = t; e < nkeep; e += kT) {
+      a.trace_slot[(size_t)run * K + e] = dslot[e];
+      a.trace_src[(size_t)run * K + e] = dj[e];
+    }
+  if (a.trace_n && t == 0) {
+    a.trace_n[run * 2] = nkeep;
+    a.trace_n[run * 2 + 1] = stopped ? 1 : 0;
+  }
   // dead-point coordinates (optional), in death order
   if (a.store_samples) {
     for (int e = 0; e < nkeep; ++e) {
@@ -730,16 +749,47 @@ __global__ void __launch_bounds__(kT) ns_finish(NsArgs a) {
   __syncthreads();
   if (t == 0) {
     NsRun& r = a.st[run];
-    double logz = r.logz, h = r.h, prev = r.dead_prev, logzvar = r.logzvar;
+    // The final live points, lowest first (sampler.py:780-930).  What Results reports is
+    // compute_integrals over the whole run (sampler.py:1342-1348, utils.py:1411-1467): ln Z the
+    // accumulated logaddexp, and the partial informations H_i normalised by the FINAL Z,
+    //   H_i = (1/Z_f) sum_{k<=i} [L ln L]-terms - (Z_i / Z_f) ln Z_f,   var ln Z = |sum_i (H_i - H_{i-1}) dlnX_i|.
+    // First pass: ln Z_f.  With G = e^{lnZ}(H + lnZ) (additive) the state after the dead points gives
+    // H_n = e^{lnZ_n - lnZ_f} (H^run_n + lnZ_n - lnZ_f); over the dead points dlnX is constant, so their
+    // share of the variance sum telescopes to dlnX * H_n.
     const double lv0 = r.logvol;
-    double lvprev = lv0;
+    double logz_f = r.logz;
+    {
+      double prev = r.dead_prev, lvprev = lv0;
+      for (int i = 1; i <= N; ++i) {
+        const double cur = sorted[i - 1];
+        const double lv = lv0 + log(1.0 - (double)i / ((double)N + 1.0));
+        const double logdvol = lv + log(0.5 * expm1(lvprev - lv));
+        logz_f = logaddexp_dev(logz_f, logaddexp_dev(cur, prev) + logdvol);
+        prev = cur;
+        lvprev = lv;
+      }
+    }
+    const double dlv = log(((double)N + 1.0) / (double)N);
+    const double wn = exp(r.logz - logz_f);
+    double hpart = r.it > 0 && wn > 0.0 ? wn * (r.h + r.logz) : 0.0;  // (1/Z_f) sum of the L ln L terms so far
+    double hcur = hpart - (r.it > 0 ? wn * logz_f : 0.0);              // H_n
+    double logzvar = hcur * dlv;
+    double logz = r.logz, prev = r.dead_prev, lvprev = lv0;
     for (int i = 1; i <= N; ++i) {
       const double cur = sorted[i - 1];
       const double lv = lv0 + log(1.0 - (double)i / ((double)N + 1.0));
-      integrate_step(logz, h, logzvar, prev, cur, lv, lvprev - lv);
+      const double dl = lvprev - lv;
+      const double logdvol = lv + log(0.5 * expm1(dl));
+      logz = logaddexp_dev(logz, logaddexp_dev(cur, prev) + logdvol);
+      const double t0 = exp(prev - logz_f + logdvol), t1 = exp(cur - logz_f + logdvol);
+      hpart += (t1 > 0.0 ? t1 * cur : 0.0) + (t0 > 0.0 ? t0 * prev : 0.0);
+      const double hi = hpart - logz_f * exp(logz - logz_f);
+      logzvar += (hi - hcur) * dl;
+      hcur = hi;
       prev = cur;
       lvprev = lv;
     }
+    const double h = hcur;
     double* rec = a.records + (size_t)run * 8;
     rec[0] = logz;
     rec[1] = sqrt(fabs(logzvar));
@@ -755,6 +805,96 @@ __global__ void __launch_bounds__(kT) ns_finish(NsArgs a) {
 }  // namespace
 
 extern "C" {
+
+// see include/dynhip.h
+int dh_ns_consume(dh_ctx* ctx, int runs, int nlive, int queue_size, double dlogz, double* live_logl,
+                  const double* q_logl, const int32_t* q_ncalls, double* state, double* dead_logl,
+                  int32_t* dead_slot, int32_t* dead_src, int32_t* ndead, int32_t* stopped) {
+  DH_CHECK_CTX(ctx);
+  if (runs < 1 || nlive < 4 || queue_size < 1 || !live_logl || !q_logl || !q_ncalls || !state || !dead_logl ||
+      !dead_slot || !dead_src || !ndead || !stopped)
+    return fail(ctx, DH_ERR_ARG, "ns_consume: bad arguments");
+  const int R = runs, N = nlive, K = queue_size;
+  if (K > kEPT * kT) return fail(ctx, DH_ERR_ARG, "ns_consume: queue_size %d > %d", K, kEPT * kT);
+  const size_t lds_heap = (size_t)heap_cap(N) * 16 + (size_t)N * 8 + 64;
+  const size_t lds_cons = (size_t)heap_cap(N) * 16 + (size_t)N * 4 + (size_t)K * 32 + 64;
+  const size_t lds_max = lds_cons > lds_heap ? lds_cons : lds_heap;
+  if (lds_max > 150 * 1024) return fail(ctx, DH_ERR_ARG, "ns_consume: nlive/queue too large for LDS");
+  NsArgs a{};
+  a.runs = R;
+  a.nlive = N;
+  a.ndim = 0;  // log-likelihoods only: no coordinates travel
+  a.K = K;
+  a.walks = 1;
+  a.cap = K;
+  a.dlogz = dlogz;
+  a.dead_rel = 1;
+  arena_reset(ctx);
+  int rc = arena_reserve(ctx, (size_t)R * (sizeof(NsRun) + (size_t)N * 20 + (size_t)K * 28 + 64) + 16384);
+  if (rc) return rc;
+  std::vector<NsRun> st((size_t)R);
+  for (int r = 0; r < R; ++r) {
+    NsRun& x = st[(size_t)r];
+    memset(&x, 0, sizeof x);
+    const double* sv = state + (size_t)r * 8;
+    x.logvol = sv[0];
+    x.logz = sv[1];
+    x.h = sv[2];
+    x.logzvar = sv[3];
+    x.dead_prev = sv[4];
+    x.it = (long long)sv[5];
+    x.ncall = (long long)sv[6];
+    x.mode = MODE_CUBE;  // the queue's ncalls come from q_ncalls; no sampler tuning
+    x.scale = 1.0;
+  }
+  a.st = arena_up(ctx, st.data(), (size_t)R);
+  a.live_logl = arena_up(ctx, live_logl, (size_t)R * N);
+  a.heap_key = (double*)arena_get(ctx, (size_t)R * N * 8);
+  a.heap_slot = (int*)arena_get(ctx, (size_t)R * N * 4);
+  a.dead_logl = (double*)arena_get(ctx, (size_t)R * K * 8);
+  a.r_logl = arena_up(ctx, q_logl, (size_t)R * K);
+  a.r_a = (int*)arena_up(ctx, q_ncalls, (size_t)R * K);
+  a.trace_slot = (int*)arena_get(ctx, (size_t)R * K * 4);
+  a.trace_src = (int*)arena_get(ctx, (size_t)R * K * 4);
+  a.trace_n = (int*)arena_get(ctx, (size_t)R * 8);
+  a.ndone = (int*)arena_get(ctx, 64);
+  a.bstatus = (int*)arena_get(ctx, (size_t)R * 4);
+  if (!a.st || !a.live_logl || !a.heap_key || !a.heap_slot || !a.dead_logl || !a.r_logl || !a.r_a ||
+      !a.trace_slot || !a.trace_src || !a.trace_n || !a.ndone || !a.bstatus)
+    return DH_ERR_NOMEM;
+  hipStream_t s = ctx->stream;
+  if (!hip_ok(ctx, hipMemsetAsync(a.ndone, 0, 64, s), "memset") ||
+      !hip_ok(ctx, hipMemsetAsync(a.bstatus, 0, (size_t)R * 4, s), "memset") ||
+      !hip_ok(ctx, hipMemsetAsync(a.trace_n, 0, (size_t)R * 8, s), "memset"))
+    return DH_ERR_HIP;
+  if (!hip_ok(ctx, hipFuncSetAttribute((const void*)ns_consume, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max), "hipFuncSetAttribute(ns_consume)") ||
+      !hip_ok(ctx, hipFuncSetAttribute((const void*)ns_heapify, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max), "hipFuncSetAttribute(ns_heapify)"))
+    return DH_ERR_HIP;
+  hipLaunchKernelGGL(ns_heapify, dim3(R), dim3(kT), lds_heap, s, a);  // heap + lmax = max(live_logl)
+  hipLaunchKernelGGL(ns_consume, dim3(R), dim3(kT), lds_cons, s, a);
+  if (!hip_ok(ctx, hipGetLastError(), "ns_consume launch")) return DH_ERR_HIP;
+  std::vector<int> tn((size_t)R * 2);
+  if (!down(ctx, st.data(), a.st, (size_t)R) || !down(ctx, live_logl, a.live_logl, (size_t)R * N) ||
+      !down(ctx, dead_logl, a.dead_logl, (size_t)R * K) || !down(ctx, (int*)dead_slot, a.trace_slot, (size_t)R * K) ||
+      !down(ctx, (int*)dead_src, a.trace_src, (size_t)R * K) || !down(ctx, tn.data(), a.trace_n, (size_t)R * 2))
+    return DH_ERR_HIP;
+  if ((rc = dh_sync(ctx))) return rc;
+  for (int r = 0; r < R; ++r) {
+    const NsRun& x = st[(size_t)r];
+    double* sv = state + (size_t)r * 8;
+    sv[0] = x.logvol;
+    sv[1] = x.logz;
+    sv[2] = x.h;
+    sv[3] = x.logzvar;
+    sv[4] = x.dead_prev;
+    sv[5] = (double)x.it;
+    sv[6] = (double)x.ncall;
+    sv[7] = x.loglstar;  // the current worst live point
+    ndead[r] = tn[(size_t)r * 2];
+    stopped[r] = tn[(size_t)r * 2 + 1];
+  }
+  return DH_OK;
+}
 
 int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int queue_size, int sampler,
                    int walks, int bound_multi, int rebuild_sync, double dlogz, double enlarge, int64_t max_fills,
@@ -774,7 +914,7 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
   if (ndim > kMaxRegDim) return fail(ctx, DH_ERR_ARG, "ns_ensemble: ndim=%d > %d not built", ndim, kMaxRegDim);
   const int N = nlive, D = ndim, K = queue_size, R = runs;
   const int me = bound_multi ? (N / (2 * D) > 0 ? N / (2 * D) : 1) : 1;
-  NsArgs a;
+  NsArgs a{};
   a.runs = R;
   a.nlive = N;
   a.ndim = D;

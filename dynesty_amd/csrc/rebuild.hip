@@ -1659,6 +1659,30 @@ __global__ void __launch_bounds__(kThreads) k_finish(RebuildArgs a) {
 }
 
 // ---------------------------------------------------------------------------
+// improve_covar_mat (bounding.py:1311-1384) as a call of its own: one workgroup per matrix runs
+// the very `regularize` routine of the rebuild pipeline on a caller-supplied matrix.
+// work: m x D x LD (odd leading dimension), in: the matrix, out: the returned covariance.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(kThreads)
+    improve_cov_kernel(int m, int D, double* work, int* good, double* covs, double* ams, double* axes) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  Lds L;
+  carve(L, smem, D);
+  const int e = blockIdx.x, t = threadIdx.x, LD = L.LD;
+  if (e >= m) return;
+  double* cov = work + (size_t)e * D * LD;
+  const bool g = regularize(L, cov, D);
+  __syncthreads();
+  for (int q = t; q < D * D; q += kThreads) {
+    const int i = q / D, j = q % D;
+    covs[(size_t)e * D * D + q] = cov[i * LD + j];
+    ams[(size_t)e * D * D + q] = L.AM[i * LD + j];
+    axes[(size_t)e * D * D + q] = L.AX[i * LD + j];
+  }
+  if (t == 0) good[e] = g ? 1 : 0;
+}
+
+// ---------------------------------------------------------------------------
 // Ellipsoid.__init__ from (ctr, cov) (bounding.py:201-240): eigen-decomposition
 // -> axlens, axes, am, logvol.  One wavefront per ellipsoid.
 // ---------------------------------------------------------------------------
@@ -2121,6 +2145,45 @@ int dh_ell_from_cov(dh_ctx* ctx, int m, int d, const double* covs, double* axes,
     if (st[i] != DH_OK)
       return fail(ctx, DH_ERR_VALUE, "The input covariance of ellipsoid %d is singular or not finite", i);
   return DH_OK;
+}
+
+int dh_improve_covar_mat(dh_ctx* ctx, int m, int d, const double* covs_in, int32_t* good, double* covs,
+                         double* ams, double* axes) {
+  DH_CHECK_CTX(ctx);
+  if (m <= 0) return DH_OK;
+  if (!covs_in || !good || !covs || !ams || !axes || d < 1)
+    return fail(ctx, DH_ERR_ARG, "improve_covar_mat: bad arguments");
+  if (d > 44) return fail(ctx, DH_ERR_ARG, "improve_covar_mat: d=%d > 44 (narrow-D routine)", d);
+  const int LD = d | 1;
+  const size_t lds = rebuild_lds_bytes(d);
+  const size_t dd = (size_t)d * d;
+  arena_reset(ctx);
+  int rc = arena_reserve(ctx, (size_t)m * ((size_t)d * LD + 3 * dd + 1) * 8 + 8192);
+  if (rc) return rc;
+  std::vector<double> padded((size_t)m * d * LD, 0.0);
+  for (int e = 0; e < m; ++e)
+    for (int i = 0; i < d; ++i)
+      for (int j = 0; j < d; ++j) padded[((size_t)e * d + i) * LD + j] = covs_in[(size_t)e * dd + i * d + j];
+  double* d_w = arena_up(ctx, padded.data(), padded.size());
+  double* d_c = (double*)arena_get(ctx, (size_t)m * dd * 8);
+  double* d_am = (double*)arena_get(ctx, (size_t)m * dd * 8);
+  double* d_ax = (double*)arena_get(ctx, (size_t)m * dd * 8);
+  int* d_g = (int*)arena_get(ctx, (size_t)m * 4);
+  if (!d_w || !d_c || !d_am || !d_ax || !d_g) return DH_ERR_NOMEM;
+  if (!hip_ok(ctx, hipStreamSynchronize(ctx->stream), "sync(H2D of a temporary)")) return DH_ERR_HIP;
+  DH_DEV_MEMO(attr_icm);
+  if (lds > attr_icm) {
+    if (!hip_ok(ctx, hipFuncSetAttribute((const void*)improve_cov_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+                "hipFuncSetAttribute(improve_cov LDS)"))
+      return DH_ERR_HIP;
+    attr_icm = lds;
+  }
+  hipLaunchKernelGGL(improve_cov_kernel, dim3(m), dim3(kThreads), lds, ctx->stream, m, d, d_w, d_g, d_c, d_am, d_ax);
+  if (!hip_ok(ctx, hipGetLastError(), "improve_covar_mat launch")) return DH_ERR_HIP;
+  if (!down(ctx, covs, d_c, (size_t)m * dd) || !down(ctx, ams, d_am, (size_t)m * dd) ||
+      !down(ctx, axes, d_ax, (size_t)m * dd) || !down(ctx, (int*)good, d_g, (size_t)m))
+    return DH_ERR_HIP;
+  return dh_sync(ctx);
 }
 
 int dh_enlarge_batch_dev(dh_ctx* ctx, int runs, int max_ells, const int32_t* nells, int d, double* covs,

@@ -166,6 +166,16 @@ int dh_scale_to_logvol(dh_ctx* ctx, int m, int d, double* covs, double* ams,
                        double* axes, double* axlens, double* logvols,
                        const double* targets);
 
+/* improve_covar_mat (bounding.py:1311-1384; exercised by the reference's tests/test_ellipsoid.py:242-255
+ * test_bounds): for each of m symmetric d x d matrices the 100-trial regularisation loop of the rebuild
+ * kernels -- eigenvalue floor at 10 * max / 1e12 when the condition number exceeds 1e12, blend towards
+ * the identity when the eigenvalues are not finite / not positive, identity after 100 failures.
+ * Outputs: good[e] = 1 iff the input needed no change (the reference's `good_mat`), the returned
+ * covariance, its inverse and the axes (eigenvectors * sqrt(eigenvalues), ascending, sign-canonical).
+ * d <= 44. */
+int dh_improve_covar_mat(dh_ctx* ctx, int m, int d, const double* covs_in, int32_t* good,
+                         double* covs, double* ams, double* axes);
+
 /* Sampler.update_bound's enlargement (sampler.py:506-508):
  * bound.scale_to_logvol(bound.logvol + log(enlarge)) for `runs` bounds laid out
  * as by dh_rebuild_batch_dev (max_ells slots per run, nells[run] live): every
@@ -275,6 +285,25 @@ int dh_bound_draw(dh_ctx* ctx, const uint64_t* state4, int nsamp, int d, int m,
                   const double* ctrs, const double* axes, const double* ams,
                   const double* cumprob, int return_q, double* xs, int32_t* idxs,
                   int32_t* qs, uint64_t* state4_out);
+
+/* One queue consumption of the static run loop for `runs` independent runs -- the iteration loop of
+ * Sampler.sample over ONE queue fill (sampler.py:1070-1185) with _new_point's queue rule
+ * (sampler.py:741-776): while the dlogz criterion has not fired, the worst live point dies and is replaced
+ * by the next queue entry whose logl beats it (entries that do not are discarded, their calls still
+ * charged); every death takes the volume step ln((N+1)/N) and one step of progress_integration
+ * (utils.py:1470-1492).  This is the `ns_consume` stage of dh_ns_ensemble as an operator of its own
+ * (used to hold it to the oracle's restatement of the reference loop; a host-driven loop can use it too).
+ *   live_logl  runs x nlive   in/out, slot order
+ *   q_logl     runs x K       the queue's log-likelihoods in queue order; q_ncalls their call counts
+ *   state      runs x 8       in/out: logvol, logz, h, logzvar, loglstar of the last dead point
+ *                             (-1e300 before the first), it, ncall, [out only] the current worst logl
+ *   dead_logl / dead_slot / dead_src   runs x K: this call's deaths in order (logl, slot, queue index of
+ *                             the replacement); ndead[r] of them are valid; stopped[r] = dlogz fired
+ * Deviations from the reference, both documented in DESIGN.md: equal log-likelihoods die in heap order
+ * (reference: lowest slot first) and the plateau volume steps (sampler.py:1110-1127) are not taken. */
+int dh_ns_consume(dh_ctx* ctx, int runs, int nlive, int queue_size, double dlogz, double* live_logl,
+                  const double* q_logl, const int32_t* q_ncalls, double* state, double* dead_logl,
+                  int32_t* dead_slot, int32_t* dead_src, int32_t* ndead, int32_t* stopped);
 
 /* ---- device-resident ensemble of static nested-sampling runs (BASELINE config
  * C5): the loop of Sampler.sample (sampler.py:932-1212) with a

@@ -1,0 +1,139 @@
+"""The device-resident run loop's bookkeeping (csrc/ns.hip: ns_consume / ns_finish) pinned to the
+oracle's restatement of the reference loop (oracle/nested_ref.py, itself bit-identical to a recorded
+real NestedSampler run: tests/test_oracle_nsloop_golden.py):
+
+  * dh_ns_consume replays queue fills the REAL reference run recorded (tests/golden/nsloop.npz):
+    dead points, slots and replacements exact, ln Z / H / var ln Z to 1e-11
+  * chains of synthetic fills over several runs vs oracle.consume_queue (incl. the dlogz stop)
+  * a whole device run: the reported ln Z, error and information equal compute_integrals
+    (what the reference's Results holds) over the run's own dead + live log-likelihoods to 1e-9
+"""
+import os
+
+import numpy as np
+import pytest
+
+import inputs
+from oracle import nested_ref as R
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "nsloop.npz")
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from dynesty_amd import _lib
+    return _lib.Context(0)
+
+
+def pack(states):
+    return np.array([[s.logvol, s.logz, s.h, s.logzvar, s.loglstar, s.it, s.ncall, 0.0] for s in states])
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_replay_of_a_real_reference_fill(ctx, tag):
+    g = np.load(G)
+    assert int(g[f"fill_{tag}/it0"]) + len(g[f"fill_{tag}/dead_logl"]) <= int(g["run/first_plateau_it"])
+    nlive = int(g["nlive"])
+    s = R.RunState(nlive)
+    s.logz, s.logzvar, s.h = (float(g[f"fill_{tag}/state_{k}"]) for k in ("logz", "logzvar", "h"))
+    s.logvol, s.loglstar = float(g[f"fill_{tag}/state_logvol"]), float(g[f"fill_{tag}/state_logl"])
+    s.it = int(g[f"fill_{tag}/it0"])
+    live = g[f"fill_{tag}/live_logl"][None, :].copy()
+    state = pack([s])
+    out = ctx.ns_consume(live, g[f"fill_{tag}/q_logl"][None], g[f"fill_{tag}/q_ncalls"][None], state,
+                         float(g["dlogz"]))
+    np.testing.assert_array_equal(out["dead_logl"][0], g[f"fill_{tag}/dead_logl"])
+    np.testing.assert_array_equal(out["dead_slot"][0], g[f"fill_{tag}/dead_slot"])
+    assert not out["stopped"][0]
+    np.testing.assert_allclose(state[0, 1], g[f"fill_{tag}/logz"][-1], rtol=0, atol=1e-11)
+    np.testing.assert_allclose(state[0, 2], g[f"fill_{tag}/h"][-1], rtol=1e-10, atol=1e-13)
+    np.testing.assert_allclose(state[0, 3], g[f"fill_{tag}/logzvar"][-1], rtol=1e-9, atol=1e-15)
+    assert int(state[0, 5]) == s.it + len(g[f"fill_{tag}/dead_logl"])
+    assert int(state[0, 6]) == int(g[f"fill_{tag}/q_ncalls"].sum())
+    # the live set after the fill: the oracle's
+    ref_live = g[f"fill_{tag}/live_logl"].copy()
+    R.consume_queue(ref_live, g[f"fill_{tag}/q_logl"], g[f"fill_{tag}/q_ncalls"], s, float(g["dlogz"]))
+    np.testing.assert_array_equal(live[0], ref_live)
+
+
+@pytest.mark.parametrize("nlive,K,runs", [(300, 100, 5), (2000, 512, 3), (64, 17, 4)])
+def test_fill_chains_vs_oracle(ctx, nlive, K, runs):
+    """Several runs, consecutive fills, each run's state carried from fill to fill on both sides.
+    The queue mixes entries above and below the moving threshold (stale ones are discarded);
+    dlogz is set so that the stopping rule fires inside one of the last fills."""
+    rng = np.random.default_rng(nlive + K)
+    # a Gaussian-like likelihood in 6-D: logl = -r^2/2, live points uniform in a ball of radius 6
+    def draw(n, rad):
+        return -0.5 * (rad * rng.random(n) ** (1 / 6.0)) ** 2
+    live = np.stack([draw(nlive, 6.0) for _ in range(runs)])
+    ref_live = live.copy()
+    states = [R.RunState(nlive) for _ in range(runs)]
+    state = pack(states)
+    dlogz = 0.5
+    done = np.zeros(runs, bool)
+    nfill = 0
+    while not done.all() and nfill < 400:
+        nfill += 1
+        ql = np.empty((runs, K))
+        for r in range(runs):
+            thr = ref_live[r].min()
+            rad = np.sqrt(-2 * thr)
+            # proposals drawn inside a ball slightly LARGER than the contour: ~25% are stale at birth,
+            # more become stale while the fill is consumed
+            ql[r] = draw(K, rad * 1.05)
+        qn = rng.integers(1, 60, size=(runs, K)).astype(np.int32)
+        act = ~done
+        if not act.all():  # finished runs leave the ensemble (as MODE_DONE runs do on the device)
+            live_a, state_a = np.ascontiguousarray(live[act]), np.ascontiguousarray(state[act])
+        else:
+            live_a, state_a = live, state
+        out = ctx.ns_consume(live_a, ql[act], qn[act], state_a, dlogz)
+        live[act], state[act] = live_a, state_a
+        for i, r in enumerate(np.flatnonzero(act)):
+            ref = R.consume_queue(ref_live[r], ql[r], qn[r], states[r], dlogz, plateau=False)
+            np.testing.assert_array_equal(out["dead_logl"][i], ref["dead_logl"])
+            np.testing.assert_array_equal(out["dead_slot"][i], ref["dead_slot"])
+            np.testing.assert_array_equal(out["dead_src"][i], ref["dead_src"])
+            assert bool(out["stopped"][i]) == ref["stopped"]
+            s = states[r]
+            np.testing.assert_allclose(state[r, 0], s.logvol, rtol=1e-13)
+            np.testing.assert_allclose(state[r, 1], s.logz, rtol=0, atol=1e-10)
+            np.testing.assert_allclose(state[r, 2], s.h, rtol=1e-9, atol=1e-12)
+            np.testing.assert_allclose(state[r, 3], s.logzvar, rtol=1e-8, atol=1e-14)
+            assert int(state[r, 5]) == s.it
+            if not ref["stopped"]:
+                assert int(state[r, 6]) == s.ncall
+            else:
+                # the reference stops BEFORE popping the next entry; the device charges the calls up to
+                # the replacement of the last death: identical
+                assert int(state[r, 6]) == s.ncall
+            np.testing.assert_array_equal(live[r], ref_live[r])
+            assert state[r, 7] == ref_live[r].min()
+            done[r] = ref["stopped"]
+    assert done.all() and nfill > 3
+
+
+def test_whole_run_results_are_compute_integrals(ctx):
+    """dh_ns_ensemble's record (ln Z, sqrt var, H) = the reference's final recomputation
+    (compute_integrals, sampler.py:1342-1348) over the run's own dead and live log-likelihoods."""
+    prob = inputs.problem("G5")
+    r = ctx.ns_ensemble(prob, 6, 300, 64, walks=25, bound="multi", entropy=[31], dlogz=0.05,
+                        max_iter=40000, want_dead_logl=True)
+    assert np.all(r["status"] == 0)
+    for i in range(6):
+        n = int(r["niter"][i])
+        lz, lzerr, h = R.final_results(r["dead_logl"][i, :n], r["live_logl"][i], 300)
+        np.testing.assert_allclose(r["logz"][i], lz, rtol=0, atol=1e-9)
+        np.testing.assert_allclose(r["logzerr"][i], lzerr, rtol=1e-7)
+        np.testing.assert_allclose(r["h"][i], h, rtol=1e-9)
+        # and the stopping rule held exactly at the last dead point, not before (recurrence values)
+        s = R.RunState(300)
+        dead = r["dead_logl"][i, :n]
+        for lnew in dead:
+            s.logvol -= s.dlv
+            _, s.logz, s.logzvar, s.h = R.progress_integration(s.loglstar, lnew, s.logz, s.logzvar,
+                                                               s.logvol, s.dlv, s.h)
+            s.loglstar = lnew
+        lmax = r["live_logl"][i].max()
+        assert np.logaddexp(0, lmax + s.logvol - s.logz) < 0.05

@@ -87,20 +87,57 @@ def test_multi_update_golden(ctx, name, golden_bounding):
                   g[f"{name}/mu/ams"][j], g[f"{name}/mu/axes"][j],
                   g[f"{name}/mu/axlens"][j], g[f"{name}/mu/logvol_ells"][j],
                   loose=loose)
-    # cluster membership: the oracle's leaves, as a partition of the points
-    trace = []
-    first = B.bounding_ellipsoid(pts)
-    ells = B.split_tree(pts, first, trace=trace)
-    assert len(ells) == got["nells"]
+    # cluster membership: the oracle's leaves, as a partition of the points.  The oracle's split
+    # tree (same k-means, same accept tests as the reference) yields the point set of every leaf;
+    # each device cluster must be exactly one of them.
+    ref_leaves = oracle_leaf_partition(pts)
+    assert len(ref_leaves) == got["nells"]
     lab = got["labels"]
     assert lab.min() >= 0 and lab.max() == got["nells"] - 1
-    # every device cluster must be exactly the point set of one oracle leaf
+    ref_sets = {frozenset(ix.tolist()) for ix in ref_leaves}
+    assert len(ref_sets) == len(ref_leaves)
     for i in range(got["nells"]):
-        mine = pts[lab == i]
-        e = ells[p[i]] if False else None
-        ctr = mine.mean(axis=0)
-        np.testing.assert_allclose(ctr, got["ctrs"][i], rtol=0, atol=1e-12)
-        assert mine.shape[0] >= 2 * pts.shape[1] or got["nells"] == 1
+        mine = frozenset(np.flatnonzero(lab == i).tolist())
+        assert mine in ref_sets, f"device cluster {i} is not a leaf of the oracle's tree"
+        ref_sets.discard(mine)
+    assert not ref_sets
+
+
+def oracle_leaf_partition(pts):
+    """Index sets of the leaves MultiEllipsoid.update keeps, from the oracle's recursion
+    (oracle.bounding_ref.split_tree restated over index arrays: bounding.py:1464-1563)."""
+    from scipy.cluster.vq import kmeans2
+    from scipy.special import logsumexp
+    import warnings
+
+    def rec(idx, ell, scale):
+        sub = pts[idx]
+        n, d = sub.shape
+        if n < 4 * d:
+            return [(idx, ell)]
+        p1, p2 = B.major_axis_endpoints(ell)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            _, labels = kmeans2(sub / scale, k=np.vstack((p1, p2)) / scale, iter=10, minit='matrix',
+                                check_finite=False)
+        parts = [idx[labels == k] for k in (0, 1)]
+        if min(len(parts[0]), len(parts[1])) < 2 * d:
+            return [(idx, ell)]
+        kids = [B.bounding_ellipsoid(pts[p]) for p in parts]
+        dec = (d * (d + 3)) // 2 * np.log(n) / n
+        out = rec(parts[0], kids[0], scale) + rec(parts[1], kids[1], scale)
+        if np.logaddexp(kids[0].logvol, kids[1].logvol) - ell.logvol < -dec:
+            return out
+        if logsumexp([e.logvol for _, e in out]) - ell.logvol < -dec * (len(out) - 1):
+            return out
+        return [(idx, ell)]
+    leaves = rec(np.arange(len(pts)), B.bounding_ellipsoid(pts), pts.std(axis=0)[None, :])
+    # the restatement must agree with the oracle proper
+    ells = B.split_tree(pts, B.bounding_ellipsoid(pts))
+    assert len(ells) == len(leaves)
+    for (ix, e), e2 in zip(leaves, ells):
+        np.testing.assert_array_equal(e.ctr, e2.ctr)
+    return [ix for ix, _ in leaves]
 
 
 @pytest.mark.parametrize("name", ["c2", "c3", "two5", "ring2"])

@@ -483,11 +483,116 @@ def gen_livesets(out):
     print("wrote", out, len(g), "arrays")
 
 
+def gen_nsloop(out):
+    """The run loop's bookkeeping from a REAL NestedSampler run (G5, nlive 200, multi/rwalk, queue of
+    64 through a serial pool): for three queue fills the live log-likelihoods at the moment of the
+    fill, the queue's (logl, ncalls) in order, and the dead points / evidence history the run
+    recorded until the next fill; plus the whole run's dead and final live log-likelihoods with its
+    final ln Z, error and information.  Pins oracle/nested_ref.py (sampler.py:741-776, 1070-1185,
+    780-930; utils.py:1470-1492)."""
+    import dynesty
+    from dynesty import sampler as dsamp
+    import inputs
+    prob = inputs.problem("G5")
+    nlive, K = 200, 64
+
+    class SerialPool:
+        size = K
+
+        def map(self, f, x):
+            return list(map(f, x))
+    fills = []
+    orig = dsamp.Sampler._fill_queue
+
+    def spy(self, loglstar):
+        snap = dict(it=len(self.saved_run['logl']), live_logl=np.array(self.live_logl),
+                    loglstar_arg=float(loglstar), plateau_mode=bool(self.plateau_mode),
+                    plateau_counter=int(getattr(self, "plateau_counter", 0) or 0),
+                    plateau_logdvol=float(getattr(self, "plateau_logdvol", 0.) or 0.),
+                    ncall=int(self.ncall))
+        orig(self, loglstar)
+        snap["q_logl"] = np.array([float(r.logl) for r in self.queue])
+        snap["q_ncalls"] = np.array([int(r.ncalls) for r in self.queue], dtype=np.int64)
+        fills.append(snap)
+    dsamp.Sampler._fill_queue = spy
+    # run_nested replaces the evidence history by compute_integrals' at the very end
+    # (sampler.py:1342-1348): keep what the recurrence (progress_integration) had recorded
+    rec = {}
+    orig_ci = dsamp.compute_integrals
+
+    def spy_ci(**kw):
+        for key in ("logz", "logzvar", "h"):
+            rec[key] = np.array(s.saved_run[key], dtype=np.float64)
+        return orig_ci(**kw)
+    dsamp.compute_integrals = spy_ci
+    try:
+        s = dynesty.NestedSampler(prob.loglikelihood, prob.prior_transform, prob.ndim, nlive=nlive,
+                                  bound='multi', sample='rwalk', walks=20, pool=SerialPool(),
+                                  queue_size=K, rstate=np.random.default_rng(77))
+        s.run_nested(dlogz=0.05, print_progress=False)
+    finally:
+        dsamp.Sampler._fill_queue = orig
+        dsamp.compute_integrals = orig_ci
+    sr = dict(s.saved_run.items()) if hasattr(s.saved_run, "items") else s.saved_run
+    final = {key: np.array(s.saved_run[key], dtype=np.float64) for key in ("logz", "logzvar", "h")}
+    sr = {key: s.saved_run[key] for key in ("logl", "id", "logvol")}
+    sr.update(rec)  # the per-iteration history below is the recurrence's
+    niter = len(sr['logl']) - nlive  # add_live appended the final live points
+    g = {"nlive": np.int64(nlive), "K": np.int64(K), "dlogz": np.float64(0.05),
+         "nfills": np.int64(len(fills)), "niter": np.int64(niter),
+         "run/logl": np.array(sr['logl'], dtype=np.float64),
+         "run/logvol": np.array(sr['logvol'], dtype=np.float64),
+         # every fill of the run, so that the whole loop can be replayed
+         "fills/live_logl0": fills[0]["live_logl"],
+         "fills/q_logl": np.array([f["q_logl"] for f in fills]),
+         "fills/q_ncalls": np.array([f["q_ncalls"] for f in fills]),
+         "run/ncall_init": np.int64(fills[0]["ncall"]),
+         # final values of the recurrence (what the stopping rule saw) ...
+         "rec/logz_final": np.float64(rec["logz"][-1]), "rec/logzvar_final": np.float64(rec["logzvar"][-1]),
+         "rec/h_final": np.float64(rec["h"][-1]),
+         # ... and compute_integrals' per-point history (what Results reports)
+         "run/logz": final["logz"], "run/logzvar": final["logzvar"], "run/h": final["h"],
+         "run/logz_final": np.float64(s.results.logz[-1]),
+         "run/logzerr_final": np.float64(s.results.logzerr[-1]),
+         "run/h_final": np.float64(s.results.information[-1]),
+         "run/ncall": np.int64(s.ncall)}
+    picks = (2, len(fills) // 2, len(fills) - 1)
+    for tag, f in zip("abc", picks):
+        a = fills[f]
+        b = fills[f + 1]["it"] if f + 1 < len(fills) else niter
+        i0 = a["it"]
+        g[f"fill_{tag}/index"] = np.int64(f)
+        g[f"fill_{tag}/it0"] = np.int64(i0)
+        g[f"fill_{tag}/live_logl"] = a["live_logl"]
+        g[f"fill_{tag}/q_logl"] = a["q_logl"]
+        g[f"fill_{tag}/q_ncalls"] = a["q_ncalls"]
+        # state after iteration i0 - 1 (the fill is asked for inside iteration i0)
+        for key in ("logz", "logzvar", "h", "logvol", "logl"):
+            g[f"fill_{tag}/state_{key}"] = np.float64(sr[key][i0 - 1] if i0 > 0 else
+                                                      dict(logz=-1.e300, logzvar=0., h=0., logvol=0.,
+                                                           logl=-1.e300)[key])
+        g[f"fill_{tag}/dead_logl"] = np.array(sr['logl'][i0:b], dtype=np.float64)
+        g[f"fill_{tag}/dead_slot"] = np.array(sr['id'][i0:b], dtype=np.int64)
+        g[f"fill_{tag}/logz"] = np.array(sr['logz'][i0:b], dtype=np.float64)
+        g[f"fill_{tag}/logzvar"] = np.array(sr['logzvar'][i0:b], dtype=np.float64)
+        g[f"fill_{tag}/h"] = np.array(sr['h'][i0:b], dtype=np.float64)
+        g[f"fill_{tag}/is_last"] = np.bool_(f + 1 == len(fills))
+        g[f"fill_{tag}/state_plateau_mode"] = np.bool_(a["plateau_mode"])
+        g[f"fill_{tag}/state_plateau_counter"] = np.int64(a["plateau_counter"])
+        g[f"fill_{tag}/state_plateau_logdvol"] = np.float64(a["plateau_logdvol"])
+        print("fill", tag, f, "it0", i0, "deaths", b - i0)
+    lv = np.array(sr['logvol'][:niter], dtype=np.float64)
+    ladder = np.abs(np.diff(lv, prepend=0.) + np.log((nlive + 1.) / nlive)) > 1e-12
+    g["run/first_plateau_it"] = np.int64(np.argmax(ladder) if ladder.any() else niter)
+    np.savez_compressed(out, **g)
+    print("wrote", out, len(g), "arrays; niter", niter, "fills", len(fills), "logz", g["run/logz_final"])
+
+
 if __name__ == "__main__":
     import_reference()
     gdir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(gdir, exist_ok=True)
-    which = sys.argv[1:] or ["bounding", "proposals", "rng", "runs", "friends", "wide"]
+    which = sys.argv[1:] or ["bounding", "proposals", "rng", "runs", "friends", "wide", "nsloop"]
     if "bounding" in which:
         gen_bounding(os.path.join(gdir, "bounding.npz"))
     if "proposals" in which:
@@ -500,5 +605,7 @@ if __name__ == "__main__":
         gen_friends(os.path.join(gdir, "friends.npz"))
     if "wide" in which:
         gen_wide(os.path.join(gdir, "wide.npz"))
+    if "nsloop" in which:
+        gen_nsloop(os.path.join(gdir, "nsloop.npz"))
     if "livesets" in which:  # not in the default list: two partial reference runs (minutes)
         gen_livesets(os.path.join(gdir, "livesets.npz"))
