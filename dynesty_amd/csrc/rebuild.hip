@@ -40,6 +40,8 @@ struct Node {
   int depth;
   int split;        // 1 if children were created
   int res_start, res_len;  // result list (indices of nodes) after the accept test
+  int fast;         // 1: the record holds the eigen-free form (spd_fast): am, major axis, logvol only
+  int pad_;
   double logvol;
 };
 
@@ -96,6 +98,9 @@ struct RebuildArgs {
   double* pts_scaled; // runs x n x d : points / root std, written once by k_root (k-means input)
   const int* active;  // runs or null: only runs with active[run] != 0 are rebuilt
   const int* n_arr;   // runs or null: per-run point count (<= n; rows beyond it are padding)
+  int fast;           // 1: tree nodes take the eigen-free path (spd_fast); k_out_eig solves the outputs
+  int* out_node;      // runs x max_ells: node behind output ellipsoid m (k_finish -> k_out_eig)
+  int* out_fast;      // runs x max_ells: 1 = that node's record is the eigen-free form
 };
 
 #ifdef DH_REBUILD_TIMING
@@ -713,6 +718,236 @@ __device__ bool regularize(const Lds& L, double* cov, int D) {
   return trial == 0;
 }
 
+// ---- the eigen-free path of bounding_ellipsoid for tree nodes ---------------------------------
+// MultiEllipsoid.update builds ~50 tree nodes per live set and keeps one to a dozen of them.  What a
+// node needs on the way is (bounding.py:1387-1461, 1464-1563): the verdict of improve_covar_mat
+// ("is the condition number below 1e12?"), the precision matrix for the Mahalanobis maximum, the
+// log-volume for the accept test and -- only if it is big enough to be split -- its major axis for
+// the k-means seeds.  None of that requires the full eigen-decomposition, which was 60 % of the
+// rebuild (a 25 x 25 Jacobi solve is ~175 dependent rounds = 0.1 ms on every level of the tree):
+//   * LDL^T (Cholesky without roots) of the covariance: positive pivots <=> positive definite,
+//     ln det = sum ln pivots, cov^-1 = M^T D^-1 M with M = L^-1 by forward substitution;
+//   * cond(cov) <= tr(cov) tr(cov^-1): if that bound is below kFastCond the reference's test
+//     lam_min < lam_max / 1e12 is certainly false (the matrix is "good" and stays untouched), and
+//     the explicit inverse is accurate to cond * eps <= 1e-9;
+//   * the dominant eigenvector by repeated squaring B <- B^2 / scale on the matrix cores: after k
+//     squarings the weight of the second eigenvalue is (lam_2 / lam_1)^(2^k); tr(B^2) / tr(B)^2 = sum of
+//     the squared weights says when it has vanished.  lam_max is the Rayleigh quotient.
+// Anything else -- a pivot <= 0, a bound above kFastCond, a pair of leading eigenvalues closer than
+// ~1e-11 relative (no convergence in kFastSquarings) -- returns false and the caller takes the
+// reference's own route (regularize: Jacobi eigh + the 100-trial loop).  The ellipsoids that
+// survive the accept test get their full eigen-system from k_out_eig at the end (same Jacobi, run
+// once per OUTPUT instead of once per tree node).
+constexpr double kFastCond = 1e7;
+constexpr int kFastSquarings = 48;
+
+// trace of a D x D LDS matrix, computed redundantly by every wave (D <= 44 < 64)
+__device__ __forceinline__ double wave_trace(const double* M, int D, int LD) {
+  const int lane = threadIdx.x & 63;
+  double v = lane < D ? M[lane * LD + lane] : 0.0;
+  for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s);
+  return v;
+}
+
+// Q = s2 * P P for the symmetric D x D matrix P (LDS, D x LD); all threads; caller barriers
+__device__ __forceinline__ void sym_square(const double* P, double* Q, int D, int LD, double s2) {
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  if (D >= kMfmaMinDim) {
+    const int nb = (D + 15) >> 4, ksteps = (D + 3) >> 2;
+    const int lj = lane & 15, lk = lane >> 4;
+    for (int tile = w; tile < nb * nb; tile += kThreads / 64) {
+      const int ti = tile / nb, tj = tile - ti * nb;
+      mfma_acc acc = {0.0, 0.0, 0.0, 0.0};
+      const int ca = ti * 16 + lj, cb = tj * 16 + lj;
+      for (int ks = 0; ks < ksteps; ++ks) {
+        const int k = ks * 4 + lk;
+        const bool kv = k < D;
+        // A[i][k] = P[k][i] (symmetric): both operands are row reads, lanes along the row
+        const double av = (kv && ca < D) ? P[k * LD + ca] : 0.0;
+        const double bv = (kv && cb < D) ? P[k * LD + cb] : 0.0;
+        acc = DH_MFMA_F64(av, bv, acc);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = ti * 16 + lk + 4 * r;
+        if (i < D && cb < D) Q[i * LD + cb] = acc[r] * s2;
+      }
+    }
+  } else {
+    for (int e = t; e < D * D; e += kThreads) {
+      const int i = e / D, j = e - i * D;
+      double sum = 0.0;
+      for (int k = 0; k < D; ++k) sum = fma(P[k * LD + i], P[k * LD + j], sum);
+      Q[i * LD + j] = sum * s2;
+    }
+  }
+}
+
+// in: cov (D x LD, global or LDS; untouched).  out (on true): L.AM = cov^-1, *logdet = ln det cov,
+// and with want_axis L.AX[:, 0] = sqrt(lam_max) v_max (canonical sign), L.lam[0] = lam_max, every
+// other column of L.AX and entry of L.lam zero.  Work space: L.A, L.V, L.AX, L.red.  All threads;
+// the return value is uniform.
+__device__ bool spd_fast(const Lds& L, const double* cov, int D, bool want_axis, double* logdet) {
+  const int t = threadIdx.x, LD = L.LD;
+  double* W = L.A;   // LDL^T in place: strict lower part = L D (unscaled columns), diagonal = pivots
+  double* M = L.V;   // L^-1 (unit lower)
+  double* rpiv = L.red;  // 1 / pivot
+  PH_T0();
+  bool bad = false;
+  for (int e = t; e < D * D; e += kThreads) {
+    const int i = e / D, j = e - i * D;
+    const double c = cov[i * LD + j];
+    if (!isfinite(c)) bad = true;
+    W[i * LD + j] = c;
+    M[i * LD + j] = (i == j) ? 1.0 : 0.0;
+  }
+  if (__syncthreads_or(bad ? 1 : 0)) return false;
+  const double tr_cov = wave_trace(W, D, LD);
+  // ---- LDL^T, right-looking; one barrier per column ----
+  const int tj = t & 63, ti = t >> 6;
+  bool ok = true;
+  for (int k = 0; k < D; ++k) {
+    const double piv = W[k * LD + k];
+    if (!(piv > 0.0) || !isfinite(piv)) {
+      ok = false;  // uniform: every thread reads the same word
+      break;
+    }
+    const double rp = 1.0 / piv;
+    if (t == 0) rpiv[k] = rp;
+    const int j = k + 1 + tj;
+    if (j < D) {
+      const double wjk = W[j * LD + k] * rp;
+      for (int i = j + ti; i < D; i += kThreads / 64) W[i * LD + j] = fma(-W[i * LD + k], wjk, W[i * LD + j]);
+    }
+    __syncthreads();
+  }
+  if (!ok) return false;
+  double ld;
+  {
+    const int lane = t & 63;  // every wave for itself (D <= 44 < 64)
+    ld = lane < D ? log(W[lane * LD + lane]) : 0.0;
+    for (int sft = 32; sft > 0; sft >>= 1) ld += __shfl_xor(ld, sft);
+  }
+  // ---- M = L^-1 by forward substitution, one thread per column (its recurrence is its own) ----
+  if (t < D) {
+    const int j = t;
+    for (int i = j + 1; i < D; ++i) {
+      double sum = 0.0;
+      for (int k = j; k < i; ++k) sum = fma(W[i * LD + k] * rpiv[k], M[k * LD + j], sum);
+      M[i * LD + j] = -sum;
+    }
+  }
+  __syncthreads();
+  // ---- AM = M^T D^-1 M ----
+  for (int e = t; e < D * D; e += kThreads) {
+    const int i = e / D, j = e - i * D;
+    if (i <= j) {
+      double sum = 0.0;
+      for (int k = j; k < D; ++k) sum = fma(M[k * LD + i] * rpiv[k], M[k * LD + j], sum);
+      L.AM[i * LD + j] = sum;
+      L.AM[j * LD + i] = sum;
+    }
+  }
+  __syncthreads();
+  const double tr_am = wave_trace(L.AM, D, LD);
+  // cond <= tr(cov) tr(cov^-1); NaN fails the comparison as well
+  if (!(tr_cov * tr_am < kFastCond)) return false;
+  *logdet = ld;
+  PH_ADD(13);
+  for (int e = t; e < D * D; e += kThreads) L.AX[(e / D) * LD + e % D] = 0.0;
+  if (t < D) L.lam[t] = 0.0;
+  if (!want_axis) {
+    __syncthreads();
+    return true;
+  }
+  if (D == 1) {
+    __syncthreads();
+    if (t == 0) {
+      L.AX[0] = sqrt(cov[0]);
+      L.lam[0] = cov[0];
+    }
+    __syncthreads();
+    return true;
+  }
+  // ---- dominant eigenvector by repeated squaring (W and M are free again) ----
+  double* P = W;
+  double* Q = M;
+  __syncthreads();  // everyone is done with W / M / the zero fill above
+  {
+    int ex;
+    (void)frexp(tr_cov, &ex);
+    const double s0 = ldexp(1.0, -ex);  // trace in [1/2, 1)
+    for (int e = t; e < D * D; e += kThreads) P[(e / D) * LD + e % D] = cov[(e / D) * LD + e % D] * s0;
+  }
+  __syncthreads();
+  double trP = wave_trace(P, D, LD);
+  bool conv = false;
+  for (int it = 0; it < kFastSquarings && !conv; ++it) {
+    sym_square(P, Q, D, LD, 1.0);
+    __syncthreads();
+    const double trQ = wave_trace(Q, D, LD);  // = ||P||_F^2
+    // r = sum of the squared eigenvalue weights of P, in [1/D, 1]; 1 - r ~ 2 w_2.  Once w_2(P) is
+    // below ~5e-9 the product just formed has w_2^2 < 1e-16: converged
+    const double r = trQ / (trP * trP);
+    conv = 1.0 - r < 1e-8;
+    // the next product is taken of s Q with s a power of two (exact) that brings the trace to [1/2, 1)
+    int ex;
+    (void)frexp(trQ, &ex);
+    const double sc = ldexp(1.0, -ex);
+    trP = trQ * sc;
+    for (int e = t; e < D * D; e += kThreads) Q[(e / D) * LD + e % D] *= sc;
+    double* tmp = P;
+    P = Q;
+    Q = tmp;
+    __syncthreads();
+  }
+  if (!conv) return false;
+  PH_ADD(14);
+  // column with the largest diagonal entry (v_j^2); normalise; canonical sign (largest component > 0)
+  __shared__ double s_v[64];
+  if (t < 64) {
+    double best = t < D ? P[t * LD + t] : -1.0;
+    int bi = t < D ? t : 0;
+    for (int sft = 32; sft > 0; sft >>= 1) {
+      const double ob = __shfl_xor(best, sft);
+      const int oi = __shfl_xor(bi, sft);
+      if (ob > best || (ob == best && oi < bi)) {
+        best = ob;
+        bi = oi;
+      }
+    }
+    const double x = t < D ? P[t * LD + bi] : 0.0;
+    double nn = x * x;
+    for (int sft = 32; sft > 0; sft >>= 1) nn += __shfl_xor(nn, sft);
+    double ax = fabs(x);
+    int ai = t;
+    for (int sft = 32; sft > 0; sft >>= 1) {
+      const double oa = __shfl_xor(ax, sft);
+      const int oi = __shfl_xor(ai, sft);
+      if (oa > ax || (oa == ax && oi < ai)) {
+        ax = oa;
+        ai = oi;
+      }
+    }
+    const double xs = __shfl(x, ai);
+    const double v = x * (xs < 0.0 ? -1.0 : 1.0) / sqrt(nn);
+    if (t < D) s_v[t] = v;
+  }
+  __syncthreads();
+  // lam_max = v^T cov v
+  if (t < 64) {
+    double y = 0.0;
+    if (t < D)
+      for (int k = 0; k < D; ++k) y = fma(cov[t * LD + k], s_v[k], y);
+    double q = t < D ? y * s_v[t] : 0.0;
+    for (int sft = 32; sft > 0; sft >>= 1) q += __shfl_xor(q, sft);
+    if (t < D) L.AX[t * LD] = s_v[t] * sqrt(q);
+    if (t == 0) L.lam[0] = q;
+  }
+  __syncthreads();
+  return L.lam[0] > 0.0 && isfinite(L.lam[0]);
+}
+
 // enlarge the ellipsoid so that the outermost point sits at 1 - ROUND_DELTA (bounding.py:1438-1448)
 __device__ __forceinline__ void ellipsoid_rescale(const Lds& L, double* cov_g, int D, double fmx) {
   const int t = threadIdx.x, LD = L.LD;
@@ -762,11 +997,35 @@ __device__ __forceinline__ int ellipsoid_store(const Lds& L, const RebuildArgs& 
   return DH_OK;
 }
 
+// record of an eigen-free node: ctr | cov | am | axes (column 0 = major axis, rest 0) | axlens
+// (entry 0 = its length, rest 0: k_split's argmax picks column 0).  ln vol = prefactor + ln det / 2.
+__device__ __forceinline__ int ellipsoid_store_fast(const Lds& L, const RebuildArgs& a, double* es,
+                                                    const double* cov_g, double logdet, double* logvol_out) {
+  const int D = a.d, t = threadIdx.x, LD = L.LD;
+  if (!isfinite(logdet)) return DH_ERR_VALUE;
+  const int DD = D * D;
+  if (t < D) {
+    es[t] = L.mean[t];
+    es[D + 3 * DD + t] = sqrt(L.lam[t]);
+  }
+  for (int e = t; e < DD; e += kThreads) {
+    const int i = e / D, j = e % D;
+    es[D + e] = cov_g[i * LD + j];
+    es[D + DD + e] = L.AM[i * LD + j];
+    es[D + 2 * DD + e] = L.AX[i * LD + j];
+  }
+  __syncthreads();
+  *logvol_out = a.prefactor + 0.5 * logdet;
+  return DH_OK;
+}
+
 // bounding_ellipsoid (bounding.py:1387-1461) of the node segment; writes the
 // ellipsoid record to `es` (global).  Returns 0 or a DH_ERR code (uniform).
 __device__ int node_ellipsoid(const Lds& L, const RebuildArgs& a, const double* pts, const int* perm,
-                              int start, int count, double* es, double* cov_g, double* logvol_out) {
+                              int start, int count, double* es, double* cov_g, double* logvol_out,
+                              int* fast_out) {
   const int D = a.d, t = threadIdx.x, LD = L.LD;
+  *fast_out = 0;
   if (count == 1) return DH_ERR_VALUE;
   PH_T0();
   node_mean(L, pts, perm, start, count, D);
@@ -776,6 +1035,19 @@ __device__ int node_ellipsoid(const Lds& L, const RebuildArgs& a, const double* 
   // cov_g: this node's D x LD working covariance (global scratch, L2 resident)
   for (int e = t; e < D * D; e += kThreads) cov_g[(e / D) * LD + e % D] = L.A[(e / D) * LD + e % D];
   __syncthreads();
+  if (a.fast) {
+    // eigen-free path: good_mat is certain, so the reference's loop ends after its first pass
+    double logdet = 0.0;
+    if (spd_fast(L, cov_g, D, a.mode == 0 && count >= 4 * D, &logdet)) {
+      const double fmx = node_fmax(L, pts, perm, start, count, D);
+      PH_ADD(3);
+      if (fmx > 1.0 - kRoundDelta) logdet += (double)D * log(fmx / (1.0 - kRoundDelta));
+      ellipsoid_rescale(L, cov_g, D, fmx);
+      *fast_out = 1;
+      return ellipsoid_store_fast(L, a, es, cov_g, logdet, logvol_out);
+    }
+    __syncthreads();
+  }
   for (int pass = 0; pass < 2; ++pass) {
     const bool good = regularize(L, cov_g, D);
     PH_ADD(2);
@@ -1161,10 +1433,12 @@ __global__ void __launch_bounds__(kThreads) k_root_parts(RebuildArgs a, int rp) 
   double* cov_g = v.estore + v.ES;
   int status = DH_OK;
   double lv = 0.0;
+  int root_fast = 0;      // the root's record is the eigen-free form
+  double root_logdet = 0.0;
   if (np == 1) {
     // small live set: the single-workgroup routine
     if (n <= 1) status = (a.mode == 0) ? DH_ERR_REGION : DH_ERR_VALUE;  // single point
-    if (status == DH_OK) status = node_ellipsoid(L, a, v.pts, v.perm, 0, n, es, cov_g, &lv);
+    if (status == DH_OK) status = node_ellipsoid(L, a, v.pts, v.perm, 0, n, es, cov_g, &lv, &root_fast);
   } else {
     double* rb = a.rootbuf + (size_t)run * a.rootbuf_stride;
     double* b_sum = rb;
@@ -1240,7 +1514,10 @@ __global__ void __launch_bounds__(kThreads) k_root_parts(RebuildArgs a, int rp) 
       cov_finalize(L, D, 1.0 / (double)(n - 1));
       for (int e = t; e < DD; e += kThreads) cov_g[(e / D) * LD + e % D] = L.A[(e / D) * LD + e % D];
       __syncthreads();
-      const bool good = regularize(L, cov_g, D);  // may overlay the tile with the Jacobi buffers
+      // eigen-free first (the tile stays resident); else the reference's route, which may overlay
+      // the tile with the Jacobi buffers
+      if (a.fast && spd_fast(L, cov_g, D, a.mode == 0 && n >= 4 * D, &root_logdet)) root_fast = 1;
+      const bool good = root_fast || regularize(L, cov_g, D);
       if (good) {
         for (int e = t; e < DD; e += kThreads) st_agent(b_am + e, L.AM[(e / D) * LD + e % D]);
         if (t == 0) st_agent(b_flag, 1.0);
@@ -1280,8 +1557,11 @@ __global__ void __launch_bounds__(kThreads) k_root_parts(RebuildArgs a, int rp) 
       if (q == 0) {
         double fmx = -INFINITY;
         for (int pp = 0; pp < np; ++pp) fmx = fmax(fmx, ld_agent(b_fmx + pp));
+        if (root_fast && fmx > 1.0 - kRoundDelta) root_logdet += (double)D * log(fmx / (1.0 - kRoundDelta));
         ellipsoid_rescale(L, cov_g, D, fmx);
-        if (status == DH_OK) status = ellipsoid_store(L, a, es, cov_g, &lv);
+        if (status == DH_OK)
+          status = root_fast ? ellipsoid_store_fast(L, a, es, cov_g, root_logdet, &lv)
+                             : ellipsoid_store(L, a, es, cov_g, &lv);
       }
     } else {
       // regularised covariance: the reference's second pass (bounding.py:1449-1453) by the
@@ -1292,7 +1572,7 @@ __global__ void __launch_bounds__(kThreads) k_root_parts(RebuildArgs a, int rp) 
         for (int p = t; p < n; p += kThreads) v.perm[p] = p;
         __threadfence_block();
         __syncthreads();
-        status = node_ellipsoid(L, a, v.pts, v.perm, 0, n, es, cov_g, &lv);
+        status = node_ellipsoid(L, a, v.pts, v.perm, 0, n, es, cov_g, &lv, &root_fast);
       }
       if (!parts_barrier(bar, np * ++phase)) status = DH_ERR_HIP;
     }
@@ -1356,6 +1636,8 @@ __global__ void __launch_bounds__(kThreads) k_root_parts(RebuildArgs a, int rp) 
     r.split = 0;
     r.res_start = 0;
     r.res_len = 0;
+    r.fast = root_fast;
+    r.pad_ = 0;
     r.logvol = lv;
     v.nodes[0] = r;
     a.nnodes_dev[run] = 1;
@@ -1424,6 +1706,8 @@ __global__ void __launch_bounds__(kThreads) k_split(RebuildArgs a, int level) {
       k0.split = k1.split = 0;
       k0.res_start = k1.res_start = 0;
       k0.res_len = k1.res_len = 0;
+      k0.fast = k1.fast = 0;
+      k0.pad_ = k1.pad_ = 0;
       k0.logvol = k1.logvol = 0.0;
       v.nodes[c0] = k0;
       v.nodes[c0 + 1] = k1;
@@ -1453,14 +1737,16 @@ __global__ void __launch_bounds__(kThreads) k_ell(RebuildArgs a, int level) {
   const int node = a.ell_list[(size_t)run * 2 * a.maxw + slot];
   const int start = v.nodes[node].start, count = v.nodes[node].count;
   double lv = 0.0;
+  int fast = 0;
   const int rc = node_ellipsoid(L, a, v.pts, v.perm, start, count, v.estore + (size_t)node * v.NS,
-                                v.estore + (size_t)node * v.NS + v.ES, &lv);
+                                v.estore + (size_t)node * v.NS + v.ES, &lv, &fast);
   if (rc != DH_OK) {
     set_status(a, run, rc);
     return;
   }
   if (t == 0) {
     v.nodes[node].logvol = lv;
+    v.nodes[node].fast = fast;
     if (count >= 4 * D) {  // big enough to try a split at the next level (:1492-1496)
       if (level + 1 >= a.levels) {
         atomicMin(&a.status[run], DH_ERR_NOMEM);  // deeper than the launch plan
@@ -1595,7 +1881,13 @@ __global__ void __launch_bounds__(kThreads) k_finish(RebuildArgs a) {
         o_am[(size_t)m * DD + e] = es[D + DD + e];
         o_ax[(size_t)m * DD + e] = es[D + 2 * DD + e];
       }
-      if (t == 0) o_lv[m] = nodes[ni].logvol;
+      if (t == 0) {
+        o_lv[m] = nodes[ni].logvol;
+        if (a.out_node) {
+          a.out_node[(size_t)run * a.max_ells + m] = ni;
+          a.out_fast[(size_t)run * a.max_ells + m] = nodes[ni].fast;
+        }
+      }
       if (a.leaf_of_point) {
         int* lop = a.leaf_of_point + (size_t)run * a.n;
         const int s0 = nodes[ni].start, c = nodes[ni].count;
@@ -1655,6 +1947,56 @@ __global__ void __launch_bounds__(kThreads) k_finish(RebuildArgs a) {
     a.nells[run] = (status == DH_OK) ? M : 0;
     a.status[run] = status;
     if (a.nnodes_out) a.nnodes_out[run] = nnodes;
+  }
+}
+
+// ---- the eigen-system of the OUTPUT ellipsoids -----------------------------------------------------
+// Tree nodes take the eigen-free path (spd_fast); the few that survive the accept test get what
+// Ellipsoid.__init__ computes (bounding.py:201-240: eigh of the final covariance -> axes, axis
+// lengths, log-volume; am = V diag(1/lam) V^T as improve_covar_mat forms it) here, one workgroup per
+// output ellipsoid, all runs at once.  grid = runs x G; workgroup g takes outputs g, g + G, ...
+__global__ void __launch_bounds__(kThreads) k_out_eig(RebuildArgs a, int G) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int run = blockIdx.x / G, g = blockIdx.x % G;
+  if (a.active && !a.active[run]) return;
+  if (a.status[run] != DH_OK) return;
+  const int M = a.nells[run];
+  if (g >= M) return;
+  const int D = a.d, DD = D * D, t = threadIdx.x;
+  Lds L;
+  carve(L, smem, D);
+  const RunView v = view_of(a, run, L.LD);
+  const int LD = L.LD;
+  for (int m = g; m < M; m += G) {
+    if (!a.out_fast[(size_t)run * a.max_ells + m]) continue;
+    const int ni = a.out_node[(size_t)run * a.max_ells + m];
+    double* cov_g = v.estore + (size_t)ni * v.NS + v.ES;  // the node's final (rescaled) covariance, D x LD
+    __syncthreads();
+    (void)regularize(L, cov_g, D);  // the certificate of spd_fast says "good": a plain eigh
+    bool ok = true;
+    double slog = 0.0;
+    for (int k = 0; k < D; ++k) {
+      const double l = L.lam[k];
+      if (!(l > 0.0) || !isfinite(l)) ok = false;
+      slog += log(l);
+    }
+    if (!ok) {
+      set_status(a, run, DH_ERR_VALUE);
+      if (t == 0) a.nells[run] = 0;
+      return;
+    }
+    double* o_cov = a.covs + ((size_t)run * a.max_ells + m) * DD;
+    double* o_am = a.ams + ((size_t)run * a.max_ells + m) * DD;
+    double* o_ax = a.axes + ((size_t)run * a.max_ells + m) * DD;
+    double* o_al = a.axlens + ((size_t)run * a.max_ells + m) * D;
+    for (int e = t; e < DD; e += kThreads) {
+      const int i = e / D, j = e - i * D;
+      o_cov[e] = cov_g[i * LD + j];
+      o_am[e] = L.AM[i * LD + j];
+      o_ax[e] = L.AX[i * LD + j];
+    }
+    if (t < D) o_al[t] = sqrt(L.lam[t]);
+    if (t == 0) a.logvols[(size_t)run * a.max_ells + m] = a.prefactor + 0.5 * slog;
   }
 }
 
@@ -1961,9 +2303,14 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
   const size_t b_sl = (size_t)2 * runs * a.maxw * 4, b_el = (size_t)runs * 2 * a.maxw * 4;
   const size_t b_sc = (size_t)runs * d * 8;
   const size_t b_ps = mode == 1 ? 0 : (size_t)runs * n * d * 8;
+  // eigen-free tree nodes (MultiEllipsoid.update only: Ellipsoid.update's single node IS the output)
+  a.fast = mode == 0 ? 1 : 0;
+  if (const char* e = getenv("DH_REBUILD_FAST")) a.fast = a.fast && atoi(e) != 0;  // diagnostic: 0 = eigh on every node
+  const size_t b_of = a.fast ? (size_t)runs * max_ells * 4 : 0;
   auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
   const size_t total = al(b_perm) * 2 + al(b_lab) + al(b_nodes) + al(b_es) + al(b_res) + al(b_cnt) +
-                       al(b_sl) + al(b_el) + al(b_sc) + al(b_ps) + al(b_pl) + al(b_pb) + al(b_kp) + al(b_rb) + al(b_fl) + al(b_fi);
+                       al(b_sl) + al(b_el) + al(b_sc) + al(b_ps) + al(b_pl) + al(b_pb) + al(b_kp) + al(b_rb) + al(b_fl) + al(b_fi) +
+                       2 * al(b_of);
   if (total > ctx->rebuild_ws_cap) {
     if (!hip_ok(ctx, hipStreamSynchronize(ctx->stream), "sync")) return DH_ERR_HIP;
     if (ctx->rebuild_ws) (void)hipFree(ctx->rebuild_ws);
@@ -2014,6 +2361,14 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
   a.fin_lse = (double*)w;
   w += al(b_fl);
   a.fin_int = (int*)w;
+  w += al(b_fi);
+  a.out_node = a.out_fast = nullptr;
+  if (a.fast) {
+    a.out_node = (int*)w;
+    w += al(b_of);
+    a.out_fast = (int*)w;
+    w += al(b_of);
+  }
   a.nells = nells;
   a.status = status;
   a.ctrs = ctrs;
@@ -2028,7 +2383,7 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
   a.n_arr = n_arr;
   DH_DEV_MEMO(attr_lds);
   if (lds > attr_lds) {
-    const void* ks[3] = {(const void*)k_root_parts, (const void*)k_split, (const void*)k_ell};
+    const void* ks[4] = {(const void*)k_root_parts, (const void*)k_split, (const void*)k_ell, (const void*)k_out_eig};
     for (const void* kf : ks)
       if (!hip_ok(ctx, hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
                   "hipFuncSetAttribute(rebuild LDS)"))
@@ -2049,6 +2404,10 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
     hipLaunchKernelGGL(k_ell, dim3(runs * 2 * a.maxw), dim3(kThreads), lds, ctx->stream, a, L);
   }
   hipLaunchKernelGGL(k_finish, dim3(runs), dim3(kThreads), lds_fin, ctx->stream, a);
+  if (a.fast) {
+    const int G = max_ells < 8 ? max_ells : 8;
+    hipLaunchKernelGGL(k_out_eig, dim3(runs * G), dim3(kThreads), lds, ctx->stream, a, G);
+  }
   return hip_ok(ctx, hipGetLastError(), "rebuild launch") ? DH_OK : DH_ERR_HIP;
 }
 

@@ -101,7 +101,9 @@ def test_improve_covar_mat_golden(ctx, tag, golden_bounding):
     # rank1: one eigenvalue 30, the rest floored at 10 * 30 / 1e12: cov to 1e-9 of its
     # norm; am (eigenvalues up to 1/3e-10) relative to ITS norm
     np.testing.assert_allclose(cov, ref_cov, rtol=0, atol=1e-9 * max(np.abs(ref_cov).max(), 1e-300))
-    np.testing.assert_allclose(am, ref_am, rtol=0, atol=1e-6 * np.abs(ref_am).max())
+    # rank1: the floored eigenvalues (3e-10 next to 30) are only defined to eps * 30 / 3e-10 = 2e-5
+    # relative by ANY eigensolver, and am = V diag(1/lam) V^T inherits that
+    np.testing.assert_allclose(am, ref_am, rtol=0, atol=(2e-4 if tag == "rank1" else 1e-9) * np.abs(ref_am).max())
     np.testing.assert_allclose(axes @ axes.T, cov, rtol=0, atol=1e-9 * np.abs(cov).max())
     lam = np.linalg.eigvalsh(cov)
     assert lam.min() > 0 and lam.max() / lam.min() <= 1e12 * (1 + 1e-6)  # the reference's own test_bounds
@@ -167,10 +169,15 @@ def test_scale_to_logvol_anisotropic_golden(ctx, name, golden_bounding):
     np.testing.assert_allclose(e.cov, rc, rtol=0, atol=(1e-5 if loose else 1e-9) * np.abs(rc).max())
     ra = g[f"{name}/aniso/am"]
     np.testing.assert_allclose(e.am, ra, rtol=0, atol=(1e-3 if loose else 1e-8) * np.abs(ra).max())
-    # the capped axes sit at sqrt(D)/2, the volume is the target
-    assert e.axlens.max() <= math.sqrt(d) / 2 * (1 + 1e-12)
+    # no axis is pushed beyond sqrt(D)/2 (one that already exceeds it is left alone); the volume
+    # is the target
+    grown = e.axlens > g[f"{name}/be/axlens"] * (1 + 1e-12)
+    assert np.all(e.axlens[grown] <= math.sqrt(d) / 2 * (1 + 1e-12))
+    # (two5: an axis already exceeds the cap and the "target" is below the current volume -- the
+    # reference then changes nothing but the stored logvol; the device follows, see the asserts above)
     from dynesty_amd.bounding import logvol_prefactor
-    np.testing.assert_allclose(logvol_prefactor(d) + np.log(e.axlens).sum(), target, atol=1e-9)
+    if target > float(g[f"{name}/be/logvol"]) and not np.any(g[f"{name}/be/axlens"] > math.sqrt(d) / 2):
+        np.testing.assert_allclose(logvol_prefactor(d) + np.log(e.axlens).sum(), target, atol=1e-9)
 
 
 def test_scale_to_logvol_iterable_targets(ctx, golden_bounding):
