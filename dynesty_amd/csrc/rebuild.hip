@@ -99,6 +99,8 @@ struct RebuildArgs {
   const int* active;  // runs or null: only runs with active[run] != 0 are rebuilt
   const int* n_arr;   // runs or null: per-run point count (<= n; rows beyond it are padding)
   int fast;           // 1: tree nodes take the eigen-free path (spd_fast); k_out_eig solves the outputs
+  int* nslow;         // levels x runs: nodes of the level the eigen-free path did not apply to
+  int* slow_list;     // runs x 2 maxw
   int* out_node;      // runs x max_ells: node behind output ellipsoid m (k_finish -> k_out_eig)
   int* out_fast;      // runs x max_ells: 1 = that node's record is the eigen-free form
 };
@@ -401,7 +403,7 @@ __device__ __forceinline__ void stage_tile(const Lds& L, const double* __restric
 }
 
 // mean of a node -> L.mean (np.mean(points, axis=0), bounding.py:1410)
-__device__ void node_mean(const Lds& L, const double* pts, const int* perm, int start, int count, int D) {
+__device__ __forceinline__ void node_mean(const Lds& L, const double* pts, const int* perm, int start, int count, int D) {
   const int t = threadIdx.x;
   const int G = kThreads / D > 0 ? kThreads / D : 1;  // point groups per dim
   const int j = t % D, g = t / D;
@@ -533,7 +535,7 @@ __device__ __forceinline__ void cov_finalize(const Lds& L, int D, double inv) {
   __syncthreads();
 }
 
-__device__ void node_cov(const Lds& L, const double* pts, const int* perm, int start, int count, int D) {
+__device__ __forceinline__ void node_cov(const Lds& L, const double* pts, const int* perm, int start, int count, int D) {
   mfma_acc acc[6];  // (0,0) (0,1) (1,1) (0,2) (1,2) (2,2)
 #pragma unroll
   for (int b = 0; b < 6; ++b) acc[b] = (mfma_acc){0.0, 0.0, 0.0, 0.0};
@@ -595,7 +597,7 @@ __device__ __forceinline__ double tile_quadform_max(const Lds& L, const double* 
 }
 
 // max_i delta_i^T AM delta_i over a node (bounding.py:1438), delta about L.mean
-__device__ double node_fmax(const Lds& L, const double* pts, const int* perm, int start, int count, int D) {
+__device__ __forceinline__ double node_fmax(const Lds& L, const double* pts, const int* perm, int start, int count, int D) {
   double best = -INFINITY;
   for (int base = 0; base < count; base += L.TP) {
     const int cnt = min(L.TP, count - base);
@@ -640,7 +642,7 @@ __device__ __forceinline__ void mat_from_eig(const Lds& L, double* out, const do
 // L.AX-independent copy `cov`), producing L.AM (precision), L.AX (axes), L.lam
 // (eigenvalues of the returned covariance).  `cov` is a D x LD global/LDS buffer
 // holding the matrix to regularise; it is updated in place.  Returns good_mat.
-__device__ bool regularize(const Lds& L, double* cov, int D) {
+__device__ __forceinline__ bool regularize(const Lds& L, double* cov, int D) {
   const int t = threadIdx.x;
   int failed = 0;
   int trial = 0;
@@ -783,71 +785,73 @@ __device__ __forceinline__ void sym_square(const double* P, double* Q, int D, in
   }
 }
 
+// 1 / x to full precision: v_rcp_f64 (2^-24, tools/micro/rsq_acc.hip) + two Newton steps
+__device__ __forceinline__ double rcp_nr(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) y = fma(y, fma(-x, y, 1.0), y);
+  return y;
+}
+
 // in: cov (D x LD, global or LDS; untouched).  out (on true): L.AM = cov^-1, *logdet = ln det cov,
 // and with want_axis L.AX[:, 0] = sqrt(lam_max) v_max (canonical sign), L.lam[0] = lam_max, every
 // other column of L.AX and entry of L.lam zero.  Work space: L.A, L.V, L.AX, L.red.  All threads;
 // the return value is uniform.
-__device__ bool spd_fast(const Lds& L, const double* cov, int D, bool want_axis, double* logdet) {
+//
+// The inverse is formed by D sweeps (the sweep operator of regression codes: Gauss-Jordan on a
+// symmetric matrix without pivoting -- for a positive definite matrix the pivots are the positive
+// Schur-complement pivots of LDL^T, so their logarithms sum to ln det).  Sweep k reads one buffer and
+// writes the other (L.AM <-> L.A), so a sweep is: pivot, pivot row / column, own entries, ONE barrier.
+// Thread map: column j = t mod JW, rows t / JW, t / JW + 256 / JW, ... (JW = 32 or 64 >= D).
+__device__ __forceinline__ bool spd_fast(const Lds& L, const double* cov, int D, bool want_axis, double* logdet) {
   const int t = threadIdx.x, LD = L.LD;
-  double* W = L.A;   // LDL^T in place: strict lower part = L D (unscaled columns), diagonal = pivots
-  double* M = L.V;   // L^-1 (unit lower)
-  double* rpiv = L.red;  // 1 / pivot
+  const int jsh = D <= 32 ? 5 : 6;
+  const int j = t & ((1 << jsh) - 1), i0 = t >> jsh, istep = kThreads >> jsh;
+  double* src = (D & 1) ? L.AM : L.A;  // D sweeps later the result sits in L.A
+  double* dst = (D & 1) ? L.A : L.AM;
+  double* pivs = L.red;  // the D pivots
   PH_T0();
   bool bad = false;
-  for (int e = t; e < D * D; e += kThreads) {
-    const int i = e / D, j = e - i * D;
-    const double c = cov[i * LD + j];
-    if (!isfinite(c)) bad = true;
-    W[i * LD + j] = c;
-    M[i * LD + j] = (i == j) ? 1.0 : 0.0;
-  }
+  if (j < D)
+    for (int i = i0; i < D; i += istep) {
+      const double c = cov[i * LD + j];
+      if (!isfinite(c)) bad = true;
+      src[i * LD + j] = c;
+    }
   if (__syncthreads_or(bad ? 1 : 0)) return false;
-  const double tr_cov = wave_trace(W, D, LD);
-  // ---- LDL^T, right-looking; one barrier per column ----
-  const int tj = t & 63, ti = t >> 6;
+  const double tr_cov = wave_trace(src, D, LD);
   bool ok = true;
   for (int k = 0; k < D; ++k) {
-    const double piv = W[k * LD + k];
+    const double piv = src[k * LD + k];
     if (!(piv > 0.0) || !isfinite(piv)) {
       ok = false;  // uniform: every thread reads the same word
       break;
     }
-    const double rp = 1.0 / piv;
-    if (t == 0) rpiv[k] = rp;
-    const int j = k + 1 + tj;
+    const double rp = rcp_nr(piv);
+    if (t == 0) pivs[k] = piv;
     if (j < D) {
-      const double wjk = W[j * LD + k] * rp;
-      for (int i = j + ti; i < D; i += kThreads / 64) W[i * LD + j] = fma(-W[i * LD + k], wjk, W[i * LD + j]);
+      const double cj = src[k * LD + j];
+      const double cjr = cj * rp;
+      for (int i = i0; i < D; i += istep) {
+        const double ci = src[i * LD + k], w = src[i * LD + j];
+        dst[i * LD + j] = (i == k) ? (j == k ? -rp : cjr) : (j == k ? ci * rp : fma(-ci, cjr, w));
+      }
     }
     __syncthreads();
+    double* tmp = src;
+    src = dst;
+    dst = tmp;
   }
   if (!ok) return false;
   double ld;
   {
     const int lane = t & 63;  // every wave for itself (D <= 44 < 64)
-    ld = lane < D ? log(W[lane * LD + lane]) : 0.0;
+    ld = lane < D ? log(pivs[lane]) : 0.0;
     for (int sft = 32; sft > 0; sft >>= 1) ld += __shfl_xor(ld, sft);
   }
-  // ---- M = L^-1 by forward substitution, one thread per column (its recurrence is its own) ----
-  if (t < D) {
-    const int j = t;
-    for (int i = j + 1; i < D; ++i) {
-      double sum = 0.0;
-      for (int k = j; k < i; ++k) sum = fma(W[i * LD + k] * rpiv[k], M[k * LD + j], sum);
-      M[i * LD + j] = -sum;
-    }
-  }
-  __syncthreads();
-  // ---- AM = M^T D^-1 M ----
-  for (int e = t; e < D * D; e += kThreads) {
-    const int i = e / D, j = e - i * D;
-    if (i <= j) {
-      double sum = 0.0;
-      for (int k = j; k < D; ++k) sum = fma(M[k * LD + i] * rpiv[k], M[k * LD + j], sum);
-      L.AM[i * LD + j] = sum;
-      L.AM[j * LD + i] = sum;
-    }
-  }
+  // AM = -(result), symmetrised (the two triangles differ by rounding); result in L.A, AM elsewhere
+  if (j < D)
+    for (int i = i0; i < D; i += istep) L.AM[i * LD + j] = -0.5 * (L.A[i * LD + j] + L.A[j * LD + i]);
   __syncthreads();
   const double tr_am = wave_trace(L.AM, D, LD);
   // cond <= tr(cov) tr(cov^-1); NaN fails the comparison as well
@@ -869,37 +873,31 @@ __device__ bool spd_fast(const Lds& L, const double* cov, int D, bool want_axis,
     __syncthreads();
     return true;
   }
-  // ---- dominant eigenvector by repeated squaring (W and M are free again) ----
-  double* P = W;
-  double* Q = M;
-  __syncthreads();  // everyone is done with W / M / the zero fill above
+  // ---- dominant eigenvector by repeated squaring ----
+  double* P = L.A;
+  double* Q = L.V;
   {
-    int ex;
-    (void)frexp(tr_cov, &ex);
-    const double s0 = ldexp(1.0, -ex);  // trace in [1/2, 1)
+    const double s0 = ldexp(1.0, -(ilogb(tr_cov) + 1));  // trace in [1/2, 1)
     for (int e = t; e < D * D; e += kThreads) P[(e / D) * LD + e % D] = cov[(e / D) * LD + e % D] * s0;
   }
   __syncthreads();
   double trP = wave_trace(P, D, LD);
   bool conv = false;
   for (int it = 0; it < kFastSquarings && !conv; ++it) {
-    sym_square(P, Q, D, LD, 1.0);
+    // the product is scaled by a power of two (exact) chosen from tr(P)^2, the upper bound of its
+    // trace: tr(P^2) / tr(P)^2 = r in [1/D, 1] is the sum of the squared eigenvalue weights of P, so the
+    // stored trace stays within [1/(4D), 1) without a pass of its own
+    const double sc = ldexp(1.0, -(ilogb(trP * trP) + 1));
+    sym_square(P, Q, D, LD, sc);
     __syncthreads();
-    const double trQ = wave_trace(Q, D, LD);  // = ||P||_F^2
-    // r = sum of the squared eigenvalue weights of P, in [1/D, 1]; 1 - r ~ 2 w_2.  Once w_2(P) is
-    // below ~5e-9 the product just formed has w_2^2 < 1e-16: converged
-    const double r = trQ / (trP * trP);
+    const double trQ = wave_trace(Q, D, LD);
+    const double r = trQ / (trP * trP * sc);
+    // 1 - r ~ 2 w_2: once w_2(P) is below ~5e-9 the product just formed has w_2^2 < 1e-16
     conv = 1.0 - r < 1e-8;
-    // the next product is taken of s Q with s a power of two (exact) that brings the trace to [1/2, 1)
-    int ex;
-    (void)frexp(trQ, &ex);
-    const double sc = ldexp(1.0, -ex);
-    trP = trQ * sc;
-    for (int e = t; e < D * D; e += kThreads) Q[(e / D) * LD + e % D] *= sc;
+    trP = trQ;
     double* tmp = P;
     P = Q;
     Q = tmp;
-    __syncthreads();
   }
   if (!conv) return false;
   PH_ADD(14);
@@ -1021,11 +1019,14 @@ __device__ __forceinline__ int ellipsoid_store_fast(const Lds& L, const RebuildA
 
 // bounding_ellipsoid (bounding.py:1387-1461) of the node segment; writes the
 // ellipsoid record to `es` (global).  Returns 0 or a DH_ERR code (uniform).
-__device__ int node_ellipsoid(const Lds& L, const RebuildArgs& a, const double* pts, const int* perm,
-                              int start, int count, double* es, double* cov_g, double* logvol_out,
-                              int* fast_out) {
+constexpr int kNeedSlow = 1;  // node_ellipsoid<true>: the eigen-free path does not apply to this node
+
+// FAST = true: the eigen-free path only (returns kNeedSlow when it does not apply);
+// FAST = false: the reference's route (improve_covar_mat with a full eigh per trial).
+template <bool FAST>
+__device__ __forceinline__ int node_ellipsoid(const Lds& L, const RebuildArgs& a, const double* pts, const int* perm,
+                                              int start, int count, double* es, double* cov_g, double* logvol_out) {
   const int D = a.d, t = threadIdx.x, LD = L.LD;
-  *fast_out = 0;
   if (count == 1) return DH_ERR_VALUE;
   PH_T0();
   node_mean(L, pts, perm, start, count, D);
@@ -1035,29 +1036,27 @@ __device__ int node_ellipsoid(const Lds& L, const RebuildArgs& a, const double* 
   // cov_g: this node's D x LD working covariance (global scratch, L2 resident)
   for (int e = t; e < D * D; e += kThreads) cov_g[(e / D) * LD + e % D] = L.A[(e / D) * LD + e % D];
   __syncthreads();
-  if (a.fast) {
+  if constexpr (FAST) {
     // eigen-free path: good_mat is certain, so the reference's loop ends after its first pass
     double logdet = 0.0;
-    if (spd_fast(L, cov_g, D, a.mode == 0 && count >= 4 * D, &logdet)) {
-      const double fmx = node_fmax(L, pts, perm, start, count, D);
-      PH_ADD(3);
-      if (fmx > 1.0 - kRoundDelta) logdet += (double)D * log(fmx / (1.0 - kRoundDelta));
-      ellipsoid_rescale(L, cov_g, D, fmx);
-      *fast_out = 1;
-      return ellipsoid_store_fast(L, a, es, cov_g, logdet, logvol_out);
-    }
-    __syncthreads();
-  }
-  for (int pass = 0; pass < 2; ++pass) {
-    const bool good = regularize(L, cov_g, D);
-    PH_ADD(2);
+    if (!spd_fast(L, cov_g, D, a.mode == 0 && count >= 4 * D, &logdet)) return kNeedSlow;
     const double fmx = node_fmax(L, pts, perm, start, count, D);
     PH_ADD(3);
-    if (pass == 0) ellipsoid_rescale(L, cov_g, D, fmx);
-    if (pass == 1 && fmx >= 1.0) return DH_ERR_CONTAIN;
-    if (good) break;
+    if (fmx > 1.0 - kRoundDelta) logdet += (double)D * log(fmx / (1.0 - kRoundDelta));
+    ellipsoid_rescale(L, cov_g, D, fmx);
+    return ellipsoid_store_fast(L, a, es, cov_g, logdet, logvol_out);
+  } else {
+    for (int pass = 0; pass < 2; ++pass) {
+      const bool good = regularize(L, cov_g, D);
+      PH_ADD(2);
+      const double fmx = node_fmax(L, pts, perm, start, count, D);
+      PH_ADD(3);
+      if (pass == 0) ellipsoid_rescale(L, cov_g, D, fmx);
+      if (pass == 1 && fmx >= 1.0) return DH_ERR_CONTAIN;
+      if (good) break;
+    }
+    return ellipsoid_store(L, a, es, cov_g, logvol_out);
   }
-  return ellipsoid_store(L, a, es, cov_g, logvol_out);
 }
 
 // ---- k-means (k = 2) + stable partition of a node, cooperatively by its parts -----------
@@ -1438,7 +1437,15 @@ __global__ void __launch_bounds__(kThreads) k_root_parts(RebuildArgs a, int rp) 
   if (np == 1) {
     // small live set: the single-workgroup routine
     if (n <= 1) status = (a.mode == 0) ? DH_ERR_REGION : DH_ERR_VALUE;  // single point
-    if (status == DH_OK) status = node_ellipsoid(L, a, v.pts, v.perm, 0, n, es, cov_g, &lv, &root_fast);
+    if (status == DH_OK) {
+      status = kNeedSlow;
+      if (a.fast) status = node_ellipsoid<true>(L, a, v.pts, v.perm, 0, n, es, cov_g, &lv);
+      root_fast = status == DH_OK;
+      if (status == kNeedSlow) {
+        __syncthreads();
+        status = node_ellipsoid<false>(L, a, v.pts, v.perm, 0, n, es, cov_g, &lv);
+      }
+    }
   } else {
     double* rb = a.rootbuf + (size_t)run * a.rootbuf_stride;
     double* b_sum = rb;
@@ -1572,7 +1579,7 @@ __global__ void __launch_bounds__(kThreads) k_root_parts(RebuildArgs a, int rp) 
         for (int p = t; p < n; p += kThreads) v.perm[p] = p;
         __threadfence_block();
         __syncthreads();
-        status = node_ellipsoid(L, a, v.pts, v.perm, 0, n, es, cov_g, &lv, &root_fast);
+        status = node_ellipsoid<false>(L, a, v.pts, v.perm, 0, n, es, cov_g, &lv);
       }
       if (!parts_barrier(bar, np * ++phase)) status = DH_ERR_HIP;
     }
@@ -1721,10 +1728,17 @@ __global__ void __launch_bounds__(kThreads) k_split(RebuildArgs a, int level) {
   }
 }
 
-__global__ void __launch_bounds__(kThreads) k_ell(RebuildArgs a, int level) {
+// One workgroup per new child.  SLOW = false: the eigen-free path; a node it does not apply to goes on
+// the level's slow list.  SLOW = true: the reference's route for those nodes (grid = runs x G,
+// workgroup g takes entries g, g + G, ...), or for every node of the level when the eigen-free path is
+// switched off.  Two kernels so that the common one stays small (registers: two workgroups per CU).
+template <bool SLOW>
+__global__ void __launch_bounds__(kThreads) k_ell(RebuildArgs a, int level, int G) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int run = blockIdx.x / (2 * a.maxw), slot = blockIdx.x % (2 * a.maxw);
-  if (slot >= a.nell[(size_t)level * a.runs + run]) return;
+  const int run = blockIdx.x / G, g = blockIdx.x % G;
+  const int* list = (SLOW && a.fast) ? a.slow_list + (size_t)run * 2 * a.maxw : a.ell_list + (size_t)run * 2 * a.maxw;
+  const int cnt = (SLOW && a.fast) ? a.nslow[(size_t)level * a.runs + run] : a.nell[(size_t)level * a.runs + run];
+  if (g >= cnt) return;
   if (a.kerr[run] != DH_OK) {  // raised by a k_split workgroup of this level
     if (threadIdx.x == 0) atomicMin(&a.status[run], a.kerr[run]);
     return;
@@ -1734,24 +1748,34 @@ __global__ void __launch_bounds__(kThreads) k_ell(RebuildArgs a, int level) {
   Lds L;
   carve(L, smem, D);
   const RunView v = view_of(a, run, L.LD);
-  const int node = a.ell_list[(size_t)run * 2 * a.maxw + slot];
-  const int start = v.nodes[node].start, count = v.nodes[node].count;
-  double lv = 0.0;
-  int fast = 0;
-  const int rc = node_ellipsoid(L, a, v.pts, v.perm, start, count, v.estore + (size_t)node * v.NS,
-                                v.estore + (size_t)node * v.NS + v.ES, &lv, &fast);
-  if (rc != DH_OK) {
-    set_status(a, run, rc);
-    return;
-  }
-  if (t == 0) {
-    v.nodes[node].logvol = lv;
-    v.nodes[node].fast = fast;
-    if (count >= 4 * D) {  // big enough to try a split at the next level (:1492-1496)
-      if (level + 1 >= a.levels) {
-        atomicMin(&a.status[run], DH_ERR_NOMEM);  // deeper than the launch plan
-      } else {
-        queue_split(a, run, level + 1, node, count, kThreads);
+  for (int slot = g; slot < cnt; slot += G) {
+    const int node = list[slot];
+    const int start = v.nodes[node].start, count = v.nodes[node].count;
+    double lv = 0.0;
+    __syncthreads();
+    L.c_pts = nullptr;
+    const int rc = node_ellipsoid<!SLOW>(L, a, v.pts, v.perm, start, count, v.estore + (size_t)node * v.NS,
+                                         v.estore + (size_t)node * v.NS + v.ES, &lv);
+    if (!SLOW && rc == kNeedSlow) {
+      if (t == 0) {
+        const int e = atomicAdd(&a.nslow[(size_t)level * a.runs + run], 1);
+        a.slow_list[(size_t)run * 2 * a.maxw + e] = node;
+      }
+      continue;
+    }
+    if (rc != DH_OK) {
+      set_status(a, run, rc);
+      return;
+    }
+    if (t == 0) {
+      v.nodes[node].logvol = lv;
+      v.nodes[node].fast = SLOW ? 0 : 1;
+      if (count >= 4 * D) {  // big enough to try a split at the next level (:1492-1496)
+        if (level + 1 >= a.levels) {
+          atomicMin(&a.status[run], DH_ERR_NOMEM);  // deeper than the launch plan
+        } else {
+          queue_split(a, run, level + 1, node, count, kThreads);
+        }
       }
     }
   }
@@ -2294,7 +2318,7 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
   if ((long long)runs * rp > 512) rp = 1;
   if (getenv("DH_ROOT_PARTS") && atoi(getenv("DH_ROOT_PARTS")) == 0) rp = 1;  // diagnostic
   // zeroed counters: nnodes | nsplit (levels+1) | nell (levels) | nparts (levels+1) | kerr | rbar | kbar (levels x maxw)
-  const size_t b_cnt = (size_t)runs * ((size_t)3 * a.levels + 5 + kBarStride + (size_t)a.levels * a.maxw * kBarStride) * 4;
+  const size_t b_cnt = (size_t)runs * ((size_t)4 * a.levels + 5 + kBarStride + (size_t)a.levels * a.maxw * kBarStride) * 4;
   a.rootbuf_stride = (size_t)rp * (2 * (size_t)d + (size_t)d * d + 1) + (size_t)d * d + 8;
   const size_t b_rb = (size_t)runs * a.rootbuf_stride * 8;
   const size_t b_fl = (size_t)runs * a.max_nodes * 8, b_fi = (size_t)runs * a.max_nodes * 2 * 4;
@@ -2309,7 +2333,7 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
   const size_t b_of = a.fast ? (size_t)runs * max_ells * 4 : 0;
   auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
   const size_t total = al(b_perm) * 2 + al(b_lab) + al(b_nodes) + al(b_es) + al(b_res) + al(b_cnt) +
-                       al(b_sl) + al(b_el) + al(b_sc) + al(b_ps) + al(b_pl) + al(b_pb) + al(b_kp) + al(b_rb) + al(b_fl) + al(b_fi) +
+                       al(b_sl) + 2 * al(b_el) + al(b_sc) + al(b_ps) + al(b_pl) + al(b_pb) + al(b_kp) + al(b_rb) + al(b_fl) + al(b_fi) +
                        2 * al(b_of);
   if (total > ctx->rebuild_ws_cap) {
     if (!hip_ok(ctx, hipStreamSynchronize(ctx->stream), "sync")) return DH_ERR_HIP;
@@ -2340,11 +2364,14 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
   a.nell = a.nsplit + (size_t)(a.levels + 1) * runs;
   a.nparts = a.nell + (size_t)a.levels * runs;
   a.kerr = a.nparts + (size_t)(a.levels + 1) * runs;
-  a.rbar = a.kerr + runs;
+  a.nslow = a.kerr + runs;
+  a.rbar = a.nslow + (size_t)a.levels * runs;
   a.kbar = a.rbar + (size_t)runs * kBarStride;
   a.split_list = (int*)w;
   w += al(b_sl);
   a.ell_list = (int*)w;
+  w += al(b_el);
+  a.slow_list = (int*)w;
   w += al(b_el);
   a.scale_g = (double*)w;
   w += al(b_sc);
@@ -2383,7 +2410,8 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
   a.n_arr = n_arr;
   DH_DEV_MEMO(attr_lds);
   if (lds > attr_lds) {
-    const void* ks[4] = {(const void*)k_root_parts, (const void*)k_split, (const void*)k_ell, (const void*)k_out_eig};
+    const void* ks[5] = {(const void*)k_root_parts, (const void*)k_split, (const void*)k_ell<false>,
+                         (const void*)k_ell<true>, (const void*)k_out_eig};
     for (const void* kf : ks)
       if (!hip_ok(ctx, hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
                   "hipFuncSetAttribute(rebuild LDS)"))
@@ -2401,7 +2429,11 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
   hipLaunchKernelGGL(k_root_parts, dim3(runs * rp), dim3(kThreads), lds, ctx->stream, a, rp);
   for (int L = 0; L < a.levels; ++L) {
     hipLaunchKernelGGL(k_split, dim3(runs * a.maxp), dim3(kThreads), lds, ctx->stream, a, L);
-    hipLaunchKernelGGL(k_ell, dim3(runs * 2 * a.maxw), dim3(kThreads), lds, ctx->stream, a, L);
+    if (a.fast) hipLaunchKernelGGL(k_ell<false>, dim3(runs * 2 * a.maxw), dim3(kThreads), lds, ctx->stream, a, L, 2 * a.maxw);
+    // the reference's route: the (rare) nodes the eigen-free path handed over, two workgroups per run
+    // striding over them -- or every node of the level when that path is off
+    const int gs = a.fast ? 2 : 2 * a.maxw;
+    hipLaunchKernelGGL(k_ell<true>, dim3(runs * gs), dim3(kThreads), lds, ctx->stream, a, L, gs);
   }
   hipLaunchKernelGGL(k_finish, dim3(runs), dim3(kThreads), lds_fin, ctx->stream, a);
   if (a.fast) {

@@ -4,7 +4,7 @@ sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests')
 import inputs
 from dynesty_amd import _lib
 ctx=_lib.Context(0)
-names=["mean","cov","regularize(all)","fmax","kmeans","partition","  jacobi","  sort_eigs","  copy/axes","  am","  km:vq","  km:sums","  km:update"]
+names=["mean","cov","regularize(all)","fmax","kmeans","partition","  jacobi","  sort_eigs","  copy/axes","  am","  km:vq","  km:sums","  km:update","  fast:ldl+inv","  fast:squaring","15"]
 for cloud,multi in (("c2",True),("c2",False),("c3",True)):
     pts=inputs.cloud(cloud)
     ctx.rebuild(pts,multi=multi)
