@@ -131,6 +131,12 @@ void dh_destroy(dh_ctx* ctx) {
   if (ctx->arena) (void)hipFree(ctx->arena);
   if (ctx->axes_t) (void)hipFree(ctx->axes_t);
   if (ctx->rebuild_ws) (void)hipFree(ctx->rebuild_ws);
+  if (ctx->side_stream) {
+    (void)hipStreamSynchronize(ctx->side_stream);
+    (void)hipStreamDestroy(ctx->side_stream);
+  }
+  if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+  if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }

@@ -52,6 +52,10 @@ struct dh_ctx {
   // scratch of the rebuild kernel (permutations, node table, per-node ellipsoids)
   char* rebuild_ws = nullptr;
   size_t rebuild_ws_cap = 0;
+  // side stream of the rebuild: the root's full eigen-system is solved there while the tree is built
+  // on `stream` (fork after k_root, join before k_finish); created on first use
+  hipStream_t side_stream = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 
   const uint64_t* zki() const { return zig; }
   const uint64_t* zwi() const { return zig + 256; }

@@ -43,6 +43,7 @@ struct Node {
   int fast;         // 1: the record holds the eigen-free form (spd_fast): am, major axis, logvol only
   int pad_;
   double logvol;
+  double fmax;      // max_i delta_i^T am delta_i over the node's own points, with the stored am (after the rescale)
 };
 
 struct RebuildArgs {
@@ -101,6 +102,7 @@ struct RebuildArgs {
   int fast;           // 1: tree nodes take the eigen-free path (spd_fast); k_out_eig solves the outputs
   int* nslow;         // levels x runs: nodes of the level the eigen-free path did not apply to
   int* slow_list;     // runs x 2 maxw
+  double* root_eig;   // runs x (2 D^2 + D + 2): am | axes | axlens | logvol | ok -- the root's eigen-system (k_root_eig)
   int* out_node;      // runs x max_ells: node behind output ellipsoid m (k_finish -> k_out_eig)
   int* out_fast;      // runs x max_ells: 1 = that node's record is the eigen-free form
 };
@@ -1025,7 +1027,8 @@ constexpr int kNeedSlow = 1;  // node_ellipsoid<true>: the eigen-free path does 
 // FAST = false: the reference's route (improve_covar_mat with a full eigh per trial).
 template <bool FAST>
 __device__ __forceinline__ int node_ellipsoid(const Lds& L, const RebuildArgs& a, const double* pts, const int* perm,
-                                              int start, int count, double* es, double* cov_g, double* logvol_out) {
+                                              int start, int count, double* es, double* cov_g, double* logvol_out,
+                                              double* fmax_out) {
   const int D = a.d, t = threadIdx.x, LD = L.LD;
   if (count == 1) return DH_ERR_VALUE;
   PH_T0();
@@ -1044,6 +1047,7 @@ __device__ __forceinline__ int node_ellipsoid(const Lds& L, const RebuildArgs& a
     PH_ADD(3);
     if (fmx > 1.0 - kRoundDelta) logdet += (double)D * log(fmx / (1.0 - kRoundDelta));
     ellipsoid_rescale(L, cov_g, D, fmx);
+    *fmax_out = fmin(fmx, 1.0 - kRoundDelta);  // the quadratic forms scale with am: fmx / mult
     return ellipsoid_store_fast(L, a, es, cov_g, logdet, logvol_out);
   } else {
     for (int pass = 0; pass < 2; ++pass) {
@@ -1053,6 +1057,7 @@ __device__ __forceinline__ int node_ellipsoid(const Lds& L, const RebuildArgs& a
       PH_ADD(3);
       if (pass == 0) ellipsoid_rescale(L, cov_g, D, fmx);
       if (pass == 1 && fmx >= 1.0) return DH_ERR_CONTAIN;
+      *fmax_out = pass == 0 ? fmin(fmx, 1.0 - kRoundDelta) : fmx;
       if (good) break;
     }
     return ellipsoid_store(L, a, es, cov_g, logvol_out);
@@ -1434,16 +1439,17 @@ __global__ void __launch_bounds__(kThreads) k_root_parts(RebuildArgs a, int rp) 
   double lv = 0.0;
   int root_fast = 0;      // the root's record is the eigen-free form
   double root_logdet = 0.0;
+  double root_fmax = INFINITY;  // "unknown": k_finish then runs the coverage pass
   if (np == 1) {
     // small live set: the single-workgroup routine
     if (n <= 1) status = (a.mode == 0) ? DH_ERR_REGION : DH_ERR_VALUE;  // single point
     if (status == DH_OK) {
       status = kNeedSlow;
-      if (a.fast) status = node_ellipsoid<true>(L, a, v.pts, v.perm, 0, n, es, cov_g, &lv);
+      if (a.fast) status = node_ellipsoid<true>(L, a, v.pts, v.perm, 0, n, es, cov_g, &lv, &root_fmax);
       root_fast = status == DH_OK;
       if (status == kNeedSlow) {
         __syncthreads();
-        status = node_ellipsoid<false>(L, a, v.pts, v.perm, 0, n, es, cov_g, &lv);
+        status = node_ellipsoid<false>(L, a, v.pts, v.perm, 0, n, es, cov_g, &lv, &root_fmax);
       }
     }
   } else {
@@ -1566,6 +1572,7 @@ __global__ void __launch_bounds__(kThreads) k_root_parts(RebuildArgs a, int rp) 
         for (int pp = 0; pp < np; ++pp) fmx = fmax(fmx, ld_agent(b_fmx + pp));
         if (root_fast && fmx > 1.0 - kRoundDelta) root_logdet += (double)D * log(fmx / (1.0 - kRoundDelta));
         ellipsoid_rescale(L, cov_g, D, fmx);
+        root_fmax = fmin(fmx, 1.0 - kRoundDelta);
         if (status == DH_OK)
           status = root_fast ? ellipsoid_store_fast(L, a, es, cov_g, root_logdet, &lv)
                              : ellipsoid_store(L, a, es, cov_g, &lv);
@@ -1579,7 +1586,7 @@ __global__ void __launch_bounds__(kThreads) k_root_parts(RebuildArgs a, int rp) 
         for (int p = t; p < n; p += kThreads) v.perm[p] = p;
         __threadfence_block();
         __syncthreads();
-        status = node_ellipsoid<false>(L, a, v.pts, v.perm, 0, n, es, cov_g, &lv);
+        status = node_ellipsoid<false>(L, a, v.pts, v.perm, 0, n, es, cov_g, &lv, &root_fmax);
       }
       if (!parts_barrier(bar, np * ++phase)) status = DH_ERR_HIP;
     }
@@ -1646,6 +1653,7 @@ __global__ void __launch_bounds__(kThreads) k_root_parts(RebuildArgs a, int rp) 
     r.fast = root_fast;
     r.pad_ = 0;
     r.logvol = lv;
+    r.fmax = root_fmax;
     v.nodes[0] = r;
     a.nnodes_dev[run] = 1;
     a.status[run] = status;
@@ -1716,6 +1724,7 @@ __global__ void __launch_bounds__(kThreads) k_split(RebuildArgs a, int level) {
       k0.fast = k1.fast = 0;
       k0.pad_ = k1.pad_ = 0;
       k0.logvol = k1.logvol = 0.0;
+      k0.fmax = k1.fmax = INFINITY;
       v.nodes[c0] = k0;
       v.nodes[c0 + 1] = k1;
       v.nodes[cur].child0 = c0;
@@ -1751,11 +1760,11 @@ __global__ void __launch_bounds__(kThreads) k_ell(RebuildArgs a, int level, int 
   for (int slot = g; slot < cnt; slot += G) {
     const int node = list[slot];
     const int start = v.nodes[node].start, count = v.nodes[node].count;
-    double lv = 0.0;
+    double lv = 0.0, fmx = INFINITY;
     __syncthreads();
     L.c_pts = nullptr;
     const int rc = node_ellipsoid<!SLOW>(L, a, v.pts, v.perm, start, count, v.estore + (size_t)node * v.NS,
-                                         v.estore + (size_t)node * v.NS + v.ES, &lv);
+                                         v.estore + (size_t)node * v.NS + v.ES, &lv, &fmx);
     if (!SLOW && rc == kNeedSlow) {
       if (t == 0) {
         const int e = atomicAdd(&a.nslow[(size_t)level * a.runs + run], 1);
@@ -1769,6 +1778,7 @@ __global__ void __launch_bounds__(kThreads) k_ell(RebuildArgs a, int level, int 
     }
     if (t == 0) {
       v.nodes[node].logvol = lv;
+      v.nodes[node].fmax = fmx;
       v.nodes[node].fast = SLOW ? 0 : 1;
       if (count >= 4 * D) {  // big enough to try a split at the next level (:1492-1496)
         if (level + 1 >= a.levels) {
@@ -1905,12 +1915,26 @@ __global__ void __launch_bounds__(kThreads) k_finish(RebuildArgs a) {
         o_am[(size_t)m * DD + e] = es[D + DD + e];
         o_ax[(size_t)m * DD + e] = es[D + 2 * DD + e];
       }
-      if (t == 0) {
-        o_lv[m] = nodes[ni].logvol;
-        if (a.out_node) {
-          a.out_node[(size_t)run * a.max_ells + m] = ni;
-          a.out_fast[(size_t)run * a.max_ells + m] = nodes[ni].fast;
+      int need_eig = nodes[ni].fast;
+      if (need_eig && ni == 0 && a.root_eig) {
+        // the root's eigen-system was solved on the side stream (k_root_eig)
+        const double* re = a.root_eig + (size_t)run * (2 * DD + D + 2);
+        if (re[2 * DD + D + 1] == 1.0) {
+          for (int e = t; e < DD; e += kThreads) {
+            o_am[(size_t)m * DD + e] = re[e];
+            o_ax[(size_t)m * DD + e] = re[DD + e];
+          }
+          for (int e = t; e < D; e += kThreads) o_al[m * D + e] = re[2 * DD + e];
+          if (t == 0) o_lv[m] = re[2 * DD + D];
+          need_eig = 0;
         }
+      } else if (t == 0) {
+        o_lv[m] = nodes[ni].logvol;
+      }
+      if (need_eig && t == 0) o_lv[m] = nodes[ni].logvol;
+      if (t == 0 && a.out_node) {
+        a.out_node[(size_t)run * a.max_ells + m] = ni;
+        a.out_fast[(size_t)run * a.max_ells + m] = need_eig;
       }
       if (a.leaf_of_point) {
         int* lop = a.leaf_of_point + (size_t)run * a.n;
@@ -1926,8 +1950,18 @@ __global__ void __launch_bounds__(kThreads) k_finish(RebuildArgs a) {
       // fast path: the leaves partition the points, so "every point lies in its own leaf's
       // ellipsoid" (max of the quadratic form over the leaf < 1, the matrix-core pass of
       // node_fmax) already proves coverage with n instead of n x M quadratic forms
+      // ... and that maximum was taken when the leaf's ellipsoid was built and rescaled (Node.fmax:
+      // 1 - 1e-3 after the rescale, or the measured value): a list whose leaves all carry a value
+      // safely below 1 is covered without touching the points again
       double worst = -INFINITY;
+      bool known = true;
       for (int m = 0; m < M; ++m) {
+        const double f = nodes[reslist[rs0 + m]].fmax;
+        if (!(f <= 1.0 - 0.5 * kRoundDelta)) known = false;
+        worst = fmax(worst, f);
+      }
+      if (!known) worst = -INFINITY;
+      for (int m = 0; m < M && !known; ++m) {
         const int ni = reslist[rs0 + m];
         __syncthreads();
         for (int e = t; e < DD; e += kThreads) L.AM[(e / D) * L.LD + e % D] = o_am[(size_t)m * DD + e];
@@ -1971,6 +2005,45 @@ __global__ void __launch_bounds__(kThreads) k_finish(RebuildArgs a) {
     a.nells[run] = (status == DH_OK) ? M : 0;
     a.status[run] = status;
     if (a.nnodes_out) a.nnodes_out[run] = nnodes;
+  }
+}
+
+// ---- the root's eigen-system, speculatively -------------------------------------------------------
+// For a unimodal live set the accept test keeps the root alone, and its eigh would sit on the
+// critical path behind k_finish.  It needs nothing but the root's final covariance, which k_root
+// leaves behind: this kernel runs on the context's side stream next to the level kernels and files
+// the result (am | axes | axlens | logvol | ok) for k_finish to pick up if the root is an output.
+__global__ void __launch_bounds__(kThreads) k_root_eig(RebuildArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int run = blockIdx.x, D = a.d, DD = D * D, t = threadIdx.x;
+  double* re = a.root_eig + (size_t)run * (2 * DD + D + 2);
+  if (a.active && !a.active[run]) return;
+  if (t == 0) re[2 * DD + D + 1] = 0.0;
+  if (a.status[run] != DH_OK) return;
+  Lds L;
+  carve(L, smem, D);
+  const RunView v = view_of(a, run, L.LD);
+  const int LD = L.LD;
+  if (!v.nodes[0].fast) return;       // the reference route already left the full record
+  double* cov_g = v.estore + v.ES;    // node 0: the final (rescaled) covariance; a "good" matrix is not modified
+  (void)regularize(L, cov_g, D);
+  bool ok = true;
+  double slog = 0.0;
+  for (int k = 0; k < D; ++k) {
+    const double l = L.lam[k];
+    if (!(l > 0.0) || !isfinite(l)) ok = false;
+    slog += log(l);
+  }
+  for (int e = t; e < DD; e += kThreads) {
+    const int i = e / D, j = e - i * D;
+    re[e] = L.AM[i * LD + j];
+    re[DD + e] = L.AX[i * LD + j];
+  }
+  if (t < D) re[2 * DD + t] = sqrt(L.lam[t]);
+  __syncthreads();
+  if (t == 0) {
+    re[2 * DD + D] = a.prefactor + 0.5 * slog;
+    re[2 * DD + D + 1] = ok ? 1.0 : 0.0;
   }
 }
 
@@ -2331,10 +2404,11 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
   a.fast = mode == 0 ? 1 : 0;
   if (const char* e = getenv("DH_REBUILD_FAST")) a.fast = a.fast && atoi(e) != 0;  // diagnostic: 0 = eigh on every node
   const size_t b_of = a.fast ? (size_t)runs * max_ells * 4 : 0;
+  const size_t b_re = a.fast ? (size_t)runs * (2 * (size_t)d * d + d + 2) * 8 : 0;
   auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
   const size_t total = al(b_perm) * 2 + al(b_lab) + al(b_nodes) + al(b_es) + al(b_res) + al(b_cnt) +
                        al(b_sl) + 2 * al(b_el) + al(b_sc) + al(b_ps) + al(b_pl) + al(b_pb) + al(b_kp) + al(b_rb) + al(b_fl) + al(b_fi) +
-                       2 * al(b_of);
+                       2 * al(b_of) + al(b_re);
   if (total > ctx->rebuild_ws_cap) {
     if (!hip_ok(ctx, hipStreamSynchronize(ctx->stream), "sync")) return DH_ERR_HIP;
     if (ctx->rebuild_ws) (void)hipFree(ctx->rebuild_ws);
@@ -2390,11 +2464,14 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
   a.fin_int = (int*)w;
   w += al(b_fi);
   a.out_node = a.out_fast = nullptr;
+  a.root_eig = nullptr;
   if (a.fast) {
     a.out_node = (int*)w;
     w += al(b_of);
     a.out_fast = (int*)w;
     w += al(b_of);
+    a.root_eig = (double*)w;
+    w += al(b_re);
   }
   a.nells = nells;
   a.status = status;
@@ -2410,8 +2487,8 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
   a.n_arr = n_arr;
   DH_DEV_MEMO(attr_lds);
   if (lds > attr_lds) {
-    const void* ks[5] = {(const void*)k_root_parts, (const void*)k_split, (const void*)k_ell<false>,
-                         (const void*)k_ell<true>, (const void*)k_out_eig};
+    const void* ks[6] = {(const void*)k_root_parts, (const void*)k_split, (const void*)k_ell<false>,
+                         (const void*)k_ell<true>, (const void*)k_out_eig, (const void*)k_root_eig};
     for (const void* kf : ks)
       if (!hip_ok(ctx, hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
                   "hipFuncSetAttribute(rebuild LDS)"))
@@ -2427,6 +2504,23 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
   }
   if (!hip_ok(ctx, hipMemsetAsync(cnt, 0, b_cnt, ctx->stream), "memset(rebuild counters)")) return DH_ERR_HIP;
   hipLaunchKernelGGL(k_root_parts, dim3(runs * rp), dim3(kThreads), lds, ctx->stream, a, rp);
+  bool forked = false;
+  if (a.fast && !(getenv("DH_ROOT_EIG_SIDE") && atoi(getenv("DH_ROOT_EIG_SIDE")) == 0)) {
+    if (!ctx->side_stream) {
+      if (!hip_ok(ctx, hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking), "hipStreamCreate(side)") ||
+          !hip_ok(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming), "hipEventCreate") ||
+          !hip_ok(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming), "hipEventCreate"))
+        return DH_ERR_HIP;
+    }
+    if (!hip_ok(ctx, hipEventRecord(ctx->ev_fork, ctx->stream), "hipEventRecord(fork)") ||
+        !hip_ok(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->ev_fork, 0), "hipStreamWaitEvent(fork)"))
+      return DH_ERR_HIP;
+    hipLaunchKernelGGL(k_root_eig, dim3(runs), dim3(kThreads), lds, ctx->side_stream, a);
+    if (!hip_ok(ctx, hipEventRecord(ctx->ev_join, ctx->side_stream), "hipEventRecord(join)")) return DH_ERR_HIP;
+    forked = true;
+  } else {
+    a.root_eig = nullptr;
+  }
   for (int L = 0; L < a.levels; ++L) {
     hipLaunchKernelGGL(k_split, dim3(runs * a.maxp), dim3(kThreads), lds, ctx->stream, a, L);
     if (a.fast) hipLaunchKernelGGL(k_ell<false>, dim3(runs * 2 * a.maxw), dim3(kThreads), lds, ctx->stream, a, L, 2 * a.maxw);
@@ -2435,6 +2529,7 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
     const int gs = a.fast ? 2 : 2 * a.maxw;
     hipLaunchKernelGGL(k_ell<true>, dim3(runs * gs), dim3(kThreads), lds, ctx->stream, a, L, gs);
   }
+  if (forked && !hip_ok(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0), "hipStreamWaitEvent(join)")) return DH_ERR_HIP;
   hipLaunchKernelGGL(k_finish, dim3(runs), dim3(kThreads), lds_fin, ctx->stream, a);
   if (a.fast) {
     const int G = max_ells < 8 ? max_ells : 8;
