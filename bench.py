@@ -143,6 +143,17 @@ class Shard:
                                         off(self.d_v, d * 8), off(self.d_logl, 8),
                                         off(self.d_na, 4), off(self.d_nr, 4), off(b, 32)))
 
+    def walk_philox(self, i=0):
+        """The same launch in the throughput RNG mode (hiprand Philox4x32-10; no generator states in
+        HBM): seed = the shard's entropy word, walker key = its index, offset advances per launch."""
+        c, lib, h = self.ctx, self.ctx.lib, self.ctx.handle
+        d = self.d
+        c._check(lib.dh_rwalk_batch_philox_dev(h, self.ph, self.k, d, d, self.d_u0, self.d_axes,
+                                               self.runs * self.me, self.d_idx, self.scale,
+                                               self.loglstar, self.walks, None, int(self.entropy[0]), 0,
+                                               int(i) * 4096, self.d_u, self.d_v, self.d_logl,
+                                               self.d_na, self.d_nr))
+
     def step(self, i=0, rebuild=True):
         if rebuild:
             self.rebuild()
@@ -413,6 +424,21 @@ def main():
 
     wkr = sh.fetch_walk()
     bnd = sh.fetch_bound()
+    # throughput RNG mode (outside the timed region): the same step with Philox draws
+    t_ph = step_ph = 0.0
+    for i in range(nrep + 1):
+        ctx.record(ev[0])
+        if not args.no_rebuild:
+            sh.rebuild()
+        ctx.record(ev[1])
+        sh.walk_philox(i)
+        ctx.record(ev[2])
+        ctx.sync()
+        if i:  # first launch: warm-up
+            t_ph += ctx.elapsed_ms(ev[1], ev[2]) / nrep
+            step_ph += ctx.elapsed_ms(ev[0], ev[2]) / nrep
+    wk_ph = sh.fetch_walk()
+    assert np.all(wk_ph["accept"] + wk_ph["reject"] == args.walks)
     nacc, nrej, status, nells = wkr["accept"], wkr["reject"], bnd["status"], bnd["nells"]
     assert np.all(nacc + nrej == args.walks)
     assert np.all(status == 0), status
@@ -542,6 +568,13 @@ def main():
                 "nells_per_run": float(nells.mean()),
                 "accept_frac": float(nacc.sum() / (k * args.walks)),
                 "rng": "PCG64 + ziggurat, stream-identical to numpy.random.Generator (parity mode)",
+                "throughput_rng_mode": {
+                    "rng": "hiprand Philox4x32-10, fp32 Box-Muller normals (dh_rwalk_batch_philox_dev); "
+                           "not stream-compatible, validated statistically (tests/test_gpu_philox.py)",
+                    "rwalk_kernel_ms": t_ph, "step_ms": step_ph,
+                    "proposals_per_s_rwalk_kernel_only": world * props_per_step_rank / (t_ph * 1e-3),
+                    "proposals_per_s_step": world * props_per_step_rank / (step_ph * 1e-3),
+                    "accept_frac": float(wk_ph["accept"].sum() / (k * args.walks))},
                 "verified": verified,
             },
             "roofline": {

@@ -79,6 +79,10 @@ SIGNATURES = {
     "dh_rwalk_batch_dev": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _dbl,
                                 _dbl, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                 _vp]),
+    "dh_rwalk_batch_philox": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _dbl, _dbl, _i, _vp, _u64,
+                                   _u64, _u64, _vp, _vp, _vp, _vp, _vp]),
+    "dh_rwalk_batch_philox_dev": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _dbl, _dbl, _i, _vp, _u64,
+                                       _u64, _u64, _vp, _vp, _vp, _vp, _vp]),
     "dh_slice_batch": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _dbl, _dbl,
                             _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                             _vp]),
@@ -469,6 +473,25 @@ class Context:
         return dict(u=u, v=v, logl=logl, accept=nacc, reject=nrej,
                     rng_out=rng_out)
 
+
+    def rwalk_batch_philox(self, prob, u0, axes, scale, loglstar, walks, seed,
+                           sequence0=0, offset=0, axes_idx=None, ncdim=None, bc=None):
+        """Throughput mode of the batched RWalkSampler.sample (dh_rwalk_batch_philox):
+        hiprand Philox4x32-10 keyed (seed, sequence0 + walker, offset)."""
+        ndim = prob.ndim
+        u0 = _f64(u0).reshape(-1, ndim)
+        k = u0.shape[0]
+        ncdim = ndim if ncdim is None else int(ncdim)
+        axes = _f64(axes).reshape(-1, ncdim, ncdim)
+        idx = None if axes_idx is None else np.ascontiguousarray(axes_idx, dtype=np.int32)
+        bcarr = None if bc is None else np.ascontiguousarray(bc, dtype=np.int8)
+        u = np.empty((k, ndim)); v = np.empty((k, ndim)); logl = np.empty(k)
+        nacc = np.empty(k, dtype=np.int32); nrej = np.empty(k, dtype=np.int32)
+        self._check(self.lib.dh_rwalk_batch_philox(
+            self.handle, self.problem(prob), k, ndim, ncdim, _ptr(u0), _ptr(axes), axes.shape[0],
+            _ptr(idx), float(scale), float(loglstar), int(walks), _ptr(bcarr), int(seed),
+            int(sequence0), int(offset), _ptr(u), _ptr(v), _ptr(logl), _ptr(nacc), _ptr(nrej)))
+        return dict(u=u, v=v, logl=logl, accept=nacc, reject=nrej)
 
     def rwalk_propose(self, u0, axes, scale, rng_states, axes_idx=None,
                       ncdim=None, bc=None):

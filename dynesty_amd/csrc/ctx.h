@@ -11,7 +11,9 @@
 
 // Walker / candidate state lives in registers, so the per-lane kernels are
 // instantiated for a fixed list of padded dimensions.
+#ifndef DH_DIM_LIST  // (a reduced list speeds up compile-time experiments: -D"DH_DIM_LIST(X)=X(25)")
 #define DH_DIM_LIST(X) X(1) X(2) X(3) X(4) X(5) X(6) X(8) X(10) X(12) X(16) X(20) X(25) X(32)
+#endif
 constexpr int kMaxRegDim = 32;
 // hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute: the memo of what was already
 // set is kept per device ordinal (a process may hold contexts on several GPUs)
@@ -93,13 +95,20 @@ inline bool down(dh_ctx* ctx, T* host, const T* dev, size_t count) {
 
 bool get_problem(dh_ctx* ctx, int handle, ProblemDev* out);
 
+// key of the throughput-mode generator (hiprand Philox4x32-10): walker w draws from subsequence
+// seq0 + w of `seed`, starting `offset` draws in
+struct PhiloxKey {
+  unsigned long long seed, seq0, offset;
+};
+
 // ensemble forms used by ns.hip: per-run loglstar / scale arrays, walkers of
 // runs whose run_mode != my_mode are skipped (run = walker / wpr)
 int rwalk_launch_runs(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, const double* u0,
                       const double* axes, int m, const int32_t* axes_idx, double scale, double loglstar,
                       int walks, const int8_t* bc, const uint64_t* rng, double* u, double* v, double* logl,
                       int32_t* naccept, int32_t* nreject, uint64_t* rng_out, const double* run_loglstar,
-                      const double* run_scale, const int* run_mode, int wpr, int my_mode);
+                      const double* run_scale, const int* run_mode, int wpr, int my_mode,
+                      const PhiloxKey* philox = nullptr);
 int slice_launch_runs(dh_ctx* ctx, int problem, int k, int ndim, int mode, const double* u0,
                       const double* axes, int m, const int32_t* axes_idx, double scale, double loglstar,
                       int slices, int doubling, const uint64_t* rng, double* u, double* v, double* logl,

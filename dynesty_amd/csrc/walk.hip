@@ -12,6 +12,8 @@
 // bound, not bandwidth bound.
 #include <stdlib.h>
 
+#include <hiprand/hiprand_kernel.h>
+
 #include "ctx.h"
 #include "rng_pcg64.h"
 
@@ -33,6 +35,23 @@ __device__ __forceinline__ double reflect01(double x) {
   double m1 = wrap01(x);
   return (m2 < 1.0) ? m1 : 1.0 - m1;
 }
+
+// DH_ABLATE is a diagnostic of the `make ablate` build only (libdynhip_ablate.so): the production kernel
+// carries no ablation branches
+#ifdef DH_RW_ABLATE
+#define DH_ABL(a, bit) ((a).ablate & (bit))
+#else
+#define DH_ABL(a, bit) 0
+#endif
+
+// random-number policy of the walk kernels
+//   RNG_PCG64   numpy.random.Generator(PCG64) streams, bit for bit (ziggurat normals): the parity mode
+//   RNG_PHILOX  hiprand's Philox4x32-10 device generator, keyed (seed, subsequence = seq0 + walker,
+//               offset): counter based, so no generator state travels through HBM; normals are hiprand's
+//               fp32 Box-Muller pairs (hiprand_normal4) widened to fp64, uniforms hiprand_uniform_double.
+//               Same algorithm, same distributions to fp32 resolution of the step direction -- the
+//               proposal stays exactly symmetric -- but NOT the reference's streams: the throughput mode.
+enum : int { RNG_PCG64 = 0, RNG_PHILOX = 1 };
 
 struct RwalkArgs {
   ProblemDev prob;
@@ -61,8 +80,37 @@ struct RwalkArgs {
   // lock-step form for host-evaluated likelihoods: do ONE proposal, write it to u,
   // its in-cube flag to nacc, the advanced stream to rng_out, and stop
   int propose_only;
-  int ablate;  // profiling aid (env DH_ABLATE): 1 no normals, 2 no frame mat-vec, 4 no likelihood, 8 no pow
+  int fence;   // always 0 (see the likelihood call in rwalk_kernel)
+  int ablate;  // `make ablate` build only (env DH_ABLATE): 1 no normals, 2 no frame mat-vec, 4 no likelihood, 8 no pow
+  // RNG_PHILOX
+  unsigned long long ph_seed, ph_seq0, ph_offset;
 };
+
+// nc N(0,1) draws of the Philox stream into the per-lane LDS column, returning their sum of squares
+__device__ __forceinline__ double normals_to_lds_philox(hiprandStatePhilox4_32_10_t* st, double* dst, int lane,
+                                                        int nc) {
+  double ss = 0.0;
+#pragma unroll 1
+  for (int i = 0; i < nc; i += 4) {
+    const float4 z = hiprand_normal4(st);
+    const double z0 = (double)z.x, z1 = (double)z.y, z2 = (double)z.z, z3 = (double)z.w;
+    dst[i * 64 + lane] = z0;
+    ss = fma(z0, z0, ss);
+    if (i + 1 < nc) {
+      dst[(i + 1) * 64 + lane] = z1;
+      ss = fma(z1, z1, ss);
+    }
+    if (i + 2 < nc) {
+      dst[(i + 2) * 64 + lane] = z2;
+      ss = fma(z2, z2, ss);
+    }
+    if (i + 3 < nc) {
+      dst[(i + 3) * 64 + lane] = z3;
+      ss = fma(z3, z3, ss);
+    }
+  }
+  return ss;
+}
 
 // frames arrive row-major with column i = axis i (bounding.py:225-229); the walk
 // kernel wants, for a fixed input index j, the N outputs contiguous so one
@@ -78,11 +126,11 @@ __global__ void prep_axes_kernel(const double* __restrict__ axes, int m, int nc,
 
 // generic_random_walk (internal_samplers.py:866-986), one walker per lane.
 // FULL: ndim == ncdim == N (all guards fold away).  KIND: problem.h.
-template <int N, bool FULL, int KIND>
+template <int N, bool FULL, int KIND, int RNG>
 __global__ void __launch_bounds__(64, DH_RW_OCC) rwalk_kernel(RwalkArgs a) {
   __shared__ ZigLds zig;
   __shared__ double sx[N * 64];  // per-lane column: dr, then v = prior(u')
-  zig_stage(&zig, a.zki, a.zwi, a.zfi);
+  if constexpr (RNG == RNG_PCG64) zig_stage(&zig, a.zki, a.zwi, a.zfi);
   const int lane = threadIdx.x;
   const int w = blockIdx.x * 64 + lane;
   const bool live = w < a.k;
@@ -100,7 +148,11 @@ __global__ void __launch_bounds__(64, DH_RW_OCC) rwalk_kernel(RwalkArgs a) {
 #pragma unroll
   for (int i = 0; i < N; ++i) u[i] = (FULL || i < n) ? a.u0[(size_t)wi * n + i] : 0.5;
   Pcg64 g;
-  g.load(a.rng_in + (size_t)wi * 4);
+  hiprandStatePhilox4_32_10_t ph;
+  if constexpr (RNG == RNG_PCG64)
+    g.load(a.rng_in + (size_t)wi * 4);
+  else
+    hiprand_init(a.ph_seed, a.ph_seq0 + (unsigned long long)wi, a.ph_offset, &ph);
   const int my_frame = a.axes_idx ? a.axes_idx[wi] : 0;
 
   int nacc = 0, nrej = 0;
@@ -113,22 +165,25 @@ __global__ void __launch_bounds__(64, DH_RW_OCC) rwalk_kernel(RwalkArgs a) {
     // redrawn first (rstate.random(n - n_cluster)) ...
     if (!FULL) {
 #pragma unroll 1
-      for (int i = nc; i < n; ++i) sx[i * 64 + lane] = g.next_double();
+      for (int i = nc; i < n; ++i)
+        sx[i * 64 + lane] = RNG == RNG_PCG64 ? g.next_double() : hiprand_uniform_double(&ph);
     }
     // ... then randsphere (bounding.py:1288-1297): nc normals, one uniform
     double ss = 0.0;
-    if (a.ablate & 1) {
+    if (DH_ABL(a, 1)) {
 #pragma unroll 1
       for (int i = 0; i < nc; ++i) {
         const double x = 0.1 * (i + 1);
         sx[i * 64 + lane] = x;
         ss = fma(x, x, ss);
       }
-    } else {
+    } else if constexpr (RNG == RNG_PCG64) {
       ss = normals_to_lds(g, &zig, sx, lane, nc);
+    } else {
+      ss = normals_to_lds_philox(&ph, sx, lane, nc);
     }
-    const double ur = g.next_double();
-    const double fac = scale * (((a.ablate & 8) ? ur : pow(ur, inv_nc)) / sqrt(ss));
+    const double ur = RNG == RNG_PCG64 ? g.next_double() : hiprand_uniform_double(&ph);
+    const double fac = scale * ((DH_ABL(a, 8) ? ur : pow(ur, inv_nc)) / sqrt(ss));
     // du = axes @ dr, frame wave-uniform: waterfall over the distinct frames
 #pragma unroll
     for (int i = 0; i < N; ++i) acc[i] = 0.0;
@@ -136,7 +191,7 @@ __global__ void __launch_bounds__(64, DH_RW_OCC) rwalk_kernel(RwalkArgs a) {
     while (!done) {
       const int cur = __builtin_amdgcn_readfirstlane(my_frame);
       if (cur == my_frame) {
-        if (!(a.ablate & 2)) matvec_sgpr<N>(as_const(a.axes_t + (size_t)cur * N * N), sx, lane, nc, acc);
+        if (!DH_ABL(a, 2)) matvec_sgpr<N>(as_const(a.axes_t + (size_t)cur * N * N), sx, lane, nc, acc);
         done = true;
       }
     }
@@ -179,7 +234,7 @@ __global__ void __launch_bounds__(64, DH_RW_OCC) rwalk_kernel(RwalkArgs a) {
         for (int i = 0; i < N; ++i)
           if (FULL || i < n) a.u[(size_t)w * n + i] = up[i];
         a.nacc[w] = inside ? 1 : 0;
-        if (a.rng_out) g.store(a.rng_out + (size_t)w * 4);
+        if (RNG == RNG_PCG64 && a.rng_out) g.store(a.rng_out + (size_t)w * 4);
       }
       return;
     }
@@ -188,8 +243,15 @@ __global__ void __launch_bounds__(64, DH_RW_OCC) rwalk_kernel(RwalkArgs a) {
       continue;
     }
     prior_to_lds<N, FULL, KIND>(a.prob, up, n, sx, lane);
-    const double ll = (a.ablate & 4) ? loglstar + ur - 0.6
-                                     : loglike_lds<N, FULL, KIND>(a.prob, n, sx, lane, acc);
+    // `a.fence` is always 0, but the compiler cannot know: the never-taken branch ends the scheduling
+    // region in front of the 325 unrolled FMAs of the likelihood.  As one region with the frame product
+    // the scheduler clusters their scalar loads and spills 690 SGPRs (kernel +20 %); measured, not guessed:
+    // tools/rw_ablate.sh, -Rpass-analysis=kernel-resource-usage.
+    double ll;
+    if (a.fence | DH_ABL(a, 4))
+      ll = loglstar + ur - 0.6;
+    else
+      ll = loglike_lds<N, FULL, KIND>(a.prob, n, sx, lane, acc);
     if (ll > loglstar) {
 #pragma unroll
       for (int i = 0; i < N; ++i) u[i] = up[i];
@@ -213,7 +275,7 @@ __global__ void __launch_bounds__(64, DH_RW_OCC) rwalk_kernel(RwalkArgs a) {
     a.logl[w] = logl_cur;
     a.nacc[w] = nacc;
     a.nrej[w] = nrej;
-    if (a.rng_out) g.store(a.rng_out + (size_t)w * 4);
+    if (RNG == RNG_PCG64 && a.rng_out) g.store(a.rng_out + (size_t)w * 4);
   }
 }
 
@@ -272,7 +334,18 @@ int dh_rwalk_batch_dev(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, con
                        uint64_t* rng_out) {
   return dh::rwalk_launch_runs(ctx, problem, k, ndim, ncdim, u0, axes, m, axes_idx, scale, loglstar, walks,
                                bc, rng, u, v, logl, naccept, nreject, rng_out, nullptr, nullptr, nullptr, 1,
-                               0);
+                               0, nullptr);
+}
+
+int dh_rwalk_batch_philox_dev(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, const double* u0,
+                              const double* axes, int m, const int32_t* axes_idx, double scale,
+                              double loglstar, int walks, const int8_t* bc, uint64_t seed, uint64_t sequence0,
+                              uint64_t offset, double* u, double* v, double* logl, int32_t* naccept,
+                              int32_t* nreject) {
+  const dh::PhiloxKey key = {seed, sequence0, offset};
+  return dh::rwalk_launch_runs(ctx, problem, k, ndim, ncdim, u0, axes, m, axes_idx, scale, loglstar, walks,
+                               bc, nullptr, u, v, logl, naccept, nreject, nullptr, nullptr, nullptr, nullptr,
+                               1, 0, &key);
 }
 
 }  // extern "C"
@@ -282,9 +355,13 @@ int dh::rwalk_launch_runs(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, 
                           double loglstar, int walks, const int8_t* bc, const uint64_t* rng, double* u,
                           double* v, double* logl, int32_t* naccept, int32_t* nreject, uint64_t* rng_out,
                           const double* run_loglstar, const double* run_scale, const int* run_mode,
-                          int wpr, int my_mode) {
+                          int wpr, int my_mode, const dh::PhiloxKey* philox) {
   DH_CHECK_CTX(ctx);
   RwalkArgs a;
+  a.ph_seed = philox ? philox->seed : 0;
+  a.ph_seq0 = philox ? philox->seq0 : 0;
+  a.ph_offset = philox ? philox->offset : 0;
+  if (!philox && !rng && k > 0) return fail(ctx, DH_ERR_ARG, "rwalk: no generator states");
   a.run_loglstar = run_loglstar;
   a.run_scale = run_scale;
   a.run_mode = run_mode;
@@ -305,6 +382,7 @@ int dh::rwalk_launch_runs(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, 
     return fail(ctx, DH_ERR_ARG, "rwalk: ncdim=%d ndim=%d m=%d walks=%d", ncdim, ndim, m, walks);
   if (ndim > kMaxRegDim) {
     if (run_mode) return fail(ctx, DH_ERR_ARG, "ensemble rwalk: ndim=%d > %d not built", ndim, kMaxRegDim);
+    if (philox) return fail(ctx, DH_ERR_ARG, "rwalk: the Philox mode is built for ndim <= %d", kMaxRegDim);
     return wide_walk_launch(ctx, 0, problem, k, ndim, ncdim, u0, axes, m, axes_idx, scale, loglstar, walks,
                             0, bc, rng, u, v, logl, naccept, nreject, nullptr, nullptr, rng_out);
   }
@@ -328,10 +406,14 @@ int dh::rwalk_launch_runs(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, 
   a.zki = ctx->zki();
   a.zwi = ctx->zwi();
   a.zfi = ctx->zfi();
+  a.ablate = 0;
+  a.fence = 0;
+#ifdef DH_RW_ABLATE
   {
     const char* e = getenv("DH_ABLATE");
     a.ablate = e ? atoi(e) : 0;
   }
+#endif
   const int N = pad_dim(ndim);
   // transposed + padded copy of the frames (stream ordered, context scratch)
   const size_t at_bytes = (size_t)m * N * N * sizeof(double);
@@ -350,7 +432,13 @@ int dh::rwalk_launch_runs(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, 
   const dim3 grid((k + 63) / 64), block(64);
   const bool full = (ndim == N && ncdim == N) && !a.propose_only;
   const int kind = full ? problem_kind(a.prob.like_id, a.prob.prior_id) : KIND_GENERIC;
-#define L(NN, FF, KK) hipLaunchKernelGGL((rwalk_kernel<NN, FF, KK>), grid, block, 0, ctx->stream, a)
+#define L(NN, FF, KK)                                                                            \
+  do {                                                                                           \
+    if (philox)                                                                                  \
+      hipLaunchKernelGGL((rwalk_kernel<NN, FF, KK, RNG_PHILOX>), grid, block, 0, ctx->stream, a); \
+    else                                                                                         \
+      hipLaunchKernelGGL((rwalk_kernel<NN, FF, KK, RNG_PCG64>), grid, block, 0, ctx->stream, a);  \
+  } while (0)
 #define X(NN)                                       \
   if (N == NN) {                                    \
     if (!full)                                      \
@@ -400,7 +488,7 @@ int dh_rwalk_propose(dh_ctx* ctx, int k, int ndim, int ncdim, const double* u0, 
   if (!d_u0 || !d_axes || !d_rng || !d_u || !d_in || !d_ro || (axes_idx && !d_idx) || (bc && !d_bc))
     return DH_ERR_NOMEM;
   rc = dh::rwalk_launch_runs(ctx, -1, k, ndim, ncdim, d_u0, d_axes, m, d_idx, scale, 0.0, 1, d_bc, d_rng, d_u,
-                             nullptr, nullptr, d_in, nullptr, d_ro, nullptr, nullptr, nullptr, 1, 0);
+                             nullptr, nullptr, d_in, nullptr, d_ro, nullptr, nullptr, nullptr, 1, 0, nullptr);
   if (rc) return rc;
   if (!down(ctx, u_prop, d_u, kd) || !down(ctx, inside, d_in, (size_t)k) ||
       !down(ctx, rng_out, d_ro, (size_t)k * 4))
@@ -442,6 +530,39 @@ int dh_rwalk_batch(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, const d
   if (!down(ctx, u, d_u, kd) || !down(ctx, v, d_v, kd) || !down(ctx, logl, d_logl, (size_t)k) ||
       !down(ctx, naccept, d_na, (size_t)k) || !down(ctx, nreject, d_nr, (size_t)k) ||
       !down(ctx, rng_out, d_ro, (size_t)k * 4))
+    return DH_ERR_HIP;
+  return dh_sync(ctx);
+}
+
+int dh_rwalk_batch_philox(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, const double* u0,
+                          const double* axes, int m, const int32_t* axes_idx, double scale, double loglstar,
+                          int walks, const int8_t* bc, uint64_t seed, uint64_t sequence0, uint64_t offset,
+                          double* u, double* v, double* logl, int32_t* naccept, int32_t* nreject) {
+  DH_CHECK_CTX(ctx);
+  if (k <= 0) return DH_OK;
+  if (!u0 || !axes || !u || !v || !logl || !naccept || !nreject)
+    return fail(ctx, DH_ERR_ARG, "rwalk (philox): null pointer");
+  arena_reset(ctx);
+  const size_t kd = (size_t)k * ndim;
+  size_t need = 3 * kd * 8 + (size_t)m * ncdim * ncdim * 8 + (size_t)k * (4 + 8 + 4 + 4) + (size_t)ndim + 16 * 256;
+  int rc = arena_reserve(ctx, need);
+  if (rc) return rc;
+  const double* d_u0 = arena_up(ctx, u0, kd);
+  const double* d_axes = arena_up(ctx, axes, (size_t)m * ncdim * ncdim);
+  const int32_t* d_idx = axes_idx ? arena_up(ctx, axes_idx, (size_t)k) : nullptr;
+  const int8_t* d_bc = bc ? arena_up(ctx, bc, (size_t)ndim) : nullptr;
+  double* d_u = (double*)arena_get(ctx, kd * 8);
+  double* d_v = (double*)arena_get(ctx, kd * 8);
+  double* d_logl = (double*)arena_get(ctx, (size_t)k * 8);
+  int32_t* d_na = (int32_t*)arena_get(ctx, (size_t)k * 4);
+  int32_t* d_nr = (int32_t*)arena_get(ctx, (size_t)k * 4);
+  if (!d_u0 || !d_axes || !d_u || !d_v || !d_logl || !d_na || !d_nr || (axes_idx && !d_idx) || (bc && !d_bc))
+    return DH_ERR_NOMEM;
+  rc = dh_rwalk_batch_philox_dev(ctx, problem, k, ndim, ncdim, d_u0, d_axes, m, d_idx, scale, loglstar, walks,
+                                 d_bc, seed, sequence0, offset, d_u, d_v, d_logl, d_na, d_nr);
+  if (rc) return rc;
+  if (!down(ctx, u, d_u, kd) || !down(ctx, v, d_v, kd) || !down(ctx, logl, d_logl, (size_t)k) ||
+      !down(ctx, naccept, d_na, (size_t)k) || !down(ctx, nreject, d_nr, (size_t)k))
     return DH_ERR_HIP;
   return dh_sync(ctx);
 }

@@ -208,6 +208,28 @@ int dh_rwalk_batch_dev(dh_ctx* ctx, int problem, int k, int ndim, int ncdim,
                        double* u, double* v, double* logl, int32_t* naccept,
                        int32_t* nreject, uint64_t* rng_out);
 
+/* Throughput mode of RWalkSampler.sample: the same walk (generic_random_walk, propose_ball_point,
+ * randsphere; internal_samplers.py:866-1035, bounding.py:1288-1297) drawing from hiprand's Philox4x32-10
+ * device generator instead of NumPy-compatible PCG64 streams: walker i uses subsequence sequence0 + i of
+ * `seed`, starting `offset` draws in, so no generator state is read or written.  Normals are hiprand's
+ * fp32 Box-Muller pairs widened to fp64 (the step direction is resolved to 6e-8; the proposal stays
+ * exactly symmetric), uniforms hiprand_uniform_double.  Everything else -- frame product, wrap / reflect,
+ * unitcheck, prior transform, log-likelihood, accept rule, counters -- is the parity kernel's code.
+ * NOT stream-compatible with the reference: validated statistically (tests/test_gpu_philox.py: the
+ * reference's KS tests of tests/test_ellipsoid.py on device output, chain statistics against the parity
+ * mode).  ndim <= 32.  A caller advances `offset` by at least walks * (ndim + 8) per launch (or changes
+ * `seed`) to get fresh draws. */
+int dh_rwalk_batch_philox(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, const double* u0,
+                          const double* axes, int m, const int32_t* axes_idx, double scale,
+                          double loglstar, int walks, const int8_t* bc, uint64_t seed,
+                          uint64_t sequence0, uint64_t offset, double* u, double* v, double* logl,
+                          int32_t* naccept, int32_t* nreject);
+int dh_rwalk_batch_philox_dev(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, const double* u0,
+                              const double* axes, int m, const int32_t* axes_idx, double scale,
+                              double loglstar, int walks, const int8_t* bc, uint64_t seed,
+                              uint64_t sequence0, uint64_t offset, double* u, double* v, double* logl,
+                              int32_t* naccept, int32_t* nreject);
+
 /* Lock-step form for an arbitrary host likelihood: ONE propose_ball_point
  * (internal_samplers.py:989-1035) per walker -- draws, frame mat-vec,
  * wrap/reflect, unitcheck -- returning the proposals, their in-cube flags and the

@@ -334,6 +334,44 @@ __global__ void __launch_bounds__(64) kR(const double* MT, const double* __restr
   for (int i = 0; i < N; ++i) out[(size_t)blockIdx.x * N * 64 + i * 64 + lane] = acc[i];
 }
 
+// A2: as A, but every lane carries TWO vectors (two walkers per lane): each scalar operand feeds two
+// FMAs, so the scalar data path carries half the dwords per flop
+template <int W>
+__global__ void __launch_bounds__(64) kAW(const double* MT, const double* __restrict__ x, double* out,
+                                         int iters) {
+  __shared__ double xs[W * N * 64];
+  const int lane = threadIdx.x;
+  for (int w = 0; w < W; ++w)
+    for (int j = 0; j < N; ++j)
+      xs[(w * N + j) * 64 + lane] = x[((size_t)blockIdx.x * W + w) * N * 64 + j * 64 + lane];
+  double acc[W][N];
+#pragma unroll
+  for (int w = 0; w < W; ++w)
+#pragma unroll
+    for (int i = 0; i < N; ++i) acc[w][i] = 0;
+  cdptr M = (cdptr)(unsigned long long)MT;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll 1
+    for (int j = 0; j < N; ++j) {
+      double d[W];
+#pragma unroll
+      for (int w = 0; w < W; ++w) d[w] = xs[(w * N + j) * 64 + lane];
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        const double m = M[j * NP + i];
+#pragma unroll
+        for (int w = 0; w < W; ++w) acc[w][i] = fma(m, d[w], acc[w][i]);
+      }
+    }
+#pragma unroll
+    for (int w = 0; w < W; ++w) xs[(w * N + it % N) * 64 + lane] = acc[w][it % N] * 1e-3;
+  }
+#pragma unroll
+  for (int w = 0; w < W; ++w)
+#pragma unroll
+    for (int i = 0; i < N; ++i) out[((size_t)blockIdx.x * W + w) * N * 64 + i * 64 + lane] = acc[w][i];
+}
+
 int main(int argc, char** argv) {
   int blocks = argc > 1 ? atoi(argv[1]) : 2048, iters = argc > 2 ? atoi(argv[2]) : 90;
   std::vector<double> MT(N * NP, 0.0), x((size_t)blocks * N * 64);
@@ -385,6 +423,15 @@ int main(int argc, char** argv) {
       hipEventRecord(e0); kA5<<<blocks, 64>>>(dM, dx, dB, iters); hipEventRecord(e1); hipEventSynchronize(e1);
       hipEventElapsedTime(&m5, e0, e1);
       printf("sgpr x5: %.2f TF | ", (double)blocks * 64 * iters * N * N * 2 / m5 / 1e9);
+    }
+    {
+      float m2;
+      hipEventRecord(e0); kAW<2><<<blocks / 2, 64>>>(dM, dx, dB, iters); hipEventRecord(e1); hipEventSynchronize(e1);
+      hipEventElapsedTime(&m2, e0, e1);
+      printf("sgpr W=2: %.2f TF | ", (double)blocks * 64 * iters * N * N * 2 / m2 / 1e9);
+      hipEventRecord(e0); kAW<3><<<blocks / 3, 64>>>(dM, dx, dB, iters); hipEventRecord(e1); hipEventSynchronize(e1);
+      hipEventElapsedTime(&m2, e0, e1);
+      printf("sgpr W=3: %.2f TF | ", (double)(blocks / 3) * 3 * 64 * iters * N * N * 2 / m2 / 1e9);
     }
     float mm;
     hipEventRecord(e0); kM<<<blocks, 64>>>(dM, dx, dB, iters); hipEventRecord(e1); hipEventSynchronize(e1);
