@@ -36,6 +36,18 @@ __host__ __device__ inline int problem_kind(int like_id, int prior_id) {
 // addressed through the constant address space so the backend always selects
 // scalar-cache loads (s_load_dwordxN) and feeds v_fma_f64 from SGPRs.
 typedef const __attribute__((address_space(4))) double* cdptr;
+// A wave-uniform pointer the compiler does not KNOW to be uniform -- e.g. one indexed by the
+// readfirstlane value of a waterfall loop: inside `if (cur == my_frame)` LLVM's equality propagation
+// rewrites `cur` (SGPR) to `my_frame` (VGPR) and the matrix rows then arrive as 13 per-lane
+// global_load_dwordx4 per row instead of scalar loads (found in the ISA of rwalk_kernel; the frame product
+// was 2x slower than its SGPR form).  Reading the two halves back through readfirstlane pins it to SGPRs.
+__device__ __forceinline__ cdptr as_const_uniform(const double* p) {
+  const unsigned long long v = (unsigned long long)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return (cdptr)(((unsigned long long)hi << 32) | lo);
+}
+
 __device__ __forceinline__ cdptr as_const(const double* p) {
   return (cdptr)(unsigned long long)p;
 }
@@ -225,6 +237,27 @@ __device__ __forceinline__ double loglike_lds(const ProblemDev& P, int n, const 
     // (half the FMAs of a full mat-vec); rows of P come through the scalar cache.
 #pragma unroll
     for (int i = 0; i < N; ++i) w[i] = sv[i * 64 + lane];
+#ifdef DH_LIKE_MATVEC
+    if constexpr (FULL) {
+      // y = P v with the rolled, double-buffered row loop of the frame product (P is symmetric, so its
+      // rows are its columns); q = v . y / 2.  Twice the FMAs of the triangular form below, but that form
+      // is 325 unrolled FMAs in one scheduling region whose scalar loads the compiler clusters and spills
+      // (594 v_writelane + 598 v_readlane per step in the PCG64 kernel).
+      double y[N];
+#pragma unroll
+      for (int i = 0; i < N; ++i) y[i] = 0.0;
+      matvec_sgpr<N>(lp + 1, sv, lane, N, y);
+      double q0 = 0.0, q1 = 0.0;
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        if (i & 1)
+          q1 = fma(w[i], y[i], q1);
+        else
+          q0 = fma(w[i], y[i], q0);
+      }
+      return lp[0] - 0.5 * (q0 + q1);
+    } else
+#endif
     if constexpr (FULL) {
       cdptr A = lp + 1;
       double q0 = 0.0, q1 = 0.0;

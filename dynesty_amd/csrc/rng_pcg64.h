@@ -368,8 +368,13 @@ __device__ __forceinline__ void wave_normals(Pcg64& g, const PcgLanes& L, const 
 // 128-bit multiply overlap; a rejected candidate consumes the prefetched draw
 // as its wedge/tail uniform exactly as the sequential algorithm would, and a
 // lane that is finished hands its unconsumed candidate back (state rewind).
-__device__ __forceinline__ double normals_to_lds(Pcg64& g, const ZigLds* z, double* dst, int lane,
-                                                 int nc) {
+#ifdef DH_NORMALS_NOINLINE
+#define DH_NORMALS_INLINE __attribute__((noinline))
+#else
+#define DH_NORMALS_INLINE __forceinline__
+#endif
+__device__ DH_NORMALS_INLINE double normals_to_lds(Pcg64& g, const ZigLds* z, double* dst, int lane,
+                                                   int nc) {
 #pragma clang fp contract(off)
   double ss = 0.0;
   int i = 0;

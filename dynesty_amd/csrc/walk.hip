@@ -44,6 +44,16 @@ __device__ __forceinline__ double reflect01(double x) {
 #define DH_ABL(a, bit) 0
 #endif
 
+// experiment hooks: -DDH_FENCES=<bitmask> places further never-taken branches (scheduling-region ends)
+//   1 after the normals, 2 after the frame product, 4 after the cube check, 8 after the prior transform
+#ifndef DH_FENCES
+#define DH_FENCES 8  // measured best (tools/rw_exp.sh / rw_exp_run.sh): fence after the prior transform
+#endif
+#define DH_SCHED_FENCE(a, bit)                                \
+  do {                                                        \
+    if ((DH_FENCES & (bit)) && (a).fence) asm volatile("s_sleep 1"); \
+  } while (0)
+
 // random-number policy of the walk kernels
 //   RNG_PCG64   numpy.random.Generator(PCG64) streams, bit for bit (ziggurat normals): the parity mode
 //   RNG_PHILOX  hiprand's Philox4x32-10 device generator, keyed (seed, subsequence = seq0 + walker,
@@ -182,6 +192,7 @@ __global__ void __launch_bounds__(64, DH_RW_OCC) rwalk_kernel(RwalkArgs a) {
     } else {
       ss = normals_to_lds_philox(&ph, sx, lane, nc);
     }
+    DH_SCHED_FENCE(a, 1);
     const double ur = RNG == RNG_PCG64 ? g.next_double() : hiprand_uniform_double(&ph);
     const double fac = scale * ((DH_ABL(a, 8) ? ur : pow(ur, inv_nc)) / sqrt(ss));
     // du = axes @ dr, frame wave-uniform: waterfall over the distinct frames
@@ -191,10 +202,19 @@ __global__ void __launch_bounds__(64, DH_RW_OCC) rwalk_kernel(RwalkArgs a) {
     while (!done) {
       const int cur = __builtin_amdgcn_readfirstlane(my_frame);
       if (cur == my_frame) {
-        if (!DH_ABL(a, 2)) matvec_sgpr<N>(as_const(a.axes_t + (size_t)cur * N * N), sx, lane, nc, acc);
+        // Philox kernel: frame rows through the scalar cache (pointer pinned to SGPRs, see as_const_uniform):
+        // 1.26 -> 0.87 ms.  PCG64 kernel: the same change tips its register allocation (690 SGPR spills in
+        // the likelihood block, 1.4 -> 1.5 ms), so it keeps the per-lane vector loads of the rows.
+        if (!DH_ABL(a, 2)) {
+          if constexpr (RNG == RNG_PHILOX)
+            matvec_sgpr<N>(as_const_uniform(a.axes_t + (size_t)cur * N * N), sx, lane, nc, acc);
+          else
+            matvec_sgpr<N>(as_const(a.axes_t + (size_t)cur * N * N), sx, lane, nc, acc);
+        }
         done = true;
       }
     }
+    DH_SCHED_FENCE(a, 2);
 #pragma unroll
     for (int i = 0; i < N; ++i) {
       if (FULL || i < nc)
@@ -242,7 +262,9 @@ __global__ void __launch_bounds__(64, DH_RW_OCC) rwalk_kernel(RwalkArgs a) {
       ++nrej;
       continue;
     }
+    DH_SCHED_FENCE(a, 4);
     prior_to_lds<N, FULL, KIND>(a.prob, up, n, sx, lane);
+    DH_SCHED_FENCE(a, 8);
     // `a.fence` is always 0, but the compiler cannot know: the never-taken branch ends the scheduling
     // region in front of the 325 unrolled FMAs of the likelihood.  As one region with the frame product
     // the scheduler clusters their scalar loads and spills 690 SGPRs (kernel +20 %); measured, not guessed:
