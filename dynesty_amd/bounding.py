@@ -132,10 +132,19 @@ class HipEllipsoid(HipBound):
         return np.sqrt(quad[:, 0])
 
     def contains(self, x):
-        """bounding.py:302-305 (sqrt(q) <= 1)."""
+        """bounding.py:302-305 (sqrt(q) <= 1) for ONE point: a scalar query of the sampler's serial
+        loop (Sampler.propose_live asks it once per queue entry, sampler.py:484-488), answered on the
+        host from the instance's NumPy state with the reference's own expression -- a device round trip
+        per point (~50 us) was two thirds of the backend time of a replayed dynesty run.  Batches of
+        points go to the membership kernel (`contains_many`, `distance_many`)."""
+        d = np.asarray(x, dtype=np.float64) - self.ctr
+        return bool(np.sqrt(np.einsum('j,jk,k', d, self.am, d)) <= 1.0)
+
+    def contains_many(self, x):
+        """Membership of a batch of points (device, dh_contains)."""
         count, _, _ = get_backend().contains(np.asarray(x), self.ctr[None],
                                              self.am[None], mode=1)
-        return bool(count[0] > 0)
+        return count > 0
 
     def sample(self, rstate=None):
         """bounding.py:307-319."""
@@ -267,10 +276,15 @@ class HipMultiEllipsoid(HipBound):
         return len(self.within(x, j=j))
 
     def contains(self, x):
-        """bounding.py:520-523 (strict <)."""
+        """bounding.py:520-523 (strict <) for ONE point: host scalar query, see HipEllipsoid.contains."""
+        delt = np.asarray(x, dtype=np.float64)[None, :] - self.ctrs
+        return bool(np.any(np.einsum('ai,aij,aj->a', delt, self.ams, delt) < 1.))
+
+    def contains_many(self, x):
+        """Membership of a batch of points in the union (device, dh_contains)."""
         count, _, _ = get_backend().contains(np.asarray(x, dtype=np.float64),
                                              self.ctrs, self.ams, mode=0)
-        return bool(count[0] > 0)
+        return count > 0
 
     # -- draws --------------------------------------------------------------------
     def sample(self, rstate=None, return_q=False):

@@ -20,6 +20,24 @@ MAX_COND = 1e12  # ref: bounding.py:1311
 EIG_MULT = 10  # ref: bounding.py:1326
 NTRIES = 100  # ref: bounding.py:1311
 
+# LAPACK leaves the sign of every eigenvector open; the device fixes it (largest-magnitude component
+# positive).  The sign decides which k-means seed is "cluster 0" (ctr - axis vs ctr + axis, ref:
+# bounding.py:278-284, 1505-1510) and with it the ORDER of the children, of the ellipsoid list and of
+# every draw that indexes it.  With CANON_SIGNS the oracle applies the device's convention at the same
+# place (right after eigh), so that whole runs can be compared seed for seed; tests/refshim.py patches
+# the real reference's eigh the same way.  Off by default: the golden vectors hold LAPACK's signs.
+CANON_SIGNS = False
+
+
+def canon_cols(vec):
+    """Flip every column so that its largest-magnitude component is positive (first one on ties)."""
+    out = np.array(vec, dtype=np.float64)
+    for k in range(out.shape[1]):
+        i = np.argmax(np.abs(out[:, k]))
+        if out[i, k] < 0:
+            out[:, k] = -out[:, k]
+    return out
+
 
 @dataclass
 class Ell:
@@ -52,6 +70,8 @@ def make_ell(ctr, cov, am=None, axes=None):
     cov = np.asarray(cov)
     ndim = ctr.shape[0]
     lam, vec = sla.eigh(cov, check_finite=False)
+    if CANON_SIGNS:
+        vec = canon_cols(vec)
     if not np.all((lam > 0.) & np.isfinite(lam)):
         raise ValueError("singular ellipsoid covariance")
     axlens = np.sqrt(lam)
@@ -83,6 +103,8 @@ def regularize_cov(cov_in):
         failed = 0
         try:
             lam, vec = sla.eigh(cov, check_finite=False)
+            if CANON_SIGNS:
+                vec = canon_cols(vec)
             top = lam.max()
             bot = lam.min()
             if np.isfinite(lam).all():
@@ -275,6 +297,8 @@ def scale_ell_to_logvol(ell, logvol):
         left = logf
         nleft = ndim
         lam, vec = sla.eigh(ell.cov, check_finite=False)
+        if CANON_SIGNS:
+            vec = canon_cols(vec)
         for i in np.argsort(lam)[::-1]:
             delta = max(min(max_log_axlen - log_axlen[i], left / nleft), 0)
             logfax[i] = delta

@@ -45,7 +45,25 @@ def _ell(ctr, cov, am, axes, axlens, logvol):
 
 
 class OracleBackend:
+    """canon=True: eigenvector signs fixed inside the split tree as on the device (see
+    oracle.bounding_ref.CANON_SIGNS), so that ellipsoid lists come out in the device's order."""
     name = "oracle (tests only)"
+
+    def __init__(self, canon=False):
+        self.canon = bool(canon)
+
+    def _signs(self):
+        be = self
+
+        class _Ctx:
+            def __enter__(self):
+                self.old = B.CANON_SIGNS
+                B.CANON_SIGNS = be.canon or self.old
+
+            def __exit__(self, *exc):
+                B.CANON_SIGNS = self.old
+                return False
+        return _Ctx()
 
     def seed_children(self, entropy, first, k):
         kids = np.random.SeedSequence(
@@ -80,8 +98,9 @@ class OracleBackend:
 
     def rebuild(self, points, multi=True, max_ells=None, want_labels=False):
         pts = np.asarray(points, dtype=np.float64)
-        ells = B.multi_update(pts).ells if multi else \
-            [B.bounding_ellipsoid(pts)]
+        with self._signs():
+            ells = B.multi_update(pts).ells if multi else \
+                [B.bounding_ellipsoid(pts)]
         return dict(nells=len(ells), ctrs=np.array([e.ctr for e in ells]),
                     covs=np.array([e.cov for e in ells]),
                     ams=np.array([e.am for e in ells]),

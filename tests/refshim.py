@@ -26,3 +26,30 @@ def import_reference():
     sys.path.insert(0, REF)
     import dynesty
     return dynesty
+
+
+class canonical_eigh:
+    """Context manager: inside it every `lalg.eigh` call of dynesty.bounding returns eigenvectors with the
+    device's sign convention (largest-magnitude component positive) -- the SURVEY section 7a-iii harness for
+    comparing whole runs seed for seed (bounding.py:212, 261, 1338 are the call sites)."""
+
+    def __enter__(self):
+        import dynesty.bounding as db
+        from oracle.bounding_ref import canon_cols
+        self.db, self.orig = db, db.lalg
+        orig = db.lalg
+
+        class Proxy:
+            def __getattr__(self, name):
+                return getattr(orig, name)
+
+            @staticmethod
+            def eigh(*a, **kw):
+                lam, vec = orig.eigh(*a, **kw)
+                return lam, canon_cols(vec)
+        db.lalg = Proxy()
+        return self
+
+    def __exit__(self, *exc):
+        self.db.lalg = self.orig
+        return False

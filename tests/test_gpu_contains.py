@@ -83,3 +83,29 @@ def test_ragged_sizes(ctx):
         np.testing.assert_allclose(quad, want, rtol=1e-12)
         np.testing.assert_array_equal(count, (want < 1).sum(1))
         np.testing.assert_array_equal(unpack(mask, k), (want < 1).T)
+
+
+@pytest.mark.parametrize("name", inputs.CLOUDS_SMALL)
+def test_class_contains_scalar_and_batch_golden(ctx, name, golden_bounding):
+    """Bound.contains(x) for one point (host scalar query) and contains_many (membership kernel) both
+    give the reference's golden verdicts (MultiEllipsoid.contains / Ellipsoid.contains on the probes)."""
+    from dynesty_amd import backend
+    from dynesty_amd.bounding import HipEllipsoid, HipMultiEllipsoid
+    g = golden_bounding
+    probes = g[f"{name}/kat/probes"]
+    backend.set_backend(ctx)
+    try:
+        m = HipMultiEllipsoid.__new__(HipMultiEllipsoid)
+        m._set_arrays(g[f"{name}/mu/ctrs"], g[f"{name}/mu/covs"], g[f"{name}/mu/ams"], g[f"{name}/mu/axes"],
+                      g[f"{name}/mu/axlens"], g[f"{name}/mu/logvol_ells"])
+        want = g[f"{name}/kat/contains"]
+        np.testing.assert_array_equal([m.contains(p) for p in probes], want)
+        np.testing.assert_array_equal(m.contains_many(probes), want)
+        d = probes.shape[1]
+        e = HipEllipsoid(d)
+        e.update(inputs.cloud(name))
+        got_one = np.array([e.contains(p) for p in probes])
+        np.testing.assert_array_equal(got_one, e.contains_many(probes))
+        np.testing.assert_array_equal(got_one, g[f"{name}/single/contains"])
+    finally:
+        backend.set_backend(None)

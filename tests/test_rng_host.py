@@ -184,3 +184,22 @@ def test_frames_dedupe_by_memory_and_value():
     # a single frame -> no index array
     frames, idx = samplers._frames([SimpleNamespace(axes=m.axes_ells[0])] * 5)
     assert len(frames) == 1 and idx is None
+
+
+def test_scalar_contains_matches_reference_golden():
+    """HipMultiEllipsoid.contains / HipEllipsoid.contains for a single point are host scalar queries (the
+    reference's einsum): held to the reference's golden verdicts without a GPU."""
+    import os
+    import inputs
+    from dynesty_amd.bounding import HipEllipsoid, HipMultiEllipsoid
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bounding.npz"))
+    for name in inputs.CLOUDS_SMALL:
+        probes = g[f"{name}/kat/probes"]
+        m = HipMultiEllipsoid.__new__(HipMultiEllipsoid)
+        m._set_arrays(g[f"{name}/mu/ctrs"], g[f"{name}/mu/covs"], g[f"{name}/mu/ams"], g[f"{name}/mu/axes"],
+                      g[f"{name}/mu/axlens"], g[f"{name}/mu/logvol_ells"])
+        np.testing.assert_array_equal([m.contains(p) for p in probes], g[f"{name}/kat/contains"])
+        d = probes.shape[1]
+        e = HipEllipsoid(d, ctr=g[f"{name}/be/ctr"], cov=g[f"{name}/be/cov"], am=g[f"{name}/be/am"],
+                         axes=g[f"{name}/be/axes"], axlens=g[f"{name}/be/axlens"], logvol=float(g[f"{name}/be/logvol"]))
+        np.testing.assert_array_equal([e.contains(p) for p in probes], g[f"{name}/single/contains"])
