@@ -334,6 +334,8 @@ def main():
     ap.add_argument("--nlive", type=int, default=2000)
     ap.add_argument("--walks", type=int, default=45)
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--preroll", type=int, default=80,
+                    help="untimed steps before the warm-up (GPU clock ramp)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-rebuild", action="store_true",
                     help="time the proposal kernel alone (diagnostic)")
@@ -341,8 +343,13 @@ def main():
                     help="skip the end-to-end device-loop leg (tap C)")
     ap.add_argument("--no-verify", action="store_true",
                     help="skip the oracle check of the timed entry points (diagnostic)")
+    ap.add_argument("--lean", action="store_true",
+                    help="profiling runs: only the timed launch shape (no CPU / end-to-end / oracle-check / "
+                         "queue-512 / Philox legs), so that per-kernel averages are those of the headline step")
     ap.add_argument("--launch-selftest", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.lean:
+        args.no_cpu = args.no_e2e = args.no_verify = True
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
@@ -389,6 +396,11 @@ def main():
             torch.cuda.synchronize()
 
     sh.rebuild()  # frames must exist even with --no-rebuild
+    # untimed pre-roll before the W warm-up steps: the first ~0.2 s after the context is created run at
+    # ramping clocks (20 timed steps right after 5 warm-up steps measured 4.5 ms, the same steps 3.4 ms
+    # once the device is busy); not part of W, not part of the timed region
+    for i in range(args.preroll):
+        sh.step(i, rebuild=not args.no_rebuild)
     for i in range(args.warmup):
         sh.step(i, rebuild=not args.no_rebuild)
     barrier()
@@ -426,7 +438,7 @@ def main():
     bnd = sh.fetch_bound()
     # throughput RNG mode (outside the timed region): the same step with Philox draws
     t_ph = step_ph = 0.0
-    for i in range(nrep + 1):
+    for i in range(0 if args.lean else nrep + 1):
         ctx.record(ev[0])
         if not args.no_rebuild:
             sh.rebuild()
@@ -439,6 +451,8 @@ def main():
             step_ph += ctx.elapsed_ms(ev[0], ev[2]) / nrep
     wk_ph = sh.fetch_walk()
     assert np.all(wk_ph["accept"] + wk_ph["reject"] == args.walks)
+    if args.lean:
+        t_ph = step_ph = float("nan")
     nacc, nrej, status, nells = wkr["accept"], wkr["reject"], bnd["status"], bnd["nells"]
     assert np.all(nacc + nrej == args.walks)
     assert np.all(status == 0), status
@@ -451,7 +465,7 @@ def main():
     kq = 512
     nq = (nlive + kq - 1) // kq
     tq = None
-    if not args.no_rebuild and nlive >= kq:
+    if not args.no_rebuild and nlive >= kq and not args.lean:
         idxq = (np.arange(runs * kq, dtype=np.int32) // kq) * MAX_ELLS
         ctx._check(ctx.lib.dh_memcpy_h2d(ctx.handle, sh.d_idx, idxq.ctypes.data, idxq.nbytes))
         for rep in range(3):
@@ -541,6 +555,7 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
+            "preroll_steps": args.preroll,
             "ms_per_step": wall / args.steps * 1e3,
             "higher_is_better": True,
             "scaling": "weak",
@@ -666,6 +681,7 @@ def cpu_baseline(prob, u0, nlive, scale, loglstar, walks, budget_s):
     (the ensemble mode of SURVEY.md section 8d)."""
     import multiprocessing as mp
     from oracle import bounding_ref as B
+    from oracle import proposals_ref as _P  # noqa: F401  (imported here so that forked workers inherit it)
     os.environ.setdefault("OMP_NUM_THREADS", "1")
     pts = u0[:nlive]
     t0 = time.perf_counter()

@@ -100,8 +100,6 @@ struct RebuildArgs {
   const int* active;  // runs or null: only runs with active[run] != 0 are rebuilt
   const int* n_arr;   // runs or null: per-run point count (<= n; rows beyond it are padding)
   int fast;           // 1: tree nodes take the eigen-free path (spd_fast); k_out_eig solves the outputs
-  int* nslow;         // levels x runs: nodes of the level the eigen-free path did not apply to
-  int* slow_list;     // runs x 2 maxw
   double* root_eig;   // runs x (2 D^2 + D + 2): am | axes | axlens | logvol | ok -- the root's eigen-system (k_root_eig)
   int* out_node;      // runs x max_ells: node behind output ellipsoid m (k_finish -> k_out_eig)
   int* out_fast;      // runs x max_ells: 1 = that node's record is the eigen-free form
@@ -644,6 +642,10 @@ __device__ __forceinline__ void mat_from_eig(const Lds& L, double* out, const do
 // L.AX-independent copy `cov`), producing L.AM (precision), L.AX (axes), L.lam
 // (eigenvalues of the returned covariance).  `cov` is a D x LD global/LDS buffer
 // holding the matrix to regularise; it is updated in place.  Returns good_mat.
+// WAVE = true: the eigen-solves run on wave 0 with the compact wave-level Jacobi of eig_wave.h (three LDS
+// passes per round: several times slower than jacobi_block, but a fraction of its registers).  Used where
+// the route is a rare fallback inside a kernel that must stay small (k_ell<false>).
+template <bool WAVE = false>
 __device__ __forceinline__ bool regularize(const Lds& L, double* cov, int D) {
   const int t = threadIdx.x;
   int failed = 0;
@@ -655,7 +657,14 @@ __device__ __forceinline__ bool regularize(const Lds& L, double* cov, int D) {
     for (int e = t; e < D * D; e += kThreads) L.A[(e / D) * L.LD + e % D] = cov[(e / D) * L.LD + e % D];
     __syncthreads();
     PH_ADD(8);
-    const bool fin = jacobi_block(L, D);
+    bool fin;
+    if constexpr (WAVE) {
+      int ok = 1;
+      if (t < 64) ok = jacobi_wave(L.A, L.V, D, L.LD, L.rc, L.rs, L.ri) ? 1 : 0;
+      fin = __syncthreads_and(ok) != 0;
+    } else {
+      fin = jacobi_block(L, D);
+    }
     PH_ADD(6);
     if (fin && t < 64) sort_eigs_wave(L.A, L.V, L.lam, L.perm_sort, L.AX, D, L.LD);
     __syncthreads();
@@ -1021,10 +1030,11 @@ __device__ __forceinline__ int ellipsoid_store_fast(const Lds& L, const RebuildA
 
 // bounding_ellipsoid (bounding.py:1387-1461) of the node segment; writes the
 // ellipsoid record to `es` (global).  Returns 0 or a DH_ERR code (uniform).
-constexpr int kNeedSlow = 1;  // node_ellipsoid<true>: the eigen-free path does not apply to this node
+constexpr int kFullRecord = 1;  // node_ellipsoid<true>: done, but by the reference route (complete eigen record)
 
-// FAST = true: the eigen-free path only (returns kNeedSlow when it does not apply);
-// FAST = false: the reference's route (improve_covar_mat with a full eigh per trial).
+// FAST = true: the eigen-free path; a node it does not apply to takes the reference's route in place with
+//              the compact wave-level solver (returns kFullRecord);
+// FAST = false: the reference's route (improve_covar_mat with a full eigh per trial) for every node.
 template <bool FAST>
 __device__ __forceinline__ int node_ellipsoid(const Lds& L, const RebuildArgs& a, const double* pts, const int* perm,
                                               int start, int count, double* es, double* cov_g, double* logvol_out,
@@ -1042,13 +1052,27 @@ __device__ __forceinline__ int node_ellipsoid(const Lds& L, const RebuildArgs& a
   if constexpr (FAST) {
     // eigen-free path: good_mat is certain, so the reference's loop ends after its first pass
     double logdet = 0.0;
-    if (!spd_fast(L, cov_g, D, a.mode == 0 && count >= 4 * D, &logdet)) return kNeedSlow;
-    const double fmx = node_fmax(L, pts, perm, start, count, D);
-    PH_ADD(3);
-    if (fmx > 1.0 - kRoundDelta) logdet += (double)D * log(fmx / (1.0 - kRoundDelta));
-    ellipsoid_rescale(L, cov_g, D, fmx);
-    *fmax_out = fmin(fmx, 1.0 - kRoundDelta);  // the quadratic forms scale with am: fmx / mult
-    return ellipsoid_store_fast(L, a, es, cov_g, logdet, logvol_out);
+    if (spd_fast(L, cov_g, D, a.mode == 0 && count >= 4 * D, &logdet)) {
+      const double fmx = node_fmax(L, pts, perm, start, count, D);
+      PH_ADD(3);
+      if (fmx > 1.0 - kRoundDelta) logdet += (double)D * log(fmx / (1.0 - kRoundDelta));
+      ellipsoid_rescale(L, cov_g, D, fmx);
+      *fmax_out = fmin(fmx, 1.0 - kRoundDelta);  // the quadratic forms scale with am: fmx / mult
+      return ellipsoid_store_fast(L, a, es, cov_g, logdet, logvol_out);
+    }
+    // the eigen-free path does not apply (not positive definite, condition bound >= 1e7, degenerate
+    // leading eigenvalues): the reference's route, right here, with the wave-level solver
+    __syncthreads();
+    for (int pass = 0; pass < 2; ++pass) {
+      const bool good = regularize<true>(L, cov_g, D);
+      const double fmx = node_fmax(L, pts, perm, start, count, D);
+      if (pass == 0) ellipsoid_rescale(L, cov_g, D, fmx);
+      if (pass == 1 && fmx >= 1.0) return DH_ERR_CONTAIN;
+      *fmax_out = pass == 0 ? fmin(fmx, 1.0 - kRoundDelta) : fmx;
+      if (good) break;
+    }
+    const int rc = ellipsoid_store(L, a, es, cov_g, logvol_out);
+    return rc == DH_OK ? kFullRecord : rc;
   } else {
     for (int pass = 0; pass < 2; ++pass) {
       const bool good = regularize(L, cov_g, D);
@@ -1444,11 +1468,11 @@ __global__ void __launch_bounds__(kThreads) k_root_parts(RebuildArgs a, int rp) 
     // small live set: the single-workgroup routine
     if (n <= 1) status = (a.mode == 0) ? DH_ERR_REGION : DH_ERR_VALUE;  // single point
     if (status == DH_OK) {
-      status = kNeedSlow;
-      if (a.fast) status = node_ellipsoid<true>(L, a, v.pts, v.perm, 0, n, es, cov_g, &lv, &root_fmax);
-      root_fast = status == DH_OK;
-      if (status == kNeedSlow) {
-        __syncthreads();
+      if (a.fast) {
+        status = node_ellipsoid<true>(L, a, v.pts, v.perm, 0, n, es, cov_g, &lv, &root_fmax);
+        root_fast = status == DH_OK;
+        if (status == kFullRecord) status = DH_OK;
+      } else {
         status = node_ellipsoid<false>(L, a, v.pts, v.perm, 0, n, es, cov_g, &lv, &root_fmax);
       }
     }
@@ -1737,16 +1761,15 @@ __global__ void __launch_bounds__(kThreads) k_split(RebuildArgs a, int level) {
   }
 }
 
-// One workgroup per new child.  SLOW = false: the eigen-free path; a node it does not apply to goes on
-// the level's slow list.  SLOW = true: the reference's route for those nodes (grid = runs x G,
-// workgroup g takes entries g, g + G, ...), or for every node of the level when the eigen-free path is
-// switched off.  Two kernels so that the common one stays small (registers: two workgroups per CU).
+// One workgroup per new child.  SLOW = false: the eigen-free path (with its in-place fallback);
+// SLOW = true: the reference's route for every node -- the kernel of the diagnostic mode
+// DH_REBUILD_FAST=0.  Two kernels so that the common one stays small (registers: two workgroups per CU).
 template <bool SLOW>
-__global__ void __launch_bounds__(kThreads) k_ell(RebuildArgs a, int level, int G) {
+__global__ void __launch_bounds__(kThreads, SLOW ? 1 : 2) k_ell(RebuildArgs a, int level, int G) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int run = blockIdx.x / G, g = blockIdx.x % G;
-  const int* list = (SLOW && a.fast) ? a.slow_list + (size_t)run * 2 * a.maxw : a.ell_list + (size_t)run * 2 * a.maxw;
-  const int cnt = (SLOW && a.fast) ? a.nslow[(size_t)level * a.runs + run] : a.nell[(size_t)level * a.runs + run];
+  const int* list = a.ell_list + (size_t)run * 2 * a.maxw;
+  const int cnt = a.nell[(size_t)level * a.runs + run];
   if (g >= cnt) return;
   if (a.kerr[run] != DH_OK) {  // raised by a k_split workgroup of this level
     if (threadIdx.x == 0) atomicMin(&a.status[run], a.kerr[run]);
@@ -1765,21 +1788,15 @@ __global__ void __launch_bounds__(kThreads) k_ell(RebuildArgs a, int level, int 
     L.c_pts = nullptr;
     const int rc = node_ellipsoid<!SLOW>(L, a, v.pts, v.perm, start, count, v.estore + (size_t)node * v.NS,
                                          v.estore + (size_t)node * v.NS + v.ES, &lv, &fmx);
-    if (!SLOW && rc == kNeedSlow) {
-      if (t == 0) {
-        const int e = atomicAdd(&a.nslow[(size_t)level * a.runs + run], 1);
-        a.slow_list[(size_t)run * 2 * a.maxw + e] = node;
-      }
-      continue;
-    }
-    if (rc != DH_OK) {
+    const bool full = SLOW || rc == kFullRecord;
+    if (rc != DH_OK && rc != kFullRecord) {
       set_status(a, run, rc);
       return;
     }
     if (t == 0) {
       v.nodes[node].logvol = lv;
       v.nodes[node].fmax = fmx;
-      v.nodes[node].fast = SLOW ? 0 : 1;
+      v.nodes[node].fast = full ? 0 : 1;
       if (count >= 4 * D) {  // big enough to try a split at the next level (:1492-1496)
         if (level + 1 >= a.levels) {
           atomicMin(&a.status[run], DH_ERR_NOMEM);  // deeper than the launch plan
@@ -2391,7 +2408,7 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
   if ((long long)runs * rp > 512) rp = 1;
   if (getenv("DH_ROOT_PARTS") && atoi(getenv("DH_ROOT_PARTS")) == 0) rp = 1;  // diagnostic
   // zeroed counters: nnodes | nsplit (levels+1) | nell (levels) | nparts (levels+1) | kerr | rbar | kbar (levels x maxw)
-  const size_t b_cnt = (size_t)runs * ((size_t)4 * a.levels + 5 + kBarStride + (size_t)a.levels * a.maxw * kBarStride) * 4;
+  const size_t b_cnt = (size_t)runs * ((size_t)3 * a.levels + 5 + kBarStride + (size_t)a.levels * a.maxw * kBarStride) * 4;
   a.rootbuf_stride = (size_t)rp * (2 * (size_t)d + (size_t)d * d + 1) + (size_t)d * d + 8;
   const size_t b_rb = (size_t)runs * a.rootbuf_stride * 8;
   const size_t b_fl = (size_t)runs * a.max_nodes * 8, b_fi = (size_t)runs * a.max_nodes * 2 * 4;
@@ -2407,7 +2424,7 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
   const size_t b_re = a.fast ? (size_t)runs * (2 * (size_t)d * d + d + 2) * 8 : 0;
   auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
   const size_t total = al(b_perm) * 2 + al(b_lab) + al(b_nodes) + al(b_es) + al(b_res) + al(b_cnt) +
-                       al(b_sl) + 2 * al(b_el) + al(b_sc) + al(b_ps) + al(b_pl) + al(b_pb) + al(b_kp) + al(b_rb) + al(b_fl) + al(b_fi) +
+                       al(b_sl) + al(b_el) + al(b_sc) + al(b_ps) + al(b_pl) + al(b_pb) + al(b_kp) + al(b_rb) + al(b_fl) + al(b_fi) +
                        2 * al(b_of) + al(b_re);
   if (total > ctx->rebuild_ws_cap) {
     if (!hip_ok(ctx, hipStreamSynchronize(ctx->stream), "sync")) return DH_ERR_HIP;
@@ -2438,14 +2455,11 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
   a.nell = a.nsplit + (size_t)(a.levels + 1) * runs;
   a.nparts = a.nell + (size_t)a.levels * runs;
   a.kerr = a.nparts + (size_t)(a.levels + 1) * runs;
-  a.nslow = a.kerr + runs;
-  a.rbar = a.nslow + (size_t)a.levels * runs;
+  a.rbar = a.kerr + runs;
   a.kbar = a.rbar + (size_t)runs * kBarStride;
   a.split_list = (int*)w;
   w += al(b_sl);
   a.ell_list = (int*)w;
-  w += al(b_el);
-  a.slow_list = (int*)w;
   w += al(b_el);
   a.scale_g = (double*)w;
   w += al(b_sc);
@@ -2523,11 +2537,10 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
   }
   for (int L = 0; L < a.levels; ++L) {
     hipLaunchKernelGGL(k_split, dim3(runs * a.maxp), dim3(kThreads), lds, ctx->stream, a, L);
-    if (a.fast) hipLaunchKernelGGL(k_ell<false>, dim3(runs * 2 * a.maxw), dim3(kThreads), lds, ctx->stream, a, L, 2 * a.maxw);
-    // the reference's route: the (rare) nodes the eigen-free path handed over, two workgroups per run
-    // striding over them -- or every node of the level when that path is off
-    const int gs = a.fast ? 2 : 2 * a.maxw;
-    hipLaunchKernelGGL(k_ell<true>, dim3(runs * gs), dim3(kThreads), lds, ctx->stream, a, L, gs);
+    if (a.fast)
+      hipLaunchKernelGGL(k_ell<false>, dim3(runs * 2 * a.maxw), dim3(kThreads), lds, ctx->stream, a, L, 2 * a.maxw);
+    else
+      hipLaunchKernelGGL(k_ell<true>, dim3(runs * 2 * a.maxw), dim3(kThreads), lds, ctx->stream, a, L, 2 * a.maxw);
   }
   if (forked && !hip_ok(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0), "hipStreamWaitEvent(join)")) return DH_ERR_HIP;
   hipLaunchKernelGGL(k_finish, dim3(runs), dim3(kThreads), lds_fin, ctx->stream, a);

@@ -1,9 +1,9 @@
 """HBM traffic per launch from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE collected separately, each with
 --kernel-trace only, as MI355X_MICROARCH.md prescribes):
 
-    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_f -- python bench.py --no-cpu --no-e2e --steps 3 --warmup 1
-    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_w -- python bench.py --no-cpu --no-e2e --steps 3 --warmup 1
-    python tools/pmc_traffic.py gpurun_out/pmc_f gpurun_out/pmc_w > profiles/r01/pmc_traffic.json
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_f -- python bench.py --lean --preroll 0 --steps 3 --warmup 1
+    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_w -- python bench.py --lean --preroll 0 --steps 3 --warmup 1
+    python tools/pmc_traffic.py gpurun_out/pmc_f gpurun_out/pmc_w > profiles/r02/pmc_traffic.json
 
 gfx950 correction: FETCH_SIZE counts 128-byte requests as 64 B -> x2; both counters are in KB."""
 import csv, glob, json, sys
@@ -22,12 +22,13 @@ def load(d, counter):
 
 
 fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
-out = {"command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python bench.py --no-cpu "
-                  "--no-e2e --steps 3 --warmup 1 (two separate passes)",
+out = {"command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python bench.py --lean "
+                  "--preroll 0 --steps 3 --warmup 1 (two separate passes)",
        "correction": "gfx950: FETCH_SIZE counts 128-B requests at 64 B -> x2 (MI355X_MICROARCH.md, HBM section); "
                      "WRITE_SIZE uncorrected; both in KB",
        "kernels": {}}
-steps = len(fetch.get("rwalk_kernel<25, true, 1>", [])) or 1
+rw = [k for k in fetch if k.startswith("rwalk_kernel<25, true, 1")]
+steps = len(fetch.get(rw[0], [])) if rw else 1
 for name in sorted(set(fetch) | set(write)):
     fk = sum(v for _, v in fetch.get(name, []))
     wk = sum(v for _, v in write.get(name, []))
@@ -36,11 +37,12 @@ for name in sorted(set(fetch) | set(write)):
                             "WRITE_SIZE_KB_per_launch_raw": wk / max(n, 1),
                             "traffic_bytes_per_launch": (2 * fk + wk) * 1024 / max(n, 1),
                             "traffic_bytes_per_bench_step": (2 * fk + wk) * 1024 / steps}
-rb = [k for k in out["kernels"] if k in ("k_root", "k_split", "k_ell", "k_finish")]
+rb = [k for k in out["kernels"] if k.split("<")[0] in ("k_root_parts", "k_split", "k_ell", "k_finish", "k_out_eig",
+                                                      "k_root_eig")]
 out["rwalk_launches_profiled"] = steps
-nrb = out["kernels"].get("k_root", {}).get("launches", 0)
+nrb = out["kernels"].get("k_root_parts", {}).get("launches", 0)
 out["rebuild_pipelines_profiled"] = nrb
-# one pipeline = k_root + levels x (k_split, k_ell) + k_finish over all runs of the batch
+# one pipeline = k_root_parts (+ k_root_eig on the side stream) + levels x (k_split, k_ell<false>, k_ell<true>) + k_finish + k_out_eig
 out["rebuild_pipeline_bytes_per_launch_sequence"] = sum(
     out["kernels"][k]["traffic_bytes_per_launch"] * out["kernels"][k]["launches"] for k in rb) / max(nrb, 1)
 for k in out["kernels"].values():
