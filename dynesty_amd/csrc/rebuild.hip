@@ -41,7 +41,7 @@ struct Node {
   int split;        // 1 if children were created
   int res_start, res_len;  // result list (indices of nodes) after the accept test
   int fast;         // 1: the record holds the eigen-free form (spd_fast): am, major axis, logvol only
-  int pad_;
+  int has_mean;     // 1: the record's centre slot already holds the node's mean (from the k-means cluster sums)
   double logvol;
   double fmax;      // max_i delta_i^T am delta_i over the node's own points, with the stored am (after the rescale)
 };
@@ -402,53 +402,60 @@ __device__ __forceinline__ void stage_tile(const Lds& L, const double* __restric
   __syncthreads();
 }
 
-// mean of a node -> L.mean (np.mean(points, axis=0), bounding.py:1410)
+// mean of a node -> L.mean (np.mean(points, axis=0), bounding.py:1410).  Tile partials are reduced per
+// tile and added in tile order: the grouping of the cooperative root (one part per tile, partials summed in
+// part order), so that a live set gives the same bits whichever root routine its batch size selects.
 __device__ __forceinline__ void node_mean(const Lds& L, const double* pts, const int* perm, int start, int count, int D) {
   const int t = threadIdx.x;
   const int G = kThreads / D > 0 ? kThreads / D : 1;  // point groups per dim
   const int j = t % D, g = t / D;
-  double acc = 0.0;
+  double total = 0.0;
   for (int base = 0; base < count; base += L.TP) {
     const int cnt = min(L.TP, count - base);
     stage_tile(L, pts, perm, start + base, cnt, D, 0);
+    double acc = 0.0;
     if (g < G && t < G * D)
       for (int p = g; p < cnt; p += G) acc += L.tile[p * L.LD + j];
+    L.red[t] = acc;
+    __syncthreads();
+    if (t < D) {
+      double s = 0.0;
+      for (int gg = 0; gg < G; ++gg) s += L.red[gg * D + t];
+      total += s;
+    }
     __syncthreads();
   }
-  L.red[t] = acc;
-  __syncthreads();
-  if (t < D) {
-    double s = 0.0;
-    for (int gg = 0; gg < G; ++gg) s += L.red[gg * D + t];
-    L.mean[t] = s / (double)count;
-  }
+  if (t < D) L.mean[t] = total / (double)count;
   __syncthreads();
 }
 
-// population std of a node -> L.scale (points.std(axis=0), bounding.py:1503-1504)
+// population std of a node -> L.scale (points.std(axis=0), bounding.py:1503-1504); same tile-ordered
+// grouping as node_mean
 __device__ void node_std(const Lds& L, const double* pts, const int* perm, int start, int count, int D) {
   node_mean(L, pts, perm, start, count, D);
   const int t = threadIdx.x;
   const int G = kThreads / D > 0 ? kThreads / D : 1;
   const int j = t % D, g = t / D;
-  double acc = 0.0;
+  double total = 0.0;
   for (int base = 0; base < count; base += L.TP) {
     const int cnt = min(L.TP, count - base);
     stage_tile(L, pts, perm, start + base, cnt, D, 1);
+    double acc = 0.0;
     if (g < G && t < G * D)
       for (int p = g; p < cnt; p += G) {
         const double x = L.tile[p * L.LD + j];
         acc = fma(x, x, acc);
       }
+    L.red[t] = acc;
+    __syncthreads();
+    if (t < D) {
+      double s = 0.0;
+      for (int gg = 0; gg < G; ++gg) s += L.red[gg * D + t];
+      total += s;
+    }
     __syncthreads();
   }
-  L.red[t] = acc;
-  __syncthreads();
-  if (t < D) {
-    double s = 0.0;
-    for (int gg = 0; gg < G; ++gg) s += L.red[gg * D + t];
-    L.scale[t] = sqrt(s / (double)count);
-  }
+  if (t < D) L.scale[t] = sqrt(total / (double)count);
   __syncthreads();
 }
 
@@ -1038,11 +1045,16 @@ constexpr int kFullRecord = 1;  // node_ellipsoid<true>: done, but by the refere
 template <bool FAST>
 __device__ __forceinline__ int node_ellipsoid(const Lds& L, const RebuildArgs& a, const double* pts, const int* perm,
                                               int start, int count, double* es, double* cov_g, double* logvol_out,
-                                              double* fmax_out) {
+                                              double* fmax_out, bool have_mean = false) {
   const int D = a.d, t = threadIdx.x, LD = L.LD;
   if (count == 1) return DH_ERR_VALUE;
   PH_T0();
-  node_mean(L, pts, perm, start, count, D);
+  if (have_mean) {  // left in the record by k_split (the final k-means centroid of this cluster)
+    if (t < D) L.mean[t] = es[t];
+    __syncthreads();
+  } else {
+    node_mean(L, pts, perm, start, count, D);
+  }
   PH_ADD(0);
   node_cov(L, pts, perm, start, count, D);
   PH_ADD(1);
@@ -1675,7 +1687,7 @@ __global__ void __launch_bounds__(kThreads) k_root_parts(RebuildArgs a, int rp) 
     r.res_start = 0;
     r.res_len = 0;
     r.fast = root_fast;
-    r.pad_ = 0;
+    r.has_mean = 0;
     r.logvol = lv;
     r.fmax = root_fmax;
     v.nodes[0] = r;
@@ -1730,6 +1742,7 @@ __global__ void __launch_bounds__(kThreads) k_split(RebuildArgs a, int level) {
   const int n1 = count - n0;
   if (min(n0, n1) < min_size) return;  // reject the split (:1521-1522): node stays a leaf
   if (q == 0 && t == 0) {
+    L.ri[300] = -1;
     const int c0 = atomicAdd(&a.nnodes_dev[run], 2);
     if (c0 + 2 > a.max_nodes) {
       atomicMin(&a.kerr[run], DH_ERR_NOMEM);
@@ -1746,7 +1759,7 @@ __global__ void __launch_bounds__(kThreads) k_split(RebuildArgs a, int level) {
       k0.res_start = k1.res_start = 0;
       k0.res_len = k1.res_len = 0;
       k0.fast = k1.fast = 0;
-      k0.pad_ = k1.pad_ = 0;
+      k0.has_mean = k1.has_mean = 1;
       k0.logvol = k1.logvol = 0.0;
       k0.fmax = k1.fmax = INFINITY;
       v.nodes[c0] = k0;
@@ -1757,6 +1770,19 @@ __global__ void __launch_bounds__(kThreads) k_split(RebuildArgs a, int level) {
       const int e = atomicAdd(&a.nell[(size_t)level * a.runs + run], 2);
       a.ell_list[(size_t)run * 2 * a.maxw + e] = c0;
       a.ell_list[(size_t)run * 2 * a.maxw + e + 1] = c0 + 1;
+      L.ri[300] = c0;
+    }
+  }
+  // The children's means come for free: the centroids after the tenth update ARE the means of the final
+  // clusters (cluster sums / counts, in the scaled coordinates of the k-means).  k_ell then skips its
+  // mean pass over the points (one of its three gathers).
+  if (q == 0) {
+    if (t == 0 && !(L.ri[300] >= 0 && L.ri[300] + 2 <= a.max_nodes)) L.ri[300] = -1;
+    __syncthreads();
+    const int c0 = L.ri[300];
+    if (c0 >= 0 && t < 2 * D) {
+      const int c = t >= D ? 1 : 0, j = t - c * D;
+      v.estore[(size_t)(c0 + c) * v.NS + j] = L.cen[c * D + j] * L.scale[j];
     }
   }
 }
@@ -1787,7 +1813,8 @@ __global__ void __launch_bounds__(kThreads, SLOW ? 1 : 2) k_ell(RebuildArgs a, i
     __syncthreads();
     L.c_pts = nullptr;
     const int rc = node_ellipsoid<!SLOW>(L, a, v.pts, v.perm, start, count, v.estore + (size_t)node * v.NS,
-                                         v.estore + (size_t)node * v.NS + v.ES, &lv, &fmx);
+                                         v.estore + (size_t)node * v.NS + v.ES, &lv, &fmx,
+                                         v.nodes[node].has_mean != 0);
     const bool full = SLOW || rc == kFullRecord;
     if (rc != DH_OK && rc != kFullRecord) {
       set_status(a, run, rc);
