@@ -120,3 +120,30 @@ def test_full_size_properties_c3_and_c5_shard(ctx):
     assert len(many) == 512
     lv = np.array([np.logaddexp.reduce(r["logvol_ells"]) for r in many])
     assert np.ptp(lv) < 1e-6  # the same cloud, permuted: the same bound
+
+
+@pytest.mark.parametrize("d", [2, 3, 5])
+def test_exactly_degenerate_leading_eigenvalues(ctx, d):
+    """A lattice cloud has a covariance proportional to the identity: the leading eigenvalues coincide
+    exactly, the repeated-squaring iteration of the eigen-free node path cannot converge, and the node must
+    take the reference's route in place (regularize with the wave-level Jacobi).  Which of the equal axes is
+    'major' is LAPACK's arbitrary choice in the reference, so only properties are checked."""
+    g = np.linspace(0.2, 0.8, 7 if d == 2 else 5 if d == 3 else 3)
+    pts = np.stack(np.meshgrid(*[g] * d), -1).reshape(-1, d)
+    pts = pts[np.random.default_rng(d).permutation(len(pts))]
+    a = ctx.rebuild(pts, multi=True, want_labels=True)
+    b = ctx.rebuild(pts, multi=True, want_labels=True)
+    assert a["nells"] >= 1 and a["nells"] == b["nells"]
+    for k in FIELDS:
+        np.testing.assert_array_equal(a[k], b[k])
+    count, _, _ = ctx.contains(pts, a["ctrs"], a["ams"], mode=0)
+    assert (count > 0).all()
+    for i in range(a["nells"]):
+        ax = a["axes"][i]
+        np.testing.assert_allclose(ax @ ax.T, a["covs"][i], rtol=0, atol=1e-10 * np.abs(a["covs"][i]).max())
+    # the single-ellipsoid form of the same cloud: the sample covariance itself is c * I
+    one = ctx.rebuild(pts, multi=False)
+    cov = one["covs"][0]
+    np.testing.assert_allclose(cov, np.eye(d) * cov[0, 0], rtol=0, atol=1e-12 * cov[0, 0])
+    ref = B.bounding_ellipsoid(pts)
+    np.testing.assert_allclose(one["logvol_ells"][0], ref.logvol, rtol=0, atol=1e-9)
