@@ -542,17 +542,41 @@ __device__ __forceinline__ void cov_finalize(const Lds& L, int D, double inv) {
   __syncthreads();
 }
 
-__device__ __forceinline__ void node_cov(const Lds& L, const double* pts, const int* perm, int start, int count, int D) {
+// tile_order: fold the four wave partials per TILE and add the tiles in order -- the grouping of the
+// cooperative root (one part per tile, parts summed in part order), used for the root so that a live set
+// gives the same bits whichever root routine its batch size selects.  Tree nodes keep the cheaper form
+// (accumulators across all tiles, one fold): they are always built by this routine.
+__device__ __forceinline__ void node_cov(const Lds& L, const double* pts, const int* perm, int start, int count, int D,
+                                         bool tile_order = false) {
   mfma_acc acc[6];  // (0,0) (0,1) (1,1) (0,2) (1,2) (2,2)
 #pragma unroll
   for (int b = 0; b < 6; ++b) acc[b] = (mfma_acc){0.0, 0.0, 0.0, 0.0};
+  const bool multi = tile_order && count > L.TP;
   for (int base = 0; base < count; base += L.TP) {
     const int cnt = min(L.TP, count - base);
     stage_tile(L, pts, perm, start + base, cnt, D, 1);
     tile_cov_accumulate(L, cnt, D, acc);
     __syncthreads();
+    if (multi) {
+      cov_fold_waves(L, D, acc);  // -> upper triangle of L.A
+      for (int e = threadIdx.x; e < D * D; e += kThreads) {
+        const int i = e / D, j = e - i * D;
+        if (i <= j) L.V[i * L.LD + j] = (base ? L.V[i * L.LD + j] : 0.0) + L.A[i * L.LD + j];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int b = 0; b < 6; ++b) acc[b] = (mfma_acc){0.0, 0.0, 0.0, 0.0};
+    }
   }
-  cov_fold_waves(L, D, acc);
+  if (multi) {
+    for (int e = threadIdx.x; e < D * D; e += kThreads) {
+      const int i = e / D, j = e - i * D;
+      if (i <= j) L.A[i * L.LD + j] = L.V[i * L.LD + j];
+    }
+    __syncthreads();
+  } else {
+    cov_fold_waves(L, D, acc);
+  }
   cov_finalize(L, D, 1.0 / (double)(count - 1));
 }
 
@@ -1056,7 +1080,7 @@ __device__ __forceinline__ int node_ellipsoid(const Lds& L, const RebuildArgs& a
     node_mean(L, pts, perm, start, count, D);
   }
   PH_ADD(0);
-  node_cov(L, pts, perm, start, count, D);
+  node_cov(L, pts, perm, start, count, D, !have_mean);  // no mean handed down = the root
   PH_ADD(1);
   // cov_g: this node's D x LD working covariance (global scratch, L2 resident)
   for (int e = t; e < D * D; e += kThreads) cov_g[(e / D) * LD + e % D] = L.A[(e / D) * LD + e % D];
@@ -2431,8 +2455,36 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
   }
   // parts of the root: cooperative only while all parts of all runs are resident with room to spare
   // (a part idles at a barrier while part 0 runs the eigensolver, so on a full chip it only costs slots)
+  // Co-residency.  Workgroups that meet at a spin barrier -- the parts of the root, the parts of one
+  // k-means node -- must be on the chip together.  How many workgroups of a kernel fit is asked of the
+  // runtime (occupancy API x CU count), not assumed.  The whole grid of k_root_parts must fit (every part
+  // waits for part 0's solve); for k_split only the <= ceil(n / 256) parts of ONE node must: they have
+  // consecutive workgroup ids and the dispatcher hands out workgroups in id order, so the parts of the
+  // lowest unfinished node are always all dispatched, and every earlier workgroup can finish without them.
+  int cap_root = 0, cap_split = 0;
+  {
+    static int cu_count[kMaxDev] = {};
+    int& ncu = cu_count[ctx->device & (kMaxDev - 1)];
+    if (!ncu) {
+      hipDeviceProp_t prop;
+      ncu = hipGetDeviceProperties(&prop, ctx->device) == hipSuccess ? prop.multiProcessorCount : 1;
+    }
+    int occ_root = 0, occ_split = 0;
+    // (the LDS attribute must be in place for the query to count the dynamic allocation)
+    (void)hipFuncSetAttribute((const void*)k_root_parts, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)k_split, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_root, (const void*)k_root_parts, kThreads, lds) != hipSuccess)
+      occ_root = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_split, (const void*)k_split, kThreads, lds) != hipSuccess)
+      occ_split = 1;
+    cap_root = ncu * (occ_root > 0 ? occ_root : 1);
+    cap_split = ncu * (occ_split > 0 ? occ_split : 1);
+  }
   int rp = n > 1 ? (n + kThreads - 1) / kThreads : 1;
-  if ((long long)runs * rp > 512) rp = 1;
+  if ((long long)runs * rp > cap_root) rp = 1;
+  if (mode == 0 && (n + kThreads - 1) / kThreads > cap_split)
+    return fail(ctx, DH_ERR_ARG, "rebuild: the %d parts of a %d-point node exceed the %d co-resident workgroups of k_split",
+                (n + kThreads - 1) / kThreads, n, cap_split);
   if (getenv("DH_ROOT_PARTS") && atoi(getenv("DH_ROOT_PARTS")) == 0) rp = 1;  // diagnostic
   // zeroed counters: nnodes | nsplit (levels+1) | nell (levels) | nparts (levels+1) | kerr | rbar | kbar (levels x maxw)
   const size_t b_cnt = (size_t)runs * ((size_t)3 * a.levels + 5 + kBarStride + (size_t)a.levels * a.maxw * kBarStride) * 4;

@@ -147,3 +147,22 @@ def test_exactly_degenerate_leading_eigenvalues(ctx, d):
     np.testing.assert_allclose(cov, np.eye(d) * cov[0, 0], rtol=0, atol=1e-12 * cov[0, 0])
     ref = B.bounding_ellipsoid(pts)
     np.testing.assert_allclose(one["logvol_ells"][0], ref.logvol, rtol=0, atol=1e-9)
+
+
+def test_cooperative_root_threshold_follows_the_occupancy(ctx):
+    """The cooperative root (resident parts meeting at spin barriers) is only used while runs x parts fit the
+    chip (capacity from the occupancy API); beyond that the single-workgroup routine runs -- with bit-identical
+    results either way."""
+    import os
+    pts = inputs.cloud("c2")
+    sets = [pts[np.random.default_rng(s).permutation(2000)] for s in range(3)]
+    coop = [ctx.rebuild(p, multi=True) for p in sets]
+    os.environ["DH_ROOT_PARTS"] = "0"
+    try:
+        single = [ctx.rebuild(p, multi=True) for p in sets]
+    finally:
+        del os.environ["DH_ROOT_PARTS"]
+    for a, b in zip(coop, single):
+        assert a["nells"] == b["nells"]
+        for k in FIELDS:
+            np.testing.assert_array_equal(a[k], b[k])
