@@ -1,6 +1,7 @@
 """One BASELINE-C5 shard on the device: R full C2 runs through dh_ns_ensemble.  usage: ns_c5.py [runs] [K]"""
-import sys, time, json, numpy as np
-sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+import os, sys, time, json, numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import inputs
 from dynesty_amd import _lib
 runs = int(sys.argv[1]) if len(sys.argv) > 1 else 64
