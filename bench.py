@@ -498,13 +498,13 @@ def main():
     if not args.no_e2e:
         from dynesty_amd import ensemble
 
-        def e2e_leg(rebuild_sync):
+        def e2e_leg(rebuild_sync, rng="pcg64"):
             t0 = time.perf_counter()
             table = ensemble.run_ensemble_device(
                 prob, runs * world, base_seed=21, world=world, rank=rank,
                 dist=dist, device=dev if dist else None,
                 nlive=nlive, queue_size=512, walks=args.walks,
-                rebuild_sync=rebuild_sync)
+                rebuild_sync=rebuild_sync, rng=rng)
             dt = time.perf_counter() - t0
             if dist is not None:
                 t = torch.tensor([dt], dtype=torch.float64, device="cuda")
@@ -526,6 +526,8 @@ def main():
                               "single process"})
         # ... and with the ensemble's rebuilds synchronised (early, never late)
         e2e["rebuild_sync"] = e2e_leg(True)
+        # ... and with the proposals drawn from hiprand Philox streams (throughput RNG mode)
+        e2e["throughput_rng"] = e2e_leg(False, rng="philox")
 
     if rank == 0:
         alg_bytes = 8 * (2 * d + 1)  # read u, write u', write logl

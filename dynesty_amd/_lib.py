@@ -692,7 +692,7 @@ class Context:
                     bound='multi', dlogz=0.01, enlarge=1.25, entropy=(21,),
                     first_run=0, max_fills=0, max_iter=400000,
                     want_dead_logl=False, sample='rwalk', slices=None,
-                    rebuild_sync=False, want_samples=False):
+                    rebuild_sync=False, want_samples=False, rng='pcg64'):
         """Device-resident ensemble of static NS runs (dh_ns_ensemble).
 
         rebuild_sync=False keeps the reference's per-run update schedule
@@ -709,6 +709,10 @@ class Context:
             raise ValueError(f"ns_ensemble: sample={sample!r} is not supported by the "
                              "device-resident loop ('rwalk', 'rslice' or 'slice')")
         kind = dict(rwalk=0, rslice=1, slice=2)[sample]
+        if rng not in ('pcg64', 'philox'):
+            raise ValueError("ns_ensemble: rng must be 'pcg64' or 'philox'")
+        if rng == 'philox' and kind != 0:
+            raise ValueError("ns_ensemble: the Philox throughput mode exists for sample='rwalk'")
         if kind == 0:
             if walks is None:
                 walks = nd + 20  # dynesty.py:128
@@ -726,7 +730,7 @@ class Context:
         nf = C.c_int64(0)
         self._check(self.lib.dh_ns_ensemble(
             self.handle, self.problem(prob), int(runs), int(nlive), nd,
-            int(queue_size), kind, int(walks), 1 if bound == 'multi' else 0,
+            int(queue_size), 3 if rng == 'philox' else kind, int(walks), 1 if bound == 'multi' else 0,
             1 if rebuild_sync else 0, float(dlogz), float(enlarge), int(max_fills), int(max_iter),
             _ptr(words), words.size, int(first_run), _ptr(rec), _ptr(dead),
             _ptr(livel), _ptr(dead_u), _ptr(live_u), C.byref(nf)))

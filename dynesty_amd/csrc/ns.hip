@@ -906,6 +906,10 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
   ProblemDev pd;
   if (!get_problem(ctx, problem, &pd)) return DH_ERR_ARG;
   if (pd.ndim != ndim) return fail(ctx, DH_ERR_ARG, "problem ndim %d != %d", pd.ndim, ndim);
+  // sampler 3 = rwalk with the proposals drawn from hiprand Philox streams (throughput RNG mode, DESIGN.md
+  // section 2); start points, frames and the unit-cube phase keep their PCG64 streams
+  const bool philox = sampler == 3;
+  if (philox) sampler = 0;
   if (runs < 1 || nlive < 4 || queue_size < 1 || walks < 1 || sampler < 0 || sampler > 2 || !entropy_words ||
       n_words < 1 || !records)
     return fail(ctx, DH_ERR_ARG, "ns_ensemble: bad arguments");
@@ -1044,10 +1048,17 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
                             a.q_rng, 0, a.r_u, a.r_v, a.r_logl, a.r_a, a.r_b, a.q_rng_out, a.run_loglstar,
                             a.run_mode, K, MODE_CUBE);
       if (rc) return cleanup(rc);
-      if (sampler == 0)
+      if (sampler == 0) {
+        // Philox key: seed from the entropy words, subsequence = global walker slot (first_run + run) * K + w
+        // (independent of the sharding), offset advancing by 4096 draws per fill (a walker uses < 31 per step)
+        dh::PhiloxKey key;
+        key.seed = ((unsigned long long)entropy_words[0] << 32) ^ (n_words > 1 ? entropy_words[1] : 0u) ^ 0x9E3779B97F4A7C15ull;
+        key.seq0 = (unsigned long long)first_run * (unsigned long long)K;
+        key.offset = (unsigned long long)fill * 4096ull * (unsigned long long)((walks + 127) / 128);
         rc = rwalk_launch_runs(ctx, problem, R * K, D, D, a.q_u0, a.b_axes, R * me, a.q_frame, 1.0, 0.0, walks,
                                nullptr, a.q_rng, a.r_u, a.r_v, a.r_logl, a.r_a, a.r_b, a.q_rng_out,
-                               a.run_loglstar, a.run_scale, a.run_mode, K, MODE_BOUND);
+                               a.run_loglstar, a.run_scale, a.run_mode, K, MODE_BOUND, philox ? &key : nullptr);
+      }
       else
         rc = slice_launch_runs(ctx, problem, R * K, D, sampler - 1, a.q_u0, a.b_axes, R * me, a.q_frame, 1.0,
                                0.0, walks, 0, a.q_rng, a.r_u, a.r_v, a.r_logl, a.r_a, a.r_b, a.r_c, a.r_d,

@@ -351,7 +351,7 @@ int dh_ns_consume(dh_ctx* ctx, int runs, int nlive, int queue_size, double dlogz
  * rebuild comes early, never late): a rebuild is a latency-bound tree construction
  * that costs about the same for one run or the whole ensemble. */
 int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim,
-                   int queue_size, int sampler /* 0 rwalk, 1 rslice, 2 slice */,
+                   int queue_size, int sampler /* 0 rwalk, 1 rslice, 2 slice, 3 rwalk with hiprand Philox proposals */,
                    int walks /* or slices */, int bound_multi,
                    int rebuild_sync /* 1: all runs rebuild together, see below */, double dlogz,
                    double enlarge, int64_t max_fills, int64_t max_iter,

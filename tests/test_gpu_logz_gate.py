@@ -33,11 +33,12 @@ def bound(se_a, se_b):
     return max(0.05, 3.0 * math.sqrt(se_a * se_a + se_b * se_b))
 
 
-@pytest.mark.parametrize("K,ref_key", [(512, "K512"), (512, "K1"), (2000, "K2000")])
-def test_c2_device_ensemble_vs_reference_ensemble(ctx, K, ref_key):
+@pytest.mark.parametrize("K,ref_key,rng", [(512, "K512", "pcg64"), (512, "K1", "pcg64"), (2000, "K2000", "pcg64"),
+                                           (512, "K512", "philox")])
+def test_c2_device_ensemble_vs_reference_ensemble(ctx, K, ref_key, rng):
     ref = json.load(open(os.path.join(GOLD, "c2_logz_ref.json")))["ensembles"][ref_key]
     prob = inputs.problem("C2")
-    r = ctx.ns_ensemble(prob, 64, 2000, K, walks=45, bound="multi", entropy=[2026, K], dlogz=0.01)
+    r = ctx.ns_ensemble(prob, 64, 2000, K, walks=45, bound="multi", entropy=[2026, K], dlogz=0.01, rng=rng)
     assert np.all(r["status"] == 0)
     lz = r["logz"]
     mean, se = lz.mean(), lz.std(ddof=1) / math.sqrt(len(lz))

@@ -150,3 +150,26 @@ def test_sharded_merge_equals_single_process(ctx):
     np.testing.assert_array_equal(a.logl, b.logl)
     np.testing.assert_array_equal(a.samples_u, b.samples_u)
     np.testing.assert_array_equal(a.logz, b.logz)
+
+
+def test_philox_proposals_in_the_device_loop(ctx):
+    """sample='rwalk', rng='philox': the proposals of the device-resident loop drawn from hiprand Philox
+    streams (throughput RNG mode).  Same statistics as the parity streams, deterministic, and independent of
+    how the ensemble is sharded (the Philox subsequence is the global walker slot)."""
+    prob = inputs.problem("G5")
+    kw = dict(nlive=300, queue_size=64, walks=25, bound="multi", entropy=[17, 4], dlogz=0.05, rng="philox")
+    r = ctx.ns_ensemble(prob, 16, **kw)
+    assert np.all(r["status"] == 0)
+    lz = r["logz"]
+    se = lz.std(ddof=1) / 4.0
+    assert abs(lz.mean() - prob.logz_truth) < 5 * se + 0.08, (lz.mean(), se)
+    again = ctx.ns_ensemble(prob, 16, **kw)
+    np.testing.assert_array_equal(again["logz"], lz)
+    lo = ctx.ns_ensemble(prob, 8, first_run=0, **kw)
+    hi = ctx.ns_ensemble(prob, 8, first_run=8, **kw)
+    np.testing.assert_array_equal(np.concatenate([lo["logz"], hi["logz"]]), lz)
+    # not the PCG64 streams
+    pcg = ctx.ns_ensemble(prob, 16, **dict(kw, rng="pcg64"))
+    assert (pcg["logz"] != lz).all()
+    with pytest.raises(ValueError):
+        ctx.ns_ensemble(prob, 2, 100, 16, sample="rslice", rng="philox")
