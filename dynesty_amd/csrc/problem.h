@@ -227,7 +227,12 @@ __device__ __forceinline__ void prior_to_lds(const ProblemDev& P, const double (
 
 // log-likelihood of the v staged in `sv` by prior_to_lds.  `w` is register
 // scratch for the precision mat-vec.
-template <int N, bool FULL, int KIND>
+// SB > 0: a scheduling barrier after every SB rows of the triangular form (LIKE_GAUSS_PREC, FULL).  Without
+// it the scheduler clusters the scalar loads of all 325 unrolled FMAs; in the PCG64 rwalk kernel, whose
+// registers are exhausted, that meant ~690 SGPR spills as soon as the frame rows also came through the
+// scalar cache.  With SB = 4 that kernel runs 1.44 -> 1.24 ms; the Philox kernel is faster without (0.86 vs
+// 1.1-1.2 ms), so the caller chooses.
+template <int N, bool FULL, int KIND, int SB = 0>
 __device__ __forceinline__ double loglike_lds(const ProblemDev& P, int n, const double* sv, int lane,
                                               double (&w)[N]) {
   cdptr lp = as_const(P.like_par);
@@ -270,6 +275,9 @@ __device__ __forceinline__ double loglike_lds(const ProblemDev& P, int n, const 
           q1 = fma(w[i], r, q1);
         else
           q0 = fma(w[i], r, q0);
+        if constexpr (SB > 0) {
+          if ((i % SB) == SB - 1) __builtin_amdgcn_sched_barrier(0);
+        }
       }
       return lp[0] - (q0 + q1);
     } else {

@@ -202,15 +202,8 @@ __global__ void __launch_bounds__(64, DH_RW_OCC) rwalk_kernel(RwalkArgs a) {
     while (!done) {
       const int cur = __builtin_amdgcn_readfirstlane(my_frame);
       if (cur == my_frame) {
-        // Philox kernel: frame rows through the scalar cache (pointer pinned to SGPRs, see as_const_uniform):
-        // 1.26 -> 0.87 ms.  PCG64 kernel: the same change tips its register allocation (690 SGPR spills in
-        // the likelihood block, 1.4 -> 1.5 ms), so it keeps the per-lane vector loads of the rows.
-        if (!DH_ABL(a, 2)) {
-          if constexpr (RNG == RNG_PHILOX)
-            matvec_sgpr<N>(as_const_uniform(a.axes_t + (size_t)cur * N * N), sx, lane, nc, acc);
-          else
-            matvec_sgpr<N>(as_const(a.axes_t + (size_t)cur * N * N), sx, lane, nc, acc);
-        }
+        // frame rows through the scalar cache: the pointer is pinned to SGPRs (see as_const_uniform)
+        if (!DH_ABL(a, 2)) matvec_sgpr<N>(as_const_uniform(a.axes_t + (size_t)cur * N * N), sx, lane, nc, acc);
         done = true;
       }
     }
@@ -273,7 +266,7 @@ __global__ void __launch_bounds__(64, DH_RW_OCC) rwalk_kernel(RwalkArgs a) {
     if (a.fence | DH_ABL(a, 4))
       ll = loglstar + ur - 0.6;
     else
-      ll = loglike_lds<N, FULL, KIND>(a.prob, n, sx, lane, acc);
+      ll = loglike_lds<N, FULL, KIND, (RNG == RNG_PCG64 ? 4 : 0)>(a.prob, n, sx, lane, acc);
     if (ll > loglstar) {
 #pragma unroll
       for (int i = 0; i < N; ++i) u[i] = up[i];
