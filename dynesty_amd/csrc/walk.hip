@@ -46,6 +46,12 @@ __device__ __forceinline__ double reflect01(double x) {
 
 // experiment hooks: -DDH_FENCES=<bitmask> places further never-taken branches (scheduling-region ends)
 //   1 after the normals, 2 after the frame product, 4 after the cube check, 8 after the prior transform
+#ifndef DH_PCG_SB
+#define DH_PCG_SB 4     // scheduling barrier every 4 rows of the likelihood in the PCG64 kernel (problem.h)
+#endif
+#ifndef DH_PHILOX_SB
+#define DH_PHILOX_SB 0  // none in the Philox kernel
+#endif
 #ifndef DH_FENCES
 #define DH_FENCES 8  // measured best (tools/rw_exp.sh / rw_exp_run.sh): fence after the prior transform
 #endif
@@ -266,7 +272,7 @@ __global__ void __launch_bounds__(64, DH_RW_OCC) rwalk_kernel(RwalkArgs a) {
     if (a.fence | DH_ABL(a, 4))
       ll = loglstar + ur - 0.6;
     else
-      ll = loglike_lds<N, FULL, KIND, (RNG == RNG_PCG64 ? 4 : 0)>(a.prob, n, sx, lane, acc);
+      ll = loglike_lds<N, FULL, KIND, (RNG == RNG_PCG64 ? DH_PCG_SB : DH_PHILOX_SB)>(a.prob, n, sx, lane, acc);
     if (ll > loglstar) {
 #pragma unroll
       for (int i = 0; i < N; ++i) u[i] = up[i];
