@@ -128,7 +128,7 @@ __global__ void __launch_bounds__(64, 2) slice_kernel(SliceArgs a) {
         while (!done) {
           const int cur = __builtin_amdgcn_readfirstlane(my_frame);
           if (cur == my_frame) {
-            matvec_sgpr<N>(as_const(a.axes_t + (size_t)cur * N * N), sx, lane, n, acc);
+            matvec_sgpr<N>(as_const_uniform(a.axes_t + (size_t)cur * N * N), sx, lane, n, acc);
             done = true;
           }
         }
@@ -520,7 +520,7 @@ __global__ void __launch_bounds__(64, 2) unif_kernel(UnifArgs a) {
         while (!mv) {
           const int cur = __builtin_amdgcn_readfirstlane(idx);
           if (cur == idx) {
-            matvec_sgpr<N>(as_const(a.axes_t + (size_t)cur * N * N), sx, lane, nc, acc);
+            matvec_sgpr<N>(as_const_uniform(a.axes_t + (size_t)cur * N * N), sx, lane, nc, acc);
             mv = true;
           }
         }

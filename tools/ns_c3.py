@@ -1,6 +1,7 @@
 """C3 ensemble (eggbox 2-D, nlive 5000, multi/rslice): python tools/ns_c3.py [runs]"""
-import sys, time, json, numpy as np
-sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+import os, sys, time, json, numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import inputs
 from dynesty_amd import _lib
 runs = int(sys.argv[1]) if len(sys.argv) > 1 else 16
