@@ -94,10 +94,11 @@ SIGNATURES = {
     "dh_unif_batch_dev": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp,
                                _dbl, _vp, _vp, C.c_int64, _vp, _vp, _vp, _vp,
                                _vp, _vp]),
-    "dh_ns_consume": (_i, [_vp, _i, _i, _i, _dbl, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dh_ns_consume": (_i, [_vp, _i, _i, _i, _dbl, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                           _vp, _vp, _vp]),
     "dh_ns_ensemble": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _dbl, _dbl,
                             C.c_int64, C.c_int64, _vp, _i, _u32, _vp, _vp,
-                            _vp, _vp, _vp, _vp]),
+                            _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dh_friends_update": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp,
                                _vp, _vp, _vp, _vp]),
     "dh_friends_within": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp]),
@@ -667,10 +668,12 @@ class Context:
             _ptr(logl), _ptr(nc), _ptr(rng_out), None, None))
         return dict(u=u, v=v, logl=logl, ncalls=nc, rng_out=rng_out)
 
-    def ns_consume(self, live_logl, q_logl, q_ncalls, state, dlogz):
+    def ns_consume(self, live_logl, q_logl, q_ncalls, state, dlogz, live_it=None):
         """One queue consumption per run (dh_ns_consume).  live_logl (R, N) and
         state (R, 8) are updated in place; returns dict(dead_logl, dead_slot,
-        dead_src (lists per run), stopped (R,) bool)."""
+        dead_src (lists per run), stopped (R,) bool).  With live_it ((R, N) int32,
+        updated in place: iteration at which each live point was proposed) also
+        dead_it / dead_nc per run (the reference's per-point 'it' and 'nc')."""
         live = np.ascontiguousarray(live_logl, dtype=np.float64)
         assert live is live_logl and live.ndim == 2
         R, N = live.shape
@@ -680,13 +683,22 @@ class Context:
         assert state.dtype == np.float64 and state.shape == (R, 8) and state.flags.c_contiguous
         dl = np.empty((R, K)); ds = np.empty((R, K), dtype=np.int32); dj = np.empty((R, K), dtype=np.int32)
         nd = np.empty(R, dtype=np.int32); stp = np.empty(R, dtype=np.int32)
+        dit = dnc = None
+        if live_it is not None:
+            assert live_it.dtype == np.int32 and live_it.shape == (R, N) and live_it.flags.c_contiguous
+            dit = np.empty((R, K), dtype=np.int32)
+            dnc = np.empty((R, K), dtype=np.int32)
         self._check(self.lib.dh_ns_consume(self.handle, R, N, K, float(dlogz), _ptr(live), _ptr(ql),
                                            _ptr(qn), _ptr(state), _ptr(dl), _ptr(ds), _ptr(dj),
-                                           _ptr(nd), _ptr(stp)))
-        return dict(dead_logl=[dl[r, :nd[r]].copy() for r in range(R)],
-                    dead_slot=[ds[r, :nd[r]].copy() for r in range(R)],
-                    dead_src=[dj[r, :nd[r]].copy() for r in range(R)],
-                    stopped=stp.astype(bool))
+                                           _ptr(nd), _ptr(stp), _ptr(live_it), _ptr(dit), _ptr(dnc)))
+        out = dict(dead_logl=[dl[r, :nd[r]].copy() for r in range(R)],
+                   dead_slot=[ds[r, :nd[r]].copy() for r in range(R)],
+                   dead_src=[dj[r, :nd[r]].copy() for r in range(R)],
+                   stopped=stp.astype(bool))
+        if live_it is not None:
+            out["dead_it"] = [dit[r, :nd[r]].copy() for r in range(R)]
+            out["dead_nc"] = [dnc[r, :nd[r]].copy() for r in range(R)]
+        return out
 
     def ns_ensemble(self, prob, runs, nlive, queue_size, walks=None,
                     bound='multi', dlogz=0.01, enlarge=1.25, entropy=(21,),
@@ -727,13 +739,19 @@ class Context:
         # runs x max_iter x ndim: only the niter rows a run produced are touched
         dead_u = np.empty((runs, max_iter, nd)) if want_samples else None
         live_u = np.empty((runs, nlive, nd)) if want_samples else None
+        # the reference's per-point id / it / nc (sampler.py:1165-1182) travel with the samples
+        pid = np.empty((runs, max_iter), dtype=np.int32) if want_samples else None
+        pit = np.empty((runs, max_iter), dtype=np.int32) if want_samples else None
+        pnc = np.empty((runs, max_iter), dtype=np.int32) if want_samples else None
+        lit = np.empty((runs, nlive), dtype=np.int32) if want_samples else None
         nf = C.c_int64(0)
         self._check(self.lib.dh_ns_ensemble(
             self.handle, self.problem(prob), int(runs), int(nlive), nd,
             int(queue_size), 3 if rng == 'philox' else kind, int(walks), 1 if bound == 'multi' else 0,
             1 if rebuild_sync else 0, float(dlogz), float(enlarge), int(max_fills), int(max_iter),
             _ptr(words), words.size, int(first_run), _ptr(rec), _ptr(dead),
-            _ptr(livel), _ptr(dead_u), _ptr(live_u), C.byref(nf)))
+            _ptr(livel), _ptr(dead_u), _ptr(live_u), C.byref(nf), _ptr(pid), _ptr(pit), _ptr(pnc),
+            _ptr(lit)))
         out = dict(logz=rec[:, 0], logzerr=rec[:, 1],
                    niter=rec[:, 2].astype(np.int64),
                    ncall=rec[:, 3].astype(np.int64), h=rec[:, 4],
@@ -746,6 +764,7 @@ class Context:
         if want_samples:
             out["dead_u"] = dead_u
             out["live_u"] = live_u
+            out["dead_id"], out["dead_it"], out["dead_nc"], out["live_it"] = pid, pit, pnc, lit
         return out
 
     # ---- RadFriends / SupFriends ------------------------------------------

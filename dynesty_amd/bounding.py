@@ -397,25 +397,32 @@ class _HipFriends(HipBound):
         self.logvol = logvol
 
     # -- membership ---------------------------------------------------------------
+    def _whitened(self, x):
+        # one point against every shape: (ctrs - x) axes_inv on the host -- a device call here would
+        # re-upload all centres for a single point, once per queue entry (sampler.py:485)
+        return np.dot(np.asarray(self.ctrs, dtype=np.float64) - np.asarray(x, dtype=np.float64), self.axes_inv)
+
     def within(self, x):
         """Indices of the shapes containing x (bounding.py:777-784, 1043-1051)."""
-        ctrs = np.asarray(self.ctrs, dtype=np.float64)
-        _, bits = get_backend().friends_within(ctrs, self.kind, self.axes_inv,
-                                               np.asarray(x)[None],
-                                               want_bits=True)
-        b = np.unpackbits(bits[0].view(np.uint8), bitorder="little")[:len(ctrs)]
-        return np.nonzero(b)[0]
+        w = self._whitened(x)
+        if self.kind == 'balls':
+            return np.where(np.linalg.norm(w, axis=1) <= 1.)[0]
+        return np.where(np.max(np.abs(w), axis=1) <= 1.)[0]
 
     def overlap(self, x):
         """bounding.py:786-791, 1053-1059."""
-        counts, _ = get_backend().friends_within(
-            np.asarray(self.ctrs, dtype=np.float64), self.kind, self.axes_inv,
-            np.asarray(x)[None])
-        return int(counts[0])
+        return len(self.within(x))
 
     def contains(self, x):
         """bounding.py:793-796, 1061-1064."""
         return self.overlap(x) > 0
+
+    def overlap_many(self, x):
+        """overlap() of every row of x in one device launch (workgroup-per-point membership)."""
+        counts, _ = get_backend().friends_within(
+            np.asarray(self.ctrs, dtype=np.float64), self.kind, self.axes_inv,
+            np.atleast_2d(np.asarray(x, dtype=np.float64)))
+        return np.asarray(counts)
 
     # -- draws ------------------------------------------------------------------
     def _draw(self, rstate, nsamp, return_q=False):

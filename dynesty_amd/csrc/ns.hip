@@ -40,6 +40,7 @@ struct NsRun {
   int acc, rej, doubling, pad1;
   double logzvar;
   uint64_t rng[4];
+  long long nc_carry;  // calls of the entries popped after the last death: charged to the NEXT death (sampler.py:1141)
 };
 
 struct NsArgs {
@@ -94,6 +95,11 @@ struct NsArgs {
   int* trace_slot;  // runs x K or null: slot of every death
   int* trace_src;   // runs x K or null: queue index of its replacement
   int* trace_n;     // runs x 2 or null: number of deaths kept, stopped flag
+  // per-point bookkeeping of the reference's saved_run (sampler.py:1165-1182), all optional (null together):
+  int* live_it;  // runs x N   in/out: iteration at which the point living in the slot was proposed (0 = initial)
+  int* dead_id;  // like dead_logl: slot of the dead point                        ('id')
+  int* dead_it;  //                 iteration at which it had been proposed        ('it')
+  int* dead_nc;  //                 likelihood calls spent to replace it           ('nc')
 };
 
 __device__ __forceinline__ double logaddexp_dev(double x, double y) {
@@ -149,6 +155,7 @@ __global__ void __launch_bounds__(kT)
     r.nfill = 0;
     r.acc = r.rej = r.doubling = r.pad1 = 0;
     r.logzvar = 0.0;
+    r.nc_carry = 0;
     Pcg64 g;
     seed_from_child(g, entropy, nwords, 0x80000000u + first_run + (uint32_t)run);
     g.store(r.rng);
@@ -471,6 +478,7 @@ __global__ void __launch_bounds__(kT) ns_consume(NsArgs a) {
   int* dj = qc + K;                 // K   death list: queue index of the replacement
   int* dslot = dj + K;              // K               slot
   int* dsrc = dslot + K;            // K               content source at death
+  int* qborn = dsrc + K;            // K   (per-point bookkeeping only) death index at which entry j went live
   __shared__ int misc[8];
   __shared__ double wred[2][4];
   __shared__ double bcast[4];
@@ -511,7 +519,7 @@ __global__ void __launch_bounds__(kT) ns_consume(NsArgs a) {
     }
     __syncthreads();
   }
-  const long long it0 = r.it;
+  const long long it0 = r.it, carry0 = r.nc_carry;
   const double logvol0 = r.logvol, logz0 = r.logz, h0 = r.h, lmax0 = r.lmax, dead_prev0 = r.dead_prev;
   const double dlv = log(((double)N + 1.0) / (double)N);
   const double ldv_c = log(0.5 * expm1(dlv));  // ln(dX_e / X_e) of the trapezoid rule
@@ -655,6 +663,14 @@ __global__ void __launch_bounds__(kT) ns_consume(NsArgs a) {
     }
     r.loglstar = hp[0].x;
     r.nfill += 1;
+    {
+      // entries popped after the last kept death found no worse point to replace any more in this fill: the
+      // reference goes on popping from the refilled queue within the same iteration, so their calls belong
+      // to the next death's 'nc'
+      long long c = nkeep > 0 ? 0 : carry0;
+      for (int j = nkeep > 0 ? dj[E] + 1 : 0; j <= jlast; ++j) c += qc[j];
+      r.nc_carry = c;
+    }
     if (mode == MODE_BOUND) {
       const int ta = racc[0], tr = rrej[0];
       if (a.sampler == 0) {
@@ -686,6 +702,22 @@ __global__ void __launch_bounds__(kT) ns_consume(NsArgs a) {
   if (a.trace_n && t == 0) {
     a.trace_n[run * 2] = nkeep;
     a.trace_n[run * 2 + 1] = stopped ? 1 : 0;
+  }
+  if (a.dead_id) {
+    for (int e = t; e < nkeep; e += kT) qborn[dj[e]] = e;
+    __syncthreads();
+    for (int e = t; e < nkeep; e += kT) {
+      long long nc = e ? 0 : carry0;
+      for (int j = e ? dj[e - 1] + 1 : 0; j <= dj[e]; ++j) nc += qc[j];
+      const int sj = dsrc[e];
+      a.dead_nc[dbase + e] = (int)nc;
+      a.dead_id[dbase + e] = dslot[e];
+      // self.it starts at 1 (sampler.py:396): the replacement of death index i (0-based) is born at i + 1
+      a.dead_it[dbase + e] = sj < 0 ? a.live_it[(size_t)run * N + dslot[e]] : (int)(it0 + qborn[sj] + 1);
+    }
+    __syncthreads();
+    for (int sl = t; sl < N; sl += kT)
+      if (src[sl] >= 0) a.live_it[(size_t)run * N + sl] = (int)(it0 + qborn[src[sl]] + 1);
   }
   // dead-point coordinates (optional), in death order
   if (a.store_samples) {
@@ -809,15 +841,19 @@ extern "C" {
 // see include/dynhip.h
 int dh_ns_consume(dh_ctx* ctx, int runs, int nlive, int queue_size, double dlogz, double* live_logl,
                   const double* q_logl, const int32_t* q_ncalls, double* state, double* dead_logl,
-                  int32_t* dead_slot, int32_t* dead_src, int32_t* ndead, int32_t* stopped) {
+                  int32_t* dead_slot, int32_t* dead_src, int32_t* ndead, int32_t* stopped, int32_t* live_it,
+                  int32_t* dead_it, int32_t* dead_nc) {
   DH_CHECK_CTX(ctx);
+  const bool want_pt = live_it || dead_it || dead_nc;
+  if (want_pt && !(live_it && dead_it && dead_nc))
+    return fail(ctx, DH_ERR_ARG, "ns_consume: live_it, dead_it and dead_nc come together");
   if (runs < 1 || nlive < 4 || queue_size < 1 || !live_logl || !q_logl || !q_ncalls || !state || !dead_logl ||
       !dead_slot || !dead_src || !ndead || !stopped)
     return fail(ctx, DH_ERR_ARG, "ns_consume: bad arguments");
   const int R = runs, N = nlive, K = queue_size;
   if (K > kEPT * kT) return fail(ctx, DH_ERR_ARG, "ns_consume: queue_size %d > %d", K, kEPT * kT);
   const size_t lds_heap = (size_t)heap_cap(N) * 16 + (size_t)N * 8 + 64;
-  const size_t lds_cons = (size_t)heap_cap(N) * 16 + (size_t)N * 4 + (size_t)K * 32 + 64;
+  const size_t lds_cons = (size_t)heap_cap(N) * 16 + (size_t)N * 4 + (size_t)K * 36 + 64;
   const size_t lds_max = lds_cons > lds_heap ? lds_cons : lds_heap;
   if (lds_max > 150 * 1024) return fail(ctx, DH_ERR_ARG, "ns_consume: nlive/queue too large for LDS");
   NsArgs a{};
@@ -830,7 +866,7 @@ int dh_ns_consume(dh_ctx* ctx, int runs, int nlive, int queue_size, double dlogz
   a.dlogz = dlogz;
   a.dead_rel = 1;
   arena_reset(ctx);
-  int rc = arena_reserve(ctx, (size_t)R * (sizeof(NsRun) + (size_t)N * 20 + (size_t)K * 28 + 64) + 16384);
+  int rc = arena_reserve(ctx, (size_t)R * (sizeof(NsRun) + (size_t)N * 24 + (size_t)K * 40 + 64) + 16384);
   if (rc) return rc;
   std::vector<NsRun> st((size_t)R);
   for (int r = 0; r < R; ++r) {
@@ -859,6 +895,13 @@ int dh_ns_consume(dh_ctx* ctx, int runs, int nlive, int queue_size, double dlogz
   a.trace_n = (int*)arena_get(ctx, (size_t)R * 8);
   a.ndone = (int*)arena_get(ctx, 64);
   a.bstatus = (int*)arena_get(ctx, (size_t)R * 4);
+  if (want_pt) {
+    a.live_it = (int*)arena_up(ctx, (const int*)live_it, (size_t)R * N);
+    a.dead_id = (int*)arena_get(ctx, (size_t)R * K * 4);
+    a.dead_it = (int*)arena_get(ctx, (size_t)R * K * 4);
+    a.dead_nc = (int*)arena_get(ctx, (size_t)R * K * 4);
+    if (!a.live_it || !a.dead_id || !a.dead_it || !a.dead_nc) return DH_ERR_NOMEM;
+  }
   if (!a.st || !a.live_logl || !a.heap_key || !a.heap_slot || !a.dead_logl || !a.r_logl || !a.r_a ||
       !a.trace_slot || !a.trace_src || !a.trace_n || !a.ndone || !a.bstatus)
     return DH_ERR_NOMEM;
@@ -877,6 +920,9 @@ int dh_ns_consume(dh_ctx* ctx, int runs, int nlive, int queue_size, double dlogz
   if (!down(ctx, st.data(), a.st, (size_t)R) || !down(ctx, live_logl, a.live_logl, (size_t)R * N) ||
       !down(ctx, dead_logl, a.dead_logl, (size_t)R * K) || !down(ctx, (int*)dead_slot, a.trace_slot, (size_t)R * K) ||
       !down(ctx, (int*)dead_src, a.trace_src, (size_t)R * K) || !down(ctx, tn.data(), a.trace_n, (size_t)R * 2))
+    return DH_ERR_HIP;
+  if (want_pt && (!down(ctx, (int*)live_it, a.live_it, (size_t)R * N) || !down(ctx, (int*)dead_it, a.dead_it, (size_t)R * K) ||
+                  !down(ctx, (int*)dead_nc, a.dead_nc, (size_t)R * K)))
     return DH_ERR_HIP;
   if ((rc = dh_sync(ctx))) return rc;
   for (int r = 0; r < R; ++r) {
@@ -901,8 +947,12 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
                    int64_t max_iter,
                    const uint32_t* entropy_words, int n_words, uint32_t first_run, double* records,
                    double* dead_logl_out, double* live_logl_out, double* dead_u_out, double* live_u_out,
-                   int64_t* n_fills_out) {
+                   int64_t* n_fills_out, int32_t* dead_id_out, int32_t* dead_it_out, int32_t* dead_nc_out,
+                   int32_t* live_it_out) {
   DH_CHECK_CTX(ctx);
+  const bool want_pt = dead_id_out || dead_it_out || dead_nc_out || live_it_out;
+  if (want_pt && !(dead_id_out && dead_it_out && dead_nc_out && live_it_out))
+    return fail(ctx, DH_ERR_ARG, "ns_ensemble: the per-point outputs (id, it, nc, live it) come together");
   ProblemDev pd;
   if (!get_problem(ctx, problem, &pd)) return DH_ERR_ARG;
   if (pd.ndim != ndim) return fail(ctx, DH_ERR_ARG, "problem ndim %d != %d", pd.ndim, ndim);
@@ -963,7 +1013,9 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
                o_bs = take((size_t)R * 4), o_bc = take((size_t)R * me * D * 8), o_bv = take((size_t)R * me * dd * 8),
                o_ba = take((size_t)R * me * dd * 8), o_bx = take((size_t)R * me * dd * 8),
                o_bl = take((size_t)R * me * D * 8), o_bg = take((size_t)R * me * 8),
-               o_rec = take((size_t)R * 8 * 8), o_ent = take((size_t)n_words * 4);
+               o_rec = take((size_t)R * 8 * 8), o_ent = take((size_t)n_words * 4),
+               o_lit = take(want_pt ? (size_t)R * N * 4 : 8), o_pid = take(want_pt ? (size_t)R * a.cap * 4 : 8),
+               o_pit = take(want_pt ? (size_t)R * a.cap * 4 : 8), o_pnc = take(want_pt ? (size_t)R * a.cap * 4 : 8);
   char* base = nullptr;
   (void)hipSetDevice(ctx->device);
   if (!hip_ok(ctx, hipMalloc((void**)&base, off), "hipMalloc(ns state)")) return DH_ERR_NOMEM;
@@ -1006,8 +1058,15 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
   a.b_axl = (double*)(base + o_bl);
   a.b_lv = (double*)(base + o_bg);
   a.records = (double*)(base + o_rec);
+  if (want_pt) {
+    a.live_it = (int*)(base + o_lit);
+    a.dead_id = (int*)(base + o_pid);
+    a.dead_it = (int*)(base + o_pit);
+    a.dead_nc = (int*)(base + o_pnc);
+  }
   uint32_t* d_ent = (uint32_t*)(base + o_ent);
   hipStream_t s = ctx->stream;
+  if (want_pt && !hip_ok(ctx, hipMemsetAsync(base + o_lit, 0, (size_t)R * N * 4, s), "memset")) return cleanup(DH_ERR_HIP);
   if (!hip_ok(ctx, hipMemsetAsync(base + o_nd, 0, 64, s), "memset") ||
       !hip_ok(ctx, hipMemsetAsync(base + o_bs, 0, (size_t)R * 4, s), "memset") ||
       !hip_ok(ctx, hipMemsetAsync(base + o_ne, 0, (size_t)R * 4, s), "memset") ||
@@ -1018,7 +1077,7 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
   int rc = eval_launch_dev(ctx, problem, R * N, a.live_u, a.live_v, a.live_logl);
   if (rc) return cleanup(rc);
   const size_t lds_heap = (size_t)heap_cap(N) * 16 + (size_t)N * 8 + 64;
-  const size_t lds_cons = (size_t)heap_cap(N) * 16 + (size_t)N * 4 + (size_t)K * 32 + 64;
+  const size_t lds_cons = (size_t)heap_cap(N) * 16 + (size_t)N * 4 + (size_t)K * 36 + 64;
   if (K > kEPT * kT) return cleanup(fail(ctx, DH_ERR_ARG, "ns_ensemble: queue_size %d > %d", K, kEPT * kT));
   if (lds_cons > 150 * 1024) return cleanup(fail(ctx, DH_ERR_ARG, "ns_ensemble: nlive/queue too large for LDS"));
   const size_t lds_max = lds_cons > lds_heap ? lds_cons : lds_heap;
@@ -1088,6 +1147,12 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
   if (live_u_out &&
       !hip_ok(ctx, hipMemcpyAsync(live_u_out, a.live_u, (size_t)R * N * D * 8, hipMemcpyDeviceToHost, s),
               "D2H live u"))
+    return cleanup(DH_ERR_HIP);
+  if (want_pt &&
+      (!hip_ok(ctx, hipMemcpyAsync(live_it_out, a.live_it, (size_t)R * N * 4, hipMemcpyDeviceToHost, s), "D2H live it") ||
+       !hip_ok(ctx, hipMemcpyAsync(dead_id_out, a.dead_id, (size_t)R * a.cap * 4, hipMemcpyDeviceToHost, s), "D2H id") ||
+       !hip_ok(ctx, hipMemcpyAsync(dead_it_out, a.dead_it, (size_t)R * a.cap * 4, hipMemcpyDeviceToHost, s), "D2H it") ||
+       !hip_ok(ctx, hipMemcpyAsync(dead_nc_out, a.dead_nc, (size_t)R * a.cap * 4, hipMemcpyDeviceToHost, s), "D2H nc")))
     return cleanup(DH_ERR_HIP);
   if (dead_u_out) {
     // only the niter rows each run produced (the caller's runs x max_iter x ndim buffer may be

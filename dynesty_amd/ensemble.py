@@ -178,7 +178,8 @@ class MergedRun(dict):
 
 
 def merge_static_runs(dead_logl, niter, live_logl, dead_u=None, live_u=None,
-                      prior_transform=None, ncall=None):
+                      prior_transform=None, ncall=None, dead_id=None, dead_it=None,
+                      dead_nc=None, live_it=None, live_id=None):
     """Combine R static runs of equal, constant nlive into ONE run with R*nlive
     live points -- what the reference's utils.merge_runs / _merge_two
     (utils.py:1817-1900, 2000-2226) produce for such runs.
@@ -196,15 +197,27 @@ def merge_static_runs(dead_logl, niter, live_logl, dead_u=None, live_u=None,
     samples); prior_transform: optional callable mapping an (n, D) array of
     unit-cube points to parameters (gives `samples`).
 
+    dead_id / dead_it / dead_nc: (R, >=max niter) and live_it: (R, N) optional
+    (together): the per-point bookkeeping the reference's runs carry -- live
+    slot, iteration at which the point was proposed, likelihood calls spent on
+    its replacement (sampler.py:1165-1182; the final live points have id = their
+    slot and nc = 1, sampler.py:870-890) -- which _merge_two copies point by
+    point into samples_id / samples_it / ncall (utils.py:2154-2156, 2196-2207).
+    live_id: (R, N) slots of the rows of live_logl when they are not in slot order.
+
     Returns a MergedRun with niter, logl, logvol, logwt, logz, logzerr,
     information (all per point, cumulative where the reference's are),
-    samples_n, samples_run (run index of each point), samples_it (index within
-    its run's own sequence) and, with coordinates given, samples_u / samples."""
+    samples_n, samples_run (run index of each point), samples_seq (index within
+    its run's own sequence), with coordinates given samples_u / samples, and with
+    the per-point bookkeeping given samples_id, samples_it and ncall (array; its
+    sum replaces the `ncall` argument in eff = 100 niter / sum(ncall))."""
     from .nested import _integrate_full
     dead_logl = np.asarray(dead_logl)
     live_logl = np.asarray(live_logl)
     R, N = live_logl.shape
     ls, ns, rs, its, us = [], [], [], [], []
+    point_info = dead_id is not None
+    ids, bits, ncs = [], [], []
     for r in range(R):
         k = int(niter[r])
         d = dead_logl[r, :k]
@@ -217,6 +230,13 @@ def merge_static_runs(dead_logl, niter, live_logl, dead_u=None, live_u=None,
         if dead_u is not None:
             us.append(np.concatenate([np.asarray(dead_u[r][:k]),
                                       np.asarray(live_u[r])[lo]]))
+        if point_info:
+            ids.append(np.concatenate([np.asarray(dead_id[r][:k], dtype=np.int64),
+                                       lo if live_id is None else np.asarray(live_id[r], dtype=np.int64)[lo]]))
+            bits.append(np.concatenate([np.asarray(dead_it[r][:k], dtype=np.int64),
+                                        np.asarray(live_it[r], dtype=np.int64)[lo]]))
+            ncs.append(np.concatenate([np.asarray(dead_nc[r][:k], dtype=np.int64),
+                                       np.ones(N, dtype=np.int64)]))
     logl = np.concatenate(ls)
     dn = np.concatenate(ns)
     order = np.argsort(logl, kind="stable")
@@ -228,8 +248,13 @@ def merge_static_runs(dead_logl, niter, live_logl, dead_u=None, live_u=None,
                     logz=logz, logzerr=np.sqrt(logzvar), information=h,
                     samples_n=nlive_at.astype(np.int64),
                     samples_run=np.concatenate(rs)[order],
-                    samples_it=np.concatenate(its)[order])
-    if ncall is not None:
+                    samples_seq=np.concatenate(its)[order])
+    if point_info:
+        out["samples_id"] = np.concatenate(ids)[order]
+        out["samples_it"] = np.concatenate(bits)[order]
+        out["ncall"] = np.concatenate(ncs)[order]
+        out["eff"] = 100. * len(logl) / float(out["ncall"].sum())
+    elif ncall is not None:
         out["ncall"] = int(np.sum(ncall))
         out["eff"] = 100. * len(logl) / out["ncall"]
     if us:
@@ -263,7 +288,8 @@ def run_ensemble_merged(prob, runs, nlive=2000, queue_size=512, entropy=(21,),
         return be.problem_eval(prob, u)[0]
     m = merge_static_runs(r["dead_logl"], r["niter"], r["live_logl"],
                           r["dead_u"], r["live_u"], prior_transform=ptform,
-                          ncall=r["ncall"])
+                          dead_id=r["dead_id"], dead_it=r["dead_it"], dead_nc=r["dead_nc"],
+                          live_it=r["live_it"])
     m["runs"] = r
     return m
 
@@ -272,24 +298,32 @@ def gather_and_merge(points_per_run, nlive, world=1, rank=0, dist=None,
                      device=None, prior_transform=None, ncall=None):
     """The sharded form of the combiner (north star: "gather of logZ / posterior
     samples"): every rank contributes, per local run, ONE array of rows
-    [logl, is_final_live, u_0 .. u_{D-1}] (dead points in death order, then the
-    final live points in any order); the rows travel in the ragged all-gather
+    [logl, is_final_live, id, it, nc, u_0 .. u_{D-1}] (`run_rows`: dead points in
+    death order, then the final live points in any order; id = -1: no per-point
+    bookkeeping); the rows travel in the ragged all-gather
     (`gather_ragged`: counts + padded rows, RCCL on GPUs, gloo on CPU) and every
     rank merges all runs with `merge_static_runs`.  Returns the MergedRun."""
     allruns = gather_ragged(points_per_run, world, rank, dist=dist, device=device)
     R = len(allruns)
-    d = allruns[0].shape[1] - 2
+    d = allruns[0].shape[1] - 5
     nit = np.array([int((a[:, 1] == 0).sum()) for a in allruns])
     dead_l = np.zeros((R, max(1, nit.max())))
     dead_u = np.zeros((R, max(1, nit.max()), d))
+    dead_i = np.zeros((3, R, max(1, nit.max())), dtype=np.int64)
     live_l = np.zeros((R, nlive))
     live_u = np.zeros((R, nlive, d))
+    live_i = np.zeros((2, R, nlive), dtype=np.int64)
     for i, a in enumerate(allruns):
         dmask = a[:, 1] == 0
         dead_l[i, :nit[i]] = a[dmask, 0]
-        dead_u[i, :nit[i]] = a[dmask, 2:]
+        dead_u[i, :nit[i]] = a[dmask, 5:]
+        dead_i[:, i, :nit[i]] = a[dmask, 2:5].T
         live_l[i] = a[~dmask, 0]
-        live_u[i] = a[~dmask, 2:]
+        live_u[i] = a[~dmask, 5:]
+        live_i[:, i] = a[~dmask, 2:4].T
+    info = {}
+    if all((a[:, 2] >= 0).all() for a in allruns):
+        info = dict(dead_id=dead_i[0], dead_it=dead_i[1], dead_nc=dead_i[2], live_id=live_i[0], live_it=live_i[1])
     if ncall is not None and dist is not None and world > 1:
         import torch
         t = torch.tensor([float(np.sum(ncall))], dtype=torch.float64)
@@ -298,16 +332,22 @@ def gather_and_merge(points_per_run, nlive, world=1, rank=0, dist=None,
         dist.all_reduce(t)
         ncall = [float(t.item())]
     return merge_static_runs(dead_l, nit, live_l, dead_u, live_u,
-                             prior_transform=prior_transform, ncall=ncall)
+                             prior_transform=prior_transform, ncall=ncall, **info)
 
 
-def run_rows(dead_logl, dead_u, live_logl, live_u):
-    """One run as the row block `gather_and_merge` expects."""
+def run_rows(dead_logl, dead_u, live_logl, live_u, dead_id=None, dead_it=None, dead_nc=None, live_it=None):
+    """One run as the row block `gather_and_merge` expects (live points in slot order)."""
     k, n = len(dead_logl), len(live_logl)
-    out = np.empty((k + n, 2 + np.shape(live_u)[1]))
+    out = np.empty((k + n, 5 + np.shape(live_u)[1]))
     out[:k, 0], out[k:, 0] = dead_logl, live_logl
     out[:k, 1], out[k:, 1] = 0., 1.
-    out[:k, 2:], out[k:, 2:] = dead_u, live_u
+    if dead_id is None:
+        out[:, 2:5] = -1.
+    else:
+        out[:k, 2], out[k:, 2] = dead_id, np.arange(n)
+        out[:k, 3], out[k:, 3] = dead_it, live_it
+        out[:k, 4], out[k:, 4] = dead_nc, 1.
+    out[:k, 5:], out[k:, 5:] = dead_u, live_u
     return out
 
 
@@ -333,7 +373,8 @@ def run_ensemble_merged_sharded(prob, total_runs, base_seed=21, world=1, rank=0,
         for i in range(len(mine)):
             k = int(r["niter"][i])
             rows.append(run_rows(r["dead_logl"][i, :k], r["dead_u"][i, :k],
-                                 r["live_logl"][i], r["live_u"][i]))
+                                 r["live_logl"][i], r["live_u"][i], r["dead_id"][i, :k],
+                                 r["dead_it"][i, :k], r["dead_nc"][i, :k], r["live_it"][i]))
 
     def ptform(u):
         return be.problem_eval(prob, u)[0]

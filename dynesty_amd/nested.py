@@ -86,7 +86,11 @@ def run_static(prob, nlive=500, bound='multi', sample='rwalk', queue_size=None,
                maxiter=None, first_update_min_ncall=None,
                first_update_min_eff=10., verbose=False):
     """One static nested-sampling run on the device.  Returns a RunResult with
-    logz, logzerr, niter, ncall, samples_u, samples_logl, logwt, nbound."""
+    logz, logzerr, niter, ncall, samples_u, samples_logl, logwt, nbound and the
+    reference's per-point bookkeeping (sampler.py:1165-1182, 870-890): samples_id
+    (live slot), samples_it (iteration at which the point was proposed, counted
+    from 1; 0 = initial point), samples_nc (likelihood calls spent on the point's
+    replacement; 1 for the final live points)."""
     be = get_backend()
     if rstate is None:
         rstate = np.random.default_rng()
@@ -127,6 +131,9 @@ def run_static(prob, nlive=500, bound='multi', sample='rwalk', queue_size=None,
     logvol = 0.
     dlv = math.log((nlive + 1.) / nlive)
     dead_u, dead_logl, dead_logvol = [], [], []
+    dead_id, dead_it, dead_nc = [], [], []
+    live_it = np.zeros(nlive, dtype=np.int64)
+    nc_acc = 0  # calls of the entries popped since the last death (sampler.py:1141: 'nc')
     logz = -1.e300
     hist = dict(acc=0, rej=0, nexp=0, ncon=0)
 
@@ -219,6 +226,7 @@ def run_static(prob, nlive=500, bound='multi', sample='rwalk', queue_size=None,
         o_nc = [int(x) for x in out["ncalls"]]
         for j in range(K):
             ncall += o_nc[j]
+            nc_acc += o_nc[j]
             cur, worst = heap[0]
             if not o_logl[j] > cur:
                 continue  # stale proposal: discarded (sampler.py:774-776)
@@ -226,6 +234,11 @@ def run_static(prob, nlive=500, bound='multi', sample='rwalk', queue_size=None,
             dead_u.append(live_u[worst].copy())
             dead_logl.append(cur)
             dead_logvol.append(logvol)
+            dead_id.append(worst)
+            dead_it.append(live_it[worst])
+            dead_nc.append(nc_acc)
+            nc_acc = 0
+            live_it[worst] = it + 1  # self.it starts at 1 (sampler.py:396, 1182)
             lw = cur + logvol  # coarse running evidence for the stop rule
             logz = _logaddexp(logz, lw - log_nlive)
             live_u[worst] = out["u"][j]
@@ -257,4 +270,8 @@ def run_static(prob, nlive=500, bound='multi', sample='rwalk', queue_size=None,
                      logzerr=math.sqrt(logzvar), niter=it,
                      ncall=ncall, h=h, nbound=nbound, samples_u=all_u,
                      samples_logl=all_logl, logwt=logwt, scale=scale,
-                     eff=100. * it / ncall)
+                     eff=100. * it / ncall,
+                     samples_id=np.concatenate([np.array(dead_id, dtype=np.int64), order]),
+                     samples_it=np.concatenate([np.array(dead_it, dtype=np.int64), live_it[order]]),
+                     samples_nc=np.concatenate([np.array(dead_nc, dtype=np.int64),
+                                                np.ones(nlive, dtype=np.int64)]))

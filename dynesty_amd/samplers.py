@@ -570,9 +570,19 @@ def batched(runner):
     """Wrap a queue runner as the static per-argument ``sample`` dynesty
     expects; ``HipBatchPool.map`` finds the runner on ``_dynhip_batch``."""
 
-    def sample(arg):
-        return runner([arg])[0]
+    def checked(args):
+        # save_evaluation_history (utils.LogLikelihood, utils.py:120-262; internal_samplers.py:311,
+        # 426, 663) wants every point a sampler evaluated: the device walkers keep those in
+        # registers and hand back only the result -- an empty history would be written silently
+        if args and getattr(args[0].loglikelihood, 'save_evaluation_history', False):
+            raise NotImplementedError(
+                "dynesty_amd: save_evaluation_history=True is not supported by the device samplers "
+                "(the walkers' intermediate evaluations never leave the GPU registers)")
+        return runner(args)
 
-    sample._dynhip_batch = runner
+    def sample(arg):
+        return checked([arg])[0]
+
+    sample._dynhip_batch = checked
     sample.__doc__ = runner.__doc__
     return sample

@@ -321,11 +321,18 @@ int dh_bound_draw(dh_ctx* ctx, const uint64_t* state4, int nsamp, int d, int m,
  *                             (-1e300 before the first), it, ncall, [out only] the current worst logl
  *   dead_logl / dead_slot / dead_src   runs x K: this call's deaths in order (logl, slot, queue index of
  *                             the replacement); ndead[r] of them are valid; stopped[r] = dlogz fired
+ *   live_it / dead_it / dead_nc  optional (NULL together): the per-point bookkeeping of saved_run
+ *                             (sampler.py:1107, 1141, 1165-1182).  live_it runs x nlive in/out = iteration at
+ *                             which the point living in each slot was proposed (0 = initial point; the
+ *                             reference counts iterations from 1); dead_it runs x K = that value for every
+ *                             dead point ('it'); dead_nc runs x K = likelihood calls spent on its replacement
+ *                             ('nc': every queue entry popped since the previous death); dead_slot is 'id'.
  * Deviations from the reference, both documented in DESIGN.md: equal log-likelihoods die in heap order
  * (reference: lowest slot first) and the plateau volume steps (sampler.py:1110-1127) are not taken. */
 int dh_ns_consume(dh_ctx* ctx, int runs, int nlive, int queue_size, double dlogz, double* live_logl,
                   const double* q_logl, const int32_t* q_ncalls, double* state, double* dead_logl,
-                  int32_t* dead_slot, int32_t* dead_src, int32_t* ndead, int32_t* stopped);
+                  int32_t* dead_slot, int32_t* dead_src, int32_t* ndead, int32_t* stopped, int32_t* live_it,
+                  int32_t* dead_it, int32_t* dead_nc);
 
 /* ---- device-resident ensemble of static nested-sampling runs (BASELINE config
  * C5): the loop of Sampler.sample (sampler.py:932-1212) with a
@@ -345,6 +352,12 @@ int dh_ns_consume(dh_ctx* ctx, int runs, int nlive, int queue_size, double dlogz
  * points in death order (only the first niter rows of a run are written);
  * live_u_out (optional): runs x nlive x ndim final live points (slot order, matching
  * live_logl_out) -- the posterior samples of the runs.
+ * dead_id_out / dead_it_out / dead_nc_out (optional, NULL together with live_it_out): runs x max_iter
+ * int32 = the reference's per-point 'id' (live slot), 'it' (iteration at which the point was proposed,
+ * counted from 1; 0 = initial point) and 'nc' (likelihood calls spent on the point's replacement) of every
+ * dead point (sampler.py:1165-1182) -- what utils.merge_runs carries through as samples_id / samples_it /
+ * ncall; live_it_out: runs x nlive = 'it' of the final live points (slot order; their id is the slot,
+ * their nc is 1 by the reference's convention, sampler.py:880-886).
  * rebuild_sync = 0 keeps the reference's schedule per run (rebuild when ncall has
  * advanced by update_interval, sampler.py:625-674); rebuild_sync = 1 lets every run
  * that already has a bound rebuild whenever ANY run of the ensemble is due (its
@@ -357,7 +370,8 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim,
                    double enlarge, int64_t max_fills, int64_t max_iter,
                    const uint32_t* entropy_words, int n_words, uint32_t first_run,
                    double* records, double* dead_logl_out, double* live_logl_out,
-                   double* dead_u_out, double* live_u_out, int64_t* n_fills_out);
+                   double* dead_u_out, double* live_u_out, int64_t* n_fills_out, int32_t* dead_id_out,
+                   int32_t* dead_it_out, int32_t* dead_nc_out, int32_t* live_it_out);
 
 /* ---- RadFriends / SupFriends (bounding.py:734-1263, 1651-1702) ----------------
  * kind: 0 = 'balls' (RadFriends, Euclidean norm), 1 = 'cubes' (SupFriends, max norm).

@@ -51,7 +51,7 @@ class RunState:
         return (self.logz, self.logzvar, self.h, self.logvol, self.loglstar, self.it, self.ncall)
 
 
-def consume_queue(live_logl, queue_logl, queue_ncalls, state, dlogz, plateau=True):
+def consume_queue(live_logl, queue_logl, queue_ncalls, state, dlogz, plateau=True, live_it=None):
     """One queue fill consumed by the iteration loop (no maxiter/maxcall).
 
     ref: sampler.py:1070-1195 (stopping rule, worst point, plateau bookkeeping, volume step,
@@ -66,11 +66,16 @@ def consume_queue(live_logl, queue_logl, queue_ncalls, state, dlogz, plateau=Tru
 
     live_logl: (N,) in slot order, modified in place.  Returns a dict: dead_logl / dead_slot /
     dead_src (queue index that replaced the slot) in death order, stopped (bool), used (number of
-    queue entries popped)."""
+    queue entries popped).  With live_it ((N,) ints, modified in place: iteration at which the
+    point in each slot was proposed, ref: sampler.py:1107, 1182 -- self.it starts at 1, :396) also
+    dead_it ('it' of saved_run) and dead_nc ('nc': the calls of every entry popped for that
+    iteration, ref: sampler.py:1141-1142, 1176); nc_carry = calls popped after the last death."""
     live_logl = np.asarray(live_logl)
     K = len(queue_logl)
     s = state
     dead_logl, dead_slot, dead_src = [], [], []
+    dead_it, dead_nc = [], []
+    nc = 0
     j = 0
     stopped = False
     while True:
@@ -86,6 +91,7 @@ def consume_queue(live_logl, queue_logl, queue_ncalls, state, dlogz, plateau=Tru
             cand = j
             j += 1
             s.ncall += int(queue_ncalls[cand])
+            nc += int(queue_ncalls[cand])
             if queue_logl[cand] > loglstar_new:
                 found = cand
                 break
@@ -109,13 +115,19 @@ def consume_queue(live_logl, queue_logl, queue_ncalls, state, dlogz, plateau=Tru
         dead_slot.append(worst)
         dead_src.append(found)
         live_logl[worst] = queue_logl[found]
+        dead_nc.append(nc)
+        nc = 0
+        if live_it is not None:
+            dead_it.append(int(live_it[worst]))
+            live_it[worst] = s.it + 1  # RunState.it counts deaths from 0; the reference's self.it from 1
         s.it += 1
         if s.plateau_mode:  # ref: sampler.py:1190-1193
             s.plateau_counter -= 1
             if s.plateau_counter == 0:
                 s.plateau_mode = False
     return dict(dead_logl=np.array(dead_logl), dead_slot=np.array(dead_slot, dtype=np.int64),
-                dead_src=np.array(dead_src, dtype=np.int64), stopped=stopped, used=j)
+                dead_src=np.array(dead_src, dtype=np.int64), stopped=stopped, used=j,
+                dead_it=np.array(dead_it, dtype=np.int64), dead_nc=np.array(dead_nc, dtype=np.int64), nc_carry=nc)
 
 
 def add_live_points(live_logl, state):

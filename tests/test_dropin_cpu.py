@@ -418,3 +418,23 @@ def test_slice_lockstep_lookahead_refill(dyn, monkeypatch):
             assert g.logl == r.logl and g.ncalls == r.ncalls
         for a, b in zip(ga, gb):
             assert a.bit_generator.state == b.bit_generator.state
+
+
+def test_evaluation_history_request_fails_loudly():
+    """save_evaluation_history=True (utils.LogLikelihood) asks the samplers for every point they
+    evaluated (internal_samplers.py:28-31, 311, 426, 663); the device walkers cannot hand those
+    back, and an empty history must not be written silently."""
+    from collections import namedtuple
+    from dynesty_amd import samplers
+
+    class LL:
+        save_evaluation_history = True
+    Arg = namedtuple('SamplerArgument', ['u', 'loglstar', 'axes', 'scale', 'prior_transform', 'loglikelihood',
+                                         'rseed', 'kwargs'])
+    arg = Arg(u=np.zeros(3), loglstar=0.0, axes=np.eye(3), scale=1.0, prior_transform=None, loglikelihood=LL(),
+              rseed=None, kwargs={})
+    for run in (samplers.run_rwalk, samplers.run_rslice, samplers.run_unif):
+        with pytest.raises(NotImplementedError):
+            samplers.batched(run)(arg)
+        with pytest.raises(NotImplementedError):
+            samplers.batched(run)._dynhip_batch([arg])

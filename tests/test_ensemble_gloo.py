@@ -33,12 +33,20 @@ rag = ensemble.gather_ragged([r.samples_u[:3 + rid] for rid, r in zip(mine, resu
 rows = []
 for r in results:
     k = r.niter
-    rows.append(ensemble.run_rows(r.samples_logl[:k], r.samples_u[:k], r.samples_logl[k:], r.samples_u[k:]))
-merged = ensemble.gather_and_merge(rows, 60, world, rank, dist=dist if world > 1 else None,
-                                   ncall=[sum(r.ncall for r in results)])
+    # final live points back in slot order (run_rows numbers them by position)
+    sl = np.argsort(r.samples_id[k:])
+    rows.append(ensemble.run_rows(r.samples_logl[:k], r.samples_u[:k], r.samples_logl[k:][sl], r.samples_u[k:][sl],
+                                  r.samples_id[:k], r.samples_it[:k], r.samples_nc[:k], r.samples_it[k:][sl]))
+merged = ensemble.gather_and_merge(rows, 60, world, rank, dist=dist if world > 1 else None)
+assert merged.ncall.shape == merged.logl.shape and (merged.samples_id < 60).all() and (merged.samples_id >= 0).all()
+# the per-point columns travelled with their points: every (run, id, it) triple is one of the run's own
+for rid, r in zip(mine, results):
+    sel = merged.samples_run == rid
+    got = set(zip(merged.samples_id[sel].tolist(), merged.samples_it[sel].tolist(), merged.ncall[sel].tolist()))
+    assert got == set(zip(r.samples_id.tolist(), r.samples_it.tolist(), r.samples_nc.tolist()))
 out = dict(table=table.tolist(), nrag=[len(a) for a in rag],
            rag0=rag[0].tolist(), mlogz=float(merged.logz[-1]), mlogzerr=float(merged.logzerr[-1]),
-           mniter=int(merged.niter), mncall=int(merged.ncall), mu0=merged.samples_u[:5].tolist())
+           mniter=int(merged.niter), mncall=int(merged.ncall.sum()), mu0=merged.samples_u[:5].tolist())
 with open(os.path.join(%(out)r, "r%%d_of_%%d.json" %% (rank, world)), "w") as f:
     json.dump(out, f)
 if world > 1:

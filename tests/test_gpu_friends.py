@@ -160,7 +160,8 @@ def test_host_classes_on_device(ctx, kind):
         close(getattr(b, k), GOLD[f"{key}/u2/{k}"])
     assert abs(b.logvol - GOLD[f"{key}/u2/logvol"]) < 1e-9
     probes = GOLD[f"{key}/probes"]
-    assert [b.overlap(x) for x in probes] == list(GOLD[f"{key}/within_counts"])
+    assert [b.overlap(x) for x in probes] == list(GOLD[f"{key}/within_counts"])  # one point: host
+    assert list(b.overlap_many(probes)) == list(GOLD[f"{key}/within_counts"])  # many points: one launch
     assert b.contains(pts[0]) and not b.contains(np.array([5.0, 5.0]))
     xs = b.samples(12, rstate=np.random.default_rng(13))
     np.testing.assert_allclose(xs, GOLD[f"{key}/samples"], rtol=0, atol=1e-12)

@@ -70,6 +70,9 @@ def test_fill_chains_vs_oracle(ctx, nlive, K, runs):
     ref_live = live.copy()
     states = [R.RunState(nlive) for _ in range(runs)]
     state = pack(states)
+    # the reference's per-point bookkeeping ('it', 'nc' of saved_run) rides along
+    live_it = np.zeros((runs, nlive), dtype=np.int32)
+    ref_it = np.zeros((runs, nlive), dtype=np.int64)
     dlogz = 0.5
     done = np.zeros(runs, bool)
     nfill = 0
@@ -86,12 +89,16 @@ def test_fill_chains_vs_oracle(ctx, nlive, K, runs):
         act = ~done
         if not act.all():  # finished runs leave the ensemble (as MODE_DONE runs do on the device)
             live_a, state_a = np.ascontiguousarray(live[act]), np.ascontiguousarray(state[act])
+            it_a = np.ascontiguousarray(live_it[act])
         else:
-            live_a, state_a = live, state
-        out = ctx.ns_consume(live_a, ql[act], qn[act], state_a, dlogz)
-        live[act], state[act] = live_a, state_a
+            live_a, state_a, it_a = live, state, live_it
+        out = ctx.ns_consume(live_a, ql[act], qn[act], state_a, dlogz, live_it=it_a)
+        live[act], state[act], live_it[act] = live_a, state_a, it_a
         for i, r in enumerate(np.flatnonzero(act)):
-            ref = R.consume_queue(ref_live[r], ql[r], qn[r], states[r], dlogz, plateau=False)
+            ref = R.consume_queue(ref_live[r], ql[r], qn[r], states[r], dlogz, plateau=False, live_it=ref_it[r])
+            np.testing.assert_array_equal(out["dead_it"][i], ref["dead_it"])
+            np.testing.assert_array_equal(out["dead_nc"][i], ref["dead_nc"])
+            np.testing.assert_array_equal(live_it[r], ref_it[r])
             np.testing.assert_array_equal(out["dead_logl"][i], ref["dead_logl"])
             np.testing.assert_array_equal(out["dead_slot"][i], ref["dead_slot"])
             np.testing.assert_array_equal(out["dead_src"][i], ref["dead_src"])

@@ -125,6 +125,24 @@ def test_samples_and_merged_run(ctx):
         _, ll = ctx.problem_eval(prob, r["live_u"][run])
         np.testing.assert_allclose(ll, r["live_logl"][run], rtol=0, atol=1e-10)
         assert (np.diff(r["dead_logl"][run, :k]) >= 0).all()
+        # the reference's per-point bookkeeping (sampler.py:1165-1182): 'id' = live slot, 'it' = iteration
+        # (from 1) at which the point was proposed, 'nc' = calls spent on its replacement.  Exact chain
+        # property: a dead point of slot s was born when the previous occupant of s died (0: initial point)
+        ids, its, ncs = (r[f][run, :k] for f in ("dead_id", "dead_it", "dead_nc"))
+        assert ids.min() >= 0 and ids.max() < 300 and ncs.min() >= 1
+        last = np.zeros(300, dtype=np.int64)
+        for i in range(k):
+            assert its[i] == last[ids[i]], (run, i)
+            last[ids[i]] = i + 1
+        np.testing.assert_array_equal(r["live_it"][run], last)
+        # every call of the run is charged to exactly one death, except those after the last one and the
+        # nlive calls of the initial points
+        assert 0 <= int(r["ncall"][run]) - 300 - int(ncs.sum()) < 64 * 25 + 1
+    assert m.ncall.shape == m.logl.shape and int(m.ncall.sum()) == int(sum(
+        r["dead_nc"][q, :int(r["niter"][q])].sum() for q in range(8))) + 8 * 300
+    sel = m.samples_run == 3
+    np.testing.assert_array_equal(np.sort(m.samples_it[sel]), np.sort(np.concatenate(
+        [r["dead_it"][3, :int(r["niter"][3])], r["live_it"][3]])))
     assert m.niter == int(r["niter"].sum()) + 8 * 300
     assert (np.diff(m.logl) >= 0).all()
     assert abs(m.logz[-1] - prob.logz_truth) < 5 * m.logzerr[-1] + 0.05
@@ -146,7 +164,9 @@ def test_sharded_merge_equals_single_process(ctx):
     kw = dict(nlive=200, queue_size=32, walks=23, bound="single", dlogz=0.3, max_iter=20000)
     a = ensemble.run_ensemble_merged(prob, 5, entropy=[12], **kw)
     b = ensemble.run_ensemble_merged_sharded(prob, 5, base_seed=12, **kw)
-    assert a.niter == b.niter and a.ncall == b.ncall
+    assert a.niter == b.niter
+    for k in ("ncall", "samples_id", "samples_it"):  # the per-point bookkeeping travels through the gather
+        np.testing.assert_array_equal(a[k], b[k])
     np.testing.assert_array_equal(a.logl, b.logl)
     np.testing.assert_array_equal(a.samples_u, b.samples_u)
     np.testing.assert_array_equal(a.logz, b.logz)

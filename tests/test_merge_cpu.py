@@ -62,20 +62,30 @@ def test_merge_static_runs_matches_reference_fields():
     dead_u = np.zeros((R, max(nit), 3))
     live_l = np.zeros((R, N))
     live_u = np.zeros((R, N, 3))
-    rng = np.random.default_rng(0)
+    dead_i = np.zeros((3, R, max(nit)), dtype=np.int64)
+    live_it = np.zeros((R, N), dtype=np.int64)
     for i, r in enumerate(res):
         dead_l[i, :nit[i]] = r.logl[:nit[i]]
         dead_u[i, :nit[i]] = r.samples_u[:nit[i]]
-        # the device hands the final live points over in SLOT order, not sorted
-        sl = rng.permutation(N)
+        dead_i[0, i, :nit[i]] = r.samples_id[:nit[i]]
+        dead_i[1, i, :nit[i]] = r.samples_it[:nit[i]]
+        dead_i[2, i, :nit[i]] = r.ncall[:nit[i]]
+        # the device hands the final live points over in SLOT order (slot = the reference's 'id'), not sorted
+        sl = np.argsort(r.samples_id[nit[i]:])
+        assert (np.asarray(r.samples_id[nit[i]:])[sl] == np.arange(N)).all()
         live_l[i] = np.asarray(r.logl[nit[i]:])[sl]
         live_u[i] = np.asarray(r.samples_u[nit[i]:])[sl]
+        live_it[i] = np.asarray(r.samples_it[nit[i]:])[sl]
 
     def ptform(u):
         return np.array([prob.prior_transform(x) for x in u])
     m = ensemble.merge_static_runs(dead_l, nit, live_l, dead_u, live_u,
-                                   prior_transform=ptform,
-                                   ncall=[r.ncall.sum() for r in res])
+                                   prior_transform=ptform, dead_id=dead_i[0], dead_it=dead_i[1],
+                                   dead_nc=dead_i[2], live_it=live_it)
+    # the per-point bookkeeping _merge_two copies through (utils.py:2154-2156, 2196-2207)
+    np.testing.assert_array_equal(m.samples_id, ref.samples_id)
+    np.testing.assert_array_equal(m.samples_it, ref.samples_it)
+    np.testing.assert_array_equal(m.ncall, ref.ncall)
     assert m.niter == ref.niter
     np.testing.assert_array_equal(m.logl, ref.logl)
     np.testing.assert_array_equal(m.samples_n, ref.samples_n)

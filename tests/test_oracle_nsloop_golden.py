@@ -52,14 +52,34 @@ def test_whole_run_recurrence(g):
     nlive, nf = int(g["nlive"]), int(g["nfills"])
     s = R.RunState(nlive)
     live = g["fills/live_logl0"].copy()
-    dead = []
+    live_it = np.zeros(nlive, dtype=np.int64)
+    dead, ids, its, ncs = [], [], [], []
+    carry = 0
     for f in range(nf):
-        out = R.consume_queue(live, g["fills/q_logl"][f], g["fills/q_ncalls"][f], s, float(g["dlogz"]))
+        out = R.consume_queue(live, g["fills/q_logl"][f], g["fills/q_ncalls"][f], s, float(g["dlogz"]),
+                              live_it=live_it)
         dead.append(out["dead_logl"])
+        ids.append(out["dead_slot"])
+        its.append(out["dead_it"])
+        nc = out["dead_nc"].copy()
+        if len(nc):  # entries popped after the previous fill's last death belong to this fill's first
+            nc[0] += carry
+            carry = 0
+        carry += out["nc_carry"]
+        ncs.append(nc)
         assert out["stopped"] == (f == nf - 1)
     dead = np.concatenate(dead)
     niter = int(g["niter"])
     np.testing.assert_array_equal(dead, g["run/logl"][:niter])
+    # the reference's per-point id / it / nc (saved_run; what merge_runs carries as samples_id /
+    # samples_it / ncall): dead points, then the final live points (id = slot, nc = 1)
+    np.testing.assert_array_equal(np.concatenate(ids), g["run/id"][:niter])
+    np.testing.assert_array_equal(np.concatenate(its), g["run/it"][:niter])
+    np.testing.assert_array_equal(np.concatenate(ncs), g["run/nc"][:niter])
+    order = np.argsort(live)
+    np.testing.assert_array_equal(order, g["run/id"][niter:])
+    np.testing.assert_array_equal(live_it[order], g["run/it"][niter:])
+    assert (g["run/nc"][niter:] == 1).all()
     assert s.ncall + int(g["run/ncall_init"]) == int(g["run/ncall"])
     logz, logzvar, h = R.add_live_points(live, s)
     assert logz == float(g["rec/logz_final"])

@@ -542,6 +542,10 @@ def gen_nsloop(out):
          "nfills": np.int64(len(fills)), "niter": np.int64(niter),
          "run/logl": np.array(sr['logl'], dtype=np.float64),
          "run/logvol": np.array(sr['logvol'], dtype=np.float64),
+         # the per-point bookkeeping of saved_run (sampler.py:1165-1182, 870-890)
+         "run/id": np.array(s.saved_run['id'], dtype=np.int64),
+         "run/it": np.array(s.saved_run['it'], dtype=np.int64),
+         "run/nc": np.array(s.saved_run['nc'], dtype=np.int64),
          # every fill of the run, so that the whole loop can be replayed
          "fills/live_logl0": fills[0]["live_logl"],
          "fills/q_logl": np.array([f["q_logl"] for f in fills]),
