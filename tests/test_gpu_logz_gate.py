@@ -80,3 +80,7 @@ def test_c4_device_run_vs_reference_runs(ctx):
     assert abs(r.logz - ref_mean) < 3.0 * ref_err * math.sqrt(1.5), (r.logz, ref_mean)
     assert abs(r.logzerr - ref_err) < 0.01
     assert abs(r.niter / np.mean([x["niter"] for x in k1]) - 1) < 0.05
+    # and against the reference at the SAME queue size (SerialPool(1000)): one run against one run
+    for x in (q for q in ref["runs"] if q["K"] == 1000):
+        assert abs(r.logz - x["logz"]) < 3.0 * math.hypot(r.logzerr, x["logzerr"]), (r.logz, x["logz"])
+        assert abs(r.niter / x["niter"] - 1) < 0.06
