@@ -22,7 +22,6 @@ Semantics kept from the reference because they decide the statistics:
   * ln X decreases by ln((N+1)/N) per iteration; trapezoid weights; the final
     live points are appended (sampler.py:780-930).
 """
-import heapq
 import math
 
 import numpy as np
@@ -67,17 +66,6 @@ def _integrate(logl, logvol):
     """ln weights, cumulative ln Z, final information and final var[ln Z]."""
     logwt, logz, h, logzvar = _integrate_full(logl, logvol)
     return logwt, logz, float(h[-1]), float(logzvar[-1])
-
-
-def _logaddexp(x, y):
-    # np.logaddexp's formula on Python floats (a NumPy scalar call per iteration was a third of the
-    # host loop's time)
-    if x == y:
-        return x + 0.6931471805599453
-    d = x - y
-    if d > 0:
-        return x + math.log1p(math.exp(-d))
-    return y + math.log1p(math.exp(d))
 
 
 def run_static(prob, nlive=500, bound='multi', sample='rwalk', queue_size=None,
@@ -132,9 +120,7 @@ def run_static(prob, nlive=500, bound='multi', sample='rwalk', queue_size=None,
     dlv = math.log((nlive + 1.) / nlive)
     dead_u, dead_logl, dead_logvol = [], [], []
     dead_id, dead_it, dead_nc = [], [], []
-    live_it = np.zeros(nlive, dtype=np.int64)
     nc_acc = 0  # calls of the entries popped since the last death (sampler.py:1141: 'nc')
-    logz = -1.e300
     hist = dict(acc=0, rej=0, nexp=0, ncon=0)
 
     def rebuild():
@@ -204,13 +190,18 @@ def run_static(prob, nlive=500, bound='multi', sample='rwalk', queue_size=None,
         return out, start
 
     done = False
-    log_nlive = math.log(nlive)
-    # min-heap over (logl, slot): the worst live point in O(log N) per iteration
-    heap = [(float(l), i) for i, l in enumerate(live_logl)]
-    heapq.heapify(heap)
-    lmax = float(live_logl.max())
+    # The queue is consumed by the device operator dh_ns_consume (one workgroup: the loop of sampler.py:
+    # 1070-1195 over a whole fill with _new_point's queue rule, the dlogz criterion tested at every
+    # iteration); the host keeps the coordinates and applies the surviving replacements in bulk.
+    live_l2 = np.ascontiguousarray(live_logl, dtype=np.float64)[None, :]
+    live_logl = live_l2[0]
+    live_it2 = np.zeros((1, nlive), dtype=np.int32)
+    live_it = live_it2[0]
+    # logvol, logz, h, logzvar, loglstar of the last dead point, it, ncall, [out] current worst logl
+    state = np.array([[0., -1.e300, 0., 0., -1.e300, 0., float(nlive), 0.]])
+    loglstar = float(live_logl.min())
     while not done:
-        loglstar = heap[0][0]
+        it, ncall = int(state[0, 5]), int(state[0, 6])
         # bound-update policy, evaluated when the queue is empty
         eff = 100. * max(it, 1) / ncall
         if unit_cube:
@@ -222,56 +213,68 @@ def run_static(prob, nlive=500, bound='multi', sample='rwalk', queue_size=None,
             rebuild()
             ncall_last_update = ncall
         out, _ = fill(loglstar)
-        o_logl = out["logl"].tolist()
-        o_nc = [int(x) for x in out["ncalls"]]
-        for j in range(K):
-            ncall += o_nc[j]
-            nc_acc += o_nc[j]
-            cur, worst = heap[0]
-            if not o_logl[j] > cur:
-                continue  # stale proposal: discarded (sampler.py:774-776)
-            logvol -= dlv
-            dead_u.append(live_u[worst].copy())
-            dead_logl.append(cur)
-            dead_logvol.append(logvol)
-            dead_id.append(worst)
-            dead_it.append(live_it[worst])
-            dead_nc.append(nc_acc)
-            nc_acc = 0
-            live_it[worst] = it + 1  # self.it starts at 1 (sampler.py:396, 1182)
-            lw = cur + logvol  # coarse running evidence for the stop rule
-            logz = _logaddexp(logz, lw - log_nlive)
-            live_u[worst] = out["u"][j]
-            live_v[worst] = out["v"][j]
-            live_logl[worst] = o_logl[j]
-            heapq.heapreplace(heap, (o_logl[j], worst))
-            if o_logl[j] > lmax:
-                lmax = o_logl[j]
-            it += 1
-            if maxiter is not None and it >= maxiter:
+        q_logl = np.ascontiguousarray(out["logl"], dtype=np.float64)
+        q_nc = np.ascontiguousarray(out["ncalls"], dtype=np.int32)
+        pos = 0
+        while pos < K and not done:
+            # with maxiter a chunk can produce at most (maxiter - it) deaths: deaths <= entries popped
+            # chunks of <= 512 entries keep the operator's LDS footprint independent of K
+            n = min(K - pos, 512)
+            if maxiter is not None:
+                n = min(n, maxiter - int(state[0, 5]))
+            res = be.ns_consume(live_l2, q_logl[None, pos:pos + n], q_nc[None, pos:pos + n], state, dlogz,
+                                live_it=live_it2)
+            slots, srcs = res["dead_slot"][0].astype(np.int64), res["dead_src"][0].astype(np.int64) + pos
+            ndead = len(slots)
+            if ndead:
+                # what lived in the slot when it died: the replacement of the previous death of the same
+                # slot within this chunk, else the live point from before
+                order = np.argsort(slots, kind="stable")
+                same = slots[order][1:] == slots[order][:-1]
+                prev = np.full(ndead, -1, dtype=np.int64)
+                prev[order[1:][same]] = srcs[order[:-1][same]]
+                du = np.where((prev < 0)[:, None], live_u[slots], out["u"][np.maximum(prev, 0)])
+                dead_u.append(du)
+                dead_logl.append(res["dead_logl"][0])
+                dead_id.append(slots)
+                dead_it.append(res["dead_it"][0].astype(np.int64))
+                nc = res["dead_nc"][0].astype(np.int64)
+                nc[0] += nc_acc
+                dead_nc.append(nc)
+                # surviving replacement of every slot = the one of its LAST death
+                last = np.ones(ndead, dtype=bool)
+                last[order[:-1][same]] = False
+                live_u[slots[last]] = out["u"][srcs[last]]
+                live_v[slots[last]] = out["v"][srcs[last]]
+                nc_acc = int(q_nc[srcs[-1] + 1:pos + n].sum())  # entries popped after the last death
+            else:
+                nc_acc += int(q_nc[pos:pos + n].sum())
+            pos += n
+            if res["stopped"][0] or (maxiter is not None and int(state[0, 5]) >= maxiter):
                 done = True
-                break
-            if it % 64 == 0 or j == K - 1:
-                dz = _logaddexp(0., lmax + logvol - logz)
-                if dz < dlogz:
-                    done = True
-                    break
+        loglstar = float(state[0, 7])
         if verbose:
-            print(f"it={it} ncall={ncall} logz~{logz:.3f} nbound={nbound} "
+            print(f"it={int(state[0, 5])} ncall={int(state[0, 6])} logz~{state[0, 1]:.3f} nbound={nbound} "
                   f"scale={scale:.3f}")
+    it, ncall = int(state[0, 5]), int(state[0, 6])
+    logvol = -it * dlv
+    dead_u = np.concatenate(dead_u) if dead_u else np.zeros((0, nd))
+    dead_logl = np.concatenate(dead_logl) if dead_logl else np.zeros(0)
+    dead_logvol = -dlv * np.arange(1, it + 1)
+    dead_id, dead_it, dead_nc = (np.concatenate(x) if x else np.zeros(0, dtype=np.int64)
+                                 for x in (dead_id, dead_it, dead_nc))
     # ---- add the remaining live points (sampler.py:780-930) ----
     order = np.argsort(live_logl)
     lv_live = logvol + np.log(1. - (np.arange(nlive) + 1.) / (nlive + 1.))
     all_logl = np.concatenate([dead_logl, live_logl[order]])
     all_logvol = np.concatenate([dead_logvol, lv_live])
-    all_u = np.concatenate([np.array(dead_u).reshape(-1, nd), live_u[order]])
+    all_u = np.concatenate([dead_u.reshape(-1, nd), live_u[order]])
     logwt, logz_arr, h, logzvar = _integrate(all_logl, all_logvol)
     return RunResult(logz=float(logz_arr[-1]),
                      logzerr=math.sqrt(logzvar), niter=it,
                      ncall=ncall, h=h, nbound=nbound, samples_u=all_u,
                      samples_logl=all_logl, logwt=logwt, scale=scale,
                      eff=100. * it / ncall,
-                     samples_id=np.concatenate([np.array(dead_id, dtype=np.int64), order]),
-                     samples_it=np.concatenate([np.array(dead_it, dtype=np.int64), live_it[order]]),
-                     samples_nc=np.concatenate([np.array(dead_nc, dtype=np.int64),
-                                                np.ones(nlive, dtype=np.int64)]))
+                     samples_id=np.concatenate([dead_id, order]),
+                     samples_it=np.concatenate([dead_it, live_it[order].astype(np.int64)]),
+                     samples_nc=np.concatenate([dead_nc, np.ones(nlive, dtype=np.int64)]))

@@ -73,6 +73,28 @@ class OracleBackend:
             out[i] = _words(np.random.Generator(np.random.PCG64(c)))
         return out
 
+    def ns_consume(self, live_logl, q_logl, q_ncalls, state, dlogz, live_it=None):
+        """dh_ns_consume through the oracle's restatement of the reference loop (no plateau steps, as on
+        the device)."""
+        from oracle import nested_ref as R
+        out = dict(dead_logl=[], dead_slot=[], dead_src=[], dead_it=[], dead_nc=[], stopped=[])
+        for r in range(live_logl.shape[0]):
+            s = R.RunState(live_logl.shape[1])
+            s.logvol, s.logz, s.h, s.logzvar, s.loglstar = (float(x) for x in state[r, :5])
+            s.it, s.ncall = int(state[r, 5]), int(state[r, 6])
+            it = None if live_it is None else live_it[r].astype(np.int64)
+            res = R.consume_queue(live_logl[r], np.asarray(q_logl)[r], np.asarray(q_ncalls)[r], s, dlogz,
+                                  plateau=False, live_it=it)
+            if live_it is not None:
+                live_it[r] = it
+            state[r, :7] = [s.logvol, s.logz, s.h, s.logzvar, s.loglstar, s.it, s.ncall]
+            state[r, 7] = live_logl[r].min()
+            for k in ("dead_logl", "dead_slot", "dead_src", "dead_it", "dead_nc"):
+                out[k].append(res[k])
+            out["stopped"].append(res["stopped"])
+        out["stopped"] = np.array(out["stopped"], dtype=bool)
+        return out
+
     def problem_eval(self, prob, u):
         u = np.asarray(u, dtype=np.float64).reshape(-1, prob.ndim)
         v = prob.prior_transform_many(u)
