@@ -83,7 +83,9 @@ struct RebuildArgs {
   // ("parts"), each keeping its TP points resident in LDS for all ten iterations
   int fin_extra_off;  // k_finish: byte offset of the LDS node/result-list copies (0: keep them in global memory)
   int fin_res_lds;    // 1: the result-list arena is in LDS too
-  int maxp;           // max parts of one run at one level: n / TP + maxw + 1
+  int tpe;            // points per tile of k_ell<false> (cov / fmax passes of the tree nodes)
+  int tps;            // points per k-means part (the tile k_split keeps resident); a node of c points has ceil(c / tps) parts
+  int maxp;           // max parts of one run at one level: n / tps + maxw + 1
   int* nparts;        // (levels+1) x runs
   int* part_list;     // 2 x runs x maxp x 2   (by level parity): (slot in split_list, part index)
   int* part_base;     // 2 x runs x maxw       first part slot of the node in split_list slot
@@ -1359,6 +1361,7 @@ __device__ __forceinline__ double logaddexp_d(double x, double y) {
 constexpr size_t kLdsLimit = 159 * 1024;
 // separate Jacobi buffers only while two workgroups still fit one CU's 160 KB
 constexpr size_t kLdsSeparate = 79 * 1024;
+constexpr size_t kLdsSeparate3 = 53 * 1024;  // ... while THREE still fit (kernels on a smaller tile)
 __host__ __device__ inline size_t rebuild_lds_base_bytes(int D, int TP) {
   const int LD = D | 1;
   const size_t dbl = (size_t)TP * LD + 4 * (size_t)D * LD + 7 * (size_t)D + 2 + kThreads + 128;
@@ -1409,12 +1412,54 @@ __device__ __forceinline__ void carve(Lds& L, unsigned char* smem, int D, int TP
   const int P = (D + 1) & ~1;
   L.JLD = P | 1;
   const size_t jdbl = 4 * (size_t)P * L.JLD;
-  L.j_alias = rebuild_lds_base_bytes(D, TP) + jdbl * 8 > kLdsSeparate;
+  L.j_alias = rebuild_lds_base_bytes(D, TP) + jdbl * 8 > (TP < kThreads ? kLdsSeparate3 : kLdsSeparate);
   double* jb = L.j_alias ? L.tile : (double*)(smem + rebuild_lds_base_bytes(D, TP));
   L.JA[0] = jb;
   L.JA[1] = jb + (size_t)P * L.JLD;
   L.JV[0] = jb + 2 * (size_t)P * L.JLD;
   L.JV[1] = jb + 3 * (size_t)P * L.JLD;
+}
+
+// k_split's own, smaller layout: the resident tile of tps points and what the k-means touches (scale, centroids,
+// sums, the partial-sum scratch, the integer scratch) -- 31 KB at D = 25, tps = 128, so that five workgroups share a
+// CU.  (With the common layout's 77 KB two did, and a level of the 64-run bench rebuild has 512-1 000 busy parts:
+// every level took two rounds of workgroups, 135 us instead of the 65-70 us it takes alone.)
+__host__ __device__ inline size_t split_lds_bytes(int D, int TP) {
+  const int LD = D | 1;
+  return ((((size_t)TP * LD + 5 * (size_t)D + 2 + kThreads + 128) * 8 + (320 + (size_t)D + 8) * 4) + 15) & ~(size_t)15;
+}
+
+__device__ __forceinline__ void carve_split(Lds& L, unsigned char* smem, int D, int TP) {
+  L.LD = D | 1;
+  L.TP = TP;
+  L.c_pts = nullptr;
+  L.c_start = L.c_cnt = L.c_how = -1;
+  L.DP = 1;
+  L.DPlog = 0;
+  while (L.DP < D) {
+    L.DP <<= 1;
+    ++L.DPlog;
+  }
+  double* p = (double*)smem;
+  L.tile = p;
+  p += (size_t)TP * L.LD;
+  L.scale = p;
+  p += D;
+  L.cen = p;
+  p += 2 * D;
+  L.sums = p;
+  p += 2 * D + 2;
+  L.red = p;
+  L.rc = p + kThreads;
+  L.rs = L.rc + 64;
+  L.kred = L.red;
+  p += kThreads + 128;
+  L.ri = (int*)p;
+  L.perm_sort = L.ri + 320;
+  L.A = L.V = L.AM = L.AX = L.mean = L.lam = nullptr;
+  L.JA[0] = L.JA[1] = L.JV[0] = L.JV[1] = nullptr;
+  L.JLD = 0;
+  L.j_alias = false;
 }
 
 struct RunView {
@@ -1449,10 +1494,10 @@ __device__ __forceinline__ void set_status(const RebuildArgs& a, int run, int rc
 }
 
 // queue `node` (count points) for splitting at `level`: one split_list slot + its parts
-__device__ __forceinline__ void queue_split(const RebuildArgs& a, int run, int level, int node, int count, int TP) {
+__device__ __forceinline__ void queue_split(const RebuildArgs& a, int run, int level, int node, int count) {
   const size_t lp = (size_t)(level & 1) * a.runs + run;
   const int sidx = atomicAdd(&a.nsplit[(size_t)level * a.runs + run], 1);
-  const int np = (count + TP - 1) / TP;
+  const int np = (count + a.tps - 1) / a.tps;
   const int pb = atomicAdd(&a.nparts[(size_t)level * a.runs + run], np);
   if (sidx >= a.maxw || pb + np > a.maxp) {
     atomicMin(&a.status[run], DH_ERR_NOMEM);
@@ -1696,7 +1741,7 @@ __global__ void __launch_bounds__(kThreads) k_root_parts(RebuildArgs a, int rp) 
       }
       if (q == 0) {
         if (t < D) a.scale_g[(size_t)run * D + t] = L.scale[t];
-        if (t == 0 && status == DH_OK) queue_split(a, run, 0, 0, n, kThreads);
+        if (t == 0 && status == DH_OK) queue_split(a, run, 0, 0, n);
       }
     }
   }
@@ -1727,7 +1772,7 @@ __global__ void __launch_bounds__(kThreads) k_root_parts(RebuildArgs a, int rp) 
       const double sj = L.scale[jj];
       for (int p = p0; p < n; p += pstep) ps[(size_t)p * D + jj] = v.pts[(size_t)p * D + jj] / sj;
     }
-    if (t == 0) queue_split(a, run, 0, 0, n, kThreads);
+    if (t == 0) queue_split(a, run, 0, 0, n);
   }
 }
 
@@ -1740,7 +1785,7 @@ __global__ void __launch_bounds__(kThreads) k_split(RebuildArgs a, int level) {
   if (a.status[run] != DH_OK) return;
   const int D = a.d, t = threadIdx.x;
   Lds L;
-  carve(L, smem, D);
+  carve_split(L, smem, D, a.tps);
   const RunView v = view_of(a, run, L.LD);
   if (t < D) L.scale[t] = a.scale_g[(size_t)run * D + t];
   __syncthreads();
@@ -1815,7 +1860,10 @@ __global__ void __launch_bounds__(kThreads) k_split(RebuildArgs a, int level) {
 // SLOW = true: the reference's route for every node -- the kernel of the diagnostic mode
 // DH_REBUILD_FAST=0.  Two kernels so that the common one stays small (registers: two workgroups per CU).
 template <bool SLOW>
-__global__ void __launch_bounds__(kThreads, SLOW ? 1 : 2) k_ell(RebuildArgs a, int level, int G) {
+#ifndef DH_ELL_OCC
+#define DH_ELL_OCC 2
+#endif
+__global__ void __launch_bounds__(kThreads, SLOW ? 1 : DH_ELL_OCC) k_ell(RebuildArgs a, int level, int G) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int run = blockIdx.x / G, g = blockIdx.x % G;
   const int* list = a.ell_list + (size_t)run * 2 * a.maxw;
@@ -1828,7 +1876,7 @@ __global__ void __launch_bounds__(kThreads, SLOW ? 1 : 2) k_ell(RebuildArgs a, i
   if (a.status[run] != DH_OK) return;
   const int D = a.d, t = threadIdx.x;
   Lds L;
-  carve(L, smem, D);
+  carve(L, smem, D, SLOW ? kThreads : a.tpe);
   const RunView v = view_of(a, run, L.LD);
   for (int slot = g; slot < cnt; slot += G) {
     const int node = list[slot];
@@ -1852,7 +1900,7 @@ __global__ void __launch_bounds__(kThreads, SLOW ? 1 : 2) k_ell(RebuildArgs a, i
         if (level + 1 >= a.levels) {
           atomicMin(&a.status[run], DH_ERR_NOMEM);  // deeper than the launch plan
         } else {
-          queue_split(a, run, level + 1, node, count, kThreads);
+          queue_split(a, run, level + 1, node, count);
         }
       }
     }
@@ -2337,7 +2385,7 @@ size_t rebuild_lds_bytes(int D, int TP = kThreads) {
   const size_t base = rebuild_lds_base_bytes(D, TP);
   const int P = (D + 1) & ~1;
   const size_t jb = 4 * (size_t)P * (P | 1) * 8;
-  return base + jb > kLdsSeparate ? base : base + jb;  // else the Jacobi buffers overlay the tile
+  return base + jb > (TP < kThreads ? kLdsSeparate3 : kLdsSeparate) ? base : base + jb;  // else the Jacobi buffers overlay the tile
 }
 
 }  // namespace
@@ -2431,7 +2479,20 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
   int lv = 4;
   while ((1 << lv) < n / (2 * d) + 1) ++lv;
   a.levels = mode == 1 ? 0 : (2 * lv + 8);
-  a.maxp = n / kThreads + a.maxw + 1;
+  // 128 points per k-means part: five k_split workgroups per CU (see carve_split); DH_SPLIT_TP overrides (64 .. 256)
+  a.tps = 128;
+  if (const char* e = getenv("DH_SPLIT_TP")) {
+    const int v = atoi(e);
+    if (v == 64 || v == 128 || v == 192 || v == 256) a.tps = v;
+  }
+  a.maxp = n / a.tps + a.maxw + 1;
+  const size_t lds_split = split_lds_bytes(d, a.tps);
+  a.tpe = kThreads;
+  if (const char* e = getenv("DH_ELL_TP")) {
+    const int v = atoi(e);
+    if (v == 64 || v == 128 || v == 192 || v == 256) a.tpe = v;
+  }
+  const size_t lds_ell = rebuild_lds_bytes(d, a.tpe);
   // the parts of one node meet at a device-scope barrier, so they must all be resident at the
   // same time: 256 parts (65 536 points per run) fit the 256 CUs with room to spare
   if (mode == 0 && n > 256 * kThreads)
@@ -2475,16 +2536,16 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
     (void)hipFuncSetAttribute((const void*)k_split, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_root, (const void*)k_root_parts, kThreads, lds) != hipSuccess)
       occ_root = 1;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_split, (const void*)k_split, kThreads, lds) != hipSuccess)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_split, (const void*)k_split, kThreads, lds_split) != hipSuccess)
       occ_split = 1;
     cap_root = ncu * (occ_root > 0 ? occ_root : 1);
     cap_split = ncu * (occ_split > 0 ? occ_split : 1);
   }
   int rp = n > 1 ? (n + kThreads - 1) / kThreads : 1;
   if ((long long)runs * rp > cap_root) rp = 1;
-  if (mode == 0 && (n + kThreads - 1) / kThreads > cap_split)
+  if (mode == 0 && (n + a.tps - 1) / a.tps > cap_split)
     return fail(ctx, DH_ERR_ARG, "rebuild: the %d parts of a %d-point node exceed the %d co-resident workgroups of k_split",
-                (n + kThreads - 1) / kThreads, n, cap_split);
+                (n + a.tps - 1) / a.tps, n, cap_split);
   if (getenv("DH_ROOT_PARTS") && atoi(getenv("DH_ROOT_PARTS")) == 0) rp = 1;  // diagnostic
   // zeroed counters: nnodes | nsplit (levels+1) | nell (levels) | nparts (levels+1) | kerr | rbar | kbar (levels x maxw)
   const size_t b_cnt = (size_t)runs * ((size_t)3 * a.levels + 5 + kBarStride + (size_t)a.levels * a.maxw * kBarStride) * 4;
@@ -2615,9 +2676,9 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
     a.root_eig = nullptr;
   }
   for (int L = 0; L < a.levels; ++L) {
-    hipLaunchKernelGGL(k_split, dim3(runs * a.maxp), dim3(kThreads), lds, ctx->stream, a, L);
+    hipLaunchKernelGGL(k_split, dim3(runs * a.maxp), dim3(kThreads), lds_split, ctx->stream, a, L);
     if (a.fast)
-      hipLaunchKernelGGL(k_ell<false>, dim3(runs * 2 * a.maxw), dim3(kThreads), lds, ctx->stream, a, L, 2 * a.maxw);
+      hipLaunchKernelGGL(k_ell<false>, dim3(runs * 2 * a.maxw), dim3(kThreads), lds_ell, ctx->stream, a, L, 2 * a.maxw);
     else
       hipLaunchKernelGGL(k_ell<true>, dim3(runs * 2 * a.maxw), dim3(kThreads), lds, ctx->stream, a, L, 2 * a.maxw);
   }
