@@ -142,6 +142,7 @@ struct Lds {
   int* ri;        // 256 ints (pair indices, scan scratch, ...)
   int* perm_sort; // D
   int TP, LD, DP, DPlog;
+  int KG;         // waves per partial-sum group of the k-means (the whole workgroup unless a bigger tile stands in for parts)
   double* JA[2];  // Jacobi work buffers, P x JLD (P = D rounded up to even)
   double* JV[2];
   int JLD;
@@ -1253,8 +1254,14 @@ __device__ int node_kmeans_part(const Lds& L, const double* pts, int* perm, int*
     double* kp = (it & 1) ? kp1 : kp0;
     if (t < 2 * D) {
       const int c = t >= D ? 1 : 0, j = t - c * D;
+      // (grouped like the parts of the level kernels when one 256-point tile stands in for two 128-point
+      // parts -- k_deep -- so that a node's sums do not depend on which kernel worked on it)
       double sum = 0.0;
-      for (int wv = 0; wv < kThreads / 64; ++wv) sum += L.kred[(wv * 2 + c) * 48 + j];
+      for (int g0 = 0; g0 < kThreads / 64; g0 += L.KG) {
+        double gs = 0.0;
+        for (int wv = g0; wv < g0 + L.KG; ++wv) gs += L.kred[(wv * 2 + c) * 48 + j];
+        sum += gs;
+      }
       if (np > 1) st_agent(kp + (size_t)q * KP + c * D + j, sum);
       L.sums[c * D + j] = sum;
     }
@@ -1373,6 +1380,7 @@ __device__ __forceinline__ void carve(Lds& L, unsigned char* smem, int D, int TP
   L.TP = TP;
   L.c_pts = nullptr;
   L.c_start = L.c_cnt = L.c_how = -1;
+  L.KG = kThreads / 64;
   L.DP = 1;
   L.DPlog = 0;
   while (L.DP < D) {
@@ -1434,6 +1442,7 @@ __device__ __forceinline__ void carve_split(Lds& L, unsigned char* smem, int D, 
   L.TP = TP;
   L.c_pts = nullptr;
   L.c_start = L.c_cnt = L.c_how = -1;
+  L.KG = kThreads / 64;
   L.DP = 1;
   L.DPlog = 0;
   while (L.DP < D) {
@@ -1776,25 +1785,17 @@ __global__ void __launch_bounds__(kThreads) k_root_parts(RebuildArgs a, int rp) 
   }
 }
 
-__global__ void __launch_bounds__(kThreads) k_split(RebuildArgs a, int level) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int run = blockIdx.x / a.maxp, ps = blockIdx.x % a.maxp;
-  if (ps >= a.nparts[(size_t)level * a.runs + run]) return;
-  // status is only written by the other kernels of the pipeline (errors of THIS kernel go
-  // to kerr): all parts of a node take the same decision here
-  if (a.status[run] != DH_OK) return;
+// One part of one splittable node: k-means + partition (node_kmeans_part), and by part 0 the two child records and
+// their means.  single = true (k_deep): the calling workgroup is the node's only part whatever its size -- the node
+// must fit the tile (count <= L.TP).
+__device__ __forceinline__ void split_body(const RebuildArgs& a, const Lds& L, const RunView& v, int run, int level, int slot, int q,
+                           bool single) {
   const int D = a.d, t = threadIdx.x;
-  Lds L;
-  carve_split(L, smem, D, a.tps);
-  const RunView v = view_of(a, run, L.LD);
-  if (t < D) L.scale[t] = a.scale_g[(size_t)run * D + t];
-  __syncthreads();
   const size_t lp = (size_t)(level & 1) * a.runs + run;
-  const int slot = a.part_list[(lp * a.maxp + ps) * 2], q = a.part_list[(lp * a.maxp + ps) * 2 + 1];
   const int pb = a.part_base[lp * a.maxw + slot];
   const int cur = a.split_list[lp * a.maxw + slot];
   const int start = v.nodes[cur].start, count = v.nodes[cur].count, depth = v.nodes[cur].depth;
-  const int np = (count + L.TP - 1) / L.TP;
+  const int np = single ? 1 : (count + L.TP - 1) / L.TP;
   const int min_size = 2 * D;
   const int KP = 2 * D + 2;
   double* kp0 = a.kpart + ((size_t)run * a.maxp + pb) * KP;
@@ -1856,6 +1857,56 @@ __global__ void __launch_bounds__(kThreads) k_split(RebuildArgs a, int level) {
   }
 }
 
+__global__ void __launch_bounds__(kThreads) k_split(RebuildArgs a, int level) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int run = blockIdx.x / a.maxp, ps = blockIdx.x % a.maxp;
+  if (ps >= a.nparts[(size_t)level * a.runs + run]) return;
+  // status is only written by the other kernels of the pipeline (errors of THIS kernel go
+  // to kerr): all parts of a node take the same decision here
+  if (a.status[run] != DH_OK) return;
+  const int D = a.d, t = threadIdx.x;
+  Lds L;
+  carve_split(L, smem, D, a.tps);
+  const RunView v = view_of(a, run, L.LD);
+  if (t < D) L.scale[t] = a.scale_g[(size_t)run * D + t];
+  __syncthreads();
+  const size_t lp = (size_t)(level & 1) * a.runs + run;
+  const int slot = a.part_list[(lp * a.maxp + ps) * 2], q = a.part_list[(lp * a.maxp + ps) * 2 + 1];
+  split_body(a, L, v, run, level, slot, q, false);
+}
+
+// The bounding ellipsoid of one new child and, if it is big enough, its entry in the next level's split list.
+// Returns false after an error (status set).
+template <bool SLOW>
+__device__ __forceinline__ bool ell_body(const RebuildArgs& a, const Lds& L, const RunView& v, int run, int level, int node) {
+  const int D = a.d, t = threadIdx.x;
+  const int start = v.nodes[node].start, count = v.nodes[node].count;
+  double lv = 0.0, fmx = INFINITY;
+  __syncthreads();
+  L.c_pts = nullptr;
+  const int rc = node_ellipsoid<!SLOW>(L, a, v.pts, v.perm, start, count, v.estore + (size_t)node * v.NS,
+                                       v.estore + (size_t)node * v.NS + v.ES, &lv, &fmx,
+                                       v.nodes[node].has_mean != 0);
+  const bool full = SLOW || rc == kFullRecord;
+  if (rc != DH_OK && rc != kFullRecord) {
+    set_status(a, run, rc);
+    return false;
+  }
+  if (t == 0) {
+    v.nodes[node].logvol = lv;
+    v.nodes[node].fmax = fmx;
+    v.nodes[node].fast = full ? 0 : 1;
+    if (count >= 4 * D) {  // big enough to try a split at the next level (:1492-1496)
+      if (level + 1 >= a.levels) {
+        atomicMin(&a.status[run], DH_ERR_NOMEM);  // deeper than the launch plan
+      } else {
+        queue_split(a, run, level + 1, node, count);
+      }
+    }
+  }
+  return true;
+}
+
 // One workgroup per new child.  SLOW = false: the eigen-free path (with its in-place fallback);
 // SLOW = true: the reference's route for every node -- the kernel of the diagnostic mode
 // DH_REBUILD_FAST=0.  Two kernels so that the common one stays small (registers: two workgroups per CU).
@@ -1874,36 +1925,65 @@ __global__ void __launch_bounds__(kThreads, SLOW ? 1 : DH_ELL_OCC) k_ell(Rebuild
     return;
   }
   if (a.status[run] != DH_OK) return;
-  const int D = a.d, t = threadIdx.x;
+  const int D = a.d;
   Lds L;
   carve(L, smem, D, SLOW ? kThreads : a.tpe);
   const RunView v = view_of(a, run, L.LD);
-  for (int slot = g; slot < cnt; slot += G) {
-    const int node = list[slot];
-    const int start = v.nodes[node].start, count = v.nodes[node].count;
-    double lv = 0.0, fmx = INFINITY;
+  for (int slot = g; slot < cnt; slot += G)
+    if (!ell_body<SLOW>(a, L, v, run, level, list[slot])) return;
+}
+
+// ---- the deep tail of the tree: one workgroup per run, every remaining level ------------------------------
+// The level kernels are launched for the first `first_level` levels (a balanced tree's depth plus two); a tree
+// that is deeper -- unbalanced splits -- is rare, but the launch plan cannot know, and an idle pair of level
+// launches costs 9 us (round 2 measured 14 idle pairs of 20 on the bench shard: 0.13 ms of a 1.6 ms rebuild).
+// This kernel takes whatever the last launched level has queued and works the rest of the run's tree off
+// serially, level by level, with the same node routines (a node = one part: it must fit the 256-point tile,
+// else the run fails loudly as a too-deep tree did before).  In the common case it finds an empty list and exits.
+__global__ void __launch_bounds__(kThreads) k_deep(RebuildArgs a, int first_level) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int run = blockIdx.x, t = threadIdx.x, D = a.d;
+  if (a.nsplit[(size_t)first_level * a.runs + run] == 0) return;
+  __shared__ int go;
+  Lds L;
+  carve(L, smem, D);
+  L.KG = a.tps >= 64 && a.tps <= kThreads ? a.tps / 64 : kThreads / 64;
+  const RunView v = view_of(a, run, L.LD);
+  for (int level = first_level; level < a.levels; ++level) {
+    // (same-workgroup producer / consumer through global memory: ordered by the barriers)
     __syncthreads();
-    L.c_pts = nullptr;
-    const int rc = node_ellipsoid<!SLOW>(L, a, v.pts, v.perm, start, count, v.estore + (size_t)node * v.NS,
-                                         v.estore + (size_t)node * v.NS + v.ES, &lv, &fmx,
-                                         v.nodes[node].has_mean != 0);
-    const bool full = SLOW || rc == kFullRecord;
-    if (rc != DH_OK && rc != kFullRecord) {
-      set_status(a, run, rc);
+    if (t == 0) {
+      int ok = a.status[run] == DH_OK ? a.nsplit[(size_t)level * a.runs + run] : 0;
+      if (ok > a.maxw) ok = 0;  // queue_split has raised DH_ERR_NOMEM
+      go = ok;
+    }
+    __syncthreads();
+    const int ns = go;
+    if (ns == 0) return;
+    const size_t lp = (size_t)(level & 1) * a.runs + run;
+    for (int slot = 0; slot < ns; ++slot) {
+      __syncthreads();
+      const int cur = a.split_list[lp * a.maxw + slot];
+      if (v.nodes[cur].count > L.TP) {
+        if (t == 0) atomicMin(&a.status[run], DH_ERR_NOMEM);  // a big node this deep: beyond the launch plan
+        return;
+      }
+      if (t < D) L.scale[t] = a.scale_g[(size_t)run * D + t];
+      L.c_pts = nullptr;
+      __syncthreads();
+      split_body(a, L, v, run, level, slot, 0, true);
+    }
+    __syncthreads();
+    if (t == 0) go = a.kerr[run] != DH_OK ? -1 : a.nell[(size_t)level * a.runs + run];
+    __syncthreads();
+    const int ne = go;
+    if (ne < 0) {
+      if (t == 0) atomicMin(&a.status[run], a.kerr[run]);
       return;
     }
-    if (t == 0) {
-      v.nodes[node].logvol = lv;
-      v.nodes[node].fmax = fmx;
-      v.nodes[node].fast = full ? 0 : 1;
-      if (count >= 4 * D) {  // big enough to try a split at the next level (:1492-1496)
-        if (level + 1 >= a.levels) {
-          atomicMin(&a.status[run], DH_ERR_NOMEM);  // deeper than the launch plan
-        } else {
-          queue_split(a, run, level + 1, node, count);
-        }
-      }
-    }
+    const int* list = a.ell_list + (size_t)run * 2 * a.maxw;
+    for (int e = 0; e < ne; ++e)
+      if (!ell_body<false>(a, L, v, run, level, list[e])) return;
   }
 }
 
@@ -2474,8 +2554,8 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
   const size_t b_es = (size_t)runs * a.max_nodes * NS * 8;
   const size_t b_res = (size_t)runs * a.reslist_cap * 4;
   a.maxw = n / (4 * d) + 1;
-  // depth: a balanced tree needs log2(n / 2d) levels; unbalanced splits need more.
-  // Idle level launches cost ~2 us each, a run that is deeper still fails loudly.
+  // depth: a balanced tree needs log2(n / 2d) levels; unbalanced splits need more.  The level kernels are launched
+  // for lv + 2 levels, k_deep takes the rest (up to a.levels: a run that is deeper still fails loudly).
   int lv = 4;
   while ((1 << lv) < n / (2 * d) + 1) ++lv;
   a.levels = mode == 1 ? 0 : (2 * lv + 8);
@@ -2641,8 +2721,9 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
   a.n_arr = n_arr;
   DH_DEV_MEMO(attr_lds);
   if (lds > attr_lds) {
-    const void* ks[6] = {(const void*)k_root_parts, (const void*)k_split, (const void*)k_ell<false>,
-                         (const void*)k_ell<true>, (const void*)k_out_eig, (const void*)k_root_eig};
+    const void* ks[7] = {(const void*)k_root_parts, (const void*)k_split, (const void*)k_ell<false>,
+                         (const void*)k_ell<true>, (const void*)k_out_eig, (const void*)k_root_eig,
+                         (const void*)k_deep};
     for (const void* kf : ks)
       if (!hip_ok(ctx, hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
                   "hipFuncSetAttribute(rebuild LDS)"))
@@ -2675,13 +2756,22 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
   } else {
     a.root_eig = nullptr;
   }
-  for (int L = 0; L < a.levels; ++L) {
+  // level kernels for a balanced tree's depth plus two; k_deep works off whatever is deeper (DH_DEEP=0: all levels
+  // by level kernels, as before; the diagnostic slow mode keeps them too)
+  int nlev = a.levels;
+  if (a.fast && !(getenv("DH_DEEP") && atoi(getenv("DH_DEEP")) == 0)) nlev = a.levels < lv + 2 ? a.levels : lv + 2;
+  if (a.fast && getenv("DH_DEEP_FROM")) {  // diagnostic: hand the tree to k_deep from this level on
+    const int f = atoi(getenv("DH_DEEP_FROM"));
+    if (f >= 1 && f < a.levels) nlev = f;
+  }
+  for (int L = 0; L < nlev; ++L) {
     hipLaunchKernelGGL(k_split, dim3(runs * a.maxp), dim3(kThreads), lds_split, ctx->stream, a, L);
     if (a.fast)
       hipLaunchKernelGGL(k_ell<false>, dim3(runs * 2 * a.maxw), dim3(kThreads), lds_ell, ctx->stream, a, L, 2 * a.maxw);
     else
       hipLaunchKernelGGL(k_ell<true>, dim3(runs * 2 * a.maxw), dim3(kThreads), lds, ctx->stream, a, L, 2 * a.maxw);
   }
+  if (nlev < a.levels) hipLaunchKernelGGL(k_deep, dim3(runs), dim3(kThreads), lds, ctx->stream, a, nlev);
   if (forked && !hip_ok(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0), "hipStreamWaitEvent(join)")) return DH_ERR_HIP;
   hipLaunchKernelGGL(k_finish, dim3(runs), dim3(kThreads), lds_fin, ctx->stream, a);
   if (a.fast) {

@@ -166,3 +166,37 @@ def test_cooperative_root_threshold_follows_the_occupancy(ctx):
         assert a["nells"] == b["nells"]
         for k in FIELDS:
             np.testing.assert_array_equal(a[k], b[k])
+
+
+def test_deep_tail_kernel_equals_the_level_kernels(ctx):
+    """The level kernels are launched for a balanced tree's depth + 2; whatever is deeper is worked off by k_deep
+    (one workgroup per run, serially).  Forced to take over early (DH_DEEP_FROM) it must give bit-identical results
+    to the level kernels (DH_DEEP=0), and a node that does not fit its tile must fail loudly, not silently."""
+    import os
+    # (cloud, levels from which every node has at most 256 points)
+    cases = [(inputs.cloud("c2"), ("4", "6")), (inputs.cloud("c3"), ("6", "9")), (inputs.cloud("two5"), ("3", "5")),
+             (inputs.cloud("ring2"), ("5", "7"))]
+
+    def run(pts, env):
+        old = {k: os.environ.get(k) for k in ("DH_DEEP", "DH_DEEP_FROM")}
+        os.environ.update(env)
+        try:
+            return ctx.rebuild(pts, multi=True, want_labels=True)
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+    deep_trees = 0
+    for pts, firsts in cases:
+        ref = run(pts, {"DH_DEEP": "0"})
+        deep_trees += ref["nells"] > 4
+        for env in [{"DH_DEEP_FROM": f} for f in firsts] + [{}]:
+            got = run(pts, env)
+            assert ref["nells"] == got["nells"] and ref["nnodes"] == got["nnodes"], env
+            for k in FIELDS + ("labels",):
+                np.testing.assert_array_equal(ref[k], got[k])
+    assert deep_trees >= 2
+    with pytest.raises(RuntimeError):
+        run(inputs.cloud("c2"), {"DH_DEEP_FROM": "1"})  # 1000-point nodes at level 1 do not fit k_deep's 256-point tile
