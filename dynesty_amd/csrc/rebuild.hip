@@ -1141,10 +1141,19 @@ __device__ __forceinline__ int node_ellipsoid(const Lds& L, const RebuildArgs& a
 // No cache-wide release/acquire fences (an agent-scope fence writes back / invalidates the
 // whole XCD L2, and with hundreds of parts doing that 11 times each the L2 never holds
 // anything): everything the parts exchange is written with agent-scope stores (write-through)
-// and read with agent-scope loads (bypass), so the barrier only has to order, not to flush --
-// __syncthreads() drains every wave's stores (s_waitcnt vmcnt(0)) before thread 0 arrives.
+// and read with agent-scope loads (bypass), so the barrier only has to order, not to flush.
+// Ordering needs every wave's stores ACKNOWLEDGED before thread 0 announces the arrival: s_barrier alone
+// does not wait for them (the compiler emits `s_waitcnt lgkmcnt(0); s_barrier` for __syncthreads(); a
+// store still in flight to another L2 channel can land after the counter's atomic and a partner then
+// reads the previous iteration's partial -- seen as 3 differing results in 2 700 eggbox rebuilds once
+// 128-point parts made multi-part nodes common), hence the explicit vmcnt(0).
+__device__ __forceinline__ void drain_stores() {
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // gfx9 encoding: vmcnt(0), expcnt / lgkmcnt untouched
+}
+
 __device__ __forceinline__ bool parts_barrier(int* bar, int target) {
   __shared__ int ok_flag;
+  drain_stores();
   __syncthreads();
   if (threadIdx.x == 0) {
     __hip_atomic_fetch_add(bar, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -1238,6 +1238,9 @@ struct WideEigArgs {
 constexpr int kEigMaxSweeps = 30;
 
 __device__ __forceinline__ bool eig_barrier(int* bar, int target, int* ok_flag) {
+  // every wave's (agent-scope, write-through) stores acknowledged before thread 0 announces the arrival:
+  // __syncthreads() = s_waitcnt lgkmcnt(0) + s_barrier does not wait for them (see rebuild.hip: parts_barrier)
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // gfx9 encoding: vmcnt(0)
   __syncthreads();
   if (threadIdx.x == 0) {
     __hip_atomic_fetch_add(bar, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

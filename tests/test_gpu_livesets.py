@@ -60,3 +60,24 @@ def test_rebuild_of_a_captured_live_set(ctx, tag, i):
     assert slow["nells"] == m
     np.testing.assert_allclose(slow["covs"], got["covs"], rtol=1e-10, atol=0)
     np.testing.assert_allclose(slow["axes"], got["axes"], rtol=0, atol=1e-9 * np.abs(got["axes"]).max())
+
+
+def test_rebuild_is_bit_reproducible_under_stress(ctx):
+    """The parts of a k-means node exchange partial sums through agent-scope stores and a counter barrier.  Round 2
+    found that __syncthreads() does not wait for those stores (s_waitcnt lgkmcnt(0); s_barrier), so a partner could
+    read the previous iteration's partial: 3 of 2 700 eggbox rebuilds differed (different clusters, not rounding)
+    once 128-point parts made multi-part nodes common.  The barrier now drains the stores explicitly; this test
+    repeats batched rebuilds of captured eggbox / C2 live sets (permuted) and requires identical bits every time."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "livesets.npz"))
+    fields = ("ctrs", "covs", "ams", "axes", "axlens", "logvol_ells")
+    for name, reps in (("C3", 60), ("C2", 20)):
+        rng = np.random.default_rng(0)
+        sets = [g[f"{name}/{i}/live_u"][rng.permutation(len(g[f"{name}/{i}/live_u"]))] for i in range(3) for _ in range(6)]
+        ref = ctx.rebuild_many(sets, multi=True)
+        for _ in range(reps):
+            got = ctx.rebuild_many(sets, multi=True)
+            for x, y in zip(ref, got):
+                assert x["nells"] == y["nells"]
+                for k in fields:
+                    np.testing.assert_array_equal(x[k], y[k])
