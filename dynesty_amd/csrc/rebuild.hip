@@ -633,9 +633,11 @@ __device__ __forceinline__ double tile_quadform_max(const Lds& L, const double* 
 // max_i delta_i^T AM delta_i over a node (bounding.py:1438), delta about L.mean
 __device__ __forceinline__ double node_fmax(const Lds& L, const double* pts, const int* perm, int start, int count, int D) {
   double best = -INFINITY;
+  PH_T0();
   for (int base = 0; base < count; base += L.TP) {
     const int cnt = min(L.TP, count - base);
     stage_tile(L, pts, perm, start + base, cnt, D, 1);
+    PH_ADD(5);
     if (D >= kMfmaMinDim) {
       best = tile_quadform_max(L, L.AM, cnt, D, best);
     } else {
@@ -988,6 +990,7 @@ __device__ __forceinline__ bool spd_fast(const Lds& L, const double* cov, int D,
     if (t == 0) L.lam[0] = q;
   }
   __syncthreads();
+  PH_ADD(15);
   return L.lam[0] > 0.0 && isfinite(L.lam[0]);
 }
 
@@ -1239,18 +1242,32 @@ __device__ int node_kmeans_part(const Lds& L, const double* pts, int* perm, int*
     // four independent 4x4x4 products) takes the indicators as its 4 rows and 4 x 4 dimensions as the
     // columns of its four blocks.  Operand lanes: A row = lane & 3, k = lane >> 4 (any block);
     // B column = dimension lane & 15, k = lane >> 4; D row = lane >> 4, dimension lane & 15.
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    // two independent accumulator chains (groups of 4 points alternate between them): a dependent
+    // chain of 16 x 3 matrix instructions per wave was most of this phase
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, b0 = 0.0, b1 = 0.0, b2 = 0.0;
     const int pend = min(cnt, w * 64 + 64);
     const int li = lane & 3;
-    for (int p0 = w * 64; p0 < pend; p0 += 4) {
-      const int p = p0 + lk;
-      const bool pv = p < cnt;
+    for (int p0 = w * 64; p0 < pend; p0 += 8) {
+      const int p = p0 + lk, pb = p0 + 4 + lk;
+      const bool pv = p < cnt, pvb = pb < cnt;
       const double ind = (pv && li < 2 && L.ri[pv ? p : 0] == li) ? 1.0 : 0.0;
+      const double indb = (pvb && li < 2 && L.ri[pvb ? pb : 0] == li) ? 1.0 : 0.0;
       const double* row = L.tile + p * LD + lj;
+      const double* rowb = L.tile + pb * LD + lj;
       a0 = DH_MFMA_F64_4X4(ind, (pv && lj < D) ? row[0] : 0.0, a0);
-      if (nb > 1) a1 = DH_MFMA_F64_4X4(ind, (pv && 16 + lj < D) ? row[16] : 0.0, a1);
-      if (nb > 2) a2 = DH_MFMA_F64_4X4(ind, (pv && 32 + lj < D) ? row[32] : 0.0, a2);
+      b0 = DH_MFMA_F64_4X4(indb, (pvb && lj < D) ? rowb[0] : 0.0, b0);
+      if (nb > 1) {
+        a1 = DH_MFMA_F64_4X4(ind, (pv && 16 + lj < D) ? row[16] : 0.0, a1);
+        b1 = DH_MFMA_F64_4X4(indb, (pvb && 16 + lj < D) ? rowb[16] : 0.0, b1);
+      }
+      if (nb > 2) {
+        a2 = DH_MFMA_F64_4X4(ind, (pv && 32 + lj < D) ? row[32] : 0.0, a2);
+        b2 = DH_MFMA_F64_4X4(indb, (pvb && 32 + lj < D) ? rowb[32] : 0.0, b2);
+      }
     }
+    a0 += b0;
+    a1 += b1;
+    a2 += b2;
     // result rows 0 and 1 (the two clusters) sit in lanes 0..15 and 16..31
     if (lane < 32) {
       double* o = L.kred + (w * 2 + lk) * 48;

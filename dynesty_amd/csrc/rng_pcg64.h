@@ -390,10 +390,13 @@ __device__ DH_NORMALS_INLINE double normals_to_lds(Pcg64& g, const ZigLds* z, do
     const double nwi = z->wi[nxt & 0xff];
     if (active) {
       const int idx = (int)(cand & 0xff);
-      const uint64_t r = cand >> 8;
-      const uint64_t rabs = (r >> 1) & 0x000fffffffffffffull;
-      double x = (double)rabs * cwi;
-      if (r & 1) x = -x;
+      const uint64_t rabs = (cand >> 9) & 0x000fffffffffffffull;
+      // (double)rabs, exact for rabs < 2^52, as 2^52 + rabs with the integer in the mantissa field (two
+      // instructions instead of cvt / ldexp / cvt / add); the sign is bit 8 of the draw, moved onto x's
+      // sign bit (x >= 0 here; +0 becomes -0 exactly as `x = -x` would make it)
+      const double rd = __longlong_as_double((long long)(rabs | 0x4330000000000000ull)) - 4503599627370496.0;
+      double x = rd * cwi;
+      x = __longlong_as_double(__double_as_longlong(x) ^ (long long)((cand & 0x100ull) << 55));
       bool take = rabs < cki;
       bool used_next = false;
       if (!take) {
