@@ -141,7 +141,8 @@ int wide_walk_launch(dh_ctx* ctx, int kind, int problem, int k, int ndim, int nc
                      const double* axes, int m, const int32_t* axes_idx, double scale, double loglstar,
                      int iters, int doubling, const int8_t* bc, const uint64_t* rng, double* u, double* v,
                      double* logl, int32_t* c0, int32_t* c1, int32_t* c2, int32_t* flags,
-                     uint64_t* rng_out);
+                     uint64_t* rng_out, const double* run_loglstar = nullptr, const double* run_scale = nullptr,
+                     const int* run_mode = nullptr, const int* run_doubling = nullptr, int wpr = 0, int my_mode = 0);
 int wide_eval_launch(dh_ctx* ctx, const ProblemDev& p, int k, const double* u, double* v, double* logl);
 // UniformBoundSampler inside a (multi-)ellipsoid at wide D; problem = -1: propose only (lock-step)
 int wide_unif_launch(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, int m, const double* ctrs,
@@ -153,6 +154,9 @@ int wide_contains_launch(dh_ctx* ctx, const double* x, int k, int d, const doubl
 int wide_single_launch(dh_ctx* ctx, int runs, const double* pts, int n, int d, int32_t* nells,
                        int32_t* status, double* ctrs, double* covs, double* ams, double* axes,
                        double* axlens, double* logvols);
+int wide_single_launch_masked(dh_ctx* ctx, int runs, const double* pts, int n, int d, int32_t* nells,
+                              int32_t* status, double* ctrs, double* covs, double* ams, double* axes,
+                              double* axlens, double* logvols, const int* active);
 // MultiEllipsoid.update at wide D: host recursion over device node work (wide.hip)
 int wide_multi_launch(dh_ctx* ctx, int runs, const double* pts, int n, int d, int max_ells, int32_t* nells,
                       int32_t* status, double* ctrs, double* covs, double* ams, double* axes, double* axlens,

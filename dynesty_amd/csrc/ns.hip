@@ -963,9 +963,14 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
   if (runs < 1 || nlive < 4 || queue_size < 1 || walks < 1 || sampler < 0 || sampler > 2 || !entropy_words ||
       n_words < 1 || !records)
     return fail(ctx, DH_ERR_ARG, "ns_ensemble: bad arguments");
-  if (sampler != 0 && pad_dim(ndim) != ndim)
-    return fail(ctx, DH_ERR_ARG, "ns_ensemble: slice samplers need ndim in {1-6,8,10,12,16,20,25,32}");
-  if (ndim > kMaxRegDim) return fail(ctx, DH_ERR_ARG, "ns_ensemble: ndim=%d > %d not built", ndim, kMaxRegDim);
+  // Above the register-resident dimensions (and for slice samplers at dimensions without an instantiation) the
+  // walker launches go to the wave-per-walker kernels of wide.hip, which take the same per-run arrays; above
+  // d = 44 the bound is the multi-workgroup Ellipsoid.update with the run mask (single ellipsoid only: the wide
+  // MultiEllipsoid.update is a host recursion).
+  if (philox && ndim > kMaxRegDim)
+    return fail(ctx, DH_ERR_ARG, "ns_ensemble: the Philox proposals are built for ndim <= %d", kMaxRegDim);
+  if (bound_multi && ndim > 44)
+    return fail(ctx, DH_ERR_ARG, "ns_ensemble: bound='multi' in the device-resident loop needs ndim <= 44 (ndim=%d)", ndim);
   const int N = nlive, D = ndim, K = queue_size, R = runs;
   const int me = bound_multi ? (N / (2 * D) > 0 ? N / (2 * D) : 1) : 1;
   NsArgs a{};

@@ -402,10 +402,10 @@ int dh::rwalk_launch_runs(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, 
   if (ncdim < 1 || ncdim > ndim || m < 1 || walks < 1)
     return fail(ctx, DH_ERR_ARG, "rwalk: ncdim=%d ndim=%d m=%d walks=%d", ncdim, ndim, m, walks);
   if (ndim > kMaxRegDim) {
-    if (run_mode) return fail(ctx, DH_ERR_ARG, "ensemble rwalk: ndim=%d > %d not built", ndim, kMaxRegDim);
     if (philox) return fail(ctx, DH_ERR_ARG, "rwalk: the Philox mode is built for ndim <= %d", kMaxRegDim);
     return wide_walk_launch(ctx, 0, problem, k, ndim, ncdim, u0, axes, m, axes_idx, scale, loglstar, walks,
-                            0, bc, rng, u, v, logl, naccept, nreject, nullptr, nullptr, rng_out);
+                            0, bc, rng, u, v, logl, naccept, nreject, nullptr, nullptr, rng_out, run_loglstar,
+                            run_scale, run_mode, nullptr, wpr, my_mode);
   }
   a.k = k;
   a.ndim = ndim;

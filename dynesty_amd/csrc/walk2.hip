@@ -775,12 +775,10 @@ int dh::slice_launch_runs(dh_ctx* ctx, int problem, int k, int ndim, int mode, c
   if (m < 1 || slices < 1 || (mode != 0 && mode != 1))
     return fail(ctx, DH_ERR_ARG, "slice: m=%d slices=%d mode=%d", m, slices, mode);
   const int N = pad_dim(ndim);
-  if (N != ndim && run_mode)
-    return fail(ctx, DH_ERR_ARG, "ensemble slice: ndim=%d has no register-resident instantiation", ndim);
   if (N != ndim)  // no register-resident instantiation for this dimension: wave-per-walker path
     return wide_walk_launch(ctx, mode + 1, problem, k, ndim, ndim, u0, axes, m, axes_idx, scale, loglstar,
                             slices, doubling, nullptr, rng, u, v, logl, ncalls, nexpand, ncontract, flags,
-                            rng_out);
+                            rng_out, run_loglstar, run_scale, run_mode, run_doubling, wpr, my_mode);
   int rc = ensure_axes_t(ctx, (size_t)m * N * N * 8);
   if (rc) return rc;
   hipLaunchKernelGGL(pad_mats_kernel, dim3((m * N * N + 255) / 256), dim3(256), 0, ctx->stream, axes, m,
@@ -941,13 +939,15 @@ int dh::unif_launch_runs(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, i
   if (k <= 0) return DH_OK;
   if (m < 0 || ncdim < 1 || ncdim > ndim) return fail(ctx, DH_ERR_ARG, "unif: m=%d ncdim=%d", m, ncdim);
   if (ndim > kMaxRegDim) {
-    if (run_mode) return fail(ctx, DH_ERR_ARG, "ensemble unif: ndim=%d > %d not built", ndim, kMaxRegDim);
-    if (m != 0 || a.propose_only)
+    if (m != 0 || a.propose_only) {
+      if (run_mode)
+        return fail(ctx, DH_ERR_ARG, "ensemble unif inside a bound: ndim=%d > %d not built", ndim, kMaxRegDim);
       return wide_unif_launch(ctx, problem, k, ndim, ncdim, m, ctrs, axes, ams, cumprob, loglstar, bc, rng,
                               max_tries, u, v, logl, ncalls, flags, rng_out);
+    }
     return wide_walk_launch(ctx, 3, problem, k, ndim, ndim, nullptr, nullptr, 1,
                             nullptr, 1.0, loglstar, 0, 0, bc, rng, u, v, logl, ncalls, nullptr, nullptr,
-                            flags, rng_out);
+                            flags, rng_out, run_loglstar, nullptr, run_mode, nullptr, wpr, my_mode);
   }
   const int N = pad_dim(ndim);
   const size_t mats = (size_t)(m > 0 ? m : 1) * N * N * 8;

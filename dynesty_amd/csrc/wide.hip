@@ -161,6 +161,13 @@ struct WideWalkArgs {
   const uint64_t* zfi;
   int dbg;  // DH_WIDE_PROF=1: wave 0 prints its cycle split (normals / mat-vec / F evaluations)
   int lds_ws;  // doubles per wave region in LDS (4 D rounded up to odd)
+  // ensemble form (ns.hip): walker w belongs to run w / wpr; per-run threshold / scale / doubling flag, and only
+  // the runs whose mode is my_mode are served (all null / 0: the plain batch)
+  const double* run_loglstar;
+  const double* run_scale;
+  const int* run_mode;
+  const int* run_doubling;
+  int wpr, my_mode;
 };
 
 __device__ __forceinline__ void lds_sync() {
@@ -280,8 +287,14 @@ __global__ void __launch_bounds__(64 * kWalkMaxWaves, 2) wide_walk_kernel(WideWa
   zig_stage(&zig, a.zki, a.zwi, a.zfi);
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wpw = blockDim.x >> 6;
   const int wq = blockIdx.x * wpw + wv;
-  const bool ghost = wq >= a.k;  // padding wavefront of the last workgroup: barriers only
-  const int w = ghost ? a.k - 1 : wq;
+  // ghost = barriers only, no results: the padding wavefronts of the last workgroup, and (ensemble form) the
+  // walkers of a run that is not in the mode this launch serves
+  const int w = wq >= a.k ? a.k - 1 : wq;
+  const int run = __builtin_amdgcn_readfirstlane(a.wpr > 0 ? w / a.wpr : 0);
+  const bool ghost = wq >= a.k || (a.run_mode && a.run_mode[run] != a.my_mode);
+  if (__syncthreads_and(ghost ? 1 : 0)) return;  // nobody in this workgroup has work
+  const double loglstar = a.run_loglstar ? a.run_loglstar[run] : a.loglstar;
+  const double scale = a.run_scale ? a.run_scale[run] : a.scale;
   const int D = a.ndim, nc = a.ncdim;
   const int ws = a.lds_ws;  // doubles per wave region (odd: conflict-free column reads in the GEMM)
   double* wbase = (double*)smem;
@@ -297,9 +310,10 @@ __global__ void __launch_bounds__(64 * kWalkMaxWaves, 2) wide_walk_kernel(WideWa
   const PcgLanes PL = pcg_lanes_init(g, lane);
   const int frame = __builtin_amdgcn_readfirstlane(a.axes_idx ? a.axes_idx[w] : 0);
   const double* AT = a.axes_t + (size_t)frame * nc * nc;  // unused when there are no frames (kind 3)
-  if (lane == 0) sframe[wv] = frame;
+  // (walkers of different runs never share a frame index: frames are numbered run * m + ellipsoid)
+  if (lane == 0) sframe[wv] = frame + (a.run_scale ? run * 0x100000 : 0);
   __syncthreads();
-  bool coop = a.axes_t != nullptr;  // all walkers of the workgroup on one frame: GEMM path
+  bool coop = a.axes_t != nullptr;  // all walkers of the workgroup on one frame (and one run's scale): GEMM path
   for (int q = 0; q < wpw; ++q) coop = coop && sframe[q] == sframe[0];
   coop = __builtin_amdgcn_readfirstlane((int)coop) != 0;
   lds_sync();
@@ -314,7 +328,7 @@ __global__ void __launch_bounds__(64 * kWalkMaxWaves, 2) wide_walk_kernel(WideWa
       ll = wide_logl(a.prob, D, su, sv, lane);
       ++ncall;
       lds_sync();
-      if (ll > a.loglstar) break;
+      if (ll > loglstar) break;
     }
     if (ghost) return;
     for (int i = lane; i < D; i += 64) {
@@ -340,7 +354,7 @@ __global__ void __launch_bounds__(64 * kWalkMaxWaves, 2) wide_walk_kernel(WideWa
       double ss = 0.0;
       for (int i = lane; i < nc; i += 64) ss = fma(sd[i], sd[i], ss);
       ss = wave_sum(ss);
-      const double fac = a.scale * (pow(g.next_double(), 1.0 / (double)nc) / sqrt(ss));
+      const double fac = scale * (pow(g.next_double(), 1.0 / (double)nc) / sqrt(ss));
       lds_sync();
       if (coop) {
         __syncthreads();
@@ -374,7 +388,7 @@ __global__ void __launch_bounds__(64 * kWalkMaxWaves, 2) wide_walk_kernel(WideWa
         continue;
       }
       const double ll = wide_logl(a.prob, D, sp, sv, lane);
-      if (ll > a.loglstar) {
+      if (ll > loglstar) {
         for (int i = lane; i < D; i += 64) su[i] = sp[i];
         logl_cur = ll;
         ++nacc;
@@ -402,7 +416,7 @@ __global__ void __launch_bounds__(64 * kWalkMaxWaves, 2) wide_walk_kernel(WideWa
 
   // ---- rslice / slice (internal_samplers.py:593-855, 1038-1206) ----
   long long cy_n = 0, cy_m = 0, cy_f = 0, cy_g = 0, cy_t0 = clock64();
-  bool doubling = a.doubling0 != 0, warn_set = false, failed = false;
+  bool doubling = (a.run_doubling ? a.run_doubling[run] : a.doubling0) != 0, warn_set = false, failed = false;
   int ncall = 0, n_expand = 0, n_contract = 0;
   double logl_cur = 0.0;
   const double maxlen = sqrt((double)D) / 2.0;
@@ -442,18 +456,18 @@ __global__ void __launch_bounds__(64 * kWalkMaxWaves, 2) wide_walk_kernel(WideWa
         if (coop) {
           __syncthreads();
           const long long cg_ = clock64();
-          wg_frame_gemm(AT, D, wbase, ws, 3 * D, 2 * D, a.scale, wpw, wv, wpw);
+          wg_frame_gemm(AT, D, wbase, ws, 3 * D, 2 * D, scale, wpw, wv, wpw);
           cy_g += clock64() - cg_;
           __syncthreads();
         } else if (!failed) {
-          wg_frame_gemm(AT, D, su, ws, 3 * D, 2 * D, a.scale, 1, 0, 1);
+          wg_frame_gemm(AT, D, su, ws, 3 * D, 2 * D, scale, 1, 0, 1);
         }
         cy_m += clock64() - c1_;
         if (failed) continue;
       } else {
         const int idx = sperm[sub];
         const double* col = AT + (size_t)idx * D;
-        for (int i = lane; i < D; i += 64) sd[i] = a.scale * col[i];
+        for (int i = lane; i < D; i += 64) sd[i] = scale * col[i];
       }
       lds_sync();
       const double rand0 = g.next_double();
@@ -504,11 +518,11 @@ __global__ void __launch_bounds__(64 * kWalkMaxWaves, 2) wide_walk_kernel(WideWa
           case SL_RIGHT0:
             f_r = f;
             if (!doubling) {
-              if (f_l > a.loglstar) {
+              if (f_l > loglstar) {
                 phase = SL_OUT_L;
                 left -= 1.0;
                 xq = left;
-              } else if (f_r > a.loglstar) {
+              } else if (f_r > loglstar) {
                 phase = SL_OUT_R;
                 right += 1.0;
                 xq = right;
@@ -522,10 +536,10 @@ __global__ void __launch_bounds__(64 * kWalkMaxWaves, 2) wide_walk_kernel(WideWa
           case SL_OUT_L:
             f_l = f;
             ++nexp_step;
-            if (f_l > a.loglstar) {
+            if (f_l > loglstar) {
               left -= 1.0;
               xq = left;
-            } else if (f_r > a.loglstar) {
+            } else if (f_r > loglstar) {
               phase = SL_OUT_R;
               right += 1.0;
               xq = right;
@@ -536,7 +550,7 @@ __global__ void __launch_bounds__(64 * kWalkMaxWaves, 2) wide_walk_kernel(WideWa
           case SL_OUT_R:
             f_r = f;
             ++nexp_step;
-            if (f_r > a.loglstar) {
+            if (f_r > loglstar) {
               right += 1.0;
               xq = right;
             } else {
@@ -553,7 +567,7 @@ __global__ void __launch_bounds__(64 * kWalkMaxWaves, 2) wide_walk_kernel(WideWa
             break;
           case SL_SHRINK: {
             ++n_contract;
-            bool ok = f > a.loglstar;
+            bool ok = f > loglstar;
             if (ok && doubling) {  // start Neal's acceptance test for x1 = xq
               x1 = xq;
               logl_x1 = f;
@@ -587,7 +601,7 @@ __global__ void __launch_bounds__(64 * kWalkMaxWaves, 2) wide_walk_kernel(WideWa
               f_rhat = f;
             else
               f_lhat = f;
-            if (Dflag && a.loglstar >= f_lhat && a.loglstar >= f_rhat) {
+            if (Dflag && loglstar >= f_lhat && loglstar >= f_rhat) {
               phase = SL_SHRINK;  // rejected: shrink towards the origin as for any failed proposal
               if (x1 < 0.0)
                 left = x1;
@@ -604,7 +618,7 @@ __global__ void __launch_bounds__(64 * kWalkMaxWaves, 2) wide_walk_kernel(WideWa
         }
         // phases that choose their next abscissa after the switch
         if (phase == SL_DBL) {
-          if (f_l > a.loglstar || f_r > a.loglstar) {
+          if (f_l > loglstar || f_r > loglstar) {
             if (g.next_double() < 0.5) {
               left -= (right - left);
               xq = left;
@@ -915,6 +929,7 @@ struct WideRebuildArgs {
   double* axes;
   double* axlens;
   double* logvols;
+  const int* active;  // runs or null: runs with active[run] == 0 are left untouched (ensemble loop)
 };
 
 __device__ double block_max_1024(double v, double* red) {
@@ -1234,6 +1249,7 @@ struct WideEigArgs {
   int* ok;            // runs
   int D, B, b;
   int dbg;
+  const int* active;  // see WideRebuildArgs
 };
 constexpr int kEigMaxSweeps = 30;
 
@@ -1265,6 +1281,7 @@ __global__ void __launch_bounds__(kRT) wide_eig_kernel(WideEigArgs a) {
   const int D = a.D, B = a.B, b = a.b, M = 2 * B, CL = 2 * D;
   const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6), nwv = kRT / 64;
   const int run = blockIdx.x / B, w = blockIdx.x - run * B;
+  if (a.active && !a.active[run]) return;  // all B workgroups of the run leave together: no barrier is missed
   double* col = (double*)smem;  // 2b columns x CL
   const double* cov = a.cov + (size_t)run * D * D;
   double* xb = a.xbuf + (size_t)run * 2 * M * b * CL;
@@ -1452,6 +1469,7 @@ __global__ void __launch_bounds__(kRT) wide_eig2_kernel(WideEigArgs a) {
   const int D = a.D, B = a.B, b = a.b, M = 2 * B, CL = 2 * D + 1;  // CL odd: conflict-free writes across columns
   const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6), nwv = kRT / 64;
   const int run = blockIdx.x / B, w = blockIdx.x - run * B;
+  if (a.active && !a.active[run]) return;  // all B workgroups of the run leave together: no barrier is missed
   double* col = (double*)smem;              // 2b columns x CL: [G (D) | V (D) | pad]
   double* gm0 = col + (size_t)2 * b * CL;   // Gram matrix of the G parts, two buffers of 32 x kGS
   double* jm0 = gm0 + 2 * 32 * kGS;         // accumulated rotations of the round, two buffers
@@ -1723,6 +1741,7 @@ __global__ void __launch_bounds__(kRT) wide_eig2_kernel(WideEigArgs a) {
 __global__ void __launch_bounds__(kRT) wide_single_kernel(WideRebuildArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int D = a.d, n = a.n, t = threadIdx.x, run = blockIdx.x;
+  if (a.active && !a.active[run]) return;
   const int LD = D | 1;
   double* tile = (double*)smem;            // tp x LD
   double* mean = tile + (size_t)a.tp * LD;  // D
@@ -1976,6 +1995,7 @@ __global__ void __launch_bounds__(kRT) wide_mean_part_kernel(WideRebuildArgs a) 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double* sacc = (double*)smem;  // G x D
   const int D = a.d, t = threadIdx.x, run = blockIdx.x / a.P, q = blockIdx.x - run * a.P;
+  if (a.active && !a.active[run]) return;
   const int pbeg = min(a.n, q * a.chunk), pend = min(a.n, pbeg + a.chunk);
   const double* pts = a.pts + (size_t)run * a.n * D;
   const int G = kRT / D > 0 ? kRT / D : 1;
@@ -2004,6 +2024,7 @@ __device__ __forceinline__ void wide_mean_from_parts(const WideRebuildArgs& a, i
 __global__ void __launch_bounds__(kRT) wide_cov_part_kernel(WideRebuildArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int D = a.d, LD = D | 1, run = blockIdx.x / a.P, q = blockIdx.x - run * a.P;
+  if (a.active && !a.active[run]) return;
   double* tile = (double*)smem;
   double* mean = tile + (size_t)a.tp * LD;
   const int pbeg = min(a.n, q * a.chunk), pend = min(a.n, pbeg + a.chunk);
@@ -2014,6 +2035,7 @@ __global__ void __launch_bounds__(kRT) wide_cov_part_kernel(WideRebuildArgs a) {
 
 __global__ void __launch_bounds__(256) wide_cov_reduce_kernel(WideRebuildArgs a) {
   const int D = a.d, run = blockIdx.y, e = blockIdx.x * 256 + threadIdx.x;
+  if (a.active && !a.active[run]) return;
   if (e < D * D) {
     const int i = e / D, j = e - i * D;
     const size_t src = (i >> 4) <= (j >> 4) ? (size_t)i * D + j : (size_t)j * D + i;
@@ -2131,9 +2153,16 @@ int wide_walk_launch(dh_ctx* ctx, int kind, int problem, int k, int ndim, int nc
                      const double* axes, int m, const int32_t* axes_idx, double scale, double loglstar,
                      int iters, int doubling, const int8_t* bc, const uint64_t* rng, double* u, double* v,
                      double* logl, int32_t* c0, int32_t* c1, int32_t* c2, int32_t* flags,
-                     uint64_t* rng_out) {
+                     uint64_t* rng_out, const double* run_loglstar, const double* run_scale, const int* run_mode,
+                     const int* run_doubling, int wpr, int my_mode) {
   WideWalkArgs a;
   if (!get_problem(ctx, problem, &a.prob)) return DH_ERR_ARG;
+  a.run_loglstar = run_loglstar;
+  a.run_scale = run_scale;
+  a.run_mode = run_mode;
+  a.run_doubling = run_doubling;
+  a.wpr = wpr;
+  a.my_mode = my_mode;
   if (ndim > kWideMaxD) return fail(ctx, DH_ERR_ARG, "ndim=%d exceeds the wide-D limit %d", ndim, kWideMaxD);
   // transposed frames in the context scratch
   const size_t at_bytes = axes ? (size_t)m * ncdim * ncdim * 8 : 0;
@@ -2278,7 +2307,7 @@ int wide_contains_launch(dh_ctx* ctx, const double* x, int k, int d, const doubl
   return hip_ok(ctx, hipGetLastError(), "wide contains launch") ? DH_OK : DH_ERR_HIP;
 }
 
-static int wide_single_enqueue(dh_ctx* ctx, int runs, const double* pts, int n, int d, int32_t* status,
+static int wide_single_enqueue(dh_ctx* ctx, int runs, const double* pts, int n, int d, const int* active, int32_t* status,
                                double* ctrs, double* covs, double* ams, double* axes, double* axlens,
                                double* logvols) {
   if (d > kWideMaxD) return fail(ctx, DH_ERR_ARG, "rebuild: d=%d exceeds the wide-D limit %d", d, kWideMaxD);
@@ -2353,6 +2382,7 @@ static int wide_single_enqueue(dh_ctx* ctx, int runs, const double* pts, int n, 
   a.axes = axes;
   a.axlens = axlens;
   a.logvols = logvols;
+  a.active = active;
   const int LD = d | 1;
   const size_t lds_part = ((size_t)tp * LD + d + 64 + (size_t)((d + 15) / 16) * 64) * 8;
   const size_t lds_mean = (size_t)std::max(1, kRT / d) * d * 8;
@@ -2410,6 +2440,7 @@ static int wide_single_enqueue(dh_ctx* ctx, int runs, const double* pts, int n, 
     g.B = B;
     g.b = b;
     g.dbg = a.dbg;
+    g.active = active;
     if (gram)
       hipLaunchKernelGGL(wide_eig2_kernel, dim3(runs * B), dim3(kRT), eig_lds, ctx->stream, g);
     else
@@ -2425,7 +2456,7 @@ static int wide_single_enqueue(dh_ctx* ctx, int runs, const double* pts, int n, 
 int wide_single_launch(dh_ctx* ctx, int runs, const double* pts, int n, int d, int32_t* nells,
                        int32_t* status, double* ctrs, double* covs, double* ams, double* axes,
                        double* axlens, double* logvols) {
-  const int rc0 = wide_single_enqueue(ctx, runs, pts, n, d, status, ctrs, covs, ams, axes, axlens, logvols);
+  const int rc0 = wide_single_enqueue(ctx, runs, pts, n, d, nullptr, status, ctrs, covs, ams, axes, axlens, logvols);
   if (rc0) return rc0;
   // nells = 1 per run (status decides validity)
   std::vector<int32_t> ones((size_t)runs, 1);
@@ -2435,6 +2466,22 @@ int wide_single_launch(dh_ctx* ctx, int runs, const double* pts, int n, int d, i
   return hip_ok(ctx, hipStreamSynchronize(ctx->stream), "sync") ? DH_OK : DH_ERR_HIP;
 }
 
+
+// Ellipsoid.update of the runs with active[run] != 0, everything on the stream, nothing synchronised: the
+// rebuild stage of the device-resident loop (ns.hip) above the register-resident dimensions.
+__global__ void wide_mark_single_kernel(int runs, const int* __restrict__ active, int32_t* __restrict__ nells) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < runs && (!active || active[r])) nells[r] = 1;
+}
+
+int wide_single_launch_masked(dh_ctx* ctx, int runs, const double* pts, int n, int d, int32_t* nells,
+                              int32_t* status, double* ctrs, double* covs, double* ams, double* axes,
+                              double* axlens, double* logvols, const int* active) {
+  const int rc0 = wide_single_enqueue(ctx, runs, pts, n, d, active, status, ctrs, covs, ams, axes, axlens, logvols);
+  if (rc0) return rc0;
+  hipLaunchKernelGGL(wide_mark_single_kernel, dim3((runs + 63) / 64), dim3(64), 0, ctx->stream, runs, active, nells);
+  return hip_ok(ctx, hipGetLastError(), "wide masked rebuild launch") ? DH_OK : DH_ERR_HIP;
+}
 
 // ---------------------------------------------------------------------------
 // MultiEllipsoid.update at wide D (bounding.py:632-686, 1464-1563).  Nodes are big here (a split
@@ -2583,7 +2630,7 @@ int wide_node_ell(WideTree& T, const double* p, int cnt) {
   }
   const int s = S.used++;
   const size_t d = T.d, dd = d * d;
-  int rc = wide_single_enqueue(T.ctx, 1, p, cnt, T.d, S.status + s, S.ctrs + s * d, S.covs + s * dd, S.ams + s * dd,
+  int rc = wide_single_enqueue(T.ctx, 1, p, cnt, T.d, nullptr, S.status + s, S.ctrs + s * d, S.covs + s * dd, S.ams + s * dd,
                                S.axes + s * dd, S.axlens + s * d, S.logvols + s);
   if (rc) {
     T.err = rc;

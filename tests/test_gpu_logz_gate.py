@@ -84,3 +84,21 @@ def test_c4_device_run_vs_reference_runs(ctx):
     for x in (q for q in ref["runs"] if q["K"] == 1000):
         assert abs(r.logz - x["logz"]) < 3.0 * math.hypot(r.logzerr, x["logzerr"]), (r.logz, x["logz"])
         assert abs(r.niter / x["niter"] - 1) < 0.06
+
+
+def test_c4_device_resident_loop_vs_reference_runs(ctx):
+    """BASELINE C4 through the device-resident loop (dh_ns_ensemble at 200-D: wave-per-walker rslice kernels with
+    per-run thresholds, masked multi-workgroup Ellipsoid.update): two runs against the converged runs of the real
+    reference, serial and at the same queue size."""
+    from dynesty_amd import problems
+    ref = json.load(open(os.path.join(GOLD, "c4_logz_ref.json")))
+    prob = problems.gauss_normal_prior(200, "C4")
+    r = ctx.ns_ensemble(prob, 2, 4000, 1000, bound='single', sample='rslice', slices=203, entropy=[21], dlogz=0.01,
+                        max_iter=250000)
+    assert (r["status"] == 0).all()
+    refs = np.array([x["logz"] for x in ref["runs"]])
+    err = float(np.mean([x["logzerr"] for x in ref["runs"]]))
+    # two runs against the mean of the reference's three (K = 1, 1, 1000)
+    assert abs(r["logz"].mean() - refs.mean()) < 3.0 * err * math.sqrt(1 / 2 + 1 / len(refs)), (r["logz"], refs)
+    assert abs(r["logzerr"].mean() - err) < 0.01
+    assert abs(r["niter"].mean() / np.mean([x["niter"] for x in ref["runs"]]) - 1) < 0.05

@@ -360,3 +360,66 @@ def test_wide_walkers_golden(ctx, tag, d):
         np.testing.assert_array_equal(out["accept"], g[f"{tag}/ti_accept"])
     np.testing.assert_allclose(out["u"], g[f"{tag}/u"], rtol=0, atol=1e-11)
     np.testing.assert_allclose(out["logl"], g[f"{tag}/logl"], rtol=1e-10)
+
+
+def test_device_resident_loop_above_the_register_dimensions(ctx):
+    """dh_ns_ensemble at D = 64 (wave-per-walker kernels with per-run thresholds / scales, masked multi-workgroup
+    Ellipsoid.update): the same reference pin as the host-driven loop above (rslice_bias_ref.json: the real
+    dynesty at nlive 500, bound='single', sample='rslice'), determinism, and a run's result independent of its
+    shard mates (run i of an ensemble == the same run alone via first_run)."""
+    import json
+    import os
+    from dynesty_amd import problems
+    ref = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "rslice_bias_ref.json")))["runs"]
+    prob = problems.gauss_normal_prior(64, "C4")
+    kw = dict(bound='single', sample='rslice', dlogz=0.01, entropy=[5], max_iter=60000)
+    r = ctx.ns_ensemble(prob, 6, 500, 100, **kw)
+    assert (r["status"] == 0).all() and (r["nbound"] > 10).all()
+    zr = np.array([x["logz"] for x in ref])
+    err = np.mean([x["logzerr"] for x in ref])
+    se = err * np.sqrt(1.0 / len(zr) + 1.0 / 6)
+    assert abs(r["logz"].mean() - zr.mean()) < 3.0 * se, (r["logz"], zr, se)
+    assert abs(r["logzerr"].mean() - err) < 0.02
+    again = ctx.ns_ensemble(prob, 6, 500, 100, **kw)
+    np.testing.assert_array_equal(again["logz"], r["logz"])
+    alone = ctx.ns_ensemble(prob, 2, 500, 100, first_run=3, **kw)
+    np.testing.assert_array_equal(alone["logz"], r["logz"][3:5])
+    np.testing.assert_array_equal(alone["ncall"], r["ncall"][3:5])
+
+
+@pytest.mark.parametrize("d,bound,sample", [(40, "multi", "rwalk"), (48, "single", "rwalk"), (7, "multi", "rslice"),
+                                           (7, "single", "slice")])
+def test_device_resident_loop_mixed_paths(ctx, d, bound, sample):
+    """Dimensions where the loop mixes the paths: 33..44 = narrow (multi-ellipsoid) rebuild + wide walkers; above 44
+    = wide rebuild + wide walkers; slice samplers at a dimension without a register-resident instantiation = narrow
+    rebuild + wide walkers.  ln Z against the analytic value of the iid-Normal / Normal-prior family."""
+    from dynesty_amd import backend, nested, problems
+    prob = problems.gauss_normal_prior(d, "C4")
+    r = ctx.ns_ensemble(prob, 8, 400, 64, bound=bound, sample=sample, dlogz=0.05, entropy=[d], max_iter=60000)
+    assert (r["status"] == 0).all(), r["status"]
+    lz = r["logz"]
+    se = lz.std(ddof=1) / np.sqrt(8)
+    assert abs(r["logzerr"].mean() / lz.std(ddof=1) - 1) < 0.8
+    if sample == "rwalk":
+        # rwalk with the default walks = 20 + d under-mixes at these dimensions (ln Z comes out +1.5 high at d = 48,
+        # in the host-driven loop over the single-launch kernels exactly as here): hold the resident loop to that
+        # loop -- same kernels, independent loop bookkeeping -- not to the analytic value
+        backend.set_backend(ctx)
+        try:
+            host = np.array([nested.run_static(prob, nlive=400, bound=bound, sample=sample, queue_size=64,
+                                               rstate=np.random.default_rng(100 + i), dlogz=0.05).logz for i in range(8)])
+        finally:
+            backend.set_backend(None)
+        se2 = np.hypot(se, host.std(ddof=1) / np.sqrt(8))
+        assert abs(lz.mean() - host.mean()) < 4 * se2, (lz.mean(), host.mean(), se2)
+    else:
+        assert abs(lz.mean() - prob.logz_truth) < 5 * se + 0.1, (lz.mean(), prob.logz_truth, se)
+
+
+def test_device_resident_loop_refuses_what_is_not_built(ctx):
+    from dynesty_amd import problems
+    prob = problems.gauss_normal_prior(64, "C4")
+    with pytest.raises(Exception):
+        ctx.ns_ensemble(prob, 2, 400, 64, bound='multi', sample='rwalk')  # wide MultiEllipsoid.update: host recursion
+    with pytest.raises(Exception):
+        ctx.ns_ensemble(prob, 2, 400, 64, bound='single', sample='rwalk', rng='philox')
