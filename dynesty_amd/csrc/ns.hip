@@ -31,6 +31,7 @@ using namespace dh;
 namespace {
 
 constexpr int kT = 256;
+constexpr int kSelCap = 2048;  // >= kEPT * kT: the largest queue ns_consume takes
 enum : int { MODE_CUBE = 0, MODE_BOUND = 1, MODE_DONE = 2, MODE_FAILED = 3 };
 
 struct NsRun {
@@ -332,6 +333,7 @@ constexpr int kMaxCum = 4096;  // ellipsoids per run the frame choice can weigh 
 __global__ void __launch_bounds__(kT) ns_select(NsArgs a) {
   __shared__ uint64_t ent[4];
   __shared__ double cum[kMaxCum];  // rand_choice weights of ALL ellipsoids of the run (bounding.py:726-731)
+  __shared__ int sel_frame[kSelCap];  // the walkers' ellipsoid choices (q_frame carries the live index meanwhile)
   __shared__ int Msh;
   __shared__ double mxs;
   const int run = blockIdx.x, t = threadIdx.x;
@@ -387,9 +389,7 @@ __global__ void __launch_bounds__(kT) ns_select(NsArgs a) {
       do {
         i = (int)g.interval((uint64_t)(N - 1));
       } while (!(a.live_logl[(size_t)run * N + i] > loglstar) && ++guard < 100000);
-      const double* src = a.live_u + ((size_t)run * N + i) * D;
-      double* dst = a.q_u0 + q * D;
-      for (int j = 0; j < D; ++j) dst[j] = src[j];
+      a.q_frame[q] = i;  // the chosen live point: its coordinates are copied by all threads below
       if (M > 1) {
         // min(searchsorted(cum, xr), M - 1): first index with cum[i] >= xr
         const double xr = g.next_double();
@@ -401,8 +401,23 @@ __global__ void __launch_bounds__(kT) ns_select(NsArgs a) {
         frame = lo;
       }
     }
-    a.q_frame[q] = run * a.max_ells + frame;
+    if (mode == MODE_BOUND) sel_frame[w < kSelCap ? w : 0] = frame;
+    else a.q_frame[q] = run * a.max_ells + frame;
     g.store(a.q_rng + q * 4);
+  }
+  if (mode == MODE_BOUND) {
+    // start points: K rows of D doubles, element-parallel (a thread per row was a serial copy of D strided doubles:
+    // 0.23 ms per fill at D = 200)
+    __syncthreads();
+    const double* lu = a.live_u + (size_t)run * N * D;
+    double* qu = a.q_u0 + (size_t)run * K * D;
+    const int* qi = a.q_frame + (size_t)run * K;
+    for (int e = t; e < K * D; e += kT) {
+      const int w = e / D, j = e - w * D;
+      qu[e] = lu[(size_t)qi[w] * D + j];
+    }
+    __syncthreads();
+    for (int w = t; w < K; w += kT) a.q_frame[(size_t)run * K + w] = run * a.max_ells + sel_frame[w];
   }
 }
 
@@ -721,28 +736,41 @@ __global__ void __launch_bounds__(kT) ns_consume(NsArgs a) {
   }
   // dead-point coordinates (optional), in death order
   if (a.store_samples) {
-    for (int e = 0; e < nkeep; ++e) {
+    double* to = a.dead_u + ((size_t)run * a.cap + it0) * D;
+    for (int x = t; x < nkeep * D; x += kT) {
+      const int e = x / D, j = x - e * D;
       const int s = dslot[e], sj = dsrc[e];
-      const double* from = sj < 0 ? a.live_u + ((size_t)run * N + s) * D
-                                  : a.r_u + ((size_t)run * K + sj) * D;
-      double* to = a.dead_u + ((size_t)run * a.cap + it0 + e) * D;
-      for (int j = t; j < D; j += kT) to[j] = from[j];
+      to[x] = sj < 0 ? a.live_u[((size_t)run * N + s) * D + j] : a.r_u[((size_t)run * K + sj) * D + j];
     }
   }
   __syncthreads();
   NS_PROF(4);
-  // apply the surviving replacements to the live set
+  // apply the surviving replacements to the live set: the replaced slots are listed first (dslot / dj are free by
+  // now), then their rows are copied element-parallel (one thread per slot copying 2 D strided doubles was 1 ms of
+  // the 1.7 ms this kernel took per fill at D = 200)
+  if (t == 0) misc[4] = 0;
+  __syncthreads();
   for (int s = t; s < N; s += kT) {
     const int sj = src[s];
     if (sj >= 0) {
-      const size_t q = (size_t)run * K + sj;
       a.live_logl[(size_t)run * N + s] = ql[sj];
-      double* lu = a.live_u + ((size_t)run * N + s) * D;
-      double* lv = a.live_v + ((size_t)run * N + s) * D;
-      for (int j = 0; j < D; ++j) {
-        lu[j] = a.r_u[q * D + j];
-        lv[j] = a.r_v[q * D + j];
-      }
+      const int c = atomicAdd(&misc[4], 1);  // at most K slots change
+      dslot[c] = s;
+      dj[c] = sj;
+    }
+  }
+  __syncthreads();
+  {
+    const int nrep = misc[4];
+    double* lu = a.live_u + (size_t)run * N * D;
+    double* lv = a.live_v + (size_t)run * N * D;
+    const double* ru = a.r_u + (size_t)run * K * D;
+    const double* rv = a.r_v + (size_t)run * K * D;
+    for (int e = t; e < nrep * D; e += kT) {
+      const int c = e / D, j = e - c * D;
+      const size_t to = (size_t)dslot[c] * D + j, from = (size_t)dj[c] * D + j;
+      lu[to] = ru[from];
+      lv[to] = rv[from];
     }
   }
   for (int i = t; i < N; i += kT) {
