@@ -31,7 +31,6 @@ using namespace dh;
 namespace {
 
 constexpr int kT = 256;
-constexpr int kSelCap = 2048;  // >= kEPT * kT: the largest queue ns_consume takes
 enum : int { MODE_CUBE = 0, MODE_BOUND = 1, MODE_DONE = 2, MODE_FAILED = 3 };
 
 struct NsRun {
@@ -333,11 +332,10 @@ constexpr int kMaxCum = 4096;  // ellipsoids per run the frame choice can weigh 
 __global__ void __launch_bounds__(kT) ns_select(NsArgs a) {
   __shared__ uint64_t ent[4];
   __shared__ double cum[kMaxCum];  // rand_choice weights of ALL ellipsoids of the run (bounding.py:726-731)
-  __shared__ int sel_frame[kSelCap];  // the walkers' ellipsoid choices (q_frame carries the live index meanwhile)
   __shared__ int Msh;
   __shared__ double mxs;
   const int run = blockIdx.x, t = threadIdx.x;
-  const int N = a.nlive, D = a.ndim, K = a.K;
+  const int N = a.nlive, K = a.K;
   NsRun& r = a.st[run];
   const int mode = r.mode;
   if (mode != MODE_CUBE && mode != MODE_BOUND) return;
@@ -389,7 +387,7 @@ __global__ void __launch_bounds__(kT) ns_select(NsArgs a) {
       do {
         i = (int)g.interval((uint64_t)(N - 1));
       } while (!(a.live_logl[(size_t)run * N + i] > loglstar) && ++guard < 100000);
-      a.q_frame[q] = i;  // the chosen live point: its coordinates are copied by all threads below
+      a.r_d[q] = i;  // the chosen live point: ns_gather copies its coordinates (r_d is free until the walkers run)
       if (M > 1) {
         // min(searchsorted(cum, xr), M - 1): first index with cum[i] >= xr
         const double xr = g.next_double();
@@ -401,24 +399,21 @@ __global__ void __launch_bounds__(kT) ns_select(NsArgs a) {
         frame = lo;
       }
     }
-    if (mode == MODE_BOUND) sel_frame[w < kSelCap ? w : 0] = frame;
-    else a.q_frame[q] = run * a.max_ells + frame;
+    a.q_frame[q] = run * a.max_ells + frame;
     g.store(a.q_rng + q * 4);
   }
-  if (mode == MODE_BOUND) {
-    // start points: K rows of D doubles, element-parallel (a thread per row was a serial copy of D strided doubles:
-    // 0.23 ms per fill at D = 200)
-    __syncthreads();
-    const double* lu = a.live_u + (size_t)run * N * D;
-    double* qu = a.q_u0 + (size_t)run * K * D;
-    const int* qi = a.q_frame + (size_t)run * K;
-    for (int e = t; e < K * D; e += kT) {
-      const int w = e / D, j = e - w * D;
-      qu[e] = lu[(size_t)qi[w] * D + j];
-    }
-    __syncthreads();
-    for (int w = t; w < K; w += kT) a.q_frame[(size_t)run * K + w] = run * a.max_ells + sel_frame[w];
-  }
+}
+
+// start points of the walkers: q_u0[q] = live_u[run, r_d[q]], one thread per coordinate over the whole ensemble (a
+// thread per walker inside ns_select was a serial copy of D strided doubles: 0.23 ms per fill at D = 200)
+__global__ void __launch_bounds__(256) ns_gather(NsArgs a) {
+  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int D = a.ndim, K = a.K, N = a.nlive;
+  if (e >= (size_t)a.runs * K * D) return;
+  const size_t q = e / D;
+  const int j = (int)(e - q * D), run = (int)(q / K);
+  if (a.st[run].mode != MODE_BOUND || a.bstatus[run] != DH_OK) return;
+  a.q_u0[e] = a.live_u[((size_t)run * N + a.r_d[q]) * D + j];
 }
 
 // ---- consume the queue (sampler.py:732-778 + 1105-1185), one workgroup per run ----
@@ -1136,6 +1131,7 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
                                  a.enlarge_log, a.rebuild_mask);
       if (rc) return cleanup(rc);
       hipLaunchKernelGGL(ns_select, dim3(R), dim3(kT), 0, s, a);
+      hipLaunchKernelGGL(ns_gather, dim3((unsigned)(((size_t)R * K * D + 255) / 256)), dim3(256), 0, s, a);
       rc = unif_launch_runs(ctx, problem, R * K, D, D, 0, nullptr, nullptr, nullptr, nullptr, 0.0, nullptr,
                             a.q_rng, 0, a.r_u, a.r_v, a.r_logl, a.r_a, a.r_b, a.q_rng_out, a.run_loglstar,
                             a.run_mode, K, MODE_CUBE);
