@@ -341,7 +341,9 @@ int dh_ns_consume(dh_ctx* ctx, int runs, int nlive, int queue_size, double dlogz
  * unit-cube start, MultiEllipsoid (bound_multi=1) or Ellipsoid bound rebuilt
  * every walks*nlive calls and enlarged by `enlarge`, RWalkSampler.tune, evidence
  * integration (utils.py:1470-1492) and the final live points -- all on the
- * device for `runs` independent runs at once.  Run r seeds from
+ * device for `runs` independent runs at once.  Dimensions: any ndim <= 512 with the Ellipsoid bound (above 32
+ * the walkers are the wave-per-walker kernels, above 44 the bound is the multi-workgroup Ellipsoid.update: BASELINE
+ * config C4), ndim <= 44 with the MultiEllipsoid bound; sampler 3 (Philox) ndim <= 32.  Run r seeds from
  * SeedSequence(entropy) children keyed on first_run + r (independent of how the
  * ensemble is sharded).  records: runs x 8 doubles {logz, logzerr, niter, ncall,
  * h, nbound, status (0 ok, 1 max_fills hit, -1 failed), eff%}.
