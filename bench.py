@@ -528,6 +528,13 @@ def main():
         e2e["rebuild_sync"] = e2e_leg(True)
         # ... and with the proposals drawn from hiprand Philox streams (throughput RNG mode)
         e2e["throughput_rng"] = e2e_leg(False, rng="philox")
+        # BASELINE config C4 (200-D iid Normal, Normal prior, bound='single', sample='rslice', nlive 4000) through the
+        # same loop (wave-per-walker kernels, multi-workgroup Ellipsoid.update), rank 0 only: 4 runs to dlogz = 0.01
+        if rank == 0:
+            try:
+                e2e["config_C4"] = c4_leg(ctx)
+            except Exception as exc:  # the C4 leg must not take the headline down with it
+                e2e["config_C4"] = {"error": repr(exc)}
 
     if rank == 0:
         alg_bytes = 8 * (2 * d + 1)  # read u, write u', write logl
@@ -640,6 +647,27 @@ def main():
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+
+
+def c4_leg(ctx, runs=4, queue=1000):
+    from dynesty_amd import problems
+    prob = problems.gauss_normal_prior(200, "C4")
+    kw = dict(bound='single', sample='rslice', slices=203, dlogz=0.01, max_iter=250000)
+    ctx.ns_ensemble(prob, 1, 4000, queue, entropy=[3], max_fills=2, **kw)  # allocations, code objects
+    t0 = time.perf_counter()
+    r = ctx.ns_ensemble(prob, runs, 4000, queue, entropy=[21], **kw)
+    dt = time.perf_counter() - t0
+    out = {"what": "200-D iid Normal / Normal prior, nlive 4000, single ellipsoid, rslice x 203, device-resident loop",
+           "runs": runs, "queue_size": queue, "seconds": dt, "seconds_per_run": dt / runs,
+           "likelihood_calls_per_s": float(r["ncall"].sum() / dt), "status_ok": bool((r["status"] == 0).all()),
+           "logz_mean": float(r["logz"].mean()), "logz_se": float(r["logz"].std(ddof=1) / math.sqrt(runs)),
+           "logz_truth": float(prob.logz_truth)}
+    ref = os.path.join(ROOT, "tests", "golden", "c4_logz_ref.json")
+    if os.path.exists(ref):
+        runs_ref = json.load(open(ref))["runs"]
+        out["logz_reference_runs"] = [{"K": x["K"], "logz": x["logz"], "logzerr": x["logzerr"],
+                                       "seconds": x["seconds"]} for x in runs_ref]
+    return out
 
 
 def reference_logz_gate():
