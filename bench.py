@@ -529,8 +529,9 @@ def main():
         # ... and with the proposals drawn from hiprand Philox streams (throughput RNG mode)
         e2e["throughput_rng"] = e2e_leg(False, rng="philox")
         # BASELINE config C4 (200-D iid Normal, Normal prior, bound='single', sample='rslice', nlive 4000) through the
-        # same loop (wave-per-walker kernels, multi-workgroup Ellipsoid.update), rank 0 only: 4 runs to dlogz = 0.01
-        if rank == 0:
+        # same loop (wave-per-walker kernels, multi-workgroup Ellipsoid.update), at N = 1 only (no rank waits for
+        # another at the end of a scaling run): 4 runs to dlogz = 0.01
+        if rank == 0 and world == 1:
             try:
                 e2e["config_C4"] = c4_leg(ctx)
             except Exception as exc:  # the C4 leg must not take the headline down with it
