@@ -1150,6 +1150,9 @@ __device__ __forceinline__ int node_ellipsoid(const Lds& L, const RebuildArgs& a
 // store still in flight to another L2 channel can land after the counter's atomic and a partner then
 // reads the previous iteration's partial -- seen as 3 differing results in 2 700 eggbox rebuilds once
 // 128-point parts made multi-part nodes common), hence the explicit vmcnt(0).
+#ifndef DH_BAR_SLEEP
+#define DH_BAR_SLEEP 4
+#endif
 __device__ __forceinline__ void drain_stores() {
   __builtin_amdgcn_s_waitcnt(0x0F70);  // gfx9 encoding: vmcnt(0), expcnt / lgkmcnt untouched
 }
@@ -1163,7 +1166,7 @@ __device__ __forceinline__ bool parts_barrier(int* bar, int target) {
     int ok = 1;
     long long spins = 0;
     while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-      __builtin_amdgcn_s_sleep(4);
+      __builtin_amdgcn_s_sleep(DH_BAR_SLEEP);
       if (++spins > (1ll << 20)) {  // partners never arrived (would otherwise hang the device)
         ok = 0;
         break;
