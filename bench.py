@@ -637,10 +637,11 @@ def main():
                 "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": rb_bytes, "kernel_ms": t_rb,
                 "note": "a tree of ~55 nodes per run built level by level (critical path: "
-                        "6 levels x [k-means, covariance, 25x25 Jacobi eigensolve, "
-                        "Mahalanobis max]); latency-bound, not bandwidth-bound: the "
-                        "k-means parts keep their points resident in LDS, so the live "
-                        "set is read ~3 times per level, not 12"}
+                        "6 levels x [k-means of 10 iterations, covariance, eigen-free 25x25 "
+                        "solve (sweep inverse + repeated squaring), Mahalanobis max]); "
+                        "latency- and residency-bound, not bandwidth-bound: the k-means parts "
+                        "keep their points resident in LDS, so the live set is read ~3 times "
+                        "per level, not 12"}
         if e2e is not None:
             line["config"]["end_to_end"] = e2e
         if cpu is not None:  # the CPU baseline is timed on rank 0 at N = 1 only
