@@ -343,7 +343,9 @@ int dh_ns_consume(dh_ctx* ctx, int runs, int nlive, int queue_size, double dlogz
  * integration (utils.py:1470-1492) and the final live points -- all on the
  * device for `runs` independent runs at once.  Dimensions: any ndim <= 512 with the Ellipsoid bound (above 32
  * the walkers are the wave-per-walker kernels, above 44 the bound is the multi-workgroup Ellipsoid.update: BASELINE
- * config C4), ndim <= 44 with the MultiEllipsoid bound; sampler 3 (Philox) ndim <= 32.  Run r seeds from
+ * config C4), ndim <= 44 with the MultiEllipsoid bound; sampler 3 (Philox) ndim <= 32.  Sizes: the queue
+ * consumption keeps a run's heap and queue in LDS, 20 nlive + 36 queue_size bytes <= 150 KB and queue_size <= 2048
+ * (nlive 2000: any queue; 4000: <= 1900; 5000: <= 1390); DH_ERR_ARG otherwise.  Run r seeds from
  * SeedSequence(entropy) children keyed on first_run + r (independent of how the
  * ensemble is sharded).  records: runs x 8 doubles {logz, logzerr, niter, ncall,
  * h, nbound, status (0 ok, 1 max_fills hit, -1 failed), eff%}.
