@@ -1218,7 +1218,7 @@ __device__ int node_kmeans_part(const Lds& L, const double* pts, int* perm, int*
   __syncthreads();
   const int nb = (D + 15) >> 4;
   const int lj = lane & 15, lk = lane >> 4;
-  int lb = 0, n0 = 0, c0_tile = 0;
+  int lb = 0, lb_prev = -1, n0 = 0, c0_tile = 0, last_it = 9;
   PH_T0();
   for (int it = 0; it < 10; ++it) {
     // vq: nearest centroid, strict '<' so the lower index wins ties
@@ -1236,7 +1236,15 @@ __device__ int node_kmeans_part(const Lds& L, const double* pts, int* perm, int*
       lb = d1 < d0 ? 1 : 0;
       L.ri[t] = lb;
     }
+    {
+      // labels that moved since the last iteration (per wave, summed after the barrier): none anywhere in the node
+      // = a fixed point of the Lloyd iteration, the remaining iterations would reproduce this one bit for bit
+      const unsigned long long mv = __ballot(t < cnt && lb != lb_prev);
+      if (lane == 0) L.ri[260 + w] = __popcll(mv);
+      lb_prev = lb;
+    }
     c0_tile = __syncthreads_count(t < cnt && lb == 0);  // also publishes the labels
+    const int ch_tile = L.ri[260] + L.ri[261] + L.ri[262] + L.ri[263];
     PH_ADD(10);
     // update_cluster_means: per-cluster sums = Labels^T X on the matrix cores; wave w
     // contracts its 64 points (rows 0/1 of the 16-row A operand are the two indicators)
@@ -1296,13 +1304,16 @@ __device__ int node_kmeans_part(const Lds& L, const double* pts, int* perm, int*
     }
     n0 = c0_tile;
     if (np > 1) {
-      if (t == 0) st_agent(kp + (size_t)q * KP + 2 * D, (double)c0_tile);
+      if (t == 0) {
+        st_agent(kp + (size_t)q * KP + 2 * D, (double)c0_tile);
+        st_agent(kp + (size_t)q * KP + 2 * D + 1, (double)ch_tile);
+      }
       if (!parts_barrier(bar, np * (it + 1))) return -1;
       // the partners' partials: 8 independent bypassing loads in flight per round trip (a plain
       // loop serialises np ~2 us memory-side round trips), summed in part order.  Column 2D is
       // the label-0 count, read by every thread.
       {
-        const int col = t < 2 * D ? t : 2 * D;
+        const int col = t < 2 * D + 2 ? t : 2 * D;  // column 2D + 1: the number of labels that moved
         double sum = 0.0;
         for (int pp0 = 0; pp0 < np; pp0 += 8) {
           double part[8];
@@ -1312,13 +1323,13 @@ __device__ int node_kmeans_part(const Lds& L, const double* pts, int* perm, int*
 #pragma unroll
           for (int uu = 0; uu < 8; ++uu) sum += part[uu];
         }
-        if (t < 2 * D) L.sums[t] = sum;
-        if (t == 2 * D) L.sums[2 * D] = sum;
+        if (t < 2 * D + 2) L.sums[t] = sum;
       }
       __syncthreads();
       n0 = (int)L.sums[2 * D];
     }
     __syncthreads();
+    const int moved = np > 1 ? (int)L.sums[2 * D + 1] : ch_tile;
     const int n1 = count - n0;
     if (t < D) {
       if (n0 > 0) L.cen[t] = L.sums[t] / (double)n0;  // empty cluster keeps its centroid
@@ -1326,6 +1337,10 @@ __device__ int node_kmeans_part(const Lds& L, const double* pts, int* perm, int*
     }
     __syncthreads();
     PH_ADD(12);
+    if (moved == 0) {  // (never at it = 0: every label counts as moved there)
+      last_it = it;
+      break;
+    }
   }
   if (min(n0, count - n0) < min_size) return n0;  // split rejected (:1521-1522): no partition needed
   // ---- stable partition by label (label 0 first) ----
@@ -1340,7 +1355,7 @@ __device__ int node_kmeans_part(const Lds& L, const double* pts, int* perm, int*
   const int rank0 = before0 + __popcll(m0 & lt);
   int off0 = 0, off1 = n0;
   if (np > 1) {
-    const double* kp = kp1;  // the last iteration (it = 9) used parity 1
+    const double* kp = (last_it & 1) ? kp1 : kp0;  // the last iteration run
     for (int pp0 = 0; pp0 < q; pp0 += 8) {
       double part[8];
 #pragma unroll
@@ -1362,7 +1377,7 @@ __device__ int node_kmeans_part(const Lds& L, const double* pts, int* perm, int*
       perm2[start + pos] = perm[s0 + t];
   }
   if (np > 1) {
-    if (!parts_barrier(bar, np * 11)) return -1;
+    if (!parts_barrier(bar, np * (last_it + 2))) return -1;
     if (valid) perm[s0 + t] = __hip_atomic_load(perm2 + s0 + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   } else {
     __threadfence_block();
