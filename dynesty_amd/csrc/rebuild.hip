@@ -83,7 +83,6 @@ struct RebuildArgs {
   // ("parts"), each keeping its TP points resident in LDS for all ten iterations
   int fin_extra_off;  // k_finish: byte offset of the LDS node/result-list copies (0: keep them in global memory)
   int fin_res_lds;    // 1: the result-list arena is in LDS too
-  int tpe;            // points per tile of k_ell<false> (cov / fmax passes of the tree nodes)
   int tps;            // points per k-means part (the tile k_split keeps resident); a node of c points has ceil(c / tps) parts
   int maxp;           // max parts of one run at one level: n / tps + maxw + 1
   int* nparts;        // (levels+1) x runs
@@ -1412,7 +1411,6 @@ __device__ __forceinline__ double logaddexp_d(double x, double y) {
 constexpr size_t kLdsLimit = 159 * 1024;
 // separate Jacobi buffers only while two workgroups still fit one CU's 160 KB
 constexpr size_t kLdsSeparate = 79 * 1024;
-constexpr size_t kLdsSeparate3 = 53 * 1024;  // ... while THREE still fit (kernels on a smaller tile)
 __host__ __device__ inline size_t rebuild_lds_base_bytes(int D, int TP) {
   const int LD = D | 1;
   const size_t dbl = (size_t)TP * LD + 4 * (size_t)D * LD + 7 * (size_t)D + 2 + kThreads + 128;
@@ -1464,7 +1462,7 @@ __device__ __forceinline__ void carve(Lds& L, unsigned char* smem, int D, int TP
   const int P = (D + 1) & ~1;
   L.JLD = P | 1;
   const size_t jdbl = 4 * (size_t)P * L.JLD;
-  L.j_alias = rebuild_lds_base_bytes(D, TP) + jdbl * 8 > (TP < kThreads ? kLdsSeparate3 : kLdsSeparate);
+  L.j_alias = rebuild_lds_base_bytes(D, TP) + jdbl * 8 > kLdsSeparate;
   double* jb = L.j_alias ? L.tile : (double*)(smem + rebuild_lds_base_bytes(D, TP));
   L.JA[0] = jb;
   L.JA[1] = jb + (size_t)P * L.JLD;
@@ -1955,10 +1953,9 @@ __device__ __forceinline__ bool ell_body(const RebuildArgs& a, const Lds& L, con
 // SLOW = true: the reference's route for every node -- the kernel of the diagnostic mode
 // DH_REBUILD_FAST=0.  Two kernels so that the common one stays small (registers: two workgroups per CU).
 template <bool SLOW>
-#ifndef DH_ELL_OCC
-#define DH_ELL_OCC 2
-#endif
-__global__ void __launch_bounds__(kThreads, SLOW ? 1 : DH_ELL_OCC) k_ell(RebuildArgs a, int level, int G) {
+// (two workgroups per CU: held to the 168 registers of three, with a 128-point tile so that LDS would allow it, the
+// eigen-free path spills and the rebuild loses 7 %)
+__global__ void __launch_bounds__(kThreads, SLOW ? 1 : 2) k_ell(RebuildArgs a, int level, int G) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int run = blockIdx.x / G, g = blockIdx.x % G;
   const int* list = a.ell_list + (size_t)run * 2 * a.maxw;
@@ -1971,7 +1968,7 @@ __global__ void __launch_bounds__(kThreads, SLOW ? 1 : DH_ELL_OCC) k_ell(Rebuild
   if (a.status[run] != DH_OK) return;
   const int D = a.d;
   Lds L;
-  carve(L, smem, D, SLOW ? kThreads : a.tpe);
+  carve(L, smem, D);
   const RunView v = view_of(a, run, L.LD);
   for (int slot = g; slot < cnt; slot += G)
     if (!ell_body<SLOW>(a, L, v, run, level, list[slot])) return;
@@ -2509,7 +2506,7 @@ size_t rebuild_lds_bytes(int D, int TP = kThreads) {
   const size_t base = rebuild_lds_base_bytes(D, TP);
   const int P = (D + 1) & ~1;
   const size_t jb = 4 * (size_t)P * (P | 1) * 8;
-  return base + jb > (TP < kThreads ? kLdsSeparate3 : kLdsSeparate) ? base : base + jb;  // else the Jacobi buffers overlay the tile
+  return base + jb > kLdsSeparate ? base : base + jb;  // else the Jacobi buffers overlay the tile
 }
 
 }  // namespace
@@ -2614,12 +2611,6 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
   }
   a.maxp = n / a.tps + a.maxw + 1;
   const size_t lds_split = split_lds_bytes(d, a.tps);
-  a.tpe = kThreads;
-  if (const char* e = getenv("DH_ELL_TP")) {
-    const int v = atoi(e);
-    if (v == 64 || v == 128 || v == 192 || v == 256) a.tpe = v;
-  }
-  const size_t lds_ell = rebuild_lds_bytes(d, a.tpe);
   // the parts of one node meet at a device-scope barrier, so they must all be resident at the
   // same time: 256 parts (65 536 points per run) fit the 256 CUs with room to spare
   if (mode == 0 && n > 256 * kThreads)
@@ -2814,7 +2805,7 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
   for (int L = 0; L < nlev; ++L) {
     hipLaunchKernelGGL(k_split, dim3(runs * a.maxp), dim3(kThreads), lds_split, ctx->stream, a, L);
     if (a.fast)
-      hipLaunchKernelGGL(k_ell<false>, dim3(runs * 2 * a.maxw), dim3(kThreads), lds_ell, ctx->stream, a, L, 2 * a.maxw);
+      hipLaunchKernelGGL(k_ell<false>, dim3(runs * 2 * a.maxw), dim3(kThreads), lds, ctx->stream, a, L, 2 * a.maxw);
     else
       hipLaunchKernelGGL(k_ell<true>, dim3(runs * 2 * a.maxw), dim3(kThreads), lds, ctx->stream, a, L, 2 * a.maxw);
   }
