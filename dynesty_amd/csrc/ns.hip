@@ -90,6 +90,7 @@ struct NsArgs {
   double* b_lv;
   // results
   double* records;  // runs x 8: logz, logzerr, niter, ncall, h, nbound, status, eff
+  double* fin_ws;   // runs x 3 nlive: ns_finish's per-point terms
   // dh_ns_consume (one queue consumption as an operator of its own): death list of THIS call
   int dead_rel;     // 1: dead_logl rows are K wide and hold this call's deaths from index 0
   int* trace_slot;  // runs x K or null: slot of every death
@@ -779,70 +780,83 @@ __global__ void __launch_bounds__(kT) ns_consume(NsArgs a) {
 __global__ void __launch_bounds__(kT) ns_finish(NsArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int run = blockIdx.x, t = threadIdx.x, N = a.nlive;
-  const int HC = heap_cap(N);
-  HeapEnt* hp = (HeapEnt*)smem;
-  double* sorted = (double*)(hp + HC);  // N  the final live log-likelihoods, ascending
-  for (int i = t; i < HC; i += kT)
-    hp[i] = i < N ? heap_ent(a.heap_key[(size_t)run * N + i], a.heap_slot[(size_t)run * N + i])
-                  : heap_ent(INFINITY, 0);
+  // the final live log-likelihoods, ascending: a bitonic sort of the keys over the whole workgroup (values only -- the
+  // integration below does not care which slot a value came from; N pops of the heap by one wavefront were 15 ms of
+  // the eggbox run's 190 at N = 5 000)
+  double* sorted = (double*)smem;  // P >= N, a power of two; the padding sorts to the end
+  int P = 1;
+  while (P < N) P <<= 1;
+  for (int i = t; i < P; i += kT) sorted[i] = i < N ? a.heap_key[(size_t)run * N + i] : INFINITY;
   __syncthreads();
-  if (t < 64) {
-    // heap sort by wave 0: N pops of the 64-ary heap (two levels each)
-    int n = N;
-    for (int i = 0; i < N; ++i) {
-      const HeapEnt root = hp[0];
-      --n;
-      const HeapEnt last = hp[n];
-      if (t == 0) {
-        sorted[i] = root.x;
-        hp[n] = heap_ent(INFINITY, 0);
+  for (int k = 2; k <= P; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = t; i < P; i += kT) {
+        const int l = i ^ j;
+        if (l > i) {
+          const double x = sorted[i], y = sorted[l];
+          const bool up = (i & k) == 0;
+          if ((x > y) == up) {
+            sorted[i] = y;
+            sorted[l] = x;
+          }
+        }
       }
-      wave_lds_fence();
-      if (n > 0) heap64_sift(hp, n, 0, last.x, heap_slot_of(last), t);
+      __syncthreads();
     }
+  // The final live points, lowest first (sampler.py:780-930).  What Results reports is
+  // compute_integrals over the whole run (sampler.py:1342-1348, utils.py:1411-1467): ln Z the
+  // accumulated logaddexp, and the partial informations H_i normalised by the FINAL Z,
+  //   H_i = (1/Z_f) sum_{k<=i} [L ln L]-terms - (Z_i / Z_f) ln Z_f,   var ln Z = |sum_i (H_i - H_{i-1}) dlnX_i|.
+  // First pass: ln Z_f.  With G = e^{lnZ}(H + lnZ) (additive) the state after the dead points gives
+  // H_n = e^{lnZ_n - lnZ_f} (H^run_n + lnZ_n - lnZ_f); over the dead points dlnX is constant, so their
+  // share of the variance sum telescopes to dlnX * H_n.
+  // Everything that does not depend on the running sums -- the volumes' logarithms, the trapezoid weights, the
+  // L e^L terms: ~10 transcendentals per point -- is computed by all threads into three arrays first; one thread then
+  // runs the two recurrences over them in the reference's order (one thread doing all of it was 17 ms at N = 5 000).
+  __shared__ double bc[2];
+  NsRun& r = a.st[run];
+  const double lv0 = r.logvol, dead_prev = r.dead_prev;
+  double* W = a.fin_ws + (size_t)run * 3 * N;  // trapezoid ln-weights
+  double* DL = W + N;                          // -d ln X
+  double* T = DL + N;                          // ln dX, then the L e^L terms
+  for (int i = 1 + t; i <= N; i += kT) {
+    const double cur = sorted[i - 1], prev = i > 1 ? sorted[i - 2] : dead_prev;
+    const double lv = lv0 + log(1.0 - (double)i / ((double)N + 1.0));
+    const double lvprev = i > 1 ? lv0 + log(1.0 - (double)(i - 1) / ((double)N + 1.0)) : lv0;
+    const double dl = lvprev - lv;
+    const double logdvol = lv + log(0.5 * expm1(dl));
+    W[i - 1] = logaddexp_dev(cur, prev) + logdvol;
+    DL[i - 1] = dl;
+    T[i - 1] = logdvol;
   }
   __syncthreads();
   if (t == 0) {
-    NsRun& r = a.st[run];
-    // The final live points, lowest first (sampler.py:780-930).  What Results reports is
-    // compute_integrals over the whole run (sampler.py:1342-1348, utils.py:1411-1467): ln Z the
-    // accumulated logaddexp, and the partial informations H_i normalised by the FINAL Z,
-    //   H_i = (1/Z_f) sum_{k<=i} [L ln L]-terms - (Z_i / Z_f) ln Z_f,   var ln Z = |sum_i (H_i - H_{i-1}) dlnX_i|.
-    // First pass: ln Z_f.  With G = e^{lnZ}(H + lnZ) (additive) the state after the dead points gives
-    // H_n = e^{lnZ_n - lnZ_f} (H^run_n + lnZ_n - lnZ_f); over the dead points dlnX is constant, so their
-    // share of the variance sum telescopes to dlnX * H_n.
-    const double lv0 = r.logvol;
     double logz_f = r.logz;
-    {
-      double prev = r.dead_prev, lvprev = lv0;
-      for (int i = 1; i <= N; ++i) {
-        const double cur = sorted[i - 1];
-        const double lv = lv0 + log(1.0 - (double)i / ((double)N + 1.0));
-        const double logdvol = lv + log(0.5 * expm1(lvprev - lv));
-        logz_f = logaddexp_dev(logz_f, logaddexp_dev(cur, prev) + logdvol);
-        prev = cur;
-        lvprev = lv;
-      }
-    }
+    for (int i = 0; i < N; ++i) logz_f = logaddexp_dev(logz_f, W[i]);
+    bc[0] = logz_f;
+  }
+  __syncthreads();
+  const double logz_f = bc[0];
+  for (int i = 1 + t; i <= N; i += kT) {
+    const double cur = sorted[i - 1], prev = i > 1 ? sorted[i - 2] : dead_prev;
+    const double logdvol = T[i - 1];
+    const double t0 = exp(prev - logz_f + logdvol), t1 = exp(cur - logz_f + logdvol);
+    T[i - 1] = (t1 > 0.0 ? t1 * cur : 0.0) + (t0 > 0.0 ? t0 * prev : 0.0);
+  }
+  __syncthreads();
+  if (t == 0) {
     const double dlv = log(((double)N + 1.0) / (double)N);
     const double wn = exp(r.logz - logz_f);
     double hpart = r.it > 0 && wn > 0.0 ? wn * (r.h + r.logz) : 0.0;  // (1/Z_f) sum of the L ln L terms so far
     double hcur = hpart - (r.it > 0 ? wn * logz_f : 0.0);              // H_n
     double logzvar = hcur * dlv;
-    double logz = r.logz, prev = r.dead_prev, lvprev = lv0;
-    for (int i = 1; i <= N; ++i) {
-      const double cur = sorted[i - 1];
-      const double lv = lv0 + log(1.0 - (double)i / ((double)N + 1.0));
-      const double dl = lvprev - lv;
-      const double logdvol = lv + log(0.5 * expm1(dl));
-      logz = logaddexp_dev(logz, logaddexp_dev(cur, prev) + logdvol);
-      const double t0 = exp(prev - logz_f + logdvol), t1 = exp(cur - logz_f + logdvol);
-      hpart += (t1 > 0.0 ? t1 * cur : 0.0) + (t0 > 0.0 ? t0 * prev : 0.0);
+    double logz = r.logz;
+    for (int i = 0; i < N; ++i) {
+      logz = logaddexp_dev(logz, W[i]);
+      hpart += T[i];
       const double hi = hpart - logz_f * exp(logz - logz_f);
-      logzvar += (hi - hcur) * dl;
+      logzvar += (hi - hcur) * DL[i];
       hcur = hi;
-      prev = cur;
-      lvprev = lv;
     }
     const double h = hcur;
     double* rec = a.records + (size_t)run * 8;
@@ -1042,6 +1056,7 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
                o_ba = take((size_t)R * me * dd * 8), o_bx = take((size_t)R * me * dd * 8),
                o_bl = take((size_t)R * me * D * 8), o_bg = take((size_t)R * me * 8),
                o_rec = take((size_t)R * 8 * 8), o_ent = take((size_t)n_words * 4),
+               o_fw = take((size_t)R * 3 * N * 8),
                o_lit = take(want_pt ? (size_t)R * N * 4 : 8), o_pid = take(want_pt ? (size_t)R * a.cap * 4 : 8),
                o_pit = take(want_pt ? (size_t)R * a.cap * 4 : 8), o_pnc = take(want_pt ? (size_t)R * a.cap * 4 : 8);
   char* base = nullptr;
@@ -1086,6 +1101,7 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
   a.b_axl = (double*)(base + o_bl);
   a.b_lv = (double*)(base + o_bg);
   a.records = (double*)(base + o_rec);
+  a.fin_ws = (double*)(base + o_fw);
   if (want_pt) {
     a.live_it = (int*)(base + o_lit);
     a.dead_id = (int*)(base + o_pid);
