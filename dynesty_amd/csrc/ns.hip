@@ -441,33 +441,131 @@ __global__ void __launch_bounds__(256) ns_gather(NsArgs a) {
 
 constexpr int kEPT = 8;  // deaths per lane in the scan phase: K <= kEPT * kT
 
-// The serial part of the queue consumption (sampler.py:741-776), run by wave 0: stale test,
-// death record, heap update.  Returns the number of deaths (wave-uniform).
-__device__ __forceinline__ int consume_heap(HeapEnt* hp, int* src, const double* ql, double* dcur, int* dj,
-                                            int* dslot, int* dsrc, int N, int K, long long room, int limit,
-                                            int* jcap, int lane) {
-  int ndead = 0;
+// LDS of ns_consume: keys and slot sources by slot, the sorted slot order (padded to a power of two), the queue's
+// arrays and the buffer of low replacements
+__host__ __device__ inline size_t ns_consume_lds(int N, int K) {
+  size_t P = 1;
+  while (P < (size_t)N) P <<= 1;
+  return (size_t)N * 12 + (size_t)K * 52 + P * 2 + 64;
+}
+
+// The serial part of the queue consumption (sampler.py:741-776), run by wave 0: stale test, death record,
+// replacement.  The live points are NOT kept in a priority queue: the run's slots are sorted once per fill by
+// (log-likelihood, slot) -- `sidx` -- and the worst live point is then either the next unconsumed entry of that order
+// or the smallest of the replacements made during this fill.  Of those only the ones below theta = the K-th smallest
+// original value can ever become the worst point within K deaths (K originals stand before any other), so they are
+// the only ones kept, unsorted, in a buffer B whose minimum is re-scanned by the wave when it is consumed.  A step is
+// a few LDS words instead of two sift levels of a 64-ary heap (1 950 cycles).  Ties die lowest slot first, as the
+// reference's np.argmin picks them (sampler.py:1107).  Returns the number of deaths (wave-uniform); *newmin = the
+// worst live log-likelihood after the walk.
+struct WorstKey {
+  double key;
+  int slot;
+};
+__device__ __forceinline__ bool key_before(double ka, int sa, double kb, int sb) { return ka < kb || (ka == kb && sa < sb); }
+
+__device__ __forceinline__ int consume_sorted(const double* skey, const unsigned short* sidx, int* src, const double* ql,
+                                              double* dcur, int* dj, int* dslot, int* dsrc, double* bkey, int* bslot,
+                                              int* bsrc, int N, int K, long long room, int limit, int* jcap,
+                                              double* newmin, int lane) {
+  int ndead = 0, ptr = 0, nb = 0, bpos = -1;
   *jcap = -1;
+  const double theta = K < N ? skey[sidx[K]] : INFINITY;
+  // The queue and the sorted order are walked through registers: every lane holds one of the next 64 entries, the
+  // current one comes by readlane (the index is wave-uniform) -- no LDS round trip on the serial chain.
+  auto lane_d = [](double v, int l) {
+    const int lo = __builtin_amdgcn_readlane((int)(unsigned)__double_as_longlong(v), l);
+    const int hi = __builtin_amdgcn_readlane((int)(unsigned)(__double_as_longlong(v) >> 32), l);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+  };
+  int pb = 0;  // sorted positions pb .. pb + 63 are in the lanes
+  int my_slot = pb + lane < N ? (int)sidx[pb + lane] : 0x7fffffff;
+  double my_key = pb + lane < N ? skey[my_slot] : INFINITY;
+  int sslot = __builtin_amdgcn_readlane(my_slot, 0);
+  double skeyp = lane_d(my_key, 0), bmin = INFINITY;
+  int bminslot = 0x7fffffff;
+  double my_q = 0.0;
   for (int j = 0; j < K; ++j) {
-    const HeapEnt root = hp[0];
-    const double lj = ql[j];
-    if (!(lj > root.x)) continue;  // stale proposal (sampler.py:774-776)
-    if (ndead >= room) {           // dead-point store exhausted
+    if ((j & 63) == 0) my_q = j + lane < K ? ql[j + lane] : 0.0;
+    const bool from_b = nb > 0 && key_before(bmin, bminslot, skeyp, sslot);
+    const double worst = from_b ? bmin : skeyp;
+    const double lj = lane_d(my_q, j & 63);
+    if (!(lj > worst)) continue;  // stale proposal (sampler.py:774-776)
+    if (ndead >= room) {          // dead-point store exhausted
       *jcap = j;
       break;
     }
-    const int s = heap_slot_of(root);
+    int s, from;
+    if (from_b) {
+      s = bminslot;
+      from = bsrc[bpos];
+      // remove B[bpos] (the last entry takes its place) and find the new minimum with the whole wave
+      --nb;
+      wave_lds_fence();
+      if (lane == 0 && bpos != nb) {
+        bkey[bpos] = bkey[nb];
+        bslot[bpos] = bslot[nb];
+        bsrc[bpos] = bsrc[nb];
+      }
+      wave_lds_fence();
+      double mk = INFINITY;
+      int ms = 0x7fffffff, mp = -1;
+      for (int q = lane; q < nb; q += 64) {
+        const double kq = bkey[q];
+        const int sq = bslot[q];
+        if (key_before(kq, sq, mk, ms)) {
+          mk = kq;
+          ms = sq;
+          mp = q;
+        }
+      }
+      double kmin;
+      (void)wave_argmin(mk, &kmin);
+      // among the lanes holding kmin the lowest slot wins
+      const unsigned cand = (nb > 0 && mk == kmin) ? (unsigned)ms : 0xFFFFFFFFu;
+      const unsigned smin = wave_min_u32(cand);
+      const unsigned long long win = __ballot(cand == smin && mp >= 0);
+      const int wl = win ? __ffsll((long long)win) - 1 : 0;
+      bpos = __builtin_amdgcn_readlane(mp, wl);
+      bmin = nb > 0 ? kmin : INFINITY;
+      bminslot = nb > 0 ? (int)smin : 0x7fffffff;
+    } else {
+      s = sslot;
+      from = -1;
+      ++ptr;
+      if (ptr - pb == 64) {  // next 64 positions of the sorted order
+        pb = ptr;
+        my_slot = pb + lane < N ? (int)sidx[pb + lane] : 0x7fffffff;
+        my_key = pb + lane < N ? skey[my_slot] : INFINITY;
+      }
+      sslot = __builtin_amdgcn_readlane(my_slot, ptr - pb);
+      skeyp = lane_d(my_key, ptr - pb);
+    }
     if (lane == 0) {
-      dcur[ndead] = root.x;
+      dcur[ndead] = worst;
       dj[ndead] = j;
       dslot[ndead] = s;
-      dsrc[ndead] = src[s];
+      dsrc[ndead] = from;
       src[s] = j;
+      if (lj < theta) {  // may become the worst point again within this fill
+        bkey[nb] = lj;
+        bslot[nb] = s;
+        bsrc[nb] = j;
+      }
+    }
+    if (lj < theta) {
+      if (nb == 0 || key_before(lj, s, bmin, bminslot)) {
+        bmin = lj;
+        bminslot = s;
+        bpos = nb;
+      }
+      ++nb;
     }
     ++ndead;
-    heap64_sift(hp, N, 0, lj, s, lane);
     if (ndead == limit) break;
   }
+  wave_lds_fence();
+  *newmin = (nb > 0 && key_before(bmin, bminslot, skeyp, sslot)) ? bmin : skeyp;
   return ndead;
 }
 
@@ -480,25 +578,65 @@ __global__ void __launch_bounds__(kT) ns_consume(NsArgs a) {
   if (mode != MODE_CUBE && mode != MODE_BOUND) return;
   if (mode == MODE_BOUND && a.bstatus[run] != DH_OK) return;
   long long pt_ = a.prof ? clock64() : 0;
-  const int HC = heap_cap(N);
-  HeapEnt* hp = (HeapEnt*)smem;            // HC  64-ary min-heap over (logl, slot), entries >= N are +inf sentinels
-  double* ql = (double*)(hp + HC);         // K   proposal logl
-  double* dcur = ql + K;                   // K   death list: logl of the dead point
-  int* src = (int*)(dcur + K);             // N   queue index now living in the slot, -1 = original
+  int P = 1;
+  while (P < N) P <<= 1;
+  double* skey = (double*)smem;     // N   live log-likelihoods by slot
+  double* ql = skey + N;            // K   proposal logl
+  double* dcur = ql + K;            // K   death list: logl of the dead point
+  double* bkey = dcur + K;          // K   low replacements of this fill (see consume_sorted)
+  int* src = (int*)(bkey + K);      // N   queue index now living in the slot, -1 = original
   int* qc = src + N;                // K   calls
   int* dj = qc + K;                 // K   death list: queue index of the replacement
   int* dslot = dj + K;              // K               slot
   int* dsrc = dslot + K;            // K               content source at death
   int* qborn = dsrc + K;            // K   (per-point bookkeeping only) death index at which entry j went live
+  int* bslot = qborn + K;           // K
+  int* bsrc = bslot + K;            // K
+  unsigned short* sidx = (unsigned short*)(bsrc + K);  // P   slots in ascending (logl, slot) order; 0xFFFF = padding
   __shared__ int misc[8];
   __shared__ double wred[2][4];
   __shared__ double bcast[4];
   __shared__ long long lred[4];
-  for (int i = t; i < HC; i += kT) {
-    hp[i] = i < N ? heap_ent(a.heap_key[(size_t)run * N + i], a.heap_slot[(size_t)run * N + i])
-                  : heap_ent(INFINITY, 0);
-    if (i < N) src[i] = -1;
+  for (int i = t; i < P; i += kT) {
+    if (i < N) {
+      skey[i] = a.live_logl[(size_t)run * N + i];
+      src[i] = -1;
+    }
+    sidx[i] = i < N ? (unsigned short)i : (unsigned short)0xFFFF;
   }
+  __syncthreads();
+  // bitonic sort of the slots by (log-likelihood, slot); the padding sorts to the end
+  // (pairs enumerated directly and four at a time: all index reads, then all key reads, then the exchanges -- one
+  // LDS round trip per batch instead of a read -> wait -> branch chain per element)
+  for (int k = 2; k <= P; k <<= 1)
+    for (int jj = k >> 1; jj > 0; jj >>= 1) {
+      for (int p0 = t; p0 < P / 2; p0 += 4 * kT) {
+        int ii[4], ia[4], ib[4];
+        double ka[4], kb[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int pp = p0 + u * kT;
+          const int pc = pp < P / 2 ? pp : 0;
+          ii[u] = ((pc & ~(jj - 1)) << 1) | (pc & (jj - 1));  // the pair's lower element; its partner is ii | jj
+          ia[u] = sidx[ii[u]];
+          ib[u] = sidx[ii[u] | jj];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          ka[u] = ia[u] == 0xFFFF ? INFINITY : skey[ia[u] == 0xFFFF ? 0 : ia[u]];
+          kb[u] = ib[u] == 0xFFFF ? INFINITY : skey[ib[u] == 0xFFFF ? 0 : ib[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const bool a_after_b = key_before(kb[u], ib[u], ka[u], ia[u]);
+          if (p0 + u * kT < P / 2 && a_after_b == ((ii[u] & k) == 0)) {
+            sidx[ii[u]] = (unsigned short)ib[u];
+            sidx[ii[u] | jj] = (unsigned short)ia[u];
+          }
+        }
+      }
+      __syncthreads();
+    }
   int acc = 0, rej = 0;
   for (int j = t; j < K; j += kT) {
     const size_t q = (size_t)run * K + j;
@@ -538,11 +676,13 @@ __global__ void __launch_bounds__(kT) ns_consume(NsArgs a) {
   // ---- phase A: the heap walk (wave 0, lanes cooperating on every sift level) ----
   if (t < 64) {
     int jcap;
-    const int nd = consume_heap(hp, src, ql, dcur, dj, dslot, dsrc, N, K, a.dead_rel ? (long long)K + 1 : a.cap - it0,
-                                K + 1, &jcap, t);
+    double nm;
+    const int nd = consume_sorted(skey, sidx, src, ql, dcur, dj, dslot, dsrc, bkey, bslot, bsrc, N, K,
+                                  a.dead_rel ? (long long)K + 1 : a.cap - it0, K + 1, &jcap, &nm, t);
     if (t == 0) {
       misc[0] = nd;
       misc[1] = jcap;
+      bcast[2] = nm;
     }
   }
   __syncthreads();
@@ -644,17 +784,17 @@ __global__ void __launch_bounds__(kT) ns_consume(NsArgs a) {
     lred[wv] = calls;
   }
   NS_PROF(2);
-  // ---- replay the heap walk up to the stop index (once per run) ----
+  // ---- replay the walk up to the stop index (once per run): the sorted order is untouched ----
   if (nkeep < ndead) {
     __syncthreads();
-    for (int i = t; i < N; i += kT) {
-      hp[i] = heap_ent(a.heap_key[(size_t)run * N + i], a.heap_slot[(size_t)run * N + i]);
-      src[i] = -1;
-    }
+    for (int i = t; i < N; i += kT) src[i] = -1;
     __syncthreads();
     if (t < 64) {
       int jc;
-      consume_heap(hp, src, ql, dcur, dj, dslot, dsrc, N, K, a.dead_rel ? (long long)K + 1 : a.cap - it0, nkeep, &jc, t);
+      double nm;
+      consume_sorted(skey, sidx, src, ql, dcur, dj, dslot, dsrc, bkey, bslot, bsrc, N, K,
+                     a.dead_rel ? (long long)K + 1 : a.cap - it0, nkeep, &jc, &nm, t);
+      if (t == 0) bcast[2] = nm;
     }
   }
   __syncthreads();
@@ -672,7 +812,7 @@ __global__ void __launch_bounds__(kT) ns_consume(NsArgs a) {
       r.logvol = logvol0 - (double)nkeep * dlv;
       r.it = it0 + nkeep;
     }
-    r.loglstar = hp[0].x;
+    r.loglstar = bcast[2];
     r.nfill += 1;
     {
       // entries popped after the last kept death found no worse point to replace any more in this fill: the
@@ -769,10 +909,6 @@ __global__ void __launch_bounds__(kT) ns_consume(NsArgs a) {
       lv[to] = rv[from];
     }
   }
-  for (int i = t; i < N; i += kT) {
-    a.heap_key[(size_t)run * N + i] = hp[i].x;
-    a.heap_slot[(size_t)run * N + i] = heap_slot_of(hp[i]);
-  }
   NS_PROF(5);
 }
 
@@ -786,7 +922,7 @@ __global__ void __launch_bounds__(kT) ns_finish(NsArgs a) {
   double* sorted = (double*)smem;  // P >= N, a power of two; the padding sorts to the end
   int P = 1;
   while (P < N) P <<= 1;
-  for (int i = t; i < P; i += kT) sorted[i] = i < N ? a.heap_key[(size_t)run * N + i] : INFINITY;
+  for (int i = t; i < P; i += kT) sorted[i] = i < N ? a.live_logl[(size_t)run * N + i] : INFINITY;
   __syncthreads();
   for (int k = 2; k <= P; k <<= 1)
     for (int j = k >> 1; j > 0; j >>= 1) {
@@ -890,7 +1026,7 @@ int dh_ns_consume(dh_ctx* ctx, int runs, int nlive, int queue_size, double dlogz
   const int R = runs, N = nlive, K = queue_size;
   if (K > kEPT * kT) return fail(ctx, DH_ERR_ARG, "ns_consume: queue_size %d > %d", K, kEPT * kT);
   const size_t lds_heap = (size_t)heap_cap(N) * 16 + (size_t)N * 8 + 64;
-  const size_t lds_cons = (size_t)heap_cap(N) * 16 + (size_t)N * 4 + (size_t)K * 36 + 64;
+  const size_t lds_cons = ns_consume_lds(N, K);
   const size_t lds_max = lds_cons > lds_heap ? lds_cons : lds_heap;
   if (lds_max > 150 * 1024) return fail(ctx, DH_ERR_ARG, "ns_consume: nlive/queue too large for LDS");
   NsArgs a{};
@@ -1121,7 +1257,7 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
   int rc = eval_launch_dev(ctx, problem, R * N, a.live_u, a.live_v, a.live_logl);
   if (rc) return cleanup(rc);
   const size_t lds_heap = (size_t)heap_cap(N) * 16 + (size_t)N * 8 + 64;
-  const size_t lds_cons = (size_t)heap_cap(N) * 16 + (size_t)N * 4 + (size_t)K * 36 + 64;
+  const size_t lds_cons = ns_consume_lds(N, K);
   if (K > kEPT * kT) return cleanup(fail(ctx, DH_ERR_ARG, "ns_ensemble: queue_size %d > %d", K, kEPT * kT));
   if (lds_cons > 150 * 1024) return cleanup(fail(ctx, DH_ERR_ARG, "ns_ensemble: nlive/queue too large for LDS"));
   const size_t lds_max = lds_cons > lds_heap ? lds_cons : lds_heap;

@@ -327,8 +327,8 @@ int dh_bound_draw(dh_ctx* ctx, const uint64_t* state4, int nsamp, int d, int m,
  *                             reference counts iterations from 1); dead_it runs x K = that value for every
  *                             dead point ('it'); dead_nc runs x K = likelihood calls spent on its replacement
  *                             ('nc': every queue entry popped since the previous death); dead_slot is 'id'.
- * Deviations from the reference, both documented in DESIGN.md: equal log-likelihoods die in heap order
- * (reference: lowest slot first) and the plateau volume steps (sampler.py:1110-1127) are not taken. */
+ * Equal log-likelihoods die lowest slot first, as in the reference (np.argmin, sampler.py:1107).  Deviation
+ * documented in DESIGN.md: the plateau volume steps (sampler.py:1110-1127) are not taken. */
 int dh_ns_consume(dh_ctx* ctx, int runs, int nlive, int queue_size, double dlogz, double* live_logl,
                   const double* q_logl, const int32_t* q_ncalls, double* state, double* dead_logl,
                   int32_t* dead_slot, int32_t* dead_src, int32_t* ndead, int32_t* stopped, int32_t* live_it,
@@ -344,8 +344,9 @@ int dh_ns_consume(dh_ctx* ctx, int runs, int nlive, int queue_size, double dlogz
  * device for `runs` independent runs at once.  Dimensions: any ndim <= 512 with the Ellipsoid bound (above 32
  * the walkers are the wave-per-walker kernels, above 44 the bound is the multi-workgroup Ellipsoid.update: BASELINE
  * config C4), ndim <= 44 with the MultiEllipsoid bound; sampler 3 (Philox) ndim <= 32.  Sizes: the queue
- * consumption keeps a run's heap and queue in LDS, 20 nlive + 36 queue_size bytes <= 150 KB and queue_size <= 2048
- * (nlive 2000: any queue; 4000: <= 1900; 5000: <= 1390); DH_ERR_ARG otherwise.  Run r seeds from
+ * consumption keeps a run's keys, their sorted order and the queue in LDS, 12 nlive + 2 P + 52 queue_size bytes
+ * <= 150 KB (P = nlive rounded up to a power of two) and queue_size <= 2048 (nlive 2000: any queue; 4000: <= 1870;
+ * 5000: <= 1480); DH_ERR_ARG otherwise.  Run r seeds from
  * SeedSequence(entropy) children keyed on first_run + r (independent of how the
  * ensemble is sharded).  records: runs x 8 doubles {logz, logzerr, niter, ncall,
  * h, nbound, status (0 ok, 1 max_fills hit, -1 failed), eff%}.

@@ -144,3 +144,33 @@ def test_whole_run_results_are_compute_integrals(ctx):
             s.loglstar = lnew
         lmax = r["live_logl"][i].max()
         assert np.logaddexp(0, lmax + s.logvol - s.logz) < 0.05
+
+
+def test_ties_die_lowest_slot_first_like_the_reference(ctx):
+    """Equal log-likelihoods among the live points (rwalk hands back its start point when no step was accepted) die
+    lowest slot first -- np.argmin's rule in the reference (sampler.py:1107) -- also when the tie is between an original
+    live point and a replacement made earlier in the same fill.  Values drawn from a small set force many ties."""
+    rng = np.random.default_rng(3)
+    nlive, K, runs = 300, 200, 4
+    vals = -np.sort(rng.random(40) * 20)  # 40 distinct levels
+    live = vals[rng.integers(0, 40, size=(runs, nlive))].copy()
+    ref_live = live.copy()
+    states = [R.RunState(nlive) for _ in range(runs)]
+    state = pack(states)
+    live_it = np.zeros((runs, nlive), dtype=np.int32)
+    ref_it = np.zeros((runs, nlive), dtype=np.int64)
+    for fill in range(6):
+        ql = vals[rng.integers(0, 40, size=(runs, K))] + (fill * 0.0)
+        ql[:, ::3] += 0.5  # some entries off the grid
+        qn = rng.integers(1, 9, size=(runs, K)).astype(np.int32)
+        out = ctx.ns_consume(live, ql, qn, state, None if False else 1e-300, live_it=live_it)
+        for r in range(runs):
+            ref = R.consume_queue(ref_live[r], ql[r], qn[r], states[r], 1e-300, plateau=False, live_it=ref_it[r])
+            np.testing.assert_array_equal(out["dead_logl"][r], ref["dead_logl"])
+            np.testing.assert_array_equal(out["dead_slot"][r], ref["dead_slot"])
+            np.testing.assert_array_equal(out["dead_src"][r], ref["dead_src"])
+            np.testing.assert_array_equal(out["dead_it"][r], ref["dead_it"])
+            np.testing.assert_array_equal(out["dead_nc"][r], ref["dead_nc"])
+            np.testing.assert_array_equal(live[r], ref_live[r])
+            np.testing.assert_array_equal(live_it[r], ref_it[r])
+            assert state[r, 7] == ref_live[r].min()
