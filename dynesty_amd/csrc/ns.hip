@@ -9,11 +9,12 @@
 //              rebuild pipeline + enlarge        (only runs that asked for it)
 //              ns_select   (K start points, proposal frames, walker RNG streams)
 //              unit-cube / rwalk walk kernels    (all runs x K walkers, one launch each)
-//              ns_consume  (sequential queue consumption per run on a min-heap in
-//                           LDS, dead-point record, evidence integration, tuning)
+//              ns_gather   (the walkers' start coordinates)
+//              ns_consume  (queue consumption per run: slots sorted once, deaths walk that
+//                           order; dead-point record, evidence integration, tuning)
 //   at the end: ns_finish  (append the final live points, write the record)
 //
-// All state (live points, heap, dead points, integrals, RNG) stays in HBM; with
+// All state (live points, dead points, integrals, RNG) stays in HBM; with
 // 288 GB there is room for the full dead-point history of thousands of runs.
 #include <math.h>
 #include <stdio.h>
@@ -56,8 +57,6 @@ struct NsArgs {
   double* live_u;
   double* live_v;
   double* live_logl;
-  double* heap_key;
-  int* heap_slot;
   double* dead_logl;
   double* dead_u;      // optional
   // queue
@@ -164,29 +163,7 @@ __global__ void __launch_bounds__(kT)
   }
 }
 
-// heap node = one 16-byte LDS entry {logl, slot}: x = key, y = slot (integer bits)
-typedef double HeapEnt __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ HeapEnt heap_ent(double key, int slot) {
-  HeapEnt e;
-  e.x = key;
-  e.y = __longlong_as_double((long long)slot);
-  return e;
-}
-__device__ __forceinline__ int heap_slot_of(HeapEnt e) { return (int)__double_as_longlong(e.y); }
-
-// ---- wave-cooperative 64-ary min-heap -----------------------------------------------------
-// The queue walk is a chain of dependent LDS accesses; a lone lane pays ~150-250 cycles per
-// round trip and a binary heap over 2000 live points needs 11 levels.  Here the heap has
-// fan-out 64: the children of node i are the 64 contiguous entries 64 i + 1 ..., fetched by
-// ONE wave-wide 128-bit read (lane = child), the smallest child is found with two DPP
-// min-reductions on the order-preserving integer image of the key (high then low word, ties
-// to the lowest lane), and 2000 points are TWO levels deep.  Entries past the heap size are
-// +inf sentinels, so partial child groups need no special cases.
-constexpr int kFan = 64;
-__host__ __device__ inline int heap_cap(int n) {  // entries including the sentinel padding
-  return n < 2 ? kFan + 1 : ((n - 2) / kFan) * kFan + kFan + 1;
-}
-
+// ---- wave-level minimum helpers (the queue walk of ns_consume) --------------------------------------
 __device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
   // butterflies inside each row of 16 lanes, then row_bcast15 / row_bcast31: lane 63 holds the minimum
 #define DH_DPP_MIN(ctrl, rmask) \
@@ -221,60 +198,29 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_wave_barrier();
 }
 
-// place (key, slot) at node i of a heap of n entries and sift it down.  All 64 lanes of ONE
-// wave call this with identical (wave-uniform) arguments.
-__device__ __forceinline__ void heap64_sift(HeapEnt* hp, int n, int i, double key, int slot, int lane) {
-  for (;;) {
-    const int c0 = kFan * i + 1;
-    if (c0 >= n) break;
-    const HeapEnt e = hp[c0 + lane];
-    double kmin;
-    const int lmin = wave_argmin(e.x, &kmin);
-    if (!(kmin < key)) break;
-    if (lane == lmin) hp[i] = e;
-    i = c0 + lmin;
-  }
-  if (lane == 0) hp[i] = heap_ent(key, slot);
-  wave_lds_fence();
-}
-
-// Floyd heapify of hp[0 .. n) (sentinels beyond n already in place); one wave
-__device__ __forceinline__ void heap64_build(HeapEnt* hp, int n, int lane) {
-  if (n < 2) return;
-  for (int p = (n - 2) / kFan; p >= 0; --p) {
-    const HeapEnt e = hp[p];
-    heap64_sift(hp, n, p, e.x, heap_slot_of(e), lane);
-  }
-}
-
-// ---- heapify after the initial evaluation ------------------------------------
-__global__ void __launch_bounds__(kT) ns_heapify(NsArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+// ---- after the initial evaluation: the worst and the best live log-likelihood of every run ------------
+__global__ void __launch_bounds__(kT) ns_start(NsArgs a) {
   const int run = blockIdx.x, t = threadIdx.x, N = a.nlive;
-  const int HC = heap_cap(N);
-  HeapEnt* hp = (HeapEnt*)smem;
-  __shared__ double red[kT];
-  double mx = -1e300;
-  for (int i = t; i < HC; i += kT) {
-    const double k = i < N ? a.live_logl[(size_t)run * N + i] : INFINITY;
-    hp[i] = heap_ent(k, i < N ? i : 0);
-    if (i < N) mx = fmax(mx, k);
+  __shared__ double rmax[kT], rmin[kT];
+  double mx = -1e300, mn = INFINITY;
+  for (int i = t; i < N; i += kT) {
+    const double k = a.live_logl[(size_t)run * N + i];
+    mx = fmax(mx, k);
+    mn = fmin(mn, k);
   }
-  red[t] = mx;
+  rmax[t] = mx;
+  rmin[t] = mn;
   __syncthreads();
   for (int s = kT / 2; s > 0; s >>= 1) {
-    if (t < s) red[t] = fmax(red[t], red[t + s]);
+    if (t < s) {
+      rmax[t] = fmax(rmax[t], rmax[t + s]);
+      rmin[t] = fmin(rmin[t], rmin[t + s]);
+    }
     __syncthreads();
   }
-  if (t < 64) heap64_build(hp, N, t);
-  __syncthreads();
   if (t == 0) {
-    a.st[run].lmax = red[0];
-    a.st[run].loglstar = hp[0].x;
-  }
-  for (int i = t; i < N; i += kT) {
-    a.heap_key[(size_t)run * N + i] = hp[i].x;
-    a.heap_slot[(size_t)run * N + i] = heap_slot_of(hp[i]);
+    a.st[run].lmax = rmax[0];
+    a.st[run].loglstar = rmin[0];
   }
 }
 
@@ -418,9 +364,8 @@ __global__ void __launch_bounds__(256) ns_gather(NsArgs a) {
 }
 
 // ---- consume the queue (sampler.py:732-778 + 1105-1185), one workgroup per run ----
-// Only the heap walk is inherently serial (which proposal kills which live point depends
-// on every earlier one).  It is done by one lane and touches nothing but LDS integers and
-// keys; everything transcendental -- the evidence integration of progress_integration
+// Only the walk over the queue is inherently serial (which proposal kills which live point
+// depends on every earlier one): consume_sorted, one wavefront.  Everything transcendental -- the evidence integration of progress_integration
 // (utils.py:1470-1492) and the dlogz stopping rule, ~10 exp/log per dead point -- is a
 // prefix scan over the deaths of the fill and runs on all lanes afterwards:
 //   ln Z_e   = logaddexp-scan of the trapezoid weights,
@@ -428,8 +373,7 @@ __global__ void __launch_bounds__(256) ns_gather(NsArgs a) {
 //   stop     = first e with ln(1 + exp(lmax_e + lnX_e - lnZ_e)) < dlogz,
 //   H_E      = e^{-lnZ_E} [ G_0 + sum_{e<=E} dX_e (L e^L terms) ] - lnZ_E   (G = e^{lnZ}(H + lnZ) is additive),
 //   var lnZ += dlnX (H_E - H_0)                         (the per-step sum telescopes: dlnX is constant).
-// If the stop index falls inside the fill, the heap walk is replayed up to it from the
-// untouched copy in HBM (once per run).
+// If the stop index falls inside the fill, the walk is replayed up to it (once per run).
 #define NS_PROF(i)                                              \
   do {                                                          \
     if (a.prof && run == 0 && t == 0) {                          \
@@ -673,7 +617,7 @@ __global__ void __launch_bounds__(kT) ns_consume(NsArgs a) {
   const double dlv = log(((double)N + 1.0) / (double)N);
   const double ldv_c = log(0.5 * expm1(dlv));  // ln(dX_e / X_e) of the trapezoid rule
   NS_PROF(0);
-  // ---- phase A: the heap walk (wave 0, lanes cooperating on every sift level) ----
+  // ---- phase A: the walk over the queue (wave 0) ----
   if (t < 64) {
     int jcap;
     double nm;
@@ -1025,9 +969,9 @@ int dh_ns_consume(dh_ctx* ctx, int runs, int nlive, int queue_size, double dlogz
     return fail(ctx, DH_ERR_ARG, "ns_consume: bad arguments");
   const int R = runs, N = nlive, K = queue_size;
   if (K > kEPT * kT) return fail(ctx, DH_ERR_ARG, "ns_consume: queue_size %d > %d", K, kEPT * kT);
-  const size_t lds_heap = (size_t)heap_cap(N) * 16 + (size_t)N * 8 + 64;
+  const size_t lds_fin = (size_t)N * 16 + 64;  // ns_finish: the keys padded to a power of two
   const size_t lds_cons = ns_consume_lds(N, K);
-  const size_t lds_max = lds_cons > lds_heap ? lds_cons : lds_heap;
+  const size_t lds_max = lds_cons > lds_fin ? lds_cons : lds_fin;
   if (lds_max > 150 * 1024) return fail(ctx, DH_ERR_ARG, "ns_consume: nlive/queue too large for LDS");
   NsArgs a{};
   a.runs = R;
@@ -1058,8 +1002,6 @@ int dh_ns_consume(dh_ctx* ctx, int runs, int nlive, int queue_size, double dlogz
   }
   a.st = arena_up(ctx, st.data(), (size_t)R);
   a.live_logl = arena_up(ctx, live_logl, (size_t)R * N);
-  a.heap_key = (double*)arena_get(ctx, (size_t)R * N * 8);
-  a.heap_slot = (int*)arena_get(ctx, (size_t)R * N * 4);
   a.dead_logl = (double*)arena_get(ctx, (size_t)R * K * 8);
   a.r_logl = arena_up(ctx, q_logl, (size_t)R * K);
   a.r_a = (int*)arena_up(ctx, q_ncalls, (size_t)R * K);
@@ -1075,7 +1017,7 @@ int dh_ns_consume(dh_ctx* ctx, int runs, int nlive, int queue_size, double dlogz
     a.dead_nc = (int*)arena_get(ctx, (size_t)R * K * 4);
     if (!a.live_it || !a.dead_id || !a.dead_it || !a.dead_nc) return DH_ERR_NOMEM;
   }
-  if (!a.st || !a.live_logl || !a.heap_key || !a.heap_slot || !a.dead_logl || !a.r_logl || !a.r_a ||
+  if (!a.st || !a.live_logl || !a.dead_logl || !a.r_logl || !a.r_a ||
       !a.trace_slot || !a.trace_src || !a.trace_n || !a.ndone || !a.bstatus)
     return DH_ERR_NOMEM;
   hipStream_t s = ctx->stream;
@@ -1084,9 +1026,9 @@ int dh_ns_consume(dh_ctx* ctx, int runs, int nlive, int queue_size, double dlogz
       !hip_ok(ctx, hipMemsetAsync(a.trace_n, 0, (size_t)R * 8, s), "memset"))
     return DH_ERR_HIP;
   if (!hip_ok(ctx, hipFuncSetAttribute((const void*)ns_consume, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max), "hipFuncSetAttribute(ns_consume)") ||
-      !hip_ok(ctx, hipFuncSetAttribute((const void*)ns_heapify, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max), "hipFuncSetAttribute(ns_heapify)"))
+      !hip_ok(ctx, hipFuncSetAttribute((const void*)ns_start, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max), "hipFuncSetAttribute(ns_start)"))
     return DH_ERR_HIP;
-  hipLaunchKernelGGL(ns_heapify, dim3(R), dim3(kT), lds_heap, s, a);  // heap + lmax = max(live_logl)
+  hipLaunchKernelGGL(ns_start, dim3(R), dim3(kT), 0, s, a);  // loglstar = min, lmax = max of live_logl
   hipLaunchKernelGGL(ns_consume, dim3(R), dim3(kT), lds_cons, s, a);
   if (!hip_ok(ctx, hipGetLastError(), "ns_consume launch")) return DH_ERR_HIP;
   std::vector<int> tn((size_t)R * 2);
@@ -1180,7 +1122,7 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
     return o;
   };
   const size_t o_st = take(sizeof(NsRun) * R), o_lu = take((size_t)R * N * D * 8), o_lv = take((size_t)R * N * D * 8),
-               o_ll = take((size_t)R * N * 8), o_hk = take((size_t)R * N * 8), o_hs = take((size_t)R * N * 4),
+               o_ll = take((size_t)R * N * 8),
                o_dl = take((size_t)R * a.cap * 8), o_du = take(dead_u_out ? (size_t)R * a.cap * D * 8 : 8), o_qu = take((size_t)R * K * D * 8),
                o_qf = take((size_t)R * K * 4), o_qr = take((size_t)R * K * 32), o_qo = take((size_t)R * K * 32),
                o_ru = take((size_t)R * K * D * 8), o_rv = take((size_t)R * K * D * 8),
@@ -1207,8 +1149,6 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
   a.live_u = (double*)(base + o_lu);
   a.live_v = (double*)(base + o_lv);
   a.live_logl = (double*)(base + o_ll);
-  a.heap_key = (double*)(base + o_hk);
-  a.heap_slot = (int*)(base + o_hs);
   a.dead_logl = (double*)(base + o_dl);
   a.dead_u = dead_u_out ? (double*)(base + o_du) : nullptr;
   a.q_u0 = (double*)(base + o_qu);
@@ -1256,20 +1196,20 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
   hipLaunchKernelGGL(ns_init, dim3(R), dim3(kT), 0, s, a, d_ent, n_words, first_run);
   int rc = eval_launch_dev(ctx, problem, R * N, a.live_u, a.live_v, a.live_logl);
   if (rc) return cleanup(rc);
-  const size_t lds_heap = (size_t)heap_cap(N) * 16 + (size_t)N * 8 + 64;
+  const size_t lds_fin = (size_t)N * 16 + 64;  // ns_finish: the keys padded to a power of two
   const size_t lds_cons = ns_consume_lds(N, K);
   if (K > kEPT * kT) return cleanup(fail(ctx, DH_ERR_ARG, "ns_ensemble: queue_size %d > %d", K, kEPT * kT));
   if (lds_cons > 150 * 1024) return cleanup(fail(ctx, DH_ERR_ARG, "ns_ensemble: nlive/queue too large for LDS"));
-  const size_t lds_max = lds_cons > lds_heap ? lds_cons : lds_heap;
+  const size_t lds_max = lds_cons > lds_fin ? lds_cons : lds_fin;
   if (lds_max > 150 * 1024) return cleanup(fail(ctx, DH_ERR_ARG, "ns_ensemble: nlive/queue too large for LDS"));
   if (me > kMaxCum) return cleanup(fail(ctx, DH_ERR_ARG, "ns_ensemble: nlive/(2 ndim) = %d ellipsoids > %d", me, kMaxCum));
   // the attribute is per device (and the call is cheap): set it on every call, on this context's device
   if (!hip_ok(ctx, hipFuncSetAttribute((const void*)ns_consume, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max), "hipFuncSetAttribute(ns_consume)") ||
-      !hip_ok(ctx, hipFuncSetAttribute((const void*)ns_heapify, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max), "hipFuncSetAttribute(ns_heapify)") ||
+      !hip_ok(ctx, hipFuncSetAttribute((const void*)ns_start, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max), "hipFuncSetAttribute(ns_start)") ||
       !hip_ok(ctx, hipFuncSetAttribute((const void*)ns_finish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max), "hipFuncSetAttribute(ns_finish)"))
     return cleanup(DH_ERR_HIP);
-  hipLaunchKernelGGL(ns_heapify, dim3(R), dim3(kT), lds_heap, s, a);
-  if (!hip_ok(ctx, hipGetLastError(), "ns_heapify launch")) return cleanup(DH_ERR_HIP);
+  hipLaunchKernelGGL(ns_start, dim3(R), dim3(kT), 0, s, a);
+  if (!hip_ok(ctx, hipGetLastError(), "ns_start launch")) return cleanup(DH_ERR_HIP);
   const int64_t fills_cap = max_fills > 0 ? max_fills : 1000000;
   int64_t fill = 0;
   int ndone = 0;
@@ -1311,7 +1251,7 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
         !hip_ok(ctx, hipStreamSynchronize(s), "sync"))
       return cleanup(DH_ERR_HIP);
   }
-  hipLaunchKernelGGL(ns_finish, dim3(R), dim3(kT), lds_heap, s, a);
+  hipLaunchKernelGGL(ns_finish, dim3(R), dim3(kT), lds_fin, s, a);
   if (!hip_ok(ctx, hipGetLastError(), "ns launch") ||
       !hip_ok(ctx, hipMemcpyAsync(records, a.records, (size_t)R * 64, hipMemcpyDeviceToHost, s), "D2H records"))
     return cleanup(DH_ERR_HIP);
@@ -1353,7 +1293,7 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
     long long h[16];
     (void)hipStreamSynchronize(s);
     (void)hipMemcpy(h, a.prof, sizeof h, hipMemcpyDeviceToHost);
-    fprintf(stderr, "ns_consume cycles (run 0, %lld fills): load %lld | heap %lld | scan %lld | replay+state %lld | dead %lld | live+heap store %lld\n",
+    fprintf(stderr, "ns_consume cycles (run 0, %lld fills): load+sort %lld | walk %lld | scan %lld | replay+state %lld | dead %lld | live store %lld\n",
             (long long)fill, h[0], h[1], h[2], h[3], h[4], h[5]);
     (void)hipFree(a.prof);
   }
