@@ -373,9 +373,13 @@ def main():
     dist = None
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+    # One process group for every world size, 1 included: the record exchange below is then always an
+    # RCCL collective that ran on this device (`rccl_ranks` is an observed count, never a constant).
+    import torch.distributed as dist
+    if world == 1 and "MASTER_ADDR" not in os.environ:
+        os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(_free_port())})
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # "nccl" is RCCL on ROCm
 
     from dynesty_amd import _lib
     ctx = _lib.Context(local_rank)
@@ -485,7 +489,7 @@ def main():
         verified = sh.verify()  # raises on any mismatch
 
     # ensemble exchange step (C5): one record per run gathered over RCCL
-    rccl_ranks = 1
+    rccl_ranks = 0
     if dist is not None:
         rec = torch.tensor(nacc.reshape(runs, -1).mean(1), device="cuda")
         out = [torch.empty_like(rec) for _ in range(world)]

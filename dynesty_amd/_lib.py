@@ -111,6 +111,7 @@ SIGNATURES = {
                            _vp, _vp, _vp]),
     "dh_slice_feed": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _dbl, _vp, _vp, _i, _vp,
                            _vp, _vp]),
+    "dh_set_rwalk_form": (_i, [_vp, _i]),
 }
 
 
@@ -233,6 +234,11 @@ class Context:
         if rc in (ERR_CONTAIN, ERR_REGION, ERR_SLICE, ERR_QZERO):
             raise RuntimeError(msg)
         raise DynHipError(f"libdynhip error {rc}: {msg}")
+
+    def set_rwalk_form(self, form):
+        """0 (default): four lanes per walker + matrix cores where that kernel is built
+        (csrc/walkq.hip); 1: one walker per lane always (csrc/walk.hip)."""
+        self._check(self.lib.dh_set_rwalk_form(self.handle, int(form)))
 
     def sync(self):
         self._check(self.lib.dh_sync(self.handle))

@@ -4,6 +4,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <stdlib.h>
+
 #include "ctx.h"
 #include "npy_ziggurat_tables.h"
 
@@ -100,6 +102,7 @@ dh_ctx* dh_create(int device) {
   }
   dh_ctx* ctx = new dh_ctx();
   ctx->device = device;
+  if (const char* e = getenv("DH_RWALKQ")) ctx->rwalk_form = atoi(e) == 0 ? 1 : 0;
   if (!hip_ok(ctx, hipSetDevice(device), "hipSetDevice") ||
       !hip_ok(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking), "hipStreamCreate") ||
       !hip_ok(ctx, hipMalloc((void**)&ctx->zig, 3 * 256 * sizeof(uint64_t)), "hipMalloc(zig)")) {

@@ -58,6 +58,9 @@ struct dh_ctx {
   // on `stream` (fork after k_root, join before k_finish); created on first use
   hipStream_t side_stream = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  // rwalk kernel form: 0 = four lanes per walker where built (walkq.hip), 1 = one walker per lane always
+  // (dh_set_rwalk_form; initial value from the environment variable DH_RWALKQ=0)
+  int rwalk_form = 0;
 
   const uint64_t* zki() const { return zig; }
   const uint64_t* zwi() const { return zig + 256; }
@@ -109,6 +112,12 @@ int rwalk_launch_runs(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, cons
                       int32_t* naccept, int32_t* nreject, uint64_t* rng_out, const double* run_loglstar,
                       const double* run_scale, const int* run_mode, int wpr, int my_mode,
                       const PhiloxKey* philox = nullptr);
+// walkq.hip: the same walk with four lanes per walker (ndim == ncdim in 9..32, no boundary conditions)
+int rwalkq_launch(dh_ctx* ctx, const ProblemDev& prob, int k, int ndim, const double* u0, const double* axes, int m,
+                  const int32_t* axes_idx, double scale, double loglstar, int walks, const uint64_t* rng, double* u,
+                  double* v, double* logl, int32_t* naccept, int32_t* nreject, uint64_t* rng_out,
+                  const double* run_loglstar, const double* run_scale, const int* run_mode, int wpr, int my_mode,
+                  const PhiloxKey* philox);
 int slice_launch_runs(dh_ctx* ctx, int problem, int k, int ndim, int mode, const double* u0,
                       const double* axes, int m, const int32_t* axes_idx, double scale, double loglstar,
                       int slices, int doubling, const uint64_t* rng, double* u, double* v, double* logl,

@@ -1234,7 +1234,9 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
         dh::PhiloxKey key;
         key.seed = ((unsigned long long)entropy_words[0] << 32) ^ (n_words > 1 ? entropy_words[1] : 0u) ^ 0x9E3779B97F4A7C15ull;
         key.seq0 = (unsigned long long)first_run * (unsigned long long)K;
-        key.offset = (unsigned long long)fill * 4096ull * (unsigned long long)((walks + 127) / 128);
+        // 32-bit draws one walker consumes per fill: per step hiprand_normal4 x ceil(D / 4) and one
+        // hiprand_uniform_double (2 draws; padded to 4 so that a fill's block stays 4-aligned)
+        key.offset = (unsigned long long)fill * (unsigned long long)walks * (unsigned long long)(4 * ((D + 3) / 4) + 4);
         rc = rwalk_launch_runs(ctx, problem, R * K, D, D, a.q_u0, a.b_axes, R * me, a.q_frame, 1.0, 0.0, walks,
                                nullptr, a.q_rng, a.r_u, a.r_v, a.r_logl, a.r_a, a.r_b, a.q_rng_out,
                                a.run_loglstar, a.run_scale, a.run_mode, K, MODE_BOUND, philox ? &key : nullptr);

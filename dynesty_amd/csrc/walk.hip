@@ -348,6 +348,13 @@ __global__ void __launch_bounds__(64)
 
 extern "C" {
 
+int dh_set_rwalk_form(dh_ctx* ctx, int form) {
+  DH_CHECK_CTX(ctx);
+  if (form != 0 && form != 1) return fail(ctx, DH_ERR_ARG, "rwalk form %d (0 = four lanes per walker where built, 1 = lane per walker)", form);
+  ctx->rwalk_form = form;
+  return DH_OK;
+}
+
 int dh_rwalk_batch_dev(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, const double* u0,
                        const double* axes, int m, const int32_t* axes_idx, double scale,
                        double loglstar, int walks, const int8_t* bc, const uint64_t* rng, double* u,
@@ -407,6 +414,14 @@ int dh::rwalk_launch_runs(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, 
                             0, bc, rng, u, v, logl, naccept, nreject, nullptr, nullptr, rng_out, run_loglstar,
                             run_scale, run_mode, nullptr, wpr, my_mode);
   }
+  // Four lanes per walker + matrix cores (walkq.hip) wherever that kernel is built: full-dimensional
+  // proposals without boundary conditions, 9 <= ndim <= 32, fused likelihood, affine / identity prior.  The choice depends on the
+  // problem only -- never on the batch size -- so a walker's result does not depend on its company.
+  // dh_set_rwalk_form(ctx, 1) / DH_RWALKQ=0 keep the lane-per-walker kernel (A/B measurements, tests of it).
+  if (ctx->rwalk_form == 0 && !a.propose_only && !bc && ndim == ncdim && ndim >= 9 && ndim <= kMaxRegDim &&
+      a.prob.prior_id != PRIOR_NORMAL)
+    return rwalkq_launch(ctx, a.prob, k, ndim, u0, axes, m, axes_idx, scale, loglstar, walks, rng, u, v, logl,
+                         naccept, nreject, rng_out, run_loglstar, run_scale, run_mode, wpr, my_mode, philox);
   a.k = k;
   a.ndim = ndim;
   a.ncdim = ncdim;

@@ -28,13 +28,16 @@ def run_seeds(base_seed, total):
     return np.random.SeedSequence(base_seed).spawn(int(total))
 
 
-def gather_records(local, total, world, rank, dist=None, device=None):
+def gather_records(local, total, world, rank, dist=None, device=None, nfield=None):
     """All-gather the per-run records (n_local x len(RECORD_FIELDS), float64;
     column 0 is the global run id).  Returns the (total x nfield) table ordered
-    by run id on every rank.  With dist=None (single process) it is a sort."""
+    by run id on every rank.  With dist=None (no process group) it is a sort;
+    with a process group the collective runs for every world size, 1 included
+    (a one-rank RCCL communicator is still RCCL: `bench.py` and the `-m gpu`
+    tests go through it on a single MI355X)."""
     local = np.ascontiguousarray(local, dtype=np.float64).reshape(
-        -1, len(RECORD_FIELDS))
-    if dist is None or world == 1:
+        -1, nfield or len(RECORD_FIELDS))
+    if dist is None:
         out = local
     else:
         import torch
@@ -58,7 +61,7 @@ def gather_ragged(arrays, world, rank, dist=None, device=None):
     (e.g. weighted posterior samples) as [counts all-gather, padded
     all-gather].  Returns the list of arrays of every rank, in rank order."""
     arrays = [np.ascontiguousarray(a, dtype=np.float64) for a in arrays]
-    if dist is None or world == 1:
+    if dist is None:
         return arrays
     import torch
     d = arrays[0].shape[1] if arrays else 0
@@ -127,29 +130,37 @@ def run_ensemble_device(prob, total_runs, base_seed=21, world=1, rank=0,
         raise ValueError("on_failure must be 'raise' or 'nan'")
     from .backend import get_backend
     mine = shard_runs(total_runs, world, rank)
-    local = np.zeros((0, len(RECORD_FIELDS)))
+    nf = len(RECORD_FIELDS)
+    local = np.zeros((0, nf + 1))
     if len(mine):
         r = get_backend().ns_ensemble(prob, len(mine), nlive, queue_size,
                                       walks=walks, bound=bound, dlogz=dlogz,
                                       entropy=np.atleast_1d(base_seed),
                                       first_run=mine.start, **kw)
-        bad = np.flatnonzero(np.asarray(r["status"]) != 0)
-        if len(bad):
-            # a failed run (bound rebuild error, dead-point capacity) or one that hit max_fills
-            # before dlogz must never enter the table as a valid ln Z estimate
-            if on_failure == 'raise':
-                raise RuntimeError(
-                    f"ns_ensemble: runs {[int(mine.start + b) for b in bad]} ended with status "
-                    f"{[int(r['status'][b]) for b in bad]} (1 = not converged within max_fills, "
-                    f"< 0 = failed)")
-            for key in ("logz", "logzerr", "h"):
-                r[key] = np.array(r[key], dtype=np.float64)
-                r[key][bad] = np.nan
+        status = np.asarray(r["status"]).astype(np.float64)
+        bad = np.flatnonzero(status != 0)
+        # a failed run (bound rebuild error, dead-point capacity) or one that hit max_fills
+        # before dlogz must never enter the table as a valid ln Z estimate
+        for key in ("logz", "logzerr", "h"):
+            r[key] = np.array(r[key], dtype=np.float64)
+            r[key][bad] = np.nan
         local = np.stack([np.arange(mine.start, mine.stop, dtype=np.float64),
                           r["logz"], r["logzerr"], r["niter"].astype(float),
-                          r["ncall"].astype(float), r["h"]], axis=1)
-    return gather_records(local, total_runs, world, rank, dist=dist,
-                          device=device)
+                          r["ncall"].astype(float), r["h"], status], axis=1)
+    # The collective comes FIRST: the status column travels with the records, so that every rank
+    # learns of a failed run and all of them raise together -- raising on the owning rank alone
+    # would leave the others blocked in the all-gather until the communicator times out.
+    table = gather_records(local, total_runs, world, rank, dist=dist,
+                           device=device, nfield=nf + 1)
+    status = table[:, nf]
+    table = np.ascontiguousarray(table[:, :nf])
+    bad = np.flatnonzero(status != 0)
+    if len(bad) and on_failure == 'raise':
+        raise RuntimeError(
+            f"ns_ensemble: runs {[int(table[b, 0]) for b in bad]} ended with status "
+            f"{[int(status[b]) for b in bad]} (1 = not converged within max_fills, "
+            f"< 0 = failed)")
+    return table
 
 
 def combine_logz(table):
@@ -324,7 +335,7 @@ def gather_and_merge(points_per_run, nlive, world=1, rank=0, dist=None,
     info = {}
     if all((a[:, 2] >= 0).all() for a in allruns):
         info = dict(dead_id=dead_i[0], dead_it=dead_i[1], dead_nc=dead_i[2], live_id=live_i[0], live_it=live_i[1])
-    if ncall is not None and dist is not None and world > 1:
+    if ncall is not None and dist is not None:
         import torch
         t = torch.tensor([float(np.sum(ncall))], dtype=torch.float64)
         if device is not None:
@@ -362,13 +373,28 @@ def run_ensemble_merged_sharded(prob, total_runs, base_seed=21, world=1, rank=0,
     mine = shard_runs(total_runs, world, rank)
     if max_iter is None:
         max_iter = 80 * nlive
-    rows, ncall = [], 0
+    rows, ncall, nbad = [], 0, 0
+    r = None
     if len(mine):
         r = be.ns_ensemble(prob, len(mine), nlive, queue_size,
                            entropy=np.atleast_1d(base_seed), first_run=mine.start,
                            max_iter=max_iter, want_samples=True, **kw)
-        if (r["status"] != 0).any():
-            raise RuntimeError(f"ns_ensemble: runs failed, status {r['status']}")
+        nbad = int((r["status"] != 0).sum())
+    # every rank learns of a failure before anyone leaves the collective sequence (see
+    # run_ensemble_device): one all-reduce of the failure count, then raise everywhere
+    if dist is not None:
+        import torch
+        t = torch.tensor([float(nbad)], dtype=torch.float64)
+        if device is not None:
+            t = t.to(device)
+        dist.all_reduce(t)
+        nbad_all = int(t.item())
+    else:
+        nbad_all = nbad
+    if nbad_all:
+        raise RuntimeError(f"ns_ensemble: {nbad_all} run(s) of the ensemble failed"
+                           + (f", local status {r['status']}" if nbad else ""))
+    if len(mine):
         ncall = int(r["ncall"].sum())
         for i in range(len(mine)):
             k = int(r["niter"][i])

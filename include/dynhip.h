@@ -208,6 +208,17 @@ int dh_rwalk_batch_dev(dh_ctx* ctx, int problem, int k, int ndim, int ncdim,
                        double* u, double* v, double* logl, int32_t* naccept,
                        int32_t* nreject, uint64_t* rng_out);
 
+/* Kernel form of the fused rwalk entry points (dh_rwalk_batch[_dev], dh_rwalk_batch_philox[_dev], the
+ * rwalk stage of dh_ns_ensemble).  form 0 (default): a walker is spread over four lanes of a wavefront
+ * and the frame product / Gaussian quadratic form run on the fp64 matrix cores wherever that kernel is
+ * built (ndim == ncdim in 9..32, no periodic / reflective coordinates, affine or identity prior), one
+ * walker per lane elsewhere; form 1: one walker per lane always.  Both forms implement
+ * generic_random_walk (internal_samplers.py:866-986) on the same generator streams -- accept / reject
+ * counts and generator end states are identical, coordinates agree to rounding (~1e-15: sums over a
+ * vector are taken in a different order).  The choice depends on the problem only, never on the batch
+ * size.  The environment variable DH_RWALKQ=0 makes form 1 the initial value. */
+int dh_set_rwalk_form(dh_ctx* ctx, int form);
+
 /* Throughput mode of RWalkSampler.sample: the same walk (generic_random_walk, propose_ball_point,
  * randsphere; internal_samplers.py:866-1035, bounding.py:1288-1297) drawing from hiprand's Philox4x32-10
  * device generator instead of NumPy-compatible PCG64 streams: walker i uses subsequence sequence0 + i of

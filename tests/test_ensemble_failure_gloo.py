@@ -1,0 +1,109 @@
+"""A failed run on ONE rank must fail the whole job cleanly: the records (with their status column) are
+all-gathered first and every rank raises afterwards -- raising before the collective would leave the
+other ranks blocked in the all-gather until the communicator times out.  Two processes,
+gloo, world_size 2; plus the world_size-1 process group (the collective must run there too: it is what
+the single-GPU bench and the `-m gpu` RCCL test go through)."""
+import os
+import socket
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys, json
+import numpy as np
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import torch.distributed as dist
+from dynesty_amd import backend, ensemble
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+bad_rank = int(os.environ["BAD_RANK"])
+
+class FakeBackend:
+    def ns_ensemble(self, prob, runs, nlive, queue_size, first_run=0, want_samples=False, **kw):
+        status = np.zeros(runs, dtype=np.int32)
+        if rank == bad_rank:
+            status[-1] = -2
+        out = dict(logz=-57.5 + 0.01 * (first_run + np.arange(runs)), logzerr=np.full(runs, 0.1),
+                   niter=np.full(runs, 10), ncall=np.full(runs, 100), h=np.full(runs, 28.0), status=status)
+        if want_samples:
+            d = 2
+            out.update(dead_logl=np.sort(np.random.default_rng(first_run).random((runs, 10)), axis=1),
+                       dead_u=np.random.default_rng(1).random((runs, 10, d)),
+                       live_logl=1.0 + np.random.default_rng(2).random((runs, nlive)),
+                       live_u=np.random.default_rng(3).random((runs, nlive, d)),
+                       dead_id=np.zeros((runs, 10), dtype=np.int64), dead_it=np.ones((runs, 10), dtype=np.int64),
+                       dead_nc=np.ones((runs, 10), dtype=np.int64), live_it=np.zeros((runs, nlive), dtype=np.int64))
+        return out
+
+    def problem_eval(self, prob, u):
+        return np.asarray(u), None
+
+backend.set_backend(FakeBackend())
+dist.init_process_group("gloo")
+res = {}
+try:
+    t = ensemble.run_ensemble_device(None, 5, world=world, rank=rank, dist=dist)
+    res["device"] = ["ok", t[:, 1].tolist()]
+except RuntimeError as e:
+    res["device"] = ["raised", str(e)]
+t = ensemble.run_ensemble_device(None, 5, world=world, rank=rank, dist=dist, on_failure='nan')
+res["nan"] = [int(np.isnan(t[:, 1]).sum()), t.shape]
+try:
+    m = ensemble.run_ensemble_merged_sharded(None, 5, world=world, rank=rank, dist=dist, nlive=8, queue_size=4)
+    res["merged"] = ["ok", int(m.niter)]
+except RuntimeError as e:
+    res["merged"] = ["raised", str(e)]
+dist.barrier()
+with open(os.path.join(%(out)r, "f%%d_of_%%d.json" %% (rank, world)), "w") as f:
+    json.dump(res, f)
+dist.destroy_process_group()
+'''
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _launch(tmp, world, bad_rank):
+    import json
+    script = os.path.join(str(tmp), "worker.py")
+    with open(script, "w") as f:
+        f.write(WORKER % dict(root=ROOT, out=str(tmp)))
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="1", BAD_RANK=str(bad_rank))
+        procs.append(subprocess.Popen([sys.executable, script], env=env))
+    for p in procs:
+        assert p.wait(timeout=300) == 0  # a hang in the collective would time out here
+    return [json.load(open(os.path.join(str(tmp), f"f{r}_of_{world}.json"))) for r in range(world)]
+
+
+def test_a_failed_run_on_one_rank_raises_on_every_rank(tmp_path):
+    res = _launch(tmp_path, 2, bad_rank=1)
+    for r in res:
+        assert r["device"][0] == "raised" and "status" in r["device"][1], r
+        assert "[4]" in r["device"][1]  # the failed run's GLOBAL id, known to both ranks
+        assert r["nan"] == [1, [5, 6]]
+        assert r["merged"][0] == "raised", r
+
+
+def test_no_failure_two_ranks(tmp_path):
+    res = _launch(tmp_path, 2, bad_rank=-1)
+    assert res[0] == res[1]
+    assert res[0]["device"][0] == "ok" and len(res[0]["device"][1]) == 5
+    assert res[0]["nan"] == [0, [5, 6]]
+    assert res[0]["merged"] == ["ok", 5 * 18]
+
+
+def test_world_size_one_process_group_runs_the_collectives(tmp_path):
+    res = _launch(tmp_path, 1, bad_rank=-1)
+    assert res[0]["device"][0] == "ok" and res[0]["merged"] == ["ok", 5 * 18]
+    res = _launch(tmp_path, 1, bad_rank=0)
+    assert res[0]["device"][0] == "raised" and res[0]["merged"][0] == "raised"

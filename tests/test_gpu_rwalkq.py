@@ -1,0 +1,132 @@
+"""rwalk with four lanes per walker (csrc/walkq.hip: frame product and Gaussian quadratic form on the fp64
+matrix cores, PCG64 consumed by four lanes through LCG jumps) against the oracle's restatement of
+RWalkSampler.sample (internal_samplers.py:866-1035) on the same child streams -- accept / reject counts and
+the generator end state exact, u within 1e-12, logl 1e-11 relative -- over every padded register count the
+kernel is built for, several frames inside one wavefront, ragged batch sizes and the three fused
+likelihoods; and against the lane-per-walker kernel (csrc/walk.hip), which consumes the same streams."""
+import math
+
+import numpy as np
+import pytest
+
+from dynesty_amd import problems
+from oracle import proposals_ref as P
+
+pytestmark = pytest.mark.gpu
+
+ATOL_U = 1e-12
+RTOL_L = 1e-11
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from dynesty_amd import _lib
+    c = _lib.Context(0)
+    yield c
+    c.set_rwalk_form(0)
+
+
+def make_case(prob, nwalk, seed, shrink=0.5):
+    """tests/inputs.walker_case for an arbitrary problem object."""
+    d = prob.ndim
+    rng = np.random.default_rng(seed)
+    if prob.like_id == problems.LIKE_EGGBOX:
+        u0 = 0.5 + 0.004 * rng.standard_normal((nwalk, d))
+        spread = 0.004
+    else:
+        hw = prob.prior_par[0]
+        u0 = 0.5 + (shrink / (2 * hw)) * rng.standard_normal((nwalk, d))
+        spread = shrink / (2 * hw)
+    u0 = np.clip(u0, 1e-3, 1 - 1e-3)
+    logl = prob.loglikelihood_many(prob.prior_transform_many(u0))
+    loglstar = float(np.quantile(logl, 0.05))
+    q, _ = np.linalg.qr(rng.standard_normal((d, d)))
+    axes = q * (spread * math.sqrt(d) * rng.uniform(0.8, 1.6, size=d))
+    keep = logl > loglstar
+    return dict(u0=u0[keep], loglstar=loglstar, axes=axes, scale=0.7, problem=prob)
+
+
+def the_problem(kind, d):
+    if kind == "prec":
+        return problems.gauss_corr(d, 0.4, 5.0, f"corr{d}")
+    if kind == "iid":
+        return problems.gauss_iid(d, 6.0, f"iid{d}")
+    return problems.eggbox(d, name=f"egg{d}")
+
+
+CASES = [("prec", 9), ("prec", 12), ("prec", 16), ("prec", 17), ("prec", 20), ("prec", 25), ("prec", 28),
+         ("prec", 29), ("prec", 32), ("iid", 10), ("iid", 27), ("egg", 9), ("egg", 18)]
+
+
+@pytest.mark.parametrize("kind,d", CASES)
+def test_quad_rwalk_vs_oracle(ctx, kind, d):
+    """Three frames mixed inside every wavefront (16 walkers per wave), a batch size off every
+    granularity of the kernel (16 walkers per wave, 64 per workgroup)."""
+    from dynesty_amd import _lib
+    ctx.set_rwalk_form(0)
+    prob = the_problem(kind, d)
+    case = make_case(prob, 120, 1000 + d)
+    walks = 18
+    u0 = case["u0"][:83]
+    k = len(u0)
+    a = case["axes"]
+    axes3 = np.stack([a, 0.5 * a[::-1, ::-1].copy(), 0.8 * a.T.copy()])
+    idx = (np.arange(k) * 5 % 3).astype(np.int32)
+    ent = [d, 6, 7]
+    st = ctx.seed_children(ent, 3, k)
+    out = ctx.rwalk_batch(prob, u0, axes3, case["scale"], case["loglstar"], walks, st, axes_idx=idx)
+    kids = np.random.SeedSequence(ent).spawn(3 + k)[3:]
+    for i in range(k):
+        bg = np.random.PCG64(kids[i])
+        ref = P.rwalk(u0[i].copy(), case["loglstar"], axes3[idx[i]], case["scale"], prob.prior_transform,
+                      prob.loglikelihood, np.random.Generator(bg), walks)
+        assert ref["accept"] == out["accept"][i], (i, ref["accept"], out["accept"][i])
+        assert ref["reject"] == out["reject"][i]
+        np.testing.assert_allclose(out["u"][i], ref["u"], rtol=0, atol=ATOL_U)
+        np.testing.assert_allclose(out["v"][i], prob.prior_transform(ref["u"]), rtol=0, atol=2e-11)
+        np.testing.assert_allclose(out["logl"][i], ref["logl"], rtol=RTOL_L, atol=1e-11)
+        np.testing.assert_array_equal(out["rng_out"][i], _lib.pcg_state_words(bg))
+    assert out["accept"].sum() > 0 and out["reject"].sum() > 0
+
+
+def test_quad_equals_lane_form_and_batch_halves(ctx):
+    """Both kernel forms walk the same streams: counts and generator end states identical, coordinates to
+    rounding.  And a walker's result does not depend on its company: a batch equals its halves bit for bit
+    (split off the wave / workgroup granularity)."""
+    prob = problems.gauss_corr(25, 0.4, 5.0, "C2")
+    case = make_case(prob, 6000, 5)
+    u0 = case["u0"][:5003]
+    k = len(u0)
+    st = ctx.seed_children([11, 12], 0, k)
+    args = (prob, u0, case["axes"], case["scale"], case["loglstar"], 45, st)
+    ctx.set_rwalk_form(1)
+    lane = ctx.rwalk_batch(*args)
+    ctx.set_rwalk_form(0)
+    quad = ctx.rwalk_batch(*args)
+    np.testing.assert_array_equal(quad["accept"], lane["accept"])
+    np.testing.assert_array_equal(quad["reject"], lane["reject"])
+    np.testing.assert_array_equal(quad["rng_out"], lane["rng_out"])
+    np.testing.assert_allclose(quad["u"], lane["u"], rtol=0, atol=1e-13)
+    np.testing.assert_allclose(quad["logl"], lane["logl"], rtol=1e-12, atol=1e-12)
+    cut = 2501
+    h0 = ctx.rwalk_batch(prob, u0[:cut], case["axes"], case["scale"], case["loglstar"], 45, st[:cut])
+    h1 = ctx.rwalk_batch(prob, u0[cut:], case["axes"], case["scale"], case["loglstar"], 45, st[cut:])
+    for key in ("u", "v", "logl", "accept", "reject", "rng_out"):
+        np.testing.assert_array_equal(quad[key], np.concatenate([h0[key], h1[key]]))
+
+
+def test_quad_philox_equals_lane_philox(ctx):
+    """Throughput RNG mode: the four-lane kernel positions hiprand's Philox stream exactly where the
+    lane-per-walker kernel reads it (per step ceil(n / 4) normal4 blocks, one uniform double)."""
+    prob = problems.gauss_corr(25, 0.4, 5.0, "C2")
+    case = make_case(prob, 3000, 6)
+    u0 = case["u0"][:2049]
+    args = (prob, u0, case["axes"], case["scale"], case["loglstar"], 45, 1234)
+    ctx.set_rwalk_form(1)
+    lane = ctx.rwalk_batch_philox(*args, sequence0=17, offset=4096)
+    ctx.set_rwalk_form(0)
+    quad = ctx.rwalk_batch_philox(*args, sequence0=17, offset=4096)
+    assert (quad["accept"] != lane["accept"]).mean() < 1e-3  # same draws; a knife-edge accept may differ
+    same = quad["accept"] == lane["accept"]
+    np.testing.assert_allclose(quad["u"][same], lane["u"][same], rtol=0, atol=1e-12)
+    assert 0.2 < quad["accept"].mean() / 45 < 0.8
