@@ -5,17 +5,25 @@ on MI355X (contract: see the round prompt; metric from BASELINE.json).
 Workload (config.workload): BASELINE config C2 -- 25-D rho=0.4 correlated
 Normal, nlive=2000, bound='multi', sample='rwalk' (walks = 45) -- as `runs`
 independent runs per GPU (64 = one GPU's shard of the C5 ensemble of 512 runs
-on 8 GPUs).  One *step* = one pass of the hot path for every run of the shard,
-all inputs resident in HBM:
+on 8 GPUs).  One *step* = one bound-update interval of every run of the shard
+at the queue size the evidence gate allows (K = 512 walkers in flight per run:
+ln Z within 0.05 of the reference, tests/test_gpu_logz_gate.py), all inputs
+resident in HBM:
 
   1. MultiEllipsoid.update on each run's live set        (rebuild kernels)
   2. scale_to_logvol(logvol + ln 1.25)                   (enlarge kernel)
-  3. K = nlive walkers x `walks` rwalk proposals per run against the rebuilt,
-     enlarged ellipsoid frame (in-kernel PCG64/ziggurat draws, frame mat-vec,
-     prior transform, Gaussian log-likelihood, accept test)
+  3. ceil(nlive / K) = 4 queue fills: each ONE launch of runs x K walkers x
+     `walks` rwalk proposals against the rebuilt, enlarged ellipsoid frame of
+     the walker's run, started from live points of that run (in-kernel
+     PCG64/ziggurat draws, frame mat-vec, prior transform, Gaussian
+     log-likelihood, accept test)
 
-i.e. exactly one bound-update interval of the reference
-(update_interval = walks * nlive = 90 000 calls, dynesty.py:213-232).
+i.e. what the reference does between two bound updates
+(update_interval = walks * nlive = 90 000 calls, dynesty.py:213-232) when its
+queue holds K proposals.  The same interval flown as ONE launch of nlive
+walkers per run (K = nlive: faster per proposal, but a queue that large
+biases ln Z -- in the reference exactly as on the device) is reported beside it
+(config.interval_at_queue_nlive; it was the headline of rounds 1-2).
 
 Live sets are uniform-in-contour shells: a run's live points are distributed
 uniformly inside {logl > loglstar} (here an ellipsoid well inside the prior
@@ -50,6 +58,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 FP64_PEAK_TFLOPS = 78.6  # vector fp64 (datasheet)
 MAX_ELLS = 8
+GATE_QUEUE = 512  # walkers in flight per run for which ln Z passes the gate against the reference (K = nlive does not)
 RWALK_SCALE = 0.27  # acceptance ~0.5 on the contour shells: the reference's tuned state (facc = 0.5)
 # the REAL dynesty 3.0.0 on C2, one core of the build container (it cannot
 # travel to the GPU box: /root/reference does not exist there)
@@ -88,11 +97,13 @@ class Shard:
     dh_rwalk_batch_dev).  tests/test_gpu_bench_shape.py drives the same object."""
 
     def __init__(self, ctx, prob, runs=64, nlive=2000, walks=45, seed=1000,
-                 scale=RWALK_SCALE, entropy=(21, 0, 0, 0)):
+                 scale=RWALK_SCALE, entropy=(21, 0, 0, 0), queue=GATE_QUEUE):
         self.ctx, self.prob = ctx, prob
         self.runs, self.nlive, self.walks, self.scale = runs, nlive, walks, scale
         self.d = d = prob.ndim
         self.k = k = runs * nlive
+        self.kq = kq = min(int(queue), nlive)   # walkers in flight per run
+        self.nq = nq = -(-nlive // kq)          # queue fills per bound-update interval
         self.u0, self.loglstar = make_shard(prob, runs, nlive, seed)
         self.log_enlarge = math.log(1.25)
         self.entropy = list(entropy)
@@ -100,6 +111,14 @@ class Shard:
         self.d_u0 = ctx.to_device(self.u0)  # live sets == walker start points
         self.idx = (np.arange(k, dtype=np.int32) // nlive) * me
         self.d_idx = ctx.to_device(self.idx)
+        # queue form: fill j starts walker i of run r from live point (j * kq + i) % nlive of run r
+        # (every start point is a live point of the walker's own run, as in Sampler.propose_live)
+        pick = (np.arange(nq)[:, None] * kq + np.arange(kq)[None, :]) % nlive          # (nq, kq)
+        self.u0q = np.ascontiguousarray(
+            self.u0.reshape(runs, nlive, d)[:, pick].transpose(1, 0, 2, 3).reshape(nq, runs * kq, d))
+        self.d_u0q = ctx.to_device(self.u0q)
+        self.idxq = (np.arange(runs * kq, dtype=np.int32) // kq) * me
+        self.d_idxq = ctx.to_device(self.idxq)
         self.states0 = ctx.seed_children(self.entropy, 0, k)
         self.d_rng = ctx.to_device(self.states0)
         self.d_rng2 = ctx.malloc(k * 32)
@@ -154,7 +173,26 @@ class Shard:
                                                int(i) * 4096, self.d_u, self.d_v, self.d_logl,
                                                self.d_na, self.d_nr))
 
+    def walk_q(self, i=0, j=0):
+        """Queue fill j of step i: one rwalk launch of runs x kq walkers (walker (r, w) starts from a
+        live point of run r and walks in run r's frame)."""
+        c, lib, h = self.ctx, self.ctx.lib, self.ctx.handle
+        a, b = (self.d_rng, self.d_rng2) if (i * self.nq + j) % 2 == 0 else (self.d_rng2, self.d_rng)
+        d, n = self.d, self.runs * self.kq
+        c._check(lib.dh_rwalk_batch_dev(h, self.ph, n, d, d, self.d_u0q + j * n * d * 8, self.d_axes,
+                                        self.runs * self.me, self.d_idxq, self.scale, self.loglstar,
+                                        self.walks, None, a, self.d_u, self.d_v, self.d_logl,
+                                        self.d_na, self.d_nr, b))
+
     def step(self, i=0, rebuild=True):
+        """One bound-update interval at the gate queue size: rebuild + enlarge + nq queue fills."""
+        if rebuild:
+            self.rebuild()
+        for j in range(self.nq):
+            self.walk_q(i, j)
+
+    def step_full(self, i=0, rebuild=True):
+        """The same interval as ONE launch of nlive walkers per run (queue size = nlive)."""
         if rebuild:
             self.rebuild()
         self.walk(i)

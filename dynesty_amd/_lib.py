@@ -236,8 +236,9 @@ class Context:
         raise DynHipError(f"libdynhip error {rc}: {msg}")
 
     def set_rwalk_form(self, form):
-        """0 (default): four lanes per walker + matrix cores where that kernel is built
-        (csrc/walkq.hip); 1: one walker per lane always (csrc/walk.hip)."""
+        """0 (default): four lanes per walker + matrix cores (csrc/walkq.hip) for launches that
+        would leave SIMDs empty with one walker per lane; 1: one walker per lane always
+        (csrc/walk.hip); 2: four lanes per walker wherever that kernel is built."""
         self._check(self.lib.dh_set_rwalk_form(self.handle, int(form)))
 
     def sync(self):

@@ -102,7 +102,11 @@ dh_ctx* dh_create(int device) {
   }
   dh_ctx* ctx = new dh_ctx();
   ctx->device = device;
-  if (const char* e = getenv("DH_RWALKQ")) ctx->rwalk_form = atoi(e) == 0 ? 1 : 0;
+  if (const char* e = getenv("DH_RWALK_FORM")) ctx->rwalk_form = atoi(e) == 1 ? 1 : atoi(e) == 2 ? 2 : 0;
+  {
+    int cu = 0;
+    if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cu > 0) ctx->num_cu = cu;
+  }
   if (!hip_ok(ctx, hipSetDevice(device), "hipSetDevice") ||
       !hip_ok(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking), "hipStreamCreate") ||
       !hip_ok(ctx, hipMalloc((void**)&ctx->zig, 3 * 256 * sizeof(uint64_t)), "hipMalloc(zig)")) {

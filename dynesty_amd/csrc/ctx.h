@@ -58,9 +58,11 @@ struct dh_ctx {
   // on `stream` (fork after k_root, join before k_finish); created on first use
   hipStream_t side_stream = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  // rwalk kernel form: 0 = four lanes per walker where built (walkq.hip), 1 = one walker per lane always
-  // (dh_set_rwalk_form; initial value from the environment variable DH_RWALKQ=0)
+  // rwalk kernel form (dh_set_rwalk_form): 0 = four lanes per walker (walkq.hip) for launches that would
+  // leave SIMDs empty with one walker per lane, 1 = one walker per lane always, 2 = four lanes per walker
+  // wherever that kernel is built
   int rwalk_form = 0;
+  int num_cu = 256;  // hipDeviceProp_t::multiProcessorCount
 
   const uint64_t* zki() const { return zig; }
   const uint64_t* zwi() const { return zig + 256; }

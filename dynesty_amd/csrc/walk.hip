@@ -350,7 +350,8 @@ extern "C" {
 
 int dh_set_rwalk_form(dh_ctx* ctx, int form) {
   DH_CHECK_CTX(ctx);
-  if (form != 0 && form != 1) return fail(ctx, DH_ERR_ARG, "rwalk form %d (0 = four lanes per walker where built, 1 = lane per walker)", form);
+  if (form < 0 || form > 2)
+    return fail(ctx, DH_ERR_ARG, "rwalk form %d (0 = by launch size, 1 = lane per walker, 2 = four lanes per walker)", form);
   ctx->rwalk_form = form;
   return DH_OK;
 }
@@ -414,12 +415,16 @@ int dh::rwalk_launch_runs(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, 
                             0, bc, rng, u, v, logl, naccept, nreject, nullptr, nullptr, rng_out, run_loglstar,
                             run_scale, run_mode, nullptr, wpr, my_mode);
   }
-  // Four lanes per walker + matrix cores (walkq.hip) wherever that kernel is built: full-dimensional
-  // proposals without boundary conditions, 9 <= ndim <= 32, fused likelihood, affine / identity prior.  The choice depends on the
-  // problem only -- never on the batch size -- so a walker's result does not depend on its company.
-  // dh_set_rwalk_form(ctx, 1) / DH_RWALKQ=0 keep the lane-per-walker kernel (A/B measurements, tests of it).
-  if (ctx->rwalk_form == 0 && !a.propose_only && !bc && ndim == ncdim && ndim >= 9 && ndim <= kMaxRegDim &&
-      a.prob.prior_id != PRIOR_NORMAL)
+  // Four lanes per walker + matrix cores (walkq.hip): built for full-dimensional proposals without
+  // boundary conditions, 9 <= ndim <= 32, fused likelihood, affine / identity prior.  It does the same
+  // walk on the same streams (counts and generator states identical, coordinates to rounding) with 4x the
+  // wavefronts, which pays while the lane-per-walker launch leaves SIMDs empty: measured on the C2 shard,
+  // 64 x 512 walkers 0.86 -> 0.44 ms, 64 x 2000 walkers 1.26 -> 1.67 ms (per walker it issues about twice
+  // the instructions: 32 lane-draws for 26, per-walker scalars on four lanes).  Form 0 therefore takes it
+  // up to one lane-per-walker wavefront per SIMD (k <= 64 * 4 * CUs), form 2 always, form 1 never.
+  const bool quad_ok = !a.propose_only && !bc && ndim == ncdim && ndim >= 9 && ndim <= kMaxRegDim &&
+                       a.prob.prior_id != PRIOR_NORMAL;
+  if (quad_ok && (ctx->rwalk_form == 2 || (ctx->rwalk_form == 0 && k <= 256 * ctx->num_cu)))
     return rwalkq_launch(ctx, a.prob, k, ndim, u0, axes, m, axes_idx, scale, loglstar, walks, rng, u, v, logl,
                          naccept, nreject, rng_out, run_loglstar, run_scale, run_mode, wpr, my_mode, philox);
   a.k = k;

@@ -166,18 +166,23 @@ __device__ __forceinline__ void quad_draw_step(QuadPcg& q, const ZigLds* z, doub
       }
     }
     const int my = count + t - shift;
-    const bool valid = act && t >= shift && my < NI;
+    const bool valid = act & (t >= shift) & (my < NI);
     const int idx = (int)(r & 0xff);
     const uint64_t rabs = (r >> 9) & 0x000fffffffffffffull;
     const double rd = __longlong_as_double((long long)(rabs | 0x4330000000000000ull)) - 4503599627370496.0;
     double x = rd * z->wi[idx];
     x = __longlong_as_double(__double_as_longlong(x) ^ (long long)((r & 0x100ull) << 55));
-    const bool isn = valid && my < nc;
-    const bool miss = isn && !(rabs < z->ki[idx]);
+    const bool isn = valid & (my < nc);
+    const uint64_t kk = z->ki[idx];  // looked up by every lane: no branch around the LDS read
+    const bool miss = isn & !(rabs < kk);
     const int fm = grp_first(grp_bits(__ballot(miss), j));       // first missing sub-lane of my walker
     int tend = shift + NI - count;                                // one past the last valid sub-lane
     tend = tend < 4 ? tend : 4;
-    if (valid && t < fm) items[my * 64 + slot] = isn ? x : (double)(r >> 11) * (1.0 / 9007199254740992.0);
+    if (valid && t < fm) {
+      double val = x;
+      if (!isn) val = (double)(r >> 11) * (1.0 / 9007199254740992.0);  // the step's uniform: once in ~7 rounds
+      items[my * 64 + slot] = val;
+    }
     const int stop = fm < tend ? fm : tend;  // sub-lanes [shift, stop) were consumed as items
     if (act) count += stop - shift;
     // re-alignment: everyone's new state is A * B + T with (A, B, T) = (A4, own S, T4) when all four
@@ -411,7 +416,13 @@ __global__ void __launch_bounds__(256) rwalkq_kernel(RwalkQArgs a) {
     const double ur = items[n * 64 + slot];
     wave_sync();
     ss = grp_sum(ss);
-    const double fac = scale * (pow(ur, inv_n) / sqrt(ss));
+    // scale * ur^(1/n) / |dr| (bounding.py:1295-1296).  This is per-walker scalar work that all four
+    // sub-lanes repeat, so it is kept short: exp(log(ur) / n) instead of ocml's double-double pow (|log
+    // ur| / n is O(1): the product costs no accuracy), 1 / sqrt by v_rsq_f64 + two Newton steps
+    double y = __builtin_amdgcn_rsq(ss);
+    y = y * fma(-0.5 * ss * y, y, 1.5);
+    y = y * fma(-0.5 * ss * y, y, 1.5);
+    const double fac = scale * (exp(inv_n * log(ur)) * y);
     // du = axes @ dr on the matrix cores; walkers of a wave on different frames: one product per frame
     mfma_acc acc[MT];
     if (uni) {

@@ -209,14 +209,18 @@ int dh_rwalk_batch_dev(dh_ctx* ctx, int problem, int k, int ndim, int ncdim,
                        int32_t* nreject, uint64_t* rng_out);
 
 /* Kernel form of the fused rwalk entry points (dh_rwalk_batch[_dev], dh_rwalk_batch_philox[_dev], the
- * rwalk stage of dh_ns_ensemble).  form 0 (default): a walker is spread over four lanes of a wavefront
- * and the frame product / Gaussian quadratic form run on the fp64 matrix cores wherever that kernel is
- * built (ndim == ncdim in 9..32, no periodic / reflective coordinates, affine or identity prior), one
- * walker per lane elsewhere; form 1: one walker per lane always.  Both forms implement
- * generic_random_walk (internal_samplers.py:866-986) on the same generator streams -- accept / reject
- * counts and generator end states are identical, coordinates agree to rounding (~1e-15: sums over a
- * vector are taken in a different order).  The choice depends on the problem only, never on the batch
- * size.  The environment variable DH_RWALKQ=0 makes form 1 the initial value. */
+ * rwalk stage of dh_ns_ensemble).  Two kernels implement generic_random_walk
+ * (internal_samplers.py:866-986) on the same generator streams: one walker per lane (any ndim <= 32, any
+ * options), and one walker on four lanes of a wavefront with the frame product / Gaussian quadratic form
+ * on the fp64 matrix cores (built for ndim == ncdim in 9..32, no periodic / reflective coordinates,
+ * affine or identity prior).  Accept / reject counts and generator end states of the two are identical,
+ * coordinates agree to rounding (~1e-15: sums over a vector are taken in a different order).
+ *   form 0 (default)  four lanes per walker while the launch is small enough to leave SIMDs empty with
+ *                     one walker per lane (k <= 256 * compute units), else one walker per lane
+ *   form 1            one walker per lane always
+ *   form 2            four lanes per walker wherever built (a job that wants bit-identical results for
+ *                     every sharding of an ensemble pins form 1 or 2)
+ * The environment variable DH_RWALK_FORM sets the initial value. */
 int dh_set_rwalk_form(dh_ctx* ctx, int form);
 
 /* Throughput mode of RWalkSampler.sample: the same walk (generic_random_walk, propose_ball_point,

@@ -19,6 +19,23 @@ def pytest_configure(config):
         "markers", "reference: needs /root/reference (build container only)")
 
 
+def pytest_collection_finish(session):
+    """GPU sessions: bring torch's HIP runtime up BEFORE the first libdynhip context exists.  The torch
+    wheel carries its own copy of the ROCm runtime; initialised late -- after a dozen contexts of the
+    system runtime that libdynhip.so links -- it reported "No HIP GPUs are available" on the MI355X box
+    (tests/test_gpu_rccl.py needs torch.cuda for its RCCL process group; bench.py has always initialised
+    torch first)."""
+    if not any(item.get_closest_marker("gpu") for item in session.items):
+        return
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+            torch.zeros(1, device="cuda:0")
+    except Exception:  # no torch / no device: the gpu tests themselves will say so
+        pass
+
+
 @pytest.fixture(scope="session")
 def golden_bounding():
     return np.load(os.path.join(GOLDEN, "bounding.npz"))

@@ -63,7 +63,7 @@ def test_quad_rwalk_vs_oracle(ctx, kind, d):
     """Three frames mixed inside every wavefront (16 walkers per wave), a batch size off every
     granularity of the kernel (16 walkers per wave, 64 per workgroup)."""
     from dynesty_amd import _lib
-    ctx.set_rwalk_form(0)
+    ctx.set_rwalk_form(2)
     prob = the_problem(kind, d)
     case = make_case(prob, 120, 1000 + d)
     walks = 18
@@ -101,7 +101,7 @@ def test_quad_equals_lane_form_and_batch_halves(ctx):
     args = (prob, u0, case["axes"], case["scale"], case["loglstar"], 45, st)
     ctx.set_rwalk_form(1)
     lane = ctx.rwalk_batch(*args)
-    ctx.set_rwalk_form(0)
+    ctx.set_rwalk_form(2)
     quad = ctx.rwalk_batch(*args)
     np.testing.assert_array_equal(quad["accept"], lane["accept"])
     np.testing.assert_array_equal(quad["reject"], lane["reject"])
@@ -124,9 +124,9 @@ def test_quad_philox_equals_lane_philox(ctx):
     args = (prob, u0, case["axes"], case["scale"], case["loglstar"], 45, 1234)
     ctx.set_rwalk_form(1)
     lane = ctx.rwalk_batch_philox(*args, sequence0=17, offset=4096)
-    ctx.set_rwalk_form(0)
+    ctx.set_rwalk_form(2)
     quad = ctx.rwalk_batch_philox(*args, sequence0=17, offset=4096)
     assert (quad["accept"] != lane["accept"]).mean() < 1e-3  # same draws; a knife-edge accept may differ
     same = quad["accept"] == lane["accept"]
     np.testing.assert_allclose(quad["u"][same], lane["u"][same], rtol=0, atol=1e-12)
-    assert 0.2 < quad["accept"].mean() / 45 < 0.8
+    assert 0.05 < quad["accept"].mean() / 45 < 0.8

@@ -21,7 +21,7 @@ ev = [ctx.event() for _ in range(2)]
 kq = 512
 idxq = (np.arange(64 * kq, dtype=np.int32) // kq) * bench.MAX_ELLS
 out = {}
-for form in (1, 0):
+for form in (1, 2):
     ctx.set_rwalk_form(form)
     for name, count, idx in (("64x2000", None, sh.idx), ("64x512", 64 * kq, idxq)):
         ctx._check(ctx.lib.dh_memcpy_h2d(ctx.handle, sh.d_idx, idx.ctypes.data, idx.nbytes))
