@@ -184,6 +184,16 @@ class Shard:
                                         self.walks, None, a, self.d_u, self.d_v, self.d_logl,
                                         self.d_na, self.d_nr, b))
 
+    def walk_q_philox(self, i=0, j=0):
+        """Queue fill j of step i in the throughput RNG mode."""
+        c, lib, h = self.ctx, self.ctx.lib, self.ctx.handle
+        d, n = self.d, self.runs * self.kq
+        c._check(lib.dh_rwalk_batch_philox_dev(h, self.ph, n, d, d, self.d_u0q + j * n * d * 8, self.d_axes,
+                                               self.runs * self.me, self.d_idxq, self.scale,
+                                               self.loglstar, self.walks, None, int(self.entropy[0]), 0,
+                                               int(i * self.nq + j) * 4096, self.d_u, self.d_v, self.d_logl,
+                                               self.d_na, self.d_nr))
+
     def step(self, i=0, rebuild=True):
         """One bound-update interval at the gate queue size: rebuild + enlarge + nq queue fills."""
         if rebuild:
@@ -240,11 +250,17 @@ class Shard:
         self.ctx.sync()
         plain = self.fetch_bound()
         self.rebuild(enlarge=True)
-        self.walk(0)
+        self.walk_q(0, 0)        # the timed launch shape: runs x kq walkers, queue fill 0
         self.ctx.sync()
-        bnd, wk = self.fetch_bound(), self.fetch_walk()
+        bnd, wkq = self.fetch_bound(), self.fetch_walk()
+        self.reset_rng()
+        self.walk(0)             # the K = nlive launch (config.interval_at_queue_nlive)
+        self.ctx.sync()
+        wk = self.fetch_walk()
         assert np.all(bnd["status"] == 0), bnd["status"]
         assert np.all(wk["accept"] + wk["reject"] == self.walks)
+        kq = self.kq
+        assert np.all((wkq["accept"] + wkq["reject"])[:runs * kq] == self.walks)
         kids = np.random.SeedSequence(self.entropy).spawn(self.k)
         nwalk = 0
         for r in check_runs:
@@ -274,21 +290,28 @@ class Shard:
             # in the device's frame (its columns equal the oracle's up to LAPACK's arbitrary signs,
             # checked through axes @ axes.T above)
             frame = bnd["axes"][r, 0]
-            for w in range(r * nlive, r * nlive + min(walkers_per_run, nlive)):
-                rng = np.random.Generator(np.random.PCG64(kids[w]))
-                ref = P.rwalk(self.u0[w].copy(), self.loglstar, frame, self.scale,
+            # (launch, walker index in the launch, its start point, its child stream)
+            cases = [(wkq, r * kq + i, self.u0q[0, r * kq + i], kids[r * kq + i])
+                     for i in range(min(walkers_per_run, kq))]
+            cases += [(wk, r * nlive + i, self.u0[r * nlive + i], kids[r * nlive + i])
+                      for i in range(min(max(walkers_per_run // 4, 1), nlive))]
+            for got, w, start, kid in cases:
+                rng = np.random.Generator(np.random.PCG64(kid))
+                ref = P.rwalk(start.copy(), self.loglstar, frame, self.scale,
                               self.prob.prior_transform, self.prob.loglikelihood, rng, self.walks)
-                assert ref["accept"] == wk["accept"][w], (w, ref["accept"], wk["accept"][w])
-                assert ref["reject"] == wk["reject"][w], (w, ref["reject"], wk["reject"][w])
-                np.testing.assert_allclose(wk["u"][w], ref["u"], rtol=0, atol=1e-12)
-                np.testing.assert_allclose(wk["logl"][w], ref["logl"], rtol=1e-11)
+                assert ref["accept"] == got["accept"][w], (w, ref["accept"], got["accept"][w])
+                assert ref["reject"] == got["reject"][w], (w, ref["reject"], got["reject"][w])
+                np.testing.assert_allclose(got["u"][w], ref["u"], rtol=0, atol=1e-12)
+                np.testing.assert_allclose(got["logl"][w], ref["logl"], rtol=1e-11)
                 nwalk += 1
         return {"checker": "oracle/ (NumPy restatement pinned to the reference's golden vectors)",
                 "runs_checked": [int(r) for r in check_runs],
                 "ellipsoids": "nells exact; ctr 1e-13; cov/axlens/logvol 1e-9 (before and after "
                               "the 1.25 enlargement)",
                 "walkers_checked": nwalk,
-                "walkers": "accept/reject counts exact; u 1e-12 abs; logl 1e-11 rel",
+                "walkers": "accept/reject counts exact; u 1e-12 abs; logl 1e-11 rel; per checked run "
+                           f"{min(walkers_per_run, kq)} walkers of the timed launch shape (runs x {kq}) and "
+                           f"{min(max(walkers_per_run // 4, 1), nlive)} of the K = nlive launch",
                 "ok": True}
 
 
@@ -365,12 +388,14 @@ def launch_selftest(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--runs", type=int, default=64,
                     help="independent C2 runs per GPU (C5 shard = 64)")
     ap.add_argument("--nlive", type=int, default=2000)
     ap.add_argument("--walks", type=int, default=45)
+    ap.add_argument("--queue", type=int, default=GATE_QUEUE,
+                    help="walkers in flight per run (the queue size of the evidence gate)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--preroll", type=int, default=80,
                     help="untimed steps before the warm-up (GPU clock ramp)")
@@ -378,12 +403,12 @@ def main():
     ap.add_argument("--no-rebuild", action="store_true",
                     help="time the proposal kernel alone (diagnostic)")
     ap.add_argument("--no-e2e", action="store_true",
-                    help="skip the end-to-end device-loop leg (tap C)")
+                    help="skip the end-to-end device-loop legs (tap C)")
     ap.add_argument("--no-verify", action="store_true",
                     help="skip the oracle check of the timed entry points (diagnostic)")
     ap.add_argument("--lean", action="store_true",
                     help="profiling runs: only the timed launch shape (no CPU / end-to-end / oracle-check / "
-                         "queue-512 / Philox legs), so that per-kernel averages are those of the headline step")
+                         "queue-nlive / Philox legs), so that per-kernel averages are those of the headline step")
     ap.add_argument("--launch-selftest", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.lean:
@@ -399,6 +424,12 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # stdout carries ONE line, the JSON record.  RCCL prints a version banner through C stdio on fd 1
+    # (flushed at exit, i.e. after the record), so fd 1 is pointed at stderr for the life of the process
+    # and the record is written to the saved descriptor.
+    sys.stdout.flush()
+    record_fd = os.dup(1)
+    os.dup2(2, 1)
     prob = c2_problem()
     # CPU baseline first, while this process holds no HIP / torch state: the all-cores leg forks
     # its workers (256 spawned interpreters took 30 s to start on the GPU box's host)
@@ -408,7 +439,6 @@ def main():
         cpu = cpu_baseline(prob, u0c, args.nlive, RWALK_SCALE, loglstar_c, args.walks, args.cpu_seconds)
         del u0c
     import torch
-    dist = None
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # One process group for every world size, 1 included: the record exchange below is then always an
@@ -423,8 +453,8 @@ def main():
     ctx = _lib.Context(local_rank)
     d = prob.ndim
     runs, nlive = args.runs, args.nlive
-    sh = Shard(ctx, prob, runs, nlive, args.walks, seed=1000 + rank, entropy=(21, rank, 0, 0))
-    k = sh.k
+    sh = Shard(ctx, prob, runs, nlive, args.walks, seed=1000 + rank, entropy=(21, rank, 0, 0), queue=args.queue)
+    k, kq, nq = sh.k, sh.kq, sh.nq
 
     ev = [ctx.event() for _ in range(4)]
 
@@ -433,9 +463,8 @@ def main():
         # see), then the cross-rank barrier, then a device-wide synchronize
         ctx.sync()
         torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
 
     sh.rebuild()  # frames must exist even with --no-rebuild
     # untimed pre-roll before the W warm-up steps: the first ~0.2 s after the context is created run at
@@ -454,10 +483,9 @@ def main():
     barrier()
     wall = time.perf_counter() - t0
     dev_ms = ctx.elapsed_ms(ev[3], ev[0]) / args.steps
-    if dist is not None:
-        t = torch.tensor([wall], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall = float(t.item())
+    t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    wall = float(t.item())
 
     # per-kernel durations (HIP events on the launch stream), outside the
     # timed region so the event records do not perturb it
@@ -468,71 +496,76 @@ def main():
         if not args.no_rebuild:
             sh.rebuild()
         ctx.record(ev[1])
-        sh.walk(i)
+        for j in range(nq):
+            sh.walk_q(i, j)
         ctx.record(ev[2])
         ctx.sync()
         t_rb += ctx.elapsed_ms(ev[0], ev[1])
-        t_wk += ctx.elapsed_ms(ev[1], ev[2])
+        t_wk += ctx.elapsed_ms(ev[1], ev[2]) / nq   # one launch of runs x kq walkers
     t_rb /= nrep
     t_wk /= nrep
 
     wkr = sh.fetch_walk()
     bnd = sh.fetch_bound()
-    # throughput RNG mode (outside the timed region): the same step with Philox draws
-    t_ph = step_ph = 0.0
-    for i in range(0 if args.lean else nrep + 1):
-        ctx.record(ev[0])
-        if not args.no_rebuild:
-            sh.rebuild()
-        ctx.record(ev[1])
-        sh.walk_philox(i)
-        ctx.record(ev[2])
-        ctx.sync()
-        if i:  # first launch: warm-up
-            t_ph += ctx.elapsed_ms(ev[1], ev[2]) / nrep
-            step_ph += ctx.elapsed_ms(ev[0], ev[2]) / nrep
-    wk_ph = sh.fetch_walk()
-    assert np.all(wk_ph["accept"] + wk_ph["reject"] == args.walks)
-    if args.lean:
-        t_ph = step_ph = float("nan")
-    nacc, nrej, status, nells = wkr["accept"], wkr["reject"], bnd["status"], bnd["nells"]
+    nacc, nrej = wkr["accept"][:runs * kq], wkr["reject"][:runs * kq]
+    status, nells = bnd["status"], bnd["nells"]
     assert np.all(nacc + nrej == args.walks)
     assert np.all(status == 0), status
-    props_per_step_rank = k * args.walks
+    props_per_launch = runs * kq * args.walks
+    props_per_step_rank = props_per_launch * nq
     value = world * props_per_step_rank * args.steps / wall
 
-    # the same interval at the queue size of the end-to-end leg (K = 512 walkers in flight per
-    # run: ceil(nlive / 512) launches of runs x 512 walkers after one rebuild) -- outside the
-    # timed region, reported beside the headline
-    kq = 512
-    nq = (nlive + kq - 1) // kq
-    tq = None
-    if not args.no_rebuild and nlive >= kq and not args.lean:
-        idxq = (np.arange(runs * kq, dtype=np.int32) // kq) * MAX_ELLS
-        ctx._check(ctx.lib.dh_memcpy_h2d(ctx.handle, sh.d_idx, idxq.ctypes.data, idxq.nbytes))
-        for rep in range(3):
-            if rep == 1:
+    # The same interval as ONE launch of nlive walkers per run (queue size = nlive: the headline of rounds
+    # 1-2), and both shapes in the throughput RNG mode (hiprand Philox) -- outside the timed region
+    full = ph = None
+    if not args.lean:
+        def timed(fn_rb, fn_wk, nwk):
+            trb = twk = 0.0
+            for i in range(nrep + 1):
                 ctx.record(ev[0])
-            for _ in range(2 if rep else 1):
-                sh.rebuild()
-                for j in range(nq):
-                    sh.walk(j, 0, runs * kq)
-        ctx.record(ev[1])
-        ctx.sync()
-        tq = ctx.elapsed_ms(ev[0], ev[1]) / 4
-        ctx._check(ctx.lib.dh_memcpy_h2d(ctx.handle, sh.d_idx, sh.idx.ctypes.data, sh.idx.nbytes))
+                if not args.no_rebuild:
+                    fn_rb()
+                ctx.record(ev[1])
+                for j in range(nwk):
+                    fn_wk(i, j)
+                ctx.record(ev[2])
+                ctx.sync()
+                if i:  # first pass: warm-up
+                    trb += ctx.elapsed_ms(ev[0], ev[1]) / nrep
+                    twk += ctx.elapsed_ms(ev[1], ev[2]) / nrep
+            return trb, twk
+        trb, twk = timed(sh.rebuild, lambda i, j: sh.walk(i), 1)
+        wk_full = sh.fetch_walk()
+        assert np.all(wk_full["accept"] + wk_full["reject"] == args.walks)
+        full = {"what": f"the same bound-update interval as ONE launch of {runs} x {nlive} walkers after one "
+                        f"rebuild (queue size = nlive; ln Z at this queue size is biased by +0.2 in the "
+                        f"reference and on the device alike, tests/test_gpu_logz_gate.py)",
+                "ms": trb + twk, "rwalk_kernel_ms": twk, "kernel": "rwalk_kernel<25,true,PREC_AFFINE> (one walker per lane)",
+                "proposals_per_s": world * k * args.walks / ((trb + twk) * 1e-3),
+                "proposals_per_s_rwalk_kernel_only": world * k * args.walks / (twk * 1e-3),
+                "hbm_frac_algorithmic": k * args.walks * 8 * (2 * d + 1) / (twk * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        trb, twk = timed(sh.rebuild, lambda i, j: sh.walk_q_philox(i, j), nq)
+        wq = sh.fetch_walk()
+        assert np.all((wq["accept"] + wq["reject"])[:runs * kq] == args.walks)
+        trb2, twk2 = timed(sh.rebuild, lambda i, j: sh.walk_philox(i), 1)
+        ph = {"rng": "hiprand Philox4x32-10, fp32 Box-Muller normals (dh_rwalk_batch_philox_dev); "
+                     "not stream-compatible, validated statistically (tests/test_gpu_philox.py)",
+              "rwalk_kernel_ms": twk / nq, "step_ms": trb + twk,
+              "proposals_per_s_rwalk_kernel_only": world * props_per_launch / (twk / nq * 1e-3),
+              "proposals_per_s_step": world * props_per_step_rank / ((trb + twk) * 1e-3),
+              "accept_frac": float(wq["accept"][:runs * kq].sum() / props_per_launch),
+              "at_queue_nlive": {"rwalk_kernel_ms": twk2, "step_ms": trb2 + twk2,
+                                 "proposals_per_s_step": world * k * args.walks / ((trb2 + twk2) * 1e-3)}}
 
     verified = None
     if not args.no_verify and not args.no_rebuild:
         verified = sh.verify()  # raises on any mismatch
 
-    # ensemble exchange step (C5): one record per run gathered over RCCL
-    rccl_ranks = 0
-    if dist is not None:
-        rec = torch.tensor(nacc.reshape(runs, -1).mean(1), device="cuda")
-        out = [torch.empty_like(rec) for _ in range(world)]
-        dist.all_gather(out, rec)
-        rccl_ranks = _gather_ranks(dist, torch, rank, world, dev)
+    # ensemble exchange step (C5): one record per run gathered over RCCL -- at every world size
+    rec = torch.tensor(nacc.reshape(runs, -1).mean(1), device="cuda")
+    out = [torch.empty_like(rec) for _ in range(world)]
+    dist.all_gather(out, rec)
+    rccl_ranks = _gather_ranks(dist, torch, rank, world, dev)
 
     # ---- tap C (outside the timed region): the same shard run END TO END by the
     # device-resident nested-sampling loop, every run to dlogz = 0.01
@@ -544,14 +577,12 @@ def main():
             t0 = time.perf_counter()
             table = ensemble.run_ensemble_device(
                 prob, runs * world, base_seed=21, world=world, rank=rank,
-                dist=dist, device=dev if dist else None,
-                nlive=nlive, queue_size=512, walks=args.walks,
+                dist=dist, device=dev, nlive=nlive, queue_size=GATE_QUEUE, walks=args.walks,
                 rebuild_sync=rebuild_sync, rng=rng)
             dt = time.perf_counter() - t0
-            if dist is not None:
-                t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                dt = float(t.item())
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
             lz = table[:, 1]
             return {"runs": int(len(table)), "seconds": dt,
                     "likelihood_calls_per_s": float(table[:, 4].sum() / dt),
@@ -560,45 +591,43 @@ def main():
                     "logz_se": float(lz.std(ddof=1) / math.sqrt(len(lz)))}
 
         # reference bound-update schedule per run (results independent of the sharding) ...
-        e2e = {"tap_point": "C (device-resident NS loop, dh_ns_ensemble)", "queue_size": 512}
+        e2e = {"tap_point": "C (device-resident NS loop, dh_ns_ensemble)", "queue_size": GATE_QUEUE}
         e2e.update(e2e_leg(False))
         e2e.update(reference_logz_gate())
         e2e.update({"logz_truth": -57.5646,
-                    "gather": "RCCL all_gather of 6 doubles per run" if dist else
-                              "single process"})
+                    "gather": f"RCCL all_gather of the per-run records (7 doubles each) over {world} rank(s)"})
         # ... and with the ensemble's rebuilds synchronised (early, never late)
         e2e["rebuild_sync"] = e2e_leg(True)
         # ... and with the proposals drawn from hiprand Philox streams (throughput RNG mode)
         e2e["throughput_rng"] = e2e_leg(False, rng="philox")
-        # BASELINE config C4 (200-D iid Normal, Normal prior, bound='single', sample='rslice', nlive 4000) through the
-        # same loop (wave-per-walker kernels, multi-workgroup Ellipsoid.update), at N = 1 only (no rank waits for
-        # another at the end of a scaling run): 4 runs to dlogz = 0.01
+        # BASELINE configs C3 (eggbox 2-D, multi / rslice, nlive 5000) and C4 (200-D iid Normal, Normal prior,
+        # single / rslice, nlive 4000) through the same loop, at N = 1 only (no rank waits for another at
+        # the end of a scaling run): every run to dlogz = 0.01, the real reference's ensembles beside them
         if rank == 0 and world == 1:
-            try:
-                e2e["config_C4"] = c4_leg(ctx)
-            except Exception as exc:  # the C4 leg must not take the headline down with it
-                e2e["config_C4"] = {"error": repr(exc)}
+            for name, leg in (("config_C3", c3_leg), ("config_C4", c4_leg)):
+                try:
+                    e2e[name] = leg(ctx)
+                except Exception as exc:  # a side leg must not take the headline down with it
+                    e2e[name] = {"error": repr(exc)}
 
     if rank == 0:
         alg_bytes = 8 * (2 * d + 1)  # read u, write u', write logl
         flops = 2 * d * d + 8 * d + (d * d + 3 * d)  # frame mat-vec + sym. quad form
-        achieved = props_per_step_rank * alg_bytes / (t_wk * 1e-3) / 1e9
+        achieved = props_per_launch * alg_bytes / (t_wk * 1e-3) / 1e9
         traffic, traffic_src, traffic_rb = None, None, None
-        for rnd in ("r02", "r01"):
-            pmc = os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json")
-            if os.path.exists(pmc) and runs == 64 and nlive == 2000 and args.walks == 45:
-                # PMC counters cannot be read from inside this process; the values are
-                # the committed rocprofv3 measurement of this same launch shape
-                # (tools/pmc_traffic.py: 2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes)
-                with open(pmc) as f:
-                    pj = json.load(f)
-                kk = [x for x in pj["kernels"] if x.startswith("rwalk_kernel<25")]
-                if kk:
-                    traffic = pj["kernels"][kk[0]]["traffic_bytes_per_launch"]
-                traffic_rb = pj.get("rebuild_pipeline_bytes_per_launch_sequence")
-                traffic_src = (f"profiles/{rnd}/pmc_traffic.json (2*FETCH_SIZE + WRITE_SIZE, "
-                               "separate --pmc passes)")
-                break
+        pmc = os.path.join(ROOT, "profiles", "r03", "pmc_traffic.json")
+        if os.path.exists(pmc) and runs == 64 and nlive == 2000 and args.walks == 45 and kq == GATE_QUEUE:
+            # PMC counters cannot be read from inside this process; the values are
+            # the committed rocprofv3 measurement of this same launch shape
+            # (tools/pmc_traffic.py: 2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes)
+            with open(pmc) as f:
+                pj = json.load(f)
+            kk = [x for x in pj["kernels"] if x.startswith("rwalkq_kernel<7")]
+            if kk:
+                traffic = pj["kernels"][kk[0]]["traffic_bytes_per_launch"]
+            traffic_rb = pj.get("rebuild_pipeline_bytes_per_launch_sequence")
+            traffic_src = ("profiles/r03/pmc_traffic.json (2*FETCH_SIZE + WRITE_SIZE, "
+                           "separate --pmc passes)")
         line = {
             "metric": "proposals/sec + ellipsoid-rebuilds/sec, 25-D corr-Normal "
                       "nlive=2000 (multi/rwalk)",
@@ -617,53 +646,47 @@ def main():
             "rccl_ranks": rccl_ranks,
             "config": {
                 "workload": f"C2 x {runs} independent runs per GPU (C5 shard); "
-                            f"per step and run: 1 MultiEllipsoid rebuild + "
-                            f"enlarge 1.25 + K={nlive} walkers x {args.walks} "
-                            f"rwalk steps (= one bound-update interval); live sets "
-                            f"uniform inside the likelihood contour",
-                "ndim": d, "nlive": nlive, "walks": args.walks,
+                            f"per step and run: 1 MultiEllipsoid rebuild + enlarge 1.25 + "
+                            f"{nq} queue fills of K={kq} walkers x {args.walks} rwalk steps "
+                            f"(= one bound-update interval at the queue size that passes the "
+                            f"ln Z gate); live sets uniform inside the likelihood contour",
+                "ndim": d, "nlive": nlive, "walks": args.walks, "queue_size": kq,
+                "queue_fills_per_step": nq,
                 "runs_per_gpu": runs, "tap_point": "A (kernel boundary)",
                 "rebuild_in_step": not args.no_rebuild,
                 "rebuilds_per_s": (0.0 if args.no_rebuild else
                                    world * runs * args.steps / wall),
                 "rebuild_kernel_ms": t_rb, "rwalk_kernel_ms": t_wk,
+                "rwalk_launches_per_step": nq,
                 "device_ms_per_step": dev_ms,
                 "proposals_per_s_rwalk_kernel_only":
-                    world * props_per_step_rank / (t_wk * 1e-3),
+                    world * props_per_launch / (t_wk * 1e-3),
                 "rebuilds_per_s_rebuild_kernel_only":
                     world * runs / (t_rb * 1e-3) if t_rb > 0 else None,
                 "nells_per_run": float(nells.mean()),
-                "accept_frac": float(nacc.sum() / (k * args.walks)),
+                "accept_frac": float(nacc.sum() / props_per_launch),
                 "rng": "PCG64 + ziggurat, stream-identical to numpy.random.Generator (parity mode)",
-                "throughput_rng_mode": {
-                    "rng": "hiprand Philox4x32-10, fp32 Box-Muller normals (dh_rwalk_batch_philox_dev); "
-                           "not stream-compatible, validated statistically (tests/test_gpu_philox.py)",
-                    "rwalk_kernel_ms": t_ph, "step_ms": step_ph,
-                    "proposals_per_s_rwalk_kernel_only": world * props_per_step_rank / (t_ph * 1e-3),
-                    "proposals_per_s_step": world * props_per_step_rank / (step_ph * 1e-3),
-                    "accept_frac": float(wk_ph["accept"].sum() / (k * args.walks))},
                 "verified": verified,
             },
             "roofline": {
-                "bound": "hbm", "kernel": "rwalk_kernel<25,true,PREC_AFFINE>",
+                "bound": "hbm", "kernel": "rwalkq_kernel<7,PREC_AFFINE,PCG64> (four lanes per walker)",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
-                "algorithmic_bytes_per_launch": props_per_step_rank * alg_bytes,
-                "kernel_ms": t_wk,
+                "algorithmic_bytes_per_launch": props_per_launch * alg_bytes,
+                "kernel_ms": t_wk, "launches_per_step": nq,
                 "note": "algorithmic bytes = 408 B/proposal (SURVEY 8d); walker "
                         "state stays in registers for all 45 steps, so the "
-                        "binding roof is fp64 VALU, reported below",
+                        "binding roof is the fp64 pipes (VALU + MFMA), reported below",
                 "fp64_valu": {
-                    "achieved": props_per_step_rank * flops / (t_wk * 1e-3) / 1e12,
+                    "achieved": props_per_launch * flops / (t_wk * 1e-3) / 1e12,
                     "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s"},
             },
         }
-        if tq is not None:
-            line["config"]["interval_at_queue_512"] = {
-                "what": f"the same bound-update interval flown as {nq} launches of {runs} x {kq} "
-                        f"walkers after one rebuild (queue size of the end-to-end leg)",
-                "ms": tq, "proposals_per_s": world * runs * kq * nq * args.walks / (tq * 1e-3)}
+        if full is not None:
+            line["config"]["interval_at_queue_nlive"] = full
+        if ph is not None:
+            line["config"]["throughput_rng_mode"] = ph
         if not args.no_rebuild and t_rb > 0:
             # the rebuild pipeline (k_root / k_split / k_ell / k_finish) takes most of the
             # step; SURVEY 8d prices it at 8*N*D*P bytes with P = 62 dependency-ordered
@@ -688,9 +711,29 @@ def main():
             line["config"]["end_to_end"] = e2e
         if cpu is not None:  # the CPU baseline is timed on rank 0 at N = 1 only
             line["cpu_baseline"] = cpu
-        print(json.dumps(line), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
+        os.write(record_fd, (json.dumps(line) + "\n").encode())
+    dist.destroy_process_group()
+
+
+def c3_leg(ctx, runs=16, queue=1024):
+    from dynesty_amd import problems
+    prob = problems.eggbox(2, name="C3")
+    kw = dict(bound='multi', sample='rslice', slices=5, dlogz=0.01)
+    ctx.ns_ensemble(prob, 2, 5000, queue, entropy=[3], max_fills=2, **kw)  # allocations, code objects
+    t0 = time.perf_counter()
+    r = ctx.ns_ensemble(prob, runs, 5000, queue, entropy=[21], **kw)
+    dt = time.perf_counter() - t0
+    out = {"what": "eggbox 2-D, nlive 5000, MultiEllipsoid (13-15 ellipsoids), rslice x 5, device-resident loop",
+           "runs": runs, "queue_size": queue, "seconds": dt, "seconds_per_run": dt / runs,
+           "likelihood_calls_per_s": float(r["ncall"].sum() / dt), "status_ok": bool((r["status"] == 0).all()),
+           "logz_mean": float(r["logz"].mean()), "logz_se": float(r["logz"].std(ddof=1) / math.sqrt(runs)),
+           "logz_truth": 235.856, "mean_bound_updates": float(np.mean(r["nbound"]))}
+    ref = os.path.join(ROOT, "tests", "golden", "c3_logz_ref.json")
+    if os.path.exists(ref):
+        ens = json.load(open(ref))["ensembles"]
+        out["logz_reference"] = {k: {"mean": e["mean"], "se": e["se"], "n": e["n"],
+                                     "mean_seconds_1core": e["mean_seconds_1core"]} for k, e in ens.items()}
+    return out
 
 
 def c4_leg(ctx, runs=4, queue=1000):
@@ -757,11 +800,16 @@ def cpu_baseline(prob, u0, nlive, scale, loglstar, walks, budget_s):
     from oracle import bounding_ref as B
     from oracle import proposals_ref as _P  # noqa: F401  (imported here so that forked workers inherit it)
     os.environ.setdefault("OMP_NUM_THREADS", "1")
-    pts = u0[:nlive]
-    t0 = time.perf_counter()
-    mell = B.multi_update(pts)
-    mell = B.scale_multi_to_logvol(mell, mell.logvol + math.log(1.25))
-    t_rebuild = time.perf_counter() - t0
+    # rebuild: the median of five (one per live set of the shard's first five runs) -- a single timing
+    # swung 28 -> 106 ms between rounds on the GPU box's host
+    t_rebuilds = []
+    for r in range(5):
+        pts = u0[r * nlive:(r + 1) * nlive] if len(u0) >= (r + 1) * nlive else u0[:nlive]
+        t0 = time.perf_counter()
+        mell = B.multi_update(pts)
+        mell = B.scale_multi_to_logvol(mell, mell.logvol + math.log(1.25))
+        t_rebuilds.append(time.perf_counter() - t0)
+    t_rebuild = float(np.median(t_rebuilds))
     axes = mell.ells[0].axes
     sample = u0[:4096]
     n, dt = _cpu_walk_worker((99, sample, loglstar, axes, scale, walks, budget_s * 0.6))
@@ -771,8 +819,9 @@ def cpu_baseline(prob, u0, nlive, scale, loglstar, walks, budget_s):
            "kind": "port",
            "rebuilds_per_s": 1.0 / t_rebuild,
            "proposals_per_s_walk_only": 1.0 / per_prop,
-           "sample": f"1 rebuild of a {nlive}x{prob.ndim} live set "
-                     f"({t_rebuild * 1e3:.0f} ms) + {n} walkers x {walks} steps "
+           "sample": f"5 rebuilds of {nlive}x{prob.ndim} live sets "
+                     f"(median {t_rebuild * 1e3:.0f} ms, range {min(t_rebuilds) * 1e3:.0f}-{max(t_rebuilds) * 1e3:.0f} ms) "
+                     f"+ {n} walkers x {walks} steps "
                      f"({dt:.1f} s), oracle/ (NumPy/SciPy restatement), 1 thread",
            "reference_figure": {
                "proposals_per_s": REFERENCE_C2_PROPOSALS_PER_S_1CORE,

@@ -27,7 +27,7 @@ def test_bench_shape_vs_oracle(ctx):
         sh.step(i)
     ctx.sync()
     info = sh.verify(check_runs=[0, 31, 63], walkers_per_run=64)
-    assert info["ok"] and info["walkers_checked"] == 192
+    assert info["ok"] and info["walkers_checked"] == 240
     # every run of the shard: one ellipsoid for a unimodal contour, all live points inside
     b = sh.fetch_bound()
     assert np.all(b["status"] == 0)

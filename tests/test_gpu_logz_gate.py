@@ -5,6 +5,8 @@ paths use.  An ensemble mean is only known to its standard error, so the bound i
 max(0.05, 3 * sqrt(se_device^2 + se_reference^2)).
 
 Reference facts these files hold (and that the gate therefore carries):
+  C3 (eggbox 2-D, nlive 5000, multi/rslice):  see tests/golden/c3_logz_ref.json (16 runs each at K = 1 and
+     SerialPool(1024); about 235.89 +- 0.01, test-suite truth 235.856);
   C2 (25-D rho=0.4 Normal, nlive 2000, multi/rwalk):  K=1 -57.485 +- 0.026, K=512 -57.493 +- 0.023,
      K=2000 -57.266 +- 0.028  (analytic -57.5646): the queue-size bias at K = nlive is the reference's own;
   C4 (200-D, nlive 4000, single/rslice):  -250.857, -250.862 (logzerr 0.07; analytic -253.10): the +2.2
@@ -58,6 +60,27 @@ def test_c2_throughput_k_is_not_the_gate_k(ctx):
     g = json.load(open(os.path.join(GOLD, "c2_logz_ref.json")))["ensembles"]
     assert g["K2000"]["mean"] - g["K512"]["mean"] > 0.15
     assert abs(g["K512"]["mean"] - g["K1"]["mean"]) < bound(g["K512"]["se"], g["K1"]["se"])
+
+
+@pytest.mark.parametrize("K,ref_key", [(1024, "K1024"), (1024, "K1")])
+def test_c3_device_ensemble_vs_reference_ensemble(ctx, K, ref_key):
+    """BASELINE C3 at full size -- eggbox 2-D, nlive 5000, MultiEllipsoid (13-15 ellipsoids), rslice x 5 --
+    through the device-resident loop: 32 runs against 16 runs of the real reference at the same queue size
+    (SerialPool(1024)) and against its serial ensemble (tests/golden/c3_logz_ref.json, tools/ref_c3_runs.py).
+    Driver followed: sampler.py:690-778, 1214-1356."""
+    ref = json.load(open(os.path.join(GOLD, "c3_logz_ref.json")))["ensembles"][ref_key]
+    assert ref["n"] >= 16
+    prob = inputs.problem("C3")
+    r = ctx.ns_ensemble(prob, 32, 5000, K, bound="multi", sample="rslice", slices=5, entropy=[2026, 3], dlogz=0.01)
+    assert np.all(r["status"] == 0)
+    lz = r["logz"]
+    mean, se = lz.mean(), lz.std(ddof=1) / math.sqrt(len(lz))
+    assert abs(mean - ref["mean"]) < bound(se, ref["se"]), (mean, se, ref["mean"], ref["se"])
+    assert 0.5 < lz.std(ddof=1) / ref["std"] < 2.0
+    assert abs(r["logzerr"].mean() - ref["mean_logzerr"]) < 0.005
+    assert abs(r["niter"].mean() / ref["mean_niter"] - 1) < 0.02
+    if ref["K"] == K:
+        assert abs(r["ncall"].mean() / ref["mean_ncall"] - 1) < 0.08
 
 
 def test_c4_device_run_vs_reference_runs(ctx):
