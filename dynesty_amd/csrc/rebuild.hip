@@ -104,6 +104,15 @@ struct RebuildArgs {
   double* root_eig;   // runs x (2 D^2 + D + 2): am | axes | axlens | logvol | ok -- the root's eigen-system (k_root_eig)
   int* out_node;      // runs x max_ells: node behind output ellipsoid m (k_finish -> k_out_eig)
   int* out_fast;      // runs x max_ells: 1 = that node's record is the eigen-free form
+  // persistent work-queue form of the tree (k_tree): no levels -- a node's split is queued when its
+  // ellipsoid exists, its children's ellipsoids when its last part has finished the partition
+  int tree;           // 1: queue_split / split_body / ell_body feed the queue instead of the level lists
+  unsigned long long* tq_items;  // tq_cap work items, 0 = not published yet
+  int* tq_ctl;        // [0] head (next ticket), [16] tail (next free slot), [32] items queued or in flight, [48] error
+  int tq_cap;
+  int* nbar;          // runs x max_nodes x kBarStride: per node [0] part barrier, [1] parts done, [2] first k-means partial slot
+  int* kp_top;        // runs: partial-sum slots handed out (multi-part nodes only; capacity maxp per run)
+  int tq_sleep, tq_nocoh;  // diagnostics (DH_TREE_SLEEP, DH_TREE_NOCOH)
 };
 
 #ifdef DH_REBUILD_TIMING
@@ -149,6 +158,10 @@ struct Lds {
   // what the tile currently holds (see stage_tile)
   mutable const double* c_pts;
   mutable int c_start, c_cnt, c_how;
+  // k_tree: producer and consumer of a node's permutation range, record and tree entry are different
+  // workgroups of the SAME kernel (other CUs, other XCDs with their own L2): everything that crosses goes
+  // through agent-scope stores / loads (write-through / bypassing), see parts_barrier
+  bool coh;
 };
 
 // block reductions: wave shuffles, then one LDS exchange across the 4 waves
@@ -352,6 +365,35 @@ __device__ bool jacobi_block(const Lds& L, int D) {
 // rows per thread before any of them is consumed.  The Lds struct remembers what the tile
 // holds: a node that fits one tile is staged ONCE per kernel and reused by the mean / cov /
 // fmax / k-means passes (raw -> centred is done in place).
+// agent-scope (device-coherent) accesses: write-through stores, cache-bypassing loads
+__device__ __forceinline__ double ld_agent(const double* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent(double* p, double v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int ld_agent_i(const int* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent_i(int* p, int v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// through the L.coh switch
+__device__ __forceinline__ double ld_c(const Lds& L, const double* p) { return L.coh ? ld_agent(p) : *p; }
+__device__ __forceinline__ void st_c(const Lds& L, double* p, double v) {
+  if (L.coh)
+    st_agent(p, v);
+  else
+    *p = v;
+}
+__device__ __forceinline__ int ld_ci(const Lds& L, const int* p) { return L.coh ? ld_agent_i(p) : *p; }
+__device__ __forceinline__ void st_ci(const Lds& L, int* p, int v) {
+  if (L.coh)
+    st_agent_i(p, v);
+  else
+    *p = v;
+}
+
 constexpr int kStageBatch = 8;
 __device__ __forceinline__ void stage_tile(const Lds& L, const double* __restrict__ pts,
                                            const int* __restrict__ perm, int start, int cnt, int D,
@@ -381,7 +423,7 @@ __device__ __forceinline__ void stage_tile(const Lds& L, const double* __restric
 #pragma unroll
       for (int k = 0; k < kStageBatch; ++k) {
         const int p = pb + k * pstep;
-        idx[k] = p < cnt ? perm[start + p] : -1;
+        idx[k] = p < cnt ? ld_ci(L, perm + start + p) : -1;
       }
 #pragma unroll
       for (int k = 0; k < kStageBatch; ++k) x[k] = idx[k] >= 0 ? pts[(size_t)idx[k] * D + j] : 0.0;
@@ -1046,14 +1088,14 @@ __device__ __forceinline__ int ellipsoid_store(const Lds& L, const RebuildArgs& 
   const double logvol = a.prefactor + 0.5 * slog;
   const int DD = D * D;
   if (t < D) {
-    es[t] = L.mean[t];
-    es[D + 3 * DD + t] = sqrt(L.lam[t]);
+    st_c(L, es + t, L.mean[t]);
+    st_c(L, es + D + 3 * DD + t, sqrt(L.lam[t]));
   }
   for (int e = t; e < DD; e += kThreads) {
     const int i = e / D, j = e % D;
-    es[D + e] = cov_g[i * LD + j];
-    es[D + DD + e] = L.AM[i * LD + j];
-    es[D + 2 * DD + e] = L.AX[i * LD + j];
+    st_c(L, es + D + e, cov_g[i * LD + j]);
+    st_c(L, es + D + DD + e, L.AM[i * LD + j]);
+    st_c(L, es + D + 2 * DD + e, L.AX[i * LD + j]);
   }
   __syncthreads();
   *logvol_out = logvol;
@@ -1068,14 +1110,14 @@ __device__ __forceinline__ int ellipsoid_store_fast(const Lds& L, const RebuildA
   if (!isfinite(logdet)) return DH_ERR_VALUE;
   const int DD = D * D;
   if (t < D) {
-    es[t] = L.mean[t];
-    es[D + 3 * DD + t] = sqrt(L.lam[t]);
+    st_c(L, es + t, L.mean[t]);
+    st_c(L, es + D + 3 * DD + t, sqrt(L.lam[t]));
   }
   for (int e = t; e < DD; e += kThreads) {
     const int i = e / D, j = e % D;
-    es[D + e] = cov_g[i * LD + j];
-    es[D + DD + e] = L.AM[i * LD + j];
-    es[D + 2 * DD + e] = L.AX[i * LD + j];
+    st_c(L, es + D + e, cov_g[i * LD + j]);
+    st_c(L, es + D + DD + e, L.AM[i * LD + j]);
+    st_c(L, es + D + 2 * DD + e, L.AX[i * LD + j]);
   }
   __syncthreads();
   *logvol_out = a.prefactor + 0.5 * logdet;
@@ -1097,7 +1139,7 @@ __device__ __forceinline__ int node_ellipsoid(const Lds& L, const RebuildArgs& a
   if (count == 1) return DH_ERR_VALUE;
   PH_T0();
   if (have_mean) {  // left in the record by k_split (the final k-means centroid of this cluster)
-    if (t < D) L.mean[t] = es[t];
+    if (t < D) L.mean[t] = ld_c(L, es + t);
     __syncthreads();
   } else {
     node_mean(L, pts, perm, start, count, D);
@@ -1195,13 +1237,6 @@ __device__ __forceinline__ bool parts_barrier(int* bar, int target) {
   return ok_flag != 0;
 }
 
-__device__ __forceinline__ double ld_agent(const double* p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void st_agent(double* p, double v) {
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
 // One part's share of the k-means + partition of node [start, start+count).  q = part
 // index, np = number of parts, kp = this node's partial-sum slots (2 parities x np x KP),
 // bar = its barrier counter.  Returns n0 (size of cluster 0) or -1 on a barrier timeout;
@@ -1213,7 +1248,7 @@ __device__ int node_kmeans_part(const Lds& L, const double* pts, int* perm, int*
   const int DD = D * D, KP = 2 * D + 2;
   const int s0 = start + q * L.TP, cnt = min(L.TP, count - q * L.TP);
   // seeds: major-axis endpoints ctr -/+ axes[:, argmax(axlens)] (bounding.py:278-284)
-  if (t < D) L.sums[t] = es[D + 3 * DD + t];  // axis lengths: one parallel fetch, then a scan in LDS
+  if (t < D) L.sums[t] = ld_c(L, es + D + 3 * DD + t);  // axis lengths: one parallel fetch, then a scan in LDS
   __syncthreads();
   if (t == 0) {
     int best = 0;
@@ -1228,9 +1263,9 @@ __device__ int node_kmeans_part(const Lds& L, const double* pts, int* perm, int*
   stage_tile(L, pts, perm, s0, cnt, D, 0);  // pts = points / scale (pre-divided); resident from here on
   const int kbest = L.ri[301];
   if (t < D) {
-    const double v = es[D + 2 * DD + t * D + kbest];
-    L.cen[t] = (es[t] - v) / L.scale[t];
-    L.cen[D + t] = (es[t] + v) / L.scale[t];
+    const double v = ld_c(L, es + D + 2 * DD + t * D + kbest), ct = ld_c(L, es + t);
+    L.cen[t] = (ct - v) / L.scale[t];
+    L.cen[D + t] = (ct + v) / L.scale[t];
   }
   __syncthreads();
   const int nb = (D + 15) >> 4;
@@ -1388,14 +1423,19 @@ __device__ int node_kmeans_part(const Lds& L, const double* pts, int* perm, int*
   }
   if (valid) {
     const int pos = lb == 0 ? off0 + rank0 : off1 + (t - rank0);
-    if (np > 1)
-      __hip_atomic_store(perm2 + start + pos, perm[s0 + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int src = ld_ci(L, perm + s0 + t);
+    if (np > 1 || L.coh)
+      st_agent_i(perm2 + start + pos, src);
     else
-      perm2[start + pos] = perm[s0 + t];
+      perm2[start + pos] = src;
   }
   if (np > 1) {
     if (!parts_barrier(bar, np * (last_it + 2))) return -1;
-    if (valid) perm[s0 + t] = __hip_atomic_load(perm2 + s0 + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (valid) st_ci(L, perm + s0 + t, ld_agent_i(perm2 + s0 + t));
+  } else if (L.coh) {
+    drain_stores();
+    __syncthreads();
+    if (valid) st_agent_i(perm + s0 + t, ld_agent_i(perm2 + s0 + t));
   } else {
     __threadfence_block();
     __syncthreads();
@@ -1440,6 +1480,7 @@ __device__ __forceinline__ void carve(Lds& L, unsigned char* smem, int D, int TP
   L.TP = TP;
   L.c_pts = nullptr;
   L.c_start = L.c_cnt = L.c_how = -1;
+  L.coh = false;
   L.KG = kThreads / 64;
   L.DP = 1;
   L.DPlog = 0;
@@ -1502,6 +1543,7 @@ __device__ __forceinline__ void carve_split(Lds& L, unsigned char* smem, int D, 
   L.TP = TP;
   L.c_pts = nullptr;
   L.c_start = L.c_cnt = L.c_how = -1;
+  L.coh = false;
   L.KG = kThreads / 64;
   L.DP = 1;
   L.DPlog = 0;
@@ -1563,7 +1605,48 @@ __device__ __forceinline__ void set_status(const RebuildArgs& a, int run, int rc
 }
 
 // queue `node` (count points) for splitting at `level`: one split_list slot + its parts
+// ---- work queue of k_tree ------------------------------------------------------------------------
+// item = valid bit 63 | kind (bit 62: 0 = ellipsoid of a node, 1 = one k-means part of a node) | run (22 bits) |
+// node (24 bits) | part (16 bits).  Producers: count the items as pending FIRST, reserve slots, publish each
+// with an agent-scope store -- after everything the consumer will read has been stored (agent scope) and
+// acknowledged (drain_stores + barrier in the callers).
+constexpr unsigned long long kItemValid = 1ull << 63, kItemSplit = 1ull << 62;
+__device__ __forceinline__ unsigned long long tq_item(bool split, int run, int node, int part) {
+  return kItemValid | (split ? kItemSplit : 0ull) | ((unsigned long long)run << 40) | ((unsigned long long)node << 16) |
+         (unsigned long long)part;
+}
+// one thread: queue n items (ellipsoid of node0, node0 + 1, ... or parts 0 .. n-1 of node0)
+__device__ __forceinline__ bool tq_push(const RebuildArgs& a, bool split, int run, int node0, int n) {
+  __hip_atomic_fetch_add(a.tq_ctl + 32, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const int s0 = __hip_atomic_fetch_add(a.tq_ctl + 16, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (s0 + n > a.tq_cap) {
+    __hip_atomic_fetch_add(a.tq_ctl + 32, -n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    atomicMin(&a.status[run], DH_ERR_NOMEM);
+    return false;
+  }
+  for (int i = 0; i < n; ++i)
+    __hip_atomic_store(a.tq_items + s0 + i, split ? tq_item(true, run, node0, i) : tq_item(false, run, node0 + i, 0),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return true;
+}
+
 __device__ __forceinline__ void queue_split(const RebuildArgs& a, int run, int level, int node, int count) {
+  if (a.tree) {
+    const int np = (count + a.tps - 1) / a.tps;
+    int* nb = a.nbar + ((size_t)run * a.max_nodes + node) * kBarStride;
+    int pb = 0;
+    if (np > 1) {  // only multi-part nodes exchange partial sums
+      pb = atomicAdd(&a.kp_top[run], np);
+      if (pb + np > a.maxp) {
+        atomicMin(&a.status[run], DH_ERR_NOMEM);
+        return;
+      }
+    }
+    st_agent_i(nb + 2, pb);
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // the slot index is acknowledged before the parts are published
+    (void)tq_push(a, true, run, node, np);
+    return;
+  }
   const size_t lp = (size_t)(level & 1) * a.runs + run;
   const int sidx = atomicAdd(&a.nsplit[(size_t)level * a.runs + run], 1);
   const int np = (count + a.tps - 1) / a.tps;
@@ -1852,30 +1935,45 @@ __device__ __forceinline__ void split_body(const RebuildArgs& a, const Lds& L, c
                            bool single) {
   const int D = a.d, t = threadIdx.x;
   const size_t lp = (size_t)(level & 1) * a.runs + run;
-  const int pb = a.part_base[lp * a.maxw + slot];
-  const int cur = a.split_list[lp * a.maxw + slot];
-  const int start = v.nodes[cur].start, count = v.nodes[cur].count, depth = v.nodes[cur].depth;
+  // k_tree (a.tree): `slot` IS the node; its barrier / done counter / first partial-sum slot sit in nbar
+  int* nb = a.tree ? a.nbar + ((size_t)run * a.max_nodes + slot) * kBarStride : nullptr;
+  const int pb = a.tree ? ld_agent_i(nb + 2) : a.part_base[lp * a.maxw + slot];
+  const int cur = a.tree ? slot : a.split_list[lp * a.maxw + slot];
+  const int start = ld_ci(L, &v.nodes[cur].start), count = ld_ci(L, &v.nodes[cur].count),
+            depth = ld_ci(L, &v.nodes[cur].depth);
   const int np = single ? 1 : (count + L.TP - 1) / L.TP;
   const int min_size = 2 * D;
   const int KP = 2 * D + 2;
   double* kp0 = a.kpart + ((size_t)run * a.maxp + pb) * KP;
   double* kp1 = kp0 + (size_t)a.runs * a.maxp * KP;
-  int* bar = a.kbar + (((size_t)level * a.runs + run) * a.maxw + slot) * kBarStride;
+  int* bar = a.tree ? nb : a.kbar + (((size_t)level * a.runs + run) * a.maxw + slot) * kBarStride;
   PH_T0();
   const int n0 = node_kmeans_part(L, a.pts_scaled + (size_t)run * a.n * D, v.perm, v.perm2, start, count, D,
                                   v.estore + (size_t)cur * v.NS, q, np, kp0, kp1, bar, min_size);
   PH_ADD(4);
   if (n0 < 0) {
-    if (t == 0) atomicMin(&a.kerr[run], DH_ERR_HIP);
+    if (t == 0) atomicMin(a.tree ? &a.status[run] : &a.kerr[run], DH_ERR_HIP);
     return;
   }
   const int n1 = count - n0;
   if (min(n0, n1) < min_size) return;  // reject the split (:1521-1522): node stays a leaf
-  if (q == 0 && t == 0) {
+  // Who creates the children: part 0 in the level pipeline (the next kernel starts after every part has
+  // finished); in k_tree the part that finishes LAST -- the children's ellipsoids may be started by other
+  // workgroups the moment they are queued, and they read the permutation ranges all parts have just written.
+  bool creator = q == 0;
+  if (a.tree) {
+    drain_stores();  // this part's permutation range (agent-scope stores) is acknowledged
+    __syncthreads();
+    if (t == 0)
+      L.ri[302] = __hip_atomic_fetch_add(nb + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == np - 1 ? 1 : 0;
+    __syncthreads();
+    creator = L.ri[302] != 0;
+  }
+  if (creator && t == 0) {
     L.ri[300] = -1;
     const int c0 = atomicAdd(&a.nnodes_dev[run], 2);
     if (c0 + 2 > a.max_nodes) {
-      atomicMin(&a.kerr[run], DH_ERR_NOMEM);
+      atomicMin(a.tree ? &a.status[run] : &a.kerr[run], DH_ERR_NOMEM);
     } else {
       Node k0, k1;
       k0.start = start;
@@ -1892,27 +1990,48 @@ __device__ __forceinline__ void split_body(const RebuildArgs& a, const Lds& L, c
       k0.has_mean = k1.has_mean = 1;
       k0.logvol = k1.logvol = 0.0;
       k0.fmax = k1.fmax = INFINITY;
-      v.nodes[c0] = k0;
-      v.nodes[c0 + 1] = k1;
-      v.nodes[cur].child0 = c0;
-      v.nodes[cur].child1 = c0 + 1;
-      v.nodes[cur].split = 1;
-      const int e = atomicAdd(&a.nell[(size_t)level * a.runs + run], 2);
-      a.ell_list[(size_t)run * 2 * a.maxw + e] = c0;
-      a.ell_list[(size_t)run * 2 * a.maxw + e + 1] = c0 + 1;
+      if (a.tree) {
+        // word by word through agent-scope stores (Node is 16 ints)
+        static_assert(sizeof(Node) % 4 == 0, "Node is copied as ints");
+        const int* w0 = (const int*)&k0;
+        const int* w1 = (const int*)&k1;
+        int* d0 = (int*)&v.nodes[c0];
+        int* d1 = (int*)&v.nodes[c0 + 1];
+        for (int i = 0; i < (int)(sizeof(Node) / 4); ++i) {
+          st_agent_i(d0 + i, w0[i]);
+          st_agent_i(d1 + i, w1[i]);
+        }
+        st_agent_i(&v.nodes[cur].child0, c0);
+        st_agent_i(&v.nodes[cur].child1, c0 + 1);
+        st_agent_i(&v.nodes[cur].split, 1);
+      } else {
+        v.nodes[c0] = k0;
+        v.nodes[c0 + 1] = k1;
+        v.nodes[cur].child0 = c0;
+        v.nodes[cur].child1 = c0 + 1;
+        v.nodes[cur].split = 1;
+        const int e = atomicAdd(&a.nell[(size_t)level * a.runs + run], 2);
+        a.ell_list[(size_t)run * 2 * a.maxw + e] = c0;
+        a.ell_list[(size_t)run * 2 * a.maxw + e + 1] = c0 + 1;
+      }
       L.ri[300] = c0;
     }
   }
   // The children's means come for free: the centroids after the tenth update ARE the means of the final
   // clusters (cluster sums / counts, in the scaled coordinates of the k-means).  k_ell then skips its
   // mean pass over the points (one of its three gathers).
-  if (q == 0) {
+  if (creator) {
     if (t == 0 && !(L.ri[300] >= 0 && L.ri[300] + 2 <= a.max_nodes)) L.ri[300] = -1;
     __syncthreads();
     const int c0 = L.ri[300];
     if (c0 >= 0 && t < 2 * D) {
       const int c = t >= D ? 1 : 0, j = t - c * D;
-      v.estore[(size_t)(c0 + c) * v.NS + j] = L.cen[c * D + j] * L.scale[j];
+      st_c(L, v.estore + (size_t)(c0 + c) * v.NS + j, L.cen[c * D + j] * L.scale[j]);
+    }
+    if (a.tree && c0 >= 0) {
+      drain_stores();  // tree entries and means acknowledged before the children are published
+      __syncthreads();
+      if (t == 0) (void)tq_push(a, false, run, c0, 2);
     }
   }
 }
@@ -1940,24 +2059,28 @@ __global__ void __launch_bounds__(kThreads) k_split(RebuildArgs a, int level) {
 template <bool SLOW>
 __device__ __forceinline__ bool ell_body(const RebuildArgs& a, const Lds& L, const RunView& v, int run, int level, int node) {
   const int D = a.d, t = threadIdx.x;
-  const int start = v.nodes[node].start, count = v.nodes[node].count;
+  const int start = ld_ci(L, &v.nodes[node].start), count = ld_ci(L, &v.nodes[node].count);
   double lv = 0.0, fmx = INFINITY;
   __syncthreads();
   L.c_pts = nullptr;
   const int rc = node_ellipsoid<!SLOW>(L, a, v.pts, v.perm, start, count, v.estore + (size_t)node * v.NS,
                                        v.estore + (size_t)node * v.NS + v.ES, &lv, &fmx,
-                                       v.nodes[node].has_mean != 0);
+                                       ld_ci(L, &v.nodes[node].has_mean) != 0);
   const bool full = SLOW || rc == kFullRecord;
   if (rc != DH_OK && rc != kFullRecord) {
     set_status(a, run, rc);
     return false;
+  }
+  if (a.tree) {  // the record (agent-scope stores of all threads) is acknowledged before the split is queued
+    drain_stores();
+    __syncthreads();
   }
   if (t == 0) {
     v.nodes[node].logvol = lv;
     v.nodes[node].fmax = fmx;
     v.nodes[node].fast = full ? 0 : 1;
     if (count >= 4 * D) {  // big enough to try a split at the next level (:1492-1496)
-      if (level + 1 >= a.levels) {
+      if (!a.tree && level + 1 >= a.levels) {
         atomicMin(&a.status[run], DH_ERR_NOMEM);  // deeper than the launch plan
       } else {
         queue_split(a, run, level + 1, node, count);
@@ -2046,6 +2169,78 @@ __global__ void __launch_bounds__(kThreads) k_deep(RebuildArgs a, int first_leve
   }
 }
 
+// ---- the whole tree by persistent workers on one work queue -----------------------------------------------
+// The level pipeline makes every level wait for its slowest node, twice (k_split, k_ell), launches a pair
+// of kernels per possible level, and cannot run a node's k-means before ALL ellipsoids of its level exist.
+// Here the tree is a set of work items -- "ellipsoid of node x", "k-means part q of node x" -- taken by
+// resident workgroups from one FIFO queue in ticket order: a node's parts are queued (contiguously) when its
+// ellipsoid exists, its children's ellipsoids when its last part has finished the partition.  The node
+// routines are those of the level kernels (same arithmetic, same bits); what changes is that producer and
+// consumer are workgroups of one kernel, so everything that crosses between them is written and read at
+// agent scope (L.coh) and published only after the stores are acknowledged.
+// Progress: tickets are claimed in order and the parts of a node hold consecutive tickets, so at most one
+// node can have claimed and unclaimed parts at a time -- the one straddling the lowest unclaimed ticket --
+// and every other workgroup works on something that finishes without it (np <= resident workgroups is
+// checked by the launcher).  The kernel ends when nothing is queued or in flight ([32] == 0).
+// the two item routines are calls, not inlined code: inlined into one loop body their register needs add
+// up past the 256 of two workgroups per CU (42 VGPRs spilled); behind a call each has its own allocation and
+// the loop keeps nothing live across it but the item
+__device__ __attribute__((noinline)) void tree_split_item(const RebuildArgs& a, unsigned char* smem, int run, int node, int part) {
+  const int D = a.d, t = threadIdx.x;
+  Lds LS;
+  carve_split(LS, smem, D, a.tps);
+  LS.coh = !a.tq_nocoh;
+  const RunView v = view_of(a, run, LS.LD);
+  if (t < D) LS.scale[t] = a.scale_g[(size_t)run * D + t];
+  __syncthreads();
+  split_body(a, LS, v, run, 0, node, part, false);
+}
+__device__ __attribute__((noinline)) void tree_ell_item(const RebuildArgs& a, unsigned char* smem, int run, int node) {
+  Lds L;
+  carve(L, smem, a.d);
+  L.coh = !a.tq_nocoh;
+  const RunView v = view_of(a, run, L.LD);
+  (void)ell_body<false>(a, L, v, run, 0, node);
+}
+
+__global__ void __launch_bounds__(kThreads, 2) k_tree(RebuildArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ unsigned long long s_item;
+  const int t = threadIdx.x;
+  for (;;) {
+    __syncthreads();  // the previous item's LDS use is over
+    if (t == 0) {
+      unsigned long long it = 0;
+      const int ticket = __hip_atomic_fetch_add(a.tq_ctl, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (ticket < a.tq_cap) {
+        long long spins = 0;
+        for (;;) {
+          it = __hip_atomic_load(a.tq_items + ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (it) break;
+          if ((spins & 3) == 0 && __hip_atomic_load(a.tq_ctl + 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= 0) break;
+          for (int k = 0; k < a.tq_sleep; ++k) __builtin_amdgcn_s_sleep(8);
+          if (++spins > (1ll << 22)) {  // a producer died: fail loudly instead of hanging the device
+            __hip_atomic_store(a.tq_ctl + 48, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+          }
+        }
+      }
+      s_item = it;
+    }
+    __syncthreads();
+    const unsigned long long it = s_item;
+    if (!it) return;
+    const int run = (int)((it >> 40) & 0x3fffff), node = (int)((it >> 16) & 0xffffff), part = (int)(it & 0xffff);
+    if (it & kItemSplit)
+      tree_split_item(a, smem, run, node, part);
+    else
+      tree_ell_item(a, smem, run, node);
+    drain_stores();
+    __syncthreads();
+    if (t == 0) __hip_atomic_fetch_add(a.tq_ctl + 32, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 __global__ void __launch_bounds__(kThreads) k_finish(RebuildArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int D = a.d, t = threadIdx.x, run = blockIdx.x;
@@ -2059,6 +2254,7 @@ __global__ void __launch_bounds__(kThreads) k_finish(RebuildArgs a) {
   const double* estore = v.estore;
   const int NS = v.NS, DD = D * D;
   int status = min(a.status[run], a.kerr[run]);  // k_split errors of the last level are folded here
+  if (a.tree && a.tq_ctl[48]) status = min(status, (int)DH_ERR_HIP);  // a k_tree worker gave up waiting
   const int nnodes = min(a.nnodes_dev[run], a.max_nodes);
   // the accept test below is a serial walk over the tree by one thread: every access to a
   // node in global memory is a dependent ~1 us load, so the tree (and, when it fits, the
@@ -2628,6 +2824,26 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
     if (v == 64 || v == 128 || v == 192 || v == 256) a.tps = v;
   }
   a.maxp = n / a.tps + a.maxw + 1;
+  // eigen-free tree nodes (MultiEllipsoid.update only: Ellipsoid.update's single node IS the output)
+  a.fast = mode == 0 ? 1 : 0;
+  if (const char* e = getenv("DH_REBUILD_FAST")) a.fast = a.fast && atoi(e) != 0;  // diagnostic: 0 = eigh on every node
+  // DH_TREE=1: the tree by persistent workers on a work queue (k_tree) instead of the level pipeline
+  // (k_split / k_ell / k_deep).  Same node routines, bit-identical results (tests/test_gpu_edges.py), no
+  // depth limit -- but measured SLOWER (round 3, 20 launches each): 64 C2 runs 1.44 vs 1.29 ms, 16 runs 1.06
+  // vs 0.95, 16 eggbox runs 2.37 vs 2.15, one eggbox run 1.20 vs 0.99.  With 64 runs the chip is saturated
+  // either way (the time scales with the number of workers: 256 -> 2.18 ms, 384 -> 1.68, 512 -> 1.52), and the
+  // queue form loses the level pipeline's five k_split workgroups per CU (its workers carry the 77 KB layout of
+  // the ellipsoid routine: two per CU), pays agent-scope (cache-bypassing) accesses for everything a node hands
+  // to the next, and leaves the early parts of a multi-part node spinning until the late ones find a worker.
+  a.tree = 0;
+  if (const char* e = getenv("DH_TREE")) a.tree = a.fast && atoi(e) != 0;
+  a.tq_cap = 0;
+  if (a.tree) {
+    // partial-sum slots of the multi-part nodes of a whole tree: a depth has at most n / tps + (nodes) parts
+    a.maxp = a.levels * (n / a.tps + 1) + 8;
+    // items: one ellipsoid per node, and per split node ceil(count / tps) parts
+    a.tq_cap = runs * (2 * a.max_nodes + a.levels * (n / a.tps + 1) + 8);
+  }
   const size_t lds_split = split_lds_bytes(d, a.tps);
   // the parts of one node meet at a device-scope barrier, so they must all be resident at the
   // same time: 256 parts (65 536 points per run) fit the 256 CUs with room to spare
@@ -2658,7 +2874,7 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
   // waits for part 0's solve); for k_split only the <= ceil(n / 256) parts of ONE node must: they have
   // consecutive workgroup ids and the dispatcher hands out workgroups in id order, so the parts of the
   // lowest unfinished node are always all dispatched, and every earlier workgroup can finish without them.
-  int cap_root = 0, cap_split = 0;
+  int cap_root = 0, cap_split = 0, cap_tree = 0;
   {
     static int cu_count[kMaxDev] = {};
     int& ncu = cu_count[ctx->device & (kMaxDev - 1)];
@@ -2676,6 +2892,14 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
       occ_split = 1;
     cap_root = ncu * (occ_root > 0 ? occ_root : 1);
     cap_split = ncu * (occ_split > 0 ? occ_split : 1);
+    if (a.tree) {
+      int occ_tree = 0;
+      (void)hipFuncSetAttribute((const void*)k_tree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_tree, (const void*)k_tree, kThreads, lds) != hipSuccess)
+        occ_tree = 1;
+      cap_tree = ncu * (occ_tree > 0 ? occ_tree : 1);
+      cap_split = cap_tree;  // the parts of a node are k_tree workgroups
+    }
   }
   int rp = n > 1 ? (n + kThreads - 1) / kThreads : 1;
   if ((long long)runs * rp > cap_root) rp = 1;
@@ -2684,7 +2908,10 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
                 (n + a.tps - 1) / a.tps, n, cap_split);
   if (getenv("DH_ROOT_PARTS") && atoi(getenv("DH_ROOT_PARTS")) == 0) rp = 1;  // diagnostic
   // zeroed counters: nnodes | nsplit (levels+1) | nell (levels) | nparts (levels+1) | kerr | rbar | kbar (levels x maxw)
-  const size_t b_cnt = (size_t)runs * ((size_t)3 * a.levels + 5 + kBarStride + (size_t)a.levels * a.maxw * kBarStride) * 4;
+  // ... | kp_top (runs) | tq_ctl (64) | nbar (runs x max_nodes x kBarStride) | tq_items (tq_cap x 2 ints)   [k_tree]
+  const size_t n_cnt_old = (size_t)runs * ((size_t)3 * a.levels + 5 + kBarStride + (a.tree ? 0 : (size_t)a.levels * a.maxw * kBarStride));
+  const size_t n_cnt_tree = a.tree ? (size_t)runs + 64 + (size_t)runs * a.max_nodes * kBarStride + 2 * (size_t)a.tq_cap + 2 : 0;
+  const size_t b_cnt = (n_cnt_old + n_cnt_tree) * 4;
   a.rootbuf_stride = (size_t)rp * (2 * (size_t)d + (size_t)d * d + 1) + (size_t)d * d + 8;
   const size_t b_rb = (size_t)runs * a.rootbuf_stride * 8;
   const size_t b_fl = (size_t)runs * a.max_nodes * 8, b_fi = (size_t)runs * a.max_nodes * 2 * 4;
@@ -2693,9 +2920,6 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
   const size_t b_sl = (size_t)2 * runs * a.maxw * 4, b_el = (size_t)runs * 2 * a.maxw * 4;
   const size_t b_sc = (size_t)runs * d * 8;
   const size_t b_ps = mode == 1 ? 0 : (size_t)runs * n * d * 8;
-  // eigen-free tree nodes (MultiEllipsoid.update only: Ellipsoid.update's single node IS the output)
-  a.fast = mode == 0 ? 1 : 0;
-  if (const char* e = getenv("DH_REBUILD_FAST")) a.fast = a.fast && atoi(e) != 0;  // diagnostic: 0 = eigh on every node
   const size_t b_of = a.fast ? (size_t)runs * max_ells * 4 : 0;
   const size_t b_re = a.fast ? (size_t)runs * (2 * (size_t)d * d + d + 2) * 8 : 0;
   auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
@@ -2733,6 +2957,16 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
   a.kerr = a.nparts + (size_t)(a.levels + 1) * runs;
   a.rbar = a.kerr + runs;
   a.kbar = a.rbar + (size_t)runs * kBarStride;
+  a.kp_top = a.nbar = a.tq_ctl = nullptr;
+  a.tq_items = nullptr;
+  if (a.tree) {
+    a.kp_top = cnt + n_cnt_old;
+    a.tq_ctl = a.kp_top + runs;
+    a.nbar = a.tq_ctl + 64;
+    int* q = a.nbar + (size_t)runs * a.max_nodes * kBarStride;
+    if (((uintptr_t)q) & 7) ++q;  // 8-byte items
+    a.tq_items = (unsigned long long*)q;
+  }
   a.split_list = (int*)w;
   w += al(b_sl);
   a.ell_list = (int*)w;
@@ -2777,9 +3011,9 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
   a.n_arr = n_arr;
   DH_DEV_MEMO(attr_lds);
   if (lds > attr_lds) {
-    const void* ks[7] = {(const void*)k_root_parts, (const void*)k_split, (const void*)k_ell<false>,
+    const void* ks[8] = {(const void*)k_root_parts, (const void*)k_split, (const void*)k_ell<false>,
                          (const void*)k_ell<true>, (const void*)k_out_eig, (const void*)k_root_eig,
-                         (const void*)k_deep};
+                         (const void*)k_deep, (const void*)k_tree};
     for (const void* kf : ks)
       if (!hip_ok(ctx, hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
                   "hipFuncSetAttribute(rebuild LDS)"))
@@ -2814,7 +3048,17 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
   }
   // level kernels for a balanced tree's depth plus two; k_deep works off whatever is deeper (DH_DEEP=0: all levels
   // by level kernels, as before; the diagnostic slow mode keeps them too)
-  int nlev = a.levels;
+  if (a.tree) {
+    // persistent workers: as many as can be resident (the parts of a node meet at spin barriers), but
+    // no more than the tree can ever keep busy
+    long long want = (long long)runs * (n / a.tps + 2 * a.maxw + 1);
+    int G = (int)(want < cap_tree ? (want < 1 ? 1 : want) : cap_tree);
+    if (const char* e = getenv("DH_TREE_G")) G = atoi(e) > 0 ? atoi(e) : G;
+    a.tq_sleep = getenv("DH_TREE_SLEEP") ? atoi(getenv("DH_TREE_SLEEP")) : 1;
+    a.tq_nocoh = getenv("DH_TREE_NOCOH") ? atoi(getenv("DH_TREE_NOCOH")) : 0;
+    hipLaunchKernelGGL(k_tree, dim3(G), dim3(kThreads), lds, ctx->stream, a);
+  }
+  int nlev = a.tree ? 0 : a.levels;
   if (a.fast && !(getenv("DH_DEEP") && atoi(getenv("DH_DEEP")) == 0)) nlev = a.levels < lv + 2 ? a.levels : lv + 2;
   if (a.fast && getenv("DH_DEEP_FROM")) {  // diagnostic: hand the tree to k_deep from this level on
     const int f = atoi(getenv("DH_DEEP_FROM"));
@@ -2827,7 +3071,7 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
     else
       hipLaunchKernelGGL(k_ell<true>, dim3(runs * 2 * a.maxw), dim3(kThreads), lds, ctx->stream, a, L, 2 * a.maxw);
   }
-  if (nlev < a.levels) hipLaunchKernelGGL(k_deep, dim3(runs), dim3(kThreads), lds, ctx->stream, a, nlev);
+  if (!a.tree && nlev < a.levels) hipLaunchKernelGGL(k_deep, dim3(runs), dim3(kThreads), lds, ctx->stream, a, nlev);
   if (forked && !hip_ok(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0), "hipStreamWaitEvent(join)")) return DH_ERR_HIP;
   hipLaunchKernelGGL(k_finish, dim3(runs), dim3(kThreads), lds_fin, ctx->stream, a);
   if (a.fast) {

@@ -168,6 +168,45 @@ def test_cooperative_root_threshold_follows_the_occupancy(ctx):
             np.testing.assert_array_equal(a[k], b[k])
 
 
+def test_work_queue_tree_equals_the_level_kernels(ctx):
+    """The work-queue form of the tree (DH_TREE=1: persistent workers on one FIFO queue, no levels -- a node's
+    k-means is queued when its ellipsoid exists, its children when its last part has partitioned; built in
+    round 3, measured slower than the level pipeline and therefore not the default) runs the level kernels'
+    node routines, so it must reproduce the level pipeline bit for bit: single live sets and a ragged batch."""
+    import os
+
+    def run(fn, tree):
+        old = os.environ.get("DH_TREE")
+        os.environ["DH_TREE"] = "1" if tree else "0"
+        try:
+            return fn()
+        finally:
+            if old is None:
+                os.environ.pop("DH_TREE", None)
+            else:
+                os.environ["DH_TREE"] = old
+    many = 0
+    for name in ("c2", "c3", "two5", "ring2", "flat10", "small4", "egg13", "c2s"):
+        pts = inputs.cloud(name)
+        ref = run(lambda: ctx.rebuild(pts, multi=True, want_labels=True), False)
+        for rep in range(3):
+            got = run(lambda: ctx.rebuild(pts, multi=True, want_labels=True), True)
+            assert ref["nells"] == got["nells"] and ref["nnodes"] == got["nnodes"], name
+            for k in FIELDS + ("labels",):
+                np.testing.assert_array_equal(ref[k], got[k])
+        many += ref["nells"] > 4
+    assert many >= 2
+    # a ragged batch of different live sets in one launch sequence
+    sets = [inputs.cloud("c2")[:n] for n in (2000, 1500, 777, 300, 120, 60)] + [inputs.cloud("c2")[::-1].copy()]
+    ref = run(lambda: ctx.rebuild_many(sets, multi=True), False)
+    got = run(lambda: ctx.rebuild_many(sets, multi=True), True)
+    assert len(ref) == len(got) == len(sets)
+    for a, b in zip(ref, got):
+        assert a["nells"] == b["nells"]
+        for k in FIELDS:
+            np.testing.assert_array_equal(a[k], b[k])
+
+
 def test_deep_tail_kernel_equals_the_level_kernels(ctx):
     """The level kernels are launched for a balanced tree's depth + 2; whatever is deeper is worked off by k_deep
     (one workgroup per run, serially).  Forced to take over early (DH_DEEP_FROM) it must give bit-identical results
@@ -178,8 +217,8 @@ def test_deep_tail_kernel_equals_the_level_kernels(ctx):
              (inputs.cloud("ring2"), ("5", "7"))]
 
     def run(pts, env):
-        old = {k: os.environ.get(k) for k in ("DH_DEEP", "DH_DEEP_FROM")}
-        os.environ.update(env)
+        old = {k: os.environ.get(k) for k in ("DH_DEEP", "DH_DEEP_FROM", "DH_TREE")}
+        os.environ.update(dict(env, DH_TREE="0"))  # the level pipeline
         try:
             return ctx.rebuild(pts, multi=True, want_labels=True)
         finally:
