@@ -272,6 +272,12 @@ __global__ void __launch_bounds__(kT) ns_prepare(NsArgs a) {
     a.run_scale[run] = r.scale;
     a.run_doubling[run] = r.doubling;
   }
+  // runs still in the unit-cube phase (the host stops launching that phase's kernel once there are none:
+  // a run never returns to it)
+  int ncube = 0;
+  for (int run = t; run < a.runs; run += kT) ncube += a.st[run].mode == MODE_CUBE ? 1 : 0;
+  ncube = __syncthreads_count(ncube > 0) ? 1 : 0;
+  if (t == 0) a.ndone[1] = ncube;
 }
 
 // ---- queue fill: start points, frames, walker streams ---------------------------
@@ -1213,6 +1219,8 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
   const int64_t fills_cap = max_fills > 0 ? max_fills : 1000000;
   int64_t fill = 0;
   int ndone = 0;
+  int h_state[2] = {0, 1};  // [runs done, any run still in the unit-cube phase]
+  bool cube_phase = true;
   while (fill < fills_cap && ndone < R) {
     for (int burst = 0; burst < 8 && fill < fills_cap; ++burst, ++fill) {
       hipLaunchKernelGGL(ns_prepare, dim3(1), dim3(kT), 0, s, a);
@@ -1224,10 +1232,12 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
       if (rc) return cleanup(rc);
       hipLaunchKernelGGL(ns_select, dim3(R), dim3(kT), 0, s, a);
       hipLaunchKernelGGL(ns_gather, dim3((unsigned)(((size_t)R * K * D + 255) / 256)), dim3(256), 0, s, a);
-      rc = unif_launch_runs(ctx, problem, R * K, D, D, 0, nullptr, nullptr, nullptr, nullptr, 0.0, nullptr,
-                            a.q_rng, 0, a.r_u, a.r_v, a.r_logl, a.r_a, a.r_b, a.q_rng_out, a.run_loglstar,
-                            a.run_mode, K, MODE_CUBE);
-      if (rc) return cleanup(rc);
+      if (cube_phase) {
+        rc = unif_launch_runs(ctx, problem, R * K, D, D, 0, nullptr, nullptr, nullptr, nullptr, 0.0, nullptr,
+                              a.q_rng, 0, a.r_u, a.r_v, a.r_logl, a.r_a, a.r_b, a.q_rng_out, a.run_loglstar,
+                              a.run_mode, K, MODE_CUBE);
+        if (rc) return cleanup(rc);
+      }
       if (sampler == 0) {
         // Philox key: seed from the entropy words, subsequence = global walker slot (first_run + run) * K + w
         // (independent of the sharding), offset advancing by 4096 draws per fill (a walker uses < 31 per step)
@@ -1249,20 +1259,16 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
       if (rc) return cleanup(rc);
       hipLaunchKernelGGL(ns_consume, dim3(R), dim3(kT), lds_cons, s, a);
     }
-    if (!hip_ok(ctx, hipMemcpyAsync(&ndone, a.ndone, 4, hipMemcpyDeviceToHost, s), "D2H ndone") ||
+    if (!hip_ok(ctx, hipMemcpyAsync(h_state, a.ndone, 8, hipMemcpyDeviceToHost, s), "D2H ndone") ||
         !hip_ok(ctx, hipStreamSynchronize(s), "sync"))
       return cleanup(DH_ERR_HIP);
+    ndone = h_state[0];
+    if (!h_state[1]) cube_phase = false;  // (as of the last ns_prepare: every run has its first bound)
   }
   hipLaunchKernelGGL(ns_finish, dim3(R), dim3(kT), lds_fin, s, a);
   if (!hip_ok(ctx, hipGetLastError(), "ns launch") ||
       !hip_ok(ctx, hipMemcpyAsync(records, a.records, (size_t)R * 64, hipMemcpyDeviceToHost, s), "D2H records"))
     return cleanup(DH_ERR_HIP);
-  if (dead_logl_out) {
-    // first max_iter entries per run (caller allocates runs * cap doubles)
-    if (!hip_ok(ctx, hipMemcpyAsync(dead_logl_out, a.dead_logl, (size_t)R * a.cap * 8, hipMemcpyDeviceToHost, s),
-                "D2H dead"))
-      return cleanup(DH_ERR_HIP);
-  }
   if (live_logl_out &&
       !hip_ok(ctx, hipMemcpyAsync(live_logl_out, a.live_logl, (size_t)R * N * 8, hipMemcpyDeviceToHost, s),
               "D2H live"))
@@ -1272,21 +1278,27 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
               "D2H live u"))
     return cleanup(DH_ERR_HIP);
   if (want_pt &&
-      (!hip_ok(ctx, hipMemcpyAsync(live_it_out, a.live_it, (size_t)R * N * 4, hipMemcpyDeviceToHost, s), "D2H live it") ||
-       !hip_ok(ctx, hipMemcpyAsync(dead_id_out, a.dead_id, (size_t)R * a.cap * 4, hipMemcpyDeviceToHost, s), "D2H id") ||
-       !hip_ok(ctx, hipMemcpyAsync(dead_it_out, a.dead_it, (size_t)R * a.cap * 4, hipMemcpyDeviceToHost, s), "D2H it") ||
-       !hip_ok(ctx, hipMemcpyAsync(dead_nc_out, a.dead_nc, (size_t)R * a.cap * 4, hipMemcpyDeviceToHost, s), "D2H nc")))
+      !hip_ok(ctx, hipMemcpyAsync(live_it_out, a.live_it, (size_t)R * N * 4, hipMemcpyDeviceToHost, s), "D2H live it"))
     return cleanup(DH_ERR_HIP);
-  if (dead_u_out) {
-    // only the niter rows each run produced (the caller's runs x max_iter x ndim buffer may be
-    // far larger than what is touched here)
+  if (dead_u_out || want_pt || dead_logl_out) {
+    // only the niter rows each run produced (the caller's runs x max_iter (x ndim) buffers may be
+    // far larger than what is touched here: 64 runs x 400 000 would be 300 MB of pageable copies)
     if (!hip_ok(ctx, hipStreamSynchronize(s), "sync")) return cleanup(DH_ERR_HIP);
     for (int r = 0; r < R; ++r) {
       long long nit = (long long)records[(size_t)r * 8 + 2];
       if (nit > a.cap) nit = a.cap;
-      if (nit > 0 &&
-          !hip_ok(ctx, hipMemcpyAsync(dead_u_out + (size_t)r * a.cap * D, a.dead_u + (size_t)r * a.cap * D,
-                                      (size_t)nit * D * 8, hipMemcpyDeviceToHost, s), "D2H dead u"))
+      if (nit <= 0) continue;
+      const size_t o = (size_t)r * a.cap;
+      if (dead_logl_out && !hip_ok(ctx, hipMemcpyAsync(dead_logl_out + o, a.dead_logl + o, (size_t)nit * 8,
+                                                       hipMemcpyDeviceToHost, s), "D2H dead"))
+        return cleanup(DH_ERR_HIP);
+      if (dead_u_out && !hip_ok(ctx, hipMemcpyAsync(dead_u_out + o * D, a.dead_u + o * D, (size_t)nit * D * 8,
+                                                    hipMemcpyDeviceToHost, s), "D2H dead u"))
+        return cleanup(DH_ERR_HIP);
+      if (want_pt &&
+          (!hip_ok(ctx, hipMemcpyAsync(dead_id_out + o, a.dead_id + o, (size_t)nit * 4, hipMemcpyDeviceToHost, s), "D2H id") ||
+           !hip_ok(ctx, hipMemcpyAsync(dead_it_out + o, a.dead_it + o, (size_t)nit * 4, hipMemcpyDeviceToHost, s), "D2H it") ||
+           !hip_ok(ctx, hipMemcpyAsync(dead_nc_out + o, a.dead_nc + o, (size_t)nit * 4, hipMemcpyDeviceToHost, s), "D2H nc")))
         return cleanup(DH_ERR_HIP);
     }
   }

@@ -404,6 +404,14 @@ template <int N, bool FULL, int KIND>
 __global__ void __launch_bounds__(64, 2) unif_kernel(UnifArgs a) {
   __shared__ ZigLds zig;
   __shared__ double sx[N * 64];
+  if (a.run_mode) {
+    // ensemble form: a workgroup (= one wavefront) none of whose walkers belongs to this launch leaves
+    // before it stages anything (the unit-cube launch of the resident loop cost 52 us per fill long after
+    // the last run had left that phase)
+    const int w0 = blockIdx.x * 64 + threadIdx.x;
+    const int wq = w0 < a.k ? w0 : a.k - 1;
+    if (!__any(a.run_mode[wq / a.wpr] == a.my_mode)) return;
+  }
   zig_stage(&zig, a.zki, a.zwi, a.zfi);
   const int lane = threadIdx.x;
   const int w = blockIdx.x * 64 + lane;
