@@ -112,6 +112,14 @@ SIGNATURES = {
     "dh_slice_feed": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _dbl, _vp, _vp, _i, _vp,
                            _vp, _vp]),
     "dh_set_rwalk_form": (_i, [_vp, _i]),
+    "dh_slice_batch_philox": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _dbl, _dbl, _i, _i, _u64, _u64, _u64,
+                                   _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dh_slice_batch_philox_dev": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _dbl, _dbl, _i, _i, _u64, _u64,
+                                       _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dh_unif_batch_philox": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _dbl, _vp, _u64, _u64, _u64,
+                                  C.c_int64, _vp, _vp, _vp, _vp]),
+    "dh_unif_batch_philox_dev": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _dbl, _vp, _u64, _u64, _u64,
+                                      C.c_int64, _vp, _vp, _vp, _vp, _vp]),
 }
 
 
@@ -577,6 +585,51 @@ class Context:
                     expansion_warning_set=(fl & 1).astype(bool),
                     rng_out=rng_out)
 
+    def slice_batch_philox(self, prob, u0, axes, scale, loglstar, slices, seed, sequence0=0, offset=0,
+                           axes_idx=None, principal=False, doubling=False):
+        """Throughput mode of the batched slice samplers (dh_slice_batch_philox): hiprand
+        Philox4x32-10 keyed (seed, sequence0 + walker, offset)."""
+        ndim = prob.ndim
+        u0 = _f64(u0).reshape(-1, ndim)
+        k = u0.shape[0]
+        axes = _f64(axes).reshape(-1, ndim, ndim)
+        idx = None if axes_idx is None else np.ascontiguousarray(axes_idx, dtype=np.int32)
+        u = np.empty((k, ndim)); v = np.empty((k, ndim)); logl = np.empty(k)
+        nc = np.empty(k, dtype=np.int32); ne = np.empty(k, dtype=np.int32)
+        nt = np.empty(k, dtype=np.int32); fl = np.empty(k, dtype=np.int32)
+        self._check(self.lib.dh_slice_batch_philox(
+            self.handle, self.problem(prob), k, ndim, 1 if principal else 0, _ptr(u0), _ptr(axes),
+            axes.shape[0], _ptr(idx), float(scale), float(loglstar), int(slices), 1 if doubling else 0,
+            int(seed), int(sequence0), int(offset), _ptr(u), _ptr(v), _ptr(logl), _ptr(nc), _ptr(ne),
+            _ptr(nt), _ptr(fl)))
+        return dict(u=u, v=v, logl=logl, ncalls=nc, n_expand=ne, n_contract=nt,
+                    expansion_warning_set=(fl & 1).astype(bool))
+
+    def unif_batch_philox(self, prob, loglstar, k, seed, sequence0=0, offset=0, ctrs=None, axes=None,
+                          ams=None, logvol_ells=None, ncdim=None, bc=None, max_tries=0):
+        """Throughput mode of the batched UniformBoundSampler.sample / UnitCubeSampler.sample
+        (dh_unif_batch_philox) for k walkers."""
+        ndim = prob.ndim
+        ncdim = ndim if ncdim is None else int(ncdim)
+        if ctrs is None:
+            m, c, ax, am, cp = 0, None, None, None, None
+        else:
+            c = _f64(ctrs).reshape(-1, ncdim)
+            m = c.shape[0]
+            ax = _f64(axes).reshape(m, ncdim, ncdim)
+            am = cp = None
+            if m > 1:
+                am = _f64(ams).reshape(m, ncdim, ncdim)
+                cp = cumprob_of(logvol_ells)
+        bcarr = None if bc is None else np.ascontiguousarray(bc, dtype=np.int8)
+        u = np.empty((k, ndim)); v = np.empty((k, ndim)); logl = np.empty(k)
+        nc = np.empty(k, dtype=np.int32)
+        self._check(self.lib.dh_unif_batch_philox(
+            self.handle, self.problem(prob), int(k), ndim, ncdim, m, _ptr(c), _ptr(ax), _ptr(am), _ptr(cp),
+            float(loglstar), _ptr(bcarr), int(seed), int(sequence0), int(offset), int(max_tries),
+            _ptr(u), _ptr(v), _ptr(logl), _ptr(nc)))
+        return dict(u=u, v=v, logl=logl, ncalls=nc)
+
     def unif_batch(self, prob, loglstar, rng_states, ctrs=None, axes=None,
                    ams=None, logvol_ells=None, ncdim=None, bc=None,
                    max_tries=0):
@@ -730,8 +783,6 @@ class Context:
         kind = dict(rwalk=0, rslice=1, slice=2)[sample]
         if rng not in ('pcg64', 'philox'):
             raise ValueError("ns_ensemble: rng must be 'pcg64' or 'philox'")
-        if rng == 'philox' and kind != 0:
-            raise ValueError("ns_ensemble: the Philox throughput mode exists for sample='rwalk'")
         if kind == 0:
             if walks is None:
                 walks = nd + 20  # dynesty.py:128
@@ -754,7 +805,7 @@ class Context:
         nf = C.c_int64(0)
         self._check(self.lib.dh_ns_ensemble(
             self.handle, self.problem(prob), int(runs), int(nlive), nd,
-            int(queue_size), 3 if rng == 'philox' else kind, int(walks), 1 if bound == 'multi' else 0,
+            int(queue_size), kind + (3 if rng == 'philox' else 0), int(walks), 1 if bound == 'multi' else 0,
             1 if rebuild_sync else 0, float(dlogz), float(enlarge), int(max_fills), int(max_iter),
             _ptr(words), words.size, int(first_run), _ptr(rec), _ptr(dead),
             _ptr(livel), _ptr(dead_u), _ptr(live_u), C.byref(nf), _ptr(pid), _ptr(pit), _ptr(pnc),

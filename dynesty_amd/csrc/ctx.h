@@ -125,12 +125,14 @@ int slice_launch_runs(dh_ctx* ctx, int problem, int k, int ndim, int mode, const
                       int slices, int doubling, const uint64_t* rng, double* u, double* v, double* logl,
                       int32_t* ncalls, int32_t* nexpand, int32_t* ncontract, int32_t* flags,
                       uint64_t* rng_out, const double* run_loglstar, const double* run_scale,
-                      const int* run_mode, const int* run_doubling, int wpr, int my_mode);
+                      const int* run_mode, const int* run_doubling, int wpr, int my_mode,
+                      const PhiloxKey* philox = nullptr);
 int unif_launch_runs(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, int m, const double* ctrs,
                      const double* axes, const double* ams, const double* cumprob, double loglstar,
                      const int8_t* bc, const uint64_t* rng, int64_t max_tries, double* u, double* v,
                      double* logl, int32_t* ncalls, int32_t* flags, uint64_t* rng_out,
-                     const double* run_loglstar, const int* run_mode, int wpr, int my_mode);
+                     const double* run_loglstar, const int* run_mode, int wpr, int my_mode,
+                     const PhiloxKey* philox = nullptr);
 
 int rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int d, int mode, int max_ells,
                         int32_t* nells, int32_t* status, double* ctrs, double* covs, double* ams,
@@ -153,13 +155,14 @@ int wide_walk_launch(dh_ctx* ctx, int kind, int problem, int k, int ndim, int nc
                      int iters, int doubling, const int8_t* bc, const uint64_t* rng, double* u, double* v,
                      double* logl, int32_t* c0, int32_t* c1, int32_t* c2, int32_t* flags,
                      uint64_t* rng_out, const double* run_loglstar = nullptr, const double* run_scale = nullptr,
-                     const int* run_mode = nullptr, const int* run_doubling = nullptr, int wpr = 0, int my_mode = 0);
+                     const int* run_mode = nullptr, const int* run_doubling = nullptr, int wpr = 0, int my_mode = 0,
+                     const PhiloxKey* philox = nullptr);
 int wide_eval_launch(dh_ctx* ctx, const ProblemDev& p, int k, const double* u, double* v, double* logl);
 // UniformBoundSampler inside a (multi-)ellipsoid at wide D; problem = -1: propose only (lock-step)
 int wide_unif_launch(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, int m, const double* ctrs,
                      const double* axes, const double* ams, const double* cumprob, double loglstar,
                      const int8_t* bc, const uint64_t* rng, int64_t max_tries, double* u, double* v, double* logl,
-                     int32_t* ncalls, int32_t* flags, uint64_t* rng_out);
+                     int32_t* ncalls, int32_t* flags, uint64_t* rng_out, const PhiloxKey* philox = nullptr);
 int wide_contains_launch(dh_ctx* ctx, const double* x, int k, int d, const double* ctrs, const double* ams,
                          int m, int mode, int32_t* count, uint64_t* mask, double* quad);
 int wide_single_launch(dh_ctx* ctx, int runs, const double* pts, int n, int d, int32_t* nells,

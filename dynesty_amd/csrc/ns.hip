@@ -1077,10 +1077,10 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
   ProblemDev pd;
   if (!get_problem(ctx, problem, &pd)) return DH_ERR_ARG;
   if (pd.ndim != ndim) return fail(ctx, DH_ERR_ARG, "problem ndim %d != %d", pd.ndim, ndim);
-  // sampler 3 = rwalk with the proposals drawn from hiprand Philox streams (throughput RNG mode, DESIGN.md
-  // section 2); start points, frames and the unit-cube phase keep their PCG64 streams
-  const bool philox = sampler == 3;
-  if (philox) sampler = 0;
+  // sampler 3 / 4 / 5 = rwalk / rslice / slice with the unit-cube phase and the proposals drawn from hiprand
+  // Philox streams (throughput RNG mode); start points and frames keep their PCG64 streams
+  const bool philox = sampler >= 3 && sampler <= 5;  // 3 rwalk, 4 rslice, 5 slice: proposals from Philox streams
+  if (philox) sampler -= 3;
   if (runs < 1 || nlive < 4 || queue_size < 1 || walks < 1 || sampler < 0 || sampler > 2 || !entropy_words ||
       n_words < 1 || !records)
     return fail(ctx, DH_ERR_ARG, "ns_ensemble: bad arguments");
@@ -1088,8 +1088,6 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
   // walker launches go to the wave-per-walker kernels of wide.hip, which take the same per-run arrays; above
   // d = 44 the bound is the multi-workgroup Ellipsoid.update with the run mask (single ellipsoid only: the wide
   // MultiEllipsoid.update is a host recursion).
-  if (philox && ndim > kMaxRegDim)
-    return fail(ctx, DH_ERR_ARG, "ns_ensemble: the Philox proposals are built for ndim <= %d", kMaxRegDim);
   if (bound_multi && ndim > 44)
     return fail(ctx, DH_ERR_ARG, "ns_ensemble: bound='multi' in the device-resident loop needs ndim <= 44 (ndim=%d)", ndim);
   const int N = nlive, D = ndim, K = queue_size, R = runs;
@@ -1232,18 +1230,23 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
       if (rc) return cleanup(rc);
       hipLaunchKernelGGL(ns_select, dim3(R), dim3(kT), 0, s, a);
       hipLaunchKernelGGL(ns_gather, dim3((unsigned)(((size_t)R * K * D + 255) / 256)), dim3(256), 0, s, a);
+      // Philox keys: seed from the entropy words (one per stage, so that the stages' offset schemes cannot
+      // meet), subsequence = global walker slot (first_run + run) * K + w (independent of the sharding)
+      dh::PhiloxKey key;
+      key.seed = ((unsigned long long)entropy_words[0] << 32) ^ (n_words > 1 ? entropy_words[1] : 0u) ^ 0x9E3779B97F4A7C15ull;
+      key.seq0 = (unsigned long long)first_run * (unsigned long long)K;
+      // stages whose consumption depends on the data (unit cube, slice samplers): 2^24 draws per walker and fill
+      dh::PhiloxKey key_cube = key, key_slice = key;
+      key_cube.seed ^= 0x5BD1E995C0BEull;
+      key_slice.seed ^= 0x27D4EB2F511CEull;
+      key_cube.offset = key_slice.offset = (unsigned long long)fill << 24;
       if (cube_phase) {
         rc = unif_launch_runs(ctx, problem, R * K, D, D, 0, nullptr, nullptr, nullptr, nullptr, 0.0, nullptr,
                               a.q_rng, 0, a.r_u, a.r_v, a.r_logl, a.r_a, a.r_b, a.q_rng_out, a.run_loglstar,
-                              a.run_mode, K, MODE_CUBE);
+                              a.run_mode, K, MODE_CUBE, philox ? &key_cube : nullptr);
         if (rc) return cleanup(rc);
       }
       if (sampler == 0) {
-        // Philox key: seed from the entropy words, subsequence = global walker slot (first_run + run) * K + w
-        // (independent of the sharding), offset advancing by 4096 draws per fill (a walker uses < 31 per step)
-        dh::PhiloxKey key;
-        key.seed = ((unsigned long long)entropy_words[0] << 32) ^ (n_words > 1 ? entropy_words[1] : 0u) ^ 0x9E3779B97F4A7C15ull;
-        key.seq0 = (unsigned long long)first_run * (unsigned long long)K;
         // 32-bit draws one walker consumes per fill: per step hiprand_normal4 x ceil(D / 4) and one
         // hiprand_uniform_double (2 draws; padded to 4 so that a fill's block stays 4-aligned)
         key.offset = (unsigned long long)fill * (unsigned long long)walks * (unsigned long long)(4 * ((D + 3) / 4) + 4);
@@ -1255,7 +1258,7 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
         rc = slice_launch_runs(ctx, problem, R * K, D, sampler - 1, a.q_u0, a.b_axes, R * me, a.q_frame, 1.0,
                                0.0, walks, 0, a.q_rng, a.r_u, a.r_v, a.r_logl, a.r_a, a.r_b, a.r_c, a.r_d,
                                a.q_rng_out, a.run_loglstar, a.run_scale, a.run_mode, a.run_doubling, K,
-                               MODE_BOUND);
+                               MODE_BOUND, philox ? &key_slice : nullptr);
       if (rc) return cleanup(rc);
       hipLaunchKernelGGL(ns_consume, dim3(R), dim3(kT), lds_cons, s, a);
     }

@@ -409,12 +409,10 @@ int dh::rwalk_launch_runs(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, 
   if (k <= 0) return DH_OK;
   if (ncdim < 1 || ncdim > ndim || m < 1 || walks < 1)
     return fail(ctx, DH_ERR_ARG, "rwalk: ncdim=%d ndim=%d m=%d walks=%d", ncdim, ndim, m, walks);
-  if (ndim > kMaxRegDim) {
-    if (philox) return fail(ctx, DH_ERR_ARG, "rwalk: the Philox mode is built for ndim <= %d", kMaxRegDim);
+  if (ndim > kMaxRegDim)
     return wide_walk_launch(ctx, 0, problem, k, ndim, ncdim, u0, axes, m, axes_idx, scale, loglstar, walks,
                             0, bc, rng, u, v, logl, naccept, nreject, nullptr, nullptr, rng_out, run_loglstar,
-                            run_scale, run_mode, nullptr, wpr, my_mode);
-  }
+                            run_scale, run_mode, nullptr, wpr, my_mode, philox);
   // Four lanes per walker + matrix cores (walkq.hip): built for full-dimensional proposals without
   // boundary conditions, 9 <= ndim <= 32, fused likelihood, affine / identity prior.  It does the same
   // walk on the same streams (counts and generator states identical, coordinates to rounding) with 4x the

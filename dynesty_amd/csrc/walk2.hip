@@ -5,7 +5,7 @@
 #include <stdlib.h>
 
 #include "ctx.h"
-#include "rng_pcg64.h"
+#include "rng_gen.h"
 
 using namespace dh;
 
@@ -56,14 +56,15 @@ struct SliceArgs {
   const int* run_mode;
   const int* run_doubling;
   int wpr, my_mode;
+  PhiloxKey ph;  // RNG_PHILOX
 };
 
-template <int N, int KIND>
+template <int N, int KIND, int RNG>
 __global__ void __launch_bounds__(64, 2) slice_kernel(SliceArgs a) {
   __shared__ ZigLds zig;
   __shared__ double sx[N * 64];
   __shared__ int sperm[N * 64];
-  zig_stage(&zig, a.zki, a.zwi, a.zfi);
+  if constexpr (RNG == RNG_PCG64) zig_stage(&zig, a.zki, a.zwi, a.zfi);
   const int lane = threadIdx.x;
   const int w = blockIdx.x * 64 + lane;
   const bool live = w < a.k;
@@ -73,8 +74,8 @@ __global__ void __launch_bounds__(64, 2) slice_kernel(SliceArgs a) {
   double u[N], dir[N], acc[N];
 #pragma unroll
   for (int i = 0; i < N; ++i) u[i] = a.u0[(size_t)wi * n + i];
-  Pcg64 g;
-  g.load(a.rng_in + (size_t)wi * 4);
+  LaneGen<RNG> g;
+  g.init(a.rng_in, (size_t)wi, &zig, a.ph);
   const int my_frame = a.axes_idx ? a.axes_idx[wi] : 0;
 
   double loglstar = a.loglstar, scale = a.scale;
@@ -115,7 +116,7 @@ __global__ void __launch_bounds__(64, 2) slice_kernel(SliceArgs a) {
         double ss = 0.0;
 #pragma unroll 1
         for (int i = 0; i < n; ++i) {
-          const double x = std_normal(g, &zig);
+          const double x = g.normal();
           sx[i * 64 + lane] = x;
           ss = fma(x, x, ss);
         }
@@ -142,7 +143,7 @@ __global__ void __launch_bounds__(64, 2) slice_kernel(SliceArgs a) {
         for (int i = 0; i < N; ++i) dir[i] = scale * col[i];
       }
       // ---- generic_slice_step ----
-      const double rand0 = g.next_double();
+      const double rand0 = g.uniform();
       double dl = 0.0;
 #pragma unroll
       for (int i = 0; i < N; ++i) dl = fma(dir[i], dir[i], dl);
@@ -291,7 +292,7 @@ __global__ void __launch_bounds__(64, 2) slice_kernel(SliceArgs a) {
           // ---- phases that decide their next abscissa after the switch ----
           if (phase == PH_DBL) {
             if (f_l > loglstar || f_r > loglstar) {
-              const double V = g.next_double();
+              const double V = g.uniform();
               if (V < 0.5) {
                 left -= (right - left);
                 xq = left;
@@ -332,7 +333,7 @@ __global__ void __launch_bounds__(64, 2) slice_kernel(SliceArgs a) {
           }
           if (phase == PH_SHRINK) {
             const double width = right - left;
-            xq = left + g.next_double() * width;
+            xq = left + g.uniform() * width;
           }
         }
       }
@@ -356,7 +357,7 @@ __global__ void __launch_bounds__(64, 2) slice_kernel(SliceArgs a) {
     a.nexpand[w] = n_expand;
     a.ncontract[w] = n_contract;
     a.flags[w] = (warn_set ? 1 : 0) | (failed ? 2 : 0);
-    if (a.rng_out) g.store(a.rng_out + (size_t)w * 4);
+    g.store(a.rng_out, (size_t)w);
   }
 }
 
@@ -398,9 +399,10 @@ struct UnifArgs {
   const double* run_loglstar;
   const int* run_mode;
   int wpr, my_mode;
+  PhiloxKey ph;  // RNG_PHILOX
 };
 
-template <int N, bool FULL, int KIND>
+template <int N, bool FULL, int KIND, int RNG>
 __global__ void __launch_bounds__(64, 2) unif_kernel(UnifArgs a) {
   __shared__ ZigLds zig;
   __shared__ double sx[N * 64];
@@ -412,7 +414,7 @@ __global__ void __launch_bounds__(64, 2) unif_kernel(UnifArgs a) {
     const int wq = w0 < a.k ? w0 : a.k - 1;
     if (!__any(a.run_mode[wq / a.wpr] == a.my_mode)) return;
   }
-  zig_stage(&zig, a.zki, a.zwi, a.zfi);
+  if constexpr (RNG == RNG_PCG64) zig_stage(&zig, a.zki, a.zwi, a.zfi);
   const int lane = threadIdx.x;
   const int w = blockIdx.x * 64 + lane;
   const bool live = w < a.k;
@@ -426,11 +428,13 @@ __global__ void __launch_bounds__(64, 2) unif_kernel(UnifArgs a) {
     loglstar = a.run_loglstar[run];
   }
   const bool idle = done;
-  Pcg64 g;
-  g.load(a.rng_in + (size_t)wi * 4);
-  if (a.rng32_in) {
-    g.has32 = (uint32_t)a.rng32_in[(size_t)wi * 2];
-    g.buf32 = (uint32_t)a.rng32_in[(size_t)wi * 2 + 1];
+  LaneGen<RNG> g;
+  g.init(a.rng_in, (size_t)wi, &zig, a.ph);
+  if constexpr (RNG == RNG_PCG64) {
+    if (a.rng32_in) {
+      g.g.has32 = (uint32_t)a.rng32_in[(size_t)wi * 2];
+      g.g.buf32 = (uint32_t)a.rng32_in[(size_t)wi * 2 + 1];
+    }
   }
   double x[N], acc[N];
   int ncall = 0, flags = 0;
@@ -444,7 +448,7 @@ __global__ void __launch_bounds__(64, 2) unif_kernel(UnifArgs a) {
       if (a.m == 0) {
         // unit cube: rstate.uniform(size=ndim)
 #pragma unroll 1
-        for (int i = 0; i < n; ++i) sx[i * 64 + lane] = g.next_double();
+        for (int i = 0; i < n; ++i) sx[i * 64 + lane] = g.uniform();
 #pragma unroll
         for (int i = 0; i < N; ++i) x[i] = (FULL || i < n) ? sx[i * 64 + lane] : 0.5;
         cand = true;
@@ -460,17 +464,17 @@ __global__ void __launch_bounds__(64, 2) unif_kernel(UnifArgs a) {
             double ss = 0.0;
 #pragma unroll 1
             for (int i = 0; i < nc; ++i) {
-              const double z = std_normal(g, &zig);
+              const double z = g.normal();
               sx[i * 64 + lane] = z;
               ss = fma(z, z, ss);
             }
-            fac = pow(g.next_double(), inv_nc) / sqrt(ss);
+            fac = pow(g.uniform(), inv_nc) / sqrt(ss);
           } else {
 #pragma unroll 1
-            for (int i = 0; i < nc; ++i) sx[i * 64 + lane] = -1.0 + 2.0 * g.next_double();
+            for (int i = 0; i < nc; ++i) sx[i * 64 + lane] = -1.0 + 2.0 * g.uniform();
           }
           int idx = 0;
-          if (a.fr_n > 1) idx = (int)g.bounded_lemire32((uint32_t)(a.fr_n - 1));
+          if (a.fr_n > 1) idx = (int)g.bounded32((uint32_t)(a.fr_n - 1));
 #pragma unroll
           for (int i = 0; i < N; ++i) acc[i] = 0.0;
           matvec_sgpr<N>(as_const(a.axes_t), sx, lane, nc, acc);
@@ -504,24 +508,24 @@ __global__ void __launch_bounds__(64, 2) unif_kernel(UnifArgs a) {
             if (q == 0)
               accept = false;
             else if (q > 1)
-              accept = g.next_double() < (1.0 / (double)q);
+              accept = g.uniform() < (1.0 / (double)q);
           }
         } else {
         int idx = 0;
         if (a.m > 1) {
           // rand_choice (bounding.py:1300-1308): searchsorted(cumsum(pb), U)
-          const double xr = g.next_double();
+          const double xr = g.uniform();
           while (idx < a.m - 1 && a.cumprob[idx] < xr) ++idx;
         }
         // randsphere: nc normals then one uniform
         double ss = 0.0;
 #pragma unroll 1
         for (int i = 0; i < nc; ++i) {
-          const double z = std_normal(g, &zig);
+          const double z = g.normal();
           sx[i * 64 + lane] = z;
           ss = fma(z, z, ss);
         }
-        const double fac = pow(g.next_double(), inv_nc) / sqrt(ss);
+        const double fac = pow(g.uniform(), inv_nc) / sqrt(ss);
 #pragma unroll
         for (int i = 0; i < N; ++i) acc[i] = 0.0;
         bool mv = false;
@@ -563,7 +567,7 @@ __global__ void __launch_bounds__(64, 2) unif_kernel(UnifArgs a) {
               accept = false;
             }
           }
-          if (accept && q > 1) accept = g.next_double() < (1.0 / (double)q);
+          if (accept && q > 1) accept = g.uniform() < (1.0 / (double)q);
         }
         }
         if (accept) {
@@ -583,7 +587,7 @@ __global__ void __launch_bounds__(64, 2) unif_kernel(UnifArgs a) {
             if (!FULL) {
               // non-cluster dims: rstate.uniform(size=ndim - n_cluster)
 #pragma unroll 1
-              for (int i = nc; i < n; ++i) sx[i * 64 + lane] = g.next_double();
+              for (int i = nc; i < n; ++i) sx[i * 64 + lane] = g.uniform();
 #pragma unroll
               for (int i = 0; i < N; ++i)
                 if (i >= nc && i < n) x[i] = sx[i * 64 + lane];
@@ -633,10 +637,12 @@ __global__ void __launch_bounds__(64, 2) unif_kernel(UnifArgs a) {
       a.ncalls[w] = ncall;
     }
     a.flags[w] = flags;
-    if (a.rng_out) g.store(a.rng_out + (size_t)w * 4);
-    if (a.rng32_out) {
-      a.rng32_out[(size_t)w * 2] = g.has32;
-      a.rng32_out[(size_t)w * 2 + 1] = g.buf32;
+    g.store(a.rng_out, (size_t)w);
+    if constexpr (RNG == RNG_PCG64) {
+      if (a.rng32_out) {
+        a.rng32_out[(size_t)w * 2] = g.g.has32;
+        a.rng32_out[(size_t)w * 2 + 1] = g.g.buf32;
+      }
     }
   }
 }
@@ -760,6 +766,17 @@ int dh_slice_batch_dev(dh_ctx* ctx, int problem, int k, int ndim, int mode, cons
                                nullptr, nullptr, nullptr, 1, 0);
 }
 
+int dh_slice_batch_philox_dev(dh_ctx* ctx, int problem, int k, int ndim, int mode, const double* u0,
+                              const double* axes, int m, const int32_t* axes_idx, double scale, double loglstar,
+                              int slices, int doubling, uint64_t seed, uint64_t sequence0, uint64_t offset,
+                              double* u, double* v, double* logl, int32_t* ncalls, int32_t* nexpand,
+                              int32_t* ncontract, int32_t* flags) {
+  const dh::PhiloxKey key = {seed, sequence0, offset};
+  return dh::slice_launch_runs(ctx, problem, k, ndim, mode, u0, axes, m, axes_idx, scale, loglstar, slices,
+                               doubling, nullptr, u, v, logl, ncalls, nexpand, ncontract, flags, nullptr, nullptr,
+                               nullptr, nullptr, nullptr, 1, 0, &key);
+}
+
 }  // extern "C"
 
 int dh::slice_launch_runs(dh_ctx* ctx, int problem, int k, int ndim, int mode, const double* u0,
@@ -768,9 +785,11 @@ int dh::slice_launch_runs(dh_ctx* ctx, int problem, int k, int ndim, int mode, c
                           double* v, double* logl, int32_t* ncalls, int32_t* nexpand, int32_t* ncontract,
                           int32_t* flags, uint64_t* rng_out, const double* run_loglstar,
                           const double* run_scale, const int* run_mode, const int* run_doubling, int wpr,
-                          int my_mode) {
+                          int my_mode, const dh::PhiloxKey* philox) {
   DH_CHECK_CTX(ctx);
   SliceArgs a;
+  a.ph = philox ? *philox : dh::PhiloxKey{0, 0, 0};
+  if (!philox && !rng && k > 0) return fail(ctx, DH_ERR_ARG, "slice: no generator states");
   a.run_loglstar = run_loglstar;
   a.run_scale = run_scale;
   a.run_mode = run_mode;
@@ -786,7 +805,7 @@ int dh::slice_launch_runs(dh_ctx* ctx, int problem, int k, int ndim, int mode, c
   if (N != ndim)  // no register-resident instantiation for this dimension: wave-per-walker path
     return wide_walk_launch(ctx, mode + 1, problem, k, ndim, ndim, u0, axes, m, axes_idx, scale, loglstar,
                             slices, doubling, nullptr, rng, u, v, logl, ncalls, nexpand, ncontract, flags,
-                            rng_out, run_loglstar, run_scale, run_mode, run_doubling, wpr, my_mode);
+                            rng_out, run_loglstar, run_scale, run_mode, run_doubling, wpr, my_mode, philox);
   int rc = ensure_axes_t(ctx, (size_t)m * N * N * 8);
   if (rc) return rc;
   hipLaunchKernelGGL(pad_mats_kernel, dim3((m * N * N + 255) / 256), dim3(256), 0, ctx->stream, axes, m,
@@ -816,7 +835,20 @@ int dh::slice_launch_runs(dh_ctx* ctx, int problem, int k, int ndim, int mode, c
   a.zfi = ctx->zfi();
   const dim3 grid((k + 63) / 64), block(64);
   const int kind = problem_kind(a.prob.like_id, a.prob.prior_id);
-#define L(NN, KK) hipLaunchKernelGGL((slice_kernel<NN, KK>), grid, block, 0, ctx->stream, a)
+  // throughput mode: built for the generic kind of every dimension and for BASELINE C3's (2-D eggbox)
+#define LP(NN, KK) hipLaunchKernelGGL((slice_kernel<NN, KK, RNG_PHILOX>), grid, block, 0, ctx->stream, a)
+#define X(NN)                                        \
+  if (philox && N == NN) {                           \
+    if (NN == 2 && kind == KIND_EGGBOX_IDENTITY)     \
+      LP(2, KIND_EGGBOX_IDENTITY);                   \
+    else                                             \
+      LP(NN, KIND_GENERIC);                          \
+  }
+  DH_DIM_LIST(X)
+#undef X
+#undef LP
+  if (philox) return hip_ok(ctx, hipGetLastError(), "slice launch") ? DH_OK : DH_ERR_HIP;
+#define L(NN, KK) hipLaunchKernelGGL((slice_kernel<NN, KK, RNG_PCG64>), grid, block, 0, ctx->stream, a)
 #define X(NN)                              \
   if (N == NN) {                           \
     if (kind == KIND_PREC_AFFINE)          \
@@ -839,14 +871,17 @@ int dh::slice_launch_runs(dh_ctx* ctx, int problem, int k, int ndim, int mode, c
 extern "C" {
 
 
-int dh_slice_batch(dh_ctx* ctx, int problem, int k, int ndim, int mode, const double* u0,
-                   const double* axes, int m, const int32_t* axes_idx, double scale, double loglstar,
-                   int slices, int doubling, const uint64_t* rng, double* u, double* v, double* logl,
-                   int32_t* ncalls, int32_t* nexpand, int32_t* ncontract, int32_t* flags,
-                   uint64_t* rng_out) {
+}  // extern "C"
+
+namespace {
+// host-pointer form of the batched slice samplers; key == nullptr: PCG64 streams from `rng`
+int slice_batch_host(dh_ctx* ctx, int problem, int k, int ndim, int mode, const double* u0, const double* axes, int m,
+                     const int32_t* axes_idx, double scale, double loglstar, int slices, int doubling,
+                     const uint64_t* rng, double* u, double* v, double* logl, int32_t* ncalls, int32_t* nexpand,
+                     int32_t* ncontract, int32_t* flags, uint64_t* rng_out, const dh::PhiloxKey* key) {
   DH_CHECK_CTX(ctx);
   if (k <= 0) return DH_OK;
-  if (!u0 || !axes || !rng || !u || !v || !logl || !ncalls || !nexpand || !ncontract || !flags)
+  if (!u0 || !axes || (!rng && !key) || !u || !v || !logl || !ncalls || !nexpand || !ncontract || !flags)
     return fail(ctx, DH_ERR_ARG, "slice: null pointer");
   arena_reset(ctx);
   const size_t kd = (size_t)k * ndim;
@@ -855,7 +890,7 @@ int dh_slice_batch(dh_ctx* ctx, int problem, int k, int ndim, int mode, const do
   const double* d_u0 = arena_up(ctx, u0, kd);
   const double* d_axes = arena_up(ctx, axes, (size_t)m * ndim * ndim);
   const int32_t* d_idx = axes_idx ? arena_up(ctx, axes_idx, (size_t)k) : nullptr;
-  const uint64_t* d_rng = arena_up(ctx, rng, (size_t)k * 4);
+  const uint64_t* d_rng = key ? nullptr : arena_up(ctx, rng, (size_t)k * 4);
   double* d_u = (double*)arena_get(ctx, kd * 8);
   double* d_v = (double*)arena_get(ctx, kd * 8);
   double* d_l = (double*)arena_get(ctx, (size_t)k * 8);
@@ -864,22 +899,43 @@ int dh_slice_batch(dh_ctx* ctx, int problem, int k, int ndim, int mode, const do
   int32_t* d_nt = (int32_t*)arena_get(ctx, (size_t)k * 4);
   int32_t* d_fl = (int32_t*)arena_get(ctx, (size_t)k * 4);
   uint64_t* d_ro = (uint64_t*)arena_get(ctx, (size_t)k * 32);
-  if (!d_u0 || !d_axes || !d_rng || !d_u || !d_v || !d_l || !d_nc || !d_ne || !d_nt || !d_fl || !d_ro ||
+  if (!d_u0 || !d_axes || (!key && !d_rng) || !d_u || !d_v || !d_l || !d_nc || !d_ne || !d_nt || !d_fl || !d_ro ||
       (axes_idx && !d_idx))
     return DH_ERR_NOMEM;
-  rc = dh_slice_batch_dev(ctx, problem, k, ndim, mode, d_u0, d_axes, m, d_idx, scale, loglstar, slices,
-                          doubling, d_rng, d_u, d_v, d_l, d_nc, d_ne, d_nt, d_fl, d_ro);
+  rc = dh::slice_launch_runs(ctx, problem, k, ndim, mode, d_u0, d_axes, m, d_idx, scale, loglstar, slices, doubling,
+                             d_rng, d_u, d_v, d_l, d_nc, d_ne, d_nt, d_fl, key ? nullptr : d_ro, nullptr, nullptr,
+                             nullptr, nullptr, 1, 0, key);
   if (rc) return rc;
   if (!down(ctx, u, d_u, kd) || !down(ctx, v, d_v, kd) || !down(ctx, logl, d_l, (size_t)k) ||
       !down(ctx, ncalls, d_nc, (size_t)k) || !down(ctx, nexpand, d_ne, (size_t)k) ||
       !down(ctx, ncontract, d_nt, (size_t)k) || !down(ctx, flags, d_fl, (size_t)k) ||
-      !down(ctx, rng_out, d_ro, (size_t)k * 4))
+      (!key && !down(ctx, rng_out, d_ro, (size_t)k * 4)))
     return DH_ERR_HIP;
   if ((rc = dh_sync(ctx))) return rc;
   for (int i = 0; i < k; ++i)
     if (flags[i] & 2)
       return fail(ctx, DH_ERR_SLICE, "Slice sampler has failed to find a valid point (walker %d)", i);
   return DH_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int dh_slice_batch(dh_ctx* ctx, int problem, int k, int ndim, int mode, const double* u0, const double* axes, int m,
+                   const int32_t* axes_idx, double scale, double loglstar, int slices, int doubling,
+                   const uint64_t* rng, double* u, double* v, double* logl, int32_t* ncalls, int32_t* nexpand,
+                   int32_t* ncontract, int32_t* flags, uint64_t* rng_out) {
+  return slice_batch_host(ctx, problem, k, ndim, mode, u0, axes, m, axes_idx, scale, loglstar, slices, doubling, rng, u,
+                          v, logl, ncalls, nexpand, ncontract, flags, rng_out, nullptr);
+}
+
+int dh_slice_batch_philox(dh_ctx* ctx, int problem, int k, int ndim, int mode, const double* u0, const double* axes,
+                          int m, const int32_t* axes_idx, double scale, double loglstar, int slices, int doubling,
+                          uint64_t seed, uint64_t sequence0, uint64_t offset, double* u, double* v, double* logl,
+                          int32_t* ncalls, int32_t* nexpand, int32_t* ncontract, int32_t* flags) {
+  const dh::PhiloxKey key = {seed, sequence0, offset};
+  return slice_batch_host(ctx, problem, k, ndim, mode, u0, axes, m, axes_idx, scale, loglstar, slices, doubling,
+                          nullptr, u, v, logl, ncalls, nexpand, ncontract, flags, nullptr, &key);
 }
 
 int dh_unif_batch_dev(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, int m, const double* ctrs,
@@ -890,16 +946,45 @@ int dh_unif_batch_dev(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, int 
                               max_tries, u, v, logl, ncalls, flags, rng_out, nullptr, nullptr, 1, 0);
 }
 
+int dh_unif_batch_philox_dev(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, int m, const double* ctrs,
+                             const double* axes, const double* ams, const double* cumprob, double loglstar,
+                             const int8_t* bc, uint64_t seed, uint64_t sequence0, uint64_t offset, int64_t max_tries,
+                             double* u, double* v, double* logl, int32_t* ncalls, int32_t* flags) {
+  const dh::PhiloxKey key = {seed, sequence0, offset};
+  return dh::unif_launch_runs(ctx, problem, k, ndim, ncdim, m, ctrs, axes, ams, cumprob, loglstar, bc, nullptr,
+                              max_tries, u, v, logl, ncalls, flags, nullptr, nullptr, nullptr, 1, 0, &key);
+}
+
 }  // extern "C"
 
 namespace {
 
-int unif_dispatch(dh_ctx* ctx, const UnifArgs& a, int N) {
+int unif_dispatch(dh_ctx* ctx, const UnifArgs& a, int N, bool philox = false) {
   const int k = a.k, ndim = a.ndim, ncdim = a.ncdim;
   const dim3 grid((k + 63) / 64), block(64);
   const bool full = (ndim == N && ncdim == N);
   const int kind = (full && !a.propose_only) ? problem_kind(a.prob.like_id, a.prob.prior_id) : KIND_GENERIC;
-#define L(NN, FF, KK) hipLaunchKernelGGL((unif_kernel<NN, FF, KK>), grid, block, 0, ctx->stream, a)
+  // throughput mode: the generic kind of every dimension, and the BASELINE configs' own
+  // (C1 3-D iid Normal, C2 25-D correlated Normal, C3 2-D eggbox)
+#define LP(NN, FF, KK) hipLaunchKernelGGL((unif_kernel<NN, FF, KK, RNG_PHILOX>), grid, block, 0, ctx->stream, a)
+#define X(NN)                                                 \
+  if (philox && N == NN) {                                    \
+    if (!full)                                                \
+      LP(NN, false, KIND_GENERIC);                            \
+    else if (NN == 25 && kind == KIND_PREC_AFFINE)            \
+      LP(25, true, KIND_PREC_AFFINE);                         \
+    else if (NN == 3 && kind == KIND_IID_AFFINE)              \
+      LP(3, true, KIND_IID_AFFINE);                           \
+    else if (NN == 2 && kind == KIND_EGGBOX_IDENTITY)         \
+      LP(2, true, KIND_EGGBOX_IDENTITY);                      \
+    else                                                      \
+      LP(NN, true, KIND_GENERIC);                             \
+  }
+  DH_DIM_LIST(X)
+#undef X
+#undef LP
+  if (philox) return hip_ok(ctx, hipGetLastError(), "unif launch") ? DH_OK : DH_ERR_HIP;
+#define L(NN, FF, KK) hipLaunchKernelGGL((unif_kernel<NN, FF, KK, RNG_PCG64>), grid, block, 0, ctx->stream, a)
 #define X(NN)                              \
   if (N == NN) {                           \
     if (!full)                             \
@@ -927,9 +1012,12 @@ int dh::unif_launch_runs(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, i
                          const double* axes, const double* ams, const double* cumprob, double loglstar,
                          const int8_t* bc, const uint64_t* rng, int64_t max_tries, double* u, double* v,
                          double* logl, int32_t* ncalls, int32_t* flags, uint64_t* rng_out,
-                         const double* run_loglstar, const int* run_mode, int wpr, int my_mode) {
+                         const double* run_loglstar, const int* run_mode, int wpr, int my_mode,
+                         const dh::PhiloxKey* philox) {
   DH_CHECK_CTX(ctx);
   UnifArgs a;
+  a.ph = philox ? *philox : dh::PhiloxKey{0, 0, 0};
+  if (!philox && !rng && k > 0) return fail(ctx, DH_ERR_ARG, "unif: no generator states");
   a.run_loglstar = run_loglstar;
   a.run_mode = run_mode;
   a.wpr = wpr;
@@ -951,11 +1039,11 @@ int dh::unif_launch_runs(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, i
       if (run_mode)
         return fail(ctx, DH_ERR_ARG, "ensemble unif inside a bound: ndim=%d > %d not built", ndim, kMaxRegDim);
       return wide_unif_launch(ctx, problem, k, ndim, ncdim, m, ctrs, axes, ams, cumprob, loglstar, bc, rng,
-                              max_tries, u, v, logl, ncalls, flags, rng_out);
+                              max_tries, u, v, logl, ncalls, flags, rng_out, philox);
     }
     return wide_walk_launch(ctx, 3, problem, k, ndim, ndim, nullptr, nullptr, 1,
                             nullptr, 1.0, loglstar, 0, 0, bc, rng, u, v, logl, ncalls, nullptr, nullptr,
-                            flags, rng_out, run_loglstar, nullptr, run_mode, nullptr, wpr, my_mode);
+                            flags, rng_out, run_loglstar, nullptr, run_mode, nullptr, wpr, my_mode, philox);
   }
   const int N = pad_dim(ndim);
   const size_t mats = (size_t)(m > 0 ? m : 1) * N * N * 8;
@@ -996,19 +1084,23 @@ int dh::unif_launch_runs(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, i
   a.zki = ctx->zki();
   a.zwi = ctx->zwi();
   a.zfi = ctx->zfi();
-  return unif_dispatch(ctx, a, N);
+  return unif_dispatch(ctx, a, N, philox != nullptr);
 }
 
 extern "C" {
 
 
-int dh_unif_batch(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, int m, const double* ctrs,
-                  const double* axes, const double* ams, const double* cumprob, double loglstar,
-                  const int8_t* bc, const uint64_t* rng, int64_t max_tries, double* u, double* v,
-                  double* logl, int32_t* ncalls, uint64_t* rng_out) {
+}  // extern "C"
+
+namespace {
+// host-pointer form of the batched UniformBoundSampler / UnitCubeSampler; key == nullptr: PCG64 streams from `rng`
+int unif_batch_host(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, int m, const double* ctrs, const double* axes,
+                    const double* ams, const double* cumprob, double loglstar, const int8_t* bc, const uint64_t* rng,
+                    int64_t max_tries, double* u, double* v, double* logl, int32_t* ncalls, uint64_t* rng_out,
+                    const dh::PhiloxKey* key) {
   DH_CHECK_CTX(ctx);
   if (k <= 0) return DH_OK;
-  if (!rng || !u || (problem != -1 && (!v || !logl || !ncalls)) || (m > 0 && (!ctrs || !axes)) ||
+  if ((!rng && !key) || !u || (problem != -1 && (!v || !logl || !ncalls)) || (m > 0 && (!ctrs || !axes)) ||
       (m > 1 && (!ams || !cumprob)))
     return fail(ctx, DH_ERR_ARG, "unif: null pointer");
   arena_reset(ctx);
@@ -1021,19 +1113,20 @@ int dh_unif_batch(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, int m, c
   const double* d_am = m > 1 ? arena_up(ctx, ams, (size_t)m * ncdim * ncdim) : nullptr;
   const double* d_cp = m > 1 ? arena_up(ctx, cumprob, (size_t)m) : nullptr;
   const int8_t* d_bc = bc ? arena_up(ctx, bc, (size_t)ndim) : nullptr;
-  const uint64_t* d_rng = arena_up(ctx, rng, (size_t)k * 4);
+  const uint64_t* d_rng = key ? nullptr : arena_up(ctx, rng, (size_t)k * 4);
   double* d_u = (double*)arena_get(ctx, kd * 8);
   double* d_v = (double*)arena_get(ctx, kd * 8);
   double* d_l = (double*)arena_get(ctx, (size_t)k * 8);
   int32_t* d_nc = (int32_t*)arena_get(ctx, (size_t)k * 4);
   int32_t* d_fl = (int32_t*)arena_get(ctx, (size_t)k * 4);
   uint64_t* d_ro = (uint64_t*)arena_get(ctx, (size_t)k * 32);
-  if (!d_rng || !d_u || !d_v || !d_l || !d_nc || !d_fl || !d_ro) return DH_ERR_NOMEM;
-  rc = dh_unif_batch_dev(ctx, problem, k, ndim, ncdim, m, d_c, d_ax, d_am, d_cp, loglstar, d_bc, d_rng,
-                         max_tries, d_u, d_v, d_l, d_nc, d_fl, d_ro);
+  if ((!key && !d_rng) || !d_u || !d_v || !d_l || !d_nc || !d_fl || !d_ro) return DH_ERR_NOMEM;
+  rc = dh::unif_launch_runs(ctx, problem, k, ndim, ncdim, m, d_c, d_ax, d_am, d_cp, loglstar, d_bc, d_rng, max_tries,
+                            d_u, d_v, d_l, d_nc, d_fl, key ? nullptr : d_ro, nullptr, nullptr, 1, 0, key);
   if (rc) return rc;
   std::vector<int32_t> fl((size_t)k);
-  if (!down(ctx, u, d_u, kd) || !down(ctx, fl.data(), d_fl, (size_t)k) || !down(ctx, rng_out, d_ro, (size_t)k * 4))
+  if (!down(ctx, u, d_u, kd) || !down(ctx, fl.data(), d_fl, (size_t)k) ||
+      (!key && !down(ctx, rng_out, d_ro, (size_t)k * 4)))
     return DH_ERR_HIP;
   if (problem != -1 && (!down(ctx, v, d_v, kd) || !down(ctx, logl, d_l, (size_t)k) ||
                         !down(ctx, ncalls, d_nc, (size_t)k)))
@@ -1045,6 +1138,25 @@ int dh_unif_batch(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, int m, c
       return fail(ctx, DH_ERR_ARG, "unif: walker %d exceeded max_tries without reaching loglstar", i);
   }
   return DH_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int dh_unif_batch(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, int m, const double* ctrs, const double* axes,
+                  const double* ams, const double* cumprob, double loglstar, const int8_t* bc, const uint64_t* rng,
+                  int64_t max_tries, double* u, double* v, double* logl, int32_t* ncalls, uint64_t* rng_out) {
+  return unif_batch_host(ctx, problem, k, ndim, ncdim, m, ctrs, axes, ams, cumprob, loglstar, bc, rng, max_tries, u, v,
+                         logl, ncalls, rng_out, nullptr);
+}
+
+int dh_unif_batch_philox(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, int m, const double* ctrs,
+                         const double* axes, const double* ams, const double* cumprob, double loglstar, const int8_t* bc,
+                         uint64_t seed, uint64_t sequence0, uint64_t offset, int64_t max_tries, double* u, double* v,
+                         double* logl, int32_t* ncalls) {
+  const dh::PhiloxKey key = {seed, sequence0, offset};
+  return unif_batch_host(ctx, problem, k, ndim, ncdim, m, ctrs, axes, ams, cumprob, loglstar, bc, nullptr, max_tries, u,
+                         v, logl, ncalls, nullptr, &key);
 }
 
 // UniformBoundSampler.sample over a queue with a RadFriends / SupFriends bound

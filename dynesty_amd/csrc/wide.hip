@@ -22,7 +22,7 @@
 
 #include "ctx.h"
 #include "eig_wave.h"
-#include "rng_pcg64.h"
+#include "rng_gen.h"
 
 using namespace dh;
 
@@ -168,6 +168,7 @@ struct WideWalkArgs {
   const int* run_mode;
   const int* run_doubling;
   int wpr, my_mode;
+  PhiloxKey ph;  // RNG_PHILOX
 };
 
 __device__ __forceinline__ void lds_sync() {
@@ -279,12 +280,12 @@ constexpr int kWalkMaxWaves = 4;  // walkers per workgroup: one wavefront per SI
 // (256 VGPRs): a lone wavefront issues a v_fma_f64 only every 8.5 cycles (tools/micro/
 // mfma_f64_shapes.hip), so a second wavefront per SIMD nearly doubles the fp64 throughput of the F
 // evaluations once there are more than 1024 walkers; the spills this costs are outside the hot loops.
-template <int KIND>
+template <int KIND, int RNG>
 __global__ void __launch_bounds__(64 * kWalkMaxWaves, 2) wide_walk_kernel(WideWalkArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ ZigLds zig;
   __shared__ int sframe[16];
-  zig_stage(&zig, a.zki, a.zwi, a.zfi);
+  if constexpr (RNG == RNG_PCG64) zig_stage(&zig, a.zki, a.zwi, a.zfi);
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wpw = blockDim.x >> 6;
   const int wq = blockIdx.x * wpw + wv;
   // ghost = barriers only, no results: the padding wavefronts of the last workgroup, and (ensemble form) the
@@ -305,9 +306,8 @@ __global__ void __launch_bounds__(64 * kWalkMaxWaves, 2) wide_walk_kernel(WideWa
   int* sperm = (int*)(wbase + (size_t)wpw * ws) + (size_t)wv * ((D + 1) & ~1);
   if (a.u0)
     for (int i = lane; i < D; i += 64) su[i] = a.u0[(size_t)w * D + i];
-  Pcg64 g;
-  g.load(a.rng_in + (size_t)w * 4);
-  const PcgLanes PL = pcg_lanes_init(g, lane);
+  WaveGen<RNG> g;
+  g.init(a.rng_in, (size_t)w, lane, &zig, a.ph);
   const int frame = __builtin_amdgcn_readfirstlane(a.axes_idx ? a.axes_idx[w] : 0);
   const double* AT = a.axes_t + (size_t)frame * nc * nc;  // unused when there are no frames (kind 3)
   // (walkers of different runs never share a frame index: frames are numbered run * m + ellipsoid)
@@ -323,7 +323,7 @@ __global__ void __launch_bounds__(64 * kWalkMaxWaves, 2) wide_walk_kernel(WideWa
     int ncall = 0;
     double ll = -INFINITY;
     for (;;) {
-      wave_doubles(g, PL, su, D, lane);
+      g.doubles(su, D, lane);
       lds_sync();
       ll = wide_logl(a.prob, D, su, sv, lane);
       ++ncall;
@@ -339,7 +339,7 @@ __global__ void __launch_bounds__(64 * kWalkMaxWaves, 2) wide_walk_kernel(WideWa
       a.logl[w] = ll;
       a.c0[w] = ncall;
       a.flags[w] = 0;
-      if (a.rng_out) g.store(a.rng_out + (size_t)w * 4);
+      g.store(a.rng_out, (size_t)w);
     }
     return;
   }
@@ -348,13 +348,13 @@ __global__ void __launch_bounds__(64 * kWalkMaxWaves, 2) wide_walk_kernel(WideWa
     int nacc = 0, nrej = 0;
     double logl_cur = 0.0;
     for (int step = 0; step < a.iters; ++step) {
-      if (nc < D) wave_doubles(g, PL, sp + nc, D - nc, lane);
-      wave_normals(g, PL, &zig, sd, nc, lane);
+      if (nc < D) g.doubles(sp + nc, D - nc, lane);
+      g.normals(sd, nc, lane);
       lds_sync();
       double ss = 0.0;
       for (int i = lane; i < nc; i += 64) ss = fma(sd[i], sd[i], ss);
       ss = wave_sum(ss);
-      const double fac = scale * (pow(g.next_double(), 1.0 / (double)nc) / sqrt(ss));
+      const double fac = scale * (pow(g.uniform(), 1.0 / (double)nc) / sqrt(ss));
       lds_sync();
       if (coop) {
         __syncthreads();
@@ -409,7 +409,7 @@ __global__ void __launch_bounds__(64 * kWalkMaxWaves, 2) wide_walk_kernel(WideWa
       a.logl[w] = logl_cur;
       a.c0[w] = nacc;
       a.c1[w] = nrej;
-      if (a.rng_out) g.store(a.rng_out + (size_t)w * 4);
+      g.store(a.rng_out, (size_t)w);
     }
     return;
   }
@@ -441,7 +441,7 @@ __global__ void __launch_bounds__(64 * kWalkMaxWaves, 2) wide_walk_kernel(WideWa
         // a failed walker keeps the workgroup's barriers company and does nothing else
         const long long c0_ = clock64();
         if (!failed) {
-          wave_normals(g, PL, &zig, sv, D, lane);  // sv as scratch for drhat
+          g.normals(sv, D, lane);  // sv as scratch for drhat
           lds_sync();
           double ss = 0.0;
           for (int i = lane; i < D; i += 64) ss = fma(sv[i], sv[i], ss);
@@ -470,7 +470,7 @@ __global__ void __launch_bounds__(64 * kWalkMaxWaves, 2) wide_walk_kernel(WideWa
         for (int i = lane; i < D; i += 64) sd[i] = scale * col[i];
       }
       lds_sync();
-      const double rand0 = g.next_double();
+      const double rand0 = g.uniform();
       double dl = 0.0;
       for (int i = lane; i < D; i += 64) dl = fma(sd[i], sd[i], dl);
       dl = sqrt(wave_sum(dl));
@@ -619,7 +619,7 @@ __global__ void __launch_bounds__(64 * kWalkMaxWaves, 2) wide_walk_kernel(WideWa
         // phases that choose their next abscissa after the switch
         if (phase == SL_DBL) {
           if (f_l > loglstar || f_r > loglstar) {
-            if (g.next_double() < 0.5) {
+            if (g.uniform() < 0.5) {
               left -= (right - left);
               xq = left;
               acc_right = false;
@@ -656,7 +656,7 @@ __global__ void __launch_bounds__(64 * kWalkMaxWaves, 2) wide_walk_kernel(WideWa
             phase = SL_DONE;
           }
         }
-        if (phase == SL_SHRINK) xq = left + g.next_double() * (right - left);
+        if (phase == SL_SHRINK) xq = left + g.uniform() * (right - left);
       }
       n_expand += nexp_step;
       if (!doubling && nexp_step > 1000) {
@@ -681,7 +681,7 @@ __global__ void __launch_bounds__(64 * kWalkMaxWaves, 2) wide_walk_kernel(WideWa
     a.c1[w] = n_expand;
     a.c2[w] = n_contract;
     a.flags[w] = (warn_set ? 1 : 0) | (failed ? 2 : 0);
-    if (a.rng_out) g.store(a.rng_out + (size_t)w * 4);
+    g.store(a.rng_out, (size_t)w);
   }
 }
 
@@ -710,19 +710,20 @@ struct WideUnifArgs {
   const uint64_t* zki;
   const uint64_t* zwi;
   const uint64_t* zfi;
+  PhiloxKey ph;  // RNG_PHILOX
 };
 
+template <int RNG>
 __global__ void __launch_bounds__(64) wide_unif_kernel(WideUnifArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ ZigLds zig;
-  zig_stage(&zig, a.zki, a.zwi, a.zfi);
+  if constexpr (RNG == RNG_PCG64) zig_stage(&zig, a.zki, a.zwi, a.zfi);
   const int lane = threadIdx.x, w = blockIdx.x, D = a.ndim, nc = a.ncdim;
   double* sz = (double*)smem;  // nc: normals, then x - c
   double* sx = sz + nc;        // D : candidate
   double* sv = sx + D;         // D : v
-  Pcg64 g;
-  g.load(a.rng_in + (size_t)w * 4);
-  const PcgLanes PL = pcg_lanes_init(g, lane);
+  WaveGen<RNG> g;
+  g.init(a.rng_in, (size_t)w, lane, &zig, a.ph);
   int ncall = 0, flags = 0;
   double logl_cur = 0.0;
   int64_t tries = 0;
@@ -733,7 +734,7 @@ __global__ void __launch_bounds__(64) wide_unif_kernel(WideUnifArgs a) {
     }
     ++tries;
     if (a.m == 0) {  // unit cube: rstate.uniform(size=ndim)
-      wave_doubles(g, PL, sx, D, lane);
+      g.doubles(sx, D, lane);
       lds_sync();
       if (a.propose_only) break;
       const double ll0 = wide_logl(a.prob, D, sx, sv, lane);
@@ -747,14 +748,14 @@ __global__ void __launch_bounds__(64) wide_unif_kernel(WideUnifArgs a) {
     }
     int idx = 0;
     if (a.m > 1) {  // rand_choice (bounding.py:1300-1308)
-      const double xr = g.next_double();
+      const double xr = g.uniform();
       while (idx < a.m - 1 && a.cumprob[idx] < xr) ++idx;
     }
-    wave_normals(g, PL, &zig, sz, nc, lane);
+    g.normals(sz, nc, lane);
     lds_sync();
     double ss = 0.0;
     for (int i = 0; i < nc; ++i) ss = fma(sz[i], sz[i], ss);  // index order, as the narrow kernel
-    const double fac = pow(g.next_double(), 1.0 / (double)nc) / sqrt(ss);
+    const double fac = pow(g.uniform(), 1.0 / (double)nc) / sqrt(ss);
     const double* AT = a.axes_t + (size_t)idx * nc * nc;
     const double* c = a.ctrs + (size_t)idx * nc;
     for (int i = lane; i < nc; i += 64) {
@@ -789,7 +790,7 @@ __global__ void __launch_bounds__(64) wide_unif_kernel(WideUnifArgs a) {
           break;
         }
       }
-      if (q > 1) accept = g.next_double() < (1.0 / (double)q);
+      if (q > 1) accept = g.uniform() < (1.0 / (double)q);
     }
     if (!accept) continue;
     bool inside = true;
@@ -804,7 +805,7 @@ __global__ void __launch_bounds__(64) wide_unif_kernel(WideUnifArgs a) {
     inside = __all(inside);
     if (!inside) continue;
     if (nc < D) {
-      wave_doubles(g, PL, sx + nc, D - nc, lane);
+      g.doubles(sx + nc, D - nc, lane);
       lds_sync();
     }
     if (a.propose_only) break;
@@ -826,7 +827,7 @@ __global__ void __launch_bounds__(64) wide_unif_kernel(WideUnifArgs a) {
       a.ncalls[w] = ncall;
     }
     a.flags[w] = flags;
-    if (a.rng_out) g.store(a.rng_out + (size_t)w * 4);
+    g.store(a.rng_out, (size_t)w);
   }
 }
 
@@ -2154,8 +2155,11 @@ int wide_walk_launch(dh_ctx* ctx, int kind, int problem, int k, int ndim, int nc
                      int iters, int doubling, const int8_t* bc, const uint64_t* rng, double* u, double* v,
                      double* logl, int32_t* c0, int32_t* c1, int32_t* c2, int32_t* flags,
                      uint64_t* rng_out, const double* run_loglstar, const double* run_scale, const int* run_mode,
-                     const int* run_doubling, int wpr, int my_mode) {
+                     const int* run_doubling, int wpr, int my_mode, const PhiloxKey* philox) {
   WideWalkArgs a;
+  a.ph = philox ? *philox : PhiloxKey{0, 0, 0};
+  a.ph.offset = (a.ph.offset + 3ull) & ~3ull;  // WaveGen<RNG_PHILOX> advances in whole blocks
+  if (!philox && !rng && k > 0) return fail(ctx, DH_ERR_ARG, "wide walk: no generator states");
   if (!get_problem(ctx, problem, &a.prob)) return DH_ERR_ARG;
   a.run_loglstar = run_loglstar;
   a.run_scale = run_scale;
@@ -2211,36 +2215,41 @@ int wide_walk_launch(dh_ctx* ctx, int kind, int problem, int k, int ndim, int nc
   if (const char* e = getenv("DH_WIDE_WPW")) wpw = std::max(1, std::min(wpw, atoi(e)));
   wpw = std::max(1, std::min(wpw, k));
   const size_t lds = per_wave * wpw;
-  static size_t lds_attr_dev[kMaxDev][4] = {};
+  static size_t lds_attr_dev[kMaxDev][8] = {};
   size_t* lds_attr = lds_attr_dev[ctx->device & (kMaxDev - 1)];
-  const int kk = kind < 0 || kind > 3 ? 3 : kind;
+  const int kk = (kind < 0 || kind > 3 ? 3 : kind) + (philox ? 4 : 0);
+  const void* fns[8] = {(const void*)wide_walk_kernel<0, RNG_PCG64>,  (const void*)wide_walk_kernel<1, RNG_PCG64>,
+                        (const void*)wide_walk_kernel<2, RNG_PCG64>,  (const void*)wide_walk_kernel<3, RNG_PCG64>,
+                        (const void*)wide_walk_kernel<0, RNG_PHILOX>, (const void*)wide_walk_kernel<1, RNG_PHILOX>,
+                        (const void*)wide_walk_kernel<2, RNG_PHILOX>, (const void*)wide_walk_kernel<3, RNG_PHILOX>};
   if (lds > lds_attr[kk]) {
-    const void* fn = kk == 0   ? (const void*)wide_walk_kernel<0>
-                     : kk == 1 ? (const void*)wide_walk_kernel<1>
-                     : kk == 2 ? (const void*)wide_walk_kernel<2>
-                               : (const void*)wide_walk_kernel<3>;
-    if (!hip_ok(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+    if (!hip_ok(ctx, hipFuncSetAttribute(fns[kk], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
                 "hipFuncSetAttribute(wide_walk)"))
       return DH_ERR_HIP;
     lds_attr[kk] = lds;
   }
   const dim3 grid((k + wpw - 1) / wpw), block(64 * wpw);
-  if (kind == 0)
-    hipLaunchKernelGGL(wide_walk_kernel<0>, grid, block, lds, ctx->stream, a);
-  else if (kind == 1)
-    hipLaunchKernelGGL(wide_walk_kernel<1>, grid, block, lds, ctx->stream, a);
-  else if (kind == 2)
-    hipLaunchKernelGGL(wide_walk_kernel<2>, grid, block, lds, ctx->stream, a);
-  else
-    hipLaunchKernelGGL(wide_walk_kernel<3>, grid, block, lds, ctx->stream, a);
+  switch (kk) {
+    case 0: hipLaunchKernelGGL((wide_walk_kernel<0, RNG_PCG64>), grid, block, lds, ctx->stream, a); break;
+    case 1: hipLaunchKernelGGL((wide_walk_kernel<1, RNG_PCG64>), grid, block, lds, ctx->stream, a); break;
+    case 2: hipLaunchKernelGGL((wide_walk_kernel<2, RNG_PCG64>), grid, block, lds, ctx->stream, a); break;
+    case 3: hipLaunchKernelGGL((wide_walk_kernel<3, RNG_PCG64>), grid, block, lds, ctx->stream, a); break;
+    case 4: hipLaunchKernelGGL((wide_walk_kernel<0, RNG_PHILOX>), grid, block, lds, ctx->stream, a); break;
+    case 5: hipLaunchKernelGGL((wide_walk_kernel<1, RNG_PHILOX>), grid, block, lds, ctx->stream, a); break;
+    case 6: hipLaunchKernelGGL((wide_walk_kernel<2, RNG_PHILOX>), grid, block, lds, ctx->stream, a); break;
+    default: hipLaunchKernelGGL((wide_walk_kernel<3, RNG_PHILOX>), grid, block, lds, ctx->stream, a); break;
+  }
   return hip_ok(ctx, hipGetLastError(), "wide walk launch") ? DH_OK : DH_ERR_HIP;
 }
 
 int wide_unif_launch(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, int m, const double* ctrs,
                      const double* axes, const double* ams, const double* cumprob, double loglstar,
                      const int8_t* bc, const uint64_t* rng, int64_t max_tries, double* u, double* v, double* logl,
-                     int32_t* ncalls, int32_t* flags, uint64_t* rng_out) {
+                     int32_t* ncalls, int32_t* flags, uint64_t* rng_out, const PhiloxKey* philox) {
   WideUnifArgs a;
+  a.ph = philox ? *philox : PhiloxKey{0, 0, 0};
+  a.ph.offset = (a.ph.offset + 3ull) & ~3ull;
+  if (!philox && !rng && k > 0) return fail(ctx, DH_ERR_ARG, "wide unif: no generator states");
   a.propose_only = problem == -1 ? 1 : 0;
   if (a.propose_only) {
     a.prob = ProblemDev();
@@ -2284,7 +2293,10 @@ int wide_unif_launch(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, int m
   a.zki = ctx->zki();
   a.zwi = ctx->zwi();
   a.zfi = ctx->zfi();
-  hipLaunchKernelGGL(wide_unif_kernel, dim3(k), dim3(64), (size_t)(ncdim + 2 * ndim) * 8, ctx->stream, a);
+  if (philox)
+    hipLaunchKernelGGL(wide_unif_kernel<RNG_PHILOX>, dim3(k), dim3(64), (size_t)(ncdim + 2 * ndim) * 8, ctx->stream, a);
+  else
+    hipLaunchKernelGGL(wide_unif_kernel<RNG_PCG64>, dim3(k), dim3(64), (size_t)(ncdim + 2 * ndim) * 8, ctx->stream, a);
   return hip_ok(ctx, hipGetLastError(), "wide unif launch") ? DH_OK : DH_ERR_HIP;
 }
 

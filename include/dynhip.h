@@ -232,7 +232,7 @@ int dh_set_rwalk_form(dh_ctx* ctx, int form);
  * unitcheck, prior transform, log-likelihood, accept rule, counters -- is the parity kernel's code.
  * NOT stream-compatible with the reference: validated statistically (tests/test_gpu_philox.py: the
  * reference's KS tests of tests/test_ellipsoid.py on device output, chain statistics against the parity
- * mode).  ndim <= 32.  A caller advances `offset` by at least walks * (ndim + 8) per launch (or changes
+ * mode).  Any ndim <= 512 (above 32 the wave-per-walker kernel).  A caller advances `offset` by at least walks * (ndim + 8) per launch (or changes
  * `seed`) to get fresh draws. */
 int dh_rwalk_batch_philox(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, const double* u0,
                           const double* axes, int m, const int32_t* axes_idx, double scale,
@@ -295,6 +295,24 @@ int dh_slice_batch_dev(dh_ctx* ctx, int problem, int k, int ndim, int mode,
                        double* v, double* logl, int32_t* ncalls, int32_t* nexpand,
                        int32_t* ncontract, int32_t* flags, uint64_t* rng_out);
 
+/* Throughput mode of the slice samplers (see dh_rwalk_batch_philox): the same kernels drawing from
+ * hiprand's Philox4x32-10 generator -- directions (internal_samplers.py:820) from fp32 Box-Muller normals
+ * widened to fp64, the axis shuffle (:673) by masked rejection on 32-bit draws, rand0 / doubling coin /
+ * shrink uniforms (:1099, 1151, 1173) from 53-bit doubles in [0, 1) -- walker i on subsequence
+ * sequence0 + i of `seed`, `offset` draws in.  Consumption depends on the data: advance `offset` by more
+ * than a walker can draw in one call (2^24 is what dh_ns_ensemble uses).  Any ndim <= 512 (above 32, and
+ * at dimensions without a register instantiation, the wave-per-walker kernels of the wide path). */
+int dh_slice_batch_philox(dh_ctx* ctx, int problem, int k, int ndim, int mode, const double* u0,
+                          const double* axes, int m, const int32_t* axes_idx, double scale,
+                          double loglstar, int slices, int doubling, uint64_t seed, uint64_t sequence0,
+                          uint64_t offset, double* u, double* v, double* logl, int32_t* ncalls,
+                          int32_t* nexpand, int32_t* ncontract, int32_t* flags);
+int dh_slice_batch_philox_dev(dh_ctx* ctx, int problem, int k, int ndim, int mode, const double* u0,
+                              const double* axes, int m, const int32_t* axes_idx, double scale,
+                              double loglstar, int slices, int doubling, uint64_t seed, uint64_t sequence0,
+                              uint64_t offset, double* u, double* v, double* logl, int32_t* ncalls,
+                              int32_t* nexpand, int32_t* ncontract, int32_t* flags);
+
 /* UniformBoundSampler.sample (internal_samplers.py:243-340) with the bound's
  * sample() inlined: m == 1 Ellipsoid.sample (bounding.py:307-319), m > 1
  * MultiEllipsoid.sample incl. the 1/q overlap rejection (bounding.py:525-590),
@@ -313,6 +331,20 @@ int dh_unif_batch_dev(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, int 
                       const uint64_t* rng, int64_t max_tries, double* u, double* v,
                       double* logl, int32_t* ncalls, int32_t* flags,
                       uint64_t* rng_out);
+
+/* Throughput mode of UniformBoundSampler.sample / UnitCubeSampler.sample (m = 0: north_star's "hiprand for the
+ * unit-cube draws"): ellipsoid choice, randsphere (bounding.py:1288-1297, 543-590), the 1/q test and the
+ * unit-cube uniforms (internal_samplers.py:428) from hiprand's Philox4x32-10 generator, keyed as in
+ * dh_rwalk_batch_philox.  Consumption depends on the data: advance `offset` generously between calls. */
+int dh_unif_batch_philox(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, int m, const double* ctrs,
+                         const double* axes, const double* ams, const double* cumprob, double loglstar,
+                         const int8_t* bc, uint64_t seed, uint64_t sequence0, uint64_t offset,
+                         int64_t max_tries, double* u, double* v, double* logl, int32_t* ncalls);
+int dh_unif_batch_philox_dev(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, int m, const double* ctrs,
+                             const double* axes, const double* ams, const double* cumprob, double loglstar,
+                             const int8_t* bc, uint64_t seed, uint64_t sequence0, uint64_t offset,
+                             int64_t max_tries, double* u, double* v, double* logl, int32_t* ncalls,
+                             int32_t* flags);
 
 /* Bound.sample / samples from ONE generator: Ellipsoid.sample(s)
  * (bounding.py:307-334) for m == 1, MultiEllipsoid.sample(s)
@@ -384,7 +416,7 @@ int dh_ns_consume(dh_ctx* ctx, int runs, int nlive, int queue_size, double dlogz
  * rebuild comes early, never late): a rebuild is a latency-bound tree construction
  * that costs about the same for one run or the whole ensemble. */
 int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim,
-                   int queue_size, int sampler /* 0 rwalk, 1 rslice, 2 slice, 3 rwalk with hiprand Philox proposals */,
+                   int queue_size, int sampler /* 0 rwalk, 1 rslice, 2 slice; + 3: unit-cube phase and proposals from hiprand Philox streams */,
                    int walks /* or slices */, int bound_multi,
                    int rebuild_sync /* 1: all runs rebuild together, see below */, double dlogz,
                    double enlarge, int64_t max_fills, int64_t max_iter,

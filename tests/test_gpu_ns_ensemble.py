@@ -191,5 +191,4 @@ def test_philox_proposals_in_the_device_loop(ctx):
     # not the PCG64 streams
     pcg = ctx.ns_ensemble(prob, 16, **dict(kw, rng="pcg64"))
     assert (pcg["logz"] != lz).all()
-    with pytest.raises(ValueError):
-        ctx.ns_ensemble(prob, 2, 100, 16, sample="rslice", rng="philox")
+    # (rslice / slice with rng='philox': tests/test_gpu_philox.py::test_philox_resident_loop_all_samplers)
