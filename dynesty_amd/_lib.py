@@ -95,7 +95,7 @@ SIGNATURES = {
                                _dbl, _vp, _vp, C.c_int64, _vp, _vp, _vp, _vp,
                                _vp, _vp]),
     "dh_ns_consume": (_i, [_vp, _i, _i, _i, _dbl, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
-                           _vp, _vp, _vp]),
+                           _vp, _vp, _vp, _vp]),
     "dh_ns_ensemble": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _dbl, _dbl,
                             C.c_int64, C.c_int64, _vp, _i, _u32, _vp, _vp,
                             _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -728,12 +728,15 @@ class Context:
             _ptr(logl), _ptr(nc), _ptr(rng_out), None, None))
         return dict(u=u, v=v, logl=logl, ncalls=nc, rng_out=rng_out)
 
-    def ns_consume(self, live_logl, q_logl, q_ncalls, state, dlogz, live_it=None):
+    def ns_consume(self, live_logl, q_logl, q_ncalls, state, dlogz, live_it=None, plateau=None):
         """One queue consumption per run (dh_ns_consume).  live_logl (R, N) and
         state (R, 8) are updated in place; returns dict(dead_logl, dead_slot,
         dead_src (lists per run), stopped (R,) bool).  With live_it ((R, N) int32,
         updated in place: iteration at which each live point was proposed) also
-        dead_it / dead_nc per run (the reference's per-point 'it' and 'nc')."""
+        dead_it / dead_nc per run (the reference's per-point 'it' and 'nc').
+        plateau: optional (R, 2) float64, updated in place -- the reference's
+        likelihood-plateau mode carried between calls (deaths left, ln of the
+        plateau's volume step; sampler.py:1112-1127)."""
         live = np.ascontiguousarray(live_logl, dtype=np.float64)
         assert live is live_logl and live.ndim == 2
         R, N = live.shape
@@ -748,9 +751,12 @@ class Context:
             assert live_it.dtype == np.int32 and live_it.shape == (R, N) and live_it.flags.c_contiguous
             dit = np.empty((R, K), dtype=np.int32)
             dnc = np.empty((R, K), dtype=np.int32)
+        if plateau is not None:
+            assert plateau.dtype == np.float64 and plateau.shape == (R, 2) and plateau.flags.c_contiguous
         self._check(self.lib.dh_ns_consume(self.handle, R, N, K, float(dlogz), _ptr(live), _ptr(ql),
                                            _ptr(qn), _ptr(state), _ptr(dl), _ptr(ds), _ptr(dj),
-                                           _ptr(nd), _ptr(stp), _ptr(live_it), _ptr(dit), _ptr(dnc)))
+                                           _ptr(nd), _ptr(stp), _ptr(live_it), _ptr(dit), _ptr(dnc),
+                                           _ptr(plateau)))
         out = dict(dead_logl=[dl[r, :nd[r]].copy() for r in range(R)],
                    dead_slot=[ds[r, :nd[r]].copy() for r in range(R)],
                    dead_src=[dj[r, :nd[r]].copy() for r in range(R)],

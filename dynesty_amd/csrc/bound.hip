@@ -48,7 +48,79 @@ __global__ void __launch_bounds__(64)
   if (live) count[w] = cnt;
 }
 
+// Sampler.propose_live's membership test of the start points (sampler.py:484-489) for an ensemble: candidate w
+// belongs to run w / wpr and is tested against THAT run's ellipsoids (bound arrays strided by max_ells); a run
+// with a candidate outside its bound gets flag[run] = 1 (the caller rebuilds that run's bound).  Same lane map
+// and arithmetic as contains_kernel; the runs of a wavefront are served one after the other so that centre
+// and precision matrix stay wave-uniform.  strict = 1: MultiEllipsoid.contains (any quad < 1), 0:
+// Ellipsoid.contains (sqrt(quad) <= 1).
+template <int N>
+__global__ void __launch_bounds__(64)
+    contains_runs_kernel(const double* __restrict__ x, int k, int d, int wpr, const double* __restrict__ ctrs,
+                         const double* __restrict__ ams, const int* __restrict__ nells, int max_ells, int strict,
+                         const int* __restrict__ run_mode, int my_mode, const int* __restrict__ bstatus, int* flag) {
+  const int w = blockIdx.x * 64 + threadIdx.x;
+  const bool live = w < k;
+  const int wi = live ? w : k - 1;
+  const int my_run = wi / wpr;
+  double xx[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) xx[i] = (i < d) ? x[(size_t)wi * d + i] : 0.0;
+  bool pending = live;
+  while (__any(pending)) {
+    // the lowest pending lane's run, for the whole wave (wave-uniform operands below)
+    const unsigned long long pm = __ballot(pending);
+    const int run = __shfl(my_run, __ffsll((long long)pm) - 1);
+    const bool mine = pending && my_run == run;
+    const bool served = (!run_mode || run_mode[run] == my_mode) && (!bstatus || bstatus[run] == 0);
+    if (served) {
+      const int m = nells ? nells[run] : 1;
+      bool inside = false;
+      for (int a = 0; a < m; ++a) {
+        const double* __restrict__ c = ctrs + ((size_t)run * max_ells + a) * d;
+        const double* __restrict__ A = ams + ((size_t)run * max_ells + a) * d * d;
+        double dl[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) dl[i] = (i < d) ? xx[i] - c[i] : 0.0;
+        double q = 0.0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+          if (i < d) {
+            double r = 0.0;
+#pragma unroll
+            for (int j = 0; j < N; ++j)
+              if (j < d) r = fma(A[i * d + j], dl[j], r);
+            q = fma(dl[i], r, q);
+          }
+        }
+        inside = inside || (strict ? (q < 1.0) : (sqrt(q) <= 1.0));
+      }
+      if (__any(mine && !inside) && threadIdx.x == (unsigned)(__ffsll((long long)__ballot(mine)) - 1)) atomicOr(&flag[run], 1);
+    }
+    if (mine) pending = false;
+  }
+}
+
 }  // namespace
+
+namespace dh {
+int contains_runs_launch(dh_ctx* ctx, const double* x, int k, int d, int wpr, const double* ctrs, const double* ams,
+                         const int* nells, int max_ells, int strict, const int* run_mode, int my_mode,
+                         const int* bstatus, int* flag) {
+  if (k <= 0 || d > kMaxRegDim) return DH_OK;  // (above the register dimensions the check is not built)
+  const dim3 grid((k + 63) / 64), block(64);
+  bool hit = false;
+#define X(NN)                                                                                              \
+  if (!hit && d <= NN) {                                                                                   \
+    hit = true;                                                                                            \
+    hipLaunchKernelGGL(contains_runs_kernel<NN>, grid, block, 0, ctx->stream, x, k, d, wpr, ctrs, ams, nells, \
+                       max_ells, strict, run_mode, my_mode, bstatus, flag);                                \
+  }
+  DH_DIM_LIST(X)
+#undef X
+  return hip_ok(ctx, hipGetLastError(), "contains_runs launch") ? DH_OK : DH_ERR_HIP;
+}
+}  // namespace dh
 
 extern "C" {
 

@@ -42,6 +42,11 @@ struct NsRun {
   double logzvar;
   uint64_t rng[4];
   long long nc_carry;  // calls of the entries popped after the last death: charged to the NEXT death (sampler.py:1141)
+  // likelihood plateau (sampler.py:1112-1127, 1190-1193): deaths still to be taken with the plateau's volume
+  // step (0 = not in plateau mode), ln of that step's volume, and the two sums that make var[ln Z] exact
+  // although the dead points' d ln X is then no longer constant (see ns_finish)
+  int pcount, force_rebuild;
+  double plogdvol, var_a, var_b;
 };
 
 struct NsArgs {
@@ -77,6 +82,7 @@ struct NsArgs {
   double* run_scale;
   int* run_mode;
   int* rebuild_mask;
+  int* force;  // runs: set by the start-point membership check of the previous fill (forced rebuild, sampler.py:484-489)
   int* ndone;
   // bound (rebuild outputs)
   int* nells;
@@ -156,6 +162,8 @@ __global__ void __launch_bounds__(kT)
     r.acc = r.rej = r.doubling = r.pad1 = 0;
     r.logzvar = 0.0;
     r.nc_carry = 0;
+    r.pcount = r.force_rebuild = 0;
+    r.plogdvol = r.var_a = r.var_b = 0.0;
     Pcg64 g;
     seed_from_child(g, entropy, nwords, 0x80000000u + first_run + (uint32_t)run);
     g.store(r.rng);
@@ -248,7 +256,8 @@ __global__ void __launch_bounds__(kT) ns_prepare(NsArgs a) {
             r.mode = MODE_BOUND;
             need = 1;
           }
-        } else if (r.ncall >= r.ncall_last_update + a.update_interval) {
+        } else if (r.ncall >= r.ncall_last_update + a.update_interval || (a.force && a.force[run])) {
+          // (force: a start point of the last fill lay outside the bound, sampler.py:484-489)
           need = 1;
         }
       }
@@ -266,6 +275,7 @@ __global__ void __launch_bounds__(kT) ns_prepare(NsArgs a) {
       r.nbound += 1;
     }
     r.need_rebuild = need;
+    if (a.force) a.force[run] = 0;
     a.rebuild_mask[run] = need;
     a.run_mode[run] = r.mode;
     a.run_loglstar[run] = r.loglstar;
@@ -638,9 +648,92 @@ __global__ void __launch_bounds__(kT) ns_consume(NsArgs a) {
   __syncthreads();
   const int ndead = misc[0], jcap = misc[1];
   NS_PROF(1);
+  // ---- likelihood plateaus (sampler.py:1112-1127, 1190-1193) ----
+  // When the worst live point shares its log-likelihood with others -- rwalk hands back its start point when no
+  // step was accepted: about one queue fill in seven of a C2 run meets such a pair -- the reference takes the
+  // next `multiplicity` deaths with a constant VOLUME step X_s / (N + 1) instead of the constant ln X step.
+  // Equal values die consecutively, so the plateaus of a fill are its runs of equal death values (and what an
+  // earlier fill left open); the j-th death of a plateau shrinks ln X by ln((N + 2 - j) / (N + 1 - j)) whatever
+  // X_s was.  Every death's own step is therefore known without walking the fill; a sum scan of the steps gives
+  // ln X, and the scans below take both per death (has_tie) instead of the closed form of the constant step.
+  __shared__ int pl_int[4];
+  __shared__ double pl_dbl[2];
+  __shared__ double sred[3][4];
+  int has_tie = r.pcount > 0 ? 1 : 0;
+  for (int e = t; e < ndead; e += kT)
+    if ((e + 1 < ndead && dcur[e + 1] == dcur[e]) || (e + 1 == ndead && bcast[2] == dcur[e])) has_tie = 1;
+  has_tie = __syncthreads_or(has_tie);
+  if (a.prof && t == 0 && has_tie) atomicAdd((unsigned long long*)&a.prof[8 + (r.pcount > 0 ? 1 : 0)], 1ull);
+  int ntail_tot = 0;
+  if (has_tie) {
+    // live points left after this fill's deaths that share the last death's value (a plateau that goes on)
+    int ntail = 0;
+    if (ndead > 0 && bcast[2] == dcur[ndead - 1]) {
+      const double x = dcur[ndead - 1];
+      for (int sl = t; sl < N; sl += kT) ntail += (src[sl] >= 0 ? ql[src[sl]] : skey[sl]) == x ? 1 : 0;
+    }
+    if (t == 0) pl_int[2] = 0;
+    __syncthreads();
+    if (ntail) atomicAdd(&pl_int[2], ntail);
+    __syncthreads();
+    ntail_tot = pl_int[2];
+  }
+  const int pc_in = r.pcount;                      // deaths an open plateau still has to take
+  const int pc0 = pc_in < ndead ? pc_in : ndead;   // ... of which this fill holds the first pc0
+  const double rho0 = pc_in > 0 ? exp(r.plogdvol - logvol0) : 0.0;
+  // position j (1-based) of death e >= pc0 in its run of equal values and the run's multiplicity m at its start
+  auto run_info = [&](int e, int& j, int& m) {
+    const double x = dcur[e];
+    int sst = e, fin = e;
+    while (sst > pc0 && dcur[sst - 1] == x) --sst;
+    while (fin + 1 < ndead && dcur[fin + 1] == x) ++fin;
+    m = fin - sst + 1 + ((fin == ndead - 1 && bcast[2] == x) ? ntail_tot : 0);
+    j = e - sst + 1;
+  };
+  auto step_of = [&](int e) -> double {  // -d ln X of death e
+    if (e < pc0) return -log1p(-rho0 / (1.0 - (double)e * rho0));
+    int j, m;
+    run_info(e, j, m);
+    return m > 1 ? -log1p(-1.0 / ((double)N + 2.0 - (double)j)) : dlv;
+  };
+  // sum over the workgroup's per-thread totals: returns this thread's exclusive prefix (threads own contiguous deaths)
+  auto excl_sum = [&](double v, double* scratch4) -> double {
+    double sc = v;
+    for (int off = 1; off < 64; off <<= 1) {
+      const double y = __shfl_up(sc, off);
+      if (lane >= off) sc += y;
+    }
+    double ex = __shfl_up(sc, 1);
+    if (lane == 0) ex = 0.0;
+    __syncthreads();
+    if (lane == 63) scratch4[wv] = sc;
+    __syncthreads();
+    double pre = 0.0;
+    for (int w2 = 0; w2 < wv; ++w2) pre += scratch4[w2];
+    return pre + ex;
+  };
   // ---- phase B: integration + stopping rule as prefix scans over the deaths ----
   const int EPT = (K + kT - 1) / kT;
-  double lw[kEPT], nl[kEPT];
+  double lw[kEPT], nl[kEPT], cd[kEPT], lvv[kEPT];
+  {
+    double run_cd = 0.0;
+#pragma unroll
+    for (int i = 0; i < kEPT; ++i) {
+      const int e = t * EPT + i;
+      cd[i] = dlv;
+      lvv[i] = logvol0 - (double)(e + 1) * dlv;
+      if (has_tie && i < EPT && e < ndead) {
+        cd[i] = step_of(e);
+        run_cd += cd[i];
+        lvv[i] = run_cd;
+      }
+    }
+    if (has_tie) {
+      const double ex = excl_sum(run_cd, sred[0]);
+#pragma unroll
+      for (int i = 0; i < kEPT; ++i) lvv[i] = logvol0 - (ex + lvv[i]);
+    }
+  }
   double tz = -INFINITY, tm = -INFINITY;
 #pragma unroll
   for (int i = 0; i < kEPT; ++i) {
@@ -649,8 +742,8 @@ __global__ void __launch_bounds__(kT) ns_consume(NsArgs a) {
     const int e = t * EPT + i;
     if (i < EPT && e < ndead) {
       const double lnew = dcur[e], lprev = e ? dcur[e - 1] : dead_prev0;
-      const double logvol_e = logvol0 - (double)(e + 1) * dlv;
-      lw[i] = logaddexp_dev(lnew, lprev) + logvol_e + ldv_c;
+      const double logvol_e = lvv[i];
+      lw[i] = logaddexp_dev(lnew, lprev) + logvol_e + (has_tie ? log(0.5 * expm1(cd[i])) : ldv_c);
       nl[i] = ql[dj[e]];
     }
     tz = logaddexp_dev(tz, lw[i]);  // running (inclusive) values of this lane's segment
@@ -691,8 +784,7 @@ __global__ void __launch_bounds__(kT) ns_consume(NsArgs a) {
     if (i < EPT && e < ndead) {
       lw[i] = logaddexp_dev(pz, lw[i]);  // ln Z after death e
       nl[i] = fmax(pm, nl[i]);           // lmax after death e
-      const double logvol_e = logvol0 - (double)(e + 1) * dlv;
-      const double dz = logaddexp_dev(0.0, nl[i] + logvol_e - lw[i]);
+      const double dz = logaddexp_dev(0.0, nl[i] + lvv[i] - lw[i]);
       if (dz < a.dlogz && e < mystop) mystop = e;
     }
   }
@@ -707,31 +799,88 @@ __global__ void __launch_bounds__(kT) ns_consume(NsArgs a) {
     if (i < EPT && t * EPT + i == E) {
       bcast[0] = lw[i];
       bcast[1] = nl[i];
+      bcast[3] = lvv[i];
+      // the plateau mode after death E: what its plateau still has to take
+      int pcn = 0;
+      double plogn = 0.0;
+      if (has_tie) {
+        if (E < pc_in) {
+          pcn = pc_in - nkeep;
+          plogn = r.plogdvol;
+        } else {
+          int j, m;
+          run_info(E, j, m);
+          if (m > j) {
+            pcn = m - j;
+            // ln of the plateau's volume step: ln X at its start (ln X now minus the j steps taken) - ln(N + 1)
+            plogn = lvv[i] - log1p(-(double)j / ((double)N + 1.0)) - log((double)N + 1.0);
+          }
+        }
+      }
+      pl_int[0] = pcn;
+      pl_dbl[0] = plogn;
     }
   __syncthreads();
   const double logz_E = E >= 0 ? bcast[0] : logz0, lmax_E = E >= 0 ? bcast[1] : lmax0;
   // information: sum of the L e^L dX terms relative to e^{lnZ_E}
   double hs = 0.0;
+  double tt[kEPT];
   long long calls = 0;
   const int jlast = stopped ? dj[E] : (jcap >= 0 ? jcap : K - 1);
 #pragma unroll
   for (int i = 0; i < kEPT; ++i) {
     const int e = t * EPT + i;
+    tt[i] = 0.0;
     if (i < EPT && e <= E) {
       const double lnew = dcur[e], lprev = e ? dcur[e - 1] : dead_prev0;
-      const double ldv = logvol0 - (double)(e + 1) * dlv + ldv_c;
+      const double ldv = lvv[i] + (has_tie ? log(0.5 * expm1(cd[i])) : ldv_c);
       const double t0 = exp(lprev - logz_E + ldv), t1 = exp(lnew - logz_E + ldv);
-      hs += (t0 > 0.0 ? t0 * lprev : 0.0) + (t1 > 0.0 ? t1 * lnew : 0.0);
+      tt[i] = (t0 > 0.0 ? t0 * lprev : 0.0) + (t1 > 0.0 ? t1 * lnew : 0.0);
+      hs += tt[i];
+    }
+  }
+  // plateau deaths: their d ln X differs from the constant step, so their share of var[ln Z] = sum dH dlnX does not
+  // telescope -- each needs its own dH = H_e - H_{e-1}, from the prefix sums of the terms above:
+  //   H_e = e^{lnZ_E - lnZ_e} (w0 (H_0 + lnZ_0) + P_e) - lnZ_e,   P_e = sum_{k <= e} terms_k
+  // -- and the two sums ns_finish needs for the same purpose (relative to Z_E): A += terms_e delta_e, B += (dZ_e / Z_E) delta_e
+  double corr = 0.0, va_add = 0.0, vb_add = 0.0;
+  if (has_tie) {
+    const double ex = excl_sum(hs, sred[1]);
+    const double w0 = exp(logz0 - logz_E);
+    const double g0 = w0 > 0.0 ? w0 * (h0 + logz0) : 0.0;
+    double pbefore = ex, lzbefore = pz;
+#pragma unroll
+    for (int i = 0; i < kEPT; ++i) {
+      const int e = t * EPT + i;
+      if (i < EPT && e <= E) {
+        const double delta = cd[i] - dlv;
+        if (delta != 0.0) {
+          const double hprev = e == 0 ? h0 : exp(logz_E - lzbefore) * (g0 + pbefore) - lzbefore;
+          const double he = exp(logz_E - lw[i]) * (g0 + pbefore + tt[i]) - lw[i];
+          corr += (he - hprev) * delta;
+          va_add += tt[i] * delta;
+          vb_add += (exp(lw[i] - logz_E) - exp(lzbefore - logz_E)) * delta;
+        }
+        pbefore += tt[i];
+        lzbefore = lw[i];
+      }
     }
   }
   for (int j = t; j <= jlast; j += kT) calls += qc[j];
   for (int off = 32; off > 0; off >>= 1) {
     hs += __shfl_xor(hs, off);
     calls += __shfl_xor(calls, off);
+    corr += __shfl_xor(corr, off);
+    va_add += __shfl_xor(va_add, off);
+    vb_add += __shfl_xor(vb_add, off);
   }
+  __syncthreads();  // (sred[1] / wred were read above)
   if (lane == 0) {
     wred[0][wv] = hs;
     lred[wv] = calls;
+    sred[0][wv] = corr;
+    sred[1][wv] = va_add;
+    sred[2][wv] = vb_add;
   }
   NS_PROF(2);
   // ---- replay the walk up to the stop index (once per run): the sorted order is untouched ----
@@ -759,8 +908,18 @@ __global__ void __launch_bounds__(kT) ns_consume(NsArgs a) {
       r.logz = logz_E;
       r.lmax = lmax_E;
       r.dead_prev = dcur[E];
-      r.logvol = logvol0 - (double)nkeep * dlv;
+      r.logvol = has_tie ? bcast[3] : logvol0 - (double)nkeep * dlv;
       r.it = it0 + nkeep;
+      if (has_tie || r.var_a != 0.0 || r.var_b != 0.0) {
+        // (the plateau sums are kept relative to the running Z)
+        r.logzvar += sred[0][0] + sred[0][1] + sred[0][2] + sred[0][3];
+        r.var_a = (w > 0.0 ? r.var_a * w : 0.0) + (sred[1][0] + sred[1][1] + sred[1][2] + sred[1][3]);
+        r.var_b = (w > 0.0 ? r.var_b * w : 0.0) + (sred[2][0] + sred[2][1] + sred[2][2] + sred[2][3]);
+      }
+      if (has_tie) {
+        r.pcount = pl_int[0];
+        r.plogdvol = pl_dbl[0];
+      }
     }
     r.loglstar = bcast[2];
     r.nfill += 1;
@@ -905,10 +1064,19 @@ __global__ void __launch_bounds__(kT) ns_finish(NsArgs a) {
   double* W = a.fin_ws + (size_t)run * 3 * N;  // trapezoid ln-weights
   double* DL = W + N;                          // -d ln X
   double* T = DL + N;                          // ln dX, then the L e^L terms
+  // a plateau still being worked off keeps its volume steps for its remaining points, the rest of the final
+  // points share what is left (sampler.py:813-830)
+  const int pc = r.pcount < N ? r.pcount : N;
+  const double pstep = pc > 0 ? exp(r.plogdvol - lv0) : 0.0;
+  auto lv_at = [&](int i) {  // ln X after the i-th final point (1-based; 0: before the first)
+    if (pc == 0) return i > 0 ? lv0 + log(1.0 - (double)i / ((double)N + 1.0)) : lv0;
+    if (i <= pc) return lv0 + log1p(-(double)i * pstep);
+    return lv0 + log1p(-(double)pc * pstep) + log1p(-(double)(i - pc) / ((double)(N - pc) + 1.0));
+  };
   for (int i = 1 + t; i <= N; i += kT) {
     const double cur = sorted[i - 1], prev = i > 1 ? sorted[i - 2] : dead_prev;
-    const double lv = lv0 + log(1.0 - (double)i / ((double)N + 1.0));
-    const double lvprev = i > 1 ? lv0 + log(1.0 - (double)(i - 1) / ((double)N + 1.0)) : lv0;
+    const double lv = lv_at(i);
+    const double lvprev = lv_at(i - 1);
     const double dl = lvprev - lv;
     const double logdvol = lv + log(0.5 * expm1(dl));
     W[i - 1] = logaddexp_dev(cur, prev) + logdvol;
@@ -935,7 +1103,9 @@ __global__ void __launch_bounds__(kT) ns_finish(NsArgs a) {
     const double wn = exp(r.logz - logz_f);
     double hpart = r.it > 0 && wn > 0.0 ? wn * (r.h + r.logz) : 0.0;  // (1/Z_f) sum of the L ln L terms so far
     double hcur = hpart - (r.it > 0 ? wn * logz_f : 0.0);              // H_n
-    double logzvar = hcur * dlv;
+    // the dead points' share of sum_i (H_i - H_{i-1}) dlnX_i: it telescopes for the constant step, and the
+    // plateau deaths' departures from it were summed on the way (ns_consume: var_a, var_b, relative to Z_n)
+    double logzvar = hcur * dlv + (wn > 0.0 ? wn * (r.var_a - logz_f * r.var_b) : 0.0);
     double logz = r.logz;
     for (int i = 0; i < N; ++i) {
       logz = logaddexp_dev(logz, W[i]);
@@ -965,7 +1135,7 @@ extern "C" {
 int dh_ns_consume(dh_ctx* ctx, int runs, int nlive, int queue_size, double dlogz, double* live_logl,
                   const double* q_logl, const int32_t* q_ncalls, double* state, double* dead_logl,
                   int32_t* dead_slot, int32_t* dead_src, int32_t* ndead, int32_t* stopped, int32_t* live_it,
-                  int32_t* dead_it, int32_t* dead_nc) {
+                  int32_t* dead_it, int32_t* dead_nc, double* plateau) {
   DH_CHECK_CTX(ctx);
   const bool want_pt = live_it || dead_it || dead_nc;
   if (want_pt && !(live_it && dead_it && dead_nc))
@@ -1005,6 +1175,10 @@ int dh_ns_consume(dh_ctx* ctx, int runs, int nlive, int queue_size, double dlogz
     x.ncall = (long long)sv[6];
     x.mode = MODE_CUBE;  // the queue's ncalls come from q_ncalls; no sampler tuning
     x.scale = 1.0;
+    if (plateau) {  // plateau mode carried from the previous call (sampler.py:1112-1127)
+      x.pcount = (int)plateau[(size_t)r * 2];
+      x.plogdvol = plateau[(size_t)r * 2 + 1];
+    }
   }
   a.st = arena_up(ctx, st.data(), (size_t)R);
   a.live_logl = arena_up(ctx, live_logl, (size_t)R * N);
@@ -1057,6 +1231,10 @@ int dh_ns_consume(dh_ctx* ctx, int runs, int nlive, int queue_size, double dlogz
     sv[5] = (double)x.it;
     sv[6] = (double)x.ncall;
     sv[7] = x.loglstar;  // the current worst live point
+    if (plateau) {
+      plateau[(size_t)r * 2] = (double)x.pcount;
+      plateau[(size_t)r * 2 + 1] = x.plogdvol;
+    }
     ndead[r] = tn[(size_t)r * 2];
     stopped[r] = tn[(size_t)r * 2 + 1];
   }
@@ -1133,7 +1311,7 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
                o_rl = take((size_t)R * K * 8), o_ra = take((size_t)R * K * 4), o_rb = take((size_t)R * K * 4),
                o_rc = take((size_t)R * K * 4), o_rd = take((size_t)R * K * 4), o_dbl = take((size_t)R * 4),
                o_pl = take((size_t)R * 8), o_ps = take((size_t)R * 8), o_pm = take((size_t)R * 4),
-               o_rm = take((size_t)R * 4), o_nd = take(64), o_ne = take((size_t)R * 4),
+               o_rm = take((size_t)R * 4), o_fo = take((size_t)R * 4), o_nd = take(64), o_ne = take((size_t)R * 4),
                o_bs = take((size_t)R * 4), o_bc = take((size_t)R * me * D * 8), o_bv = take((size_t)R * me * dd * 8),
                o_ba = take((size_t)R * me * dd * 8), o_bx = take((size_t)R * me * dd * 8),
                o_bl = take((size_t)R * me * D * 8), o_bg = take((size_t)R * me * 8),
@@ -1171,6 +1349,7 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
   a.run_scale = (double*)(base + o_ps);
   a.run_mode = (int*)(base + o_pm);
   a.rebuild_mask = (int*)(base + o_rm);
+  a.force = (int*)(base + o_fo);
   a.ndone = (int*)(base + o_nd);
   a.nells = (int*)(base + o_ne);
   a.bstatus = (int*)(base + o_bs);
@@ -1193,6 +1372,7 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
   if (want_pt && !hip_ok(ctx, hipMemsetAsync(base + o_lit, 0, (size_t)R * N * 4, s), "memset")) return cleanup(DH_ERR_HIP);
   if (!hip_ok(ctx, hipMemsetAsync(base + o_nd, 0, 64, s), "memset") ||
       !hip_ok(ctx, hipMemsetAsync(base + o_bs, 0, (size_t)R * 4, s), "memset") ||
+      !hip_ok(ctx, hipMemsetAsync(base + o_fo, 0, (size_t)R * 4, s), "memset") ||
       !hip_ok(ctx, hipMemsetAsync(base + o_ne, 0, (size_t)R * 4, s), "memset") ||
       !hip_ok(ctx, hipMemcpyAsync(d_ent, entropy_words, (size_t)n_words * 4, hipMemcpyHostToDevice, s), "H2D"))
     return cleanup(DH_ERR_HIP);
@@ -1219,6 +1399,7 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
   int ndone = 0;
   int h_state[2] = {0, 1};  // [runs done, any run still in the unit-cube phase]
   bool cube_phase = true;
+  const bool force_check = !(getenv("DH_NS_FORCE") && atoi(getenv("DH_NS_FORCE")) == 0);  // diagnostic: 0 = no forced rebuilds
   while (fill < fills_cap && ndone < R) {
     for (int burst = 0; burst < 8 && fill < fills_cap; ++burst, ++fill) {
       hipLaunchKernelGGL(ns_prepare, dim3(1), dim3(kT), 0, s, a);
@@ -1230,6 +1411,15 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
       if (rc) return cleanup(rc);
       hipLaunchKernelGGL(ns_select, dim3(R), dim3(kT), 0, s, a);
       hipLaunchKernelGGL(ns_gather, dim3((unsigned)(((size_t)R * K * D + 255) / 256)), dim3(256), 0, s, a);
+      // Sampler.propose_live rebuilds the bound at once when a start point lies outside it (sampler.py:484-489:
+      // a point accepted since the last update, beyond the enlarged ellipsoids).  Here the run is flagged and
+      // rebuilds before its NEXT fill: the walkers of this fill are already chosen, and a queue of K proposals
+      // is as stale in the reference.  (Register-resident dimensions.)
+      if (force_check) {
+        rc = contains_runs_launch(ctx, a.q_u0, R * K, D, K, a.b_ctrs, a.b_ams, bound_multi ? a.nells : nullptr, me,
+                                  bound_multi ? 1 : 0, a.run_mode, MODE_BOUND, a.bstatus, a.force);
+        if (rc) return cleanup(rc);
+      }
       // Philox keys: seed from the entropy words (one per stage, so that the stages' offset schemes cannot
       // meet), subsequence = global walker slot (first_run + run) * K + w (independent of the sharding)
       dh::PhiloxKey key;
@@ -1310,8 +1500,8 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
     long long h[16];
     (void)hipStreamSynchronize(s);
     (void)hipMemcpy(h, a.prof, sizeof h, hipMemcpyDeviceToHost);
-    fprintf(stderr, "ns_consume cycles (run 0, %lld fills): load+sort %lld | walk %lld | scan %lld | replay+state %lld | dead %lld | live store %lld\n",
-            (long long)fill, h[0], h[1], h[2], h[3], h[4], h[5]);
+    fprintf(stderr, "ns_consume cycles (run 0, %lld fills): load+sort %lld | walk %lld | scan %lld | replay+state %lld | dead %lld | live store %lld ; fills integrated serially (all runs): %lld new plateau + %lld carried\n",
+            (long long)fill, h[0], h[1], h[2], h[3], h[4], h[5], h[8], h[9]);
     (void)hipFree(a.prof);
   }
   return cleanup(DH_OK);

@@ -62,6 +62,49 @@ def _integrate_full(logl, logvol):
     return logwt, logz, saved_h, logzvar
 
 
+def static_run_logvol(dead_logl, dead_it, live_logl_sorted, live_it_sorted, nlive):
+    """ln X of every point of a static run -- dead points in death order, then the final live points
+    lowest first -- as the reference's run loop assigns them: ln((N + 1) / N) per iteration
+    (sampler.py:1121-1129), except inside a likelihood PLATEAU: when the worst live point shares its
+    log-likelihood with others (rwalk hands back its start point if no step was accepted) the next
+    `multiplicity` deaths take the constant VOLUME step X / (N + 1) instead (sampler.py:1112-1127,
+    1190-1193), and a plateau still open at the end passes its step to the first final points
+    (sampler.py:813-830).  Which points were alive at a death follows from the per-point 'it' (iteration at
+    which a point was proposed; 0 = initial): alive at death e (0-based) = born at it <= e, not yet dead.
+    Returns (dead_logvol, live_logvol)."""
+    dead_logl = np.asarray(dead_logl, dtype=np.float64)
+    live = np.asarray(live_logl_sorted, dtype=np.float64)
+    n, N = len(dead_logl), int(nlive)
+    dlv = math.log((N + 1.) / N)
+    all_l = np.concatenate([dead_logl, live])
+    if len(np.unique(all_l)) == len(all_l):  # no equal values anywhere: no plateau can open
+        dead_lv = -dlv * np.arange(1, n + 1)
+        return dead_lv, (dead_lv[-1] if n else 0.) + np.log(1. - (np.arange(N) + 1.) / (N + 1.))
+    born = np.concatenate([np.asarray(dead_it, dtype=np.int64), np.asarray(live_it_sorted, dtype=np.int64)])
+    death = np.concatenate([np.arange(n), np.full(N, n + N)])  # final points: after every death
+    vals, counts = np.unique(all_l, return_counts=True)
+    dup = set(vals[counts > 1].tolist())
+    dead_lv = np.empty(n)
+    logvol, pc, plog = 0., 0, 0.
+    for e in range(n):
+        x = dead_logl[e]
+        if pc == 0 and x in dup:
+            mult = int(((all_l == x) & (born <= e) & (death >= e)).sum())
+            if mult > 1:
+                pc, plog = mult, math.log(1. / (N + 1.)) + logvol
+        logvol -= -math.log1p(-math.exp(plog - logvol)) if pc else dlv
+        dead_lv[e] = logvol
+        if pc:
+            pc -= 1
+    if pc == 0:
+        rel = np.log(1. - (np.arange(N) + 1.) / (N + 1.))
+    else:
+        rel = np.log1p(-((1 + np.arange(pc)) * math.exp(plog - logvol)))
+        nrest = N - pc
+        rel = np.concatenate([rel, rel[-1] + np.log1p(-(1 + np.arange(nrest)) / (nrest + 1.))])
+    return dead_lv, logvol + rel
+
+
 def _integrate(logl, logvol):
     """ln weights, cumulative ln Z, final information and final var[ln Z]."""
     logwt, logz, h, logzvar = _integrate_full(logl, logvol)
@@ -199,6 +242,7 @@ def run_static(prob, nlive=500, bound='multi', sample='rwalk', queue_size=None,
     live_it = live_it2[0]
     # logvol, logz, h, logzvar, loglstar of the last dead point, it, ncall, [out] current worst logl
     state = np.array([[0., -1.e300, 0., 0., -1.e300, 0., float(nlive), 0.]])
+    plateau = np.zeros((1, 2))  # the reference's plateau mode, carried from chunk to chunk
     loglstar = float(live_logl.min())
     while not done:
         it, ncall = int(state[0, 5]), int(state[0, 6])
@@ -223,7 +267,7 @@ def run_static(prob, nlive=500, bound='multi', sample='rwalk', queue_size=None,
             if maxiter is not None:
                 n = min(n, maxiter - int(state[0, 5]))
             res = be.ns_consume(live_l2, q_logl[None, pos:pos + n], q_nc[None, pos:pos + n], state, dlogz,
-                                live_it=live_it2)
+                                live_it=live_it2, plateau=plateau)
             slots, srcs = res["dead_slot"][0].astype(np.int64), res["dead_src"][0].astype(np.int64) + pos
             ndead = len(slots)
             if ndead:
@@ -257,15 +301,13 @@ def run_static(prob, nlive=500, bound='multi', sample='rwalk', queue_size=None,
             print(f"it={int(state[0, 5])} ncall={int(state[0, 6])} logz~{state[0, 1]:.3f} nbound={nbound} "
                   f"scale={scale:.3f}")
     it, ncall = int(state[0, 5]), int(state[0, 6])
-    logvol = -it * dlv
     dead_u = np.concatenate(dead_u) if dead_u else np.zeros((0, nd))
     dead_logl = np.concatenate(dead_logl) if dead_logl else np.zeros(0)
-    dead_logvol = -dlv * np.arange(1, it + 1)
     dead_id, dead_it, dead_nc = (np.concatenate(x) if x else np.zeros(0, dtype=np.int64)
                                  for x in (dead_id, dead_it, dead_nc))
     # ---- add the remaining live points (sampler.py:780-930) ----
     order = np.argsort(live_logl)
-    lv_live = logvol + np.log(1. - (np.arange(nlive) + 1.) / (nlive + 1.))
+    dead_logvol, lv_live = static_run_logvol(dead_logl, dead_it, live_logl[order], live_it[order], nlive)
     all_logl = np.concatenate([dead_logl, live_logl[order]])
     all_logvol = np.concatenate([dead_logvol, lv_live])
     all_u = np.concatenate([dead_u.reshape(-1, nd), live_u[order]])

@@ -359,7 +359,7 @@ int dh_bound_draw(dh_ctx* ctx, const uint64_t* state4, int nsamp, int d, int m,
  * Sampler.sample over ONE queue fill (sampler.py:1070-1185) with _new_point's queue rule
  * (sampler.py:741-776): while the dlogz criterion has not fired, the worst live point dies and is replaced
  * by the next queue entry whose logl beats it (entries that do not are discarded, their calls still
- * charged); every death takes the volume step ln((N+1)/N) and one step of progress_integration
+ * charged); every death takes the volume step ln((N+1)/N) (inside a likelihood plateau: the plateau's step) and one step of progress_integration
  * (utils.py:1470-1492).  This is the `ns_consume` stage of dh_ns_ensemble as an operator of its own
  * (used to hold it to the oracle's restatement of the reference loop; a host-driven loop can use it too).
  *   live_logl  runs x nlive   in/out, slot order
@@ -374,12 +374,16 @@ int dh_bound_draw(dh_ctx* ctx, const uint64_t* state4, int nsamp, int d, int m,
  *                             reference counts iterations from 1); dead_it runs x K = that value for every
  *                             dead point ('it'); dead_nc runs x K = likelihood calls spent on its replacement
  *                             ('nc': every queue entry popped since the previous death); dead_slot is 'id'.
- * Equal log-likelihoods die lowest slot first, as in the reference (np.argmin, sampler.py:1107).  Deviation
- * documented in DESIGN.md: the plateau volume steps (sampler.py:1110-1127) are not taken. */
+ *   plateau    optional, runs x 2 in/out: the likelihood-plateau mode of the reference (sampler.py:1112-1127,
+ *                             1190-1193) carried between calls -- deaths still to be taken with the plateau's
+ *                             constant volume step (0 = off) and the logarithm of that step's volume; NULL:
+ *                             the call starts outside plateau mode and the state is not handed back
+ * Equal log-likelihoods die lowest slot first, as in the reference (np.argmin, sampler.py:1107), and when the
+ * worst point shares its value with others the deaths take the reference's plateau volume steps. */
 int dh_ns_consume(dh_ctx* ctx, int runs, int nlive, int queue_size, double dlogz, double* live_logl,
                   const double* q_logl, const int32_t* q_ncalls, double* state, double* dead_logl,
                   int32_t* dead_slot, int32_t* dead_src, int32_t* ndead, int32_t* stopped, int32_t* live_it,
-                  int32_t* dead_it, int32_t* dead_nc);
+                  int32_t* dead_it, int32_t* dead_nc, double* plateau);
 
 /* ---- device-resident ensemble of static nested-sampling runs (BASELINE config
  * C5): the loop of Sampler.sample (sampler.py:932-1212) with a

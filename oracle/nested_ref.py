@@ -208,3 +208,49 @@ def final_results(dead_logl, live_logl, nlive):
     logl = np.concatenate([np.asarray(dead_logl, dtype=np.float64), np.sort(np.asarray(live_logl))])
     _, logz, logzvar, h = compute_integrals(logl, static_run_logvol(len(dead_logl), nlive))
     return float(logz[-1]), float(math.sqrt(logzvar[-1])), float(h[-1])
+
+
+def logvol_from_record(dead_logl, dead_id, live_logl, nlive):
+    """ln X of every point of a FINISHED static run, replayed from its record -- dead points in death order with
+    the slot ('id') each lived in, and the final live points by slot -- with the reference loop's volume
+    bookkeeping: the worst point dies, nplateau = number of live points sharing its log-likelihood opens the
+    plateau mode (sampler.py:1112-1119), the step is ln((N + 1) / N) or the plateau's (sampler.py:1121-1129),
+    the counter runs down (sampler.py:1190-1193); then the final live points as add_live_points assigns them
+    (sampler.py:813-830).  Returns the volumes of dead points followed by the final live points in ascending
+    log-likelihood.  (Independent of dynesty_amd.nested.static_run_logvol, which works from the 'it' column.)"""
+    dead_logl = np.asarray(dead_logl, dtype=np.float64)
+    dead_id = np.asarray(dead_id, dtype=np.int64)
+    final = np.asarray(live_logl, dtype=np.float64)
+    n, N = len(dead_logl), int(nlive)
+    # what enters a slot when its occupant dies: the next point to die there, or the final occupant
+    repl = np.empty(n)
+    nxt = final.copy()
+    for e in range(n - 1, -1, -1):
+        repl[e] = nxt[dead_id[e]]
+        nxt[dead_id[e]] = dead_logl[e]
+    cur = nxt  # the live set before the first death, by slot
+    s = RunState(N)
+    out = np.empty(n)
+    for e in range(n):
+        worst = int(np.argmin(cur))
+        assert cur[worst] == dead_logl[e] and cur[dead_id[e]] == dead_logl[e]
+        if not s.plateau_mode:
+            nplateau = int((cur == cur[worst]).sum())
+            if nplateau > 1:
+                s.plateau_mode, s.plateau_counter = True, nplateau
+                s.plateau_logdvol = np.log(1. / (N + 1)) + s.logvol
+        cur_dlv = s.dlv if not s.plateau_mode else -np.log1p(-np.exp(s.plateau_logdvol - s.logvol))
+        s.logvol -= cur_dlv
+        out[e] = s.logvol
+        cur[dead_id[e]] = repl[e]
+        if s.plateau_mode:
+            s.plateau_counter -= 1
+            if s.plateau_counter == 0:
+                s.plateau_mode = False
+    if not s.plateau_mode:
+        rel = np.log(1. - (np.arange(N) + 1.) / (N + 1.))
+    else:
+        rel = np.log1p(-((1 + np.arange(s.plateau_counter)) * np.exp(s.plateau_logdvol - s.logvol)))
+        nrest = N - s.plateau_counter
+        rel = np.concatenate([rel, rel[-1] + np.log1p(-(1 + np.arange(nrest)) / (nrest + 1))])
+    return np.concatenate([out, rel + s.logvol])

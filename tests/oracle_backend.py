@@ -73,9 +73,9 @@ class OracleBackend:
             out[i] = _words(np.random.Generator(np.random.PCG64(c)))
         return out
 
-    def ns_consume(self, live_logl, q_logl, q_ncalls, state, dlogz, live_it=None):
-        """dh_ns_consume through the oracle's restatement of the reference loop (no plateau steps, as on
-        the device)."""
+    def ns_consume(self, live_logl, q_logl, q_ncalls, state, dlogz, live_it=None, plateau=None):
+        """dh_ns_consume through the oracle's restatement of the reference loop (plateau steps included;
+        `plateau` carries the mode between calls as on the device)."""
         from oracle import nested_ref as R
         out = dict(dead_logl=[], dead_slot=[], dead_src=[], dead_it=[], dead_nc=[], stopped=[])
         for r in range(live_logl.shape[0]):
@@ -83,8 +83,12 @@ class OracleBackend:
             s.logvol, s.logz, s.h, s.logzvar, s.loglstar = (float(x) for x in state[r, :5])
             s.it, s.ncall = int(state[r, 5]), int(state[r, 6])
             it = None if live_it is None else live_it[r].astype(np.int64)
+            if plateau is not None and plateau[r, 0] > 0:
+                s.plateau_mode, s.plateau_counter, s.plateau_logdvol = True, int(plateau[r, 0]), float(plateau[r, 1])
             res = R.consume_queue(live_logl[r], np.asarray(q_logl)[r], np.asarray(q_ncalls)[r], s, dlogz,
-                                  plateau=False, live_it=it)
+                                  plateau=True, live_it=it)
+            if plateau is not None:
+                plateau[r] = [s.plateau_counter if s.plateau_mode else 0, s.plateau_logdvol]
             if live_it is not None:
                 live_it[r] = it
             state[r, :7] = [s.logvol, s.logz, s.h, s.logzvar, s.loglstar, s.it, s.ncall]

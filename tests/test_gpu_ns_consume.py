@@ -75,6 +75,7 @@ def test_fill_chains_vs_oracle(ctx, nlive, K, runs):
     ref_it = np.zeros((runs, nlive), dtype=np.int64)
     dlogz = 0.5
     done = np.zeros(runs, bool)
+    plat = np.zeros((runs, 2))
     nfill = 0
     while not done.all() and nfill < 400:
         nfill += 1
@@ -89,13 +90,13 @@ def test_fill_chains_vs_oracle(ctx, nlive, K, runs):
         act = ~done
         if not act.all():  # finished runs leave the ensemble (as MODE_DONE runs do on the device)
             live_a, state_a = np.ascontiguousarray(live[act]), np.ascontiguousarray(state[act])
-            it_a = np.ascontiguousarray(live_it[act])
+            it_a, plat_a = np.ascontiguousarray(live_it[act]), np.ascontiguousarray(plat[act])
         else:
-            live_a, state_a, it_a = live, state, live_it
-        out = ctx.ns_consume(live_a, ql[act], qn[act], state_a, dlogz, live_it=it_a)
-        live[act], state[act], live_it[act] = live_a, state_a, it_a
+            live_a, state_a, it_a, plat_a = live, state, live_it, plat
+        out = ctx.ns_consume(live_a, ql[act], qn[act], state_a, dlogz, live_it=it_a, plateau=plat_a)
+        live[act], state[act], live_it[act], plat[act] = live_a, state_a, it_a, plat_a
         for i, r in enumerate(np.flatnonzero(act)):
-            ref = R.consume_queue(ref_live[r], ql[r], qn[r], states[r], dlogz, plateau=False, live_it=ref_it[r])
+            ref = R.consume_queue(ref_live[r], ql[r], qn[r], states[r], dlogz, plateau=True, live_it=ref_it[r])
             np.testing.assert_array_equal(out["dead_it"][i], ref["dead_it"])
             np.testing.assert_array_equal(out["dead_nc"][i], ref["dead_nc"])
             np.testing.assert_array_equal(live_it[r], ref_it[r])
@@ -146,10 +147,38 @@ def test_whole_run_results_are_compute_integrals(ctx):
         assert np.logaddexp(0, lmax + s.logvol - s.logz) < 0.05
 
 
-def test_ties_die_lowest_slot_first_like_the_reference(ctx):
+def test_whole_run_with_plateaus_is_compute_integrals(ctx):
+    """rwalk with two steps per proposal hands back its start point about a quarter of the time: duplicates among
+    the live points, i.e. likelihood plateaus all along the run.  The device-resident loop's record must then equal
+    the reference's final recomputation over the run's points WITH the plateau volume steps (oracle replay of the
+    bookkeeping from the run's own record: dead points + slots, final live points)."""
+    prob = inputs.problem("G5")
+    r = ctx.ns_ensemble(prob, 4, 300, 64, walks=2, bound="multi", entropy=[41], dlogz=0.05, max_iter=40000,
+                        want_samples=True)
+    assert np.all(r["status"] == 0)
+    for i in range(4):
+        n = int(r["niter"][i])
+        dead, ids = r["dead_logl"][i, :n], r["dead_id"][i, :n]
+        assert len(np.unique(np.concatenate([dead, r["live_logl"][i]]))) < n  # duplicates: the run met plateaus
+        lv = R.logvol_from_record(dead, ids, r["live_logl"][i], 300)
+        assert np.abs(lv[:n] - R.static_run_logvol(n, 300)[:n]).max() > 1e-5  # and its volumes left the ladder
+        logl = np.concatenate([dead, np.sort(r["live_logl"][i])])
+        _, logz, logzvar, h = R.compute_integrals(logl, lv)
+        np.testing.assert_allclose(r["logz"][i], logz[-1], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(r["logzerr"][i], np.sqrt(logzvar[-1]), rtol=1e-7)
+        np.testing.assert_allclose(r["h"][i], h[-1], rtol=1e-9)
+        # the plain ladder would NOT have given this ln Z
+        lz2, _, _ = R.final_results(dead, r["live_logl"][i], 300)
+        assert abs(lz2 - r["logz"][i]) > 1e-8
+
+
+def test_ties_die_lowest_slot_first_and_take_the_plateau_steps(ctx):
     """Equal log-likelihoods among the live points (rwalk hands back its start point when no step was accepted) die
     lowest slot first -- np.argmin's rule in the reference (sampler.py:1107) -- also when the tie is between an original
-    live point and a replacement made earlier in the same fill.  Values drawn from a small set force many ties."""
+    live point and a replacement made earlier in the same fill, and their deaths take the reference's PLATEAU volume
+    steps (sampler.py:1112-1127, 1190-1193: a constant volume step X / (N + 1) per death while the plateau lasts)
+    instead of ln((N + 1) / N).  Values drawn from a small set force many plateaus, also across fill boundaries; the
+    oracle runs with plateau=True (the restatement that is bit-identical to the recorded real run)."""
     rng = np.random.default_rng(3)
     nlive, K, runs = 300, 200, 4
     vals = -np.sort(rng.random(40) * 20)  # 40 distinct levels
@@ -157,15 +186,17 @@ def test_ties_die_lowest_slot_first_like_the_reference(ctx):
     ref_live = live.copy()
     states = [R.RunState(nlive) for _ in range(runs)]
     state = pack(states)
+    plat = np.zeros((runs, 2))
     live_it = np.zeros((runs, nlive), dtype=np.int32)
     ref_it = np.zeros((runs, nlive), dtype=np.int64)
+    nplateau_fills = 0
     for fill in range(6):
         ql = vals[rng.integers(0, 40, size=(runs, K))] + (fill * 0.0)
         ql[:, ::3] += 0.5  # some entries off the grid
         qn = rng.integers(1, 9, size=(runs, K)).astype(np.int32)
-        out = ctx.ns_consume(live, ql, qn, state, None if False else 1e-300, live_it=live_it)
+        out = ctx.ns_consume(live, ql, qn, state, None if False else 1e-300, live_it=live_it, plateau=plat)
         for r in range(runs):
-            ref = R.consume_queue(ref_live[r], ql[r], qn[r], states[r], 1e-300, plateau=False, live_it=ref_it[r])
+            ref = R.consume_queue(ref_live[r], ql[r], qn[r], states[r], 1e-300, plateau=True, live_it=ref_it[r])
             np.testing.assert_array_equal(out["dead_logl"][r], ref["dead_logl"])
             np.testing.assert_array_equal(out["dead_slot"][r], ref["dead_slot"])
             np.testing.assert_array_equal(out["dead_src"][r], ref["dead_src"])
@@ -174,3 +205,48 @@ def test_ties_die_lowest_slot_first_like_the_reference(ctx):
             np.testing.assert_array_equal(live[r], ref_live[r])
             np.testing.assert_array_equal(live_it[r], ref_it[r])
             assert state[r, 7] == ref_live[r].min()
+            sr = states[r]
+            # the volume really left the ln((N + 1) / N) ladder
+            assert abs(sr.logvol + sr.it * sr.dlv) > 1e-6
+            np.testing.assert_allclose(state[r, 0], sr.logvol, rtol=1e-12)
+            np.testing.assert_allclose(state[r, 1], sr.logz, rtol=0, atol=1e-10)
+            np.testing.assert_allclose(state[r, 2], sr.h, rtol=1e-9, atol=1e-12)
+            np.testing.assert_allclose(state[r, 3], sr.logzvar, rtol=1e-8, atol=1e-14)
+            assert int(plat[r, 0]) == (sr.plateau_counter if sr.plateau_mode else 0)
+            if sr.plateau_mode:
+                nplateau_fills += 1
+                np.testing.assert_allclose(plat[r, 1], sr.plateau_logdvol, rtol=1e-12)
+    assert nplateau_fills > 0  # plateaus were carried across fill boundaries
+
+
+def test_replay_of_the_whole_real_run_with_its_plateaus(ctx):
+    """Every queue fill the REAL reference run recorded (tests/golden/nsloop.npz), chained through dh_ns_consume with the
+    plateau mode carried from fill to fill: the same dead points in the same slots, and after every fill the run's own
+    recorded ln X (plateau steps included: the run meets its first plateau at iteration `first_plateau_it`) and ln Z
+    (the information and var[ln Z] of the recurrence are held to the oracle in the test above; the run's own record
+    of them is the final recomputation, normalised differently)."""
+    g = np.load(G)
+    nlive, nf, niter = int(g["nlive"]), int(g["nfills"]), int(g["niter"])
+    assert int(g["run/first_plateau_it"]) < niter  # the recorded run does contain plateaus
+    live = g["fills/live_logl0"][None, :].copy()
+    state = pack([R.RunState(nlive)])
+    plat = np.zeros((1, 2))
+    live_it = np.zeros((1, nlive), dtype=np.int32)
+    dead, ids, its = [], [], []
+    for f in range(nf):
+        out = ctx.ns_consume(live, g["fills/q_logl"][f][None], g["fills/q_ncalls"][f][None], state, float(g["dlogz"]),
+                             live_it=live_it, plateau=plat)
+        dead.append(out["dead_logl"][0])
+        ids.append(out["dead_slot"][0])
+        its.append(out["dead_it"][0])
+        assert bool(out["stopped"][0]) == (f == nf - 1)
+        it = int(state[0, 5])
+        if it:
+            np.testing.assert_allclose(state[0, 0], g["run/logvol"][it - 1], rtol=1e-12)
+            np.testing.assert_allclose(state[0, 1], g["run/logz"][it - 1], rtol=0, atol=1e-10)
+    np.testing.assert_array_equal(np.concatenate(dead), g["run/logl"][:niter])
+    np.testing.assert_array_equal(np.concatenate(ids), g["run/id"][:niter])
+    np.testing.assert_array_equal(np.concatenate(its), g["run/it"][:niter])
+    # the volumes did leave the constant ladder
+    dlv = np.log((nlive + 1.0) / nlive)
+    assert abs(state[0, 0] + niter * dlv) > 1e-7

@@ -118,3 +118,33 @@ def test_integrate_full_is_compute_integrals(g):
     np.testing.assert_allclose(logz, g["run/logz"], rtol=0, atol=1e-11)
     np.testing.assert_allclose(h, g["run/h"], rtol=1e-9, atol=1e-12)
     np.testing.assert_allclose(logzvar, g["run/logzvar"], rtol=1e-8, atol=1e-14)
+
+
+def test_static_run_logvol_reproduces_the_plateau_steps_of_the_real_run(g):
+    """dynesty_amd.nested.static_run_logvol (the host driver's ln X of every point: the constant ladder, the
+    reference's plateau steps where live points share a log-likelihood, sampler.py:1112-1127 / 813-830) from the
+    run's own per-point record (logl, it) against the real run's recorded volumes -- dead and final live points."""
+    from dynesty_amd import nested
+    niter, nlive = int(g["niter"]), int(g["nlive"])
+    logl, it = g["run/logl"], g["run/it"]
+    dead_lv, live_lv = nested.static_run_logvol(logl[:niter], it[:niter], logl[niter:], it[niter:], nlive)
+    np.testing.assert_allclose(dead_lv, g["run/logvol"][:niter], rtol=1e-13, atol=0)
+    np.testing.assert_allclose(live_lv, g["run/logvol"][niter:], rtol=1e-13, atol=0)
+    first = int(g["run/first_plateau_it"])
+    dlv = np.log((nlive + 1.0) / nlive)
+    assert np.abs(dead_lv[:first] + dlv * np.arange(1, first + 1)).max() < 1e-12
+    assert abs(dead_lv[-1] + niter * dlv) > 1e-6  # the plateau steps are really there
+    # and with them the product's integration gives the run's final record
+    _, logz, h, logzvar = nested._integrate_full(logl, np.concatenate([dead_lv, live_lv]))
+    np.testing.assert_allclose(logz[-1], float(g["run/logz_final"]), rtol=0, atol=1e-11)
+    np.testing.assert_allclose(np.sqrt(logzvar[-1]), float(g["run/logzerr_final"]), rtol=1e-9)
+
+
+def test_logvol_from_record_is_the_real_runs(g):
+    """The oracle's replay of the volume bookkeeping from a finished run's record (used to check whole device
+    runs that contain plateaus) against the real run's recorded volumes."""
+    niter, nlive = int(g["niter"]), int(g["nlive"])
+    final = np.empty(nlive)
+    final[g["run/id"][niter:]] = g["run/logl"][niter:]
+    lv = R.logvol_from_record(g["run/logl"][:niter], g["run/id"][:niter], final, nlive)
+    np.testing.assert_array_equal(lv, g["run/logvol"])
