@@ -107,11 +107,13 @@ struct RebuildArgs {
   // persistent work-queue form of the tree (k_tree): no levels -- a node's split is queued when its
   // ellipsoid exists, its children's ellipsoids when its last part has finished the partition
   int tree;           // 1: queue_split / split_body / ell_body feed the queue instead of the level lists
+  int tree_from;      // level pipeline: splits for levels >= tree_from are queued for the k_tree tail instead
   unsigned long long* tq_items;  // tq_cap work items, 0 = not published yet
   int* tq_ctl;        // [0] head (next ticket), [16] tail (next free slot), [32] items queued or in flight, [48] error
   int tq_cap;
   int* nbar;          // runs x max_nodes x kBarStride: per node [0] part barrier, [1] parts done, [2] first k-means partial slot
-  int* kp_top;        // runs: partial-sum slots handed out (multi-part nodes only; capacity maxp per run)
+  int* kp_top;        // runs: partial-sum slots handed out by the queue form (multi-part nodes only; capacity kp_cap per run)
+  int kp_cap;
   int tq_sleep, tq_nocoh;  // diagnostics (DH_TREE_SLEEP, DH_TREE_NOCOH)
 };
 
@@ -1344,7 +1346,7 @@ __device__ int node_kmeans_part(const Lds& L, const double* pts, int* perm, int*
     if (t < 2 * D) {
       const int c = t >= D ? 1 : 0, j = t - c * D;
       // (grouped like the parts of the level kernels when one 256-point tile stands in for two 128-point
-      // parts -- k_deep -- so that a node's sums do not depend on which kernel worked on it)
+      // parts -- L.KG < 4 -- so that a node's sums do not depend on the tile that held it)
       double sum = 0.0;
       for (int g0 = 0; g0 < kThreads / 64; g0 += L.KG) {
         double gs = 0.0;
@@ -1631,13 +1633,13 @@ __device__ __forceinline__ bool tq_push(const RebuildArgs& a, bool split, int ru
 }
 
 __device__ __forceinline__ void queue_split(const RebuildArgs& a, int run, int level, int node, int count) {
-  if (a.tree) {
+  if (a.tree || level >= a.tree_from) {
     const int np = (count + a.tps - 1) / a.tps;
     int* nb = a.nbar + ((size_t)run * a.max_nodes + node) * kBarStride;
     int pb = 0;
     if (np > 1) {  // only multi-part nodes exchange partial sums
       pb = atomicAdd(&a.kp_top[run], np);
-      if (pb + np > a.maxp) {
+      if (pb + np > a.kp_cap) {
         atomicMin(&a.status[run], DH_ERR_NOMEM);
         return;
       }
@@ -1929,7 +1931,7 @@ __global__ void __launch_bounds__(kThreads) k_root_parts(RebuildArgs a, int rp) 
 }
 
 // One part of one splittable node: k-means + partition (node_kmeans_part), and by part 0 the two child records and
-// their means.  single = true (k_deep): the calling workgroup is the node's only part whatever its size -- the node
+// their means.  single = true: the calling workgroup is the node's only part whatever its size -- the node
 // must fit the tile (count <= L.TP).
 __device__ __forceinline__ void split_body(const RebuildArgs& a, const Lds& L, const RunView& v, int run, int level, int slot, int q,
                            bool single) {
@@ -2080,7 +2082,7 @@ __device__ __forceinline__ bool ell_body(const RebuildArgs& a, const Lds& L, con
     v.nodes[node].fmax = fmx;
     v.nodes[node].fast = full ? 0 : 1;
     if (count >= 4 * D) {  // big enough to try a split at the next level (:1492-1496)
-      if (!a.tree && level + 1 >= a.levels) {
+      if (!a.tree && a.tree_from > a.levels && level + 1 >= a.levels) {
         atomicMin(&a.status[run], DH_ERR_NOMEM);  // deeper than the launch plan
       } else {
         queue_split(a, run, level + 1, node, count);
@@ -2113,60 +2115,6 @@ __global__ void __launch_bounds__(kThreads, SLOW ? 1 : 2) k_ell(RebuildArgs a, i
   const RunView v = view_of(a, run, L.LD);
   for (int slot = g; slot < cnt; slot += G)
     if (!ell_body<SLOW>(a, L, v, run, level, list[slot])) return;
-}
-
-// ---- the deep tail of the tree: one workgroup per run, every remaining level ------------------------------
-// The level kernels are launched for the first `first_level` levels (a balanced tree's depth plus two); a tree
-// that is deeper -- unbalanced splits -- is rare, but the launch plan cannot know, and an idle pair of level
-// launches costs 9 us (round 2 measured 14 idle pairs of 20 on the bench shard: 0.13 ms of a 1.6 ms rebuild).
-// This kernel takes whatever the last launched level has queued and works the rest of the run's tree off
-// serially, level by level, with the same node routines (a node = one part: it must fit the 256-point tile,
-// else the run fails loudly as a too-deep tree did before).  In the common case it finds an empty list and exits.
-__global__ void __launch_bounds__(kThreads) k_deep(RebuildArgs a, int first_level) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int run = blockIdx.x, t = threadIdx.x, D = a.d;
-  if (a.nsplit[(size_t)first_level * a.runs + run] == 0) return;
-  __shared__ int go;
-  Lds L;
-  carve(L, smem, D);
-  L.KG = a.tps >= 64 && a.tps <= kThreads ? a.tps / 64 : kThreads / 64;
-  const RunView v = view_of(a, run, L.LD);
-  for (int level = first_level; level < a.levels; ++level) {
-    // (same-workgroup producer / consumer through global memory: ordered by the barriers)
-    __syncthreads();
-    if (t == 0) {
-      int ok = a.status[run] == DH_OK ? a.nsplit[(size_t)level * a.runs + run] : 0;
-      if (ok > a.maxw) ok = 0;  // queue_split has raised DH_ERR_NOMEM
-      go = ok;
-    }
-    __syncthreads();
-    const int ns = go;
-    if (ns == 0) return;
-    const size_t lp = (size_t)(level & 1) * a.runs + run;
-    for (int slot = 0; slot < ns; ++slot) {
-      __syncthreads();
-      const int cur = a.split_list[lp * a.maxw + slot];
-      if (v.nodes[cur].count > L.TP) {
-        if (t == 0) atomicMin(&a.status[run], DH_ERR_NOMEM);  // a big node this deep: beyond the launch plan
-        return;
-      }
-      if (t < D) L.scale[t] = a.scale_g[(size_t)run * D + t];
-      L.c_pts = nullptr;
-      __syncthreads();
-      split_body(a, L, v, run, level, slot, 0, true);
-    }
-    __syncthreads();
-    if (t == 0) go = a.kerr[run] != DH_OK ? -1 : a.nell[(size_t)level * a.runs + run];
-    __syncthreads();
-    const int ne = go;
-    if (ne < 0) {
-      if (t == 0) atomicMin(&a.status[run], a.kerr[run]);
-      return;
-    }
-    const int* list = a.ell_list + (size_t)run * 2 * a.maxw;
-    for (int e = 0; e < ne; ++e)
-      if (!ell_body<false>(a, L, v, run, level, list[e])) return;
-  }
 }
 
 // ---- the whole tree by persistent workers on one work queue -----------------------------------------------
@@ -2254,7 +2202,7 @@ __global__ void __launch_bounds__(kThreads) k_finish(RebuildArgs a) {
   const double* estore = v.estore;
   const int NS = v.NS, DD = D * D;
   int status = min(a.status[run], a.kerr[run]);  // k_split errors of the last level are folded here
-  if (a.tree && a.tq_ctl[48]) status = min(status, (int)DH_ERR_HIP);  // a k_tree worker gave up waiting
+  if (a.tq_ctl && a.tq_ctl[48]) status = min(status, (int)DH_ERR_HIP);  // a k_tree worker gave up waiting
   const int nnodes = min(a.nnodes_dev[run], a.max_nodes);
   // the accept test below is a serial walk over the tree by one thread: every access to a
   // node in global memory is a dependent ~1 us load, so the tree (and, when it fits, the
@@ -2813,7 +2761,7 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
   const size_t b_res = (size_t)runs * a.reslist_cap * 4;
   a.maxw = n / (4 * d) + 1;
   // depth: a balanced tree needs log2(n / 2d) levels; unbalanced splits need more.  The level kernels are launched
-  // for lv + 2 levels, k_deep takes the rest (up to a.levels: a run that is deeper still fails loudly).
+  // for lv + 2 levels, the work-queue form (k_tree) takes whatever is deeper.
   int lv = 4;
   while ((1 << lv) < n / (2 * d) + 1) ++lv;
   a.levels = mode == 1 ? 0 : (2 * lv + 8);
@@ -2827,20 +2775,34 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
   // eigen-free tree nodes (MultiEllipsoid.update only: Ellipsoid.update's single node IS the output)
   a.fast = mode == 0 ? 1 : 0;
   if (const char* e = getenv("DH_REBUILD_FAST")) a.fast = a.fast && atoi(e) != 0;  // diagnostic: 0 = eigh on every node
-  // DH_TREE=1: the tree by persistent workers on a work queue (k_tree) instead of the level pipeline
-  // (k_split / k_ell / k_deep).  Same node routines, bit-identical results (tests/test_gpu_edges.py), no
-  // depth limit -- but measured SLOWER (round 3, 20 launches each): 64 C2 runs 1.44 vs 1.29 ms, 16 runs 1.06
-  // vs 0.95, 16 eggbox runs 2.37 vs 2.15, one eggbox run 1.20 vs 0.99.  With 64 runs the chip is saturated
-  // either way (the time scales with the number of workers: 256 -> 2.18 ms, 384 -> 1.68, 512 -> 1.52), and the
-  // queue form loses the level pipeline's five k_split workgroups per CU (its workers carry the 77 KB layout of
-  // the ellipsoid routine: two per CU), pays agent-scope (cache-bypassing) accesses for everything a node hands
-  // to the next, and leaves the early parts of a multi-part node spinning until the late ones find a worker.
+  // The tree is built by the level pipeline (k_split / k_ell per level) for a balanced tree's depth + 2 levels;
+  // whatever is deeper -- unbalanced splits -- is handed to persistent workers on a work queue (k_tree: the same
+  // node routines, any depth, any node size; in the common case it finds its queue empty and leaves).
+  // DH_TREE=1: the WHOLE tree by the work-queue form.  Bit-identical results (tests/test_gpu_edges.py), but
+  // measured SLOWER (round 3, 20 launches each): 64 C2 runs 1.44 vs 1.29 ms, 16 runs 1.06 vs 0.95, 16 eggbox
+  // runs 2.37 vs 2.15, one eggbox run 1.20 vs 0.99.  With 64 runs the chip is saturated either way (the time
+  // scales with the number of workers: 256 -> 2.18 ms, 384 -> 1.68, 512 -> 1.52), and the queue form loses the
+  // level pipeline's five k_split workgroups per CU (its workers carry the 77 KB layout of the ellipsoid routine:
+  // two per CU), pays agent-scope (cache-bypassing) accesses for everything a node hands to the next, and leaves
+  // the early parts of a multi-part node spinning until the late ones find a worker.
   a.tree = 0;
   if (const char* e = getenv("DH_TREE")) a.tree = a.fast && atoi(e) != 0;
+  // level kernels for a balanced tree's depth plus two, the work-queue tail for the rest (DH_DEEP=0: every level
+  // by level kernels and no tail, as does the diagnostic slow mode; DH_DEEP_FROM=f: the tail takes over at level f)
+  int nlev = a.levels;
+  if (a.fast && !(getenv("DH_DEEP") && atoi(getenv("DH_DEEP")) == 0)) nlev = a.levels < lv + 2 ? a.levels : lv + 2;
+  if (a.fast && getenv("DH_DEEP_FROM")) {
+    const int f = atoi(getenv("DH_DEEP_FROM"));
+    if (f >= 1 && f < a.levels) nlev = f;
+  }
+  if (a.tree) nlev = 0;
+  const bool tail = a.fast && (a.tree || nlev < a.levels);
+  a.tree_from = tail ? nlev : a.levels + 1;
   a.tq_cap = 0;
-  if (a.tree) {
-    // partial-sum slots of the multi-part nodes of a whole tree: a depth has at most n / tps + (nodes) parts
-    a.maxp = a.levels * (n / a.tps + 1) + 8;
+  a.kp_cap = 0;
+  if (tail) {
+    // partial-sum slots of the multi-part nodes the queue form may meet: a depth has at most n / tps + (nodes) parts
+    a.kp_cap = a.levels * (n / a.tps + 1) + 8;
     // items: one ellipsoid per node, and per split node ceil(count / tps) parts
     a.tq_cap = runs * (2 * a.max_nodes + a.levels * (n / a.tps + 1) + 8);
   }
@@ -2892,13 +2854,13 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
       occ_split = 1;
     cap_root = ncu * (occ_root > 0 ? occ_root : 1);
     cap_split = ncu * (occ_split > 0 ? occ_split : 1);
-    if (a.tree) {
+    if (tail) {
       int occ_tree = 0;
       (void)hipFuncSetAttribute((const void*)k_tree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_tree, (const void*)k_tree, kThreads, lds) != hipSuccess)
         occ_tree = 1;
       cap_tree = ncu * (occ_tree > 0 ? occ_tree : 1);
-      cap_split = cap_tree;  // the parts of a node are k_tree workgroups
+      if (cap_tree < cap_split) cap_split = cap_tree;  // the parts of a node may be k_tree workgroups
     }
   }
   int rp = n > 1 ? (n + kThreads - 1) / kThreads : 1;
@@ -2909,14 +2871,15 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
   if (getenv("DH_ROOT_PARTS") && atoi(getenv("DH_ROOT_PARTS")) == 0) rp = 1;  // diagnostic
   // zeroed counters: nnodes | nsplit (levels+1) | nell (levels) | nparts (levels+1) | kerr | rbar | kbar (levels x maxw)
   // ... | kp_top (runs) | tq_ctl (64) | nbar (runs x max_nodes x kBarStride) | tq_items (tq_cap x 2 ints)   [k_tree]
-  const size_t n_cnt_old = (size_t)runs * ((size_t)3 * a.levels + 5 + kBarStride + (a.tree ? 0 : (size_t)a.levels * a.maxw * kBarStride));
-  const size_t n_cnt_tree = a.tree ? (size_t)runs + 64 + (size_t)runs * a.max_nodes * kBarStride + 2 * (size_t)a.tq_cap + 2 : 0;
+  const size_t n_cnt_old = (size_t)runs * ((size_t)3 * a.levels + 5 + kBarStride + (size_t)a.levels * a.maxw * kBarStride);
+  const size_t n_cnt_tree = tail ? (size_t)runs + 64 + (size_t)runs * a.max_nodes * kBarStride + 2 * (size_t)a.tq_cap + 2 : 0;
   const size_t b_cnt = (n_cnt_old + n_cnt_tree) * 4;
   a.rootbuf_stride = (size_t)rp * (2 * (size_t)d + (size_t)d * d + 1) + (size_t)d * d + 8;
   const size_t b_rb = (size_t)runs * a.rootbuf_stride * 8;
   const size_t b_fl = (size_t)runs * a.max_nodes * 8, b_fi = (size_t)runs * a.max_nodes * 2 * 4;
   const size_t b_pl = (size_t)2 * runs * a.maxp * 2 * 4, b_pb = (size_t)2 * runs * a.maxw * 4;
   const size_t b_kp = mode == 1 ? 0 : (size_t)2 * runs * a.maxp * (2 * (size_t)d + 2) * 8;
+  const size_t b_kpt = tail ? (size_t)2 * runs * a.kp_cap * (2 * (size_t)d + 2) * 8 : 0;  // the queue form's own
   const size_t b_sl = (size_t)2 * runs * a.maxw * 4, b_el = (size_t)runs * 2 * a.maxw * 4;
   const size_t b_sc = (size_t)runs * d * 8;
   const size_t b_ps = mode == 1 ? 0 : (size_t)runs * n * d * 8;
@@ -2924,7 +2887,7 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
   const size_t b_re = a.fast ? (size_t)runs * (2 * (size_t)d * d + d + 2) * 8 : 0;
   auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
   const size_t total = al(b_perm) * 2 + al(b_lab) + al(b_nodes) + al(b_es) + al(b_res) + al(b_cnt) +
-                       al(b_sl) + al(b_el) + al(b_sc) + al(b_ps) + al(b_pl) + al(b_pb) + al(b_kp) + al(b_rb) + al(b_fl) + al(b_fi) +
+                       al(b_sl) + al(b_el) + al(b_sc) + al(b_ps) + al(b_pl) + al(b_pb) + al(b_kp) + al(b_kpt) + al(b_rb) + al(b_fl) + al(b_fi) +
                        2 * al(b_of) + al(b_re);
   if (total > ctx->rebuild_ws_cap) {
     if (!hip_ok(ctx, hipStreamSynchronize(ctx->stream), "sync")) return DH_ERR_HIP;
@@ -2959,7 +2922,7 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
   a.kbar = a.rbar + (size_t)runs * kBarStride;
   a.kp_top = a.nbar = a.tq_ctl = nullptr;
   a.tq_items = nullptr;
-  if (a.tree) {
+  if (tail) {
     a.kp_top = cnt + n_cnt_old;
     a.tq_ctl = a.kp_top + runs;
     a.nbar = a.tq_ctl + 64;
@@ -2981,6 +2944,8 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
   w += al(b_pb);
   a.kpart = (double*)w;
   w += al(b_kp);
+  double* kpart_tail = (double*)w;
+  w += al(b_kpt);
   a.rootbuf = (double*)w;
   w += al(b_rb);
   a.fin_lse = (double*)w;
@@ -3013,7 +2978,7 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
   if (lds > attr_lds) {
     const void* ks[8] = {(const void*)k_root_parts, (const void*)k_split, (const void*)k_ell<false>,
                          (const void*)k_ell<true>, (const void*)k_out_eig, (const void*)k_root_eig,
-                         (const void*)k_deep, (const void*)k_tree};
+                         (const void*)k_tree, (const void*)k_tree};
     for (const void* kf : ks)
       if (!hip_ok(ctx, hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
                   "hipFuncSetAttribute(rebuild LDS)"))
@@ -3046,24 +3011,6 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
   } else {
     a.root_eig = nullptr;
   }
-  // level kernels for a balanced tree's depth plus two; k_deep works off whatever is deeper (DH_DEEP=0: all levels
-  // by level kernels, as before; the diagnostic slow mode keeps them too)
-  if (a.tree) {
-    // persistent workers: as many as can be resident (the parts of a node meet at spin barriers), but
-    // no more than the tree can ever keep busy
-    long long want = (long long)runs * (n / a.tps + 2 * a.maxw + 1);
-    int G = (int)(want < cap_tree ? (want < 1 ? 1 : want) : cap_tree);
-    if (const char* e = getenv("DH_TREE_G")) G = atoi(e) > 0 ? atoi(e) : G;
-    a.tq_sleep = getenv("DH_TREE_SLEEP") ? atoi(getenv("DH_TREE_SLEEP")) : 1;
-    a.tq_nocoh = getenv("DH_TREE_NOCOH") ? atoi(getenv("DH_TREE_NOCOH")) : 0;
-    hipLaunchKernelGGL(k_tree, dim3(G), dim3(kThreads), lds, ctx->stream, a);
-  }
-  int nlev = a.tree ? 0 : a.levels;
-  if (a.fast && !(getenv("DH_DEEP") && atoi(getenv("DH_DEEP")) == 0)) nlev = a.levels < lv + 2 ? a.levels : lv + 2;
-  if (a.fast && getenv("DH_DEEP_FROM")) {  // diagnostic: hand the tree to k_deep from this level on
-    const int f = atoi(getenv("DH_DEEP_FROM"));
-    if (f >= 1 && f < a.levels) nlev = f;
-  }
   for (int L = 0; L < nlev; ++L) {
     hipLaunchKernelGGL(k_split, dim3(runs * a.maxp), dim3(kThreads), lds_split, ctx->stream, a, L);
     if (a.fast)
@@ -3071,7 +3018,20 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
     else
       hipLaunchKernelGGL(k_ell<true>, dim3(runs * 2 * a.maxw), dim3(kThreads), lds, ctx->stream, a, L, 2 * a.maxw);
   }
-  if (!a.tree && nlev < a.levels) hipLaunchKernelGGL(k_deep, dim3(runs), dim3(kThreads), lds, ctx->stream, a, nlev);
+  if (tail) {
+    // persistent workers: as many as can be resident (the parts of a node meet at spin barriers), but
+    // no more than the tree can ever keep busy; the queue form indexes its own partial-sum slots
+    RebuildArgs at = a;
+    at.tree = 1;
+    at.kpart = kpart_tail;
+    at.maxp = a.kp_cap;
+    long long want = (long long)runs * (n / a.tps + 2 * a.maxw + 1);
+    int G = (int)(want < cap_tree ? (want < 1 ? 1 : want) : cap_tree);
+    if (const char* e = getenv("DH_TREE_G")) G = atoi(e) > 0 ? atoi(e) : G;
+    at.tq_sleep = getenv("DH_TREE_SLEEP") ? atoi(getenv("DH_TREE_SLEEP")) : 1;
+    at.tq_nocoh = getenv("DH_TREE_NOCOH") ? atoi(getenv("DH_TREE_NOCOH")) : 0;
+    hipLaunchKernelGGL(k_tree, dim3(G), dim3(kThreads), lds, ctx->stream, at);
+  }
   if (forked && !hip_ok(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0), "hipStreamWaitEvent(join)")) return DH_ERR_HIP;
   hipLaunchKernelGGL(k_finish, dim3(runs), dim3(kThreads), lds_fin, ctx->stream, a);
   if (a.fast) {

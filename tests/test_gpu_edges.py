@@ -207,13 +207,13 @@ def test_work_queue_tree_equals_the_level_kernels(ctx):
             np.testing.assert_array_equal(a[k], b[k])
 
 
-def test_deep_tail_kernel_equals_the_level_kernels(ctx):
-    """The level kernels are launched for a balanced tree's depth + 2; whatever is deeper is worked off by k_deep
-    (one workgroup per run, serially).  Forced to take over early (DH_DEEP_FROM) it must give bit-identical results
-    to the level kernels (DH_DEEP=0), and a node that does not fit its tile must fail loudly, not silently."""
+def test_work_queue_tail_equals_the_level_kernels(ctx):
+    """The level kernels are launched for a balanced tree's depth + 2; whatever is deeper is handed to the work-queue
+    form (k_tree: persistent workers, any depth, any node size).  Forced to take over early (DH_DEEP_FROM) it must
+    give bit-identical results to the level kernels alone (DH_DEEP=0) -- also from level 1 on, where the C2 cloud's
+    nodes have 1000 points (the single-workgroup tail of round 2 could only take nodes of <= 256 points)."""
     import os
-    # (cloud, levels from which every node has at most 256 points)
-    cases = [(inputs.cloud("c2"), ("4", "6")), (inputs.cloud("c3"), ("6", "9")), (inputs.cloud("two5"), ("3", "5")),
+    cases = [(inputs.cloud("c2"), ("1", "4", "6")), (inputs.cloud("c3"), ("2", "6", "9")), (inputs.cloud("two5"), ("3", "5")),
              (inputs.cloud("ring2"), ("5", "7"))]
 
     def run(pts, env):
@@ -237,5 +237,30 @@ def test_deep_tail_kernel_equals_the_level_kernels(ctx):
             for k in FIELDS + ("labels",):
                 np.testing.assert_array_equal(ref[k], got[k])
     assert deep_trees >= 2
-    with pytest.raises(RuntimeError):
-        run(inputs.cloud("c2"), {"DH_DEEP_FROM": "1"})  # 1000-point nodes at level 1 do not fit k_deep's 256-point tile
+
+
+def test_unbalanced_tree_deeper_than_the_level_plan(ctx):
+    """A chain of unbalanced splits -- every 2-means split peels one small far cluster off a big rest -- is deeper
+    than the levels the launch plan gives a balanced tree, with nodes of far more than a tile of points down there
+    (the serial tail failed such a run with DH_ERR_NOMEM).  The work-queue tail builds it; all level
+    kernels (DH_DEEP=0: 2 log2(n / 2d) + 8 of them) give the same bits."""
+    import os
+    rng = np.random.default_rng(5)
+    parts = [0.5 + 0.0005 * rng.standard_normal((900, 2))]
+    for k in range(14):  # clusters further and further out, each far from everything nearer
+        c = np.array([0.5 + 0.45 * 0.62 ** k, 0.5 + 0.3 * 0.62 ** k])
+        parts.append(c + 0.02 * 0.62 ** k * 0.02 * rng.standard_normal((70, 2)))
+    pts = np.concatenate(parts)[rng.permutation(900 + 14 * 70)]
+    got = ctx.rebuild(pts, multi=True, want_labels=True)
+    os.environ["DH_DEEP"] = "0"
+    try:
+        ref = ctx.rebuild(pts, multi=True, want_labels=True)
+    finally:
+        del os.environ["DH_DEEP"]
+    assert got["nells"] == ref["nells"] and got["nnodes"] == ref["nnodes"] and got["nells"] >= 10
+    for k in FIELDS + ("labels",):
+        np.testing.assert_array_equal(ref[k], got[k])
+    # the oracle's tree on the same cloud: same number of ellipsoids, same partition of the points
+    from oracle import bounding_ref as B
+    m = B.multi_update(pts)
+    assert m.nells == got["nells"]
