@@ -736,13 +736,15 @@ def c3_leg(ctx, runs=16, queue=1024):
     return out
 
 
-def c4_leg(ctx, runs=4, queue=1000):
+def c4_leg(ctx, runs=16, queue=128):
+    """BASELINE C4 at the queue size whose ln Z stays within the gate of the SERIAL reference ensemble (ln Z drifts
+    down with the queue size, in the reference as on the device: tests/test_gpu_logz_gate.py)."""
     from dynesty_amd import problems
     prob = problems.gauss_normal_prior(200, "C4")
     kw = dict(bound='single', sample='rslice', slices=203, dlogz=0.01, max_iter=250000)
     ctx.ns_ensemble(prob, 1, 4000, queue, entropy=[3], max_fills=2, **kw)  # allocations, code objects
     t0 = time.perf_counter()
-    r = ctx.ns_ensemble(prob, runs, 4000, queue, entropy=[21], **kw)
+    r = ctx.ns_ensemble(prob, runs, 4000, queue, entropy=[21, queue], **kw)
     dt = time.perf_counter() - t0
     out = {"what": "200-D iid Normal / Normal prior, nlive 4000, single ellipsoid, rslice x 203, device-resident loop",
            "runs": runs, "queue_size": queue, "seconds": dt, "seconds_per_run": dt / runs,
@@ -751,9 +753,9 @@ def c4_leg(ctx, runs=4, queue=1000):
            "logz_truth": float(prob.logz_truth)}
     ref = os.path.join(ROOT, "tests", "golden", "c4_logz_ref.json")
     if os.path.exists(ref):
-        runs_ref = json.load(open(ref))["runs"]
-        out["logz_reference_runs"] = [{"K": x["K"], "logz": x["logz"], "logzerr": x["logzerr"],
-                                       "seconds": x["seconds"]} for x in runs_ref]
+        ens = json.load(open(ref)).get("ensembles", {})
+        out["logz_reference"] = {k: {"mean": e["mean"], "se": e["se"], "n": e["n"],
+                                     "mean_seconds_1core": e["mean_seconds_1core"]} for k, e in ens.items()}
     return out
 
 

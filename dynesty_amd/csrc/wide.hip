@@ -1251,8 +1251,62 @@ struct WideEigArgs {
   int D, B, b;
   int dbg;
   const int* active;  // see WideRebuildArgs
+  // warm start (wide_warm_kernel): the previous rebuild's eigenvectors as rows of V0t and Wt = (cov V0)^T;
+  // cold[run] != 0 (or null pointers): start from the identity
+  const double* V0t;
+  const double* Wt;
+  const int* cold;
 };
 constexpr int kEigMaxSweeps = 30;
+
+// Warm start of the one-sided Jacobi solver.  Between two consecutive rebuilds of a run the covariance of the live
+// points barely moves (one queue fill replaces a few per cent of them), so the previous eigenvectors V0 nearly
+// diagonalise the new matrix: Hestenes' iteration started from G = A V0, V = V0 instead of G = A, V = I finds its
+// columns almost orthogonal and ends after two or three sweeps instead of eleven.  One workgroup per (run, vector):
+// the unit vector from the previous `axes` column (axes = V sqrt(lambda) times the enlargement: normalising the
+// column gives V back), then its image under the new covariance (symmetric: column reads are coalesced).  A run
+// without a previous bound, or with a degenerate column, is flagged cold.
+__global__ void __launch_bounds__(256)
+    wide_warm_kernel(int D, const double* __restrict__ cov_all, const double* __restrict__ axes_all,
+                     const int32_t* __restrict__ nells_prev, const int* __restrict__ active, double* V0t_all,
+                     double* Wt_all, int* cold) {
+  __shared__ double sv[kWideMaxD];
+  __shared__ double sred[4];
+  const int run = blockIdx.y, g = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  if (active && !active[run]) return;
+  if (nells_prev[run] != 1) {
+    if (t == 0) cold[run] = 1;
+    return;
+  }
+  const double* axes = axes_all + (size_t)run * D * D;
+  const double* cov = cov_all + (size_t)run * D * D;
+  double ss = 0.0;
+  for (int i = t; i < D; i += 256) {
+    const double x = axes[(size_t)i * D + g];
+    sv[i] = x;
+    ss = fma(x, x, ss);
+  }
+  ss = wave_sum(ss);
+  if (lane == 0) sred[wv] = ss;
+  __syncthreads();
+  const double nn = (sred[0] + sred[1]) + (sred[2] + sred[3]);
+  if (!(nn > 0.0) || !isfinite(nn)) {
+    if (t == 0) cold[run] = 1;
+    return;
+  }
+  const double inv = 1.0 / sqrt(nn);
+  __syncthreads();
+  for (int i = t; i < D; i += 256) {
+    sv[i] *= inv;
+    V0t_all[((size_t)run * D + g) * D + i] = sv[i];
+  }
+  __syncthreads();
+  for (int i = t; i < D; i += 256) {
+    double acc = 0.0;
+    for (int k = 0; k < D; ++k) acc = fma(cov[(size_t)k * D + i], sv[k], acc);
+    Wt_all[((size_t)run * D + g) * D + i] = acc;
+  }
+}
 
 __device__ __forceinline__ bool eig_barrier(int* bar, int target, int* ok_flag) {
   // every wave's (agent-scope, write-through) stores acknowledged before thread 0 announces the arrival:
@@ -1502,7 +1556,11 @@ __global__ void __launch_bounds__(kRT) wide_eig2_kernel(WideEigArgs a) {
   for (int e = t; e < D * D; e += kRT) amax = fmax(amax, fabs(cov[e]));
   amax = block_max_1024(amax, s_red);
   const double scale = (amax > 0.0 && isfinite(amax)) ? 1.0 / amax : 1.0;
-  // initial blocks: G column g = column g of the covariance, V column = e_g; padding columns zero
+  // initial blocks: G column g = column g of the covariance, V column = e_g (cold), or G = cov v0_g, V = v0_g with
+  // the previous rebuild's eigenvectors v0 (warm, see wide_warm_kernel); padding columns zero
+  const bool warm = a.V0t && a.Wt && a.cold && a.cold[run] == 0;
+  const double* V0t = a.V0t ? a.V0t + (size_t)run * D * D : nullptr;
+  const double* Wt = a.Wt ? a.Wt + (size_t)run * D * D : nullptr;
   {
     int top, bot;
     pair_of(0, top, bot);
@@ -1510,7 +1568,12 @@ __global__ void __launch_bounds__(kRT) wide_eig2_kernel(WideEigArgs a) {
       const int c = e / CL, i = e - c * CL;
       const int g = (c < b ? top : bot) * b + (c < b ? c : c - b);
       double v = 0.0;
-      if (g < D && i < 2 * D) v = i < D ? cov[(size_t)g * D + i] * scale : (i - D == g ? 1.0 : 0.0);
+      if (g < D && i < 2 * D) {
+        if (warm)
+          v = i < D ? Wt[(size_t)g * D + i] * scale : V0t[(size_t)g * D + (i - D)];
+        else
+          v = i < D ? cov[(size_t)g * D + i] * scale : (i - D == g ? 1.0 : 0.0);
+      }
       col[e] = v;
     }
     if (t == 0) s_rot = 0;
@@ -2319,9 +2382,11 @@ int wide_contains_launch(dh_ctx* ctx, const double* x, int k, int d, const doubl
   return hip_ok(ctx, hipGetLastError(), "wide contains launch") ? DH_OK : DH_ERR_HIP;
 }
 
+// warm_nells != null: axes / axlens still hold the previous rebuild's result for every run with warm_nells[run] == 1,
+// and the eigensolver starts from it (the device-resident loop: consecutive rebuilds of the same runs)
 static int wide_single_enqueue(dh_ctx* ctx, int runs, const double* pts, int n, int d, const int* active, int32_t* status,
                                double* ctrs, double* covs, double* ams, double* axes, double* axlens,
-                               double* logvols) {
+                               double* logvols, const int32_t* warm_nells = nullptr) {
   if (d > kWideMaxD) return fail(ctx, DH_ERR_ARG, "rebuild: d=%d exceeds the wide-D limit %d", d, kWideMaxD);
   const size_t lds = wide_single_lds(d);
   if (lds > 159 * 1024) return fail(ctx, DH_ERR_ARG, "rebuild: d=%d needs %zu B of LDS", d, lds);
@@ -2356,8 +2421,8 @@ static int wide_single_enqueue(dh_ctx* ctx, int runs, const double* pts, int n, 
   const int ntiles = (n + tp - 1) / tp;
   const int ct = std::max(1, (ntiles + 31) / 32), P = (ntiles + ct - 1) / ct, chunk = ct * tp;
   const size_t part_bytes = ((size_t)P * d + (size_t)P * d * d + P + d) * 8 + (size_t)d * 4 + 64;
-  const size_t ints = (size_t)(kEigMaxSweeps + 3) * 4;
-  int rc = ensure_ws(ctx, (3 * dd + ww + xb + (size_t)d * 8 + ints + part_bytes) * runs + 4096);
+  const size_t ints = (size_t)(kEigMaxSweeps + 4) * 4;
+  int rc = ensure_ws(ctx, (5 * dd + ww + xb + (size_t)d * 8 + ints + part_bytes) * runs + 4096);
   if (rc) return rc;
   WideRebuildArgs a;
   a.pts = pts;
@@ -2368,7 +2433,9 @@ static int wide_single_enqueue(dh_ctx* ctx, int runs, const double* pts, int n, 
   a.wsA = (double*)ctx->rebuild_ws;
   a.wsV = a.wsA + (size_t)runs * d * d;
   a.wscov = a.wsV + (size_t)runs * d * d;
-  a.wsW = a.wscov + (size_t)runs * d * d;
+  double* ws_v0t = a.wscov + (size_t)runs * d * d;   // warm start: previous eigenvectors (rows) ...
+  double* ws_wt = ws_v0t + (size_t)runs * d * d;     // ... and their images under the new covariance
+  a.wsW = ws_wt + (size_t)runs * d * d;
   double* x_buf = a.wsW + (size_t)runs * 4 * pw * pw;
   double* lam_pre = x_buf + (size_t)runs * 2 * M * b * clen;
   a.meanpart = lam_pre + (size_t)runs * d;
@@ -2376,8 +2443,9 @@ static int wide_single_enqueue(dh_ctx* ctx, int runs, const double* pts, int n, 
   a.fmaxpart = a.covpart + (size_t)runs * P * d * d;
   a.lam_ws = a.fmaxpart + (size_t)runs * P;
   a.order_ws = (int*)(a.lam_ws + (size_t)runs * d);
-  // bar[runs] | rot[runs x kEigMaxSweeps] | ok[runs] | fast[runs]
+  // bar[runs] | rot[runs x kEigMaxSweeps] | ok[runs] | fast[runs] | cold[runs]
   int* eig_int = a.order_ws + (size_t)runs * d + 2;
+  int* eig_cold = eig_int + (size_t)runs * (3 + kEigMaxSweeps);
   a.dbg = getenv("DH_WIDE_PROF") ? 1 : 0;
   a.phase = 0;
   a.lam_pre = lam_pre;
@@ -2453,6 +2521,15 @@ static int wide_single_enqueue(dh_ctx* ctx, int runs, const double* pts, int n, 
     g.b = b;
     g.dbg = a.dbg;
     g.active = active;
+    g.V0t = g.Wt = nullptr;
+    g.cold = nullptr;
+    if (gram && warm_nells && !(getenv("DH_WIDE_WARM") && atoi(getenv("DH_WIDE_WARM")) == 0)) {
+      hipLaunchKernelGGL(wide_warm_kernel, dim3(d, runs), dim3(256), 0, ctx->stream, d, a.wscov, axes, warm_nells, active,
+                         ws_v0t, ws_wt, eig_cold);
+      g.V0t = ws_v0t;
+      g.Wt = ws_wt;
+      g.cold = eig_cold;
+    }
     if (gram)
       hipLaunchKernelGGL(wide_eig2_kernel, dim3(runs * B), dim3(kRT), eig_lds, ctx->stream, g);
     else
@@ -2489,7 +2566,7 @@ __global__ void wide_mark_single_kernel(int runs, const int* __restrict__ active
 int wide_single_launch_masked(dh_ctx* ctx, int runs, const double* pts, int n, int d, int32_t* nells,
                               int32_t* status, double* ctrs, double* covs, double* ams, double* axes,
                               double* axlens, double* logvols, const int* active) {
-  const int rc0 = wide_single_enqueue(ctx, runs, pts, n, d, active, status, ctrs, covs, ams, axes, axlens, logvols);
+  const int rc0 = wide_single_enqueue(ctx, runs, pts, n, d, active, status, ctrs, covs, ams, axes, axlens, logvols, nells);
   if (rc0) return rc0;
   hipLaunchKernelGGL(wide_mark_single_kernel, dim3((runs + 63) / 64), dim3(64), 0, ctx->stream, runs, active, nells);
   return hip_ok(ctx, hipGetLastError(), "wide masked rebuild launch") ? DH_OK : DH_ERR_HIP;
