@@ -98,7 +98,8 @@ SIGNATURES = {
                            _vp, _vp, _vp, _vp]),
     "dh_ns_ensemble": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _dbl, _dbl,
                             C.c_int64, C.c_int64, _vp, _i, _u32, _vp, _vp,
-                            _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+                            _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i]),
+    "dh_bootstrap_expand": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "dh_friends_update": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp,
                                _vp, _vp, _vp, _vp]),
     "dh_friends_within": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp]),
@@ -207,6 +208,24 @@ def set_pcg_state_words(bitgen, words):
     st["state"]["state"] = (w[0] << 64) | w[1]
     st["state"]["inc"] = (w[2] << 64) | w[3]
     bitgen.state = st
+
+
+def enlarge_bootstrap_defaults(sample, enlarge, bootstrap):
+    """(enlarge, bootstrap) of a run as the reference's _get_enlarge_bootstrap
+    decides them (dynesty.py:169-200)."""
+    if enlarge is not None and bootstrap is None:
+        if enlarge < 1:
+            raise ValueError("enlarge must be >= 1")
+        return float(enlarge), 0
+    if enlarge is None and bootstrap is not None:
+        if not (bootstrap > 1 or bootstrap == 0):
+            raise ValueError("bootstrap must be 0 or > 1")
+        return 1.0, int(bootstrap)
+    if enlarge is None and bootstrap is None:
+        return (1.0, 5) if sample == 'unif' else (1.25, 0)
+    if bootstrap == 0 or enlarge == 1:
+        return float(enlarge), int(bootstrap)
+    raise ValueError('Enlarge and bootstrap together do not make sense unless bootstrap=0 or enlarge = 1')
 
 
 class Context:
@@ -767,11 +786,14 @@ class Context:
         return out
 
     def ns_ensemble(self, prob, runs, nlive, queue_size, walks=None,
-                    bound='multi', dlogz=0.01, enlarge=1.25, entropy=(21,),
+                    bound='multi', dlogz=0.01, enlarge=None, entropy=(21,),
                     first_run=0, max_fills=0, max_iter=400000,
                     want_dead_logl=False, sample='rwalk', slices=None,
-                    rebuild_sync=False, want_samples=False, rng='pcg64'):
+                    rebuild_sync=False, want_samples=False, rng='pcg64', bootstrap=None):
         """Device-resident ensemble of static NS runs (dh_ns_ensemble).
+
+        sample: 'rwalk' | 'rslice' | 'slice' | 'unif'.  enlarge / bootstrap default as the reference's
+        _get_enlarge_bootstrap (dynesty.py:169-200): (1.25, 0), and (1, 5) for 'unif'.
 
         rebuild_sync=False keeps the reference's per-run update schedule
         (sampler.py:625-674): a run's result then depends only on its own seed,
@@ -783,13 +805,16 @@ class Context:
         if bound not in ('multi', 'single'):
             raise ValueError(f"ns_ensemble: bound={bound!r} is not supported by the device-resident "
                              "loop ('multi' or 'single'; balls / cubes: nested.run_static)")
-        if sample not in ('rwalk', 'rslice', 'slice'):
+        if sample not in ('rwalk', 'rslice', 'slice', 'unif'):
             raise ValueError(f"ns_ensemble: sample={sample!r} is not supported by the "
-                             "device-resident loop ('rwalk', 'rslice' or 'slice')")
-        kind = dict(rwalk=0, rslice=1, slice=2)[sample]
+                             "device-resident loop ('rwalk', 'rslice', 'slice' or 'unif')")
+        kind = dict(rwalk=0, rslice=1, slice=2, unif=6)[sample]
         if rng not in ('pcg64', 'philox'):
             raise ValueError("ns_ensemble: rng must be 'pcg64' or 'philox'")
-        if kind == 0:
+        enlarge, bootstrap = enlarge_bootstrap_defaults(sample, enlarge, bootstrap)
+        if kind == 6:
+            walks = 1  # unused
+        elif kind == 0:
             if walks is None:
                 walks = nd + 20  # dynesty.py:128
         else:
@@ -811,11 +836,12 @@ class Context:
         nf = C.c_int64(0)
         self._check(self.lib.dh_ns_ensemble(
             self.handle, self.problem(prob), int(runs), int(nlive), nd,
-            int(queue_size), kind + (3 if rng == 'philox' else 0), int(walks), 1 if bound == 'multi' else 0,
+            int(queue_size), kind + ((1 if kind == 6 else 3) if rng == 'philox' else 0), int(walks),
+            1 if bound == 'multi' else 0,
             1 if rebuild_sync else 0, float(dlogz), float(enlarge), int(max_fills), int(max_iter),
             _ptr(words), words.size, int(first_run), _ptr(rec), _ptr(dead),
             _ptr(livel), _ptr(dead_u), _ptr(live_u), C.byref(nf), _ptr(pid), _ptr(pit), _ptr(pnc),
-            _ptr(lit)))
+            _ptr(lit), int(bootstrap)))
         out = dict(logz=rec[:, 0], logzerr=rec[:, 1],
                    niter=rec[:, 2].astype(np.int64),
                    ncall=rec[:, 3].astype(np.int64), h=rec[:, 4],
@@ -832,6 +858,21 @@ class Context:
         return out
 
     # ---- RadFriends / SupFriends ------------------------------------------
+    def bootstrap_expand(self, points, ent, bootstrap, multi, want_n_in=False):
+        """dh_bootstrap_expand: points (runs, n, d), ent (runs, 4) uint64 ->
+        (runs,) expansion factors (bounding.py:1619-1648, max over replicas)
+        [, (runs, bootstrap) sample sizes]."""
+        pts = np.ascontiguousarray(points, dtype=np.float64)
+        if pts.ndim == 2:
+            pts = pts[None]
+        runs, n, d = pts.shape
+        ent = np.ascontiguousarray(ent, dtype=np.uint64).reshape(runs, 4)
+        out = np.empty(runs)
+        nin = np.empty((runs, int(bootstrap)), dtype=np.int32) if want_n_in else None
+        self._check(self.lib.dh_bootstrap_expand(self.handle, runs, _ptr(pts), n, d, 1 if multi else 0,
+                                                 int(bootstrap), _ptr(ent), _ptr(out), _ptr(nin)))
+        return (out, nin) if want_n_in else out
+
     def friends_update(self, points, kind, am_prev=None, in_masks=None):
         """RadFriends.update / SupFriends.update (dh_friends_update).
         kind 'balls' | 'cubes'; am_prev = previous metric (None: no

@@ -132,7 +132,7 @@ int unif_launch_runs(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, int m
                      const int8_t* bc, const uint64_t* rng, int64_t max_tries, double* u, double* v,
                      double* logl, int32_t* ncalls, int32_t* flags, uint64_t* rng_out,
                      const double* run_loglstar, const int* run_mode, int wpr, int my_mode,
-                     const PhiloxKey* philox = nullptr);
+                     const PhiloxKey* philox = nullptr, const int* run_nells = nullptr, int run_me = 0);
 
 int rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int d, int mode, int max_ells,
                         int32_t* nells, int32_t* status, double* ctrs, double* covs, double* ams,
@@ -143,7 +143,13 @@ int rebuild_launch_masked(dh_ctx* ctx, int runs, const double* pts, int n, int d
                           double* axes, double* axlens, double* logvols, const int* active);
 int enlarge_launch_masked(dh_ctx* ctx, int runs, int max_ells, const int32_t* nells, int d, double* covs,
                           double* ams, double* axes, double* axlens, double* logvols, double log_enlarge,
-                          const int* active);
+                          const int* active, const double* run_shift = nullptr);
+// boot.hip: the bootstrap expansion factor of runs x B resampled replicas (bounding.py:381-400, 688-703, 1593-1648);
+// run_shift[run] = d * ln(expand) (0 where expand <= 1 or the run is not active); ws of bootstrap_ws_bytes(...)
+size_t bootstrap_ws_bytes(int runs, int n, int d, int max_ells, int B);
+int bootstrap_expand_launch(dh_ctx* ctx, int runs, const double* pts, int n, int d, int multi, int max_ells, int B,
+                            const uint64_t* ent, const int* active, void* ws, double* run_shift, double* expand,
+                            int* bstatus);
 int eval_launch_dev(dh_ctx* ctx, int problem, int k, const double* u, double* v, double* logl);
 // bound.hip: start-point membership per run (candidate w -> run w / wpr); flag[run] |= 1 if one lies outside
 int contains_runs_launch(dh_ctx* ctx, const double* x, int k, int d, int wpr, const double* ctrs, const double* ams,

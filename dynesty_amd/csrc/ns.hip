@@ -45,19 +45,21 @@ struct NsRun {
   // likelihood plateau (sampler.py:1112-1127, 1190-1193): deaths still to be taken with the plateau's volume
   // step (0 = not in plateau mode), ln of that step's volume, and the two sums that make var[ln Z] exact
   // although the dead points' d ln X is then no longer constant (see ns_finish)
-  int pcount, force_rebuild;
+  int pcount, sampler_failed;  // (sampler_failed: a uniform-sampler walker gave up, see ns_consume)
   double plogdvol, var_a, var_b;
 };
 
 struct NsArgs {
   int runs, nlive, ndim, K, walks, bound_multi, max_ells;
-  int sampler;  // 0 rwalk, 1 rslice, 2 slice ; `walks` holds the slice count for 1, 2
+  int sampler;  // 0 rwalk, 1 rslice, 2 slice, 3 unif ; `walks` holds the slice count for 1, 2 (unused for 3)
+  int bootstrap;  // replicas of the bootstrap expansion per rebuild (0: none)
   long long cap;  // dead-point capacity per run
   double dlogz, enlarge_log, facc, first_eff;
   long long first_ncall, update_interval;
   int store_samples;
   long long* prof;   // optional (DH_NS_PROF=1): cycle counters of ns_consume's phases, run 0
   int rebuild_sync;  // 1: all bound-mode runs rebuild whenever any run is due (see ns_prepare)
+  int serial_walk;   // diagnostic (DH_NS_SERIAL=1): ns_consume walks every queue with the one-wavefront routine
   NsRun* st;
   double* live_u;
   double* live_v;
@@ -93,6 +95,9 @@ struct NsArgs {
   double* b_axes;
   double* b_axl;
   double* b_lv;
+  double* b_cum;        // unif sampler: rand_choice weights of the run's ellipsoids, cumulated (bounding.py:726-731)
+  uint64_t* boot_ent;   // runs x 4: the words a rebuilding run drew for its bootstrap replicas
+  double* run_shift;    // runs: ndim * ln(bootstrap expansion factor) of the rebuild just done
   // results
   double* records;  // runs x 8: logz, logzerr, niter, ncall, h, nbound, status, eff
   double* fin_ws;   // runs x 3 nlive: ns_finish's per-point terms
@@ -162,7 +167,7 @@ __global__ void __launch_bounds__(kT)
     r.acc = r.rej = r.doubling = r.pad1 = 0;
     r.logzvar = 0.0;
     r.nc_carry = 0;
-    r.pcount = r.force_rebuild = 0;
+    r.pcount = r.sampler_failed = 0;
     r.plogdvol = r.var_a = r.var_b = 0.0;
     Pcg64 g;
     seed_from_child(g, entropy, nwords, 0x80000000u + first_run + (uint32_t)run);
@@ -273,6 +278,12 @@ __global__ void __launch_bounds__(kT) ns_prepare(NsArgs a) {
     if (need) {
       r.ncall_last_update = r.ncall;
       r.nbound += 1;
+      if (a.bootstrap > 0) {  // get_seed_sequence(rstate, bootstrap) (utils.py:1002-1009): one draw per rebuild
+        Pcg64 g;
+        g.load(r.rng);
+        for (int i = 0; i < 4; ++i) a.boot_ent[(size_t)run * 4 + i] = g.next64();
+        g.store(r.rng);
+      }
     }
     r.need_rebuild = need;
     if (a.force) a.force[run] = 0;
@@ -334,6 +345,8 @@ __global__ void __launch_bounds__(kT) ns_select(NsArgs a) {
       for (int e = 0; e < M; ++e) cum[e] *= inv;
     }
     __syncthreads();
+    if (a.sampler == 3)
+      for (int e = t; e < M; e += kT) a.b_cum[(size_t)run * a.max_ells + e] = cum[e];
   }
   const double loglstar = r.loglstar;
   for (int w = t; w < K; w += kT) {
@@ -343,7 +356,7 @@ __global__ void __launch_bounds__(kT) ns_select(NsArgs a) {
     g.seed(is, iq);
     const size_t q = (size_t)run * K + w;
     int frame = 0;
-    if (mode == MODE_BOUND) {
+    if (mode == MODE_BOUND && a.sampler != 3) {  // (the uniform sampler starts nowhere: internal_samplers.py:214-242)
       // a live point with logl > loglstar, uniformly (sampler.py:469-474)
       int i;
       int guard = 0;
@@ -406,6 +419,7 @@ constexpr int kEPT = 8;  // deaths per lane in the scan phase: K <= kEPT * kT
 __host__ __device__ inline size_t ns_consume_lds(int N, int K) {
   size_t P = 1;
   while (P < (size_t)N) P <<= 1;
+  if (P < 256) P = 256;  // (the slot order is sorted 256 entries at a time at least)
   return (size_t)N * 12 + (size_t)K * 52 + P * 2 + 64;
 }
 
@@ -423,6 +437,12 @@ struct WorstKey {
   int slot;
 };
 __device__ __forceinline__ bool key_before(double ka, int sa, double kb, int sb) { return ka < kb || (ka == kb && sa < sb); }
+// the same without short-circuit evaluation (the compiler turns || and && on lane values into exec-mask branches:
+// a dozen scalar branches per compare-exchange of the sort)
+__device__ __forceinline__ int key_before_nb(double ka, int sa, double kb, int sb) {
+  const int lt = ka < kb ? 1 : 0, eq = ka == kb ? 1 : 0, sl = sa < sb ? 1 : 0;
+  return lt | (eq & sl);
+}
 
 __device__ __forceinline__ int consume_sorted(const double* skey, const unsigned short* sidx, int* src, const double* ql,
                                               double* dcur, int* dj, int* dslot, int* dsrc, double* bkey, int* bslot,
@@ -529,6 +549,337 @@ __device__ __forceinline__ int consume_sorted(const double* skey, const unsigned
   return ndead;
 }
 
+// Bitonic sort of a run's slots by (log-likelihood, slot) with the elements in REGISTERS: thread t holds the SPT
+// consecutive positions t * SPT .. of the P = SPT * kT, so a compare-exchange at distance jj is inside the thread
+// (jj < SPT), a lane exchange inside the wavefront (jj < 64 SPT: __shfl_xor), and only the two or three widest
+// distances go through LDS (the slots travel, the keys are looked up again).  The version that kept the order in
+// LDS and read every key through its slot paid two dependent LDS round trips and a workgroup barrier for each of
+// the 66 stages of 2048 elements: 55 us of the 150 us of a C2 queue consumption.
+// sidx: max(P, kT) entries; padding = slot 0xFFFF / key +inf sorts to the end.
+template <int SPT>
+__device__ __attribute__((noinline)) void sort_slots(const double* skey, unsigned short* sidx, int N, int nsidx) {
+  constexpr int P = SPT * kT;
+  const int t = threadIdx.x, lane = t & 63, g0 = t * SPT;
+  double k[SPT];
+  int sl[SPT];
+#pragma unroll
+  for (int e = 0; e < SPT; ++e) {
+    const int g = g0 + e;
+    sl[e] = g < N ? g : 0xFFFF;
+    k[e] = g < N ? skey[g] : INFINITY;
+  }
+  for (int kk = 2; kk <= P; kk <<= 1) {
+    int jj = kk >> 1;
+    // distances between wavefronts: through LDS
+    for (; jj >= 64 * SPT; jj >>= 1) {
+#pragma unroll
+      for (int e = 0; e < SPT; ++e)
+        if (g0 + e < nsidx) sidx[g0 + e] = (unsigned short)sl[e];
+      __syncthreads();
+      int ps[SPT];
+      double pk[SPT];
+#pragma unroll
+      for (int e = 0; e < SPT; ++e) {
+        const int gp = (g0 + e) ^ jj;
+        ps[e] = gp < nsidx ? (int)sidx[gp] : 0xFFFF;
+      }
+#pragma unroll
+      for (int e = 0; e < SPT; ++e) pk[e] = ps[e] == 0xFFFF ? INFINITY : skey[ps[e]];
+#pragma unroll
+      for (int e = 0; e < SPT; ++e) {
+        const int g = g0 + e;
+        const int keep_min = (((g & jj) == 0) == ((g & kk) == 0)) ? 1 : 0;
+        // (a strict total order: "partner first" decides both directions; identical paddings swap harmlessly)
+        const bool take = key_before_nb(pk[e], ps[e], k[e], sl[e]) == keep_min;
+        k[e] = take ? pk[e] : k[e];
+        sl[e] = take ? ps[e] : sl[e];
+      }
+      __syncthreads();
+    }
+    // distances between lanes
+    for (; jj >= SPT; jj >>= 1) {
+      const int m = jj / SPT;
+      const bool lower = (lane & m) == 0;
+      // (all exchanges issued before the first comparison: one LDS-crossbar latency per stage, not per element)
+      int plo[SPT], phi[SPT], ps[SPT];
+      const int src_lane = (lane ^ m) << 2;
+#pragma unroll
+      for (int e = 0; e < SPT; ++e) {
+        const long long bits = __double_as_longlong(k[e]);
+        plo[e] = __builtin_amdgcn_ds_bpermute(src_lane, (int)(unsigned)bits);
+        phi[e] = __builtin_amdgcn_ds_bpermute(src_lane, (int)(unsigned)(bits >> 32));
+        ps[e] = __builtin_amdgcn_ds_bpermute(src_lane, sl[e]);
+      }
+#pragma unroll
+      for (int e = 0; e < SPT; ++e) {
+        const double pk = __longlong_as_double(((long long)phi[e] << 32) | (unsigned)plo[e]);
+        const int keep_min = (lower == (((g0 + e) & kk) == 0)) ? 1 : 0;
+        const bool take = key_before_nb(pk, ps[e], k[e], sl[e]) == keep_min;
+        k[e] = take ? pk : k[e];
+        sl[e] = take ? ps[e] : sl[e];
+      }
+    }
+    // distances inside the thread
+#pragma unroll
+    for (int J = SPT / 2; J >= 1; J >>= 1) {
+      if (J <= (kk >> 1)) {
+#pragma unroll
+        for (int e = 0; e < SPT; ++e) {
+          if ((e & J) == 0) {
+            const int e2 = e | J;
+            const int asc = (((g0 + e) & kk) == 0) ? 1 : 0;
+            const bool sw = key_before_nb(k[e2], sl[e2], k[e], sl[e]) == asc;
+            const double ka = k[e], kb = k[e2];
+            const int sa = sl[e], sb = sl[e2];
+            k[e] = sw ? kb : ka;
+            k[e2] = sw ? ka : kb;
+            sl[e] = sw ? sb : sa;
+            sl[e2] = sw ? sa : sb;
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < SPT; ++e)
+    if (g0 + e < nsidx) sidx[g0 + e] = (unsigned short)sl[e];
+  __syncthreads();
+}
+
+// The same walk without the serial chain, by the whole workgroup.  Let U_j = the run's live values at the start of
+// the fill plus the proposals accepted before entry j, dead or alive; c_j = the deaths before j.  Entry j is
+// accepted iff q_j beats the worst live value, i.e. iff more than c_j values of U_j are below q_j:
+//     R_j = #{originals < q_j} + #{accepted i < j : q_i < q_j} > c_j .
+// The worst value never decreases, so a stale entry i < j (q_i <= the worst at its time) lies below every LATER
+// accepted q_j: for an accepted j all j - c_j stale entries before it count into #{i < j : q_i < q_j}, and for a
+// stale j at most that many do.  Hence
+//     entry j is accepted  <=>  #{originals < q_j} + #{i < j : q_i < q_j}  >  j ,
+// a rank that does not depend on what happened to the entries before it.  Proposals accepted after death e are
+// strictly above its value, so death e is the e-th smallest of originals + all accepted proposals: a merge of the
+// sorted originals with the (few) accepted values low enough to die within this fill; a proposal inherits the slot
+// of the death that let it in (chains of such inheritances are followed until none is open).  Equal values are
+// ordered by slot in the reference (np.argmin, sampler.py:1107), and the slot of a proposal is only known after the
+// deaths below it: whenever an accepted value that could die in this fill equals an original or another such value
+// (rwalk handing back its start point), and when the dead-point store runs out, this routine changes nothing and
+// returns 0 -- the serial walk takes the fill.  All threads call it; cj = K ints of scratch (c_j of every entry);
+// sh = 4 shared ints; on success *ndead_out / *newmin as consume_sorted.
+__device__ int consume_parallel(const double* skey, const unsigned short* sidx, int* src, const double* ql, double* dcur,
+                                int* dj, int* dslot, int* dsrc, double* bkey, int* cj, int N, int K, long long room,
+                                int* sh, int* ndead_out, double* newmin, long long* prof) {
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  long long pt_ = prof ? clock64() : 0;
+#define CP_PROF(i)                         \
+  do {                                     \
+    if (prof && t == 0) {                  \
+      const long long now_ = clock64();    \
+      prof[i] += now_ - pt_;               \
+      pt_ = now_;                          \
+    }                                      \
+  } while (0)
+  __shared__ int wcnt[kEPT][kT / 64];
+  int* rA = dsrc;                  // #{originals < q_j}   (dsrc is written last)
+  int* posB = (int*)dcur;          // death index of the r-th lowest accepted value   (dcur likewise)
+  int* bq = posB + K;              // its queue entry
+  double qv[kEPT];
+#pragma unroll
+  for (int u = 0; u < kEPT; ++u) {
+    const int j = t + u * kT;
+    qv[u] = j < K ? ql[j] : -INFINITY;
+    if (j < K) {
+      int lo = 0, hi = N;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (skey[sidx[mid]] < qv[u]) lo = mid + 1; else hi = mid;
+      }
+      rA[j] = lo;
+    }
+  }
+  CP_PROF(11);
+  if (t == 0) sh[0] = sh[1] = sh[2] = 0;  // [0] low accepted values, [1] tie, [2] entries the originals do not decide
+  __syncthreads();
+  // #{i < j : q_i < q_j} is needed only where the originals alone do not decide (rA[j] <= j: a quarter of a late
+  // fill): those entries are listed, and every one is counted by four lanes (a quarter of i < j each)
+  const int nu = (K + kT - 1) / kT;
+  int* needl = posB;  // (scratch until the merge)
+  int* lcnt = bq;
+  for (int u = 0; u < nu; ++u) {
+    const int j = t + u * kT;
+    const bool need = j < K && rA[j] <= j;
+    const unsigned long long b = __ballot(need);
+    if (j < K) cj[j] = 1;  // accepted unless found otherwise below
+    if (b) {
+      int base = 0;
+      if (lane == 0) base = atomicAdd(&sh[2], __popcll(b));
+      base = __builtin_amdgcn_readfirstlane(base);
+      if (need) {
+        const int x = base + __popcll(b & ((1ull << lane) - 1ull));
+        needl[x] = j;
+        lcnt[x] = 0;
+      }
+    }
+  }
+  __syncthreads();
+  const int nn = sh[2];
+  for (int w = t; w < 4 * nn; w += kT) {
+    const int x = w >> 2, part = w & 3, j = needl[x];
+    const double q = ql[j];
+    int c = 0, i = (j * part) >> 2;
+    const int i1 = (j * (part + 1)) >> 2;
+    for (; i + 8 <= i1; i += 8) {  // (eight loads in flight: the loop is LDS latency otherwise)
+      double v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = ql[i + k];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) c += v[k] < q ? 1 : 0;
+    }
+    for (; i < i1; ++i) c += ql[i] < q ? 1 : 0;
+    if (c) atomicAdd(&lcnt[x], c);
+  }
+  __syncthreads();
+  for (int x = t; x < nn; x += kT) {
+    const int j = needl[x];
+    cj[j] = rA[j] + lcnt[x] > j ? 1 : 0;
+  }
+  __syncthreads();
+  CP_PROF(12);
+  bool acc[kEPT];
+  int pre[kEPT];
+#pragma unroll
+  for (int u = 0; u < kEPT; ++u) {
+    const int j = t + u * kT;
+    acc[u] = u < nu && j < K && cj[j] != 0;
+    pre[u] = 0;
+    if (u < nu) {
+      const unsigned long long b = __ballot(acc[u]);
+      pre[u] = __popcll(b & ((1ull << lane) - 1ull));
+      if (lane == 0) wcnt[u][wv] = __popcll(b);
+    }
+  }
+  __syncthreads();
+  int ndead = 0;
+  {
+    int run_sum = 0;
+    for (int uu = 0; uu < nu; ++uu)
+      for (int w = 0; w < kT / 64; ++w) {
+        const int c = wcnt[uu][w];
+#pragma unroll
+        for (int u = 0; u < kEPT; ++u)
+          if (uu == u && w == wv) pre[u] += run_sum;
+        run_sum += c;
+      }
+    ndead = run_sum;
+  }
+  if ((long long)ndead > room) return 0;  // (uniform)
+#pragma unroll
+  for (int u = 0; u < kEPT; ++u) {
+    const int j = t + u * kT;
+    if (u < nu) {
+      const bool low = acc[u] && rA[j] <= ndead;  // may die within this fill (or be the worst point left)
+      const unsigned long long b = __ballot(low);
+      int base = 0;
+      if (b) {
+        if (lane == 0) base = atomicAdd(&sh[0], __popcll(b));
+        base = __builtin_amdgcn_readfirstlane(base);
+      }
+      if (j < K) {
+        cj[j] = pre[u];
+        if (acc[u]) dj[pre[u]] = j;
+        if (low) {
+          const int x = base + __popcll(b & ((1ull << lane) - 1ull));
+          bkey[x] = qv[u];
+          bq[x] = j;
+          if (rA[j] < N && skey[sidx[rA[j]]] == qv[u]) sh[1] = 1;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const int nB = sh[0];
+  CP_PROF(13);
+  // rank among the low accepted values (counted: there are few)
+  int myr[kEPT], myq[kEPT];
+  for (int u = 0; u < kEPT; ++u) {
+    const int x = t + u * kT;
+    myr[u] = -1;
+    if (x < nB) {
+      const double v = bkey[x];
+      int r = 0, eq = 0;
+      for (int y = 0; y < nB; ++y) {
+        const double w = bkey[y];
+        r += w < v ? 1 : 0;
+        eq += w == v ? 1 : 0;
+      }
+      if (eq > 1) sh[1] = 1;
+      myr[u] = r;
+      myq[u] = bq[x];
+    }
+  }
+  __syncthreads();
+  if (sh[1]) return 0;  // an accepted value ties with another candidate: slot order decides (serial walk)
+  for (int u = 0; u < kEPT; ++u)
+    if (myr[u] >= 0) {
+      posB[myr[u]] = rA[myq[u]] + myr[u];
+      bq[myr[u]] = myq[u];  // (ranks are a permutation; every old bq entry sits in a register by now)
+    }
+  __syncthreads();
+  CP_PROF(14);
+  // death e = the element of rank e in the merge; e == ndead: the worst point left
+  double dval[kEPT + 1];
+  int dsl[kEPT + 1], dsr[kEPT + 1];
+  for (int u = 0; u <= kEPT; ++u) {
+    const int e = u < kEPT ? t + u * kT : (t == 0 ? ndead : ndead + 1);  // (thread 0: also the worst point left)
+    dsl[u] = dsr[u] = -1;
+    dval[u] = INFINITY;
+    if (e <= ndead) {
+      int lo = 0, hi = nB;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (posB[mid] < e) lo = mid + 1; else hi = mid;
+      }
+      if (lo < nB && posB[lo] == e) {
+        dsr[u] = bq[lo];
+        dval[u] = ql[dsr[u]];
+      } else if (e - lo < N) {
+        dsl[u] = sidx[e - lo];
+        dval[u] = skey[dsl[u]];
+      }
+    }
+  }
+  __syncthreads();
+  for (int u = 0; u < kEPT; ++u) {
+    const int e = t + u * kT;
+    if (e < ndead) {
+      dcur[e] = dval[u];
+      dsrc[e] = dsr[u];
+      dslot[e] = dsl[u];
+    }
+  }
+  if (t == 0) {
+    *newmin = dval[kEPT];
+    *ndead_out = ndead;
+  }
+  __syncthreads();
+  CP_PROF(15);
+  // a proposal lives in the slot of the death that let it in
+  for (;;) {
+    int open = 0;
+    for (int e = t; e < ndead; e += kT)
+      if (((volatile int*)dslot)[e] < 0) {
+        const int sl = ((volatile int*)dslot)[cj[dsrc[e]]];
+        if (sl >= 0)
+          ((volatile int*)dslot)[e] = sl;
+        else
+          open = 1;
+      }
+    if (!__syncthreads_or(open)) break;
+  }
+  for (int j = t; j < K; j += kT)
+    if (cj[j] < ndead && dj[cj[j]] == j) atomicMax(&src[dslot[cj[j]]], j);
+  __syncthreads();
+  CP_PROF(7);
+  return 1;
+}
+
 __global__ void __launch_bounds__(kT) ns_consume(NsArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int run = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
@@ -557,52 +908,34 @@ __global__ void __launch_bounds__(kT) ns_consume(NsArgs a) {
   __shared__ double wred[2][4];
   __shared__ double bcast[4];
   __shared__ long long lred[4];
-  for (int i = t; i < P; i += kT) {
-    if (i < N) {
-      skey[i] = a.live_logl[(size_t)run * N + i];
-      src[i] = -1;
-    }
-    sidx[i] = i < N ? (unsigned short)i : (unsigned short)0xFFFF;
+  for (int i = t; i < N; i += kT) {
+    skey[i] = a.live_logl[(size_t)run * N + i];
+    src[i] = -1;
   }
   __syncthreads();
-  // bitonic sort of the slots by (log-likelihood, slot); the padding sorts to the end
-  // (pairs enumerated directly and four at a time: all index reads, then all key reads, then the exchanges -- one
-  // LDS round trip per batch instead of a read -> wait -> branch chain per element)
-  for (int k = 2; k <= P; k <<= 1)
-    for (int jj = k >> 1; jj > 0; jj >>= 1) {
-      for (int p0 = t; p0 < P / 2; p0 += 4 * kT) {
-        int ii[4], ia[4], ib[4];
-        double ka[4], kb[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int pp = p0 + u * kT;
-          const int pc = pp < P / 2 ? pp : 0;
-          ii[u] = ((pc & ~(jj - 1)) << 1) | (pc & (jj - 1));  // the pair's lower element; its partner is ii | jj
-          ia[u] = sidx[ii[u]];
-          ib[u] = sidx[ii[u] | jj];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          ka[u] = ia[u] == 0xFFFF ? INFINITY : skey[ia[u] == 0xFFFF ? 0 : ia[u]];
-          kb[u] = ib[u] == 0xFFFF ? INFINITY : skey[ib[u] == 0xFFFF ? 0 : ib[u]];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const bool a_after_b = key_before(kb[u], ib[u], ka[u], ia[u]);
-          if (p0 + u * kT < P / 2 && a_after_b == ((ii[u] & k) == 0)) {
-            sidx[ii[u]] = (unsigned short)ib[u];
-            sidx[ii[u] | jj] = (unsigned short)ia[u];
-          }
-        }
-      }
-      __syncthreads();
+  NS_PROF(16);
+  {
+    const int nsidx = P > kT ? P : kT;
+    switch (nsidx / kT) {
+      case 1: sort_slots<1>(skey, sidx, N, nsidx); break;
+      case 2: sort_slots<2>(skey, sidx, N, nsidx); break;
+      case 4: sort_slots<4>(skey, sidx, N, nsidx); break;
+      case 8: sort_slots<8>(skey, sidx, N, nsidx); break;
+      case 16: sort_slots<16>(skey, sidx, N, nsidx); break;
+      default: sort_slots<32>(skey, sidx, N, nsidx); break;
     }
+  }
+  NS_PROF(17);
   int acc = 0, rej = 0;
   for (int j = t; j < K; j += kT) {
     const size_t q = (size_t)run * K + j;
     ql[j] = a.r_logl[q];
     if (mode == MODE_CUBE) {
       qc[j] = a.r_a[q];
+    } else if (a.sampler == 3) {
+      qc[j] = a.r_a[q];
+      if (a.r_b[q] & 3) ql[j] = -INFINITY;  // no ellipsoid held the draw / the try limit: never accepted, the run fails below
+      if (a.r_b[q] & 3) atomicOr(&r.sampler_failed, 1);
     } else if (a.sampler == 0) {
       qc[j] = a.walks;
       acc += a.r_a[q];
@@ -634,11 +967,19 @@ __global__ void __launch_bounds__(kT) ns_consume(NsArgs a) {
   const double ldv_c = log(0.5 * expm1(dlv));  // ln(dX_e / X_e) of the trapezoid rule
   NS_PROF(0);
   // ---- phase A: the walk over the queue (wave 0) ----
-  if (t < 64) {
+  const long long room = a.dead_rel ? (long long)K + 1 : a.cap - it0;
+  int walked = 0;
+  if (!a.serial_walk) {
+    walked = consume_parallel(skey, sidx, src, ql, dcur, dj, dslot, dsrc, bkey, qborn, N, K, room, &misc[4], &misc[0],
+                              &bcast[2], run == 0 ? a.prof : nullptr);
+    if (walked && t == 0) misc[1] = -1;
+    if (a.prof && run == 0 && t == 0 && !walked) atomicAdd((unsigned long long*)&a.prof[10], 1ull);
+  }
+  if (!walked && t < 64) {
     int jcap;
     double nm;
-    const int nd = consume_sorted(skey, sidx, src, ql, dcur, dj, dslot, dsrc, bkey, bslot, bsrc, N, K,
-                                  a.dead_rel ? (long long)K + 1 : a.cap - it0, K + 1, &jcap, &nm, t);
+    const int nd = consume_sorted(skey, sidx, src, ql, dcur, dj, dslot, dsrc, bkey, bslot, bsrc, N, K, room, K + 1,
+                                  &jcap, &nm, t);
     if (t == 0) {
       misc[0] = nd;
       misc[1] = jcap;
@@ -931,7 +1272,7 @@ __global__ void __launch_bounds__(kT) ns_consume(NsArgs a) {
       for (int j = nkeep > 0 ? dj[E] + 1 : 0; j <= jlast; ++j) c += qc[j];
       r.nc_carry = c;
     }
-    if (mode == MODE_BOUND) {
+    if (mode == MODE_BOUND && a.sampler != 3) {
       const int ta = racc[0], tr = rrej[0];
       if (a.sampler == 0) {
         // RWalkSampler.tune (internal_samplers.py:460-493), once per queue fill
@@ -944,7 +1285,7 @@ __global__ void __launch_bounds__(kT) ns_consume(NsArgs a) {
         r.scale *= mult;
       }
     }
-    const int done = stopped ? 1 : (jcap >= 0 ? 2 : 0);
+    const int done = stopped ? 1 : ((jcap >= 0 || atomicOr(&r.sampler_failed, 0)) ? 2 : 0);
     if (done) {
       r.mode = done == 1 ? MODE_DONE : MODE_FAILED;
       atomicAdd(a.ndone, 1);
@@ -1011,11 +1352,27 @@ __global__ void __launch_bounds__(kT) ns_consume(NsArgs a) {
     double* lv = a.live_v + (size_t)run * N * D;
     const double* ru = a.r_u + (size_t)run * K * D;
     const double* rv = a.r_v + (size_t)run * K * D;
-    for (int e = t; e < nrep * D; e += kT) {
-      const int c = e / D, j = e - c * D;
-      const size_t to = (size_t)dslot[c] * D + j, from = (size_t)dj[c] * D + j;
-      lu[to] = ru[from];
-      lv[to] = rv[from];
+    // (eight elements per thread in flight: one at a time the loop ran at one global round trip per element)
+    const int tot = nrep * D;
+    for (int e0 = t; e0 < tot; e0 += 8 * kT) {
+      size_t to[8];
+      double xu[8], xv[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int e = e0 + q * kT;
+        const int ec = e < tot ? e : 0;
+        const int c = ec / D, j = ec - c * D;
+        to[q] = (size_t)dslot[c] * D + j;
+        const size_t from = (size_t)dj[c] * D + j;
+        xu[q] = ru[from];
+        xv[q] = rv[from];
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+        if (e0 + q * kT < tot) {
+          lu[to[q]] = xu[q];
+          lv[to[q]] = xv[q];
+        }
     }
   }
   NS_PROF(5);
@@ -1150,6 +1507,7 @@ int dh_ns_consume(dh_ctx* ctx, int runs, int nlive, int queue_size, double dlogz
   const size_t lds_max = lds_cons > lds_fin ? lds_cons : lds_fin;
   if (lds_max > 150 * 1024) return fail(ctx, DH_ERR_ARG, "ns_consume: nlive/queue too large for LDS");
   NsArgs a{};
+  a.serial_walk = (getenv("DH_NS_SERIAL") && atoi(getenv("DH_NS_SERIAL")) != 0) ? 1 : 0;
   a.runs = R;
   a.nlive = N;
   a.ndim = 0;  // log-likelihoods only: no coordinates travel
@@ -1247,7 +1605,7 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
                    const uint32_t* entropy_words, int n_words, uint32_t first_run, double* records,
                    double* dead_logl_out, double* live_logl_out, double* dead_u_out, double* live_u_out,
                    int64_t* n_fills_out, int32_t* dead_id_out, int32_t* dead_it_out, int32_t* dead_nc_out,
-                   int32_t* live_it_out) {
+                   int32_t* live_it_out, int bootstrap) {
   DH_CHECK_CTX(ctx);
   const bool want_pt = dead_id_out || dead_it_out || dead_nc_out || live_it_out;
   if (want_pt && !(dead_id_out && dead_it_out && dead_nc_out && live_it_out))
@@ -1257,11 +1615,21 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
   if (pd.ndim != ndim) return fail(ctx, DH_ERR_ARG, "problem ndim %d != %d", pd.ndim, ndim);
   // sampler 3 / 4 / 5 = rwalk / rslice / slice with the unit-cube phase and the proposals drawn from hiprand
   // Philox streams (throughput RNG mode); start points and frames keep their PCG64 streams
-  const bool philox = sampler >= 3 && sampler <= 5;  // 3 rwalk, 4 rslice, 5 slice: proposals from Philox streams
-  if (philox) sampler -= 3;
-  if (runs < 1 || nlive < 4 || queue_size < 1 || walks < 1 || sampler < 0 || sampler > 2 || !entropy_words ||
-      n_words < 1 || !records)
+  // sampler 6 / 7 = the uniform sampler inside the bound (UniformBoundSampler) from PCG64 / Philox streams
+  const bool philox = (sampler >= 3 && sampler <= 5) || sampler == 7;
+  if (sampler >= 6 && sampler <= 7)
+    sampler = 3;  // internal code of `unif`
+  else if (philox)
+    sampler -= 3;
+  else if (sampler > 2)
+    sampler = -1;
+  if (runs < 1 || nlive < 4 || queue_size < 1 || walks < 1 || sampler < 0 || sampler > 3 || !entropy_words ||
+      n_words < 1 || !records || bootstrap < 0 || bootstrap == 1)
     return fail(ctx, DH_ERR_ARG, "ns_ensemble: bad arguments");
+  if (sampler == 3 && ndim > kMaxRegDim)
+    return fail(ctx, DH_ERR_ARG, "ns_ensemble: sample='unif' in the device-resident loop needs ndim <= %d (ndim=%d)", kMaxRegDim, ndim);
+  if (bootstrap > 0 && ndim > 44)
+    return fail(ctx, DH_ERR_ARG, "ns_ensemble: bootstrap in the device-resident loop needs ndim <= 44 (ndim=%d)", ndim);
   // Above the register-resident dimensions (and for slice samplers at dimensions without an instantiation) the
   // walker launches go to the wave-per-walker kernels of wide.hip, which take the same per-run arrays; above
   // d = 44 the bound is the multi-workgroup Ellipsoid.update with the run mask (single ellipsoid only: the wide
@@ -1286,13 +1654,16 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
   a.first_eff = 10.0;
   a.first_ncall = 2ll * N;
   // update_bound_interval_ratio (internal_samplers.py:495-502, 581-588, 737-744) * nlive
-  a.update_interval = (long long)(sampler == 2 ? walks * D : walks) * N;
+  // (UniformBoundSampler keeps the base class's ratio 1, internal_samplers.py:88-94)
+  a.update_interval = (long long)(sampler == 3 ? 1 : sampler == 2 ? walks * D : walks) * N;
+  a.bootstrap = bootstrap;
   a.store_samples = dead_u_out ? 1 : 0;
   a.rebuild_sync = rebuild_sync ? 1 : 0;
+  a.serial_walk = (getenv("DH_NS_SERIAL") && atoi(getenv("DH_NS_SERIAL")) != 0) ? 1 : 0;
   a.prof = nullptr;
   if (getenv("DH_NS_PROF")) {
-    if (hipMalloc((void**)&a.prof, 16 * sizeof(long long)) != hipSuccess) a.prof = nullptr;
-    if (a.prof) (void)hipMemset(a.prof, 0, 16 * sizeof(long long));
+    if (hipMalloc((void**)&a.prof, 32 * sizeof(long long)) != hipSuccess) a.prof = nullptr;
+    if (a.prof) (void)hipMemset(a.prof, 0, 32 * sizeof(long long));
   }
   // ---- one allocation for all state ----
   auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
@@ -1316,7 +1687,9 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
                o_ba = take((size_t)R * me * dd * 8), o_bx = take((size_t)R * me * dd * 8),
                o_bl = take((size_t)R * me * D * 8), o_bg = take((size_t)R * me * 8),
                o_rec = take((size_t)R * 8 * 8), o_ent = take((size_t)n_words * 4),
-               o_fw = take((size_t)R * 3 * N * 8),
+               o_fw = take((size_t)R * 3 * N * 8), o_cum = take((size_t)R * me * 8), o_be = take((size_t)R * 32),
+               o_rs = take((size_t)R * 8),
+               o_boot = take(bootstrap > 0 ? bootstrap_ws_bytes(R, N, D, me, bootstrap) : 8),
                o_lit = take(want_pt ? (size_t)R * N * 4 : 8), o_pid = take(want_pt ? (size_t)R * a.cap * 4 : 8),
                o_pit = take(want_pt ? (size_t)R * a.cap * 4 : 8), o_pnc = take(want_pt ? (size_t)R * a.cap * 4 : 8);
   char* base = nullptr;
@@ -1361,6 +1734,9 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
   a.b_lv = (double*)(base + o_bg);
   a.records = (double*)(base + o_rec);
   a.fin_ws = (double*)(base + o_fw);
+  a.b_cum = (double*)(base + o_cum);
+  a.boot_ent = (uint64_t*)(base + o_be);
+  a.run_shift = (double*)(base + o_rs);
   if (want_pt) {
     a.live_it = (int*)(base + o_lit);
     a.dead_id = (int*)(base + o_pid);
@@ -1406,16 +1782,29 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
       rc = rebuild_launch_masked(ctx, R, a.live_u, N, D, bound_multi ? 0 : 1, me, a.nells, a.bstatus, a.b_ctrs,
                                  a.b_covs, a.b_ams, a.b_axes, a.b_axl, a.b_lv, a.rebuild_mask);
       if (rc) return cleanup(rc);
-      rc = enlarge_launch_masked(ctx, R, me, a.nells, D, a.b_covs, a.b_ams, a.b_axes, a.b_axl, a.b_lv,
-                                 a.enlarge_log, a.rebuild_mask);
-      if (rc) return cleanup(rc);
+      if (bootstrap > 0) {
+        // bound.update(points, bootstrap=B): the expansion factor from B resampled replicas per rebuilding run,
+        // then scale_to_logvol(logvol + ndim ln(expand)) where it exceeds 1 (bounding.py:381-400, 688-703)
+        rc = bootstrap_expand_launch(ctx, R, a.live_u, N, D, bound_multi, me, bootstrap, a.boot_ent, a.rebuild_mask,
+                                     base + o_boot, a.run_shift, nullptr, a.bstatus);
+        if (rc) return cleanup(rc);
+        rc = enlarge_launch_masked(ctx, R, me, a.nells, D, a.b_covs, a.b_ams, a.b_axes, a.b_axl, a.b_lv, 0.0,
+                                   a.rebuild_mask, a.run_shift);
+        if (rc) return cleanup(rc);
+      }
+      if (enlarge != 1.0) {  // sampler.py:506-508
+        rc = enlarge_launch_masked(ctx, R, me, a.nells, D, a.b_covs, a.b_ams, a.b_axes, a.b_axl, a.b_lv,
+                                   a.enlarge_log, a.rebuild_mask);
+        if (rc) return cleanup(rc);
+      }
       hipLaunchKernelGGL(ns_select, dim3(R), dim3(kT), 0, s, a);
-      hipLaunchKernelGGL(ns_gather, dim3((unsigned)(((size_t)R * K * D + 255) / 256)), dim3(256), 0, s, a);
+      if (sampler != 3)
+        hipLaunchKernelGGL(ns_gather, dim3((unsigned)(((size_t)R * K * D + 255) / 256)), dim3(256), 0, s, a);
       // Sampler.propose_live rebuilds the bound at once when a start point lies outside it (sampler.py:484-489:
       // a point accepted since the last update, beyond the enlarged ellipsoids).  Here the run is flagged and
       // rebuilds before its NEXT fill: the walkers of this fill are already chosen, and a queue of K proposals
       // is as stale in the reference.  (Register-resident dimensions.)
-      if (force_check) {
+      if (force_check && sampler != 3) {
         rc = contains_runs_launch(ctx, a.q_u0, R * K, D, K, a.b_ctrs, a.b_ams, bound_multi ? a.nells : nullptr, me,
                                   bound_multi ? 1 : 0, a.run_mode, MODE_BOUND, a.bstatus, a.force);
         if (rc) return cleanup(rc);
@@ -1436,7 +1825,16 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
                               a.run_mode, K, MODE_CUBE, philox ? &key_cube : nullptr);
         if (rc) return cleanup(rc);
       }
-      if (sampler == 0) {
+      if (sampler == 3) {
+        // UniformBoundSampler.sample (internal_samplers.py:243-340): draws from the run's bound until one beats
+        // the run's threshold; r_a = calls, r_b = flags
+        dh::PhiloxKey key_unif = key_slice;
+        key_unif.seed ^= 0x3C6EF372FE94F82Bull;
+        rc = unif_launch_runs(ctx, problem, R * K, D, D, R * me, a.b_ctrs, a.b_axes, a.b_ams, a.b_cum, 0.0, nullptr,
+                              a.q_rng, 0, a.r_u, a.r_v, a.r_logl, a.r_a, a.r_b, a.q_rng_out, a.run_loglstar,
+                              a.run_mode, K, MODE_BOUND, philox ? &key_unif : nullptr, bound_multi ? a.nells : nullptr,
+                              me);
+      } else if (sampler == 0) {
         // 32-bit draws one walker consumes per fill: per step hiprand_normal4 x ceil(D / 4) and one
         // hiprand_uniform_double (2 draws; padded to 4 so that a fill's block stays 4-aligned)
         key.offset = (unsigned long long)fill * (unsigned long long)walks * (unsigned long long)(4 * ((D + 3) / 4) + 4);
@@ -1497,11 +1895,12 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
   }
   if (n_fills_out) *n_fills_out = fill;
   if (a.prof) {
-    long long h[16];
+    long long h[32];
     (void)hipStreamSynchronize(s);
     (void)hipMemcpy(h, a.prof, sizeof h, hipMemcpyDeviceToHost);
-    fprintf(stderr, "ns_consume cycles (run 0, %lld fills): load+sort %lld | walk %lld | scan %lld | replay+state %lld | dead %lld | live store %lld ; fills integrated serially (all runs): %lld new plateau + %lld carried\n",
-            (long long)fill, h[0], h[1], h[2], h[3], h[4], h[5], h[8], h[9]);
+    fprintf(stderr, "ns_consume cycles (run 0, %lld fills): load+sort %lld | walk %lld | scan %lld | replay+state %lld | dead %lld | live store %lld ; fills integrated serially (all runs): %lld new plateau + %lld carried ; queues of run 0 left to the serial walk: %lld ; parallel walk: ranks %lld | counts %lld | scan+pick %lld | low ranks %lld | merge %lld | slots %lld\n",
+            (long long)fill, h[0], h[1], h[2], h[3], h[4], h[5], h[8], h[9], h[10], h[11], h[12], h[13], h[14], h[15], h[7]);
+    fprintf(stderr, "  load+sort = live keys %lld | sort %lld | queue + sums %lld\n", h[16], h[17], h[0]);
     (void)hipFree(a.prof);
   }
   return cleanup(DH_OK);

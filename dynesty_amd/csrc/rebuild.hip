@@ -2580,7 +2580,8 @@ __global__ void __launch_bounds__(64)
 __global__ void __launch_bounds__(1024)
     scale_logvol_kernel(int m, int D, double* covs, double* ams, double* axes, double* axlens,
                         double* logvols, const double* __restrict__ targets, double shift,
-                        const int* __restrict__ nells, int stride, const int* __restrict__ active) {
+                        const int* __restrict__ nells, int stride, const int* __restrict__ active,
+                        const double* __restrict__ run_shift) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double* fax = (double*)smem;  // D
   double* lax = fax + D;        // D  log axlens
@@ -2601,7 +2602,9 @@ __global__ void __launch_bounds__(1024)
   double* P = ams + (size_t)e * D * D;
   double* X = axes + (size_t)e * D * D;
   double* al = axlens + (size_t)e * D;
-  const double target = targets ? targets[e] : logvols[e] + shift;
+  // run_shift: a per-run addition to ln V (the bootstrap expansion); a run whose factor is 1 is left alone
+  if (run_shift && run_shift[e / stride] == 0.0 && shift == 0.0) return;
+  const double target = targets ? targets[e] : logvols[e] + (run_shift ? run_shift[e / stride] : 0.0) + shift;
   const double logf = target - logvols[e];
   const double max_log_axlen = log(sqrt((double)D) / 2.0);
   for (int k = lane; k < D; k += nt) lax[k] = log(al[k]);
@@ -2712,11 +2715,11 @@ int dh::rebuild_launch_masked(dh_ctx* ctx, int runs, const double* pts, int n, i
 
 int dh::enlarge_launch_masked(dh_ctx* ctx, int runs, int max_ells, const int32_t* nells, int d, double* covs,
                               double* ams, double* axes, double* axlens, double* logvols,
-                              double log_enlarge, const int* active) {
+                              double log_enlarge, const int* active, const double* run_shift) {
   const int m = runs * max_ells;
   hipLaunchKernelGGL(scale_logvol_kernel, dim3(m), dim3(d > 64 ? 1024 : 64), (size_t)2 * d * 8 + 64, ctx->stream, m, d,
                      covs, ams, axes, axlens, logvols, (const double*)nullptr, log_enlarge, nells, max_ells,
-                     active);
+                     active, run_shift);
   return hip_ok(ctx, hipGetLastError(), "enlarge launch") ? DH_OK : DH_ERR_HIP;
 }
 
@@ -3184,7 +3187,7 @@ int dh_enlarge_batch_dev(dh_ctx* ctx, int runs, int max_ells, const int32_t* nel
   const int m = runs * max_ells;
   hipLaunchKernelGGL(scale_logvol_kernel, dim3(m), dim3(d > 64 ? 1024 : 64), (size_t)2 * d * 8 + 64, ctx->stream, m, d,
                      covs, ams, axes, axlens, logvols, (const double*)nullptr, log_enlarge, nells,
-                     max_ells, (const int*)nullptr);
+                     max_ells, (const int*)nullptr, (const double*)nullptr);
   return hip_ok(ctx, hipGetLastError(), "enlarge launch") ? DH_OK : DH_ERR_HIP;
 }
 
@@ -3206,7 +3209,8 @@ int dh_scale_to_logvol(dh_ctx* ctx, int m, int d, double* covs, double* ams, dou
   const double* d_t = arena_up(ctx, targets, (size_t)m);
   if (!d_c || !d_p || !d_x || !d_al || !d_lv || !d_t) return DH_ERR_NOMEM;
   hipLaunchKernelGGL(scale_logvol_kernel, dim3(m), dim3(d > 64 ? 1024 : 64), (size_t)2 * d * 8 + 64, ctx->stream, m, d,
-                     d_c, d_p, d_x, d_al, d_lv, d_t, 0.0, (const int*)nullptr, 1, (const int*)nullptr);
+                     d_c, d_p, d_x, d_al, d_lv, d_t, 0.0, (const int*)nullptr, 1, (const int*)nullptr,
+                     (const double*)nullptr);
   if (!hip_ok(ctx, hipGetLastError(), "scale_to_logvol launch")) return DH_ERR_HIP;
   if (!down(ctx, covs, d_c, (size_t)m * dd) || !down(ctx, ams, d_p, (size_t)m * dd) ||
       !down(ctx, axes, d_x, (size_t)m * dd) || !down(ctx, axlens, d_al, (size_t)m * d) ||

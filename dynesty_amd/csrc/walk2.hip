@@ -396,9 +396,14 @@ struct UnifArgs {
   const uint64_t* zwi;
   const uint64_t* zfi;
   // ensemble form (ns.hip), as in RwalkArgs
+  // (a wavefront serves walkers of ONE run there: run = blockIdx / ceil(wpr / 64))
   const double* run_loglstar;
   const int* run_mode;
   int wpr, my_mode;
+  // per-run bounds of the ensemble form: run r owns the ellipsoids [r * run_me, r * run_me + M_r) of ctrs /
+  // axes_t / ams_p / cumprob, M_r = run_nells[r] (null: 1); run_me == 0: one bound (or the unit cube) for all
+  const int* run_nells = nullptr;
+  int run_me = 0;
   PhiloxKey ph;  // RNG_PHILOX
 };
 
@@ -406,28 +411,32 @@ template <int N, bool FULL, int KIND, int RNG>
 __global__ void __launch_bounds__(64, 2) unif_kernel(UnifArgs a) {
   __shared__ ZigLds zig;
   __shared__ double sx[N * 64];
+  const int lane = threadIdx.x;
+  int w = blockIdx.x * 64 + lane;
+  bool live = w < a.k;
+  double loglstar = a.loglstar;
+  int M = a.m;      // ellipsoids of this wavefront's bound (0: unit cube)
+  size_t eb = 0;    // first of them
   if (a.run_mode) {
-    // ensemble form: a workgroup (= one wavefront) none of whose walkers belongs to this launch leaves
-    // before it stages anything (the unit-cube launch of the resident loop cost 52 us per fill long after
-    // the last run had left that phase)
-    const int w0 = blockIdx.x * 64 + threadIdx.x;
-    const int wq = w0 < a.k ? w0 : a.k - 1;
-    if (!__any(a.run_mode[wq / a.wpr] == a.my_mode)) return;
+    // ensemble form: a wavefront of a run that does not belong to this launch leaves before it stages
+    // anything (the unit-cube launch of the resident loop cost 52 us per fill long after the last run had
+    // left that phase)
+    const int wpw = (a.wpr + 63) >> 6, run = blockIdx.x / wpw, iw = (blockIdx.x - run * wpw) * 64 + lane;
+    if (a.run_mode[run] != a.my_mode) return;
+    live = iw < a.wpr;
+    w = run * a.wpr + (live ? iw : 0);
+    loglstar = a.run_loglstar[run];
+    if (a.run_me > 0) {
+      M = a.run_nells ? a.run_nells[run] : 1;
+      eb = (size_t)run * a.run_me;
+    }
   }
   if constexpr (RNG == RNG_PCG64) zig_stage(&zig, a.zki, a.zwi, a.zfi);
-  const int lane = threadIdx.x;
-  const int w = blockIdx.x * 64 + lane;
-  const bool live = w < a.k;
-  const int wi = live ? w : a.k - 1;
+  const int wi = live ? w : (a.run_mode ? w : a.k - 1);
   const int n = FULL ? N : a.ndim, nc = FULL ? N : a.ncdim;
-  double loglstar = a.loglstar;
   bool done = false;
-  if (a.run_mode) {
-    const int run = wi / a.wpr;
-    if (a.run_mode[run] != a.my_mode) done = true;  // idle lane (keeps wave-level votes valid)
-    loglstar = a.run_loglstar[run];
-  }
-  const bool idle = done;
+  const bool idle = false;
+  const double* cum = a.cumprob ? a.cumprob + eb : nullptr;
   LaneGen<RNG> g;
   g.init(a.rng_in, (size_t)wi, &zig, a.ph);
   if constexpr (RNG == RNG_PCG64) {
@@ -445,7 +454,7 @@ __global__ void __launch_bounds__(64, 2) unif_kernel(UnifArgs a) {
     bool cand = false;  // x holds a candidate inside the cube
     if (!done) {
       ++tries;
-      if (a.m == 0) {
+      if (M == 0) {
         // unit cube: rstate.uniform(size=ndim)
 #pragma unroll 1
         for (int i = 0; i < n; ++i) sx[i * 64 + lane] = g.uniform();
@@ -512,10 +521,10 @@ __global__ void __launch_bounds__(64, 2) unif_kernel(UnifArgs a) {
           }
         } else {
         int idx = 0;
-        if (a.m > 1) {
+        if (M > 1) {
           // rand_choice (bounding.py:1300-1308): searchsorted(cumsum(pb), U)
           const double xr = g.uniform();
-          while (idx < a.m - 1 && a.cumprob[idx] < xr) ++idx;
+          while (idx < M - 1 && cum[idx] < xr) ++idx;
         }
         // randsphere: nc normals then one uniform
         double ss = 0.0;
@@ -532,19 +541,19 @@ __global__ void __launch_bounds__(64, 2) unif_kernel(UnifArgs a) {
         while (!mv) {
           const int cur = __builtin_amdgcn_readfirstlane(idx);
           if (cur == idx) {
-            matvec_sgpr<N>(as_const_uniform(a.axes_t + (size_t)cur * N * N), sx, lane, nc, acc);
+            matvec_sgpr<N>(as_const_uniform(a.axes_t + (eb + cur) * N * N), sx, lane, nc, acc);
             mv = true;
           }
         }
-        const double* c = a.ctrs + (size_t)idx * nc;
+        const double* c = a.ctrs + (eb + idx) * nc;
 #pragma unroll
         for (int i = 0; i < N; ++i) x[i] = (FULL || i < nc) ? fma(fac, acc[i], c[i]) : 0.5;
-        if (a.m > 1) {
+        if (M > 1) {
           // q = number of ellipsoids containing x (strict), 1/q acceptance
           int q = 0, qloose = 0;
-          for (int e = 0; e < a.m; ++e) {
-            cdptr ce = as_const(a.ctrs + (size_t)e * nc);
-            cdptr A = as_const(a.ams_p + (size_t)e * N * N);
+          for (int e = 0; e < M; ++e) {
+            cdptr ce = as_const(a.ctrs + (eb + e) * nc);
+            cdptr A = as_const(a.ams_p + (eb + e) * N * N);
             double quad = 0.0;
 #pragma unroll
             for (int i = 0; i < N; ++i) {
@@ -961,7 +970,8 @@ namespace {
 
 int unif_dispatch(dh_ctx* ctx, const UnifArgs& a, int N, bool philox = false) {
   const int k = a.k, ndim = a.ndim, ncdim = a.ncdim;
-  const dim3 grid((k + 63) / 64), block(64);
+  // ensemble form: whole wavefronts per run (a.wpr walkers each)
+  const dim3 grid(a.run_mode ? (k / a.wpr) * ((a.wpr + 63) / 64) : (k + 63) / 64), block(64);
   const bool full = (ndim == N && ncdim == N);
   const int kind = (full && !a.propose_only) ? problem_kind(a.prob.like_id, a.prob.prior_id) : KIND_GENERIC;
   // throughput mode: the generic kind of every dimension, and the BASELINE configs' own
@@ -1013,9 +1023,12 @@ int dh::unif_launch_runs(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, i
                          const int8_t* bc, const uint64_t* rng, int64_t max_tries, double* u, double* v,
                          double* logl, int32_t* ncalls, int32_t* flags, uint64_t* rng_out,
                          const double* run_loglstar, const int* run_mode, int wpr, int my_mode,
-                         const dh::PhiloxKey* philox) {
+                         const dh::PhiloxKey* philox, const int* run_nells, int run_me) {
   DH_CHECK_CTX(ctx);
   UnifArgs a;
+  a.run_nells = run_nells;
+  a.run_me = run_me;
+  if (run_mode && (wpr < 1 || k % wpr)) return fail(ctx, DH_ERR_ARG, "unif: k=%d is not runs x %d", k, wpr);
   a.ph = philox ? *philox : dh::PhiloxKey{0, 0, 0};
   if (!philox && !rng && k > 0) return fail(ctx, DH_ERR_ARG, "unif: no generator states");
   a.run_loglstar = run_loglstar;

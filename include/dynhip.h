@@ -418,16 +418,34 @@ int dh_ns_consume(dh_ctx* ctx, int runs, int nlive, int queue_size, double dlogz
  * advanced by update_interval, sampler.py:625-674); rebuild_sync = 1 lets every run
  * that already has a bound rebuild whenever ANY run of the ensemble is due (its
  * rebuild comes early, never late): a rebuild is a latency-bound tree construction
- * that costs about the same for one run or the whole ensemble. */
+ * that costs about the same for one run or the whole ensemble.
+ * sampler 6 (PCG64) / 7 (Philox): the uniform sampler inside the run's bound (UniformBoundSampler.sample,
+ * internal_samplers.py:243-340; rand_choice over the ellipsoids, randsphere, 1/q acceptance), ndim <= 32; the
+ * bound is rebuilt every nlive calls (its update_bound_interval_ratio is the base class's 1,
+ * internal_samplers.py:88-94), `walks` is ignored, a walker whose draw no ellipsoid holds fails its run as the
+ * reference's RuntimeError does.  bootstrap = B > 1: every rebuild is followed by the bootstrap expansion of
+ * bounding.py:381-400 / 688-703 -- B resampled replicas per run (bounding.py:1593-1648), all rebuilt in one ragged
+ * batch, the bound scaled by max(1, largest normalised distance of a left-out point)^ndim; the reference's default
+ * for sample='unif' is (enlarge 1, bootstrap 5), dynesty.py:169-200.  ndim <= 44.  0: none. */
 int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim,
-                   int queue_size, int sampler /* 0 rwalk, 1 rslice, 2 slice; + 3: unit-cube phase and proposals from hiprand Philox streams */,
+                   int queue_size, int sampler /* 0 rwalk, 1 rslice, 2 slice; + 3: unit-cube phase and proposals from hiprand Philox streams; 6 / 7 unif */,
                    int walks /* or slices */, int bound_multi,
                    int rebuild_sync /* 1: all runs rebuild together, see below */, double dlogz,
                    double enlarge, int64_t max_fills, int64_t max_iter,
                    const uint32_t* entropy_words, int n_words, uint32_t first_run,
                    double* records, double* dead_logl_out, double* live_logl_out,
                    double* dead_u_out, double* live_u_out, int64_t* n_fills_out, int32_t* dead_id_out,
-                   int32_t* dead_it_out, int32_t* dead_nc_out, int32_t* live_it_out);
+                   int32_t* dead_it_out, int32_t* dead_nc_out, int32_t* live_it_out, int bootstrap);
+
+/* The bootstrap expansion factor on its own (host pointers; what the resident loop runs after a rebuild):
+ * for each of `runs` point sets (runs x n x d) the max over `bootstrap` replicas of max(1, largest normalised
+ * distance of a left-out point to the replica's Ellipsoid (multi = 0) / nearest of its MultiEllipsoid's ellipsoids
+ * (multi = 1)) -- _ellipsoid_bootstrap_expand, bounding.py:1619-1648.  Replica b of run r resamples with the
+ * PCG64 stream seeded (ent[4r], ent[4r+1] + b) with increment words (ent[4r+2], ent[4r+3] + 2b)
+ * (oracle/nested_ref.py boot_generator).  expand: runs doubles; n_in (optional): runs x bootstrap sample sizes
+ * (distinct points drawn, after _bootstrap_points' repairs). */
+int dh_bootstrap_expand(dh_ctx* ctx, int runs, const double* pts, int n, int d, int multi, int bootstrap,
+                        const uint64_t* ent, double* expand, int32_t* n_in);
 
 /* ---- RadFriends / SupFriends (bounding.py:734-1263, 1651-1702) ----------------
  * kind: 0 = 'balls' (RadFriends, Euclidean norm), 1 = 'cubes' (SupFriends, max norm).

@@ -254,3 +254,35 @@ def logvol_from_record(dead_logl, dead_id, live_logl, nlive):
         nrest = N - s.plateau_counter
         rel = np.concatenate([rel, rel[-1] + np.log1p(-(1 + np.arange(nrest)) / (nrest + 1))])
     return np.concatenate([out, rel + s.logvol])
+
+
+# ---------------------------------------------------------------------------
+# streams of the resident loop's bootstrap replicas (dynesty_amd/csrc/boot.hip)
+# ---------------------------------------------------------------------------
+_PCG_MULT = 0x2360ED051FC65DA44385DF649FCCF645
+_M128 = (1 << 128) - 1
+
+
+def boot_generator(ent, b):
+    """The NumPy Generator replica `b` of a rebuild resamples with: PCG64 seeded by
+    pcg_setseq_128_srandom_r(initstate = (ent[0], ent[1] + b), initseq = (ent[2], ent[3] + 2 b)), the four
+    64-bit words `ent` being what the run drew for this rebuild (high word first)."""
+    import numpy as np
+    e = [int(x) for x in ent]
+    m64 = (1 << 64) - 1
+    initstate = (e[0] << 64) | ((e[1] + b) & m64)
+    initseq = (e[2] << 64) | ((e[3] + 2 * b) & m64)
+    inc = ((initseq << 1) | 1) & _M128
+    state = inc  # 0 * MULT + inc
+    state = (state + initstate) & _M128
+    state = (state * _PCG_MULT + inc) & _M128
+    bg = np.random.PCG64()
+    bg.state = {'bit_generator': 'PCG64', 'state': {'state': state, 'inc': inc}, 'has_uint32': 0, 'uinteger': 0}
+    return np.random.Generator(bg)
+
+
+def boot_expand(points, ent, bootstrap, multi):
+    """max over the replicas of _ellipsoid_bootstrap_expand (ref: bounding.py:381-400 / 688-703, 1619-1648)
+    with the replica streams of boot_generator."""
+    from . import bounding_ref as B
+    return max(B.bootstrap_expand(multi, points, boot_generator(ent, b)) for b in range(bootstrap))

@@ -41,12 +41,12 @@ def test_failed_runs_raise_or_are_masked():
 
 
 def test_ns_ensemble_rejects_unsupported_bound_and_sampler():
-    """The device-resident loop knows 'multi' / 'single' and rwalk / rslice / slice only; anything
+    """The device-resident loop knows 'multi' / 'single' and rwalk / rslice / slice / unif only; anything
     else must raise instead of silently running a single ellipsoid."""
     ctx = _lib.Context.__new__(_lib.Context)  # no device needed: validation comes first
 
     class P:
         ndim = 3
-    for kw in (dict(bound='balls'), dict(bound='cubes'), dict(sample='unif'), dict(bound='none')):
+    for kw in (dict(bound='balls'), dict(bound='cubes'), dict(sample='hslice'), dict(bound='none')):
         with pytest.raises(ValueError, match="not supported"):
             _lib.Context.ns_ensemble(ctx, P(), 2, 100, 16, **kw)

@@ -154,3 +154,25 @@ def test_c4_queue_size_effect_is_the_references_own(ctx):
         backend.set_backend(None)
     assert abs(r.logz - z4.mean()) < 3.0 * err * math.sqrt(1 + 1 / len(z4)), (r.logz, z4)
     assert abs(r.niter / np.mean([x["niter"] for x in k4]) - 1) < 0.05
+
+
+@pytest.mark.parametrize("bnd,rng", [("single", "pcg64"), ("multi", "pcg64"), ("single", "philox")])
+def test_c1_device_unif_ensemble_vs_reference_ensemble(ctx, bnd, rng):
+    """BASELINE config C1 with the reference's defaults for sample='unif' (bootstrap 5, enlarge 1) through the
+    device-resident loop, against 32 runs of the real reference at the same queue size (K = 64) and serial."""
+    g = json.load(open(os.path.join(GOLD, "c1_logz_ref.json")))["ensembles"]
+    prob = inputs.problem("C1")
+    r = ctx.ns_ensemble(prob, 64, 500, 64, bound=bnd, sample="unif", entropy=[2026, 1], dlogz=0.01, rng=rng)
+    assert np.all(r["status"] == 0)
+    lz = r["logz"]
+    mean, se = lz.mean(), lz.std(ddof=1) / math.sqrt(len(lz))
+    for key in (f"{bnd}_K64", f"{bnd}_K1"):
+        ref = g[key]
+        assert abs(mean - ref["mean"]) < bound(se, ref["se"]), (key, mean, se, ref["mean"], ref["se"])
+    ref = g[f"{bnd}_K64"]
+    assert 0.6 < lz.std(ddof=1) / ref["std"] < 1.6
+    assert abs(r["logzerr"].mean() - ref["mean_logzerr"]) < 0.01
+    assert abs(r["niter"].mean() / ref["mean_niter"] - 1) < 0.02
+    # calls and bounds per run: the bootstrap-expanded bound is as tight as the reference's
+    assert abs(r["ncall"].mean() / ref["mean_ncall"] - 1) < 0.08
+    assert abs(r["nbound"].mean() / ref["mean_nbound"] - 1) < 0.25
