@@ -600,11 +600,11 @@ def main():
         e2e["rebuild_sync"] = e2e_leg(True)
         # ... and with the proposals drawn from hiprand Philox streams (throughput RNG mode)
         e2e["throughput_rng"] = e2e_leg(False, rng="philox")
-        # BASELINE configs C3 (eggbox 2-D, multi / rslice, nlive 5000) and C4 (200-D iid Normal, Normal prior,
+        # BASELINE configs C1 (3-D Normal, single / unif + bootstrap 5), C3 (eggbox 2-D, multi / rslice, nlive 5000) and C4 (200-D iid Normal, Normal prior,
         # single / rslice, nlive 4000) through the same loop, at N = 1 only (no rank waits for another at
         # the end of a scaling run): every run to dlogz = 0.01, the real reference's ensembles beside them
         if rank == 0 and world == 1:
-            for name, leg in (("config_C3", c3_leg), ("config_C4", c4_leg)):
+            for name, leg in (("config_C1", c1_leg), ("config_C3", c3_leg), ("config_C4", c4_leg)):
                 try:
                     e2e[name] = leg(ctx)
                 except Exception as exc:  # a side leg must not take the headline down with it
@@ -733,6 +733,31 @@ def c3_leg(ctx, runs=16, queue=1024):
         ens = json.load(open(ref))["ensembles"]
         out["logz_reference"] = {k: {"mean": e["mean"], "se": e["se"], "n": e["n"],
                                      "mean_seconds_1core": e["mean_seconds_1core"]} for k, e in ens.items()}
+    return out
+
+
+def c1_leg(ctx, runs=64, queue=64):
+    """BASELINE C1 (the reference's own CPU-runnable case) with the reference's defaults for sample='unif':
+    bootstrap 5, enlarge 1 -- every rebuild of the loop runs 5 resampled replicas per run (boot.hip)."""
+    from dynesty_amd import problems
+    prob = problems.gauss_iid(3, 10.0, "C1")
+    kw = dict(bound='single', sample='unif', dlogz=0.01)
+    ctx.ns_ensemble(prob, 2, 500, queue, entropy=[3], max_fills=2, **kw)  # allocations, code objects
+    t0 = time.perf_counter()
+    r = ctx.ns_ensemble(prob, runs, 500, queue, entropy=[21], **kw)
+    dt = time.perf_counter() - t0
+    out = {"what": "3-D unit Normal, prior +-10, nlive 500, single ellipsoid + bootstrap 5, uniform sampler, "
+                   "device-resident loop",
+           "runs": runs, "queue_size": queue, "seconds": dt, "seconds_per_run": dt / runs,
+           "likelihood_calls_per_s": float(r["ncall"].sum() / dt), "status_ok": bool((r["status"] == 0).all()),
+           "logz_mean": float(r["logz"].mean()), "logz_se": float(r["logz"].std(ddof=1) / math.sqrt(runs)),
+           "logz_truth": float(prob.logz_truth), "mean_bound_updates": float(np.mean(r["nbound"]))}
+    ref = os.path.join(ROOT, "tests", "golden", "c1_logz_ref.json")
+    if os.path.exists(ref):
+        ens = json.load(open(ref))["ensembles"]
+        out["logz_reference"] = {k: {"mean": e["mean"], "se": e["se"], "n": e["n"],
+                                     "mean_seconds_1core": e["mean_seconds_1core"]} for k, e in ens.items()
+                                 if k.startswith("single")}
     return out
 
 

@@ -3,7 +3,7 @@
 
     rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_f -- python bench.py --lean --preroll 0 --steps 3 --warmup 1
     rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_w -- python bench.py --lean --preroll 0 --steps 3 --warmup 1
-    python tools/pmc_traffic.py gpurun_out/pmc_f gpurun_out/pmc_w > profiles/r02/pmc_traffic.json
+    python tools/pmc_traffic.py gpurun_out/pmc_f gpurun_out/pmc_w > profiles/r03/pmc_traffic.json
 
 gfx950 correction: FETCH_SIZE counts 128-byte requests as 64 B -> x2; both counters are in KB."""
 import csv, glob, json, sys
@@ -27,7 +27,8 @@ out = {"command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output
        "correction": "gfx950: FETCH_SIZE counts 128-B requests at 64 B -> x2 (MI355X_MICROARCH.md, HBM section); "
                      "WRITE_SIZE uncorrected; both in KB",
        "kernels": {}}
-rw = [k for k in fetch if k.startswith("rwalk_kernel<25, true, 1")]
+# the walk kernel of the bench's launch shape: four lanes per walker at the gate queue (round 3), else one per lane
+rw = [k for k in fetch if k.startswith("rwalkq_kernel<7")] or [k for k in fetch if k.startswith("rwalk_kernel<25, true, 1")]
 steps = len(fetch.get(rw[0], [])) if rw else 1
 for name in sorted(set(fetch) | set(write)):
     fk = sum(v for _, v in fetch.get(name, []))
@@ -38,11 +39,11 @@ for name in sorted(set(fetch) | set(write)):
                             "traffic_bytes_per_launch": (2 * fk + wk) * 1024 / max(n, 1),
                             "traffic_bytes_per_bench_step": (2 * fk + wk) * 1024 / steps}
 rb = [k for k in out["kernels"] if k.split("<")[0] in ("k_root_parts", "k_split", "k_ell", "k_finish", "k_out_eig",
-                                                      "k_root_eig")]
+                                                      "k_root_eig", "k_tree")]
 out["rwalk_launches_profiled"] = steps
 nrb = out["kernels"].get("k_root_parts", {}).get("launches", 0)
 out["rebuild_pipelines_profiled"] = nrb
-# one pipeline = k_root_parts (+ k_root_eig on the side stream) + levels x (k_split, k_ell<false>, k_ell<true>) + k_finish + k_out_eig
+# one pipeline = k_root_parts (+ k_root_eig on the side stream) + levels x (k_split, k_ell<false>) + k_tree + k_finish + k_out_eig
 out["rebuild_pipeline_bytes_per_launch_sequence"] = sum(
     out["kernels"][k]["traffic_bytes_per_launch"] * out["kernels"][k]["launches"] for k in rb) / max(nrb, 1)
 for k in out["kernels"].values():
