@@ -27,6 +27,8 @@ def pytest_collection_finish(session):
     torch first)."""
     if not any(item.get_closest_marker("gpu") for item in session.items):
         return
+    if os.environ.get("DH_TEST_NO_TORCH"):  # sanitizer runs (make asan): the system runtime only
+        return
     try:
         import torch
         if torch.cuda.is_available():

@@ -54,3 +54,31 @@ def test_rebuild_node_kernel_keeps_two_workgroups_per_cu():
     assert len(key) == 1, list(res)
     r = res[key[0]]
     assert r["Occupancy [waves/SIMD]"] >= 2 and r["ScratchSize [bytes/lane]"] == 0, r
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc")
+def test_rwalkq_kernel_keeps_two_wavefronts_per_simd():
+    """The four-lanes-per-walker kernel of the bench's launch shape (NR = 7: 25-D; KIND 1 = correlated Normal /
+    affine prior): two wavefronts per SIMD is what the form is for; the Normal prior's erfcinv once took it to
+    256 VGPRs + 160 spilled (it is excluded from this kernel since)."""
+    res = usage("walkq.hip")
+    for rng in ("0", "1"):
+        key = [k for k in res if "13rwalkq_kernelILi7ELi1ELi" + rng in k]
+        assert len(key) == 1, list(res)
+        r = res[key[0]]
+        assert r["VGPRs"] <= 256 and r["Occupancy [waves/SIMD]"] >= 2, r
+        assert r["VGPRs Spill"] == 0, r
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc")
+def test_ns_consume_does_not_spill_vector_registers():
+    """ns_consume carries the register sort as a non-inlined call (its own allocation: inlined, the 236-VGPR kernel
+    made the same code 2.6x slower); neither may spill vector registers."""
+    res = usage("ns.hip")
+    key = [k for k in res if "10ns_consume" in k]
+    assert len(key) == 1, list(res)
+    # (the call ABI's save area is scratch: 368 B per lane measured)
+    assert res[key[0]]["VGPRs Spill"] == 0 and res[key[0]]["ScratchSize [bytes/lane]"] <= 1024, res[key[0]]
+    sorts = [k for k in res if "sort_slots" in k]
+    for k in sorts:
+        assert res[k]["VGPRs Spill"] == 0, (k, res[k])
