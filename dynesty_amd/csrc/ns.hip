@@ -32,7 +32,7 @@ using namespace dh;
 namespace {
 
 constexpr int kT = 256;
-enum : int { MODE_CUBE = 0, MODE_BOUND = 1, MODE_DONE = 2, MODE_FAILED = 3 };
+enum : int { MODE_CUBE = 0, MODE_BOUND = 1, MODE_DONE = 2, MODE_FAILED = 3, MODE_WAIT = 4 /* run_mode only: sits this fill out */ };
 
 struct NsRun {
   double logvol, logz, h, lmax, scale, loglstar, dead_prev;
@@ -59,6 +59,7 @@ struct NsArgs {
   int store_samples;
   long long* prof;   // optional (DH_NS_PROF=1): cycle counters of ns_consume's phases, run 0
   int rebuild_sync;  // 1: all bound-mode runs rebuild whenever any run is due (see ns_prepare)
+  int overlap;       // 1: a run whose bound is being rebuilt sits the fill out (its rebuild runs beside the others' walk)
   int serial_walk;   // diagnostic (DH_NS_SERIAL=1): ns_consume walks every queue with the one-wavefront routine
   NsRun* st;
   double* live_u;
@@ -288,7 +289,7 @@ __global__ void __launch_bounds__(kT) ns_prepare(NsArgs a) {
     r.need_rebuild = need;
     if (a.force) a.force[run] = 0;
     a.rebuild_mask[run] = need;
-    a.run_mode[run] = r.mode;
+    a.run_mode[run] = (a.overlap && need) ? MODE_WAIT : r.mode;
     a.run_loglstar[run] = r.loglstar;
     a.run_scale[run] = r.scale;
     a.run_doubling[run] = r.doubling;
@@ -313,6 +314,7 @@ __global__ void __launch_bounds__(kT) ns_select(NsArgs a) {
   NsRun& r = a.st[run];
   const int mode = r.mode;
   if (mode != MODE_CUBE && mode != MODE_BOUND) return;
+  if (a.overlap && r.need_rebuild) return;  // its bound is under construction: the run proposes nothing this fill
   if (mode == MODE_BOUND && a.bstatus[run] != DH_OK) return;  // ns_prepare fails the run next fill
   int M = 1;
   if (t == 0) {
@@ -389,6 +391,7 @@ __global__ void __launch_bounds__(256) ns_gather(NsArgs a) {
   const size_t q = e / D;
   const int j = (int)(e - q * D), run = (int)(q / K);
   if (a.st[run].mode != MODE_BOUND || a.bstatus[run] != DH_OK) return;
+  if (a.overlap && a.st[run].need_rebuild) return;
   a.q_u0[e] = a.live_u[((size_t)run * N + a.r_d[q]) * D + j];
 }
 
@@ -887,6 +890,7 @@ __global__ void __launch_bounds__(kT) ns_consume(NsArgs a) {
   NsRun& r = a.st[run];
   const int mode = r.mode;
   if (mode != MODE_CUBE && mode != MODE_BOUND) return;
+  if (a.overlap && r.need_rebuild) return;
   if (mode == MODE_BOUND && a.bstatus[run] != DH_OK) return;
   long long pt_ = a.prof ? clock64() : 0;
   int P = 1;
@@ -1660,6 +1664,15 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
   a.store_samples = dead_u_out ? 1 : 0;
   a.rebuild_sync = rebuild_sync ? 1 : 0;
   a.serial_walk = (getenv("DH_NS_SERIAL") && atoi(getenv("DH_NS_SERIAL")) != 0) ? 1 : 0;
+  // Runs are independent, so WHEN a run's bound is rebuilt relative to the other runs' walks is free: a run that is
+  // due sits the fill out (run_mode MODE_WAIT) while its rebuild -- a latency chain that leaves most of the chip idle
+  // -- runs on a second stream beside the other runs' walkers, and walks from the new bound in the next fill.  Its own
+  // sequence (rebuild, then walk from the same live set with the same generator state) is unchanged: with PCG64
+  // streams every run's result is bit-identical to the serial schedule's (tests).  MEASURED, AND OFF BY DEFAULT
+  // (DH_NS_OVERLAP=1 switches it on): a rebuild beside a walk slows both (77 KB of LDS and 256 VGPRs per rebuild
+  // workgroup against two 230-VGPR walk workgroups per CU), and every run spends one more fill per bound update --
+  // 64 C2 runs 0.336 -> 0.328 s, 16 eggbox runs 0.127 -> 0.160 s, 16 C4 runs 11.1 -> 11.3 s.
+  a.overlap = (getenv("DH_NS_OVERLAP") && atoi(getenv("DH_NS_OVERLAP")) != 0) ? 1 : 0;
   a.prof = nullptr;
   if (getenv("DH_NS_PROF")) {
     if (hipMalloc((void**)&a.prof, 32 * sizeof(long long)) != hipSuccess) a.prof = nullptr;
@@ -1695,11 +1708,23 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
   char* base = nullptr;
   (void)hipSetDevice(ctx->device);
   if (!hip_ok(ctx, hipMalloc((void**)&base, off), "hipMalloc(ns state)")) return DH_ERR_NOMEM;
+  hipStream_t main_stream = ctx->stream, rb_stream = nullptr;
+  hipEvent_t ev_prep = nullptr, ev_rb = nullptr;
   auto cleanup = [&](int rc) {
+    ctx->stream = main_stream;
+    if (rb_stream) (void)hipStreamSynchronize(rb_stream);
     (void)hipStreamSynchronize(ctx->stream);
+    if (ev_prep) (void)hipEventDestroy(ev_prep);
+    if (ev_rb) (void)hipEventDestroy(ev_rb);
+    if (rb_stream) (void)hipStreamDestroy(rb_stream);
     (void)hipFree(base);
     return rc;
   };
+  if (a.overlap &&
+      (!hip_ok(ctx, hipStreamCreateWithFlags(&rb_stream, hipStreamNonBlocking), "hipStreamCreate(rebuild)") ||
+       !hip_ok(ctx, hipEventCreateWithFlags(&ev_prep, hipEventDisableTiming), "hipEventCreate") ||
+       !hip_ok(ctx, hipEventCreateWithFlags(&ev_rb, hipEventDisableTiming), "hipEventCreate")))
+    return cleanup(DH_ERR_HIP);
   a.st = (NsRun*)(base + o_st);
   a.live_u = (double*)(base + o_lu);
   a.live_v = (double*)(base + o_lv);
@@ -1778,7 +1803,16 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
   const bool force_check = !(getenv("DH_NS_FORCE") && atoi(getenv("DH_NS_FORCE")) == 0);  // diagnostic: 0 = no forced rebuilds
   while (fill < fills_cap && ndone < R) {
     for (int burst = 0; burst < 8 && fill < fills_cap; ++burst, ++fill) {
+      if (a.overlap && fill > 0 && !hip_ok(ctx, hipStreamWaitEvent(s, ev_rb, 0), "hipStreamWaitEvent(rebuild)"))
+        return cleanup(DH_ERR_HIP);
       hipLaunchKernelGGL(ns_prepare, dim3(1), dim3(kT), 0, s, a);
+      if (a.overlap) {
+        // the bound work of this fill goes to the second stream (everything below enqueues on ctx->stream)
+        if (!hip_ok(ctx, hipEventRecord(ev_prep, s), "hipEventRecord") ||
+            !hip_ok(ctx, hipStreamWaitEvent(rb_stream, ev_prep, 0), "hipStreamWaitEvent(prepare)"))
+          return cleanup(DH_ERR_HIP);
+        ctx->stream = rb_stream;
+      }
       rc = rebuild_launch_masked(ctx, R, a.live_u, N, D, bound_multi ? 0 : 1, me, a.nells, a.bstatus, a.b_ctrs,
                                  a.b_covs, a.b_ams, a.b_axes, a.b_axl, a.b_lv, a.rebuild_mask);
       if (rc) return cleanup(rc);
@@ -1796,6 +1830,10 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
         rc = enlarge_launch_masked(ctx, R, me, a.nells, D, a.b_covs, a.b_ams, a.b_axes, a.b_axl, a.b_lv,
                                    a.enlarge_log, a.rebuild_mask);
         if (rc) return cleanup(rc);
+      }
+      if (a.overlap) {
+        ctx->stream = main_stream;
+        if (!hip_ok(ctx, hipEventRecord(ev_rb, rb_stream), "hipEventRecord")) return cleanup(DH_ERR_HIP);
       }
       hipLaunchKernelGGL(ns_select, dim3(R), dim3(kT), 0, s, a);
       if (sampler != 3)
@@ -1856,6 +1894,8 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
     ndone = h_state[0];
     if (!h_state[1]) cube_phase = false;  // (as of the last ns_prepare: every run has its first bound)
   }
+  if (a.overlap && fill > 0 && !hip_ok(ctx, hipStreamWaitEvent(s, ev_rb, 0), "hipStreamWaitEvent(rebuild)"))
+    return cleanup(DH_ERR_HIP);
   hipLaunchKernelGGL(ns_finish, dim3(R), dim3(kT), lds_fin, s, a);
   if (!hip_ok(ctx, hipGetLastError(), "ns launch") ||
       !hip_ok(ctx, hipMemcpyAsync(records, a.records, (size_t)R * 64, hipMemcpyDeviceToHost, s), "D2H records"))

@@ -192,3 +192,19 @@ def test_philox_proposals_in_the_device_loop(ctx):
     pcg = ctx.ns_ensemble(prob, 16, **dict(kw, rng="pcg64"))
     assert (pcg["logz"] != lz).all()
     # (rslice / slice with rng='philox': tests/test_gpu_philox.py::test_philox_resident_loop_all_samplers)
+
+
+def test_rebuild_beside_the_walk_gives_the_same_runs(monkeypatch):
+    """DH_NS_OVERLAP=1 (measured, off by default): a run whose bound is due sits one fill out while its rebuild runs on
+    a second stream beside the other runs' walkers.  Its own sequence is unchanged, so with PCG64 streams every run's
+    result is bit-identical to the serial schedule's."""
+    from dynesty_amd import _lib
+    prob = inputs.problem("G5")
+    kw = dict(nlive=300, queue_size=64, walks=20, bound="multi", entropy=[5, 5], dlogz=0.1)
+    a = _lib.Context(0).ns_ensemble(prob, 8, **kw)
+    monkeypatch.setenv("DH_NS_OVERLAP", "1")
+    b = _lib.Context(0).ns_ensemble(prob, 8, **kw)
+    np.testing.assert_array_equal(a["logz"], b["logz"])
+    np.testing.assert_array_equal(a["ncall"], b["ncall"])
+    np.testing.assert_array_equal(a["nbound"], b["nbound"])
+    assert b["nfills"] > a["nfills"]

@@ -42,6 +42,29 @@ int main() {
     std::printf("bootstrap_expand: rc %d, expand %.6f\n", rc, expand);
     if (rc) return 1;
   }
+  // the device-resident loop on the 3-D unit Normal (prior +-10): unif + bootstrap 5, and rwalk with per-point output
+  {
+    const double like_par[1] = {-2.756815599614018};  // -1.5 ln(2 pi)
+    const double prior_par[2] = {10.0, 0.0};
+    const int prob = dh_problem_create(ctx, 3, 0 /* iid Normal */, like_par, 1, 1 /* affine */, prior_par, 2);
+    if (prob < 0) return 1;
+    const int runs = 3, nlive = 200, K = 48;
+    const int64_t max_iter = 20000;
+    const uint32_t words[2] = {7u, 11u};
+    for (int sampler : {6, 0}) {
+      std::vector<double> rec((size_t)runs * 8), dead((size_t)runs * max_iter), live((size_t)runs * nlive),
+          dead_u((size_t)runs * max_iter * 3), live_u((size_t)runs * nlive * 3);
+      std::vector<int32_t> did((size_t)runs * max_iter), dit(did.size()), dnc(did.size()), lit((size_t)runs * nlive);
+      int64_t nf = 0;
+      rc = dh_ns_ensemble(ctx, prob, runs, nlive, 3, K, sampler, 23, sampler == 0, 0, 0.1, sampler == 6 ? 1.0 : 1.25, 0,
+                          max_iter, words, 2, 0, rec.data(), dead.data(), live.data(), dead_u.data(), live_u.data(), &nf,
+                          did.data(), dit.data(), dnc.data(), lit.data(), sampler == 6 ? 5 : 0);
+      std::printf("ns_ensemble sampler %d: rc %d, %lld fills, ln Z %.3f %.3f %.3f (truth -8.987)\n", sampler, rc,
+                  (long long)nf, rec[0], rec[8], rec[16]);
+      if (rc) return 1;
+    }
+    dh_problem_destroy(ctx, prob);
+  }
   dh_destroy(ctx);
   std::printf("asan smoke done\n");
   return 0;
