@@ -388,7 +388,7 @@ def launch_selftest(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--steps", type=int, default=350)  # > 1 s of timed region at 3.1 ms per step
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--runs", type=int, default=64,
                     help="independent C2 runs per GPU (C5 shard = 64)")
@@ -439,6 +439,14 @@ def main():
         cpu = cpu_baseline(prob, u0c, args.nlive, RWALK_SCALE, loglstar_c, args.walks, args.cpu_seconds)
         del u0c
     import torch
+    # LOCAL_RANK indexes the devices this process can SEE: with HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES pre-set by a
+    # scheduler the visible list is renumbered from 0 for torch and for libdynhip alike (same runtime rule), so the
+    # only thing that can go wrong is a rank without a device of its own -- said here, not as an ordinal error later
+    nvis = torch.cuda.device_count()
+    if local_rank >= nvis:
+        raise SystemExit(f"rank {rank}: LOCAL_RANK={local_rank} but only {nvis} device(s) are visible "
+                         f"(HIP_VISIBLE_DEVICES={os.environ.get('HIP_VISIBLE_DEVICES')!r}, "
+                         f"ROCR_VISIBLE_DEVICES={os.environ.get('ROCR_VISIBLE_DEVICES')!r})")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # One process group for every world size, 1 included: the record exchange below is then always an

@@ -79,3 +79,24 @@ def test_ragged_gather_and_merge_through_rccl(pg, ctx):
     for key in ("logl", "logwt", "logz", "samples_u", "samples_id", "samples_it", "ncall"):
         np.testing.assert_array_equal(m_coll[key], m_none[key])
     assert abs(m_coll.logz[-1] - prob.logz_truth) < 0.8
+
+
+def test_bench_under_a_preset_visible_device_list():
+    """A scheduler that pre-sets HIP_VISIBLE_DEVICES renumbers the devices from 0 for torch and for libdynhip alike:
+    the bench (own process: LOCAL_RANK -> torch.cuda.set_device -> dh_create) runs and gathers through RCCL there;
+    a rank without a visible device of its own says so."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--lean", "--steps", "3", "--warmup", "1", "--preroll", "2"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["rccl_ranks"] == 1 and line["value"] > 0
+    bad = subprocess.run(cmd, env=dict(env, LOCAL_RANK="1", RANK="0", WORLD_SIZE="1"), capture_output=True, text=True,
+                         timeout=600)
+    assert bad.returncode != 0 and "only 1 device(s) are visible" in bad.stderr
