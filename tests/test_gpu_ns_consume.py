@@ -57,7 +57,8 @@ def test_replay_of_a_real_reference_fill(ctx, tag):
     np.testing.assert_array_equal(live[0], ref_live)
 
 
-@pytest.mark.parametrize("nlive,K,runs", [(300, 100, 5), (2000, 512, 3), (64, 17, 4)])
+@pytest.mark.parametrize("nlive,K,runs", [(300, 100, 5), (2000, 512, 3), (64, 17, 4), (100, 256, 3), (1000, 2048, 2),
+                                          (5000, 1024, 2)])
 def test_fill_chains_vs_oracle(ctx, nlive, K, runs):
     """Several runs, consecutive fills, each run's state carried from fill to fill on both sides.
     The queue mixes entries above and below the moving threshold (stale ones are discarded);
