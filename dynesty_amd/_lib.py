@@ -98,7 +98,7 @@ SIGNATURES = {
                            _vp, _vp, _vp, _vp]),
     "dh_ns_ensemble": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _dbl, _dbl,
                             C.c_int64, C.c_int64, _vp, _i, _u32, _vp, _vp,
-                            _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i]),
+                            _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i]),
     "dh_bootstrap_expand": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "dh_friends_update": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp,
                                _vp, _vp, _vp, _vp]),
@@ -789,8 +789,12 @@ class Context:
                     bound='multi', dlogz=0.01, enlarge=None, entropy=(21,),
                     first_run=0, max_fills=0, max_iter=400000,
                     want_dead_logl=False, sample='rwalk', slices=None,
-                    rebuild_sync=False, want_samples=False, rng='pcg64', bootstrap=None):
+                    rebuild_sync=False, want_samples=False, rng='pcg64', bootstrap=None, rebuild_every=0):
         """Device-resident ensemble of static NS runs (dh_ns_ensemble).
+
+        rebuild_every=n: bounds are built every n-th fill and runs that become due in
+        between wait -- per-run results unchanged (bit-identical with PCG64 streams),
+        fewer and fuller rebuild fills; 0 = chosen from the run's shape.
 
         sample: 'rwalk' | 'rslice' | 'slice' | 'unif'.  enlarge / bootstrap default as the reference's
         _get_enlarge_bootstrap (dynesty.py:169-200): (1.25, 0), and (1, 5) for 'unif'.
@@ -841,7 +845,7 @@ class Context:
             1 if rebuild_sync else 0, float(dlogz), float(enlarge), int(max_fills), int(max_iter),
             _ptr(words), words.size, int(first_run), _ptr(rec), _ptr(dead),
             _ptr(livel), _ptr(dead_u), _ptr(live_u), C.byref(nf), _ptr(pid), _ptr(pit), _ptr(pnc),
-            _ptr(lit), int(bootstrap)))
+            _ptr(lit), int(bootstrap), int(rebuild_every)))
         out = dict(logz=rec[:, 0], logzerr=rec[:, 1],
                    niter=rec[:, 2].astype(np.int64),
                    ncall=rec[:, 3].astype(np.int64), h=rec[:, 4],

@@ -38,7 +38,7 @@ struct NsRun {
   double logvol, logz, h, lmax, scale, loglstar, dead_prev;
   long long it, ncall, ncall_last_update;
   int mode, need_rebuild, nbound, nfill;
-  int acc, rej, doubling, pad1;
+  int acc, rej, doubling, due;  // due: a bound update the run is waiting for (see ns_prepare: rebuild_fill)
   double logzvar;
   uint64_t rng[4];
   long long nc_carry;  // calls of the entries popped after the last death: charged to the NEXT death (sampler.py:1141)
@@ -60,6 +60,7 @@ struct NsArgs {
   long long* prof;   // optional (DH_NS_PROF=1): cycle counters of ns_consume's phases, run 0
   int rebuild_sync;  // 1: all bound-mode runs rebuild whenever any run is due (see ns_prepare)
   int overlap;       // 1: a run whose bound is being rebuilt sits the fill out (its rebuild runs beside the others' walk)
+  int rebuild_fill;  // 1: this fill builds bounds; 0: a run that is due waits (idle) for the next fill that does
   int serial_walk;   // diagnostic (DH_NS_SERIAL=1): ns_consume walks every queue with the one-wavefront routine
   NsRun* st;
   double* live_u;
@@ -165,7 +166,7 @@ __global__ void __launch_bounds__(kT)
     r.need_rebuild = 0;
     r.nbound = 0;
     r.nfill = 0;
-    r.acc = r.rej = r.doubling = r.pad1 = 0;
+    r.acc = r.rej = r.doubling = r.due = 0;
     r.logzvar = 0.0;
     r.nc_carry = 0;
     r.pcount = r.sampler_failed = 0;
@@ -250,7 +251,7 @@ __global__ void __launch_bounds__(kT) ns_prepare(NsArgs a) {
   int any = 0;
   for (int run = t; run < a.runs; run += kT) {
     NsRun& r = a.st[run];
-    int need = 0;
+    int want = 0;
     if (r.mode == MODE_CUBE || r.mode == MODE_BOUND) {
       if (r.mode == MODE_BOUND && a.bstatus[run] != DH_OK) {
         r.mode = MODE_FAILED;
@@ -258,25 +259,33 @@ __global__ void __launch_bounds__(kT) ns_prepare(NsArgs a) {
       } else {
         const double eff = 100.0 * (double)(r.it > 0 ? r.it : 1) / (double)r.ncall;
         if (r.mode == MODE_CUBE) {
-          if (r.ncall >= a.first_ncall && eff < a.first_eff) {
-            r.mode = MODE_BOUND;
-            need = 1;
-          }
+          want = (r.ncall >= a.first_ncall && eff < a.first_eff) ? 1 : 0;
         } else if (r.ncall >= r.ncall_last_update + a.update_interval || (a.force && a.force[run])) {
           // (force: a start point of the last fill lay outside the bound, sampler.py:484-489)
-          need = 1;
+          want = 1;
         }
+        if (r.due) want = 1;
       }
     }
-    r.need_rebuild = need;
-    any |= need;
+    // The rebuild is a latency chain that costs about the same for one run or sixty-four, so the loop builds bounds
+    // only every rebuild_every-th fill: a run that becomes due in between WAITS -- it proposes nothing and consumes
+    // nothing until then.  Runs are independent, so idling changes nothing in a run's own sequence (rebuild on the
+    // same live set, then walk with the same generator state): results are those of the reference schedule.
+    if (want && !a.rebuild_fill) {
+      r.due = 1;
+      want = 0;
+    }
+    r.need_rebuild = want;
+    any |= want;
   }
   any = __syncthreads_or(any);
   for (int run = t; run < a.runs; run += kT) {
     NsRun& r = a.st[run];
     int need = r.need_rebuild;
-    if (a.rebuild_sync && any && r.mode == MODE_BOUND) need = 1;
+    if (a.rebuild_sync && any && a.rebuild_fill && r.mode == MODE_BOUND) need = 1;
     if (need) {
+      if (r.mode == MODE_CUBE) r.mode = MODE_BOUND;
+      r.due = 0;
       r.ncall_last_update = r.ncall;
       r.nbound += 1;
       if (a.bootstrap > 0) {  // get_seed_sequence(rstate, bootstrap) (utils.py:1002-1009): one draw per rebuild
@@ -289,7 +298,7 @@ __global__ void __launch_bounds__(kT) ns_prepare(NsArgs a) {
     r.need_rebuild = need;
     if (a.force) a.force[run] = 0;
     a.rebuild_mask[run] = need;
-    a.run_mode[run] = (a.overlap && need) ? MODE_WAIT : r.mode;
+    a.run_mode[run] = (r.due || (a.overlap && need)) ? MODE_WAIT : r.mode;
     a.run_loglstar[run] = r.loglstar;
     a.run_scale[run] = r.scale;
     a.run_doubling[run] = r.doubling;
@@ -314,7 +323,7 @@ __global__ void __launch_bounds__(kT) ns_select(NsArgs a) {
   NsRun& r = a.st[run];
   const int mode = r.mode;
   if (mode != MODE_CUBE && mode != MODE_BOUND) return;
-  if (a.overlap && r.need_rebuild) return;  // its bound is under construction: the run proposes nothing this fill
+  if (a.run_mode[run] == MODE_WAIT) return;  // waiting for its bound: the run proposes nothing this fill
   if (mode == MODE_BOUND && a.bstatus[run] != DH_OK) return;  // ns_prepare fails the run next fill
   int M = 1;
   if (t == 0) {
@@ -391,7 +400,7 @@ __global__ void __launch_bounds__(256) ns_gather(NsArgs a) {
   const size_t q = e / D;
   const int j = (int)(e - q * D), run = (int)(q / K);
   if (a.st[run].mode != MODE_BOUND || a.bstatus[run] != DH_OK) return;
-  if (a.overlap && a.st[run].need_rebuild) return;
+  if (a.run_mode[run] == MODE_WAIT) return;
   a.q_u0[e] = a.live_u[((size_t)run * N + a.r_d[q]) * D + j];
 }
 
@@ -890,7 +899,7 @@ __global__ void __launch_bounds__(kT) ns_consume(NsArgs a) {
   NsRun& r = a.st[run];
   const int mode = r.mode;
   if (mode != MODE_CUBE && mode != MODE_BOUND) return;
-  if (a.overlap && r.need_rebuild) return;
+  if (a.run_mode && a.run_mode[run] == MODE_WAIT) return;
   if (mode == MODE_BOUND && a.bstatus[run] != DH_OK) return;
   long long pt_ = a.prof ? clock64() : 0;
   int P = 1;
@@ -1609,7 +1618,7 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
                    const uint32_t* entropy_words, int n_words, uint32_t first_run, double* records,
                    double* dead_logl_out, double* live_logl_out, double* dead_u_out, double* live_u_out,
                    int64_t* n_fills_out, int32_t* dead_id_out, int32_t* dead_it_out, int32_t* dead_nc_out,
-                   int32_t* live_it_out, int bootstrap) {
+                   int32_t* live_it_out, int bootstrap, int rebuild_every) {
   DH_CHECK_CTX(ctx);
   const bool want_pt = dead_id_out || dead_it_out || dead_nc_out || live_it_out;
   if (want_pt && !(dead_id_out && dead_it_out && dead_nc_out && live_it_out))
@@ -1673,6 +1682,25 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
   // workgroup against two 230-VGPR walk workgroups per CU), and every run spends one more fill per bound update --
   // 64 C2 runs 0.336 -> 0.328 s, 16 eggbox runs 0.127 -> 0.160 s, 16 C4 runs 11.1 -> 11.3 s.
   a.overlap = (getenv("DH_NS_OVERLAP") && atoi(getenv("DH_NS_OVERLAP")) != 0) ? 1 : 0;
+  // Bounds are built every rebuild_every-th fill (runs that become due in between wait, see ns_prepare); 0 = chosen
+  // here.  Once the period reaches the number of fills a run needs to spend its update interval, EVERY run is due (and
+  // waiting) by the next rebuild fill: the ensemble rebuilds together and walks together, one latency chain per
+  // interval instead of one per fill, with each run's own sequence untouched.  Longer periods only add idle fills
+  // (a fill in which every run waits costs its launches, ~75 us), shorter ones lose the synchrony -- measured flat
+  // from the interval upwards (64 C2 runs: 0.335 s at 1, 0.246 at 2, 0.29 at 3, 0.20 at 4 ... 12).  The interval in
+  // fills is nlive / K for rwalk (every walker spends `walks` calls), about nlive / (4.4 K) for the slice samplers
+  // (4.4 evaluations per slice step measured) and nlive / (1.7 K) for the uniform sampler; rounded up generously.
+  // The choice is a function of the arguments only -- never of timings -- so a run's global fill indices, and with
+  // them its Philox offsets, are reproducible.
+  int every = rebuild_every;
+  if (const char* e = getenv("DH_NS_REBUILD_EVERY")) every = atoi(e);
+  if (every <= 0) {
+    const double I = sampler == 0 ? (double)N / K : 1.3 * (double)N / ((sampler == 3 ? 1.7 : 4.4) * K);
+    every = (int)ceil(I - 1e-9);
+  }
+  if (every < 1) every = 1;
+  if (every > 16) every = 16;
+  if (a.overlap) every = 1;
   a.prof = nullptr;
   if (getenv("DH_NS_PROF")) {
     if (hipMalloc((void**)&a.prof, 32 * sizeof(long long)) != hipSuccess) a.prof = nullptr;
@@ -1805,6 +1833,7 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
     for (int burst = 0; burst < 8 && fill < fills_cap; ++burst, ++fill) {
       if (a.overlap && fill > 0 && !hip_ok(ctx, hipStreamWaitEvent(s, ev_rb, 0), "hipStreamWaitEvent(rebuild)"))
         return cleanup(DH_ERR_HIP);
+      a.rebuild_fill = fill % every == 0 ? 1 : 0;
       hipLaunchKernelGGL(ns_prepare, dim3(1), dim3(kT), 0, s, a);
       if (a.overlap) {
         // the bound work of this fill goes to the second stream (everything below enqueues on ctx->stream)
@@ -1813,6 +1842,7 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
           return cleanup(DH_ERR_HIP);
         ctx->stream = rb_stream;
       }
+      if (a.rebuild_fill) {
       rc = rebuild_launch_masked(ctx, R, a.live_u, N, D, bound_multi ? 0 : 1, me, a.nells, a.bstatus, a.b_ctrs,
                                  a.b_covs, a.b_ams, a.b_axes, a.b_axl, a.b_lv, a.rebuild_mask);
       if (rc) return cleanup(rc);
@@ -1830,6 +1860,7 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
         rc = enlarge_launch_masked(ctx, R, me, a.nells, D, a.b_covs, a.b_ams, a.b_axes, a.b_axl, a.b_lv,
                                    a.enlarge_log, a.rebuild_mask);
         if (rc) return cleanup(rc);
+      }
       }
       if (a.overlap) {
         ctx->stream = main_stream;

@@ -426,7 +426,14 @@ int dh_ns_consume(dh_ctx* ctx, int runs, int nlive, int queue_size, double dlogz
  * reference's RuntimeError does.  bootstrap = B > 1: every rebuild is followed by the bootstrap expansion of
  * bounding.py:381-400 / 688-703 -- B resampled replicas per run (bounding.py:1593-1648), all rebuilt in one ragged
  * batch, the bound scaled by max(1, largest normalised distance of a left-out point)^ndim; the reference's default
- * for sample='unif' is (enlarge 1, bootstrap 5), dynesty.py:169-200.  ndim <= 44.  0: none. */
+ * for sample='unif' is (enlarge 1, bootstrap 5), dynesty.py:169-200.  ndim <= 44.  0: none.
+ * rebuild_every = n: bounds are built only every n-th queue fill; a run that becomes due in between idles (proposes
+ * and consumes nothing) until then.  Runs are independent, so a run's own sequence -- and with PCG64 streams its
+ * result, bit for bit -- is that of the reference schedule (n = 1).  Once n reaches the number of fills a run needs
+ * to spend its update interval every run is due by the next rebuild fill: the ensemble rebuilds together, one
+ * latency chain per interval instead of one per fill (64 C2 runs: 0.335 s at n = 1, 0.20 s at n >= 4).  0: chosen
+ * from (sampler, nlive, queue_size) alone: ceil(nlive / K) for rwalk, ceil(1.3 nlive / (4.4 K)) for the slice
+ * samplers, ceil(1.3 nlive / (1.7 K)) for unif; at most 16. */
 int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim,
                    int queue_size, int sampler /* 0 rwalk, 1 rslice, 2 slice; + 3: unit-cube phase and proposals from hiprand Philox streams; 6 / 7 unif */,
                    int walks /* or slices */, int bound_multi,
@@ -435,7 +442,8 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim,
                    const uint32_t* entropy_words, int n_words, uint32_t first_run,
                    double* records, double* dead_logl_out, double* live_logl_out,
                    double* dead_u_out, double* live_u_out, int64_t* n_fills_out, int32_t* dead_id_out,
-                   int32_t* dead_it_out, int32_t* dead_nc_out, int32_t* live_it_out, int bootstrap);
+                   int32_t* dead_it_out, int32_t* dead_nc_out, int32_t* live_it_out, int bootstrap,
+                   int rebuild_every /* bounds are built every n-th fill, runs due in between wait; 0: chosen from the shape */);
 
 /* The bootstrap expansion factor on its own (host pointers; what the resident loop runs after a rebuild):
  * for each of `runs` point sets (runs x n x d) the max over `bootstrap` replicas of max(1, largest normalised

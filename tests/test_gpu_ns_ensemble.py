@@ -208,3 +208,21 @@ def test_rebuild_beside_the_walk_gives_the_same_runs(monkeypatch):
     np.testing.assert_array_equal(a["ncall"], b["ncall"])
     np.testing.assert_array_equal(a["nbound"], b["nbound"])
     assert b["nfills"] > a["nfills"]
+
+
+@pytest.mark.parametrize("sample,kw", [("rwalk", dict(walks=20)), ("rslice", dict(slices=4)), ("unif", {})])
+def test_waiting_for_the_rebuild_fill_changes_no_run(ctx, sample, kw):
+    """rebuild_every = n: bounds are built every n-th fill and a run that is due waits.  Its own sequence is unchanged:
+    with PCG64 streams every run's record is bit-identical for any n (1 = the reference schedule; 0 = the automatic
+    choice), and so is the ensemble whatever its sharding."""
+    prob = inputs.problem("G5")
+    base = dict(nlive=300, queue_size=64, bound="multi", sample=sample, entropy=[8, 1], dlogz=0.1, **kw)
+    ref = ctx.ns_ensemble(prob, 8, rebuild_every=1, **base)
+    assert np.all(ref["status"] == 0)
+    for n in (0, 2, 5, 16):
+        r = ctx.ns_ensemble(prob, 8, rebuild_every=n, **base)
+        for k in ("logz", "logzerr", "niter", "ncall", "nbound", "h"):
+            np.testing.assert_array_equal(r[k], ref[k], err_msg=f"{k} at rebuild_every={n}")
+    lo = ctx.ns_ensemble(prob, 4, first_run=0, rebuild_every=5, **base)
+    hi = ctx.ns_ensemble(prob, 4, first_run=4, rebuild_every=5, **base)
+    np.testing.assert_array_equal(np.concatenate([lo["logz"], hi["logz"]]), ref["logz"])

@@ -58,7 +58,7 @@ int main() {
       int64_t nf = 0;
       rc = dh_ns_ensemble(ctx, prob, runs, nlive, 3, K, sampler, 23, sampler == 0, 0, 0.1, sampler == 6 ? 1.0 : 1.25, 0,
                           max_iter, words, 2, 0, rec.data(), dead.data(), live.data(), dead_u.data(), live_u.data(), &nf,
-                          did.data(), dit.data(), dnc.data(), lit.data(), sampler == 6 ? 5 : 0);
+                          did.data(), dit.data(), dnc.data(), lit.data(), sampler == 6 ? 5 : 0, 0);
       std::printf("ns_ensemble sampler %d: rc %d, %lld fills, ln Z %.3f %.3f %.3f (truth -8.987)\n", sampler, rc,
                   (long long)nf, rec[0], rec[8], rec[16]);
       if (rc) return 1;
