@@ -127,13 +127,13 @@ def run_static(prob, nlive=500, bound='multi', sample='rwalk', queue_size=None,
     operator dh_ns_consume, which keeps the run's keys, their sorted order and the
     chunk in LDS (12 nlive + 2 P + 52 * 512 + 64 bytes <= 150 KB, P = nlive rounded up
     to a power of two; slots are 16-bit)."""
-    be = get_backend()
     p2 = 1
     while p2 < nlive:
         p2 *= 2
     if nlive < 4 or 12 * nlive + 2 * max(p2, 256) + 52 * 512 + 64 > 150 * 1024:
         raise ValueError(f"run_static: nlive={nlive} is outside what the device's queue consumption holds in LDS "
                          "(4 <= nlive <= 8192)")
+    be = get_backend()
     if rstate is None:
         rstate = np.random.default_rng()
     # dynesty.py:186-193: uniform sampling bootstraps the bound (5 replicas) instead of

@@ -50,3 +50,30 @@ def test_ns_ensemble_rejects_unsupported_bound_and_sampler():
     for kw in (dict(bound='balls'), dict(bound='cubes'), dict(sample='hslice'), dict(bound='none')):
         with pytest.raises(ValueError, match="not supported"):
             _lib.Context.ns_ensemble(ctx, P(), 2, 100, 16, **kw)
+
+
+def test_enlarge_bootstrap_defaults_follow_the_reference():
+    """_get_enlarge_bootstrap (dynesty.py:169-200): unif -> (1, 5), others -> (1.25, 0); one given -> the other off;
+    both only if one of them is neutral."""
+    f = _lib.enlarge_bootstrap_defaults
+    assert f('unif', None, None) == (1.0, 5)
+    assert f('rwalk', None, None) == (1.25, 0) and f('rslice', None, None) == (1.25, 0)
+    assert f('unif', 1.5, None) == (1.5, 0)
+    assert f('rwalk', None, 7) == (1.0, 7) and f('rwalk', None, 0) == (1.0, 0)
+    assert f('unif', 1.0, 5) == (1.0, 5) and f('unif', 1.3, 0) == (1.3, 0)
+    with pytest.raises(ValueError):
+        f('unif', 1.3, 5)
+    with pytest.raises(ValueError):
+        f('rwalk', None, 1)
+    with pytest.raises(ValueError):
+        f('rwalk', 0.9, None)
+
+
+def test_run_static_refuses_an_nlive_the_device_cannot_hold():
+    from dynesty_amd import nested
+
+    class P:
+        ndim = 3
+    for nlive in (3, 8193, 20000):
+        with pytest.raises(ValueError, match="nlive"):
+            nested.run_static(P(), nlive=nlive)
