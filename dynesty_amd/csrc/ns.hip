@@ -1392,43 +1392,64 @@ __global__ void __launch_bounds__(kT) ns_consume(NsArgs a) {
 }
 
 // ---- final live points (sampler.py:780-930) + record -----------------------------
+// exclusive prefix of one value per thread over the workgroup (threads in order), and the total; OP = logaddexp or +
+template <bool LOGADD>
+__device__ __forceinline__ double block_excl_scan(double v, double ident, double* wtot /* 4 shared */, double* total) {
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  double sc = v;
+  for (int off = 1; off < 64; off <<= 1) {
+    const double y = __shfl_up(sc, off);
+    if (lane >= off) sc = LOGADD ? logaddexp_dev(y, sc) : y + sc;
+  }
+  double ex = __shfl_up(sc, 1);
+  if (lane == 0) ex = ident;
+  __syncthreads();
+  if (lane == 63) wtot[wv] = sc;
+  __syncthreads();
+  double pre = ident, tot = ident;
+  for (int w2 = 0; w2 < kT / 64; ++w2) {
+    if (w2 < wv) pre = LOGADD ? logaddexp_dev(pre, wtot[w2]) : pre + wtot[w2];
+    tot = LOGADD ? logaddexp_dev(tot, wtot[w2]) : tot + wtot[w2];
+  }
+  *total = tot;
+  return LOGADD ? logaddexp_dev(pre, ex) : pre + ex;
+}
+
 __global__ void __launch_bounds__(kT) ns_finish(NsArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int run = blockIdx.x, t = threadIdx.x, N = a.nlive;
-  // the final live log-likelihoods, ascending: a bitonic sort of the keys over the whole workgroup (values only -- the
-  // integration below does not care which slot a value came from; N pops of the heap by one wavefront were 15 ms of
-  // the eggbox run's 190 at N = 5 000)
-  double* sorted = (double*)smem;  // P >= N, a power of two; the padding sorts to the end
+  // the final live log-likelihoods, ascending: the slots sorted by (value, slot) with the register network of
+  // ns_consume, then the values in that order (the integration below does not care which slot a value came from)
   int P = 1;
   while (P < N) P <<= 1;
-  for (int i = t; i < P; i += kT) sorted[i] = i < N ? a.live_logl[(size_t)run * N + i] : INFINITY;
+  const int nsidx = P > kT ? P : kT;
+  double* skey = (double*)smem;                                // N   by slot
+  double* sorted = skey + N;                                   // N   ascending
+  unsigned short* sidx = (unsigned short*)(sorted + N);        // max(P, kT)
+  for (int i = t; i < N; i += kT) skey[i] = a.live_logl[(size_t)run * N + i];
   __syncthreads();
-  for (int k = 2; k <= P; k <<= 1)
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i = t; i < P; i += kT) {
-        const int l = i ^ j;
-        if (l > i) {
-          const double x = sorted[i], y = sorted[l];
-          const bool up = (i & k) == 0;
-          if ((x > y) == up) {
-            sorted[i] = y;
-            sorted[l] = x;
-          }
-        }
-      }
-      __syncthreads();
-    }
+  switch (nsidx / kT) {
+    case 1: sort_slots<1>(skey, sidx, N, nsidx); break;
+    case 2: sort_slots<2>(skey, sidx, N, nsidx); break;
+    case 4: sort_slots<4>(skey, sidx, N, nsidx); break;
+    case 8: sort_slots<8>(skey, sidx, N, nsidx); break;
+    case 16: sort_slots<16>(skey, sidx, N, nsidx); break;
+    default: sort_slots<32>(skey, sidx, N, nsidx); break;
+  }
+  for (int i = t; i < N; i += kT) sorted[i] = skey[sidx[i]];
+  __syncthreads();
   // The final live points, lowest first (sampler.py:780-930).  What Results reports is
   // compute_integrals over the whole run (sampler.py:1342-1348, utils.py:1411-1467): ln Z the
   // accumulated logaddexp, and the partial informations H_i normalised by the FINAL Z,
   //   H_i = (1/Z_f) sum_{k<=i} [L ln L]-terms - (Z_i / Z_f) ln Z_f,   var ln Z = |sum_i (H_i - H_{i-1}) dlnX_i|.
-  // First pass: ln Z_f.  With G = e^{lnZ}(H + lnZ) (additive) the state after the dead points gives
+  // With G = e^{lnZ}(H + lnZ) (additive) the state after the dead points gives
   // H_n = e^{lnZ_n - lnZ_f} (H^run_n + lnZ_n - lnZ_f); over the dead points dlnX is constant, so their
   // share of the variance sum telescopes to dlnX * H_n.
-  // Everything that does not depend on the running sums -- the volumes' logarithms, the trapezoid weights, the
-  // L e^L terms: ~10 transcendentals per point -- is computed by all threads into three arrays first; one thread then
-  // runs the two recurrences over them in the reference's order (one thread doing all of it was 17 ms at N = 5 000).
-  __shared__ double bc[2];
+  // Every thread owns a contiguous stretch of the points; the two running quantities -- ln Z_i (logaddexp) and the sum
+  // of the L e^L terms -- are prefix scans over the stretches' totals, after which a thread walks its own stretch
+  // (one thread walking all N points in the reference's order was 1.4 of this kernel's 6.5 ms at N = 5 000; the
+  // results agree to 1e-13).
+  __shared__ double wtot[kT / 64];
   NsRun& r = a.st[run];
   const double lv0 = r.logvol, dead_prev = r.dead_prev;
   double* W = a.fin_ws + (size_t)run * 3 * N;  // trapezoid ln-weights
@@ -1443,54 +1464,65 @@ __global__ void __launch_bounds__(kT) ns_finish(NsArgs a) {
     if (i <= pc) return lv0 + log1p(-(double)i * pstep);
     return lv0 + log1p(-(double)pc * pstep) + log1p(-(double)(i - pc) / ((double)(N - pc) + 1.0));
   };
-  for (int i = 1 + t; i <= N; i += kT) {
+  const int per = (N + kT - 1) / kT, c0 = t * per < N ? t * per : N, c1 = c0 + per < N ? c0 + per : N;
+  double zc = -INFINITY;  // ln of the stretch's summed weights
+  for (int i = c0 + 1; i <= c1; ++i) {
     const double cur = sorted[i - 1], prev = i > 1 ? sorted[i - 2] : dead_prev;
     const double lv = lv_at(i);
     const double lvprev = lv_at(i - 1);
     const double dl = lvprev - lv;
     const double logdvol = lv + log(0.5 * expm1(dl));
-    W[i - 1] = logaddexp_dev(cur, prev) + logdvol;
+    const double w = logaddexp_dev(cur, prev) + logdvol;
+    W[i - 1] = w;
     DL[i - 1] = dl;
     T[i - 1] = logdvol;
+    zc = logaddexp_dev(zc, w);
   }
-  __syncthreads();
-  if (t == 0) {
-    double logz_f = r.logz;
-    for (int i = 0; i < N; ++i) logz_f = logaddexp_dev(logz_f, W[i]);
-    bc[0] = logz_f;
-  }
-  __syncthreads();
-  const double logz_f = bc[0];
-  for (int i = 1 + t; i <= N; i += kT) {
+  double ztot;
+  double zpre = block_excl_scan<true>(zc, -INFINITY, wtot, &ztot);
+  const double logz_f = logaddexp_dev(r.logz, ztot);
+  zpre = logaddexp_dev(r.logz, zpre);  // ln Z before this thread's stretch
+  double hc = 0.0;
+  for (int i = c0 + 1; i <= c1; ++i) {
     const double cur = sorted[i - 1], prev = i > 1 ? sorted[i - 2] : dead_prev;
     const double logdvol = T[i - 1];
     const double t0 = exp(prev - logz_f + logdvol), t1 = exp(cur - logz_f + logdvol);
-    T[i - 1] = (t1 > 0.0 ? t1 * cur : 0.0) + (t0 > 0.0 ? t0 * prev : 0.0);
+    const double tt = (t1 > 0.0 ? t1 * cur : 0.0) + (t0 > 0.0 ? t0 * prev : 0.0);
+    T[i - 1] = tt;
+    hc += tt;
   }
+  double htot;
+  const double hpre = block_excl_scan<false>(hc, 0.0, wtot, &htot);
+  const double dlv = log(((double)N + 1.0) / (double)N);
+  const double wn = exp(r.logz - logz_f);
+  const double hpart0 = r.it > 0 && wn > 0.0 ? wn * (r.h + r.logz) : 0.0;  // (1/Z_f) sum of the L ln L terms so far
+  // H before this thread's stretch (for the first stretch: H_n)
+  double logz = zpre, hpart = hpart0 + hpre;
+  double hcur = hpart - (c0 == 0 ? (r.it > 0 ? wn * logz_f : 0.0) : logz_f * exp(logz - logz_f));
+  double var = 0.0;
+  for (int i = c0; i < c1; ++i) {
+    logz = logaddexp_dev(logz, W[i]);
+    hpart += T[i];
+    const double hi = hpart - logz_f * exp(logz - logz_f);
+    var += (hi - hcur) * DL[i];
+    hcur = hi;
+  }
+  __shared__ double fin_h;
+  if (c1 == N && c0 < N) fin_h = hcur;  // the thread that owns the last point
+  double vtot;
+  (void)block_excl_scan<false>(var, 0.0, wtot, &vtot);
   __syncthreads();
   if (t == 0) {
-    const double dlv = log(((double)N + 1.0) / (double)N);
-    const double wn = exp(r.logz - logz_f);
-    double hpart = r.it > 0 && wn > 0.0 ? wn * (r.h + r.logz) : 0.0;  // (1/Z_f) sum of the L ln L terms so far
-    double hcur = hpart - (r.it > 0 ? wn * logz_f : 0.0);              // H_n
     // the dead points' share of sum_i (H_i - H_{i-1}) dlnX_i: it telescopes for the constant step, and the
     // plateau deaths' departures from it were summed on the way (ns_consume: var_a, var_b, relative to Z_n)
-    double logzvar = hcur * dlv + (wn > 0.0 ? wn * (r.var_a - logz_f * r.var_b) : 0.0);
-    double logz = r.logz;
-    for (int i = 0; i < N; ++i) {
-      logz = logaddexp_dev(logz, W[i]);
-      hpart += T[i];
-      const double hi = hpart - logz_f * exp(logz - logz_f);
-      logzvar += (hi - hcur) * DL[i];
-      hcur = hi;
-    }
-    const double h = hcur;
+    const double h_n = hpart0 - (r.it > 0 ? wn * logz_f : 0.0);
+    const double logzvar = h_n * dlv + (wn > 0.0 ? wn * (r.var_a - logz_f * r.var_b) : 0.0) + vtot;
     double* rec = a.records + (size_t)run * 8;
-    rec[0] = logz;
+    rec[0] = logz_f;
     rec[1] = sqrt(fabs(logzvar));
     rec[2] = (double)r.it;
     rec[3] = (double)r.ncall;
-    rec[4] = h;
+    rec[4] = N > 0 ? fin_h : h_n;
     rec[5] = (double)r.nbound;
     rec[6] = (double)(r.mode == MODE_DONE ? 0 : (r.mode == MODE_FAILED ? -1 : 1));  // 1: hit maxfills
     rec[7] = 100.0 * (double)r.it / (double)r.ncall;
@@ -1515,7 +1547,12 @@ int dh_ns_consume(dh_ctx* ctx, int runs, int nlive, int queue_size, double dlogz
     return fail(ctx, DH_ERR_ARG, "ns_consume: bad arguments");
   const int R = runs, N = nlive, K = queue_size;
   if (K > kEPT * kT) return fail(ctx, DH_ERR_ARG, "ns_consume: queue_size %d > %d", K, kEPT * kT);
-  const size_t lds_fin = (size_t)N * 16 + 64;  // ns_finish: the keys padded to a power of two
+  size_t lds_fin = (size_t)N * 16 + 64;  // ns_finish: the keys by slot, the keys in order, the sorted slots
+  {
+    size_t Pf = 1;
+    while (Pf < (size_t)N) Pf <<= 1;
+    lds_fin += (Pf > 256 ? Pf : 256) * 2;
+  }
   const size_t lds_cons = ns_consume_lds(N, K);
   const size_t lds_max = lds_cons > lds_fin ? lds_cons : lds_fin;
   if (lds_max > 150 * 1024) return fail(ctx, DH_ERR_ARG, "ns_consume: nlive/queue too large for LDS");
@@ -1809,7 +1846,12 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
   hipLaunchKernelGGL(ns_init, dim3(R), dim3(kT), 0, s, a, d_ent, n_words, first_run);
   int rc = eval_launch_dev(ctx, problem, R * N, a.live_u, a.live_v, a.live_logl);
   if (rc) return cleanup(rc);
-  const size_t lds_fin = (size_t)N * 16 + 64;  // ns_finish: the keys padded to a power of two
+  size_t lds_fin = (size_t)N * 16 + 64;  // ns_finish: the keys by slot, the keys in order, the sorted slots
+  {
+    size_t Pf = 1;
+    while (Pf < (size_t)N) Pf <<= 1;
+    lds_fin += (Pf > 256 ? Pf : 256) * 2;
+  }
   const size_t lds_cons = ns_consume_lds(N, K);
   if (K > kEPT * kT) return cleanup(fail(ctx, DH_ERR_ARG, "ns_ensemble: queue_size %d > %d", K, kEPT * kT));
   if (lds_cons > 150 * 1024) return cleanup(fail(ctx, DH_ERR_ARG, "ns_ensemble: nlive/queue too large for LDS"));
