@@ -676,8 +676,8 @@ __device__ __attribute__((noinline)) void sort_slots(const double* skey, unsigne
 // returns 0 -- the serial walk takes the fill.  All threads call it; cj = K ints of scratch (c_j of every entry);
 // sh = 4 shared ints; on success *ndead_out / *newmin as consume_sorted.
 __device__ int consume_parallel(const double* skey, const unsigned short* sidx, int* src, const double* ql, double* dcur,
-                                int* dj, int* dslot, int* dsrc, double* bkey, int* cj, int N, int K, long long room,
-                                int* sh, int* ndead_out, double* newmin, long long* prof) {
+                                int* dj, int* dslot, int* dsrc, double* bkey, int* bqs, int* cj, int N, int K,
+                                long long room, int* sh, int* ndead_out, double* newmin, long long* prof) {
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
   long long pt_ = prof ? clock64() : 0;
 #define CP_PROF(i)                         \
@@ -707,7 +707,7 @@ __device__ int consume_parallel(const double* skey, const unsigned short* sidx, 
     }
   }
   CP_PROF(11);
-  if (t == 0) sh[0] = sh[1] = sh[2] = 0;  // [0] low accepted values, [1] tie, [2] entries the originals do not decide
+  if (t == 0) sh[0] = sh[1] = sh[2] = sh[3] = 0;  // [0] low accepted values, [1] tie, [2] undecided entries, [3] give up
   __syncthreads();
   // #{i < j : q_i < q_j} is needed only where the originals alone do not decide (rA[j] <= j: a quarter of a late
   // fill): those entries are listed, and every one is counted by four lanes (a quarter of i < j each)
@@ -800,7 +800,7 @@ __device__ int consume_parallel(const double* skey, const unsigned short* sidx, 
           const int x = base + __popcll(b & ((1ull << lane) - 1ull));
           bkey[x] = qv[u];
           bq[x] = j;
-          if (rA[j] < N && skey[sidx[rA[j]]] == qv[u]) sh[1] = 1;
+          if (rA[j] < N && skey[sidx[rA[j]]] == qv[u]) sh[1] = 1;  // ties with an original: slot order decides (below)
         }
       }
     }
@@ -818,20 +818,23 @@ __device__ int consume_parallel(const double* skey, const unsigned short* sidx, 
       int r = 0, eq = 0;
       for (int y = 0; y < nB; ++y) {
         const double w = bkey[y];
-        r += w < v ? 1 : 0;
+        r += (w < v || (w == v && y < x)) ? 1 : 0;  // equal values: a provisional order, settled by slot below
         eq += w == v ? 1 : 0;
       }
       if (eq > 1) sh[1] = 1;
+      if (eq > 8) sh[3] = 1;  // (a plateau of proposals: left to the serial walk)
       myr[u] = r;
       myq[u] = bq[x];
     }
   }
   __syncthreads();
-  if (sh[1]) return 0;  // an accepted value ties with another candidate: slot order decides (serial walk)
+  if (sh[3]) return 0;
+  const bool tied = sh[1] != 0;  // an accepted value that could die now equals an original or another such value
   for (int u = 0; u < kEPT; ++u)
     if (myr[u] >= 0) {
       posB[myr[u]] = rA[myq[u]] + myr[u];
       bq[myr[u]] = myq[u];  // (ranks are a permutation; every old bq entry sits in a register by now)
+      bqs[myr[u]] = myq[u];  // ... and once more where the death list will not overwrite it
     }
   __syncthreads();
   CP_PROF(14);
@@ -872,17 +875,117 @@ __device__ int consume_parallel(const double* skey, const unsigned short* sidx, 
   }
   __syncthreads();
   CP_PROF(15);
-  // a proposal lives in the slot of the death that let it in
+  // Equal values die lowest slot first (np.argmin, sampler.py:1107), and a proposal's slot is that of the death that
+  // let it in -- a death of a strictly lower value.  The merge above put equal values in a provisional order; the
+  // positions of a group of equal values that holds a proposal are marked (-2) and settled -- group by group, from the
+  // lowest value up, as their members' slots become known -- by selecting the (e - group start)-th smallest slot of
+  // the group: its originals (already in slot order) and its proposals (at most 8).
+  auto val_of = [&](int r) { return ql[bqs[r]]; };
+  if (tied) {
+    for (int e = t; e < ndead; e += kT) {
+      const double v = dcur[e];
+      int lo = 0, hi = nB;  // proposals of value v: [rl, rh)
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (val_of(mid) < v) lo = mid + 1; else hi = mid;
+      }
+      const int rl = lo;
+      hi = nB;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (val_of(mid) <= v) lo = mid + 1; else hi = mid;
+      }
+      const int rh = lo;
+      if (rh > rl) {
+        const bool orig_too = dsrc[e] < 0 || (e + 1 < ndead && dcur[e + 1] == v && dsrc[e + 1] < 0) ||
+                              (e > 0 && dcur[e - 1] == v && dsrc[e - 1] < 0);
+        // (an original of the same value sits, in the provisional order, right behind the group's proposals; one
+        // that is not among the deaths still counts: test the sorted originals)
+        int pl = 0, ph = N;
+        while (pl < ph) {
+          const int mid = (pl + ph) >> 1;
+          if (skey[sidx[mid]] < v) pl = mid + 1; else ph = mid;
+        }
+        const bool has_orig = orig_too || (pl < N && skey[sidx[pl]] == v);
+        if (rh - rl > 1 || has_orig) dslot[e] = -2;
+      }
+    }
+    __syncthreads();
+  }
   for (;;) {
     int open = 0;
-    for (int e = t; e < ndead; e += kT)
-      if (((volatile int*)dslot)[e] < 0) {
+    for (int e = t; e < ndead; e += kT) {
+      const int s0 = ((volatile int*)dslot)[e];
+      if (s0 == -1) {  // a proposal alone at its value: the slot of the death that let it in
         const int sl = ((volatile int*)dslot)[cj[dsrc[e]]];
         if (sl >= 0)
           ((volatile int*)dslot)[e] = sl;
         else
           open = 1;
+      } else if (s0 == -2) {
+        const double v = dcur[e];
+        int lo = 0, hi = nB;
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          if (val_of(mid) < v) lo = mid + 1; else hi = mid;
+        }
+        const int rl = lo;
+        hi = nB;
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          if (val_of(mid) <= v) lo = mid + 1; else hi = mid;
+        }
+        const int rh = lo, gi = rh - rl;
+        int pl = 0, ph = N;
+        while (pl < ph) {
+          const int mid = (pl + ph) >> 1;
+          if (skey[sidx[mid]] < v) pl = mid + 1; else ph = mid;
+        }
+        int pu = pl, pe = N;
+        while (pu < pe) {
+          const int mid = (pu + pe) >> 1;
+          if (skey[sidx[mid]] <= v) pu = mid + 1; else pe = mid;
+        }
+        // the proposals' slots (all must be known)
+        int sr[8];
+        bool known = true;
+        for (int q = 0; q < 8; ++q) {
+          sr[q] = 0x7fffffff;
+          if (q < gi) {
+            sr[q] = ((volatile int*)dslot)[cj[bqs[rl + q]]];
+            known = known && sr[q] >= 0;
+          }
+        }
+        if (!known) {
+          open = 1;
+        } else {
+          const int m = e - (pl + rl);  // rank inside the group
+          int chosen = -1, below = 0;
+          for (int q = 0; q < 8; ++q)
+            if (q < gi) {
+              int rk = 0;
+              {  // originals of the group with a smaller slot (they are in slot order)
+                int a0 = pl, a1 = pu;
+                while (a0 < a1) {
+                  const int mid = (a0 + a1) >> 1;
+                  if ((int)sidx[mid] < sr[q]) a0 = mid + 1; else a1 = mid;
+                }
+                rk = a0 - pl;
+              }
+              for (int q2 = 0; q2 < 8; ++q2) rk += (q2 < gi && sr[q2] < sr[q]) ? 1 : 0;
+              if (rk == m) chosen = q;
+              below += rk < m ? 1 : 0;
+            }
+          if (chosen >= 0) {
+            dsrc[e] = bqs[rl + chosen];
+            ((volatile int*)dslot)[e] = sr[chosen];
+          } else {
+            dsrc[e] = -1;
+            ((volatile int*)dslot)[e] = (int)sidx[pl + m - below];
+          }
+        }
       }
+    }
     if (!__syncthreads_or(open)) break;
   }
   for (int j = t; j < K; j += kT)
@@ -983,8 +1086,8 @@ __global__ void __launch_bounds__(kT) ns_consume(NsArgs a) {
   const long long room = a.dead_rel ? (long long)K + 1 : a.cap - it0;
   int walked = 0;
   if (!a.serial_walk) {
-    walked = consume_parallel(skey, sidx, src, ql, dcur, dj, dslot, dsrc, bkey, qborn, N, K, room, &misc[4], &misc[0],
-                              &bcast[2], run == 0 ? a.prof : nullptr);
+    walked = consume_parallel(skey, sidx, src, ql, dcur, dj, dslot, dsrc, bkey, bslot, qborn, N, K, room, &misc[4],
+                              &misc[0], &bcast[2], run == 0 ? a.prof : nullptr);
     if (walked && t == 0) misc[1] = -1;
     if (a.prof && run == 0 && t == 0 && !walked) atomicAdd((unsigned long long*)&a.prof[10], 1ull);
   }
