@@ -1169,6 +1169,7 @@ __global__ void __launch_bounds__(kT) ns_consume(NsArgs a) {
     for (int w2 = 0; w2 < wv; ++w2) pre += scratch4[w2];
     return pre + ex;
   };
+  NS_PROF(18);
   // ---- phase B: integration + stopping rule as prefix scans over the deaths ----
   const int EPT = (K + kT - 1) / kT;
   double lw[kEPT], nl[kEPT], cd[kEPT], lvv[kEPT];
@@ -1191,7 +1192,11 @@ __global__ void __launch_bounds__(kT) ns_consume(NsArgs a) {
       for (int i = 0; i < kEPT; ++i) lvv[i] = logvol0 - (ex + lvv[i]);
     }
   }
-  double tz = -INFINITY, tm = -INFINITY;
+  // ln Z after every death = ln(Z_0 + prefix sum of the weights): the weights are summed in the LINEAR domain, relative
+  // to M = the largest of them and of ln Z_0 (one exp and one log per death; a logaddexp scan -- an exp and a log1p
+  // for every element AND every scan step -- was the largest part of this phase: 41 k of its 67 k cycles at C2).  The
+  // recurrence's rounding differs from the serial chain's in the last bits only (tested to 1e-10 absolute).
+  double mloc = logz0;
 #pragma unroll
   for (int i = 0; i < kEPT; ++i) {
     lw[i] = -INFINITY;
@@ -1202,18 +1207,29 @@ __global__ void __launch_bounds__(kT) ns_consume(NsArgs a) {
       const double logvol_e = lvv[i];
       lw[i] = logaddexp_dev(lnew, lprev) + logvol_e + (has_tie ? log(0.5 * expm1(cd[i])) : ldv_c);
       nl[i] = ql[dj[e]];
+      mloc = fmax(mloc, lw[i]);
     }
-    tz = logaddexp_dev(tz, lw[i]);  // running (inclusive) values of this lane's segment
-    tm = fmax(tm, nl[i]);
-    lw[i] = tz;
-    nl[i] = tm;
   }
+  for (int off = 32; off > 0; off >>= 1) mloc = fmax(mloc, __shfl_xor(mloc, off));
+  if (lane == 0) wred[0][wv] = mloc;
+  __syncthreads();
+  const double M = fmax(fmax(wred[0][0], wred[0][1]), fmax(wred[0][2], wred[0][3]));
+  __syncthreads();
+  double tz = 0.0, tm = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < kEPT; ++i)
+    if (i < EPT) {
+      tz += lw[i] > -INFINITY ? exp(lw[i] - M) : 0.0;  // running (inclusive) values of this lane's segment
+      tm = fmax(tm, nl[i]);
+      lw[i] = tz;
+      nl[i] = tm;
+    }
   // inclusive scan of the lane totals across the wave, then across the 4 waves
   double sz = tz, sm = tm;
   for (int off = 1; off < 64; off <<= 1) {
     const double yz = __shfl_up(sz, off), ym = __shfl_up(sm, off);
     if (lane >= off) {
-      sz = logaddexp_dev(yz, sz);
+      sz += yz;
       sm = fmax(ym, sm);
     }
   }
@@ -1223,23 +1239,26 @@ __global__ void __launch_bounds__(kT) ns_consume(NsArgs a) {
   }
   double ez = __shfl_up(sz, 1), em = __shfl_up(sm, 1);  // exclusive prefix inside the wave
   if (lane == 0) {
-    ez = -INFINITY;
+    ez = 0.0;
     em = -INFINITY;
   }
   __syncthreads();
-  double pz = logz0, pm = lmax0;  // everything before this lane's segment
+  const double z0 = logz0 > -INFINITY ? exp(logz0 - M) : 0.0;
+  double sbefore = z0, pm = lmax0;  // everything before this lane's segment
   for (int w2 = 0; w2 < wv; ++w2) {
-    pz = logaddexp_dev(pz, wred[0][w2]);
+    sbefore += wred[0][w2];
     pm = fmax(pm, wred[1][w2]);
   }
-  pz = logaddexp_dev(pz, ez);
+  sbefore += ez;
   pm = fmax(pm, em);
+  const double pz = M + log(sbefore);  // ln Z before this lane's segment
+  NS_PROF(19);
   int mystop = 0x7fffffff;
 #pragma unroll
   for (int i = 0; i < kEPT; ++i) {
     const int e = t * EPT + i;
     if (i < EPT && e < ndead) {
-      lw[i] = logaddexp_dev(pz, lw[i]);  // ln Z after death e
+      lw[i] = M + log(sbefore + lw[i]);  // ln Z after death e
       nl[i] = fmax(pm, nl[i]);           // lmax after death e
       const double dz = logaddexp_dev(0.0, nl[i] + lvv[i] - lw[i]);
       if (dz < a.dlogz && e < mystop) mystop = e;
@@ -1279,6 +1298,7 @@ __global__ void __launch_bounds__(kT) ns_consume(NsArgs a) {
     }
   __syncthreads();
   const double logz_E = E >= 0 ? bcast[0] : logz0, lmax_E = E >= 0 ? bcast[1] : lmax0;
+  NS_PROF(20);
   // information: sum of the L e^L dX terms relative to e^{lnZ_E}
   double hs = 0.0;
   double tt[kEPT];
@@ -1323,6 +1343,7 @@ __global__ void __launch_bounds__(kT) ns_consume(NsArgs a) {
       }
     }
   }
+  NS_PROF(21);
   for (int j = t; j <= jlast; j += kT) calls += qc[j];
   for (int off = 32; off > 0; off >>= 1) {
     hs += __shfl_xor(hs, off);
@@ -2116,7 +2137,7 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
     (void)hipMemcpy(h, a.prof, sizeof h, hipMemcpyDeviceToHost);
     fprintf(stderr, "ns_consume cycles (run 0, %lld fills): load+sort %lld | walk %lld | scan %lld | replay+state %lld | dead %lld | live store %lld ; fills integrated serially (all runs): %lld new plateau + %lld carried ; queues of run 0 left to the serial walk: %lld ; parallel walk: ranks %lld | counts %lld | scan+pick %lld | low ranks %lld | merge %lld | slots %lld\n",
             (long long)fill, h[0], h[1], h[2], h[3], h[4], h[5], h[8], h[9], h[10], h[11], h[12], h[13], h[14], h[15], h[7]);
-    fprintf(stderr, "  load+sort = live keys %lld | sort %lld | queue + sums %lld\n", h[16], h[17], h[0]);
+    fprintf(stderr, "  load+sort = live keys %lld | sort %lld | queue + sums %lld ; scan = ties %lld | weights + ln Z scan %lld | stop %lld | information %lld | rest %lld\n", h[16], h[17], h[0], h[18], h[19], h[20], h[21], h[2]);
     (void)hipFree(a.prof);
   }
   return cleanup(DH_OK);
