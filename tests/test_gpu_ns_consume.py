@@ -173,17 +173,20 @@ def test_whole_run_with_plateaus_is_compute_integrals(ctx):
         assert abs(lz2 - r["logz"][i]) > 1e-8
 
 
-def test_ties_die_lowest_slot_first_and_take_the_plateau_steps(ctx):
+@pytest.mark.parametrize("nlev", [40, 400, 3000])
+def test_ties_die_lowest_slot_first_and_take_the_plateau_steps(ctx, nlev):
     """Equal log-likelihoods among the live points (rwalk hands back its start point when no step was accepted) die
     lowest slot first -- np.argmin's rule in the reference (sampler.py:1107) -- also when the tie is between an original
     live point and a replacement made earlier in the same fill, and their deaths take the reference's PLATEAU volume
     steps (sampler.py:1112-1127, 1190-1193: a constant volume step X / (N + 1) per death while the plateau lasts)
     instead of ln((N + 1) / N).  Values drawn from a small set force many plateaus, also across fill boundaries; the
-    oracle runs with plateau=True (the restatement that is bit-identical to the recorded real run)."""
-    rng = np.random.default_rng(3)
+    oracle runs with plateau=True (the restatement that is bit-identical to the recorded real run).  40 levels: groups
+    of dozens of equal proposals (the serial walk takes those fills); 400 / 3000 levels: pairs and triples, settled
+    inside the parallel walk."""
+    rng = np.random.default_rng(3 + nlev)
     nlive, K, runs = 300, 200, 4
-    vals = -np.sort(rng.random(40) * 20)  # 40 distinct levels
-    live = vals[rng.integers(0, 40, size=(runs, nlive))].copy()
+    vals = -np.sort(rng.random(nlev) * 20)  # nlev distinct levels
+    live = vals[rng.integers(0, nlev, size=(runs, nlive))].copy()
     ref_live = live.copy()
     states = [R.RunState(nlive) for _ in range(runs)]
     state = pack(states)
@@ -192,7 +195,7 @@ def test_ties_die_lowest_slot_first_and_take_the_plateau_steps(ctx):
     ref_it = np.zeros((runs, nlive), dtype=np.int64)
     nplateau_fills = 0
     for fill in range(6):
-        ql = vals[rng.integers(0, 40, size=(runs, K))] + (fill * 0.0)
+        ql = vals[rng.integers(0, nlev, size=(runs, K))] + (fill * 0.0)
         ql[:, ::3] += 0.5  # some entries off the grid
         qn = rng.integers(1, 9, size=(runs, K)).astype(np.int32)
         out = ctx.ns_consume(live, ql, qn, state, None if False else 1e-300, live_it=live_it, plateau=plat)
@@ -208,7 +211,7 @@ def test_ties_die_lowest_slot_first_and_take_the_plateau_steps(ctx):
             assert state[r, 7] == ref_live[r].min()
             sr = states[r]
             # the volume really left the ln((N + 1) / N) ladder
-            assert abs(sr.logvol + sr.it * sr.dlv) > 1e-6
+            assert abs(sr.logvol + sr.it * sr.dlv) > (1e-6 if nlev <= 400 else 0.0)
             np.testing.assert_allclose(state[r, 0], sr.logvol, rtol=1e-12)
             np.testing.assert_allclose(state[r, 1], sr.logz, rtol=0, atol=1e-10)
             np.testing.assert_allclose(state[r, 2], sr.h, rtol=1e-9, atol=1e-12)
@@ -217,7 +220,7 @@ def test_ties_die_lowest_slot_first_and_take_the_plateau_steps(ctx):
             if sr.plateau_mode:
                 nplateau_fills += 1
                 np.testing.assert_allclose(plat[r, 1], sr.plateau_logdvol, rtol=1e-12)
-    assert nplateau_fills > 0  # plateaus were carried across fill boundaries
+    assert nplateau_fills > 0 or nlev > 400  # plateaus were carried across fill boundaries
 
 
 def test_replay_of_the_whole_real_run_with_its_plateaus(ctx):
