@@ -103,6 +103,7 @@ dh_ctx* dh_create(int device) {
   dh_ctx* ctx = new dh_ctx();
   ctx->device = device;
   if (const char* e = getenv("DH_RWALK_FORM")) ctx->rwalk_form = atoi(e) == 1 ? 1 : atoi(e) == 2 ? 2 : 0;
+  if (const char* e = getenv("DH_CUBE_FORM")) ctx->cube_form = atoi(e) == 1 ? 1 : atoi(e) == 2 ? 2 : 0;
   {
     int cu = 0;
     if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cu > 0) ctx->num_cu = cu;

@@ -62,6 +62,9 @@ struct dh_ctx {
   // leave SIMDs empty with one walker per lane, 1 = one walker per lane always, 2 = four lanes per walker
   // wherever that kernel is built
   int rwalk_form = 0;
+  // unit-cube sampler form (env DH_CUBE_FORM): 0 = four lanes per walker for launches that would leave SIMDs empty with
+  // one walker per lane, 1 = one walker per lane always, 2 = four lanes always (PCG64 streams, ndim <= 32)
+  int cube_form = 0;
   int num_cu = 256;  // hipDeviceProp_t::multiProcessorCount
 
   const uint64_t* zki() const { return zig; }

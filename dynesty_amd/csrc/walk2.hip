@@ -656,6 +656,119 @@ __global__ void __launch_bounds__(64, 2) unif_kernel(UnifArgs a) {
   }
 }
 
+// ---- UnitCubeSampler.sample with FOUR lanes per walker (internal_samplers.py:364-441) ---------------------------
+// The unit-cube phase of the resident loop draws until a point beats the run's threshold: a chain of independent
+// tries whose length is geometric, so the launch lasts as long as its unluckiest walker (a hundred tries at the end of
+// the phase, 0.38 ms per fill of 64 x 512 walkers with one walker per lane, on a half-empty chip).  Try k of a
+// walker consumes draws [k n, (k + 1) n) of the walker's PCG64 stream whatever happened before, so four lanes take
+// tries 4 r + t of round r from generators jumped t n draws ahead (the 128-bit LCG jumps: state after m steps =
+// A_m s + G_m inc), the first lane that succeeds is the walker's result, its generator state the walker's new
+// state and 4 r + t + 1 its call count: the same point, counts and stream as the sequential form, bit for bit
+// (tests/test_gpu_slice_unif.py).
+struct CubeQArgs {
+  ProblemDev prob;
+  int k, ndim;
+  const uint64_t* rng_in;
+  int64_t max_tries;
+  double* u;
+  double* v;
+  double* logl;
+  int32_t* ncalls;
+  int32_t* flags;
+  uint64_t* rng_out;
+  const double* run_loglstar;
+  const int* run_mode;
+  int wpr, my_mode;
+  double loglstar;
+};
+
+template <int N, bool FULL, int KIND>
+__global__ void __launch_bounds__(64, 2) cube_quad_kernel(CubeQArgs a) {
+  __shared__ double sx[N * 64];
+  const int lane = threadIdx.x, t = lane & 3;
+  const int w0 = blockIdx.x * 16 + (lane >> 2);
+  const bool live = w0 < a.k;
+  const int w = live ? w0 : a.k - 1;
+  const int n = FULL ? N : a.ndim;
+  double loglstar = a.loglstar;
+  bool done = false;
+  if (a.run_mode) {
+    const int run = w / a.wpr;
+    if (a.run_mode[run] != a.my_mode) done = true;
+    loglstar = a.run_loglstar[run];
+  }
+  if (!__any(!done)) return;
+  const bool idle = done;
+  // jump constants: n draws (one try), and from the end of a try to the start of this lane's next one (3 n draws)
+  U128 An = {0ull, 1ull}, Gn = {0ull, 0ull};
+  {
+    const U128 m = {DH_PCG_MULT_HI, DH_PCG_MULT_LO}, one = {0ull, 1ull};
+    for (int i = 0; i < n; ++i) {
+      An = mul128(An, m);
+      Gn = add128(mul128(Gn, m), one);
+    }
+  }
+  Pcg64 g;
+  g.load(a.rng_in + (size_t)w * 4);
+  const U128 Cn = mul128(Gn, g.inc);
+  for (int i = 0; i < t; ++i) g.state = add128(mul128(g.state, An), Cn);  // this lane's first try starts t n draws in
+  const U128 A2 = mul128(An, An), A3 = mul128(A2, An);
+  const U128 C3 = add128(mul128(add128(mul128(Cn, An), Cn), An), Cn);  // ((Cn An) + Cn) An + Cn
+  double x[N], acc[N];
+  int64_t round = 0;
+  int flags = 0;
+  while (__any(!done)) {
+    bool ok = false;
+    double ll = 0.0;
+    if (!done) {
+#pragma unroll 1
+      for (int i = 0; i < n; ++i) sx[i * 64 + lane] = g.next_double();
+#pragma unroll
+      for (int i = 0; i < N; ++i) x[i] = (FULL || i < n) ? sx[i * 64 + lane] : 0.5;
+    }
+    if (__any(!done)) {
+      prior_to_lds<N, FULL, KIND>(a.prob, x, n, sx, lane);
+      ll = loglike_lds<N, FULL, KIND>(a.prob, n, sx, lane, acc);
+      ok = !done && ll > loglstar;
+    }
+    // the first of the walker's four lanes that succeeded
+    const unsigned long long b = __ballot(ok);
+    const unsigned nib = (unsigned)(b >> (lane & ~3)) & 0xfu;
+    if (!done && nib) {
+      const int first = __ffs((int)nib) - 1;
+      if (t == first && live && !idle) {
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+          if (FULL || i < n) {
+            a.u[(size_t)w0 * n + i] = x[i];
+            a.v[(size_t)w0 * n + i] = sx[i * 64 + lane];
+          }
+        a.logl[w0] = ll;
+        a.ncalls[w0] = (int32_t)(round * 4 + t + 1);
+        a.flags[w0] = 0;
+        g.has32 = 0;
+        g.buf32 = 0;
+        if (a.rng_out) g.store(a.rng_out + (size_t)w0 * 4);
+      }
+      done = true;
+    }
+    if (!done) {
+      ++round;
+      if (round * 4 >= a.max_tries) {
+        flags = 2;
+        if (t == 0 && live && !idle) {
+          a.flags[w0] = flags;
+          a.ncalls[w0] = (int32_t)(round * 4);
+          a.logl[w0] = 0.0;
+        }
+        done = true;
+      } else {
+        g.state = add128(mul128(g.state, A3), C3);
+      }
+    }
+  }
+}
+
 // pad + transpose m matrices (row-major nc x nc) to m x N x N; transpose=0 keeps
 // the orientation (precision matrices), 1 transposes (frames)
 __global__ void pad_mats_kernel(const double* __restrict__ in, int m, int nc, int N, int transpose,
@@ -1018,6 +1131,32 @@ int unif_dispatch(dh_ctx* ctx, const UnifArgs& a, int N, bool philox = false) {
 
 }  // namespace
 
+namespace {
+int cube_quad_dispatch(dh_ctx* ctx, const CubeQArgs& a, int N) {
+  const dim3 grid((a.k + 15) / 16), block(64);
+  const bool full = a.ndim == N;
+  const int kind = full ? problem_kind(a.prob.like_id, a.prob.prior_id) : KIND_GENERIC;
+#define LQ(NN, FF, KK) hipLaunchKernelGGL((cube_quad_kernel<NN, FF, KK>), grid, block, 0, ctx->stream, a)
+#define X(NN)                                         \
+  if (N == NN) {                                      \
+    if (!full)                                        \
+      LQ(NN, false, KIND_GENERIC);                    \
+    else if (NN == 25 && kind == KIND_PREC_AFFINE)    \
+      LQ(25, true, KIND_PREC_AFFINE);                 \
+    else if (NN == 3 && kind == KIND_IID_AFFINE)      \
+      LQ(3, true, KIND_IID_AFFINE);                   \
+    else if (NN == 2 && kind == KIND_EGGBOX_IDENTITY) \
+      LQ(2, true, KIND_EGGBOX_IDENTITY);              \
+    else                                              \
+      LQ(NN, true, KIND_GENERIC);                     \
+  }
+  DH_DIM_LIST(X)
+#undef X
+#undef LQ
+  return hip_ok(ctx, hipGetLastError(), "unit-cube launch") ? DH_OK : DH_ERR_HIP;
+}
+}  // namespace
+
 int dh::unif_launch_runs(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, int m, const double* ctrs,
                          const double* axes, const double* ams, const double* cumprob, double loglstar,
                          const int8_t* bc, const uint64_t* rng, int64_t max_tries, double* u, double* v,
@@ -1059,6 +1198,28 @@ int dh::unif_launch_runs(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, i
                             flags, rng_out, run_loglstar, nullptr, run_mode, nullptr, wpr, my_mode, philox);
   }
   const int N = pad_dim(ndim);
+  // the unit cube with four lanes per walker (PCG64 streams) where one walker per lane would leave SIMDs empty
+  if (m == 0 && !a.propose_only && !philox && rng &&
+      (ctx->cube_form == 2 || (ctx->cube_form == 0 && k <= 256 * ctx->num_cu))) {
+    CubeQArgs q;
+    q.prob = a.prob;
+    q.k = k;
+    q.ndim = ndim;
+    q.rng_in = rng;
+    q.max_tries = max_tries > 0 ? max_tries : ((int64_t)1 << 32);
+    q.u = u;
+    q.v = v;
+    q.logl = logl;
+    q.ncalls = ncalls;
+    q.flags = flags;
+    q.rng_out = rng_out;
+    q.run_loglstar = run_loglstar;
+    q.run_mode = run_mode;
+    q.wpr = wpr;
+    q.my_mode = my_mode;
+    q.loglstar = loglstar;
+    return cube_quad_dispatch(ctx, q, N);
+  }
   const size_t mats = (size_t)(m > 0 ? m : 1) * N * N * 8;
   int rc = ensure_axes_t(ctx, 2 * mats);
   if (rc) return rc;

@@ -303,3 +303,32 @@ def test_slice_lockstep_on_device_feed(ctx, which):
         assert g.ncalls == r.ncalls and g.tuning_info == r.tuning_info
         np.testing.assert_allclose(g.u, r.u, rtol=1e-9, atol=1e-12)
         np.testing.assert_allclose(g.logl, r.logl, rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.parametrize("pname", ["C1", "C3", "G5", "C2", "C4nd13"])
+def test_unit_cube_four_lanes_per_walker_equals_one_lane(pname, monkeypatch):
+    """UnitCubeSampler.sample with four lanes per walker (tries 4 r + t of round r from generators jumped t n draws
+    ahead; DH_CUBE_FORM=2) against one walker per lane (=1): the same points, log-likelihoods, call counts and
+    generator end states, bit for bit -- also through whole resident runs, whose unit-cube phase takes it."""
+    from dynesty_amd import _lib, problems
+    prob = problems.gauss_iid(13, 4.0, "g13") if pname == "C4nd13" else inputs.problem(pname)
+    ctxs = []
+    for form in ("1", "2"):
+        monkeypatch.setenv("DH_CUBE_FORM", form)
+        ctxs.append(_lib.Context(0))
+    k = 777
+    states = ctxs[0].seed_children(np.array([5, 6, 7, 8]), 0, k)
+    # a threshold a few per cent of the cube beats: tens of tries per walker
+    u = np.random.default_rng(1).random((4000, prob.ndim))
+    ll = prob.loglikelihood_many(prob.prior_transform_many(u))
+    loglstar = float(np.quantile(ll, 0.97))
+    a = ctxs[0].unif_batch(prob, loglstar, states)
+    b = ctxs[1].unif_batch(prob, loglstar, states)
+    for key in ("u", "v", "logl", "ncalls", "rng_out"):
+        np.testing.assert_array_equal(a[key], b[key], err_msg=key)
+    assert a["ncalls"].max() > 40 and np.all(a["logl"] > loglstar)
+    kw = dict(nlive=200, queue_size=48, walks=15, bound="single", entropy=[4, 4], dlogz=0.5)
+    ra = ctxs[0].ns_ensemble(prob, 5, **kw)
+    rb = ctxs[1].ns_ensemble(prob, 5, **kw)
+    np.testing.assert_array_equal(ra["logz"], rb["logz"])
+    np.testing.assert_array_equal(ra["ncall"], rb["ncall"])
