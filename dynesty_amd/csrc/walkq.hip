@@ -117,6 +117,13 @@ __device__ __forceinline__ U128 sub128(U128 a, U128 b) {
   return r;
 }
 
+// The ziggurat's two per-draw look-ups (acceptance bound ki, scale wi) side by side: one 16-byte LDS read per draw
+// instead of two 8-byte reads at random banks; fi (wedge test only) apart.
+struct ZigQ {
+  ulonglong2 kw[256];  // .x = ki, .y = bits of wi
+  double fi[256];
+};
+
 // One walker's PCG64 on four lanes.  S = the walker's generator state advanced t + 1 steps.
 struct QuadPcg {
   U128 S, inc, AJ, TJ, T4;
@@ -138,7 +145,7 @@ struct QuadPcg {
 
 // One step's draws of the reference (nc normals, then one uniform) -> items[i * 64 + slot], i = 0..nc.
 // `slot` = the walker's column of the staging array; j = lane & 15, t = lane >> 4.
-__device__ __forceinline__ void quad_draw_step(QuadPcg& q, const ZigLds* z, double* items, int slot, int j, int t,
+__device__ __forceinline__ void quad_draw_step(QuadPcg& q, const ZigQ* z, double* items, int slot, int j, int t,
                                                int nc) {
 #pragma clang fp contract(off)
   const int NI = nc + 1;
@@ -170,10 +177,11 @@ __device__ __forceinline__ void quad_draw_step(QuadPcg& q, const ZigLds* z, doub
     const int idx = (int)(r & 0xff);
     const uint64_t rabs = (r >> 9) & 0x000fffffffffffffull;
     const double rd = __longlong_as_double((long long)(rabs | 0x4330000000000000ull)) - 4503599627370496.0;
-    double x = rd * z->wi[idx];
+    const ulonglong2 kw = z->kw[idx];  // looked up by every lane: no branch around the LDS read
+    double x = rd * __longlong_as_double((long long)kw.y);
     x = __longlong_as_double(__double_as_longlong(x) ^ (long long)((r & 0x100ull) << 55));
     const bool isn = valid & (my < nc);
-    const uint64_t kk = z->ki[idx];  // looked up by every lane: no branch around the LDS read
+    const uint64_t kk = kw.x;
     const bool miss = isn & !(rabs < kk);
     const int fm = grp_first(grp_bits(__ballot(miss), j));       // first missing sub-lane of my walker
     int tend = shift + NI - count;                                // one past the last valid sub-lane
@@ -327,7 +335,7 @@ __device__ __forceinline__ void prior_quad(const ProblemDev& P, int n, int t, co
 template <int NR, int KIND, int RNG>
 __global__ void __launch_bounds__(256) rwalkq_kernel(RwalkQArgs a) {
   constexpr int MT = (4 * NR + 15) / 16;
-  __shared__ ZigLds zig;
+  __shared__ ZigQ zig;
   __shared__ double items[(4 * NR + 1) * 64];  // [item][walker slot]: a step's normals and its uniform
   __shared__ double sprec[MT * NR * 64];       // MFMA fragments of the precision matrix
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -339,8 +347,7 @@ __global__ void __launch_bounds__(256) rwalkq_kernel(RwalkQArgs a) {
   const int n = a.ndim;
   if constexpr (RNG == RNGQ_PCG64) {
     for (int i = tid; i < 256; i += 256) {
-      zig.ki[i] = a.zki[i];
-      zig.wi[i] = __longlong_as_double((long long)a.zwi[i]);
+      zig.kw[i] = make_ulonglong2(a.zki[i], a.zwi[i]);
       zig.fi[i] = __longlong_as_double((long long)a.zfi[i]);
     }
   }
