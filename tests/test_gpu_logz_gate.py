@@ -9,8 +9,8 @@ Reference facts these files hold (and that the gate therefore carries):
      SerialPool(1024); about 235.89 +- 0.01, test-suite truth 235.856);
   C2 (25-D rho=0.4 Normal, nlive 2000, multi/rwalk):  K=1 -57.485 +- 0.026, K=512 -57.493 +- 0.023,
      K=2000 -57.266 +- 0.028  (analytic -57.5646): the queue-size bias at K = nlive is the reference's own;
-  C4 (200-D, nlive 4000, single/rslice):  K=1 -250.820 +- 0.021 (9 runs), SerialPool(1000) -250.955 +- 0.048
-     (5 runs), SerialPool(4000) -251.30 (2 runs); analytic -253.10: the +2.2 offset, and the drift with the queue
+  C4 (200-D, nlive 4000, single/rslice):  K=1 -250.820 +- 0.021 (9 runs), SerialPool(1000) -250.960 +- 0.028
+     (9 runs), SerialPool(4000) -251.30 (2 runs); analytic -253.10: the +2.2 offset, and the drift with the queue
      size, are the reference's own.
 """
 import json
@@ -114,7 +114,7 @@ def test_c4_device_run_vs_reference_runs(ctx):
 def test_c4_device_resident_loop_vs_reference_ensembles(ctx, K, ref_key, runs):
     """BASELINE C4 through the device-resident loop (dh_ns_ensemble at 200-D: wave-per-walker rslice kernels with
     per-run thresholds, masked multi-workgroup Ellipsoid.update) against the converged ensembles of the real reference
-    (tests/golden/c4_logz_ref.json: 9 serial runs -250.820 +- 0.021, 5 runs with SerialPool(1000) -250.955 +- 0.048;
+    (tests/golden/c4_logz_ref.json: 9 serial runs -250.820 +- 0.021, 9 runs with SerialPool(1000) -250.960 +- 0.028;
     45-70 minutes per run): at the reference's own queue size, and -- with the small queue the bench's C4 leg uses --
     against the SERIAL ensemble (ln Z drifts down with the queue size in the reference exactly as on the device:
     device 128 / 256 / 512 / 1000 -> -250.874 / -250.890 / -250.928 / -250.979, 16 runs each)."""
