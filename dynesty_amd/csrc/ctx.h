@@ -187,7 +187,7 @@ int wide_single_launch_masked(dh_ctx* ctx, int runs, const double* pts, int n, i
 // MultiEllipsoid.update at wide D: host recursion over device node work (wide.hip)
 int wide_multi_launch(dh_ctx* ctx, int runs, const double* pts, int n, int d, int max_ells, int32_t* nells,
                       int32_t* status, double* ctrs, double* covs, double* ams, double* axes, double* axlens,
-                      double* logvols, int32_t* leaf_of_point, int32_t* nnodes);
+                      double* logvols, int32_t* leaf_of_point, int32_t* nnodes, const int* active = nullptr);
 
 }  // namespace dh
 

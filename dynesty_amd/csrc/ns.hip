@@ -1806,10 +1806,9 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
     return fail(ctx, DH_ERR_ARG, "ns_ensemble: bootstrap in the device-resident loop needs ndim <= 44 (ndim=%d)", ndim);
   // Above the register-resident dimensions (and for slice samplers at dimensions without an instantiation) the
   // walker launches go to the wave-per-walker kernels of wide.hip, which take the same per-run arrays; above
-  // d = 44 the bound is the multi-workgroup Ellipsoid.update with the run mask (single ellipsoid only: the wide
-  // MultiEllipsoid.update is a host recursion).
-  if (bound_multi && ndim > 44)
-    return fail(ctx, DH_ERR_ARG, "ns_ensemble: bound='multi' in the device-resident loop needs ndim <= 44 (ndim=%d)", ndim);
+  // d = 44 the bound is the multi-workgroup Ellipsoid.update with the run mask, or -- bound='multi' -- the wide
+  // MultiEllipsoid.update: a host recursion over device node work, so a rebuild fill there synchronises the stream
+  // and reads the run mask back (the loop is no longer launch-ahead on those fills; the tree is a handful of nodes).
   const int N = nlive, D = ndim, K = queue_size, R = runs;
   const int me = bound_multi ? (N / (2 * D) > 0 ? N / (2 * D) : 1) : 1;
   NsArgs a{};

@@ -2736,13 +2736,13 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
     if (mode == 1 && !active && !n_arr)
       return wide_single_launch(ctx, runs, pts, n, d, nells, status, ctrs, covs, ams, axes, axlens,
                                 logvols);
-    if (mode == 0 && !active && !n_arr)
+    if (mode == 0 && !n_arr)  // (with a run mask: the device-resident loop's MultiEllipsoid.update, host-driven)
       return wide_multi_launch(ctx, runs, pts, n, d, max_ells, nells, status, ctrs, covs, ams, axes, axlens,
-                               logvols, leaf_of_point, nnodes);
+                               logvols, leaf_of_point, nnodes, active);
     if (mode == 1 && active && !n_arr)  // the device-resident loop's masked Ellipsoid.update
       return wide_single_launch_masked(ctx, runs, pts, n, d, nells, status, ctrs, covs, ams, axes, axlens, logvols,
                                        active);
-    return fail(ctx, DH_ERR_ARG, "rebuild: ragged batches, and masked MultiEllipsoid batches, for d=%d (> 44) are not built", d);
+    return fail(ctx, DH_ERR_ARG, "rebuild: ragged batches for d=%d (> 44) are not built", d);
   }
   RebuildArgs a;
   a.pts = pts;

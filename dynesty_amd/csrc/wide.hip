@@ -2831,9 +2831,20 @@ void wide_split(WideTree& T, const std::vector<int32_t>& idx, const double* p, i
 
 int wide_multi_launch(dh_ctx* ctx, int runs, const double* pts, int n, int d, int max_ells, int32_t* nells,
                       int32_t* status, double* ctrs, double* covs, double* ams, double* axes, double* axlens,
-                      double* logvols, int32_t* leaf_of_point, int32_t* nnodes) {
+                      double* logvols, int32_t* leaf_of_point, int32_t* nnodes, const int* active) {
   if (d > kWideMaxD) return fail(ctx, DH_ERR_ARG, "rebuild: d=%d exceeds the wide-D limit %d", d, kWideMaxD);
   const size_t dd = (size_t)d * d;
+  // run mask of the device-resident loop (device array): the recursion is driven from the host, so the mask comes here
+  std::vector<int> h_active;
+  if (active) {
+    h_active.resize((size_t)runs);
+    if (!hip_ok(ctx, hipMemcpyAsync(h_active.data(), active, (size_t)runs * 4, hipMemcpyDeviceToHost, ctx->stream), "D2H run mask") ||
+        !hip_ok(ctx, hipStreamSynchronize(ctx->stream), "sync"))
+      return DH_ERR_HIP;
+    bool any = false;
+    for (int v : h_active) any = any || v != 0;
+    if (!any) return DH_OK;
+  }
   const int cap = std::max(3, n / d + 3);  // every split makes two children of >= 2d points
   char* pool = nullptr;
   const size_t per = (3 * dd + 2 * (size_t)d + 1) * 8 + 4;
@@ -2841,6 +2852,7 @@ int wide_multi_launch(dh_ctx* ctx, int runs, const double* pts, int n, int d, in
   if (!hip_ok(ctx, hipMalloc((void**)&pool, bytes), "hipMalloc(wide multi scratch)")) return DH_ERR_NOMEM;
   int rc = DH_OK;
   for (int run = 0; run < runs && rc == DH_OK; ++run) {
+    if (active && !h_active[(size_t)run]) continue;
     WideTree T;
     T.ctx = ctx;
     T.pts = pts + (size_t)run * n * d;

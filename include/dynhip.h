@@ -392,9 +392,10 @@ int dh_ns_consume(dh_ctx* ctx, int runs, int nlive, int queue_size, double dlogz
  * unit-cube start, MultiEllipsoid (bound_multi=1) or Ellipsoid bound rebuilt
  * every walks*nlive calls and enlarged by `enlarge`, RWalkSampler.tune, evidence
  * integration (utils.py:1470-1492) and the final live points -- all on the
- * device for `runs` independent runs at once.  Dimensions: any ndim <= 512 with the Ellipsoid bound (above 32
- * the walkers are the wave-per-walker kernels, above 44 the bound is the multi-workgroup Ellipsoid.update: BASELINE
- * config C4), ndim <= 44 with the MultiEllipsoid bound; sampler 3 (Philox) ndim <= 32.  Sizes: the queue
+ * device for `runs` independent runs at once.  Dimensions: any ndim <= 512 (above 32 the walkers are the
+ * wave-per-walker kernels, above 44 the bound is the multi-workgroup Ellipsoid.update: BASELINE config C4 -- or,
+ * bound_multi=1, the wide MultiEllipsoid.update, whose recursion the host drives: such a run synchronises the
+ * stream on its rebuild fills); sample='unif' ndim <= 32; bootstrap ndim <= 44.  Sizes: the queue
  * consumption keeps a run's keys, their sorted order and the queue in LDS, 12 nlive + 2 P + 52 queue_size bytes
  * <= 150 KB (P = nlive rounded up to a power of two) and queue_size <= 2048 (nlive 2000: any queue; 4000: <= 1870;
  * 5000: <= 1480); DH_ERR_ARG otherwise.  Run r seeds from

@@ -420,5 +420,27 @@ def test_device_resident_loop_refuses_what_is_not_built(ctx):
     from dynesty_amd import problems
     prob = problems.gauss_normal_prior(64, "C4")
     with pytest.raises(Exception):
-        ctx.ns_ensemble(prob, 2, 400, 64, bound='multi', sample='rwalk')  # wide MultiEllipsoid.update: host recursion
+        ctx.ns_ensemble(prob, 2, 400, 64, bound='single', sample='rwalk', bootstrap=5)  # ragged replica batch: D <= 44
+    with pytest.raises(Exception):
+        ctx.ns_ensemble(prob, 2, 400, 64, bound='single', sample='unif')  # resident unif: register dimensions
     # (the Philox proposals above 32 dimensions are built since round 3: tests/test_gpu_philox.py)
+
+
+def test_device_resident_loop_multi_bound_above_44(ctx):
+    """bound='multi' above D = 44 in the resident loop: the masked wide MultiEllipsoid.update (host recursion over
+    device node work, run mask read back on rebuild fills).  On a unimodal cloud the tree keeps its root, the same
+    ellipsoid as bound='single' up to the eigensolver's start (warm there, cold per node here), so the two ensembles
+    run the same streams and land within rounding-driven differences of each other; a run's result must not depend
+    on its shard mates; ln Z agrees with the single-bound ensemble and the analytic value."""
+    from dynesty_amd import problems
+    prob = problems.gauss_normal_prior(48, "C4")
+    kw = dict(sample='rslice', dlogz=0.05, entropy=[48], max_iter=60000)
+    m = ctx.ns_ensemble(prob, 6, 400, 64, bound='multi', **kw)
+    s1 = ctx.ns_ensemble(prob, 6, 400, 64, bound='single', **kw)
+    assert (m["status"] == 0).all() and (m["nbound"] > 5).all(), (m["status"], m["nbound"])
+    se = np.hypot(m["logz"].std(ddof=1), s1["logz"].std(ddof=1)) / np.sqrt(6)
+    assert abs(m["logz"].mean() - s1["logz"].mean()) < 4 * se + 1e-12
+    assert abs(m["logz"].mean() - prob.logz_truth) < 5 * m["logz"].std(ddof=1) / np.sqrt(6) + 0.1
+    alone = ctx.ns_ensemble(prob, 2, 400, 64, bound='multi', first_run=2, **kw)
+    np.testing.assert_array_equal(alone["logz"], m["logz"][2:4])
+    np.testing.assert_array_equal(alone["ncall"], m["ncall"][2:4])
