@@ -18,6 +18,7 @@
 #include <stdlib.h>
 
 #include "ctx.h"
+#include <vector>
 #include "eig_wave.h"
 
 using namespace dh;
@@ -2742,7 +2743,42 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
     if (mode == 1 && active && !n_arr)  // the device-resident loop's masked Ellipsoid.update
       return wide_single_launch_masked(ctx, runs, pts, n, d, nells, status, ctrs, covs, ams, axes, axlens, logvols,
                                        active);
-    return fail(ctx, DH_ERR_ARG, "rebuild: ragged batches for d=%d (> 44) are not built", d);
+    // ragged batch above d = 44 (the bootstrap replicas of a wide bound): the wide constructions take one point
+    // set per call, so the sizes (and the mask) come to the host and the sets go through one after the other
+    std::vector<int32_t> h_n((size_t)runs), h_act;
+    if (!hip_ok(ctx, hipMemcpyAsync(h_n.data(), n_arr, (size_t)runs * 4, hipMemcpyDeviceToHost, ctx->stream), "D2H ragged sizes"))
+      return DH_ERR_HIP;
+    if (active) {
+      h_act.resize((size_t)runs);
+      if (!hip_ok(ctx, hipMemcpyAsync(h_act.data(), active, (size_t)runs * 4, hipMemcpyDeviceToHost, ctx->stream), "D2H run mask"))
+        return DH_ERR_HIP;
+    }
+    if (!hip_ok(ctx, hipStreamSynchronize(ctx->stream), "sync")) return DH_ERR_HIP;
+    const size_t dd = (size_t)d * d;
+    for (int s = 0; s < runs; ++s) {
+      if (active && !h_act[(size_t)s]) continue;
+      const int cnt = h_n[(size_t)s];
+      if (cnt < 0 || cnt > n) return fail(ctx, DH_ERR_ARG, "rebuild: ragged size %d of set %d outside [0, %d]", cnt, s, n);
+      const size_t o = (size_t)s * max_ells;
+      int rc;
+      if (cnt < 2) {  // bounding_ellipsoid of a single point raises (bounding.py:1383-1385)
+        const int32_t st = DH_ERR_VALUE, one = 1;
+        rc = hip_ok(ctx, hipMemcpyAsync(status + s, &st, 4, hipMemcpyHostToDevice, ctx->stream), "H2D") &&
+                     hip_ok(ctx, hipMemcpyAsync(nells + s, &one, 4, hipMemcpyHostToDevice, ctx->stream), "H2D") &&
+                     hip_ok(ctx, hipStreamSynchronize(ctx->stream), "sync")
+                 ? DH_OK
+                 : DH_ERR_HIP;
+      } else if (mode == 1) {
+        rc = wide_single_launch(ctx, 1, pts + (size_t)s * n * d, cnt, d, nells + s, status + s, ctrs + o * d, covs + o * dd,
+                                ams + o * dd, axes + o * dd, axlens + o * d, logvols + o);
+      } else {
+        rc = wide_multi_launch(ctx, 1, pts + (size_t)s * n * d, cnt, d, max_ells, nells + s, status + s, ctrs + o * d,
+                               covs + o * dd, ams + o * dd, axes + o * dd, axlens + o * d, logvols + o,
+                               leaf_of_point ? leaf_of_point + (size_t)s * n : nullptr, nnodes ? nnodes + s : nullptr);
+      }
+      if (rc) return rc;
+    }
+    return DH_OK;
   }
   RebuildArgs a;
   a.pts = pts;

@@ -132,7 +132,8 @@ int dh_contains(dh_ctx* ctx, const double* x, int k, int d, const double* ctrs,
  * Dimensions: d <= 44 runs the LDS-resident kernel pipeline (rebuild.hip);
  * 44 < d <= 512 the wide path (wide.hip: multi-workgroup covariance /
  * eigensolver / Mahalanobis maximum; mode 0 as a host recursion over device node
- * work).  The batched / ragged forms below are d <= 44 for mode 0. */
+ * work).  The batched / ragged forms below take any d <= 512 too; above 44 their
+ * sets go through the wide constructions one after the other. */
 int dh_rebuild(dh_ctx* ctx, const double* pts, int n, int d, int mode, int max_ells,
                int32_t* nells, double* ctrs, double* covs, double* ams, double* axes,
                double* axlens, double* logvols, int32_t* leaf_of_point,
@@ -395,7 +396,7 @@ int dh_ns_consume(dh_ctx* ctx, int runs, int nlive, int queue_size, double dlogz
  * device for `runs` independent runs at once.  Dimensions: any ndim <= 512 (above 32 the walkers are the
  * wave-per-walker kernels, above 44 the bound is the multi-workgroup Ellipsoid.update: BASELINE config C4 -- or,
  * bound_multi=1, the wide MultiEllipsoid.update, whose recursion the host drives: such a run synchronises the
- * stream on its rebuild fills); sample='unif' ndim <= 32; bootstrap ndim <= 44.  Sizes: the queue
+ * stream on its rebuild fills); sample='unif' ndim <= 32.  Sizes: the queue
  * consumption keeps a run's keys, their sorted order and the queue in LDS, 12 nlive + 2 P + 52 queue_size bytes
  * <= 150 KB (P = nlive rounded up to a power of two) and queue_size <= 2048 (nlive 2000: any queue; 4000: <= 1870;
  * 5000: <= 1480); DH_ERR_ARG otherwise.  Run r seeds from
@@ -427,7 +428,8 @@ int dh_ns_consume(dh_ctx* ctx, int runs, int nlive, int queue_size, double dlogz
  * reference's RuntimeError does.  bootstrap = B > 1: every rebuild is followed by the bootstrap expansion of
  * bounding.py:381-400 / 688-703 -- B resampled replicas per run (bounding.py:1593-1648), all rebuilt in one ragged
  * batch, the bound scaled by max(1, largest normalised distance of a left-out point)^ndim; the reference's default
- * for sample='unif' is (enlarge 1, bootstrap 5), dynesty.py:169-200.  ndim <= 44.  0: none.
+ * for sample='unif' is (enlarge 1, bootstrap 5), dynesty.py:169-200.  (Above ndim = 44 the replicas are built one
+ * by one by the wide constructions, with the host between them.)  0: none.
  * rebuild_every = n: bounds are built only every n-th queue fill; a run that becomes due in between idles (proposes
  * and consumes nothing) until then.  Runs are independent, so a run's own sequence -- and with PCG64 streams its
  * result, bit for bit -- is that of the reference schedule (n = 1).  Once n reaches the number of fills a run needs

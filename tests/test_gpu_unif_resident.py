@@ -26,7 +26,9 @@ def _clouds(runs, n, d, seed, two=False):
 
 
 @pytest.mark.parametrize("n,d,multi,two", [(200, 3, False, False), (500, 3, True, True), (300, 10, False, False),
-                                           (1000, 2, True, True), (64, 25, False, False)])
+                                           (1000, 2, True, True), (64, 25, False, False),
+                                           # above d = 44: the replicas go through the wide constructions one by one
+                                           (300, 48, False, False), (420, 48, True, True)])
 def test_bootstrap_expand_vs_oracle(ctx, n, d, multi, two):
     """Every replica's resampling mask is the NumPy draw of the oracle's generator (bit for bit: the expansion
     factor is the distance of one particular left-out point), its bound the oracle's construction."""

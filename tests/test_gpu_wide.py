@@ -420,8 +420,6 @@ def test_device_resident_loop_refuses_what_is_not_built(ctx):
     from dynesty_amd import problems
     prob = problems.gauss_normal_prior(64, "C4")
     with pytest.raises(Exception):
-        ctx.ns_ensemble(prob, 2, 400, 64, bound='single', sample='rwalk', bootstrap=5)  # ragged replica batch: D <= 44
-    with pytest.raises(Exception):
         ctx.ns_ensemble(prob, 2, 400, 64, bound='single', sample='unif')  # resident unif: register dimensions
     # (the Philox proposals above 32 dimensions are built since round 3: tests/test_gpu_philox.py)
 
@@ -444,3 +442,20 @@ def test_device_resident_loop_multi_bound_above_44(ctx):
     alone = ctx.ns_ensemble(prob, 2, 400, 64, bound='multi', first_run=2, **kw)
     np.testing.assert_array_equal(alone["logz"], m["logz"][2:4])
     np.testing.assert_array_equal(alone["ncall"], m["ncall"][2:4])
+
+
+def test_device_resident_loop_bootstrap_above_44(ctx):
+    """bootstrap > 0 above D = 44: the replicas of a rebuilding run go through the wide constructions one by one
+    (rebuild_launch_full's ragged form above the narrow kernels).  The expansion only widens the bound: ln Z must agree
+    with the plain run's ensemble and the analytic value, with more calls per iteration spent."""
+    from dynesty_amd import problems
+    prob = problems.gauss_normal_prior(48, "C4")
+    kw = dict(bound='single', sample='rslice', dlogz=0.05, entropy=[7], max_iter=60000)
+    b = ctx.ns_ensemble(prob, 4, 400, 64, bootstrap=3, **kw)
+    p = ctx.ns_ensemble(prob, 4, 400, 64, **kw)
+    assert (b["status"] == 0).all(), b["status"]
+    se = np.hypot(b["logz"].std(ddof=1), p["logz"].std(ddof=1)) / 2.0
+    assert abs(b["logz"].mean() - p["logz"].mean()) < 4 * se
+    assert abs(b["logz"].mean() - prob.logz_truth) < 5 * b["logz"].std(ddof=1) / 2.0 + 0.1
+    again = ctx.ns_ensemble(prob, 4, 400, 64, bootstrap=3, **kw)
+    np.testing.assert_array_equal(again["logz"], b["logz"])
