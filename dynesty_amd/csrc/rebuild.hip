@@ -2800,7 +2800,7 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
   const size_t b_res = (size_t)runs * a.reslist_cap * 4;
   a.maxw = n / (4 * d) + 1;
   // depth: a balanced tree needs log2(n / 2d) levels; unbalanced splits need more.  The level kernels are launched
-  // for lv + 2 levels, the work-queue form (k_tree) takes whatever is deeper.
+  // for lv levels, the work-queue form (k_tree) takes whatever is deeper.
   int lv = 4;
   while ((1 << lv) < n / (2 * d) + 1) ++lv;
   a.levels = mode == 1 ? 0 : (2 * lv + 8);
@@ -2814,7 +2814,8 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
   // eigen-free tree nodes (MultiEllipsoid.update only: Ellipsoid.update's single node IS the output)
   a.fast = mode == 0 ? 1 : 0;
   if (const char* e = getenv("DH_REBUILD_FAST")) a.fast = a.fast && atoi(e) != 0;  // diagnostic: 0 = eigh on every node
-  // The tree is built by the level pipeline (k_split / k_ell per level) for a balanced tree's depth + 2 levels;
+  // The tree is built by the level pipeline (k_split / k_ell per level) for a balanced tree's depth (lv levels: an
+  // idle level pair costs 10 us, and the bench trees use lv = 6 exactly);
   // whatever is deeper -- unbalanced splits -- is handed to persistent workers on a work queue (k_tree: the same
   // node routines, any depth, any node size; in the common case it finds its queue empty and leaves).
   // DH_TREE=1: the WHOLE tree by the work-queue form.  Bit-identical results (tests/test_gpu_edges.py), but
@@ -2826,10 +2827,10 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
   // the early parts of a multi-part node spinning until the late ones find a worker.
   a.tree = 0;
   if (const char* e = getenv("DH_TREE")) a.tree = a.fast && atoi(e) != 0;
-  // level kernels for a balanced tree's depth plus two, the work-queue tail for the rest (DH_DEEP=0: every level
+  // level kernels for a balanced tree's depth, the work-queue tail for the rest (DH_DEEP=0: every level
   // by level kernels and no tail, as does the diagnostic slow mode; DH_DEEP_FROM=f: the tail takes over at level f)
   int nlev = a.levels;
-  if (a.fast && !(getenv("DH_DEEP") && atoi(getenv("DH_DEEP")) == 0)) nlev = a.levels < lv + 2 ? a.levels : lv + 2;
+  if (a.fast && !(getenv("DH_DEEP") && atoi(getenv("DH_DEEP")) == 0)) nlev = a.levels < lv ? a.levels : lv;
   if (a.fast && getenv("DH_DEEP_FROM")) {
     const int f = atoi(getenv("DH_DEEP_FROM"));
     if (f >= 1 && f < a.levels) nlev = f;
