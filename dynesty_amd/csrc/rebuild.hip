@@ -2156,6 +2156,9 @@ __global__ void __launch_bounds__(kThreads, 2) k_tree(RebuildArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ unsigned long long s_item;
   const int t = threadIdx.x;
+  // nothing queued by the level kernels (they are complete: stream order) = nothing ever will be.  A load instead of
+  // a ticket: 512 workgroups taking tickets from one counter of an empty queue cost 13 us.
+  if (__hip_atomic_load(a.tq_ctl + 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= 0) return;
   for (;;) {
     __syncthreads();  // the previous item's LDS use is over
     if (t == 0) {
