@@ -168,6 +168,7 @@ struct Lds {
 };
 
 // block reductions: wave shuffles, then one LDS exchange across the 4 waves
+template <int NT = kThreads>
 __device__ __forceinline__ double block_reduce_max(double v, double* red) {
   for (int s = 32; s > 0; s >>= 1) v = fmax(v, __shfl_xor(v, s));
   const int t = threadIdx.x;
@@ -175,7 +176,7 @@ __device__ __forceinline__ double block_reduce_max(double v, double* red) {
   if ((t & 63) == 0) red[t >> 6] = v;
   __syncthreads();
   double r = red[0];
-  for (int i = 1; i < kThreads / 64; ++i) r = fmax(r, red[i]);
+  for (int i = 1; i < NT / 64; ++i) r = fmax(r, red[i]);
   __syncthreads();
   return r;
 }
@@ -398,13 +399,14 @@ __device__ __forceinline__ void st_ci(const Lds& L, int* p, int v) {
 }
 
 constexpr int kStageBatch = 8;
+template <int NT = kThreads>
 __device__ __forceinline__ void stage_tile(const Lds& L, const double* __restrict__ pts,
                                            const int* __restrict__ perm, int start, int cnt, int D,
                                            int how) {
-  // column j = t & (DP-1) (DP = pow2 >= D), rows stride by kThreads/DP: consecutive lanes
+  // column j = t & (DP-1) (DP = pow2 >= D), rows stride by NT/DP: consecutive lanes
   // read consecutive doubles of one point (coalesced), no integer division.
   const int j = threadIdx.x & (L.DP - 1);
-  const int p0 = threadIdx.x >> L.DPlog, pstep = kThreads >> L.DPlog;
+  const int p0 = threadIdx.x >> L.DPlog, pstep = NT >> L.DPlog;
   if (L.c_pts == pts && L.c_start == start && L.c_cnt == cnt) {
     if (L.c_how == how) return;  // the tile already holds exactly this (callers barrier after use)
     if (L.c_how == 0 && how == 1) {
@@ -522,8 +524,8 @@ constexpr int kMfmaMinDim = 10;  // below this the quadratic form stays on the V
 // C = Xc^T Xc.  Each wave contracts its own 64 points of every tile (K = points, 16 MFMA
 // steps of 4), upper 16x16 blocks only; the four partial sums are folded in wave order.
 // accumulate Xc^T Xc of the staged (centred) tile: each wave contracts its own 64 points
-__device__ __forceinline__ void tile_cov_accumulate(const Lds& L, int cnt, int D, mfma_acc (&acc)[6]) {
-  const int t = threadIdx.x, lane = t & 63, w = t >> 6, LD = L.LD;
+__device__ __forceinline__ void tile_cov_accumulate(const Lds& L, int cnt, int D, mfma_acc (&acc)[6], int wsel = -1) {
+  const int t = threadIdx.x, lane = t & 63, w = wsel >= 0 ? wsel : (t >> 6), LD = L.LD;  // wsel: k_ell_wave plays the waves in turn
   const int nb = (D + 15) >> 4;  // 16-wide dimension blocks: 1..3 (D <= 44)
   const int lj = lane & 15, lk = lane >> 4;
   const bool v0 = lj < D, v1 = 16 + lj < D, v2 = 32 + lj < D;
@@ -577,8 +579,9 @@ __device__ __forceinline__ void cov_fold_waves(const Lds& L, int D, const mfma_a
 }
 
 // upper triangle of L.A times inv, mirrored
+template <int NT = kThreads>
 __device__ __forceinline__ void cov_finalize(const Lds& L, int D, double inv) {
-  for (int e = threadIdx.x; e < D * D; e += kThreads) {
+  for (int e = threadIdx.x; e < D * D; e += NT) {
     const int i = e / D, j = e - i * D;
     if (i <= j) {
       const double c = L.A[i * L.LD + j] * inv;
@@ -631,11 +634,12 @@ __device__ __forceinline__ void node_cov(const Lds& L, const double* pts, const 
 // Z = X AM on the matrix cores (M = 16 points per block, N = dimension blocks, K = D in
 // steps of 4), then the row-wise dot Z.x and a 16-lane reduction.  Returns the per-thread
 // running maximum (callers reduce over the block).
+template <int NT = kThreads>
 __device__ __forceinline__ double tile_quadform_max(const Lds& L, const double* AM, int cnt, int D, double best) {
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, LD = L.LD;
   const int nb = (D + 15) >> 4, ksteps = (D + 3) >> 2;
   const int lj = lane & 15, lk = lane >> 4;
-  for (int mb = w; mb * 16 < cnt; mb += kThreads / 64) {
+  for (int mb = w; mb * 16 < cnt; mb += NT / 64) {
     const int p0 = mb * 16;
     mfma_acc z0 = {0.0, 0.0, 0.0, 0.0}, z1 = z0, z2 = z0;
     const bool pa = p0 + lj < cnt;
@@ -675,18 +679,19 @@ __device__ __forceinline__ double tile_quadform_max(const Lds& L, const double* 
 }
 
 // max_i delta_i^T AM delta_i over a node (bounding.py:1438), delta about L.mean
+template <int NT = kThreads>
 __device__ __forceinline__ double node_fmax(const Lds& L, const double* pts, const int* perm, int start, int count, int D) {
   double best = -INFINITY;
   PH_T0();
   for (int base = 0; base < count; base += L.TP) {
     const int cnt = min(L.TP, count - base);
-    stage_tile(L, pts, perm, start + base, cnt, D, 1);
+    stage_tile<NT>(L, pts, perm, start + base, cnt, D, 1);
     PH_ADD(5);
     if (D >= kMfmaMinDim) {
-      best = tile_quadform_max(L, L.AM, cnt, D, best);
+      best = tile_quadform_max<NT>(L, L.AM, cnt, D, best);
     } else {
       // small D: a point's D^2 FMAs are cheaper than the 16-lane reductions of the MFMA form
-      for (int p = threadIdx.x; p < cnt; p += kThreads) {
+      for (int p = threadIdx.x; p < cnt; p += NT) {
         const double* x = L.tile + p * L.LD;
         double q = 0.0;
         for (int i = 0; i < D; ++i) {
@@ -700,7 +705,7 @@ __device__ __forceinline__ double node_fmax(const Lds& L, const double* pts, con
     }
     __syncthreads();
   }
-  return block_reduce_max(best, L.red);
+  return block_reduce_max<NT>(best, L.red);
 }
 
 // helpers on D x D LDS matrices (all threads)
@@ -843,12 +848,13 @@ __device__ __forceinline__ double wave_trace(const double* M, int D, int LD) {
 }
 
 // Q = s2 * P P for the symmetric D x D matrix P (LDS, D x LD); all threads; caller barriers
+template <int NT = kThreads>
 __device__ __forceinline__ void sym_square(const double* P, double* Q, int D, int LD, double s2) {
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   if (D >= kMfmaMinDim) {
     const int nb = (D + 15) >> 4, ksteps = (D + 3) >> 2;
     const int lj = lane & 15, lk = lane >> 4;
-    for (int tile = w; tile < nb * nb; tile += kThreads / 64) {
+    for (int tile = w; tile < nb * nb; tile += NT / 64) {
       const int ti = tile / nb, tj = tile - ti * nb;
       mfma_acc acc = {0.0, 0.0, 0.0, 0.0};
       const int ca = ti * 16 + lj, cb = tj * 16 + lj;
@@ -867,7 +873,7 @@ __device__ __forceinline__ void sym_square(const double* P, double* Q, int D, in
       }
     }
   } else {
-    for (int e = t; e < D * D; e += kThreads) {
+    for (int e = t; e < D * D; e += NT) {
       const int i = e / D, j = e - i * D;
       double sum = 0.0;
       for (int k = 0; k < D; ++k) sum = fma(P[k * LD + i], P[k * LD + j], sum);
@@ -894,10 +900,11 @@ __device__ __forceinline__ double rcp_nr(double x) {
 // Schur-complement pivots of LDL^T, so their logarithms sum to ln det).  Sweep k reads one buffer and
 // writes the other (L.AM <-> L.A), so a sweep is: pivot, pivot row / column, own entries, ONE barrier.
 // Thread map: column j = t mod JW, rows t / JW, t / JW + 256 / JW, ... (JW = 32 or 64 >= D).
+template <int NT = kThreads>
 __device__ __forceinline__ bool spd_fast(const Lds& L, const double* cov, int D, bool want_axis, double* logdet) {
   const int t = threadIdx.x, LD = L.LD;
   const int jsh = D <= 32 ? 5 : 6;
-  const int j = t & ((1 << jsh) - 1), i0 = t >> jsh, istep = kThreads >> jsh;
+  const int j = t & ((1 << jsh) - 1), i0 = t >> jsh, istep = NT >> jsh;
   double* src = (D & 1) ? L.AM : L.A;  // D sweeps later the result sits in L.A
   double* dst = (D & 1) ? L.A : L.AM;
   double* pivs = L.red;  // the D pivots
@@ -967,7 +974,7 @@ __device__ __forceinline__ bool spd_fast(const Lds& L, const double* cov, int D,
   if (!(tr_cov * tr_am < kFastCond)) return false;
   *logdet = ld;
   PH_ADD(13);
-  for (int e = t; e < D * D; e += kThreads) L.AX[(e / D) * LD + e % D] = 0.0;
+  for (int e = t; e < D * D; e += NT) L.AX[(e / D) * LD + e % D] = 0.0;
   if (t < D) L.lam[t] = 0.0;
   if (!want_axis) {
     __syncthreads();
@@ -987,7 +994,7 @@ __device__ __forceinline__ bool spd_fast(const Lds& L, const double* cov, int D,
   double* Q = L.V;
   {
     const double s0 = ldexp(1.0, -(ilogb(tr_cov) + 1));  // trace in [1/2, 1)
-    for (int e = t; e < D * D; e += kThreads) P[(e / D) * LD + e % D] = cov[(e / D) * LD + e % D] * s0;
+    for (int e = t; e < D * D; e += NT) P[(e / D) * LD + e % D] = cov[(e / D) * LD + e % D] * s0;
   }
   __syncthreads();
   double trP = wave_trace(P, D, LD);
@@ -997,7 +1004,7 @@ __device__ __forceinline__ bool spd_fast(const Lds& L, const double* cov, int D,
     // trace: tr(P^2) / tr(P)^2 = r in [1/D, 1] is the sum of the squared eigenvalue weights of P, so the
     // stored trace stays within [1/(4D), 1) without a pass of its own
     const double sc = ldexp(1.0, -(ilogb(trP * trP) + 1));
-    sym_square(P, Q, D, LD, sc);
+    sym_square<NT>(P, Q, D, LD, sc);
     __syncthreads();
     const double trQ = wave_trace(Q, D, LD);
     const double r = trQ / (trP * trP * sc);
@@ -1057,13 +1064,14 @@ __device__ __forceinline__ bool spd_fast(const Lds& L, const double* cov, int D,
 }
 
 // enlarge the ellipsoid so that the outermost point sits at 1 - ROUND_DELTA (bounding.py:1438-1448)
+template <int NT = kThreads>
 __device__ __forceinline__ void ellipsoid_rescale(const Lds& L, double* cov_g, int D, double fmx) {
   const int t = threadIdx.x, LD = L.LD;
   const double lim = 1.0 - kRoundDelta;
   if (fmx > lim) {
     const double mult = fmx / lim;
     const double rt = sqrt(mult);
-    for (int e = t; e < D * D; e += kThreads) {
+    for (int e = t; e < D * D; e += NT) {
       const int i = e / D, j = e % D;
       cov_g[i * LD + j] *= mult;
       L.AM[i * LD + j] /= mult;
@@ -1107,6 +1115,7 @@ __device__ __forceinline__ int ellipsoid_store(const Lds& L, const RebuildArgs& 
 
 // record of an eigen-free node: ctr | cov | am | axes (column 0 = major axis, rest 0) | axlens
 // (entry 0 = its length, rest 0: k_split's argmax picks column 0).  ln vol = prefactor + ln det / 2.
+template <int NT = kThreads>
 __device__ __forceinline__ int ellipsoid_store_fast(const Lds& L, const RebuildArgs& a, double* es,
                                                     const double* cov_g, double logdet, double* logvol_out) {
   const int D = a.d, t = threadIdx.x, LD = L.LD;
@@ -1116,7 +1125,7 @@ __device__ __forceinline__ int ellipsoid_store_fast(const Lds& L, const RebuildA
     st_c(L, es + t, L.mean[t]);
     st_c(L, es + D + 3 * DD + t, sqrt(L.lam[t]));
   }
-  for (int e = t; e < DD; e += kThreads) {
+  for (int e = t; e < DD; e += NT) {
     const int i = e / D, j = e % D;
     st_c(L, es + D + e, cov_g[i * LD + j]);
     st_c(L, es + D + DD + e, L.AM[i * LD + j]);
@@ -2099,7 +2108,7 @@ __device__ __forceinline__ bool ell_body(const RebuildArgs& a, const Lds& L, con
 template <bool SLOW>
 // (two workgroups per CU: held to the 168 registers of three, with a 128-point tile so that LDS would allow it, the
 // eigen-free path spills and the rebuild loses 7 %)
-__global__ void __launch_bounds__(kThreads, SLOW ? 1 : 2) k_ell(RebuildArgs a, int level, int G) {
+__global__ void __launch_bounds__(kThreads, SLOW ? 1 : 2) k_ell(RebuildArgs a, int level, int G, int skip_done) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int run = blockIdx.x / G, g = blockIdx.x % G;
   const int* list = a.ell_list + (size_t)run * 2 * a.maxw;
@@ -2114,8 +2123,160 @@ __global__ void __launch_bounds__(kThreads, SLOW ? 1 : 2) k_ell(RebuildArgs a, i
   Lds L;
   carve(L, smem, D);
   const RunView v = view_of(a, run, L.LD);
-  for (int slot = g; slot < cnt; slot += G)
+  for (int slot = g; slot < cnt; slot += G) {
+    // (a child is created with fmax = inf: a finite value = k_ell_wave has built this one)
+    if (skip_done && v.nodes[list[slot]].fmax < INFINITY) continue;
     if (!ell_body<SLOW>(a, L, v, run, level, list[slot])) return;
+  }
+}
+
+// ---- small nodes, one wavefront each ---------------------------------------------------------------------
+// The deep levels of a tree are many small nodes (the 64-run bench rebuild: 2 048 leaves of ~62 points at level
+// 5; an eggbox live set: hundreds of nodes of 8-60 points per level and run), and a level's time is the number of
+// ROUNDS its nodes need on the chip's workgroup slots: k_ell holds 256 threads, 242 registers and 77 KB of LDS per
+// node -- two nodes per CU.  k_ell_wave builds a node of at most `cap` points with ONE wavefront and an LDS carve of
+// its own (tile of cap points, two or four D x D matrices): the same routines instantiated for 64 threads
+// (stage_tile / spd_fast / node_fmax / ... <64>: every element-wise loop and every MFMA tile is the same
+// instruction on the same operands whichever thread issues it), the covariance contraction with the four waves of
+// k_ell played in turn (tile_cov_accumulate's wsel: wave w takes points [64 w, 64 w + 64), partial sums folded in
+// wave order).  So a node gets the SAME BITS from either kernel (tests/test_gpu_edges.py holds the whole tree to
+// that), and which kernel builds it is a scheduling decision: k_ell_wave runs first over the level's list and takes
+// the nodes that fit (`axis` = 0: leaves only -- count < 4 D, no major axis wanted, half the matrices), marks them
+// by their finite fmax, and k_ell skips those.  A node whose eigen-free path does not apply (spd_fast false) is
+// left untouched for k_ell's in-place fallback.
+constexpr int kWaveDeclined = 2;
+
+__host__ __device__ inline size_t wave_lds_bytes(int D, int cap, bool axis) {
+  const int LD = D | 1;
+  return ((((size_t)cap * LD + (axis ? 4 : 2) * (size_t)D * LD + 2 * (size_t)D + 64) * 8) + 15) & ~(size_t)15;
+}
+
+__device__ __forceinline__ void carve_wave(Lds& L, unsigned char* smem, int D, int cap, bool axis) {
+  L.LD = D | 1;
+  L.TP = cap;
+  L.c_pts = nullptr;
+  L.c_start = L.c_cnt = L.c_how = -1;
+  L.coh = false;
+  L.KG = 1;
+  L.DP = 1;
+  L.DPlog = 0;
+  while (L.DP < D) {
+    L.DP <<= 1;
+    ++L.DPlog;
+  }
+  double* p = (double*)smem;
+  L.tile = p;
+  p += (size_t)cap * L.LD;
+  L.A = p;
+  p += D * L.LD;
+  L.AM = p;
+  p += D * L.LD;
+  if (axis) {
+    L.V = p;
+    p += D * L.LD;
+    L.AX = p;
+    p += D * L.LD;
+  } else {
+    L.V = nullptr;  // (the squarings of the major axis: not wanted for a leaf)
+    L.AX = L.A;     // spd_fast zeroes AX after its last use of A
+  }
+  L.mean = p;
+  p += D;
+  L.lam = p;
+  p += D;
+  L.red = p;
+  L.scale = L.cen = L.sums = L.rc = L.rs = L.kred = nullptr;
+  L.ri = L.perm_sort = nullptr;
+  L.JA[0] = L.JA[1] = L.JV[0] = L.JV[1] = nullptr;
+  L.JLD = 0;
+  L.j_alias = false;
+}
+
+// node_ellipsoid<true> for a child (mean in its record) of at most L.TP points, by one wavefront
+__device__ __forceinline__ int node_ellipsoid_wave(const Lds& L, const RebuildArgs& a, const double* pts, const int* perm,
+                                                   int start, int count, double* es, double* cov_g,
+                                                   double* logvol_out, double* fmax_out) {
+  constexpr int NT = 64;
+  const int D = a.d, t = threadIdx.x, LD = L.LD;
+  if (t < D) L.mean[t] = es[t];
+  __syncthreads();
+  // node_cov, one tile
+  stage_tile<NT>(L, pts, perm, start, count, D, 1);
+  {
+    const int nb = (D + 15) >> 4, lj = t & 15, lk = t >> 4;
+    for (int wv = 0; wv * 64 < count; ++wv) {
+      mfma_acc acc[6];
+#pragma unroll
+      for (int b = 0; b < 6; ++b) acc[b] = (mfma_acc){0.0, 0.0, 0.0, 0.0};
+      tile_cov_accumulate(L, count, D, acc, wv);
+#pragma unroll
+      for (int b = 0; b < 6; ++b) {  // cov_fold_waves, this wave's turn
+        const int ib = b == 0 ? 0 : b == 1 ? 0 : b == 2 ? 1 : b == 3 ? 0 : b == 4 ? 1 : 2;
+        const int jb = b == 0 ? 0 : b == 1 ? 1 : b == 2 ? 1 : 2;
+        if (jb < nb) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int i = ib * 16 + lk + 4 * r, j = jb * 16 + lj;
+            if (i < D && j < D) {
+              double v = acc[b][r];
+              if (wv > 0) v += L.A[i * LD + j];
+              L.A[i * LD + j] = v;
+            }
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  cov_finalize<NT>(L, D, 1.0 / (double)(count - 1));
+  for (int e = t; e < D * D; e += NT) cov_g[(e / D) * LD + e % D] = L.A[(e / D) * LD + e % D];
+  __syncthreads();
+  double logdet = 0.0;
+  if (!spd_fast<NT>(L, cov_g, D, a.mode == 0 && count >= 4 * D, &logdet)) return kWaveDeclined;
+  const double fmx = node_fmax<NT>(L, pts, perm, start, count, D);
+  if (fmx > 1.0 - kRoundDelta) logdet += (double)D * log(fmx / (1.0 - kRoundDelta));
+  ellipsoid_rescale<NT>(L, cov_g, D, fmx);
+  *fmax_out = fmin(fmx, 1.0 - kRoundDelta);
+  return ellipsoid_store_fast<NT>(L, a, es, cov_g, logdet, logvol_out);
+}
+
+__global__ void __launch_bounds__(64, 3) k_ell_wave(RebuildArgs a, int level, int G, int cap, int axis) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int run = blockIdx.x / G, g = blockIdx.x % G;
+  const int* list = a.ell_list + (size_t)run * 2 * a.maxw;
+  const int cnt = a.nell[(size_t)level * a.runs + run];
+  if (g >= cnt) return;
+  if (a.kerr[run] != DH_OK || a.status[run] != DH_OK) return;  // (k_ell, next on the stream, reports it)
+  const int D = a.d, t = threadIdx.x;
+  Lds L;
+  carve_wave(L, smem, D, cap, axis != 0);
+  const RunView v = view_of(a, run, L.LD);
+  for (int slot = g; slot < cnt; slot += G) {
+    const int node = list[slot];
+    const int start = v.nodes[node].start, count = v.nodes[node].count;
+    if (!v.nodes[node].has_mean || count < 2 || count > cap || (!axis && count >= 4 * D)) continue;
+    double lv = 0.0, fmx = INFINITY;
+    __syncthreads();
+    L.c_pts = nullptr;
+    const int rc = node_ellipsoid_wave(L, a, v.pts, v.perm, start, count, v.estore + (size_t)node * v.NS,
+                                       v.estore + (size_t)node * v.NS + v.ES, &lv, &fmx);
+    if (rc == kWaveDeclined) continue;
+    if (rc != DH_OK) {
+      set_status(a, run, rc);
+      return;
+    }
+    if (t == 0) {  // ell_body's tail
+      v.nodes[node].logvol = lv;
+      v.nodes[node].fast = 1;
+      if (count >= 4 * D) {
+        if (a.tree_from > a.levels && level + 1 >= a.levels)
+          atomicMin(&a.status[run], DH_ERR_NOMEM);
+        else
+          queue_split(a, run, level + 1, node, count);
+      }
+      v.nodes[node].fmax = fmx;
+    }
+  }
 }
 
 // ---- the whole tree by persistent workers on one work queue -----------------------------------------------
@@ -3054,12 +3215,38 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
   } else {
     a.root_eig = nullptr;
   }
+  // small nodes by one wavefront each (k_ell_wave), from the level where the average child fits -- where eight such
+  // nodes (128-point tile, four D x D matrices) share a CU's LDS: D <= 13.  Measured (tools/wave_ell_ab.py, 64 sets):
+  // eggbox 2-D 6.54 -> 4.67 ms, two blobs 5-D 0.91 -> 0.75, 3-D blob 0.71 -> 0.62.  At D = 25 the leaves-only form
+  // LOSES (1.29 -> 1.41 ms: 39 point loads and 13 matrix rows per lane and sweep outweigh the rounds saved), so
+  // above D = 13 it is off.  DH_WAVE_ELL=0: off; =1: leaves only; =2: with the axis, at any D that fits 64 KB.
+  int wave_from = nlev, wave_cap = 0, wave_axis = 0;
+  size_t lds_wave = 0;
+  if (a.fast) {
+    const char* e = getenv("DH_WAVE_ELL");
+    const int mode_w = e ? atoi(e) : -1;
+    if (mode_w != 0) {
+      wave_cap = 128;
+      const bool fits8 = wave_lds_bytes(d, wave_cap, true) * 8 <= kLdsLimit;
+      wave_axis = mode_w == 2 || (mode_w < 0 && fits8) ? 1 : 0;
+      if (!wave_axis) wave_cap = 4 * d - 1 < 128 ? 4 * d - 1 : 128;
+      lds_wave = wave_lds_bytes(d, wave_cap, wave_axis != 0);
+      if ((mode_w > 0 || fits8) && wave_cap >= 2 && lds_wave <= 64 * 1024) {
+        wave_from = 0;
+        while (wave_from < nlev && (n >> (wave_from + 1)) > 2 * wave_cap) ++wave_from;
+      }
+    }
+  }
   for (int L = 0; L < nlev; ++L) {
     hipLaunchKernelGGL(k_split, dim3(runs * a.maxp), dim3(kThreads), lds_split, ctx->stream, a, L);
+    const int wave = L >= wave_from ? 1 : 0;
+    if (wave)
+      hipLaunchKernelGGL(k_ell_wave, dim3(runs * 2 * a.maxw), dim3(64), lds_wave, ctx->stream, a, L, 2 * a.maxw, wave_cap,
+                         wave_axis);
     if (a.fast)
-      hipLaunchKernelGGL(k_ell<false>, dim3(runs * 2 * a.maxw), dim3(kThreads), lds, ctx->stream, a, L, 2 * a.maxw);
+      hipLaunchKernelGGL(k_ell<false>, dim3(runs * 2 * a.maxw), dim3(kThreads), lds, ctx->stream, a, L, 2 * a.maxw, wave);
     else
-      hipLaunchKernelGGL(k_ell<true>, dim3(runs * 2 * a.maxw), dim3(kThreads), lds, ctx->stream, a, L, 2 * a.maxw);
+      hipLaunchKernelGGL(k_ell<true>, dim3(runs * 2 * a.maxw), dim3(kThreads), lds, ctx->stream, a, L, 2 * a.maxw, 0);
   }
   if (tail) {
     // persistent workers: as many as can be resident (the parts of a node meet at spin barriers), but

@@ -208,7 +208,7 @@ def test_work_queue_tree_equals_the_level_kernels(ctx):
 
 
 def test_work_queue_tail_equals_the_level_kernels(ctx):
-    """The level kernels are launched for a balanced tree's depth + 2; whatever is deeper is handed to the work-queue
+    """The level kernels are launched for a balanced tree's depth; whatever is deeper is handed to the work-queue
     form (k_tree: persistent workers, any depth, any node size).  Forced to take over early (DH_DEEP_FROM) it must
     give bit-identical results to the level kernels alone (DH_DEEP=0) -- also from level 1 on, where the C2 cloud's
     nodes have 1000 points (the single-workgroup tail of round 2 could only take nodes of <= 256 points)."""
@@ -237,6 +237,52 @@ def test_work_queue_tail_equals_the_level_kernels(ctx):
             for k in FIELDS + ("labels",):
                 np.testing.assert_array_equal(ref[k], got[k])
     assert deep_trees >= 2
+
+
+def test_one_wavefront_per_small_node_gives_the_same_bits(ctx):
+    """k_ell_wave builds the small nodes of the deep levels with one wavefront each (the same routines instantiated
+    for 64 threads, the covariance contraction with k_ell's four waves played in turn): which kernel builds a node is
+    a scheduling decision, so every output must be bit-identical with it off (DH_WAVE_ELL=0), on by default
+    (D <= 13), leaves only (=1) and with the major axis at any D (=2) -- single live sets and a batch."""
+    import os
+    clouds = [inputs.cloud(n) for n in ("c3", "two5", "ring2", "g3", "egg13", "c2", "flat10", "small4")]
+
+    def run(pts, env):
+        old = os.environ.get("DH_WAVE_ELL")
+        if env is None:
+            os.environ.pop("DH_WAVE_ELL", None)
+        else:
+            os.environ["DH_WAVE_ELL"] = env
+        try:
+            return ctx.rebuild(pts, multi=True, want_labels=True)
+        finally:
+            if old is None:
+                os.environ.pop("DH_WAVE_ELL", None)
+            else:
+                os.environ["DH_WAVE_ELL"] = old
+    many = 0
+    for pts in clouds:
+        ref = run(pts, "0")
+        many += ref["nells"] > 4
+        for env in (None, "1", "2"):
+            got = run(pts, env)
+            assert ref["nells"] == got["nells"] and ref["nnodes"] == got["nnodes"], env
+            for k in FIELDS + ("labels",):
+                np.testing.assert_array_equal(ref[k], got[k])
+    assert many >= 3
+    # a batch of permuted eggbox live sets (the rounds of workgroup slots are what the wave form is for)
+    c3 = inputs.cloud("c3")
+    sets = [c3[np.random.default_rng(r).permutation(len(c3))] for r in range(8)]
+    os.environ["DH_WAVE_ELL"] = "0"
+    try:
+        ref = ctx.rebuild_many(sets, multi=True)
+    finally:
+        del os.environ["DH_WAVE_ELL"]
+    got = ctx.rebuild_many(sets, multi=True)
+    for a, b in zip(ref, got):
+        assert a["nells"] == b["nells"]
+        for k in a:
+            np.testing.assert_array_equal(np.asarray(a[k]), np.asarray(b[k]))
 
 
 def test_unbalanced_tree_deeper_than_the_level_plan(ctx):
