@@ -2313,13 +2313,12 @@ __device__ __attribute__((noinline)) void tree_ell_item(const RebuildArgs& a, un
   (void)ell_body<false>(a, L, v, run, 0, node);
 }
 
-__global__ void __launch_bounds__(kThreads, 2) k_tree(RebuildArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+// (the item routines take the argument block by reference, so the worker keeps a copy of it on its stack: 476 bytes
+// per lane.  Behind a call the copy is made only by workers that have work: in the kernel's own prologue it was 58 MB
+// of scratch stores -- the whole 10 us of the empty-queue launch that every rebuild ends with.)
+__device__ __attribute__((noinline)) void tree_worker(RebuildArgs a, unsigned char* smem) {
   __shared__ unsigned long long s_item;
   const int t = threadIdx.x;
-  // nothing queued by the level kernels (they are complete: stream order) = nothing ever will be.  A load instead of
-  // a ticket: 512 workgroups taking tickets from one counter of an empty queue cost 13 us.
-  if (__hip_atomic_load(a.tq_ctl + 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= 0) return;
   for (;;) {
     __syncthreads();  // the previous item's LDS use is over
     if (t == 0) {
@@ -2352,6 +2351,13 @@ __global__ void __launch_bounds__(kThreads, 2) k_tree(RebuildArgs a) {
     __syncthreads();
     if (t == 0) __hip_atomic_fetch_add(a.tq_ctl + 32, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+}
+
+__global__ void __launch_bounds__(kThreads, 2) k_tree(RebuildArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // nothing queued by the level kernels (they are complete: stream order) = nothing ever will be
+  if (__hip_atomic_load(a.tq_ctl + 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= 0) return;
+  tree_worker(a, smem);
 }
 
 __global__ void __launch_bounds__(kThreads) k_finish(RebuildArgs a) {
