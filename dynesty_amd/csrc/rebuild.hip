@@ -1928,7 +1928,13 @@ __global__ void __launch_bounds__(kThreads) k_root_parts(RebuildArgs a, int rp) 
     a.status[run] = status;
   }
   if (np == 1 && status == DH_OK && a.mode == 0 && n >= 4 * D) {
-    node_std(L, v.pts, v.perm, 0, n, D);
+    {
+      // (node_std is a call: handing it a copy keeps L itself out of memory -- with its address taken the carve-up
+      // lived on every lane's stack for the whole kernel, 224 bytes written and every L.xxx a scratch load)
+      const Lds Lc = L;
+      node_std(Lc, v.pts, v.perm, 0, n, D);
+      L.c_pts = nullptr;  // the tile now holds what the copy staged
+    }
     if (t < D) a.scale_g[(size_t)run * D + t] = L.scale[t];
     double* ps = a.pts_scaled + (size_t)run * a.n * D;
     const int jj = t & (L.DP - 1), p0 = t >> L.DPlog, pstep = kThreads >> L.DPlog;
