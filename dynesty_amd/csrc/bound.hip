@@ -103,13 +103,50 @@ __global__ void __launch_bounds__(64)
   }
 }
 
+// The same test above the register-resident dimensions: one wavefront per start point, lanes over the rows of the
+// symmetric precision matrix (r_i = sum_j A[j][i] dl[j]: consecutive lanes read consecutive doubles), the point's
+// offset from the centre in LDS, q = sum_i dl_i r_i by a wave reduction.
+__global__ void __launch_bounds__(64)
+    contains_runs_wide_kernel(const double* __restrict__ x, int k, int d, int wpr, const double* __restrict__ ctrs,
+                              const double* __restrict__ ams, const int* __restrict__ nells, int max_ells, int strict,
+                              const int* __restrict__ run_mode, int my_mode, const int* __restrict__ bstatus, int* flag) {
+  extern __shared__ double dl[];
+  const int w = blockIdx.x, lane = threadIdx.x;
+  if (w >= k) return;
+  const int run = w / wpr;
+  if ((run_mode && run_mode[run] != my_mode) || (bstatus && bstatus[run] != 0)) return;
+  const int m = nells ? nells[run] : 1;
+  bool inside = false;
+  for (int a = 0; a < m && !inside; ++a) {
+    const double* __restrict__ c = ctrs + ((size_t)run * max_ells + a) * d;
+    const double* __restrict__ A = ams + ((size_t)run * max_ells + a) * d * d;
+    __syncthreads();
+    for (int i = lane; i < d; i += 64) dl[i] = x[(size_t)w * d + i] - c[i];
+    __syncthreads();
+    double q = 0.0;
+    for (int i = lane; i < d; i += 64) {
+      double r = 0.0;
+      for (int j = 0; j < d; ++j) r = fma(A[(size_t)j * d + i], dl[j], r);
+      q = fma(dl[i], r, q);
+    }
+    for (int sft = 32; sft > 0; sft >>= 1) q += __shfl_xor(q, sft);
+    inside = strict ? (q < 1.0) : (sqrt(q) <= 1.0);
+  }
+  if (!inside && lane == 0) atomicOr(&flag[run], 1);
+}
+
 }  // namespace
 
 namespace dh {
 int contains_runs_launch(dh_ctx* ctx, const double* x, int k, int d, int wpr, const double* ctrs, const double* ams,
                          const int* nells, int max_ells, int strict, const int* run_mode, int my_mode,
                          const int* bstatus, int* flag) {
-  if (k <= 0 || d > kMaxRegDim) return DH_OK;  // (above the register dimensions the check is not built)
+  if (k <= 0) return DH_OK;
+  if (d > kMaxRegDim) {
+    hipLaunchKernelGGL(contains_runs_wide_kernel, dim3(k), dim3(64), (size_t)d * 8, ctx->stream, x, k, d, wpr, ctrs, ams,
+                       nells, max_ells, strict, run_mode, my_mode, bstatus, flag);
+    return hip_ok(ctx, hipGetLastError(), "contains_runs launch") ? DH_OK : DH_ERR_HIP;
+  }
   const dim3 grid((k + 63) / 64), block(64);
   bool hit = false;
 #define X(NN)                                                                                              \

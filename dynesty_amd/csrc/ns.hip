@@ -2035,7 +2035,7 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
       // Sampler.propose_live rebuilds the bound at once when a start point lies outside it (sampler.py:484-489:
       // a point accepted since the last update, beyond the enlarged ellipsoids).  Here the run is flagged and
       // rebuilds before its NEXT fill: the walkers of this fill are already chosen, and a queue of K proposals
-      // is as stale in the reference.  (Register-resident dimensions.)
+      // is as stale in the reference.  (Above the register-resident dimensions: one wavefront per start point.)
       if (force_check && sampler != 3) {
         rc = contains_runs_launch(ctx, a.q_u0, R * K, D, K, a.b_ctrs, a.b_ams, bound_multi ? a.nells : nullptr, me,
                                   bound_multi ? 1 : 0, a.run_mode, MODE_BOUND, a.bstatus, a.force);

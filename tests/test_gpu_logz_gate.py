@@ -176,3 +176,27 @@ def test_c1_device_unif_ensemble_vs_reference_ensemble(ctx, bnd, rng):
     # calls and bounds per run: the bootstrap-expanded bound is as tight as the reference's
     assert abs(r["ncall"].mean() / ref["mean_ncall"] - 1) < 0.08
     assert abs(r["nbound"].mean() / ref["mean_nbound"] - 1) < 0.25
+
+
+@pytest.mark.parametrize("K,bound,ref_key", [(1, "multi", "multi_K1"), (64, "multi", "multi_K64"), (64, "single", "single_K64")])
+def test_forced_bound_updates_above_the_register_dimensions(ctx, K, bound, ref_key):
+    """Sampler.propose_live rebuilds the bound when a walker's start point lies outside it (sampler.py:484-489).
+    At 40 dimensions with 333 live points that happens all the time -- the ellipsoid of so few points, enlarged by
+    1.25 in VOLUME (0.6 % in radius), misses most new live points: the reference makes ~120 bound updates where the
+    call-count schedule alone makes ~45 -- and with an under-mixed rwalk (walks = 60) the evidence depends on it by
+    several nats at queue size 64 (the real reference: -85.7 +- 0.4 multi / -80.6 +- 0.6 single; without the forced
+    updates the device loop gave -83.2 / -76.3; tests/golden/c40_logz_ref.json by tools/ref_c40_runs.py).  The check
+    was not built above 32 dimensions until the shape sweep of tools/fuzz_loop.py met this case."""
+    from dynesty_amd import problems
+    ref = json.load(open(os.path.join(GOLD, "c40_logz_ref.json")))["groups"][ref_key]
+    prob = problems.gauss_corr(40, 0.3, 5.0, "c40")
+    runs = 16
+    r = ctx.ns_ensemble(prob, runs, 333, K, bound=bound, sample="rwalk", walks=60, dlogz=0.5, entropy=[K, 40])
+    assert (r["status"] == 0).all()
+    lz = r["logz"]
+    se = math.hypot(lz.std(ddof=1) / math.sqrt(runs), ref["se"])
+    assert abs(lz.mean() - ref["mean"]) < 3.5 * se, (lz.mean(), ref["mean"], se)
+    assert abs(r["niter"].mean() / ref["mean_niter"] - 1) < 0.03
+    # bound updates: well above the call-count schedule's ncall / (walks * nlive)
+    scheduled = r["ncall"].mean() / (60 * 333)
+    assert r["nbound"].mean() > 1.5 * scheduled, (r["nbound"].mean(), scheduled)
