@@ -200,3 +200,31 @@ def test_forced_bound_updates_above_the_register_dimensions(ctx, K, bound, ref_k
     # bound updates: well above the call-count schedule's ncall / (walks * nlive)
     scheduled = r["ncall"].mean() / (60 * 333)
     assert r["nbound"].mean() > 1.5 * scheduled, (r["nbound"].mean(), scheduled)
+
+
+SHAPES = ["rslice40_multi", "slice3_Kgtn", "unif5_multi", "rwalk25_Kgtn", "rslice_egg", "rwalk13_multi"]
+
+
+@pytest.mark.parametrize("case", SHAPES)
+@pytest.mark.parametrize("rng", ["pcg64", "philox"])
+def test_odd_shapes_vs_reference_ensembles(ctx, case, rng):
+    """Shapes away from the BASELINE configs, each against an ensemble of the REAL reference at the same settings
+    (tests/golden/shape_logz_ref.json, tools/ref_shape_runs.py / shape_cases.json): rslice in 40 dimensions with 320
+    live points (wide walkers, narrow multi-ellipsoid rebuild, forced updates), queues LARGER than the live set
+    (slice 3-D nlive 60 K 257; rwalk 25-D nlive 60 K 257, whose ln Z is 5 nats off the truth in the reference and
+    here alike), unif + bootstrap on a correlated 5-D problem with the multi bound, a small eggbox run, rwalk 13-D
+    multi.  Ensemble ln Z within 4 combined standard errors, iterations within 3 %, calls within 6 %."""
+    from dynesty_amd import problems
+    ref = json.load(open(os.path.join(GOLD, "shape_logz_ref.json")))["cases"][case]
+    c = ref["config"]
+    prob = getattr(problems, c["prob"][0])(*c["prob"][1:])
+    kw = {k: c[k] for k in ("walks", "slices", "bootstrap", "enlarge") if k in c}
+    runs = 16 if case == "rslice40_multi" else 48
+    r = ctx.ns_ensemble(prob, runs, c["nlive"], c["K"], bound=c["bound"], sample=c["sample"], dlogz=c.get("dlogz", 0.5),
+                        entropy=[11, len(case)], rng=rng, **kw)
+    assert (r["status"] == 0).all()
+    lz = r["logz"]
+    se = math.hypot(lz.std(ddof=1) / math.sqrt(runs), ref["se"])
+    assert abs(lz.mean() - ref["mean"]) < 4.0 * se, (lz.mean(), ref["mean"], se)
+    assert abs(r["niter"].mean() / ref["mean_niter"] - 1) < 0.03, (r["niter"].mean(), ref["mean_niter"])
+    assert abs(r["ncall"].mean() / ref["mean_ncall"] - 1) < 0.06, (r["ncall"].mean(), ref["mean_ncall"])
