@@ -202,7 +202,8 @@ def test_forced_bound_updates_above_the_register_dimensions(ctx, K, bound, ref_k
     assert r["nbound"].mean() > 1.5 * scheduled, (r["nbound"].mean(), scheduled)
 
 
-SHAPES = ["rslice40_multi", "slice3_Kgtn", "unif5_multi", "rwalk25_Kgtn", "rslice_egg", "rwalk13_multi"]
+SHAPES = ["rslice40_multi", "slice3_Kgtn", "unif5_multi", "rwalk25_Kgtn", "rslice_egg", "rwalk13_multi", "unif_egg", "rwalk_egg",
+          "slice9_single", "rwalk25_K1"]
 
 
 @pytest.mark.parametrize("case", SHAPES)
@@ -212,8 +213,8 @@ def test_odd_shapes_vs_reference_ensembles(ctx, case, rng):
     (tests/golden/shape_logz_ref.json, tools/ref_shape_runs.py / shape_cases.json): rslice in 40 dimensions with 320
     live points (wide walkers, narrow multi-ellipsoid rebuild, forced updates), queues LARGER than the live set
     (slice 3-D nlive 60 K 257; rwalk 25-D nlive 60 K 257, whose ln Z is 5 nats off the truth in the reference and
-    here alike), unif + bootstrap on a correlated 5-D problem with the multi bound, a small eggbox run, rwalk 13-D
-    multi.  Ensemble ln Z within 4 combined standard errors, iterations within 3 %, calls within 6 %."""
+    here alike), unif + bootstrap on a correlated 5-D problem with the multi bound, small eggbox runs by rslice / unif (the
+    reference's own default for 2-D) / rwalk, rwalk 13-D multi, slice 9-D single at K = 7, rwalk 25-D at K = 1.  Ensemble ln Z within 4 combined standard errors, iterations within 3 %, calls within 6 %."""
     from dynesty_amd import problems
     ref = json.load(open(os.path.join(GOLD, "shape_logz_ref.json")))["cases"][case]
     c = ref["config"]
