@@ -203,7 +203,7 @@ def test_forced_bound_updates_above_the_register_dimensions(ctx, K, bound, ref_k
 
 
 SHAPES = ["rslice40_multi", "slice3_Kgtn", "unif5_multi", "rwalk25_Kgtn", "rslice_egg", "rwalk13_multi", "unif_egg", "rwalk_egg",
-          "slice9_single", "rwalk25_K1"]
+          "slice9_single", "rwalk25_K1", "multi2_tiny", "unif3_Kgtn", "slice36_single", "rwalk64_multi"]
 
 
 @pytest.mark.parametrize("case", SHAPES)
@@ -214,18 +214,20 @@ def test_odd_shapes_vs_reference_ensembles(ctx, case, rng):
     live points (wide walkers, narrow multi-ellipsoid rebuild, forced updates), queues LARGER than the live set
     (slice 3-D nlive 60 K 257; rwalk 25-D nlive 60 K 257, whose ln Z is 5 nats off the truth in the reference and
     here alike), unif + bootstrap on a correlated 5-D problem with the multi bound, small eggbox runs by rslice / unif (the
-    reference's own default for 2-D) / rwalk, rwalk 13-D multi, slice 9-D single at K = 7, rwalk 25-D at K = 1.  Ensemble ln Z within 4 combined standard errors, iterations within 3 %, calls within 6 %."""
+    reference's own default for 2-D) / rwalk, rwalk 13-D multi, slice 9-D single at K = 7, rwalk 25-D at K = 1, 25 live points in 2-D, unif with K > nlive, slice 36-D (wide
+    walkers) and rwalk 64-D with the multi bound (the host-driven wide MultiEllipsoid.update inside the loop).  Ensemble ln Z within 4 combined standard errors, iterations within 3 %, calls within 6 %."""
     from dynesty_amd import problems
     ref = json.load(open(os.path.join(GOLD, "shape_logz_ref.json")))["cases"][case]
     c = ref["config"]
     prob = getattr(problems, c["prob"][0])(*c["prob"][1:])
     kw = {k: c[k] for k in ("walks", "slices", "bootstrap", "enlarge") if k in c}
-    runs = 16 if case == "rslice40_multi" else 48
+    runs = 16 if c["prob"][1] >= 36 else 48
     r = ctx.ns_ensemble(prob, runs, c["nlive"], c["K"], bound=c["bound"], sample=c["sample"], dlogz=c.get("dlogz", 0.5),
                         entropy=[11, len(case)], rng=rng, **kw)
     assert (r["status"] == 0).all()
     lz = r["logz"]
     se = math.hypot(lz.std(ddof=1) / math.sqrt(runs), ref["se"])
     assert abs(lz.mean() - ref["mean"]) < 4.0 * se, (lz.mean(), ref["mean"], se)
-    assert abs(r["niter"].mean() / ref["mean_niter"] - 1) < 0.03, (r["niter"].mean(), ref["mean_niter"])
-    assert abs(r["ncall"].mean() / ref["mean_ncall"] - 1) < 0.06, (r["ncall"].mean(), ref["mean_ncall"])
+    tol = 0.03 if ref["n"] >= 30 else 0.05  # (the small reference ensembles of the expensive shapes)
+    assert abs(r["niter"].mean() / ref["mean_niter"] - 1) < tol, (r["niter"].mean(), ref["mean_niter"])
+    assert abs(r["ncall"].mean() / ref["mean_ncall"] - 1) < 2 * tol, (r["ncall"].mean(), ref["mean_ncall"])

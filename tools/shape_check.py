@@ -14,10 +14,10 @@ for name, c in json.load(open(os.path.join(ROOT, "tools", "shape_cases.json"))).
     kw = {k: c[k] for k in ("walks", "slices", "bootstrap", "enlarge") if k in c}
     for rng in ("pcg64", "philox"):
         try:
-            r = ctx.ns_ensemble(prob, NRUN, c["nlive"], c["K"], bound=c["bound"], sample=c["sample"], dlogz=c.get("dlogz", 0.5),
+            r = ctx.ns_ensemble(prob, (NRUN if NRUN < 40 else (8 if c["prob"][1] >= 36 else NRUN)), c["nlive"], c["K"], bound=c["bound"], sample=c["sample"], dlogz=c.get("dlogz", 0.5),
                                 entropy=[7, len(name)], rng=rng, **kw)
             lz = r["logz"]
-            print(json.dumps(dict(case=name, rng=rng, logz=round(float(lz.mean()), 3), se=round(float(lz.std(ddof=1) / np.sqrt(NRUN)), 3),
+            print(json.dumps(dict(case=name, rng=rng, logz=round(float(lz.mean()), 3), se=round(float(lz.std(ddof=1) / np.sqrt(len(lz))), 3),
                                   niter=int(r["niter"].mean()), ncall=int(r["ncall"].mean()), nbound=float(r["nbound"].mean()),
                                   ok=bool((r["status"] == 0).all()), truth=prob.logz_truth)), flush=True)
         except Exception as ex:  # noqa: BLE001
