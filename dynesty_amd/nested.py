@@ -21,6 +21,11 @@ Semantics kept from the reference because they decide the statistics:
     fill (internal_samplers.py:460-493); slice tuning per tune_slice (:1209-1239);
   * ln X decreases by ln((N+1)/N) per iteration; trapezoid weights; the final
     live points are appended (sampler.py:780-930).
+
+Not taken over: the forced bound update of Sampler.propose_live (sampler.py:484-489: a start point outside
+the bound rebuilds it at once).  The device-resident loop (dh_ns_ensemble) makes those updates at every
+dimension; here the bound follows the call-count schedule only, which matters for few live points in many
+dimensions (the 40-D / 333-live-point case) -- use the resident loop or the drop-in there.
 """
 import math
 
