@@ -203,7 +203,8 @@ def test_forced_bound_updates_above_the_register_dimensions(ctx, K, bound, ref_k
 
 
 SHAPES = ["rslice40_multi", "slice3_Kgtn", "unif5_multi", "rwalk25_Kgtn", "rslice_egg", "rwalk13_multi", "unif_egg", "rwalk_egg",
-          "slice9_single", "rwalk25_K1", "multi2_tiny", "unif3_Kgtn", "slice36_single", "rwalk64_multi"]
+          "slice9_single", "rwalk25_K1", "multi2_tiny", "unif3_Kgtn", "slice36_single", "rwalk64_multi",
+          "rslice48_boot3", "rwalk44_multi", "unif9_single_enl", "slice2_egg"]
 
 
 @pytest.mark.parametrize("case", SHAPES)
@@ -215,7 +216,9 @@ def test_odd_shapes_vs_reference_ensembles(ctx, case, rng):
     (slice 3-D nlive 60 K 257; rwalk 25-D nlive 60 K 257, whose ln Z is 5 nats off the truth in the reference and
     here alike), unif + bootstrap on a correlated 5-D problem with the multi bound, small eggbox runs by rslice / unif (the
     reference's own default for 2-D) / rwalk, rwalk 13-D multi, slice 9-D single at K = 7, rwalk 25-D at K = 1, 25 live points in 2-D, unif with K > nlive, slice 36-D (wide
-    walkers) and rwalk 64-D with the multi bound (the host-driven wide MultiEllipsoid.update inside the loop).  Ensemble ln Z within 4 combined standard errors, iterations within 3 %, calls within 6 %."""
+    walkers) and rwalk 64-D with the multi bound (the host-driven wide MultiEllipsoid.update inside the loop), rslice 48-D
+    with three bootstrap replicas (the ragged wide batch inside the loop), rwalk 44-D multi (the last narrow rebuild
+    dimension), unif 9-D with enlarge 1.5 and no bootstrap, slice on the eggbox.  Ensemble ln Z within 4 combined standard errors, iterations within 3 %, calls within 6 %."""
     from dynesty_amd import problems
     ref = json.load(open(os.path.join(GOLD, "shape_logz_ref.json")))["cases"][case]
     c = ref["config"]

@@ -7,7 +7,7 @@ from dynesty_amd import _lib, problems
 ctx = _lib.Context(0)
 NRUN = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 ONLY = sys.argv[2:]
-for name, c in json.load(open(os.path.join(ROOT, "tools", "shape_cases.json"))).items():
+for name, c in json.load(open(os.path.join(ROOT, "tools", os.environ.get("SHAPE_CASES", "shape_cases.json")))).items():
     if ONLY and name not in ONLY:
         continue
     prob = getattr(problems, c["prob"][0])(*c["prob"][1:])
