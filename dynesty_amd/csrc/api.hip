@@ -8,6 +8,7 @@
 
 #include "ctx.h"
 #include "npy_ziggurat_tables.h"
+#include "rng_pcg64.h"
 
 static std::string g_err;
 
@@ -110,7 +111,7 @@ dh_ctx* dh_create(int device) {
   }
   if (!hip_ok(ctx, hipSetDevice(device), "hipSetDevice") ||
       !hip_ok(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking), "hipStreamCreate") ||
-      !hip_ok(ctx, hipMalloc((void**)&ctx->zig, 3 * 256 * sizeof(uint64_t)), "hipMalloc(zig)")) {
+      !hip_ok(ctx, hipMalloc((void**)&ctx->zig, (3 * 256 + 128) * sizeof(uint64_t)), "hipMalloc(zig)")) {
     g_err = ctx->err;
     delete ctx;
     return nullptr;
@@ -118,6 +119,19 @@ dh_ctx* dh_create(int device) {
   (void)hipMemcpy(ctx->zig, dh_zig_ki_host, 2048, hipMemcpyHostToDevice);
   (void)hipMemcpy(ctx->zig + 256, dh_zig_wi_bits_host, 2048, hipMemcpyHostToDevice);
   (void)hipMemcpy(ctx->zig + 512, dh_zig_fi_bits_host, 2048, hipMemcpyHostToDevice);
+  {
+    // PCG64 jump constants G_k = 1 + mult + ... + mult^(k-1) (mod 2^128), k = 1..64, as (hi, lo) pairs: the state k
+    // steps ahead is S_0 + G_k (S_1 - S_0) (walkq.hip: one stream drawn by the 64 lanes of a wavefront)
+    uint64_t jt[128];
+    dh::U128 G = {0ull, 0ull};
+    const dh::U128 m = {DH_PCG_MULT_HI, DH_PCG_MULT_LO}, one = {0ull, 1ull};
+    for (int k = 0; k < 64; ++k) {
+      G = dh::add128(dh::mul128(G, m), one);
+      jt[2 * k] = G.hi;
+      jt[2 * k + 1] = G.lo;
+    }
+    (void)hipMemcpy(ctx->zig + 768, jt, sizeof(jt), hipMemcpyHostToDevice);
+  }
   if (arena_reserve(ctx, 8u << 20) != DH_OK) {
     g_err = ctx->err;
     dh_destroy(ctx);

@@ -70,6 +70,7 @@ struct dh_ctx {
   const uint64_t* zki() const { return zig; }
   const uint64_t* zwi() const { return zig + 256; }
   const uint64_t* zfi() const { return zig + 512; }
+  const uint64_t* pcg_jump() const { return zig + 768; }  // G_1 .. G_64 as (hi, lo)
 };
 
 namespace dh {

@@ -57,6 +57,7 @@ struct RwalkQArgs {
   const uint64_t* zki;
   const uint64_t* zwi;
   const uint64_t* zfi;
+  const uint64_t* pcg_jump;
   const double* run_loglstar;
   const double* run_scale;
   const int* run_mode;
@@ -96,19 +97,8 @@ __device__ __forceinline__ int grp_first(uint64_t g) {  // first sub-lane whose 
   return g ? (__ffsll((long long)g) - 1) >> 4 : 4;
 }
 
-// LCG jump constants of PCG64's multiplier: A_j = mult^j, G_j = 1 + mult + ... + mult^(j-1) (mod 2^128)
-__device__ __forceinline__ U128 jump_A(int j) {  // j = 1..4
-  const U128 a1 = {0x2360ed051fc65da4ull, 0x4385df649fccf645ull}, a2 = {0x17bce35bdf69743cull, 0x529ed9eb20e0ae99ull},
-             a3 = {0x25f041404bd80e82ull, 0xeb5ae837ed42153dull}, a4 = {0xf4dd417327db7a9bull, 0xd194dfbe42d45771ull};
-  return j == 1 ? a1 : j == 2 ? a2 : j == 3 ? a3 : a4;
-}
-__device__ __forceinline__ U128 jump_G(int j) {
-  const U128 g1 = {0x0ull, 0x1ull}, g2 = {0x2360ed051fc65da4ull, 0x4385df649fccf646ull},
-             g3 = {0x3b1dd060ff2fd1e0ull, 0x9624b94fc0ada4dfull}, g4 = {0x610e11a14b07e063ull, 0x817fa187adefba1cull};
-  return j == 1 ? g1 : j == 2 ? g2 : j == 3 ? g3 : g4;
-}
-#define DH_PCG_MULT_INV_HI 0x07dda22b93979860ull  // mult^-1 mod 2^128
-#define DH_PCG_MULT_INV_LO 0x98abc8b0716eac8dull
+#define DH_PCG_MULTM1_HI 0x2360ed051fc65da4ull  // mult - 1
+#define DH_PCG_MULTM1_LO 0x4385df649fccf644ull
 
 __device__ __forceinline__ U128 sub128(U128 a, U128 b) {
   U128 r;
@@ -122,125 +112,264 @@ __device__ __forceinline__ U128 sub128(U128 a, U128 b) {
 struct ZigQ {
   ulonglong2 kw[256];  // .x = ki, .y = bits of wi
   double fi[256];
+  float2 ff[256];      // single-precision (fi[i-1] - fi[i], fi[i]) for the first look at a wedge test
 };
 
-// One walker's PCG64 on four lanes.  S = the walker's generator state advanced t + 1 steps.
-struct QuadPcg {
-  U128 S, inc, AJ, TJ, T4;
-  __device__ __forceinline__ void init(const uint64_t* p, int t) {
-    const U128 base = {p[0], p[1]};
-    inc.hi = p[2];
-    inc.lo = p[3];
-    AJ = jump_A(t + 1);
-    TJ = mul128(jump_G(t + 1), inc);
-    T4 = mul128(jump_G(4), inc);
-    S = add128(mul128(base, AJ), TJ);
-  }
-  // the walker's generator state itself (meaningful on sub-lane 0: S = mult * base + inc)
-  __device__ __forceinline__ U128 base() const {
-    const U128 minv = {DH_PCG_MULT_INV_HI, DH_PCG_MULT_INV_LO};
-    return mul128(sub128(S, inc), minv);
-  }
+// ---- one PCG64 stream per walker, drawn by the whole wavefront ----------------------------------------------
+// Round 4.  The four-lanes-per-walker draw logic of round 3 (every quad classifying four candidates of its own
+// stream per round, lane exchanges of 128-bit state after every miss and at every step end) was 64 % of the
+// kernel.  The stream a walker consumes is a function of its generator alone (internal_samplers.py:1007-1021:
+// per step n normals and one uniform, whatever the walk accepts), so the wavefront now serves its sixteen
+// walkers ONE AFTER THE OTHER, all 64 lanes on one stream: with d = S_1 - S_0 the LCG's state after k steps is
+// S_0 + G_k d (G_k = 1 + mult + ... + mult^(k-1)), so lane l evaluates position l + 1 with one 128-bit
+// multiply by its own constant, and a round classifies 63 consecutive positions (the 64th only yields the
+// next round's d = S_64 - S_63: no scalar multiply anywhere).  What role a position plays -- normal candidate,
+// wedge uniform of a missed candidate, the step's uniform -- is the sequential algorithm's, resolved by scalar
+// code on the ballot of the fast-accept test (a walker is wave-uniform here); a missed candidate takes the next
+// position as its wedge uniform and the round goes on behind it.  Items leave in consumption order into the
+// walker's ring in LDS (96 entries: at most 32 unread + 63 new), from which the four sub-lanes of the walker
+// pick a step's n + 1 values.  tests/test_quad_rng_host.py restates the round on the host and holds it to
+// numpy draw for draw; tests/test_gpu_rwalkq.py holds the kernel to the oracle's walkers.
+constexpr int kRingCap = 96;
+constexpr int kRingStride = 98;  // doubles per walker: 98 = 2 mod 32 spreads the 16 walkers x 4 sub-lanes over the banks
+
+#ifdef DH_WQ_PROF
+#define WQP(...) __VA_ARGS__
+struct WqProf { long long fill, rest, rounds, segs, wedges, t0; };
+#else
+#define WQP(...)
+#endif
+
+// Per-walker generator state lives in LDS (one row per walker of the wavefront): S_0, S_1 (the states at the
+// next two positions' predecessors: d = S_1 - S_0) and the number of items produced.  A round reads the row of
+// its walker with wave-uniform addresses (every lane gets the words: no cross-lane reads on the vector pipe) and
+// the two lanes that hold the new S_0, S_1 write them back.
+struct WaveGenRow {
+  uint32_t s[8];  // S_0 (little-endian words 0..3), S_1 (4..7)
+};
+struct WaveGenLds {
+  WaveGenRow row[16];
+  int W[16];
 };
 
-// One step's draws of the reference (nc normals, then one uniform) -> items[i * 64 + slot], i = 0..nc.
-// `slot` = the walker's column of the staging array; j = lane & 15, t = lane >> 4.
-__device__ __forceinline__ void quad_draw_step(QuadPcg& q, const ZigQ* z, double* items, int slot, int j, int t,
-                                               int nc) {
+__device__ __forceinline__ uint32_t rl32(uint32_t v, int l) {
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, l);
+}
+__device__ __forceinline__ uint64_t rl64(uint64_t v, int l) {
+  return ((uint64_t)rl32((uint32_t)(v >> 32), l) << 32) | rl32((uint32_t)v, l);
+}
+__device__ __forceinline__ uint32_t sfirst(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
+// lane j < 16 (p = walker j's generator words): row j
+__device__ __forceinline__ void wavegen_init(WaveGenLds* g, int j, const uint64_t* p) {
+  const U128 base = {p[0], p[1]}, inc = {p[2], p[3]}, m = {DH_PCG_MULT_HI, DH_PCG_MULT_LO};
+  const U128 s1 = add128(mul128(base, m), inc);
+  uint32_t* r = g->row[j].s;
+  r[0] = (uint32_t)base.lo;
+  r[1] = (uint32_t)(base.lo >> 32);
+  r[2] = (uint32_t)base.hi;
+  r[3] = (uint32_t)(base.hi >> 32);
+  r[4] = (uint32_t)s1.lo;
+  r[5] = (uint32_t)(s1.lo >> 32);
+  r[6] = (uint32_t)s1.hi;
+  r[7] = (uint32_t)(s1.hi >> 32);
+  g->W[j] = 0;
+}
+
+// wave-uniform constants of a launch
+struct WaveGenConst {
+  int n, n1, T;
+  uint32_t magic_n1;  // floor(2^32 / n1) + 1: W / n1 = (W * magic) >> 32 for W < 2^32 / n1
+  uint64_t U0;        // bits 0, n1, 2 n1, ... < 64
+};
+#define DH_MAGIC_RING 44739243u  // floor(2^32 / 96) + 1
+
+// low 128 bits of a * b in ten 32 x 32 products (the multiplier runs at a quarter of the vector rate and this
+// product is the largest single item of a round; the compiler's expansion of 64-bit products takes thirteen to
+// fourteen, some of them by a zero high half it does not see through)
+__device__ __forceinline__ uint64_t mad_u64_u32(uint32_t a, uint32_t b, uint64_t c) {
+  uint64_t d;
+  asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c) : "vcc");
+  return d;
+}
+__device__ __forceinline__ U128 mul128_limbs(const U128& a, const U128& b) {
+  uint32_t a0 = (uint32_t)a.lo, a1 = (uint32_t)(a.lo >> 32), a2 = (uint32_t)a.hi, a3 = (uint32_t)(a.hi >> 32);
+  uint32_t b0 = (uint32_t)b.lo, b1 = (uint32_t)(b.lo >> 32), b2 = (uint32_t)b.hi, b3 = (uint32_t)(b.hi >> 32);
+  // (opaque limbs: seen as halves of 64-bit values, their 32-bit products are widened to 64-bit ones again)
+  asm("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3));
+  const uint64_t p00 = mad_u64_u32(a0, b0, 0ull);
+  const uint64_t p01 = mad_u64_u32(a0, b1, p00 >> 32);                     // < 2^64: (2^32 - 1)^2 + 2^32 - 1
+  const uint64_t p10 = mad_u64_u32(a1, b0, (uint64_t)(uint32_t)p01);
+  const uint64_t p11 = mad_u64_u32(a1, b1, (p01 >> 32) + (p10 >> 32));     // bits 64..127 of a.lo * b.lo
+  uint64_t hi = mad_u64_u32(a0, b2, p11);                                  // (mod 2^64 from here on)
+  hi = mad_u64_u32(a2, b0, hi);
+  uint32_t top = a0 * b3 + a1 * b2 + a2 * b1 + a3 * b0;
+  asm("" : "+v"(top));
+  U128 r;
+  r.lo = (p10 << 32) | (uint32_t)p00;
+  r.hi = hi + ((uint64_t)top << 32);
+  return r;
+}
+
+// One round of walker jw's stream (jw wave-uniform): up to 63 positions -> items into ring row `rw`.
+// What counts here is the NUMBER of instructions of any kind: hardware counters (profiles/r04) show a wavefront
+// of this kernel issuing one instruction per ~4.4 cycles for 46 % of its time and waiting for the rest, two
+// wavefronts per SIMD hiding little of each other's chains.  So the common round -- no missed candidate among its
+// 63 positions, 47 % of them -- goes straight through; the wedge verdicts, first in single precision, are only
+// formed when a real candidate missed.
+__device__ __forceinline__ void wavegen_round(WaveGenLds* g, int jw, const U128& Gl, const ZigQ* z, double* rw,
+                                              int lane, const WaveGenConst& k, const uint64_t* rng_in,
+                                              int walker0, int kmax WQP(, WqProf* pf)) {
 #pragma clang fp contract(off)
-  const int NI = nc + 1;
-  const U128 A4 = jump_A(4);
-  int count = 0;      // items finished (the same in the four sub-lanes of a walker)
-  bool pend = false;  // a candidate that missed the fast accept waits for its wedge uniform
-  int pidx = 0;
-  double px = 0.0;
-  while (__any(count < NI)) {
-    const bool act = count < NI;
-    const uint64_t r = pcg_output(q.S);
-    int shift = 0;
-    if (__any(pend)) {
-      // sub-lane 0's draw is the wedge uniform of the pending candidate (numpy distributions.c:
-      // (fi[idx-1] - fi[idx]) * next_double() + fi[idx] < exp(-0.5 x x))
-      const uint32_t rlo = grp32((uint32_t)r, j), rhi = grp32((uint32_t)(r >> 32), j);
-      if (pend) {
-        const double u1 = (double)((((uint64_t)rhi << 32) | rlo) >> 11) * (1.0 / 9007199254740992.0);
-        if ((z->fi[pidx - 1] - z->fi[pidx]) * u1 + z->fi[pidx] < exp(-0.5 * px * px)) {
-          if (t == 0) items[count * 64 + slot] = px;
-          ++count;
-        }
-        shift = 1;
-        pend = false;
+  U128 S0, D;
+  {
+    const uint4 a = *reinterpret_cast<const uint4*>(g->row[jw].s), b = *reinterpret_cast<const uint4*>(g->row[jw].s + 4);
+    S0.lo = ((uint64_t)a.y << 32) | a.x;
+    S0.hi = ((uint64_t)a.w << 32) | a.z;
+    U128 S1;
+    S1.lo = ((uint64_t)b.y << 32) | b.x;
+    S1.hi = ((uint64_t)b.w << 32) | b.z;
+    D = sub128(S1, S0);
+  }
+  const uint32_t W = sfirst((uint32_t)g->W[jw]);
+  const U128 st = add128(S0, mul128_limbs(Gl, D));  // state at position lane + 1
+  const uint64_t r = pcg_output(st);
+  const int idx = (int)(r & 0xff);
+  const uint64_t rabs = (r >> 9) & 0x000fffffffffffffull;
+  const double rd = __longlong_as_double((long long)(rabs | 0x4330000000000000ull)) - 4503599627370496.0;
+  const ulonglong2 kw = z->kw[idx];
+  double x = rd * __longlong_as_double((long long)kw.y);
+  x = __longlong_as_double(__double_as_longlong(x) ^ (long long)((r & 0x100ull) << 55));
+  const uint64_t missmask = __ballot(!(rabs < kw.x)) & 0x7fffffffffffffffull;  // position 63 is never consumed
+  const int c = (int)(W - (uint32_t)(((uint64_t)W * k.magic_n1) >> 32) * (uint32_t)k.n1);  // item index within the step
+  const int wm = (int)(W - (uint32_t)(((uint64_t)W * DH_MAGIC_RING) >> 32) * (uint32_t)kRingCap);
+  // roles: bit p of umask = position p is a step's uniform.  Without a miss the items follow the positions;
+  // a missed candidate at f takes position f + 1 as its wedge uniform, which moves every later role up by one
+  // position (candidate accepted) or two (rejected).
+  uint64_t umask = k.U0 << (k.n - c);
+  uint64_t dead = 0;  // positions that yield no item
+  int endpos = 63, tailf = -1;
+  uint64_t m = missmask & ~umask;
+  WQP(++pf->rounds;)
+  if (m) {
+    // the wedge verdict of every lane at once, as if it were a missed candidate (numpy distributions.c:
+    // (fi[idx-1] - fi[idx]) * next_double() + fi[idx] < exp(-0.5 x x)); the uniform is the next position's draw.
+    // First in single precision: every term is good to 2e-7 of a value in [1e-3, 1], so outside a band of 1e-5
+    // around equality the verdict is the double-precision one; a real candidate inside the band sends the
+    // wavefront to the double-precision test.
+    const float2 ff = z->ff[idx];
+    const uint32_t nhi = (uint32_t)__shfl_down((int)(uint32_t)(r >> 40), 1);
+    const float xf = (float)x;
+    const float lhs = ff.x * ((float)nhi * 5.9604644775390625e-08f) + ff.y;
+    const float ef = __expf(-0.5f * xf * xf);
+    uint64_t accmask = __ballot(lhs < ef);
+    const uint64_t zeromask = __ballot(idx == 0);
+    if (__ballot(fabsf(lhs - ef) <= 1e-5f) & m) {
+      const int ic = idx > 0 ? idx : 1;
+      const uint32_t nlo = (uint32_t)__shfl_down((int)(uint32_t)(r >> 11), 1),
+                     nh2 = (uint32_t)__shfl_down((int)(uint32_t)(r >> 43), 1);
+      const double u1 = (double)(((uint64_t)nh2 << 32) | nlo) * (1.0 / 9007199254740992.0);
+      const double f1 = z->fi[ic - 1], f0 = z->fi[ic];
+      accmask = __ballot((f1 - f0) * u1 + f0 < exp(-0.5 * x * x));
+    }
+    do {
+      WQP(++pf->segs;)
+      const int f = (int)__ffsll((long long)m) - 1;
+      if ((zeromask >> f) & 1ull) {  // tail of the distribution: finished sequentially below
+        tailf = f;
+        endpos = f;
+        break;
+      }
+      if (f == 62) {  // its wedge uniform is not in this round: the next round starts with this candidate
+        endpos = 62;
+        break;
+      }
+      const uint64_t acc = (accmask >> f) & 1ull;
+      dead |= (2ull | (acc ^ 1ull)) << f;
+      const int keep = f + 2;
+      const uint64_t low = umask & ((1ull << keep) - 1ull);
+      umask = low | ((umask >> (f + (int)acc)) << keep);  // later roles move up by 2 - acc positions
+      m = missmask & ~umask & (~0ull << keep);
+    } while (m);
+  }
+  const int off = lane - (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(dead >> 32),
+                                                        __builtin_amdgcn_mbcnt_lo((uint32_t)dead, 0u));
+  int total = endpos - (int)__popcll(dead);  // dead positions all lie below endpos
+  const int need = k.T - (int)W;
+  const bool alive = !__builtin_amdgcn_inverse_ballot_w64(dead);
+  if (total >= need) {
+    // the walker's last round: its last item is a step's uniform (never a miss); the generator stops there
+    const uint64_t b = __ballot(alive && off == need - 1);
+    endpos = (int)__ffsll((long long)b);
+    total = need;
+    tailf = -1;
+  }
+  if (alive && off < total) {
+    int qi = wm + off;
+    qi = qi >= kRingCap ? qi - kRingCap : qi;
+    // a step's uniform travels as its 53 random bits; the walker's lanes scale them when they read the item
+    rw[qi] = __builtin_amdgcn_inverse_ballot_w64(umask) ? __longlong_as_double((long long)(r >> 11)) : x;
+  }
+  if (tailf >= 0) {
+    // about 3 in 10^4 draws: finished sequentially, redundantly by all lanes
+    int wi = walker0 + jw;
+    wi = wi < kmax ? wi : kmax - 1;
+    Pcg64 s;
+    s.state.hi = rl64(st.hi, tailf);
+    s.state.lo = rl64(st.lo, tailf);
+    s.inc.hi = rng_in[(size_t)wi * 4 + 2];
+    s.inc.lo = rng_in[(size_t)wi * 4 + 3];
+    const uint64_t rabsf = rl64(rabs, tailf);
+    double xf;
+    for (;;) {
+      const double xx = -DH_ZIG_INV_R * log1p(-s.next_double());
+      const double yy = -log1p(-s.next_double());
+      if (yy + yy > xx * xx) {
+        xf = ((rabsf >> 8) & 1) ? -(DH_ZIG_R + xx) : DH_ZIG_R + xx;
+        break;
       }
     }
-    const int my = count + t - shift;
-    const bool valid = act & (t >= shift) & (my < NI);
-    const int idx = (int)(r & 0xff);
-    const uint64_t rabs = (r >> 9) & 0x000fffffffffffffull;
-    const double rd = __longlong_as_double((long long)(rabs | 0x4330000000000000ull)) - 4503599627370496.0;
-    const ulonglong2 kw = z->kw[idx];  // looked up by every lane: no branch around the LDS read
-    double x = rd * __longlong_as_double((long long)kw.y);
-    x = __longlong_as_double(__double_as_longlong(x) ^ (long long)((r & 0x100ull) << 55));
-    const bool isn = valid & (my < nc);
-    const uint64_t kk = kw.x;
-    const bool miss = isn & !(rabs < kk);
-    const int fm = grp_first(grp_bits(__ballot(miss), j));       // first missing sub-lane of my walker
-    int tend = shift + NI - count;                                // one past the last valid sub-lane
-    tend = tend < 4 ? tend : 4;
-    if (valid && t < fm) {
-      double val = x;
-      if (!isn) val = (double)(r >> 11) * (1.0 / 9007199254740992.0);  // the step's uniform: once in ~7 rounds
-      items[my * 64 + slot] = val;
+    int qi = wm + total;
+    qi = qi >= kRingCap ? qi - kRingCap : qi;
+    ++total;
+    const U128 s0n = s.state;
+    s.step();
+    if (lane == 0) {
+      rw[qi] = xf;
+      uint32_t* o = g->row[jw].s;
+      o[0] = (uint32_t)s0n.lo;
+      o[1] = (uint32_t)(s0n.lo >> 32);
+      o[2] = (uint32_t)s0n.hi;
+      o[3] = (uint32_t)(s0n.hi >> 32);
+      o[4] = (uint32_t)s.state.lo;
+      o[5] = (uint32_t)(s.state.lo >> 32);
+      o[6] = (uint32_t)s.state.hi;
+      o[7] = (uint32_t)(s.state.hi >> 32);
     }
-    const int stop = fm < tend ? fm : tend;  // sub-lanes [shift, stop) were consumed as items
-    if (act) count += stop - shift;
-    // re-alignment: everyone's new state is A * B + T with (A, B, T) = (A4, own S, T4) when all four
-    // candidates were consumed, else (A_{t+1}, S of the last consumed sub-lane, G_{t+1} inc)
-    const bool hit = act && fm < tend;                     // a miss inside the valid range
-    const bool rejump = act && (hit || tend < 4);
-    U128 B = q.S, A = A4, T = q.T4;
-    if (__any(rejump)) {
-      const int src = hit ? fm : tend - 1;
-      const int srclane = rejump ? ((src << 4) | j) : ((t << 4) | j);
-      // every lane shuffles (no cross-lane reads under a divergent mask)
-      const U128 Sf = grp128(q.S, srclane);
-      const int fidx = (int)grp32((uint32_t)idx, srclane);
-      const uint64_t xb = (uint64_t)__double_as_longlong(x);
-      const double fx = __longlong_as_double(
-          (long long)(((uint64_t)grp32((uint32_t)(xb >> 32), srclane) << 32) | grp32((uint32_t)xb, srclane)));
-      if (hit && fidx == 0) {
-        // tail of the distribution (idx == 0): finished sequentially, redundantly by the walker's four
-        // lanes -- rare (about 3 in 10^4 draws)
-        Pcg64 g;
-        g.state = Sf;
-        g.inc = q.inc;
-        const uint64_t rf = pcg_output(Sf);
-        const uint64_t rabsf = (rf >> 9) & 0x000fffffffffffffull;
-        double xf;
-        for (;;) {
-          const double xx = -DH_ZIG_INV_R * log1p(-g.next_double());
-          const double yy = -log1p(-g.next_double());
-          if (yy + yy > xx * xx) {
-            xf = ((rabsf >> 8) & 1) ? -(DH_ZIG_R + xx) : DH_ZIG_R + xx;
-            break;
-          }
-        }
-        if (t == 0) items[count * 64 + slot] = xf;
-        ++count;
-        B = g.state;
-      } else if (hit) {
-        pend = true;
-        pidx = fidx;
-        px = fx;
-        B = Sf;
-      } else if (rejump) {
-        B = Sf;
-      }
-      if (rejump) {
-        A = q.AJ;
-        T = q.TJ;
-      }
+  } else {
+    // positions [0, endpos) are consumed (1 <= endpos <= 63): the states of lanes endpos - 1 and endpos are the
+    // walker's new S_0 and S_1
+    const int which = lane - (endpos - 1);
+    if ((unsigned)which < 2u)
+      *reinterpret_cast<uint4*>(g->row[jw].s + 4 * which) =
+          make_uint4((uint32_t)st.lo, (uint32_t)(st.lo >> 32), (uint32_t)st.hi, (uint32_t)(st.hi >> 32));
+  }
+  if (lane == 0) g->W[jw] = (int)W + total;
+}
+
+// all sixteen walkers of the wavefront up to `target` items (their rows: ring + j * kRingStride)
+__device__ __forceinline__ void wavegen_fill(WaveGenLds* g, int target, const U128& Gl, const ZigQ* z, double* ring,
+                                             int lane, const WaveGenConst& k, const uint64_t* rng_in, int walker0,
+                                             int kmax WQP(, WqProf* pf)) {
+  for (;;) {
+    uint64_t nm = __ballot(lane < 16 && g->W[lane & 15] < target);
+    if (!nm) break;
+    while (nm) {
+      const int jw = (int)__ffsll((long long)nm) - 1;
+      nm &= nm - 1;
+      wavegen_round(g, jw, Gl, z, ring + jw * kRingStride, lane, k, rng_in, walker0, kmax WQP(, pf));
     }
-    if (act) q.S = add128(mul128(B, A), T);
+    wave_sync();
   }
 }
 
@@ -269,7 +398,7 @@ __device__ __forceinline__ void frag_matvec(const double (&F)[MT][NR], const dou
 // log-likelihood of the walker's v (quarter vector per sub-lane); every sub-lane returns the same bits
 template <int NR, int MT, int KIND>
 __device__ __forceinline__ double loglike_quad(const ProblemDev& P, int n, int t, const double (&v)[NR],
-                                               const double* sprec, int lane, double* col) {
+                                               const double* sprec, int lane) {
   cdptr lp = as_const(P.like_par);
   const int lid = like_of<KIND>(P);
   if (lid == LIKE_GAUSS_PREC) {
@@ -294,10 +423,8 @@ __device__ __forceinline__ double loglike_quad(const ProblemDev& P, int n, int t
     const double tmax = lp[0];
     double prod = 1.0;
 #pragma unroll
-    for (int r = 0; r < NR; ++r) col[(4 * r + t) * 64] = v[r];
-#pragma unroll 1
     for (int r = 0; r < NR; ++r)
-      if (4 * r + t < n) prod *= cos((2.0 * tmax * col[(4 * r + t) * 64] - tmax) / 2.0);
+      if (r < NR - 1 || 4 * r + t < n) prod *= cos((2.0 * tmax * v[r] - tmax) / 2.0);
     const double b = 2.0 + grp_prod(prod);
     const double b2 = b * b;
     return b2 * b2 * b;
@@ -323,11 +450,36 @@ __device__ __forceinline__ void prior_quad(const ProblemDev& P, int n, int t, co
     cdptr pp = as_const(P.prior_par);
     const double a = pp[0], b = pp[1];
 #pragma unroll
-    for (int r = 0; r < NR; ++r) v[r] = (4 * r + t < n) ? a * (2.0 * u[r] - 1.0) + b : 0.0;
+    for (int r = 0; r < NR; ++r) v[r] = (r < NR - 1 || 4 * r + t < n) ? a * (2.0 * u[r] - 1.0) + b : 0.0;
   } else {
 #pragma unroll
-    for (int r = 0; r < NR; ++r) v[r] = (4 * r + t < n) ? u[r] : 0.0;
+    for (int r = 0; r < NR; ++r) v[r] = (r < NR - 1 || 4 * r + t < n) ? u[r] : 0.0;
   }
+}
+
+// ur^(1/n) for ur in [0, 1), 2 <= n < 64 (bounding.py:1295: the radius of a point uniform in the n-ball).  ocml's
+// log + exp are ~80 instructions that all four lanes of a walker repeat every step; here a single-precision seed
+// (relative error ~1e-7) and two Newton steps on y^n = ur, y^n by binary powering (n is wave-uniform: scalar
+// branches).  The second step's correction is ~1e-13, so the quotient only needs the seed's precision; the
+// result is good to ~2e-16.
+__device__ __forceinline__ double pow_small_int(double y, int n) {
+  double p = (n & 1) ? y : 1.0, b = y;
+#pragma unroll
+  for (int bit = 1; bit < 6; ++bit) {
+    if ((n >> bit) == 0) break;
+    b *= b;
+    if ((n >> bit) & 1) p *= b;
+  }
+  return p;
+}
+__device__ __forceinline__ double root_n(double ur, int n, double inv_n) {
+  double y = (double)exp2f(__log2f((float)ur) * (float)inv_n);
+  double p = pow_small_int(y, n);
+  const double rp = (double)__frcp_rn((float)p);
+  y = fma(-(y * ((p - ur) * rp)), inv_n, y);
+  p = pow_small_int(y, n);
+  y = fma(-(y * ((p - ur) * rp)), inv_n, y);
+  return ur > 0.0 ? y : 0.0;
 }
 
 // generic_random_walk (internal_samplers.py:866-986) for ndim == ncdim, no periodic / reflective
@@ -336,8 +488,9 @@ template <int NR, int KIND, int RNG>
 __global__ void __launch_bounds__(256) rwalkq_kernel(RwalkQArgs a) {
   constexpr int MT = (4 * NR + 15) / 16;
   __shared__ ZigQ zig;
-  __shared__ double items[(4 * NR + 1) * 64];  // [item][walker slot]: a step's normals and its uniform
+  __shared__ double ring_all[64 * kRingStride];  // [walker slot][ring position]: the walkers' next items
   __shared__ double sprec[MT * NR * 64];       // MFMA fragments of the precision matrix
+  __shared__ WaveGenLds gen_all[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int t = lane >> 4, j = lane & 15;
   const int slot = wave * 16 + j;
@@ -349,6 +502,9 @@ __global__ void __launch_bounds__(256) rwalkq_kernel(RwalkQArgs a) {
     for (int i = tid; i < 256; i += 256) {
       zig.kw[i] = make_ulonglong2(a.zki[i], a.zwi[i]);
       zig.fi[i] = __longlong_as_double((long long)a.zfi[i]);
+      const int im = i > 0 ? i - 1 : 0;
+      const double fa = __longlong_as_double((long long)a.zfi[im]), fb = __longlong_as_double((long long)a.zfi[i]);
+      zig.ff[i] = make_float2((float)(fa - fb), (float)fb);
     }
   }
   if (like_of<KIND>(a.prob) == LIKE_GAUSS_PREC) {
@@ -374,10 +530,30 @@ __global__ void __launch_bounds__(256) rwalkq_kernel(RwalkQArgs a) {
 
   double u[NR], up[NR], dr[NR], vv[NR];
 #pragma unroll
-  for (int r = 0; r < NR; ++r) u[r] = (4 * r + t < n) ? a.u0[(size_t)wi * n + 4 * r + t] : 0.5;
-  QuadPcg q;
+  for (int r = 0; r < NR; ++r) u[r] = (r < NR - 1 || 4 * r + t < n) ? a.u0[(size_t)wi * n + 4 * r + t] : 0.5;
+  WaveGenLds* gen = &gen_all[wave];
+  U128 Gl = {0ull, 0ull};
   hiprandStatePhilox4_32_10_t ph;
-  if constexpr (RNG == RNGQ_PCG64) q.init(a.rng_in + (size_t)wi * 4, t);
+  const int n1 = n + 1, T = a.walks * n1;
+  WaveGenConst gk;
+  gk.n = n;
+  gk.n1 = n1;
+  gk.T = T;
+  gk.magic_n1 = (uint32_t)(0x100000000ull / (uint32_t)n1) + 1u;
+  gk.U0 = 0;
+  for (int b = 0; b < 64; b += n1) gk.U0 |= 1ull << b;
+  double* ring = ring_all + wave * 16 * kRingStride;  // this wavefront's sixteen rows
+  double* myrow = ring + j * kRingStride;
+  const int walker0 = blockIdx.x * 64 + wave * 16;
+  if constexpr (RNG == RNGQ_PCG64) {
+    if (lane < 16) wavegen_init(gen, lane, a.rng_in + (size_t)wi * 4);
+    wave_sync();
+    Gl.hi = a.pcg_jump[2 * lane];  // G_{lane + 1}
+    Gl.lo = a.pcg_jump[2 * lane + 1];
+  }
+  const bool lastok = 4 * (NR - 1) + t < n;
+  int start = 0;  // ring position of the current step's first item: (step * n1) mod kRingCap
+  WQP(WqProf pf; pf.fill = pf.rest = pf.rounds = pf.segs = pf.wedges = pf.t0 = 0;)
   const int nb = (n + 3) >> 2;           // hiprand_normal4 blocks per step
   const int ph_stride = 4 * nb + 2;      // 32-bit draws per step of the lane-per-walker Philox kernel
 
@@ -395,7 +571,9 @@ __global__ void __launch_bounds__(256) rwalkq_kernel(RwalkQArgs a) {
   for (int step = 0; step < a.walks; ++step) {
     // randsphere (bounding.py:1288-1297): n normals, one uniform
     if constexpr (RNG == RNGQ_PCG64) {
-      quad_draw_step(q, &zig, items, slot, j, t, n);
+      WQP(const long long tq0 = clock64();)
+      wavegen_fill(gen, (step + 1) * n1, Gl, &zig, ring, lane, gk, a.rng_in, walker0, a.k WQP(, &pf));
+      WQP(const long long tq1 = clock64(); pf.fill += tq1 - tq0; if (step) pf.rest += tq0 - pf.t0; pf.t0 = tq1;)
     } else {
       // the walker's Philox subsequence exactly as walk.hip consumes it (per step: nb blocks of four
       // normals, one uniform double), block b drawn by sub-lane b & 3
@@ -404,12 +582,18 @@ __global__ void __launch_bounds__(256) rwalkq_kernel(RwalkQArgs a) {
                      a.ph_offset + (unsigned long long)step * ph_stride + 4ull * b, &ph);
         if (b < nb) {
           const float4 zf = hiprand_normal4(&ph);
-          items[(4 * b) * 64 + slot] = (double)zf.x;
-          if (4 * b + 1 < n) items[(4 * b + 1) * 64 + slot] = (double)zf.y;
-          if (4 * b + 2 < n) items[(4 * b + 2) * 64 + slot] = (double)zf.z;
-          if (4 * b + 3 < n) items[(4 * b + 3) * 64 + slot] = (double)zf.w;
+          const double zz[4] = {(double)zf.x, (double)zf.y, (double)zf.z, (double)zf.w};
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (4 * b + i < n) {
+              int qi = start + 4 * b + i;
+              qi = qi >= kRingCap ? qi - kRingCap : qi;
+              myrow[qi] = zz[i];
+            }
         } else {
-          items[n * 64 + slot] = hiprand_uniform_double(&ph);
+          int qi = start + n;
+          qi = qi >= kRingCap ? qi - kRingCap : qi;
+          myrow[qi] = hiprand_uniform_double(&ph);
         }
       }
     }
@@ -417,11 +601,21 @@ __global__ void __launch_bounds__(256) rwalkq_kernel(RwalkQArgs a) {
     double ss = 0.0;
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
-      dr[r] = (4 * r + t < n) ? items[(4 * r + t) * 64 + slot] : 0.0;
+      int qi = start + 4 * r + t;
+      qi = qi >= kRingCap ? qi - kRingCap : qi;
+      // (NR = ceil(n / 4): only the last register of a vector has lanes past the dimension)
+      const double item = myrow[qi];
+      dr[r] = (r < NR - 1 || lastok) ? item : 0.0;
       ss = fma(dr[r], dr[r], ss);
     }
-    const double ur = items[n * 64 + slot];
+    int qu = start + n;
+    qu = qu >= kRingCap ? qu - kRingCap : qu;
+    double ur = myrow[qu];
+    if constexpr (RNG == RNGQ_PCG64)  // the generator hands over the uniform's 53 random bits
+      ur = (double)(uint64_t)__double_as_longlong(ur) * (1.0 / 9007199254740992.0);
     wave_sync();
+    start += n1;
+    start = start >= kRingCap ? start - kRingCap : start;
     ss = grp_sum(ss);
     // scale * ur^(1/n) / |dr| (bounding.py:1295-1296).  This is per-walker scalar work that all four
     // sub-lanes repeat, so it is kept short: exp(log(ur) / n) instead of ocml's double-double pow (|log
@@ -429,7 +623,7 @@ __global__ void __launch_bounds__(256) rwalkq_kernel(RwalkQArgs a) {
     double y = __builtin_amdgcn_rsq(ss);
     y = y * fma(-0.5 * ss * y, y, 1.5);
     y = y * fma(-0.5 * ss * y, y, 1.5);
-    const double fac = scale * (exp(inv_n * log(ur)) * y);
+    const double fac = scale * (root_n(ur, n, inv_n) * y);
     // du = axes @ dr on the matrix cores; walkers of a wave on different frames: one product per frame
     mfma_acc acc[MT];
     if (uni) {
@@ -455,7 +649,7 @@ __global__ void __launch_bounds__(256) rwalkq_kernel(RwalkQArgs a) {
     double lo = 0.5, hi = 0.5;
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
-      up[r] = (4 * r + t < n) ? fma(fac, acc[r >> 2][r & 3], u[r]) : 0.5;
+      up[r] = (r < NR - 1 || lastok) ? fma(fac, acc[r >> 2][r & 3], u[r]) : 0.5;
       lo = fmin(lo, up[r]);
       hi = fmax(hi, up[r]);
     }
@@ -465,7 +659,7 @@ __global__ void __launch_bounds__(256) rwalkq_kernel(RwalkQArgs a) {
     // a proposal outside the cube is counted as a call and a reject, no likelihood evaluated; here the
     // evaluation runs anyway (the matrix instruction serves the whole wave) and its verdict is ignored
     prior_quad<NR, KIND>(a.prob, n, t, up, vv);
-    const double ll = loglike_quad<NR, MT, KIND>(a.prob, n, t, vv, sprec, lane, items + slot);
+    const double ll = loglike_quad<NR, MT, KIND>(a.prob, n, t, vv, sprec, lane);
     if (inside && ll > loglstar) {
 #pragma unroll
       for (int r = 0; r < NR; ++r) u[r] = up[r];
@@ -477,26 +671,34 @@ __global__ void __launch_bounds__(256) rwalkq_kernel(RwalkQArgs a) {
   }
   // v of the returned point; logl is re-evaluated when nothing was accepted (internal_samplers.py:970-975)
   prior_quad<NR, KIND>(a.prob, n, t, u, vv);
-  const double ll0 = loglike_quad<NR, MT, KIND>(a.prob, n, t, vv, sprec, lane, items + slot);
+  const double ll0 = loglike_quad<NR, MT, KIND>(a.prob, n, t, vv, sprec, lane);
   if (nacc == 0) logl_cur = ll0;
   if (live && on) {
 #pragma unroll
     for (int r = 0; r < NR; ++r)
-      if (4 * r + t < n) {
+      if (r < NR - 1 || lastok) {
         a.u[(size_t)w * n + 4 * r + t] = u[r];
         a.v[(size_t)w * n + 4 * r + t] = vv[r];
       }
+#ifdef DH_WQ_PROF
+    if (lane == 0) {
+      double* o = a.v + (size_t)w * n;
+      o[0] = (double)pf.fill; o[1] = (double)pf.rest; o[2] = (double)pf.rounds; o[3] = (double)pf.segs;
+      o[4] = (double)pf.wedges;
+    }
+#endif
     if (t == 0) {
       a.logl[w] = logl_cur;
       a.nacc[w] = nacc;
       a.nrej[w] = nrej;
       if (RNG == RNGQ_PCG64 && a.rng_out) {
-        const U128 b = q.base();
+        // every item of the walk is drawn: S_0 is the generator state after the last of them
         uint64_t* o = a.rng_out + (size_t)w * 4;
-        o[0] = b.hi;
-        o[1] = b.lo;
-        o[2] = q.inc.hi;
-        o[3] = q.inc.lo;
+        const uint32_t* gs = gen->row[j].s;
+        o[0] = ((uint64_t)gs[3] << 32) | gs[2];
+        o[1] = ((uint64_t)gs[1] << 32) | gs[0];
+        o[2] = a.rng_in[(size_t)w * 4 + 2];
+        o[3] = a.rng_in[(size_t)w * 4 + 3];
       }
     }
   }
@@ -534,6 +736,7 @@ int rwalkq_launch(dh_ctx* ctx, const ProblemDev& prob, int k, int ndim, const do
   a.zki = ctx->zki();
   a.zwi = ctx->zwi();
   a.zfi = ctx->zfi();
+  a.pcg_jump = ctx->pcg_jump();
   a.run_loglstar = run_loglstar;
   a.run_scale = run_scale;
   a.run_mode = run_mode;
@@ -544,7 +747,7 @@ int rwalkq_launch(dh_ctx* ctx, const ProblemDev& prob, int k, int ndim, const do
   a.ph_offset = philox ? philox->offset : 0;
   const dim3 grid((k + 63) / 64), block(256);
   const int kind = problem_kind(prob.like_id, prob.prior_id) == KIND_PREC_AFFINE ? KIND_PREC_AFFINE : KIND_GENERIC;
-  const int nr = ndim <= 16 ? 4 : ndim <= 28 ? 7 : 8;
+  const int nr = (ndim + 3) / 4;  // 9 <= ndim <= 32: 3 .. 8
 #define L(NRR, KK)                                                                                     \
   do {                                                                                                 \
     if (philox)                                                                                        \
@@ -559,7 +762,7 @@ int rwalkq_launch(dh_ctx* ctx, const ProblemDev& prob, int k, int ndim, const do
     else                               \
       L(NRR, KIND_GENERIC);            \
   }
-  X(4) X(7) X(8)
+  X(3) X(4) X(5) X(6) X(7) X(8)
 #undef X
 #undef L
   return hip_ok(ctx, hipGetLastError(), "rwalkq launch") ? DH_OK : DH_ERR_HIP;
