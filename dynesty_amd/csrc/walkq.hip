@@ -111,7 +111,6 @@ __device__ __forceinline__ U128 sub128(U128 a, U128 b) {
 // instead of two 8-byte reads at random banks; fi (wedge test only) apart.
 struct ZigQ {
   ulonglong2 kw[256];  // .x = ki, .y = bits of wi
-  double fi[256];
   float2 ff[256];      // single-precision (fi[i-1] - fi[i], fi[i]) for the first look at a wedge test
 };
 
@@ -130,8 +129,20 @@ struct ZigQ {
 // walker's ring in LDS (96 entries: at most 32 unread + 63 new), from which the four sub-lanes of the walker
 // pick a step's n + 1 values.  tests/test_quad_rng_host.py restates the round on the host and holds it to
 // numpy draw for draw; tests/test_gpu_rwalkq.py holds the kernel to the oracle's walkers.
-constexpr int kRingCap = 96;
-constexpr int kRingStride = 98;  // doubles per walker: 98 = 2 mod 32 spreads the 16 walkers x 4 sub-lanes over the banks
+// Ring geometry: the capacity is a whole number of steps (cap = n1 * ceil((n1 + 62) / n1) >= the at most n1 - 1
+// unread items + the 63 a round can add), so that a step's n1 items never wrap; the row stride (doubles) is the
+// largest capacity of the kernel's dimensions made 2 (mod 4), which spreads 16 walkers x 4 sub-lanes over the banks.
+__host__ __device__ constexpr int ring_cap(int n1) { return n1 * ((n1 + 62 + n1 - 1) / n1); }
+template <int NR>
+struct RingGeom {
+  static constexpr int lo = 4 * (NR - 1) + 2, hi = 4 * NR + 1;  // n1 = ndim + 1 of the dimensions this NR serves
+  static constexpr int cmax() {
+    int m = 0;
+    for (int n1 = lo; n1 <= hi; ++n1) m = ring_cap(n1) > m ? ring_cap(n1) : m;
+    return m;
+  }
+  static constexpr int stride = cmax() + ((2 - cmax() % 4) + 4) % 4;
+};
 
 #ifdef DH_WQ_PROF
 #define WQP(...) __VA_ARGS__
@@ -178,11 +189,11 @@ __device__ __forceinline__ void wavegen_init(WaveGenLds* g, int j, const uint64_
 
 // wave-uniform constants of a launch
 struct WaveGenConst {
-  int n, n1, T;
-  uint32_t magic_n1;  // floor(2^32 / n1) + 1: W / n1 = (W * magic) >> 32 for W < 2^32 / n1
-  uint64_t U0;        // bits 0, n1, 2 n1, ... < 64
+  int n, n1, T, cap;
+  uint32_t magic_n1, magic_cap;  // floor(2^32 / d) + 1: W / d = (W * magic) >> 32 for W < 2^32 / d
+  uint64_t U0;                   // bits 0, n1, 2 n1, ... < 64
+  const uint64_t* zfi;           // the ziggurat's fi table (global memory: only the rare double-precision wedge test reads it)
 };
-#define DH_MAGIC_RING 44739243u  // floor(2^32 / 96) + 1
 
 // low 128 bits of a * b in ten 32 x 32 products (the multiplier runs at a quarter of the vector rate and this
 // product is the largest single item of a round; the compiler's expansion of 64-bit products takes thirteen to
@@ -192,11 +203,23 @@ __device__ __forceinline__ uint64_t mad_u64_u32(uint32_t a, uint32_t b, uint64_t
   asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c) : "vcc");
   return d;
 }
-__device__ __forceinline__ U128 mul128_limbs(const U128& a, const U128& b) {
-  uint32_t a0 = (uint32_t)a.lo, a1 = (uint32_t)(a.lo >> 32), a2 = (uint32_t)a.hi, a3 = (uint32_t)(a.hi >> 32);
+struct Limbs128 {
+  uint32_t w[4];  // little-endian
+};
+// (opaque limbs: seen as halves of 64-bit values, their 32-bit products are widened to 64-bit ones again)
+__device__ __forceinline__ Limbs128 opaque_limbs(const U128& a) {
+  Limbs128 l;
+  l.w[0] = (uint32_t)a.lo;
+  l.w[1] = (uint32_t)(a.lo >> 32);
+  l.w[2] = (uint32_t)a.hi;
+  l.w[3] = (uint32_t)(a.hi >> 32);
+  asm("" : "+v"(l.w[0]), "+v"(l.w[1]), "+v"(l.w[2]), "+v"(l.w[3]));
+  return l;
+}
+__device__ __forceinline__ U128 mul128_limbs(const Limbs128& a, const U128& b) {
+  const uint32_t a0 = a.w[0], a1 = a.w[1], a2 = a.w[2], a3 = a.w[3];
   uint32_t b0 = (uint32_t)b.lo, b1 = (uint32_t)(b.lo >> 32), b2 = (uint32_t)b.hi, b3 = (uint32_t)(b.hi >> 32);
-  // (opaque limbs: seen as halves of 64-bit values, their 32-bit products are widened to 64-bit ones again)
-  asm("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3));
+  asm("" : "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3));
   const uint64_t p00 = mad_u64_u32(a0, b0, 0ull);
   const uint64_t p01 = mad_u64_u32(a0, b1, p00 >> 32);                     // < 2^64: (2^32 - 1)^2 + 2^32 - 1
   const uint64_t p10 = mad_u64_u32(a1, b0, (uint64_t)(uint32_t)p01);
@@ -211,13 +234,14 @@ __device__ __forceinline__ U128 mul128_limbs(const U128& a, const U128& b) {
   return r;
 }
 
-// One round of walker jw's stream (jw wave-uniform): up to 63 positions -> items into ring row `rw`.
+// One round of walker jw's stream (jw wave-uniform): up to 63 positions -> items into ring row `rw`; returns the
+// walker's new item count.
 // What counts here is the NUMBER of instructions of any kind: hardware counters (profiles/r04) show a wavefront
 // of this kernel issuing one instruction per ~4.4 cycles for 46 % of its time and waiting for the rest, two
 // wavefronts per SIMD hiding little of each other's chains.  So the common round -- no missed candidate among its
 // 63 positions, 47 % of them -- goes straight through; the wedge verdicts, first in single precision, are only
 // formed when a real candidate missed.
-__device__ __forceinline__ void wavegen_round(WaveGenLds* g, int jw, const U128& Gl, const ZigQ* z, double* rw,
+__device__ __forceinline__ int wavegen_round(WaveGenLds* g, int jw, const Limbs128& Gl, const ZigQ* z, double* rw,
                                               int lane, const WaveGenConst& k, const uint64_t* rng_in,
                                               int walker0, int kmax WQP(, WqProf* pf)) {
 #pragma clang fp contract(off)
@@ -242,7 +266,7 @@ __device__ __forceinline__ void wavegen_round(WaveGenLds* g, int jw, const U128&
   x = __longlong_as_double(__double_as_longlong(x) ^ (long long)((r & 0x100ull) << 55));
   const uint64_t missmask = __ballot(!(rabs < kw.x)) & 0x7fffffffffffffffull;  // position 63 is never consumed
   const int c = (int)(W - (uint32_t)(((uint64_t)W * k.magic_n1) >> 32) * (uint32_t)k.n1);  // item index within the step
-  const int wm = (int)(W - (uint32_t)(((uint64_t)W * DH_MAGIC_RING) >> 32) * (uint32_t)kRingCap);
+  const int wm = (int)(W - (uint32_t)(((uint64_t)W * k.magic_cap) >> 32) * (uint32_t)k.cap);
   // roles: bit p of umask = position p is a step's uniform.  Without a miss the items follow the positions;
   // a missed candidate at f takes position f + 1 as its wedge uniform, which moves every later role up by one
   // position (candidate accepted) or two (rejected).
@@ -269,7 +293,7 @@ __device__ __forceinline__ void wavegen_round(WaveGenLds* g, int jw, const U128&
       const uint32_t nlo = (uint32_t)__shfl_down((int)(uint32_t)(r >> 11), 1),
                      nh2 = (uint32_t)__shfl_down((int)(uint32_t)(r >> 43), 1);
       const double u1 = (double)(((uint64_t)nh2 << 32) | nlo) * (1.0 / 9007199254740992.0);
-      const double f1 = z->fi[ic - 1], f0 = z->fi[ic];
+      const double f1 = __longlong_as_double((long long)k.zfi[ic - 1]), f0 = __longlong_as_double((long long)k.zfi[ic]);
       accmask = __ballot((f1 - f0) * u1 + f0 < exp(-0.5 * x * x));
     }
     do {
@@ -306,7 +330,7 @@ __device__ __forceinline__ void wavegen_round(WaveGenLds* g, int jw, const U128&
   }
   if (alive && off < total) {
     int qi = wm + off;
-    qi = qi >= kRingCap ? qi - kRingCap : qi;
+    qi = qi >= k.cap ? qi - k.cap : qi;
     // a step's uniform travels as its 53 random bits; the walker's lanes scale them when they read the item
     rw[qi] = __builtin_amdgcn_inverse_ballot_w64(umask) ? __longlong_as_double((long long)(r >> 11)) : x;
   }
@@ -330,7 +354,7 @@ __device__ __forceinline__ void wavegen_round(WaveGenLds* g, int jw, const U128&
       }
     }
     int qi = wm + total;
-    qi = qi >= kRingCap ? qi - kRingCap : qi;
+    qi = qi >= k.cap ? qi - k.cap : qi;
     ++total;
     const U128 s0n = s.state;
     s.step();
@@ -355,21 +379,27 @@ __device__ __forceinline__ void wavegen_round(WaveGenLds* g, int jw, const U128&
           make_uint4((uint32_t)st.lo, (uint32_t)(st.lo >> 32), (uint32_t)st.hi, (uint32_t)(st.hi >> 32));
   }
   if (lane == 0) g->W[jw] = (int)W + total;
+  return (int)W + total;
 }
 
-// all sixteen walkers of the wavefront up to `target` items (their rows: ring + j * kRingStride)
-__device__ __forceinline__ void wavegen_fill(WaveGenLds* g, int target, const U128& Gl, const ZigQ* z, double* ring,
+// all sixteen walkers of the wavefront up to `target` items (their rows: ring + j * stride).  Returns when no
+// walker is short any more; a round that leaves its walker short (many misses, a tail) is rare, so the walkers
+// are only asked again when one reported it.
+template <int STRIDE>
+__device__ __forceinline__ void wavegen_fill(WaveGenLds* g, int target, const Limbs128& Gl, const ZigQ* z, double* ring,
                                              int lane, const WaveGenConst& k, const uint64_t* rng_in, int walker0,
                                              int kmax WQP(, WqProf* pf)) {
   for (;;) {
-    uint64_t nm = __ballot(lane < 16 && g->W[lane & 15] < target);
+    uint32_t nm = (uint32_t)__ballot(lane < 16 && g->W[lane & 15] < target);
     if (!nm) break;
+    bool again = false;
     while (nm) {
-      const int jw = (int)__ffsll((long long)nm) - 1;
+      const int jw = __ffs((int)nm) - 1;
       nm &= nm - 1;
-      wavegen_round(g, jw, Gl, z, ring + jw * kRingStride, lane, k, rng_in, walker0, kmax WQP(, pf));
+      again |= wavegen_round(g, jw, Gl, z, ring + jw * STRIDE, lane, k, rng_in, walker0, kmax WQP(, pf)) < target;
     }
     wave_sync();
+    if (!again) break;
   }
 }
 
@@ -457,27 +487,31 @@ __device__ __forceinline__ void prior_quad(const ProblemDev& P, int n, int t, co
   }
 }
 
-// ur^(1/n) for ur in [0, 1), 2 <= n < 64 (bounding.py:1295: the radius of a point uniform in the n-ball).  ocml's
-// log + exp are ~80 instructions that all four lanes of a walker repeat every step; here a single-precision seed
-// (relative error ~1e-7) and two Newton steps on y^n = ur, y^n by binary powering (n is wave-uniform: scalar
-// branches).  The second step's correction is ~1e-13, so the quotient only needs the seed's precision; the
-// result is good to ~2e-16.
-__device__ __forceinline__ double pow_small_int(double y, int n) {
-  double p = (n & 1) ? y : 1.0, b = y;
+// ur^(1/n) for ur in [0, 1), n = 4 (NR - 1) + k with k in 1..4 (bounding.py:1295: the radius of a point uniform in
+// the n-ball).  ocml's log + exp are ~90 instructions that all four lanes of a walker repeat every step; here a
+// single-precision seed (relative error ~1e-7) and two Newton steps on y^n = ur, y^n by a multiplication chain
+// that is fixed at compile time up to the factor y^k (wave-uniform selects).  The second step's correction is
+// ~1e-13, so the quotient only needs the seed's precision; the result is good to ~2e-16.
+template <int NR>
+__device__ __forceinline__ double pow_n(double y, int k) {
+  const double y2 = y * y, y4 = y2 * y2;
+  double z = 1.0, b = y4;  // z = y4^(NR - 1)
 #pragma unroll
-  for (int bit = 1; bit < 6; ++bit) {
-    if ((n >> bit) == 0) break;
-    b *= b;
-    if ((n >> bit) & 1) p *= b;
+  for (int e = NR - 1; e > 0; e >>= 1) {
+    if (e & 1) z = (z == 1.0 && e == NR - 1) ? b : z * b;
+    if (e > 1) b *= b;
   }
-  return p;
+  const double yk = k == 1 ? y : k == 2 ? y2 : k == 3 ? y * y2 : y4;
+  return z * yk;
 }
+template <int NR>
 __device__ __forceinline__ double root_n(double ur, int n, double inv_n) {
-  double y = (double)exp2f(__log2f((float)ur) * (float)inv_n);
-  double p = pow_small_int(y, n);
-  const double rp = (double)__frcp_rn((float)p);
+  const int k = n - 4 * (NR - 1);
+  double y = (double)__builtin_amdgcn_exp2f(__builtin_amdgcn_logf((float)ur) * (float)inv_n);
+  double p = pow_n<NR>(y, k);
+  const double rp = (double)__builtin_amdgcn_rcpf((float)p);
   y = fma(-(y * ((p - ur) * rp)), inv_n, y);
-  p = pow_small_int(y, n);
+  p = pow_n<NR>(y, k);
   y = fma(-(y * ((p - ur) * rp)), inv_n, y);
   return ur > 0.0 ? y : 0.0;
 }
@@ -488,7 +522,8 @@ template <int NR, int KIND, int RNG>
 __global__ void __launch_bounds__(256) rwalkq_kernel(RwalkQArgs a) {
   constexpr int MT = (4 * NR + 15) / 16;
   __shared__ ZigQ zig;
-  __shared__ double ring_all[64 * kRingStride];  // [walker slot][ring position]: the walkers' next items
+  constexpr int STRIDE = RingGeom<NR>::stride;
+  __shared__ double ring_all[64 * STRIDE];  // [walker slot][ring position]: the walkers' next items
   __shared__ double sprec[MT * NR * 64];       // MFMA fragments of the precision matrix
   __shared__ WaveGenLds gen_all[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -501,7 +536,6 @@ __global__ void __launch_bounds__(256) rwalkq_kernel(RwalkQArgs a) {
   if constexpr (RNG == RNGQ_PCG64) {
     for (int i = tid; i < 256; i += 256) {
       zig.kw[i] = make_ulonglong2(a.zki[i], a.zwi[i]);
-      zig.fi[i] = __longlong_as_double((long long)a.zfi[i]);
       const int im = i > 0 ? i - 1 : 0;
       const double fa = __longlong_as_double((long long)a.zfi[im]), fb = __longlong_as_double((long long)a.zfi[i]);
       zig.ff[i] = make_float2((float)(fa - fb), (float)fb);
@@ -532,27 +566,30 @@ __global__ void __launch_bounds__(256) rwalkq_kernel(RwalkQArgs a) {
 #pragma unroll
   for (int r = 0; r < NR; ++r) u[r] = (r < NR - 1 || 4 * r + t < n) ? a.u0[(size_t)wi * n + 4 * r + t] : 0.5;
   WaveGenLds* gen = &gen_all[wave];
-  U128 Gl = {0ull, 0ull};
+  Limbs128 Gl = {{0u, 0u, 0u, 0u}};
   hiprandStatePhilox4_32_10_t ph;
   const int n1 = n + 1, T = a.walks * n1;
   WaveGenConst gk;
   gk.n = n;
   gk.n1 = n1;
   gk.T = T;
+  gk.cap = ring_cap(n1);
   gk.magic_n1 = (uint32_t)(0x100000000ull / (uint32_t)n1) + 1u;
+  gk.magic_cap = (uint32_t)(0x100000000ull / (uint32_t)gk.cap) + 1u;
+  gk.zfi = a.zfi;
   gk.U0 = 0;
   for (int b = 0; b < 64; b += n1) gk.U0 |= 1ull << b;
-  double* ring = ring_all + wave * 16 * kRingStride;  // this wavefront's sixteen rows
-  double* myrow = ring + j * kRingStride;
+  double* ring = ring_all + wave * 16 * STRIDE;  // this wavefront's sixteen rows
+  double* myrow = ring + j * STRIDE;
   const int walker0 = blockIdx.x * 64 + wave * 16;
   if constexpr (RNG == RNGQ_PCG64) {
     if (lane < 16) wavegen_init(gen, lane, a.rng_in + (size_t)wi * 4);
     wave_sync();
-    Gl.hi = a.pcg_jump[2 * lane];  // G_{lane + 1}
-    Gl.lo = a.pcg_jump[2 * lane + 1];
+    const U128 gj = {a.pcg_jump[2 * lane], a.pcg_jump[2 * lane + 1]};  // G_{lane + 1}
+    Gl = opaque_limbs(gj);
   }
   const bool lastok = 4 * (NR - 1) + t < n;
-  int start = 0;  // ring position of the current step's first item: (step * n1) mod kRingCap
+  int start = 0;  // ring position of the current step's first item: (step * n1) mod cap
   WQP(WqProf pf; pf.fill = pf.rest = pf.rounds = pf.segs = pf.wedges = pf.t0 = 0;)
   const int nb = (n + 3) >> 2;           // hiprand_normal4 blocks per step
   const int ph_stride = 4 * nb + 2;      // 32-bit draws per step of the lane-per-walker Philox kernel
@@ -572,7 +609,7 @@ __global__ void __launch_bounds__(256) rwalkq_kernel(RwalkQArgs a) {
     // randsphere (bounding.py:1288-1297): n normals, one uniform
     if constexpr (RNG == RNGQ_PCG64) {
       WQP(const long long tq0 = clock64();)
-      wavegen_fill(gen, (step + 1) * n1, Gl, &zig, ring, lane, gk, a.rng_in, walker0, a.k WQP(, &pf));
+      wavegen_fill<STRIDE>(gen, (step + 1) * n1, Gl, &zig, ring, lane, gk, a.rng_in, walker0, a.k WQP(, &pf));
       WQP(const long long tq1 = clock64(); pf.fill += tq1 - tq0; if (step) pf.rest += tq0 - pf.t0; pf.t0 = tq1;)
     } else {
       // the walker's Philox subsequence exactly as walk.hip consumes it (per step: nb blocks of four
@@ -585,15 +622,9 @@ __global__ void __launch_bounds__(256) rwalkq_kernel(RwalkQArgs a) {
           const double zz[4] = {(double)zf.x, (double)zf.y, (double)zf.z, (double)zf.w};
 #pragma unroll
           for (int i = 0; i < 4; ++i)
-            if (4 * b + i < n) {
-              int qi = start + 4 * b + i;
-              qi = qi >= kRingCap ? qi - kRingCap : qi;
-              myrow[qi] = zz[i];
-            }
+            if (4 * b + i < n) myrow[start + 4 * b + i] = zz[i];
         } else {
-          int qi = start + n;
-          qi = qi >= kRingCap ? qi - kRingCap : qi;
-          myrow[qi] = hiprand_uniform_double(&ph);
+          myrow[start + n] = hiprand_uniform_double(&ph);
         }
       }
     }
@@ -601,21 +632,18 @@ __global__ void __launch_bounds__(256) rwalkq_kernel(RwalkQArgs a) {
     double ss = 0.0;
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
-      int qi = start + 4 * r + t;
-      qi = qi >= kRingCap ? qi - kRingCap : qi;
-      // (NR = ceil(n / 4): only the last register of a vector has lanes past the dimension)
-      const double item = myrow[qi];
+      // a step's items lie in a row without wrapping; NR = ceil(n / 4): only the last register of a vector has
+      // lanes past the dimension
+      const double item = myrow[start + 4 * r + t];
       dr[r] = (r < NR - 1 || lastok) ? item : 0.0;
       ss = fma(dr[r], dr[r], ss);
     }
-    int qu = start + n;
-    qu = qu >= kRingCap ? qu - kRingCap : qu;
-    double ur = myrow[qu];
+    double ur = myrow[start + n];
     if constexpr (RNG == RNGQ_PCG64)  // the generator hands over the uniform's 53 random bits
       ur = (double)(uint64_t)__double_as_longlong(ur) * (1.0 / 9007199254740992.0);
     wave_sync();
     start += n1;
-    start = start >= kRingCap ? start - kRingCap : start;
+    start = start >= gk.cap ? 0 : start;
     ss = grp_sum(ss);
     // scale * ur^(1/n) / |dr| (bounding.py:1295-1296).  This is per-walker scalar work that all four
     // sub-lanes repeat, so it is kept short: exp(log(ur) / n) instead of ocml's double-double pow (|log
@@ -623,7 +651,7 @@ __global__ void __launch_bounds__(256) rwalkq_kernel(RwalkQArgs a) {
     double y = __builtin_amdgcn_rsq(ss);
     y = y * fma(-0.5 * ss * y, y, 1.5);
     y = y * fma(-0.5 * ss * y, y, 1.5);
-    const double fac = scale * (root_n(ur, n, inv_n) * y);
+    const double fac = scale * (root_n<NR>(ur, n, inv_n) * y);
     // du = axes @ dr on the matrix cores; walkers of a wave on different frames: one product per frame
     mfma_acc acc[MT];
     if (uni) {

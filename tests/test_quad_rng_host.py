@@ -4,7 +4,8 @@ stream (state at position l + 1 = S_0 + G_{l+1} d with d = S_1 - S_0), scalar co
 position plays in the sequential algorithm (normal candidate / wedge uniform of a missed candidate / the step's
 uniform) from the ballot of the fast-accept test and of every lane's wedge verdict, a missed candidate takes the
 next position as its wedge uniform and the later roles move up, item offsets are a masked bit count,
-position 64 only yields the next round's d, the tail is finished sequentially, items go to a 96-entry ring.  The
+position 64 only yields the next round's d, the tail is finished sequentially, items go to a ring of a whole
+number of steps.  The
 claim pinned here: the items produced per step (nc normals, one uniform -- what propose_ball_point / randsphere
 draw, internal_samplers.py:1007-1021, bounding.py:1291-1295) and the generator state left behind are EXACTLY
 numpy's, step after step.  The device code is held to the oracle's walkers by the `-m gpu` tests; this test
@@ -19,7 +20,11 @@ from test_rng_host import M128, M64, MULT, Pcg, load_tables, normal, R, INVR
 G = [0]
 for _ in range(64):
     G.append((G[-1] * MULT + 1) & M128)
-CAP = 96
+
+
+def ring_cap(n1):
+    """a whole number of steps that holds the at most n1 - 1 unread items + the 63 a round can add"""
+    return n1 * -(-(n1 + 62) // n1)
 
 
 def out64(s):
@@ -41,7 +46,8 @@ class WaveGen:
         self.D = ((MULT - 1) * base + inc) & M128
         self.T = steps * self.n1
         self.U0 = sum(1 << b for b in range(0, 64, self.n1))
-        self.ring = [None] * CAP
+        self.cap = ring_cap(self.n1)
+        self.ring = [None] * self.cap
         self.W = 0
         self.rounds = 0
 
@@ -50,6 +56,7 @@ class WaveGen:
         n, n1 = self.n, self.n1
         W = self.W
         c = W - ((W * ((1 << 32) // n1 + 1)) >> 32) * n1
+        CAP = self.cap
         wm = W - ((W * ((1 << 32) // CAP + 1)) >> 32) * CAP
         assert c == W % n1 and wm == W % CAP
         st = [(self.S0 + G[l + 1] * self.D) & M128 for l in range(64)]
@@ -115,10 +122,11 @@ class WaveGen:
         """what the walker's four sub-lanes read at `step` (after wavegen_fill up to (step + 1) * n1)"""
         while self.W < (step + 1) * self.n1:
             self.round(ki, wi, fi)
-        start = (step * self.n1) % CAP
+        start = (step * self.n1) % self.cap
+        assert start + self.n1 <= self.cap  # a step's items never wrap
         items = []
         for e in range(self.n1):
-            q = (start + e) % CAP
+            q = start + e
             items.append(self.ring[q])
             self.ring[q] = None  # read: the slot is free again
         return items
@@ -181,4 +189,4 @@ def test_jump_constants_match_the_kernel_source():
     hi = int(re.search(r"DH_PCG_MULTM1_HI 0x([0-9a-f]+)ull", src).group(1), 16)
     lo = int(re.search(r"DH_PCG_MULTM1_LO 0x([0-9a-f]+)ull", src).group(1), 16)
     assert ((hi << 64) | lo) == MULT - 1
-    assert int(re.search(r"kRingCap = (\d+)", src).group(1)) == CAP
+    assert "return n1 * ((n1 + 62 + n1 - 1) / n1);" in src  # ring_cap
