@@ -113,6 +113,7 @@ SIGNATURES = {
     "dh_slice_feed": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _dbl, _vp, _vp, _i, _vp,
                            _vp, _vp]),
     "dh_set_rwalk_form": (_i, [_vp, _i]),
+    "dh_set_rwalk_items": (_i, [_vp, _i, C.c_longlong]),
     "dh_slice_batch_philox": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _dbl, _dbl, _i, _i, _u64, _u64, _u64,
                                    _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dh_slice_batch_philox_dev": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _dbl, _dbl, _i, _i, _u64, _u64,
@@ -263,10 +264,15 @@ class Context:
         raise DynHipError(f"libdynhip error {rc}: {msg}")
 
     def set_rwalk_form(self, form):
-        """0 (default): four lanes per walker + matrix cores (csrc/walkq.hip) for launches that
-        would leave SIMDs empty with one walker per lane; 1: one walker per lane always
-        (csrc/walk.hip); 2: four lanes per walker wherever that kernel is built."""
+        """0 (default) / 2: four lanes per walker + matrix cores (csrc/walkq.hip) wherever that kernel is
+        built -- decided by the problem alone, never by the launch size; 1: one walker per lane always
+        (csrc/walk.hip)."""
         self._check(self.lib.dh_set_rwalk_form(self.handle, int(form)))
+
+    def set_rwalk_items(self, on=True, budget_bytes=0):
+        """Four-lane rwalk: PCG64 item streams from a generator pass ahead of the walk (default) or drawn inside
+        the walk kernel; `budget_bytes` > 0 bounds the pass's buffer (larger launches go in chunks of walkers)."""
+        self._check(self.lib.dh_set_rwalk_items(self.handle, int(bool(on)), int(budget_bytes)))
 
     def sync(self):
         self._check(self.lib.dh_sync(self.handle))

@@ -104,6 +104,8 @@ dh_ctx* dh_create(int device) {
   dh_ctx* ctx = new dh_ctx();
   ctx->device = device;
   if (const char* e = getenv("DH_RWALK_FORM")) ctx->rwalk_form = atoi(e) == 1 ? 1 : atoi(e) == 2 ? 2 : 0;
+  if (const char* e = getenv("DH_RWALK_ITEMS")) ctx->rwalk_items = atoi(e) != 0;
+  if (const char* e = getenv("DH_RWALK_ITEMS_MB")) ctx->items_budget = (size_t)(atol(e) > 0 ? atol(e) : 1024) << 20;
   if (const char* e = getenv("DH_CUBE_FORM")) ctx->cube_form = atoi(e) == 1 ? 1 : atoi(e) == 2 ? 2 : 0;
   {
     int cu = 0;
@@ -150,6 +152,7 @@ void dh_destroy(dh_ctx* ctx) {
     if (p.prec_t) (void)hipFree(p.prec_t);
   }
   if (ctx->zig) (void)hipFree(ctx->zig);
+  if (ctx->items) (void)hipFree(ctx->items);
   if (ctx->arena) (void)hipFree(ctx->arena);
   if (ctx->axes_t) (void)hipFree(ctx->axes_t);
   if (ctx->rebuild_ws) (void)hipFree(ctx->rebuild_ws);

@@ -58,14 +58,20 @@ struct dh_ctx {
   // on `stream` (fork after k_root, join before k_finish); created on first use
   hipStream_t side_stream = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  // rwalk kernel form (dh_set_rwalk_form): 0 = four lanes per walker (walkq.hip) for launches that would
-  // leave SIMDs empty with one walker per lane, 1 = one walker per lane always, 2 = four lanes per walker
-  // wherever that kernel is built
+  // rwalk kernel form (dh_set_rwalk_form): 0 / 2 = four lanes per walker (walkq.hip) wherever that kernel is
+  // built -- decided by the problem alone, never by the launch size --, 1 = one walker per lane always
   int rwalk_form = 0;
   // unit-cube sampler form (env DH_CUBE_FORM): 0 = four lanes per walker for launches that would leave SIMDs empty with
   // one walker per lane, 1 = one walker per lane always, 2 = four lanes always (PCG64 streams, ndim <= 32)
   int cube_form = 0;
   int num_cu = 256;  // hipDeviceProp_t::multiProcessorCount
+  // rwalk, four lanes per walker: the walkers' PCG64 item streams written out by a generator pass ahead of the walk
+  // (walkq.hip: itemgen_kernel; env DH_RWALK_ITEMS=0 keeps the generator inside the walk kernel).  Grow-only
+  // buffer, launches larger than the budget go in chunks of walkers
+  int rwalk_items = 1;
+  double* items = nullptr;
+  size_t items_cap = 0;
+  size_t items_budget = (size_t)1 << 30;
 
   const uint64_t* zki() const { return zig; }
   const uint64_t* zwi() const { return zig + 256; }

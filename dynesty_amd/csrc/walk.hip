@@ -351,8 +351,16 @@ extern "C" {
 int dh_set_rwalk_form(dh_ctx* ctx, int form) {
   DH_CHECK_CTX(ctx);
   if (form < 0 || form > 2)
-    return fail(ctx, DH_ERR_ARG, "rwalk form %d (0 = by launch size, 1 = lane per walker, 2 = four lanes per walker)", form);
+    return fail(ctx, DH_ERR_ARG, "rwalk form %d (0 / 2 = four lanes per walker where built, 1 = lane per walker)", form);
   ctx->rwalk_form = form;
+  return DH_OK;
+}
+
+int dh_set_rwalk_items(dh_ctx* ctx, int on, long long budget_bytes) {
+  DH_CHECK_CTX(ctx);
+  if (budget_bytes < 0) return fail(ctx, DH_ERR_ARG, "rwalk item-stream budget %lld", budget_bytes);
+  ctx->rwalk_items = on ? 1 : 0;
+  if (budget_bytes > 0) ctx->items_budget = (size_t)budget_bytes;
   return DH_OK;
 }
 
@@ -415,14 +423,14 @@ int dh::rwalk_launch_runs(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, 
                             run_scale, run_mode, nullptr, wpr, my_mode, philox);
   // Four lanes per walker + matrix cores (walkq.hip): built for full-dimensional proposals without
   // boundary conditions, 9 <= ndim <= 32, fused likelihood, affine / identity prior.  It does the same
-  // walk on the same streams (counts and generator states identical, coordinates to rounding) with 4x the
-  // wavefronts, which pays while the lane-per-walker launch leaves SIMDs empty: measured on the C2 shard,
-  // 64 x 512 walkers 0.86 -> 0.44 ms, 64 x 2000 walkers 1.26 -> 1.67 ms (per walker it issues about twice
-  // the instructions: 32 lane-draws for 26, per-walker scalars on four lanes).  Form 0 therefore takes it
-  // up to one lane-per-walker wavefront per SIMD (k <= 64 * 4 * CUs), form 2 always, form 1 never.
+  // walk on the same streams (counts and generator states identical, coordinates to rounding).  Round 4: with
+  // the PCG64 streams written out by a generator pass of their own it is the faster form at every launch size
+  // (64 x 512 walkers: 0.27 ms against 0.86; 64 x 2000: 1.02 against 1.23), so form 0 takes it whenever it
+  // applies -- a function of the problem alone, never of the launch size or the device, so that a run's
+  // accept / reject sequence cannot depend on how many runs share a GPU (form 1: never, 2: same as 0).
   const bool quad_ok = !a.propose_only && !bc && ndim == ncdim && ndim >= 9 && ndim <= kMaxRegDim &&
-                       a.prob.prior_id != PRIOR_NORMAL;
-  if (quad_ok && (ctx->rwalk_form == 2 || (ctx->rwalk_form == 0 && k <= 256 * ctx->num_cu)))
+                       a.prob.prior_id != PRIOR_NORMAL && (long long)walks * (ndim + 1) < (1ll << 24);
+  if (quad_ok && ctx->rwalk_form != 1)
     return rwalkq_launch(ctx, a.prob, k, ndim, u0, axes, m, axes_idx, scale, loglstar, walks, rng, u, v, logl,
                          naccept, nreject, rng_out, run_loglstar, run_scale, run_mode, wpr, my_mode, philox);
   a.k = k;

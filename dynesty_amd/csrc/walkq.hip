@@ -38,7 +38,7 @@ namespace {
 typedef double mfma_acc __attribute__((ext_vector_type(4)));
 #define DH_MFMA_F64(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
 
-enum : int { RNGQ_PCG64 = 0, RNGQ_PHILOX = 1 };
+enum : int { RNGQ_PCG64 = 0, RNGQ_PHILOX = 1, RNGQ_ITEMS = 2 };  // ITEMS: the PCG64 stream written out by itemgen_kernel
 
 struct RwalkQArgs {
   ProblemDev prob;
@@ -58,6 +58,8 @@ struct RwalkQArgs {
   const uint64_t* zwi;
   const uint64_t* zfi;
   const uint64_t* pcg_jump;
+  const double* items;  // RNGQ_ITEMS: [walker][walks * (ndim + 1)]
+  int wbase;            // index of this launch's first walker in the caller's batch (run lookup)
   const double* run_loglstar;
   const double* run_scale;
   const int* run_mode;
@@ -403,6 +405,189 @@ __device__ __forceinline__ void wavegen_fill(WaveGenLds* g, int target, const Li
   }
 }
 
+// ---- the generator as a pass of its own (round 4) ------------------------------------------------------------
+// Inside the walk kernel a round costs ~170 instructions that two wavefronts per SIMD issue at ~10 cycles each
+// (profiles/r04): 70 % of the kernel.  The item stream of a walker depends on nothing but its generator, so
+// `itemgen_kernel` writes it out ahead of the walk -- walks x (n normals, then the step's uniform as its 53 random
+// bits) per walker, in consumption order, T = walks (n + 1) doubles per walker -- with one wavefront per walker at
+// eight wavefronts per SIMD (40 registers, the walker's state in scalar registers: no state in LDS, no ring), and
+// the walk kernel (RNGQ_ITEMS) reads a step's items with plain loads, one step ahead.  Same rounds, same
+// arithmetic: the streams are bit for bit the fused kernel's.
+struct ItemGenArgs {
+  const uint64_t* rng_in;
+  uint64_t* rng_out;
+  double* items;  // [walker][T]
+  const uint64_t* zki;
+  const uint64_t* zwi;
+  const uint64_t* zfi;
+  const uint64_t* pcg_jump;
+  const int* run_mode;
+  int k, n, walks, wpr, my_mode, wbase;
+};
+
+__device__ __forceinline__ uint64_t mad_u64_u32_s(uint32_t a, uint32_t b_uniform, uint64_t c) {
+  uint64_t d;
+  asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(d) : "v"(a), "s"(b_uniform), "v"(c) : "vcc");
+  return d;
+}
+// a (per-lane limbs) * b (wave-uniform, in scalar registers), low 128 bits
+__device__ __forceinline__ U128 mul128_limbs_s(const Limbs128& a, const U128& b) {
+  const uint32_t a0 = a.w[0], a1 = a.w[1], a2 = a.w[2], a3 = a.w[3];
+  const uint32_t b0 = sfirst((uint32_t)b.lo), b1 = sfirst((uint32_t)(b.lo >> 32)), b2 = sfirst((uint32_t)b.hi),
+                 b3 = sfirst((uint32_t)(b.hi >> 32));
+  const uint64_t p00 = mad_u64_u32_s(a0, b0, 0ull);
+  const uint64_t p01 = mad_u64_u32_s(a0, b1, p00 >> 32);
+  const uint64_t p10 = mad_u64_u32_s(a1, b0, (uint64_t)(uint32_t)p01);
+  const uint64_t p11 = mad_u64_u32_s(a1, b1, (p01 >> 32) + (p10 >> 32));
+  uint64_t hi = mad_u64_u32_s(a0, b2, p11);
+  hi = mad_u64_u32_s(a2, b0, hi);
+  uint32_t top = a0 * b3 + a1 * b2 + a2 * b1 + a3 * b0;
+  asm("" : "+v"(top));
+  U128 r;
+  r.lo = (p10 << 32) | (uint32_t)p00;
+  r.hi = hi + ((uint64_t)top << 32);
+  return r;
+}
+
+__global__ void __launch_bounds__(256) itemgen_kernel(ItemGenArgs a) {
+#pragma clang fp contract(off)
+  __shared__ ZigQ zig;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  {
+    const int i = tid;
+    zig.kw[i] = make_ulonglong2(a.zki[i], a.zwi[i]);
+    const int im = i > 0 ? i - 1 : 0;
+    const double fa = __longlong_as_double((long long)a.zfi[im]), fb = __longlong_as_double((long long)a.zfi[i]);
+    zig.ff[i] = make_float2((float)(fa - fb), (float)fb);
+  }
+  __syncthreads();
+  const ZigQ* z = &zig;
+  const U128 gj = {a.pcg_jump[2 * lane], a.pcg_jump[2 * lane + 1]};  // G_{lane + 1}
+  const Limbs128 Gl = opaque_limbs(gj);
+  const int n = a.n, n1 = n + 1, T = a.walks * n1;
+  const uint32_t magic_n1 = (uint32_t)(0x100000000ull / (uint32_t)n1) + 1u;
+  uint64_t U0 = 0;
+  for (int b = 0; b < 64; b += n1) U0 |= 1ull << b;
+  const int nwaves = gridDim.x * 4;
+  for (int w = blockIdx.x * 4 + wave; w < a.k; w += nwaves) {
+    if (a.run_mode && a.run_mode[(a.wbase + w) / a.wpr] != a.my_mode) continue;
+    const uint64_t* p = a.rng_in + (size_t)w * 4;
+    U128 S0 = {p[0], p[1]};
+    const U128 inc = {p[2], p[3]};
+    U128 D;
+    {
+      const U128 mm1 = {DH_PCG_MULTM1_HI, DH_PCG_MULTM1_LO};
+      D = add128(mul128(S0, mm1), inc);  // S_1 - S_0
+    }
+    double* out = a.items + (size_t)w * T;
+    uint32_t W = 0;
+    while ((int)W < T) {
+      const U128 st = add128(S0, mul128_limbs_s(Gl, D));  // state at position lane + 1
+      const uint64_t r = pcg_output(st);
+      const int idx = (int)(r & 0xff);
+      const uint64_t rabs = (r >> 9) & 0x000fffffffffffffull;
+      const double rd = __longlong_as_double((long long)(rabs | 0x4330000000000000ull)) - 4503599627370496.0;
+      const ulonglong2 kw = z->kw[idx];
+      double x = rd * __longlong_as_double((long long)kw.y);
+      x = __longlong_as_double(__double_as_longlong(x) ^ (long long)((r & 0x100ull) << 55));
+      const uint64_t missmask = __ballot(!(rabs < kw.x)) & 0x7fffffffffffffffull;  // position 63 is never consumed
+      const int c = (int)(W - (uint32_t)(((uint64_t)W * magic_n1) >> 32) * (uint32_t)n1);
+      uint64_t umask = U0 << (n - c);
+      uint64_t dead = 0;
+      int endpos = 63, tailf = -1;
+      uint64_t m = missmask & ~umask;
+      if (m) {  // (the same resolution as wavegen_round's)
+        const float2 ff = z->ff[idx];
+        const uint32_t nhi = (uint32_t)__shfl_down((int)(uint32_t)(r >> 40), 1);
+        const float xf = (float)x;
+        const float lhs = ff.x * ((float)nhi * 5.9604644775390625e-08f) + ff.y;
+        const float ef = __expf(-0.5f * xf * xf);
+        uint64_t accmask = __ballot(lhs < ef);
+        const uint64_t zeromask = __ballot(idx == 0);
+        if (__ballot(fabsf(lhs - ef) <= 1e-5f) & m) {
+          const int ic = idx > 0 ? idx : 1;
+          const uint32_t nlo = (uint32_t)__shfl_down((int)(uint32_t)(r >> 11), 1),
+                         nh2 = (uint32_t)__shfl_down((int)(uint32_t)(r >> 43), 1);
+          const double u1 = (double)(((uint64_t)nh2 << 32) | nlo) * (1.0 / 9007199254740992.0);
+          const double f1 = __longlong_as_double((long long)a.zfi[ic - 1]), f0 = __longlong_as_double((long long)a.zfi[ic]);
+          accmask = __ballot((f1 - f0) * u1 + f0 < exp(-0.5 * x * x));
+        }
+        do {
+          const int f = (int)__ffsll((long long)m) - 1;
+          if ((zeromask >> f) & 1ull) {
+            tailf = f;
+            endpos = f;
+            break;
+          }
+          if (f == 62) {
+            endpos = 62;
+            break;
+          }
+          const uint64_t acc = (accmask >> f) & 1ull;
+          dead |= (2ull | (acc ^ 1ull)) << f;
+          const int keep = f + 2;
+          const uint64_t low = umask & ((1ull << keep) - 1ull);
+          umask = low | ((umask >> (f + (int)acc)) << keep);
+          m = missmask & ~umask & (~0ull << keep);
+        } while (m);
+      }
+      const int off = lane - (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(dead >> 32),
+                                                            __builtin_amdgcn_mbcnt_lo((uint32_t)dead, 0u));
+      int total = endpos - (int)__popcll(dead);
+      const int need = T - (int)W;
+      const bool alive = !__builtin_amdgcn_inverse_ballot_w64(dead);
+      if (total >= need) {
+        const uint64_t b = __ballot(alive && off == need - 1);
+        endpos = (int)__ffsll((long long)b);
+        total = need;
+        tailf = -1;
+      }
+#ifdef DH_IG_NOSTORE
+      if (alive && off < total && (r == 0x1234567ull))
+#else
+      if (alive && off < total)
+#endif
+        out[W + off] = __builtin_amdgcn_inverse_ballot_w64(umask) ? __longlong_as_double((long long)(r >> 11)) : x;
+      if (tailf >= 0) {
+        Pcg64 s;
+        s.state.hi = rl64(st.hi, tailf);
+        s.state.lo = rl64(st.lo, tailf);
+        s.inc = inc;
+        const uint64_t rabsf = rl64(rabs, tailf);
+        double xf;
+        for (;;) {
+          const double xx = -DH_ZIG_INV_R * log1p(-s.next_double());
+          const double yy = -log1p(-s.next_double());
+          if (yy + yy > xx * xx) {
+            xf = ((rabsf >> 8) & 1) ? -(DH_ZIG_R + xx) : DH_ZIG_R + xx;
+            break;
+          }
+        }
+        if (lane == 0) out[W + total] = xf;
+        ++total;
+        S0 = s.state;
+        s.step();
+        D = sub128(s.state, S0);
+      } else {
+        U128 S1;
+        S0.hi = rl64(st.hi, endpos - 1);
+        S0.lo = rl64(st.lo, endpos - 1);
+        S1.hi = rl64(st.hi, endpos);
+        S1.lo = rl64(st.lo, endpos);
+        D = sub128(S1, S0);
+      }
+      W += (uint32_t)total;
+    }
+    if (lane == 0 && a.rng_out) {
+      uint64_t* o = a.rng_out + (size_t)w * 4;
+      o[0] = S0.hi;
+      o[1] = S0.lo;
+      o[2] = inc.hi;
+      o[3] = inc.lo;
+    }
+  }
+}
+
 // fragments of a D x D row-major matrix M for the MFMA A operand: F[mt][s] = M[16 mt + (lane & 15)][4 s + (lane >> 4)]
 template <int NR, int MT>
 __device__ __forceinline__ void load_frags(const double* M, int n, int j, int t, double (&F)[MT][NR]) {
@@ -521,11 +706,12 @@ __device__ __forceinline__ double root_n(double ur, int n, double inv_n) {
 template <int NR, int KIND, int RNG>
 __global__ void __launch_bounds__(256) rwalkq_kernel(RwalkQArgs a) {
   constexpr int MT = (4 * NR + 15) / 16;
-  __shared__ ZigQ zig;
   constexpr int STRIDE = RingGeom<NR>::stride;
-  __shared__ double ring_all[64 * STRIDE];  // [walker slot][ring position]: the walkers' next items
+  __shared__ __attribute__((aligned(16))) char zig_mem[RNG == RNGQ_PCG64 ? sizeof(ZigQ) : 16];
+  __shared__ double ring_all[RNG == RNGQ_ITEMS ? 1 : 64 * STRIDE];  // [walker slot][ring position]: the walkers' next items
   __shared__ double sprec[MT * NR * 64];       // MFMA fragments of the precision matrix
-  __shared__ WaveGenLds gen_all[4];
+  __shared__ WaveGenLds gen_all[RNG == RNGQ_PCG64 ? 4 : 1];
+  ZigQ& zig = *reinterpret_cast<ZigQ*>(zig_mem);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int t = lane >> 4, j = lane & 15;
   const int slot = wave * 16 + j;
@@ -554,7 +740,7 @@ __global__ void __launch_bounds__(256) rwalkq_kernel(RwalkQArgs a) {
   double loglstar = a.loglstar, scale = a.scale;
   bool on = true;
   if (a.run_mode) {
-    const int run = wi / a.wpr;
+    const int run = (a.wbase + wi) / a.wpr;
     on = a.run_mode[run] == a.my_mode;
     loglstar = a.run_loglstar[run];
     scale = a.run_scale[run];
@@ -589,6 +775,14 @@ __global__ void __launch_bounds__(256) rwalkq_kernel(RwalkQArgs a) {
     Gl = opaque_limbs(gj);
   }
   const bool lastok = 4 * (NR - 1) + t < n;
+  // RNGQ_ITEMS: the walker's stream in global memory and the registers that hold the coming step's items
+  const double* myitems = a.items + (size_t)wi * T;
+  double nx[NR], nxu = 0.0;
+  if constexpr (RNG == RNGQ_ITEMS) {
+#pragma unroll
+    for (int r = 0; r < NR; ++r) nx[r] = myitems[(r < NR - 1 || lastok) ? 4 * r + t : 0];
+    nxu = myitems[n];
+  }
   int start = 0;  // ring position of the current step's first item: (step * n1) mod cap
   WQP(WqProf pf; pf.fill = pf.rest = pf.rounds = pf.segs = pf.wedges = pf.t0 = 0;)
   const int nb = (n + 3) >> 2;           // hiprand_normal4 blocks per step
@@ -607,7 +801,9 @@ __global__ void __launch_bounds__(256) rwalkq_kernel(RwalkQArgs a) {
 #pragma unroll 1
   for (int step = 0; step < a.walks; ++step) {
     // randsphere (bounding.py:1288-1297): n normals, one uniform
-    if constexpr (RNG == RNGQ_PCG64) {
+    if constexpr (RNG == RNGQ_ITEMS) {
+      // this step's items were loaded a step ahead (below)
+    } else if constexpr (RNG == RNGQ_PCG64) {
       WQP(const long long tq0 = clock64();)
       wavegen_fill<STRIDE>(gen, (step + 1) * n1, Gl, &zig, ring, lane, gk, a.rng_in, walker0, a.k WQP(, &pf));
       WQP(const long long tq1 = clock64(); pf.fill += tq1 - tq0; if (step) pf.rest += tq0 - pf.t0; pf.t0 = tq1;)
@@ -628,22 +824,36 @@ __global__ void __launch_bounds__(256) rwalkq_kernel(RwalkQArgs a) {
         }
       }
     }
-    wave_sync();
-    double ss = 0.0;
+    double ss = 0.0, ur;
+    if constexpr (RNG == RNGQ_ITEMS) {
 #pragma unroll
-    for (int r = 0; r < NR; ++r) {
-      // a step's items lie in a row without wrapping; NR = ceil(n / 4): only the last register of a vector has
-      // lanes past the dimension
-      const double item = myrow[start + 4 * r + t];
-      dr[r] = (r < NR - 1 || lastok) ? item : 0.0;
-      ss = fma(dr[r], dr[r], ss);
+      for (int r = 0; r < NR; ++r) {
+        dr[r] = (r < NR - 1 || lastok) ? nx[r] : 0.0;
+        ss = fma(dr[r], dr[r], ss);
+      }
+      ur = (double)(uint64_t)__double_as_longlong(nxu) * (1.0 / 9007199254740992.0);
+      // the next step's items: in flight while this step computes (the last step reads its own again)
+      const double* nrow = myitems + (step + 1 < a.walks ? (step + 1) * n1 : step * n1);
+#pragma unroll
+      for (int r = 0; r < NR; ++r) nx[r] = nrow[(r < NR - 1 || lastok) ? 4 * r + t : 0];
+      nxu = nrow[n];
+    } else {
+      wave_sync();
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        // a step's items lie in a row without wrapping; NR = ceil(n / 4): only the last register of a vector has
+        // lanes past the dimension
+        const double item = myrow[start + 4 * r + t];
+        dr[r] = (r < NR - 1 || lastok) ? item : 0.0;
+        ss = fma(dr[r], dr[r], ss);
+      }
+      ur = myrow[start + n];
+      if constexpr (RNG == RNGQ_PCG64)  // the generator hands over the uniform's 53 random bits
+        ur = (double)(uint64_t)__double_as_longlong(ur) * (1.0 / 9007199254740992.0);
+      wave_sync();
+      start += n1;
+      start = start >= gk.cap ? 0 : start;
     }
-    double ur = myrow[start + n];
-    if constexpr (RNG == RNGQ_PCG64)  // the generator hands over the uniform's 53 random bits
-      ur = (double)(uint64_t)__double_as_longlong(ur) * (1.0 / 9007199254740992.0);
-    wave_sync();
-    start += n1;
-    start = start >= gk.cap ? 0 : start;
     ss = grp_sum(ss);
     // scale * ur^(1/n) / |dr| (bounding.py:1295-1296).  This is per-walker scalar work that all four
     // sub-lanes repeat, so it is kept short: exp(log(ur) / n) instead of ocml's double-double pow (|log
@@ -773,24 +983,86 @@ int rwalkq_launch(dh_ctx* ctx, const ProblemDev& prob, int k, int ndim, const do
   a.ph_seed = philox ? philox->seed : 0;
   a.ph_seq0 = philox ? philox->seq0 : 0;
   a.ph_offset = philox ? philox->offset : 0;
-  const dim3 grid((k + 63) / 64), block(256);
+  a.items = nullptr;
+  a.wbase = 0;
+  const dim3 block(256);
   const int kind = problem_kind(prob.like_id, prob.prior_id) == KIND_PREC_AFFINE ? KIND_PREC_AFFINE : KIND_GENERIC;
   const int nr = (ndim + 3) / 4;  // 9 <= ndim <= 32: 3 .. 8
-#define L(NRR, KK)                                                                                     \
+#define L(NRR, KK, GRID)                                                                               \
   do {                                                                                                 \
     if (philox)                                                                                        \
-      hipLaunchKernelGGL((rwalkq_kernel<NRR, KK, RNGQ_PHILOX>), grid, block, 0, ctx->stream, a);       \
+      hipLaunchKernelGGL((rwalkq_kernel<NRR, KK, RNGQ_PHILOX>), GRID, block, 0, ctx->stream, a);       \
+    else if (a.items)                                                                                  \
+      hipLaunchKernelGGL((rwalkq_kernel<NRR, KK, RNGQ_ITEMS>), GRID, block, 0, ctx->stream, a);        \
     else                                                                                               \
-      hipLaunchKernelGGL((rwalkq_kernel<NRR, KK, RNGQ_PCG64>), grid, block, 0, ctx->stream, a);        \
+      hipLaunchKernelGGL((rwalkq_kernel<NRR, KK, RNGQ_PCG64>), GRID, block, 0, ctx->stream, a);        \
   } while (0)
-#define X(NRR)                         \
+#define X(NRR, GRID)                   \
   if (nr == NRR) {                     \
     if (kind == KIND_PREC_AFFINE)      \
-      L(NRR, KIND_PREC_AFFINE);        \
+      L(NRR, KIND_PREC_AFFINE, GRID);  \
     else                               \
-      L(NRR, KIND_GENERIC);            \
+      L(NRR, KIND_GENERIC, GRID);      \
   }
-  X(3) X(4) X(5) X(6) X(7) X(8)
+#define XALL(GRID) X(3, GRID) X(4, GRID) X(5, GRID) X(6, GRID) X(7, GRID) X(8, GRID)
+  if (philox || !ctx->rwalk_items) {
+    const dim3 grid((k + 63) / 64);
+    XALL(grid)
+    return hip_ok(ctx, hipGetLastError(), "rwalkq launch") ? DH_OK : DH_ERR_HIP;
+  }
+  // PCG64 streams, generator as a pass of its own: walkers in chunks whose item streams fit the context's buffer
+  const size_t T = (size_t)walks * (ndim + 1), per_walker = T * sizeof(double);
+  size_t chunk = ctx->items_budget / per_walker;
+  if (chunk < 64) chunk = 64;
+  if (chunk > (size_t)k) chunk = (size_t)k;
+  chunk = (chunk + 63) / 64 * 64;
+  const size_t need = (chunk < (size_t)k ? chunk : (size_t)k) * per_walker;
+  if (need > ctx->items_cap) {
+    if (!hip_ok(ctx, hipStreamSynchronize(ctx->stream), "sync")) return DH_ERR_HIP;
+    if (ctx->items) (void)hipFree(ctx->items);
+    ctx->items = nullptr;
+    ctx->items_cap = 0;
+    if (!hip_ok(ctx, hipMalloc((void**)&ctx->items, need), "hipMalloc(rwalk item streams)")) return DH_ERR_NOMEM;
+    ctx->items_cap = need;
+  }
+  for (size_t first = 0; first < (size_t)k; first += chunk) {
+    const int kc = (int)((size_t)k - first < chunk ? (size_t)k - first : chunk);
+    ItemGenArgs g;
+    g.rng_in = rng + first * 4;
+    g.rng_out = rng_out ? rng_out + first * 4 : nullptr;
+    g.items = ctx->items;
+    g.zki = ctx->zki();
+    g.zwi = ctx->zwi();
+    g.zfi = ctx->zfi();
+    g.pcg_jump = ctx->pcg_jump();
+    g.run_mode = run_mode;
+    g.k = kc;
+    g.n = ndim;
+    g.walks = walks;
+    g.wpr = wpr;
+    g.my_mode = my_mode;
+    g.wbase = (int)first;
+    // one wavefront per walker up to eight wavefronts per SIMD; beyond that the wavefronts loop
+    int gblocks = (kc + 3) / 4;
+    const int gmax = ctx->num_cu * 8;
+    if (gblocks > gmax) gblocks = gmax;
+    hipLaunchKernelGGL(itemgen_kernel, dim3(gblocks), block, 0, ctx->stream, g);
+    a.k = kc;
+    a.wbase = (int)first;
+    a.items = ctx->items;
+    a.u0 = u0 + first * ndim;
+    a.axes_idx = axes_idx ? axes_idx + first : nullptr;
+    a.rng_in = rng + first * 4;
+    a.u = u + first * ndim;
+    a.v = v + first * ndim;
+    a.logl = logl + first;
+    a.nacc = naccept + first;
+    a.nrej = nreject + first;
+    a.rng_out = nullptr;  // written by the generator pass
+    const dim3 grid((kc + 63) / 64);
+    XALL(grid)
+  }
+#undef XALL
 #undef X
 #undef L
   return hip_ok(ctx, hipGetLastError(), "rwalkq launch") ? DH_OK : DH_ERR_HIP;

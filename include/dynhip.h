@@ -216,13 +216,22 @@ int dh_rwalk_batch_dev(dh_ctx* ctx, int problem, int k, int ndim, int ncdim,
  * on the fp64 matrix cores (built for ndim == ncdim in 9..32, no periodic / reflective coordinates,
  * affine or identity prior).  Accept / reject counts and generator end states of the two are identical,
  * coordinates agree to rounding (~1e-15: sums over a vector are taken in a different order).
- *   form 0 (default)  four lanes per walker while the launch is small enough to leave SIMDs empty with
- *                     one walker per lane (k <= 256 * compute units), else one walker per lane
+ *   form 0 (default)  four lanes per walker wherever built: decided by the problem alone (dimension, boundary
+ *                     conditions, prior), never by the launch size or the device, so that a run's results do
+ *                     not depend on how an ensemble is sharded
  *   form 1            one walker per lane always
- *   form 2            four lanes per walker wherever built (a job that wants bit-identical results for
- *                     every sharding of an ensemble pins form 1 or 2)
- * The environment variable DH_RWALK_FORM sets the initial value. */
+ *   form 2            same as 0 (kept for callers of the round-3 interface)
+ * The environment variable DH_RWALK_FORM sets the initial value.  DH_RWALK_ITEMS=0 keeps the PCG64 generator of
+ * the four-lane form inside the walk kernel instead of a generator pass ahead of it (same streams, same results);
+ * DH_RWALK_ITEMS_MB bounds that pass's buffer (default 1024: larger launches go in chunks of walkers). */
 int dh_set_rwalk_form(dh_ctx* ctx, int form);
+
+/* The four-lane form's PCG64 generator as a pass of its own ahead of the walk (on = 1, default: every walker's
+ * walks x (ndim normals + 1 uniform) items written to a context buffer by one wavefront per walker, read back by
+ * the walk kernel) or inside the walk kernel (on = 0).  Same streams, bit-identical results either way.
+ * budget_bytes > 0 bounds the buffer (default 2^30): a launch whose streams need more runs in chunks of walkers;
+ * 0 leaves the bound as it is.  (RWalkSampler.sample draws them in internal_samplers.py:1007-1021.) */
+int dh_set_rwalk_items(dh_ctx* ctx, int on, long long budget_bytes);
 
 /* Throughput mode of RWalkSampler.sample: the same walk (generic_random_walk, propose_ball_point,
  * randsphere; internal_samplers.py:866-1035, bounding.py:1288-1297) drawing from hiprand's Philox4x32-10

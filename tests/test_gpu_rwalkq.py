@@ -24,6 +24,7 @@ def ctx():
     c = _lib.Context(0)
     yield c
     c.set_rwalk_form(0)
+    c.set_rwalk_items(True, 1 << 30)
 
 
 def make_case(prob, nwalk, seed, shrink=0.5):
@@ -113,6 +114,55 @@ def test_quad_equals_lane_form_and_batch_halves(ctx):
     h1 = ctx.rwalk_batch(prob, u0[cut:], case["axes"], case["scale"], case["loglstar"], 45, st[cut:])
     for key in ("u", "v", "logl", "accept", "reject", "rng_out"):
         np.testing.assert_array_equal(quad[key], np.concatenate([h0[key], h1[key]]))
+
+
+def test_generator_pass_equals_fused_generator_and_chunks(ctx):
+    """Round 4: the walkers' PCG64 item streams come from a generator pass ahead of the walk (itemgen_kernel) or from
+    the generator inside the walk kernel -- the same rounds on the same streams: every output bit for bit, also
+    when the pass's buffer is so small that the launch goes in chunks of walkers (chunk edges off every
+    granularity), with several frames and ragged sizes."""
+    for d, k, walks in ((25, 3001, 45), (12, 517, 20), (32, 260, 7)):
+        prob = problems.gauss_corr(d, 0.4, 5.0, f"corr{d}")
+        case = make_case(prob, k + 400, 40 + d)
+        u0 = case["u0"][:k]
+        assert len(u0) == k
+        a = case["axes"]
+        axes3 = np.stack([a, 0.5 * a[::-1, ::-1].copy(), 0.8 * a.T.copy()])
+        idx = (np.arange(k) * 7 % 3).astype(np.int32)
+        st = ctx.seed_children([d, 1, 2], 5, k)
+        args = (prob, u0, axes3, case["scale"], case["loglstar"], walks, st)
+        ctx.set_rwalk_form(2)
+        ctx.set_rwalk_items(False)
+        fused = ctx.rwalk_batch(*args, axes_idx=idx)
+        ctx.set_rwalk_items(True, 1 << 30)
+        one = ctx.rwalk_batch(*args, axes_idx=idx)
+        ctx.set_rwalk_items(True, 200 * walks * (d + 1) * 8)  # 200 walkers' streams -> chunks of 192
+        chunks = ctx.rwalk_batch(*args, axes_idx=idx)
+        ctx.set_rwalk_items(True, 1 << 30)
+        for key in ("u", "v", "logl", "accept", "reject", "rng_out"):
+            np.testing.assert_array_equal(one[key], fused[key], err_msg=key)
+            np.testing.assert_array_equal(chunks[key], fused[key], err_msg=key)
+        assert fused["accept"].sum() > 0 and fused["reject"].sum() > 0
+
+
+def test_a_walker_does_not_depend_on_the_launch_size(ctx):
+    """the kernel form used to follow the launch size (four lanes per walker up to 256 x #CU
+    walkers, one per lane above), and the two agree only to rounding, so a run's accept / reject sequence could
+    depend on how many runs share a GPU.  The form is a function of the problem alone now: walkers of a launch on
+    the far side of the old threshold equal the same walkers launched alone, bit for bit."""
+    prob = problems.gauss_corr(25, 0.4, 5.0, "C2")
+    case = make_case(prob, 9000, 77)
+    base = case["u0"][:8192]
+    reps = 10  # 81 920 walkers > 256 x 256
+    u0 = np.tile(base, (reps, 1))
+    k = len(u0)
+    st = ctx.seed_children([3, 1, 4], 0, k)
+    ctx.set_rwalk_form(0)
+    big = ctx.rwalk_batch(prob, u0, case["axes"], case["scale"], case["loglstar"], 12, st)
+    lo, hi = 70001, 70001 + 333
+    small = ctx.rwalk_batch(prob, u0[lo:hi], case["axes"], case["scale"], case["loglstar"], 12, st[lo:hi])
+    for key in ("u", "v", "logl", "accept", "reject", "rng_out"):
+        np.testing.assert_array_equal(big[key][lo:hi], small[key], err_msg=key)
 
 
 def test_quad_philox_equals_lane_philox(ctx):
