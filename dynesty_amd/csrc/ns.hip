@@ -1422,7 +1422,13 @@ __global__ void __launch_bounds__(kT) ns_consume(NsArgs a) {
         r.scale *= mult;
       }
     }
-    const int done = stopped ? 1 : ((jcap >= 0 || atomicOr(&r.sampler_failed, 0)) ? 2 : 0);
+    int done = stopped ? 1 : ((jcap >= 0 || atomicOr(&r.sampler_failed, 0)) ? 2 : 0);
+    // The plateau mode's companion stop (sampler.py:1095-1100: np.ptp(live_logl) == 0 -> "we have reached the plateau
+    // in the likelihood", the run ends normally): lmax is the largest value ever inserted and the point that carries
+    // it is alive until it is the worst, so the live set has no spread exactly when its worst value has reached
+    // lmax.  No proposal can beat such a threshold: without this stop the run would idle to max_fills (and the
+    // uniform samplers retry 2^32 times per walker).  (The reference tests before every death, here once per fill.)
+    if (!done && bcast[2] >= r.lmax) done = 1;
     if (done) {
       r.mode = done == 1 ? MODE_DONE : MODE_FAILED;
       atomicAdd(a.ndone, 1);
@@ -1671,6 +1677,8 @@ int dh_ns_consume(dh_ctx* ctx, int runs, int nlive, int queue_size, double dlogz
     return fail(ctx, DH_ERR_ARG, "ns_consume: bad arguments");
   const int R = runs, N = nlive, K = queue_size;
   if (K > kEPT * kT) return fail(ctx, DH_ERR_ARG, "ns_consume: queue_size %d > %d", K, kEPT * kT);
+  // the register sort of the live slots is built for at most 32 keys per thread (sort_slots<32>)
+  if (N > 32 * kT) return fail(ctx, DH_ERR_ARG, "ns_consume: nlive %d > %d", N, 32 * kT);
   size_t lds_fin = (size_t)N * 16 + 64;  // ns_finish: the keys by slot, the keys in order, the sorted slots
   {
     size_t Pf = 1;
@@ -1808,6 +1816,9 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
   // MultiEllipsoid.update: a host recursion over device node work, so a rebuild fill there synchronises the stream
   // and reads the run mask back (the loop is no longer launch-ahead on those fills; the tree is a handful of nodes).
   const int N = nlive, D = ndim, K = queue_size, R = runs;
+  // the register sort of the live slots is built for at most 32 keys per thread (sort_slots<32>); the LDS bound of
+  // ns_finish below is tighter today, this one is the sort's own
+  if (N > 32 * kT) return fail(ctx, DH_ERR_ARG, "ns_ensemble: nlive %d > %d", N, 32 * kT);
   const int me = bound_multi ? (N / (2 * D) > 0 ? N / (2 * D) : 1) : 1;
   NsArgs a{};
   a.runs = R;

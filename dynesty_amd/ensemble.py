@@ -116,6 +116,9 @@ def run_ensemble(prob, total_runs, base_seed=21, world=1, rank=0, dist=None,
     return table, results
 
 
+STATUS_RAISED = -99.0  # status of the runs of a rank whose ns_ensemble call raised (never a device status)
+
+
 def run_ensemble_device(prob, total_runs, base_seed=21, world=1, rank=0,
                         dist=None, device=None, nlive=2000, queue_size=512,
                         walks=None, bound='multi', dlogz=0.01, on_failure='raise', **kw):
@@ -132,21 +135,34 @@ def run_ensemble_device(prob, total_runs, base_seed=21, world=1, rank=0,
     mine = shard_runs(total_runs, world, rank)
     nf = len(RECORD_FIELDS)
     local = np.zeros((0, nf + 1))
+    raised = None
     if len(mine):
-        r = get_backend().ns_ensemble(prob, len(mine), nlive, queue_size,
-                                      walks=walks, bound=bound, dlogz=dlogz,
-                                      entropy=np.atleast_1d(base_seed),
-                                      first_run=mine.start, **kw)
-        status = np.asarray(r["status"]).astype(np.float64)
-        bad = np.flatnonzero(status != 0)
-        # a failed run (bound rebuild error, dead-point capacity) or one that hit max_fills
-        # before dlogz must never enter the table as a valid ln Z estimate
-        for key in ("logz", "logzerr", "h"):
-            r[key] = np.array(r[key], dtype=np.float64)
-            r[key][bad] = np.nan
-        local = np.stack([np.arange(mine.start, mine.stop, dtype=np.float64),
-                          r["logz"], r["logzerr"], r["niter"].astype(float),
-                          r["ncall"].astype(float), r["h"], status], axis=1)
+        try:
+            r = get_backend().ns_ensemble(prob, len(mine), nlive, queue_size,
+                                          walks=walks, bound=bound, dlogz=dlogz,
+                                          entropy=np.atleast_1d(base_seed),
+                                          first_run=mine.start, **kw)
+        except Exception as e:  # argument / memory / HIP errors raise before any status exists
+            #  this rank must still enter the collective, else the others block in the all-gather
+            # until the communicator times out: its runs travel as NaN rows with the sentinel status, and every
+            # rank raises after the gather; this rank re-raises its own exception
+            raised = e
+            r = None
+        if r is None:
+            local = np.full((len(mine), nf + 1), np.nan)
+            local[:, 0] = np.arange(mine.start, mine.stop)
+            local[:, nf] = STATUS_RAISED
+        else:
+            status = np.asarray(r["status"]).astype(np.float64)
+            bad = np.flatnonzero(status != 0)
+            # a failed run (bound rebuild error, dead-point capacity) or one that hit max_fills
+            # before dlogz must never enter the table as a valid ln Z estimate
+            for key in ("logz", "logzerr", "h"):
+                r[key] = np.array(r[key], dtype=np.float64)
+                r[key][bad] = np.nan
+            local = np.stack([np.arange(mine.start, mine.stop, dtype=np.float64),
+                              r["logz"], r["logzerr"], r["niter"].astype(float),
+                              r["ncall"].astype(float), r["h"], status], axis=1)
     # The collective comes FIRST: the status column travels with the records, so that every rank
     # learns of a failed run and all of them raise together -- raising on the owning rank alone
     # would leave the others blocked in the all-gather until the communicator times out.
@@ -154,6 +170,12 @@ def run_ensemble_device(prob, total_runs, base_seed=21, world=1, rank=0,
                            device=device, nfield=nf + 1)
     status = table[:, nf]
     table = np.ascontiguousarray(table[:, :nf])
+    if raised is not None:
+        raise raised
+    if np.any(status == STATUS_RAISED):
+        raise RuntimeError(
+            f"ns_ensemble raised on the rank(s) owning runs "
+            f"{[int(table[b, 0]) for b in np.flatnonzero(status == STATUS_RAISED)]}")
     bad = np.flatnonzero(status != 0)
     if len(bad) and on_failure == 'raise':
         raise RuntimeError(
@@ -374,12 +396,16 @@ def run_ensemble_merged_sharded(prob, total_runs, base_seed=21, world=1, rank=0,
     if max_iter is None:
         max_iter = 80 * nlive
     rows, ncall, nbad = [], 0, 0
-    r = None
+    r, raised = None, None
     if len(mine):
-        r = be.ns_ensemble(prob, len(mine), nlive, queue_size,
-                           entropy=np.atleast_1d(base_seed), first_run=mine.start,
-                           max_iter=max_iter, want_samples=True, **kw)
-        nbad = int((r["status"] != 0).sum())
+        try:
+            r = be.ns_ensemble(prob, len(mine), nlive, queue_size,
+                               entropy=np.atleast_1d(base_seed), first_run=mine.start,
+                               max_iter=max_iter, want_samples=True, **kw)
+            nbad = int((r["status"] != 0).sum())
+        except Exception as e:  # this rank still joins the all-reduce below, then re-raises
+            raised = e
+            nbad = len(mine)
     # every rank learns of a failure before anyone leaves the collective sequence (see
     # run_ensemble_device): one all-reduce of the failure count, then raise everywhere
     if dist is not None:
@@ -391,6 +417,8 @@ def run_ensemble_merged_sharded(prob, total_runs, base_seed=21, world=1, rank=0,
         nbad_all = int(t.item())
     else:
         nbad_all = nbad
+    if raised is not None:
+        raise raised
     if nbad_all:
         raise RuntimeError(f"ns_ensemble: {nbad_all} run(s) of the ensemble failed"
                            + (f", local status {r['status']}" if nbad else ""))

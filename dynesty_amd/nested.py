@@ -22,12 +22,14 @@ Semantics kept from the reference because they decide the statistics:
   * ln X decreases by ln((N+1)/N) per iteration; trapezoid weights; the final
     live points are appended (sampler.py:780-930).
 
-Not taken over: the forced bound update of Sampler.propose_live (sampler.py:484-489: a start point outside
-the bound rebuilds it at once).  The device-resident loop (dh_ns_ensemble) makes those updates at every
-dimension; here the bound follows the call-count schedule only, which matters for few live points in many
-dimensions (the 40-D / 333-live-point case) -- use the resident loop or the drop-in there.
+The forced bound update of Sampler.propose_live (sampler.py:484-489: a start point outside the bound rebuilds it
+at once) is made per queue fill: the fill's start points go through the batched membership test and one outside
+the (enlarged) bound rebuilds it before the frames are drawn (round 4; it matters for few live points in many
+dimensions, DESIGN.md section 3.6: the 40-D / 333-live-point case).  The plateau mode's companion stop
+(sampler.py:1095-1100, a live set without spread) ends the run with the reference's warning.
 """
 import math
+import warnings
 
 import numpy as np
 from scipy.special import logsumexp
@@ -194,6 +196,8 @@ def run_static(prob, nlive=500, bound='multi', sample='rwalk', queue_size=None,
             bnd.scale_to_logvol(bnd.logvol + math.log(enlarge))
         nbound += 1
 
+    forced = [False]  # set by fill(): the bound was rebuilt for a start point outside it
+
     def fill(loglstar):
         """One queue fill: K proposals against loglstar (one launch)."""
         nonlocal scale, doubling
@@ -218,6 +222,14 @@ def run_static(prob, nlive=500, bound='multi', sample='rwalk', queue_size=None,
         if len(above) == 0:
             raise RuntimeError('No live points are above loglstar.')
         start = rstate.choice(above, size=K)
+        # forced bound update (sampler.py:484-489): a start point outside the bound rebuilds it at once
+        if bound in ('balls', 'cubes'):
+            inside = bnd.overlap_many(live_u[start]) > 0
+        else:
+            inside = np.asarray(bnd.contains_many(live_u[start]))
+        if not inside.all():
+            rebuild()
+            forced[0] = True
         if bound == 'multi':
             probs = np.exp(bnd.logvol_ells - bnd.logvol)
             fidx = np.minimum(np.searchsorted(np.cumsum(probs),
@@ -272,7 +284,13 @@ def run_static(prob, nlive=500, bound='multi', sample='rwalk', queue_size=None,
         elif ncall >= ncall_last_update + update_interval:
             rebuild()
             ncall_last_update = ncall
+        if np.ptp(live_logl) == 0:  # sampler.py:1095-1100
+            warnings.warn('We have reached the plateau in the likelihood we are stopping sampling')
+            break
         out, _ = fill(loglstar)
+        if forced[0]:
+            forced[0] = False
+            ncall_last_update = ncall
         q_logl = np.ascontiguousarray(out["logl"], dtype=np.float64)
         q_nc = np.ascontiguousarray(out["ncalls"], dtype=np.int32)
         pos = 0

@@ -18,9 +18,12 @@ import torch.distributed as dist
 from dynesty_amd import backend, ensemble
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 bad_rank = int(os.environ["BAD_RANK"])
+raise_rank = int(os.environ.get("RAISE_RANK", "-1"))
 
 class FakeBackend:
     def ns_ensemble(self, prob, runs, nlive, queue_size, first_run=0, want_samples=False, **kw):
+        if rank == raise_rank:
+            raise MemoryError("libdynhip error -5: hipMalloc failed")  # what _check raises for DH_ERR_NOMEM-like codes
         status = np.zeros(runs, dtype=np.int32)
         if rank == bad_rank:
             status[-1] = -2
@@ -45,15 +48,16 @@ res = {}
 try:
     t = ensemble.run_ensemble_device(None, 5, world=world, rank=rank, dist=dist)
     res["device"] = ["ok", t[:, 1].tolist()]
-except RuntimeError as e:
-    res["device"] = ["raised", str(e)]
-t = ensemble.run_ensemble_device(None, 5, world=world, rank=rank, dist=dist, on_failure='nan')
-res["nan"] = [int(np.isnan(t[:, 1]).sum()), t.shape]
+except (RuntimeError, MemoryError) as e:
+    res["device"] = ["raised", type(e).__name__ + ": " + str(e)]
+if raise_rank < 0:
+    t = ensemble.run_ensemble_device(None, 5, world=world, rank=rank, dist=dist, on_failure='nan')
+    res["nan"] = [int(np.isnan(t[:, 1]).sum()), t.shape]
 try:
     m = ensemble.run_ensemble_merged_sharded(None, 5, world=world, rank=rank, dist=dist, nlive=8, queue_size=4)
     res["merged"] = ["ok", int(m.niter)]
-except RuntimeError as e:
-    res["merged"] = ["raised", str(e)]
+except (RuntimeError, MemoryError) as e:
+    res["merged"] = ["raised", type(e).__name__ + ": " + str(e)]
 dist.barrier()
 with open(os.path.join(%(out)r, "f%%d_of_%%d.json" %% (rank, world)), "w") as f:
     json.dump(res, f)
@@ -69,7 +73,7 @@ def _free_port():
     return p
 
 
-def _launch(tmp, world, bad_rank):
+def _launch(tmp, world, bad_rank, raise_rank=-1):
     import json
     script = os.path.join(str(tmp), "worker.py")
     with open(script, "w") as f:
@@ -78,7 +82,8 @@ def _launch(tmp, world, bad_rank):
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), OMP_NUM_THREADS="1", BAD_RANK=str(bad_rank))
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="1", BAD_RANK=str(bad_rank),
+                   RAISE_RANK=str(raise_rank))
         procs.append(subprocess.Popen([sys.executable, script], env=env))
     for p in procs:
         assert p.wait(timeout=300) == 0  # a hang in the collective would time out here
@@ -107,3 +112,15 @@ def test_world_size_one_process_group_runs_the_collectives(tmp_path):
     assert res[0]["device"][0] == "ok" and res[0]["merged"] == ["ok", 5 * 18]
     res = _launch(tmp_path, 1, bad_rank=0)
     assert res[0]["device"][0] == "raised" and res[0]["merged"][0] == "raised"
+
+
+def test_an_exception_on_one_rank_raises_on_every_rank(tmp_path):
+    """ns_ensemble RAISING on one rank (argument / memory / HIP errors have no status row) used to
+    leave before the collective and block the others; now its runs travel with a sentinel status and every rank
+    raises -- the owner its own exception, the others a RuntimeError naming the runs."""
+    res = _launch(tmp_path, 2, bad_rank=-1, raise_rank=1)
+    assert res[1]["device"][0] == "raised" and res[1]["device"][1].startswith("MemoryError"), res[1]
+    assert res[0]["device"][0] == "raised" and "raised on the rank" in res[0]["device"][1], res[0]
+    assert "[3, 4]" in res[0]["device"][1]
+    assert res[0]["merged"][0] == "raised" and res[1]["merged"][0] == "raised"
+    assert res[1]["merged"][1].startswith("MemoryError")
