@@ -5,7 +5,9 @@ import os
 import sys
 import tempfile
 
-REF = "/root/reference/py"
+# DYNESTY_REF_PY: another place to find the reference's `py/` directory (tools/tapb_hw.py stages a scratch copy,
+# never committed, for a run on the GPU box)
+REF = os.environ.get("DYNESTY_REF_PY", "/root/reference/py")
 
 
 def have_reference():
