@@ -138,6 +138,10 @@ __device__ __forceinline__ double ndtri_as241_core(double p, bool* far) {
   return num / den;
 }
 
+// (the far tail -- p < e^-25, or outside (0, 1) -- is a call: inlined, ocml's erfcinv sets the register need of every
+// kernel that merely might meet such a coordinate)
+__device__ __attribute__((noinline)) double ndtri_far(double p) { return ndtri_dev(p); }
+
 template <int N>
 __device__ __forceinline__ void ndtri_n(const double (&p)[N], double (&out)[N]) {
   bool far[N], any_far = false;
@@ -149,7 +153,7 @@ __device__ __forceinline__ void ndtri_n(const double (&p)[N], double (&out)[N]) 
   if (__builtin_expect(any_far, 0)) {
 #pragma unroll
     for (int i = 0; i < N; ++i)
-      if (far[i]) out[i] = ndtri_dev(p[i]);
+      if (far[i]) out[i] = ndtri_far(p[i]);
   }
 }
 
@@ -218,7 +222,7 @@ __device__ __forceinline__ void prior_to_lds(const ProblemDev& P, const double (
     for (int i = 0; i < N; ++i) sv[i * 64 + lane] = u[i];
 #pragma unroll 1
     for (int i = 0; i < N; ++i)
-      sv[i * 64 + lane] = (FULL || i < n) ? mu + sg * ndtri_dev(sv[i * 64 + lane]) : 0.0;
+      sv[i * 64 + lane] = (FULL || i < n) ? mu + sg * ndtri_far(sv[i * 64 + lane]) : 0.0;  // (a call: see ndtri_far)
   } else {
 #pragma unroll
     for (int i = 0; i < N; ++i) sv[i * 64 + lane] = (FULL || i < n) ? u[i] : 0.0;

@@ -658,10 +658,22 @@ __device__ __forceinline__ double loglike_quad(const ProblemDev& P, int n, int t
 
 template <int NR, int KIND>
 __device__ __forceinline__ void prior_quad(const ProblemDev& P, int n, int t, const double (&u)[NR], double (&v)[NR]) {
-  // (PRIOR_NORMAL is not built here: ocml's erfcinv next to the resident fragments spills ~160 VGPRs;
-  // rwalk_launch_runs keeps such problems on the lane-per-walker kernel)
+  // (PRIOR_NORMAL: ndtri behind a call -- inlined, ocml's erfcinv next to the resident fragments spilled ~160
+  // VGPRs and kept such problems on the lane-per-walker kernel until round 4)
   const int pid = prior_of<KIND>(P);
-  if (pid == PRIOR_AFFINE) {
+  if (pid == PRIOR_NORMAL) {
+    cdptr pp = as_const(P.prior_par);
+    const double mu = pp[0], sg = pp[1];
+#pragma unroll 1
+    for (int r = 0; r < NR; ++r) {
+      double x = 0.5;
+#pragma unroll
+      for (int q = 0; q < NR; ++q) x = q == r ? u[q] : x;
+      const double o = (r < NR - 1 || 4 * r + t < n) ? mu + sg * ndtri_far(x) : 0.0;
+#pragma unroll
+      for (int q = 0; q < NR; ++q) v[q] = q == r ? o : v[q];
+    }
+  } else if (pid == PRIOR_AFFINE) {
     cdptr pp = as_const(P.prior_par);
     const double a = pp[0], b = pp[1];
 #pragma unroll

@@ -137,6 +137,28 @@ __device__ __forceinline__ double wide_logl(const ProblemDev& P, int D, const do
   }
 }
 
+// F behind a call (round 4).  Inlined into wide_walk_kernel the evaluation -- four AS 241 `ndtri` chains per lane for
+// the Normal prior, every fused likelihood -- shares one register allocation with the slice state machine, the
+// generator and the frame product's sixteen requests in flight: 922 VGPRs spilled, ~900 scratch accesses inside the
+// evaluation itself, i.e. in the hot loop (1 492 B of scratch per lane).  Behind a non-inlined call it
+// gets an allocation of its own (the sort_slots lesson of ns.hip) and the caller keeps its state in callee-saved
+// registers.  The arguments are scalars, not the kernel's argument block: a struct whose address escapes into a
+// real call lives on every lane's stack.
+__device__ __attribute__((noinline)) double wide_logl_call(int like_id, int prior_id, const double* like_par,
+                                                           const double* prior_par, int D, const double* su,
+                                                           double* sv, int lane) {
+  ProblemDev P;
+  P.like_id = like_id;
+  P.prior_id = prior_id;
+  P.ndim = D;
+  P.like_par = like_par;
+  P.prior_par = prior_par;
+  P.prec_t = nullptr;
+  return wide_logl(P, D, su, sv, lane);
+}
+#define WIDE_F(prob, D, su, sv, lane) \
+  wide_logl_call((prob).like_id, (prob).prior_id, (prob).like_par, (prob).prior_par, (D), (su), (sv), (lane))
+
 struct WideWalkArgs {
   ProblemDev prob;
   int k, ndim, ncdim, m, iters;  // iters = walks or slices
@@ -325,7 +347,7 @@ __global__ void __launch_bounds__(64 * kWalkMaxWaves, 2) wide_walk_kernel(WideWa
     for (;;) {
       g.doubles(su, D, lane);
       lds_sync();
-      ll = wide_logl(a.prob, D, su, sv, lane);
+      ll = WIDE_F(a.prob, D, su, sv, lane);
       ++ncall;
       lds_sync();
       if (ll > loglstar) break;
@@ -387,7 +409,7 @@ __global__ void __launch_bounds__(64 * kWalkMaxWaves, 2) wide_walk_kernel(WideWa
         ++nrej;
         continue;
       }
-      const double ll = wide_logl(a.prob, D, sp, sv, lane);
+      const double ll = WIDE_F(a.prob, D, sp, sv, lane);
       if (ll > loglstar) {
         for (int i = lane; i < D; i += 64) su[i] = sp[i];
         logl_cur = ll;
@@ -397,7 +419,7 @@ __global__ void __launch_bounds__(64 * kWalkMaxWaves, 2) wide_walk_kernel(WideWa
       }
       lds_sync();
     }
-    const double ll0 = wide_logl(a.prob, D, su, sv, lane);
+    const double ll0 = WIDE_F(a.prob, D, su, sv, lane);
     if (nacc == 0) logl_cur = ll0;
     lds_sync();
     if (ghost) return;
@@ -505,7 +527,7 @@ __global__ void __launch_bounds__(64 * kWalkMaxWaves, 2) wide_walk_kernel(WideWa
         ++ncall;
         double f = -INFINITY;
         if (lo > 0.0 && hi < 1.0) {
-          f = wide_logl(a.prob, D, sp, sv, lane);
+          f = WIDE_F(a.prob, D, sp, sv, lane);
           lds_sync();
         }
         cy_f += clock64() - cf_;
@@ -668,7 +690,7 @@ __global__ void __launch_bounds__(64 * kWalkMaxWaves, 2) wide_walk_kernel(WideWa
   if (a.dbg && w == 0 && lane == 0)
     printf("wide_walk wave 0: total %lld | normals %lld | frame product %lld (GEMM itself %lld) | F %lld (ncall %d)\n",
            (long long)(clock64() - cy_t0), cy_n, cy_m, cy_g, cy_f, ncall);
-  (void)wide_logl(a.prob, D, su, sv, lane);  // v of the returned point
+  (void)WIDE_F(a.prob, D, su, sv, lane);  // v of the returned point
   lds_sync();
   if (ghost) return;
   for (int i = lane; i < D; i += 64) {

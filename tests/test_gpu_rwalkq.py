@@ -31,7 +31,10 @@ def make_case(prob, nwalk, seed, shrink=0.5):
     """tests/inputs.walker_case for an arbitrary problem object."""
     d = prob.ndim
     rng = np.random.default_rng(seed)
-    if prob.like_id == problems.LIKE_EGGBOX:
+    if prob.prior_id == problems.PRIOR_NORMAL:
+        u0 = 0.5 + 0.08 * rng.standard_normal((nwalk, d))
+        spread = 0.08
+    elif prob.like_id == problems.LIKE_EGGBOX:
         u0 = 0.5 + 0.004 * rng.standard_normal((nwalk, d))
         spread = 0.004
     else:
@@ -52,11 +55,13 @@ def the_problem(kind, d):
         return problems.gauss_corr(d, 0.4, 5.0, f"corr{d}")
     if kind == "iid":
         return problems.gauss_iid(d, 6.0, f"iid{d}")
+    if kind == "normal":  # Normal prior (ndtri), iid Normal likelihood: the C4 family (round 4: built here too)
+        return problems.gauss_normal_prior(d, f"nprior{d}")
     return problems.eggbox(d, name=f"egg{d}")
 
 
 CASES = [("prec", 9), ("prec", 12), ("prec", 16), ("prec", 17), ("prec", 20), ("prec", 25), ("prec", 28),
-         ("prec", 29), ("prec", 32), ("iid", 10), ("iid", 27), ("egg", 9), ("egg", 18)]
+         ("prec", 29), ("prec", 32), ("iid", 10), ("iid", 27), ("egg", 9), ("egg", 18), ("normal", 11), ("normal", 25), ("normal", 30)]
 
 
 @pytest.mark.parametrize("kind,d", CASES)

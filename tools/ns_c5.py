@@ -8,7 +8,7 @@ runs = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 512
 ctx = _lib.Context(0)
 prob = inputs.problem("C2")
-for rep in range(4):
+for rep in range(1 if (len(sys.argv) > 3 and sys.argv[3] == "once") else 4):
     t = time.perf_counter()
     r = ctx.ns_ensemble(prob, runs, 2000, K, walks=45, bound='multi', entropy=[21 + rep // 2], rebuild_sync=bool(rep % 2))
     dt = time.perf_counter() - t

@@ -29,6 +29,8 @@ out = {"command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output
        "kernels": {}}
 # the walk kernel of the bench's launch shape: four lanes per walker at the gate queue (round 3), else one per lane
 rw = [k for k in fetch if k.startswith("rwalkq_kernel<7")] or [k for k in fetch if k.startswith("rwalk_kernel<25, true, 1")]
+# round 4: a walk launch = the generator pass + the walk kernel
+ig = [k for k in fetch if k.startswith("itemgen_kernel")]
 steps = len(fetch.get(rw[0], [])) if rw else 1
 for name in sorted(set(fetch) | set(write)):
     fk = sum(v for _, v in fetch.get(name, []))
@@ -41,6 +43,9 @@ for name in sorted(set(fetch) | set(write)):
 rb = [k for k in out["kernels"] if k.split("<")[0] in ("k_root_parts", "k_split", "k_ell", "k_finish", "k_out_eig",
                                                       "k_root_eig", "k_tree")]
 out["rwalk_launches_profiled"] = steps
+if rw:
+    out["rwalk_launch_traffic_bytes"] = sum(out["kernels"][k]["traffic_bytes_per_launch"] for k in rw[:1] + ig[:1])
+    out["rwalk_launch_kernels"] = rw[:1] + ig[:1]
 nrb = out["kernels"].get("k_root_parts", {}).get("launches", 0)
 out["rebuild_pipelines_profiled"] = nrb
 # one pipeline = k_root_parts (+ k_root_eig on the side stream) + levels x (k_split, k_ell<false>) + k_tree + k_finish + k_out_eig
