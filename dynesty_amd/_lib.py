@@ -113,6 +113,7 @@ SIGNATURES = {
     "dh_slice_feed": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _dbl, _vp, _vp, _i, _vp,
                            _vp, _vp]),
     "dh_set_rwalk_form": (_i, [_vp, _i]),
+    "dh_ns_set_option": (_i, [_vp, _i, _dbl]),
     "dh_set_rwalk_items": (_i, [_vp, _i, C.c_longlong]),
     "dh_slice_batch_philox": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _dbl, _dbl, _i, _i, _u64, _u64, _u64,
                                    _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -795,8 +796,14 @@ class Context:
                     bound='multi', dlogz=0.01, enlarge=None, entropy=(21,),
                     first_run=0, max_fills=0, max_iter=400000,
                     want_dead_logl=False, sample='rwalk', slices=None,
-                    rebuild_sync=False, want_samples=False, rng='pcg64', bootstrap=None, rebuild_every=0):
+                    rebuild_sync=False, want_samples=False, rng='pcg64', bootstrap=None, rebuild_every=0,
+                    update_interval=None, first_update=None, maxiter=None, maxcall=None, logl_max=None,
+                    add_live=True):
         """Device-resident ensemble of static NS runs (dh_ns_ensemble).
+
+        update_interval / first_update (NestedSampler, dynesty.py:213-234: a float update_interval is a multiple of
+        nlive, an int a number of calls; first_update = dict(min_ncall=..., min_eff=...)) and maxiter / maxcall /
+        logl_max / add_live (run_nested, sampler.py:1214-1300) as the reference takes them; None = its default.
 
         rebuild_every=n: bounds are built every n-th fill and runs that become due in
         between wait -- per-run results unchanged (bit-identical with PCG64 streams),
@@ -844,6 +851,19 @@ class Context:
         pnc = np.empty((runs, max_iter), dtype=np.int32) if want_samples else None
         lit = np.empty((runs, nlive), dtype=np.int32) if want_samples else None
         nf = C.c_int64(0)
+        nan = float('nan')
+        if update_interval is not None:
+            # dynesty.py:213-234: a float is a multiple of nlive, an int a number of calls
+            update_interval = max(1, round(update_interval * nlive)) if isinstance(update_interval, float) \
+                else int(update_interval)
+        fu = first_update or {}
+        opts = [nan if update_interval is None else float(update_interval),
+                float(fu['min_ncall']) if 'min_ncall' in fu else nan,
+                float(fu['min_eff']) if 'min_eff' in fu else nan,
+                nan if maxiter is None else float(maxiter), nan if maxcall is None else float(maxcall),
+                nan if logl_max is None else float(logl_max), nan if add_live else 0.0]
+        for key, val in enumerate(opts):
+            self._check(self.lib.dh_ns_set_option(self.handle, key, val))
         self._check(self.lib.dh_ns_ensemble(
             self.handle, self.problem(prob), int(runs), int(nlive), nd,
             int(queue_size), kind + ((1 if kind == 6 else 3) if rng == 'philox' else 0), int(walks),

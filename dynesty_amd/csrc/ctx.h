@@ -70,6 +70,9 @@ struct dh_ctx {
   // one walker per lane, 1 = one walker per lane always, 2 = four lanes always (PCG64 streams, ndim <= 32)
   int cube_form = 0;
   int num_cu = 256;  // hipDeviceProp_t::multiProcessorCount
+  // options of the resident run loop (dh_ns_set_option, keys DH_NS_OPT_* of dynhip.h); NaN = the reference's default
+  double ns_opt[8] = {__builtin_nan(""), __builtin_nan(""), __builtin_nan(""), __builtin_nan(""),
+                      __builtin_nan(""), __builtin_nan(""), __builtin_nan(""), __builtin_nan("")};
   // rwalk, four lanes per walker: the walkers' PCG64 item streams written out by a generator pass ahead of the walk
   // (walkq.hip: itemgen_kernel; env DH_RWALK_ITEMS=0 keeps the generator inside the walk kernel).  Grow-only
   // buffer, launches larger than the budget go in chunks of walkers

@@ -23,6 +23,8 @@
 
 #include <vector>
 
+#include <cmath>
+
 #include "ctx.h"
 #include "rng_pcg64.h"
 
@@ -56,6 +58,11 @@ struct NsArgs {
   long long cap;  // dead-point capacity per run
   double dlogz, enlarge_log, facc, first_eff;
   long long first_ncall, update_interval;
+  // run_nested's other stopping rules (sampler.py:1070-1093; dh_ns_set_option): maxiter / maxcall < 0 = none,
+  // logl_max = +inf = none; add_live = 0: the record is the dead points' running evidence (no final live points)
+  long long maxiter, maxcall;
+  double logl_max;
+  int add_live;
   int store_samples;
   long long* prof;   // optional (DH_NS_PROF=1): cycle counters of ns_consume's phases, run 0
   int rebuild_sync;  // 1: all bound-mode runs rebuild whenever any run is due (see ns_prepare)
@@ -1077,7 +1084,7 @@ __global__ void __launch_bounds__(kT) ns_consume(NsArgs a) {
     }
     __syncthreads();
   }
-  const long long it0 = r.it, carry0 = r.nc_carry;
+  const long long it0 = r.it, carry0 = r.nc_carry, ncall0 = r.ncall;
   const double logvol0 = r.logvol, logz0 = r.logz, h0 = r.h, lmax0 = r.lmax, dead_prev0 = r.dead_prev;
   const double dlv = log(((double)N + 1.0) / (double)N);
   const double ldv_c = log(0.5 * expm1(dlv));  // ln(dX_e / X_e) of the trapezoid rule
@@ -1261,7 +1268,16 @@ __global__ void __launch_bounds__(kT) ns_consume(NsArgs a) {
       lw[i] = M + log(sbefore + lw[i]);  // ln Z after death e
       nl[i] = fmax(pm, nl[i]);           // lmax after death e
       const double dz = logaddexp_dev(0.0, nl[i] + lvv[i] - lw[i]);
-      if (dz < a.dlogz && e < mystop) mystop = e;
+      // the reference tests at the top of the NEXT iteration, with the state this death leaves behind:
+      // delta ln Z < dlogz, the last dead point above logl_max, its loop counter it = it0 + e + 1 > maxiter,
+      // the calls spent so far > maxcall (sampler.py:1070-1093)
+      bool stop = dz < a.dlogz || dcur[e] > a.logl_max || (a.maxiter >= 0 && it0 + e + 1 > a.maxiter);
+      if (a.maxcall >= 0 && !stop) {  // (rarely asked for: a plain sum over the entries popped up to this death)
+        long long cum = ncall0;
+        for (int j = 0; j <= dj[e]; ++j) cum += qc[j];
+        stop = cum > a.maxcall;
+      }
+      if (stop && e < mystop) mystop = e;
     }
   }
   if (mystop != 0x7fffffff) atomicMin(&misc[3], mystop);
@@ -1548,6 +1564,23 @@ __device__ __forceinline__ double block_excl_scan(double v, double ident, double
 __global__ void __launch_bounds__(kT) ns_finish(NsArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int run = blockIdx.x, t = threadIdx.x, N = a.nlive;
+  if (!a.add_live) {
+    // run_nested(add_live=False): the results are the loop's running integrals (progress_integration's values after
+    // the last death), the live points stay out (sampler.py:1319-1341)
+    if (t == 0) {
+      const NsRun& r = a.st[run];
+      double* rec = a.records + (size_t)run * 8;
+      rec[0] = r.logz;
+      rec[1] = sqrt(fabs(r.logzvar));
+      rec[2] = (double)r.it;
+      rec[3] = (double)r.ncall;
+      rec[4] = r.h;
+      rec[5] = (double)r.nbound;
+      rec[6] = (double)(r.mode == MODE_DONE ? 0 : (r.mode == MODE_FAILED ? -1 : 1));
+      rec[7] = 100.0 * (double)r.it / (double)r.ncall;
+    }
+    return;
+  }
   // the final live log-likelihoods, ascending: the slots sorted by (value, slot) with the register network of
   // ns_consume, then the values in that order (the integration below does not care which slot a value came from)
   int P = 1;
@@ -1696,6 +1729,9 @@ int dh_ns_consume(dh_ctx* ctx, int runs, int nlive, int queue_size, double dlogz
   a.K = K;
   a.walks = 1;
   a.cap = K;
+  a.maxiter = a.maxcall = -1;
+  a.logl_max = INFINITY;
+  a.add_live = 1;
   a.dlogz = dlogz;
   a.dead_rel = 1;
   arena_reset(ctx);
@@ -1781,6 +1817,13 @@ int dh_ns_consume(dh_ctx* ctx, int runs, int nlive, int queue_size, double dlogz
   return DH_OK;
 }
 
+int dh_ns_set_option(dh_ctx* ctx, int key, double value) {
+  DH_CHECK_CTX(ctx);
+  if (key < 0 || key >= DH_NS_OPT_COUNT) return fail(ctx, DH_ERR_ARG, "ns option %d", key);
+  ctx->ns_opt[key] = value;
+  return DH_OK;
+}
+
 int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int queue_size, int sampler,
                    int walks, int bound_multi, int rebuild_sync, double dlogz, double enlarge, int64_t max_fills,
                    int64_t max_iter,
@@ -1838,6 +1881,27 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
   // update_bound_interval_ratio (internal_samplers.py:495-502, 581-588, 737-744) * nlive
   // (UniformBoundSampler keeps the base class's ratio 1, internal_samplers.py:88-94)
   a.update_interval = (long long)(sampler == 3 ? 1 : sampler == 2 ? walks * D : walks) * N;
+  // the sampler's / run_nested's options a caller has set (dh_ns_set_option; NaN = the reference's default above)
+  a.maxiter = a.maxcall = -1;
+  a.logl_max = INFINITY;
+  a.add_live = 1;
+  {
+    const double* o = ctx->ns_opt;
+    if (!std::isnan(o[DH_NS_OPT_UPDATE_INTERVAL])) {
+      // update_interval as dynesty takes it (dynesty.py:213-234): a float is a multiple of nlive, an int a number of calls
+      const double v = o[DH_NS_OPT_UPDATE_INTERVAL];
+      a.update_interval = v > 0.0 ? (long long)llround(v) : a.update_interval;
+      if (a.update_interval < 1) a.update_interval = 1;
+    }
+    if (!std::isnan(o[DH_NS_OPT_FIRST_MIN_NCALL])) a.first_ncall = (long long)llround(o[DH_NS_OPT_FIRST_MIN_NCALL]);
+    if (!std::isnan(o[DH_NS_OPT_FIRST_MIN_EFF])) a.first_eff = o[DH_NS_OPT_FIRST_MIN_EFF];
+    if (!std::isnan(o[DH_NS_OPT_MAXITER])) a.maxiter = (long long)llround(o[DH_NS_OPT_MAXITER]);
+    if (!std::isnan(o[DH_NS_OPT_MAXCALL])) a.maxcall = (long long)llround(o[DH_NS_OPT_MAXCALL]);
+    if (!std::isnan(o[DH_NS_OPT_LOGL_MAX])) a.logl_max = o[DH_NS_OPT_LOGL_MAX];
+    if (!std::isnan(o[DH_NS_OPT_ADD_LIVE])) a.add_live = o[DH_NS_OPT_ADD_LIVE] != 0.0 ? 1 : 0;
+    if (a.maxcall >= 0 && a.maxcall < N)
+      return fail(ctx, DH_ERR_ARG, "ns_ensemble: maxcall %lld below the %d calls of the initial live points", a.maxcall, N);
+  }
   a.bootstrap = bootstrap;
   a.store_samples = dead_u_out ? 1 : 0;
   a.rebuild_sync = rebuild_sync ? 1 : 0;

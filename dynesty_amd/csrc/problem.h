@@ -142,6 +142,40 @@ __device__ __forceinline__ double ndtri_as241_core(double p, bool* far) {
 // kernel that merely might meet such a coordinate)
 __device__ __attribute__((noinline)) double ndtri_far(double p) { return ndtri_dev(p); }
 
+// The two halves of AS 241 on their own, for callers that route the coordinates themselves (wide.hip): the central
+// rational approximation (|p - 1/2| <= 0.425: 85 % of the coordinates of a draw from the prior) is a third of the
+// work of the tail's (logarithm, square root, a second pair of polynomials).  Same expressions as
+// ndtri_as241_core, term for term: a coordinate gets the same bits by either route.
+__device__ __forceinline__ double ndtri_as241_central(double p) {
+  const double q = p - 0.5;
+  const double r = 0.180625 - q * q;
+  const double cn =
+      (((((((r * 2509.0809287301226727 + 33430.575583588128105) * r + 67265.770927008700853) * r +
+           45921.953931549871457) * r + 13731.693765509461125) * r + 1971.5909503065514427) * r +
+        133.14166789178437745) * r + 3.387132872796366608);
+  const double cd =
+      (((((((r * 5226.495278852545925 + 28729.085735721942674) * r + 39307.89580009271061) * r +
+           21213.794301586595867) * r + 5394.1960214247511077) * r + 687.1870074920579083) * r +
+        42.313330701600911252) * r + 1.0);
+  return q * cn / cd;
+}
+__device__ __forceinline__ double ndtri_as241_tail(double p, bool* far) {
+  const double q = p - 0.5;
+  const double pm = q < 0.0 ? p : 1.0 - p;
+  const double rt = sqrt(-log_pos(pm));
+  *far = !(rt <= 5.0) || !(pm > 0.0);
+  const double r = rt - 1.6;
+  const double tn =
+      (((((((r * 7.7454501427834140764e-4 + .0227238449892691845833) * r + .24178072517745061177) * r +
+           1.27045825245236838258) * r + 3.64784832476320460504) * r + 5.7694972214606914055) * r +
+        4.6303378461565452959) * r + 1.42343711074968357734);
+  const double td =
+      (((((((r * 1.05075007164441684324e-9 + 5.475938084995344946e-4) * r + .0151986665636164571966) * r +
+           .14810397642748007459) * r + .68976733498510000455) * r + 1.6763848301838038494) * r +
+        2.05319162663775882187) * r + 1.0);
+  return (q < 0.0 ? -tn : tn) / td;
+}
+
 template <int N>
 __device__ __forceinline__ void ndtri_n(const double (&p)[N], double (&out)[N]) {
   bool far[N], any_far = false;

@@ -92,11 +92,61 @@ __device__ __forceinline__ double wave_max(double v) {
 // prior_transform + loglikelihood for one walker spread over a wave:
 // lane owns dims lane, lane+64, ...; u in LDS row `su` (D), v written to `sv`.
 // For LIKE_GAUSS_PREC the precision matrix is read from global memory.
-__device__ __forceinline__ double wide_logl(const ProblemDev& P, int D, const double* su, double* sv, int lane) {
+// tails: nullptr, or 256 doubles of LDS scratch of this wavefront -- then the Normal prior's ndtri routes the
+// coordinates (round 4): the central approximation for all of them, the tail's (three times the work: logarithm,
+// square root, second pair of polynomials) only for the ~15 % that need it, compacted over the lanes -- about one
+// pass of the tail code for a 200-D walker instead of the four that evaluating both halves for every coordinate
+// costs.  The same expressions either way: the same bits.
+__device__ __forceinline__ double wide_logl(const ProblemDev& P, int D, const double* su, double* sv, int lane,
+                                            double* tails = nullptr) {
   // prior
   if (P.prior_id == PRIOR_AFFINE) {
     const double a = P.prior_par[0], b = P.prior_par[1];
     for (int i = lane; i < D; i += 64) sv[i] = a * (2.0 * su[i] - 1.0) + b;
+  } else if (P.prior_id == PRIOR_NORMAL && tails) {
+    const double mu = P.prior_par[0], sg = P.prior_par[1];
+    for (int base_i = 0; base_i < D; base_i += 256) {  // (wave-uniform trip count: the ballots need every lane)
+      const int i0 = base_i + lane;
+      double p[4];
+      int slot[4];
+      int ntail = 0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = i0 + 64 * q;
+        const bool valid = i < D;
+        p[q] = valid ? su[i] : 0.5;
+        const bool tl = valid && !(fabs(p[q] - 0.5) <= 0.425);
+        const unsigned long long m = __ballot(tl);
+        slot[q] = tl ? ntail + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u)) : -1;
+        ntail += (int)__popcll(m);
+        if (tl) tails[slot[q]] = p[q];
+      }
+      double o[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) o[q] = ndtri_as241_central(p[q]);
+      if (ntail > 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        for (int t0 = 0; t0 < ntail; t0 += 64) {
+          const int ti = t0 + lane;
+          const double pt = ti < ntail ? tails[ti] : 0.25;
+          bool far;
+          double r = ndtri_as241_tail(pt, &far);
+          if (far) r = ndtri_far(pt);
+          if (ti < ntail) tails[ti] = r;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (slot[q] >= 0) o[q] = tails[slot[q]];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (i0 + 64 * q < D) sv[i0 + 64 * q] = mu + sg * o[q];
+    }
   } else if (P.prior_id == PRIOR_NORMAL) {
     const double mu = P.prior_par[0], sg = P.prior_par[1];
     for (int i0 = lane; i0 < D; i0 += 256) {  // 4 coordinates per lane at a time: independent chains
@@ -146,7 +196,7 @@ __device__ __forceinline__ double wide_logl(const ProblemDev& P, int D, const do
 // real call lives on every lane's stack.
 __device__ __attribute__((noinline)) double wide_logl_call(int like_id, int prior_id, const double* like_par,
                                                            const double* prior_par, int D, const double* su,
-                                                           double* sv, int lane) {
+                                                           double* sv, int lane, double* tails = nullptr) {
   ProblemDev P;
   P.like_id = like_id;
   P.prior_id = prior_id;
@@ -154,10 +204,86 @@ __device__ __attribute__((noinline)) double wide_logl_call(int like_id, int prio
   P.like_par = like_par;
   P.prior_par = prior_par;
   P.prec_t = nullptr;
-  return wide_logl(P, D, su, sv, lane);
+  return wide_logl(P, D, su, sv, lane, tails);
 }
+#ifdef DH_WIDE_F_CALL
 #define WIDE_F(prob, D, su, sv, lane) \
-  wide_logl_call((prob).like_id, (prob).prior_id, (prob).like_par, (prob).prior_par, (D), (su), (sv), (lane))
+  wide_logl_call((prob).like_id, (prob).prior_id, (prob).like_par, (prob).prior_par, (D), (su), (sv), (lane), wtails)
+#else
+#define WIDE_F(prob, D, su, sv, lane) wide_logl((prob), (D), (su), (sv), (lane), wtails)
+#endif
+
+// F(x) = logl(ptform(u + x * dir)) of the slice samplers from REGISTERS (round 4): for the iid Normal likelihood
+// and D <= 256 a lane keeps its (at most four) coordinates of u and of the direction in registers for the whole
+// slice, so an evaluation touches LDS only for ndtri's compacted tails -- no proposal vector written and read back,
+// no v vector, no fences around them -- and needs one ballot and one wave reduction (the cube check, the sum of
+// squares) instead of three reductions.  Same arithmetic per coordinate as wide_logl's: u' = fma(x, d, u),
+// the same prior expressions, v^2 summed per lane over its coordinates in index order and then across the wave
+// (wide_logl sums lane-wise in the same order), so a walker's path is the same to the last bit.
+// Returns -inf outside the unit cube (generic_slice_step's unitcheck, internal_samplers.py:1075-1100).
+__device__ __forceinline__ double wide_F_regs(const ProblemDev& P, int D, const double (&ur)[4], const double (&dr)[4],
+                                              double x, int lane, double* tails) {
+  double un[4];
+  bool inside = true;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    un[q] = fma(x, dr[q], ur[q]);
+    inside = inside && (!(lane + 64 * q < D) || (un[q] > 0.0 && un[q] < 1.0));
+  }
+  if (!__all(inside)) return -INFINITY;  // one ballot instead of the minimum and the maximum over the wave
+  double v[4];
+  if (P.prior_id == PRIOR_AFFINE) {
+    const double a = P.prior_par[0], b = P.prior_par[1];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = a * (2.0 * un[q] - 1.0) + b;
+  } else if (P.prior_id == PRIOR_NORMAL) {
+    const double mu = P.prior_par[0], sg = P.prior_par[1];
+    int slot[4], ntail = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const bool valid = lane + 64 * q < D;
+      const double p = valid ? un[q] : 0.5;
+      un[q] = p;
+      const bool tl = valid && !(fabs(p - 0.5) <= 0.425);
+      const unsigned long long m = __ballot(tl);
+      slot[q] = tl ? ntail + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u)) : -1;
+      ntail += (int)__popcll(m);
+      if (tl) tails[slot[q]] = p;
+    }
+    double o[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) o[q] = ndtri_as241_central(un[q]);
+    if (ntail > 0) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      for (int t0 = 0; t0 < ntail; t0 += 64) {
+        const int ti = t0 + lane;
+        const double pt = ti < ntail ? tails[ti] : 0.25;
+        bool far;
+        double r = ndtri_as241_tail(pt, &far);
+        if (far) r = ndtri_far(pt);
+        if (ti < ntail) tails[ti] = r;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (slot[q] >= 0) o[q] = tails[slot[q]];
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = mu + sg * o[q];
+  } else {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = un[q];
+  }
+  double s = 0.0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    if (lane + 64 * q < D) s = fma(v[q], v[q], s);
+  return P.like_par[0] - 0.5 * wave_sum(s);
+}
 
 struct WideWalkArgs {
   ProblemDev prob;
@@ -307,8 +433,10 @@ __global__ void __launch_bounds__(64 * kWalkMaxWaves, 2) wide_walk_kernel(WideWa
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ ZigLds zig;
   __shared__ int sframe[16];
+  __shared__ double tails_all[kWalkMaxWaves][256];  // ndtri's tail coordinates of a wavefront, compacted (wide_logl)
   if constexpr (RNG == RNG_PCG64) zig_stage(&zig, a.zki, a.zwi, a.zfi);
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wpw = blockDim.x >> 6;
+  double* wtails = tails_all[wv];
   const int wq = blockIdx.x * wpw + wv;
   // ghost = barriers only, no results: the padding wavefronts of the last workgroup, and (ensemble form) the
   // walkers of a run that is not in the mode this launch serves
@@ -503,6 +631,18 @@ __global__ void __launch_bounds__(64 * kWalkMaxWaves, 2) wide_walk_kernel(WideWa
       // walk2.hip's slice_kernel; control flow is wave-uniform here).  Eight inlined copies of F --
       // each with the prior and likelihood code -- made the kernel 570 KB of instructions: every
       // wavefront missed in the instruction cache all the time.
+      // iid Normal likelihood, D <= 256: the walker's point and direction stay in registers for the slice
+      const bool regF = a.prob.like_id == LIKE_GAUSS_IID && D <= 256 &&
+                        (a.prob.prior_id == PRIOR_NORMAL || a.prob.prior_id == PRIOR_AFFINE || a.prob.prior_id == PRIOR_IDENTITY);
+      double ureg[4] = {0.0, 0.0, 0.0, 0.0}, dreg[4] = {0.0, 0.0, 0.0, 0.0};
+      if (regF) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (lane + 64 * q < D) {
+            ureg[q] = su[lane + 64 * q];
+            dreg[q] = sd[lane + 64 * q];
+          }
+      }
       double left = -rand0, right = 1.0 - rand0;
       double f_l = 0.0, f_r = 0.0;
       double Lw = 0.0, Rw = 0.0, fLw = 0.0, fRw = 0.0;
@@ -514,21 +654,25 @@ __global__ void __launch_bounds__(64 * kWalkMaxWaves, 2) wide_walk_kernel(WideWa
       while (phase != SL_DONE) {
         // F(xq): u_new = u + xq * direction; unitcheck; prior; likelihood
         const long long cf_ = clock64();
-        double lo = 2.0, hi = -1.0;
-        for (int i = lane; i < D; i += 64) {
-          const double un = fma(xq, sd[i], su[i]);
-          sp[i] = un;
-          lo = fmin(lo, un);
-          hi = fmax(hi, un);
-        }
-        lo = wave_min(lo);
-        hi = wave_max(hi);
-        lds_sync();
-        ++ncall;
         double f = -INFINITY;
-        if (lo > 0.0 && hi < 1.0) {
-          f = WIDE_F(a.prob, D, sp, sv, lane);
+        ++ncall;
+        if (regF) {
+          f = wide_F_regs(a.prob, D, ureg, dreg, xq, lane, wtails);
+        } else {
+          double lo = 2.0, hi = -1.0;
+          for (int i = lane; i < D; i += 64) {
+            const double un = fma(xq, sd[i], su[i]);
+            sp[i] = un;
+            lo = fmin(lo, un);
+            hi = fmax(hi, un);
+          }
+          lo = wave_min(lo);
+          hi = wave_max(hi);
           lds_sync();
+          if (lo > 0.0 && hi < 1.0) {
+            f = WIDE_F(a.prob, D, sp, sv, lane);
+            lds_sync();
+          }
         }
         cy_f += clock64() - cf_;
         switch (phase) {

@@ -457,6 +457,34 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim,
                    int32_t* dead_it_out, int32_t* dead_nc_out, int32_t* live_it_out, int bootstrap,
                    int rebuild_every /* bounds are built every n-th fill, runs due in between wait; 0: chosen from the shape */);
 
+/* Options of the resident run loop that the reference takes in NestedSampler(...) / run_nested(...) and that
+ * dh_ns_ensemble otherwise fixes at the reference's defaults.  They are context state: set before a
+ * dh_ns_ensemble call, they hold until set again; value NaN restores the default.
+ *   DH_NS_OPT_UPDATE_INTERVAL   calls between bound updates (dynesty.py:213-234 `update_interval` as a number of calls;
+ *                               a caller holding the ratio form multiplies by nlive); default: the sampler's ratio
+ *                               (1 unif, walks rwalk, slices rslice, slices * ndim slice) * nlive
+ *   DH_NS_OPT_FIRST_MIN_NCALL   first_update['min_ncall'] (sampler.py:625-674), default 2 nlive
+ *   DH_NS_OPT_FIRST_MIN_EFF     first_update['min_eff'] in per cent, default 10
+ *   DH_NS_OPT_MAXITER           run_nested(maxiter): the loop stops once its counter exceeds it, i.e. after maxiter + 1
+ *                               deaths (sampler.py:1076-1083); default none
+ *   DH_NS_OPT_MAXCALL           run_nested(maxcall): stops once the likelihood calls (initial points included)
+ *                               exceed it; default none
+ *   DH_NS_OPT_LOGL_MAX          run_nested(logl_max): stops once the last dead point's ln L exceeds it; default +inf
+ *   DH_NS_OPT_ADD_LIVE          run_nested(add_live): 0 = the record is the dead points' running evidence, the
+ *                               final live points stay out (sampler.py:1319-1341); default 1
+ * A run ended by maxiter / maxcall / logl_max ends normally (status 0), as the reference's does. */
+enum {
+  DH_NS_OPT_UPDATE_INTERVAL = 0,
+  DH_NS_OPT_FIRST_MIN_NCALL = 1,
+  DH_NS_OPT_FIRST_MIN_EFF = 2,
+  DH_NS_OPT_MAXITER = 3,
+  DH_NS_OPT_MAXCALL = 4,
+  DH_NS_OPT_LOGL_MAX = 5,
+  DH_NS_OPT_ADD_LIVE = 6,
+  DH_NS_OPT_COUNT = 7
+};
+int dh_ns_set_option(dh_ctx* ctx, int key, double value);
+
 /* The bootstrap expansion factor on its own (host pointers; what the resident loop runs after a rebuild):
  * for each of `runs` point sets (runs x n x d) the max over `bootstrap` replicas of max(1, largest normalised
  * distance of a left-out point to the replica's Ellipsoid (multi = 0) / nearest of its MultiEllipsoid's ellipsoids
