@@ -437,7 +437,12 @@ __global__ void __launch_bounds__(64 * kWalkMaxWaves, 2) wide_walk_kernel(WideWa
   if constexpr (RNG == RNG_PCG64) zig_stage(&zig, a.zki, a.zwi, a.zfi);
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wpw = blockDim.x >> 6;
   double* wtails = tails_all[wv];
-  const int wq = blockIdx.x * wpw + wv;
+  // XCD-aware workgroup order: workgroups are dealt to the 8 XCDs round-robin, each XCD with an L2 of its own, and
+  // the walkers of a run all read the run's frame (320 KB at D = 200) for every direction.  With the plain order
+  // every XCD reads every run's frame; here XCD x gets a contiguous eighth of the walkers, i.e. two of sixteen runs.
+  const int nblk = gridDim.x;
+  const int bid = (nblk & 7) == 0 ? (int)(blockIdx.x & 7) * (nblk >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  const int wq = bid * wpw + wv;
   // ghost = barriers only, no results: the padding wavefronts of the last workgroup, and (ensemble form) the
   // walkers of a run that is not in the mode this launch serves
   const int w = wq >= a.k ? a.k - 1 : wq;
