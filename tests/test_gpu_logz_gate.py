@@ -234,3 +234,42 @@ def test_odd_shapes_vs_reference_ensembles(ctx, case, rng):
     tol = 0.03 if ref["n"] >= 30 else 0.05  # (the small reference ensembles of the expensive shapes)
     assert abs(r["niter"].mean() / ref["mean_niter"] - 1) < tol, (r["niter"].mean(), ref["mean_niter"])
     assert abs(r["ncall"].mean() / ref["mean_ncall"] - 1) < 2 * tol, (r["ncall"].mean(), ref["mean_ncall"])
+
+
+OPTION_SHAPES = ["opt_update_interval", "opt_first_update", "opt_maxiter", "opt_maxcall", "opt_add_live", "opt_logl_max"]
+
+
+@pytest.mark.parametrize("case", OPTION_SHAPES)
+def test_run_loop_options_vs_reference_ensembles(ctx, case):
+    """the options the reference takes in NestedSampler(update_interval=, first_update=) and
+    run_nested(maxiter=, maxcall=, logl_max=, add_live=) (dynesty.py:213-234, sampler.py:1070-1093, 1214-1341), fixed
+    at their defaults in the resident loop until round 4, each with a non-default value against an ensemble of 32
+    REAL reference runs at the same settings (tools/shape_cases.json, tools/ref_shape_runs.py,
+    tests/golden/shape_logz_ref.json): a float update_interval of 0.6 nlive calls (a bound update every few fills
+    instead of every 33 nlive calls), a late first update (min_ncall 900, min_eff 30 %), maxiter = 700 (exactly 701
+    deaths, as the reference's loop counter has it), maxcall = 30 000, add_live = False (the record is the dead
+    points' running evidence), logl_max = -4."""
+    from dynesty_amd import problems
+    ref = json.load(open(os.path.join(GOLD, "shape_logz_ref.json")))["cases"][case]
+    c = ref["config"]
+    prob = getattr(problems, c["prob"][0])(*c["prob"][1:])
+    kw = {k: c[k] for k in ("walks", "slices", "bootstrap", "enlarge", "update_interval", "first_update", "maxiter",
+                            "maxcall", "logl_max", "add_live") if k in c}
+    runs = 64
+    r = ctx.ns_ensemble(prob, runs, c["nlive"], c["K"], bound=c["bound"], sample=c["sample"], dlogz=c.get("dlogz", 0.5),
+                        entropy=[13, len(case)], **kw)
+    assert (r["status"] == 0).all()
+    lz = r["logz"]
+    se = math.hypot(lz.std(ddof=1) / math.sqrt(runs), ref["se"])
+    assert abs(lz.mean() - ref["mean"]) < 4.0 * se, (lz.mean(), ref["mean"], se)
+    if case == "opt_maxiter":
+        assert (r["niter"] == c["maxiter"] + 1).all(), r["niter"]
+    else:
+        assert abs(r["niter"].mean() / ref["mean_niter"] - 1) < 0.04, (r["niter"].mean(), ref["mean_niter"])
+    assert abs(r["ncall"].mean() / ref["mean_ncall"] - 1) < 0.08, (r["ncall"].mean(), ref["mean_ncall"])
+    if case == "opt_maxcall":
+        # the loop stops at the first death after which the calls exceed maxcall: never more than one fill beyond it
+        assert (r["ncall"] > c["maxcall"] * 0.9).all() and (r["ncall"] < c["maxcall"] + 40 * c["K"] * 10).all()
+    if case in ("opt_update_interval", "opt_first_update"):
+        # bound updates follow the option (the reference counts its initial unit-cube bound as one)
+        assert abs(r["nbound"].mean() / (ref["mean_nbound"] - 1) - 1) < 0.15, (r["nbound"].mean(), ref["mean_nbound"])

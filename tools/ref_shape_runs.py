@@ -22,14 +22,16 @@ c = json.loads(sys.argv[1])
 seed = int(sys.argv[2])
 prob = getattr(problems, c["prob"][0])(*c["prob"][1:])
 kw = dict(nlive=c["nlive"], bound=c["bound"], sample=c["sample"], rstate=np.random.default_rng(seed))
-for k in ("walks", "slices", "bootstrap", "enlarge"):
+for k in ("walks", "slices", "bootstrap", "enlarge", "update_interval", "first_update"):
     if k in c:
         kw[k] = c[k]
+# run_nested's own options (round 4: the resident loop takes them too)
+rkw = {k: c[k] for k in ("maxiter", "maxcall", "logl_max", "add_live") if k in c}
 if c["K"] > 1:
     kw.update(pool=SerialPool(c["K"]), queue_size=c["K"])
 t = time.time()
 s = dynesty.NestedSampler(prob.loglikelihood, prob.prior_transform, prob.ndim, **kw)
-s.run_nested(dlogz=c.get("dlogz", 0.5), print_progress=False)
+s.run_nested(dlogz=c.get("dlogz", 0.5), print_progress=False, **rkw)
 r = s.results
 print(json.dumps(dict(seed=seed, logz=float(r.logz[-1]), err=float(r.logzerr[-1]), niter=int(r.niter), ncall=int(sum(r.ncall)),
                       nbound=int(s.nbound), secs=time.time() - t, truth=prob.logz_truth)), flush=True)
