@@ -110,24 +110,34 @@ def test_c4_device_run_vs_reference_runs(ctx):
         assert abs(r.niter / x["niter"] - 1) < 0.06
 
 
-@pytest.mark.parametrize("K,ref_key,runs", [(128, "K1", 16), (1000, "K1000", 8)])
+def bound2(se_a, se_b):
+    """north_star's +-0.05, or two combined standard errors where the ensembles cannot resolve that (VERDICT round 3
+    item 5: 3 sigma was all the nine serial reference runs of round 3 allowed; there are 25+ now)."""
+    return max(0.05, 2.0 * math.sqrt(se_a * se_a + se_b * se_b))
+
+
+@pytest.mark.parametrize("K,ref_key,runs", [(128, "K1", 32), (1000, "K1000", 8)])
 def test_c4_device_resident_loop_vs_reference_ensembles(ctx, K, ref_key, runs):
     """BASELINE C4 through the device-resident loop (dh_ns_ensemble at 200-D: wave-per-walker rslice kernels with
     per-run thresholds, masked multi-workgroup Ellipsoid.update) against the converged ensembles of the real reference
     (tests/golden/c4_logz_ref.json: 9 serial runs -250.820 +- 0.021, 9 runs with SerialPool(1000) -250.960 +- 0.028;
     45-70 minutes per run): at the reference's own queue size, and -- with the small queue the bench's C4 leg uses --
     against the SERIAL ensemble (ln Z drifts down with the queue size in the reference exactly as on the device:
-    device 128 / 256 / 512 / 1000 -> -250.874 / -250.890 / -250.928 / -250.979, 16 runs each)."""
+    device 128 / 256 / 512 / 1000 -> -250.874 / -250.890 / -250.928 / -250.979, 16 runs each).
+    Round 4: the serial reference ensemble has 25+ runs (-250.832 +- 0.016; 57 min each), the device at the bench's
+    K = 128 gives -250.864 +- 0.009 with 64 runs (K = 16 / 32 / 64: -250.854 / -250.847 / -250.855: flat below 128):
+    0.032 apart, inside north_star's +-0.05 at the means; the gate is max(0.05, 2 sigma) there."""
     from dynesty_amd import problems
     ref = json.load(open(os.path.join(GOLD, "c4_logz_ref.json")))["ensembles"][ref_key]
-    assert ref["n"] >= 4
+    assert ref["n"] >= (20 if ref_key == "K1" else 4)
     prob = problems.gauss_normal_prior(200, "C4")
     r = ctx.ns_ensemble(prob, runs, 4000, K, bound='single', sample='rslice', slices=203, entropy=[21, K], dlogz=0.01,
                         max_iter=250000)
     assert (r["status"] == 0).all()
     lz = r["logz"]
     mean, se = lz.mean(), lz.std(ddof=1) / math.sqrt(runs)
-    assert abs(mean - ref["mean"]) < bound(se, ref["se"]), (mean, se, ref["mean"], ref["se"])
+    gate = bound2 if ref_key == "K1" else bound
+    assert abs(mean - ref["mean"]) < gate(se, ref["se"]), (mean, se, ref["mean"], ref["se"])
     assert abs(r["logzerr"].mean() - ref["mean_logzerr"]) < 0.005
     assert abs(r["niter"].mean() / ref["mean_niter"] - 1) < 0.03
     if ref["K"] == K:
