@@ -548,7 +548,8 @@ def main():
         full = {"what": f"the same bound-update interval as ONE launch of {runs} x {nlive} walkers after one "
                         f"rebuild (queue size = nlive; ln Z at this queue size is biased by +0.2 in the "
                         f"reference and on the device alike, tests/test_gpu_logz_gate.py)",
-                "ms": trb + twk, "rwalk_kernel_ms": twk, "kernel": "rwalk_kernel<25,true,PREC_AFFINE> (one walker per lane)",
+                "ms": trb + twk, "rwalk_kernel_ms": twk,
+                "kernel": "itemgen_kernel + rwalkq_kernel<7,PREC_AFFINE,ITEMS> (the form no longer depends on the launch size)",
                 "proposals_per_s": world * k * args.walks / ((trb + twk) * 1e-3),
                 "proposals_per_s_rwalk_kernel_only": world * k * args.walks / (twk * 1e-3),
                 "hbm_frac_algorithmic": k * args.walks * 8 * (2 * d + 1) / (twk * 1e-3) / 1e9 / HBM_PEAK_GBS}
@@ -564,6 +565,27 @@ def main():
               "accept_frac": float(wq["accept"][:runs * kq].sum() / props_per_launch),
               "at_queue_nlive": {"rwalk_kernel_ms": twk2, "step_ms": trb2 + twk2,
                                  "proposals_per_s_step": world * k * args.walks / ((trb2 + twk2) * 1e-3)}}
+
+    # saturation: the same step with 32 / 64 / 128 / 256 runs per GPU -- untimed leg
+    sweep = None
+    if not args.lean and not args.no_rebuild and runs == 64:
+        sweep = []
+        for rr in (32, 64, 128, 256):
+            shs = sh if rr == runs else Shard(ctx, prob, rr, nlive, args.walks, seed=1000 + rank, entropy=(21, rank, 0, 0),
+                                              queue=args.queue)
+            for i in range(6):
+                shs.step(i)
+            ctx.record(ev[0])
+            for i in range(12):
+                shs.step(i)
+            ctx.record(ev[1])
+            ctx.sync()
+            ms = ctx.elapsed_ms(ev[0], ev[1]) / 12
+            sweep.append({"runs_per_gpu": rr, "ms_per_step": ms,
+                          "proposals_per_s": rr * shs.kq * shs.nq * args.walks / (ms * 1e-3),
+                          "rebuilds_per_s": rr / (ms * 1e-3)})
+            if shs is not sh:
+                del shs
 
     verified = None
     if not args.no_verify and not args.no_rebuild:
@@ -623,20 +645,27 @@ def main():
         alg_bytes = 8 * (2 * d + 1)  # read u, write u', write logl
         flops = 2 * d * d + 8 * d + (d * d + 3 * d)  # frame mat-vec + sym. quad form
         achieved = props_per_launch * alg_bytes / (t_wk * 1e-3) / 1e9
-        traffic, traffic_src, traffic_rb = None, None, None
-        pmc = os.path.join(ROOT, "profiles", "r03", "pmc_traffic.json")
+        traffic, traffic_src, traffic_rb, issue = None, None, None, None
+        pmc = os.path.join(ROOT, "profiles", "r04", "pmc_traffic.json")
         if os.path.exists(pmc) and runs == 64 and nlive == 2000 and args.walks == 45 and kq == GATE_QUEUE:
             # PMC counters cannot be read from inside this process; the values are
             # the committed rocprofv3 measurement of this same launch shape
             # (tools/pmc_traffic.py: 2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes)
             with open(pmc) as f:
                 pj = json.load(f)
-            kk = [x for x in pj["kernels"] if x.startswith("rwalkq_kernel<7")]
-            if kk:
-                traffic = pj["kernels"][kk[0]]["traffic_bytes_per_launch"]
+            traffic = pj.get("rwalk_launch_traffic_bytes")  # generator pass + walk kernel
             traffic_rb = pj.get("rebuild_pipeline_bytes_per_launch_sequence")
-            traffic_src = ("profiles/r03/pmc_traffic.json (2*FETCH_SIZE + WRITE_SIZE, "
-                           "separate --pmc passes)")
+            traffic_src = ("profiles/r04/pmc_traffic.json (2*FETCH_SIZE + WRITE_SIZE, "
+                           "separate --pmc passes; walk launch = itemgen_kernel + rwalkq_kernel)")
+            pi = os.path.join(ROOT, "profiles", "r04", "pmc_issue.json")
+            if os.path.exists(pi):
+                # SQ issue / stall counters of the same launch shape (tools/pmc_issue.py, three --pmc passes)
+                with open(pi) as f:
+                    wl = json.load(f)["workloads"].get("bench", {})
+                issue = {k: {f: e[f] for f in ("valu_active_frac", "issue_active_frac", "wait_waitcnt_frac",
+                                               "wait_issue_stall_frac", "cycles_per_instruction_per_wavefront") if f in e}
+                         for k, e in wl.items() if k.startswith(("rwalkq_kernel", "itemgen_kernel", "k_ell", "k_split",
+                                                                 "k_root_parts"))}
         line = {
             "metric": "proposals/sec + ellipsoid-rebuilds/sec, 25-D corr-Normal "
                       "nlive=2000 (multi/rwalk)",
@@ -675,18 +704,29 @@ def main():
                 "nells_per_run": float(nells.mean()),
                 "accept_frac": float(nacc.sum() / props_per_launch),
                 "rng": "PCG64 + ziggurat, stream-identical to numpy.random.Generator (parity mode)",
+                "runs_per_gpu_sweep": sweep,
+                "tap_B": tap_b_record(),
                 "verified": verified,
             },
             "roofline": {
-                "bound": "hbm", "kernel": "rwalkq_kernel<7,PREC_AFFINE,PCG64> (four lanes per walker)",
+                "bound": "hbm", "kernel": "one walk launch = itemgen_kernel (the walkers' PCG64 item streams, one wavefront "
+                                          "per walker) + rwalkq_kernel<7,PREC_AFFINE,ITEMS> (four lanes per walker)",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": props_per_launch * alg_bytes,
                 "kernel_ms": t_wk, "launches_per_step": nq,
-                "note": "algorithmic bytes = 408 B/proposal (SURVEY 8d); walker "
-                        "state stays in registers for all 45 steps, so the "
-                        "binding roof is the fp64 pipes (VALU + MFMA), reported below",
+                "note": "algorithmic bytes = 408 B/proposal (SURVEY 8d); the walker stays in registers for all 45 "
+                        "steps and the generator pass streams 208 B per proposal through HBM / L2, so the measured "
+                        "traffic is now of the order of the algorithmic bytes; the walk kernel itself sits at ~85 % "
+                        "of the fp64 matrix-core rate on its padded tiles (DESIGN.md 3.1b), the generator pass is "
+                        "issue-bound (valu_active_frac below)",
+                "valu_active_frac": (None if not issue else
+                                     {k: v.get("valu_active_frac") for k, v in issue.items()
+                                      if k.startswith(("rwalkq_kernel", "itemgen_kernel"))}),
+                "issue_counters": issue,
+                "issue_counters_source": "profiles/r04/pmc_issue.json (rocprofv3 --pmc, SQ block; "
+                                         "fractions of SQ_WAVE_CYCLES)" if issue else None,
                 "fp64_valu": {
                     "achieved": props_per_launch * flops / (t_wk * 1e-3) / 1e12,
                     "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s"},
@@ -807,6 +847,32 @@ def reference_logz_gate():
     return out
 
 
+def _load_profile(name):
+    p = os.path.join(ROOT, "profiles", "r04", name)
+    if not os.path.exists(p):
+        return None
+    with open(p) as f:
+        return json.load(f)
+
+
+def tap_b_record():
+    """Tap B (the real dynesty.NestedSampler over the drop-in surface) needs the reference package, which is on neither
+    the GPU box nor in this repository: it was measured once on an MI355X box through a scratch copy
+    (tools/tapb_hw.py) and is quoted from the committed record."""
+    t = _load_profile("tapb_c2.json")
+    if not t:
+        return None
+    runs = list(t["runs"].values())
+    return {"source": "profiles/r04/tapb_c2.json (tools/tapb_hw.py on an MI355X box, round 4; not re-measured in this run)",
+            "what": t["what"], "runs": len(runs),
+            "seconds_per_run": float(np.mean([r["seconds"] for r in runs])),
+            "proposals_per_s": float(np.mean([r["proposals_per_s"] for r in runs])),
+            "iterations_per_s": float(np.mean([r["iterations_per_s"] for r in runs])),
+            "proposals_per_s_device_side": float(np.mean([r["proposals_per_s_device_side"] for r in runs])),
+            "host_python_fraction": float(np.mean([r["host_python_seconds"] / r["seconds"] for r in runs])),
+            "logz": [r["logz"] for r in runs]}
+
+
 def _cpu_walk_worker(job):
     """One host core: oracle rwalk walkers for `budget_s` seconds."""
     seed, u0, loglstar, axes, scale, walks, budget_s = job
@@ -865,6 +931,15 @@ def cpu_baseline(prob, u0, nlive, scale, loglstar, walks, budget_s):
                "note": "the real dynesty 3.0.0 on C2, measured in the build container (SURVEY.md "
                        "section 6); it cannot travel to the GPU box, so the port above is what "
                        "is timed here -- the port is the faster of the two"}}
+    ref_box = _load_profile("reference_cpu_on_gpu_box.json")
+    if ref_box and ref_box.get("bounded_phase"):
+        # the reference ITSELF on one host core of an MI355X box (round 4, through a scratch copy that is not part of
+        # the repository: tools/tapb_hw.py) -- a committed measurement, not re-timed by this run
+        out["reference_on_gpu_box"] = {
+            "proposals_per_s": ref_box["bounded_phase"]["proposals_per_s"], "cores": 1,
+            "multiellipsoid_update_ms": ref_box["multiellipsoid_update_ms"]["median"],
+            "sample": ref_box["sample"], "host_cpu_count": ref_box.get("cpu_count"),
+            "source": "profiles/r04/reference_cpu_on_gpu_box.json"}
     ncores = os.cpu_count() or 1
     if ncores > 1:
         try:
