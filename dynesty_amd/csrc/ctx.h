@@ -137,7 +137,7 @@ int rwalkq_launch(dh_ctx* ctx, const ProblemDev& prob, int k, int ndim, const do
                   const int32_t* axes_idx, double scale, double loglstar, int walks, const uint64_t* rng, double* u,
                   double* v, double* logl, int32_t* naccept, int32_t* nreject, uint64_t* rng_out,
                   const double* run_loglstar, const double* run_scale, const int* run_mode, int wpr, int my_mode,
-                  const PhiloxKey* philox);
+                  const PhiloxKey* philox, const int8_t* bc = nullptr);
 int slice_launch_runs(dh_ctx* ctx, int problem, int k, int ndim, int mode, const double* u0,
                       const double* axes, int m, const int32_t* axes_idx, double scale, double loglstar,
                       int slices, int doubling, const uint64_t* rng, double* u, double* v, double* logl,

@@ -24,6 +24,14 @@ enum : int {
   KIND_COUNT = 5
 };
 
+// periodic wrap and reflection of one unit-cube coordinate (utils.py:1053-1078 apply_reflect; np.mod(x, 1))
+__device__ __forceinline__ double wrap01(double x) { return x - floor(x); }
+__device__ __forceinline__ double reflect01(double x) {
+  const double m2 = x - 2.0 * floor(x * 0.5);  // np.mod(x, 2)
+  const double m1 = wrap01(x);
+  return (m2 < 1.0) ? m1 : 1.0 - m1;
+}
+
 __host__ __device__ inline int problem_kind(int like_id, int prior_id) {
   if (like_id == LIKE_GAUSS_PREC && prior_id == PRIOR_AFFINE) return KIND_PREC_AFFINE;
   if (like_id == LIKE_GAUSS_IID && prior_id == PRIOR_AFFINE) return KIND_IID_AFFINE;

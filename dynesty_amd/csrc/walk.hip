@@ -27,15 +27,6 @@ namespace {
 // ---------------------------------------------------------------------------
 // small helpers
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ double wrap01(double x) { return x - floor(x); }  // np.mod(x, 1)
-
-// utils.py:1053-1078 apply_reflect for one coordinate
-__device__ __forceinline__ double reflect01(double x) {
-  double m2 = x - 2.0 * floor(x * 0.5);  // np.mod(x, 2)
-  double m1 = wrap01(x);
-  return (m2 < 1.0) ? m1 : 1.0 - m1;
-}
-
 // DH_ABLATE is a diagnostic of the `make ablate` build only (libdynhip_ablate.so): the production kernel
 // carries no ablation branches
 #ifdef DH_RW_ABLATE
@@ -428,11 +419,11 @@ int dh::rwalk_launch_runs(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, 
   // (64 x 512 walkers: 0.27 ms against 0.86; 64 x 2000: 1.02 against 1.23), so form 0 takes it whenever it
   // applies -- a function of the problem alone, never of the launch size or the device, so that a run's
   // accept / reject sequence cannot depend on how many runs share a GPU (form 1: never, 2: same as 0).
-  const bool quad_ok = !a.propose_only && !bc && ndim == ncdim && ndim >= 9 && ndim <= kMaxRegDim &&
+  const bool quad_ok = !a.propose_only && ndim == ncdim && ndim >= 9 && ndim <= kMaxRegDim &&
                        (long long)walks * (ndim + 1) < (1ll << 24);
   if (quad_ok && ctx->rwalk_form != 1)
     return rwalkq_launch(ctx, a.prob, k, ndim, u0, axes, m, axes_idx, scale, loglstar, walks, rng, u, v, logl,
-                         naccept, nreject, rng_out, run_loglstar, run_scale, run_mode, wpr, my_mode, philox);
+                         naccept, nreject, rng_out, run_loglstar, run_scale, run_mode, wpr, my_mode, philox, bc);
   a.k = k;
   a.ndim = ndim;
   a.ncdim = ncdim;

@@ -65,6 +65,7 @@ struct RwalkQArgs {
   const int* run_mode;
   int wpr, my_mode;
   unsigned long long ph_seed, ph_seq0, ph_offset;
+  const int8_t* bc;  // DH_BC_* per dimension, or null: every coordinate hard
 };
 
 __device__ __forceinline__ void wave_sync() {
@@ -713,8 +714,7 @@ __device__ __forceinline__ double root_n(double ur, int n, double inv_n) {
   return ur > 0.0 ? y : 0.0;
 }
 
-// generic_random_walk (internal_samplers.py:866-986) for ndim == ncdim, no periodic / reflective
-// coordinates: four lanes per walker.  Workgroup = 4 wavefronts = 64 walkers.
+// generic_random_walk (internal_samplers.py:866-986) for ndim == ncdim: four lanes per walker.  Workgroup = 4 wavefronts = 64 walkers.
 template <int NR, int KIND, int RNG>
 __global__ void __launch_bounds__(256) rwalkq_kernel(RwalkQArgs a) {
   constexpr int MT = (4 * NR + 15) / 16;
@@ -787,6 +787,13 @@ __global__ void __launch_bounds__(256) rwalkq_kernel(RwalkQArgs a) {
     Gl = opaque_limbs(gj);
   }
   const bool lastok = 4 * (NR - 1) + t < n;
+  // boundary conditions of this lane's coordinates, two bits each (padding: hard, and it sits at 0.5)
+  uint32_t bcp = 0;
+  if (a.bc) {
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+      if (r < NR - 1 || lastok) bcp |= ((uint32_t)a.bc[4 * r + t] & 3u) << (2 * r);
+  }
   // RNGQ_ITEMS: the walker's stream in global memory and the registers that hold the coming step's items
   const double* myitems = a.items + (size_t)wi * T;
   double nx[NR], nxu = 0.0;
@@ -898,13 +905,30 @@ __global__ void __launch_bounds__(256) rwalkq_kernel(RwalkQArgs a) {
     }
     double lo = 0.5, hi = 0.5;
 #pragma unroll
-    for (int r = 0; r < NR; ++r) {
-      up[r] = (r < NR - 1 || lastok) ? fma(fac, acc[r >> 2][r & 3], u[r]) : 0.5;
-      lo = fmin(lo, up[r]);
-      hi = fmax(hi, up[r]);
+    for (int r = 0; r < NR; ++r) up[r] = (r < NR - 1 || lastok) ? fma(fac, acc[r >> 2][r & 3], u[r]) : 0.5;
+    bool inside_q;
+    if (a.bc) {
+      // periodic wrap / reflection, then unitcheck with the wider interval on those coordinates
+      // (utils.py:1036-1078; the same rule as the lane-per-walker kernel)
+      inside_q = true;
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        const uint32_t b = (bcp >> (2 * r)) & 3u;
+        double x = up[r];
+        if (b == DH_BC_PERIODIC) x = wrap01(x);
+        if (b == DH_BC_REFLECT) x = reflect01(x);
+        up[r] = x;
+        inside_q = inside_q && (b == DH_BC_HARD ? (x > 0.0) && (x < 1.0) : (x > -0.5) && (x < 1.5));
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        lo = fmin(lo, up[r]);
+        hi = fmax(hi, up[r]);
+      }
+      // unitcheck (utils.py:1036-1050) over the four quarters of the walker
+      inside_q = (lo > 0.0) && (hi < 1.0);
     }
-    // unitcheck (utils.py:1036-1050) over the four quarters of the walker
-    const bool inside_q = (lo > 0.0) && (hi < 1.0);
     const bool inside = grp_bits(__ballot(inside_q), j) == 0x0001000100010001ull;
     // a proposal outside the cube is counted as a call and a reject, no likelihood evaluated; here the
     // evaluation runs anyway (the matrix instruction serves the whole wave) and its verdict is ignored
@@ -964,9 +988,10 @@ int rwalkq_launch(dh_ctx* ctx, const ProblemDev& prob, int k, int ndim, const do
                   const int32_t* axes_idx, double scale, double loglstar, int walks, const uint64_t* rng, double* u,
                   double* v, double* logl, int32_t* naccept, int32_t* nreject, uint64_t* rng_out,
                   const double* run_loglstar, const double* run_scale, const int* run_mode, int wpr, int my_mode,
-                  const PhiloxKey* philox) {
+                  const PhiloxKey* philox, const int8_t* bc) {
   RwalkQArgs a;
   a.prob = prob;
+  a.bc = bc;
   a.k = k;
   a.ndim = ndim;
   a.walks = walks;

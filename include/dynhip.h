@@ -213,11 +213,11 @@ int dh_rwalk_batch_dev(dh_ctx* ctx, int problem, int k, int ndim, int ncdim,
  * rwalk stage of dh_ns_ensemble).  Two kernels implement generic_random_walk
  * (internal_samplers.py:866-986) on the same generator streams: one walker per lane (any ndim <= 32, any
  * options), and one walker on four lanes of a wavefront with the frame product / Gaussian quadratic form
- * on the fp64 matrix cores (built for ndim == ncdim in 9..32, no periodic / reflective coordinates,
- * affine or identity prior).  Accept / reject counts and generator end states of the two are identical,
+ * on the fp64 matrix cores (built for ndim == ncdim in 9..32; periodic / reflective coordinates and every
+ * fused prior included).  Accept / reject counts and generator end states of the two are identical,
  * coordinates agree to rounding (~1e-15: sums over a vector are taken in a different order).
- *   form 0 (default)  four lanes per walker wherever built: decided by the problem alone (dimension, boundary
- *                     conditions, prior), never by the launch size or the device, so that a run's results do
+ *   form 0 (default)  four lanes per walker wherever built: decided by the problem alone (its dimension, and
+ *                     ndim == ncdim), never by the launch size or the device, so that a run's results do
  *                     not depend on how an ensemble is sharded
  *   form 1            one walker per lane always
  *   form 2            same as 0 (kept for callers of the round-3 interface)

@@ -185,3 +185,59 @@ def test_quad_philox_equals_lane_philox(ctx):
     same = quad["accept"] == lane["accept"]
     np.testing.assert_allclose(quad["u"][same], lane["u"][same], rtol=0, atol=1e-12)
     assert 0.05 < quad["accept"].mean() / 45 < 0.8
+
+
+@pytest.mark.parametrize("d", [9, 14, 25, 32])
+def test_quad_periodic_and_reflective_coordinates(ctx, d):
+    """Round 4: the four-lanes-per-walker kernel wraps periodic and reflects reflective coordinates itself
+    (utils.py:1036-1078), so a problem with such coordinates takes the same form as one without.  Large steps, so
+    that wraps, reflections and hard-edge rejects all occur; against the oracle on the same streams (counts and
+    generator end states exact), against the lane-per-walker kernel, for both generator placements and for the
+    Philox mode."""
+    from dynesty_amd import _lib
+    prob = problems.gauss_corr(d, 0.4, 5.0, f"corr{d}")
+    case = make_case(prob, 200, 77 + d)
+    u0 = case["u0"][:131]
+    k = len(u0)
+    bc = np.zeros(d, dtype=np.int8)
+    bc[[0, 3, d - 1]] = _lib.BC_PERIODIC
+    bc[[1, d - 2]] = _lib.BC_REFLECT
+    periodic, reflective = np.where(bc == 1)[0], np.where(bc == 2)[0]
+    nonb = bc == 0
+    axes = case["axes"] * 2.0          # about half of the proposals leave the cube in some hard coordinate
+    loglstar = -1e300                  # ... and every one that stays is accepted: the wrapped point is what is kept
+    ent = [d, 60, 7]
+    st = ctx.seed_children(ent, 0, k)
+    args = (prob, u0, axes, 1.0, loglstar, 20, st)
+    ctx.set_rwalk_form(2)
+    quad = ctx.rwalk_batch(*args, bc=bc)
+    kids = np.random.SeedSequence(ent).spawn(k)
+    wrapped = 0
+    for i in range(k):
+        bg = np.random.PCG64(kids[i])
+        ref = P.rwalk(u0[i].copy(), loglstar, axes, 1.0, prob.prior_transform, prob.loglikelihood,
+                      np.random.Generator(bg), 20, periodic=periodic, reflective=reflective, nonbounded=nonb)
+        assert ref["accept"] == quad["accept"][i] and ref["reject"] == quad["reject"][i], i
+        np.testing.assert_allclose(quad["u"][i], ref["u"], rtol=0, atol=ATOL_U)
+        np.testing.assert_allclose(quad["logl"][i], ref["logl"], rtol=RTOL_L, atol=1e-11)
+        np.testing.assert_array_equal(quad["rng_out"][i], _lib.pcg_state_words(bg))
+        wrapped += ref["accept"]
+    assert wrapped > k and quad["reject"].sum() > k   # both outcomes, many times
+    assert (quad["u"] > 0).all() and (quad["u"] < 1).all()
+    hard = ctx.rwalk_batch(*args)
+    assert (hard["accept"] < quad["accept"]).any()   # proposals that only survive wrapped / reflected
+    ctx.set_rwalk_items(False, 0)
+    fused = ctx.rwalk_batch(*args, bc=bc)
+    ctx.set_rwalk_items(True, 1 << 30)
+    for key in ("u", "v", "logl", "accept", "reject", "rng_out"):
+        np.testing.assert_array_equal(fused[key], quad[key])
+    ctx.set_rwalk_form(1)
+    lane = ctx.rwalk_batch(*args, bc=bc)
+    np.testing.assert_array_equal(quad["accept"], lane["accept"])
+    np.testing.assert_array_equal(quad["rng_out"], lane["rng_out"])
+    np.testing.assert_allclose(quad["u"], lane["u"], rtol=0, atol=1e-13)
+    lane_ph = ctx.rwalk_batch_philox(prob, u0, axes, 1.0, loglstar, 20, 99, bc=bc)
+    ctx.set_rwalk_form(2)
+    quad_ph = ctx.rwalk_batch_philox(prob, u0, axes, 1.0, loglstar, 20, 99, bc=bc)
+    np.testing.assert_array_equal(quad_ph["accept"], lane_ph["accept"])
+    np.testing.assert_allclose(quad_ph["u"], lane_ph["u"], rtol=0, atol=1e-13)
