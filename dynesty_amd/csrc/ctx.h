@@ -132,7 +132,7 @@ int rwalk_launch_runs(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, cons
                       int32_t* naccept, int32_t* nreject, uint64_t* rng_out, const double* run_loglstar,
                       const double* run_scale, const int* run_mode, int wpr, int my_mode,
                       const PhiloxKey* philox = nullptr);
-// walkq.hip: the same walk with four lanes per walker (ndim == ncdim in 9..32, no boundary conditions)
+// walkq.hip: the same walk with four lanes per walker (ndim == ncdim in 2..32)
 int rwalkq_launch(dh_ctx* ctx, const ProblemDev& prob, int k, int ndim, const double* u0, const double* axes, int m,
                   const int32_t* axes_idx, double scale, double loglstar, int walks, const uint64_t* rng, double* u,
                   double* v, double* logl, int32_t* naccept, int32_t* nreject, uint64_t* rng_out,

@@ -412,14 +412,14 @@ int dh::rwalk_launch_runs(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, 
     return wide_walk_launch(ctx, 0, problem, k, ndim, ncdim, u0, axes, m, axes_idx, scale, loglstar, walks,
                             0, bc, rng, u, v, logl, naccept, nreject, nullptr, nullptr, rng_out, run_loglstar,
                             run_scale, run_mode, nullptr, wpr, my_mode, philox);
-  // Four lanes per walker + matrix cores (walkq.hip): built for full-dimensional proposals without
-  // boundary conditions, 9 <= ndim <= 32, fused likelihood and prior.  It does the same
+  // Four lanes per walker + matrix cores (walkq.hip): built for full-dimensional proposals,
+  // 2 <= ndim <= 32, fused likelihood and prior, any boundary conditions.  It does the same
   // walk on the same streams (counts and generator states identical, coordinates to rounding).  Round 4: with
   // the PCG64 streams written out by a generator pass of their own it is the faster form at every launch size
   // (64 x 512 walkers: 0.27 ms against 0.86; 64 x 2000: 1.02 against 1.23), so form 0 takes it whenever it
   // applies -- a function of the problem alone, never of the launch size or the device, so that a run's
   // accept / reject sequence cannot depend on how many runs share a GPU (form 1: never, 2: same as 0).
-  const bool quad_ok = !a.propose_only && ndim == ncdim && ndim >= 9 && ndim <= kMaxRegDim &&
+  const bool quad_ok = !a.propose_only && ndim == ncdim && ndim >= 2 && ndim <= kMaxRegDim &&
                        (long long)walks * (ndim + 1) < (1ll << 24);
   if (quad_ok && ctx->rwalk_form != 1)
     return rwalkq_launch(ctx, a.prob, k, ndim, u0, axes, m, axes_idx, scale, loglstar, walks, rng, u, v, logl,

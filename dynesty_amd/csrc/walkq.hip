@@ -982,8 +982,7 @@ __global__ void __launch_bounds__(256) rwalkq_kernel(RwalkQArgs a) {
 
 namespace dh {
 
-// Eligible launches (rwalk_launch_runs decides): ndim == ncdim in 9..32, no boundary conditions, fused
-// likelihood, affine or identity prior.  Returns DH_OK after enqueueing on the context's stream.
+// Eligible launches (rwalk_launch_runs decides): ndim == ncdim in 2..32, fused likelihood and prior.  Returns DH_OK after enqueueing on the context's stream.
 int rwalkq_launch(dh_ctx* ctx, const ProblemDev& prob, int k, int ndim, const double* u0, const double* axes, int m,
                   const int32_t* axes_idx, double scale, double loglstar, int walks, const uint64_t* rng, double* u,
                   double* v, double* logl, int32_t* naccept, int32_t* nreject, uint64_t* rng_out,
@@ -1024,7 +1023,7 @@ int rwalkq_launch(dh_ctx* ctx, const ProblemDev& prob, int k, int ndim, const do
   a.wbase = 0;
   const dim3 block(256);
   const int kind = problem_kind(prob.like_id, prob.prior_id) == KIND_PREC_AFFINE ? KIND_PREC_AFFINE : KIND_GENERIC;
-  const int nr = (ndim + 3) / 4;  // 9 <= ndim <= 32: 3 .. 8
+  const int nr = (ndim + 3) / 4;  // 2 <= ndim <= 32: 1 .. 8
 #define L(NRR, KK, GRID)                                                                               \
   do {                                                                                                 \
     if (philox)                                                                                        \
@@ -1041,7 +1040,7 @@ int rwalkq_launch(dh_ctx* ctx, const ProblemDev& prob, int k, int ndim, const do
     else                               \
       L(NRR, KIND_GENERIC, GRID);      \
   }
-#define XALL(GRID) X(3, GRID) X(4, GRID) X(5, GRID) X(6, GRID) X(7, GRID) X(8, GRID)
+#define XALL(GRID) X(1, GRID) X(2, GRID) X(3, GRID) X(4, GRID) X(5, GRID) X(6, GRID) X(7, GRID) X(8, GRID)
   if (philox || !ctx->rwalk_items) {
     const dim3 grid((k + 63) / 64);
     XALL(grid)

@@ -213,7 +213,7 @@ int dh_rwalk_batch_dev(dh_ctx* ctx, int problem, int k, int ndim, int ncdim,
  * rwalk stage of dh_ns_ensemble).  Two kernels implement generic_random_walk
  * (internal_samplers.py:866-986) on the same generator streams: one walker per lane (any ndim <= 32, any
  * options), and one walker on four lanes of a wavefront with the frame product / Gaussian quadratic form
- * on the fp64 matrix cores (built for ndim == ncdim in 9..32; periodic / reflective coordinates and every
+ * on the fp64 matrix cores (built for ndim == ncdim in 2..32; periodic / reflective coordinates and every
  * fused prior included).  Accept / reject counts and generator end states of the two are identical,
  * coordinates agree to rounding (~1e-15: sums over a vector are taken in a different order).
  *   form 0 (default)  four lanes per walker wherever built: decided by the problem alone (its dimension, and

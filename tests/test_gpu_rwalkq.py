@@ -60,7 +60,8 @@ def the_problem(kind, d):
     return problems.eggbox(d, name=f"egg{d}")
 
 
-CASES = [("prec", 9), ("prec", 12), ("prec", 16), ("prec", 17), ("prec", 20), ("prec", 25), ("prec", 28),
+CASES = [("prec", 2), ("prec", 4), ("prec", 5), ("prec", 8), ("iid", 3), ("iid", 7), ("egg", 2), ("egg", 6),
+         ("normal", 4), ("normal", 8), ("prec", 9), ("prec", 12), ("prec", 16), ("prec", 17), ("prec", 20), ("prec", 25), ("prec", 28),
          ("prec", 29), ("prec", 32), ("iid", 10), ("iid", 27), ("egg", 9), ("egg", 18), ("normal", 11), ("normal", 25), ("normal", 30)]
 
 
@@ -187,7 +188,7 @@ def test_quad_philox_equals_lane_philox(ctx):
     assert 0.05 < quad["accept"].mean() / 45 < 0.8
 
 
-@pytest.mark.parametrize("d", [9, 14, 25, 32])
+@pytest.mark.parametrize("d", [5, 8, 9, 14, 25, 32])
 def test_quad_periodic_and_reflective_coordinates(ctx, d):
     """Round 4: the four-lanes-per-walker kernel wraps periodic and reflects reflective coordinates itself
     (utils.py:1036-1078), so a problem with such coordinates takes the same form as one without.  Large steps, so

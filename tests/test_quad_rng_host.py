@@ -137,7 +137,7 @@ def np_state(bg):
     return st["state"], st["inc"]
 
 
-@pytest.mark.parametrize("nc", [9, 12, 16, 25, 28, 31, 32])
+@pytest.mark.parametrize("nc", [2, 3, 4, 5, 7, 8, 9, 12, 16, 25, 28, 31, 32])
 def test_wave_draws_equal_numpy(nc):
     ki, wi, fi = load_tables()
     for seed in range(40):
