@@ -798,8 +798,12 @@ class Context:
                     want_dead_logl=False, sample='rwalk', slices=None,
                     rebuild_sync=False, want_samples=False, rng='pcg64', bootstrap=None, rebuild_every=0,
                     update_interval=None, first_update=None, maxiter=None, maxcall=None, logl_max=None,
-                    add_live=True):
+                    add_live=True, forced_exact=False):
         """Device-resident ensemble of static NS runs (dh_ns_ensemble).
+
+        forced_exact=True: propose_live's forced bound update (sampler.py:484-489) inside the fill that finds a start
+        point outside the bound, as the reference takes it (DH_NS_OPT_FORCED_EXACT); the default flags the run and
+        rebuilds before its next fill.
 
         update_interval / first_update (NestedSampler, dynesty.py:213-234: a float update_interval is a multiple of
         nlive, an int a number of calls; first_update = dict(min_ncall=..., min_eff=...)) and maxiter / maxcall /
@@ -861,7 +865,8 @@ class Context:
                 float(fu['min_ncall']) if 'min_ncall' in fu else nan,
                 float(fu['min_eff']) if 'min_eff' in fu else nan,
                 nan if maxiter is None else float(maxiter), nan if maxcall is None else float(maxcall),
-                nan if logl_max is None else float(logl_max), nan if add_live else 0.0]
+                nan if logl_max is None else float(logl_max), nan if add_live else 0.0,
+                1.0 if forced_exact else nan]
         for key, val in enumerate(opts):
             self._check(self.lib.dh_ns_set_option(self.handle, key, val))
         self._check(self.lib.dh_ns_ensemble(

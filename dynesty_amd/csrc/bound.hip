@@ -58,7 +58,8 @@ template <int N>
 __global__ void __launch_bounds__(64)
     contains_runs_kernel(const double* __restrict__ x, int k, int d, int wpr, const double* __restrict__ ctrs,
                          const double* __restrict__ ams, const int* __restrict__ nells, int max_ells, int strict,
-                         const int* __restrict__ run_mode, int my_mode, const int* __restrict__ bstatus, int* flag) {
+                         const int* __restrict__ run_mode, int my_mode, const int* __restrict__ bstatus, int* flag,
+                         int* first) {
   const int w = blockIdx.x * 64 + threadIdx.x;
   const bool live = w < k;
   const int wi = live ? w : k - 1;
@@ -97,7 +98,11 @@ __global__ void __launch_bounds__(64)
         }
         inside = inside || (strict ? (q < 1.0) : (sqrt(q) <= 1.0));
       }
-      if (__any(mine && !inside) && threadIdx.x == (unsigned)(__ffsll((long long)__ballot(mine)) - 1)) atomicOr(&flag[run], 1);
+      const unsigned long long outm = __ballot(mine && !inside);
+      if (outm && threadIdx.x == (unsigned)(__ffsll((long long)outm) - 1)) {
+        atomicOr(&flag[run], 1);
+        if (first) atomicMin(&first[run], w - run * wpr);  // the earliest queue entry outside (lanes ascend with w)
+      }
     }
     if (mine) pending = false;
   }
@@ -109,7 +114,8 @@ __global__ void __launch_bounds__(64)
 __global__ void __launch_bounds__(64)
     contains_runs_wide_kernel(const double* __restrict__ x, int k, int d, int wpr, const double* __restrict__ ctrs,
                               const double* __restrict__ ams, const int* __restrict__ nells, int max_ells, int strict,
-                              const int* __restrict__ run_mode, int my_mode, const int* __restrict__ bstatus, int* flag) {
+                              const int* __restrict__ run_mode, int my_mode, const int* __restrict__ bstatus, int* flag,
+                              int* first) {
   extern __shared__ double dl[];
   const int w = blockIdx.x, lane = threadIdx.x;
   if (w >= k) return;
@@ -132,7 +138,10 @@ __global__ void __launch_bounds__(64)
     for (int sft = 32; sft > 0; sft >>= 1) q += __shfl_xor(q, sft);
     inside = strict ? (q < 1.0) : (sqrt(q) <= 1.0);
   }
-  if (!inside && lane == 0) atomicOr(&flag[run], 1);
+  if (!inside && lane == 0) {
+    atomicOr(&flag[run], 1);
+    if (first) atomicMin(&first[run], w - run * wpr);
+  }
 }
 
 }  // namespace
@@ -140,11 +149,11 @@ __global__ void __launch_bounds__(64)
 namespace dh {
 int contains_runs_launch(dh_ctx* ctx, const double* x, int k, int d, int wpr, const double* ctrs, const double* ams,
                          const int* nells, int max_ells, int strict, const int* run_mode, int my_mode,
-                         const int* bstatus, int* flag) {
+                         const int* bstatus, int* flag, int* first) {
   if (k <= 0) return DH_OK;
   if (d > kMaxRegDim) {
     hipLaunchKernelGGL(contains_runs_wide_kernel, dim3(k), dim3(64), (size_t)d * 8, ctx->stream, x, k, d, wpr, ctrs, ams,
-                       nells, max_ells, strict, run_mode, my_mode, bstatus, flag);
+                       nells, max_ells, strict, run_mode, my_mode, bstatus, flag, first);
     return hip_ok(ctx, hipGetLastError(), "contains_runs launch") ? DH_OK : DH_ERR_HIP;
   }
   const dim3 grid((k + 63) / 64), block(64);
@@ -153,7 +162,7 @@ int contains_runs_launch(dh_ctx* ctx, const double* x, int k, int d, int wpr, co
   if (!hit && d <= NN) {                                                                                   \
     hit = true;                                                                                            \
     hipLaunchKernelGGL(contains_runs_kernel<NN>, grid, block, 0, ctx->stream, x, k, d, wpr, ctrs, ams, nells, \
-                       max_ells, strict, run_mode, my_mode, bstatus, flag);                                \
+                       max_ells, strict, run_mode, my_mode, bstatus, flag, first);                         \
   }
   DH_DIM_LIST(X)
 #undef X

@@ -172,7 +172,7 @@ int eval_launch_dev(dh_ctx* ctx, int problem, int k, const double* u, double* v,
 // bound.hip: start-point membership per run (candidate w -> run w / wpr); flag[run] |= 1 if one lies outside
 int contains_runs_launch(dh_ctx* ctx, const double* x, int k, int d, int wpr, const double* ctrs, const double* ams,
                          const int* nells, int max_ells, int strict, const int* run_mode, int my_mode,
-                         const int* bstatus, int* flag);
+                         const int* bstatus, int* flag, int* first = nullptr);
 // friends.hip: Y = X M (n x d times d x d) on the context's stream, device pointers
 int friends_whiten_launch(dh_ctx* ctx, const double* X, const double* M, int n, int d, double* Y);
 

@@ -94,6 +94,10 @@ struct NsArgs {
   int* run_mode;
   int* rebuild_mask;
   int* force;  // runs: set by the start-point membership check of the previous fill (forced rebuild, sampler.py:484-489)
+  // DH_NS_OPT_FORCED_EXACT: the forced update inside the fill that found the start point
+  int forced_exact;
+  int* force_first;   // runs: queue index of the first start point outside the bound (INT_MAX: none)
+  uint64_t* sel_ent;  // runs x 4: the words ns_select seeded this fill's walker selections from
   int* ndone;
   // bound (rebuild outputs)
   int* nells;
@@ -338,6 +342,8 @@ __global__ void __launch_bounds__(kT) ns_select(NsArgs a) {
     g.load(r.rng);
     for (int i = 0; i < 4; ++i) ent[i] = g.next64();
     g.store(r.rng);
+    if (a.sel_ent)
+      for (int i = 0; i < 4; ++i) a.sel_ent[(size_t)run * 4 + i] = ent[i];
     if (mode == MODE_BOUND && a.bound_multi) {
       M = a.nells[run];
       if (M > kMaxCum) M = kMaxCum;  // unreachable: dh_ns_ensemble refuses max_ells > kMaxCum
@@ -409,6 +415,119 @@ __global__ void __launch_bounds__(256) ns_gather(NsArgs a) {
   if (a.st[run].mode != MODE_BOUND || a.bstatus[run] != DH_OK) return;
   if (a.run_mode[run] == MODE_WAIT) return;
   a.q_u0[e] = a.live_u[((size_t)run * N + a.r_d[q]) * D + j];
+}
+
+// ---- the forced update inside the fill (DH_NS_OPT_FORCED_EXACT; sampler.py:484-489) ----------------------------
+// Sampler._fill_queue proposes the K start points one after the other; the first one that lies outside the bound
+// rebuilds it at once (update_bound_if_needed(force=True): all live points, nbound + 1, the call counter of the last
+// update reset), AFTER its own axes were drawn from the old bound (propose_live: get_random_axes stands before the
+// membership test).  The later entries draw their axes from the new bound, which holds every live point, so there is
+// at most one forced update per fill.  Here: the membership kernel has left force[run] and force_first[run];
+// ns_force_prepare turns the flags into the rebuild mask and does the run's bookkeeping, ns_shadow_axes keeps the old
+// frames of the masked runs in the second half of the axes array, the masked rebuild runs, and ns_reselect points the
+// entries up to force_first at the kept frames and redraws the frames of the later ones from the new volumes (same
+// variates: the selection generator of entry w is a function of the fill's four words and w).
+__global__ void __launch_bounds__(kT) ns_force_prepare(NsArgs a) {
+  for (int run = threadIdx.x; run < a.runs; run += kT) {
+    NsRun& r = a.st[run];
+    const int f = (a.force[run] && r.mode == MODE_BOUND && a.run_mode[run] == MODE_BOUND && a.bstatus[run] == DH_OK) ? 1 : 0;
+    if (f) {
+      r.due = 0;
+      r.ncall_last_update = r.ncall;
+      r.nbound += 1;
+      if (a.bootstrap > 0) {
+        Pcg64 g;
+        g.load(r.rng);
+        for (int i = 0; i < 4; ++i) a.boot_ent[(size_t)run * 4 + i] = g.next64();
+        g.store(r.rng);
+      }
+    } else {
+      a.force_first[run] = 0x7fffffff;
+    }
+    a.force[run] = 0;  // (the membership test after the rebuild sets it again only if the update failed)
+    a.rebuild_mask[run] = f;
+  }
+}
+
+__global__ void __launch_bounds__(256) ns_shadow_axes(NsArgs a) {
+  const int run = blockIdx.x;
+  if (!a.rebuild_mask[run]) return;
+  const size_t dd = (size_t)a.ndim * a.ndim, n = (size_t)(a.bound_multi ? a.nells[run] : 1) * dd;
+  const double* src = a.b_axes + (size_t)run * a.max_ells * dd;
+  double* dst = a.b_axes + ((size_t)a.runs + run) * a.max_ells * dd;
+  for (size_t i = (size_t)blockIdx.y * 256 + threadIdx.x; i < n; i += (size_t)gridDim.y * 256) dst[i] = src[i];
+}
+
+__global__ void __launch_bounds__(kT) ns_reselect(NsArgs a) {
+  __shared__ double cum[kMaxCum];
+  __shared__ double mxs;
+  const int run = blockIdx.x, t = threadIdx.x;
+  if (!a.rebuild_mask[run]) return;
+  const int N = a.nlive, K = a.K;
+  NsRun& r = a.st[run];
+  if (a.force[run] || a.bstatus[run] != DH_OK) {
+    // RuntimeError('Update of the ellipsoid failed') (sampler.py:489), or the rebuild itself failed: the run proposes
+    // nothing; ns_prepare ends it at the next fill
+    if (t == 0) {
+      if (a.bstatus[run] == DH_OK) a.bstatus[run] = DH_ERR_CONTAIN;
+      a.run_mode[run] = MODE_WAIT;
+      a.force_first[run] = 0x7fffffff;
+    }
+    return;
+  }
+  int M = a.bound_multi ? a.nells[run] : 1;
+  if (M > kMaxCum) M = kMaxCum;
+  if (M > 1) {
+    if (t == 0) {
+      double mx = -INFINITY;
+      for (int e = 0; e < M; ++e) mx = fmax(mx, a.b_lv[(size_t)run * a.max_ells + e]);
+      mxs = mx;
+    }
+    __syncthreads();
+    for (int e = t; e < M; e += kT) cum[e] = exp(a.b_lv[(size_t)run * a.max_ells + e] - mxs);
+    __syncthreads();
+    if (t == 0) {
+      double c = 0.0;
+      for (int e = 0; e < M; ++e) {
+        c += cum[e];
+        cum[e] = c;
+      }
+      const double inv = 1.0 / c;
+      for (int e = 0; e < M; ++e) cum[e] *= inv;
+    }
+    __syncthreads();
+  }
+  const int jstar = a.force_first[run];
+  const double loglstar = r.loglstar;
+  const uint64_t* ent = a.sel_ent + (size_t)run * 4;
+  for (int w = t; w < K; w += kT) {
+    const size_t q = (size_t)run * K + w;
+    if (w <= jstar) {
+      a.q_frame[q] += a.runs * a.max_ells;  // its axes were drawn from the old bound
+      continue;
+    }
+    int frame = 0;
+    if (M > 1) {
+      Pcg64 g;
+      U128 is = {ent[0], ent[1] + (uint64_t)w};
+      U128 iq = {ent[2], ent[3] + 2ull * (uint64_t)w};
+      g.seed(is, iq);
+      int i, guard = 0;
+      do {
+        i = (int)g.interval((uint64_t)(N - 1));
+      } while (!(a.live_logl[(size_t)run * N + i] > loglstar) && ++guard < 100000);
+      const double xr = g.next_double();
+      int lo = 0, hi = M - 1;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (cum[mid] < xr) lo = mid + 1; else hi = mid;
+      }
+      frame = lo;
+    }
+    a.q_frame[q] = run * a.max_ells + frame;
+  }
+  __syncthreads();
+  if (t == 0) a.force_first[run] = 0x7fffffff;
 }
 
 // ---- consume the queue (sampler.py:732-778 + 1105-1185), one workgroup per run ----
@@ -1732,6 +1851,9 @@ int dh_ns_consume(dh_ctx* ctx, int runs, int nlive, int queue_size, double dlogz
   a.maxiter = a.maxcall = -1;
   a.logl_max = INFINITY;
   a.add_live = 1;
+  a.forced_exact = 0;
+  a.force_first = nullptr;
+  a.sel_ent = nullptr;
   a.dlogz = dlogz;
   a.dead_rel = 1;
   arena_reset(ctx);
@@ -1885,6 +2007,9 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
   a.maxiter = a.maxcall = -1;
   a.logl_max = INFINITY;
   a.add_live = 1;
+  a.forced_exact = 0;
+  a.force_first = nullptr;
+  a.sel_ent = nullptr;
   {
     const double* o = ctx->ns_opt;
     if (!std::isnan(o[DH_NS_OPT_UPDATE_INTERVAL])) {
@@ -1899,6 +2024,7 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
     if (!std::isnan(o[DH_NS_OPT_MAXCALL])) a.maxcall = (long long)llround(o[DH_NS_OPT_MAXCALL]);
     if (!std::isnan(o[DH_NS_OPT_LOGL_MAX])) a.logl_max = o[DH_NS_OPT_LOGL_MAX];
     if (!std::isnan(o[DH_NS_OPT_ADD_LIVE])) a.add_live = o[DH_NS_OPT_ADD_LIVE] != 0.0 ? 1 : 0;
+    if (!std::isnan(o[DH_NS_OPT_FORCED_EXACT])) a.forced_exact = (o[DH_NS_OPT_FORCED_EXACT] != 0.0 && sampler != 3) ? 1 : 0;
     if (a.maxcall >= 0 && a.maxcall < N)
       return fail(ctx, DH_ERR_ARG, "ns_ensemble: maxcall %lld below the %d calls of the initial live points", a.maxcall, N);
   }
@@ -1914,7 +2040,7 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
   // (DH_NS_OVERLAP=1 switches it on): a rebuild beside a walk slows both (77 KB of LDS and 256 VGPRs per rebuild
   // workgroup against two 230-VGPR walk workgroups per CU), and every run spends one more fill per bound update --
   // 64 C2 runs 0.336 -> 0.328 s, 16 eggbox runs 0.127 -> 0.160 s, 16 C4 runs 11.1 -> 11.3 s.
-  a.overlap = (getenv("DH_NS_OVERLAP") && atoi(getenv("DH_NS_OVERLAP")) != 0) ? 1 : 0;
+  a.overlap = (getenv("DH_NS_OVERLAP") && atoi(getenv("DH_NS_OVERLAP")) != 0 && !a.forced_exact) ? 1 : 0;
   // Bounds are built every rebuild_every-th fill (runs that become due in between wait, see ns_prepare); 0 = chosen
   // here.  Once the period reaches the number of fills a run needs to spend its update interval, EVERY run is due (and
   // waiting) by the next rebuild fill: the ensemble rebuilds together and walks together, one latency chain per
@@ -1958,11 +2084,11 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
                o_pl = take((size_t)R * 8), o_ps = take((size_t)R * 8), o_pm = take((size_t)R * 4),
                o_rm = take((size_t)R * 4), o_fo = take((size_t)R * 4), o_nd = take(64), o_ne = take((size_t)R * 4),
                o_bs = take((size_t)R * 4), o_bc = take((size_t)R * me * D * 8), o_bv = take((size_t)R * me * dd * 8),
-               o_ba = take((size_t)R * me * dd * 8), o_bx = take((size_t)R * me * dd * 8),
+               o_ba = take((size_t)R * me * dd * 8), o_bx = take((size_t)R * me * dd * 8 * (a.forced_exact ? 2 : 1)),
                o_bl = take((size_t)R * me * D * 8), o_bg = take((size_t)R * me * 8),
                o_rec = take((size_t)R * 8 * 8), o_ent = take((size_t)n_words * 4),
                o_fw = take((size_t)R * 3 * N * 8), o_cum = take((size_t)R * me * 8), o_be = take((size_t)R * 32),
-               o_rs = take((size_t)R * 8),
+               o_rs = take((size_t)R * 8), o_ff = take((size_t)R * 4), o_se = take((size_t)R * 32),
                o_boot = take(bootstrap > 0 ? bootstrap_ws_bytes(R, N, D, me, bootstrap) : 8),
                o_lit = take(want_pt ? (size_t)R * N * 4 : 8), o_pid = take(want_pt ? (size_t)R * a.cap * 4 : 8),
                o_pit = take(want_pt ? (size_t)R * a.cap * 4 : 8), o_pnc = take(want_pt ? (size_t)R * a.cap * 4 : 8);
@@ -2023,6 +2149,8 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
   a.b_cum = (double*)(base + o_cum);
   a.boot_ent = (uint64_t*)(base + o_be);
   a.run_shift = (double*)(base + o_rs);
+  a.force_first = (int*)(base + o_ff);
+  a.sel_ent = a.forced_exact ? (uint64_t*)(base + o_se) : nullptr;
   if (want_pt) {
     a.live_it = (int*)(base + o_lit);
     a.dead_id = (int*)(base + o_pid);
@@ -2035,6 +2163,7 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
   if (!hip_ok(ctx, hipMemsetAsync(base + o_nd, 0, 64, s), "memset") ||
       !hip_ok(ctx, hipMemsetAsync(base + o_bs, 0, (size_t)R * 4, s), "memset") ||
       !hip_ok(ctx, hipMemsetAsync(base + o_fo, 0, (size_t)R * 4, s), "memset") ||
+      !hip_ok(ctx, hipMemsetAsync(base + o_ff, 0x7f, (size_t)R * 4, s), "memset") ||
       !hip_ok(ctx, hipMemsetAsync(base + o_ne, 0, (size_t)R * 4, s), "memset") ||
       !hip_ok(ctx, hipMemcpyAsync(d_ent, entropy_words, (size_t)n_words * 4, hipMemcpyHostToDevice, s), "H2D"))
     return cleanup(DH_ERR_HIP);
@@ -2067,6 +2196,27 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
   int h_state[2] = {0, 1};  // [runs done, any run still in the unit-cube phase]
   bool cube_phase = true;
   const bool force_check = !(getenv("DH_NS_FORCE") && atoi(getenv("DH_NS_FORCE")) == 0);  // diagnostic: 0 = no forced rebuilds
+  // bound.update of the runs in rebuild_mask (+ bootstrap expansion, + enlarge): sampler.py:492-508
+  auto build_bounds = [&]() -> int {
+    int rc = rebuild_launch_masked(ctx, R, a.live_u, N, D, bound_multi ? 0 : 1, me, a.nells, a.bstatus, a.b_ctrs,
+                                   a.b_covs, a.b_ams, a.b_axes, a.b_axl, a.b_lv, a.rebuild_mask);
+    if (rc) return rc;
+    if (bootstrap > 0) {
+      // bound.update(points, bootstrap=B): the expansion factor from B resampled replicas per rebuilding run,
+      // then scale_to_logvol(logvol + ndim ln(expand)) where it exceeds 1 (bounding.py:381-400, 688-703)
+      rc = bootstrap_expand_launch(ctx, R, a.live_u, N, D, bound_multi, me, bootstrap, a.boot_ent, a.rebuild_mask,
+                                   base + o_boot, a.run_shift, nullptr, a.bstatus);
+      if (rc) return rc;
+      rc = enlarge_launch_masked(ctx, R, me, a.nells, D, a.b_covs, a.b_ams, a.b_axes, a.b_axl, a.b_lv, 0.0,
+                                 a.rebuild_mask, a.run_shift);
+      if (rc) return rc;
+    }
+    if (enlarge != 1.0)  // sampler.py:506-508
+      rc = enlarge_launch_masked(ctx, R, me, a.nells, D, a.b_covs, a.b_ams, a.b_axes, a.b_axl, a.b_lv,
+                                 a.enlarge_log, a.rebuild_mask);
+    return rc;
+  };
+  const int n_frames = R * me * (a.forced_exact ? 2 : 1);
   while (fill < fills_cap && ndone < R) {
     for (int burst = 0; burst < 8 && fill < fills_cap; ++burst, ++fill) {
       if (a.overlap && fill > 0 && !hip_ok(ctx, hipStreamWaitEvent(s, ev_rb, 0), "hipStreamWaitEvent(rebuild)"))
@@ -2081,24 +2231,8 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
         ctx->stream = rb_stream;
       }
       if (a.rebuild_fill) {
-      rc = rebuild_launch_masked(ctx, R, a.live_u, N, D, bound_multi ? 0 : 1, me, a.nells, a.bstatus, a.b_ctrs,
-                                 a.b_covs, a.b_ams, a.b_axes, a.b_axl, a.b_lv, a.rebuild_mask);
-      if (rc) return cleanup(rc);
-      if (bootstrap > 0) {
-        // bound.update(points, bootstrap=B): the expansion factor from B resampled replicas per rebuilding run,
-        // then scale_to_logvol(logvol + ndim ln(expand)) where it exceeds 1 (bounding.py:381-400, 688-703)
-        rc = bootstrap_expand_launch(ctx, R, a.live_u, N, D, bound_multi, me, bootstrap, a.boot_ent, a.rebuild_mask,
-                                     base + o_boot, a.run_shift, nullptr, a.bstatus);
+        rc = build_bounds();
         if (rc) return cleanup(rc);
-        rc = enlarge_launch_masked(ctx, R, me, a.nells, D, a.b_covs, a.b_ams, a.b_axes, a.b_axl, a.b_lv, 0.0,
-                                   a.rebuild_mask, a.run_shift);
-        if (rc) return cleanup(rc);
-      }
-      if (enlarge != 1.0) {  // sampler.py:506-508
-        rc = enlarge_launch_masked(ctx, R, me, a.nells, D, a.b_covs, a.b_ams, a.b_axes, a.b_axl, a.b_lv,
-                                   a.enlarge_log, a.rebuild_mask);
-        if (rc) return cleanup(rc);
-      }
       }
       if (a.overlap) {
         ctx->stream = main_stream;
@@ -2113,8 +2247,21 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
       // is as stale in the reference.  (Above the register-resident dimensions: one wavefront per start point.)
       if (force_check && sampler != 3) {
         rc = contains_runs_launch(ctx, a.q_u0, R * K, D, K, a.b_ctrs, a.b_ams, bound_multi ? a.nells : nullptr, me,
-                                  bound_multi ? 1 : 0, a.run_mode, MODE_BOUND, a.bstatus, a.force);
+                                  bound_multi ? 1 : 0, a.run_mode, MODE_BOUND, a.bstatus, a.force,
+                                  a.forced_exact ? a.force_first : nullptr);
         if (rc) return cleanup(rc);
+        if (a.forced_exact) {
+          // DH_NS_OPT_FORCED_EXACT: the flagged runs rebuild now and their later queue entries take the new frames
+          // (see ns_force_prepare); the second membership test is the reference's check that the update worked
+          hipLaunchKernelGGL(ns_force_prepare, dim3(1), dim3(kT), 0, s, a);
+          hipLaunchKernelGGL(ns_shadow_axes, dim3(R, 16), dim3(256), 0, s, a);
+          rc = build_bounds();
+          if (rc) return cleanup(rc);
+          rc = contains_runs_launch(ctx, a.q_u0, R * K, D, K, a.b_ctrs, a.b_ams, bound_multi ? a.nells : nullptr, me,
+                                    bound_multi ? 1 : 0, a.run_mode, MODE_BOUND, a.bstatus, a.force);
+          if (rc) return cleanup(rc);
+          hipLaunchKernelGGL(ns_reselect, dim3(R), dim3(kT), 0, s, a);
+        }
       }
       // Philox keys: seed from the entropy words (one per stage, so that the stages' offset schemes cannot
       // meet), subsequence = global walker slot (first_run + run) * K + w (independent of the sharding)
@@ -2145,12 +2292,12 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
         // 32-bit draws one walker consumes per fill: per step hiprand_normal4 x ceil(D / 4) and one
         // hiprand_uniform_double (2 draws; padded to 4 so that a fill's block stays 4-aligned)
         key.offset = (unsigned long long)fill * (unsigned long long)walks * (unsigned long long)(4 * ((D + 3) / 4) + 4);
-        rc = rwalk_launch_runs(ctx, problem, R * K, D, D, a.q_u0, a.b_axes, R * me, a.q_frame, 1.0, 0.0, walks,
+        rc = rwalk_launch_runs(ctx, problem, R * K, D, D, a.q_u0, a.b_axes, n_frames, a.q_frame, 1.0, 0.0, walks,
                                nullptr, a.q_rng, a.r_u, a.r_v, a.r_logl, a.r_a, a.r_b, a.q_rng_out,
                                a.run_loglstar, a.run_scale, a.run_mode, K, MODE_BOUND, philox ? &key : nullptr);
       }
       else
-        rc = slice_launch_runs(ctx, problem, R * K, D, sampler - 1, a.q_u0, a.b_axes, R * me, a.q_frame, 1.0,
+        rc = slice_launch_runs(ctx, problem, R * K, D, sampler - 1, a.q_u0, a.b_axes, n_frames, a.q_frame, 1.0,
                                0.0, walks, 0, a.q_rng, a.r_u, a.r_v, a.r_logl, a.r_a, a.r_b, a.r_c, a.r_d,
                                a.q_rng_out, a.run_loglstar, a.run_scale, a.run_mode, a.run_doubling, K,
                                MODE_BOUND, philox ? &key_slice : nullptr);

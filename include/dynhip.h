@@ -472,6 +472,13 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim,
  *   DH_NS_OPT_LOGL_MAX          run_nested(logl_max): stops once the last dead point's ln L exceeds it; default +inf
  *   DH_NS_OPT_ADD_LIVE          run_nested(add_live): 0 = the record is the dead points' running evidence, the
  *                               final live points stay out (sampler.py:1319-1341); default 1
+ *   DH_NS_OPT_FORCED_EXACT      1 = Sampler.propose_live's forced bound update (sampler.py:484-489) inside the fill that
+ *                               finds a start point outside the bound: the run's bound is rebuilt before its walkers
+ *                               start, the queue entries up to and including the first one outside keep their axes from
+ *                               the old bound, the later ones take theirs from the new one -- the reference's sequence
+ *                               for any queue size.  Default 0: the run is flagged and rebuilds before its next fill
+ *                               (the fast form: no extra launches in fills without a forced update).  Not combined
+ *                               with the uniform sampler (no start points) and switches DH_NS_OVERLAP off.
  * A run ended by maxiter / maxcall / logl_max ends normally (status 0), as the reference's does. */
 enum {
   DH_NS_OPT_UPDATE_INTERVAL = 0,
@@ -481,7 +488,8 @@ enum {
   DH_NS_OPT_MAXCALL = 4,
   DH_NS_OPT_LOGL_MAX = 5,
   DH_NS_OPT_ADD_LIVE = 6,
-  DH_NS_OPT_COUNT = 7
+  DH_NS_OPT_FORCED_EXACT = 7,
+  DH_NS_OPT_COUNT = 8
 };
 int dh_ns_set_option(dh_ctx* ctx, int key, double value);
 

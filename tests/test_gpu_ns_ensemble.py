@@ -226,3 +226,30 @@ def test_waiting_for_the_rebuild_fill_changes_no_run(ctx, sample, kw):
     lo = ctx.ns_ensemble(prob, 4, first_run=0, rebuild_every=5, **base)
     hi = ctx.ns_ensemble(prob, 4, first_run=4, rebuild_every=5, **base)
     np.testing.assert_array_equal(np.concatenate([lo["logz"], hi["logz"]]), ref["logz"])
+
+
+def test_forced_update_inside_the_fill_is_per_run_and_changes_nothing_without_forced_updates(ctx):
+    """forced_exact=True (DH_NS_OPT_FORCED_EXACT): a run's result still depends on its own seed only (the forced
+    rebuild of one run leaves the others' frames alone: an ensemble equals its shards), it is deterministic, and when
+    no start point ever lies outside the bound (one ellipsoid enlarged a thousandfold in volume) the run is bit for
+    bit the default form's."""
+    from dynesty_amd import problems
+    prob = problems.gauss_corr(13, 0.3, 5.0, "corr13")
+    kw = dict(nlive=100, queue_size=16, walks=20, bound="multi", entropy=[3, 1, 4], dlogz=0.5, forced_exact=True)
+    a = ctx.ns_ensemble(prob, 6, **kw)
+    b = ctx.ns_ensemble(prob, 6, **kw)
+    assert (a["status"] == 0).all()
+    for key in ("logz", "niter", "ncall", "nbound"):
+        np.testing.assert_array_equal(a[key], b[key])
+    lo = ctx.ns_ensemble(prob, 2, first_run=0, **kw)
+    hi = ctx.ns_ensemble(prob, 4, first_run=2, **kw)
+    for key in ("logz", "niter", "ncall", "nbound"):
+        np.testing.assert_array_equal(a[key], np.concatenate([lo[key], hi[key]]))
+    late = ctx.ns_ensemble(prob, 6, **dict(kw, forced_exact=False))
+    assert (late["logz"] != a["logz"]).any()      # (at 8 live points per dimension forced updates do occur)
+    prob = inputs.problem("G5")
+    kw1 = dict(nlive=200, queue_size=16, walks=20, bound="single", enlarge=1000.0, entropy=[9], dlogz=0.5)
+    x = ctx.ns_ensemble(prob, 4, forced_exact=True, **kw1)
+    y = ctx.ns_ensemble(prob, 4, forced_exact=False, **kw1)
+    for key in ("logz", "niter", "ncall", "nbound"):
+        np.testing.assert_array_equal(x[key], y[key])
