@@ -113,7 +113,8 @@ struct NsArgs {
   double* run_shift;    // runs: ndim * ln(bootstrap expansion factor) of the rebuild just done
   // results
   double* records;  // runs x 8: logz, logzerr, niter, ncall, h, nbound, status, eff
-  double* fin_ws;   // runs x 3 nlive: ns_finish's per-point terms
+  double* fin_ws;   // runs x fin_stride: ns_finish's per-point terms (3 nlive) and, for large live sets, the sorted values
+  size_t fin_stride;
   // dh_ns_consume (one queue consumption as an operator of its own): death list of THIS call
   int dead_rel;     // 1: dead_logl rows are K wide and hold this call's deaths from index 0
   int* trace_slot;  // runs x K or null: slot of every death
@@ -554,11 +555,48 @@ constexpr int kEPT = 8;  // deaths per lane in the scan phase: K <= kEPT * kT
 
 // LDS of ns_consume: keys and slot sources by slot, the sorted slot order (padded to a power of two), the queue's
 // arrays and the buffer of low replacements
-__host__ __device__ inline size_t ns_consume_lds(int N, int K) {
+__host__ __device__ inline size_t ns_consume_lds_full(int N, int K) {
   size_t P = 1;
   while (P < (size_t)N) P <<= 1;
   if (P < 256) P = 256;  // (the slot order is sorted 256 entries at a time at least)
   return (size_t)N * 12 + (size_t)K * 52 + P * 2 + 64;
+}
+// Large live sets (round 4).  A fill makes at most K deaths, so only the K + 1 smallest live points by
+// (log-likelihood, slot) can take part in it: at least one of them outlives the fill and stands before every other
+// point, which therefore is never the worst.  Where the whole set does not fit the arrays above (nlive > 32 kT, the
+// register sort's reach, or more than 150 KB), ns_consume first SELECTS those K + 1 from the keys in global memory
+// (radix select on the order-preserving integer image of the key, ties at the threshold by lowest slot), compacts
+// them in slot order -- so that "lowest slot first" among equal values is "lowest compact index first" -- and
+// runs the same consumption on that subset; the slots of the death list and of the replacements are translated back
+// when they are stored.  Same deaths, same replacements, same evidence as the full arrays would give
+// (tests/test_gpu_ns_consume.py holds the two paths to each other and to the oracle).
+__host__ __device__ inline bool ns_consume_compact(int N, int K) {
+  return K + 1 < N && (N > 32 * kT || ns_consume_lds_full(N, K) > (size_t)150 * 1024);
+}
+__host__ __device__ inline bool ns_finish_big(int N) {  // ns_finish: keys by slot, keys in order, sorted slots in LDS?
+  size_t P = 1;
+  while (P < (size_t)N) P <<= 1;
+  return N > 32 * kT || (size_t)N * 16 + (P > 256 ? P : 256) * 2 + 64 > (size_t)150 * 1024;
+}
+__host__ __device__ inline size_t ns_fin_stride(int N) {  // doubles of ns_finish's workspace per run
+  size_t P = 1;
+  while (P < (size_t)N) P <<= 1;
+  return 3 * (size_t)N + (ns_finish_big(N) ? P : 0);
+}
+__host__ __device__ inline size_t ns_select_scratch(int N) {  // histogram, two lane masks per 64 slots, their prefixes
+  const size_t nm = ((size_t)N + 63) / 64;
+  return 256 * 4 + nm * 16 + nm * 8 + 64;
+}
+__host__ __device__ inline size_t ns_consume_lds(int N, int K) {
+  if (!ns_consume_compact(N, K)) return ns_consume_lds_full(N, K);
+  const size_t NC = (size_t)K + 1;
+  size_t P = 1;
+  while (P < NC) P <<= 1;
+  if (P < 256) P = 256;
+  size_t q = (size_t)K * 52, sc = ns_select_scratch(N);
+  if (q < sc) q = sc;  // (the selection's scratch lies where the queue's arrays come afterwards)
+  q = (q + 15) & ~(size_t)15;
+  return NC * 12 + q + P * 2 + NC * 2 + 64 + 16;
 }
 
 // The serial part of the queue consumption (sampler.py:741-776), run by wave 0: stale test, death record,
@@ -1131,40 +1169,145 @@ __global__ void __launch_bounds__(kT) ns_consume(NsArgs a) {
   if (a.run_mode && a.run_mode[run] == MODE_WAIT) return;
   if (mode == MODE_BOUND && a.bstatus[run] != DH_OK) return;
   long long pt_ = a.prof ? clock64() : 0;
+  // NC = the slots the consumption works on: all of them, or the K + 1 smallest in slot order (ns_consume_compact)
+  const bool compact = ns_consume_compact(N, K);
+  const int NC = compact ? K + 1 : N;
   int P = 1;
-  while (P < N) P <<= 1;
-  double* skey = (double*)smem;     // N   live log-likelihoods by slot
-  double* ql = skey + N;            // K   proposal logl
+  while (P < NC) P <<= 1;
+  size_t qbytes = (size_t)K * 52;
+  if (compact) {
+    const size_t sc = ns_select_scratch(N);
+    if (qbytes < sc) qbytes = sc;
+    qbytes = (qbytes + 15) & ~(size_t)15;
+  }
+  double* skey = (double*)smem;     // NC  live log-likelihoods by (compact) slot
+  double* ql = skey + NC;           // K   proposal logl
   double* dcur = ql + K;            // K   death list: logl of the dead point
   double* bkey = dcur + K;          // K   low replacements of this fill (see consume_sorted)
-  int* src = (int*)(bkey + K);      // N   queue index now living in the slot, -1 = original
-  int* qc = src + N;                // K   calls
+  int* qc = (int*)(bkey + K);       // K   calls
   int* dj = qc + K;                 // K   death list: queue index of the replacement
   int* dslot = dj + K;              // K               slot
   int* dsrc = dslot + K;            // K               content source at death
   int* qborn = dsrc + K;            // K   (per-point bookkeeping only) death index at which entry j went live
   int* bslot = qborn + K;           // K
   int* bsrc = bslot + K;            // K
-  unsigned short* sidx = (unsigned short*)(bsrc + K);  // P   slots in ascending (logl, slot) order; 0xFFFF = padding
+  int* src = (int*)((unsigned char*)ql + qbytes);      // NC  queue index now living in the slot, -1 = original
+  unsigned short* sidx = (unsigned short*)(src + NC);  // P   slots in ascending (logl, slot) order; 0xFFFF = padding
+  unsigned short* cslot = sidx + (P > kT ? P : kT);    // NC  (compact) the live slot behind a compact index
   __shared__ int misc[8];
   __shared__ double wred[2][4];
   __shared__ double bcast[4];
   __shared__ long long lred[4];
-  for (int i = t; i < N; i += kT) {
-    skey[i] = a.live_logl[(size_t)run * N + i];
-    src[i] = -1;
+  __shared__ int sel_i[4];
+  __shared__ unsigned long long sel_u[2];
+  double sel_v = INFINITY;  // compact: the threshold value (the (K + 1)-th smallest key) ...
+  int sel_extra = 0;        // ... and how many live points OUTSIDE the subset carry it
+  if (!compact) {
+    for (int i = t; i < N; i += kT) {
+      skey[i] = a.live_logl[(size_t)run * N + i];
+      src[i] = -1;
+    }
+  } else {
+    const double* keys = a.live_logl + (size_t)run * N;
+    int* hist = (int*)ql;                                            // 256
+    const int nm = (N + 63) >> 6;
+    unsigned long long* lmask = (unsigned long long*)(hist + 256);   // nm: lanes below the threshold
+    unsigned long long* tmask = lmask + nm;                          // nm: lanes at the threshold
+    int* pless = (int*)(tmask + nm);                                 // nm: exclusive prefixes of the two counts
+    int* ptie = pless + nm;
+    // the order-preserving image of a key (-0 folded into +0, as the double comparison has it)
+    auto ord = [](double x) -> unsigned long long {
+      const unsigned long long b = (unsigned long long)__double_as_longlong(x + 0.0);
+      return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+    };
+    unsigned long long prefix = 0, mask = 0;
+    int want = K + 1;  // rank (1-based) of the threshold among the keys that share the prefix
+    for (int pass = 0; pass < 8; ++pass) {
+      const int shift = 56 - 8 * pass;
+      hist[t] = 0;
+      __syncthreads();
+      for (int i = t; i < N; i += kT) {
+        const unsigned long long o = ord(keys[i]);
+        if ((o & mask) == prefix) atomicAdd(&hist[(int)((o >> shift) & 255ull)], 1);
+      }
+      __syncthreads();
+      if (t == 0) {
+        int cum = 0, d = 0;
+        while (d < 255 && cum + hist[d] < want) cum += hist[d++];
+        sel_i[0] = d;
+        sel_i[1] = want - cum;
+        sel_i[2] = hist[d];
+      }
+      __syncthreads();
+      prefix |= (unsigned long long)sel_i[0] << shift;
+      mask |= 255ull << shift;
+      want = sel_i[1];
+      __syncthreads();
+    }
+    // `want` of the keys equal to the threshold belong to the subset: the lowest slots
+    const int need = want, eq_total = sel_i[2];
+    sel_extra = eq_total - need;
+    for (int mi = wv; mi < nm; mi += kT / 64) {
+      const int i = mi * 64 + lane;
+      const unsigned long long o = i < N ? ord(keys[i]) : ~0ull;
+      const unsigned long long lm = __ballot(i < N && o < prefix), tm = __ballot(i < N && o == prefix);
+      if (lane == 0) {
+        lmask[mi] = lm;
+        tmask[mi] = tm;
+      }
+    }
+    __syncthreads();
+    if (wv == 0) {  // exclusive prefixes of the per-mask counts, one wavefront
+      int bl = 0, bt = 0;
+      for (int m0 = 0; m0 < nm; m0 += 64) {
+        const int mi = m0 + lane;
+        const int cl = mi < nm ? __popcll(lmask[mi]) : 0, ct = mi < nm ? __popcll(tmask[mi]) : 0;
+        int sl = cl, st = ct;
+        for (int off = 1; off < 64; off <<= 1) {
+          const int yl = __shfl_up(sl, off), yt = __shfl_up(st, off);
+          if (lane >= off) {
+            sl += yl;
+            st += yt;
+          }
+        }
+        if (mi < nm) {
+          pless[mi] = bl + sl - cl;
+          ptie[mi] = bt + st - ct;
+        }
+        bl += __shfl(sl, 63);
+        bt += __shfl(st, 63);
+      }
+    }
+    __syncthreads();
+    for (int mi = wv; mi < nm; mi += kT / 64) {
+      const int i = mi * 64 + lane;
+      const unsigned long long lm = lmask[mi], tm = tmask[mi], below = (1ull << lane) - 1ull;
+      const int tb = ptie[mi] + __popcll(tm & below);
+      const bool take = ((lm >> lane) & 1ull) || (((tm >> lane) & 1ull) && tb < need);
+      if (take) {
+        const int pos = pless[mi] + __popcll(lm & below) + (tb < need ? tb : need);
+        skey[pos] = keys[i];
+        cslot[pos] = (unsigned short)i;
+        src[pos] = -1;
+      }
+      if (((tm >> lane) & 1ull) && tb == 0) sel_u[0] = (unsigned long long)__double_as_longlong(keys[i]);
+    }
+    __syncthreads();
+    sel_v = __longlong_as_double((long long)sel_u[0]);
+    __syncthreads();  // (the scratch is the queue's from here on)
   }
+  auto real_slot = [&](int sl) -> int { return compact ? (int)cslot[sl] : sl; };
   __syncthreads();
   NS_PROF(16);
   {
     const int nsidx = P > kT ? P : kT;
     switch (nsidx / kT) {
-      case 1: sort_slots<1>(skey, sidx, N, nsidx); break;
-      case 2: sort_slots<2>(skey, sidx, N, nsidx); break;
-      case 4: sort_slots<4>(skey, sidx, N, nsidx); break;
-      case 8: sort_slots<8>(skey, sidx, N, nsidx); break;
-      case 16: sort_slots<16>(skey, sidx, N, nsidx); break;
-      default: sort_slots<32>(skey, sidx, N, nsidx); break;
+      case 1: sort_slots<1>(skey, sidx, NC, nsidx); break;
+      case 2: sort_slots<2>(skey, sidx, NC, nsidx); break;
+      case 4: sort_slots<4>(skey, sidx, NC, nsidx); break;
+      case 8: sort_slots<8>(skey, sidx, NC, nsidx); break;
+      case 16: sort_slots<16>(skey, sidx, NC, nsidx); break;
+      default: sort_slots<32>(skey, sidx, NC, nsidx); break;
     }
   }
   NS_PROF(17);
@@ -1212,7 +1355,7 @@ __global__ void __launch_bounds__(kT) ns_consume(NsArgs a) {
   const long long room = a.dead_rel ? (long long)K + 1 : a.cap - it0;
   int walked = 0;
   if (!a.serial_walk) {
-    walked = consume_parallel(skey, sidx, src, ql, dcur, dj, dslot, dsrc, bkey, bslot, qborn, N, K, room, &misc[4],
+    walked = consume_parallel(skey, sidx, src, ql, dcur, dj, dslot, dsrc, bkey, bslot, qborn, NC, K, room, &misc[4],
                               &misc[0], &bcast[2], run == 0 ? a.prof : nullptr);
     if (walked && t == 0) misc[1] = -1;
     if (a.prof && run == 0 && t == 0 && !walked) atomicAdd((unsigned long long*)&a.prof[10], 1ull);
@@ -1220,7 +1363,7 @@ __global__ void __launch_bounds__(kT) ns_consume(NsArgs a) {
   if (!walked && t < 64) {
     int jcap;
     double nm;
-    const int nd = consume_sorted(skey, sidx, src, ql, dcur, dj, dslot, dsrc, bkey, bslot, bsrc, N, K, room, K + 1,
+    const int nd = consume_sorted(skey, sidx, src, ql, dcur, dj, dslot, dsrc, bkey, bslot, bsrc, NC, K, room, K + 1,
                                   &jcap, &nm, t);
     if (t == 0) {
       misc[0] = nd;
@@ -1253,7 +1396,9 @@ __global__ void __launch_bounds__(kT) ns_consume(NsArgs a) {
     int ntail = 0;
     if (ndead > 0 && bcast[2] == dcur[ndead - 1]) {
       const double x = dcur[ndead - 1];
-      for (int sl = t; sl < N; sl += kT) ntail += (src[sl] >= 0 ? ql[src[sl]] : skey[sl]) == x ? 1 : 0;
+      for (int sl = t; sl < NC; sl += kT) ntail += (src[sl] >= 0 ? ql[src[sl]] : skey[sl]) == x ? 1 : 0;
+      // (compact: no death value exceeds the threshold, and the points left out are not below it)
+      if (t == 0 && x == sel_v) ntail += sel_extra;
     }
     if (t == 0) pl_int[2] = 0;
     __syncthreads();
@@ -1499,12 +1644,12 @@ __global__ void __launch_bounds__(kT) ns_consume(NsArgs a) {
   // ---- replay the walk up to the stop index (once per run): the sorted order is untouched ----
   if (nkeep < ndead) {
     __syncthreads();
-    for (int i = t; i < N; i += kT) src[i] = -1;
+    for (int i = t; i < NC; i += kT) src[i] = -1;
     __syncthreads();
     if (t < 64) {
       int jc;
       double nm;
-      consume_sorted(skey, sidx, src, ql, dcur, dj, dslot, dsrc, bkey, bslot, bsrc, N, K,
+      consume_sorted(skey, sidx, src, ql, dcur, dj, dslot, dsrc, bkey, bslot, bsrc, NC, K,
                      a.dead_rel ? (long long)K + 1 : a.cap - it0, nkeep, &jc, &nm, t);
       if (t == 0) bcast[2] = nm;
     }
@@ -1575,7 +1720,7 @@ __global__ void __launch_bounds__(kT) ns_consume(NsArgs a) {
   for (int e = t; e < nkeep; e += kT) a.dead_logl[dbase + e] = dcur[e];
   if (a.trace_slot)
     for (int e = t; e < nkeep; e += kT) {
-      a.trace_slot[(size_t)run * K + e] = dslot[e];
+      a.trace_slot[(size_t)run * K + e] = real_slot(dslot[e]);
       a.trace_src[(size_t)run * K + e] = dj[e];
     }
   if (a.trace_n && t == 0) {
@@ -1590,20 +1735,20 @@ __global__ void __launch_bounds__(kT) ns_consume(NsArgs a) {
       for (int j = e ? dj[e - 1] + 1 : 0; j <= dj[e]; ++j) nc += qc[j];
       const int sj = dsrc[e];
       a.dead_nc[dbase + e] = (int)nc;
-      a.dead_id[dbase + e] = dslot[e];
+      a.dead_id[dbase + e] = real_slot(dslot[e]);
       // self.it starts at 1 (sampler.py:396): the replacement of death index i (0-based) is born at i + 1
-      a.dead_it[dbase + e] = sj < 0 ? a.live_it[(size_t)run * N + dslot[e]] : (int)(it0 + qborn[sj] + 1);
+      a.dead_it[dbase + e] = sj < 0 ? a.live_it[(size_t)run * N + real_slot(dslot[e])] : (int)(it0 + qborn[sj] + 1);
     }
     __syncthreads();
-    for (int sl = t; sl < N; sl += kT)
-      if (src[sl] >= 0) a.live_it[(size_t)run * N + sl] = (int)(it0 + qborn[src[sl]] + 1);
+    for (int sl = t; sl < NC; sl += kT)
+      if (src[sl] >= 0) a.live_it[(size_t)run * N + real_slot(sl)] = (int)(it0 + qborn[src[sl]] + 1);
   }
   // dead-point coordinates (optional), in death order
   if (a.store_samples) {
     double* to = a.dead_u + ((size_t)run * a.cap + it0) * D;
     for (int x = t; x < nkeep * D; x += kT) {
       const int e = x / D, j = x - e * D;
-      const int s = dslot[e], sj = dsrc[e];
+      const int s = real_slot(dslot[e]), sj = dsrc[e];
       to[x] = sj < 0 ? a.live_u[((size_t)run * N + s) * D + j] : a.r_u[((size_t)run * K + sj) * D + j];
     }
   }
@@ -1614,12 +1759,12 @@ __global__ void __launch_bounds__(kT) ns_consume(NsArgs a) {
   // the 1.7 ms this kernel took per fill at D = 200)
   if (t == 0) misc[4] = 0;
   __syncthreads();
-  for (int s = t; s < N; s += kT) {
+  for (int s = t; s < NC; s += kT) {
     const int sj = src[s];
     if (sj >= 0) {
-      a.live_logl[(size_t)run * N + s] = ql[sj];
+      a.live_logl[(size_t)run * N + real_slot(s)] = ql[sj];
       const int c = atomicAdd(&misc[4], 1);  // at most K slots change
-      dslot[c] = s;
+      dslot[c] = real_slot(s);
       dj[c] = sj;
     }
   }
@@ -1701,25 +1846,47 @@ __global__ void __launch_bounds__(kT) ns_finish(NsArgs a) {
     return;
   }
   // the final live log-likelihoods, ascending: the slots sorted by (value, slot) with the register network of
-  // ns_consume, then the values in that order (the integration below does not care which slot a value came from)
+  // ns_consume, then the values in that order (the integration below does not care which slot a value came from).
+  // Live sets beyond the sort's reach or the LDS (ns_finish_big): the values alone, by a bitonic network in global
+  // memory behind the per-point terms (once per run; padded with +inf to a power of two).
   int P = 1;
   while (P < N) P <<= 1;
   const int nsidx = P > kT ? P : kT;
-  double* skey = (double*)smem;                                // N   by slot
-  double* sorted = skey + N;                                   // N   ascending
-  unsigned short* sidx = (unsigned short*)(sorted + N);        // max(P, kT)
-  for (int i = t; i < N; i += kT) skey[i] = a.live_logl[(size_t)run * N + i];
-  __syncthreads();
-  switch (nsidx / kT) {
-    case 1: sort_slots<1>(skey, sidx, N, nsidx); break;
-    case 2: sort_slots<2>(skey, sidx, N, nsidx); break;
-    case 4: sort_slots<4>(skey, sidx, N, nsidx); break;
-    case 8: sort_slots<8>(skey, sidx, N, nsidx); break;
-    case 16: sort_slots<16>(skey, sidx, N, nsidx); break;
-    default: sort_slots<32>(skey, sidx, N, nsidx); break;
+  double* sorted;
+  if (ns_finish_big(N)) {
+    sorted = a.fin_ws + (size_t)run * a.fin_stride + 3 * (size_t)N;
+    for (int i = t; i < P; i += kT) sorted[i] = i < N ? a.live_logl[(size_t)run * N + i] + 0.0 : INFINITY;
+    __syncthreads();
+    for (int k2 = 2; k2 <= P; k2 <<= 1)
+      for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
+        for (int x = t; x < P / 2; x += kT) {
+          const int lo = 2 * x - (x & (j2 - 1)), hi = lo + j2;  // the pair (lo, lo ^ j2) with lo's bit j2 clear
+          const double va = sorted[lo], vb = sorted[hi];
+          const bool up = (lo & k2) == 0;
+          if ((va > vb) == up) {
+            sorted[lo] = vb;
+            sorted[hi] = va;
+          }
+        }
+        __syncthreads();
+      }
+  } else {
+    double* skey = (double*)smem;                                // N   by slot
+    sorted = skey + N;                                           // N   ascending
+    unsigned short* sidx = (unsigned short*)(sorted + N);        // max(P, kT)
+    for (int i = t; i < N; i += kT) skey[i] = a.live_logl[(size_t)run * N + i];
+    __syncthreads();
+    switch (nsidx / kT) {
+      case 1: sort_slots<1>(skey, sidx, N, nsidx); break;
+      case 2: sort_slots<2>(skey, sidx, N, nsidx); break;
+      case 4: sort_slots<4>(skey, sidx, N, nsidx); break;
+      case 8: sort_slots<8>(skey, sidx, N, nsidx); break;
+      case 16: sort_slots<16>(skey, sidx, N, nsidx); break;
+      default: sort_slots<32>(skey, sidx, N, nsidx); break;
+    }
+    for (int i = t; i < N; i += kT) sorted[i] = skey[sidx[i]];
+    __syncthreads();
   }
-  for (int i = t; i < N; i += kT) sorted[i] = skey[sidx[i]];
-  __syncthreads();
   // The final live points, lowest first (sampler.py:780-930).  What Results reports is
   // compute_integrals over the whole run (sampler.py:1342-1348, utils.py:1411-1467): ln Z the
   // accumulated logaddexp, and the partial informations H_i normalised by the FINAL Z,
@@ -1734,7 +1901,7 @@ __global__ void __launch_bounds__(kT) ns_finish(NsArgs a) {
   __shared__ double wtot[kT / 64];
   NsRun& r = a.st[run];
   const double lv0 = r.logvol, dead_prev = r.dead_prev;
-  double* W = a.fin_ws + (size_t)run * 3 * N;  // trapezoid ln-weights
+  double* W = a.fin_ws + (size_t)run * a.fin_stride;  // trapezoid ln-weights
   double* DL = W + N;                          // -d ln X
   double* T = DL + N;                          // ln dX, then the L e^L terms
   // a plateau still being worked off keeps its volume steps for its remaining points, the rest of the final
@@ -1829,16 +1996,10 @@ int dh_ns_consume(dh_ctx* ctx, int runs, int nlive, int queue_size, double dlogz
     return fail(ctx, DH_ERR_ARG, "ns_consume: bad arguments");
   const int R = runs, N = nlive, K = queue_size;
   if (K > kEPT * kT) return fail(ctx, DH_ERR_ARG, "ns_consume: queue_size %d > %d", K, kEPT * kT);
-  // the register sort of the live slots is built for at most 32 keys per thread (sort_slots<32>)
-  if (N > 32 * kT) return fail(ctx, DH_ERR_ARG, "ns_consume: nlive %d > %d", N, 32 * kT);
-  size_t lds_fin = (size_t)N * 16 + 64;  // ns_finish: the keys by slot, the keys in order, the sorted slots
-  {
-    size_t Pf = 1;
-    while (Pf < (size_t)N) Pf <<= 1;
-    lds_fin += (Pf > 256 ? Pf : 256) * 2;
-  }
-  const size_t lds_cons = ns_consume_lds(N, K);
-  const size_t lds_max = lds_cons > lds_fin ? lds_cons : lds_fin;
+  // slots travel as 16-bit indices; beyond the register sort's 32 keys per thread (or the LDS) the consumption works on
+  // the K + 1 smallest live points (ns_consume_compact)
+  if (N > 65535) return fail(ctx, DH_ERR_ARG, "ns_consume: nlive %d > 65535", N);
+  const size_t lds_max = ns_consume_lds(N, K);
   if (lds_max > 150 * 1024) return fail(ctx, DH_ERR_ARG, "ns_consume: nlive/queue too large for LDS");
   NsArgs a{};
   a.serial_walk = (getenv("DH_NS_SERIAL") && atoi(getenv("DH_NS_SERIAL")) != 0) ? 1 : 0;
@@ -1907,7 +2068,7 @@ int dh_ns_consume(dh_ctx* ctx, int runs, int nlive, int queue_size, double dlogz
       !hip_ok(ctx, hipFuncSetAttribute((const void*)ns_start, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max), "hipFuncSetAttribute(ns_start)"))
     return DH_ERR_HIP;
   hipLaunchKernelGGL(ns_start, dim3(R), dim3(kT), 0, s, a);  // loglstar = min, lmax = max of live_logl
-  hipLaunchKernelGGL(ns_consume, dim3(R), dim3(kT), lds_cons, s, a);
+  hipLaunchKernelGGL(ns_consume, dim3(R), dim3(kT), lds_max, s, a);
   if (!hip_ok(ctx, hipGetLastError(), "ns_consume launch")) return DH_ERR_HIP;
   std::vector<int> tn((size_t)R * 2);
   if (!down(ctx, st.data(), a.st, (size_t)R) || !down(ctx, live_logl, a.live_logl, (size_t)R * N) ||
@@ -1983,7 +2144,7 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
   const int N = nlive, D = ndim, K = queue_size, R = runs;
   // the register sort of the live slots is built for at most 32 keys per thread (sort_slots<32>); the LDS bound of
   // ns_finish below is tighter today, this one is the sort's own
-  if (N > 32 * kT) return fail(ctx, DH_ERR_ARG, "ns_ensemble: nlive %d > %d", N, 32 * kT);
+  if (N > 65535) return fail(ctx, DH_ERR_ARG, "ns_ensemble: nlive %d > 65535 (slots travel as 16-bit indices)", N);
   const int me = bound_multi ? (N / (2 * D) > 0 ? N / (2 * D) : 1) : 1;
   NsArgs a{};
   a.runs = R;
@@ -2087,7 +2248,7 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
                o_ba = take((size_t)R * me * dd * 8), o_bx = take((size_t)R * me * dd * 8 * (a.forced_exact ? 2 : 1)),
                o_bl = take((size_t)R * me * D * 8), o_bg = take((size_t)R * me * 8),
                o_rec = take((size_t)R * 8 * 8), o_ent = take((size_t)n_words * 4),
-               o_fw = take((size_t)R * 3 * N * 8), o_cum = take((size_t)R * me * 8), o_be = take((size_t)R * 32),
+               o_fw = take((size_t)R * ns_fin_stride(N) * 8), o_cum = take((size_t)R * me * 8), o_be = take((size_t)R * 32),
                o_rs = take((size_t)R * 8), o_ff = take((size_t)R * 4), o_se = take((size_t)R * 32),
                o_boot = take(bootstrap > 0 ? bootstrap_ws_bytes(R, N, D, me, bootstrap) : 8),
                o_lit = take(want_pt ? (size_t)R * N * 4 : 8), o_pid = take(want_pt ? (size_t)R * a.cap * 4 : 8),
@@ -2146,6 +2307,7 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
   a.b_lv = (double*)(base + o_bg);
   a.records = (double*)(base + o_rec);
   a.fin_ws = (double*)(base + o_fw);
+  a.fin_stride = ns_fin_stride(N);
   a.b_cum = (double*)(base + o_cum);
   a.boot_ent = (uint64_t*)(base + o_be);
   a.run_shift = (double*)(base + o_rs);
@@ -2171,11 +2333,11 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
   hipLaunchKernelGGL(ns_init, dim3(R), dim3(kT), 0, s, a, d_ent, n_words, first_run);
   int rc = eval_launch_dev(ctx, problem, R * N, a.live_u, a.live_v, a.live_logl);
   if (rc) return cleanup(rc);
-  size_t lds_fin = (size_t)N * 16 + 64;  // ns_finish: the keys by slot, the keys in order, the sorted slots
-  {
+  size_t lds_fin = 64;  // ns_finish: the keys by slot, the keys in order, the sorted slots (large sets: global memory)
+  if (!ns_finish_big(N)) {
     size_t Pf = 1;
     while (Pf < (size_t)N) Pf <<= 1;
-    lds_fin += (Pf > 256 ? Pf : 256) * 2;
+    lds_fin += (size_t)N * 16 + (Pf > 256 ? Pf : 256) * 2;
   }
   const size_t lds_cons = ns_consume_lds(N, K);
   if (K > kEPT * kT) return cleanup(fail(ctx, DH_ERR_ARG, "ns_ensemble: queue_size %d > %d", K, kEPT * kT));

@@ -130,16 +130,12 @@ def run_static(prob, nlive=500, bound='multi', sample='rwalk', queue_size=None,
     from 1; 0 = initial point), samples_nc (likelihood calls spent on the point's
     replacement; 1 for the final live points).
 
-    nlive <= 8192: the queue is consumed in chunks of <= 512 entries by the device
-    operator dh_ns_consume, which keeps the run's keys, their sorted order and the
-    chunk in LDS (12 nlive + 2 P + 52 * 512 + 64 bytes <= 150 KB, P = nlive rounded up
-    to a power of two; slots are 16-bit)."""
-    p2 = 1
-    while p2 < nlive:
-        p2 *= 2
-    if nlive < 4 or 12 * nlive + 2 * max(p2, 256) + 52 * 512 + 64 > 150 * 1024:
-        raise ValueError(f"run_static: nlive={nlive} is outside what the device's queue consumption holds in LDS "
-                         "(4 <= nlive <= 8192)")
+    nlive <= 65535 (slots are 16-bit): the queue is consumed in chunks of <= 512 entries by the device
+    operator dh_ns_consume, which keeps the run's keys, their sorted order and the chunk in LDS, or -- above
+    nlive = 8192 -- the 513 smallest of them, selected from the keys in global memory (csrc/ns.hip,
+    ns_consume_compact)."""
+    if nlive < 4 or nlive > 65535:
+        raise ValueError(f"run_static: nlive={nlive} is outside the device's queue consumption (4 <= nlive <= 65535)")
     be = get_backend()
     if rstate is None:
         rstate = np.random.default_rng()

@@ -405,10 +405,11 @@ int dh_ns_consume(dh_ctx* ctx, int runs, int nlive, int queue_size, double dlogz
  * device for `runs` independent runs at once.  Dimensions: any ndim <= 512 (above 32 the walkers are the
  * wave-per-walker kernels, above 44 the bound is the multi-workgroup Ellipsoid.update: BASELINE config C4 -- or,
  * bound_multi=1, the wide MultiEllipsoid.update, whose recursion the host drives: such a run synchronises the
- * stream on its rebuild fills); sample='unif' ndim <= 32.  Sizes: the queue
- * consumption keeps a run's keys, their sorted order and the queue in LDS, 12 nlive + 2 P + 52 queue_size bytes
- * <= 150 KB (P = nlive rounded up to a power of two) and queue_size <= 2048 (nlive 2000: any queue; 4000: <= 1870;
- * 5000: <= 1480); DH_ERR_ARG otherwise.  Run r seeds from
+ * stream on its rebuild fills); sample='unif' ndim <= 32.  Sizes: nlive <= 65535 (slots travel as 16-bit indices),
+ * queue_size <= 2048.  The queue consumption keeps a run's keys, their sorted order and the queue in LDS while
+ * 12 nlive + 2 P + 52 queue_size bytes <= 150 KB (P = nlive rounded up to a power of two) and nlive <= 8192; beyond
+ * that it selects the queue_size + 1 smallest live points from the keys in global memory first -- the only ones a fill
+ * can touch -- and works on those (same deaths, same evidence).  DH_ERR_ARG otherwise.  Run r seeds from
  * SeedSequence(entropy) children keyed on first_run + r (independent of how the
  * ensemble is sharded).  records: runs x 8 doubles {logz, logzerr, niter, ncall,
  * h, nbound, status (0 ok, 1 max_fills hit, -1 failed), eff%}.

@@ -58,11 +58,14 @@ def test_replay_of_a_real_reference_fill(ctx, tag):
 
 
 @pytest.mark.parametrize("nlive,K,runs", [(300, 100, 5), (2000, 512, 3), (64, 17, 4), (100, 256, 3), (1000, 2048, 2),
-                                          (5000, 1024, 2)])
+                                          (5000, 1024, 2), (8192, 2048, 2), (9000, 700, 2), (20000, 2048, 2),
+                                          (40000, 1500, 1)])
 def test_fill_chains_vs_oracle(ctx, nlive, K, runs):
     """Several runs, consecutive fills, each run's state carried from fill to fill on both sides.
     The queue mixes entries above and below the moving threshold (stale ones are discarded);
-    dlogz is set so that the stopping rule fires inside one of the last fills."""
+    dlogz is set so that the stopping rule fires inside one of the last fills.  The last four shapes (round 4) are
+    beyond what the kernel holds in LDS at once -- nlive = 8192 together with K = 2048, nlive > 8192 -- and go
+    through its selection of the K + 1 smallest live points (ns_consume_compact)."""
     rng = np.random.default_rng(nlive + K)
     # a Gaussian-like likelihood in 6-D: logl = -r^2/2, live points uniform in a ball of radius 6
     def draw(n, rad):
@@ -106,7 +109,8 @@ def test_fill_chains_vs_oracle(ctx, nlive, K, runs):
             np.testing.assert_array_equal(out["dead_src"][i], ref["dead_src"])
             assert bool(out["stopped"][i]) == ref["stopped"]
             s = states[r]
-            np.testing.assert_allclose(state[r, 0], s.logvol, rtol=1e-12)  # -(it * dlv) vs it subtractions
+            # -(it * dlv) on the device against `it` subtractions in the oracle (up to 3e5 of them at nlive = 40 000)
+            np.testing.assert_allclose(state[r, 0], s.logvol, rtol=1e-12 if nlive <= 5000 else 2e-11)
             np.testing.assert_allclose(state[r, 1], s.logz, rtol=0, atol=1e-10)
             np.testing.assert_allclose(state[r, 2], s.h, rtol=1e-9, atol=1e-12)
             np.testing.assert_allclose(state[r, 3], s.logzvar, rtol=1e-8, atol=1e-14)
@@ -173,8 +177,9 @@ def test_whole_run_with_plateaus_is_compute_integrals(ctx):
         assert abs(lz2 - r["logz"][i]) > 1e-8
 
 
+@pytest.mark.parametrize("nlive", [300, 9000])
 @pytest.mark.parametrize("nlev", [40, 400, 3000])
-def test_ties_die_lowest_slot_first_and_take_the_plateau_steps(ctx, nlev):
+def test_ties_die_lowest_slot_first_and_take_the_plateau_steps(ctx, nlev, nlive):
     """Equal log-likelihoods among the live points (rwalk hands back its start point when no step was accepted) die
     lowest slot first -- np.argmin's rule in the reference (sampler.py:1107) -- also when the tie is between an original
     live point and a replacement made earlier in the same fill, and their deaths take the reference's PLATEAU volume
@@ -182,9 +187,11 @@ def test_ties_die_lowest_slot_first_and_take_the_plateau_steps(ctx, nlev):
     instead of ln((N + 1) / N).  Values drawn from a small set force many plateaus, also across fill boundaries; the
     oracle runs with plateau=True (the restatement that is bit-identical to the recorded real run).  40 levels: groups
     of dozens of equal proposals (the serial walk takes those fills); 400 / 3000 levels: pairs and triples, settled
-    inside the parallel walk."""
+    inside the parallel walk.  nlive = 9000 (round 4): the same through the selection of the K + 1 smallest live
+    points, where with 40 levels the whole subset and hundreds of points outside it share one value (ties at the
+    threshold are taken lowest slot first, and the plateau's multiplicity counts the points left outside)."""
     rng = np.random.default_rng(3 + nlev)
-    nlive, K, runs = 300, 200, 4
+    K, runs = 200, 4 if nlive == 300 else 2
     vals = -np.sort(rng.random(nlev) * 20)  # nlev distinct levels
     live = vals[rng.integers(0, nlev, size=(runs, nlive))].copy()
     ref_live = live.copy()

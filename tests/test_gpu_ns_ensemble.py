@@ -253,3 +253,20 @@ def test_forced_update_inside_the_fill_is_per_run_and_changes_nothing_without_fo
     y = ctx.ns_ensemble(prob, 4, forced_exact=False, **kw1)
     for key in ("logz", "niter", "ncall", "nbound"):
         np.testing.assert_array_equal(x[key], y[key])
+
+
+def test_twenty_thousand_live_points(ctx):
+    """the resident loop beyond nlive = 8192 (the queue consumption selects the K + 1
+    smallest live points from the keys in global memory; the final live points are sorted in global memory): two runs
+    of 20 000 live points on the 5-D correlated Normal, queue of 1024.  ln Z against the analytic value with the
+    run's own error estimate (sqrt(H / N) ~ 0.02), and the dead points in order."""
+    prob = inputs.problem("G5")
+    r = ctx.ns_ensemble(prob, 2, 20000, 1024, walks=25, bound="multi", entropy=[20, 0, 0, 0], dlogz=0.01,
+                        max_iter=600000, want_dead_logl=True)
+    assert (r["status"] == 0).all()
+    for i in range(2):
+        n = int(r["niter"][i])
+        assert n > 150000
+        assert (np.diff(r["dead_logl"][i, :n]) >= 0).all()
+        assert abs(r["logz"][i] - prob.logz_truth) < 5 * r["logzerr"][i] + 0.02, (r["logz"][i], prob.logz_truth)
+        assert 0.01 < r["logzerr"][i] < 0.04
