@@ -103,6 +103,7 @@ dh_ctx* dh_create(int device) {
   }
   dh_ctx* ctx = new dh_ctx();
   ctx->device = device;
+  if (const char* e = getenv("DH_COOP_LAUNCH")) ctx->coop_launch = atoi(e) != 0 ? 1 : 0;
   if (const char* e = getenv("DH_RWALK_FORM")) ctx->rwalk_form = atoi(e) == 1 ? 1 : atoi(e) == 2 ? 2 : 0;
   if (const char* e = getenv("DH_RWALK_ITEMS")) ctx->rwalk_items = atoi(e) != 0;
   if (const char* e = getenv("DH_RWALK_ITEMS_MB")) ctx->items_budget = (size_t)(atol(e) > 0 ? atol(e) : 1024) << 20;

@@ -66,6 +66,11 @@ struct dh_ctx {
   // rwalk kernel form (dh_set_rwalk_form): 0 / 2 = four lanes per walker (walkq.hip) wherever that kernel is
   // built -- decided by the problem alone, never by the launch size --, 1 = one walker per lane always
   int rwalk_form = 0;
+  // DH_COOP_LAUNCH=1: kernels whose WHOLE grid meets at spin barriers (k_root_parts, wide_eig*_kernel) go through
+  // hipLaunchCooperativeKernel, so that the runtime vouches for the co-residency the library otherwise derives from
+  // the occupancy query (and guards with a spin limit that fails the run instead of hanging the device).  Off by
+  // default: the cooperative path costs launch latency on the rebuild's critical path (EXPERIMENTS.md).
+  int coop_launch = 0;
   // unit-cube sampler form (env DH_CUBE_FORM): 0 = four lanes per walker for launches that would leave SIMDs empty with
   // one walker per lane, 1 = one walker per lane always, 2 = four lanes always (PCG64 streams, ndim <= 32)
   int cube_form = 0;
@@ -132,6 +137,26 @@ int rwalk_launch_runs(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, cons
                       int32_t* naccept, int32_t* nreject, uint64_t* rng_out, const double* run_loglstar,
                       const double* run_scale, const int* run_mode, int wpr, int my_mode,
                       const PhiloxKey* philox = nullptr);
+// Launch of a kernel whose whole grid must be resident at once (see dh_ctx::coop_launch).
+template <class A0, class A1>
+inline hipError_t launch_all_resident(dh_ctx* ctx, void (*fn)(A0, A1), dim3 grid, dim3 block, size_t lds, A0 a0, A1 a1) {
+  if (ctx->coop_launch) {
+    void* args[2] = {(void*)&a0, (void*)&a1};
+    return hipLaunchCooperativeKernel((const void*)fn, grid, block, args, (unsigned)lds, ctx->stream);
+  }
+  hipLaunchKernelGGL(fn, grid, block, lds, ctx->stream, a0, a1);
+  return hipSuccess;
+}
+template <class A0>
+inline hipError_t launch_all_resident(dh_ctx* ctx, void (*fn)(A0), dim3 grid, dim3 block, size_t lds, A0 a0) {
+  if (ctx->coop_launch) {
+    void* args[1] = {(void*)&a0};
+    return hipLaunchCooperativeKernel((const void*)fn, grid, block, args, (unsigned)lds, ctx->stream);
+  }
+  hipLaunchKernelGGL(fn, grid, block, lds, ctx->stream, a0);
+  return hipSuccess;
+}
+
 // walkq.hip: the same walk with four lanes per walker (ndim == ncdim in 2..32)
 int rwalkq_launch(dh_ctx* ctx, const ProblemDev& prob, int k, int ndim, const double* u0, const double* axes, int m,
                   const int32_t* axes_idx, double scale, double loglstar, int walks, const uint64_t* rng, double* u,

@@ -3495,7 +3495,8 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
     attr_fin = lds_fin;
   }
   if (!hip_ok(ctx, hipMemsetAsync(cnt, 0, b_cnt, ctx->stream), "memset(rebuild counters)")) return DH_ERR_HIP;
-  hipLaunchKernelGGL(k_root_parts, dim3(runs * rp), dim3(kThreads), lds, ctx->stream, a, rp);
+  if (!hip_ok(ctx, launch_all_resident(ctx, k_root_parts, dim3(runs * rp), dim3(kThreads), lds, a, rp), "k_root_parts launch"))
+    return DH_ERR_HIP;
   bool forked = false;
   if (a.fast && !(getenv("DH_ROOT_EIG_SIDE") && atoi(getenv("DH_ROOT_EIG_SIDE")) == 0)) {
     if (!ctx->side_stream) {

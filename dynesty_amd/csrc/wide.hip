@@ -2701,10 +2701,9 @@ static int wide_single_enqueue(dh_ctx* ctx, int runs, const double* pts, int n, 
       g.Wt = ws_wt;
       g.cold = eig_cold;
     }
-    if (gram)
-      hipLaunchKernelGGL(wide_eig2_kernel, dim3(runs * B), dim3(kRT), eig_lds, ctx->stream, g);
-    else
-      hipLaunchKernelGGL(wide_eig_kernel, dim3(runs * B), dim3(kRT), eig_lds, ctx->stream, g);
+    if (!hip_ok(ctx, launch_all_resident(ctx, gram ? wide_eig2_kernel : wide_eig_kernel, dim3(runs * B), dim3(kRT), eig_lds, g),
+                "wide_eig launch"))
+      return DH_ERR_HIP;
     a.phase = 2;
     hipLaunchKernelGGL(wide_single_kernel, dim3(runs), dim3(kRT), lds, ctx->stream, a);
     hipLaunchKernelGGL(wide_fmax_part_kernel, dim3(runs * P), dim3(kRT), lds_part, ctx->stream, a);

@@ -234,3 +234,25 @@ def test_ragged_batch_bootstrap(ctx, golden_bounding):
                                            rtol=1e-8)
     finally:
         backend.set_backend(None)
+
+
+def test_cooperative_launch_of_the_whole_grid_barrier_kernels(monkeypatch):
+    """DH_COOP_LAUNCH=1: the kernels whose whole grid meets at spin barriers -- the root's parts (k_root_parts) and
+    the multi-workgroup eigensolver of the wide bound (wide_eig2_kernel) -- go through hipLaunchCooperativeKernel,
+    which has the runtime vouch for the co-residency the library otherwise derives from the occupancy query.  Same
+    kernels, same results bit for bit (a 2000-point MultiEllipsoid.update, whose root has eight parts, and a 200-D
+    Ellipsoid.update)."""
+    from dynesty_amd import _lib
+    rng = np.random.default_rng(5)
+    pts = np.clip(0.5 + 0.1 * rng.standard_normal((2000, 25)), 0.001, 0.999)
+    wide = np.clip(0.5 + 0.05 * rng.standard_normal((1200, 200)), 0.001, 0.999)
+    outs = []
+    for coop in ("0", "1"):
+        monkeypatch.setenv("DH_COOP_LAUNCH", coop)
+        c = _lib.Context(0)
+        outs.append((c.rebuild(pts, multi=True), c.rebuild(wide, multi=False)))
+        del c
+    for a, b in zip(outs[0], outs[1]):
+        assert a["nells"] == b["nells"]
+        for key in ("ctrs", "covs", "ams", "axes", "logvol_ells"):
+            np.testing.assert_array_equal(a[key], b[key])
