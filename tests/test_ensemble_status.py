@@ -74,6 +74,6 @@ def test_run_static_refuses_an_nlive_the_device_cannot_hold():
 
     class P:
         ndim = 3
-    for nlive in (3, 8193, 20000):
+    for nlive in (3, 65536, 200000):  # (round 4: up to 65535 live points, slots are 16-bit)
         with pytest.raises(ValueError, match="nlive"):
             nested.run_static(P(), nlive=nlive)
