@@ -114,6 +114,7 @@ SIGNATURES = {
                            _vp, _vp]),
     "dh_set_rwalk_form": (_i, [_vp, _i]),
     "dh_ns_set_option": (_i, [_vp, _i, _dbl]),
+    "dh_ns_set_boundary": (_i, [_vp, _i, _vp]),
     "dh_set_rwalk_items": (_i, [_vp, _i, C.c_longlong]),
     "dh_slice_batch_philox": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _dbl, _dbl, _i, _i, _u64, _u64, _u64,
                                    _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -798,8 +799,11 @@ class Context:
                     want_dead_logl=False, sample='rwalk', slices=None,
                     rebuild_sync=False, want_samples=False, rng='pcg64', bootstrap=None, rebuild_every=0,
                     update_interval=None, first_update=None, maxiter=None, maxcall=None, logl_max=None,
-                    add_live=True, forced_exact=False):
+                    add_live=True, forced_exact=False, periodic=None, reflective=None):
         """Device-resident ensemble of static NS runs (dh_ns_ensemble).
+
+        periodic / reflective: lists of coordinate indices as NestedSampler takes them (dynesty.py:297-310); they reach
+        the rwalk and uniform samplers (dh_ns_set_boundary), the slice samplers ignore them as the reference's do.
 
         forced_exact=True: propose_live's forced bound update (sampler.py:484-489) inside the fill that finds a start
         point outside the bound, as the reference takes it (DH_NS_OPT_FORCED_EXACT); the default flags the run and
@@ -869,6 +873,14 @@ class Context:
                 1.0 if forced_exact else nan]
         for key, val in enumerate(opts):
             self._check(self.lib.dh_ns_set_option(self.handle, key, val))
+        bc = None
+        if periodic is not None or reflective is not None:
+            bc = np.zeros(nd, dtype=np.int8)
+            if periodic is not None:
+                bc[np.asarray(periodic, dtype=int)] = BC_PERIODIC
+            if reflective is not None:
+                bc[np.asarray(reflective, dtype=int)] = BC_REFLECT
+        self._check(self.lib.dh_ns_set_boundary(self.handle, nd if bc is not None else 0, _ptr(bc)))
         self._check(self.lib.dh_ns_ensemble(
             self.handle, self.problem(prob), int(runs), int(nlive), nd,
             int(queue_size), kind + ((1 if kind == 6 else 3) if rng == 'philox' else 0), int(walks),

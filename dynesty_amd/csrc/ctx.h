@@ -76,6 +76,8 @@ struct dh_ctx {
   int cube_form = 0;
   int num_cu = 256;  // hipDeviceProp_t::multiProcessorCount
   // options of the resident run loop (dh_ns_set_option, keys DH_NS_OPT_* of dynhip.h); NaN = the reference's default
+  // per-dimension DH_BC_* flags for the resident loop's proposals (dh_ns_set_boundary); empty = all hard
+  std::vector<int8_t> ns_bc;
   double ns_opt[8] = {__builtin_nan(""), __builtin_nan(""), __builtin_nan(""), __builtin_nan(""),
                       __builtin_nan(""), __builtin_nan(""), __builtin_nan(""), __builtin_nan("")};
   // rwalk, four lanes per walker: the walkers' PCG64 item streams written out by a generator pass ahead of the walk

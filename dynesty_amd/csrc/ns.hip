@@ -2107,6 +2107,18 @@ int dh_ns_set_option(dh_ctx* ctx, int key, double value) {
   return DH_OK;
 }
 
+int dh_ns_set_boundary(dh_ctx* ctx, int ndim, const int8_t* bc) {
+  DH_CHECK_CTX(ctx);
+  ctx->ns_bc.clear();
+  if (bc && ndim > 0) {
+    for (int i = 0; i < ndim; ++i)
+      if (bc[i] != DH_BC_HARD && bc[i] != DH_BC_PERIODIC && bc[i] != DH_BC_REFLECT)
+        return fail(ctx, DH_ERR_ARG, "ns boundary flag %d of dimension %d", (int)bc[i], i);
+    ctx->ns_bc.assign(bc, bc + ndim);
+  }
+  return DH_OK;
+}
+
 int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int queue_size, int sampler,
                    int walks, int bound_multi, int rebuild_sync, double dlogz, double enlarge, int64_t max_fills,
                    int64_t max_iter,
@@ -2145,6 +2157,8 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
   // the register sort of the live slots is built for at most 32 keys per thread (sort_slots<32>); the LDS bound of
   // ns_finish below is tighter today, this one is the sort's own
   if (N > 65535) return fail(ctx, DH_ERR_ARG, "ns_ensemble: nlive %d > 65535 (slots travel as 16-bit indices)", N);
+  if (!ctx->ns_bc.empty() && (int)ctx->ns_bc.size() != ndim)
+    return fail(ctx, DH_ERR_ARG, "ns_ensemble: %d boundary flags for ndim %d", (int)ctx->ns_bc.size(), ndim);
   const int me = bound_multi ? (N / (2 * D) > 0 ? N / (2 * D) : 1) : 1;
   NsArgs a{};
   a.runs = R;
@@ -2250,6 +2264,7 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
                o_rec = take((size_t)R * 8 * 8), o_ent = take((size_t)n_words * 4),
                o_fw = take((size_t)R * ns_fin_stride(N) * 8), o_cum = take((size_t)R * me * 8), o_be = take((size_t)R * 32),
                o_rs = take((size_t)R * 8), o_ff = take((size_t)R * 4), o_se = take((size_t)R * 32),
+               o_bcf = take((size_t)D + 8),
                o_boot = take(bootstrap > 0 ? bootstrap_ws_bytes(R, N, D, me, bootstrap) : 8),
                o_lit = take(want_pt ? (size_t)R * N * 4 : 8), o_pid = take(want_pt ? (size_t)R * a.cap * 4 : 8),
                o_pit = take(want_pt ? (size_t)R * a.cap * 4 : 8), o_pnc = take(want_pt ? (size_t)R * a.cap * 4 : 8);
@@ -2321,6 +2336,12 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
   }
   uint32_t* d_ent = (uint32_t*)(base + o_ent);
   hipStream_t s = ctx->stream;
+  const int8_t* d_bc = nullptr;  // periodic / reflective coordinates (dh_ns_set_boundary)
+  if (!ctx->ns_bc.empty()) {
+    if (!hip_ok(ctx, hipMemcpyAsync(base + o_bcf, ctx->ns_bc.data(), (size_t)D, hipMemcpyHostToDevice, s), "H2D bc"))
+      return cleanup(DH_ERR_HIP);
+    d_bc = (const int8_t*)(base + o_bcf);
+  }
   if (want_pt && !hip_ok(ctx, hipMemsetAsync(base + o_lit, 0, (size_t)R * N * 4, s), "memset")) return cleanup(DH_ERR_HIP);
   if (!hip_ok(ctx, hipMemsetAsync(base + o_nd, 0, 64, s), "memset") ||
       !hip_ok(ctx, hipMemsetAsync(base + o_bs, 0, (size_t)R * 4, s), "memset") ||
@@ -2446,7 +2467,7 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
         // the run's threshold; r_a = calls, r_b = flags
         dh::PhiloxKey key_unif = key_slice;
         key_unif.seed ^= 0x3C6EF372FE94F82Bull;
-        rc = unif_launch_runs(ctx, problem, R * K, D, D, R * me, a.b_ctrs, a.b_axes, a.b_ams, a.b_cum, 0.0, nullptr,
+        rc = unif_launch_runs(ctx, problem, R * K, D, D, R * me, a.b_ctrs, a.b_axes, a.b_ams, a.b_cum, 0.0, d_bc,
                               a.q_rng, 0, a.r_u, a.r_v, a.r_logl, a.r_a, a.r_b, a.q_rng_out, a.run_loglstar,
                               a.run_mode, K, MODE_BOUND, philox ? &key_unif : nullptr, bound_multi ? a.nells : nullptr,
                               me);
@@ -2455,7 +2476,7 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
         // hiprand_uniform_double (2 draws; padded to 4 so that a fill's block stays 4-aligned)
         key.offset = (unsigned long long)fill * (unsigned long long)walks * (unsigned long long)(4 * ((D + 3) / 4) + 4);
         rc = rwalk_launch_runs(ctx, problem, R * K, D, D, a.q_u0, a.b_axes, n_frames, a.q_frame, 1.0, 0.0, walks,
-                               nullptr, a.q_rng, a.r_u, a.r_v, a.r_logl, a.r_a, a.r_b, a.q_rng_out,
+                               d_bc, a.q_rng, a.r_u, a.r_v, a.r_logl, a.r_a, a.r_b, a.q_rng_out,
                                a.run_loglstar, a.run_scale, a.run_mode, K, MODE_BOUND, philox ? &key : nullptr);
       }
       else

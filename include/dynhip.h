@@ -494,6 +494,13 @@ enum {
 };
 int dh_ns_set_option(dh_ctx* ctx, int key, double value);
 
+/* NestedSampler(periodic=, reflective=) for the resident loop (dynesty.py:126-142: the lists only reach the internal
+ * sampler): bc = ndim DH_BC_* flags, or NULL / ndim <= 0 for none.  Kept in the context until changed;
+ * dh_ns_ensemble refuses a flag array whose length is not its ndim.  rwalk wraps / reflects the flagged coordinates and
+ * tests them against (-0.5, 1.5) (internal_samplers.py:1023-1032), the uniform sampler only widens its unitcheck
+ * (:301-314); the slice samplers ignore the flags, as the reference's do (its `nonperiodic` kwarg is never set). */
+int dh_ns_set_boundary(dh_ctx* ctx, int ndim, const int8_t* bc);
+
 /* The bootstrap expansion factor on its own (host pointers; what the resident loop runs after a rebuild):
  * for each of `runs` point sets (runs x n x d) the max over `bootstrap` replicas of max(1, largest normalised
  * distance of a left-out point to the replica's Ellipsoid (multi = 0) / nearest of its MultiEllipsoid's ellipsoids

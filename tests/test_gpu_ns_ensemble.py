@@ -270,3 +270,21 @@ def test_twenty_thousand_live_points(ctx):
         assert (np.diff(r["dead_logl"][i, :n]) >= 0).all()
         assert abs(r["logz"][i] - prob.logz_truth) < 5 * r["logzerr"][i] + 0.02, (r["logz"][i], prob.logz_truth)
         assert 0.01 < r["logzerr"][i] < 0.04
+
+
+def test_boundary_flags_that_flag_nothing_change_nothing(ctx):
+    """periodic=[] / reflective=[] (all coordinates hard) is the run without flags, bit for bit; a value that is not a
+    DH_BC_* flag is refused; the flags are per call (the next call without them runs without them)."""
+    from dynesty_amd import _lib
+    prob = inputs.problem("G5")
+    kw = dict(nlive=200, queue_size=32, walks=20, bound="multi", entropy=[4, 4], dlogz=0.5)
+    a = ctx.ns_ensemble(prob, 4, **kw)
+    b = ctx.ns_ensemble(prob, 4, periodic=[], reflective=[], **kw)
+    c = ctx.ns_ensemble(prob, 4, periodic=[0, 2], **kw)
+    d = ctx.ns_ensemble(prob, 4, **kw)
+    for key in ("logz", "niter", "ncall"):
+        np.testing.assert_array_equal(a[key], b[key])
+        np.testing.assert_array_equal(a[key], d[key])
+    assert (c["status"] == 0).all()
+    bad = np.full(5, 7, dtype=np.int8)  # not a DH_BC_* flag
+    assert ctx.lib.dh_ns_set_boundary(ctx.handle, 5, bad.ctypes.data) < 0

@@ -19,6 +19,7 @@ for name in sys.argv[2:]:
                               mean_niter=float(np.mean([r["niter"] for r in rows])),
                               mean_ncall=float(np.mean([r["ncall"] for r in rows])),
                               mean_nbound=float(np.mean([r["nbound"] for r in rows])), truth=rows[0]["truth"],
-                              logz=[round(float(x), 6) for x in lz], seeds=[int(r["seed"]) for r in rows])
+                              logz=[round(float(x), 6) for x in lz], seeds=[int(r["seed"]) for r in rows],
+                              ncalls=[int(r["ncall"]) for r in rows])
     print(name, {k: v for k, v in out["cases"][name].items() if k not in ("logz", "seeds", "config")})
 json.dump(out, open(path, "w"), indent=1)

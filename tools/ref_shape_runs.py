@@ -22,7 +22,7 @@ c = json.loads(sys.argv[1])
 seed = int(sys.argv[2])
 prob = getattr(problems, c["prob"][0])(*c["prob"][1:])
 kw = dict(nlive=c["nlive"], bound=c["bound"], sample=c["sample"], rstate=np.random.default_rng(seed))
-for k in ("walks", "slices", "bootstrap", "enlarge", "update_interval", "first_update"):
+for k in ("walks", "slices", "bootstrap", "enlarge", "update_interval", "first_update", "periodic", "reflective"):
     if k in c:
         kw[k] = c[k]
 # run_nested's own options (round 4: the resident loop takes them too)
