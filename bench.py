@@ -243,8 +243,8 @@ class Shard:
         from oracle import bounding_ref as B
         from oracle import proposals_ref as P
         runs, nlive, d = self.runs, self.nlive, self.d
-        if check_runs is None:
-            check_runs = sorted({0, runs // 2 - 1 if runs > 2 else 0, runs - 1})
+        if check_runs is None:  # every eighth run and the last one (round 4; three runs before)
+            check_runs = sorted(set(range(0, runs, 8)) | {runs // 2 - 1 if runs > 2 else 0, runs - 1})
         self.reset_rng()
         self.rebuild(enlarge=False)
         self.ctx.sync()
@@ -261,6 +261,16 @@ class Shard:
         assert np.all(wk["accept"] + wk["reject"] == self.walks)
         kq = self.kq
         assert np.all((wkq["accept"] + wkq["reject"])[:runs * kq] == self.walks)
+        # EVERY walker of the timed launch: inside the cube, v = prior(u), ln L = L(v), and above the threshold wherever
+        # a step was accepted (the oracle's vectorised prior and likelihood: cheap for all runs x kq walkers)
+        nq = runs * kq
+        uq = wkq["u"][:nq]
+        assert np.all((uq > 0.0) & (uq < 1.0))
+        v_all = self.prob.prior_transform_many(uq)
+        np.testing.assert_allclose(wkq["v"][:nq], v_all, rtol=0, atol=2e-11)
+        np.testing.assert_allclose(wkq["logl"][:nq], self.prob.loglikelihood_many(v_all), rtol=1e-11, atol=1e-11)
+        moved = wkq["accept"][:nq] > 0
+        assert np.all(wkq["logl"][:nq][moved] > self.loglstar) and moved.mean() > 0.9
         kids = np.random.SeedSequence(self.entropy).spawn(self.k)
         nwalk = 0
         for r in check_runs:
@@ -309,6 +319,8 @@ class Shard:
                 "ellipsoids": "nells exact; ctr 1e-13; cov/axlens/logvol 1e-9 (before and after "
                               "the 1.25 enlargement)",
                 "walkers_checked": nwalk,
+                "all_walkers": f"all {nq} walkers of the timed launch: inside the cube, v = prior(u) 2e-11, "
+                               "ln L = L(v) 1e-11, above the threshold wherever a step was accepted",
                 "walkers": "accept/reject counts exact; u 1e-12 abs; logl 1e-11 rel; per checked run "
                            f"{min(walkers_per_run, kq)} walkers of the timed launch shape (runs x {kq}) and "
                            f"{min(max(walkers_per_run // 4, 1), nlive)} of the K = nlive launch",
