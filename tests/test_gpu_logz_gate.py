@@ -127,8 +127,9 @@ def test_c4_device_resident_loop_vs_reference_ensembles(ctx, K, ref_key, runs):
     Round 4: the serial reference ensemble has 32 runs (-250.820 +- 0.014; 57 min each), the device at the bench's
     K = 128 gives -250.864 +- 0.009 with 64 runs (K = 16 / 32 / 64: -250.854 / -250.847 / -250.855: flat below 128):
     0.044 apart, inside north_star's +-0.05 at the means but 2.7 combined sigma from zero -- the queue (any K >= 16)
-    shifts ln Z by about -0.03 against the serial sampler, as it does in the reference (K = 1000: -0.14); the gate is
-    max(0.05, 2 sigma) there."""
+    shifts ln Z by about -0.03 against the serial sampler, as it does in the reference (K = 1000: -0.14): at K = 4 the
+    device gives -250.828 +- 0.008 (64 runs, 4.2 s per run; profiles/r04/c4_ksweep_64runs.jsonl), 0.008 from the serial
+    reference.  The gate is max(0.05, 2 sigma) there."""
     from dynesty_amd import problems
     ref = json.load(open(os.path.join(GOLD, "c4_logz_ref.json")))["ensembles"][ref_key]
     assert ref["n"] >= (20 if ref_key == "K1" else 4)
