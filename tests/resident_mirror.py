@@ -85,17 +85,19 @@ def child_words(entropy, child):
 
 
 def mirror_run(ctx, prob, nlive, K, walks, bound, entropy, run, dlogz, enlarge=1.25, forced="late", first_run=0,
-               max_fills=100000):
-    """The run with global index first_run + run of ns_ensemble(prob, ..., sample='rwalk', rebuild_every=1)."""
+               max_fills=100000, sample="rwalk", bc=None):
+    """The run with global index first_run + run of ns_ensemble(prob, ..., rebuild_every=1); sample = 'rwalk' |
+    'rslice' | 'slice' (`walks` is then the number of slices), bc = DH_BC_* flags per dimension or None."""
     from dynesty_amd import backend, bounding
     backend.set_backend(ctx)
     try:
-        return _mirror(ctx, prob, nlive, K, walks, bound, entropy, first_run + run, dlogz, enlarge, forced, max_fills)
+        return _mirror(ctx, prob, nlive, K, walks, bound, entropy, first_run + run, dlogz, enlarge, forced, max_fills,
+                       sample, bc)
     finally:
         backend.set_backend(None)
 
 
-def _mirror(ctx, prob, N, K, walks, bound, entropy, grun, dlogz, enlarge, forced, max_fills):
+def _mirror(ctx, prob, N, K, walks, bound, entropy, grun, dlogz, enlarge, forced, max_fills, sample, bc):
     from dynesty_amd import bounding
     D = prob.ndim
     # ---- ns_init: every initial point its own child stream, the run's generator child 0x80000000 + run ----
@@ -112,7 +114,8 @@ def _mirror(ctx, prob, N, K, walks, bound, entropy, grun, dlogz, enlarge, forced
     live_it2 = np.zeros((1, N), dtype=np.int32)
     loglstar = float(live_logl.min())
     facc = min(1.0, max(1.0 / max(walks, 2), 0.5))
-    update_interval = walks * N
+    update_interval = walks * N * (D if sample == "slice" else 1)  # internal_samplers.py:495-502, 582, 737
+    doubling = False
     first_ncall, first_eff = 2 * N, 10.0
     cube, scale, nbound, ncall_last, force = True, 1.0, 0, 0, False
     bnd = None
@@ -217,9 +220,17 @@ def _mirror(ctx, prob, N, K, walks, bound, entropy, grun, dlogz, enlarge, forced
                             fidx[w] = nold
                     axes = np.concatenate([axes, new_axes])
                     assert np.asarray(bnd.contains_many(u0) if bound == "multi" else [bnd.contains(x) for x in u0]).all()
-            out = ctx.rwalk_batch(prob, u0, axes, scale, loglstar, walks, states, axes_idx=fidx)
-            q_nc = np.full(K, walks, dtype=np.int32)
-            ta, tr = int(out["accept"].sum()), int(out["reject"].sum())
+            if sample == "rwalk":
+                out = ctx.rwalk_batch(prob, u0, axes, scale, loglstar, walks, states, axes_idx=fidx, bc=bc)
+                q_nc = np.full(K, walks, dtype=np.int32)
+                ta, tr = int(out["accept"].sum()), int(out["reject"].sum())
+            else:
+                out = ctx.slice_batch(prob, u0, axes, scale, loglstar, walks, states, principal=sample == "slice",
+                                      doubling=doubling, axes_idx=fidx)
+                q_nc = out["ncalls"].astype(np.int32)
+                ta, tr = int(out["n_expand"].sum()), int(out["n_contract"].sum())
+                if out["expansion_warning_set"].any():  # slice_doubling from the next fill on (:1188-1206)
+                    doubling = True
         q_logl = np.ascontiguousarray(out["logl"], dtype=np.float64)
         res = ctx.ns_consume(live_l2, q_logl[None], q_nc[None], state, dlogz, live_it=live_it2, plateau=plateau)
         slots, srcs = res["dead_slot"][0].astype(np.int64), res["dead_src"][0].astype(np.int64)
@@ -234,8 +245,12 @@ def _mirror(ctx, prob, N, K, walks, bound, entropy, grun, dlogz, enlarge, forced
             last[order[:-1][same]] = False
             live_u[slots[last]] = out["u"][srcs[last]]
             live_v[slots[last]] = out["v"][srcs[last]]
-        if not cube and ta + tr > 0:  # RWalkSampler.tune, once per fill (internal_samplers.py:460-493)
-            scale *= math.exp((ta / (ta + tr) - facc) / D / facc)
+        if not cube and sample == "rwalk":
+            if ta + tr > 0:  # RWalkSampler.tune, once per fill (internal_samplers.py:460-493)
+                scale *= math.exp((ta / (ta + tr) - facc) / D / facc)
+        elif not cube:  # tune_slice (internal_samplers.py:1209-1239)
+            ne = float(max(ta, 1))
+            scale *= min(max(ne * 2.0 / (ne + tr), 0.5), 2.0)
         loglstar = float(state[0, 7])
         fill += 1
         if res["stopped"][0] or np.ptp(live_logl) == 0:

@@ -43,3 +43,34 @@ def test_resident_loop_equals_its_host_mirror(ctx, K, bound, forced):
         nforced += len(m["forced_fills"])
     if K <= 8:
         assert nforced > 0  # start points outside the bound did occur: both forms of the forced update were walked
+
+
+@pytest.mark.parametrize("sample,K,bound,forced,bcs", [("rslice", 8, "multi", "exact", None), ("slice", 4, "single", "late", None),
+                                                     ("rslice", 1, "single", "late", None),
+                                                     ("rwalk", 8, "multi", "late", ([0, 3], [5]))])
+def test_other_samplers_and_boundary_flags_equal_their_mirror(ctx, sample, K, bound, forced, bcs):
+    """The same for the slice samplers (tune_slice, the doubling flag, the update interval in slices) and for rwalk
+    with periodic / reflective coordinates."""
+    from dynesty_amd import _lib, problems
+    prob = problems.gauss_corr(9, 0.3, 5.0, "corr9")
+    nlive, dlogz, ent = 80, 0.5, [6, K, 1]
+    steps = 20 if sample == "rwalk" else (12 if sample == "rslice" else 3)
+    kw, bc = {}, None
+    if bcs:
+        kw = dict(periodic=bcs[0], reflective=bcs[1])
+        bc = np.zeros(9, dtype=np.int8)
+        bc[bcs[0]] = _lib.BC_PERIODIC
+        bc[bcs[1]] = _lib.BC_REFLECT
+    args = dict(walks=steps) if sample == "rwalk" else dict(slices=steps)
+    r = ctx.ns_ensemble(prob, 2, nlive, K, bound=bound, sample=sample, dlogz=dlogz, entropy=ent, rebuild_every=1,
+                        want_samples=True, want_dead_logl=True, forced_exact=forced == "exact", max_iter=20000, **args, **kw)
+    assert (r["status"] == 0).all()
+    for run in (0, 1):
+        m = mirror_run(ctx, prob, nlive, K, steps, bound, ent, run, dlogz, forced=forced, sample=sample, bc=bc)
+        n = int(r["niter"][run])
+        assert m["done"] and m["niter"] == n, (m["niter"], n)
+        np.testing.assert_array_equal(r["dead_id"][run, :n], np.array(m["dead_slot"]))
+        np.testing.assert_allclose(r["dead_logl"][run, :n], np.array(m["dead_logl"]), rtol=1e-12, atol=0)
+        np.testing.assert_allclose(r["live_u"][run], m["live_u"], rtol=0, atol=1e-12)
+        assert int(r["ncall"][run]) == m["ncall"] and int(r["nbound"][run]) == m["nbound"]
+        assert abs(r["logz"][run] - m["logz"]) < 1e-9
