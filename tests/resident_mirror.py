@@ -85,19 +85,20 @@ def child_words(entropy, child):
 
 
 def mirror_run(ctx, prob, nlive, K, walks, bound, entropy, run, dlogz, enlarge=1.25, forced="late", first_run=0,
-               max_fills=100000, sample="rwalk", bc=None):
+               max_fills=100000, sample="rwalk", bc=None, bootstrap=0, update_interval=None, first_update=None):
     """The run with global index first_run + run of ns_ensemble(prob, ..., rebuild_every=1); sample = 'rwalk' |
     'rslice' | 'slice' (`walks` is then the number of slices), bc = DH_BC_* flags per dimension or None."""
     from dynesty_amd import backend, bounding
     backend.set_backend(ctx)
     try:
         return _mirror(ctx, prob, nlive, K, walks, bound, entropy, first_run + run, dlogz, enlarge, forced, max_fills,
-                       sample, bc)
+                       sample, bc, bootstrap, update_interval, first_update)
     finally:
         backend.set_backend(None)
 
 
-def _mirror(ctx, prob, N, K, walks, bound, entropy, grun, dlogz, enlarge, forced, max_fills, sample, bc):
+def _mirror(ctx, prob, N, K, walks, bound, entropy, grun, dlogz, enlarge, forced, max_fills, sample, bc, bootstrap,
+            upd, first):
     from dynesty_amd import bounding
     D = prob.ndim
     # ---- ns_init: every initial point its own child stream, the run's generator child 0x80000000 + run ----
@@ -114,9 +115,14 @@ def _mirror(ctx, prob, N, K, walks, bound, entropy, grun, dlogz, enlarge, forced
     live_it2 = np.zeros((1, N), dtype=np.int32)
     loglstar = float(live_logl.min())
     facc = min(1.0, max(1.0 / max(walks, 2), 0.5))
-    update_interval = walks * N * (D if sample == "slice" else 1)  # internal_samplers.py:495-502, 582, 737
+    # internal_samplers.py:88-94 (unif: 1), 495-502 (rwalk: walks), 582 (slice: slices x ndim), 737 (rslice: slices)
+    update_interval = N if sample == "unif" else walks * N * (D if sample == "slice" else 1)
     doubling = False
     first_ncall, first_eff = 2 * N, 10.0
+    if upd is not None:  # dynesty.py:213-234: a float is a multiple of nlive, an int a number of calls
+        update_interval = max(1, round(upd * N)) if isinstance(upd, float) else int(upd)
+    if first:
+        first_ncall, first_eff = first.get("min_ncall", first_ncall), first.get("min_eff", first_eff)
     cube, scale, nbound, ncall_last, force = True, 1.0, 0, 0, False
     bnd = None
     ev = dict(dead_logl=[], dead_slot=[], dead_src=[], fill_of_death=[], forced_fills=[], rebuild_fills=[])
@@ -126,6 +132,13 @@ def _mirror(ctx, prob, N, K, walks, bound, entropy, grun, dlogz, enlarge, forced
         if bnd is None:
             bnd = (bounding.HipMultiEllipsoid if bound == "multi" else bounding.HipEllipsoid)(D)
         bnd.update(live_u)
+        if bootstrap > 0:
+            # bound.update(points, bootstrap=B) (bounding.py:381-400, 688-703): the replicas' streams come from four
+            # words of the run's generator, drawn when the rebuild is decided (ns_prepare)
+            bent = np.array([[rg.next64() for _ in range(4)]], dtype=np.uint64)
+            f = float(ctx.bootstrap_expand(live_u[None], bent, bootstrap, bound == "multi")[0])
+            if f > 1.0:
+                bnd.scale_to_logvol(bnd.logvol + D * math.log(f))
         if enlarge != 1.0:
             bnd.scale_to_logvol(bnd.logvol + math.log(enlarge))
         nbound += 1
@@ -175,7 +188,7 @@ def _mirror(ctx, prob, N, K, walks, bound, entropy, grun, dlogz, enlarge, forced
         for w in range(K):
             g = Pcg()
             g.seed((ent[0] << 64) | ((ent[1] + w) & M64), (ent[2] << 64) | ((ent[3] + 2 * w) & M64))
-            if not cube:
+            if not cube and sample != "unif":  # (the uniform sampler starts nowhere: internal_samplers.py:214-242)
                 while True:
                     i = g.interval(N - 1)
                     if live_logl[i] > loglstar:
@@ -187,6 +200,14 @@ def _mirror(ctx, prob, N, K, walks, bound, entropy, grun, dlogz, enlarge, forced
         if cube:
             out = ctx.unif_batch(prob, loglstar, states)
             q_nc = out["ncalls"].astype(np.int32)
+        elif sample == "unif":
+            if bound == "multi":
+                out = ctx.unif_batch(prob, loglstar, states, ctrs=bnd.ctrs, axes=bnd.axes_ells, ams=bnd.ams,
+                                     logvol_ells=bnd.logvol_ells)
+            else:
+                out = ctx.unif_batch(prob, loglstar, states, ctrs=bnd.ctr, axes=bnd.axes)
+            q_nc = out["ncalls"].astype(np.int32)
+            ta = tr = 0
         else:
             axes, lv = frames_of()
             cum = cum_of(lv) if multi else None
@@ -248,7 +269,7 @@ def _mirror(ctx, prob, N, K, walks, bound, entropy, grun, dlogz, enlarge, forced
         if not cube and sample == "rwalk":
             if ta + tr > 0:  # RWalkSampler.tune, once per fill (internal_samplers.py:460-493)
                 scale *= math.exp((ta / (ta + tr) - facc) / D / facc)
-        elif not cube:  # tune_slice (internal_samplers.py:1209-1239)
+        elif not cube and sample != "unif":  # tune_slice (internal_samplers.py:1209-1239)
             ne = float(max(ta, 1))
             scale *= min(max(ne * 2.0 / (ne + tr), 0.5), 2.0)
         loglstar = float(state[0, 7])

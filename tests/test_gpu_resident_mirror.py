@@ -74,3 +74,43 @@ def test_other_samplers_and_boundary_flags_equal_their_mirror(ctx, sample, K, bo
         np.testing.assert_allclose(r["live_u"][run], m["live_u"], rtol=0, atol=1e-12)
         assert int(r["ncall"][run]) == m["ncall"] and int(r["nbound"][run]) == m["nbound"]
         assert abs(r["logz"][run] - m["logz"]) < 1e-9
+
+
+@pytest.mark.parametrize("K,bound", [(8, "single"), (16, "multi"), (1, "multi")])
+def test_uniform_sampler_with_bootstrap_equals_its_mirror(ctx, K, bound):
+    """sample='unif' with the reference's defaults (bootstrap 5, enlarge 1): the bootstrap replicas' streams from four
+    words of the run's generator at every rebuild, the expansion applied to the bound, UniformBoundSampler over the
+    run's ellipsoids, a bound update every nlive calls (BASELINE C1's loop)."""
+    from dynesty_amd import problems
+    prob = problems.gauss_corr(4, 0.3, 5.0, "corr4")
+    nlive, dlogz, ent = 80, 0.5, [8, K, 2]
+    r = ctx.ns_ensemble(prob, 2, nlive, K, bound=bound, sample="unif", dlogz=dlogz, entropy=ent, rebuild_every=1,
+                        want_samples=True, want_dead_logl=True, max_iter=20000)
+    assert (r["status"] == 0).all()
+    for run in (0, 1):
+        m = mirror_run(ctx, prob, nlive, K, 1, bound, ent, run, dlogz, enlarge=1.0, sample="unif", bootstrap=5)
+        n = int(r["niter"][run])
+        assert m["done"] and m["niter"] == n, (m["niter"], n)
+        np.testing.assert_array_equal(r["dead_id"][run, :n], np.array(m["dead_slot"]))
+        np.testing.assert_allclose(r["dead_logl"][run, :n], np.array(m["dead_logl"]), rtol=1e-12, atol=0)
+        np.testing.assert_allclose(r["live_u"][run], m["live_u"], rtol=0, atol=1e-12)
+        assert int(r["ncall"][run]) == m["ncall"] and int(r["nbound"][run]) == m["nbound"]
+        assert abs(r["logz"][run] - m["logz"]) < 1e-9
+
+
+def test_update_interval_and_first_update_equal_their_mirror(ctx):
+    """NestedSampler(update_interval=0.7, first_update={'min_ncall': 300, 'min_eff': 40}) in the loop and in the mirror."""
+    from dynesty_amd import problems
+    prob = problems.gauss_corr(9, 0.3, 5.0, "corr9")
+    nlive, K, dlogz, ent = 80, 4, 0.5, [9, 9]
+    opt = dict(update_interval=0.7, first_update=dict(min_ncall=300, min_eff=40.0))
+    r = ctx.ns_ensemble(prob, 2, nlive, K, walks=20, bound="multi", dlogz=dlogz, entropy=ent, rebuild_every=1,
+                        want_samples=True, want_dead_logl=True, max_iter=20000, **opt)
+    for run in (0, 1):
+        m = mirror_run(ctx, prob, nlive, K, 20, "multi", ent, run, dlogz, **opt)
+        n = int(r["niter"][run])
+        assert m["done"] and m["niter"] == n
+        np.testing.assert_array_equal(r["dead_id"][run, :n], np.array(m["dead_slot"]))
+        np.testing.assert_allclose(r["dead_logl"][run, :n], np.array(m["dead_logl"]), rtol=1e-12, atol=0)
+        assert int(r["ncall"][run]) == m["ncall"] and int(r["nbound"][run]) == m["nbound"]
+        assert m["nbound"] > 10
