@@ -114,3 +114,27 @@ def test_update_interval_and_first_update_equal_their_mirror(ctx):
         np.testing.assert_allclose(r["dead_logl"][run, :n], np.array(m["dead_logl"]), rtol=1e-12, atol=0)
         assert int(r["ncall"][run]) == m["ncall"] and int(r["nbound"][run]) == m["nbound"]
         assert m["nbound"] > 10
+
+
+@pytest.mark.parametrize("sample,bound,forced", [("rslice", "single", "late"), ("rwalk", "single", "exact")])
+def test_wide_path_equals_its_mirror(ctx, sample, bound, forced):
+    """Above the register-resident dimensions (D = 40: the wave-per-walker kernels and the multi-workgroup
+    Ellipsoid.update of wide.hip) -- where round 3's shape sweep found the forced bound updates missing."""
+    from dynesty_amd import problems
+    prob = problems.gauss_corr(40, 0.3, 5.0, "corr40")
+    nlive, K, dlogz, ent = 160, 8, 2.0, [40, 1]
+    steps = 30 if sample == "rwalk" else 10
+    args = dict(walks=steps) if sample == "rwalk" else dict(slices=steps)
+    r = ctx.ns_ensemble(prob, 2, nlive, K, bound=bound, sample=sample, dlogz=dlogz, entropy=ent, rebuild_every=1,
+                        want_samples=True, want_dead_logl=True, forced_exact=forced == "exact", max_iter=40000, **args)
+    assert (r["status"] == 0).all()
+    nforced = 0
+    for run in (0, 1):
+        m = mirror_run(ctx, prob, nlive, K, steps, bound, ent, run, dlogz, forced=forced, sample=sample)
+        n = int(r["niter"][run])
+        assert m["done"] and m["niter"] == n, (m["niter"], n)
+        np.testing.assert_array_equal(r["dead_id"][run, :n], np.array(m["dead_slot"]))
+        np.testing.assert_allclose(r["dead_logl"][run, :n], np.array(m["dead_logl"]), rtol=1e-11, atol=0)
+        assert int(r["ncall"][run]) == m["ncall"] and int(r["nbound"][run]) == m["nbound"]
+        nforced += len(m["forced_fills"])
+    assert nforced > 0
