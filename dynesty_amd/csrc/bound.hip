@@ -108,39 +108,79 @@ __global__ void __launch_bounds__(64)
   }
 }
 
-// The same test above the register-resident dimensions: one wavefront per start point, lanes over the rows of the
-// symmetric precision matrix (r_i = sum_j A[j][i] dl[j]: consecutive lanes read consecutive doubles), the point's
-// offset from the centre in LDS, q = sum_i dl_i r_i by a wave reduction.
-__global__ void __launch_bounds__(64)
-    contains_runs_wide_kernel(const double* __restrict__ x, int k, int d, int wpr, const double* __restrict__ ctrs,
+// The same test above the register-resident dimensions.  One wavefront per start point re-read the run's precision
+// matrix (320 KB at D = 200) for every point: 109 us per 2 048-walker fill of C4, L2-bandwidth bound.  Now a workgroup of
+// four wavefronts takes P <= 8 start points OF ONE RUN: the points' offsets from the centre sit in LDS, wavefront w
+// forms r_i = sum_j A[j][i] dl[j] for the rows i = l + 64 c of its chunks c = w, w + 4 (consecutive lanes read
+// consecutive doubles; a matrix element is loaded once and serves all P points), and wavefront 0 folds
+// q = sum_i dl_i r_i exactly as the one-wavefront form did -- per lane over its chunks in ascending order, then
+// across the lanes -- so every point's verdict comes from the same arithmetic.
+constexpr int kWideBlock = 8;
+__global__ void __launch_bounds__(256)
+    contains_runs_wide_kernel(const double* __restrict__ x, int k, int d, int wpr, int P, const double* __restrict__ ctrs,
                               const double* __restrict__ ams, const int* __restrict__ nells, int max_ells, int strict,
                               const int* __restrict__ run_mode, int my_mode, const int* __restrict__ bstatus, int* flag,
                               int* first) {
-  extern __shared__ double dl[];
-  const int w = blockIdx.x, lane = threadIdx.x;
-  if (w >= k) return;
-  const int run = w / wpr;
+  extern __shared__ double sm[];
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int C = (d + 63) >> 6;           // 64-row chunks
+  double* dl = sm;                       // P x d
+  double* rb = sm + (size_t)P * d;       // C x P x 64: r of chunk c, point p, lane l
+  __shared__ unsigned inside_s;
+  const int bpr = (wpr + P - 1) / P;  // blocks per run
+  const int run = blockIdx.x / bpr, w0 = run * wpr + (blockIdx.x % bpr) * P;
+  if (w0 >= k) return;
+  const int np = min(P, min(run * wpr + wpr, k) - w0);
   if ((run_mode && run_mode[run] != my_mode) || (bstatus && bstatus[run] != 0)) return;
   const int m = nells ? nells[run] : 1;
-  bool inside = false;
-  for (int a = 0; a < m && !inside; ++a) {
+  const unsigned all = (1u << np) - 1u;
+  unsigned inside = 0;  // bit p: point p lies in some ellipsoid (workgroup-uniform)
+  for (int a = 0; a < m && inside != all; ++a) {
     const double* __restrict__ c = ctrs + ((size_t)run * max_ells + a) * d;
     const double* __restrict__ A = ams + ((size_t)run * max_ells + a) * d * d;
     __syncthreads();
-    for (int i = lane; i < d; i += 64) dl[i] = x[(size_t)w * d + i] - c[i];
-    __syncthreads();
-    double q = 0.0;
-    for (int i = lane; i < d; i += 64) {
-      double r = 0.0;
-      for (int j = 0; j < d; ++j) r = fma(A[(size_t)j * d + i], dl[j], r);
-      q = fma(dl[i], r, q);
+    for (int e = t; e < np * d; e += 256) {
+      const int p = e / d, i = e - p * d;
+      dl[e] = x[(size_t)(w0 + p) * d + i] - c[i];
     }
-    for (int sft = 32; sft > 0; sft >>= 1) q += __shfl_xor(q, sft);
-    inside = strict ? (q < 1.0) : (sqrt(q) <= 1.0);
+    __syncthreads();
+    for (int ch = wv; ch < C; ch += 4) {
+      const int i = ch * 64 + lane;
+      double r[kWideBlock];
+#pragma unroll
+      for (int p = 0; p < kWideBlock; ++p) r[p] = 0.0;
+      if (i < d)
+        for (int j = 0; j < d; ++j) {
+          const double aji = A[(size_t)j * d + i];
+#pragma unroll
+          for (int p = 0; p < kWideBlock; ++p)
+            if (p < np) r[p] = fma(aji, dl[p * d + j], r[p]);
+        }
+#pragma unroll
+      for (int p = 0; p < kWideBlock; ++p)
+        if (p < np) rb[((size_t)ch * P + p) * 64 + lane] = r[p];
+    }
+    __syncthreads();
+    if (wv == 0) {
+      unsigned got = 0;
+      for (int p = 0; p < np; ++p) {
+        double q = 0.0;
+        for (int ch = 0; ch < C; ++ch) {
+          const int i = ch * 64 + lane;
+          if (i < d) q = fma(dl[p * d + i], rb[((size_t)ch * P + p) * 64 + lane], q);
+        }
+        for (int sft = 32; sft > 0; sft >>= 1) q += __shfl_xor(q, sft);
+        if (strict ? (q < 1.0) : (sqrt(q) <= 1.0)) got |= 1u << p;
+      }
+      if (lane == 0) inside_s = inside | got;
+    }
+    __syncthreads();
+    inside = inside_s;
   }
-  if (!inside && lane == 0) {
+  const unsigned out = all & ~inside;
+  if (out && t == 0) {
     atomicOr(&flag[run], 1);
-    if (first) atomicMin(&first[run], w - run * wpr);
+    if (first) atomicMin(&first[run], w0 + (__ffs((int)out) - 1) - run * wpr);
   }
 }
 
@@ -152,7 +192,10 @@ int contains_runs_launch(dh_ctx* ctx, const double* x, int k, int d, int wpr, co
                          const int* bstatus, int* flag, int* first) {
   if (k <= 0) return DH_OK;
   if (d > kMaxRegDim) {
-    hipLaunchKernelGGL(contains_runs_wide_kernel, dim3(k), dim3(64), (size_t)d * 8, ctx->stream, x, k, d, wpr, ctrs, ams,
+    const int P = d <= 256 ? kWideBlock : 4;  // (LDS: P d + ceil(d / 64) P 64 doubles <= 32 KB)
+    const int bpr = (wpr + P - 1) / P, nruns = (k + wpr - 1) / wpr;
+    const size_t lds = ((size_t)P * d + (size_t)((d + 63) / 64) * P * 64) * 8;
+    hipLaunchKernelGGL(contains_runs_wide_kernel, dim3(nruns * bpr), dim3(256), lds, ctx->stream, x, k, d, wpr, P, ctrs, ams,
                        nells, max_ells, strict, run_mode, my_mode, bstatus, flag, first);
     return hip_ok(ctx, hipGetLastError(), "contains_runs launch") ? DH_OK : DH_ERR_HIP;
   }
