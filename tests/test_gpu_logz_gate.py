@@ -116,7 +116,7 @@ def bound2(se_a, se_b):
     return max(0.05, 2.0 * math.sqrt(se_a * se_a + se_b * se_b))
 
 
-@pytest.mark.parametrize("K,ref_key,runs", [(128, "K1", 32), (1000, "K1000", 8)])
+@pytest.mark.parametrize("K,ref_key,runs", [(128, "K1", 32), (128, "K128", 32), (1000, "K1000", 8)])
 def test_c4_device_resident_loop_vs_reference_ensembles(ctx, K, ref_key, runs):
     """BASELINE C4 through the device-resident loop (dh_ns_ensemble at 200-D: wave-per-walker rslice kernels with
     per-run thresholds, masked multi-workgroup Ellipsoid.update) against the converged ensembles of the real reference
@@ -129,10 +129,12 @@ def test_c4_device_resident_loop_vs_reference_ensembles(ctx, K, ref_key, runs):
     0.044 apart, inside north_star's +-0.05 at the means but 2.7 combined sigma from zero -- the queue (any K >= 16)
     shifts ln Z by about -0.03 against the serial sampler, as it does in the reference (K = 1000: -0.14): at K = 4 the
     device gives -250.828 +- 0.008 (64 runs, 4.2 s per run; profiles/r04/c4_ksweep_64runs.jsonl), 0.008 from the serial
-    reference.  The gate is max(0.05, 2 sigma) there."""
+    reference.  The gate is max(0.05, 2 sigma) there.  And at the bench's own queue size the real reference
+    (SerialPool(128), 75 min per run) gives -250.877 +- 0.027 (n = 4; more collected as they finish): the device's
+    -250.864 +- 0.009 is 0.013 from it, and the reference's own K = 128 sits 0.057 below its serial ensemble."""
     from dynesty_amd import problems
     ref = json.load(open(os.path.join(GOLD, "c4_logz_ref.json")))["ensembles"][ref_key]
-    assert ref["n"] >= (20 if ref_key == "K1" else 4)
+    assert ref["n"] >= (20 if ref_key == "K1" else 4)  # (K128: 4 runs when first committed)
     prob = problems.gauss_normal_prior(200, "C4")
     r = ctx.ns_ensemble(prob, runs, 4000, K, bound='single', sample='rslice', slices=203, entropy=[21, K], dlogz=0.01,
                         max_iter=250000)
