@@ -138,3 +138,23 @@ def test_wide_path_equals_its_mirror(ctx, sample, bound, forced):
         assert int(r["ncall"][run]) == m["ncall"] and int(r["nbound"][run]) == m["nbound"]
         nforced += len(m["forced_fills"])
     assert nforced > 0
+
+
+def test_large_live_set_equals_its_mirror(ctx):
+    """nlive = 9000 (beyond what the queue consumption holds in LDS: it works on the K + 1 smallest live points and
+    translates their slots back, csrc/ns.hip ns_consume_compact): the loop's replacements land in the right live
+    slots -- death for death against the mirror, which applies the operator's reported slots on the host."""
+    from dynesty_amd import problems
+    prob = problems.gauss_corr(4, 0.3, 5.0, "corr4")
+    nlive, K, dlogz, ent = 9000, 32, 1.0, [90, 0]
+    r = ctx.ns_ensemble(prob, 1, nlive, K, walks=10, bound="multi", dlogz=dlogz, entropy=ent, rebuild_every=1,
+                        want_samples=True, want_dead_logl=True, max_iter=200000)
+    assert (r["status"] == 0).all()
+    m = mirror_run(ctx, prob, nlive, K, 10, "multi", ent, 0, dlogz)
+    n = int(r["niter"][0])
+    assert m["done"] and m["niter"] == n and n > 20000, (m["niter"], n)
+    np.testing.assert_array_equal(r["dead_id"][0, :n], np.array(m["dead_slot"]))
+    np.testing.assert_allclose(r["dead_logl"][0, :n], np.array(m["dead_logl"]), rtol=1e-12, atol=0)
+    np.testing.assert_allclose(r["live_u"][0], m["live_u"], rtol=0, atol=1e-12)
+    assert int(r["ncall"][0]) == m["ncall"] and int(r["nbound"][0]) == m["nbound"]
+    assert abs(r["logz"][0] - m["logz"]) < 1e-8
