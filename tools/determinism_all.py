@@ -1,6 +1,6 @@
 """Repeat-and-compare stress over the entry points that synchronise workgroups through memory or atomics."""
 import os, sys, numpy as np
-sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests')
+ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0,ROOT); sys.path.insert(0,os.path.join(ROOT,'tests'))
 import inputs
 from dynesty_amd import _lib, problems
 ctx=_lib.Context(0)
