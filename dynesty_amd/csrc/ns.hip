@@ -1226,17 +1226,40 @@ __global__ void __launch_bounds__(kT) ns_consume(NsArgs a) {
       const int shift = 56 - 8 * pass;
       hist[t] = 0;
       __syncthreads();
-      for (int i = t; i < N; i += kT) {
-        const unsigned long long o = ord(keys[i]);
-        if ((o & mask) == prefix) atomicAdd(&hist[(int)((o >> shift) & 255ull)], 1);
+      // (eight independent loads in flight per thread: one at a time a pass is N / kT global round trips)
+      for (int i0 = t; i0 < N; i0 += 8 * kT) {
+        double kv[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) kv[q] = i0 + q * kT < N ? keys[i0 + q * kT] : 0.0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const unsigned long long o = ord(kv[q]);
+          if (i0 + q * kT < N && (o & mask) == prefix) atomicAdd(&hist[(int)((o >> shift) & 255ull)], 1);
+        }
       }
       __syncthreads();
-      if (t == 0) {
-        int cum = 0, d = 0;
-        while (d < 255 && cum + hist[d] < want) cum += hist[d++];
-        sel_i[0] = d;
-        sel_i[1] = want - cum;
-        sel_i[2] = hist[d];
+      if (wv == 0) {
+        // first digit whose cumulative count reaches `want`: a wave scan over four bins per lane (one thread walking
+        // the 256 bins was 256 dependent LDS reads per pass)
+        const int h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+        const int sum4 = h0 + h1 + h2 + h3;
+        int incl = sum4;
+        for (int off = 1; off < 64; off <<= 1) {
+          const int y = __shfl_up(incl, off);
+          if (lane >= off) incl += y;
+        }
+        const unsigned long long reach = __ballot(incl >= want);
+        const int hitl = reach ? (int)__ffsll((long long)reach) - 1 : 63;
+        if (lane == hitl) {
+          int cum = incl - sum4, d = 4 * lane;
+          const int hh[4] = {h0, h1, h2, h3};
+          int q = 0;
+          while (q < 3 && cum + hh[q] < want) cum += hh[q++];
+          d += q;
+          sel_i[0] = d;
+          sel_i[1] = want - cum;
+          sel_i[2] = hh[q];
+        }
       }
       __syncthreads();
       prefix |= (unsigned long long)sel_i[0] << shift;
@@ -1247,13 +1270,22 @@ __global__ void __launch_bounds__(kT) ns_consume(NsArgs a) {
     // `want` of the keys equal to the threshold belong to the subset: the lowest slots
     const int need = want, eq_total = sel_i[2];
     sel_extra = eq_total - need;
-    for (int mi = wv; mi < nm; mi += kT / 64) {
-      const int i = mi * 64 + lane;
-      const unsigned long long o = i < N ? ord(keys[i]) : ~0ull;
-      const unsigned long long lm = __ballot(i < N && o < prefix), tm = __ballot(i < N && o == prefix);
-      if (lane == 0) {
-        lmask[mi] = lm;
-        tmask[mi] = tm;
+    for (int m0 = wv; m0 < nm; m0 += 4 * (kT / 64)) {
+      double kv[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = (m0 + q * (kT / 64)) * 64 + lane;
+        kv[q] = i < N ? keys[i] : 0.0;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int mi = m0 + q * (kT / 64), i = mi * 64 + lane;
+        const unsigned long long o = ord(kv[q]);
+        const unsigned long long lm = __ballot(i < N && o < prefix), tm = __ballot(i < N && o == prefix);
+        if (lane == 0 && mi < nm) {
+          lmask[mi] = lm;
+          tmask[mi] = tm;
+        }
       }
     }
     __syncthreads();
