@@ -33,7 +33,19 @@ for d, sample, bound in cases[:int(os.environ.get("NCASE", "40"))]:
         kw["walks"] = d + 20  # the reference's default
     elif sample in ("rslice", "slice"):
         kw["slices"] = 3 + d if sample == "rslice" else 3  # the reference's defaults
-    tag = dict(d=d, sample=sample, bound=bound, nlive=nlive, K=K, runs=runs, rng=mode, prob=prob.name)
+    # round 4: the forced update inside the fill, boundary flags (one coordinate stays hard, as the reference needs),
+    # a non-default update interval, a live set beyond the LDS-resident consumption
+    if sample != "unif" and rng0.random() < 0.5:
+        kw["forced_exact"] = True
+    if sample in ("rwalk", "unif") and d >= 3 and rng0.random() < 0.4:
+        kw["periodic"], kw["reflective"] = [0], [d - 1]
+    if rng0.random() < 0.3:
+        kw["update_interval"] = float(rng0.choice([0.6, 1.7]))
+    if d <= 5 and sample == "rwalk" and rng0.random() < 0.5:
+        nlive = int(rng0.choice([8500, 12000]))
+        K = int(rng0.choice([64, 257]))
+    tag = dict(d=d, sample=sample, bound=bound, nlive=nlive, K=K, runs=runs, rng=mode, prob=prob.name,
+               opts={k: v for k, v in kw.items() if k in ("forced_exact", "periodic", "update_interval")})
     try:
         a = ctx.ns_ensemble(prob, runs, nlive, K, rebuild_every=1, **kw)
         b = ctx.ns_ensemble(prob, runs, nlive, K, rebuild_every=0, **kw)
