@@ -203,3 +203,37 @@ def test_scalar_contains_matches_reference_golden():
         e = HipEllipsoid(d, ctr=g[f"{name}/be/ctr"], cov=g[f"{name}/be/cov"], am=g[f"{name}/be/am"],
                          axes=g[f"{name}/be/axes"], axlens=g[f"{name}/be/axlens"], logvol=float(g[f"{name}/be/logvol"]))
         np.testing.assert_array_equal([e.contains(p) for p in probes], g[f"{name}/single/contains"])
+
+
+def test_mirror_generator_is_numpys_pcg64():
+    """tests/resident_mirror.py (the host mirror of the resident loop) carries its own PCG64: next64 / next_double /
+    the buffered 32-bit halves against numpy on SeedSequence children, and pcg_setseq_128_srandom_r against numpy's
+    own seeding of a PCG64 from (state, inc)."""
+    from resident_mirror import Pcg, child_words
+    ent = [5, 8, 7]
+    for child in (0, 3, 0x80000001):
+        bg = np.random.PCG64(np.random.SeedSequence(ent, spawn_key=(child,)))
+        g = Pcg(child_words(ent, child))
+        ref = np.random.Generator(bg)
+        raw = bg.random_raw(5)
+        assert [g.next64() for _ in range(5)] == [int(x) for x in raw]
+        np.testing.assert_array_equal([g.next_double() for _ in range(7)], ref.random(7))
+    # srandom: state = 0, inc = (seq << 1) | 1, step, state += initstate, step
+    g = Pcg()
+    g.seed((123 << 64) | 456, (789 << 64) | 1011)
+    mult = (0x2360ED051FC65DA4 << 64) | 0x4385DF649FCCF645
+    m128 = (1 << 128) - 1
+    inc = ((((789 << 64) | 1011) << 1) | 1) & m128
+    st = (0 * mult + inc) & m128
+    st = (st + ((123 << 64) | 456)) & m128
+    st = (st * mult + inc) & m128
+    assert g.state == st and g.inc == inc
+    # random_interval(max) on the buffered 32-bit stream: masked rejection, both halves of a 64-bit draw used
+    g = Pcg(child_words(ent, 9))
+    h = Pcg(child_words(ent, 9))
+    draws = [g.interval(99) for _ in range(200)]
+    assert all(0 <= d <= 99 for d in draws) and len(set(draws)) > 60
+    v = h.next64()
+    first = [x & 127 for x in (v & 0xFFFFFFFF, v >> 32)]
+    got = [d for d in first if d <= 99]
+    assert draws[:len(got)] == got
