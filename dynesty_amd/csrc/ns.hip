@@ -1357,6 +1357,11 @@ __global__ void __launch_bounds__(kT) ns_consume(NsArgs a) {
       qc[j] = a.walks;
       acc += a.r_a[q];
       rej += a.r_b[q];
+      // No step accepted: the walker hands back its start point, a LIVE point, and the reference's re-evaluation of it
+      // (internal_samplers.py:970-975) gives that point's own ln L again, bit for bit -- an exact tie, which dies
+      // lowest slot first and opens the plateau mode (sampler.py:1107-1119).  Two kernels evaluating the same point
+      // can differ in the last bit (summation order), so the live point's stored value is taken.
+      if (a.r_a[q] == 0) ql[j] = a.live_logl[(size_t)run * N + a.r_d[q]];
     } else {
       qc[j] = a.r_a[q];
       acc += a.r_b[q];                      // n_expand

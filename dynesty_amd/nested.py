@@ -238,6 +238,9 @@ def run_static(prob, nlive=500, bound='multi', sample='rwalk', queue_size=None,
             out = be.rwalk_batch(prob, live_u[start], frames, scale, loglstar,
                                  walks, states, axes_idx=fidx)
             out["ncalls"] = np.full(K, walks)
+            # no step accepted: the start point comes back with its own stored ln L (the reference's re-evaluation
+            # gives the same bits, internal_samplers.py:970-975: an exact tie with the live point it copies)
+            out["logl"] = np.where(out["accept"] == 0, live_logl[start], out["logl"])
             hist["acc"] += int(out["accept"].sum())
             hist["rej"] += int(out["reject"].sum())
             tot = hist["acc"] + hist["rej"]

@@ -245,6 +245,9 @@ def _mirror(ctx, prob, N, K, walks, bound, entropy, grun, dlogz, enlarge, forced
                 out = ctx.rwalk_batch(prob, u0, axes, scale, loglstar, walks, states, axes_idx=fidx, bc=bc)
                 q_nc = np.full(K, walks, dtype=np.int32)
                 ta, tr = int(out["accept"].sum()), int(out["reject"].sum())
+                # no step accepted = the start point again: its own stored ln L (the reference re-evaluates to the same
+                # bits, internal_samplers.py:970-975; two device kernels may differ in the last one)
+                out["logl"] = np.where(out["accept"] == 0, live_logl[start], out["logl"])
             else:
                 out = ctx.slice_batch(prob, u0, axes, scale, loglstar, walks, states, principal=sample == "slice",
                                       doubling=doubling, axes_idx=fidx)
