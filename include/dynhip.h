@@ -447,6 +447,8 @@ int dh_ns_consume(dh_ctx* ctx, int runs, int nlive, int queue_size, double dlogz
  * latency chain per interval instead of one per fill (64 C2 runs: 0.335 s at n = 1, 0.20 s at n >= 4).  0: chosen
  * from (sampler, nlive, queue_size) alone: ceil(nlive / K) for rwalk, ceil(1.3 nlive / (4.4 K)) for the slice
  * samplers, ceil(1.3 nlive / (1.7 K)) for unif; at most 16.
+ * An rwalk walker that accepted no step returns its start point with that live point's own stored ln L (an exact tie, as
+ * the reference's re-evaluation gives: internal_samplers.py:970-975, sampler.py:1107-1119).
  * max_fills (0: 10^6) bounds the fills the ENSEMBLE is taken through, idle ones included: a fill in which a run
  * waits for its rebuild counts for that run as well, so with rebuild_every > 1 a run reaches status 1 after fewer of
  * its own fills than max_fills (n_fills_out is the same count). */
