@@ -97,6 +97,11 @@ struct NsArgs {
   // DH_NS_OPT_FORCED_EXACT: the forced update inside the fill that found the start point
   int forced_exact;
   int* force_first;   // runs: queue index of the first start point outside the bound (INT_MAX: none)
+  // (forced_exact) update_bound_if_needed runs when the queue's last entry has been POPPED, before its point replaces the
+  // worst one (sampler.py:771-772, 1176-1185): when that entry made the fill's last death, the slot's previous content
+  // is kept here and stands in the live set while the next regular bound is built (ns_swap_undo)
+  double* undo_u;     // runs x ndim
+  int* undo_slot;     // runs: the slot, or -1
   uint64_t* sel_ent;  // runs x 4: the words ns_select seeded this fill's walker selections from
   int* ndone;
   // bound (rebuild outputs)
@@ -428,13 +433,32 @@ __global__ void __launch_bounds__(256) ns_gather(NsArgs a) {
 // frames of the masked runs in the second half of the axes array, the masked rebuild runs, and ns_reselect points the
 // entries up to force_first at the kept frames and redraws the frames of the later ones from the new volumes (same
 // variates: the selection generator of entry w is a function of the fill's four words and w).
+// (forced_exact) the live set as the reference's regular bound update sees it: without the point that the previous
+// fill's last queue entry brought in (see NsArgs::undo_u); launched before and after the masked rebuild (a swap)
+__global__ void __launch_bounds__(64) ns_swap_undo(NsArgs a) {
+  const int run = blockIdx.x;
+  if (!a.rebuild_mask[run]) return;
+  const int s = a.undo_slot[run];
+  if (s < 0) return;
+  for (int x = threadIdx.x; x < a.ndim; x += 64) {
+    double* p = a.live_u + ((size_t)run * a.nlive + s) * a.ndim + x;
+    double* q = a.undo_u + (size_t)run * a.ndim + x;
+    const double tmp = *p;
+    *p = *q;
+    *q = tmp;
+  }
+}
+
 __global__ void __launch_bounds__(kT) ns_force_prepare(NsArgs a) {
   for (int run = threadIdx.x; run < a.runs; run += kT) {
     NsRun& r = a.st[run];
     const int f = (a.force[run] && r.mode == MODE_BOUND && a.run_mode[run] == MODE_BOUND && a.bstatus[run] == DH_OK) ? 1 : 0;
     if (f) {
       r.due = 0;
-      r.ncall_last_update = r.ncall;
+      // update_bound_if_needed(-inf, force=True) records self.ncall (sampler.py:631-632, 674): the sampler's counter,
+      // which at a refill does not yet hold the calls of the entries popped since the last death (they are still in
+      // _new_point's ncall_accum, sampler.py:739-747) -- the carry
+      r.ncall_last_update = r.ncall - r.nc_carry;
       r.nbound += 1;
       if (a.bootstrap > 0) {
         Pcg64 g;
@@ -1789,6 +1813,17 @@ __global__ void __launch_bounds__(kT) ns_consume(NsArgs a) {
       to[x] = sj < 0 ? a.live_u[((size_t)run * N + s) * D + j] : a.r_u[((size_t)run * K + sj) * D + j];
     }
   }
+  if (a.undo_slot) {
+    const int E1 = nkeep - 1;
+    if (nkeep > 0 && dj[E1] == K - 1) {
+      const int s = real_slot(dslot[E1]), sj = dsrc[E1];
+      for (int x = t; x < D; x += kT)
+        a.undo_u[(size_t)run * D + x] = sj < 0 ? a.live_u[((size_t)run * N + s) * D + x] : a.r_u[((size_t)run * K + sj) * D + x];
+      if (t == 0) a.undo_slot[run] = s;
+    } else if (t == 0) {
+      a.undo_slot[run] = -1;
+    }
+  }
   __syncthreads();
   NS_PROF(4);
   // apply the surviving replacements to the live set: the replaced slots are listed first (dslot / dj are free by
@@ -2052,6 +2087,8 @@ int dh_ns_consume(dh_ctx* ctx, int runs, int nlive, int queue_size, double dlogz
   a.forced_exact = 0;
   a.force_first = nullptr;
   a.sel_ent = nullptr;
+  a.undo_u = nullptr;
+  a.undo_slot = nullptr;
   a.dlogz = dlogz;
   a.dead_rel = 1;
   arena_reset(ctx);
@@ -2222,6 +2259,8 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
   a.forced_exact = 0;
   a.force_first = nullptr;
   a.sel_ent = nullptr;
+  a.undo_u = nullptr;
+  a.undo_slot = nullptr;
   {
     const double* o = ctx->ns_opt;
     if (!std::isnan(o[DH_NS_OPT_UPDATE_INTERVAL])) {
@@ -2301,7 +2340,7 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
                o_rec = take((size_t)R * 8 * 8), o_ent = take((size_t)n_words * 4),
                o_fw = take((size_t)R * ns_fin_stride(N) * 8), o_cum = take((size_t)R * me * 8), o_be = take((size_t)R * 32),
                o_rs = take((size_t)R * 8), o_ff = take((size_t)R * 4), o_se = take((size_t)R * 32),
-               o_bcf = take((size_t)D + 8),
+               o_bcf = take((size_t)D + 8), o_uu = take((size_t)R * D * 8), o_us = take((size_t)R * 4),
                o_boot = take(bootstrap > 0 ? bootstrap_ws_bytes(R, N, D, me, bootstrap) : 8),
                o_lit = take(want_pt ? (size_t)R * N * 4 : 8), o_pid = take(want_pt ? (size_t)R * a.cap * 4 : 8),
                o_pit = take(want_pt ? (size_t)R * a.cap * 4 : 8), o_pnc = take(want_pt ? (size_t)R * a.cap * 4 : 8);
@@ -2365,6 +2404,8 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
   a.run_shift = (double*)(base + o_rs);
   a.force_first = (int*)(base + o_ff);
   a.sel_ent = a.forced_exact ? (uint64_t*)(base + o_se) : nullptr;
+  a.undo_u = a.forced_exact ? (double*)(base + o_uu) : nullptr;
+  a.undo_slot = a.forced_exact ? (int*)(base + o_us) : nullptr;
   if (want_pt) {
     a.live_it = (int*)(base + o_lit);
     a.dead_id = (int*)(base + o_pid);
@@ -2384,6 +2425,7 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
       !hip_ok(ctx, hipMemsetAsync(base + o_bs, 0, (size_t)R * 4, s), "memset") ||
       !hip_ok(ctx, hipMemsetAsync(base + o_fo, 0, (size_t)R * 4, s), "memset") ||
       !hip_ok(ctx, hipMemsetAsync(base + o_ff, 0x7f, (size_t)R * 4, s), "memset") ||
+      !hip_ok(ctx, hipMemsetAsync(base + o_us, 0xff, (size_t)R * 4, s), "memset") ||
       !hip_ok(ctx, hipMemsetAsync(base + o_ne, 0, (size_t)R * 4, s), "memset") ||
       !hip_ok(ctx, hipMemcpyAsync(d_ent, entropy_words, (size_t)n_words * 4, hipMemcpyHostToDevice, s), "H2D"))
     return cleanup(DH_ERR_HIP);
@@ -2451,8 +2493,10 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
         ctx->stream = rb_stream;
       }
       if (a.rebuild_fill) {
+        if (a.forced_exact) hipLaunchKernelGGL(ns_swap_undo, dim3(R), dim3(64), 0, ctx->stream, a);
         rc = build_bounds();
         if (rc) return cleanup(rc);
+        if (a.forced_exact) hipLaunchKernelGGL(ns_swap_undo, dim3(R), dim3(64), 0, ctx->stream, a);
       }
       if (a.overlap) {
         ctx->stream = main_stream;

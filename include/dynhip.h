@@ -482,7 +482,10 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim,
  *                               finds a start point outside the bound: the run's bound is rebuilt before its walkers
  *                               start, the queue entries up to and including the first one outside keep their axes from
  *                               the old bound, the later ones take theirs from the new one -- the reference's sequence
- *                               for any queue size.  Default 0: the run is flagged and rebuilds before its next fill
+ *                               for any queue size; the regular bound is then also built as the reference builds
+ *                               it, without the point that the previous fill's last queue entry brought in
+ *                               (update_bound_if_needed runs before that replacement: sampler.py:771-772, 1176-1185).
+ *                               Default 0: the run is flagged and rebuilds before its next fill
  *                               (the fast form: no extra launches in fills without a forced update).  Not combined
  *                               with the uniform sampler (no start points) and switches DH_NS_OVERLAP off.
  * A run ended by maxiter / maxcall / logl_max ends normally (status 0), as the reference's does. */

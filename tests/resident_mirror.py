@@ -124,6 +124,8 @@ def _mirror(ctx, prob, N, K, walks, bound, entropy, grun, dlogz, enlarge, forced
     if first:
         first_ncall, first_eff = first.get("min_ncall", first_ncall), first.get("min_eff", first_eff)
     cube, scale, nbound, ncall_last, force = True, 1.0, 0, 0, False
+    carry = 0  # calls of the entries popped since the last death (sampler.py:739-747: _new_point's ncall_accum)
+    undo = None  # (slot, its content before the replacement) when the previous fill's last entry made the last death
     bnd = None
     ev = dict(dead_logl=[], dead_slot=[], dead_src=[], fill_of_death=[], forced_fills=[], rebuild_fills=[])
 
@@ -176,7 +178,16 @@ def _mirror(ctx, prob, N, K, walks, bound, entropy, grun, dlogz, enlarge, forced
         force = False
         if want:
             cube = False
-            rebuild()
+            if forced == "exact" and undo is not None:
+                # update_bound_if_needed runs inside _new_point when the queue's LAST entry has been popped
+                # (sampler.py:771-772), before that entry's point replaces the worst one (sampler.py:1176-1185): the
+                # bound is built from the live set without the newest point
+                keep = live_u[undo[0]].copy()
+                live_u[undo[0]] = undo[1]
+                rebuild()
+                live_u[undo[0]] = keep
+            else:
+                rebuild()
             ncall_last = ncall
             ev["rebuild_fills"].append(fill)
         # ---- ns_select: four words of the run's generator seed this fill's K selection streams ----
@@ -222,7 +233,7 @@ def _mirror(ctx, prob, N, K, walks, bound, entropy, grun, dlogz, enlarge, forced
                     # sampler.py:484-489 inside the fill: entries up to the first one outside keep the old frames
                     jstar = int(np.argmin(inside))
                     rebuild()
-                    ncall_last = ncall
+                    ncall_last = ncall - carry  # self.ncall at the refill (sampler.py:631-632, 674)
                     new_axes, new_lv = frames_of()
                     multi2 = bound == "multi" and bnd.nells > 1
                     cum2 = cum_of(new_lv) if multi2 else None
@@ -262,6 +273,12 @@ def _mirror(ctx, prob, N, K, walks, bound, entropy, grun, dlogz, enlarge, forced
         ev["dead_slot"].extend(slots.tolist())
         ev["dead_src"].extend(srcs.tolist())
         ev["fill_of_death"].extend([fill] * len(slots))
+        carry = int(q_nc[srcs[-1] + 1:].sum()) if len(slots) else carry + int(q_nc.sum())
+        undo = None
+        if len(slots) and srcs[-1] == K - 1:
+            sl = int(slots[-1])
+            prev = [e for e in range(len(slots) - 1) if slots[e] == sl]
+            undo = (sl, (out["u"][srcs[prev[-1]]] if prev else live_u[sl]).copy())
         if len(slots):
             order = np.argsort(slots, kind="stable")
             same = slots[order][1:] == slots[order][:-1]
