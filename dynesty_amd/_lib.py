@@ -862,8 +862,12 @@ class Context:
         nan = float('nan')
         if update_interval is not None:
             # dynesty.py:213-234: a float is a multiple of nlive, an int a number of calls
-            update_interval = max(1, round(update_interval * nlive)) if isinstance(update_interval, float) \
-                else int(update_interval)
+            # (np.floating is not a Python float: an np.float32 ratio used to be truncated by int(); any value is
+            # clamped to >= 1 call like the reference's max(min(round(ratio * nlive), maxsize), 1), dynesty.py:646-649)
+            if isinstance(update_interval, (int, np.integer)) and not isinstance(update_interval, bool):
+                update_interval = max(1, int(update_interval))
+            else:
+                update_interval = max(1, int(round(float(update_interval) * nlive)))
         fu = first_update or {}
         opts = [nan if update_interval is None else float(update_interval),
                 float(fu['min_ncall']) if 'min_ncall' in fu else nan,

@@ -19,6 +19,8 @@ Differences that are visible to a caller (all documented in DESIGN.md):
 import math
 from collections.abc import Iterable
 
+import bisect
+
 import numpy as np
 from scipy.special import logsumexp
 
@@ -338,11 +340,28 @@ class HipMultiEllipsoid(HipBound):
                 rstate=rstate, return_overlap=True)
 
     def get_random_axes(self, rstate):
-        """bounding.py:726-731 (one uniform draw, volume-weighted choice)."""
-        probs = np.exp(self.logvol_ells - self.logvol)
-        idx = min(np.searchsorted(np.cumsum(probs), rstate.random()),
-                  len(probs) - 1)
-        return self.axes_ells[idx]
+        """bounding.py:726-731 (one uniform draw, volume-weighted choice).
+
+        dynesty calls this once per queue entry (sampler.py:689-693): the cumulative
+        volumes are kept between calls -- same expression, same bits -- for as long as
+        the arrays they were formed from are unchanged (they are compared by value: a
+        handful of doubles), and an ellipsoid's frame is always the same view object,
+        so that a queue's frames deduplicate by identity (samplers._frames)."""
+        key = (id(self.axes_ells), self.logvol_ells.tobytes(), float(self.logvol))
+        cache = self.__dict__.get('_axes_cache')
+        if cache is None or cache[0] != key:
+            probs = np.exp(self.logvol_ells - self.logvol)
+            cache = (key, np.cumsum(probs).tolist(), list(self.axes_ells))
+            self.__dict__['_axes_cache'] = cache
+        cum = cache[1]
+        # np.searchsorted(..., side='left') on the same doubles
+        idx = min(bisect.bisect_left(cum, rstate.random()), len(cum) - 1)
+        return cache[2][idx]
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state.pop('_axes_cache', None)  # views of this instance's arrays, keyed on their id
+        return state
 
 
 # ---------------------------------------------------------------------------

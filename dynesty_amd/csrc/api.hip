@@ -161,15 +161,6 @@ void dh_destroy(dh_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->side_stream);
     (void)hipStreamDestroy(ctx->side_stream);
   }
-  for (int i = 0; i < 2; ++i) {
-    if (ctx->sub_stream[i]) {
-      (void)hipStreamSynchronize(ctx->sub_stream[i]);
-      (void)hipStreamDestroy(ctx->sub_stream[i]);
-    }
-    if (ctx->ev_sub_join[i]) (void)hipEventDestroy(ctx->ev_sub_join[i]);
-  }
-  for (int i = 0; i < dh_ctx::kSubEvents; ++i)
-    if (ctx->ev_sub[i]) (void)hipEventDestroy(ctx->ev_sub[i]);
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);

@@ -58,11 +58,6 @@ struct dh_ctx {
   // on `stream` (fork after k_root, join before k_finish); created on first use
   hipStream_t side_stream = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  // streams of the rebuild's subtree kernel (k_sub: a level's small subtrees beside the next level's kernels)
-  static constexpr int kSubEvents = 32;
-  hipStream_t sub_stream[2] = {nullptr, nullptr};
-  hipEvent_t ev_sub[kSubEvents] = {};
-  hipEvent_t ev_sub_join[2] = {nullptr, nullptr};
   // rwalk kernel form (dh_set_rwalk_form): 0 / 2 = four lanes per walker (walkq.hip) wherever that kernel is
   // built -- decided by the problem alone, never by the launch size --, 1 = one walker per lane always
   int rwalk_form = 0;

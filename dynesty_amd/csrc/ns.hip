@@ -2183,12 +2183,14 @@ int dh_ns_set_option(dh_ctx* ctx, int key, double value) {
 
 int dh_ns_set_boundary(dh_ctx* ctx, int ndim, const int8_t* bc) {
   DH_CHECK_CTX(ctx);
-  ctx->ns_bc.clear();
+  // validate first: a rejected call leaves the installed flags as they were
   if (bc && ndim > 0) {
     for (int i = 0; i < ndim; ++i)
       if (bc[i] != DH_BC_HARD && bc[i] != DH_BC_PERIODIC && bc[i] != DH_BC_REFLECT)
         return fail(ctx, DH_ERR_ARG, "ns boundary flag %d of dimension %d", (int)bc[i], i);
     ctx->ns_bc.assign(bc, bc + ndim);
+  } else {
+    ctx->ns_bc.clear();
   }
   return DH_OK;
 }
@@ -2201,6 +2203,21 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
                    int64_t* n_fills_out, int32_t* dead_id_out, int32_t* dead_it_out, int32_t* dead_nc_out,
                    int32_t* live_it_out, int bootstrap, int rebuild_every) {
   DH_CHECK_CTX(ctx);
+  // Options and boundary flags are one-shot: this call takes them and the context forgets them, whichever way the call
+  // ends, so that nothing set for one ensemble (maxiter, add_live = 0, forced_exact, periodic coordinates) can leak
+  // into a later one whose caller set nothing.
+  struct NsOneShot {
+    dh_ctx* c;
+    double opt[DH_NS_OPT_COUNT];
+    std::vector<int8_t> bc;
+    explicit NsOneShot(dh_ctx* cc) : c(cc) {
+      for (int i = 0; i < DH_NS_OPT_COUNT; ++i) {
+        opt[i] = c->ns_opt[i];
+        c->ns_opt[i] = __builtin_nan("");
+      }
+      bc.swap(c->ns_bc);
+    }
+  } shot(ctx);
   const bool want_pt = dead_id_out || dead_it_out || dead_nc_out || live_it_out;
   if (want_pt && !(dead_id_out && dead_it_out && dead_nc_out && live_it_out))
     return fail(ctx, DH_ERR_ARG, "ns_ensemble: the per-point outputs (id, it, nc, live it) come together");
@@ -2231,8 +2248,8 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
   // the register sort of the live slots is built for at most 32 keys per thread (sort_slots<32>); the LDS bound of
   // ns_finish below is tighter today, this one is the sort's own
   if (N > 65535) return fail(ctx, DH_ERR_ARG, "ns_ensemble: nlive %d > 65535 (slots travel as 16-bit indices)", N);
-  if (!ctx->ns_bc.empty() && (int)ctx->ns_bc.size() != ndim)
-    return fail(ctx, DH_ERR_ARG, "ns_ensemble: %d boundary flags for ndim %d", (int)ctx->ns_bc.size(), ndim);
+  if (!shot.bc.empty() && (int)shot.bc.size() != ndim)
+    return fail(ctx, DH_ERR_ARG, "ns_ensemble: %d boundary flags for ndim %d", (int)shot.bc.size(), ndim);
   const int me = bound_multi ? (N / (2 * D) > 0 ? N / (2 * D) : 1) : 1;
   NsArgs a{};
   a.runs = R;
@@ -2262,12 +2279,12 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
   a.undo_u = nullptr;
   a.undo_slot = nullptr;
   {
-    const double* o = ctx->ns_opt;
+    const double* o = shot.opt;
     if (!std::isnan(o[DH_NS_OPT_UPDATE_INTERVAL])) {
       // update_interval as dynesty takes it (dynesty.py:213-234): a float is a multiple of nlive, an int a number of calls
       const double v = o[DH_NS_OPT_UPDATE_INTERVAL];
-      a.update_interval = v > 0.0 ? (long long)llround(v) : a.update_interval;
-      if (a.update_interval < 1) a.update_interval = 1;
+      // (a value below one call is one call: the reference's max(min(round(...), maxsize), 1), dynesty.py:646-649)
+      a.update_interval = v >= 1.0 ? (long long)llround(v) : 1;
     }
     if (!std::isnan(o[DH_NS_OPT_FIRST_MIN_NCALL])) a.first_ncall = (long long)llround(o[DH_NS_OPT_FIRST_MIN_NCALL]);
     if (!std::isnan(o[DH_NS_OPT_FIRST_MIN_EFF])) a.first_eff = o[DH_NS_OPT_FIRST_MIN_EFF];
@@ -2415,8 +2432,8 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
   uint32_t* d_ent = (uint32_t*)(base + o_ent);
   hipStream_t s = ctx->stream;
   const int8_t* d_bc = nullptr;  // periodic / reflective coordinates (dh_ns_set_boundary)
-  if (!ctx->ns_bc.empty()) {
-    if (!hip_ok(ctx, hipMemcpyAsync(base + o_bcf, ctx->ns_bc.data(), (size_t)D, hipMemcpyHostToDevice, s), "H2D bc"))
+  if (!shot.bc.empty()) {
+    if (!hip_ok(ctx, hipMemcpyAsync(base + o_bcf, shot.bc.data(), (size_t)D, hipMemcpyHostToDevice, s), "H2D bc"))
       return cleanup(DH_ERR_HIP);
     d_bc = (const int8_t*)(base + o_bcf);
   }

@@ -79,7 +79,7 @@ struct RebuildArgs {
   int* nsplit;        // (levels+1) x runs
   int* nell;          // levels x runs
   int* split_list;    // 2 x runs x maxw   (by level parity)
-  int* ell_list;      // levels x runs x 2 maxw (one list per level: k_sub reads a level's list while the next is written)
+  int* ell_list;      // levels x runs x 2 maxw (one list per level)
   // k-means parts: a splittable node of c points is worked on by ceil(c / TP) workgroups
   // ("parts"), each keeping its TP points resident in LDS for all ten iterations
   int fin_extra_off;  // k_finish: byte offset of the LDS node/result-list copies (0: keep them in global memory)
@@ -107,9 +107,7 @@ struct RebuildArgs {
   int* out_fast;      // runs x max_ells: 1 = that node's record is the eigen-free form
   // persistent work-queue form of the tree (k_tree): no levels -- a node's split is queued when its
   // ellipsoid exists, its children's ellipsoids when its last part has finished the partition
-  int tree;           // 1: queue_split / split_body / ell_body feed the queue instead of the level lists;
-                      // 2: the calling workgroup owns the node's whole subtree (k_sub): coherent accesses as in 1, no queue
-  int sub_max;        // > 0: a new child of at most sub_max points is left to k_sub (its whole subtree by ONE workgroup)
+  int tree;           // 1: queue_split / split_body / ell_body feed the queue instead of the level lists
   int tree_from;      // level pipeline: splits for levels >= tree_from are queued for the k_tree tail instead
   unsigned long long* tq_items;  // tq_cap work items, 0 = not published yet
   int* tq_ctl;        // [0] head (next ticket), [16] tail (next free slot), [32] items queued or in flight, [48] error
@@ -1956,8 +1954,6 @@ __device__ __forceinline__ void split_body(const RebuildArgs& a, const Lds& L, c
   const int D = a.d, t = threadIdx.x;
   const size_t lp = (size_t)(level & 1) * a.runs + run;
   // k_tree (a.tree): `slot` IS the node; its barrier / done counter / first partial-sum slot sit in nbar
-  // k_sub (a.tree == 2): `slot` is the node as well, the workgroup is its only part (single): no barrier, no
-  // partial-sum slots, and the children stay with this workgroup (L.ri[300] = first child or -1)
   const bool tq = a.tree == 1;
   int* nb = tq ? a.nbar + ((size_t)run * a.max_nodes + slot) * kBarStride : nullptr;
   const int pb = tq ? ld_agent_i(nb + 2) : (a.tree ? 0 : a.part_base[lp * a.maxw + slot]);
@@ -1970,7 +1966,6 @@ __device__ __forceinline__ void split_body(const RebuildArgs& a, const Lds& L, c
   double* kp0 = a.kpart + ((size_t)run * a.maxp + pb) * KP;
   double* kp1 = kp0 + (size_t)a.runs * a.maxp * KP;
   int* bar = a.tree ? nb : a.kbar + (((size_t)level * a.runs + run) * a.maxw + slot) * kBarStride;
-  if (a.tree == 2 && t == 0) L.ri[300] = -1;
   PH_T0();
   const int n0 = node_kmeans_part(L, a.pts_scaled + (size_t)run * a.n * D, v.perm, v.perm2, start, count, D,
                                   v.estore + (size_t)cur * v.NS, q, np, kp0, kp1, bar, min_size);
@@ -2104,7 +2099,7 @@ __device__ __forceinline__ bool ell_body(const RebuildArgs& a, const Lds& L, con
     v.nodes[node].logvol = lv;
     v.nodes[node].fmax = fmx;
     v.nodes[node].fast = full ? 0 : 1;
-    if (count >= 4 * D && a.tree != 2) {  // big enough to try a split at the next level (:1492-1496); k_sub: its caller splits
+    if (count >= 4 * D) {  // big enough to try a split at the next level (:1492-1496)
       if (!a.tree && a.tree_from > a.levels && level + 1 >= a.levels) {
         atomicMin(&a.status[run], DH_ERR_NOMEM);  // deeper than the launch plan
       } else {
@@ -2139,7 +2134,6 @@ __global__ void __launch_bounds__(kThreads, SLOW ? 1 : 2) k_ell(RebuildArgs a, i
   for (int slot = g; slot < cnt; slot += G) {
     // (a child is created with fmax = inf: a finite value = k_ell_wave has built this one)
     if (skip_done && v.nodes[list[slot]].fmax < INFINITY) continue;
-    if (a.sub_max > 0 && v.nodes[list[slot]].count <= a.sub_max) continue;  // k_sub's (with its whole subtree)
     if (!ell_body<SLOW>(a, L, v, run, level, list[slot])) return;
   }
 }
@@ -2269,7 +2263,6 @@ __global__ void __launch_bounds__(64, 3) k_ell_wave(RebuildArgs a, int level, in
     const int node = list[slot];
     const int start = v.nodes[node].start, count = v.nodes[node].count;
     if (!v.nodes[node].has_mean || count < 2 || count > cap || (!axis && count >= 4 * D)) continue;
-    if (a.sub_max > 0 && count <= a.sub_max) continue;  // k_sub's
     double lv = 0.0, fmx = INFINITY;
     __syncthreads();
     L.c_pts = nullptr;
@@ -2294,197 +2287,6 @@ __global__ void __launch_bounds__(64, 3) k_ell_wave(RebuildArgs a, int level, in
   }
 }
 
-// ---- leaves, one wavefront each, in registers (round 4) ----------------------------------------------------
-// Half of a tree's nodes are children too small to be split again (count < 4 d: the 2 048 children of ~62 points of
-// the 64-run bench tree's last level), and k_ell builds them like every other node: a 256-thread workgroup, the
-// point tile and four d x d matrices in LDS, 25 barrier-separated sweeps -- ~37 us a node, two nodes per CU, four
-// rounds of workgroup slots for that level alone.  A leaf needs less (no major axis: it is never split), and a
-// d x d problem with d <= 32 fits ONE wavefront's registers: lane i holds row i of the covariance.  Everything is
-// wave-local -- no LDS, no barrier -- and a value another lane holds is a v_readlane away (the loops are unrolled:
-// every lane / register index is static):
-//   covariance   lane i: C[i][k] += xc_i * xc_k over the node's points, xc_k by readlane from the lane that loaded it
-//   Cholesky     right-looking, in place: pivot d_j from lane j, L[i][j] = C[i][j] / sqrt(d_j), C[i][k] -= L[i][j] L[k][j];
-//                a pivot <= 0 declines the node (k_ell's regularising route takes it); ln det = sum ln d_j
-//   Mahalanobis  lane = point: y = L^-1 (x - mean) by forward substitution (L[j][k] read from lane j), max |y|^2;
-//                the same pass on the unit vectors gives L^-1 column by column: tr(cov^-1) for the conditioning
-//                certificate of the eigen-free path (cond <= tr(cov) tr(cov^-1) < 1e7, else declined) and
-//                am = L^-T L^-1 for the record
-// A node it builds is marked like k_ell_wave's (finite fmax) and skipped by k_ell.  The record is the eigen-free
-// one (ctr | cov | am | no axis); numbers agree with k_ell's to rounding (another summation order), not bit for bit.
-// value of `v` in lane `lane` (a compile-time constant after unrolling) as a wave-uniform scalar.  Volatile asm, not
-// the builtin: the factor's entries are read again by every forward substitution, and left to itself the compiler
-// hoists all ~650 of those scalar values out of the loops and keeps them alive in spill registers (958 spilled
-// scalar registers, 238 AGPRs: one wavefront per SIMD)
-template <int DP>
-__device__ __forceinline__ double rl_d(double v, int lane) {
-  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
-  unsigned lo, hi;
-  asm volatile("v_readlane_b32 %0, %1, %2" : "=s"(lo) : "v"((unsigned)b), "s"(lane));
-  asm volatile("v_readlane_b32 %0, %1, %2" : "=s"(hi) : "v"((unsigned)(b >> 32)), "s"(lane));
-  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-}
-__device__ __forceinline__ double wave_sum_d(double v) {
-  for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s);
-  return v;
-}
-__device__ __forceinline__ double wave_max_d(double v) {
-  for (int s = 32; s > 0; s >>= 1) v = fmax(v, __shfl_xor(v, s));
-  return v;
-}
-
-template <int DP>
-__global__ void __launch_bounds__(64) k_leaf(RebuildArgs a, int level, int G) {
-  const int run = blockIdx.x / G, g = blockIdx.x % G;
-  const int* list = a.ell_list + ((size_t)level * a.runs + run) * 2 * a.maxw;
-  const int cnt = a.nell[(size_t)level * a.runs + run];
-  if (g >= cnt) return;
-  if (a.kerr[run] != DH_OK || a.status[run] != DH_OK) return;  // (k_ell, next on the stream, reports it)
-  const int D = a.d;
-  const RunView v = view_of(a, run, D | 1);
-  for (int slot = g; slot < cnt; slot += G) {
-    // (the lane index is made opaque per node: the dozens of lane masks `k == lane` of the unrolled phases are
-    // loop-invariant otherwise, and the compiler keeps them all alive across the loop in spilled scalar registers)
-    int lane = threadIdx.x;
-    asm volatile("" : "+v"(lane));
-    const int node = list[slot];
-    const int start = v.nodes[node].start, count = v.nodes[node].count;
-    if (!v.nodes[node].has_mean || count < 2 || count > 128 || count >= 4 * D) continue;
-    double* es = v.estore + (size_t)node * v.NS;
-    const double mu = lane < D ? es[lane] : 0.0;  // lane k: mean_k
-    // ---- covariance: lane i holds row i ----
-    double c[DP];
-#pragma unroll
-    for (int k = 0; k < DP; ++k) c[k] = 0.0;
-    for (int p0 = 0; p0 < count; p0 += 4) {
-      double xc[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int p = p0 + u < count ? p0 + u : count - 1;
-        const int row = v.perm[start + p];
-        const double x = lane < D ? v.pts[(size_t)row * D + lane] - mu : 0.0;
-        xc[u] = p0 + u < count ? x : 0.0;
-      }
-      // (scheduling barriers: left alone the scheduler gathers the readlanes of a whole unrolled phase in front of
-      // their uses and spills ~950 scalar registers)
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-#pragma unroll
-        for (int k = 0; k < DP; ++k) c[k] = fma(xc[u], rl_d<DP>(xc[u], k), c[k]);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-    const double inv = 1.0 / (double)(count - 1);
-    double tr_cov = 0.0;
-#pragma unroll
-    for (int k = 0; k < DP; ++k) {
-      c[k] *= inv;
-      if (lane >= D) c[k] = (k == lane) ? 1.0 : 0.0;  // padding rows: identity
-      tr_cov += (k == lane && lane < D) ? c[k] : 0.0;
-    }
-    tr_cov = wave_sum_d(tr_cov);
-    double cc[DP];  // the covariance itself, for the record
-#pragma unroll
-    for (int k = 0; k < DP; ++k) cc[k] = c[k];
-    // ---- Cholesky in place: c[k] (k < lane) = L[lane][k], c[lane] = 1 / L[lane][lane] ----
-    bool ok = true;
-    double dsave = 1.0;
-#pragma unroll
-    for (int j = 0; j < DP; ++j) {
-      const double d = rl_d<DP>(c[j], j);
-      ok = ok && d > 0.0 && isfinite(d);
-      double r = __builtin_amdgcn_rsq(d);
-      r = r * fma(-0.5 * d * r, r, 1.5);
-      r = r * fma(-0.5 * d * r, r, 1.5);
-      const double lj = c[j] * r;  // L[lane][j] for lane >= j
-      if (lane == j) dsave = d;
-      c[j] = lane == j ? r : lj;
-#pragma unroll
-      for (int k = j + 1; k < DP; ++k) c[k] = fma(-lj, rl_d<DP>(lj, k), c[k]);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if (!ok) continue;  // not positive definite in floating point: k_ell's regularising route
-    double logdet = wave_sum_d(lane < D ? log(dsave) : 0.0);
-    // ---- forward substitution: lane p solves L y = b_p ----
-    double y[DP];
-    auto solve = [&](double& q) {
-      q = 0.0;
-#pragma unroll
-      for (int j = 0; j < DP; ++j) {
-        double s = y[j];
-#pragma unroll
-        for (int k = 0; k < j; ++k) s = fma(-rl_d<DP>(c[k], j), y[k], s);
-        y[j] = s * rl_d<DP>(c[j], j);
-        q = fma(y[j], y[j], q);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    };
-    // the node's points: Mahalanobis maximum
-    double fmx = 0.0;
-    for (int p0 = 0; p0 < count; p0 += 64) {
-      const int p = p0 + lane < count ? p0 + lane : count - 1;
-      const double* xr = v.pts + (size_t)v.perm[start + p] * D;
-#pragma unroll
-      for (int j = 0; j < DP; ++j) y[j] = j < D ? xr[j] - rl_d<DP>(mu, j) : 0.0;
-      double q;
-      solve(q);
-      fmx = fmax(fmx, p0 + lane < count ? q : 0.0);
-    }
-    fmx = wave_max_d(fmx);
-    // the unit vectors: lane p gets column p of L^-1
-#pragma unroll
-    for (int j = 0; j < DP; ++j) y[j] = j == lane ? 1.0 : 0.0;
-    double qi;
-    solve(qi);
-    const double tr_am = wave_sum_d(lane < D ? qi : 0.0);
-    if (!(tr_cov * tr_am < kFastCond) || !isfinite(logdet)) continue;  // (NaN fails as well): k_ell's route
-    // ---- enlarge so that the outermost point sits at 1 - ROUND_DELTA (bounding.py:1438-1448), record ----
-    const double lim = 1.0 - kRoundDelta;
-    double mult = 1.0;
-    if (fmx > lim) {
-      mult = fmx / lim;
-      logdet += (double)D * log(mult);
-    }
-    const double rmult = 1.0 / mult;
-    const int DD = D * D;
-    // am = L^-T L^-1: row `lane` = sum_j y_lane[j] y_b[j] (y_b[j] = 0 for j < b), stored as it is formed.
-    // Symmetric matrices: lane i writes its row as COLUMN i -- consecutive lanes, consecutive addresses.
-#pragma unroll
-    for (int b = 0; b < DP; ++b) {
-      double s = 0.0;
-#pragma unroll
-      for (int j = b; j < DP; ++j) s = fma(y[j], rl_d<DP>(y[j], b), s);
-      // (pinned here: the sums are only stored by the lanes of the matrix, and the compiler sinks the whole
-      // product into that branch while the volatile readlanes stay put -- 756 scalar values spilled in between)
-      asm volatile("" : "+v"(s));
-      if (lane < D && b < D) {
-        es[D + b * D + lane] = cc[b] * mult;
-        es[D + DD + b * D + lane] = s * rmult;
-        es[D + 2 * DD + b * D + lane] = 0.0;  // no axis: a leaf is never split
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if (lane < D) es[D + 3 * DD + lane] = 0.0;
-    if (lane == 0) {
-      v.nodes[node].logvol = a.prefactor + 0.5 * logdet;
-      v.nodes[node].fast = 1;
-      v.nodes[node].fmax = fmin(fmx, lim);  // finite: built (k_ell skips it)
-    }
-  }
-}
-
-// ---- the whole tree by persistent workers on one work queue -----------------------------------------------
-// The level pipeline makes every level wait for its slowest node, twice (k_split, k_ell), launches a pair
-// of kernels per possible level, and cannot run a node's k-means before ALL ellipsoids of its level exist.
-// Here the tree is a set of work items -- "ellipsoid of node x", "k-means part q of node x" -- taken by
-// resident workgroups from one FIFO queue in ticket order: a node's parts are queued (contiguously) when its
-// ellipsoid exists, its children's ellipsoids when its last part has finished the partition.  The node
-// routines are those of the level kernels (same arithmetic, same bits); what changes is that producer and
-// consumer are workgroups of one kernel, so everything that crosses between them is written and read at
-// agent scope (L.coh) and published only after the stores are acknowledged.
-// Progress: tickets are claimed in order and the parts of a node hold consecutive tickets, so at most one
-// node can have claimed and unclaimed parts at a time -- the one straddling the lowest unclaimed ticket --
-// and every other workgroup works on something that finishes without it (np <= resident workgroups is
-// checked by the launcher).  The kernel ends when nothing is queued or in flight ([32] == 0).
 // the two item routines are calls, not inlined code: inlined into one loop body their register needs add
 // up past the 256 of two workgroups per CU (42 VGPRs spilled); behind a call each has its own allocation and
 // the loop keeps nothing live across it but the item
@@ -2561,85 +2363,6 @@ __global__ void __launch_bounds__(kThreads, 2) k_tree(RebuildArgs a) {
 // ellipsoid, k-means of the whole node (no parts, no barrier between workgroups), the children's ellipsoids, ... --
 // depth first over a small stack, with the node routines of the level kernels (same arithmetic; the tile's
 // wavefronts are grouped like the 128-point parts, so a node's sums come out as the level kernels' would) and, as
-// producer and consumer of a node are the same workgroup of ONE kernel, the queue form's coherent accesses
-// (a.tree = 2: L.coh, stores acknowledged before they are read back).  k_ell / k_split never see these nodes; the
-// launch runs beside the level kernels of the bigger nodes on a stream of its own.
-__device__ __attribute__((noinline)) bool sub_ell_item(const RebuildArgs& a, unsigned char* smem, int run, int node) {
-  Lds L;
-  carve(L, smem, a.d);
-  L.coh = true;
-  const RunView v = view_of(a, run, L.LD);
-  return ell_body<false>(a, L, v, run, 0, node);
-}
-// returns the first of the node's two children, or -1 (split rejected / error: status says which)
-__device__ __attribute__((noinline)) int sub_split_item(const RebuildArgs& a, unsigned char* smem, int run, int node) {
-  const int D = a.d, t = threadIdx.x;
-  Lds L;
-  carve(L, smem, D);
-  L.coh = true;
-  // the 256-point tile stands in for the level kernels' parts of a.tps points: their wavefronts' partial sums are
-  // folded per part, then in part order (node_kmeans_part)
-  if (L.TP % a.tps == 0 && a.tps >= 64) L.KG = a.tps / 64;
-  const RunView v = view_of(a, run, L.LD);
-  if (t < D) L.scale[t] = a.scale_g[(size_t)run * D + t];
-  __syncthreads();
-  split_body(a, L, v, run, 0, node, 0, true);
-  __syncthreads();
-  return L.ri[300];
-}
-__device__ __attribute__((noinline)) void sub_worker(RebuildArgs a, unsigned char* smem, int run, int root) {
-  constexpr int kStack = 64;
-  __shared__ int s_stack[kStack];
-  __shared__ int s_top;
-  const int t = threadIdx.x, D = a.d;
-  Node* nodes = a.nodes + (size_t)run * a.max_nodes;
-  if (t == 0) {
-    s_stack[0] = root;
-    s_top = 1;
-  }
-  for (;;) {
-    __syncthreads();
-    const int top = s_top;
-    if (top == 0) return;
-    const int node = s_stack[top - 1];
-    __syncthreads();
-    if (t == 0) s_top = top - 1;
-    if (!sub_ell_item(a, smem, run, node)) return;
-    const int count = ld_agent_i(&nodes[node].count);
-    if (count < 4 * D) continue;  // too small to split (:1492-1496)
-    const int c0 = sub_split_item(a, smem, run, node);
-    if (ld_agent_i(&a.status[run]) != DH_OK) return;
-    if (c0 < 0) continue;
-    __syncthreads();
-    if (t == 0) {
-      const int tp = s_top;
-      if (tp + 2 > kStack) {
-        atomicMin(&a.status[run], DH_ERR_NOMEM);
-        s_top = 0;
-      } else {
-        s_stack[tp] = c0 + 1;
-        s_stack[tp + 1] = c0;  // child 0 first
-        s_top = tp + 2;
-      }
-    }
-  }
-}
-
-__global__ void __launch_bounds__(kThreads, 2) k_sub(RebuildArgs a, int level, int G) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int run = blockIdx.x / G, g = blockIdx.x % G;
-  const int* list = a.ell_list + ((size_t)level * a.runs + run) * 2 * a.maxw;
-  const int cnt = a.nell[(size_t)level * a.runs + run];
-  if (g >= cnt) return;
-  if (a.kerr[run] != DH_OK || a.status[run] != DH_OK) return;  // (k_ell, on the main stream, reports kerr)
-  const Node* nodes = a.nodes + (size_t)run * a.max_nodes;
-  for (int slot = g; slot < cnt; slot += G) {
-    const int node = list[slot];
-    if (nodes[node].count > a.sub_max) continue;  // k_ell's
-    sub_worker(a, smem, run, node);
-  }
-}
-
 __global__ void __launch_bounds__(kThreads) k_finish(RebuildArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int D = a.d, t = threadIdx.x, run = blockIdx.x;
@@ -3279,6 +3002,10 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
   if (const char* e = getenv("DH_TREE")) a.tree = a.fast && atoi(e) != 0;
   // level kernels for a balanced tree's depth, the work-queue tail for the rest (DH_DEEP=0: every level
   // by level kernels and no tail, as does the diagnostic slow mode; DH_DEEP_FROM=f: the tail takes over at level f)
+  // (one level pair fewer -- a balanced tree's last split level is the one with n >> L >= 4 d: five pairs for the
+  // bench's 2000 x 25 live sets instead of six -- was measured in round 5 and is SLOWER: 1.411 against 1.382 ms per
+  // 64-run rebuild, eggbox 5.02 against 4.51: real trees are not balanced, and what is deeper than the level kernels
+  // goes to the work-queue tail, which costs more than an almost idle level pair)
   int nlev = a.levels;
   if (a.fast && !(getenv("DH_DEEP") && atoi(getenv("DH_DEEP")) == 0)) nlev = a.levels < lv ? a.levels : lv;
   if (a.fast && getenv("DH_DEEP_FROM")) {
@@ -3288,18 +3015,6 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
   if (a.tree) nlev = 0;
   const bool tail = a.fast && (a.tree || nlev < a.levels);
   a.tree_from = tail ? nlev : a.levels + 1;
-  // Small subtrees by one workgroup each (k_sub): a child of at most sub_max points -- it must fit the 256-point tile,
-  // and below 12 d points its subtree is a handful of nodes -- never enters the level lists.  MEASURED AND LEFT OFF
-  // (round 4; DH_SUB=1 switches it on, DH_SUB_FACTOR sets the bound in units of d): green against every rebuild test,
-  // but the 64-run bench rebuild goes from 1.25 to 1.66 ms -- a subtree of 11 node routines in one workgroup is a
-  // chain of 545 us (coherent accesses, every item re-staging its tile) where the three level pairs it replaces
-  // take 670 us WITH all their slot rounds, and the level kernels of the bigger nodes slow down beside it.
-  a.sub_max = 0;
-  if (a.fast && mode == 0 && !a.tree && d >= 14 && getenv("DH_SUB") && atoi(getenv("DH_SUB")) != 0) {
-    int f = 12;
-    if (const char* e = getenv("DH_SUB_FACTOR")) f = atoi(e) > 4 ? atoi(e) : f;
-    a.sub_max = f * d - 1 < kThreads ? f * d - 1 : kThreads;
-  }
   a.tq_cap = 0;
   a.kp_cap = 0;
   if (tail) {
@@ -3478,9 +3193,9 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
   a.n_arr = n_arr;
   DH_DEV_MEMO(attr_lds);
   if (lds > attr_lds) {
-    const void* ks[8] = {(const void*)k_root_parts, (const void*)k_split, (const void*)k_ell<false>,
+    const void* ks[7] = {(const void*)k_root_parts, (const void*)k_split, (const void*)k_ell<false>,
                          (const void*)k_ell<true>, (const void*)k_out_eig, (const void*)k_root_eig,
-                         (const void*)k_tree, (const void*)k_sub};
+                         (const void*)k_tree};
     for (const void* kf : ks)
       if (!hip_ok(ctx, hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
                   "hipFuncSetAttribute(rebuild LDS)"))
@@ -3536,56 +3251,9 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
       }
     }
   }
-  // Leaves in registers, one wavefront each (k_leaf): 14 <= d <= 32 (below, k_ell_wave's LDS form serves; above, a
-  // row does not fit a lane's registers), from the level whose average child is a leaf (< 4 d points).  MEASURED AND
-  // LEFT OFF (round 4; DH_LEAF=1 switches it on): green against every rebuild test, but a leaf is ~10 000 instructions
-  // of one wavefront (two v_readlane per broadcast double, their hazard nops) = ~100 us, at one wavefront per SIMD
-  // (256 VGPRs + 52 AGPRs at d = 25): the 2 048 leaves of the bench tree's last level take 188 us against k_ell's 153.
-  int leaf_dp = 0, leaf_from = nlev;
-  if (a.fast && mode == 0 && d >= 14 && d <= 32 && getenv("DH_LEAF") && atoi(getenv("DH_LEAF")) != 0) {
-    leaf_dp = (d + 3) / 4 * 4;
-    leaf_from = 0;
-    while (leaf_from < nlev && (n >> (leaf_from + 1)) >= 4 * d) ++leaf_from;
-  }
-  // k_sub launches: from the level whose average child is within twice the bound, each on one of two streams of
-  // its own (a level's subtrees run beside the next level's), joined before k_finish
-  int sub_from = nlev, sub_used = 0;
-  if (a.sub_max > 0) {
-    sub_from = 0;
-    while (sub_from < nlev && (n >> (sub_from + 1)) > 2 * a.sub_max) ++sub_from;
-    if (sub_from < nlev && !ctx->sub_stream[0]) {
-      for (int i = 0; i < 2; ++i)
-        if (!hip_ok(ctx, hipStreamCreateWithFlags(&ctx->sub_stream[i], hipStreamNonBlocking), "hipStreamCreate(sub)") ||
-            !hip_ok(ctx, hipEventCreateWithFlags(&ctx->ev_sub_join[i], hipEventDisableTiming), "hipEventCreate"))
-          return DH_ERR_HIP;
-      for (int i = 0; i < dh_ctx::kSubEvents; ++i)
-        if (!hip_ok(ctx, hipEventCreateWithFlags(&ctx->ev_sub[i], hipEventDisableTiming), "hipEventCreate")) return DH_ERR_HIP;
-    }
-  }
-  RebuildArgs as = a;
-  as.tree = 2;
   for (int L = 0; L < nlev; ++L) {
     hipLaunchKernelGGL(k_split, dim3(runs * a.maxp), dim3(kThreads), lds_split, ctx->stream, a, L);
-    if (L >= sub_from && L < dh_ctx::kSubEvents) {
-      hipStream_t ss = ctx->sub_stream[L & 1];
-      if (!hip_ok(ctx, hipEventRecord(ctx->ev_sub[L], ctx->stream), "hipEventRecord(sub)") ||
-          !hip_ok(ctx, hipStreamWaitEvent(ss, ctx->ev_sub[L], 0), "hipStreamWaitEvent(sub)"))
-        return DH_ERR_HIP;
-      hipLaunchKernelGGL(k_sub, dim3(runs * 2 * a.maxw), dim3(kThreads), lds, ss, as, L, 2 * a.maxw);
-      sub_used |= 1 << (L & 1);
-    }
-    int wave = L >= wave_from ? 1 : 0;
-    if (leaf_dp && L >= leaf_from) {
-      const dim3 lg(runs * 2 * a.maxw), lb(64);
-      switch (leaf_dp) {
-        case 16: hipLaunchKernelGGL(k_leaf<16>, lg, lb, 0, ctx->stream, a, L, 2 * a.maxw); break;
-        case 20: hipLaunchKernelGGL(k_leaf<20>, lg, lb, 0, ctx->stream, a, L, 2 * a.maxw); break;
-        case 24: hipLaunchKernelGGL(k_leaf<24>, lg, lb, 0, ctx->stream, a, L, 2 * a.maxw); break;
-        case 28: hipLaunchKernelGGL(k_leaf<28>, lg, lb, 0, ctx->stream, a, L, 2 * a.maxw); break;
-        default: hipLaunchKernelGGL(k_leaf<32>, lg, lb, 0, ctx->stream, a, L, 2 * a.maxw); break;
-      }
-      wave = 1;  // k_ell skips what is built
-    }
+    const int wave = L >= wave_from ? 1 : 0;
     if (L >= wave_from)
       hipLaunchKernelGGL(k_ell_wave, dim3(runs * 2 * a.maxw), dim3(64), lds_wave, ctx->stream, a, L, 2 * a.maxw, wave_cap,
                          wave_axis);
@@ -3609,11 +3277,6 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
     hipLaunchKernelGGL(k_tree, dim3(G), dim3(kThreads), lds, ctx->stream, at);
   }
   if (forked && !hip_ok(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0), "hipStreamWaitEvent(join)")) return DH_ERR_HIP;
-  for (int i = 0; i < 2; ++i)
-    if (sub_used & (1 << i))
-      if (!hip_ok(ctx, hipEventRecord(ctx->ev_sub_join[i], ctx->sub_stream[i]), "hipEventRecord(sub join)") ||
-          !hip_ok(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_sub_join[i], 0), "hipStreamWaitEvent(sub join)"))
-        return DH_ERR_HIP;
   hipLaunchKernelGGL(k_finish, dim3(runs), dim3(kThreads), lds_fin, ctx->stream, a);
   if (a.fast) {
     const int G = max_ells < 8 ? max_ells : 8;

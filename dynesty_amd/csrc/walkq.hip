@@ -38,7 +38,8 @@ namespace {
 typedef double mfma_acc __attribute__((ext_vector_type(4)));
 #define DH_MFMA_F64(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
 
-enum : int { RNGQ_PCG64 = 0, RNGQ_PHILOX = 1, RNGQ_ITEMS = 2 };  // ITEMS: the PCG64 stream written out by itemgen_kernel
+// ITEMS: the PCG64 stream written out by itemgen_kernel; ITEMS32: the Philox stream written out by philox_items_kernel
+enum : int { RNGQ_PCG64 = 0, RNGQ_PHILOX = 1, RNGQ_ITEMS = 2, RNGQ_ITEMS32 = 3 };
 
 struct RwalkQArgs {
   ProblemDev prob;
@@ -59,6 +60,7 @@ struct RwalkQArgs {
   const uint64_t* zfi;
   const uint64_t* pcg_jump;
   const double* items;  // RNGQ_ITEMS: [walker][walks * (ndim + 1)]
+  const float* items32;  // RNGQ_ITEMS32: [walker][walks][4 (nb + 1)] (philox_items_kernel)
   int wbase;            // index of this launch's first walker in the caller's batch (run lookup)
   const double* run_loglstar;
   const double* run_scale;
@@ -450,10 +452,49 @@ __device__ __forceinline__ U128 mul128_limbs_s(const Limbs128& a, const U128& b)
   return r;
 }
 
-__global__ void __launch_bounds__(256) itemgen_kernel(ItemGenArgs a) {
+// The two rare paths of a round are calls, not inlined code: ocml's exp (the double-precision wedge verdict, a
+// candidate inside the single-precision band: ~1 round in 10^3) and log1p x 2 + a sequential 128-bit generator (the
+// tail of the distribution: 3 draws in 10^4) set the kernel's register need to 96 when inlined -- five wavefronts
+// per SIMD; behind calls with scalar arguments the round itself needs 40 and the kernel is what its callees need.
+__device__ __attribute__((noinline)) bool itemgen_wedge_f64(double x, double u1, double f1, double f0) {
+#pragma clang fp contract(off)
+  return (f1 - f0) * u1 + f0 < exp(-0.5 * x * x);
+}
+struct ItemTail {
+  double xf;
+  uint64_t s0hi, s0lo, dhi, dlo;  // the walker's S_0 behind the tail draw and d = S_1 - S_0
+};
+__device__ __attribute__((noinline)) ItemTail itemgen_tail(uint64_t shi, uint64_t slo, uint64_t ihi, uint64_t ilo,
+                                                           uint32_t negative) {
+#pragma clang fp contract(off)
+  Pcg64 s;
+  s.state.hi = shi;
+  s.state.lo = slo;
+  s.inc.hi = ihi;
+  s.inc.lo = ilo;
+  ItemTail o;
+  for (;;) {
+    const double xx = -DH_ZIG_INV_R * log1p(-s.next_double());
+    const double yy = -log1p(-s.next_double());
+    if (yy + yy > xx * xx) {
+      o.xf = negative ? -(DH_ZIG_R + xx) : DH_ZIG_R + xx;
+      break;
+    }
+  }
+  const U128 s0n = s.state;
+  s.step();
+  const U128 d = sub128(s.state, s0n);
+  o.s0hi = s0n.hi;
+  o.s0lo = s0n.lo;
+  o.dhi = d.hi;
+  o.dlo = d.lo;
+  return o;
+}
+
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) itemgen_kernel(ItemGenArgs a) {
 #pragma clang fp contract(off)
   __shared__ ZigQ zig;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = (int)sfirst((uint32_t)(tid >> 6));
   {
     const int i = tid;
     zig.kw[i] = make_ulonglong2(a.zki[i], a.zwi[i]);
@@ -482,7 +523,29 @@ __global__ void __launch_bounds__(256) itemgen_kernel(ItemGenArgs a) {
     }
     double* out = a.items + (size_t)w * T;
     uint32_t W = 0;
+    // A round whose single-precision wedge verdict is inside the band is run twice: the first pass only notes it
+    // (want64), the second starts with the double-precision verdicts -- formed from a front of their own, so that
+    // nothing but the walker's constants is live across the call -- and then takes the round as usual.
+    bool want64 = false;
+    uint64_t acc64 = 0;
     while ((int)W < T) {
+      if (want64) {
+        U128 D2 = D;
+        asm volatile("" : "+v"(D2.lo), "+v"(D2.hi));  // (a front of its own: not to be merged with the round's)
+        const U128 st2 = add128(S0, mul128_limbs_s(Gl, D2));
+        const uint64_t r2 = pcg_output(st2);
+        const int idx2 = (int)(r2 & 0xff);
+        const uint64_t rabs2 = (r2 >> 9) & 0x000fffffffffffffull;
+        const double rd2 = __longlong_as_double((long long)(rabs2 | 0x4330000000000000ull)) - 4503599627370496.0;
+        double x2 = rd2 * __longlong_as_double((long long)z->kw[idx2].y);
+        x2 = __longlong_as_double(__double_as_longlong(x2) ^ (long long)((r2 & 0x100ull) << 55));
+        const int ic = idx2 > 0 ? idx2 : 1;
+        const uint32_t nlo = (uint32_t)__shfl_down((int)(uint32_t)(r2 >> 11), 1),
+                       nh2 = (uint32_t)__shfl_down((int)(uint32_t)(r2 >> 43), 1);
+        const double u1 = (double)(((uint64_t)nh2 << 32) | nlo) * (1.0 / 9007199254740992.0);
+        const double f1 = __longlong_as_double((long long)a.zfi[ic - 1]), f0 = __longlong_as_double((long long)a.zfi[ic]);
+        acc64 = __ballot(itemgen_wedge_f64(x2, u1, f1, f0));
+      }
       const U128 st = add128(S0, mul128_limbs_s(Gl, D));  // state at position lane + 1
       const uint64_t r = pcg_output(st);
       const int idx = (int)(r & 0xff);
@@ -506,13 +569,13 @@ __global__ void __launch_bounds__(256) itemgen_kernel(ItemGenArgs a) {
         uint64_t accmask = __ballot(lhs < ef);
         const uint64_t zeromask = __ballot(idx == 0);
         if (__ballot(fabsf(lhs - ef) <= 1e-5f) & m) {
-          const int ic = idx > 0 ? idx : 1;
-          const uint32_t nlo = (uint32_t)__shfl_down((int)(uint32_t)(r >> 11), 1),
-                         nh2 = (uint32_t)__shfl_down((int)(uint32_t)(r >> 43), 1);
-          const double u1 = (double)(((uint64_t)nh2 << 32) | nlo) * (1.0 / 9007199254740992.0);
-          const double f1 = __longlong_as_double((long long)a.zfi[ic - 1]), f0 = __longlong_as_double((long long)a.zfi[ic]);
-          accmask = __ballot((f1 - f0) * u1 + f0 < exp(-0.5 * x * x));
+          if (!want64) {
+            want64 = true;
+            continue;
+          }
+          accmask = acc64;
         }
+        want64 = false;
         do {
           const int f = (int)__ffsll((long long)m) - 1;
           if ((zeromask >> f) & 1ull) {
@@ -550,25 +613,14 @@ __global__ void __launch_bounds__(256) itemgen_kernel(ItemGenArgs a) {
 #endif
         out[W + off] = __builtin_amdgcn_inverse_ballot_w64(umask) ? __longlong_as_double((long long)(r >> 11)) : x;
       if (tailf >= 0) {
-        Pcg64 s;
-        s.state.hi = rl64(st.hi, tailf);
-        s.state.lo = rl64(st.lo, tailf);
-        s.inc = inc;
-        const uint64_t rabsf = rl64(rabs, tailf);
-        double xf;
-        for (;;) {
-          const double xx = -DH_ZIG_INV_R * log1p(-s.next_double());
-          const double yy = -log1p(-s.next_double());
-          if (yy + yy > xx * xx) {
-            xf = ((rabsf >> 8) & 1) ? -(DH_ZIG_R + xx) : DH_ZIG_R + xx;
-            break;
-          }
-        }
-        if (lane == 0) out[W + total] = xf;
+        const ItemTail tl = itemgen_tail(rl64(st.hi, tailf), rl64(st.lo, tailf), inc.hi, inc.lo,
+                                         (uint32_t)((rl64(rabs, tailf) >> 8) & 1));
+        if (lane == 0) out[W + total] = tl.xf;
         ++total;
-        S0 = s.state;
-        s.step();
-        D = sub128(s.state, S0);
+        S0.hi = tl.s0hi;
+        S0.lo = tl.s0lo;
+        D.hi = tl.dhi;
+        D.lo = tl.dlo;
       } else {
         U128 S1;
         S0.hi = rl64(st.hi, endpos - 1);
@@ -586,6 +638,89 @@ __global__ void __launch_bounds__(256) itemgen_kernel(ItemGenArgs a) {
       o[2] = inc.hi;
       o[3] = inc.lo;
     }
+  }
+}
+
+// ---- the throughput generator as a pass of its own (round 5) ---------------------------------------------------
+// Philox4x32-10 is counter based: word p of walker w's stream is a function of (seed, subsequence = seq0 + w, p)
+// alone, so the stream the walk consumes -- per step nb = ceil(n / 4) blocks of four Box-Muller normals and one
+// uniform double, ph_stride = 4 nb + 2 words, exactly as walk.hip's lane kernel draws them from hiprand's state --
+// needs no sequential pass and no generator state at all.  Inside the walk kernel (RNGQ_PHILOX: hiprand_init +
+// hiprand_normal4 per block and step, an LDS ring, two wave_syncs per step, in a 187-register kernel at two
+// wavefronts per SIMD) it cost as much as the walk itself.  Here one thread computes ONE Philox block (ten rounds,
+// two v_mad_u64_u32 each) at full occupancy: the nb + 2 threads of a (walker, step) hold the blocks the step's words
+// come from, a thread takes the words that spill over from its neighbour's block (the step's first word sits at
+// position (offset + step ph_stride) mod 4 of a block), applies rocrand's own transforms (normal_distribution4,
+// uniform_distribution_double: what hiprand_normal4 / hiprand_uniform_double apply to these words) and stores its 16
+// bytes: a step's row is 4 (nb + 1) floats -- the normals as the fp32 values they are, the uniform as a double in
+// the last slot -- 128 bytes at n = 25.  rwalkq_kernel<.., RNGQ_ITEMS32> reads a step's row one step ahead.
+// Same words, same transforms: bit for bit the RNGQ_PHILOX kernel's and the lane kernel's walkers
+// (tests/test_gpu_rwalkq.py::test_quad_philox_equals_lane_philox).
+struct PhiloxItemArgs {
+  float* items;
+  unsigned long long seed, seq0, offset;
+  const int* run_mode;
+  int k, n, walks, wpr, my_mode, wbase;
+  int gmagic;  // floor(1024 / (nb + 2)) + 1: lane / (nb + 2) = (lane * gmagic) >> 10 for lane < 64
+};
+
+__device__ __forceinline__ uint4 philox_round(uint4 c, uint32_t k0, uint32_t k1) {
+  const uint64_t m0 = mad_u64_u32(0xD2511F53u, c.x, 0ull), m1 = mad_u64_u32(0xCD9E8D57u, c.z, 0ull);
+  return make_uint4((uint32_t)(m1 >> 32) ^ c.y ^ k0, (uint32_t)m1, (uint32_t)(m0 >> 32) ^ c.w ^ k1, (uint32_t)m0);
+}
+__device__ __forceinline__ uint4 philox_block(uint4 c, uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    c = philox_round(c, k0, k1);
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  return c;
+}
+
+__global__ void __launch_bounds__(256) philox_items_kernel(PhiloxItemArgs a) {
+  const int nb = (a.n + 3) >> 2, G = nb + 2, gpw = 64 / G, rs = 4 * (nb + 1);
+  const int lane = threadIdx.x & 63;
+  // (walker, step) of the wavefront's first group by scalar arithmetic, of this lane's group by a few adds: no
+  // per-lane division (k walks < 2^31: the launcher's chunks see to it)
+  const int wv = (int)sfirst(blockIdx.x * 4 + (threadIdx.x >> 6));
+  const int gi = (lane * a.gmagic) >> 10, q = lane - gi * G;  // lane / G for lane < 64 (host-checked magic)
+  const int total = a.k * a.walks;
+  const int ws0 = wv * gpw;
+  int w = ws0 / a.walks, step = ws0 - w * a.walks + gi;
+  while (step >= a.walks) {
+    step -= a.walks;
+    ++w;
+  }
+  int ws = ws0 + gi;
+  bool act = gi < gpw && ws < total;
+  if (ws >= total) {
+    ws = total - 1;
+    w = a.k - 1;
+    step = a.walks - 1;
+  }
+  if (a.run_mode && a.run_mode[(a.wbase + w) / a.wpr] != a.my_mode) act = false;
+  if (!__any(act)) return;
+  const unsigned long long p0 = a.offset + (unsigned long long)step * (unsigned long long)(4 * nb + 2);
+  const int sub = (int)(p0 & 3ull);
+  const unsigned long long Q = (p0 >> 2) + (unsigned long long)q, seq = a.seq0 + (unsigned long long)(a.wbase + w);
+  // rocrand's restart(subsequence, offset): counter = (block index, subsequence) as two 64-bit halves
+  const uint4 R = philox_block(make_uint4((uint32_t)Q, (uint32_t)(Q >> 32), (uint32_t)seq, (uint32_t)(seq >> 32)),
+                               (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
+  uint4 Rn;
+  Rn.x = (uint32_t)__shfl_down((int)R.x, 1);
+  Rn.y = (uint32_t)__shfl_down((int)R.y, 1);
+  Rn.z = (uint32_t)__shfl_down((int)R.z, 1);
+  const uint4 v = sub == 0   ? R
+                  : sub == 1 ? make_uint4(R.y, R.z, R.w, Rn.x)
+                  : sub == 2 ? make_uint4(R.z, R.w, Rn.x, Rn.y)
+                             : make_uint4(R.w, Rn.x, Rn.y, Rn.z);
+  if (!act || q > nb) return;
+  float* row = a.items + (size_t)ws * rs;
+  if (q < nb) {
+    *reinterpret_cast<float4*>(row + 4 * q) = rocrand_device::detail::normal_distribution4(v);
+  } else {
+    *reinterpret_cast<double*>(row + 4 * nb) = rocrand_device::detail::uniform_distribution_double(v.x, v.y);
   }
 }
 
@@ -720,7 +855,7 @@ __global__ void __launch_bounds__(256) rwalkq_kernel(RwalkQArgs a) {
   constexpr int MT = (4 * NR + 15) / 16;
   constexpr int STRIDE = RingGeom<NR>::stride;
   __shared__ __attribute__((aligned(16))) char zig_mem[RNG == RNGQ_PCG64 ? sizeof(ZigQ) : 16];
-  __shared__ double ring_all[RNG == RNGQ_ITEMS ? 1 : 64 * STRIDE];  // [walker slot][ring position]: the walkers' next items
+  __shared__ double ring_all[(RNG == RNGQ_ITEMS || RNG == RNGQ_ITEMS32) ? 1 : 64 * STRIDE];  // [walker slot][ring position]: the walkers' next items
   __shared__ double sprec[MT * NR * 64];       // MFMA fragments of the precision matrix
   __shared__ WaveGenLds gen_all[RNG == RNGQ_PCG64 ? 4 : 1];
   ZigQ& zig = *reinterpret_cast<ZigQ*>(zig_mem);
@@ -802,6 +937,15 @@ __global__ void __launch_bounds__(256) rwalkq_kernel(RwalkQArgs a) {
     for (int r = 0; r < NR; ++r) nx[r] = myitems[(r < NR - 1 || lastok) ? 4 * r + t : 0];
     nxu = myitems[n];
   }
+  // RNGQ_ITEMS32: rows of 4 (nb + 1) floats per step (philox_items_kernel)
+  const int rs32 = 4 * (((n + 3) >> 2) + 1);
+  const float* myitems32 = a.items32 + (size_t)wi * a.walks * rs32;
+  float nxf[NR];
+  if constexpr (RNG == RNGQ_ITEMS32) {
+#pragma unroll
+    for (int r = 0; r < NR; ++r) nxf[r] = myitems32[4 * r + t];  // (NR = nb: a row holds 4 nb normals)
+    nxu = *reinterpret_cast<const double*>(myitems32 + 4 * NR);
+  }
   int start = 0;  // ring position of the current step's first item: (step * n1) mod cap
   WQP(WqProf pf; pf.fill = pf.rest = pf.rounds = pf.segs = pf.wedges = pf.t0 = 0;)
   const int nb = (n + 3) >> 2;           // hiprand_normal4 blocks per step
@@ -820,7 +964,7 @@ __global__ void __launch_bounds__(256) rwalkq_kernel(RwalkQArgs a) {
 #pragma unroll 1
   for (int step = 0; step < a.walks; ++step) {
     // randsphere (bounding.py:1288-1297): n normals, one uniform
-    if constexpr (RNG == RNGQ_ITEMS) {
+    if constexpr (RNG == RNGQ_ITEMS || RNG == RNGQ_ITEMS32) {
       // this step's items were loaded a step ahead (below)
     } else if constexpr (RNG == RNGQ_PCG64) {
       WQP(const long long tq0 = clock64();)
@@ -856,6 +1000,17 @@ __global__ void __launch_bounds__(256) rwalkq_kernel(RwalkQArgs a) {
 #pragma unroll
       for (int r = 0; r < NR; ++r) nx[r] = nrow[(r < NR - 1 || lastok) ? 4 * r + t : 0];
       nxu = nrow[n];
+    } else if constexpr (RNG == RNGQ_ITEMS32) {
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        dr[r] = (r < NR - 1 || lastok) ? (double)nxf[r] : 0.0;
+        ss = fma(dr[r], dr[r], ss);
+      }
+      ur = nxu;  // hiprand_uniform_double's value, in (0, 1]
+      const float* nrow = myitems32 + (size_t)(step + 1 < a.walks ? step + 1 : step) * rs32;
+#pragma unroll
+      for (int r = 0; r < NR; ++r) nxf[r] = nrow[4 * r + t];
+      nxu = *reinterpret_cast<const double*>(nrow + 4 * NR);
     } else {
       wave_sync();
 #pragma unroll
@@ -1020,13 +1175,16 @@ int rwalkq_launch(dh_ctx* ctx, const ProblemDev& prob, int k, int ndim, const do
   a.ph_seq0 = philox ? philox->seq0 : 0;
   a.ph_offset = philox ? philox->offset : 0;
   a.items = nullptr;
+  a.items32 = nullptr;
   a.wbase = 0;
   const dim3 block(256);
   const int kind = problem_kind(prob.like_id, prob.prior_id) == KIND_PREC_AFFINE ? KIND_PREC_AFFINE : KIND_GENERIC;
   const int nr = (ndim + 3) / 4;  // 2 <= ndim <= 32: 1 .. 8
 #define L(NRR, KK, GRID)                                                                               \
   do {                                                                                                 \
-    if (philox)                                                                                        \
+    if (a.items32)                                                                                     \
+      hipLaunchKernelGGL((rwalkq_kernel<NRR, KK, RNGQ_ITEMS32>), GRID, block, 0, ctx->stream, a);      \
+    else if (philox)                                                                                   \
       hipLaunchKernelGGL((rwalkq_kernel<NRR, KK, RNGQ_PHILOX>), GRID, block, 0, ctx->stream, a);       \
     else if (a.items)                                                                                  \
       hipLaunchKernelGGL((rwalkq_kernel<NRR, KK, RNGQ_ITEMS>), GRID, block, 0, ctx->stream, a);        \
@@ -1041,13 +1199,14 @@ int rwalkq_launch(dh_ctx* ctx, const ProblemDev& prob, int k, int ndim, const do
       L(NRR, KIND_GENERIC, GRID);      \
   }
 #define XALL(GRID) X(1, GRID) X(2, GRID) X(3, GRID) X(4, GRID) X(5, GRID) X(6, GRID) X(7, GRID) X(8, GRID)
-  if (philox || !ctx->rwalk_items) {
+  if (!ctx->rwalk_items) {
     const dim3 grid((k + 63) / 64);
     XALL(grid)
     return hip_ok(ctx, hipGetLastError(), "rwalkq launch") ? DH_OK : DH_ERR_HIP;
   }
-  // PCG64 streams, generator as a pass of its own: walkers in chunks whose item streams fit the context's buffer
-  const size_t T = (size_t)walks * (ndim + 1), per_walker = T * sizeof(double);
+  // The generator as a pass of its own (PCG64: itemgen_kernel, fp64 items; Philox: philox_items_kernel, fp32 rows):
+  // walkers in chunks whose item streams fit the context's buffer
+  const size_t per_walker = philox ? (size_t)walks * 4 * (nr + 1) * sizeof(float) : (size_t)walks * (ndim + 1) * sizeof(double);
   size_t chunk = ctx->items_budget / per_walker;
   if (chunk < 64) chunk = 64;
   if (chunk > (size_t)k) chunk = (size_t)k;
@@ -1063,32 +1222,56 @@ int rwalkq_launch(dh_ctx* ctx, const ProblemDev& prob, int k, int ndim, const do
   }
   for (size_t first = 0; first < (size_t)k; first += chunk) {
     const int kc = (int)((size_t)k - first < chunk ? (size_t)k - first : chunk);
-    ItemGenArgs g;
-    g.rng_in = rng + first * 4;
-    g.rng_out = rng_out ? rng_out + first * 4 : nullptr;
-    g.items = ctx->items;
-    g.zki = ctx->zki();
-    g.zwi = ctx->zwi();
-    g.zfi = ctx->zfi();
-    g.pcg_jump = ctx->pcg_jump();
-    g.run_mode = run_mode;
-    g.k = kc;
-    g.n = ndim;
-    g.walks = walks;
-    g.wpr = wpr;
-    g.my_mode = my_mode;
-    g.wbase = (int)first;
-    // one wavefront per walker up to eight wavefronts per SIMD; beyond that the wavefronts loop
-    int gblocks = (kc + 3) / 4;
-    const int gmax = ctx->num_cu * 8;
-    if (gblocks > gmax) gblocks = gmax;
-    hipLaunchKernelGGL(itemgen_kernel, dim3(gblocks), block, 0, ctx->stream, g);
+    if (philox) {
+      PhiloxItemArgs g;
+      g.items = reinterpret_cast<float*>(ctx->items);
+      g.seed = philox->seed;
+      g.seq0 = philox->seq0;
+      g.offset = philox->offset;
+      g.run_mode = run_mode;
+      g.k = kc;
+      g.n = ndim;
+      g.walks = walks;
+      g.wpr = wpr;
+      g.my_mode = my_mode;
+      g.wbase = (int)first;
+      g.gmagic = 1024 / (nr + 2) + 1;
+      for (int l = 0; l < 64; ++l)
+        if (((l * g.gmagic) >> 10) != l / (nr + 2)) return fail(ctx, DH_ERR_ARG, "rwalkq: lane-group magic");
+      const long long gpw = 64 / (nr + 2), nws = (long long)kc * walks;
+      if (nws >= (1ll << 31) - 64) return fail(ctx, DH_ERR_ARG, "rwalkq: %lld walker-steps in one generator launch", nws);
+      const long long gwaves = (nws + gpw - 1) / gpw;
+      hipLaunchKernelGGL(philox_items_kernel, dim3((unsigned)((gwaves + 3) / 4)), block, 0, ctx->stream, g);
+      a.items32 = reinterpret_cast<const float*>(ctx->items);
+      a.ph_seq0 = philox->seq0 + first;
+    } else {
+      ItemGenArgs g;
+      g.rng_in = rng + first * 4;
+      g.rng_out = rng_out ? rng_out + first * 4 : nullptr;
+      g.items = ctx->items;
+      g.zki = ctx->zki();
+      g.zwi = ctx->zwi();
+      g.zfi = ctx->zfi();
+      g.pcg_jump = ctx->pcg_jump();
+      g.run_mode = run_mode;
+      g.k = kc;
+      g.n = ndim;
+      g.walks = walks;
+      g.wpr = wpr;
+      g.my_mode = my_mode;
+      g.wbase = (int)first;
+      // one wavefront per walker up to eight wavefronts per SIMD; beyond that the wavefronts loop
+      int gblocks = (kc + 3) / 4;
+      const int gmax = ctx->num_cu * 8;
+      if (gblocks > gmax) gblocks = gmax;
+      hipLaunchKernelGGL(itemgen_kernel, dim3(gblocks), block, 0, ctx->stream, g);
+      a.items = ctx->items;
+      a.rng_in = rng + first * 4;
+    }
     a.k = kc;
     a.wbase = (int)first;
-    a.items = ctx->items;
     a.u0 = u0 + first * ndim;
     a.axes_idx = axes_idx ? axes_idx + first : nullptr;
-    a.rng_in = rng + first * 4;
     a.u = u + first * ndim;
     a.v = v + first * ndim;
     a.logl = logl + first;

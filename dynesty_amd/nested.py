@@ -283,7 +283,10 @@ def run_static(prob, nlive=500, bound='multi', sample='rwalk', queue_size=None,
         elif ncall >= ncall_last_update + update_interval:
             rebuild()
             ncall_last_update = ncall
-        if np.ptp(live_logl) == 0:  # sampler.py:1095-1100
+        # sampler.py:1095-1100; tested here once per fill, before it (the reference tests every iteration: a live set
+        # that collapses onto one value in mid-queue is noticed at the next fill; dh_ns_consume's own plateau steps
+        # keep the volumes right in between)
+        if np.ptp(live_logl) == 0:
             warnings.warn('We have reached the plateau in the likelihood we are stopping sampling')
             break
         out, _ = fill(loglstar)
@@ -294,11 +297,13 @@ def run_static(prob, nlive=500, bound='multi', sample='rwalk', queue_size=None,
         q_nc = np.ascontiguousarray(out["ncalls"], dtype=np.int32)
         pos = 0
         while pos < K and not done:
-            # with maxiter a chunk can produce at most (maxiter - it) deaths: deaths <= entries popped
-            # chunks of <= 512 entries keep the operator's LDS footprint independent of K
+            # maxiter as the reference and the resident loop count it: the loop stops once its counter EXCEEDS maxiter,
+            # i.e. after maxiter + 1 deaths (sampler.py:1076-1083; DH_NS_OPT_MAXITER).  A chunk can produce at most
+            # as many deaths as entries popped; chunks of <= 512 entries keep the operator's LDS footprint
+            # independent of K
             n = min(K - pos, 512)
             if maxiter is not None:
-                n = min(n, maxiter - int(state[0, 5]))
+                n = min(n, maxiter + 1 - int(state[0, 5]))
             res = be.ns_consume(live_l2, q_logl[None, pos:pos + n], q_nc[None, pos:pos + n], state, dlogz,
                                 live_it=live_it2, plateau=plateau)
             slots, srcs = res["dead_slot"][0].astype(np.int64), res["dead_src"][0].astype(np.int64) + pos
@@ -327,7 +332,7 @@ def run_static(prob, nlive=500, bound='multi', sample='rwalk', queue_size=None,
             else:
                 nc_acc += int(q_nc[pos:pos + n].sum())
             pos += n
-            if res["stopped"][0] or (maxiter is not None and int(state[0, 5]) >= maxiter):
+            if res["stopped"][0] or (maxiter is not None and int(state[0, 5]) > maxiter):
                 done = True
         loglstar = float(state[0, 7])
         if verbose:

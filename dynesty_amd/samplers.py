@@ -47,7 +47,7 @@ class _Streams:
     """Per-walker PCG64 states for a list of rseeds + write-back."""
 
     def __init__(self, seeds):
-        self.seeds = list(seeds)
+        self.seeds = seeds if isinstance(seeds, list) else list(seeds)
         k = len(self.seeds)
         be = get_backend()
         first = self.seeds[0]
@@ -61,17 +61,23 @@ class _Streams:
         # SeedSequence children of one parent, consecutive spawn keys: hash on
         # the device (utils.py:1002-1009 spawns exactly this)
         ent = first.entropy
-        keys = [s.spawn_key for s in self.seeds]
-        consecutive = all(
-            len(kk) == 1 and kk[0] == keys[0][0] + i and np.array_equal(
-                np.atleast_1d(s.entropy), np.atleast_1d(ent))
-            for i, (kk, s) in enumerate(zip(keys, self.seeds))) and len(
-                keys[0]) == 1 and first.pool_size == 4
+        key0 = first.spawn_key
+        consecutive = len(key0) == 1 and first.pool_size == 4
         if consecutive:
-            self.states = be.seed_children(np.atleast_1d(ent), keys[0][0], k)
+            base = key0[0]
+            # spawn() hands every child the parent's entropy object itself: identity is the cheap test,
+            # equality the fallback (a fill is 512+ seeds; np.array_equal per seed was 4 ms of a fill)
+            for i, sq in enumerate(self.seeds):
+                if sq.spawn_key != (base + i,) or (
+                        sq.entropy is not ent and not np.array_equal(
+                            np.atleast_1d(sq.entropy), np.atleast_1d(ent))):
+                    consecutive = False
+                    break
+        if consecutive:
+            self.states = be.seed_children(np.atleast_1d(ent), key0[0], k)
         else:
             self.states = np.array([
-                _lib.pcg_state_words(np.random.PCG64(s)) for s in self.seeds
+                _lib.pcg_state_words(np.random.PCG64(sq)) for sq in self.seeds
             ], dtype=np.uint64)
 
     def write_back(self, rng_out):
@@ -81,30 +87,52 @@ class _Streams:
 
 
 def _frames(args):
-    """Unique proposal frames + index per walker.  Frames are deduplicated first by
-    the memory they view (HipMultiEllipsoid.get_random_axes hands out a fresh ndarray
-    view of `axes_ells[i]` per call: same data pointer, different `id`), then by value,
-    so a fill uploads one frame per ellipsoid, not one per walker."""
-    uniq, by_mem, by_val = [], {}, {}
+    """Unique proposal frames + index per walker.  Frames are deduplicated by object
+    (HipMultiEllipsoid.get_random_axes hands out one cached view per ellipsoid), then by
+    the memory they view (the reference's MultiEllipsoid returns a fresh ndarray view of
+    `ells[i].axes` per call: same data pointer, different `id`), then by value, so a fill
+    uploads one frame per ellipsoid, not one per walker."""
+    uniq, by_id, by_mem, by_val = [], {}, {}, {}
     idx = np.empty(len(args), dtype=np.int32)
     for i, a in enumerate(args):
         ax = a.axes
-        if isinstance(ax, np.ndarray):
-            key = (ax.__array_interface__['data'][0], ax.shape, ax.strides, ax.dtype.str)
-        else:
-            key = ('id', id(ax))
-        j = by_mem.get(key)
+        j = by_id.get(id(ax))
         if j is None:
-            arr = np.ascontiguousarray(ax, dtype=np.float64)
-            vkey = (arr.shape, arr.tobytes())
-            j = by_val.get(vkey)
+            if isinstance(ax, np.ndarray):
+                key = (ax.__array_interface__['data'][0], ax.shape, ax.strides, ax.dtype.str)
+            else:
+                key = ('id', id(ax))
+            j = by_mem.get(key)
             if j is None:
-                j = len(uniq)
-                by_val[vkey] = j
-                uniq.append(arr)
-            by_mem[key] = j
+                arr = np.ascontiguousarray(ax, dtype=np.float64)
+                vkey = (arr.shape, arr.tobytes())
+                j = by_val.get(vkey)
+                if j is None:
+                    j = len(uniq)
+                    by_val[vkey] = j
+                    uniq.append(arr)
+                by_mem[key] = j
+            by_id[id(ax)] = j
         idx[i] = j
     return np.stack(uniq), (None if len(uniq) == 1 else idx)
+
+
+_NO_HISTORY = ()  # SamplerReturn.evaluation_history of the fused samplers: read-only, shared (sampler.py:748 only extends FROM it)
+
+
+def _start_points(args):
+    """(k, ndim) float64 of the arguments' start points in one copy."""
+    return np.array([a.u for a in args], dtype=np.float64)
+
+
+def _returns(u, v, logl, ncalls, tuning, stats):
+    """One SamplerReturn per walker from whole-fill arrays / lists without a Python-level loop body: rows of u and
+    v are views of the output arrays, scalars are converted by tolist() in one pass."""
+    k = len(u)
+    if not isinstance(ncalls, list):
+        ncalls = [ncalls] * k
+    return list(map(SamplerReturn._make,
+                    zip(list(u), list(v), logl.tolist(), ncalls, [_NO_HISTORY] * k, tuning, stats)))
 
 
 def _bc_flags(kwargs, ndim):
@@ -179,7 +207,7 @@ def run_rwalk(args):
         return _run_rwalk_lockstep(args)
     prob = _problem_of(a0)
     kw = a0.kwargs
-    u0 = np.array([a.u for a in args], dtype=np.float64)
+    u0 = _start_points(args)
     axes, idx = _frames(args)
     streams = _Streams([a.rseed for a in args])
     out = get_backend().rwalk_batch(
@@ -187,15 +215,11 @@ def run_rwalk(args):
         axes_idx=idx, ncdim=axes.shape[1], bc=_bc_flags(kw, prob.ndim))
     streams.write_back(out["rng_out"])
     walks = int(kw['walks'])
-    res = []
-    for i in range(len(args)):
-        na, nr = int(out["accept"][i]), int(out["reject"][i])
-        res.append(SamplerReturn(
-            u=out["u"][i], v=out["v"][i], logl=float(out["logl"][i]),
-            ncalls=walks, evaluation_history=[],
-            tuning_info={'accept': na, 'reject': nr, 'scale': a0.scale},
-            proposal_stats=dict(n_accept=na, n_reject=nr)))
-    return res
+    scale = a0.scale
+    acc, rej = out["accept"].tolist(), out["reject"].tolist()
+    return _returns(out["u"], out["v"], out["logl"], walks,
+                    [{'accept': na, 'reject': nr, 'scale': scale} for na, nr in zip(acc, rej)],
+                    [{'n_accept': na, 'n_reject': nr} for na, nr in zip(acc, rej)])
 
 
 class _UniformFeed:
@@ -408,7 +432,7 @@ def _run_slice(args, principal):
         return _run_slice_lockstep(args, principal)
     prob = _problem_of(a0)
     kw = a0.kwargs
-    u0 = np.array([a.u for a in args], dtype=np.float64)
+    u0 = _start_points(args)
     axes, idx = _frames(args)
     streams = _Streams([a.rseed for a in args])
     out = get_backend().slice_batch(
@@ -416,17 +440,11 @@ def _run_slice(args, principal):
         principal=principal, doubling=bool(kw.get('slice_doubling', False)),
         axes_idx=idx)
     streams.write_back(out["rng_out"])
-    res = []
-    for i in range(len(args)):
-        ne, nt = int(out["n_expand"][i]), int(out["n_contract"][i])
-        res.append(SamplerReturn(
-            u=out["u"][i], v=out["v"][i], logl=float(out["logl"][i]),
-            ncalls=int(out["ncalls"][i]), evaluation_history=[],
-            tuning_info={'n_expand': ne, 'n_contract': nt,
-                         'expansion_warning_set':
-                         bool(out["expansion_warning_set"][i])},
-            proposal_stats=dict(n_expand=ne, n_contract=nt)))
-    return res
+    ne, nt = out["n_expand"].tolist(), out["n_contract"].tolist()
+    ws = np.asarray(out["expansion_warning_set"]).astype(bool).tolist()
+    return _returns(out["u"], out["v"], out["logl"], np.asarray(out["ncalls"]).tolist(),
+                    [{'n_expand': e, 'n_contract': t, 'expansion_warning_set': w} for e, t, w in zip(ne, nt, ws)],
+                    [{'n_expand': e, 'n_contract': t} for e, t in zip(ne, nt)])
 
 
 def run_rslice(args):
@@ -557,13 +575,9 @@ def run_unif(args):
                                        logvol_ells=lvs, ncdim=kw['n_cluster'],
                                        bc=bc)
     streams.write_back(out["rng_out"])
-    return [
-        SamplerReturn(u=out["u"][i], v=out["v"][i],
-                      logl=float(out["logl"][i]), ncalls=int(out["ncalls"][i]),
-                      evaluation_history=[], tuning_info=None,
-                      proposal_stats={'n_proposals': 0})
-        for i in range(len(args))
-    ]
+    k = len(args)
+    return _returns(out["u"], out["v"], out["logl"], np.asarray(out["ncalls"]).tolist(), [None] * k,
+                    [{'n_proposals': 0} for _ in range(k)])
 
 
 def batched(runner):

@@ -488,7 +488,9 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim,
  *                               Default 0: the run is flagged and rebuilds before its next fill
  *                               (the fast form: no extra launches in fills without a forced update).  Not combined
  *                               with the uniform sampler (no start points) and switches DH_NS_OVERLAP off.
- * A run ended by maxiter / maxcall / logl_max ends normally (status 0), as the reference's does. */
+ * A run ended by maxiter / maxcall / logl_max ends normally (status 0), as the reference's does.
+ * Options (and dh_ns_set_boundary's flags) apply to the NEXT dh_ns_ensemble call only: that call takes them and the
+ * context forgets them, however the call ends. */
 enum {
   DH_NS_OPT_UPDATE_INTERVAL = 0,
   DH_NS_OPT_FIRST_MIN_NCALL = 1,
@@ -503,7 +505,7 @@ enum {
 int dh_ns_set_option(dh_ctx* ctx, int key, double value);
 
 /* NestedSampler(periodic=, reflective=) for the resident loop (dynesty.py:126-142: the lists only reach the internal
- * sampler): bc = ndim DH_BC_* flags, or NULL / ndim <= 0 for none.  Kept in the context until changed;
+ * sampler): bc = ndim DH_BC_* flags, or NULL / ndim <= 0 for none.  Taken by the next dh_ns_ensemble call (one-shot, like the options; a rejected call leaves installed flags as they were);
  * dh_ns_ensemble refuses a flag array whose length is not its ndim.  rwalk wraps / reflects the flagged coordinates and
  * tests them against (-0.5, 1.5) (internal_samplers.py:1023-1032), the uniform sampler only widens its unitcheck
  * (:301-314); the slice samplers ignore the flags, as the reference's do (its `nonperiodic` kwarg is never set). */
