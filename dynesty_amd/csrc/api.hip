@@ -163,6 +163,7 @@ void dh_destroy(dh_ctx* ctx) {
   }
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+  if (ctx->ev_leaf) (void)hipEventDestroy(ctx->ev_leaf);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }

@@ -57,7 +57,7 @@ struct dh_ctx {
   // side stream of the rebuild: the root's full eigen-system is solved there while the tree is built
   // on `stream` (fork after k_root, join before k_finish); created on first use
   hipStream_t side_stream = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_leaf = nullptr;
   // rwalk kernel form (dh_set_rwalk_form): 0 / 2 = four lanes per walker (walkq.hip) wherever that kernel is
   // built -- decided by the problem alone, never by the launch size --, 1 = one walker per lane always
   int rwalk_form = 0;

@@ -2116,7 +2116,7 @@ __device__ __forceinline__ bool ell_body(const RebuildArgs& a, const Lds& L, con
 template <bool SLOW>
 // (two workgroups per CU: held to the 168 registers of three, with a 128-point tile so that LDS would allow it, the
 // eigen-free path spills and the rebuild loses 7 %)
-__global__ void __launch_bounds__(kThreads, SLOW ? 1 : 2) k_ell(RebuildArgs a, int level, int G, int skip_done) {
+__global__ void __launch_bounds__(kThreads, SLOW ? 1 : 2) k_ell(RebuildArgs a, int level, int G, int skip_done, int leaf_cap) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int run = blockIdx.x / G, g = blockIdx.x % G;
   const int* list = a.ell_list + ((size_t)level * a.runs + run) * 2 * a.maxw;
@@ -2134,6 +2134,10 @@ __global__ void __launch_bounds__(kThreads, SLOW ? 1 : 2) k_ell(RebuildArgs a, i
   for (int slot = g; slot < cnt; slot += G) {
     // (a child is created with fmax = inf: a finite value = k_ell_wave has built this one)
     if (skip_done && v.nodes[list[slot]].fmax < INFINITY) continue;
+    if (leaf_cap > 0) {  // the leaves of this level are k_ell_wave<128>'s, on the side stream (the same test as its own)
+      const Node& nd = v.nodes[list[slot]];
+      if (nd.has_mean && nd.count >= 2 && nd.count <= leaf_cap && nd.count < 4 * D) continue;
+    }
     if (!ell_body<SLOW>(a, L, v, run, level, list[slot])) return;
   }
 }
@@ -2200,40 +2204,49 @@ __device__ __forceinline__ void carve_wave(Lds& L, unsigned char* smem, int D, i
   L.j_alias = false;
 }
 
-// node_ellipsoid<true> for a child (mean in its record) of at most L.TP points, by one wavefront
+// node_ellipsoid<true> for a child (mean in its record) of at most L.TP points, by NT / 64 wavefronts (one, or two:
+// round 5).  With two, wavefront w takes k_ell's wavefronts w, w + 2 in turn and the partial sums are still folded in
+// k_ell's wave order: the same bits from every form.
+template <int NT>
 __device__ __forceinline__ int node_ellipsoid_wave(const Lds& L, const RebuildArgs& a, const double* pts, const int* perm,
                                                    int start, int count, double* es, double* cov_g,
                                                    double* logvol_out, double* fmax_out) {
-  constexpr int NT = 64;
+  constexpr int NW = NT / 64;
   const int D = a.d, t = threadIdx.x, LD = L.LD;
   if (t < D) L.mean[t] = es[t];
   __syncthreads();
   // node_cov, one tile
   stage_tile<NT>(L, pts, perm, start, count, D, 1);
   {
-    const int nb = (D + 15) >> 4, lj = t & 15, lk = t >> 4;
-    for (int wv = 0; wv * 64 < count; ++wv) {
+    const int nb = (D + 15) >> 4, lane = t & 63, lj = lane & 15, lk = lane >> 4, mw = t >> 6;
+    for (int wv0 = 0; wv0 * 64 < count; wv0 += NW) {
+      const int wv = wv0 + mw;  // the wave of k_ell this wavefront plays now
+      const bool mine = wv * 64 < count;
       mfma_acc acc[6];
 #pragma unroll
       for (int b = 0; b < 6; ++b) acc[b] = (mfma_acc){0.0, 0.0, 0.0, 0.0};
-      tile_cov_accumulate(L, count, D, acc, wv);
+      if (mine) tile_cov_accumulate(L, count, D, acc, wv);
+      for (int turn = 0; turn < NW; ++turn) {  // cov_fold_waves, one wave's turn after the other
+        if (mine && mw == turn) {
 #pragma unroll
-      for (int b = 0; b < 6; ++b) {  // cov_fold_waves, this wave's turn
-        const int ib = b == 0 ? 0 : b == 1 ? 0 : b == 2 ? 1 : b == 3 ? 0 : b == 4 ? 1 : 2;
-        const int jb = b == 0 ? 0 : b == 1 ? 1 : b == 2 ? 1 : 2;
-        if (jb < nb) {
+          for (int b = 0; b < 6; ++b) {
+            const int ib = b == 0 ? 0 : b == 1 ? 0 : b == 2 ? 1 : b == 3 ? 0 : b == 4 ? 1 : 2;
+            const int jb = b == 0 ? 0 : b == 1 ? 1 : b == 2 ? 1 : 2;
+            if (jb < nb) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int i = ib * 16 + lk + 4 * r, j = jb * 16 + lj;
-            if (i < D && j < D) {
-              double v = acc[b][r];
-              if (wv > 0) v += L.A[i * LD + j];
-              L.A[i * LD + j] = v;
+              for (int r = 0; r < 4; ++r) {
+                const int i = ib * 16 + lk + 4 * r, j = jb * 16 + lj;
+                if (i < D && j < D) {
+                  double v = acc[b][r];
+                  if (wv > 0) v += L.A[i * LD + j];
+                  L.A[i * LD + j] = v;
+                }
+              }
             }
           }
         }
+        __syncthreads();
       }
-      __syncthreads();
     }
   }
   cov_finalize<NT>(L, D, 1.0 / (double)(count - 1));
@@ -2248,7 +2261,11 @@ __device__ __forceinline__ int node_ellipsoid_wave(const Lds& L, const RebuildAr
   return ellipsoid_store_fast<NT>(L, a, es, cov_g, logdet, logvol_out);
 }
 
-__global__ void __launch_bounds__(64, 3) k_ell_wave(RebuildArgs a, int level, int G, int cap, int axis) {
+// NT = 128 (round 5): the leaves of a level at D >= 14 by two wavefronts each on the side stream, beside the level
+// kernels of the splittable nodes (a leaf is only read by k_finish); a node this kernel declines is queued for the
+// work-queue tail (`defer`), which runs after the side stream has joined.
+template <int NT>
+__global__ void __launch_bounds__(NT, 3) k_ell_wave(RebuildArgs a, int level, int G, int cap, int axis, int defer) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int run = blockIdx.x / G, g = blockIdx.x % G;
   const int* list = a.ell_list + ((size_t)level * a.runs + run) * 2 * a.maxw;
@@ -2266,9 +2283,13 @@ __global__ void __launch_bounds__(64, 3) k_ell_wave(RebuildArgs a, int level, in
     double lv = 0.0, fmx = INFINITY;
     __syncthreads();
     L.c_pts = nullptr;
-    const int rc = node_ellipsoid_wave(L, a, v.pts, v.perm, start, count, v.estore + (size_t)node * v.NS,
-                                       v.estore + (size_t)node * v.NS + v.ES, &lv, &fmx);
-    if (rc == kWaveDeclined) continue;
+    const int rc = node_ellipsoid_wave<NT>(L, a, v.pts, v.perm, start, count, v.estore + (size_t)node * v.NS,
+                                           v.estore + (size_t)node * v.NS + v.ES, &lv, &fmx);
+    if (rc == kWaveDeclined) {
+      // (the node is untouched: fmax = inf, no record)
+      if (defer && t == 0) (void)tq_push(a, false, run, node, 1);
+      continue;
+    }
     if (rc != DH_OK) {
       set_status(a, run, rc);
       return;
@@ -3215,7 +3236,12 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
   bool forked = false;
   if (a.fast && !(getenv("DH_ROOT_EIG_SIDE") && atoi(getenv("DH_ROOT_EIG_SIDE")) == 0)) {
     if (!ctx->side_stream) {
-      if (!hip_ok(ctx, hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking), "hipStreamCreate(side)") ||
+      // lowest priority: what runs here (the root's eigen-system, the leaves) is off the critical path and must not
+      // take workgroup slots / LDS from the level kernels that are ready at the same moment
+      int pr_lo = 0, pr_hi = 0;
+      (void)hipDeviceGetStreamPriorityRange(&pr_lo, &pr_hi);
+      if (getenv("DH_SIDE_PRIO") && atoi(getenv("DH_SIDE_PRIO")) == 0) pr_lo = 0;
+      if (!hip_ok(ctx, hipStreamCreateWithPriority(&ctx->side_stream, hipStreamNonBlocking, pr_lo), "hipStreamCreate(side)") ||
           !hip_ok(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming), "hipEventCreate") ||
           !hip_ok(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming), "hipEventCreate"))
         return DH_ERR_HIP;
@@ -3251,16 +3277,59 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
       }
     }
   }
+  // Leaves beside the tree (round 5).  A child too small to be split again (count < 4 d) is read by nothing but
+  // k_finish, yet the level kernels built it on the critical path: the 2 048 leaves of the 64-run bench tree's last busy
+  // level are four rounds of k_ell's 512 workgroup slots (150 us).  Above D = 13 (below, k_ell_wave's one-wavefront form
+  // with the axis serves on the main stream) the leaves of the levels whose average child is leaf-sized go to
+  // k_ell_wave<128> on the SIDE stream -- two wavefronts and 31 KB of LDS a node: five per CU -- while the main stream
+  // goes on with the level's few splittable children and the next level pair; k_ell skips exactly the nodes that kernel
+  // takes.  The side stream joins before the work-queue tail, to which a declined leaf (eigen-free path not applicable)
+  // is queued.  Same routines, same bits (tests/test_gpu_edges.py).  DH_LEAF_SIDE=0: off.
+  int leaf_from = nlev, leaf_cap = 0;
+  size_t lds_leaf = 0;
+  if (a.fast && mode == 0 && tail && forked && wave_from >= nlev && d >= 14 &&
+      !(getenv("DH_LEAF_SIDE") && atoi(getenv("DH_LEAF_SIDE")) == 0)) {
+    leaf_cap = 4 * d - 1 < 128 ? 4 * d - 1 : 128;
+    lds_leaf = wave_lds_bytes(d, leaf_cap, false);
+    if (lds_leaf <= 64 * 1024) {
+      // from the level whose average child is below 3 d points ... (n >> (L + 1)) < 4 d would start a level earlier,
+      // where most children are still splittable
+      leaf_from = 0;
+      int lf = 3 * d;
+      if (const char* e = getenv("DH_LEAF_FROM_PTS")) lf = atoi(e) > 0 ? atoi(e) : lf;
+      while (leaf_from < nlev && (n >> (leaf_from + 1)) >= lf) ++leaf_from;
+      if (!ctx->ev_leaf && !hip_ok(ctx, hipEventCreateWithFlags(&ctx->ev_leaf, hipEventDisableTiming), "hipEventCreate"))
+        return DH_ERR_HIP;
+    } else {
+      leaf_cap = 0;
+    }
+  }
+  bool side_leaves = false;
   for (int L = 0; L < nlev; ++L) {
     hipLaunchKernelGGL(k_split, dim3(runs * a.maxp), dim3(kThreads), lds_split, ctx->stream, a, L);
     const int wave = L >= wave_from ? 1 : 0;
     if (L >= wave_from)
-      hipLaunchKernelGGL(k_ell_wave, dim3(runs * 2 * a.maxw), dim3(64), lds_wave, ctx->stream, a, L, 2 * a.maxw, wave_cap,
-                         wave_axis);
+      hipLaunchKernelGGL(k_ell_wave<64>, dim3(runs * 2 * a.maxw), dim3(64), lds_wave, ctx->stream, a, L, 2 * a.maxw,
+                         wave_cap, wave_axis, 0);
+    const int lc = (leaf_cap > 0 && L >= leaf_from) ? leaf_cap : 0;
+    if (lc && !hip_ok(ctx, hipEventRecord(ctx->ev_leaf, ctx->stream), "hipEventRecord(leaf fork)")) return DH_ERR_HIP;
     if (a.fast)
-      hipLaunchKernelGGL(k_ell<false>, dim3(runs * 2 * a.maxw), dim3(kThreads), lds, ctx->stream, a, L, 2 * a.maxw, wave);
+      hipLaunchKernelGGL(k_ell<false>, dim3(runs * 2 * a.maxw), dim3(kThreads), lds, ctx->stream, a, L, 2 * a.maxw, wave, lc);
     else
-      hipLaunchKernelGGL(k_ell<true>, dim3(runs * 2 * a.maxw), dim3(kThreads), lds, ctx->stream, a, L, 2 * a.maxw, 0);
+      hipLaunchKernelGGL(k_ell<true>, dim3(runs * 2 * a.maxw), dim3(kThreads), lds, ctx->stream, a, L, 2 * a.maxw, 0, 0);
+    if (lc) {  // (submitted after the level's k_ell: its few splittable children should get their slots first)
+      if (!hip_ok(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->ev_leaf, 0), "hipStreamWaitEvent(leaf fork)"))
+        return DH_ERR_HIP;
+      hipLaunchKernelGGL(k_ell_wave<128>, dim3(runs * 2 * a.maxw), dim3(128), lds_leaf, ctx->side_stream, a, L, 2 * a.maxw,
+                         leaf_cap, 0, 1);
+      side_leaves = true;
+    }
+  }
+  if (side_leaves) {  // the join moves behind the leaves (k_root_eig is long done) and in front of the tail
+    if (!hip_ok(ctx, hipEventRecord(ctx->ev_join, ctx->side_stream), "hipEventRecord(join)") ||
+        !hip_ok(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0), "hipStreamWaitEvent(join)"))
+      return DH_ERR_HIP;
+    forked = false;
   }
   if (tail) {
     // persistent workers: as many as can be resident (the parts of a node meet at spin barriers), but

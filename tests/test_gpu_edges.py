@@ -310,3 +310,63 @@ def test_unbalanced_tree_deeper_than_the_level_plan(ctx):
     from oracle import bounding_ref as B
     m = B.multi_update(pts)
     assert m.nells == got["nells"]
+
+
+def test_leaves_on_the_side_stream_give_the_same_bits(ctx):
+    """Round 5: above D = 13 the leaves of the deep levels (count < 4 d: read by nothing but the accept test) are
+    built by k_ell_wave<128> on the side stream beside the level kernels, and a leaf its eigen-free path declines is
+    queued for the work-queue tail.  Which kernel builds a node is a scheduling decision: every output bit-identical
+    with it off (DH_LEAF_SIDE=0) -- blobs whose leaves are healthy, blobs whose leaves are DEGENERATE (duplicated
+    points, clusters confined to a plane: the declined route), single live sets and a batch."""
+    import os
+    rng = np.random.default_rng(11)
+    d = 16
+
+    def blobs(nblob, per, kind):
+        parts = []
+        for b in range(nblob):
+            c = rng.uniform(0.2, 0.8, d)
+            if kind == "healthy":
+                x = c + 0.01 * rng.standard_normal((per, d))
+            elif kind == "dup":  # per / 3 distinct points, three copies each
+                x = np.repeat(c + 0.01 * rng.standard_normal((per // 3, d)), 3, axis=0)
+            else:  # confined to a 5-dimensional plane
+                x = c + 0.01 * rng.standard_normal((per, 5)) @ rng.standard_normal((5, d))
+            parts.append(x)
+        pts = np.concatenate(parts)
+        return pts[rng.permutation(len(pts))]
+    # 16 blobs of ~40 points at d = 16: the leaves (count < 4 d = 64) sit at level 3, the first level whose average
+    # child is below 3 d points, i.e. the level the side-stream kernel takes
+    clouds = [blobs(16, 40, "healthy"), blobs(16, 39, "dup"), blobs(16, 40, "plane"), inputs.cloud("c2")]
+
+    def run(pts, off):
+        old = os.environ.get("DH_LEAF_SIDE")
+        if off:
+            os.environ["DH_LEAF_SIDE"] = "0"
+        else:
+            os.environ.pop("DH_LEAF_SIDE", None)
+        try:
+            return ctx.rebuild(pts, multi=True, want_labels=True)
+        finally:
+            if old is None:
+                os.environ.pop("DH_LEAF_SIDE", None)
+            else:
+                os.environ["DH_LEAF_SIDE"] = old
+    for pts in clouds:
+        ref, got = run(pts, True), run(pts, False)
+        assert ref["nells"] == got["nells"] and ref["nnodes"] == got["nnodes"]
+        for k in FIELDS + ("labels",):
+            np.testing.assert_array_equal(ref[k], got[k])
+    assert run(clouds[0], False)["nells"] >= 5
+    # a batch: 16 permutations of the degenerate cloud (declined leaves of many runs in one queue)
+    sets = [clouds[1][np.random.default_rng(r).permutation(len(clouds[1]))] for r in range(16)]
+    os.environ["DH_LEAF_SIDE"] = "0"
+    try:
+        ref = ctx.rebuild_many(sets, multi=True)
+    finally:
+        del os.environ["DH_LEAF_SIDE"]
+    got = ctx.rebuild_many(sets, multi=True)
+    for a, b in zip(ref, got):
+        assert a["nells"] == b["nells"]
+        for k in a:
+            np.testing.assert_array_equal(np.asarray(a[k]), np.asarray(b[k]))
