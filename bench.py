@@ -615,12 +615,12 @@ def main():
     if not args.no_e2e:
         from dynesty_amd import ensemble
 
-        def e2e_leg(rebuild_sync, rng="pcg64"):
+        def e2e_leg(rebuild_sync, rng="pcg64", forced_exact=True):
             t0 = time.perf_counter()
             table = ensemble.run_ensemble_device(
                 prob, runs * world, base_seed=21, world=world, rank=rank,
                 dist=dist, device=dev, nlive=nlive, queue_size=GATE_QUEUE, walks=args.walks,
-                rebuild_sync=rebuild_sync, rng=rng)
+                rebuild_sync=rebuild_sync, rng=rng, forced_exact=forced_exact)
             dt = time.perf_counter() - t0
             t = torch.tensor([dt], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -633,7 +633,10 @@ def main():
                     "logz_se": float(lz.std(ddof=1) / math.sqrt(len(lz)))}
 
         # reference bound-update schedule per run (results independent of the sharding) ...
-        e2e = {"tap_point": "C (device-resident NS loop, dh_ns_ensemble)", "queue_size": GATE_QUEUE}
+        e2e = {"tap_point": "C (device-resident NS loop, dh_ns_ensemble)", "queue_size": GATE_QUEUE,
+               "protocol": "the reference's: forced bound update inside the fill that finds the start point outside "
+                           "(sampler.py:484-489), regular bound built before the newest point enters (:771-772, "
+                           "1176-1185) -- forced_exact, the default since round 5"}
         e2e_leg(False)  # untimed: the first call allocates the state arrays and loads the loop's code objects (+7 %)
         e2e.update(e2e_leg(False))
         e2e.update(reference_logz_gate())
@@ -641,6 +644,8 @@ def main():
                     "gather": f"RCCL all_gather of the per-run records (7 doubles each) over {world} rank(s)"})
         # ... and with the ensemble's rebuilds synchronised (early, never late)
         e2e["rebuild_sync"] = e2e_leg(True)
+        # ... in the late form of the forced update (round 4's default: 9-20 % fewer bound updates than the reference)
+        e2e["forced_late"] = e2e_leg(False, forced_exact=False)
         # ... and with the proposals drawn from hiprand Philox streams (throughput RNG mode)
         e2e["throughput_rng"] = e2e_leg(False, rng="philox")
         # BASELINE configs C1 (3-D Normal, single / unif + bootstrap 5), C3 (eggbox 2-D, multi / rslice, nlive 5000) and C4 (200-D iid Normal, Normal prior,
@@ -902,6 +907,52 @@ def _cpu_walk_worker(job):
     return n, time.perf_counter() - t0
 
 
+def _reference_leg(prob, u0, nlive, scale, loglstar, walks, budget_s):
+    """The REAL reference on one host core, when a copy of it is importable: /root/reference (the build container)
+    or a staged scratch copy named by DYNESTY_REF_PY (never committed; recipe: tools/stage_reference.sh).  The same
+    bounded sample as the port's: five MultiEllipsoid.update + scale_to_logvol(ln 1.25) of the shard's live sets
+    (bounding.py:632-724), then RWalkSampler.sample (internal_samplers.py:504-561) on the shard's start points until
+    the budget is spent.  Returns None when the reference is not there."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    try:
+        import refshim
+        if not refshim.have_reference():
+            return None
+        dynesty = refshim.import_reference()
+        from dynesty import bounding as RB
+        from dynesty.internal_samplers import RWalkSampler, SamplerArgument
+    except Exception:
+        return None
+    d = prob.ndim
+    t_rebuilds, bound = [], None
+    for r in range(5):
+        pts = u0[r * nlive:(r + 1) * nlive] if len(u0) >= (r + 1) * nlive else u0[:nlive]
+        bound = RB.MultiEllipsoid(d)
+        t0 = time.perf_counter()
+        bound.update(pts, rstate=np.random.default_rng(r))
+        bound.scale_to_logvol(bound.logvol + math.log(1.25))
+        t_rebuilds.append(time.perf_counter() - t0)
+    t_rebuild = float(np.median(t_rebuilds))
+    axes = bound.ells[0].axes
+    kids = np.random.SeedSequence(99).spawn(200000)
+    kw = dict(walks=walks)
+    sample = u0[:4096]
+    t0, n = time.perf_counter(), 0
+    while time.perf_counter() - t0 < budget_s:
+        RWalkSampler.sample(SamplerArgument(u=sample[n % len(sample)].copy(), loglstar=loglstar, axes=axes, scale=scale,
+                                            prior_transform=prob.prior_transform, loglikelihood=prob.loglikelihood,
+                                            rseed=kids[n], kwargs=kw))
+        n += 1
+    dt = time.perf_counter() - t0
+    per_prop = dt / (n * walks)
+    return {"value": 1.0 / (per_prop + t_rebuild / (nlive * walks)), "unit": "proposals/s", "cores": 1,
+            "kind": "reference", "rebuilds_per_s": 1.0 / t_rebuild, "proposals_per_s_walk_only": 1.0 / per_prop,
+            "sample": f"5 x dynesty.bounding.MultiEllipsoid.update + scale_to_logvol of {nlive}x{d} live sets (median "
+                      f"{t_rebuild * 1e3:.0f} ms, range {min(t_rebuilds) * 1e3:.0f}-{max(t_rebuilds) * 1e3:.0f} ms) + {n} x "
+                      f"RWalkSampler.sample of {walks} steps ({dt:.1f} s): dynesty {getattr(dynesty, '__version__', '?')} "
+                      f"from {refshim.REF}, 1 thread"}
+
+
 def cpu_baseline(prob, u0, nlive, scale, loglstar, walks, budget_s):
     """The oracle (NumPy restatement of the reference's MultiEllipsoid.update +
     RWalkSampler.sample) timed on the host cores on a bounded sample of the same
@@ -952,6 +1003,13 @@ def cpu_baseline(prob, u0, nlive, scale, loglstar, walks, budget_s):
             "multiellipsoid_update_ms": ref_box["multiellipsoid_update_ms"]["median"],
             "sample": ref_box["sample"], "host_cpu_count": ref_box.get("cpu_count"),
             "source": "profiles/r04/reference_cpu_on_gpu_box.json"}
+    # the real reference, when this machine has a copy: it becomes the baseline, the port stays beside it
+    ref = _reference_leg(prob, u0, nlive, scale, loglstar, walks, budget_s * 0.6)
+    if ref is not None:
+        port = {k: out[k] for k in ("value", "unit", "cores", "kind", "rebuilds_per_s", "proposals_per_s_walk_only", "sample")}
+        out.update(ref)
+        out["port"] = port
+        out.pop("reference_figure", None)
     ncores = os.cpu_count() or 1
     if ncores > 1:
         try:

@@ -799,15 +799,16 @@ class Context:
                     want_dead_logl=False, sample='rwalk', slices=None,
                     rebuild_sync=False, want_samples=False, rng='pcg64', bootstrap=None, rebuild_every=0,
                     update_interval=None, first_update=None, maxiter=None, maxcall=None, logl_max=None,
-                    add_live=True, forced_exact=False, periodic=None, reflective=None):
+                    add_live=True, forced_exact=True, periodic=None, reflective=None):
         """Device-resident ensemble of static NS runs (dh_ns_ensemble).
 
         periodic / reflective: lists of coordinate indices as NestedSampler takes them (dynesty.py:297-310); they reach
         the rwalk and uniform samplers (dh_ns_set_boundary), the slice samplers ignore them as the reference's do.
 
-        forced_exact=True: propose_live's forced bound update (sampler.py:484-489) inside the fill that finds a start
-        point outside the bound, as the reference takes it (DH_NS_OPT_FORCED_EXACT); the default flags the run and
-        rebuilds before its next fill.
+        forced_exact=True (the default): the reference's protocol -- propose_live's forced bound update
+        (sampler.py:484-489) belongs to the fill that finds a start point outside the bound, and the regular bound is
+        built before the newest point enters (DH_NS_OPT_FORCED_EXACT).  False: the late form (the run is flagged and
+        rebuilds before its next fill): 9-20 % fewer bound updates than the reference, a few per cent faster.
 
         update_interval / first_update (NestedSampler, dynesty.py:213-234: a float update_interval is a multiple of
         nlive, an int a number of calls; first_update = dict(min_ncall=..., min_eff=...)) and maxiter / maxcall /
@@ -874,7 +875,7 @@ class Context:
                 float(fu['min_eff']) if 'min_eff' in fu else nan,
                 nan if maxiter is None else float(maxiter), nan if maxcall is None else float(maxcall),
                 nan if logl_max is None else float(logl_max), nan if add_live else 0.0,
-                1.0 if forced_exact else nan]
+                1.0 if forced_exact else 0.0]
         for key, val in enumerate(opts):
             self._check(self.lib.dh_ns_set_option(self.handle, key, val))
         bc = None

@@ -48,6 +48,9 @@ struct NsRun {
   // step (0 = not in plateau mode), ln of that step's volume, and the two sums that make var[ln Z] exact
   // although the dead points' d ln X is then no longer constant (see ns_finish)
   int pcount, sampler_failed;  // (sampler_failed: a uniform-sampler walker gave up, see ns_consume)
+  // forced_exact: a start point of the run's CURRENT queue (selected, kept) lies outside its bound and the forced
+  // update waits for the next fill that builds bounds; the run proposes and consumes nothing until then
+  int fpend, pad_;
   double plogdvol, var_a, var_b;
 };
 
@@ -103,6 +106,12 @@ struct NsArgs {
   double* undo_u;     // runs x ndim
   int* undo_slot;     // runs: the slot, or -1
   uint64_t* sel_ent;  // runs x 4: the words ns_select seeded this fill's walker selections from
+  // (forced_exact) what this fill does to the run's bound: 0 nothing, 1 regular update (built before the queue is
+  // selected), 2 forced update (built after: the queue found a start point outside); the runs a selection /
+  // membership pass serves (MODE_BOUND / MODE_WAIT per run); which pass ns_select / ns_gather are in
+  int* fx_kind;
+  int* pass_mode;
+  int fx_pass;  // 0: not forced_exact; 1: before the fill's rebuild (every run but the regular updates'); 2: after (those)
   int* ndone;
   // bound (rebuild outputs)
   int* nells;
@@ -184,6 +193,7 @@ __global__ void __launch_bounds__(kT)
     r.nbound = 0;
     r.nfill = 0;
     r.acc = r.rej = r.doubling = r.due = 0;
+    r.fpend = r.pad_ = 0;
     r.logzvar = 0.0;
     r.nc_carry = 0;
     r.pcount = r.sampler_failed = 0;
@@ -269,7 +279,10 @@ __global__ void __launch_bounds__(kT) ns_prepare(NsArgs a) {
   for (int run = t; run < a.runs; run += kT) {
     NsRun& r = a.st[run];
     int want = 0;
-    if (r.mode == MODE_CUBE || r.mode == MODE_BOUND) {
+    if (r.fpend) {
+      // its queue is selected and waits for the forced update: nothing is decided for it (ns_force_prepare takes it in
+      // the next fill that builds bounds)
+    } else if (r.mode == MODE_CUBE || r.mode == MODE_BOUND) {
       if (r.mode == MODE_BOUND && a.bstatus[run] != DH_OK) {
         r.mode = MODE_FAILED;
         atomicAdd(a.ndone, 1);
@@ -299,7 +312,7 @@ __global__ void __launch_bounds__(kT) ns_prepare(NsArgs a) {
   for (int run = t; run < a.runs; run += kT) {
     NsRun& r = a.st[run];
     int need = r.need_rebuild;
-    if (a.rebuild_sync && any && a.rebuild_fill && r.mode == MODE_BOUND) need = 1;
+    if (a.rebuild_sync && any && a.rebuild_fill && r.mode == MODE_BOUND && !r.fpend) need = 1;
     if (need) {
       if (r.mode == MODE_CUBE) r.mode = MODE_BOUND;
       r.due = 0;
@@ -315,7 +328,8 @@ __global__ void __launch_bounds__(kT) ns_prepare(NsArgs a) {
     r.need_rebuild = need;
     if (a.force) a.force[run] = 0;
     a.rebuild_mask[run] = need;
-    a.run_mode[run] = (r.due || (a.overlap && need)) ? MODE_WAIT : r.mode;
+    a.run_mode[run] = (r.due || (a.overlap && need) || (r.fpend && !a.rebuild_fill)) ? MODE_WAIT : r.mode;
+    if (a.fx_kind) a.fx_kind[run] = need ? 1 : 0;
     a.run_loglstar[run] = r.loglstar;
     a.run_scale[run] = r.scale;
     a.run_doubling[run] = r.doubling;
@@ -341,6 +355,8 @@ __global__ void __launch_bounds__(kT) ns_select(NsArgs a) {
   const int mode = r.mode;
   if (mode != MODE_CUBE && mode != MODE_BOUND) return;
   if (a.run_mode[run] == MODE_WAIT) return;  // waiting for its bound: the run proposes nothing this fill
+  if (a.fx_pass == 1 && (a.fx_kind[run] == 1 || r.fpend)) return;  // selects after its rebuild / keeps its queue
+  if (a.fx_pass == 2 && a.fx_kind[run] != 1) return;
   if (mode == MODE_BOUND && a.bstatus[run] != DH_OK) return;  // ns_prepare fails the run next fill
   int M = 1;
   if (t == 0) {
@@ -420,6 +436,8 @@ __global__ void __launch_bounds__(256) ns_gather(NsArgs a) {
   const int j = (int)(e - q * D), run = (int)(q / K);
   if (a.st[run].mode != MODE_BOUND || a.bstatus[run] != DH_OK) return;
   if (a.run_mode[run] == MODE_WAIT) return;
+  if (a.fx_pass == 1 && a.fx_kind[run] == 1) return;
+  if (a.fx_pass == 2 && a.fx_kind[run] != 1) return;
   a.q_u0[e] = a.live_u[((size_t)run * N + a.r_d[q]) * D + j];
 }
 
@@ -437,7 +455,7 @@ __global__ void __launch_bounds__(256) ns_gather(NsArgs a) {
 // fill's last queue entry brought in (see NsArgs::undo_u); launched before and after the masked rebuild (a swap)
 __global__ void __launch_bounds__(64) ns_swap_undo(NsArgs a) {
   const int run = blockIdx.x;
-  if (!a.rebuild_mask[run]) return;
+  if (!a.rebuild_mask[run] || a.fx_kind[run] != 1) return;  // (a forced update sees the live set as it is)
   const int s = a.undo_slot[run];
   if (s < 0) return;
   for (int x = threadIdx.x; x < a.ndim; x += 64) {
@@ -449,12 +467,28 @@ __global__ void __launch_bounds__(64) ns_swap_undo(NsArgs a) {
   }
 }
 
+// the runs a selection / membership pass serves -> pass_mode
+__global__ void __launch_bounds__(kT) ns_pass_mask(NsArgs a, int pass) {
+  for (int run = threadIdx.x; run < a.runs; run += kT) {
+    const NsRun& r = a.st[run];
+    const bool walking = r.mode == MODE_BOUND && a.run_mode[run] == MODE_BOUND && a.bstatus[run] == DH_OK;
+    const int kd = a.fx_kind[run];
+    a.pass_mode[run] = (walking && (pass == 1 ? kd != 1 : kd != 0)) ? MODE_BOUND : MODE_WAIT;
+  }
+}
+
+// After the first membership pass.  A flagged run's forced update is built with this fill's bounds if the fill builds
+// bounds; otherwise the run keeps its queue (start points, frames, streams, the selection words) and sits the fills
+// out until one does -- runs are independent, so idling changes nothing in the run's own sequence (the same live set,
+// the same generator state, the same queue: ns_prepare / ns_select leave a pending run alone), and the ensemble pays
+// one rebuild chain per rebuild fill, as without forced updates.
 __global__ void __launch_bounds__(kT) ns_force_prepare(NsArgs a) {
   for (int run = threadIdx.x; run < a.runs; run += kT) {
     NsRun& r = a.st[run];
-    const int f = (a.force[run] && r.mode == MODE_BOUND && a.run_mode[run] == MODE_BOUND && a.bstatus[run] == DH_OK) ? 1 : 0;
-    if (f) {
+    const int f = (a.force[run] && a.pass_mode[run] == MODE_BOUND) ? 1 : 0;
+    if (f && a.rebuild_fill) {
       r.due = 0;
+      r.fpend = 0;
       // update_bound_if_needed(-inf, force=True) records self.ncall (sampler.py:631-632, 674): the sampler's counter,
       // which at a refill does not yet hold the calls of the entries popped since the last death (they are still in
       // _new_point's ncall_accum, sampler.py:739-747) -- the carry
@@ -466,17 +500,25 @@ __global__ void __launch_bounds__(kT) ns_force_prepare(NsArgs a) {
         for (int i = 0; i < 4; ++i) a.boot_ent[(size_t)run * 4 + i] = g.next64();
         g.store(r.rng);
       }
+      a.fx_kind[run] = 2;
+      a.rebuild_mask[run] = 1;
+    } else if (f) {
+      r.fpend = 1;
+      a.run_mode[run] = MODE_WAIT;
+      a.force_first[run] = 0x7fffffff;  // (found again, from the same queue and bound, in the fill that rebuilds)
     } else {
-      a.force_first[run] = 0x7fffffff;
+      if (a.pass_mode[run] == MODE_BOUND) {
+        a.force_first[run] = 0x7fffffff;
+        r.fpend = 0;  // (a pending run is flagged again by construction)
+      }
     }
-    a.force[run] = 0;  // (the membership test after the rebuild sets it again only if the update failed)
-    a.rebuild_mask[run] = f;
+    a.force[run] = 0;  // (the membership test after the rebuild sets it again: update failed / a new pending run)
   }
 }
 
 __global__ void __launch_bounds__(256) ns_shadow_axes(NsArgs a) {
   const int run = blockIdx.x;
-  if (!a.rebuild_mask[run]) return;
+  if (!a.rebuild_mask[run] || a.fx_kind[run] != 2) return;
   const size_t dd = (size_t)a.ndim * a.ndim, n = (size_t)(a.bound_multi ? a.nells[run] : 1) * dd;
   const double* src = a.b_axes + (size_t)run * a.max_ells * dd;
   double* dst = a.b_axes + ((size_t)a.runs + run) * a.max_ells * dd;
@@ -490,6 +532,16 @@ __global__ void __launch_bounds__(kT) ns_reselect(NsArgs a) {
   if (!a.rebuild_mask[run]) return;
   const int N = a.nlive, K = a.K;
   NsRun& r = a.st[run];
+  if (a.fx_kind[run] == 1) {
+    // a regular update whose fresh queue has a start point outside the fresh bound (the point the bound was built
+    // without, sampler.py:771-772): a forced update of its own, taken in the next fill that builds bounds
+    if (t == 0 && a.force[run] && a.bstatus[run] == DH_OK) {
+      r.fpend = 1;
+      a.run_mode[run] = MODE_WAIT;
+      a.force[run] = 0;
+    }
+    return;
+  }
   if (a.force[run] || a.bstatus[run] != DH_OK) {
     // RuntimeError('Update of the ellipsoid failed') (sampler.py:489), or the rebuild itself failed: the run proposes
     // nothing; ns_prepare ends it at the next fill
@@ -2292,7 +2344,11 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
     if (!std::isnan(o[DH_NS_OPT_MAXCALL])) a.maxcall = (long long)llround(o[DH_NS_OPT_MAXCALL]);
     if (!std::isnan(o[DH_NS_OPT_LOGL_MAX])) a.logl_max = o[DH_NS_OPT_LOGL_MAX];
     if (!std::isnan(o[DH_NS_OPT_ADD_LIVE])) a.add_live = o[DH_NS_OPT_ADD_LIVE] != 0.0 ? 1 : 0;
-    if (!std::isnan(o[DH_NS_OPT_FORCED_EXACT])) a.forced_exact = (o[DH_NS_OPT_FORCED_EXACT] != 0.0 && sampler != 3) ? 1 : 0;
+    // default (round 5): the reference's protocol; 0 = the late form (opt-in fast mode)
+    // (the uniform sampler has no start points, hence no forced update: for it the option is the ordering of the
+    // regular update alone)
+    a.forced_exact = 1;
+    if (!std::isnan(o[DH_NS_OPT_FORCED_EXACT])) a.forced_exact = o[DH_NS_OPT_FORCED_EXACT] != 0.0 ? 1 : 0;
     if (a.maxcall >= 0 && a.maxcall < N)
       return fail(ctx, DH_ERR_ARG, "ns_ensemble: maxcall %lld below the %d calls of the initial live points", a.maxcall, N);
   }
@@ -2358,6 +2414,7 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
                o_fw = take((size_t)R * ns_fin_stride(N) * 8), o_cum = take((size_t)R * me * 8), o_be = take((size_t)R * 32),
                o_rs = take((size_t)R * 8), o_ff = take((size_t)R * 4), o_se = take((size_t)R * 32),
                o_bcf = take((size_t)D + 8), o_uu = take((size_t)R * D * 8), o_us = take((size_t)R * 4),
+               o_fk = take((size_t)R * 4), o_pmk = take((size_t)R * 4),
                o_boot = take(bootstrap > 0 ? bootstrap_ws_bytes(R, N, D, me, bootstrap) : 8),
                o_lit = take(want_pt ? (size_t)R * N * 4 : 8), o_pid = take(want_pt ? (size_t)R * a.cap * 4 : 8),
                o_pit = take(want_pt ? (size_t)R * a.cap * 4 : 8), o_pnc = take(want_pt ? (size_t)R * a.cap * 4 : 8);
@@ -2423,6 +2480,9 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
   a.sel_ent = a.forced_exact ? (uint64_t*)(base + o_se) : nullptr;
   a.undo_u = a.forced_exact ? (double*)(base + o_uu) : nullptr;
   a.undo_slot = a.forced_exact ? (int*)(base + o_us) : nullptr;
+  a.fx_kind = a.forced_exact ? (int*)(base + o_fk) : nullptr;
+  a.pass_mode = a.forced_exact ? (int*)(base + o_pmk) : nullptr;
+  a.fx_pass = 0;
   if (want_pt) {
     a.live_it = (int*)(base + o_lit);
     a.dead_id = (int*)(base + o_pid);
@@ -2443,6 +2503,7 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
       !hip_ok(ctx, hipMemsetAsync(base + o_fo, 0, (size_t)R * 4, s), "memset") ||
       !hip_ok(ctx, hipMemsetAsync(base + o_ff, 0x7f, (size_t)R * 4, s), "memset") ||
       !hip_ok(ctx, hipMemsetAsync(base + o_us, 0xff, (size_t)R * 4, s), "memset") ||
+      !hip_ok(ctx, hipMemsetAsync(base + o_fk, 0, (size_t)R * 8, s), "memset") ||
       !hip_ok(ctx, hipMemsetAsync(base + o_ne, 0, (size_t)R * 4, s), "memset") ||
       !hip_ok(ctx, hipMemcpyAsync(d_ent, entropy_words, (size_t)n_words * 4, hipMemcpyHostToDevice, s), "H2D"))
     return cleanup(DH_ERR_HIP);
@@ -2509,40 +2570,70 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
           return cleanup(DH_ERR_HIP);
         ctx->stream = rb_stream;
       }
-      if (a.rebuild_fill) {
-        if (a.forced_exact) hipLaunchKernelGGL(ns_swap_undo, dim3(R), dim3(64), 0, ctx->stream, a);
-        rc = build_bounds();
-        if (rc) return cleanup(rc);
-        if (a.forced_exact) hipLaunchKernelGGL(ns_swap_undo, dim3(R), dim3(64), 0, ctx->stream, a);
-      }
-      if (a.overlap) {
-        ctx->stream = main_stream;
-        if (!hip_ok(ctx, hipEventRecord(ev_rb, rb_stream), "hipEventRecord")) return cleanup(DH_ERR_HIP);
-      }
-      hipLaunchKernelGGL(ns_select, dim3(R), dim3(kT), 0, s, a);
-      if (sampler != 3)
-        hipLaunchKernelGGL(ns_gather, dim3((unsigned)(((size_t)R * K * D + 255) / 256)), dim3(256), 0, s, a);
-      // Sampler.propose_live rebuilds the bound at once when a start point lies outside it (sampler.py:484-489:
-      // a point accepted since the last update, beyond the enlarged ellipsoids).  Here the run is flagged and
-      // rebuilds before its NEXT fill: the walkers of this fill are already chosen, and a queue of K proposals
-      // is as stale in the reference.  (Above the register-resident dimensions: one wavefront per start point.)
-      if (force_check && sampler != 3) {
-        rc = contains_runs_launch(ctx, a.q_u0, R * K, D, K, a.b_ctrs, a.b_ams, bound_multi ? a.nells : nullptr, me,
-                                  bound_multi ? 1 : 0, a.run_mode, MODE_BOUND, a.bstatus, a.force,
-                                  a.forced_exact ? a.force_first : nullptr);
-        if (rc) return cleanup(rc);
-        if (a.forced_exact) {
-          // DH_NS_OPT_FORCED_EXACT: the flagged runs rebuild now and their later queue entries take the new frames
-          // (see ns_force_prepare); the second membership test is the reference's check that the update worked
-          hipLaunchKernelGGL(ns_force_prepare, dim3(1), dim3(kT), 0, s, a);
-          hipLaunchKernelGGL(ns_shadow_axes, dim3(R, 16), dim3(256), 0, s, a);
+      if (!a.forced_exact) {
+        if (a.rebuild_fill) {
           rc = build_bounds();
           if (rc) return cleanup(rc);
-          rc = contains_runs_launch(ctx, a.q_u0, R * K, D, K, a.b_ctrs, a.b_ams, bound_multi ? a.nells : nullptr, me,
-                                    bound_multi ? 1 : 0, a.run_mode, MODE_BOUND, a.bstatus, a.force);
-          if (rc) return cleanup(rc);
-          hipLaunchKernelGGL(ns_reselect, dim3(R), dim3(kT), 0, s, a);
         }
+        if (a.overlap) {
+          ctx->stream = main_stream;
+          if (!hip_ok(ctx, hipEventRecord(ev_rb, rb_stream), "hipEventRecord")) return cleanup(DH_ERR_HIP);
+        }
+        hipLaunchKernelGGL(ns_select, dim3(R), dim3(kT), 0, s, a);
+        if (sampler != 3)
+          hipLaunchKernelGGL(ns_gather, dim3((unsigned)(((size_t)R * K * D + 255) / 256)), dim3(256), 0, s, a);
+        // Sampler.propose_live rebuilds the bound at once when a start point lies outside it (sampler.py:484-489:
+        // a point accepted since the last update, beyond the enlarged ellipsoids).  In this form (the opt-in fast one)
+        // the run is flagged and rebuilds before its NEXT fill: the walkers of this fill are already chosen, and a
+        // queue of K proposals is as stale in the reference.  (Above the register-resident dimensions: one wavefront
+        // per start point.)
+        if (force_check && sampler != 3) {
+          rc = contains_runs_launch(ctx, a.q_u0, R * K, D, K, a.b_ctrs, a.b_ams, bound_multi ? a.nells : nullptr, me,
+                                    bound_multi ? 1 : 0, a.run_mode, MODE_BOUND, a.bstatus, a.force, nullptr);
+          if (rc) return cleanup(rc);
+        }
+      } else {
+        // The reference's protocol (DH_NS_OPT_FORCED_EXACT, the default of the Python layer since round 5), with ONE
+        // rebuild chain per fill that builds bounds.  Pass 1: every run but those of this fill's regular updates
+        // selects its queue (a pending run keeps the one it has) and the membership test finds the first start point
+        // outside (force_first).  ns_force_prepare: a flagged run takes its forced update with this fill's bounds, or
+        // -- in a fill that builds none -- keeps its queue and waits for one that does (its own sequence is unchanged).
+        // Then the masked rebuild of the regular AND the forced updates together (the regular ones see the live set
+        // without the newest point: ns_swap_undo; the forced ones as it is, their old frames kept: ns_shadow_axes),
+        // pass 2 (the regular updates' runs select from their new bounds; the membership test is the reference's check
+        // that a forced update worked, and flags a regular update's run whose newest point lies outside its new
+        // bound: pending), and ns_reselect (entries behind the first one outside redraw their frames from the new
+        // volumes with the same variates).
+        const dim3 ggrid((unsigned)(((size_t)R * K * D + 255) / 256));
+        const bool starts = sampler != 3;  // (the uniform sampler starts nowhere: no membership test, no forced update)
+        a.fx_pass = 1;
+        hipLaunchKernelGGL(ns_select, dim3(R), dim3(kT), 0, s, a);
+        if (starts) hipLaunchKernelGGL(ns_gather, ggrid, dim3(256), 0, s, a);
+        if (force_check && starts) {
+          hipLaunchKernelGGL(ns_pass_mask, dim3(1), dim3(kT), 0, s, a, 1);
+          rc = contains_runs_launch(ctx, a.q_u0, R * K, D, K, a.b_ctrs, a.b_ams, bound_multi ? a.nells : nullptr, me,
+                                    bound_multi ? 1 : 0, a.pass_mode, MODE_BOUND, a.bstatus, a.force, a.force_first);
+          if (rc) return cleanup(rc);
+          hipLaunchKernelGGL(ns_force_prepare, dim3(1), dim3(kT), 0, s, a);
+        }
+        if (a.rebuild_fill) {
+          if (starts) hipLaunchKernelGGL(ns_shadow_axes, dim3(R, 16), dim3(256), 0, s, a);
+          hipLaunchKernelGGL(ns_swap_undo, dim3(R), dim3(64), 0, s, a);
+          rc = build_bounds();
+          if (rc) return cleanup(rc);
+          hipLaunchKernelGGL(ns_swap_undo, dim3(R), dim3(64), 0, s, a);
+          a.fx_pass = 2;
+          hipLaunchKernelGGL(ns_select, dim3(R), dim3(kT), 0, s, a);
+          if (starts) hipLaunchKernelGGL(ns_gather, ggrid, dim3(256), 0, s, a);
+          if (force_check && starts) {
+            hipLaunchKernelGGL(ns_pass_mask, dim3(1), dim3(kT), 0, s, a, 2);
+            rc = contains_runs_launch(ctx, a.q_u0, R * K, D, K, a.b_ctrs, a.b_ams, bound_multi ? a.nells : nullptr, me,
+                                      bound_multi ? 1 : 0, a.pass_mode, MODE_BOUND, a.bstatus, a.force, nullptr);
+            if (rc) return cleanup(rc);
+          }
+          if (starts) hipLaunchKernelGGL(ns_reselect, dim3(R), dim3(kT), 0, s, a);
+        }
+        a.fx_pass = 0;
       }
       // Philox keys: seed from the entropy words (one per stage, so that the stages' offset schemes cannot
       // meet), subsequence = global walker slot (first_run + run) * K + w (independent of the sharding)

@@ -28,8 +28,17 @@ SamplerReturn = namedtuple('SamplerReturn', [
 ])
 
 
+# same field names as utils.py:23-24
+SamplerHistoryItem = namedtuple('SamplerHistoryItem', ['u', 'v', 'logl'])
+
+
 class NoDeviceProblem(NotImplementedError):
     pass
+
+
+def _wants_history(arg):
+    """utils.LogLikelihood(save_evaluation_history=True): the sampler must return every evaluated point."""
+    return bool(getattr(arg.loglikelihood, 'save_evaluation_history', False))
 
 
 def _problem_of(arg):
@@ -147,11 +156,13 @@ def _bc_flags(kwargs, ndim):
     return bc
 
 
-def _run_rwalk_lockstep(args):
+def _run_rwalk_lockstep(args, history=False):
     """rwalk with an arbitrary Python likelihood: the device proposes one
     propose_ball_point per walker per step (dh_rwalk_propose), the host
     evaluates the user's callbacks and applies generic_random_walk's accept
-    rule (internal_samplers.py:925-975).  Same streams, same counters."""
+    rule (internal_samplers.py:925-975).  Same streams, same counters.
+    history=True: every evaluated proposal is kept as a SamplerHistoryItem
+    (internal_samplers.py:960-961), in the walker's order."""
     a0 = args[0]
     kw = a0.kwargs
     k = len(args)
@@ -167,6 +178,7 @@ def _run_rwalk_lockstep(args):
     nrej = np.zeros(k, dtype=np.int64)
     v = [None] * k
     logl = [None] * k
+    hist = [[] for _ in range(k)] if history else None
     for _ in range(walks):
         up, inside, states = be.rwalk_propose(u, axes, a0.scale, states,
                                               axes_idx=idx,
@@ -177,6 +189,8 @@ def _run_rwalk_lockstep(args):
                 continue
             vi = a0.prior_transform(np.array(up[i]))
             li = a0.loglikelihood(np.asarray(vi))
+            if history:
+                hist[i].append(SamplerHistoryItem(u=np.array(up[i]), v=vi, logl=li))
             if li > a0.loglstar:
                 u[i], v[i], logl[i] = up[i], vi, li
                 nacc[i] += 1
@@ -190,7 +204,7 @@ def _run_rwalk_lockstep(args):
             logl[i] = a0.loglikelihood(np.asarray(v[i]))
         res.append(SamplerReturn(
             u=u[i].copy(), v=v[i], logl=logl[i], ncalls=walks,
-            evaluation_history=[],
+            evaluation_history=hist[i] if history else [],
             tuning_info={'accept': int(nacc[i]), 'reject': int(nrej[i]),
                          'scale': a0.scale},
             proposal_stats=dict(n_accept=int(nacc[i]), n_reject=int(nrej[i]))))
@@ -203,8 +217,8 @@ def run_rwalk(args):
     if not args:
         return []
     a0 = args[0]
-    if a0.kwargs.get('problem') is None:
-        return _run_rwalk_lockstep(args)
+    if a0.kwargs.get('problem') is None or _wants_history(a0):
+        return _run_rwalk_lockstep(args, history=_wants_history(a0))
     prob = _problem_of(a0)
     kw = a0.kwargs
     u0 = _start_points(args)
@@ -269,7 +283,7 @@ def _unitcheck(u, nonperiodic):
 
 
 def _slice_step_host(u, direction, nonperiodic, loglstar, ptform, loglike,
-                     doubling, rand):
+                     doubling, rand, hist=None):
     """generic_slice_step (internal_samplers.py:1076-1206) with the uniforms
     of the walker's stream handed in by `rand()`.  Returns (u, v, logl, nc,
     n_expand, n_contract, expansion_warning)."""
@@ -286,7 +300,10 @@ def _slice_step_host(u, direction, nonperiodic, loglstar, ptform, loglike,
         nc += 1
         if _unitcheck(u_new, nonperiodic):
             v_new = ptform(u_new)
-            return u_new, v_new, loglike(v_new)
+            l_new = loglike(v_new)
+            if hist is not None:  # internal_samplers.py:1118-1119
+                hist.append(SamplerHistoryItem(u=u_new, v=v_new, logl=l_new))
+            return u_new, v_new, l_new
         return u_new, None, -np.inf
 
     left, right = -rand0, 1 - rand0
@@ -351,7 +368,7 @@ def _slice_step_host(u, direction, nonperiodic, loglstar, ptform, loglike,
                 f"logl_prop: {f}\ndirection: {direction}\n")
 
 
-def _run_slice_lockstep(args, principal):
+def _run_slice_lockstep(args, principal, history=False):
     """RSliceSampler / SliceSampler with an arbitrary Python likelihood: per
     slice ONE device call hands every walker its direction (or shuffled axis
     order) and the uniforms that follow in its stream; the host runs
@@ -380,6 +397,7 @@ def _run_slice_lockstep(args, principal):
     warn_set = [False] * k
     v = [None] * k
     logl = [None] * k
+    hist = [[] for _ in range(k)] if history else None
     # axes[:, i] is the i-th principal axis (internal_samplers.py:660-663)
     scaled = [a0.scale * np.asarray(fr).T for fr in axes] if principal else None
     for _ in range(slices):
@@ -395,7 +413,8 @@ def _run_slice_lockstep(args, principal):
             for direction in steps:
                 (u[i], v[i], logl[i], c1, e1, t1, w1) = _slice_step_host(
                     u[i], direction, nonperiodic, a0.loglstar,
-                    a0.prior_transform, a0.loglikelihood, doubling[i], rand)
+                    a0.prior_transform, a0.loglikelihood, doubling[i], rand,
+                    hist[i] if history else None)
                 nc[i] += c1
                 ne[i] += e1
                 nt[i] += t1
@@ -412,7 +431,7 @@ def _run_slice_lockstep(args, principal):
     for i in range(k):
         res.append(SamplerReturn(
             u=u[i].copy(), v=v[i], logl=logl[i], ncalls=int(nc[i]),
-            evaluation_history=[],
+            evaluation_history=hist[i] if history else [],
             tuning_info={'n_expand': int(ne[i]), 'n_contract': int(nt[i]),
                          'expansion_warning_set': warn_set[i]},
             proposal_stats=dict(n_expand=int(ne[i]), n_contract=int(nt[i]))))
@@ -425,11 +444,11 @@ def _run_slice(args, principal):
         return []
     a0 = args[0]
     nonp = a0.kwargs.get('nonperiodic', None)
-    if a0.kwargs.get('problem') is None or (nonp is not None
-                                            and not np.all(nonp)):
-        # arbitrary Python likelihood, or periodic coordinates (the fused slice
-        # kernels implement the plain unit-cube check only)
-        return _run_slice_lockstep(args, principal)
+    if a0.kwargs.get('problem') is None or _wants_history(a0) or (
+            nonp is not None and not np.all(nonp)):
+        # arbitrary Python likelihood, an evaluation history wanted, or periodic
+        # coordinates (the fused slice kernels implement the plain unit-cube check only)
+        return _run_slice_lockstep(args, principal, history=_wants_history(a0))
     prob = _problem_of(a0)
     kw = a0.kwargs
     u0 = _start_points(args)
@@ -486,7 +505,7 @@ def friends_kind(bound):
     return kind
 
 
-def _run_unif_lockstep(args):
+def _run_unif_lockstep(args, history=False):
     """UniformBoundSampler / UnitCubeSampler semantics with an arbitrary Python
     likelihood: per round the device hands every unfinished walker the next
     candidate of its stream that lies in the bound and passes unitcheck
@@ -523,6 +542,7 @@ def _run_unif_lockstep(args):
     todo = np.arange(k)
     res = [None] * k
     nc = np.zeros(k, dtype=np.int64)
+    hist = [[] for _ in range(k)] if history else None
     while len(todo):
         up, out = be.unif_propose(ndim, states[todo], bc=bc, **pk)
         states[todo] = out
@@ -531,10 +551,13 @@ def _run_unif_lockstep(args):
             vi = a0.prior_transform(np.array(up[j]))
             li = a0.loglikelihood(np.asarray(vi))
             nc[i] += 1
+            if history:  # internal_samplers.py:330
+                hist[i].append(SamplerHistoryItem(u=up[j].copy(), v=vi, logl=li))
             if li > a0.loglstar:
                 res[i] = SamplerReturn(u=up[j].copy(), v=vi, logl=li,
                                        ncalls=int(nc[i]),
-                                       evaluation_history=[], tuning_info=None,
+                                       evaluation_history=hist[i] if history else [],
+                                       tuning_info=None,
                                        proposal_stats={'n_proposals': 0})
             else:
                 keep.append(i)
@@ -549,8 +572,8 @@ def run_unif(args):
     if not args:
         return []
     a0 = args[0]
-    if a0.kwargs.get('problem') is None:
-        return _run_unif_lockstep(args)
+    if a0.kwargs.get('problem') is None or _wants_history(a0):
+        return _run_unif_lockstep(args, history=_wants_history(a0))
     prob = _problem_of(a0)
     kw = a0.kwargs
     bound = kw['bound']
@@ -585,13 +608,10 @@ def batched(runner):
     expects; ``HipBatchPool.map`` finds the runner on ``_dynhip_batch``."""
 
     def checked(args):
-        # save_evaluation_history (utils.LogLikelihood, utils.py:120-262; internal_samplers.py:311,
-        # 426, 663) wants every point a sampler evaluated: the device walkers keep those in
-        # registers and hand back only the result -- an empty history would be written silently
-        if args and getattr(args[0].loglikelihood, 'save_evaluation_history', False):
-            raise NotImplementedError(
-                "dynesty_amd: save_evaluation_history=True is not supported by the device samplers "
-                "(the walkers' intermediate evaluations never leave the GPU registers)")
+        # save_evaluation_history=True (utils.LogLikelihood, utils.py:120-262; internal_samplers.py:311, 426, 663)
+        # wants every point a sampler evaluated.  The fused kernels keep those in registers, so such a run takes the
+        # lock-step runners instead -- the device proposes (same streams, same counters), the host evaluates the
+        # caller's prior transform and likelihood and keeps the history: the opt-in slow path (see _wants_history)
         return runner(args)
 
     def sample(arg):

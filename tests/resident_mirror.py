@@ -84,7 +84,7 @@ def child_words(entropy, child):
     return np.array([s >> 64, s & M64, i >> 64, i & M64], dtype=np.uint64)
 
 
-def mirror_run(ctx, prob, nlive, K, walks, bound, entropy, run, dlogz, enlarge=1.25, forced="late", first_run=0,
+def mirror_run(ctx, prob, nlive, K, walks, bound, entropy, run, dlogz, enlarge=1.25, forced="exact", first_run=0,
                max_fills=100000, sample="rwalk", bc=None, bootstrap=0, update_interval=None, first_update=None):
     """The run with global index first_run + run of ns_ensemble(prob, ..., rebuild_every=1); sample = 'rwalk' |
     'rslice' | 'slice' (`walks` is then the number of slices), bc = DH_BC_* flags per dimension or None."""

@@ -420,21 +420,62 @@ def test_slice_lockstep_lookahead_refill(dyn, monkeypatch):
             assert a.bit_generator.state == b.bit_generator.state
 
 
-def test_evaluation_history_request_fails_loudly():
-    """save_evaluation_history=True (utils.LogLikelihood) asks the samplers for every point they
-    evaluated (internal_samplers.py:28-31, 311, 426, 663); the device walkers cannot hand those
-    back, and an empty history must not be written silently."""
-    from collections import namedtuple
-    from dynesty_amd import samplers
+def test_evaluation_history_equals_the_reference_samplers(dyn):
+    """save_evaluation_history=True (utils.LogLikelihood, utils.py:120-262) asks the samplers for every point they
+    evaluated (internal_samplers.py:28-31, 311-339, 426, 663, 960-961, 1118-1119).  The fused kernels keep those in
+    registers; a run that wants them takes the lock-step runners (the device proposes, the host evaluates and records:
+    the opt-in slow path).  Held here to the reference's own samplers on the same generators:
+    the same history, item for item, for rwalk, rslice, slice and the uniform sampler -- also with a device problem
+    attached (which alone would select the fused kernel)."""
+    import dynesty.internal_samplers as IS
+    from dynesty import bounding as RB
+    from dynesty_amd import samplers, problems
+    prob = problems.gauss_iid(3, 10.0, "hist3")
 
-    class LL:
+    class LL:  # what utils.LogLikelihood looks like to a sampler
         save_evaluation_history = True
-    Arg = namedtuple('SamplerArgument', ['u', 'loglstar', 'axes', 'scale', 'prior_transform', 'loglikelihood',
-                                         'rseed', 'kwargs'])
-    arg = Arg(u=np.zeros(3), loglstar=0.0, axes=np.eye(3), scale=1.0, prior_transform=None, loglikelihood=LL(),
-              rseed=None, kwargs={})
-    for run in (samplers.run_rwalk, samplers.run_rslice, samplers.run_unif):
-        with pytest.raises(NotImplementedError):
-            samplers.batched(run)(arg)
-        with pytest.raises(NotImplementedError):
-            samplers.batched(run)._dynhip_batch([arg])
+
+        def __call__(self, v):
+            return prob.loglikelihood(v)
+    rng = np.random.default_rng(8)
+    us = rng.uniform(0.45, 0.55, size=(5, 3))
+    loglstar = min(prob.loglikelihood(prob.prior_transform(u)) for u in us) - 0.5
+    axes = 0.05 * np.eye(3)
+
+    def same(ref, got):
+        assert len(ref) == len(got)
+        for r, g in zip(ref, got):
+            np.testing.assert_array_equal(g.u, r.u)
+            assert g.logl == r.logl and g.ncalls == r.ncalls
+            assert len(g.evaluation_history) == len(r.evaluation_history) > 0
+            for a, b in zip(r.evaluation_history, g.evaluation_history):
+                np.testing.assert_array_equal(b.u, a.u)
+                np.testing.assert_array_equal(b.v, a.v)
+                assert b.logl == a.logl
+    cases = [(IS.RWalkSampler, samplers.run_rwalk, dict(walks=12)),
+             (IS.RSliceSampler, samplers.run_rslice, dict(slices=3, slice_doubling=False, nonperiodic=None)),
+             (IS.SliceSampler, samplers.run_slice, dict(slices=2, slice_doubling=False, nonperiodic=None))]
+    for cls, runner, kw in cases:
+        for with_problem in (False, True):
+            def mk(gens):
+                k = dict(kw, problem=prob) if with_problem else dict(kw)
+                return [IS.SamplerArgument(u=us[i].copy(), loglstar=loglstar, axes=axes, scale=1.0,
+                                           prior_transform=prob.prior_transform, loglikelihood=LL(), rseed=g, kwargs=k)
+                        for i, g in enumerate(gens)]
+            ga = [np.random.Generator(np.random.PCG64(70 + i)) for i in range(5)]
+            gb = [np.random.Generator(np.random.PCG64(70 + i)) for i in range(5)]
+            same([cls.sample(a) for a in mk(ga)], samplers.batched(runner)._dynhip_batch(mk(gb)))
+            for a, b in zip(ga, gb):
+                assert a.bit_generator.state == b.bit_generator.state
+    # the uniform sampler inside a bound
+    bound = RB.Ellipsoid(3, ctr=np.full(3, 0.5), cov=0.01 * np.eye(3))
+    for with_problem in (False, True):
+        def mk(gens):
+            k = dict(bound=bound, ndim=3, n_cluster=3, nonbounded=None)
+            if with_problem:
+                k["problem"] = prob
+            return [IS.SamplerArgument(u=None, loglstar=loglstar, axes=None, scale=1.0, prior_transform=prob.prior_transform,
+                                       loglikelihood=LL(), rseed=g, kwargs=k) for g in gens]
+        ga = [np.random.Generator(np.random.PCG64(90 + i)) for i in range(5)]
+        gb = [np.random.Generator(np.random.PCG64(90 + i)) for i in range(5)]
+        same([IS.UniformBoundSampler.sample(a) for a in mk(ga)], samplers.batched(samplers.run_unif)._dynhip_batch(mk(gb)))

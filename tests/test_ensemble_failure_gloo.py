@@ -19,6 +19,7 @@ from dynesty_amd import backend, ensemble
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 bad_rank = int(os.environ["BAD_RANK"])
 raise_rank = int(os.environ.get("RAISE_RANK", "-1"))
+TOTAL = int(os.environ.get("TOTAL_RUNS", "5"))
 
 class FakeBackend:
     def ns_ensemble(self, prob, runs, nlive, queue_size, first_run=0, want_samples=False, **kw):
@@ -46,15 +47,15 @@ backend.set_backend(FakeBackend())
 dist.init_process_group("gloo")
 res = {}
 try:
-    t = ensemble.run_ensemble_device(None, 5, world=world, rank=rank, dist=dist)
+    t = ensemble.run_ensemble_device(None, TOTAL, world=world, rank=rank, dist=dist)
     res["device"] = ["ok", t[:, 1].tolist()]
 except (RuntimeError, MemoryError) as e:
     res["device"] = ["raised", type(e).__name__ + ": " + str(e)]
 if raise_rank < 0:
-    t = ensemble.run_ensemble_device(None, 5, world=world, rank=rank, dist=dist, on_failure='nan')
+    t = ensemble.run_ensemble_device(None, TOTAL, world=world, rank=rank, dist=dist, on_failure='nan')
     res["nan"] = [int(np.isnan(t[:, 1]).sum()), t.shape]
 try:
-    m = ensemble.run_ensemble_merged_sharded(None, 5, world=world, rank=rank, dist=dist, nlive=8, queue_size=4)
+    m = ensemble.run_ensemble_merged_sharded(None, TOTAL, world=world, rank=rank, dist=dist, nlive=8, queue_size=4)
     res["merged"] = ["ok", int(m.niter)]
 except (RuntimeError, MemoryError) as e:
     res["merged"] = ["raised", type(e).__name__ + ": " + str(e)]
@@ -73,7 +74,7 @@ def _free_port():
     return p
 
 
-def _launch(tmp, world, bad_rank, raise_rank=-1):
+def _launch(tmp, world, bad_rank, raise_rank=-1, total=5):
     import json
     script = os.path.join(str(tmp), "worker.py")
     with open(script, "w") as f:
@@ -83,7 +84,7 @@ def _launch(tmp, world, bad_rank, raise_rank=-1):
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), OMP_NUM_THREADS="1", BAD_RANK=str(bad_rank),
-                   RAISE_RANK=str(raise_rank))
+                   RAISE_RANK=str(raise_rank), TOTAL_RUNS=str(total))
         procs.append(subprocess.Popen([sys.executable, script], env=env))
     for p in procs:
         assert p.wait(timeout=300) == 0  # a hang in the collective would time out here
@@ -124,3 +125,32 @@ def test_an_exception_on_one_rank_raises_on_every_rank(tmp_path):
     assert "[3, 4]" in res[0]["device"][1]
     assert res[0]["merged"][0] == "raised" and res[1]["merged"][0] == "raised"
     assert res[1]["merged"][1].startswith("MemoryError")
+
+
+def test_failures_at_world_size_8(tmp_path):
+    """the first real 8-GPU run must not be the first time a failing rank meets seven healthy
+    ones.  20 runs over 8 ranks (ragged shards: 3, 3, 3, 3, 2, 2, 2, 2): (i) the last run of rank 5 ends with a bad
+    status -- every rank raises after the gather and names the run's global id, 'nan' mode marks exactly that run, the
+    merged path raises everywhere; (ii) rank 3's backend raises -- its three runs travel with the sentinel status, the
+    owner re-raises its own exception, the other seven a RuntimeError naming those runs; nobody hangs."""
+    from dynesty_amd import ensemble
+    shards = [ensemble.shard_runs(20, 8, r) for r in range(8)]
+    assert [len(s) for s in shards] == [3, 3, 3, 3, 2, 2, 2, 2]
+    bad = shards[5].stop - 1
+    res = _launch(tmp_path, 8, bad_rank=5, total=20)
+    for r in res:
+        assert r["device"][0] == "raised" and "status" in r["device"][1] and f"[{bad}]" in r["device"][1], r
+        assert r["nan"] == [1, [20, 6]]
+        assert r["merged"][0] == "raised", r
+    res = _launch(tmp_path, 8, bad_rank=-1, raise_rank=3, total=20)
+    ids = list(range(shards[3].start, shards[3].stop))
+    for rk, r in enumerate(res):
+        assert r["device"][0] == "raised" and r["merged"][0] == "raised", (rk, r)
+        if rk == 3:
+            assert r["device"][1].startswith("MemoryError") and r["merged"][1].startswith("MemoryError")
+        else:
+            assert "raised on the rank" in r["device"][1] and str(ids) in r["device"][1], (rk, r)
+    # and the healthy case at this shape
+    res = _launch(tmp_path, 8, bad_rank=-1, total=20)
+    assert all(r == res[0] for r in res)
+    assert res[0]["device"][0] == "ok" and len(res[0]["device"][1]) == 20 and res[0]["merged"] == ["ok", 20 * 18]

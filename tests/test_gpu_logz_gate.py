@@ -340,7 +340,9 @@ def test_periodic_and_reflective_coordinates_in_the_resident_loop(ctx, case):
     c = ref["config"]
     prob = getattr(problems, c["prob"][0])(*c["prob"][1:])
     kw = {k: c[k] for k in ("walks", "periodic", "reflective") if k in c}
-    runs = 64
+    # (the uniform case: the median of a bimodal call count over 64 runs scatters by ~4 % -- 27.8 k against the
+    # reference's 31.4 k once in round 5, 30.9 - 31.3 k in four ensembles of 256: 256 runs there)
+    runs = 256 if case == "bc_periodic_unif_egg" else 64
     r = ctx.ns_ensemble(prob, runs, c["nlive"], c["K"], bound=c["bound"], sample=c["sample"], dlogz=c.get("dlogz", 0.5),
                         entropy=[17, len(case)], **kw)
     assert (r["status"] == 0).all()

@@ -129,20 +129,33 @@ def test_fill_chains_vs_oracle(ctx, nlive, K, runs):
 
 def test_whole_run_results_are_compute_integrals(ctx):
     """dh_ns_ensemble's record (ln Z, sqrt var, H) = the reference's final recomputation
-    (compute_integrals, sampler.py:1342-1348) over the run's own dead and live log-likelihoods."""
+    (compute_integrals, sampler.py:1342-1348) over the run's own dead and live log-likelihoods.  (The volumes are
+    replayed from the record with the reference's bookkeeping: with 25 steps per proposal an rwalk walker still hands
+    back its start point now and then -- an exact tie among the live points, i.e. a plateau step, sampler.py:1112-1127;
+    round 5's default protocol met one in run 2 of this very ensemble, where the plain ladder is 1e-5 off in ln Z.)"""
     prob = inputs.problem("G5")
     r = ctx.ns_ensemble(prob, 6, 300, 64, walks=25, bound="multi", entropy=[31], dlogz=0.05,
-                        max_iter=40000, want_dead_logl=True)
+                        max_iter=40000, want_samples=True)
     assert np.all(r["status"] == 0)
+    nties = 0
     for i in range(6):
         n = int(r["niter"][i])
-        lz, lzerr, h = R.final_results(r["dead_logl"][i, :n], r["live_logl"][i], 300)
+        dead, ids = r["dead_logl"][i, :n], r["dead_id"][i, :n]
+        ties = len(np.unique(np.concatenate([dead, r["live_logl"][i]]))) < n + 300
+        nties += ties
+        lv = R.logvol_from_record(dead, ids, r["live_logl"][i], 300)
+        if not ties:  # no plateau met: the plain ladder
+            np.testing.assert_allclose(lv, R.static_run_logvol(n, 300), rtol=0, atol=1e-9)
+        logl = np.concatenate([dead, np.sort(r["live_logl"][i])])
+        _, lzs, lzvars, hs = R.compute_integrals(logl, lv)
+        lz, lzerr, h = float(lzs[-1]), float(np.sqrt(lzvars[-1])), float(hs[-1])
         np.testing.assert_allclose(r["logz"][i], lz, rtol=0, atol=1e-9)
         np.testing.assert_allclose(r["logzerr"][i], lzerr, rtol=1e-7)
         np.testing.assert_allclose(r["h"][i], h, rtol=1e-9)
+        if ties:
+            continue
         # and the stopping rule held exactly at the last dead point, not before (recurrence values)
         s = R.RunState(300)
-        dead = r["dead_logl"][i, :n]
         for lnew in dead:
             s.logvol -= s.dlv
             _, s.logz, s.logzvar, s.h = R.progress_integration(s.loglstar, lnew, s.logz, s.logzvar,
@@ -150,6 +163,7 @@ def test_whole_run_results_are_compute_integrals(ctx):
             s.loglstar = lnew
         lmax = r["live_logl"][i].max()
         assert np.logaddexp(0, lmax + s.logvol - s.logz) < 0.05
+    assert nties < 6
 
 
 def test_whole_run_with_plateaus_is_compute_integrals(ctx):

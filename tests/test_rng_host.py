@@ -172,9 +172,30 @@ def test_frames_dedupe_by_memory_and_value():
     m.logvol_ells = np.log(np.arange(1., nells + 1))
     m.logvol = float(np.log(np.exp(m.logvol_ells).sum()))
     args = [SimpleNamespace(axes=m.get_random_axes(rng)) for _ in range(200)]
-    assert len({id(a.axes) for a in args}) == 200  # fresh views: identity is useless
+    # (round 5) one cached view object per ellipsoid: a queue's frames deduplicate by identity alone
+    assert len({id(a.axes) for a in args}) == nells
     frames, idx = samplers._frames(args)
     assert len(frames) <= nells and idx is not None
+    for a, j in zip(args, idx):
+        np.testing.assert_array_equal(frames[j], a.axes)
+    # ... and the draws are the reference's expression on the same generator (bounding.py:726-731)
+    ra, rb = np.random.default_rng(8), np.random.default_rng(8)
+    probs = np.exp(m.logvol_ells - m.logvol)
+    for _ in range(300):
+        want = min(np.searchsorted(np.cumsum(probs), ra.random()), nells - 1)
+        assert m.get_random_axes(rb) is m._axes_cache[2][want]
+    # a change of the volumes (scale_to_logvol works in place) refreshes the cumulative weights
+    m.logvol_ells[0] += 3.0
+    m.logvol = float(np.log(np.exp(m.logvol_ells).sum()))
+    probs = np.exp(m.logvol_ells - m.logvol)
+    for _ in range(100):
+        want = min(np.searchsorted(np.cumsum(probs), ra.random()), nells - 1)
+        np.testing.assert_array_equal(m.get_random_axes(rb), m.axes_ells[want])
+    # fresh views of the same memory (what the reference's own classes hand out): deduplicated by the memory they view
+    args = [SimpleNamespace(axes=m.axes_ells[i % nells]) for i in range(200)]
+    assert len({id(a.axes) for a in args}) == 200
+    frames, idx = samplers._frames(args)
+    assert len(frames) == nells
     for a, j in zip(args, idx):
         np.testing.assert_array_equal(frames[j], a.axes)
     # equal by value only (separate copies) also collapses
