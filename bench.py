@@ -760,6 +760,8 @@ def main():
             # Mahalanobis max, + coverage)
             rb_bytes = 8.0 * nlive * d * 62 * runs
             rb_gbs = rb_bytes / (t_rb * 1e-3) / 1e9
+            if e2e and isinstance(e2e.get("config_C4"), dict) and "roofline" in e2e["config_C4"]:
+                line["roofline_c4"] = e2e["config_C4"]["roofline"]
             line["roofline_rebuild"] = {
                 "bound": "hbm", "kernel": "k_root + levels x (k_split, k_ell) + k_finish",
                 "achieved": rb_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -847,6 +849,26 @@ def c4_leg(ctx, runs=16, queue=128):
         ens = json.load(open(ref)).get("ensembles", {})
         out["logz_reference"] = {k: {"mean": e["mean"], "se": e["se"], "n": e["n"],
                                      "mean_seconds_1core": e["mean_seconds_1core"]} for k, e in ens.items()}
+    # roofline of the C4 loop as a whole (BASELINE.md section 3 asks for fp64 GFLOP/s here).
+    # Algorithmic bytes: one F evaluation = read u, write u', write ln L = 8 (2 D + 1) = 3 208 B (slice
+    # evaluation); flops: per slice one frame product of 2 D^2, per evaluation the prior transform + iid-Normal ln L
+    # ~ 2 D + 3 D (the ndtri of the Normal prior is ~60 flop-equivalents per coordinate: counted apart, not as flops).
+    # Both over the WHOLE loop's seconds (bound updates and queue consumption included: wide_walk_kernel is ~83 % of it,
+    # profiles/r05); slices = queue entries walked (fills x K x runs) x slices per proposal, wasted entries included.
+    d, slices = 200, 203
+    ncall = float(r["ncall"].sum())
+    nslices = float(r["nfills"]) * queue * runs * slices
+    bytes_alg = ncall * 8 * (2 * d + 1)
+    flops = nslices * 2.0 * d * d + ncall * 5.0 * d
+    out["roofline"] = {"bound": "hbm", "achieved": bytes_alg / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": bytes_alg / dt / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                       "algorithmic_bytes_per_evaluation": 8 * (2 * d + 1), "evaluations": ncall,
+                       "evaluations_per_slice": ncall / nslices,
+                       "fp64_gflops": flops / dt / 1e9, "fp64_frac_of_vector_peak": flops / dt / 1e12 / FP64_PEAK_TFLOPS,
+                       "seconds": dt,
+                       "note": "whole-loop figures (not one kernel): the walkers stay in LDS / registers for all 203 slices, "
+                               "so the 3 208 B per evaluation never travel; what travels is the run's 320 KB frame, "
+                               "streamed from L2 once per slice and workgroup (DESIGN.md 3.5)"}
     return out
 
 

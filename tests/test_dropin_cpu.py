@@ -479,3 +479,44 @@ def test_evaluation_history_equals_the_reference_samplers(dyn):
         ga = [np.random.Generator(np.random.PCG64(90 + i)) for i in range(5)]
         gb = [np.random.Generator(np.random.PCG64(90 + i)) for i in range(5)]
         same([IS.UniformBoundSampler.sample(a) for a in mk(ga)], samplers.batched(samplers.run_unif)._dynhip_batch(mk(gb)))
+
+
+def test_pool_batches_dynestys_own_unit_cube_sampler(dyn):
+    """The phase before the first bound is dynesty's own UnitCubeSampler (sampler.py builds it; no drop-in class can be
+    handed in for it): HipBatchPool.map recognises its `sample` and runs the queue as one backend call when the
+    callbacks are a device Problem's -- the same points, call counts and generator states as the serial map -- and
+    leaves it alone otherwise (other callbacks, wrapped arguments, an evaluation history wanted)."""
+    import dynesty.internal_samplers as IS
+    from dynesty import utils as DU
+    from dynesty_amd import backend, dropin, problems
+    prob = problems.gauss_iid(3, 10.0, "cube3")
+    pool = dropin.HipBatchPool(8)
+    loglstar = -9.0
+    kids = np.random.SeedSequence(4).spawn(8)
+
+    def mk(ll, pt):
+        return [IS.SamplerArgument(u=None, loglstar=loglstar, axes=None, scale=1.0, prior_transform=pt, loglikelihood=ll,
+                                   rseed=k, kwargs=dict(ndim=3)) for k in kids]
+    ll = DU.LogLikelihood(prob.loglikelihood, 3)
+    calls = []
+    be = backend.get_backend()
+    orig = be.unif_batch
+
+    def spy(*a, **k):
+        calls.append(1)
+        return orig(*a, **k)
+    be.unif_batch = spy
+    try:
+        ref = [IS.UnitCubeSampler.sample(a) for a in mk(ll, prob.prior_transform)]
+        got = pool.map(IS.UnitCubeSampler.sample, mk(ll, prob.prior_transform))
+        assert len(calls) == 1
+        for r, g in zip(ref, got):
+            np.testing.assert_array_equal(g.u, r.u)
+            np.testing.assert_allclose(g.v, r.v, rtol=0, atol=1e-12)
+            assert g.ncalls == r.ncalls and abs(g.logl - r.logl.val if hasattr(r.logl, 'val') else g.logl - r.logl) < 1e-10
+            assert g.tuning_info is None and g.proposal_stats == dict(n_proposals=r.ncalls)
+        # not a device Problem's callbacks: the serial map
+        got = pool.map(IS.UnitCubeSampler.sample, mk(lambda v: prob.loglikelihood(v), prob.prior_transform))
+        assert len(calls) == 1 and len(got) == 8
+    finally:
+        be.unif_batch = orig
