@@ -663,7 +663,7 @@ def main():
         flops = 2 * d * d + 8 * d + (d * d + 3 * d)  # frame mat-vec + sym. quad form
         achieved = props_per_launch * alg_bytes / (t_wk * 1e-3) / 1e9
         traffic, traffic_src, traffic_rb, issue = None, None, None, None
-        pmc = os.path.join(ROOT, "profiles", "r04", "pmc_traffic.json")
+        pmc = _profile_path("pmc_traffic.json")
         if os.path.exists(pmc) and runs == 64 and nlive == 2000 and args.walks == 45 and kq == GATE_QUEUE:
             # PMC counters cannot be read from inside this process; the values are
             # the committed rocprofv3 measurement of this same launch shape
@@ -672,9 +672,9 @@ def main():
                 pj = json.load(f)
             traffic = pj.get("rwalk_launch_traffic_bytes")  # generator pass + walk kernel
             traffic_rb = pj.get("rebuild_pipeline_bytes_per_launch_sequence")
-            traffic_src = ("profiles/r04/pmc_traffic.json (2*FETCH_SIZE + WRITE_SIZE, "
+            traffic_src = (os.path.relpath(pmc, ROOT) + " (2*FETCH_SIZE + WRITE_SIZE, "
                            "separate --pmc passes; walk launch = itemgen_kernel + rwalkq_kernel)")
-            pi = os.path.join(ROOT, "profiles", "r04", "pmc_issue.json")
+            pi = _profile_path("pmc_issue.json")
             if os.path.exists(pi):
                 # SQ issue / stall counters of the same launch shape (tools/pmc_issue.py, three --pmc passes)
                 with open(pi) as f:
@@ -742,7 +742,7 @@ def main():
                                      {k: v.get("valu_active_frac") for k, v in issue.items()
                                       if k.startswith(("rwalkq_kernel", "itemgen_kernel"))}),
                 "issue_counters": issue,
-                "issue_counters_source": "profiles/r04/pmc_issue.json (rocprofv3 --pmc, SQ block; "
+                "issue_counters_source": os.path.relpath(_profile_path("pmc_issue.json"), ROOT) + " (rocprofv3 --pmc, SQ block; "
                                          "fractions of SQ_WAVE_CYCLES)" if issue else None,
                 "fp64_valu": {
                     "achieved": props_per_launch * flops / (t_wk * 1e-3) / 1e12,
@@ -839,7 +839,15 @@ def c4_leg(ctx, runs=16, queue=128):
     t0 = time.perf_counter()
     r = ctx.ns_ensemble(prob, runs, 4000, queue, entropy=[21, queue], **kw)
     dt = time.perf_counter() - t0
+    # the late form of the forced update (round 4's default; fewer bound updates than the reference) beside it
+    t1 = time.perf_counter()
+    rl = ctx.ns_ensemble(prob, runs, 4000, queue, entropy=[21, queue], forced_exact=False, **kw)
+    dtl = time.perf_counter() - t1
+    late = {"seconds": dtl, "logz_mean": float(rl["logz"].mean()), "logz_se": float(rl["logz"].std(ddof=1) / math.sqrt(runs)),
+            "bound_updates_per_run": float(rl["nbound"].mean()), "fills": int(rl["nfills"])}
     out = {"what": "200-D iid Normal / Normal prior, nlive 4000, single ellipsoid, rslice x 203, device-resident loop",
+           "protocol": "the reference's (forced_exact, default); forced_late = the late form",
+           "bound_updates_per_run": float(r["nbound"].mean()), "fills": int(r["nfills"]), "forced_late": late,
            "runs": runs, "queue_size": queue, "seconds": dt, "seconds_per_run": dt / runs,
            "likelihood_calls_per_s": float(r["ncall"].sum() / dt), "status_ok": bool((r["status"] == 0).all()),
            "logz_mean": float(r["logz"].mean()), "logz_se": float(r["logz"].std(ddof=1) / math.sqrt(runs)),
@@ -886,8 +894,17 @@ def reference_logz_gate():
     return out
 
 
+def _profile_path(name):
+    """The newest committed record of that name (profiles/r05, else profiles/r04)."""
+    for rnd in ("r05", "r04"):
+        p = os.path.join(ROOT, "profiles", rnd, name)
+        if os.path.exists(p):
+            return p
+    return os.path.join(ROOT, "profiles", "r05", name)
+
+
 def _load_profile(name):
-    p = os.path.join(ROOT, "profiles", "r04", name)
+    p = _profile_path(name)
     if not os.path.exists(p):
         return None
     with open(p) as f:
@@ -902,7 +919,7 @@ def tap_b_record():
     if not t:
         return None
     runs = list(t["runs"].values())
-    return {"source": "profiles/r04/tapb_c2.json (tools/tapb_hw.py on an MI355X box, round 4; not re-measured in this run)",
+    return {"source": os.path.relpath(_profile_path("tapb_c2.json"), ROOT) + " (tools/tapb_hw.py on an MI355X box through tools/stage_reference.sh; not re-measured in this run)",
             "what": t["what"], "runs": len(runs),
             "seconds_per_run": float(np.mean([r["seconds"] for r in runs])),
             "proposals_per_s": float(np.mean([r["proposals_per_s"] for r in runs])),
@@ -1024,7 +1041,7 @@ def cpu_baseline(prob, u0, nlive, scale, loglstar, walks, budget_s):
             "proposals_per_s": ref_box["bounded_phase"]["proposals_per_s"], "cores": 1,
             "multiellipsoid_update_ms": ref_box["multiellipsoid_update_ms"]["median"],
             "sample": ref_box["sample"], "host_cpu_count": ref_box.get("cpu_count"),
-            "source": "profiles/r04/reference_cpu_on_gpu_box.json"}
+            "source": os.path.relpath(_profile_path("reference_cpu_on_gpu_box.json"), ROOT)}
     # the real reference, when this machine has a copy: it becomes the baseline, the port stays beside it
     ref = _reference_leg(prob, u0, nlive, scale, loglstar, walks, budget_s * 0.6)
     if ref is not None:

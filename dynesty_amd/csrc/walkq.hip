@@ -455,7 +455,12 @@ __device__ __forceinline__ U128 mul128_limbs_s(const Limbs128& a, const U128& b)
 // The two rare paths of a round are calls, not inlined code: ocml's exp (the double-precision wedge verdict, a
 // candidate inside the single-precision band: ~1 round in 10^3) and log1p x 2 + a sequential 128-bit generator (the
 // tail of the distribution: 3 draws in 10^4) set the kernel's register need to 96 when inlined -- five wavefronts
-// per SIMD; behind calls with scalar arguments the round itself needs 40 and the kernel is what its callees need.
+// per SIMD; behind calls with scalar arguments the round itself needs 40 and the kernel is what its callees and the
+// call ABI's callee-saved registers need: 74 at six wavefronts per SIMD without a spill, 64 at eight with ten spilled
+// registers stored and reloaded once per walker.  MEASURED (round 5): 143 us at five, at six and at eight wavefronts
+// per SIMD -- the pass is bound by the vector pipe's throughput (~100 vector instructions a round, ten of them
+// quarter rate), not by latency -- and the eight-wavefront form's per-walker spill is 84 MB of scratch traffic per
+// launch (PMC: 433 MB instead of 340).  Hence six.
 __device__ __attribute__((noinline)) bool itemgen_wedge_f64(double x, double u1, double f1, double f0) {
 #pragma clang fp contract(off)
   return (f1 - f0) * u1 + f0 < exp(-0.5 * x * x);
@@ -491,7 +496,7 @@ __device__ __attribute__((noinline)) ItemTail itemgen_tail(uint64_t shi, uint64_
   return o;
 }
 
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) itemgen_kernel(ItemGenArgs a) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) itemgen_kernel(ItemGenArgs a) {
 #pragma clang fp contract(off)
   __shared__ ZigQ zig;
   const int tid = threadIdx.x, lane = tid & 63, wave = (int)sfirst((uint32_t)(tid >> 6));

@@ -73,14 +73,16 @@ def test_rwalkq_kernel_keeps_two_wavefronts_per_simd():
         if rng in ("2", "3"):
             assert r["ScratchSize [bytes/lane]"] == 0, r
     # The generator passes.  itemgen_kernel: its two rare paths (double-precision wedge
-    # verdict, tail of the distribution) are calls, so the round itself fits 64 registers = eight wavefronts per SIMD;
-    # the stack is the calls' save area (touched once per walker and on the rare paths, not in the round loop).
-    # Measured on the MI355X: 143 us at five wavefronts per SIMD (96 VGPRs, round 4) and 143 us at eight -- the pass is
-    # bound by the vector pipe's throughput (~100 VALU instructions a round, ten of them quarter rate), not by latency.
+    # verdict, tail of the distribution) are calls; the round itself needs 40 registers, the kernel what the call ABI
+    # needs: 74 at six wavefronts per SIMD with NO spill (pinned), or 64 at eight with a 40-byte spill per lane and
+    # walker.  Measured on the MI355X: 143 us at five (96 VGPRs, round 4), six and eight wavefronts per SIMD -- the pass
+    # is bound by the vector pipe's throughput (~100 VALU instructions a round, ten of them quarter rate), not by
+    # latency -- and the eight-wavefront form adds 84 MB of scratch traffic per launch.
     key = [k for k in res if "14itemgen_kernel" in k]
     assert len(key) == 1, list(res)
     r = res[key[0]]
-    assert r["VGPRs"] <= 64 and r["Occupancy [waves/SIMD]"] >= 8 and r["ScratchSize [bytes/lane]"] <= 160, r
+    assert r["VGPRs"] <= 80 and r["Occupancy [waves/SIMD]"] >= 6 and r["VGPRs Spill"] == 0, r
+    assert r["ScratchSize [bytes/lane]"] <= 64, r  # (the callees' frames)
     key = [k for k in res if "19philox_items_kernel" in k]
     assert len(key) == 1, list(res)
     r = res[key[0]]
