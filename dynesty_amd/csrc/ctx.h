@@ -212,7 +212,9 @@ int wide_eval_launch(dh_ctx* ctx, const ProblemDev& p, int k, const double* u, d
 int wide_unif_launch(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, int m, const double* ctrs,
                      const double* axes, const double* ams, const double* cumprob, double loglstar,
                      const int8_t* bc, const uint64_t* rng, int64_t max_tries, double* u, double* v, double* logl,
-                     int32_t* ncalls, int32_t* flags, uint64_t* rng_out, const PhiloxKey* philox = nullptr);
+                     int32_t* ncalls, int32_t* flags, uint64_t* rng_out, const PhiloxKey* philox = nullptr,
+                     const double* run_loglstar = nullptr, const int* run_mode = nullptr, int wpr = 1, int my_mode = 0,
+                     const int* run_nells = nullptr, int run_me = 0);
 int wide_contains_launch(dh_ctx* ctx, const double* x, int k, int d, const double* ctrs, const double* ams,
                          int m, int mode, int32_t* count, uint64_t* mask, double* quad);
 int wide_single_launch(dh_ctx* ctx, int runs, const double* pts, int n, int d, int32_t* nells,

@@ -2289,8 +2289,6 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
   if (runs < 1 || nlive < 4 || queue_size < 1 || walks < 1 || sampler < 0 || sampler > 3 || !entropy_words ||
       n_words < 1 || !records || bootstrap < 0 || bootstrap == 1)
     return fail(ctx, DH_ERR_ARG, "ns_ensemble: bad arguments");
-  if (sampler == 3 && ndim > kMaxRegDim)
-    return fail(ctx, DH_ERR_ARG, "ns_ensemble: sample='unif' in the device-resident loop needs ndim <= %d (ndim=%d)", kMaxRegDim, ndim);
   // Above the register-resident dimensions (and for slice samplers at dimensions without an instantiation) the
   // walker launches go to the wave-per-walker kernels of wide.hip, which take the same per-run arrays; above
   // d = 44 the bound is the multi-workgroup Ellipsoid.update with the run mask, or -- bound='multi' -- the wide

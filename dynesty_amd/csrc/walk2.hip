@@ -1188,10 +1188,10 @@ int dh::unif_launch_runs(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, i
   if (m < 0 || ncdim < 1 || ncdim > ndim) return fail(ctx, DH_ERR_ARG, "unif: m=%d ncdim=%d", m, ncdim);
   if (ndim > kMaxRegDim) {
     if (m != 0 || a.propose_only) {
-      if (run_mode)
-        return fail(ctx, DH_ERR_ARG, "ensemble unif inside a bound: ndim=%d > %d not built", ndim, kMaxRegDim);
+      // (round 5: the ensemble form -- per-run thresholds and bounds -- above the register-resident dimensions too)
       return wide_unif_launch(ctx, problem, k, ndim, ncdim, m, ctrs, axes, ams, cumprob, loglstar, bc, rng,
-                              max_tries, u, v, logl, ncalls, flags, rng_out, philox);
+                              max_tries, u, v, logl, ncalls, flags, rng_out, philox, run_loglstar, run_mode, wpr,
+                              my_mode, run_nells, run_me);
     }
     return wide_walk_launch(ctx, 3, problem, k, ndim, ndim, nullptr, nullptr, 1,
                             nullptr, 1.0, loglstar, 0, 0, bc, rng, u, v, logl, ncalls, nullptr, nullptr,

@@ -882,6 +882,13 @@ struct WideUnifArgs {
   const uint64_t* zwi;
   const uint64_t* zfi;
   PhiloxKey ph;  // RNG_PHILOX
+  // ensemble form (ns.hip, round 5): walker w belongs to run w / wpr; per-run threshold, only the runs whose mode is
+  // my_mode are served; run r owns the ellipsoids [r * run_me, r * run_me + M_r) of ctrs / axes_t / ams / cumprob,
+  // M_r = run_nells[r] (null: 1).  All null / 0: the plain batch.
+  const double* run_loglstar;
+  const int* run_mode;
+  const int* run_nells;
+  int wpr, my_mode, run_me;
 };
 
 template <int RNG>
@@ -893,6 +900,19 @@ __global__ void __launch_bounds__(64) wide_unif_kernel(WideUnifArgs a) {
   double* sz = (double*)smem;  // nc: normals, then x - c
   double* sx = sz + nc;        // D : candidate
   double* sv = sx + D;         // D : v
+  int M = a.m;
+  size_t eb = 0;
+  double loglstar = a.loglstar;
+  if (a.run_mode) {
+    const int run = w / a.wpr;
+    if (a.run_mode[run] != a.my_mode) return;
+    loglstar = a.run_loglstar[run];
+    if (a.run_me > 0) {
+      M = a.run_nells ? a.run_nells[run] : 1;
+      eb = (size_t)run * a.run_me;
+    }
+  }
+  const double* cumprob = a.cumprob ? a.cumprob + eb : nullptr;
   WaveGen<RNG> g;
   g.init(a.rng_in, (size_t)w, lane, &zig, a.ph);
   int ncall = 0, flags = 0;
@@ -904,31 +924,31 @@ __global__ void __launch_bounds__(64) wide_unif_kernel(WideUnifArgs a) {
       break;
     }
     ++tries;
-    if (a.m == 0) {  // unit cube: rstate.uniform(size=ndim)
+    if (M == 0) {  // unit cube: rstate.uniform(size=ndim)
       g.doubles(sx, D, lane);
       lds_sync();
       if (a.propose_only) break;
       const double ll0 = wide_logl(a.prob, D, sx, sv, lane);
       lds_sync();
       ++ncall;
-      if (ll0 > a.loglstar) {
+      if (ll0 > loglstar) {
         logl_cur = ll0;
         break;
       }
       continue;
     }
     int idx = 0;
-    if (a.m > 1) {  // rand_choice (bounding.py:1300-1308)
+    if (M > 1) {  // rand_choice (bounding.py:1300-1308)
       const double xr = g.uniform();
-      while (idx < a.m - 1 && a.cumprob[idx] < xr) ++idx;
+      while (idx < M - 1 && cumprob[idx] < xr) ++idx;
     }
     g.normals(sz, nc, lane);
     lds_sync();
     double ss = 0.0;
     for (int i = 0; i < nc; ++i) ss = fma(sz[i], sz[i], ss);  // index order, as the narrow kernel
     const double fac = pow(g.uniform(), 1.0 / (double)nc) / sqrt(ss);
-    const double* AT = a.axes_t + (size_t)idx * nc * nc;
-    const double* c = a.ctrs + (size_t)idx * nc;
+    const double* AT = a.axes_t + (eb + (size_t)idx) * nc * nc;
+    const double* c = a.ctrs + (eb + (size_t)idx) * nc;
     for (int i = lane; i < nc; i += 64) {
       double r = 0.0;
       for (int j = 0; j < nc; ++j) r = fma(AT[(size_t)j * nc + i], sz[j], r);
@@ -936,11 +956,11 @@ __global__ void __launch_bounds__(64) wide_unif_kernel(WideUnifArgs a) {
     }
     lds_sync();
     bool accept = true;
-    if (a.m > 1) {
+    if (M > 1) {
       int q = 0, qloose = 0;
-      for (int e = 0; e < a.m; ++e) {
-        const double* ce = a.ctrs + (size_t)e * nc;
-        const double* A = a.ams + (size_t)e * nc * nc;
+      for (int e = 0; e < M; ++e) {
+        const double* ce = a.ctrs + (eb + (size_t)e) * nc;
+        const double* A = a.ams + (eb + (size_t)e) * nc * nc;
         for (int i = lane; i < nc; i += 64) sz[i] = sx[i] - ce[i];
         lds_sync();
         double part = 0.0;
@@ -983,7 +1003,7 @@ __global__ void __launch_bounds__(64) wide_unif_kernel(WideUnifArgs a) {
     const double ll = wide_logl(a.prob, D, sx, sv, lane);
     lds_sync();
     ++ncall;
-    if (ll > a.loglstar) {
+    if (ll > loglstar) {
       logl_cur = ll;
       break;
     }
@@ -2479,8 +2499,16 @@ int wide_walk_launch(dh_ctx* ctx, int kind, int problem, int k, int ndim, int nc
 int wide_unif_launch(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, int m, const double* ctrs,
                      const double* axes, const double* ams, const double* cumprob, double loglstar,
                      const int8_t* bc, const uint64_t* rng, int64_t max_tries, double* u, double* v, double* logl,
-                     int32_t* ncalls, int32_t* flags, uint64_t* rng_out, const PhiloxKey* philox) {
+                     int32_t* ncalls, int32_t* flags, uint64_t* rng_out, const PhiloxKey* philox,
+                     const double* run_loglstar, const int* run_mode, int wpr, int my_mode, const int* run_nells,
+                     int run_me) {
   WideUnifArgs a;
+  a.run_loglstar = run_loglstar;
+  a.run_mode = run_mode;
+  a.run_nells = run_nells;
+  a.wpr = wpr;
+  a.my_mode = my_mode;
+  a.run_me = run_mode ? run_me : 0;
   a.ph = philox ? *philox : PhiloxKey{0, 0, 0};
   a.ph.offset = (a.ph.offset + 3ull) & ~3ull;
   if (!philox && !rng && k > 0) return fail(ctx, DH_ERR_ARG, "wide unif: no generator states");
@@ -2494,6 +2522,7 @@ int wide_unif_launch(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, int m
   if (ndim > kWideMaxD) return fail(ctx, DH_ERR_ARG, "ndim=%d exceeds the wide-D limit %d", ndim, kWideMaxD);
   if (m < 0 || (m > 0 && (!ctrs || !axes)) || (m > 1 && (!ams || !cumprob)))
     return fail(ctx, DH_ERR_ARG, "unif (wide): m=%d needs centres, axes and (m > 1) precision matrices", m);
+  if (run_mode && (wpr < 1 || k % wpr)) return fail(ctx, DH_ERR_ARG, "unif (wide): k=%d is not runs x %d", k, wpr);
   const size_t tot = (size_t)m * ncdim * ncdim;
   if (tot * 8 > ctx->axes_t_cap) {
     if (!hip_ok(ctx, hipStreamSynchronize(ctx->stream), "sync")) return DH_ERR_HIP;

@@ -416,12 +416,36 @@ def test_device_resident_loop_mixed_paths(ctx, d, bound, sample):
         assert abs(lz.mean() - prob.logz_truth) < 5 * se + 0.1, (lz.mean(), prob.logz_truth, se)
 
 
-def test_device_resident_loop_refuses_what_is_not_built(ctx):
+@pytest.mark.parametrize("bound,D", [("single", 36), ("multi", 34)])
+def test_device_resident_loop_uniform_sampler_above_32(ctx, bound, D):
+    """sample='unif' in the resident loop above the register-resident dimensions (round 5: the ensemble form of
+    wide_unif_kernel -- per-run thresholds and bounds; round 4 refused it).  Event for event against the host mirror,
+    which draws through the single-call entry point: the same deaths in the same slots, the same calls and bound
+    updates; and a run does not depend on its shard mates.  (A wide Normal likelihood under a narrow uniform prior
+    keeps the uniform sampler's efficiency bearable at this dimension.)"""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(__file__))
+    from resident_mirror import mirror_run
     from dynesty_amd import problems
-    prob = problems.gauss_normal_prior(64, "C4")
-    with pytest.raises(Exception):
-        ctx.ns_ensemble(prob, 2, 400, 64, bound='single', sample='unif')  # resident unif: register dimensions
-    # (the Philox proposals above 32 dimensions are built since round 3: tests/test_gpu_philox.py)
+    prob = problems.gauss_iid(D, 1.2, f"unif{D}")
+    nlive, K, dlogz, ent = 120, 8, 2.0, [D, 3]
+    # (the bound phase from 300 calls on whatever the unit cube's efficiency)
+    opt = dict(first_update=dict(min_ncall=300, min_eff=100.0))
+    kw = dict(bound=bound, sample='unif', dlogz=dlogz, entropy=ent, rebuild_every=1, bootstrap=0, enlarge=1.25,
+              want_samples=True, want_dead_logl=True, max_iter=4000, **opt)
+    r = ctx.ns_ensemble(prob, 3, nlive, K, **kw)
+    assert (r["status"] == 0).all()
+    for run in (0, 2):
+        m = mirror_run(ctx, prob, nlive, K, 1, bound, ent, run, dlogz, enlarge=1.25, sample="unif", bootstrap=0, **opt)
+        n = int(r["niter"][run])
+        assert m["done"] and m["niter"] == n, (m["niter"], n)
+        np.testing.assert_array_equal(r["dead_id"][run, :n], np.array(m["dead_slot"]))
+        np.testing.assert_allclose(r["dead_logl"][run, :n], np.array(m["dead_logl"]), rtol=1e-6, atol=0)
+        assert int(r["ncall"][run]) == m["ncall"] and int(r["nbound"][run]) == m["nbound"]
+        assert m["nbound"] >= 2
+    alone = ctx.ns_ensemble(prob, 1, nlive, K, first_run=2, **kw)
+    np.testing.assert_array_equal(alone["logz"], r["logz"][2:3])
+    np.testing.assert_array_equal(alone["ncall"], r["ncall"][2:3])
 
 
 def test_device_resident_loop_multi_bound_above_44(ctx):
