@@ -458,9 +458,11 @@ __device__ __forceinline__ U128 mul128_limbs_s(const Limbs128& a, const U128& b)
 // per SIMD; behind calls with scalar arguments the round itself needs 40 and the kernel is what its callees and the
 // call ABI's callee-saved registers need: 74 at six wavefronts per SIMD without a spill, 64 at eight with ten spilled
 // registers stored and reloaded once per walker.  MEASURED (round 5): 143 us at five, at six and at eight wavefronts
-// per SIMD -- the pass is bound by the vector pipe's throughput (~100 vector instructions a round, ten of them
-// quarter rate), not by latency -- and the eight-wavefront form's per-walker spill is 84 MB of scratch traffic per
-// launch (PMC: 433 MB instead of 340).  Hence six.
+// per SIMD -- occupancy is not what binds the pass -- and the eight-wavefront form's per-walker spill is 84 MB of
+// scratch traffic per launch (PMC: 433 MB instead of 330).  Hence six.  What does bind it (same round): not the vector
+// instruction count either (the limb form below has a third fewer vector instructions per round: 143.7 us), hardly
+// the stores (without them 133 us); without the scalar resolution of missed candidates 107 us -- the round is a chain
+// of ballots and scalar role arithmetic (40-75 scalar instructions, a dozen branches) on the CU's one scalar unit.
 __device__ __attribute__((noinline)) bool itemgen_wedge_f64(double x, double u1, double f1, double f0) {
 #pragma clang fp contract(off)
   return (f1 - f0) * u1 + f0 < exp(-0.5 * x * x);
@@ -496,6 +498,47 @@ __device__ __attribute__((noinline)) ItemTail itemgen_tail(uint64_t shi, uint64_
   return o;
 }
 
+// The round's front on 32-bit limbs (round 5): a third fewer vector instructions per round than the 64-bit form --
+// measured, it buys nothing (143.7 us against 143.0: the vector pipe is not what binds the pass, see above); kept
+// because it is the shorter code path and frees the vector pipe for whatever shares the SIMD:
+//   * S_0 and d = S_1 - S_0 live in VGPRs with the same value in every lane: the products take them as vector
+//     operands, no v_readfirstlane at the head of a round, and the new S_0 / S_1 come from the lanes that hold them
+//     by ds_bpermute -- the LDS pipe, not eight v_readlane on the vector pipe -- and d by a four-instruction borrow chain;
+//   * state = S_0 + G d: the low 128 bits of the product as limbs (six v_mad_u64_u32 + the top limb's four products),
+//     added by a four-instruction carry chain instead of re-packed 64-bit halves and a carry compare;
+//   * XSL-RR's 64-bit rotate by two v_alignbit_b32 and two selects (the 64-bit shifts are not full rate), the 52
+//     random bits and the uniform's 53 likewise by funnel shifts.
+// The arithmetic is the same integers: the same streams, bit for bit.
+struct FrontOut {
+  uint32_t st[4];   // state at position lane + 1, little-endian limbs
+  uint32_t rlo, rhi;  // pcg_output(state)
+};
+__device__ __forceinline__ FrontOut itemgen_front(const Limbs128& G, const uint32_t (&S0v)[4], const uint32_t (&Dv)[4]) {
+  const uint32_t a0 = G.w[0], a1 = G.w[1], a2 = G.w[2], a3 = G.w[3];
+  const uint32_t b0 = Dv[0], b1 = Dv[1], b2 = Dv[2], b3 = Dv[3];
+  const uint64_t p00 = mad_u64_u32(a0, b0, 0ull);
+  const uint64_t t1 = mad_u64_u32(a0, b1, p00 >> 32);                     // < 2^64
+  const uint64_t t2 = mad_u64_u32(a1, b0, (uint64_t)(uint32_t)t1);
+  const uint64_t t3 = mad_u64_u32(a1, b1, (t1 >> 32) + (t2 >> 32));       // bits 64..127 of (a.lo * b.lo)
+  uint64_t t5 = mad_u64_u32(a0, b2, t3);                                  // (mod 2^64 from here on)
+  t5 = mad_u64_u32(a2, b0, t5);
+  uint32_t top = (uint32_t)(t5 >> 32) + a0 * b3 + a1 * b2 + a2 * b1 + a3 * b0;
+  const uint32_t l0 = (uint32_t)p00, l1 = (uint32_t)t2, l2 = (uint32_t)t5;
+  FrontOut o;
+  asm("v_add_co_u32 %0, vcc, %4, %8\n\tv_addc_co_u32 %1, vcc, %5, %9, vcc\n\tv_addc_co_u32 %2, vcc, %6, %10, vcc\n\t"
+      "v_addc_co_u32 %3, vcc, %7, %11, vcc"
+      : "=&v"(o.st[0]), "=&v"(o.st[1]), "=&v"(o.st[2]), "=&v"(o.st[3])
+      : "v"(l0), "v"(l1), "v"(l2), "v"(top), "v"(S0v[0]), "v"(S0v[1]), "v"(S0v[2]), "v"(S0v[3])
+      : "vcc");
+  // XSL-RR (pcg64.h): rotr64(hi ^ lo, hi >> 58)
+  const uint32_t xh = o.st[3] ^ o.st[1], xl = o.st[2] ^ o.st[0], rot = o.st[3] >> 26;
+  const uint32_t ra = __builtin_amdgcn_alignbit(xh, xl, rot), rb = __builtin_amdgcn_alignbit(xl, xh, rot);  // by rot mod 32
+  const bool sw = rot >= 32u;
+  o.rlo = sw ? rb : ra;
+  o.rhi = sw ? ra : rb;
+  return o;
+}
+
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) itemgen_kernel(ItemGenArgs a) {
 #pragma clang fp contract(off)
   __shared__ ZigQ zig;
@@ -519,12 +562,20 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))
   for (int w = blockIdx.x * 4 + wave; w < a.k; w += nwaves) {
     if (a.run_mode && a.run_mode[(a.wbase + w) / a.wpr] != a.my_mode) continue;
     const uint64_t* p = a.rng_in + (size_t)w * 4;
-    U128 S0 = {p[0], p[1]};
+    const U128 S00 = {p[0], p[1]};
     const U128 inc = {p[2], p[3]};
-    U128 D;
+    uint32_t S0v[4], Dv[4];  // the same value in every lane
     {
       const U128 mm1 = {DH_PCG_MULTM1_HI, DH_PCG_MULTM1_LO};
-      D = add128(mul128(S0, mm1), inc);  // S_1 - S_0
+      const U128 D0 = add128(mul128(S00, mm1), inc);  // S_1 - S_0
+      S0v[0] = (uint32_t)S00.lo;
+      S0v[1] = (uint32_t)(S00.lo >> 32);
+      S0v[2] = (uint32_t)S00.hi;
+      S0v[3] = (uint32_t)(S00.hi >> 32);
+      Dv[0] = (uint32_t)D0.lo;
+      Dv[1] = (uint32_t)(D0.lo >> 32);
+      Dv[2] = (uint32_t)D0.hi;
+      Dv[3] = (uint32_t)(D0.hi >> 32);
     }
     double* out = a.items + (size_t)w * T;
     uint32_t W = 0;
@@ -535,10 +586,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))
     uint64_t acc64 = 0;
     while ((int)W < T) {
       if (want64) {
-        U128 D2 = D;
-        asm volatile("" : "+v"(D2.lo), "+v"(D2.hi));  // (a front of its own: not to be merged with the round's)
-        const U128 st2 = add128(S0, mul128_limbs_s(Gl, D2));
-        const uint64_t r2 = pcg_output(st2);
+        uint32_t D2[4] = {Dv[0], Dv[1], Dv[2], Dv[3]};
+        asm volatile("" : "+v"(D2[0]), "+v"(D2[1]), "+v"(D2[2]), "+v"(D2[3]));  // (a front of its own: not to be merged with the round's)
+        const FrontOut f2 = itemgen_front(Gl, S0v, D2);
+        const uint64_t r2 = ((uint64_t)f2.rhi << 32) | f2.rlo;
         const int idx2 = (int)(r2 & 0xff);
         const uint64_t rabs2 = (r2 >> 9) & 0x000fffffffffffffull;
         const double rd2 = __longlong_as_double((long long)(rabs2 | 0x4330000000000000ull)) - 4503599627370496.0;
@@ -551,14 +602,16 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))
         const double f1 = __longlong_as_double((long long)a.zfi[ic - 1]), f0 = __longlong_as_double((long long)a.zfi[ic]);
         acc64 = __ballot(itemgen_wedge_f64(x2, u1, f1, f0));
       }
-      const U128 st = add128(S0, mul128_limbs_s(Gl, D));  // state at position lane + 1
-      const uint64_t r = pcg_output(st);
-      const int idx = (int)(r & 0xff);
-      const uint64_t rabs = (r >> 9) & 0x000fffffffffffffull;
-      const double rd = __longlong_as_double((long long)(rabs | 0x4330000000000000ull)) - 4503599627370496.0;
+      const FrontOut fr = itemgen_front(Gl, S0v, Dv);  // state at position lane + 1 and its output
+      const uint32_t rlo = fr.rlo, rhi = fr.rhi;
+      const int idx = (int)(rlo & 0xffu);
+      // rabs = (r >> 9) & (2^52 - 1), as halves
+      const uint32_t rabs_lo = __builtin_amdgcn_alignbit(rhi, rlo, 9), rabs_hi = (rhi >> 9) & 0xfffffu;
+      const uint64_t rabs = ((uint64_t)rabs_hi << 32) | rabs_lo;
+      const double rd = __longlong_as_double((long long)(((uint64_t)(rabs_hi | 0x43300000u) << 32) | rabs_lo)) - 4503599627370496.0;
       const ulonglong2 kw = z->kw[idx];
       double x = rd * __longlong_as_double((long long)kw.y);
-      x = __longlong_as_double(__double_as_longlong(x) ^ (long long)((r & 0x100ull) << 55));
+      x = __longlong_as_double(__double_as_longlong(x) ^ (long long)((uint64_t)((rlo << 23) & 0x80000000u) << 32));
       const uint64_t missmask = __ballot(!(rabs < kw.x)) & 0x7fffffffffffffffull;  // position 63 is never consumed
       const int c = (int)(W - (uint32_t)(((uint64_t)W * magic_n1) >> 32) * (uint32_t)n1);
       uint64_t umask = U0 << (n - c);
@@ -567,7 +620,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))
       uint64_t m = missmask & ~umask;
       if (m) {  // (the same resolution as wavegen_round's)
         const float2 ff = z->ff[idx];
-        const uint32_t nhi = (uint32_t)__shfl_down((int)(uint32_t)(r >> 40), 1);
+        const uint32_t nhi = (uint32_t)__shfl_down((int)(rhi >> 8), 1);  // (r >> 40) of the next position
         const float xf = (float)x;
         const float lhs = ff.x * ((float)nhi * 5.9604644775390625e-08f) + ff.y;
         const float ef = __expf(-0.5f * xf * xf);
@@ -611,35 +664,47 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))
         total = need;
         tailf = -1;
       }
-#ifdef DH_IG_NOSTORE
-      if (alive && off < total && (r == 0x1234567ull))
-#else
-      if (alive && off < total)
-#endif
-        out[W + off] = __builtin_amdgcn_inverse_ballot_w64(umask) ? __longlong_as_double((long long)(r >> 11)) : x;
+      if (alive && off < total) {
+        // a step's uniform travels as its 53 random bits (r >> 11)
+        const uint64_t ubits = ((uint64_t)(rhi >> 11) << 32) | __builtin_amdgcn_alignbit(rhi, rlo, 11);
+        out[W + off] = __builtin_amdgcn_inverse_ballot_w64(umask) ? __longlong_as_double((long long)ubits) : x;
+      }
       if (tailf >= 0) {
-        const ItemTail tl = itemgen_tail(rl64(st.hi, tailf), rl64(st.lo, tailf), inc.hi, inc.lo,
-                                         (uint32_t)((rl64(rabs, tailf) >> 8) & 1));
+        const uint64_t sthi = ((uint64_t)rl32(fr.st[3], tailf) << 32) | rl32(fr.st[2], tailf),
+                       stlo = ((uint64_t)rl32(fr.st[1], tailf) << 32) | rl32(fr.st[0], tailf);
+        const ItemTail tl = itemgen_tail(sthi, stlo, inc.hi, inc.lo, (rl32(rabs_lo, tailf) >> 8) & 1u);  // numpy: (rabs >> 8) & 1
         if (lane == 0) out[W + total] = tl.xf;
         ++total;
-        S0.hi = tl.s0hi;
-        S0.lo = tl.s0lo;
-        D.hi = tl.dhi;
-        D.lo = tl.dlo;
+        S0v[0] = (uint32_t)tl.s0lo;
+        S0v[1] = (uint32_t)(tl.s0lo >> 32);
+        S0v[2] = (uint32_t)tl.s0hi;
+        S0v[3] = (uint32_t)(tl.s0hi >> 32);
+        Dv[0] = (uint32_t)tl.dlo;
+        Dv[1] = (uint32_t)(tl.dlo >> 32);
+        Dv[2] = (uint32_t)tl.dhi;
+        Dv[3] = (uint32_t)(tl.dhi >> 32);
       } else {
-        U128 S1;
-        S0.hi = rl64(st.hi, endpos - 1);
-        S0.lo = rl64(st.lo, endpos - 1);
-        S1.hi = rl64(st.hi, endpos);
-        S1.lo = rl64(st.lo, endpos);
-        D = sub128(S1, S0);
+        // positions [0, endpos) are consumed (1 <= endpos <= 63): the states of lanes endpos - 1 and endpos are the
+        // walker's new S_0 and S_1, fetched by every lane through the LDS crossbar; d = S_1 - S_0 by a borrow chain
+        const int a0 = (endpos - 1) << 2, a1 = endpos << 2;
+        uint32_t S1v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          S0v[q] = (uint32_t)__builtin_amdgcn_ds_bpermute(a0, (int)fr.st[q]);
+          S1v[q] = (uint32_t)__builtin_amdgcn_ds_bpermute(a1, (int)fr.st[q]);
+        }
+        asm("v_sub_co_u32 %0, vcc, %4, %8\n\tv_subb_co_u32 %1, vcc, %5, %9, vcc\n\tv_subb_co_u32 %2, vcc, %6, %10, vcc\n\t"
+            "v_subb_co_u32 %3, vcc, %7, %11, vcc"
+            : "=&v"(Dv[0]), "=&v"(Dv[1]), "=&v"(Dv[2]), "=&v"(Dv[3])
+            : "v"(S1v[0]), "v"(S1v[1]), "v"(S1v[2]), "v"(S1v[3]), "v"(S0v[0]), "v"(S0v[1]), "v"(S0v[2]), "v"(S0v[3])
+            : "vcc");
       }
       W += (uint32_t)total;
     }
     if (lane == 0 && a.rng_out) {
       uint64_t* o = a.rng_out + (size_t)w * 4;
-      o[0] = S0.hi;
-      o[1] = S0.lo;
+      o[0] = ((uint64_t)S0v[3] << 32) | S0v[2];
+      o[1] = ((uint64_t)S0v[1] << 32) | S0v[0];
       o[2] = inc.hi;
       o[3] = inc.lo;
     }

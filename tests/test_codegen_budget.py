@@ -75,9 +75,9 @@ def test_rwalkq_kernel_keeps_two_wavefronts_per_simd():
     # The generator passes.  itemgen_kernel: its two rare paths (double-precision wedge
     # verdict, tail of the distribution) are calls; the round itself needs 40 registers, the kernel what the call ABI
     # needs: 74 at six wavefronts per SIMD with NO spill (pinned), or 64 at eight with a 40-byte spill per lane and
-    # walker.  Measured on the MI355X: 143 us at five (96 VGPRs, round 4), six and eight wavefronts per SIMD -- the pass
-    # is bound by the vector pipe's throughput (~100 VALU instructions a round, ten of them quarter rate), not by
-    # latency -- and the eight-wavefront form adds 84 MB of scratch traffic per launch.
+    # walker.  Measured on the MI355X: 143 us at five (96 VGPRs, round 4), six and eight wavefronts per SIMD -- occupancy
+    # does not bind the pass (nor does its vector instruction count: a third fewer, same time; the scalar role
+    # resolution does) -- and the eight-wavefront form adds 84 MB of scratch traffic per launch.
     key = [k for k in res if "14itemgen_kernel" in k]
     assert len(key) == 1, list(res)
     r = res[key[0]]
