@@ -459,10 +459,10 @@ __device__ __forceinline__ U128 mul128_limbs_s(const Limbs128& a, const U128& b)
 // call ABI's callee-saved registers need: 74 at six wavefronts per SIMD without a spill, 64 at eight with ten spilled
 // registers stored and reloaded once per walker.  MEASURED (round 5): 143 us at five, at six and at eight wavefronts
 // per SIMD -- occupancy is not what binds the pass -- and the eight-wavefront form's per-walker spill is 84 MB of
-// scratch traffic per launch (PMC: 433 MB instead of 330).  Hence six.  What does bind it (same round): not the vector
-// instruction count either (the limb form below has a third fewer vector instructions per round: 143.7 us), hardly
-// the stores (without them 133 us); without the scalar resolution of missed candidates 107 us -- the round is a chain
-// of ballots and scalar role arithmetic (40-75 scalar instructions, a dozen branches) on the CU's one scalar unit.
+// scratch traffic per launch (PMC: 433 MB instead of 330).  Hence six.  What does bind it (same round, EXPERIMENTS.md
+// R5.1): the in-order dependent chain of a round -- a third fewer vector instructions, half the scalar instructions of
+// the common round, the new state by v_readlane instead of ds_bpermute: each within 3 us of 140; every instruction
+// ADDED costs its issue time; without the resolution of missed candidates 107 us, without the stores 133 us.
 __device__ __attribute__((noinline)) bool itemgen_wedge_f64(double x, double u1, double f1, double f0) {
 #pragma clang fp contract(off)
   return (f1 - f0) * u1 + f0 < exp(-0.5 * x * x);
@@ -501,34 +501,42 @@ __device__ __attribute__((noinline)) ItemTail itemgen_tail(uint64_t shi, uint64_
 // The round's front on 32-bit limbs (round 5): a third fewer vector instructions per round than the 64-bit form --
 // measured, it buys nothing (143.7 us against 143.0: the vector pipe is not what binds the pass, see above); kept
 // because it is the shorter code path and frees the vector pipe for whatever shares the SIMD:
-//   * S_0 and d = S_1 - S_0 live in VGPRs with the same value in every lane: the products take them as vector
-//     operands, no v_readfirstlane at the head of a round, and the new S_0 / S_1 come from the lanes that hold them
-//     by ds_bpermute -- the LDS pipe, not eight v_readlane on the vector pipe -- and d by a four-instruction borrow chain;
+//   * S_0 and d = S_1 - S_0 are wave-uniform and live in SGPRs: the new S_0 / S_1 come from the lanes that hold them
+//     by eight v_readlane, d by a scalar borrow chain (s_sub / s_subb);
 //   * state = S_0 + G d: the low 128 bits of the product as limbs (six v_mad_u64_u32 + the top limb's four products),
 //     added by a four-instruction carry chain instead of re-packed 64-bit halves and a carry compare;
 //   * XSL-RR's 64-bit rotate by two v_alignbit_b32 and two selects (the 64-bit shifts are not full rate), the 52
 //     random bits and the uniform's 53 likewise by funnel shifts.
 // The arithmetic is the same integers: the same streams, bit for bit.
+__device__ __forceinline__ uint32_t sel_mask(uint64_t mask, uint32_t if_set, uint32_t if_clear) {  // per lane: mask bit ? if_set : if_clear
+  uint32_t r;
+  asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(if_clear), "v"(if_set), "s"(mask));
+  return r;
+}
+__device__ __forceinline__ uint32_t lo32(double x) { return (uint32_t)__double_as_longlong(x); }
+__device__ __forceinline__ uint32_t hi32(double x) { return (uint32_t)((uint64_t)__double_as_longlong(x) >> 32); }
 struct FrontOut {
   uint32_t st[4];   // state at position lane + 1, little-endian limbs
   uint32_t rlo, rhi;  // pcg_output(state)
 };
-__device__ __forceinline__ FrontOut itemgen_front(const Limbs128& G, const uint32_t (&S0v)[4], const uint32_t (&Dv)[4]) {
+// S0 and D are wave-uniform and live in SGPRs: the products take D's limbs as their (one) scalar operand, the carry
+// chain S0's lowest limb (its other three ride in VGPRs: v_addc reads vcc, and vcc + an SGPR are two constant-bus reads)
+__device__ __forceinline__ FrontOut itemgen_front(const Limbs128& G, const uint32_t (&S0)[4], const uint32_t (&D)[4]) {
   const uint32_t a0 = G.w[0], a1 = G.w[1], a2 = G.w[2], a3 = G.w[3];
-  const uint32_t b0 = Dv[0], b1 = Dv[1], b2 = Dv[2], b3 = Dv[3];
-  const uint64_t p00 = mad_u64_u32(a0, b0, 0ull);
-  const uint64_t t1 = mad_u64_u32(a0, b1, p00 >> 32);                     // < 2^64
-  const uint64_t t2 = mad_u64_u32(a1, b0, (uint64_t)(uint32_t)t1);
-  const uint64_t t3 = mad_u64_u32(a1, b1, (t1 >> 32) + (t2 >> 32));       // bits 64..127 of (a.lo * b.lo)
-  uint64_t t5 = mad_u64_u32(a0, b2, t3);                                  // (mod 2^64 from here on)
-  t5 = mad_u64_u32(a2, b0, t5);
+  const uint32_t b0 = sfirst(D[0]), b1 = sfirst(D[1]), b2 = sfirst(D[2]), b3 = sfirst(D[3]);  // (folded away: D is uniform)
+  const uint64_t p00 = mad_u64_u32_s(a0, b0, 0ull);
+  const uint64_t t1 = mad_u64_u32_s(a0, b1, p00 >> 32);                     // < 2^64
+  const uint64_t t2 = mad_u64_u32_s(a1, b0, (uint64_t)(uint32_t)t1);
+  const uint64_t t3 = mad_u64_u32_s(a1, b1, (t1 >> 32) + (t2 >> 32));       // bits 64..127 of (a.lo * b.lo)
+  uint64_t t5 = mad_u64_u32_s(a0, b2, t3);                                  // (mod 2^64 from here on)
+  t5 = mad_u64_u32_s(a2, b0, t5);
   uint32_t top = (uint32_t)(t5 >> 32) + a0 * b3 + a1 * b2 + a2 * b1 + a3 * b0;
   const uint32_t l0 = (uint32_t)p00, l1 = (uint32_t)t2, l2 = (uint32_t)t5;
   FrontOut o;
-  asm("v_add_co_u32 %0, vcc, %4, %8\n\tv_addc_co_u32 %1, vcc, %5, %9, vcc\n\tv_addc_co_u32 %2, vcc, %6, %10, vcc\n\t"
+  asm("v_add_co_u32 %0, vcc, %8, %4\n\tv_addc_co_u32 %1, vcc, %5, %9, vcc\n\tv_addc_co_u32 %2, vcc, %6, %10, vcc\n\t"
       "v_addc_co_u32 %3, vcc, %7, %11, vcc"
       : "=&v"(o.st[0]), "=&v"(o.st[1]), "=&v"(o.st[2]), "=&v"(o.st[3])
-      : "v"(l0), "v"(l1), "v"(l2), "v"(top), "v"(S0v[0]), "v"(S0v[1]), "v"(S0v[2]), "v"(S0v[3])
+      : "v"(l0), "v"(l1), "v"(l2), "v"(top), "s"(sfirst(S0[0])), "v"(S0[1]), "v"(S0[2]), "v"(S0[3])
       : "vcc");
   // XSL-RR (pcg64.h): rotr64(hi ^ lo, hi >> 58)
   const uint32_t xh = o.st[3] ^ o.st[1], xl = o.st[2] ^ o.st[0], rot = o.st[3] >> 26;
@@ -537,6 +545,17 @@ __device__ __forceinline__ FrontOut itemgen_front(const Limbs128& G, const uint3
   o.rlo = sw ? rb : ra;
   o.rhi = sw ? ra : rb;
   return o;
+}
+// d = S_1 - S_0 of two wave-uniform states (limbs): a scalar borrow chain
+__device__ __forceinline__ void sub128_limbs(const uint32_t (&A)[4], const uint32_t (&B)[4], uint32_t (&R)[4]) {
+  typedef unsigned __int128 u128;
+  const u128 a = ((u128)A[3] << 96) | ((u128)A[2] << 64) | ((u128)A[1] << 32) | A[0];
+  const u128 b = ((u128)B[3] << 96) | ((u128)B[2] << 64) | ((u128)B[1] << 32) | B[0];
+  const u128 r = a - b;
+  R[0] = (uint32_t)r;
+  R[1] = (uint32_t)(r >> 32);
+  R[2] = (uint32_t)(r >> 64);
+  R[3] = (uint32_t)(r >> 96);
 }
 
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) itemgen_kernel(ItemGenArgs a) {
@@ -564,60 +583,116 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))
     const uint64_t* p = a.rng_in + (size_t)w * 4;
     const U128 S00 = {p[0], p[1]};
     const U128 inc = {p[2], p[3]};
-    uint32_t S0v[4], Dv[4];  // the same value in every lane
+    uint32_t S0v[4], Dv[4];  // wave-uniform (SGPRs)
     {
       const U128 mm1 = {DH_PCG_MULTM1_HI, DH_PCG_MULTM1_LO};
       const U128 D0 = add128(mul128(S00, mm1), inc);  // S_1 - S_0
-      S0v[0] = (uint32_t)S00.lo;
-      S0v[1] = (uint32_t)(S00.lo >> 32);
-      S0v[2] = (uint32_t)S00.hi;
-      S0v[3] = (uint32_t)(S00.hi >> 32);
-      Dv[0] = (uint32_t)D0.lo;
-      Dv[1] = (uint32_t)(D0.lo >> 32);
-      Dv[2] = (uint32_t)D0.hi;
-      Dv[3] = (uint32_t)(D0.hi >> 32);
+      S0v[0] = sfirst((uint32_t)S00.lo);
+      S0v[1] = sfirst((uint32_t)(S00.lo >> 32));
+      S0v[2] = sfirst((uint32_t)S00.hi);
+      S0v[3] = sfirst((uint32_t)(S00.hi >> 32));
+      Dv[0] = sfirst((uint32_t)D0.lo);
+      Dv[1] = sfirst((uint32_t)(D0.lo >> 32));
+      Dv[2] = sfirst((uint32_t)D0.hi);
+      Dv[3] = sfirst((uint32_t)(D0.hi >> 32));
     }
     double* out = a.items + (size_t)w * T;
     uint32_t W = 0;
-    // A round whose single-precision wedge verdict is inside the band is run twice: the first pass only notes it
-    // (want64), the second starts with the double-precision verdicts -- formed from a front of their own, so that
-    // nothing but the walker's constants is live across the call -- and then takes the round as usual.
-    bool want64 = false;
+    // A round whose single-precision wedge verdict is inside the band is run twice: the first pass forms the
+    // double-precision verdicts -- from a front of their own, and then starts the round over, so that nothing but the
+    // walker's constants is live across the call --, the second (have64) takes them.  The flag is read and written
+    // inside that branch alone: the common path carries no test of it.
+    bool have64 = false;
     uint64_t acc64 = 0;
+    const int Tfast = T - 63;
     while ((int)W < T) {
-      if (want64) {
-        uint32_t D2[4] = {Dv[0], Dv[1], Dv[2], Dv[3]};
-        asm volatile("" : "+v"(D2[0]), "+v"(D2[1]), "+v"(D2[2]), "+v"(D2[3]));  // (a front of its own: not to be merged with the round's)
-        const FrontOut f2 = itemgen_front(Gl, S0v, D2);
-        const uint64_t r2 = ((uint64_t)f2.rhi << 32) | f2.rlo;
-        const int idx2 = (int)(r2 & 0xff);
-        const uint64_t rabs2 = (r2 >> 9) & 0x000fffffffffffffull;
-        const double rd2 = __longlong_as_double((long long)(rabs2 | 0x4330000000000000ull)) - 4503599627370496.0;
-        double x2 = rd2 * __longlong_as_double((long long)z->kw[idx2].y);
-        x2 = __longlong_as_double(__double_as_longlong(x2) ^ (long long)((r2 & 0x100ull) << 55));
-        const int ic = idx2 > 0 ? idx2 : 1;
-        const uint32_t nlo = (uint32_t)__shfl_down((int)(uint32_t)(r2 >> 11), 1),
-                       nh2 = (uint32_t)__shfl_down((int)(uint32_t)(r2 >> 43), 1);
-        const double u1 = (double)(((uint64_t)nh2 << 32) | nlo) * (1.0 / 9007199254740992.0);
-        const double f1 = __longlong_as_double((long long)a.zfi[ic - 1]), f0 = __longlong_as_double((long long)a.zfi[ic]);
-        acc64 = __ballot(itemgen_wedge_f64(x2, u1, f1, f0));
+      FrontOut fr;
+      uint32_t rlo, rhi, rabs_lo;
+      int idx;
+      double x;
+      uint64_t missmask, umask, m;
+      // The common round (about one in two) is a loop of its own: no candidate missed and the walker needs all 63
+      // positions -- lane p stores item W + p, the new S_0 / S_1 are the states of lanes 62 and 63; sixteen scalar
+      // instructions and four branches where the general resolution below costs thirty-three and ten (measured: 2 us
+      // of 140, EXPERIMENTS.md R5.1).  The first round that does not qualify leaves the loop with its front formed.
+      for (;;) {
+        fr = itemgen_front(Gl, S0v, Dv);  // state at position lane + 1 and its output
+#ifdef DH_IG_EXTRA  // marginal-cost probes: sixteen extra instructions of one kind per round (tools/r5_igslope.sh)
+        {
+          uint32_t e0 = fr.rlo, e1 = fr.rhi, e2 = fr.st[0], e3 = fr.st[1];
+          uint64_t w0 = ((uint64_t)e1 << 32) | e0, w1 = ((uint64_t)e3 << 32) | e2;
+#if DH_IG_EXTRA == 1
+          asm volatile("s_add_u32 s20, s20, 1\n\ts_add_u32 s21, s21, 1\n\ts_add_u32 s22, s22, 1\n\ts_add_u32 s23, s23, 1\n\t"
+                       "s_add_u32 s20, s20, 1\n\ts_add_u32 s21, s21, 1\n\ts_add_u32 s22, s22, 1\n\ts_add_u32 s23, s23, 1\n\t"
+                       "s_add_u32 s20, s20, 1\n\ts_add_u32 s21, s21, 1\n\ts_add_u32 s22, s22, 1\n\ts_add_u32 s23, s23, 1\n\t"
+                       "s_add_u32 s20, s20, 1\n\ts_add_u32 s21, s21, 1\n\ts_add_u32 s22, s22, 1\n\ts_add_u32 s23, s23, 1" ::: "s20", "s21", "s22", "s23", "scc");
+#elif DH_IG_EXTRA == 2
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            asm volatile("v_add_u32 %0, %0, %4\n\tv_add_u32 %1, %1, %4\n\tv_add_u32 %2, %2, %4\n\tv_add_u32 %3, %3, %4"
+                         : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3) : "v"(lane));
+#elif DH_IG_EXTRA == 3
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            asm volatile("v_mad_u64_u32 %0, vcc, %2, %2, %0\n\tv_mad_u64_u32 %1, vcc, %2, %2, %1" : "+v"(w0), "+v"(w1) : "v"(lane) : "vcc");
+#elif DH_IG_EXTRA == 4
+          int a62 = 62 << 2;
+          asm volatile("" : "+v"(a62));
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            asm volatile("ds_bpermute_b32 %0, %4, %0\n\tds_bpermute_b32 %1, %4, %1\n\tds_bpermute_b32 %2, %4, %2\n\tds_bpermute_b32 %3, %4, %3\n\ts_waitcnt lgkmcnt(0)"
+                         : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3) : "v"(a62));
+#elif DH_IG_EXTRA == 5
+          asm volatile("s_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\t"
+                       "s_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0");
+#elif DH_IG_EXTRA == 6
+          asm volatile("s_branch 0\n\ts_branch 0\n\ts_branch 0\n\ts_branch 0\n\ts_branch 0\n\ts_branch 0\n\ts_branch 0\n\ts_branch 0\n\t"
+                       "s_branch 0\n\ts_branch 0\n\ts_branch 0\n\ts_branch 0\n\ts_branch 0\n\ts_branch 0\n\ts_branch 0\n\ts_branch 0");
+#elif DH_IG_EXTRA == 7
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            asm volatile("v_readlane_b32 s20, %0, 5\n\tv_readlane_b32 s21, %1, 6\n\tv_readlane_b32 s22, %2, 7\n\tv_readlane_b32 s23, %3, 8"
+                         : : "v"(e0), "v"(e1), "v"(e2), "v"(e3) : "s20", "s21", "s22", "s23");
+#endif
+          asm volatile("" : : "v"(e0), "v"(e1), "v"(e2), "v"(e3), "v"(w0), "v"(w1));
+        }
+#endif
+        rlo = fr.rlo;
+        rhi = fr.rhi;
+        idx = (int)(rlo & 0xffu);
+        // rabs = (r >> 9) & (2^52 - 1), as halves
+        rabs_lo = __builtin_amdgcn_alignbit(rhi, rlo, 9);
+        const uint32_t rabs_hi = (rhi >> 9) & 0xfffffu;
+        const uint64_t rabs = ((uint64_t)rabs_hi << 32) | rabs_lo;
+        const double rd = __longlong_as_double((long long)(((uint64_t)(rabs_hi | 0x43300000u) << 32) | rabs_lo)) - 4503599627370496.0;
+        const ulonglong2 kw = z->kw[idx];
+        x = rd * __longlong_as_double((long long)kw.y);
+        x = __longlong_as_double(__double_as_longlong(x) ^ (long long)((uint64_t)((rlo << 23) & 0x80000000u) << 32));
+        missmask = __ballot(!(rabs < kw.x)) & 0x7fffffffffffffffull;  // position 63 is never consumed
+        const int c = (int)(W - (uint32_t)(((uint64_t)W * magic_n1) >> 32) * (uint32_t)n1);
+        umask = U0 << (n - c);
+        m = missmask & ~umask;
+        if (!((int)W < Tfast)) break;
+        asm volatile("" : "+s"(m));  // (two tests, two branches: merged, the compiler spends ten scalar instructions on them)
+        if (m != 0) break;
+        const uint32_t ulo = __builtin_amdgcn_alignbit(rhi, rlo, 11), uhi = rhi >> 11;  // the uniform's 53 bits (r >> 11)
+        const double* dst = out + (W + (uint32_t)lane);
+        // lanes 0..62 store: exec's top bit cleared around the store (every lane is active here)
+        asm volatile("s_bitset0_b32 exec_hi, 31\n\tglobal_store_dwordx2 %0, %1, off\n\ts_bitset1_b32 exec_hi, 31"
+                     :
+                     : "v"(dst), "v"(((uint64_t)sel_mask(umask, uhi, hi32(x)) << 32) | sel_mask(umask, ulo, lo32(x)))
+                     : "memory");
+        uint32_t S1v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          S0v[q] = rl32(fr.st[q], 62);
+          S1v[q] = rl32(fr.st[q], 63);
+        }
+        sub128_limbs(S1v, S0v, Dv);
+        W += 63u;
       }
-      const FrontOut fr = itemgen_front(Gl, S0v, Dv);  // state at position lane + 1 and its output
-      const uint32_t rlo = fr.rlo, rhi = fr.rhi;
-      const int idx = (int)(rlo & 0xffu);
-      // rabs = (r >> 9) & (2^52 - 1), as halves
-      const uint32_t rabs_lo = __builtin_amdgcn_alignbit(rhi, rlo, 9), rabs_hi = (rhi >> 9) & 0xfffffu;
-      const uint64_t rabs = ((uint64_t)rabs_hi << 32) | rabs_lo;
-      const double rd = __longlong_as_double((long long)(((uint64_t)(rabs_hi | 0x43300000u) << 32) | rabs_lo)) - 4503599627370496.0;
-      const ulonglong2 kw = z->kw[idx];
-      double x = rd * __longlong_as_double((long long)kw.y);
-      x = __longlong_as_double(__double_as_longlong(x) ^ (long long)((uint64_t)((rlo << 23) & 0x80000000u) << 32));
-      const uint64_t missmask = __ballot(!(rabs < kw.x)) & 0x7fffffffffffffffull;  // position 63 is never consumed
-      const int c = (int)(W - (uint32_t)(((uint64_t)W * magic_n1) >> 32) * (uint32_t)n1);
-      uint64_t umask = U0 << (n - c);
       uint64_t dead = 0;
       int endpos = 63, tailf = -1;
-      uint64_t m = missmask & ~umask;
       if (m) {  // (the same resolution as wavegen_round's)
         const float2 ff = z->ff[idx];
         const uint32_t nhi = (uint32_t)__shfl_down((int)(rhi >> 8), 1);  // (r >> 40) of the next position
@@ -627,13 +702,28 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))
         uint64_t accmask = __ballot(lhs < ef);
         const uint64_t zeromask = __ballot(idx == 0);
         if (__ballot(fabsf(lhs - ef) <= 1e-5f) & m) {
-          if (!want64) {
-            want64 = true;
+          if (!have64) {
+            uint32_t D2[4] = {Dv[0], Dv[1], Dv[2], Dv[3]};
+            asm volatile("" : "+v"(D2[0]), "+v"(D2[1]), "+v"(D2[2]), "+v"(D2[3]));  // (a front of its own: not to be merged with the round's)
+            const FrontOut f2 = itemgen_front(Gl, S0v, D2);
+            const uint64_t r2 = ((uint64_t)f2.rhi << 32) | f2.rlo;
+            const int idx2 = (int)(r2 & 0xff);
+            const uint64_t rabs2 = (r2 >> 9) & 0x000fffffffffffffull;
+            const double rd2 = __longlong_as_double((long long)(rabs2 | 0x4330000000000000ull)) - 4503599627370496.0;
+            double x2 = rd2 * __longlong_as_double((long long)z->kw[idx2].y);
+            x2 = __longlong_as_double(__double_as_longlong(x2) ^ (long long)((r2 & 0x100ull) << 55));
+            const int ic = idx2 > 0 ? idx2 : 1;
+            const uint32_t nlo = (uint32_t)__shfl_down((int)(uint32_t)(r2 >> 11), 1),
+                           nh2 = (uint32_t)__shfl_down((int)(uint32_t)(r2 >> 43), 1);
+            const double u1 = (double)(((uint64_t)nh2 << 32) | nlo) * (1.0 / 9007199254740992.0);
+            const double f1 = __longlong_as_double((long long)a.zfi[ic - 1]), f0 = __longlong_as_double((long long)a.zfi[ic]);
+            acc64 = __ballot(itemgen_wedge_f64(x2, u1, f1, f0));
+            have64 = true;
             continue;
           }
           accmask = acc64;
+          have64 = false;
         }
-        want64 = false;
         do {
           const int f = (int)__ffsll((long long)m) - 1;
           if ((zeromask >> f) & 1ull) {
@@ -675,29 +765,24 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))
         const ItemTail tl = itemgen_tail(sthi, stlo, inc.hi, inc.lo, (rl32(rabs_lo, tailf) >> 8) & 1u);  // numpy: (rabs >> 8) & 1
         if (lane == 0) out[W + total] = tl.xf;
         ++total;
-        S0v[0] = (uint32_t)tl.s0lo;
-        S0v[1] = (uint32_t)(tl.s0lo >> 32);
-        S0v[2] = (uint32_t)tl.s0hi;
-        S0v[3] = (uint32_t)(tl.s0hi >> 32);
-        Dv[0] = (uint32_t)tl.dlo;
-        Dv[1] = (uint32_t)(tl.dlo >> 32);
-        Dv[2] = (uint32_t)tl.dhi;
-        Dv[3] = (uint32_t)(tl.dhi >> 32);
+        S0v[0] = sfirst((uint32_t)tl.s0lo);
+        S0v[1] = sfirst((uint32_t)(tl.s0lo >> 32));
+        S0v[2] = sfirst((uint32_t)tl.s0hi);
+        S0v[3] = sfirst((uint32_t)(tl.s0hi >> 32));
+        Dv[0] = sfirst((uint32_t)tl.dlo);
+        Dv[1] = sfirst((uint32_t)(tl.dlo >> 32));
+        Dv[2] = sfirst((uint32_t)tl.dhi);
+        Dv[3] = sfirst((uint32_t)(tl.dhi >> 32));
       } else {
         // positions [0, endpos) are consumed (1 <= endpos <= 63): the states of lanes endpos - 1 and endpos are the
-        // walker's new S_0 and S_1, fetched by every lane through the LDS crossbar; d = S_1 - S_0 by a borrow chain
-        const int a0 = (endpos - 1) << 2, a1 = endpos << 2;
+        // walker's new S_0 and S_1 (v_readlane: an SGPR each); d = S_1 - S_0 by a scalar borrow chain
         uint32_t S1v[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          S0v[q] = (uint32_t)__builtin_amdgcn_ds_bpermute(a0, (int)fr.st[q]);
-          S1v[q] = (uint32_t)__builtin_amdgcn_ds_bpermute(a1, (int)fr.st[q]);
+          S0v[q] = rl32(fr.st[q], endpos - 1);
+          S1v[q] = rl32(fr.st[q], endpos);
         }
-        asm("v_sub_co_u32 %0, vcc, %4, %8\n\tv_subb_co_u32 %1, vcc, %5, %9, vcc\n\tv_subb_co_u32 %2, vcc, %6, %10, vcc\n\t"
-            "v_subb_co_u32 %3, vcc, %7, %11, vcc"
-            : "=&v"(Dv[0]), "=&v"(Dv[1]), "=&v"(Dv[2]), "=&v"(Dv[3])
-            : "v"(S1v[0]), "v"(S1v[1]), "v"(S1v[2]), "v"(S1v[3]), "v"(S0v[0]), "v"(S0v[1]), "v"(S0v[2]), "v"(S0v[3])
-            : "vcc");
+        sub128_limbs(S1v, S0v, Dv);
       }
       W += (uint32_t)total;
     }
@@ -1330,9 +1415,22 @@ int rwalkq_launch(dh_ctx* ctx, const ProblemDev& prob, int k, int ndim, const do
       g.wpr = wpr;
       g.my_mode = my_mode;
       g.wbase = (int)first;
-      // one wavefront per walker up to eight wavefronts per SIMD; beyond that the wavefronts loop
+      // one wavefront per walker up to the grid that is RESIDENT AT ONCE (the occupancy query's blocks per CU: six
+      // at 74 registers); beyond that the wavefronts loop.  A grid of 8 blocks per CU (rounds 3-5a) ran a second
+      // generation of blocks on a third of the wavefront slots: the same walkers per wavefront, a quarter of them at
+      // a third of the occupancy (EXPERIMENTS.md R5.1)
       int gblocks = (kc + 3) / 4;
-      const int gmax = ctx->num_cu * 8;
+      static int per_cu = 0;
+      if (per_cu == 0) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, itemgen_kernel, 256, 0) != hipSuccess || nb < 1) nb = 6;
+        if (const char* e = getenv("DH_ITEMGEN_BLOCKS_PER_CU")) {
+          const int v = atoi(e);
+          if (v >= 1 && v <= 16) nb = v;
+        }
+        per_cu = nb;
+      }
+      const int gmax = ctx->num_cu * per_cu;
       if (gblocks > gmax) gblocks = gmax;
       hipLaunchKernelGGL(itemgen_kernel, dim3(gblocks), block, 0, ctx->stream, g);
       a.items = ctx->items;
