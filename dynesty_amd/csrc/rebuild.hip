@@ -167,10 +167,52 @@ struct Lds {
   bool coh;
 };
 
+// ---- lane exchanges inside a row of 16 on the vector pipe ---------------------------------------------------------
+// __shfl_xor compiles to ds_bpermute_b32 (two per double, an LDS round trip of ~130 cycles each, and every reduction
+// step waits for the one before).  For the partner masks 1, 2, 4 and 8 the same exchange is a DPP move: quad_perm for
+// 1 and 2, row_shl:4 / row_shr:4 under complementary bank masks for 4, row_ror:8 for 8.  Same partner, same operands:
+// the same bits as the shuffle.  (16 and 32 cross rows: they stay on ds_bpermute.)
+template <int CTRL, int BANK>
+__device__ __forceinline__ int dpp_mov_i32(int old, int v) {
+  return __builtin_amdgcn_update_dpp(old, v, CTRL, 0xF, BANK, false);
+}
+template <int S>
+__device__ __forceinline__ int xor_lane_i32(int v) {
+  static_assert(S == 1 || S == 2 || S == 4 || S == 8, "in-row partner masks only");
+  if constexpr (S == 1) return dpp_mov_i32<0xB1, 0xF>(v, v);  // quad_perm:[1,0,3,2]
+  if constexpr (S == 2) return dpp_mov_i32<0x4E, 0xF>(v, v);  // quad_perm:[2,3,0,1]
+  if constexpr (S == 4) return dpp_mov_i32<0x114, 0xA>(dpp_mov_i32<0x104, 0x5>(v, v), v);  // lanes 0-3 / 8-11 read +4, 4-7 / 12-15 read -4
+  return dpp_mov_i32<0x128, 0xF>(v, v);  // row_ror:8
+}
+template <int S>
+__device__ __forceinline__ double xor_lane(double v) {
+  const long long b = __double_as_longlong(v);
+  const unsigned lo = (unsigned)xor_lane_i32<S>((int)(unsigned)b), hi = (unsigned)xor_lane_i32<S>((int)(unsigned)((unsigned long long)b >> 32));
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ __forceinline__ double wave_sum(double v) {  // the butterfly of `for (s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s)`
+  v += __shfl_xor(v, 32);
+  v += __shfl_xor(v, 16);
+  v += xor_lane<8>(v);
+  v += xor_lane<4>(v);
+  v += xor_lane<2>(v);
+  v += xor_lane<1>(v);
+  return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+  v = fmax(v, __shfl_xor(v, 32));
+  v = fmax(v, __shfl_xor(v, 16));
+  v = fmax(v, xor_lane<8>(v));
+  v = fmax(v, xor_lane<4>(v));
+  v = fmax(v, xor_lane<2>(v));
+  v = fmax(v, xor_lane<1>(v));
+  return v;
+}
+
 // block reductions: wave shuffles, then one LDS exchange across the 4 waves
 template <int NT = kThreads>
 __device__ __forceinline__ double block_reduce_max(double v, double* red) {
-  for (int s = 32; s > 0; s >>= 1) v = fmax(v, __shfl_xor(v, s));
+  v = wave_max(v);
   const int t = threadIdx.x;
   __syncthreads();  // red may still be read by a previous user
   if ((t & 63) == 0) red[t >> 6] = v;
@@ -295,10 +337,8 @@ __device__ bool jacobi_block(const Lds& L, int D) {
           off = fma(x00, x00, fma(x01, x01, fma(x10, x10, fma(x11, x11, off))));
         }
       }
-    for (int sh = 32; sh > 0; sh >>= 1) {
-      off += __shfl_xor(off, sh);
-      dia += __shfl_xor(dia, sh);
-    }
+    off = wave_sum(off);
+    dia = wave_sum(dia);
     if ((t & 63) == 0) {
       L.red[t >> 6] = off;
       L.red[8 + (t >> 6)] = dia;
@@ -668,10 +708,10 @@ __device__ __forceinline__ double tile_quadform_max(const Lds& L, const double* 
       double sacc = (pv && lj < D) ? z0[r] * x[0] : 0.0;
       if (nb > 1 && pv && 16 + lj < D) sacc = fma(z1[r], x[16], sacc);
       if (nb > 2 && pv && 32 + lj < D) sacc = fma(z2[r], x[32], sacc);
-      sacc += __shfl_xor(sacc, 1);
-      sacc += __shfl_xor(sacc, 2);
-      sacc += __shfl_xor(sacc, 4);
-      sacc += __shfl_xor(sacc, 8);
+      sacc += xor_lane<1>(sacc);
+      sacc += xor_lane<2>(sacc);
+      sacc += xor_lane<4>(sacc);
+      sacc += xor_lane<8>(sacc);
       if (pv) best = fmax(best, sacc);
     }
   }
@@ -842,9 +882,7 @@ constexpr int kFastSquarings = 48;
 // trace of a D x D LDS matrix, computed redundantly by every wave (D <= 44 < 64)
 __device__ __forceinline__ double wave_trace(const double* M, int D, int LD) {
   const int lane = threadIdx.x & 63;
-  double v = lane < D ? M[lane * LD + lane] : 0.0;
-  for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s);
-  return v;
+  return wave_sum(lane < D ? M[lane * LD + lane] : 0.0);
 }
 
 // Q = s2 * P P for the symmetric D x D matrix P (LDS, D x LD); all threads; caller barriers
@@ -962,8 +1000,7 @@ __device__ __forceinline__ bool spd_fast(const Lds& L, const double* cov, int D,
   double ld;
   {
     const int lane = t & 63;  // every wave for itself (D <= 44 < 64)
-    ld = lane < D ? log(pivs[lane]) : 0.0;
-    for (int sft = 32; sft > 0; sft >>= 1) ld += __shfl_xor(ld, sft);
+    ld = wave_sum(lane < D ? log(pivs[lane]) : 0.0);
   }
   // AM = -(result), symmetrised (the two triangles differ by rounding); result in L.A, AM elsewhere
   if (j < D)
@@ -1022,27 +1059,34 @@ __device__ __forceinline__ bool spd_fast(const Lds& L, const double* cov, int D,
   if (t < 64) {
     double best = t < D ? P[t * LD + t] : -1.0;
     int bi = t < D ? t : 0;
-    for (int sft = 32; sft > 0; sft >>= 1) {
-      const double ob = __shfl_xor(best, sft);
-      const int oi = __shfl_xor(bi, sft);
+    auto take_max = [&](double ob, int oi) {  // larger value, lower index on ties
       if (ob > best || (ob == best && oi < bi)) {
         best = ob;
         bi = oi;
       }
-    }
+    };
+    take_max(__shfl_xor(best, 32), __shfl_xor(bi, 32));
+    take_max(__shfl_xor(best, 16), __shfl_xor(bi, 16));
+    take_max(xor_lane<8>(best), xor_lane_i32<8>(bi));
+    take_max(xor_lane<4>(best), xor_lane_i32<4>(bi));
+    take_max(xor_lane<2>(best), xor_lane_i32<2>(bi));
+    take_max(xor_lane<1>(best), xor_lane_i32<1>(bi));
     const double x = t < D ? P[t * LD + bi] : 0.0;
-    double nn = x * x;
-    for (int sft = 32; sft > 0; sft >>= 1) nn += __shfl_xor(nn, sft);
+    const double nn = wave_sum(x * x);
     double ax = fabs(x);
     int ai = t;
-    for (int sft = 32; sft > 0; sft >>= 1) {
-      const double oa = __shfl_xor(ax, sft);
-      const int oi = __shfl_xor(ai, sft);
+    auto take_abs = [&](double oa, int oi) {
       if (oa > ax || (oa == ax && oi < ai)) {
         ax = oa;
         ai = oi;
       }
-    }
+    };
+    take_abs(__shfl_xor(ax, 32), __shfl_xor(ai, 32));
+    take_abs(__shfl_xor(ax, 16), __shfl_xor(ai, 16));
+    take_abs(xor_lane<8>(ax), xor_lane_i32<8>(ai));
+    take_abs(xor_lane<4>(ax), xor_lane_i32<4>(ai));
+    take_abs(xor_lane<2>(ax), xor_lane_i32<2>(ai));
+    take_abs(xor_lane<1>(ax), xor_lane_i32<1>(ai));
     const double xs = __shfl(x, ai);
     const double v = x * (xs < 0.0 ? -1.0 : 1.0) / sqrt(nn);
     if (t < D) s_v[t] = v;
@@ -1053,8 +1097,7 @@ __device__ __forceinline__ bool spd_fast(const Lds& L, const double* cov, int D,
     double y = 0.0;
     if (t < D)
       for (int k = 0; k < D; ++k) y = fma(cov[t * LD + k], s_v[k], y);
-    double q = t < D ? y * s_v[t] : 0.0;
-    for (int sft = 32; sft > 0; sft >>= 1) q += __shfl_xor(q, sft);
+    const double q = wave_sum(t < D ? y * s_v[t] : 0.0);
     if (t < D) L.AX[t * LD] = s_v[t] * sqrt(q);
     if (t == 0) L.lam[0] = q;
   }
