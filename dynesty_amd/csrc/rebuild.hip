@@ -439,7 +439,12 @@ __device__ __forceinline__ void st_ci(const Lds& L, int* p, int v) {
 }
 
 constexpr int kStageBatch = 8;
-template <int NT = kThreads>
+// SB rows of a thread are fetched together: their index loads, then their point loads, in flight at once -- two
+// global round trips per SB * NT / DP points.  Measured in round 5 for k_ell's ellipsoid passes: SB = 16 / 32 (fewer
+// round trips) spill 24 / 99 registers of a kernel that sits at 248, and IDX_LDS (the tile's indices fetched together
+// and served from LDS: one round trip per batch) costs 15 spilled registers and a barrier per tile -- 1.325 ms per
+// 64-run sequence against 1.296 without.  Both stay available, neither is used.
+template <int NT = kThreads, int SB = kStageBatch, bool IDX_LDS = false>
 __device__ __forceinline__ void stage_tile(const Lds& L, const double* __restrict__ pts,
                                            const int* __restrict__ perm, int start, int cnt, int D,
                                            int how) {
@@ -459,21 +464,28 @@ __device__ __forceinline__ void stage_tile(const Lds& L, const double* __restric
       return;
     }
   }
+  // IDX_LDS: the tile's indices are fetched first, all together (one coalesced load a thread), and served from LDS
+  // (L.ri[0, cnt), cnt <= 256): a batch of rows then waits for ONE global round trip, its points, instead of two
+  const bool idx_lds = IDX_LDS && L.ri != nullptr && cnt <= 256;
+  if (idx_lds) {
+    for (int p = threadIdx.x; p < cnt; p += NT) L.ri[p] = ld_ci(L, perm + start + p);
+    __syncthreads();
+  }
   if (j < D) {
     const double mj = how == 1 ? L.mean[j] : 0.0;
     const double sj = how == 2 ? L.scale[j] : 1.0;
-    for (int pb = p0; pb < cnt; pb += kStageBatch * pstep) {
-      int idx[kStageBatch];
-      double x[kStageBatch];
+    for (int pb = p0; pb < cnt; pb += SB * pstep) {
+      int idx[SB];
+      double x[SB];
 #pragma unroll
-      for (int k = 0; k < kStageBatch; ++k) {
+      for (int k = 0; k < SB; ++k) {
         const int p = pb + k * pstep;
-        idx[k] = p < cnt ? ld_ci(L, perm + start + p) : -1;
+        idx[k] = p < cnt ? (idx_lds ? L.ri[p] : ld_ci(L, perm + start + p)) : -1;
       }
 #pragma unroll
-      for (int k = 0; k < kStageBatch; ++k) x[k] = idx[k] >= 0 ? pts[(size_t)idx[k] * D + j] : 0.0;
+      for (int k = 0; k < SB; ++k) x[k] = idx[k] >= 0 ? pts[(size_t)idx[k] * D + j] : 0.0;
 #pragma unroll
-      for (int k = 0; k < kStageBatch; ++k) {
+      for (int k = 0; k < SB; ++k) {
         const int p = pb + k * pstep;
         if (p < cnt) {
           double v = x[k];
@@ -674,8 +686,100 @@ __device__ __forceinline__ void node_cov(const Lds& L, const double* pts, const 
 // Z = X AM on the matrix cores (M = 16 points per block, N = dimension blocks, K = D in
 // steps of 4), then the row-wise dot Z.x and a 16-lane reduction.  Returns the per-thread
 // running maximum (callers reduce over the block).
+//
+// Round 5: the B operand (AM's fragments) is the same for every block of points, so a lane holds its fragments in
+// registers for the whole node (QuadB: up to 11 K steps x 3 dimension blocks) instead of re-reading them from LDS at
+// every step; a block's A operands (its K steps of x) are fetched together, one LDS round trip; and a wavefront keeps
+// TWO blocks of 16 points in flight -- four to six independent accumulation chains on the matrix pipe where one
+// block's two were each waiting for their own previous step.  Per accumulator the K steps still run in ascending
+// order: the same bits.
+// Register shape: NB dimension blocks of 16, at most KS K steps of 4.  Built for <2, 8> (17 <= D <= 32): the other
+// shapes keep the general form below -- three copies of this loop at k_ell's every call site cost more in spills
+// than they gave.
+#ifndef DH_QUAD_TWO
+#define DH_QUAD_TWO false
+#endif
+template <int NB, int KS>
+struct QuadB {
+  double b[KS][NB];
+};
+template <int NB, int KS>
+__device__ __forceinline__ void quad_load_b(const double* AM, int D, int LD, QuadB<NB, KS>& B) {
+  const int lane = threadIdx.x & 63, lj = lane & 15, lk = lane >> 4;
+  const int ksteps = (D + 3) >> 2;
+  const double* brow = AM + lk * LD + lj;
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const bool kv = ks < ksteps && ks * 4 + lk < D;
+#pragma unroll
+    for (int n = 0; n < NB; ++n) B.b[ks][n] = (kv && 16 * n + lj < D) ? brow[ks * 4 * LD + 16 * n] : 0.0;
+  }
+}
+// one block of 16 points after its products: row-wise dot with x, 16-lane sums, running maximum
+template <int NB>
+__device__ __forceinline__ double quad_block_max(const double* tile, int LD, int p0, int cnt, int D, const mfma_acc (&z)[NB], double best) {
+  const int lane = threadIdx.x & 63, lj = lane & 15, lk = lane >> 4;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int p = p0 + lk + 4 * r;
+    const bool pv = p < cnt;
+    const double* x = tile + p * LD + lj;
+    double sacc = (pv && lj < D) ? z[0][r] * x[0] : 0.0;
+    if constexpr (NB > 1)
+      if (pv && 16 + lj < D) sacc = fma(z[1][r], x[16], sacc);
+    if constexpr (NB > 2)
+      if (pv && 32 + lj < D) sacc = fma(z[2][r], x[32], sacc);
+    sacc += xor_lane<1>(sacc);
+    sacc += xor_lane<2>(sacc);
+    sacc += xor_lane<4>(sacc);
+    sacc += xor_lane<8>(sacc);
+    if (pv) best = fmax(best, sacc);
+  }
+  return best;
+}
+template <int NT, int NB, int KS>
+__device__ __forceinline__ double tile_quadform_max(const double* tile, int LD, const QuadB<NB, KS>& B, int cnt, int D, double best) {
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int ksteps = (D + 3) >> 2;
+  const int lj = lane & 15, lk = lane >> 4;
+  constexpr int NW = NT / 64;
+  constexpr bool TWO = DH_QUAD_TWO;
+  for (int mb = w; mb * 16 < cnt; mb += (TWO ? 2 : 1) * NW) {
+    const int pA = mb * 16, pB = (mb + NW) * 16;
+    const bool hasB = TWO && pB < cnt;  // (uniform per wavefront)
+    const bool va = pA + lj < cnt, vb = hasB && pB + lj < cnt;
+    const double* xa = tile + (pA + lj) * LD + lk;
+    const double* xb = tile + (pB + lj) * LD + lk;
+    double aA[KS], aB[TWO ? KS : 1];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const bool kv = ks < ksteps && ks * 4 + lk < D;
+      aA[ks] = (va && kv) ? xa[ks * 4] : 0.0;
+      if constexpr (TWO) aB[ks] = (vb && kv) ? xb[ks * 4] : 0.0;
+    }
+    mfma_acc zA[NB], zB[NB];
+#pragma unroll
+    for (int n = 0; n < NB; ++n) zA[n] = zB[n] = (mfma_acc){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      if (ks < ksteps) {
+#pragma unroll
+        for (int n = 0; n < NB; ++n) {
+          zA[n] = DH_MFMA_F64(aA[ks], B.b[ks][n], zA[n]);
+          if constexpr (TWO)
+            if (hasB) zB[n] = DH_MFMA_F64(aB[ks], B.b[ks][n], zB[n]);
+        }
+      }
+    }
+    best = quad_block_max<NB>(tile, LD, pA, cnt, D, zA, best);
+    if constexpr (TWO)
+      if (hasB) best = quad_block_max<NB>(tile, LD, pB, cnt, D, zB, best);
+  }
+  return best;
+}
+// the general form (any D >= kMfmaMinDim): both operands from LDS at every K step, one block of points at a time
 template <int NT = kThreads>
-__device__ __forceinline__ double tile_quadform_max(const Lds& L, const double* AM, int cnt, int D, double best) {
+__device__ __forceinline__ double tile_quadform_max_lds(const Lds& L, const double* AM, int cnt, int D, double best) {
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, LD = L.LD;
   const int nb = (D + 15) >> 4, ksteps = (D + 3) >> 2;
   const int lj = lane & 15, lk = lane >> 4;
@@ -717,13 +821,25 @@ __device__ __forceinline__ double tile_quadform_max(const Lds& L, const double* 
   }
   return best;
 }
+// the quadratic-form maximum of the staged tile (D >= kMfmaMinDim): the register form where it is built (256-thread
+// workgroups, 17 <= D <= 32), the general form otherwise -- per point the same operations in the same order
+template <int NT = kThreads>
+__device__ __forceinline__ double tile_quadform_max(const Lds& L, const double* AM, int cnt, int D, double best) {
+  if (NT == kThreads && D > 16 && D <= 32) {
+    QuadB<2, 8> B;
+    quad_load_b<2, 8>(AM, D, L.LD, B);
+    return tile_quadform_max<NT, 2, 8>(L.tile, L.LD, B, cnt, D, best);
+  }
+  return tile_quadform_max_lds<NT>(L, AM, cnt, D, best);
+}
 
-// max_i delta_i^T AM delta_i over a node (bounding.py:1438), delta about L.mean
+// max_i delta_i^T AM delta_i over a node (bounding.py:1438), delta about L.mean.  Tiles are taken last to first: the
+// covariance pass before left its last tile staged (a maximum does not care about the order)
 template <int NT = kThreads>
 __device__ __forceinline__ double node_fmax(const Lds& L, const double* pts, const int* perm, int start, int count, int D) {
   double best = -INFINITY;
   PH_T0();
-  for (int base = 0; base < count; base += L.TP) {
+  for (int base = ((count - 1) / L.TP) * L.TP; base >= 0; base -= L.TP) {
     const int cnt = min(L.TP, count - base);
     stage_tile<NT>(L, pts, perm, start + base, cnt, D, 1);
     PH_ADD(5);
