@@ -1059,8 +1059,13 @@ __device__ __forceinline__ bool spd_fast(const Lds& L, const double* cov, int D,
   const int t = threadIdx.x, LD = L.LD;
   const int jsh = D <= 32 ? 5 : 6;
   const int j = t & ((1 << jsh) - 1), i0 = t >> jsh, istep = NT >> jsh;
-  double* src = (D & 1) ? L.AM : L.A;  // D sweeps later the result sits in L.A
-  double* dst = (D & 1) ? L.A : L.AM;
+  // Two sweeps per barrier (round 5): sweep k + 1 needs, of the matrix sweep k produces, row k + 1, column k + 1 and
+  // the entry itself -- each of them one fma of entries of the matrix sweep k READS, so a thread forms them on its own
+  // (the very expressions sweep k would have stored) and applies both sweeps to its entries before anyone has to
+  // wait: ceil(D / 2) barriers and LDS round-trip chains instead of D, bit for bit the same inverse.
+  const int nswap = (D + 1) >> 1;
+  double* src = (nswap & 1) ? L.AM : L.A;  // nswap buffer changes later the result sits in L.A
+  double* dst = (nswap & 1) ? L.A : L.AM;
   double* pivs = L.red;  // the D pivots
   PH_T0();
   bool bad = false;
@@ -1073,36 +1078,54 @@ __device__ __forceinline__ bool spd_fast(const Lds& L, const double* cov, int D,
   if (__syncthreads_or(bad ? 1 : 0)) return false;
   const double tr_cov = wave_trace(src, D, LD);
   bool ok = true;
-  for (int k = 0; k < D; ++k) {
+  int k = 0;
+  for (; k + 1 < D; k += 2) {
+    const int k1 = k + 1;
     const double piv = src[k * LD + k];
+    const double a01 = src[k * LD + k1], a10 = src[k1 * LD + k], a11 = src[k1 * LD + k1];
     if (!(piv > 0.0) || !isfinite(piv)) {
-      ok = false;  // uniform: every thread reads the same word
+      ok = false;  // uniform: every thread reads the same words
       break;
     }
     const double rp = rcp_nr(piv);
-    if (t == 0) pivs[k] = piv;
+    const double c01r = a01 * rp;                  // sweep k: (row k, column k + 1)
+    const double piv1 = fma(-a10, c01r, a11);      // sweep k: (k + 1, k + 1) = the next pivot
+    if (!(piv1 > 0.0) || !isfinite(piv1)) {
+      ok = false;
+      break;
+    }
+    const double rp1 = rcp_nr(piv1);
+    if (t == 0) {
+      pivs[k] = piv;
+      pivs[k1] = piv1;
+    }
     if (j < D) {
-      const double cj = src[k * LD + j];
+      const double cj = src[k * LD + j], dj = src[k1 * LD + j];
       const double cjr = cj * rp;
-      // four rows per batch: all eight LDS reads in flight before the first use, selects instead of branches (the
-      // plain loop compiled to one read -> wait -> branch chain per row: two LDS round trips per row, 1 900 cycles
-      // per sweep); the arithmetic per element is unchanged.  (Hoisting the reads above the pivot test as well, with
-      // the test only accumulated, was slower.)
+      const double r1j = (j == k) ? a10 * rp : fma(-a10, cjr, dj);  // sweep k: (row k + 1, column j)
+      const double cjr1 = r1j * rp1;
       for (int ib = i0; ib < D; ib += 4 * istep) {
-        double ci[4], w[4];
+        double ci[4], ei[4], w[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const int i = ib + u * istep;
           const int ic = i < D ? i : k;
           ci[u] = src[ic * LD + k];
+          ei[u] = src[ic * LD + k1];
           w[u] = src[ic * LD + j];
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const int i = ib + u * istep;
-          double val = fma(-ci[u], cjr, w[u]);
-          val = (j == k) ? ci[u] * rp : val;
-          val = (i == k) ? ((j == k) ? -rp : cjr) : val;
+          // sweep k at (i, j) and at (i, k + 1)
+          double v = fma(-ci[u], cjr, w[u]);
+          v = (j == k) ? ci[u] * rp : v;
+          v = (i == k) ? ((j == k) ? -rp : cjr) : v;
+          const double e1 = (i == k) ? c01r : fma(-ci[u], c01r, ei[u]);
+          // sweep k + 1 at (i, j)
+          double val = fma(-e1, cjr1, v);
+          val = (j == k1) ? e1 * rp1 : val;
+          val = (i == k1) ? ((j == k1) ? -rp1 : cjr1) : val;
           if (i < D) dst[i * LD + j] = val;
         }
       }
@@ -1111,6 +1134,41 @@ __device__ __forceinline__ bool spd_fast(const Lds& L, const double* cov, int D,
     double* tmp = src;
     src = dst;
     dst = tmp;
+  }
+  if (ok && k < D) {  // D odd: the last sweep alone
+    const double piv = src[k * LD + k];
+    if (!(piv > 0.0) || !isfinite(piv)) {
+      ok = false;
+    } else {
+      const double rp = rcp_nr(piv);
+      if (t == 0) pivs[k] = piv;
+      if (j < D) {
+        const double cj = src[k * LD + j];
+        const double cjr = cj * rp;
+        for (int ib = i0; ib < D; ib += 4 * istep) {
+          double ci[4], w[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int i = ib + u * istep;
+            const int ic = i < D ? i : k;
+            ci[u] = src[ic * LD + k];
+            w[u] = src[ic * LD + j];
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int i = ib + u * istep;
+            double val = fma(-ci[u], cjr, w[u]);
+            val = (j == k) ? ci[u] * rp : val;
+            val = (i == k) ? ((j == k) ? -rp : cjr) : val;
+            if (i < D) dst[i * LD + j] = val;
+          }
+        }
+      }
+      __syncthreads();
+      double* tmp = src;
+      src = dst;
+      dst = tmp;
+    }
   }
   if (!ok) return false;
   double ld;
