@@ -1582,6 +1582,12 @@ __device__ int node_kmeans_part(const Lds& L, const double* pts, int* perm, int*
       }
       if (np > 1) st_agent(kp + (size_t)q * KP + c * D + j, sum);
       L.sums[c * D + j] = sum;
+      if (np == 1) {
+        // a node that is one part: the thread that holds a cluster sum forms the centroid entry right away (the
+        // same quotient as below) -- one barrier and one LDS round trip less per iteration
+        const int nc = c ? count - c0_tile : c0_tile;
+        if (nc > 0) L.cen[c * D + j] = sum / (double)nc;  // empty cluster keeps its centroid
+      }
     }
     n0 = c0_tile;
     if (np > 1) {
@@ -1609,12 +1615,13 @@ __device__ int node_kmeans_part(const Lds& L, const double* pts, int* perm, int*
       __syncthreads();
       n0 = (int)L.sums[2 * D];
     }
-    __syncthreads();
     const int moved = np > 1 ? (int)L.sums[2 * D + 1] : ch_tile;
-    const int n1 = count - n0;
-    if (t < D) {
-      if (n0 > 0) L.cen[t] = L.sums[t] / (double)n0;  // empty cluster keeps its centroid
-      if (n1 > 0) L.cen[D + t] = L.sums[D + t] / (double)n1;
+    if (np > 1) {
+      const int n1 = count - n0;
+      if (t < D) {
+        if (n0 > 0) L.cen[t] = L.sums[t] / (double)n0;  // empty cluster keeps its centroid
+        if (n1 > 0) L.cen[D + t] = L.sums[D + t] / (double)n1;
+      }
     }
     __syncthreads();
     PH_ADD(12);
