@@ -170,19 +170,31 @@ struct Lds {
 // ---- lane exchanges inside a row of 16 on the vector pipe ---------------------------------------------------------
 // __shfl_xor compiles to ds_bpermute_b32 (two per double, an LDS round trip of ~130 cycles each, and every reduction
 // step waits for the one before).  For the partner masks 1, 2, 4 and 8 the same exchange is a DPP move: quad_perm for
-// 1 and 2, row_shl:4 / row_shr:4 under complementary bank masks for 4, row_ror:8 for 8.  Same partner, same operands:
-// the same bits as the shuffle.  (16 and 32 cross rows: they stay on ds_bpermute.)
+// 1 and 2, row_shl:4 / row_shr:4 under complementary bank masks for 4, row_ror:8 for 8; 16 and 32 cross rows:
+// gfx950's v_permlane16_swap / v_permlane32_swap and a select.  Same partner, same operands: the same bits as the shuffle.
 template <int CTRL, int BANK>
 __device__ __forceinline__ int dpp_mov_i32(int old, int v) {
   return __builtin_amdgcn_update_dpp(old, v, CTRL, 0xF, BANK, false);
 }
 template <int S>
 __device__ __forceinline__ int xor_lane_i32(int v) {
-  static_assert(S == 1 || S == 2 || S == 4 || S == 8, "in-row partner masks only");
+  static_assert(S == 1 || S == 2 || S == 4 || S == 8 || S == 16 || S == 32, "a power of two below 64");
   if constexpr (S == 1) return dpp_mov_i32<0xB1, 0xF>(v, v);  // quad_perm:[1,0,3,2]
   if constexpr (S == 2) return dpp_mov_i32<0x4E, 0xF>(v, v);  // quad_perm:[2,3,0,1]
   if constexpr (S == 4) return dpp_mov_i32<0x114, 0xA>(dpp_mov_i32<0x104, 0x5>(v, v), v);  // lanes 0-3 / 8-11 read +4, 4-7 / 12-15 read -4
-  return dpp_mov_i32<0x128, 0xF>(v, v);  // row_ror:8
+  if constexpr (S == 8) return dpp_mov_i32<0x128, 0xF>(v, v);  // row_ror:8
+  // Across rows: gfx950's row swaps.  v_permlane16_swap(a, b) exchanges a's odd rows with b's even rows, so with
+  // a = b = v the first result is (r0, r0, r2, r2) and the second (r1, r1, r3, r3): a lane in an even row takes the
+  // second, in an odd row the first.  v_permlane32_swap exchanges a's rows 2, 3 with b's rows 0, 1 likewise.
+  if constexpr (S == 16) {
+    const auto r = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
+    return (int)((threadIdx.x & 16) ? r[0] : r[1]);
+  }
+  if constexpr (S == 32) {
+    const auto r = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
+    return (int)((threadIdx.x & 32) ? r[0] : r[1]);
+  }
+  return v;
 }
 template <int S>
 __device__ __forceinline__ double xor_lane(double v) {
@@ -191,8 +203,8 @@ __device__ __forceinline__ double xor_lane(double v) {
   return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 __device__ __forceinline__ double wave_sum(double v) {  // the butterfly of `for (s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s)`
-  v += __shfl_xor(v, 32);
-  v += __shfl_xor(v, 16);
+  v += xor_lane<32>(v);
+  v += xor_lane<16>(v);
   v += xor_lane<8>(v);
   v += xor_lane<4>(v);
   v += xor_lane<2>(v);
@@ -200,8 +212,8 @@ __device__ __forceinline__ double wave_sum(double v) {  // the butterfly of `for
   return v;
 }
 __device__ __forceinline__ double wave_max(double v) {
-  v = fmax(v, __shfl_xor(v, 32));
-  v = fmax(v, __shfl_xor(v, 16));
+  v = fmax(v, xor_lane<32>(v));
+  v = fmax(v, xor_lane<16>(v));
   v = fmax(v, xor_lane<8>(v));
   v = fmax(v, xor_lane<4>(v));
   v = fmax(v, xor_lane<2>(v));
@@ -224,7 +236,12 @@ __device__ __forceinline__ double block_reduce_max(double v, double* red) {
 }
 
 __device__ __forceinline__ int block_reduce_sum_int(int v, int* red) {
-  for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s);
+  v += xor_lane_i32<32>(v);
+  v += xor_lane_i32<16>(v);
+  v += xor_lane_i32<8>(v);
+  v += xor_lane_i32<4>(v);
+  v += xor_lane_i32<2>(v);
+  v += xor_lane_i32<1>(v);
   const int t = threadIdx.x;
   __syncthreads();
   if ((t & 63) == 0) red[t >> 6] = v;
@@ -1239,8 +1256,8 @@ __device__ __forceinline__ bool spd_fast(const Lds& L, const double* cov, int D,
         bi = oi;
       }
     };
-    take_max(__shfl_xor(best, 32), __shfl_xor(bi, 32));
-    take_max(__shfl_xor(best, 16), __shfl_xor(bi, 16));
+    take_max(xor_lane<32>(best), xor_lane_i32<32>(bi));
+    take_max(xor_lane<16>(best), xor_lane_i32<16>(bi));
     take_max(xor_lane<8>(best), xor_lane_i32<8>(bi));
     take_max(xor_lane<4>(best), xor_lane_i32<4>(bi));
     take_max(xor_lane<2>(best), xor_lane_i32<2>(bi));
@@ -1255,8 +1272,8 @@ __device__ __forceinline__ bool spd_fast(const Lds& L, const double* cov, int D,
         ai = oi;
       }
     };
-    take_abs(__shfl_xor(ax, 32), __shfl_xor(ai, 32));
-    take_abs(__shfl_xor(ax, 16), __shfl_xor(ai, 16));
+    take_abs(xor_lane<32>(ax), xor_lane_i32<32>(ai));
+    take_abs(xor_lane<16>(ax), xor_lane_i32<16>(ai));
     take_abs(xor_lane<8>(ax), xor_lane_i32<8>(ai));
     take_abs(xor_lane<4>(ax), xor_lane_i32<4>(ai));
     take_abs(xor_lane<2>(ax), xor_lane_i32<2>(ai));
@@ -2649,7 +2666,12 @@ __global__ void __launch_bounds__(kThreads) k_finish(RebuildArgs a) {
     {
       int mine = 0;
       for (int i = t; i < nnodes; i += kThreads) mine = max(mine, nodes[i].depth);
-      for (int sft = 32; sft > 0; sft >>= 1) mine = max(mine, __shfl_xor(mine, sft));
+      mine = max(mine, xor_lane_i32<32>(mine));
+      mine = max(mine, xor_lane_i32<16>(mine));
+      mine = max(mine, xor_lane_i32<8>(mine));
+      mine = max(mine, xor_lane_i32<4>(mine));
+      mine = max(mine, xor_lane_i32<2>(mine));
+      mine = max(mine, xor_lane_i32<1>(mine));
       if ((t & 63) == 0) L.ri[t >> 6] = mine;
       __syncthreads();
       md = max(max(L.ri[0], L.ri[1]), max(L.ri[2], L.ri[3]));
