@@ -3244,8 +3244,11 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
   int lv = 4;
   while ((1 << lv) < n / (2 * d) + 1) ++lv;
   a.levels = mode == 1 ? 0 : (2 * lv + 8);
-  // 128 points per k-means part: five k_split workgroups per CU (see carve_split); DH_SPLIT_TP overrides (64 .. 256)
-  a.tps = 128;
+  // 128 points per k-means part: five k_split workgroups per CU (see carve_split) -- or 256 where five 256-point
+  // tiles fit a CU's LDS as well (D <= 13): half the parts to meet at the device-scope barrier.  Measured (round 5, 64
+  // sets, tools/r5_tps.sh): eggbox 2-D 4.48 -> 4.10 ms, two blobs 5-D 0.720 -> 0.704; at D = 25 256-point parts lose
+  // (1.26 -> 1.40 ms: two workgroups per CU).  DH_SPLIT_TP overrides (64 .. 256)
+  a.tps = split_lds_bytes(d, 256) * 5 <= kLdsLimit ? 256 : 128;
   if (const char* e = getenv("DH_SPLIT_TP")) {
     const int v = atoi(e);
     if (v == 64 || v == 128 || v == 192 || v == 256) a.tps = v;
