@@ -2297,10 +2297,23 @@ __device__ __forceinline__ void split_body(const RebuildArgs& a, const Lds& L, c
   }
 }
 
-__global__ void __launch_bounds__(kThreads) k_split(RebuildArgs a, int level) {
+// gp = the parts per run this launch provides (the level's bound, <= a.maxp).  Run-minor like k_ell -- the q-th part
+// of every run before anyone's (q + 1)-th -- but only inside chunks of cr runs whose cr * gp workgroups can all be
+// resident at once: the parts of a node meet at spin barriers, workgroups are dispatched in index order, and a chunk
+// that fits the chip can always be completed by the workgroups in front of it finishing (chunks are dispatched one
+// after the other; cr = 1 is the run-major order of rounds 2-4).
+__global__ void __launch_bounds__(kThreads) k_split(RebuildArgs a, int level, int gp, int cr) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int run = blockIdx.x / a.maxp, ps = blockIdx.x % a.maxp;
-  if (ps >= a.nparts[(size_t)level * a.runs + run]) return;
+  const int per = cr * gp, chunk = blockIdx.x / per, b = blockIdx.x - chunk * per;
+  const int rc = min(cr, a.runs - chunk * cr);  // runs of this chunk (the last one may be short)
+  const int run = chunk * cr + b % rc, ps = b / rc;
+  if (ps >= gp) return;
+  const int nps = a.nparts[(size_t)level * a.runs + run];
+  if (nps > gp) {  // (cannot happen: a level's parts are bounded by n / tps + its node count)
+    if (threadIdx.x == 0) atomicMin(&a.kerr[run], DH_ERR_NOMEM);
+    return;
+  }
+  if (ps >= nps) return;
   // status is only written by the other kernels of the pipeline (errors of THIS kernel go
   // to kerr): all parts of a node take the same decision here
   if (a.status[run] != DH_OK) return;
@@ -2359,7 +2372,9 @@ template <bool SLOW>
 // eigen-free path spills and the rebuild loses 7 %)
 __global__ void __launch_bounds__(kThreads, SLOW ? 1 : 2) k_ell(RebuildArgs a, int level, int G, int skip_done, int leaf_cap) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int run = blockIdx.x / G, g = blockIdx.x % G;
+  // run-minor: the g-th node of EVERY run before anyone's (g + 1)-th -- workgroups are dispatched in index order at
+  // a finite rate (~30 per us), and with the runs major the last run's first node started after 2 600 others
+  const int run = blockIdx.x % a.runs, g = blockIdx.x / a.runs;
   const int* list = a.ell_list + ((size_t)level * a.runs + run) * 2 * a.maxw;
   const int cnt = a.nell[(size_t)level * a.runs + run];
   if (g >= cnt) return;
@@ -2508,7 +2523,7 @@ __device__ __forceinline__ int node_ellipsoid_wave(const Lds& L, const RebuildAr
 template <int NT>
 __global__ void __launch_bounds__(NT, 3) k_ell_wave(RebuildArgs a, int level, int G, int cap, int axis, int defer) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int run = blockIdx.x / G, g = blockIdx.x % G;
+  const int run = blockIdx.x % a.runs, g = blockIdx.x / a.runs;  // (run-minor, as k_ell)
   const int* list = a.ell_list + ((size_t)level * a.runs + run) * 2 * a.maxw;
   const int cnt = a.nell[(size_t)level * a.runs + run];
   if (g >= cnt) return;
@@ -3320,9 +3335,10 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
   // Co-residency.  Workgroups that meet at a spin barrier -- the parts of the root, the parts of one
   // k-means node -- must be on the chip together.  How many workgroups of a kernel fit is asked of the
   // runtime (occupancy API x CU count), not assumed.  The whole grid of k_root_parts must fit (every part
-  // waits for part 0's solve); for k_split only the <= ceil(n / 256) parts of ONE node must: they have
-  // consecutive workgroup ids and the dispatcher hands out workgroups in id order, so the parts of the
-  // lowest unfinished node are always all dispatched, and every earlier workgroup can finish without them.
+  // waits for part 0's solve); for k_split a CHUNK of runs must (round 5: cr runs x the level's parts per run, sized
+  // to this capacity; inside a chunk the workgroups are ordered part-major so that every run starts at once): chunks
+  // have consecutive workgroup ids and the dispatcher hands out workgroups in id order, so the lowest unfinished
+  // chunk is always dispatched in full as the workgroups in front of it finish, and those never wait for it.
   int cap_root = 0, cap_split = 0, cap_tree = 0;
   {
     static int cu_count[kMaxDev] = {};
@@ -3555,21 +3571,30 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
   }
   bool side_leaves = false;
   for (int L = 0; L < nlev; ++L) {
-    hipLaunchKernelGGL(k_split, dim3(runs * a.maxp), dim3(kThreads), lds_split, ctx->stream, a, L);
+    // Grids no larger than the level can need (round 5): level L splits at most 2^L nodes of a run -- at most
+    // n / tps + 2^L parts -- and creates at most 2^(L + 1) children.  Workgroups are dispatched at a finite rate: the
+    // 2 368 / 2 688-workgroup grids of the worst case cost the first levels 60 us each at 64 runs, most of them for
+    // workgroups that found nothing to do.
+    const long long nodes_L = L < 20 ? (1ll << L) : (1ll << 20);
+    const int gp = (int)(a.maxp < (long long)n / a.tps + nodes_L + 1 ? a.maxp : (long long)n / a.tps + nodes_L + 1);
+    const int ge = (int)(2ll * a.maxw < 2 * nodes_L ? 2ll * a.maxw : 2 * nodes_L);
+    int cr = cap_split > 0 ? cap_split / gp : 1;  // runs per chunk: cr * gp workgroups resident together
+    cr = cr < 1 ? 1 : (cr > runs ? runs : cr);
+    hipLaunchKernelGGL(k_split, dim3(((runs + cr - 1) / cr) * cr * gp), dim3(kThreads), lds_split, ctx->stream, a, L, gp, cr);
     const int wave = L >= wave_from ? 1 : 0;
     if (L >= wave_from)
-      hipLaunchKernelGGL(k_ell_wave<64>, dim3(runs * 2 * a.maxw), dim3(64), lds_wave, ctx->stream, a, L, 2 * a.maxw,
+      hipLaunchKernelGGL(k_ell_wave<64>, dim3(runs * ge), dim3(64), lds_wave, ctx->stream, a, L, ge,
                          wave_cap, wave_axis, 0);
     const int lc = (leaf_cap > 0 && L >= leaf_from) ? leaf_cap : 0;
     if (lc && !hip_ok(ctx, hipEventRecord(ctx->ev_leaf, ctx->stream), "hipEventRecord(leaf fork)")) return DH_ERR_HIP;
     if (a.fast)
-      hipLaunchKernelGGL(k_ell<false>, dim3(runs * 2 * a.maxw), dim3(kThreads), lds, ctx->stream, a, L, 2 * a.maxw, wave, lc);
+      hipLaunchKernelGGL(k_ell<false>, dim3(runs * ge), dim3(kThreads), lds, ctx->stream, a, L, ge, wave, lc);
     else
-      hipLaunchKernelGGL(k_ell<true>, dim3(runs * 2 * a.maxw), dim3(kThreads), lds, ctx->stream, a, L, 2 * a.maxw, 0, 0);
+      hipLaunchKernelGGL(k_ell<true>, dim3(runs * ge), dim3(kThreads), lds, ctx->stream, a, L, ge, 0, 0);
     if (lc) {  // (submitted after the level's k_ell: its few splittable children should get their slots first)
       if (!hip_ok(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->ev_leaf, 0), "hipStreamWaitEvent(leaf fork)"))
         return DH_ERR_HIP;
-      hipLaunchKernelGGL(k_ell_wave<128>, dim3(runs * 2 * a.maxw), dim3(128), lds_leaf, ctx->side_stream, a, L, 2 * a.maxw,
+      hipLaunchKernelGGL(k_ell_wave<128>, dim3(runs * ge), dim3(128), lds_leaf, ctx->side_stream, a, L, ge,
                          leaf_cap, 0, 1);
       side_leaves = true;
     }
