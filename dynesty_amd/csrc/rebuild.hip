@@ -119,11 +119,14 @@ struct RebuildArgs {
 };
 
 #ifdef DH_REBUILD_TIMING
+#ifndef DH_PHASE_WG
+#define DH_PHASE_WG 0  // the workgroup of every kernel whose phases are summed (-DDH_PHASE_WG=k: another one)
+#endif
 __device__ long long g_phase_cycles[16];
 #define PH_T0() long long t0_ = clock64()
 #define PH_ADD(i)                                                      \
   do {                                                                 \
-    if (threadIdx.x == 0 && blockIdx.x == 0) {                         \
+    if (threadIdx.x == 0 && blockIdx.x == DH_PHASE_WG) {               \
       long long t1_ = clock64();                                       \
       g_phase_cycles[i] += t1_ - t0_;                                  \
       t0_ = t1_;                                                       \
@@ -3339,7 +3342,7 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
   // to this capacity; inside a chunk the workgroups are ordered part-major so that every run starts at once): chunks
   // have consecutive workgroup ids and the dispatcher hands out workgroups in id order, so the lowest unfinished
   // chunk is always dispatched in full as the workgroups in front of it finish, and those never wait for it.
-  int cap_root = 0, cap_split = 0, cap_tree = 0;
+  int cap_root = 0, cap_split = 0, cap_split_level = 0, cap_tree = 0;
   {
     static int cu_count[kMaxDev] = {};
     int& ncu = cu_count[ctx->device & (kMaxDev - 1)];
@@ -3357,6 +3360,7 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
       occ_split = 1;
     cap_root = ncu * (occ_root > 0 ? occ_root : 1);
     cap_split = ncu * (occ_split > 0 ? occ_split : 1);
+    cap_split_level = cap_split;  // (k_split's own: what its chunks are sized to)
     if (tail) {
       int occ_tree = 0;
       (void)hipFuncSetAttribute((const void*)k_tree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -3578,9 +3582,11 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
     const long long nodes_L = L < 20 ? (1ll << L) : (1ll << 20);
     const int gp = (int)(a.maxp < (long long)n / a.tps + nodes_L + 1 ? a.maxp : (long long)n / a.tps + nodes_L + 1);
     const int ge = (int)(2ll * a.maxw < 2 * nodes_L ? 2ll * a.maxw : 2 * nodes_L);
-    int cr = cap_split > 0 ? cap_split / gp : 1;  // runs per chunk: cr * gp workgroups resident together
+    int cr = cap_split_level > 0 ? cap_split_level / gp : 1;  // runs per chunk: cr * gp workgroups resident together
     cr = cr < 1 ? 1 : (cr > runs ? runs : cr);
-    hipLaunchKernelGGL(k_split, dim3(((runs + cr - 1) / cr) * cr * gp), dim3(kThreads), lds_split, ctx->stream, a, L, gp, cr);
+    const int nchunk = (runs + cr - 1) / cr;
+    cr = (runs + nchunk - 1) / nchunk;  // (chunks of equal size)
+    hipLaunchKernelGGL(k_split, dim3(nchunk * cr * gp), dim3(kThreads), lds_split, ctx->stream, a, L, gp, cr);
     const int wave = L >= wave_from ? 1 : 0;
     if (L >= wave_from)
       hipLaunchKernelGGL(k_ell_wave<64>, dim3(runs * ge), dim3(64), lds_wave, ctx->stream, a, L, ge,

@@ -2,7 +2,7 @@
 R runs: python tools/rb_phase_batch.py [R ...]"""
 import sys, os, ctypes as C
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-os.environ["DYNHIP_LIB"] = os.path.join(ROOT, "dynesty_amd", "libdynhip_timing.so")
+os.environ.setdefault("DYNHIP_LIB", os.path.join(ROOT, "dynesty_amd", "libdynhip_timing.so"))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 from dynesty_amd import _lib  # noqa: E402
