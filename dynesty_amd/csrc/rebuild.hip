@@ -673,22 +673,29 @@ __device__ __forceinline__ void node_cov(const Lds& L, const double* pts, const 
   mfma_acc acc[6];  // (0,0) (0,1) (1,1) (0,2) (1,2) (2,2)
 #pragma unroll
   for (int b = 0; b < 6; ++b) acc[b] = (mfma_acc){0.0, 0.0, 0.0, 0.0};
-  const bool multi = tile_order && count > L.TP;
+  // The staged tile may hold more than one 256-point tile (k_ell's top levels stage 512 points at once, round 5):
+  // the arithmetic runs over the 256-point tiles inside it, in order -- the sums do not depend on the staging size
+  const bool multi = tile_order && count > kThreads;
   for (int base = 0; base < count; base += L.TP) {
     const int cnt = min(L.TP, count - base);
     stage_tile(L, pts, perm, start + base, cnt, D, 1);
-    tile_cov_accumulate(L, cnt, D, acc);
-    __syncthreads();
-    if (multi) {
-      cov_fold_waves(L, D, acc);  // -> upper triangle of L.A
-      for (int e = threadIdx.x; e < D * D; e += kThreads) {
-        const int i = e / D, j = e - i * D;
-        if (i <= j) L.V[i * L.LD + j] = (base ? L.V[i * L.LD + j] : 0.0) + L.A[i * L.LD + j];
-      }
-      __syncthreads();
+    for (int sub = 0; sub < cnt; sub += kThreads) {
+      Lds LS = L;
+      LS.tile = L.tile + (size_t)sub * L.LD;
+      tile_cov_accumulate(LS, min(kThreads, cnt - sub), D, acc);
+      if (multi) {
+        __syncthreads();
+        cov_fold_waves(L, D, acc);  // -> upper triangle of L.A
+        for (int e = threadIdx.x; e < D * D; e += kThreads) {
+          const int i = e / D, j = e - i * D;
+          if (i <= j) L.V[i * L.LD + j] = ((base + sub) ? L.V[i * L.LD + j] : 0.0) + L.A[i * L.LD + j];
+        }
+        __syncthreads();
 #pragma unroll
-      for (int b = 0; b < 6; ++b) acc[b] = (mfma_acc){0.0, 0.0, 0.0, 0.0};
+        for (int b = 0; b < 6; ++b) acc[b] = (mfma_acc){0.0, 0.0, 0.0, 0.0};
+      }
     }
+    __syncthreads();
   }
   if (multi) {
     for (int e = threadIdx.x; e < D * D; e += kThreads) {
@@ -864,7 +871,7 @@ __device__ __forceinline__ double node_fmax(const Lds& L, const double* pts, con
     stage_tile<NT>(L, pts, perm, start + base, cnt, D, 1);
     PH_ADD(5);
     if (D >= kMfmaMinDim) {
-      best = tile_quadform_max<NT>(L, L.AM, cnt, D, best);
+      best = tile_quadform_max<NT>(L, L.AM, cnt, D, best);  // (any number of staged points: a maximum has no order)
     } else {
       // small D: a point's D^2 FMAs are cheaper than the 16-lane reductions of the MFMA form
       for (int p = threadIdx.x; p < cnt; p += NT) {
@@ -2373,7 +2380,8 @@ __device__ __forceinline__ bool ell_body(const RebuildArgs& a, const Lds& L, con
 template <bool SLOW>
 // (two workgroups per CU: held to the 168 registers of three, with a 128-point tile so that LDS would allow it, the
 // eigen-free path spills and the rebuild loses 7 %)
-__global__ void __launch_bounds__(kThreads, SLOW ? 1 : 2) k_ell(RebuildArgs a, int level, int G, int skip_done, int leaf_cap) {
+__global__ void __launch_bounds__(kThreads, SLOW ? 1 : 2) k_ell(RebuildArgs a, int level, int G, int skip_done, int leaf_cap,
+                                                                 int tp) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // run-minor: the g-th node of EVERY run before anyone's (g + 1)-th -- workgroups are dispatched in index order at
   // a finite rate (~30 per us), and with the runs major the last run's first node started after 2 600 others
@@ -2388,7 +2396,7 @@ __global__ void __launch_bounds__(kThreads, SLOW ? 1 : 2) k_ell(RebuildArgs a, i
   if (a.status[run] != DH_OK) return;
   const int D = a.d;
   Lds L;
-  carve(L, smem, D);
+  carve(L, smem, D, tp);  // tp points staged at once: 256, or 512 at the top levels (the launcher's choice)
   const RunView v = view_of(a, run, L.LD);
   for (int slot = g; slot < cnt; slot += G) {
     // (a child is created with fmax = inf: a finite value = k_ell_wave has built this one)
@@ -3481,7 +3489,11 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
   a.nnodes_out = nnodes;
   a.active = active;
   a.n_arr = n_arr;
+  // k_ell's top levels: a tile of 512 points, if it fits (D <= 30); DH_ELL_TOP_TILE=0: off
+  size_t lds_top = rebuild_lds_bytes(d, 2 * kThreads);
+  if (lds_top > kLdsLimit || mode != 0 || (getenv("DH_ELL_TOP_TILE") && atoi(getenv("DH_ELL_TOP_TILE")) == 0)) lds_top = 0;
   DH_DEV_MEMO(attr_lds);
+  DH_DEV_MEMO(attr_top);
   if (lds > attr_lds) {
     const void* ks[7] = {(const void*)k_root_parts, (const void*)k_split, (const void*)k_ell<false>,
                          (const void*)k_ell<true>, (const void*)k_out_eig, (const void*)k_root_eig,
@@ -3491,6 +3503,15 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
                   "hipFuncSetAttribute(rebuild LDS)"))
         return DH_ERR_HIP;
     attr_lds = lds;
+    attr_top = 0;  // (k_ell's limit was just lowered to lds)
+  }
+  if (lds_top > attr_top) {
+    if (!hip_ok(ctx, hipFuncSetAttribute((const void*)k_ell<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_top),
+                "hipFuncSetAttribute(k_ell LDS)") ||
+        !hip_ok(ctx, hipFuncSetAttribute((const void*)k_ell<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_top),
+                "hipFuncSetAttribute(k_ell LDS)"))
+      return DH_ERR_HIP;
+    attr_top = lds_top;
   }
   DH_DEV_MEMO(attr_fin);
   if (lds_fin > attr_fin) {
@@ -3593,10 +3614,17 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
                          wave_cap, wave_axis, 0);
     const int lc = (leaf_cap > 0 && L >= leaf_from) ? leaf_cap : 0;
     if (lc && !hip_ok(ctx, hipEventRecord(ctx->ev_leaf, ctx->stream), "hipEventRecord(leaf fork)")) return DH_ERR_HIP;
+    // The top levels' children are several 256-point tiles each and few (one workgroup per CU or less): their
+    // workgroups stage 512 points at once -- a 1 000-point child is gathered three times instead of seven (covariance
+    // pass 2 + Mahalanobis pass 1, the last tile still staged), a 500-point child once instead of three times.  Only
+    // while the level's workgroups all fit the chip at one per CU (the LDS of such a tile allows no second one).
+    const bool top = lds_top > 0 && (n >> (L + 1)) > kThreads && (long long)runs * ge <= ctx->num_cu;
     if (a.fast)
-      hipLaunchKernelGGL(k_ell<false>, dim3(runs * ge), dim3(kThreads), lds, ctx->stream, a, L, ge, wave, lc);
+      hipLaunchKernelGGL(k_ell<false>, dim3(runs * ge), dim3(kThreads), top ? lds_top : lds, ctx->stream, a, L, ge, wave, lc,
+                         top ? 2 * kThreads : kThreads);
     else
-      hipLaunchKernelGGL(k_ell<true>, dim3(runs * ge), dim3(kThreads), lds, ctx->stream, a, L, ge, 0, 0);
+      hipLaunchKernelGGL(k_ell<true>, dim3(runs * ge), dim3(kThreads), top ? lds_top : lds, ctx->stream, a, L, ge, 0, 0,
+                         top ? 2 * kThreads : kThreads);
     if (lc) {  // (submitted after the level's k_ell: its few splittable children should get their slots first)
       if (!hip_ok(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->ev_leaf, 0), "hipStreamWaitEvent(leaf fork)"))
         return DH_ERR_HIP;
