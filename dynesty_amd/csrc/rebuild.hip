@@ -3603,7 +3603,9 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
     const long long nodes_L = L < 20 ? (1ll << L) : (1ll << 20);
     const int gp = (int)(a.maxp < (long long)n / a.tps + nodes_L + 1 ? a.maxp : (long long)n / a.tps + nodes_L + 1);
     const int ge = (int)(2ll * a.maxw < 2 * nodes_L ? 2ll * a.maxw : 2 * nodes_L);
-    int cr = cap_split_level > 0 ? cap_split_level / gp : 1;  // runs per chunk: cr * gp workgroups resident together
+    // runs per chunk: cr * gp workgroups resident together, with an eighth of the chip to spare (the side stream's
+    // kernels hold slots too; a chunk that does not fit would still finish -- they do not wait for it -- only later)
+    int cr = cap_split_level > 0 ? (int)((long long)cap_split_level * 7 / 8) / gp : 1;
     cr = cr < 1 ? 1 : (cr > runs ? runs : cr);
     const int nchunk = (runs + cr - 1) / cr;
     cr = (runs + nchunk - 1) / nchunk;  // (chunks of equal size)
