@@ -57,6 +57,26 @@ def test_bench_shape_batch_equals_single(ctx):
         np.testing.assert_array_equal(one["logvol_ells"], b["logvols"][r, :m])
 
 
+def test_many_runs_in_chunks_equal_single(ctx):
+    """160 runs in one batch: k_split's workgroups no longer fit the chip together, so its grid goes in chunks of
+    runs (part-major inside a chunk, chunks in index order: the parts of a node meet at spin barriers), and the top
+    levels' k_ell workgroups are more than one per CU, so they stage 256 points at a time where the 64-run batch
+    stages 512.  Every run checked == the same live set rebuilt alone, bit for bit."""
+    sh = bench.Shard(ctx, bench.c2_problem(), runs=160, nlive=2000, walks=45, seed=1000)
+    sh.rebuild(enlarge=False)
+    ctx.sync()
+    b = sh.fetch_bound()
+    assert np.all(b["status"] == 0)
+    for r in (0, 63, 64, 101, 159):
+        one = ctx.rebuild(sh.u0[r * sh.nlive:(r + 1) * sh.nlive], multi=True, max_ells=bench.MAX_ELLS)
+        m = one["nells"]
+        assert m == int(b["nells"][r])
+        np.testing.assert_array_equal(one["ctrs"], b["ctrs"][r, :m])
+        np.testing.assert_array_equal(one["covs"], b["covs"][r, :m])
+        np.testing.assert_array_equal(one["axes"], b["axes"][r, :m])
+        np.testing.assert_array_equal(one["logvol_ells"], b["logvols"][r, :m])
+
+
 def test_small_shard_other_seeds(ctx):
     """Odd sizes through the same entry points (runs not a multiple of anything, one run)."""
     for runs, seed in ((1, 5), (3, 6)):
