@@ -79,6 +79,7 @@ struct dh_ctx {
   // (walkq.hip: itemgen_kernel; env DH_RWALK_ITEMS=0 keeps the generator inside the walk kernel).  Grow-only
   // buffer, launches larger than the budget go in chunks of walkers
   int rwalk_items = 1;
+  int itemgen_blocks_per_cu = 0;  // occupancy of itemgen_kernel on this context's device, asked once (walkq.hip)
   double* items = nullptr;
   size_t items_cap = 0;
   size_t items_budget = (size_t)1 << 30;

@@ -2362,7 +2362,18 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
   // (DH_NS_OVERLAP=1 switches it on): a rebuild beside a walk slows both (77 KB of LDS and 256 VGPRs per rebuild
   // workgroup against two 230-VGPR walk workgroups per CU), and every run spends one more fill per bound update --
   // 64 C2 runs 0.336 -> 0.328 s, 16 eggbox runs 0.127 -> 0.160 s, 16 C4 runs 11.1 -> 11.3 s.
-  a.overlap = (getenv("DH_NS_OVERLAP") && atoi(getenv("DH_NS_OVERLAP")) != 0 && !a.forced_exact) ? 1 : 0;
+  const bool want_overlap = getenv("DH_NS_OVERLAP") && atoi(getenv("DH_NS_OVERLAP")) != 0;
+  if (want_overlap && a.forced_exact) {
+    // (the reference's protocol builds bounds inside the fill that needs them: nothing to overlap.  Said once, not
+    // silently ignored -- the protocol is the default since round 5, also for C callers that never set the option)
+    static bool warned = false;
+    if (!warned) {
+      fprintf(stderr, "dynhip: DH_NS_OVERLAP=1 has no effect while DH_NS_OPT_FORCED_EXACT is on (the default); "
+                      "set the option to 0 for the late form\n");
+      warned = true;
+    }
+  }
+  a.overlap = (want_overlap && !a.forced_exact) ? 1 : 0;
   // Bounds are built every rebuild_every-th fill (runs that become due in between wait, see ns_prepare); 0 = chosen
   // here.  Once the period reaches the number of fills a run needs to spend its update interval, EVERY run is due (and
   // waiting) by the next rebuild fill: the ensemble rebuilds together and walks together, one latency chain per
@@ -2501,7 +2512,8 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
       !hip_ok(ctx, hipMemsetAsync(base + o_fo, 0, (size_t)R * 4, s), "memset") ||
       !hip_ok(ctx, hipMemsetAsync(base + o_ff, 0x7f, (size_t)R * 4, s), "memset") ||
       !hip_ok(ctx, hipMemsetAsync(base + o_us, 0xff, (size_t)R * 4, s), "memset") ||
-      !hip_ok(ctx, hipMemsetAsync(base + o_fk, 0, (size_t)R * 8, s), "memset") ||
+      !hip_ok(ctx, hipMemsetAsync(base + o_fk, 0, (size_t)R * 4, s), "memset") ||   // fx_kind
+      !hip_ok(ctx, hipMemsetAsync(base + o_pmk, 0, (size_t)R * 4, s), "memset") ||  // pass_mode (its own padded block)
       !hip_ok(ctx, hipMemsetAsync(base + o_ne, 0, (size_t)R * 4, s), "memset") ||
       !hip_ok(ctx, hipMemcpyAsync(d_ent, entropy_words, (size_t)n_words * 4, hipMemcpyHostToDevice, s), "H2D"))
     return cleanup(DH_ERR_HIP);

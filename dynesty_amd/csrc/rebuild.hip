@@ -3352,12 +3352,7 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
   // chunk is always dispatched in full as the workgroups in front of it finish, and those never wait for it.
   int cap_root = 0, cap_split = 0, cap_split_level = 0, cap_tree = 0;
   {
-    static int cu_count[kMaxDev] = {};
-    int& ncu = cu_count[ctx->device & (kMaxDev - 1)];
-    if (!ncu) {
-      hipDeviceProp_t prop;
-      ncu = hipGetDeviceProperties(&prop, ctx->device) == hipSuccess ? prop.multiProcessorCount : 1;
-    }
+    const int ncu = ctx->num_cu;
     int occ_root = 0, occ_split = 0;
     // (the LDS attribute must be in place for the query to count the dynamic allocation)
     (void)hipFuncSetAttribute((const void*)k_root_parts, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -3605,7 +3600,15 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
     const int ge = (int)(2ll * a.maxw < 2 * nodes_L ? 2ll * a.maxw : 2 * nodes_L);
     // runs per chunk: cr * gp workgroups resident together, with an eighth of the chip to spare (the side stream's
     // kernels hold slots too; a chunk that does not fit would still finish -- they do not wait for it -- only later)
-    int cr = cap_split_level > 0 ? (int)((long long)cap_split_level * 7 / 8) / gp : 1;
+    // (ONE context per GPU is assumed, as for k_root_parts: a second process -- or a long-lived foreign kernel -- can
+    // hold slots this sizing counts on; DH_SPLIT_RESIDENT_PCT lowers the share of the chip a chunk may claim (87 by
+    // default, e.g. 40 on a GPU shared by two processes), and the spin limit fails a starved run instead of hanging)
+    static const int resident_pct = [] {
+      const char* e = getenv("DH_SPLIT_RESIDENT_PCT");
+      const int v = e ? atoi(e) : 0;
+      return v >= 1 && v <= 100 ? v : 87;
+    }();
+    int cr = cap_split_level > 0 ? (int)((long long)cap_split_level * resident_pct / 100) / gp : 1;
     cr = cr < 1 ? 1 : (cr > runs ? runs : cr);
     const int nchunk = (runs + cr - 1) / cr;
     cr = (runs + nchunk - 1) / nchunk;  // (chunks of equal size)

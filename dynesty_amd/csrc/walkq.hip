@@ -1420,7 +1420,7 @@ int rwalkq_launch(dh_ctx* ctx, const ProblemDev& prob, int k, int ndim, const do
       // generation of blocks on a third of the wavefront slots: the same walkers per wavefront, a quarter of them at
       // a third of the occupancy (EXPERIMENTS.md R5.1)
       int gblocks = (kc + 3) / 4;
-      static int per_cu = 0;
+      int& per_cu = ctx->itemgen_blocks_per_cu;  // (per context: the library keeps no process-global state)
       if (per_cu == 0) {
         int nb = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, itemgen_kernel, 256, 0) != hipSuccess || nb < 1) nb = 6;

@@ -2605,15 +2605,7 @@ static int wide_single_enqueue(dh_ctx* ctx, int runs, const double* pts, int n, 
   const int M = 2 * ((d + 2 * bmax - 1) / (2 * bmax)), B = M / 2, b = (d + M - 1) / M;
   const size_t xb = (size_t)2 * M * b * clen * 8;
   const size_t eig_lds = (size_t)2 * b * clen * 8 + eig_other;
-  static int n_cu = 0;
-  if (!n_cu) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-      n_cu = prop.multiProcessorCount;
-    else
-      n_cu = 1;
-  }
+  const int n_cu = ctx->num_cu;  // (the context's own device: no process-global memo)
   const char* e_eig = getenv("DH_WIDE_EIG");
   const bool split = !(e_eig && atoi(e_eig) == 0) && (long long)B * runs <= n_cu && n > 1;
   // chunks of whole 64-point tiles for the data-parallel kernels

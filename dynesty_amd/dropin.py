@@ -56,6 +56,18 @@ class HipRWalkSampler(_ProblemMixin, _dis.RWalkSampler):
         super().__init__(**kwargs)
         self._attach_problem(kwargs)
 
+    def prepare_sampler(self, loglstar=None, points=None, axes=None, seeds=None, prior_transform=None,
+                        loglikelihood=None, nested_sampler=None):
+        """internal_samplers.py:111-159, plus per walker the ln L the run holds for its start point
+        (`kwargs['logl0']`): what an unmoved walker hands back (samplers.run_rwalk)."""
+        args = super().prepare_sampler(loglstar=loglstar, points=points, axes=axes, seeds=seeds,
+                                       prior_transform=prior_transform, loglikelihood=loglikelihood,
+                                       nested_sampler=nested_sampler)
+        logl0 = _hs.stored_logl_of(points, nested_sampler)
+        if logl0 is None:
+            return args
+        return [a._replace(kwargs=dict(a.kwargs, logl0=float(l0))) for a, l0 in zip(args, logl0)]
+
     sample = staticmethod(_hs.batched(_hs.run_rwalk))
 
 

@@ -12,6 +12,18 @@ serially on the host like ``map`` would.
 """
 
 
+def _is_dynesty_unitcube(func):
+    """True only for dynesty's own ``internal_samplers.UnitCubeSampler.sample`` -- by identity against the loaded
+    module (no import here: if ``func`` is dynesty's, dynesty is in ``sys.modules``).  A user class that merely
+    shares the qualified name keeps its own semantics and is mapped serially."""
+    if getattr(func, '__qualname__', '') != 'UnitCubeSampler.sample':
+        return False
+    import sys
+    mod = sys.modules.get('dynesty.internal_samplers')
+    cls = getattr(mod, 'UnitCubeSampler', None)
+    return cls is not None and getattr(func, '__func__', func) is getattr(cls.sample, '__func__', cls.sample)
+
+
 class HipBatchPool:
 
     def __init__(self, queue_size=1024):
@@ -21,9 +33,11 @@ class HipBatchPool:
         runner = getattr(func, '_dynhip_batch', None)
         if runner is not None:
             return runner(list(iterable))
-        if getattr(func, '__qualname__', '') == 'UnitCubeSampler.sample':
+        if _is_dynesty_unitcube(func):
             # dynesty's own sampler of the phase before the first bound (it constructs it itself, so there is no
-            # drop-in class to hand it): batched when the run's callbacks are a device Problem's
+            # drop-in class to hand it): batched when the run's callbacks are a device Problem's.  The batched cube
+            # phase evaluates prior transform and ln L with the DEVICE twin's arithmetic (ocml), the serial form below
+            # with the host Problem's (NumPy): equal to ~1e-15 relative, not bit for bit (tests hold 1e-10).
             from . import samplers
             args = list(iterable)
             res = samplers.run_unitcube(args)

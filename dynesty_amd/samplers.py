@@ -211,8 +211,47 @@ def _run_rwalk_lockstep(args, history=False):
     return res
 
 
+def stored_logl_of(points, nested_sampler):
+    """ln L that the run holds for each start point of a fill, or None where it cannot be told.  A start point is a
+    copy of a live point (sampler.py:676-700, propose_live), so its row is found among `nested_sampler.live_u` bit for
+    bit and `live_logl` has its value.  (Duplicates of a row -- an unmoved walker's earlier return -- carry the same
+    stored value, so any match serves.)"""
+    live_u = getattr(nested_sampler, 'live_u', None)
+    live_logl = getattr(nested_sampler, 'live_logl', None)
+    if live_u is None or live_logl is None or len(points) == 0:
+        return None
+    live_u = np.asarray(live_u)
+    pts = np.asarray(points, dtype=np.float64)
+    if pts.ndim != 2 or live_u.ndim != 2 or pts.shape[1] != live_u.shape[1]:
+        return None
+    live_logl = np.asarray(live_logl, dtype=np.float64)
+    order = np.argsort(live_u[:, 0], kind='stable')
+    col = live_u[order, 0]
+    out = np.full(len(pts), np.nan)
+    lo = np.searchsorted(col, pts[:, 0], side='left')
+    hi = np.searchsorted(col, pts[:, 0], side='right')
+    has = hi > lo
+    cand = order[np.minimum(lo, len(order) - 1)]
+    hit = has & np.all(live_u[cand] == pts, axis=1)  # the common case: one row with that first coordinate
+    out[hit] = live_logl[cand[hit]]
+    for i in np.nonzero(has & ~hit)[0]:  # several rows share the first coordinate: look at each
+        for j in order[lo[i]:hi[i]]:
+            if np.array_equal(live_u[j], pts[i]):
+                out[i] = live_logl[j]
+                break
+    return out
+
+
 def run_rwalk(args):
-    """RWalkSampler.sample over a queue (internal_samplers.py:504-561)."""
+    """RWalkSampler.sample over a queue (internal_samplers.py:504-561).
+
+    A walker that accepted no step returns its start point (internal_samplers.py:546-553).  The reference then
+    evaluates ln L of that point again -- the same function of the same bits as when the point entered the live set,
+    hence the stored value exactly, an exact tie that `np.argmin` breaks by slot.  A device kernel's evaluation of the
+    point can differ from the stored value in the last bit (the point may have been born in another kernel, or on the
+    host), which would order the two copies by rounding instead: when the fill's arguments carry the stored values
+    (`kwargs['logl0']`, put there by HipRWalkSampler.prepare_sampler) an unmoved walker hands back THAT value, as the
+    resident loop does."""
     args = list(args)
     if not args:
         return []
@@ -231,6 +270,11 @@ def run_rwalk(args):
     walks = int(kw['walks'])
     scale = a0.scale
     acc, rej = out["accept"].tolist(), out["reject"].tolist()
+    if 'logl0' in kw:
+        logl0 = np.array([a.kwargs.get('logl0', np.nan) for a in args], dtype=np.float64)
+        unmoved = (np.asarray(out["accept"]) == 0) & np.isfinite(logl0) & np.all(np.asarray(out["u"]) == u0, axis=1)
+        if unmoved.any():
+            out["logl"] = np.where(unmoved, logl0, out["logl"])
     return _returns(out["u"], out["v"], out["logl"], walks,
                     [{'accept': na, 'reject': nr, 'scale': scale} for na, nr in zip(acc, rej)],
                     [{'n_accept': na, 'n_reject': nr} for na, nr in zip(acc, rej)])
@@ -608,7 +652,13 @@ def _device_problem_of(arg):
     (utils.LogLikelihood(.loglikelihood), _function_wrapper(.func)); underneath must sit the bound methods
     `prob.loglikelihood` and `prob.prior_transform` of ONE Problem (the object that has a device twin)."""
     def owner(fn):
-        for _ in range(4):
+        """(Problem, method name) at the bottom of a wrapper chain, or (None, '').  Every level on the way must be a
+        plain pass-through: a wrapper that holds extra positional / keyword arguments (utils._function_wrapper's
+        args / kwargs = the sampler's logl_args / ptform_args) or returns blobs (utils.LogLikelihood.blob) computes
+        something the device twin does not."""
+        for _ in range(6):
+            if getattr(fn, 'args', None) or getattr(fn, 'kwargs', None) or getattr(fn, 'blob', False):
+                return None, ''
             own = getattr(fn, '__self__', None)
             if own is not None and hasattr(own, 'device_spec'):
                 return own, getattr(fn, '__name__', '')
@@ -621,10 +671,6 @@ def _device_problem_of(arg):
     pp, npt = owner(arg.prior_transform)
     if pl is None or pl is not pp or nl != 'loglikelihood' or npt != 'prior_transform':
         return None
-    # plain pass-through wrappers only (logl_args / ptform_args would change what the callbacks compute)
-    for w in (arg.loglikelihood, arg.prior_transform):
-        if getattr(w, 'args', None) or getattr(w, 'kwargs', None):
-            return None
     return pl
 
 
