@@ -54,6 +54,7 @@ struct dh_ctx {
   // scratch of the rebuild kernel (permutations, node table, per-node ellipsoids)
   char* rebuild_ws = nullptr;
   size_t rebuild_ws_cap = 0;
+  unsigned rebuild_epoch = 0;  // rebuild launches so far (tags of the k-means partials, rebuild.hip)
   // side stream of the rebuild: the root's full eigen-system is solved there while the tree is built
   // on `stream` (fork after k_root, join before k_finish); created on first use
   hipStream_t side_stream = nullptr;

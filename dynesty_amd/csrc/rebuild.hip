@@ -116,6 +116,7 @@ struct RebuildArgs {
   int* kp_top;        // runs: partial-sum slots handed out by the queue form (multi-part nodes only; capacity kp_cap per run)
   int kp_cap;
   int tq_sleep, tq_nocoh;  // diagnostics (DH_TREE_SLEEP, DH_TREE_NOCOH)
+  unsigned epoch;          // rebuild launches of this context so far: part of the tag of the k-means partials
 };
 
 #ifdef DH_REBUILD_TIMING
@@ -132,9 +133,36 @@ __device__ long long g_phase_cycles[16];
       t0_ = t1_;                                                       \
     }                                                                  \
   } while (0)
+// per level: phases of k_split's workgroup DH_PHASE_WG (0 prologue + staging, 1 Lloyd iterations, 2 partition, 3 child
+// records, 4 number of iterations, 5 parts of the node, 6 points of the node)
+__device__ long long g_lvl_cycles[16][16];
+#define LV_T0() long long lt0_ = clock64()
+#define LV_ADD(lvl, i)                                                 \
+  do {                                                                 \
+    if (threadIdx.x == 0 && blockIdx.x == DH_PHASE_WG && (lvl) < 16) { \
+      long long lt1_ = clock64();                                      \
+      g_lvl_cycles[lvl][i] += lt1_ - lt0_;                             \
+      lt0_ = lt1_;                                                     \
+    }                                                                  \
+  } while (0)
+#define LV_SET(lvl, i, v)                                              \
+  do {                                                                 \
+    if (threadIdx.x == 0 && blockIdx.x == DH_PHASE_WG && (lvl) < 16) g_lvl_cycles[lvl][i] += (v); \
+  } while (0)
+// per workgroup of the level kernels: wall clock (100 MHz) at entry and exit, [kernel 0 = k_split, 1 = k_ell][level][workgroup]
+constexpr int kWgMax = 4096;
+__device__ long long g_wg_clock[2][8][kWgMax][2];
+#define WG_STAMP(kern, lvl, which)                                                              \
+  do {                                                                                          \
+    if (threadIdx.x == 0 && (lvl) < 8 && blockIdx.x < kWgMax) g_wg_clock[kern][lvl][blockIdx.x][which] = wall_clock64(); \
+  } while (0)
 #else
 #define PH_T0()
 #define PH_ADD(i)
+#define LV_T0()
+#define WG_STAMP(kern, lvl, which)
+#define LV_ADD(lvl, i)
+#define LV_SET(lvl, i, v)
 #endif
 
 // ---- LDS carve-up ----------------------------------------------------------
@@ -442,6 +470,15 @@ __device__ __forceinline__ int ld_agent_i(const int* p) {
 __device__ __forceinline__ void st_agent_i(int* p, int v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// (round 6) A load under a condition -- `ok ? p[i] : 0.0` -- compiles to a branch around the load: exec mask saved
+// (SGPRs spilled to VGPR lanes), the load alone in its block, `s_waitcnt 0` right behind it.  Every such load was a
+// full LDS / L2 round trip of its own: the eight groups of the k-means label sums, 32 loads, took 6 000 cycles.  sel_ld
+// reads UNCONDITIONALLY from an offset clamped to a valid one (base[0]) and selects afterwards, so the loads of a
+// phase are issued together and waited for once.  Same values: same bits.
+__device__ __forceinline__ double sel_ld(const double* base, int off, bool ok) {
+  const double v = base[ok ? off : 0];
+  return ok ? v : 0.0;
+}
 // through the L.coh switch
 __device__ __forceinline__ double ld_c(const Lds& L, const double* p) { return L.coh ? ld_agent(p) : *p; }
 __device__ __forceinline__ void st_c(const Lds& L, double* p, double v) {
@@ -500,10 +537,15 @@ __device__ __forceinline__ void stage_tile(const Lds& L, const double* __restric
 #pragma unroll
       for (int k = 0; k < SB; ++k) {
         const int p = pb + k * pstep;
-        idx[k] = p < cnt ? (idx_lds ? L.ri[p] : ld_ci(L, perm + start + p)) : -1;
+        const int pc = p < cnt ? p : 0;  // (clamped: unconditional loads, see sel_ld)
+        const int iv = idx_lds ? L.ri[pc] : ld_ci(L, perm + start + pc);
+        idx[k] = p < cnt ? iv : -1;
       }
 #pragma unroll
-      for (int k = 0; k < SB; ++k) x[k] = idx[k] >= 0 ? pts[(size_t)idx[k] * D + j] : 0.0;
+      for (int k = 0; k < SB; ++k) {
+        const double xv = pts[(size_t)(idx[k] >= 0 ? idx[k] : 0) * D + j];
+        x[k] = idx[k] >= 0 ? xv : 0.0;
+      }
 #pragma unroll
       for (int k = 0; k < SB; ++k) {
         const int p = pb + k * pstep;
@@ -605,15 +647,15 @@ __device__ __forceinline__ void tile_cov_accumulate(const Lds& L, int cnt, int D
   for (int p0 = w * 64; p0 < pend; p0 += 4) {
     const int p = p0 + lk;
     const bool pv = p < cnt;
-    const double* row = L.tile + p * LD + lj;
-    const double f0 = (pv && v0) ? row[0] : 0.0;
+    const int ro = p * LD + lj;
+    const double f0 = sel_ld(L.tile, ro, pv && v0);
     acc[0] = DH_MFMA_F64(f0, f0, acc[0]);
     if (nb > 1) {
-      const double f1 = (pv && v1) ? row[16] : 0.0;
+      const double f1 = sel_ld(L.tile, ro + 16, pv && v1);
       acc[1] = DH_MFMA_F64(f0, f1, acc[1]);
       acc[2] = DH_MFMA_F64(f1, f1, acc[2]);
       if (nb > 2) {
-        const double f2 = (pv && v2) ? row[32] : 0.0;
+        const double f2 = sel_ld(L.tile, ro + 32, pv && v2);
         acc[3] = DH_MFMA_F64(f0, f2, acc[3]);
         acc[4] = DH_MFMA_F64(f1, f2, acc[4]);
         acc[5] = DH_MFMA_F64(f2, f2, acc[5]);
@@ -664,12 +706,64 @@ __device__ __forceinline__ void cov_finalize(const Lds& L, int D, double inv) {
   __syncthreads();
 }
 
+// (round 6) cov_fold_waves + cov_finalize + the copies that followed them, in two barriers instead of seven: every wave
+// files its partial in a matrix of its own (wave 0 L.A, 1 L.V, 2 L.AM, 3 L.AX: all free while a node's covariance is
+// formed), then the thread of an upper-triangle entry adds the four in wave order -- ((p0 + p1) + p2) + p3, the very
+// sums the wave-by-wave fold forms -- scales, and writes the entry and its mirror to ALL FOUR matrices and to the
+// node's global working copy: spd_fast then finds the covariance wherever it wants it (sweep source L.A or L.AM, the
+// copy it keeps in L.AX or L.V) without a pass or a global round trip of its own.  Returns false if an entry is not
+// finite (uniform).  Needs the four matrices to be distinct (the 256-thread carve).
+__device__ __forceinline__ bool cov_fold_finalize_all(const Lds& L, int D, const mfma_acc (&acc)[6], double inv,
+                                                      double* cov_g) {
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, LD = L.LD;
+  const int nb = (D + 15) >> 4;
+  const int lj = lane & 15, lk = lane >> 4;
+  // (L.A, L.V, L.AM, L.AX are consecutive D x LD blocks of the 256-thread carve.  Written as a select among the four
+  // struct members the compiler indexed the struct -- and kept the whole carve-up on the stack for it: 224 B of scratch)
+  double* mine = L.A + (size_t)w * D * LD;
+#pragma unroll
+  for (int b = 0; b < 6; ++b) {
+    const int ib = b == 0 ? 0 : b == 1 ? 0 : b == 2 ? 1 : b == 3 ? 0 : b == 4 ? 1 : 2;
+    const int jb = b == 0 ? 0 : b == 1 ? 1 : b == 2 ? 1 : 2;
+    if (jb < nb) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = ib * 16 + lk + 4 * r, j = jb * 16 + lj;
+        if (i <= j && j < D) mine[i * LD + j] = acc[b][r];
+      }
+    }
+  }
+  __syncthreads();
+  bool bad = false;
+  for (int e = t; e < D * D; e += kThreads) {
+    const int i = e / D, j = e - i * D;
+    if (i <= j) {
+      const int o = i * LD + j, ot = j * LD + i;
+      const double c = (((L.A[o] + L.V[o]) + L.AM[o]) + L.AX[o]) * inv;
+      if (!isfinite(c)) bad = true;
+      L.A[o] = c;
+      L.A[ot] = c;
+      L.V[o] = c;
+      L.V[ot] = c;
+      L.AM[o] = c;
+      L.AM[ot] = c;
+      L.AX[o] = c;
+      L.AX[ot] = c;
+      cov_g[o] = c;
+      cov_g[ot] = c;
+    }
+  }
+  return __syncthreads_or(bad ? 1 : 0) == 0;
+}
+
 // tile_order: fold the four wave partials per TILE and add the tiles in order -- the grouping of the
 // cooperative root (one part per tile, parts summed in part order), used for the root so that a live set
 // gives the same bits whichever root routine its batch size selects.  Tree nodes keep the cheaper form
 // (accumulators across all tiles, one fold): they are always built by this routine.
+// fused_cov_g != nullptr (a tree node of the 256-thread kernels): the fold takes the fused form above and leaves the
+// covariance in L.A, L.V, L.AM, L.AX and fused_cov_g; *fused_state = 1 (done, finite) or 2 (done, not finite).
 __device__ __forceinline__ void node_cov(const Lds& L, const double* pts, const int* perm, int start, int count, int D,
-                                         bool tile_order = false) {
+                                         bool tile_order = false, double* fused_cov_g = nullptr, int* fused_state = nullptr) {
   mfma_acc acc[6];  // (0,0) (0,1) (1,1) (0,2) (1,2) (2,2)
 #pragma unroll
   for (int b = 0; b < 6; ++b) acc[b] = (mfma_acc){0.0, 0.0, 0.0, 0.0};
@@ -703,6 +797,9 @@ __device__ __forceinline__ void node_cov(const Lds& L, const double* pts, const 
       if (i <= j) L.A[i * L.LD + j] = L.V[i * L.LD + j];
     }
     __syncthreads();
+  } else if (fused_cov_g != nullptr && L.V == L.A + D * L.LD && L.AM == L.V + D * L.LD && L.AX == L.AM + D * L.LD) {
+    *fused_state = cov_fold_finalize_all(L, D, acc, 1.0 / (double)(count - 1), fused_cov_g) ? 1 : 2;
+    return;
   } else {
     cov_fold_waves(L, D, acc);
   }
@@ -734,12 +831,12 @@ template <int NB, int KS>
 __device__ __forceinline__ void quad_load_b(const double* AM, int D, int LD, QuadB<NB, KS>& B) {
   const int lane = threadIdx.x & 63, lj = lane & 15, lk = lane >> 4;
   const int ksteps = (D + 3) >> 2;
-  const double* brow = AM + lk * LD + lj;
+  const int bo = lk * LD + lj;
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
     const bool kv = ks < ksteps && ks * 4 + lk < D;
 #pragma unroll
-    for (int n = 0; n < NB; ++n) B.b[ks][n] = (kv && 16 * n + lj < D) ? brow[ks * 4 * LD + 16 * n] : 0.0;
+    for (int n = 0; n < NB; ++n) B.b[ks][n] = sel_ld(AM, bo + ks * 4 * LD + 16 * n, kv && 16 * n + lj < D);
   }
 }
 // one block of 16 points after its products: row-wise dot with x, 16-lane sums, running maximum
@@ -750,12 +847,20 @@ __device__ __forceinline__ double quad_block_max(const double* tile, int LD, int
   for (int r = 0; r < 4; ++r) {
     const int p = p0 + lk + 4 * r;
     const bool pv = p < cnt;
-    const double* x = tile + p * LD + lj;
-    double sacc = (pv && lj < D) ? z[0][r] * x[0] : 0.0;
-    if constexpr (NB > 1)
-      if (pv && 16 + lj < D) sacc = fma(z[1][r], x[16], sacc);
-    if constexpr (NB > 2)
-      if (pv && 32 + lj < D) sacc = fma(z[2][r], x[32], sacc);
+    const int xo = p * LD + lj;
+    const bool c0 = pv && lj < D;
+    const double x0 = sel_ld(tile, xo, c0);
+    double sacc = c0 ? z[0][r] * x0 : 0.0;
+    if constexpr (NB > 1) {
+      const bool c1 = pv && 16 + lj < D;
+      const double x1 = sel_ld(tile, xo + 16, c1);
+      sacc = c1 ? fma(z[1][r], x1, sacc) : sacc;
+    }
+    if constexpr (NB > 2) {
+      const bool c2 = pv && 32 + lj < D;
+      const double x2 = sel_ld(tile, xo + 32, c2);
+      sacc = c2 ? fma(z[2][r], x2, sacc) : sacc;
+    }
     sacc += xor_lane<1>(sacc);
     sacc += xor_lane<2>(sacc);
     sacc += xor_lane<4>(sacc);
@@ -775,14 +880,13 @@ __device__ __forceinline__ double tile_quadform_max(const double* tile, int LD, 
     const int pA = mb * 16, pB = (mb + NW) * 16;
     const bool hasB = TWO && pB < cnt;  // (uniform per wavefront)
     const bool va = pA + lj < cnt, vb = hasB && pB + lj < cnt;
-    const double* xa = tile + (pA + lj) * LD + lk;
-    const double* xb = tile + (pB + lj) * LD + lk;
+    const int xao = (pA + lj) * LD + lk, xbo = (pB + lj) * LD + lk;
     double aA[KS], aB[TWO ? KS : 1];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       const bool kv = ks < ksteps && ks * 4 + lk < D;
-      aA[ks] = (va && kv) ? xa[ks * 4] : 0.0;
-      if constexpr (TWO) aB[ks] = (vb && kv) ? xb[ks * 4] : 0.0;
+      aA[ks] = sel_ld(tile, xao + ks * 4, va && kv);
+      if constexpr (TWO) aB[ks] = sel_ld(tile, xbo + ks * 4, vb && kv);
     }
     mfma_acc zA[NB], zB[NB];
 #pragma unroll
@@ -814,19 +918,18 @@ __device__ __forceinline__ double tile_quadform_max_lds(const Lds& L, const doub
     const int p0 = mb * 16;
     mfma_acc z0 = {0.0, 0.0, 0.0, 0.0}, z1 = z0, z2 = z0;
     const bool pa = p0 + lj < cnt;
-    const double* xrow = L.tile + (p0 + lj) * LD + lk;
-    const double* brow = AM + lk * LD + lj;
+    const int xro = (p0 + lj) * LD + lk, bro = lk * LD + lj;
     for (int ks = 0; ks < ksteps; ++ks) {
       const int k = ks * 4 + lk;
       const bool kv = k < D;
-      const double a = (pa && kv) ? xrow[ks * 4] : 0.0;
-      const double b0 = (kv && lj < D) ? brow[ks * 4 * LD] : 0.0;
+      const double a = sel_ld(L.tile, xro + ks * 4, pa && kv);
+      const double b0 = sel_ld(AM, bro + ks * 4 * LD, kv && lj < D);
       z0 = DH_MFMA_F64(a, b0, z0);
       if (nb > 1) {
-        const double b1 = (kv && 16 + lj < D) ? brow[ks * 4 * LD + 16] : 0.0;
+        const double b1 = sel_ld(AM, bro + ks * 4 * LD + 16, kv && 16 + lj < D);
         z1 = DH_MFMA_F64(a, b1, z1);
         if (nb > 2) {
-          const double b2 = (kv && 32 + lj < D) ? brow[ks * 4 * LD + 32] : 0.0;
+          const double b2 = sel_ld(AM, bro + ks * 4 * LD + 32, kv && 32 + lj < D);
           z2 = DH_MFMA_F64(a, b2, z2);
         }
       }
@@ -835,10 +938,12 @@ __device__ __forceinline__ double tile_quadform_max_lds(const Lds& L, const doub
     for (int r = 0; r < 4; ++r) {
       const int p = p0 + lk + 4 * r;
       const bool pv = p < cnt;
-      const double* x = L.tile + p * LD + lj;
-      double sacc = (pv && lj < D) ? z0[r] * x[0] : 0.0;
-      if (nb > 1 && pv && 16 + lj < D) sacc = fma(z1[r], x[16], sacc);
-      if (nb > 2 && pv && 32 + lj < D) sacc = fma(z2[r], x[32], sacc);
+      const int xo = p * LD + lj;
+      const bool c0 = pv && lj < D, c1 = nb > 1 && pv && 16 + lj < D, c2 = nb > 2 && pv && 32 + lj < D;
+      const double x0 = sel_ld(L.tile, xo, c0), x1 = sel_ld(L.tile, xo + 16, c1), x2 = sel_ld(L.tile, xo + 32, c2);
+      double sacc = c0 ? z0[r] * x0 : 0.0;
+      sacc = c1 ? fma(z1[r], x1, sacc) : sacc;
+      sacc = c2 ? fma(z2[r], x2, sacc) : sacc;
       sacc += xor_lane<1>(sacc);
       sacc += xor_lane<2>(sacc);
       sacc += xor_lane<4>(sacc);
@@ -931,7 +1036,12 @@ __device__ __forceinline__ bool regularize(const Lds& L, double* cov, int D) {
       if (t < 64) ok = jacobi_wave(L.A, L.V, D, L.LD, L.rc, L.rs, L.ri) ? 1 : 0;
       fin = __syncthreads_and(ok) != 0;
     } else {
-      fin = jacobi_block(L, D);
+      // (jacobi_block is a call: handed a COPY of the carve-up, the original stays in registers -- with its address
+      // taken every L.xxx of the calling kernel was a scratch load and every LDS access through it a FLAT one:
+      // k_root_parts compiled to 1 132 flat loads and 448 B of scratch a lane, round 6)
+      const Lds Lc = L;
+      fin = jacobi_block(Lc, D);
+      if (L.j_alias) L.c_pts = nullptr;  // (what the callee noted on its copy: the work buffers overlay the point tile)
     }
     PH_ADD(6);
     if (fin && t < 64) sort_eigs_wave(L.A, L.V, L.lam, L.perm_sort, L.AX, D, L.LD);
@@ -1025,7 +1135,7 @@ constexpr int kFastSquarings = 48;
 // trace of a D x D LDS matrix, computed redundantly by every wave (D <= 44 < 64)
 __device__ __forceinline__ double wave_trace(const double* M, int D, int LD) {
   const int lane = threadIdx.x & 63;
-  return wave_sum(lane < D ? M[lane * LD + lane] : 0.0);
+  return wave_sum(sel_ld(M, lane * LD + lane, lane < D));
 }
 
 // Q = s2 * P P for the symmetric D x D matrix P (LDS, D x LD); all threads; caller barriers
@@ -1043,8 +1153,8 @@ __device__ __forceinline__ void sym_square(const double* P, double* Q, int D, in
         const int k = ks * 4 + lk;
         const bool kv = k < D;
         // A[i][k] = P[k][i] (symmetric): both operands are row reads, lanes along the row
-        const double av = (kv && ca < D) ? P[k * LD + ca] : 0.0;
-        const double bv = (kv && cb < D) ? P[k * LD + cb] : 0.0;
+        const double av = sel_ld(P, k * LD + ca, kv && ca < D);
+        const double bv = sel_ld(P, k * LD + cb, kv && cb < D);
         acc = DH_MFMA_F64(av, bv, acc);
       }
 #pragma unroll
@@ -1081,8 +1191,13 @@ __device__ __forceinline__ double rcp_nr(double x) {
 // Schur-complement pivots of LDL^T, so their logarithms sum to ln det).  Sweep k reads one buffer and
 // writes the other (L.AM <-> L.A), so a sweep is: pivot, pivot row / column, own entries, ONE barrier.
 // Thread map: column j = t mod JW, rows t / JW, t / JW + 256 / JW, ... (JW = 32 or 64 >= D).
+// (round 6) The covariance is taken from LDS: L.A holds it on entry (every caller has just formed it there); `cov`,
+// the node's global working copy, is only read where the carve has no room for a copy.  prepared = true: the caller's
+// fused fold (cov_fold_finalize_all) has already put it into L.A, L.V, L.AM and L.AX and checked that it is finite.
+// *cov_keep (on true): an LDS matrix that still holds the untouched covariance, or nullptr (then `cov` does).
 template <int NT = kThreads>
-__device__ __forceinline__ bool spd_fast(const Lds& L, const double* cov, int D, bool want_axis, double* logdet) {
+__device__ __forceinline__ bool spd_fast(const Lds& L, const double* cov, int D, bool want_axis, double* logdet,
+                                         const double** cov_keep = nullptr, bool prepared = false) {
   const int t = threadIdx.x, LD = L.LD;
   const int jsh = D <= 32 ? 5 : 6;
   const int j = t & ((1 << jsh) - 1), i0 = t >> jsh, istep = NT >> jsh;
@@ -1094,15 +1209,24 @@ __device__ __forceinline__ bool spd_fast(const Lds& L, const double* cov, int D,
   double* src = (nswap & 1) ? L.AM : L.A;  // nswap buffer changes later the result sits in L.A
   double* dst = (nswap & 1) ? L.A : L.AM;
   double* pivs = L.red;  // the D pivots
+  // the copy of the covariance that outlives the sweeps (they work in L.A / L.AM): L.AX while the squarings need L.A and
+  // L.V, else L.V; none where the carve has no separate matrices (k_ell_wave's leaves: no axis wanted either)
+  double* keep = (L.V != nullptr && L.AX != L.A) ? (want_axis ? L.AX : L.V) : nullptr;
+  if (cov_keep) *cov_keep = keep;
   PH_T0();
-  bool bad = false;
-  if (j < D)
-    for (int i = i0; i < D; i += istep) {
-      const double c = cov[i * LD + j];
-      if (!isfinite(c)) bad = true;
-      src[i * LD + j] = c;
-    }
-  if (__syncthreads_or(bad ? 1 : 0)) return false;
+  if (!prepared) {
+    bool bad = false;
+    if (j < D)
+      for (int i = i0; i < D; i += istep) {
+        const double c = L.A[i * LD + j];
+        if (!isfinite(c)) bad = true;
+        if (src != L.A) src[i * LD + j] = c;
+        if (keep) keep[i * LD + j] = c;
+      }
+    if (__syncthreads_or(bad ? 1 : 0)) return false;
+  }
+  // (the squarings and the Rayleigh quotient read the covariance from `keep` where there is one, else from `cov`: two
+  // code paths, not one pointer -- a pointer that may be LDS or global is a generic one, and its loads FLAT loads)
   const double tr_cov = wave_trace(src, D, LD);
   bool ok = true;
   int k = 0;
@@ -1212,8 +1336,11 @@ __device__ __forceinline__ bool spd_fast(const Lds& L, const double* cov, int D,
   if (!(tr_cov * tr_am < kFastCond)) return false;
   *logdet = ld;
   PH_ADD(13);
-  for (int e = t; e < D * D; e += NT) L.AX[(e / D) * LD + e % D] = 0.0;
-  if (t < D) L.lam[t] = 0.0;
+  // (with the copy kept in L.AX the matrix is zeroed where the axis is written, at the end)
+  if (!(want_axis && keep == L.AX)) {
+    for (int e = t; e < D * D; e += NT) L.AX[(e / D) * LD + e % D] = 0.0;
+    if (t < D) L.lam[t] = 0.0;
+  }
   if (!want_axis) {
     __syncthreads();
     return true;
@@ -1221,9 +1348,14 @@ __device__ __forceinline__ bool spd_fast(const Lds& L, const double* cov, int D,
   if (D == 1) {
     __syncthreads();
     if (t == 0) {
-      L.AX[0] = sqrt(cov[0]);
-      L.lam[0] = cov[0];
+      const double c = keep ? keep[0] : cov[0];
+      if (keep) {
+        L.V[0] = c;  // (the copy moves out of L.AX)
+      }
+      L.AX[0] = sqrt(c);
+      L.lam[0] = c;
     }
+    if (cov_keep && keep) *cov_keep = L.V;
     __syncthreads();
     return true;
   }
@@ -1232,7 +1364,10 @@ __device__ __forceinline__ bool spd_fast(const Lds& L, const double* cov, int D,
   double* Q = L.V;
   {
     const double s0 = ldexp(1.0, -(ilogb(tr_cov) + 1));  // trace in [1/2, 1)
-    for (int e = t; e < D * D; e += NT) P[(e / D) * LD + e % D] = cov[(e / D) * LD + e % D] * s0;
+    if (keep)
+      for (int e = t; e < D * D; e += NT) P[(e / D) * LD + e % D] = keep[(e / D) * LD + e % D] * s0;
+    else
+      for (int e = t; e < D * D; e += NT) P[(e / D) * LD + e % D] = cov[(e / D) * LD + e % D] * s0;
   }
   __syncthreads();
   double trP = wave_trace(P, D, LD);
@@ -1258,7 +1393,8 @@ __device__ __forceinline__ bool spd_fast(const Lds& L, const double* cov, int D,
   // column with the largest diagonal entry (v_j^2); normalise; canonical sign (largest component > 0)
   __shared__ double s_v[64];
   if (t < 64) {
-    double best = t < D ? P[t * LD + t] : -1.0;
+    const double pdiag = P[(t < D ? t : 0) * (LD + 1)];
+    double best = t < D ? pdiag : -1.0;
     int bi = t < D ? t : 0;
     auto take_max = [&](double ob, int oi) {  // larger value, lower index on ties
       if (ob > best || (ob == best && oi < bi)) {
@@ -1272,7 +1408,7 @@ __device__ __forceinline__ bool spd_fast(const Lds& L, const double* cov, int D,
     take_max(xor_lane<4>(best), xor_lane_i32<4>(bi));
     take_max(xor_lane<2>(best), xor_lane_i32<2>(bi));
     take_max(xor_lane<1>(best), xor_lane_i32<1>(bi));
-    const double x = t < D ? P[t * LD + bi] : 0.0;
+    const double x = sel_ld(P, t * LD + bi, t < D);
     const double nn = wave_sum(x * x);
     double ax = fabs(x);
     int ai = t;
@@ -1294,17 +1430,83 @@ __device__ __forceinline__ bool spd_fast(const Lds& L, const double* cov, int D,
   }
   __syncthreads();
   // lam_max = v^T cov v
+  if (keep != L.AX) {
+    if (t < 64) {
+      double y = 0.0;
+      if (t < D) {
+        if (keep)
+          for (int k = 0; k < D; ++k) y = fma(keep[t * LD + k], s_v[k], y);
+        else
+          for (int k = 0; k < D; ++k) y = fma(cov[t * LD + k], s_v[k], y);
+      }
+      const double q = wave_sum(t < D ? y * s_v[t] : 0.0);
+      if (t < D) L.AX[t * LD] = s_v[t] * sqrt(q);
+      if (t == 0) L.lam[0] = q;
+    }
+    __syncthreads();
+    PH_ADD(15);
+    return L.lam[0] > 0.0 && isfinite(L.lam[0]);
+  }
+  // the copy sits in L.AX: wave 0 forms the quotient from it, then every thread moves its entries of the copy to the
+  // squaring buffer that is free now (Q) and writes the axis matrix -- column 0 = sqrt(lam_max) v, zero elsewhere: the
+  // same values as above
+  __shared__ double s_q;
   if (t < 64) {
     double y = 0.0;
     if (t < D)
-      for (int k = 0; k < D; ++k) y = fma(cov[t * LD + k], s_v[k], y);
+      for (int k = 0; k < D; ++k) y = fma(L.AX[t * LD + k], s_v[k], y);
     const double q = wave_sum(t < D ? y * s_v[t] : 0.0);
-    if (t < D) L.AX[t * LD] = s_v[t] * sqrt(q);
-    if (t == 0) L.lam[0] = q;
+    if (t == 0) s_q = q;
   }
   __syncthreads();
-  PH_ADD(15);
-  return L.lam[0] > 0.0 && isfinite(L.lam[0]);
+  {
+    const double q = s_q, rq = sqrt(q);
+    for (int e = t; e < D * D; e += NT) {
+      const int i = e / D, jj = e - i * D, o = i * LD + jj;
+      Q[o] = L.AX[o];
+      L.AX[o] = jj == 0 ? s_v[i] * rq : 0.0;
+    }
+    if (t < D) L.lam[t] = t == 0 ? q : 0.0;
+    if (cov_keep) *cov_keep = Q;
+    __syncthreads();
+    PH_ADD(15);
+    return q > 0.0 && isfinite(q);
+  }
+}
+
+// (round 6) ellipsoid_rescale + ellipsoid_store_fast in one pass over the record: the rescaled covariance is formed from
+// the LDS copy spd_fast kept (no read of the global working copy, no read-modify-write of it in front of a second
+// read), precision matrix and axis are scaled on their way out.  The same products and quotients: the same bits.
+template <int NT = kThreads>
+__device__ __forceinline__ int ellipsoid_finish_fast(const Lds& L, const RebuildArgs& a, double* es, double* cov_g,
+                                                     const double* cov_keep, double fmx, double logdet,
+                                                     double* logvol_out) {
+  const int D = a.d, t = threadIdx.x, LD = L.LD, DD = D * D;
+  if (!isfinite(logdet)) return DH_ERR_VALUE;
+  const double lim = 1.0 - kRoundDelta;
+  const bool sc = fmx > lim;
+  const double mult = fmx / lim, rt = sqrt(mult);
+  if (t < D) {
+    st_c(L, es + t, L.mean[t]);
+    double lam = L.lam[t];
+    if (sc) lam *= mult;
+    st_c(L, es + D + 3 * DD + t, sqrt(lam));
+  }
+  for (int e = t; e < DD; e += NT) {
+    const int i = e / D, j = e - i * D, o = i * LD + j;
+    double c = cov_keep[o], am = L.AM[o], ax = L.AX[o];
+    if (sc) {
+      c *= mult;
+      am /= mult;
+      ax *= rt;
+      cov_g[o] = c;
+    }
+    st_c(L, es + D + e, c);
+    st_c(L, es + D + DD + e, am);
+    st_c(L, es + D + 2 * DD + e, ax);
+  }
+  *logvol_out = a.prefactor + 0.5 * logdet;
+  return DH_OK;
 }
 
 // enlarge the ellipsoid so that the outermost point sits at 1 - ROUND_DELTA (bounding.py:1438-1448)
@@ -1387,38 +1589,50 @@ constexpr int kFullRecord = 1;  // node_ellipsoid<true>: done, but by the refere
 // FAST = true: the eigen-free path; a node it does not apply to takes the reference's route in place with
 //              the compact wave-level solver (returns kFullRecord);
 // FAST = false: the reference's route (improve_covar_mat with a full eigh per trial) for every node.
-template <bool FAST>
+// CHILD = true (round 6; the level kernel k_ell<false>): the node is a k-means child -- its mean is in the record, so the
+// mean pass and the root's tile-ordered covariance are not even compiled in -- and a node the eigen-free path declines
+// is handed to the work-queue tail (kDeferred) instead of taking the reference's route in place: k_ell<false> carried
+// the wave-level Jacobi, the 100-trial loop and a second Mahalanobis pass for a path that tree nodes of real live sets
+// almost never take, and paid for them in registers (256 + 40 spilled).  The tail's workers run the full routine.
+constexpr int kDeferred = 3;
+template <bool FAST, bool CHILD = false>
 __device__ __forceinline__ int node_ellipsoid(const Lds& L, const RebuildArgs& a, const double* pts, const int* perm,
                                               int start, int count, double* es, double* cov_g, double* logvol_out,
                                               double* fmax_out, bool have_mean = false) {
   const int D = a.d, t = threadIdx.x, LD = L.LD;
   if (count == 1) return DH_ERR_VALUE;
   PH_T0();
-  if (have_mean) {  // left in the record by k_split (the final k-means centroid of this cluster)
+  if (CHILD || have_mean) {  // left in the record by k_split (the final k-means centroid of this cluster)
     if (t < D) L.mean[t] = ld_c(L, es + t);
     __syncthreads();
   } else {
     node_mean(L, pts, perm, start, count, D);
   }
   PH_ADD(0);
-  node_cov(L, pts, perm, start, count, D, !have_mean);  // no mean handed down = the root
+  int fused = 0;  // 1 / 2: the fused fold has filed the covariance everywhere (finite / not finite)
+  node_cov(L, pts, perm, start, count, D, CHILD ? false : !have_mean, FAST ? cov_g : nullptr, &fused);  // no mean handed down = the root
   PH_ADD(1);
   // cov_g: this node's D x LD working covariance (global scratch, L2 resident)
-  for (int e = t; e < D * D; e += kThreads) cov_g[(e / D) * LD + e % D] = L.A[(e / D) * LD + e % D];
-  __syncthreads();
+  if (!fused) {
+    for (int e = t; e < D * D; e += kThreads) cov_g[(e / D) * LD + e % D] = L.A[(e / D) * LD + e % D];
+    __syncthreads();
+  }
   if constexpr (FAST) {
     // eigen-free path: good_mat is certain, so the reference's loop ends after its first pass
     double logdet = 0.0;
-    if (spd_fast(L, cov_g, D, a.mode == 0 && count >= 4 * D, &logdet)) {
+    const double* cov_keep = nullptr;
+    if (fused != 2 && spd_fast(L, cov_g, D, a.mode == 0 && count >= 4 * D, &logdet, &cov_keep, fused == 1)) {
       const double fmx = node_fmax(L, pts, perm, start, count, D);
       PH_ADD(3);
       if (fmx > 1.0 - kRoundDelta) logdet += (double)D * log(fmx / (1.0 - kRoundDelta));
-      ellipsoid_rescale(L, cov_g, D, fmx);
       *fmax_out = fmin(fmx, 1.0 - kRoundDelta);  // the quadratic forms scale with am: fmx / mult
+      if (cov_keep != nullptr) return ellipsoid_finish_fast(L, a, es, cov_g, cov_keep, fmx, logdet, logvol_out);
+      ellipsoid_rescale(L, cov_g, D, fmx);
       return ellipsoid_store_fast(L, a, es, cov_g, logdet, logvol_out);
     }
     // the eigen-free path does not apply (not positive definite, condition bound >= 1e7, degenerate
     // leading eigenvalues): the reference's route, right here, with the wave-level solver
+    if constexpr (CHILD) return kDeferred;
     __syncthreads();
     for (int pass = 0; pass < 2; ++pass) {
       const bool good = regularize<true>(L, cov_g, D);
@@ -1472,6 +1686,41 @@ __device__ __forceinline__ void drain_stores() {
   __builtin_amdgcn_s_waitcnt(0x0F70);  // gfx9 encoding: vmcnt(0), expcnt / lgkmcnt untouched
 }
 
+// ---- tagged exchange of the k-means partials (round 6) -----------------------------------------------------------
+// An iteration of a multi-part node used to cost four device-scope round trips in a row (13 000 cycles with 16 parts:
+// the largest item of the top levels): partials stored, stores acknowledged (vmcnt 0), arrival counted by a returning
+// atomic, counter polled, partials fetched.  Now every partial travels as ONE 16-byte store (value, tag) -- tag =
+// (rebuild epoch, level, iteration), unique for the slot's whole life -- and a reader polls the words it needs until
+// they carry the tag of the iteration: no counter, no acknowledgement, the data is its own signal; an iteration costs
+// one store propagation and the polling loads that overlap it.  16-byte global accesses are single requests (not
+// torn); agent scope (sc1: write through / bypass, as the compiler emits for the 8-byte __hip_atomic forms).
+typedef double dh_d2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void st_agent16(double* p, double v, unsigned long long tag) {
+  dh_d2 x;
+  x.x = v;
+  x.y = __longlong_as_double((long long)tag);
+  // (s_nop: a store of more than 8 bytes must not be followed at once by a write to its data registers -- the compiler's
+  // hazard recognizer inserts the wait state for its own stores, it does not look inside an asm statement.  Without it
+  // a build whose next instruction happened to clear v[2:3] published zeros: found with the spilling register budgets)
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(x) : "memory");
+}
+// eight 16-byte agent-scope loads in flight together, one wait
+__device__ __forceinline__ void ld_agent16x8(const double* const (&p)[8], dh_d2 (&v)[8]) {
+  asm volatile(
+      "global_load_dwordx4 %0, %8, off sc1\n\t"
+      "global_load_dwordx4 %1, %9, off sc1\n\t"
+      "global_load_dwordx4 %2, %10, off sc1\n\t"
+      "global_load_dwordx4 %3, %11, off sc1\n\t"
+      "global_load_dwordx4 %4, %12, off sc1\n\t"
+      "global_load_dwordx4 %5, %13, off sc1\n\t"
+      "global_load_dwordx4 %6, %14, off sc1\n\t"
+      "global_load_dwordx4 %7, %15, off sc1\n\t"
+      "s_waitcnt vmcnt(0)"
+      : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+      : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6]), "v"(p[7])
+      : "memory");
+}
+
 __device__ __forceinline__ bool parts_barrier(int* bar, int target) {
   __shared__ int ok_flag;
   drain_stores();
@@ -1493,13 +1742,64 @@ __device__ __forceinline__ bool parts_barrier(int* bar, int target) {
   return ok_flag != 0;
 }
 
+// The label sums of one wave's 64 points (see node_kmeans_part): two accumulator chains per dimension block, groups of
+// four points alternating between them -- the arithmetic of rounds 3-5, bit for bit.  What round 6 changed is how the
+// operands arrive.  The old loop asked `point valid && dimension valid ? tile[..] : 0` and `labels[p] == cluster` of
+// LDS for every operand: every one of those loads became a block of its own under a saved exec mask with `s_waitcnt 0`
+// behind it -- 48 serialised LDS round trips, 4 100 cycles per Lloyd iteration.  Now:
+//   * the indicators come from the wave's own label ballots (`sel`: bit b set = point b of this wave carries this
+//     lane's indicator row), no label array in LDS;
+//   * rows beyond the part's points are ZERO in the tile (node_kmeans_part fills them after staging), so a row load
+//     needs no predicate; columns beyond D read whatever follows in LDS -- they only ever reach output columns >= D,
+//     which nobody reads (a 4x4x4 block's column j depends on B's column j alone);
+//   * four groups of eight points are straight-line code (all loads in flight before the first product), twice.
+template <bool NB3>
+__device__ __forceinline__ void kmeans_label_sums(const Lds& L, unsigned long long sel, double& o0, double& o1, double& o2) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, LD = L.LD;
+  const int lj = lane & 15, lk = lane >> 4;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, b0 = 0.0, b1 = 0.0, b2 = 0.0;
+  const unsigned long long mine = sel >> lk;  // bit 8 g (+ 4): this lane's indicator for the (second) point of group g
+  const double* base = L.tile + (w * 64 + lk) * LD + lj;
+#pragma unroll 1
+  for (int h = 0; h < 2; ++h) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int g8 = h * 4 + g;
+      const double ind = ((mine >> (8 * g8)) & 1ull) ? 1.0 : 0.0;
+      const double indb = ((mine >> (8 * g8 + 4)) & 1ull) ? 1.0 : 0.0;
+      const double* row = base + g8 * 8 * LD;
+      const double* rowb = row + 4 * LD;
+      a0 = DH_MFMA_F64_4X4(ind, row[0], a0);
+      b0 = DH_MFMA_F64_4X4(indb, rowb[0], b0);
+      a1 = DH_MFMA_F64_4X4(ind, row[16], a1);
+      b1 = DH_MFMA_F64_4X4(indb, rowb[16], b1);
+      if constexpr (NB3) {
+        a2 = DH_MFMA_F64_4X4(ind, row[32], a2);
+        b2 = DH_MFMA_F64_4X4(indb, rowb[32], b2);
+      }
+    }
+  }
+  o0 = a0 + b0;
+  o1 = a1 + b1;
+  o2 = a2 + b2;
+}
+
+// lane l's value of a double, to every lane (l uniform): two v_readlane_b32 -- no LDS round trip
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+  const long long b = __double_as_longlong(v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, l);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)b >> 32), l);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
 // One part's share of the k-means + partition of node [start, start+count).  q = part
 // index, np = number of parts, kp = this node's partial-sum slots (2 parities x np x KP),
 // bar = its barrier counter.  Returns n0 (size of cluster 0) or -1 on a barrier timeout;
 // on return perm[start + q TP ...] holds the partitioned order if the split is viable.
 __device__ int node_kmeans_part(const Lds& L, const double* pts, int* perm, int* perm2, int start, int count,
                                 int D, const double* es, int q, int np, double* kp0, double* kp1, int* bar,
-                                int min_size) {
+                                int min_size, unsigned long long tag0, int lvl = 0) {
+  LV_T0();
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, LD = L.LD;
   const int DD = D * D, KP = 2 * D + 2;
   const int s0 = start + q * L.TP, cnt = min(L.TP, count - q * L.TP);
@@ -1507,6 +1807,7 @@ __device__ int node_kmeans_part(const Lds& L, const double* pts, int* perm, int*
   if (t < D) L.sums[t] = ld_c(L, es + D + 3 * DD + t);  // axis lengths: one parallel fetch, then a scan in LDS
   __syncthreads();
   if (t == 0) {
+    L.ri[303] = 0;  // (set if a partner's partials never arrive)
     int best = 0;
     double bl = L.sums[0];
     for (int k = 1; k < D; ++k)
@@ -1527,33 +1828,65 @@ __device__ int node_kmeans_part(const Lds& L, const double* pts, int* perm, int*
   const int nb = (D + 15) >> 4;
   const int lj = lane & 15, lk = lane >> 4;
   int lb = 0, lb_prev = -1, n0 = 0, c0_tile = 0, last_it = 9;
+  LV_ADD(lvl, 0);
+  LV_SET(lvl, 5, np);
+  LV_SET(lvl, 6, count);
   PH_T0();
+  // (round 6) rows [cnt, 64 ceil(cnt / 64)) of the tile are zeroed once: the label sums then load rows without a
+  // predicate (an indicator of 0 times a stale NaN would still be NaN)
+  {
+    const int rup = min(L.TP, (cnt + 63) & ~63);
+    const int jz = t & (L.DP - 1), pz0 = cnt + (t >> L.DPlog), pzs = kThreads >> L.DPlog;
+    if (jz < D)
+      for (int pz = pz0; pz < rup; pz += pzs) L.tile[pz * LD + jz] = 0.0;
+    __syncthreads();
+  }
+  unsigned long long m0 = 0ull, m1 = 0ull;  // this wave's label ballots (valid points only)
   for (int it = 0; it < 10; ++it) {
-    // vq: nearest centroid, strict '<' so the lower index wins ties
-    if (t < cnt) {
-      const double* x = L.tile + t * LD;
+    // vq: nearest centroid, strict '<' so the lower index wins ties.  (round 6) The centroids ride in the lanes of two
+    // registers (lane j: coordinate j) and reach the distance loop through v_readlane: two LDS loads per wave and
+    // iteration instead of two per dimension and point -- with four to five parts per CU the LDS pipe was half of
+    // an iteration's time at 64 runs.  Same differences, same fma chains: the same bits.
+    const bool has = t < cnt;
+    if (w * 64 < cnt) {  // (uniform per wave)
+      const double c0l = L.cen[lane < D ? lane : 0], c1l = L.cen[D + (lane < D ? lane : 0)];
+      const double* x = L.tile + (has ? t : 0) * LD;
       double d0 = 0.0, d1 = 0.0;
-      // loads of four dimensions in flight per LDS round trip (same summation order)
-#pragma unroll 4
-      for (int jj = 0; jj < D; ++jj) {
-        const double xv = x[jj];
-        const double e0 = xv - L.cen[jj], e1 = xv - L.cen[D + jj];
-        d0 = fma(e0, e0, d0);
-        d1 = fma(e1, e1, d1);
+      // eight coordinates of the point fetched together (clamped offsets: unconditional loads), then their eight
+      // steps of the two chains -- the compiler does not unroll the loop around the lane reads by itself, and one
+      // LDS round trip per dimension was 4 000 cycles an iteration
+      for (int j0 = 0; j0 < D; j0 += 8) {
+        double xv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) xv[u] = x[min(j0 + u, D - 1)];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (j0 + u < D) {  // (uniform)
+            const double e0 = xv[u] - readlane_f64(c0l, j0 + u), e1 = xv[u] - readlane_f64(c1l, j0 + u);
+            d0 = fma(e0, e0, d0);
+            d1 = fma(e1, e1, d1);
+          }
       }
       lb = d1 < d0 ? 1 : 0;
-      L.ri[t] = lb;
     }
+    LV_ADD(lvl, 8);
     {
       // labels that moved since the last iteration (per wave, summed after the barrier): none anywhere in the node
       // = a fixed point of the Lloyd iteration, the remaining iterations would reproduce this one bit for bit
-      const unsigned long long mv = __ballot(t < cnt && lb != lb_prev);
-      if (lane == 0) L.ri[260 + w] = __popcll(mv);
+      const unsigned long long mv = __ballot(has && lb != lb_prev);
+      m1 = __ballot(has && lb == 1);
+      m0 = __ballot(has && lb == 0);
+      if (lane == 0) {
+        L.ri[260 + w] = __popcll(mv);
+        L.ri[264 + w] = __popcll(m0);
+      }
       lb_prev = lb;
     }
-    c0_tile = __syncthreads_count(t < cnt && lb == 0);  // also publishes the labels
+    __syncthreads();  // (one barrier: __syncthreads_count is three)
+    c0_tile = L.ri[264] + L.ri[265] + L.ri[266] + L.ri[267];
     const int ch_tile = L.ri[260] + L.ri[261] + L.ri[262] + L.ri[263];
     PH_ADD(10);
+    LV_ADD(lvl, 9);
     // update_cluster_means: per-cluster sums = Labels^T X on the matrix cores; wave w
     // contracts its 64 points (rows 0/1 of the 16-row A operand are the two indicators)
     // Only two of a 16x16x4 tile's sixteen rows would carry indicators, and on gfx950 that
@@ -1563,30 +1896,15 @@ __device__ int node_kmeans_part(const Lds& L, const double* pts, int* perm, int*
     // B column = dimension lane & 15, k = lane >> 4; D row = lane >> 4, dimension lane & 15.
     // two independent accumulator chains (groups of 4 points alternate between them): a dependent
     // chain of 16 x 3 matrix instructions per wave was most of this phase
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0, b0 = 0.0, b1 = 0.0, b2 = 0.0;
-    const int pend = min(cnt, w * 64 + 64);
-    const int li = lane & 3;
-    for (int p0 = w * 64; p0 < pend; p0 += 8) {
-      const int p = p0 + lk, pb = p0 + 4 + lk;
-      const bool pv = p < cnt, pvb = pb < cnt;
-      const double ind = (pv && li < 2 && L.ri[pv ? p : 0] == li) ? 1.0 : 0.0;
-      const double indb = (pvb && li < 2 && L.ri[pvb ? pb : 0] == li) ? 1.0 : 0.0;
-      const double* row = L.tile + p * LD + lj;
-      const double* rowb = L.tile + pb * LD + lj;
-      a0 = DH_MFMA_F64_4X4(ind, (pv && lj < D) ? row[0] : 0.0, a0);
-      b0 = DH_MFMA_F64_4X4(indb, (pvb && lj < D) ? rowb[0] : 0.0, b0);
-      if (nb > 1) {
-        a1 = DH_MFMA_F64_4X4(ind, (pv && 16 + lj < D) ? row[16] : 0.0, a1);
-        b1 = DH_MFMA_F64_4X4(indb, (pvb && 16 + lj < D) ? rowb[16] : 0.0, b1);
-      }
-      if (nb > 2) {
-        a2 = DH_MFMA_F64_4X4(ind, (pv && 32 + lj < D) ? row[32] : 0.0, a2);
-        b2 = DH_MFMA_F64_4X4(indb, (pvb && 32 + lj < D) ? rowb[32] : 0.0, b2);
-      }
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    if (w * 64 < cnt) {
+      const int li = lane & 3;
+      const unsigned long long sel = li == 0 ? m0 : li == 1 ? m1 : 0ull;
+      if (nb > 2)
+        kmeans_label_sums<true>(L, sel, a0, a1, a2);
+      else
+        kmeans_label_sums<false>(L, sel, a0, a1, a2);
     }
-    a0 += b0;
-    a1 += b1;
-    a2 += b2;
     // result rows 0 and 1 (the two clusters) sit in lanes 0..15 and 16..31
     if (lane < 32) {
       double* o = L.kred + (w * 2 + lk) * 48;
@@ -1594,8 +1912,10 @@ __device__ int node_kmeans_part(const Lds& L, const double* pts, int* perm, int*
       if (nb > 1) o[16 + lj] = a1;
       if (nb > 2) o[32 + lj] = a2;
     }
+    LV_ADD(lvl, 10);
     __syncthreads();
     PH_ADD(11);
+    LV_ADD(lvl, 11);
     double* kp = (it & 1) ? kp1 : kp0;
     if (t < 2 * D) {
       const int c = t >= D ? 1 : 0, j = t - c * D;
@@ -1607,7 +1927,6 @@ __device__ int node_kmeans_part(const Lds& L, const double* pts, int* perm, int*
         for (int wv = g0; wv < g0 + L.KG; ++wv) gs += L.kred[(wv * 2 + c) * 48 + j];
         sum += gs;
       }
-      if (np > 1) st_agent(kp + (size_t)q * KP + c * D + j, sum);
       L.sums[c * D + j] = sum;
       if (np == 1) {
         // a node that is one part: the thread that holds a cluster sum forms the centroid entry right away (the
@@ -1617,31 +1936,44 @@ __device__ int node_kmeans_part(const Lds& L, const double* pts, int* perm, int*
       }
     }
     n0 = c0_tile;
+    LV_ADD(lvl, 12);
     if (np > 1) {
-      if (t == 0) {
-        st_agent(kp + (size_t)q * KP + 2 * D, (double)c0_tile);
-        st_agent(kp + (size_t)q * KP + 2 * D + 1, (double)ch_tile);
-      }
-      if (!parts_barrier(bar, np * (it + 1))) return -1;
-      // the partners' partials: 8 independent bypassing loads in flight per round trip (a plain
-      // loop serialises np ~2 us memory-side round trips), summed in part order.  Column 2D is
-      // the label-0 count, read by every thread.
-      {
-        const int col = t < 2 * D + 2 ? t : 2 * D;  // column 2D + 1: the number of labels that moved
+      // publish this part's row (columns 0 .. 2D-1: the cluster sums, 2D: the label-0 count, 2D + 1: labels that moved),
+      // then fetch every partner's -- the threads that file a column poll it, summed in part order (deterministic)
+      const unsigned long long tag = tag0 + (unsigned long long)(it + 1);
+      if (t < KP) {
+        const double mine = t < 2 * D ? L.sums[t] : t == 2 * D ? (double)c0_tile : (double)ch_tile;  // (own entry: written by this thread)
+        st_agent16(kp + ((size_t)q * KP + t) * 2, mine, tag);
         double sum = 0.0;
-        for (int pp0 = 0; pp0 < np; pp0 += 8) {
-          double part[8];
+        bool ok = true;
+        for (int pp0 = 0; pp0 < np && ok; pp0 += 8) {
+          const double* ptr[8];
+          dh_d2 v[8];
 #pragma unroll
-          for (int uu = 0; uu < 8; ++uu)
-            part[uu] = pp0 + uu < np ? ld_agent(kp + (size_t)(pp0 + uu) * KP + col) : 0.0;
+          for (int uu = 0; uu < 8; ++uu) ptr[uu] = kp + ((size_t)min(pp0 + uu, np - 1) * KP + t) * 2;
+          for (int spins = 0;; ++spins) {
+            ld_agent16x8(ptr, v);
+            bool all = true;
 #pragma unroll
-          for (int uu = 0; uu < 8; ++uu) sum += part[uu];
+            for (int uu = 0; uu < 8; ++uu) all = all && (unsigned long long)__double_as_longlong(v[uu].y) == tag;
+            if (all) break;
+            if (spins > (1 << 18)) {  // a partner never arrived (would otherwise hang the device)
+              ok = false;
+              break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+          }
+#pragma unroll
+          for (int uu = 0; uu < 8; ++uu) sum += pp0 + uu < np ? v[uu].x : 0.0;
         }
-        if (t < 2 * D + 2) L.sums[t] = sum;
+        if (!ok) L.ri[303] = 1;
+        L.sums[t] = sum;
       }
       __syncthreads();
+      if (L.ri[303]) return -1;
       n0 = (int)L.sums[2 * D];
     }
+    LV_ADD(lvl, 13);
     const int moved = np > 1 ? (int)L.sums[2 * D + 1] : ch_tile;
     if (np > 1) {
       const int n1 = count - n0;
@@ -1652,22 +1984,25 @@ __device__ int node_kmeans_part(const Lds& L, const double* pts, int* perm, int*
     }
     __syncthreads();
     PH_ADD(12);
+    LV_ADD(lvl, 14);
     if (moved == 0) {  // (never at it = 0: every label counts as moved there)
       last_it = it;
       break;
     }
   }
+  LV_ADD(lvl, 1);
+  LV_SET(lvl, 4, last_it + 1);
   if (min(n0, count - n0) < min_size) return n0;  // split rejected (:1521-1522): no partition needed
   // ---- stable partition by label (label 0 first) ----
   // ranks inside the tile from wave ballots; offsets of this part from the partners' counts
   const bool valid = t < cnt;
-  const unsigned long long m0 = __ballot(valid && lb == 0);
+  const unsigned long long pm0 = __ballot(valid && lb == 0);
   const unsigned long long lt = (1ull << lane) - 1ull;
-  if (lane == 0) L.ri[256 + w] = __popcll(m0);
+  if (lane == 0) L.ri[256 + w] = __popcll(pm0);
   __syncthreads();
   int before0 = 0;
   for (int wv = 0; wv < w; ++wv) before0 += L.ri[256 + wv];
-  const int rank0 = before0 + __popcll(m0 & lt);
+  const int rank0 = before0 + __popcll(pm0 & lt);
   int off0 = 0, off1 = n0;
   if (np > 1) {
     const double* kp = (last_it & 1) ? kp1 : kp0;  // the last iteration run
@@ -1675,7 +2010,10 @@ __device__ int node_kmeans_part(const Lds& L, const double* pts, int* perm, int*
       double part[8];
 #pragma unroll
       for (int uu = 0; uu < 8; ++uu)
-        part[uu] = pp0 + uu < q ? ld_agent(kp + (size_t)(pp0 + uu) * KP + 2 * D) : 0.0;
+      {
+        const double pv8 = ld_agent(kp + ((size_t)min(pp0 + uu, q - 1) * KP + 2 * D) * 2);  // (the value half of the pair)
+        part[uu] = pp0 + uu < q ? pv8 : 0.0;
+      }
 #pragma unroll
       for (int uu = 0; uu < 8; ++uu)
         if (pp0 + uu < q) {
@@ -1693,7 +2031,7 @@ __device__ int node_kmeans_part(const Lds& L, const double* pts, int* perm, int*
       perm2[start + pos] = src;
   }
   if (np > 1) {
-    if (!parts_barrier(bar, np * (last_it + 2))) return -1;
+    if (!parts_barrier(bar, np)) return -1;  // (the node's only counted barrier: the iterations exchange tagged words)
     if (valid) st_ci(L, perm + s0 + t, ld_agent_i(perm2 + s0 + t));
   } else if (L.coh) {
     drain_stores();
@@ -1704,6 +2042,7 @@ __device__ int node_kmeans_part(const Lds& L, const double* pts, int* perm, int*
     __syncthreads();
     if (valid) perm[s0 + t] = perm2[s0 + t];
   }
+  LV_ADD(lvl, 2);
   return n0;
 }
 
@@ -1937,7 +2276,7 @@ __device__ __forceinline__ void queue_split(const RebuildArgs& a, int run, int l
 // writes the node; if the covariance needed regularising it falls back to the single-workgroup
 // routine for the rest (rare path, same code as k_root).
 // rootbuf per run: [np x D sums | np x D^2 cov partials | np fmax | np x D squares | D^2 am | 8 flags]
-__global__ void __launch_bounds__(kThreads) k_root_parts(RebuildArgs a, int rp) {
+__global__ void __launch_bounds__(kThreads, 2) k_root_parts(RebuildArgs a, int rp) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int D = a.d, DD = D * D, t = threadIdx.x, run = blockIdx.x / rp, q = blockIdx.x % rp;
   const int n = a.n_arr ? a.n_arr[run] : a.n;
@@ -2004,7 +2343,10 @@ __global__ void __launch_bounds__(kThreads) k_root_parts(RebuildArgs a, int rp) 
       for (int pp0 = 0; pp0 < np; pp0 += 8) {
         double part[8];
 #pragma unroll
-        for (int uu = 0; uu < 8; ++uu) part[uu] = pp0 + uu < np ? ld_agent(b_sum + (size_t)(pp0 + uu) * D + t) : 0.0;
+        for (int uu = 0; uu < 8; ++uu) {
+          const double pv8 = ld_agent(b_sum + (size_t)min(pp0 + uu, np - 1) * D + t);
+          part[uu] = pp0 + uu < np ? pv8 : 0.0;
+        }
 #pragma unroll
         for (int uu = 0; uu < 8; ++uu) sum += part[uu];
       }
@@ -2036,7 +2378,10 @@ __global__ void __launch_bounds__(kThreads) k_root_parts(RebuildArgs a, int rp) 
             double part[8];
 #pragma unroll
             for (int uu = 0; uu < 8; ++uu)
-              part[uu] = pp0 + uu < np ? ld_agent(b_cov + (size_t)(pp0 + uu) * DD + e) : 0.0;
+            {
+              const double pv8 = ld_agent(b_cov + (size_t)min(pp0 + uu, np - 1) * DD + e);
+              part[uu] = pp0 + uu < np ? pv8 : 0.0;
+            }
 #pragma unroll
             for (int uu = 0; uu < 8; ++uu) sum += part[uu];
           }
@@ -2139,7 +2484,10 @@ __global__ void __launch_bounds__(kThreads) k_root_parts(RebuildArgs a, int rp) 
         for (int pp0 = 0; pp0 < np; pp0 += 8) {
           double part[8];
 #pragma unroll
-          for (int uu = 0; uu < 8; ++uu) part[uu] = pp0 + uu < np ? ld_agent(b_sq + (size_t)(pp0 + uu) * D + t) : 0.0;
+          for (int uu = 0; uu < 8; ++uu) {
+            const double pv8 = ld_agent(b_sq + (size_t)min(pp0 + uu, np - 1) * D + t);
+            part[uu] = pp0 + uu < np ? pv8 : 0.0;
+          }
 #pragma unroll
           for (int uu = 0; uu < 8; ++uu) sum += part[uu];
         }
@@ -2214,13 +2562,15 @@ __device__ __forceinline__ void split_body(const RebuildArgs& a, const Lds& L, c
   const int np = single ? 1 : (count + L.TP - 1) / L.TP;
   const int min_size = 2 * D;
   const int KP = 2 * D + 2;
-  double* kp0 = a.kpart + ((size_t)run * a.maxp + pb) * KP;
-  double* kp1 = kp0 + (size_t)a.runs * a.maxp * KP;
+  double* kp0 = a.kpart + ((size_t)run * a.maxp + pb) * KP * 2;  // (value, tag) pairs
+  double* kp1 = kp0 + (size_t)a.runs * a.maxp * KP * 2;
+  const unsigned long long tag0 = ((unsigned long long)a.epoch << 24) | ((unsigned long long)(level & 0xffff) << 8);
   int* bar = a.tree ? nb : a.kbar + (((size_t)level * a.runs + run) * a.maxw + slot) * kBarStride;
   PH_T0();
   const int n0 = node_kmeans_part(L, a.pts_scaled + (size_t)run * a.n * D, v.perm, v.perm2, start, count, D,
-                                  v.estore + (size_t)cur * v.NS, q, np, kp0, kp1, bar, min_size);
+                                  v.estore + (size_t)cur * v.NS, q, np, kp0, kp1, bar, min_size, tag0, level);
   PH_ADD(4);
+  LV_T0();
   if (n0 < 0) {
     if (t == 0) atomicMin(a.tree ? &a.status[run] : &a.kerr[run], DH_ERR_HIP);
     return;
@@ -2305,6 +2655,7 @@ __device__ __forceinline__ void split_body(const RebuildArgs& a, const Lds& L, c
       if (tq && t == 0) (void)tq_push(a, false, run, c0, 2);
     }
   }
+  LV_ADD(level, 3);
 }
 
 // gp = the parts per run this launch provides (the level's bound, <= a.maxp).  Run-minor like k_ell -- the q-th part
@@ -2312,7 +2663,16 @@ __device__ __forceinline__ void split_body(const RebuildArgs& a, const Lds& L, c
 // resident at once: the parts of a node meet at spin barriers, workgroups are dispatched in index order, and a chunk
 // that fits the chip can always be completed by the workgroups in front of it finishing (chunks are dispatched one
 // after the other; cr = 1 is the run-major order of rounds 2-4).
-__global__ void __launch_bounds__(kThreads) k_split(RebuildArgs a, int level, int gp, int cr) {
+__device__ __forceinline__ void k_split_impl(const RebuildArgs& a, int level, int gp, int cr);
+#ifndef DH_KSPLIT_WAVES
+#define DH_KSPLIT_WAVES 5  // waves per SIMD the register allocation leaves room for: five 31 KB parts share a CU
+#endif
+__global__ void __launch_bounds__(kThreads, DH_KSPLIT_WAVES) k_split(RebuildArgs a, int level, int gp, int cr) {
+  WG_STAMP(0, level, 0);
+  k_split_impl(a, level, gp, cr);
+  WG_STAMP(0, level, 1);
+}
+__device__ __forceinline__ void k_split_impl(const RebuildArgs& a, int level, int gp, int cr) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int per = cr * gp, chunk = blockIdx.x / per, b = blockIdx.x - chunk * per;
   const int rc = min(cr, a.runs - chunk * cr);  // runs of this chunk (the last one may be short)
@@ -2340,16 +2700,30 @@ __global__ void __launch_bounds__(kThreads) k_split(RebuildArgs a, int level, in
 
 // The bounding ellipsoid of one new child and, if it is big enough, its entry in the next level's split list.
 // Returns false after an error (status set).
-template <bool SLOW>
+// DEFER (the level kernel's eigen-free form): a node the eigen-free path declines -- or one without a mean in its
+// record, which a child never is -- goes to the work-queue tail untouched (its record is written last, so nothing of
+// it exists yet), as k_ell_wave's declined leaves do.
+template <bool SLOW, bool DEFER = false>
 __device__ __forceinline__ bool ell_body(const RebuildArgs& a, const Lds& L, const RunView& v, int run, int level, int node) {
   const int D = a.d, t = threadIdx.x;
   const int start = ld_ci(L, &v.nodes[node].start), count = ld_ci(L, &v.nodes[node].count);
   double lv = 0.0, fmx = INFINITY;
   __syncthreads();
   L.c_pts = nullptr;
-  const int rc = node_ellipsoid<!SLOW>(L, a, v.pts, v.perm, start, count, v.estore + (size_t)node * v.NS,
-                                       v.estore + (size_t)node * v.NS + v.ES, &lv, &fmx,
-                                       ld_ci(L, &v.nodes[node].has_mean) != 0);
+  int rc;
+  if constexpr (DEFER) {
+    rc = v.nodes[node].has_mean ? node_ellipsoid<true, true>(L, a, v.pts, v.perm, start, count, v.estore + (size_t)node * v.NS,
+                                                             v.estore + (size_t)node * v.NS + v.ES, &lv, &fmx, true)
+                                : kDeferred;
+    if (rc == kDeferred) {
+      if (t == 0) (void)tq_push(a, false, run, node, 1);
+      return true;
+    }
+  } else {
+    rc = node_ellipsoid<!SLOW>(L, a, v.pts, v.perm, start, count, v.estore + (size_t)node * v.NS,
+                               v.estore + (size_t)node * v.NS + v.ES, &lv, &fmx,
+                               ld_ci(L, &v.nodes[node].has_mean) != 0);
+  }
   const bool full = SLOW || rc == kFullRecord;
   if (rc != DH_OK && rc != kFullRecord) {
     set_status(a, run, rc);
@@ -2377,11 +2751,20 @@ __device__ __forceinline__ bool ell_body(const RebuildArgs& a, const Lds& L, con
 // One workgroup per new child.  SLOW = false: the eigen-free path (with its in-place fallback);
 // SLOW = true: the reference's route for every node -- the kernel of the diagnostic mode
 // DH_REBUILD_FAST=0.  Two kernels so that the common one stays small (registers: two workgroups per CU).
-template <bool SLOW>
+// DEFER (round 6): the eigen-free form alone -- what it declines goes to the work-queue tail (launched whenever there is one)
+template <bool SLOW, bool DEFER>
 // (two workgroups per CU: held to the 168 registers of three, with a 128-point tile so that LDS would allow it, the
 // eigen-free path spills and the rebuild loses 7 %)
+__device__ __forceinline__ void k_ell_impl(const RebuildArgs& a, int level, int G, int skip_done, int leaf_cap, int tp);
+template <bool SLOW, bool DEFER = false>
 __global__ void __launch_bounds__(kThreads, SLOW ? 1 : 2) k_ell(RebuildArgs a, int level, int G, int skip_done, int leaf_cap,
                                                                  int tp) {
+  WG_STAMP(1, level, 0);
+  k_ell_impl<SLOW, DEFER>(a, level, G, skip_done, leaf_cap, tp);
+  WG_STAMP(1, level, 1);
+}
+template <bool SLOW, bool DEFER>
+__device__ __forceinline__ void k_ell_impl(const RebuildArgs& a, int level, int G, int skip_done, int leaf_cap, int tp) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // run-minor: the g-th node of EVERY run before anyone's (g + 1)-th -- workgroups are dispatched in index order at
   // a finite rate (~30 per us), and with the runs major the last run's first node started after 2 600 others
@@ -2405,7 +2788,7 @@ __global__ void __launch_bounds__(kThreads, SLOW ? 1 : 2) k_ell(RebuildArgs a, i
       const Node& nd = v.nodes[list[slot]];
       if (nd.has_mean && nd.count >= 2 && nd.count <= leaf_cap && nd.count < 4 * D) continue;
     }
-    if (!ell_body<SLOW>(a, L, v, run, level, list[slot])) return;
+    if (!ell_body<SLOW, DEFER>(a, L, v, run, level, list[slot])) return;
   }
 }
 
@@ -3153,6 +3536,17 @@ void dh_rebuild_timing(long long* out16, int reset) {
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), z, sizeof z);
   }
 }
+void dh_rebuild_wg_clock(long long* out, int kern, int level) {  // kWgMax x 2 wall-clock stamps (100 MHz)
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wg_clock), (size_t)kWgMax * 2 * sizeof(long long),
+                            (((size_t)kern * 8 + level) * kWgMax * 2) * sizeof(long long));
+}
+void dh_rebuild_timing_levels(long long* out128, int reset) {
+  (void)hipMemcpyFromSymbol(out128, HIP_SYMBOL(g_lvl_cycles), 256 * sizeof(long long));
+  if (reset) {
+    long long z[256] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lvl_cycles), z, sizeof z);
+  }
+}
 #endif
 
 // see include/dynhip.h
@@ -3388,8 +3782,8 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
   const size_t b_rb = (size_t)runs * a.rootbuf_stride * 8;
   const size_t b_fl = (size_t)runs * a.max_nodes * 8, b_fi = (size_t)runs * a.max_nodes * 2 * 4;
   const size_t b_pl = (size_t)2 * runs * a.maxp * 2 * 4, b_pb = (size_t)2 * runs * a.maxw * 4;
-  const size_t b_kp = mode == 1 ? 0 : (size_t)2 * runs * a.maxp * (2 * (size_t)d + 2) * 8;
-  const size_t b_kpt = tail ? (size_t)2 * runs * a.kp_cap * (2 * (size_t)d + 2) * 8 : 0;  // the queue form's own
+  const size_t b_kp = mode == 1 ? 0 : (size_t)2 * runs * a.maxp * (2 * (size_t)d + 2) * 16;  // (value, tag) pairs
+  const size_t b_kpt = tail ? (size_t)2 * runs * a.kp_cap * (2 * (size_t)d + 2) * 16 : 0;  // the queue form's own
   const size_t b_sl = (size_t)2 * runs * a.maxw * 4, b_el = (size_t)(a.levels > 0 ? a.levels : 1) * runs * 2 * a.maxw * 4;
   const size_t b_sc = (size_t)runs * d * 8;
   const size_t b_ps = mode == 1 ? 0 : (size_t)runs * n * d * 8;
@@ -3407,6 +3801,8 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
     if (!hip_ok(ctx, hipMalloc((void**)&ctx->rebuild_ws, total), "hipMalloc(rebuild scratch)"))
       return DH_ERR_NOMEM;
     ctx->rebuild_ws_cap = total;
+    // (the k-means partials are recognised by their tags: no stale word of a fresh allocation may pass for one)
+    if (!hip_ok(ctx, hipMemsetAsync(ctx->rebuild_ws, 0, total, ctx->stream), "memset(rebuild scratch)")) return DH_ERR_HIP;
   }
   char* w = ctx->rebuild_ws;
   a.perm = (int*)w;
@@ -3484,15 +3880,16 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
   a.nnodes_out = nnodes;
   a.active = active;
   a.n_arr = n_arr;
+  a.epoch = ++ctx->rebuild_epoch;
   // k_ell's top levels: a tile of 512 points, if it fits (D <= 30); DH_ELL_TOP_TILE=0: off
   size_t lds_top = rebuild_lds_bytes(d, 2 * kThreads);
   if (lds_top > kLdsLimit || mode != 0 || (getenv("DH_ELL_TOP_TILE") && atoi(getenv("DH_ELL_TOP_TILE")) == 0)) lds_top = 0;
   DH_DEV_MEMO(attr_lds);
   DH_DEV_MEMO(attr_top);
   if (lds > attr_lds) {
-    const void* ks[7] = {(const void*)k_root_parts, (const void*)k_split, (const void*)k_ell<false>,
+    const void* ks[8] = {(const void*)k_root_parts, (const void*)k_split, (const void*)k_ell<false>,
                          (const void*)k_ell<true>, (const void*)k_out_eig, (const void*)k_root_eig,
-                         (const void*)k_tree};
+                         (const void*)k_tree, (const void*)k_ell<false, true>};
     for (const void* kf : ks)
       if (!hip_ok(ctx, hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
                   "hipFuncSetAttribute(rebuild LDS)"))
@@ -3502,6 +3899,8 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
   }
   if (lds_top > attr_top) {
     if (!hip_ok(ctx, hipFuncSetAttribute((const void*)k_ell<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_top),
+                "hipFuncSetAttribute(k_ell LDS)") ||
+        !hip_ok(ctx, hipFuncSetAttribute((const void*)k_ell<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_top),
                 "hipFuncSetAttribute(k_ell LDS)") ||
         !hip_ok(ctx, hipFuncSetAttribute((const void*)k_ell<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_top),
                 "hipFuncSetAttribute(k_ell LDS)"))
@@ -3624,7 +4023,10 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
     // pass 2 + Mahalanobis pass 1, the last tile still staged), a 500-point child once instead of three times.  Only
     // while the level's workgroups all fit the chip at one per CU (the LDS of such a tile allows no second one).
     const bool top = lds_top > 0 && (n >> (L + 1)) > kThreads && (long long)runs * ge <= ctx->num_cu;
-    if (a.fast)
+    if (a.fast && tail && !(getenv("DH_ELL_DEFER") && atoi(getenv("DH_ELL_DEFER")) == 0))
+      hipLaunchKernelGGL((k_ell<false, true>), dim3(runs * ge), dim3(kThreads), top ? lds_top : lds, ctx->stream, a, L, ge, wave, lc,
+                         top ? 2 * kThreads : kThreads);
+    else if (a.fast)
       hipLaunchKernelGGL(k_ell<false>, dim3(runs * ge), dim3(kThreads), top ? lds_top : lds, ctx->stream, a, L, ge, wave, lc,
                          top ? 2 * kThreads : kThreads);
     else
