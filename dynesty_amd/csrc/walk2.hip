@@ -680,9 +680,15 @@ struct CubeQArgs {
   const int* run_mode;
   int wpr, my_mode;
   double loglstar;
+  PhiloxKey ph;  // RNG_PHILOX
 };
 
-template <int N, bool FULL, int KIND>
+// RNG_PHILOX (round 6): the throughput mode had no four-lane form, so the resident loop's unit-cube phase ran one
+// walker per lane -- 0.74 ms per fill against 0.12 -- and the "throughput" mode was 5 % slower end to end than the
+// parity mode.  Counter based, the jump is free: try k of walker w is the 2 n words from offset + 2 n k of the stream
+// keyed (seed, seq0 + w) -- exactly what the lane kernel's sequential tries consume, so both forms give the same
+// point, count and (none) state for the same key.
+template <int N, bool FULL, int KIND, int RNG = RNG_PCG64>
 __global__ void __launch_bounds__(64, 2) cube_quad_kernel(CubeQArgs a) {
   __shared__ double sx[N * 64];
   const int lane = threadIdx.x, t = lane & 3;
@@ -701,19 +707,26 @@ __global__ void __launch_bounds__(64, 2) cube_quad_kernel(CubeQArgs a) {
   const bool idle = done;
   // jump constants: n draws (one try), and from the end of a try to the start of this lane's next one (3 n draws)
   U128 An = {0ull, 1ull}, Gn = {0ull, 0ull};
-  {
-    const U128 m = {DH_PCG_MULT_HI, DH_PCG_MULT_LO}, one = {0ull, 1ull};
-    for (int i = 0; i < n; ++i) {
-      An = mul128(An, m);
-      Gn = add128(mul128(Gn, m), one);
-    }
-  }
   Pcg64 g;
-  g.load(a.rng_in + (size_t)w * 4);
-  const U128 Cn = mul128(Gn, g.inc);
-  for (int i = 0; i < t; ++i) g.state = add128(mul128(g.state, An), Cn);  // this lane's first try starts t n draws in
-  const U128 A2 = mul128(An, An), A3 = mul128(A2, An);
-  const U128 C3 = add128(mul128(add128(mul128(Cn, An), Cn), An), Cn);  // ((Cn An) + Cn) An + Cn
+  U128 A3 = {0ull, 1ull}, C3 = {0ull, 0ull};
+  hiprandStatePhilox4_32_10_t st;
+  if constexpr (RNG == RNG_PCG64) {
+    {
+      const U128 m = {DH_PCG_MULT_HI, DH_PCG_MULT_LO}, one = {0ull, 1ull};
+      for (int i = 0; i < n; ++i) {
+        An = mul128(An, m);
+        Gn = add128(mul128(Gn, m), one);
+      }
+    }
+    g.load(a.rng_in + (size_t)w * 4);
+    const U128 Cn = mul128(Gn, g.inc);
+    for (int i = 0; i < t; ++i) g.state = add128(mul128(g.state, An), Cn);  // this lane's first try starts t n draws in
+    const U128 A2 = mul128(An, An);
+    A3 = mul128(A2, An);
+    C3 = add128(mul128(add128(mul128(Cn, An), Cn), An), Cn);  // ((Cn An) + Cn) An + Cn
+  } else {
+    hiprand_init(a.ph.seed, a.ph.seq0 + (unsigned long long)w, a.ph.offset + 2ull * n * t, &st);
+  }
   double x[N], acc[N];
   int64_t round = 0;
   int flags = 0;
@@ -722,7 +735,12 @@ __global__ void __launch_bounds__(64, 2) cube_quad_kernel(CubeQArgs a) {
     double ll = 0.0;
     if (!done) {
 #pragma unroll 1
-      for (int i = 0; i < n; ++i) sx[i * 64 + lane] = g.next_double();
+      for (int i = 0; i < n; ++i) {
+        if constexpr (RNG == RNG_PCG64)
+          sx[i * 64 + lane] = g.next_double();
+        else
+          sx[i * 64 + lane] = 1.0 - hiprand_uniform_double(&st);  // (LaneGen<RNG_PHILOX>::uniform)
+      }
 #pragma unroll
       for (int i = 0; i < N; ++i) x[i] = (FULL || i < n) ? sx[i * 64 + lane] : 0.5;
     }
@@ -746,9 +764,11 @@ __global__ void __launch_bounds__(64, 2) cube_quad_kernel(CubeQArgs a) {
         a.logl[w0] = ll;
         a.ncalls[w0] = (int32_t)(round * 4 + t + 1);
         a.flags[w0] = 0;
-        g.has32 = 0;
-        g.buf32 = 0;
-        if (a.rng_out) g.store(a.rng_out + (size_t)w0 * 4);
+        if constexpr (RNG == RNG_PCG64) {
+          g.has32 = 0;
+          g.buf32 = 0;
+          if (a.rng_out) g.store(a.rng_out + (size_t)w0 * 4);
+        }
       }
       done = true;
     }
@@ -762,8 +782,10 @@ __global__ void __launch_bounds__(64, 2) cube_quad_kernel(CubeQArgs a) {
           a.logl[w0] = 0.0;
         }
         done = true;
-      } else {
+      } else if constexpr (RNG == RNG_PCG64) {
         g.state = add128(mul128(g.state, A3), C3);
+      } else {
+        hiprand_init(a.ph.seed, a.ph.seq0 + (unsigned long long)w, a.ph.offset + 2ull * n * (4ull * (unsigned long long)round + t), &st);
       }
     }
   }
@@ -1132,11 +1154,17 @@ int unif_dispatch(dh_ctx* ctx, const UnifArgs& a, int N, bool philox = false) {
 }  // namespace
 
 namespace {
-int cube_quad_dispatch(dh_ctx* ctx, const CubeQArgs& a, int N) {
+int cube_quad_dispatch(dh_ctx* ctx, const CubeQArgs& a, int N, bool philox) {
   const dim3 grid((a.k + 15) / 16), block(64);
   const bool full = a.ndim == N;
   const int kind = full ? problem_kind(a.prob.like_id, a.prob.prior_id) : KIND_GENERIC;
-#define LQ(NN, FF, KK) hipLaunchKernelGGL((cube_quad_kernel<NN, FF, KK>), grid, block, 0, ctx->stream, a)
+#define LQ(NN, FF, KK)                                                                                         \
+  do {                                                                                                         \
+    if (philox)                                                                                                \
+      hipLaunchKernelGGL((cube_quad_kernel<NN, FF, KK, RNG_PHILOX>), grid, block, 0, ctx->stream, a);          \
+    else                                                                                                       \
+      hipLaunchKernelGGL((cube_quad_kernel<NN, FF, KK, RNG_PCG64>), grid, block, 0, ctx->stream, a);           \
+  } while (0)
 #define X(NN)                                         \
   if (N == NN) {                                      \
     if (!full)                                        \
@@ -1199,7 +1227,7 @@ int dh::unif_launch_runs(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, i
   }
   const int N = pad_dim(ndim);
   // the unit cube with four lanes per walker (PCG64 streams) where one walker per lane would leave SIMDs empty
-  if (m == 0 && !a.propose_only && !philox && rng &&
+  if (m == 0 && !a.propose_only && (philox || rng) &&
       (ctx->cube_form == 2 || (ctx->cube_form == 0 && k <= 256 * ctx->num_cu))) {
     CubeQArgs q;
     q.prob = a.prob;
@@ -1218,7 +1246,8 @@ int dh::unif_launch_runs(dh_ctx* ctx, int problem, int k, int ndim, int ncdim, i
     q.wpr = wpr;
     q.my_mode = my_mode;
     q.loglstar = loglstar;
-    return cube_quad_dispatch(ctx, q, N);
+    q.ph = a.ph;
+    return cube_quad_dispatch(ctx, q, N, philox != nullptr);
   }
   const size_t mats = (size_t)(m > 0 ? m : 1) * N * N * 8;
   int rc = ensure_axes_t(ctx, 2 * mats);

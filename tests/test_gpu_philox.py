@@ -287,3 +287,33 @@ def test_philox_resident_loop_all_samplers(ctx):
         se = np.hypot(a.std(ddof=1), b.std(ddof=1)) / np.sqrt(32)
         assert abs(a.mean() - b.mean()) < 5 * se, (kw, a.mean(), b.mean(), se)
         assert 0.5 < a.std(ddof=1) / b.std(ddof=1) < 2.0
+
+
+@pytest.mark.parametrize("pname", ["C1", "C3", "C2"])
+def test_philox_unit_cube_four_lanes_per_walker_equals_one_lane(pname, monkeypatch):
+    """Round 6: the throughput mode's unit-cube phase with four lanes per walker (try k of a walker =
+    the 2 n words from offset + 2 n k of its keyed stream; DH_CUBE_FORM=2) against one walker per lane (=1): the same
+    points, log-likelihoods and call counts for the same key, bit for bit -- also through whole resident runs in the
+    Philox mode, whose unit-cube phase takes the four-lane form since this round (it ran one walker per lane, 0.74 ms
+    per fill against 0.12, which made the "throughput" mode slower end to end than the parity mode)."""
+    import inputs
+    from dynesty_amd import _lib
+    prob = inputs.problem(pname)
+    ctxs = []
+    for form in ("1", "2"):
+        monkeypatch.setenv("DH_CUBE_FORM", form)
+        ctxs.append(_lib.Context(0))
+    k = 777
+    u = np.random.default_rng(1).random((4000, prob.ndim))
+    ll = prob.loglikelihood_many(prob.prior_transform_many(u))
+    loglstar = float(np.quantile(ll, 0.97))
+    a = ctxs[0].unif_batch_philox(prob, loglstar, k, seed=99, sequence0=1000, offset=8192)
+    b = ctxs[1].unif_batch_philox(prob, loglstar, k, seed=99, sequence0=1000, offset=8192)
+    for key in ("u", "v", "logl", "ncalls"):
+        np.testing.assert_array_equal(a[key], b[key], err_msg=key)
+    assert a["ncalls"].max() > 40 and np.all(a["logl"] > loglstar)
+    kw = dict(nlive=200, queue_size=48, walks=15, bound="single", entropy=[4, 4], dlogz=0.5, rng="philox")
+    ra = ctxs[0].ns_ensemble(prob, 5, **kw)
+    rb = ctxs[1].ns_ensemble(prob, 5, **kw)
+    np.testing.assert_array_equal(ra["logz"], rb["logz"])
+    np.testing.assert_array_equal(ra["ncall"], rb["ncall"])

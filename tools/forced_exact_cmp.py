@@ -45,7 +45,13 @@ def forms(name, prob, runs, nlive, K, ref_row=None, **kw):
                    nbound=float(r["nbound"].mean()), niter=float(r["niter"].mean()), ncall=float(r["ncall"].mean()),
                    nfills=int(r["nfills"]))
         if ref_row:
-            row.update(ref_mean=ref_row["mean"], ref_se=ref_row["se"], ref_nbound=ref_row.get("mean_nbound"))
+            # counting conventions side by side: the reference's Sampler.nbound starts at 1 --
+            # its initial UnitCube is bound number one (sampler.py:416) and every update adds one (:673) --, the
+            # resident loop's record counts the UPDATES: nbound(loop) corresponds to nbound(reference) - 1
+            rn = ref_row.get("mean_nbound")
+            row.update(ref_mean=ref_row["mean"], ref_se=ref_row["se"], ref_nbound_incl_unit_cube=rn,
+                       ref_bound_updates=None if rn is None else rn - 1.0,
+                       bound_updates_loop_minus_reference=None if rn is None else row["nbound"] - (rn - 1.0))
         emit(row)
         del ctx
 
