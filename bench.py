@@ -895,12 +895,12 @@ def reference_logz_gate():
 
 
 def _profile_path(name):
-    """The newest committed record of that name (profiles/r05, else profiles/r04)."""
-    for rnd in ("r05", "r04"):
+    """The newest committed record of that name (profiles/r06, else r05, else r04)."""
+    for rnd in ("r06", "r05", "r04"):
         p = os.path.join(ROOT, "profiles", rnd, name)
         if os.path.exists(p):
             return p
-    return os.path.join(ROOT, "profiles", "r05", name)
+    return os.path.join(ROOT, "profiles", "r06", name)
 
 
 def _load_profile(name):
@@ -1042,6 +1042,17 @@ def cpu_baseline(prob, u0, nlive, scale, loglstar, walks, budget_s):
             "multiellipsoid_update_ms": ref_box["multiellipsoid_update_ms"]["median"],
             "sample": ref_box["sample"], "host_cpu_count": ref_box.get("cpu_count"),
             "source": os.path.relpath(_profile_path("reference_cpu_on_gpu_box.json"), ROOT)}
+    pool_box = _load_profile("reference_pool_on_gpu_box.json")
+    if pool_box and pool_box.get("legs"):
+        # the reference's OWN parallel path (dynesty.pool.Pool(ncores), queue_size = ncores) on the
+        # host cores of an MI355X box (round 6, tools/ref_pool_hw.py through a staged copy) -- a committed measurement:
+        # bound updates stay serial in the master process and proposals go through pool.map with chunksize 1
+        out["reference_pool"] = {
+            "unit": "proposals/s", "what": pool_box["what"], "host_cpu_count": pool_box.get("cpu_count"),
+            "legs": [{"cores": l["cores"], "proposals_per_s": l.get("proposals_per_s"), "iterations_per_s": l.get("iterations_per_s")}
+                     for l in pool_box["legs"]],
+            "best": pool_box.get("best"),
+            "source": os.path.relpath(_profile_path("reference_pool_on_gpu_box.json"), ROOT)}
     # the real reference, when this machine has a copy: it becomes the baseline, the port stays beside it
     ref = _reference_leg(prob, u0, nlive, scale, loglstar, walks, budget_s * 0.6)
     if ref is not None:

@@ -124,14 +124,23 @@ struct RebuildArgs {
 #define DH_PHASE_WG 0  // the workgroup of every kernel whose phases are summed (-DDH_PHASE_WG=k: another one)
 #endif
 __device__ long long g_phase_cycles[16];
+// (round 6) ... and per level of k_ell: g_ell_cycles[level][phase], the level filed by the kernel in g_ph_level
+__device__ long long g_ell_cycles[8][16];
+__shared__ int g_ph_level;
 #define PH_T0() long long t0_ = clock64()
 #define PH_ADD(i)                                                      \
   do {                                                                 \
     if (threadIdx.x == 0 && blockIdx.x == DH_PHASE_WG) {               \
       long long t1_ = clock64();                                       \
       g_phase_cycles[i] += t1_ - t0_;                                  \
+      if (g_ph_level >= 0 && g_ph_level < 8) g_ell_cycles[g_ph_level][i] += t1_ - t0_; \
       t0_ = t1_;                                                       \
     }                                                                  \
+  } while (0)
+#define PH_LEVEL(l)                          \
+  do {                                       \
+    if (threadIdx.x == 0) g_ph_level = (l);  \
+    __syncthreads();                         \
   } while (0)
 // per level: phases of k_split's workgroup DH_PHASE_WG (0 prologue + staging, 1 Lloyd iterations, 2 partition, 3 child
 // records, 4 number of iterations, 5 parts of the node, 6 points of the node)
@@ -159,6 +168,7 @@ __device__ long long g_wg_clock[2][8][kWgMax][2];
 #else
 #define PH_T0()
 #define PH_ADD(i)
+#define PH_LEVEL(l)
 #define LV_T0()
 #define WG_STAMP(kern, lvl, which)
 #define LV_ADD(lvl, i)
@@ -182,6 +192,8 @@ struct Lds {
   double* rs;     // 64
   double* kred;   // 4 waves x 2 clusters x 48: k-means partial sums (overlays red | rc | rs)
   int* ri;        // 256 ints (pair indices, scan scratch, ...)
+  int* ibuf;      // staging: a tile's permutation indices (overlays red | rc | rs: free while a tile is gathered)
+  int ibuf_cap;   // ints that fit there
   int* perm_sort; // D
   int TP, LD, DP, DPlog;
   int KG;         // waves per partial-sum group of the k-means (the whole workgroup unless a bigger tile stands in for parts)
@@ -521,39 +533,41 @@ __device__ __forceinline__ void stage_tile(const Lds& L, const double* __restric
       return;
     }
   }
-  // IDX_LDS: the tile's indices are fetched first, all together (one coalesced load a thread), and served from LDS
-  // (L.ri[0, cnt), cnt <= 256): a batch of rows then waits for ONE global round trip, its points, instead of two
-  const bool idx_lds = IDX_LDS && L.ri != nullptr && cnt <= 256;
-  if (idx_lds) {
-    for (int p = threadIdx.x; p < cnt; p += NT) L.ri[p] = ld_ci(L, perm + start + p);
+  // (round 6) A tile's permutation indices are fetched first, all together (one coalesced load or two a thread), and
+  // served from LDS as 32-bit element offsets of the rows: a batch of rows then waits for ONE global round trip, its
+  // points, instead of two (index, then row), a row's address is the scalar base plus a 32-bit lane offset, and with no
+  // index registers to hold TEN rows of a thread are in flight instead of eight.  Every kernel of the pipeline starts
+  // with a cold L2 (the XCDs' L2s are invalidated at a kernel boundary): a batch is a ~2 us trip to the memory side
+  // whatever its instruction count, so what counts is rows in flight.  512-point tile: 16 trips -> 1 + 7.
+  // Measured and dropped: `global_load_lds_dword` (a row = 2 D dwords straight into the tile, no registers, up to 63
+  // rows in flight per wavefront): correct, but 540 cycles per row instruction -- 69 k cycles per 512-point tile
+  // against 39 k; the 16-byte form that the matrix kernels use needs 16-byte aligned rows, a row here is 8 D bytes.
+  // (one code path: a tile larger than the buffer goes in chunks of the buffer's size)
+  const double mj = (how == 1 && j < D) ? L.mean[j] : 0.0;
+  const double sj = (how == 2 && j < D) ? L.scale[j] : 1.0;
+  constexpr int SB2 = 10;
+  for (int c0 = 0; c0 < cnt; c0 += L.ibuf_cap) {
+    const int cc = min(L.ibuf_cap, cnt - c0);
+    if (c0) __syncthreads();  // (the previous chunk's indices have been read)
+    for (int p = threadIdx.x; p < cc; p += NT) L.ibuf[p] = ld_ci(L, perm + start + c0 + p) * D;
     __syncthreads();
-  }
-  if (j < D) {
-    const double mj = how == 1 ? L.mean[j] : 0.0;
-    const double sj = how == 2 ? L.scale[j] : 1.0;
-    for (int pb = p0; pb < cnt; pb += SB * pstep) {
-      int idx[SB];
-      double x[SB];
+    if (j < D) {
+      for (int pb = p0; pb < cc; pb += SB2 * pstep) {
+        double x[SB2];
 #pragma unroll
-      for (int k = 0; k < SB; ++k) {
-        const int p = pb + k * pstep;
-        const int pc = p < cnt ? p : 0;  // (clamped: unconditional loads, see sel_ld)
-        const int iv = idx_lds ? L.ri[pc] : ld_ci(L, perm + start + pc);
-        idx[k] = p < cnt ? iv : -1;
-      }
+        for (int k = 0; k < SB2; ++k) {
+          const int p = pb + k * pstep;
+          x[k] = pts[(unsigned)(L.ibuf[p < cc ? p : 0] + j)];  // (clamped: unconditional loads, see sel_ld)
+        }
 #pragma unroll
-      for (int k = 0; k < SB; ++k) {
-        const double xv = pts[(size_t)(idx[k] >= 0 ? idx[k] : 0) * D + j];
-        x[k] = idx[k] >= 0 ? xv : 0.0;
-      }
-#pragma unroll
-      for (int k = 0; k < SB; ++k) {
-        const int p = pb + k * pstep;
-        if (p < cnt) {
-          double v = x[k];
-          if (how == 1) v -= mj;
-          if (how == 2) v = v / sj;
-          L.tile[p * L.LD + j] = v;
+        for (int k = 0; k < SB2; ++k) {
+          const int p = pb + k * pstep;
+          if (p < cc) {
+            double v = x[k];
+            if (how == 1) v -= mj;
+            if (how == 2) v = v / sj;
+            L.tile[(c0 + p) * L.LD + j] = v;
+          }
         }
       }
     }
@@ -2118,6 +2132,8 @@ __device__ __forceinline__ void carve(Lds& L, unsigned char* smem, int D, int TP
   L.rs = p;
   p += 64;
   L.kred = L.red;  // 384 doubles = red | rc | rs, none of which the k-means parts use
+  L.ibuf = (int*)L.red;
+  L.ibuf_cap = 2 * (kThreads + 128);
   L.ri = (int*)p;
   L.perm_sort = L.ri + 320;
   const int P = (D + 1) & ~1;
@@ -2166,6 +2182,8 @@ __device__ __forceinline__ void carve_split(Lds& L, unsigned char* smem, int D, 
   L.rc = p + kThreads;
   L.rs = L.rc + 64;
   L.kred = L.red;
+  L.ibuf = (int*)L.red;
+  L.ibuf_cap = 2 * (kThreads + 128);
   p += kThreads + 128;
   L.ri = (int*)p;
   L.perm_sort = L.ri + 320;
@@ -2278,6 +2296,7 @@ __device__ __forceinline__ void queue_split(const RebuildArgs& a, int run, int l
 // rootbuf per run: [np x D sums | np x D^2 cov partials | np fmax | np x D squares | D^2 am | 8 flags]
 __global__ void __launch_bounds__(kThreads, 2) k_root_parts(RebuildArgs a, int rp) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  PH_LEVEL(-1);
   const int D = a.d, DD = D * D, t = threadIdx.x, run = blockIdx.x / rp, q = blockIdx.x % rp;
   const int n = a.n_arr ? a.n_arr[run] : a.n;
   if (a.active && !a.active[run]) return;
@@ -2669,6 +2688,7 @@ __device__ __forceinline__ void k_split_impl(const RebuildArgs& a, int level, in
 #endif
 __global__ void __launch_bounds__(kThreads, DH_KSPLIT_WAVES) k_split(RebuildArgs a, int level, int gp, int cr) {
   WG_STAMP(0, level, 0);
+  PH_LEVEL(-1);
   k_split_impl(a, level, gp, cr);
   WG_STAMP(0, level, 1);
 }
@@ -2760,6 +2780,7 @@ template <bool SLOW, bool DEFER = false>
 __global__ void __launch_bounds__(kThreads, SLOW ? 1 : 2) k_ell(RebuildArgs a, int level, int G, int skip_done, int leaf_cap,
                                                                  int tp) {
   WG_STAMP(1, level, 0);
+  PH_LEVEL(level);
   k_ell_impl<SLOW, DEFER>(a, level, G, skip_done, leaf_cap, tp);
   WG_STAMP(1, level, 1);
 }
@@ -2847,6 +2868,8 @@ __device__ __forceinline__ void carve_wave(Lds& L, unsigned char* smem, int D, i
   L.lam = p;
   p += D;
   L.red = p;
+  L.ibuf = (int*)L.red;
+  L.ibuf_cap = 128;  // (64 doubles)
   L.scale = L.cen = L.sums = L.rc = L.rs = L.kred = nullptr;
   L.ri = L.perm_sort = nullptr;
   L.JA[0] = L.JA[1] = L.JV[0] = L.JV[1] = nullptr;
@@ -2917,6 +2940,7 @@ __device__ __forceinline__ int node_ellipsoid_wave(const Lds& L, const RebuildAr
 template <int NT>
 __global__ void __launch_bounds__(NT, 3) k_ell_wave(RebuildArgs a, int level, int G, int cap, int axis, int defer) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  PH_LEVEL(-1);
   const int run = blockIdx.x % a.runs, g = blockIdx.x / a.runs;  // (run-minor, as k_ell)
   const int* list = a.ell_list + ((size_t)level * a.runs + run) * 2 * a.maxw;
   const int cnt = a.nell[(size_t)level * a.runs + run];
@@ -3021,6 +3045,7 @@ __device__ __attribute__((noinline)) void tree_worker(RebuildArgs a, unsigned ch
 
 __global__ void __launch_bounds__(kThreads, 2) k_tree(RebuildArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  PH_LEVEL(-1);
   // nothing queued by the level kernels (they are complete: stream order) = nothing ever will be
   if (__hip_atomic_load(a.tq_ctl + 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= 0) return;
   tree_worker(a, smem);
@@ -3036,6 +3061,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_tree(RebuildArgs a) {
 // wavefronts are grouped like the 128-point parts, so a node's sums come out as the level kernels' would) and, as
 __global__ void __launch_bounds__(kThreads) k_finish(RebuildArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  PH_LEVEL(-1);
   const int D = a.d, t = threadIdx.x, run = blockIdx.x;
   const int n = a.n_arr ? a.n_arr[run] : a.n;
   if (a.active && !a.active[run]) return;
@@ -3264,6 +3290,7 @@ __global__ void __launch_bounds__(kThreads) k_finish(RebuildArgs a) {
 // the result (am | axes | axlens | logvol | ok) for k_finish to pick up if the root is an output.
 __global__ void __launch_bounds__(kThreads) k_root_eig(RebuildArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  PH_LEVEL(-1);
   const int run = blockIdx.x, D = a.d, DD = D * D, t = threadIdx.x;
   double* re = a.root_eig + (size_t)run * (2 * DD + D + 2);
   if (a.active && !a.active[run]) return;
@@ -3303,6 +3330,7 @@ __global__ void __launch_bounds__(kThreads) k_root_eig(RebuildArgs a) {
 // output ellipsoid, all runs at once.  grid = runs x G; workgroup g takes outputs g, g + G, ...
 __global__ void __launch_bounds__(kThreads) k_out_eig(RebuildArgs a, int G) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  PH_LEVEL(-1);
   const int run = blockIdx.x / G, g = blockIdx.x % G;
   if (a.active && !a.active[run]) return;
   if (a.status[run] != DH_OK) return;
@@ -3354,6 +3382,7 @@ __global__ void __launch_bounds__(kThreads) k_out_eig(RebuildArgs a, int G) {
 __global__ void __launch_bounds__(kThreads)
     improve_cov_kernel(int m, int D, double* work, int* good, double* covs, double* ams, double* axes) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  PH_LEVEL(-1);
   Lds L;
   carve(L, smem, D);
   const int e = blockIdx.x, t = threadIdx.x, LD = L.LD;
@@ -3536,6 +3565,13 @@ void dh_rebuild_timing(long long* out16, int reset) {
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), z, sizeof z);
   }
 }
+void dh_rebuild_timing_ell(long long* out128, int reset) {  // g_ell_cycles: 8 levels x 16 phases of k_ell's workgroup 0
+  (void)hipMemcpyFromSymbol(out128, HIP_SYMBOL(g_ell_cycles), 128 * sizeof(long long));
+  if (reset) {
+    long long z[128] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_ell_cycles), z, sizeof z);
+  }
+}
 void dh_rebuild_wg_clock(long long* out, int kern, int level) {  // kWgMax x 2 wall-clock stamps (100 MHz)
   (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wg_clock), (size_t)kWgMax * 2 * sizeof(long long),
                             (((size_t)kern * 8 + level) * kWgMax * 2) * sizeof(long long));
@@ -3716,6 +3752,8 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
   const size_t lds_split = split_lds_bytes(d, a.tps);
   // the parts of one node meet at a device-scope barrier, so they must all be resident at the
   // same time: 256 parts (65 536 points per run) fit the 256 CUs with room to spare
+  if ((long long)n * d >= (1ll << 31))  // (rows are addressed by 32-bit element offsets: stage_tile)
+    return fail(ctx, DH_ERR_ARG, "rebuild: n x d = %lld elements per run exceeds 2^31", (long long)n * d);
   if (mode == 0 && n > 256 * kThreads)
     return fail(ctx, DH_ERR_ARG, "rebuild: MultiEllipsoid.update supports at most %d points per run (n = %d)",
                 256 * kThreads, n);
