@@ -1735,6 +1735,40 @@ __device__ __forceinline__ void ld_agent16x8(const double* const (&p)[8], dh_d2 
       : "memory");
 }
 
+// column `col` of np partners' rows (rows of `stride` pairs), every word awaited until it carries `tag`: the sum in
+// partner order (MAXOP: the maximum) -- the tagged exchange as a reduction.  *ok = false if a partner never arrives.
+template <bool MAXOP = false>
+__device__ __forceinline__ double tagged_partner_reduce(const double* base, size_t stride, int col, int np,
+                                                        unsigned long long tag, bool* ok) {
+  double acc = MAXOP ? -INFINITY : 0.0;
+  for (int pp0 = 0; pp0 < np && *ok; pp0 += 8) {
+    const double* ptr[8];
+    dh_d2 v[8];
+#pragma unroll
+    for (int uu = 0; uu < 8; ++uu) ptr[uu] = base + ((size_t)min(pp0 + uu, np - 1) * stride + col) * 2;
+    for (int spins = 0;; ++spins) {
+      ld_agent16x8(ptr, v);
+      bool all = true;
+#pragma unroll
+      for (int uu = 0; uu < 8; ++uu) all = all && (unsigned long long)__double_as_longlong(v[uu].y) == tag;
+      if (all) break;
+      if (spins > (1 << 18)) {
+        *ok = false;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+#pragma unroll
+    for (int uu = 0; uu < 8; ++uu) {
+      if (MAXOP)
+        acc = pp0 + uu < np ? fmax(acc, v[uu].x) : acc;
+      else
+        acc += pp0 + uu < np ? v[uu].x : 0.0;
+    }
+  }
+  return acc;
+}
+
 __device__ __forceinline__ bool parts_barrier(int* bar, int target) {
   __shared__ int ok_flag;
   drain_stores();
@@ -2331,17 +2365,27 @@ __global__ void __launch_bounds__(kThreads, 2) k_root_parts(RebuildArgs a, int r
       }
     }
   } else {
+    // (round 6) The parts exchange their partials as tagged 16-byte words (value, tag = rebuild epoch + phase), polled
+    // by whoever needs them: no arrival counters, no store drains -- five counted barriers of ~3 us became four waits
+    // of one store propagation each.  And what does not depend on part 0's solve no longer waits for it: the sums of
+    // squares travel with the covariance partials, so every part forms the k-means scale and writes its rows of the
+    // scaled copy WHILE part 0 inverts the covariance (they were a barrier, a pass and a store behind it).
+    // rootbuf per run, in pairs: [rp x D sums | rp x D squares | rp x D^2 cov partials | D^2 am | rp fmax | flag | status]
     double* rb = a.rootbuf + (size_t)run * a.rootbuf_stride;
     double* b_sum = rb;
-    double* b_cov = b_sum + (size_t)rp * D;
-    double* b_fmx = b_cov + (size_t)rp * DD;
-    double* b_sq = b_fmx + rp;
-    double* b_am = b_sq + (size_t)rp * D;
-    double* b_flag = b_am + DD;
-    int* bar = a.rbar + (size_t)run * kBarStride;
-    int phase = 0;
+    double* b_sq = b_sum + (size_t)rp * D * 2;
+    double* b_cov = b_sq + (size_t)rp * D * 2;
+    double* b_am = b_cov + (size_t)rp * DD * 2;
+    double* b_fmx = b_am + (size_t)DD * 2;
+    double* b_flag = b_fmx + (size_t)rp * 2;
+    double* b_stat = b_flag + 2;
+    const unsigned long long tg = ((unsigned long long)a.epoch << 8) | 0x8000000000000000ull;  // (+ phase 1..6)
+    __shared__ int s_bad;
+    if (t == 0) s_bad = 0;
     const int G = kThreads / D > 0 ? kThreads / D : 1;
     const int j = t % D, g = t / D;
+    const bool want_split = a.mode == 0 && n >= 4 * D;
+    bool ok = true;
     // ---- mean ----
     stage_tile(L, v.pts, v.perm, s0, cnt, D, 0);
     {
@@ -2353,26 +2397,12 @@ __global__ void __launch_bounds__(kThreads, 2) k_root_parts(RebuildArgs a, int r
       if (t < D) {
         double sum = 0.0;
         for (int gg = 0; gg < G; ++gg) sum += L.red[gg * D + t];
-        st_agent(b_sum + (size_t)q * D + t, sum);
+        st_agent16(b_sum + ((size_t)q * D + t) * 2, sum, tg + 1);
+        L.mean[t] = tagged_partner_reduce(b_sum, D, t, np, tg + 1, &ok) / (double)n;
       }
-    }
-    if (!parts_barrier(bar, np * ++phase)) status = DH_ERR_HIP;
-    if (t < D) {
-      double sum = 0.0;
-      for (int pp0 = 0; pp0 < np; pp0 += 8) {
-        double part[8];
-#pragma unroll
-        for (int uu = 0; uu < 8; ++uu) {
-          const double pv8 = ld_agent(b_sum + (size_t)min(pp0 + uu, np - 1) * D + t);
-          part[uu] = pp0 + uu < np ? pv8 : 0.0;
-        }
-#pragma unroll
-        for (int uu = 0; uu < 8; ++uu) sum += part[uu];
-      }
-      L.mean[t] = sum / (double)n;
     }
     __syncthreads();
-    // ---- covariance: partial Xc^T Xc of the own tile ----
+    // ---- covariance: partial Xc^T Xc of the own tile; sums of squares of the centred tile ----
     stage_tile(L, v.pts, v.perm, s0, cnt, D, 1);  // centred in place
     {
       mfma_acc acc[6];
@@ -2383,50 +2413,73 @@ __global__ void __launch_bounds__(kThreads, 2) k_root_parts(RebuildArgs a, int r
       cov_fold_waves(L, D, acc);
       for (int e = t; e < DD; e += kThreads) {
         const int i = e / D, k = e - i * D;
-        if (i <= k) st_agent(b_cov + (size_t)q * DD + e, L.A[i * LD + k]);
+        if (i <= k) st_agent16(b_cov + ((size_t)q * DD + e) * 2, L.A[i * LD + k], tg + 2);
       }
     }
-    if (!parts_barrier(bar, np * ++phase)) status = DH_ERR_HIP;
+    if (want_split) {
+      double acc = 0.0;
+      if (t < G * D)
+        for (int p = g; p < cnt; p += G) {
+          const double x = L.tile[p * LD + j];
+          acc = fma(x, x, acc);
+        }
+      __syncthreads();  // (L.red: the fold above is done with it)
+      L.red[t] = acc;
+      __syncthreads();
+      if (t < D) {
+        double sum = 0.0;
+        for (int gg = 0; gg < G; ++gg) sum += L.red[gg * D + t];
+        st_agent16(b_sq + ((size_t)q * D + t) * 2, sum, tg + 2);
+      }
+    }
     // ---- part 0: eigensolver; publishes the precision matrix (flag 1) or falls back (flag 2) ----
+    int flag = 0;
     if (q == 0) {
       for (int e = t; e < DD; e += kThreads) {
         const int i = e / D, k = e - i * D;
-        if (i <= k) {
-          double sum = 0.0;
-          for (int pp0 = 0; pp0 < np; pp0 += 8) {
-            double part[8];
-#pragma unroll
-            for (int uu = 0; uu < 8; ++uu)
-            {
-              const double pv8 = ld_agent(b_cov + (size_t)min(pp0 + uu, np - 1) * DD + e);
-              part[uu] = pp0 + uu < np ? pv8 : 0.0;
-            }
-#pragma unroll
-            for (int uu = 0; uu < 8; ++uu) sum += part[uu];
-          }
-          L.A[i * LD + k] = sum;
-        }
+        if (i <= k) L.A[i * LD + k] = tagged_partner_reduce(b_cov, DD, e, np, tg + 2, &ok);
       }
+      if (!ok) s_bad = 1;
       __syncthreads();
       cov_finalize(L, D, 1.0 / (double)(n - 1));
       for (int e = t; e < DD; e += kThreads) cov_g[(e / D) * LD + e % D] = L.A[(e / D) * LD + e % D];
       __syncthreads();
       // eigen-free first (the tile stays resident); else the reference's route, which may overlay
       // the tile with the Jacobi buffers
-      if (a.fast && spd_fast(L, cov_g, D, a.mode == 0 && n >= 4 * D, &root_logdet)) root_fast = 1;
+      if (a.fast && spd_fast(L, cov_g, D, want_split, &root_logdet)) root_fast = 1;
       const bool good = root_fast || regularize(L, cov_g, D);
-      if (good) {
-        for (int e = t; e < DD; e += kThreads) st_agent(b_am + e, L.AM[(e / D) * LD + e % D]);
-        if (t == 0) st_agent(b_flag, 1.0);
-      } else {
-        if (t == 0) st_agent(b_flag, 2.0);
-      }
+      flag = good ? 1 : 2;
+      if (good)
+        for (int e = t; e < DD; e += kThreads) st_agent16(b_am + (size_t)e * 2, L.AM[(e / D) * LD + e % D], tg + 3);
+      if (t == 0) st_agent16(b_flag, (double)flag, tg + 3);
     }
-    if (!parts_barrier(bar, np * ++phase)) status = DH_ERR_HIP;
-    const int flag = (int)ld_agent(b_flag);
+    // ---- the k-means scale and this part's rows of the scaled copy (bounding.py:1503-1510): beside part 0's solve ----
+    if (want_split) {
+      if (t < D) L.scale[t] = sqrt(tagged_partner_reduce(b_sq, D, t, np, tg + 2, &ok) / (double)n);
+      if (!ok) s_bad = 1;
+      __syncthreads();
+      double* ps = a.pts_scaled + (size_t)run * a.n * D;
+      const int jj = t & (L.DP - 1), p0 = t >> L.DPlog, pstep = kThreads >> L.DPlog;
+      if (jj < D) {
+        const double sj = L.scale[jj];
+        for (int p = s0 + p0; p < s0 + cnt; p += pstep) ps[(size_t)p * D + jj] = v.pts[(size_t)p * D + jj] / sj;
+      }
+      if (q == 0 && t < D) a.scale_g[(size_t)run * D + t] = L.scale[t];
+    }
+    if (q > 0) {
+      if (t == 0) {
+        bool ok1 = true;
+        flag = (int)tagged_partner_reduce(b_flag, 1, 0, 1, tg + 3, &ok1);
+        if (!ok1) s_bad = 1;
+        L.ri[300] = flag;
+      }
+      __syncthreads();
+      flag = L.ri[300];
+    }
     if (flag == 1) {
       if (q > 0) {
-        for (int e = t; e < DD; e += kThreads) L.AM[(e / D) * LD + e % D] = ld_agent(b_am + e);
+        for (int e = t; e < DD; e += kThreads) L.AM[(e / D) * LD + e % D] = tagged_partner_reduce(b_am, 1, e, 1, tg + 3, &ok);
+        if (!ok) s_bad = 1;
         __syncthreads();
       }
       // ---- Mahalanobis maximum over the own tile ----
@@ -2449,11 +2502,17 @@ __global__ void __launch_bounds__(kThreads, 2) k_root_parts(RebuildArgs a, int r
       }
       __syncthreads();
       best = block_reduce_max(best, L.red);
-      if (t == 0) st_agent(b_fmx + q, best);
-      if (!parts_barrier(bar, np * ++phase)) status = DH_ERR_HIP;
+      if (t == 0) st_agent16(b_fmx + (size_t)q * 2, best, tg + 4);
       if (q == 0) {
-        double fmx = -INFINITY;
-        for (int pp = 0; pp < np; ++pp) fmx = fmax(fmx, ld_agent(b_fmx + pp));
+        if (t == 0) {
+          bool ok1 = true;
+          L.red[0] = tagged_partner_reduce<true>(b_fmx, 1, 0, np, tg + 4, &ok1);
+          if (!ok1) s_bad = 1;
+        }
+        __syncthreads();
+        const double fmx = L.red[0];
+        __syncthreads();
+        if (s_bad) status = DH_ERR_HIP;
         if (root_fast && fmx > 1.0 - kRoundDelta) root_logdet += (double)D * log(fmx / (1.0 - kRoundDelta));
         ellipsoid_rescale(L, cov_g, D, fmx);
         root_fmax = fmin(fmx, 1.0 - kRoundDelta);
@@ -2461,10 +2520,12 @@ __global__ void __launch_bounds__(kThreads, 2) k_root_parts(RebuildArgs a, int r
           status = root_fast ? ellipsoid_store_fast(L, a, es, cov_g, root_logdet, &lv)
                              : ellipsoid_store(L, a, es, cov_g, &lv);
       }
-    } else {
+    } else if (q == 0) {
       // regularised covariance: the reference's second pass (bounding.py:1449-1453) by the
       // single-workgroup routine, from scratch
-      if (q == 0 && status == DH_OK) {
+      __syncthreads();
+      if (s_bad) status = DH_ERR_HIP;
+      if (status == DH_OK) {
         // the other parts' ranges of the identity permutation were written by other CUs with
         // plain stores (not visible across XCDs inside this kernel): write them here as well
         for (int p = t; p < n; p += kThreads) v.perm[p] = p;
@@ -2472,60 +2533,16 @@ __global__ void __launch_bounds__(kThreads, 2) k_root_parts(RebuildArgs a, int r
         __syncthreads();
         status = node_ellipsoid<false>(L, a, v.pts, v.perm, 0, n, es, cov_g, &lv, &root_fmax);
       }
-      if (!parts_barrier(bar, np * ++phase)) status = DH_ERR_HIP;
     }
-    // ---- status to all parts ----
-    if (q == 0 && t == 0) st_agent(b_flag + 1, (double)status);
-    if (!parts_barrier(bar, np * ++phase)) status = DH_ERR_HIP;
-    if (status == DH_OK) status = (int)ld_agent(b_flag + 1);
-    // ---- std and the scaled copy for the k-means (bounding.py:1503-1510) ----
-    if (status == DH_OK && a.mode == 0 && n >= 4 * D) {
-      if (q == 0 && flag != 1) {
-        // the fallback recomputed the mean into L.mean: identical values, nothing to do
-      }
-      stage_tile(L, v.pts, v.perm, s0, cnt, D, 1);
-      double acc = 0.0;
-      if (t < G * D)
-        for (int p = g; p < cnt; p += G) {
-          const double x = L.tile[p * LD + j];
-          acc = fma(x, x, acc);
-        }
-      L.red[t] = acc;
-      __syncthreads();
-      if (t < D) {
-        double sum = 0.0;
-        for (int gg = 0; gg < G; ++gg) sum += L.red[gg * D + t];
-        st_agent(b_sq + (size_t)q * D + t, sum);
-      }
-      if (!parts_barrier(bar, np * ++phase)) status = DH_ERR_HIP;
-      if (t < D) {
-        double sum = 0.0;
-        for (int pp0 = 0; pp0 < np; pp0 += 8) {
-          double part[8];
-#pragma unroll
-          for (int uu = 0; uu < 8; ++uu) {
-            const double pv8 = ld_agent(b_sq + (size_t)min(pp0 + uu, np - 1) * D + t);
-            part[uu] = pp0 + uu < np ? pv8 : 0.0;
-          }
-#pragma unroll
-          for (int uu = 0; uu < 8; ++uu) sum += part[uu];
-        }
-        L.scale[t] = sqrt(sum / (double)n);
-      }
-      __syncthreads();
-      {
-        double* ps = a.pts_scaled + (size_t)run * a.n * D;
-        const int jj = t & (L.DP - 1), p0 = t >> L.DPlog, pstep = kThreads >> L.DPlog;
-        if (jj < D) {
-          const double sj = L.scale[jj];
-          for (int p = s0 + p0; p < s0 + cnt; p += pstep) ps[(size_t)p * D + jj] = v.pts[(size_t)p * D + jj] / sj;
-        }
-      }
-      if (q == 0) {
-        if (t < D) a.scale_g[(size_t)run * D + t] = L.scale[t];
-        if (t == 0 && status == DH_OK) queue_split(a, run, 0, 0, n);
-      }
+    // ---- status: part 0 alone needs it (it files the root and queues the split); a part that waited in vain says so ----
+    __syncthreads();
+    if (q > 0) {
+      if (s_bad && t == 0) atomicMin(&a.kerr[run], DH_ERR_HIP);  // (folded into the run's status by the next kernel)
+    } else {
+      if (s_bad) status = DH_ERR_HIP;
+      if (t == 0 && status == DH_OK && want_split) queue_split(a, run, 0, 0, n);
     }
+    (void)b_stat;
   }
   if (q == 0 && t == 0) {
     Node r;
@@ -3816,7 +3833,7 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
   const size_t n_cnt_old = (size_t)runs * ((size_t)3 * a.levels + 5 + kBarStride + (size_t)a.levels * a.maxw * kBarStride);
   const size_t n_cnt_tree = tail ? (size_t)runs + 64 + (size_t)runs * a.max_nodes * kBarStride + 2 * (size_t)a.tq_cap + 2 : 0;
   const size_t b_cnt = (n_cnt_old + n_cnt_tree) * 4;
-  a.rootbuf_stride = (size_t)rp * (2 * (size_t)d + (size_t)d * d + 1) + (size_t)d * d + 8;
+  a.rootbuf_stride = 2 * ((size_t)rp * (2 * (size_t)d + (size_t)d * d + 1) + (size_t)d * d + 8);  // (value, tag) pairs
   const size_t b_rb = (size_t)runs * a.rootbuf_stride * 8;
   const size_t b_fl = (size_t)runs * a.max_nodes * 8, b_fi = (size_t)runs * a.max_nodes * 2 * 4;
   const size_t b_pl = (size_t)2 * runs * a.maxp * 2 * 4, b_pb = (size_t)2 * runs * a.maxw * 4;
@@ -4006,11 +4023,14 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
   // k_ell_wave<128> on the SIDE stream -- two wavefronts and 31 KB of LDS a node: five per CU -- while the main stream
   // goes on with the level's few splittable children and the next level pair; k_ell skips exactly the nodes that kernel
   // takes.  The side stream joins before the work-queue tail, to which a declined leaf (eigen-free path not applicable)
-  // is queued.  Same routines, same bits (tests/test_gpu_edges.py).  DH_LEAF_SIDE=0: off.
+  // is queued.  Same routines, same bits (tests/test_gpu_edges.py).  Round 6: with the level kernels a third shorter the
+  // side stream no longer pays -- measured on the bench shard (tools/r6_env.sh): 64 runs 1.065 ms either way, one run
+  // 0.70 -> 0.66 and 128 runs 2.05 -> 2.01 WITHOUT it (two more event waits per level, five 31 KB leaf workgroups per
+  // CU beside the level's own) -- so it is off by default; DH_LEAF_SIDE=1 switches it on.
   int leaf_from = nlev, leaf_cap = 0;
   size_t lds_leaf = 0;
   if (a.fast && mode == 0 && tail && forked && wave_from >= nlev && d >= 14 &&
-      !(getenv("DH_LEAF_SIDE") && atoi(getenv("DH_LEAF_SIDE")) == 0)) {
+      (getenv("DH_LEAF_SIDE") && atoi(getenv("DH_LEAF_SIDE")) == 1)) {  // (round 6: off unless asked for, see below)
     leaf_cap = 4 * d - 1 < 128 ? 4 * d - 1 : 128;
     lds_leaf = wave_lds_bytes(d, leaf_cap, false);
     if (lds_leaf <= 64 * 1024) {
@@ -4060,7 +4080,10 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
     // workgroups stage 512 points at once -- a 1 000-point child is gathered three times instead of seven (covariance
     // pass 2 + Mahalanobis pass 1, the last tile still staged), a 500-point child once instead of three times.  Only
     // while the level's workgroups all fit the chip at one per CU (the LDS of such a tile allows no second one).
-    const bool top = lds_top > 0 && (n >> (L + 1)) > kThreads && (long long)runs * ge <= ctx->num_cu;
+    // (round 6: only while the level's workgroups fill at most HALF the CUs -- at 128 runs level 0's 256 one-per-CU
+    // workgroups with the big tile lost to two-per-CU with the small one: 2.09 -> 2.05 ms; 64 runs unchanged)
+    static const int top_div = getenv("DH_ELL_TOP_DIV") ? atoi(getenv("DH_ELL_TOP_DIV")) : 2;
+    const bool top = lds_top > 0 && (n >> (L + 1)) > kThreads && (long long)runs * ge * (top_div > 0 ? top_div : 1) <= ctx->num_cu;
     if (a.fast && tail && !(getenv("DH_ELL_DEFER") && atoi(getenv("DH_ELL_DEFER")) == 0))
       hipLaunchKernelGGL((k_ell<false, true>), dim3(runs * ge), dim3(kThreads), top ? lds_top : lds, ctx->stream, a, L, ge, wave, lc,
                          top ? 2 * kThreads : kThreads);

@@ -341,10 +341,7 @@ def test_leaves_on_the_side_stream_give_the_same_bits(ctx):
 
     def run(pts, off):
         old = os.environ.get("DH_LEAF_SIDE")
-        if off:
-            os.environ["DH_LEAF_SIDE"] = "0"
-        else:
-            os.environ.pop("DH_LEAF_SIDE", None)
+        os.environ["DH_LEAF_SIDE"] = "0" if off else "1"  # (round 6: the side stream is opt-in)
         try:
             return ctx.rebuild(pts, multi=True, want_labels=True)
         finally:
@@ -363,9 +360,10 @@ def test_leaves_on_the_side_stream_give_the_same_bits(ctx):
     os.environ["DH_LEAF_SIDE"] = "0"
     try:
         ref = ctx.rebuild_many(sets, multi=True)
+        os.environ["DH_LEAF_SIDE"] = "1"
+        got = ctx.rebuild_many(sets, multi=True)
     finally:
         del os.environ["DH_LEAF_SIDE"]
-    got = ctx.rebuild_many(sets, multi=True)
     for a, b in zip(ref, got):
         assert a["nells"] == b["nells"]
         for k in a:
