@@ -3199,13 +3199,30 @@ __global__ void __launch_bounds__(kThreads) k_finish(RebuildArgs a) {
       const int ni = reslist[rs0 + m];
       const double* es = estore + (size_t)ni * NS;
       for (int e = t; e < D; e += kThreads) {
-        o_ctr[m * D + e] = es[e];
-        o_al[m * D + e] = es[D + 3 * DD + e];
+        const double c0 = es[e], a0 = es[D + 3 * DD + e];
+        o_ctr[m * D + e] = c0;
+        o_al[m * D + e] = a0;
       }
-      for (int e = t; e < DD; e += kThreads) {
-        o_cov[(size_t)m * DD + e] = es[D + e];
-        o_am[(size_t)m * DD + e] = es[D + DD + e];
-        o_ax[(size_t)m * DD + e] = es[D + 2 * DD + e];
+      // (every load of a thread first, then its stores: the compiler cannot move a load of the record above a store to
+      // an output it may alias, and a serial chain of cold round trips was most of this phase)
+      for (int e0 = t; e0 < DD; e0 += 4 * kThreads) {
+        double c[4], p[4], x[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int e = e0 + u * kThreads, ec = e < DD ? e : 0;
+          c[u] = es[D + ec];
+          p[u] = es[D + DD + ec];
+          x[u] = es[D + 2 * DD + ec];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int e = e0 + u * kThreads;
+          if (e < DD) {
+            o_cov[(size_t)m * DD + e] = c[u];
+            o_am[(size_t)m * DD + e] = p[u];
+            o_ax[(size_t)m * DD + e] = x[u];
+          }
+        }
       }
       int need_eig = nodes[ni].fast;
       if (need_eig && ni == 0 && a.root_eig) {
@@ -3534,10 +3551,26 @@ __global__ void __launch_bounds__(1024)
   if (iso[0]) {
     const double f = exp(logf / D);
     const double f2 = f * f, inv = 1.0 / f2;
-    for (int t = lane; t < D * D; t += nt) {
-      C[t] *= f2;
-      P[t] *= inv;
-      X[t] *= f;
+    // (round 6: every load of a thread first, then its stores -- written as `C[t] *= f2` in a loop each
+    // read-modify-write waited for the one before, ten cold round trips of a wavefront: 12 us for 64 matrices)
+    for (int t0 = lane; t0 < D * D; t0 += 4 * nt) {
+      double c[4], p[4], x[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int t = t0 + u * nt, tc = t < D * D ? t : 0;
+        c[u] = C[tc];
+        p[u] = P[tc];
+        x[u] = X[tc];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int t = t0 + u * nt;
+        if (t < D * D) {
+          C[t] = c[u] * f2;
+          P[t] = p[u] * inv;
+          X[t] = x[u] * f;
+        }
+      }
     }
     for (int k = lane; k < D; k += nt) al[k] *= f;
   } else {
@@ -3631,7 +3664,7 @@ int dh::enlarge_launch_masked(dh_ctx* ctx, int runs, int max_ells, const int32_t
                               double* ams, double* axes, double* axlens, double* logvols,
                               double log_enlarge, const int* active, const double* run_shift) {
   const int m = runs * max_ells;
-  hipLaunchKernelGGL(scale_logvol_kernel, dim3(m), dim3(d > 64 ? 1024 : 64), (size_t)2 * d * 8 + 64, ctx->stream, m, d,
+  hipLaunchKernelGGL(scale_logvol_kernel, dim3(m), dim3(d > 64 ? 1024 : 256), (size_t)2 * d * 8 + 64, ctx->stream, m, d,
                      covs, ams, axes, axlens, logvols, (const double*)nullptr, log_enlarge, nells, max_ells,
                      active, run_shift);
   return hip_ok(ctx, hipGetLastError(), "enlarge launch") ? DH_OK : DH_ERR_HIP;
@@ -4271,7 +4304,7 @@ int dh_enlarge_batch_dev(dh_ctx* ctx, int runs, int max_ells, const int32_t* nel
   if (!nells || !covs || !ams || !axes || !axlens || !logvols || d < 1 || max_ells < 1)
     return fail(ctx, DH_ERR_ARG, "enlarge: bad arguments");
   const int m = runs * max_ells;
-  hipLaunchKernelGGL(scale_logvol_kernel, dim3(m), dim3(d > 64 ? 1024 : 64), (size_t)2 * d * 8 + 64, ctx->stream, m, d,
+  hipLaunchKernelGGL(scale_logvol_kernel, dim3(m), dim3(d > 64 ? 1024 : 256), (size_t)2 * d * 8 + 64, ctx->stream, m, d,
                      covs, ams, axes, axlens, logvols, (const double*)nullptr, log_enlarge, nells,
                      max_ells, (const int*)nullptr, (const double*)nullptr);
   return hip_ok(ctx, hipGetLastError(), "enlarge launch") ? DH_OK : DH_ERR_HIP;
@@ -4294,7 +4327,7 @@ int dh_scale_to_logvol(dh_ctx* ctx, int m, int d, double* covs, double* ams, dou
   double* d_lv = arena_up(ctx, (const double*)logvols, (size_t)m);
   const double* d_t = arena_up(ctx, targets, (size_t)m);
   if (!d_c || !d_p || !d_x || !d_al || !d_lv || !d_t) return DH_ERR_NOMEM;
-  hipLaunchKernelGGL(scale_logvol_kernel, dim3(m), dim3(d > 64 ? 1024 : 64), (size_t)2 * d * 8 + 64, ctx->stream, m, d,
+  hipLaunchKernelGGL(scale_logvol_kernel, dim3(m), dim3(d > 64 ? 1024 : 256), (size_t)2 * d * 8 + 64, ctx->stream, m, d,
                      d_c, d_p, d_x, d_al, d_lv, d_t, 0.0, (const int*)nullptr, 1, (const int*)nullptr,
                      (const double*)nullptr);
   if (!hip_ok(ctx, hipGetLastError(), "scale_to_logvol launch")) return DH_ERR_HIP;
