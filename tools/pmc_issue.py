@@ -30,7 +30,7 @@ if root == "reduce":
     for f in glob.glob(d + "/*/*.csv") + glob.glob(d + "/*.csv") + glob.glob(d + "/*/*.db"):
         os.remove(f)
     sys.exit(0)
-KEEP = ("rwalkq_kernel", "itemgen_kernel", "rwalk_kernel", "k_ell<false>", "k_split", "k_root_parts", "k_root_eig", "k_finish",
+KEEP = ("rwalkq_kernel", "itemgen_kernel", "rwalk_kernel", "k_ell<false", "k_split", "k_root_parts", "k_root_eig", "k_finish",
         "wide_walk_kernel", "wide_eig2_kernel", "ns_consume", "ns_select", "cube_quad_kernel", "contains_runs_kernel",
         "slice_kernel", "unif_kernel")
 
