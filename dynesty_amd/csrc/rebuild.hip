@@ -1143,6 +1143,13 @@ __device__ __forceinline__ bool regularize(const Lds& L, double* cov, int D) {
 // reference's own route (regularize: Jacobi eigh + the 100-trial loop).  The ellipsoids that
 // survive the accept test get their full eigen-system from k_out_eig at the end (same Jacobi, run
 // once per OUTPUT instead of once per tree node).
+#ifndef DH_SPD_OVERLAP
+// 1: the sweeps (wavefronts 0, 1) and the squarings (wavefronts 2, 3) of spd_fast side by side.  MEASURED AND OFF
+// (round 6, tools/r6_phase.py): bit-identical, but the sweeps are bound by the instructions of a wavefront, not by
+// latency -- on 128 threads a double sweep takes twice as long (ldl+inv 270 -> 520-700 per node, in hundreds of cycles)
+// and eats what the hidden squarings give (-25 .. -330): 64 runs 1.04 -> 1.09 ms.  The code stays for the record.
+#define DH_SPD_OVERLAP 0
+#endif
 constexpr double kFastCond = 1e7;
 constexpr int kFastSquarings = 48;
 
@@ -1183,6 +1190,31 @@ __device__ __forceinline__ void sym_square(const double* P, double* Q, int D, in
       double sum = 0.0;
       for (int k = 0; k < D; ++k) sum = fma(P[k * LD + i], P[k * LD + j], sum);
       Q[i * LD + j] = sum * s2;
+    }
+  }
+}
+
+// sym_square's matrix-core form for the wavefronts wfirst .. wfirst + nw - 1 alone (tile by tile the same products:
+// the same bits as sym_square's); D >= kMfmaMinDim; caller barriers
+__device__ __forceinline__ void sym_square_waves(const double* P, double* Q, int D, int LD, double s2, int wfirst, int nw) {
+  const int lane = threadIdx.x & 63, w = (threadIdx.x >> 6) - wfirst;
+  const int nb = (D + 15) >> 4, ksteps = (D + 3) >> 2;
+  const int lj = lane & 15, lk = lane >> 4;
+  for (int tile = w; tile < nb * nb; tile += nw) {
+    const int ti = tile / nb, tj = tile - ti * nb;
+    mfma_acc acc = {0.0, 0.0, 0.0, 0.0};
+    const int ca = ti * 16 + lj, cb = tj * 16 + lj;
+    for (int ks = 0; ks < ksteps; ++ks) {
+      const int k = ks * 4 + lk;
+      const bool kv = k < D;
+      const double av = sel_ld(P, k * LD + ca, kv && ca < D);
+      const double bv = sel_ld(P, k * LD + cb, kv && cb < D);
+      acc = DH_MFMA_F64(av, bv, acc);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = ti * 16 + lk + 4 * r;
+      if (i < D && cb < D) Q[i * LD + cb] = acc[r] * s2;
     }
   }
 }
@@ -1242,6 +1274,43 @@ __device__ __forceinline__ bool spd_fast(const Lds& L, const double* cov, int D,
   // (the squarings and the Rayleigh quotient read the covariance from `keep` where there is one, else from `cov`: two
   // code paths, not one pointer -- a pointer that may be LDS or global is a generic one, and its loads FLAT loads)
   const double tr_cov = wave_trace(src, D, LD);
+  // (round 6) SWEEPS AND SQUARINGS SIDE BY SIDE.  The inverse (13 double sweeps at D = 25) and the dominant eigenvector
+  // (8-14 squarings) both need only the covariance, and they ran one after the other: 12 + 8-16 us of a node's ~45.
+  // In the 256-thread kernels wavefronts 0, 1 now sweep (their 128 threads take the rows in two batches) while
+  // wavefronts 2, 3 square -- first from the untouched copy in L.AX (scaled by s0^2 in the product: powers of two,
+  // the same bits as squaring the scaled copy), then between L.V and L.AX -- meeting at the sweeps' own barriers.  A
+  // squaring chain that is not done when the sweeps are goes on with all four wavefronts, as before.  The covariance
+  // is read back from the node's global working copy afterwards (one trip) for the Rayleigh quotient and the record.
+  const int wv = threadIdx.x >> 6;
+  const bool ovl = NT == kThreads && want_axis && keep != nullptr && keep == L.AX && D <= 32 && D >= kMfmaMinDim &&
+                   !(DH_SPD_OVERLAP == 0);
+  const bool sweeper = !ovl || wv < 2;
+  const int istep_e = ovl ? (128 >> jsh) : istep;
+  const double s0_o = ldexp(1.0, -(ilogb(tr_cov) + 1));  // (as below: trace of the scaled copy in [1/2, 1))
+  const double* sP = L.AX;
+  double* sQ = L.V;
+  double trP_o = tr_cov * s0_o;
+  bool conv_o = false;
+  int nsq = 0;
+  auto square_issue = [&]() {  // wavefronts 2, 3: one squaring's products
+    if (ovl && wv >= 2 && !conv_o) {
+      const double sc = ldexp(1.0, -(ilogb(trP_o * trP_o) + 1));
+      sym_square_waves(sP, sQ, D, LD, nsq == 0 ? sc * s0_o * s0_o : sc, 2, 2);
+    }
+  };
+  auto square_close = [&]() {  // ... and, behind the barrier, its trace and the convergence test
+    if (ovl && wv >= 2 && !conv_o) {
+      const double sc = ldexp(1.0, -(ilogb(trP_o * trP_o) + 1));
+      const double trQ = wave_trace(sQ, D, LD);
+      const double r = trQ / (trP_o * trP_o * sc);
+      conv_o = 1.0 - r < 1e-8;
+      trP_o = trQ;
+      const double* nP = sQ;
+      sQ = nsq == 0 ? L.AX : const_cast<double*>(sP);
+      sP = nP;
+      ++nsq;
+    }
+  };
   bool ok = true;
   int k = 0;
   for (; k + 1 < D; k += 2) {
@@ -1264,16 +1333,16 @@ __device__ __forceinline__ bool spd_fast(const Lds& L, const double* cov, int D,
       pivs[k] = piv;
       pivs[k1] = piv1;
     }
-    if (j < D) {
+    if (sweeper && j < D) {
       const double cj = src[k * LD + j], dj = src[k1 * LD + j];
       const double cjr = cj * rp;
       const double r1j = (j == k) ? a10 * rp : fma(-a10, cjr, dj);  // sweep k: (row k + 1, column j)
       const double cjr1 = r1j * rp1;
-      for (int ib = i0; ib < D; ib += 4 * istep) {
+      for (int ib = i0; ib < D; ib += 4 * istep_e) {
         double ci[4], ei[4], w[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          const int i = ib + u * istep;
+          const int i = ib + u * istep_e;
           const int ic = i < D ? i : k;
           ci[u] = src[ic * LD + k];
           ei[u] = src[ic * LD + k1];
@@ -1281,7 +1350,7 @@ __device__ __forceinline__ bool spd_fast(const Lds& L, const double* cov, int D,
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          const int i = ib + u * istep;
+          const int i = ib + u * istep_e;
           // sweep k at (i, j) and at (i, k + 1)
           double v = fma(-ci[u], cjr, w[u]);
           v = (j == k) ? ci[u] * rp : v;
@@ -1295,7 +1364,9 @@ __device__ __forceinline__ bool spd_fast(const Lds& L, const double* cov, int D,
         }
       }
     }
+    square_issue();
     __syncthreads();
+    square_close();
     double* tmp = src;
     src = dst;
     dst = tmp;
@@ -1307,21 +1378,21 @@ __device__ __forceinline__ bool spd_fast(const Lds& L, const double* cov, int D,
     } else {
       const double rp = rcp_nr(piv);
       if (t == 0) pivs[k] = piv;
-      if (j < D) {
+      if (sweeper && j < D) {
         const double cj = src[k * LD + j];
         const double cjr = cj * rp;
-        for (int ib = i0; ib < D; ib += 4 * istep) {
+        for (int ib = i0; ib < D; ib += 4 * istep_e) {
           double ci[4], w[4];
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
-            const int i = ib + u * istep;
+            const int i = ib + u * istep_e;
             const int ic = i < D ? i : k;
             ci[u] = src[ic * LD + k];
             w[u] = src[ic * LD + j];
           }
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
-            const int i = ib + u * istep;
+            const int i = ib + u * istep_e;
             double val = fma(-ci[u], cjr, w[u]);
             val = (j == k) ? ci[u] * rp : val;
             val = (i == k) ? ((j == k) ? -rp : cjr) : val;
@@ -1329,13 +1400,24 @@ __device__ __forceinline__ bool spd_fast(const Lds& L, const double* cov, int D,
           }
         }
       }
+      square_issue();
       __syncthreads();
+      square_close();
       double* tmp = src;
       src = dst;
       dst = tmp;
     }
   }
   if (!ok) return false;
+  // the squaring wavefronts' state to everybody (read behind the barrier of the symmetrised inverse below)
+  __shared__ double s_ovl_tr;
+  __shared__ int s_ovl[3];
+  if (ovl && threadIdx.x == 128) {
+    s_ovl_tr = trP_o;
+    s_ovl[0] = conv_o ? 1 : 0;
+    s_ovl[1] = nsq;
+    s_ovl[2] = sP == L.V ? 1 : 0;
+  }
   double ld;
   {
     const int lane = t & 63;  // every wave for itself (D <= 44 < 64)
@@ -1351,7 +1433,7 @@ __device__ __forceinline__ bool spd_fast(const Lds& L, const double* cov, int D,
   *logdet = ld;
   PH_ADD(13);
   // (with the copy kept in L.AX the matrix is zeroed where the axis is written, at the end)
-  if (!(want_axis && keep == L.AX)) {
+  if (!(want_axis && keep == L.AX)) {  // (never with the overlap: it needs keep == L.AX)
     for (int e = t; e < D * D; e += NT) L.AX[(e / D) * LD + e % D] = 0.0;
     if (t < D) L.lam[t] = 0.0;
   }
@@ -1376,17 +1458,32 @@ __device__ __forceinline__ bool spd_fast(const Lds& L, const double* cov, int D,
   // ---- dominant eigenvector by repeated squaring ----
   double* P = L.A;
   double* Q = L.V;
-  {
-    const double s0 = ldexp(1.0, -(ilogb(tr_cov) + 1));  // trace in [1/2, 1)
-    if (keep)
-      for (int e = t; e < D * D; e += NT) P[(e / D) * LD + e % D] = keep[(e / D) * LD + e % D] * s0;
-    else
-      for (int e = t; e < D * D; e += NT) P[(e / D) * LD + e % D] = cov[(e / D) * LD + e % D] * s0;
-  }
-  __syncthreads();
-  double trP = wave_trace(P, D, LD);
+  double trP;
   bool conv = false;
-  for (int it = 0; it < kFastSquarings && !conv; ++it) {
+  int it0 = 0;
+  if (ovl) {
+    // what wavefronts 2, 3 have done beside the sweeps; the covariance comes back into L.A (free since the inverse was
+    // symmetrised into L.AM) from the node's global working copy
+    trP = s_ovl_tr;
+    conv = s_ovl[0] != 0;
+    it0 = s_ovl[1];
+    P = s_ovl[2] ? L.V : L.AX;
+    Q = s_ovl[2] ? L.AX : L.V;
+    if (conv)
+      for (int e = t; e < D * D; e += NT) L.A[(e / D) * LD + e % D] = cov[(e / D) * LD + e % D];
+    __syncthreads();
+  } else {
+    {
+      const double s0 = ldexp(1.0, -(ilogb(tr_cov) + 1));  // trace in [1/2, 1)
+      if (keep)
+        for (int e = t; e < D * D; e += NT) P[(e / D) * LD + e % D] = keep[(e / D) * LD + e % D] * s0;
+      else
+        for (int e = t; e < D * D; e += NT) P[(e / D) * LD + e % D] = cov[(e / D) * LD + e % D] * s0;
+    }
+    __syncthreads();
+    trP = wave_trace(P, D, LD);
+  }
+  for (int it = it0; it < kFastSquarings && !conv; ++it) {
     // the product is scaled by a power of two (exact) chosen from tr(P)^2, the upper bound of its
     // trace: tr(P^2) / tr(P)^2 = r in [1/D, 1] is the sum of the squared eigenvalue weights of P, so the
     // stored trace stays within [1/(4D), 1) without a pass of its own
@@ -1401,6 +1498,10 @@ __device__ __forceinline__ bool spd_fast(const Lds& L, const double* cov, int D,
     double* tmp = P;
     P = Q;
     Q = tmp;
+    if (ovl && conv) {  // (the covariance back into L.A, as above)
+      for (int e = t; e < D * D; e += NT) L.A[(e / D) * LD + e % D] = cov[(e / D) * LD + e % D];
+      __syncthreads();
+    }
   }
   if (!conv) return false;
   PH_ADD(14);
@@ -1465,10 +1566,11 @@ __device__ __forceinline__ bool spd_fast(const Lds& L, const double* cov, int D,
   // squaring buffer that is free now (Q) and writes the axis matrix -- column 0 = sqrt(lam_max) v, zero elsewhere: the
   // same values as above
   __shared__ double s_q;
+  const double* cvm = ovl ? L.A : L.AX;  // where the covariance sits now
   if (t < 64) {
     double y = 0.0;
     if (t < D)
-      for (int k = 0; k < D; ++k) y = fma(L.AX[t * LD + k], s_v[k], y);
+      for (int k = 0; k < D; ++k) y = fma(cvm[t * LD + k], s_v[k], y);
     const double q = wave_sum(t < D ? y * s_v[t] : 0.0);
     if (t == 0) s_q = q;
   }
@@ -1477,11 +1579,11 @@ __device__ __forceinline__ bool spd_fast(const Lds& L, const double* cov, int D,
     const double q = s_q, rq = sqrt(q);
     for (int e = t; e < D * D; e += NT) {
       const int i = e / D, jj = e - i * D, o = i * LD + jj;
-      Q[o] = L.AX[o];
+      if (!ovl) Q[o] = L.AX[o];
       L.AX[o] = jj == 0 ? s_v[i] * rq : 0.0;
     }
     if (t < D) L.lam[t] = t == 0 ? q : 0.0;
-    if (cov_keep) *cov_keep = Q;
+    if (cov_keep) *cov_keep = ovl ? L.A : Q;
     __syncthreads();
     PH_ADD(15);
     return q > 0.0 && isfinite(q);
