@@ -129,7 +129,8 @@ __device__ __forceinline__ double wide_logl(const ProblemDev& P, int D, const do
         __builtin_amdgcn_wave_barrier();
         for (int t0 = 0; t0 < ntail; t0 += 64) {
           const int ti = t0 + lane;
-          const double pt = ti < ntail ? tails[ti] : 0.25;
+          const double ptv = tails[ti < ntail ? ti : 0];
+          const double pt = ti < ntail ? ptv : 0.25;
           bool far;
           double r = ndtri_as241_tail(pt, &far);
           if (far) r = ndtri_far(pt);
@@ -137,9 +138,14 @@ __device__ __forceinline__ double wide_logl(const ProblemDev& P, int D, const do
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();
+      {  // (round 6: the four reads unconditionally and together -- under their conditions each was a branch with an
+         // LDS round trip and a full wait of its own, in every F evaluation)
+        double tv[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-          if (slot[q] >= 0) o[q] = tails[slot[q]];
+        for (int q = 0; q < 4; ++q) tv[q] = tails[slot[q] >= 0 ? slot[q] : 0];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q] = slot[q] >= 0 ? tv[q] : o[q];
+      }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();
       }
@@ -258,7 +264,8 @@ __device__ __forceinline__ double wide_F_regs(const ProblemDev& P, int D, const 
       __builtin_amdgcn_wave_barrier();
       for (int t0 = 0; t0 < ntail; t0 += 64) {
         const int ti = t0 + lane;
-        const double pt = ti < ntail ? tails[ti] : 0.25;
+        const double ptv = tails[ti < ntail ? ti : 0];
+        const double pt = ti < ntail ? ptv : 0.25;
         bool far;
         double r = ndtri_as241_tail(pt, &far);
         if (far) r = ndtri_far(pt);
@@ -266,9 +273,13 @@ __device__ __forceinline__ double wide_F_regs(const ProblemDev& P, int D, const 
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
       __builtin_amdgcn_wave_barrier();
+      {
+        double tv[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
-        if (slot[q] >= 0) o[q] = tails[slot[q]];
+        for (int q = 0; q < 4; ++q) tv[q] = tails[slot[q] >= 0 ? slot[q] : 0];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q] = slot[q] >= 0 ? tv[q] : o[q];
+      }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
       __builtin_amdgcn_wave_barrier();
     }
@@ -428,6 +439,10 @@ constexpr int kWalkMaxWaves = 4;  // walkers per workgroup: one wavefront per SI
 // (256 VGPRs): a lone wavefront issues a v_fma_f64 only every 8.5 cycles (tools/micro/
 // mfma_f64_shapes.hip), so a second wavefront per SIMD nearly doubles the fp64 throughput of the F
 // evaluations once there are more than 1024 walkers; the spills this costs are outside the hot loops.
+// (round 6) The cycle split of DH_WIDE_PROF=1 is taken only when it is asked for: every F evaluation, direction round and
+// frame product of every walker read the clock twice -- s_memtime and, with it, a wait for every outstanding LDS
+// operation of the wavefront -- whether anybody looked at the numbers or not.
+#define WCLK() (a.dbg ? clock64() : 0ll)
 template <int KIND, int RNG>
 __global__ void __launch_bounds__(64 * kWalkMaxWaves, 2) wide_walk_kernel(WideWalkArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -570,7 +585,7 @@ __global__ void __launch_bounds__(64 * kWalkMaxWaves, 2) wide_walk_kernel(WideWa
   }
 
   // ---- rslice / slice (internal_samplers.py:593-855, 1038-1206) ----
-  long long cy_n = 0, cy_m = 0, cy_f = 0, cy_g = 0, cy_t0 = clock64();
+  long long cy_n = 0, cy_m = 0, cy_f = 0, cy_g = 0, cy_t0 = WCLK();
   bool doubling = (a.run_doubling ? a.run_doubling[run] : a.doubling0) != 0, warn_set = false, failed = false;
   int ncall = 0, n_expand = 0, n_contract = 0;
   double logl_cur = 0.0;
@@ -594,7 +609,7 @@ __global__ void __launch_bounds__(64 * kWalkMaxWaves, 2) wide_walk_kernel(WideWa
     for (int sub = 0; sub < nsub && (!failed || KIND == 1); ++sub) {
       if (KIND == 1) {
         // a failed walker keeps the workgroup's barriers company and does nothing else
-        const long long c0_ = clock64();
+        const long long c0_ = WCLK();
         if (!failed) {
           g.normals(sv, D, lane);  // sv as scratch for drhat
           lds_sync();
@@ -606,18 +621,18 @@ __global__ void __launch_bounds__(64 * kWalkMaxWaves, 2) wide_walk_kernel(WideWa
           for (int i = lane; i < D; i += 64) sv[i] = sv[i] * inv;
           lds_sync();
         }
-        const long long c1_ = clock64();
+        const long long c1_ = WCLK();
         cy_n += c1_ - c0_;
         if (coop) {
           __syncthreads();
-          const long long cg_ = clock64();
+          const long long cg_ = WCLK();
           wg_frame_gemm(AT, D, wbase, ws, 3 * D, 2 * D, scale, wpw, wv, wpw);
-          cy_g += clock64() - cg_;
+          cy_g += WCLK() - cg_;
           __syncthreads();
         } else if (!failed) {
           wg_frame_gemm(AT, D, su, ws, 3 * D, 2 * D, scale, 1, 0, 1);
         }
-        cy_m += clock64() - c1_;
+        cy_m += WCLK() - c1_;
         if (failed) continue;
       } else {
         const int idx = sperm[sub];
@@ -658,7 +673,7 @@ __global__ void __launch_bounds__(64 * kWalkMaxWaves, 2) wide_walk_kernel(WideWa
       double xq = left;
       while (phase != SL_DONE) {
         // F(xq): u_new = u + xq * direction; unitcheck; prior; likelihood
-        const long long cf_ = clock64();
+        const long long cf_ = WCLK();
         double f = -INFINITY;
         ++ncall;
         if (regF) {
@@ -679,7 +694,7 @@ __global__ void __launch_bounds__(64 * kWalkMaxWaves, 2) wide_walk_kernel(WideWa
             lds_sync();
           }
         }
-        cy_f += clock64() - cf_;
+        cy_f += WCLK() - cf_;
         switch (phase) {
           case SL_LEFT0:
             f_l = f;
@@ -838,7 +853,7 @@ __global__ void __launch_bounds__(64 * kWalkMaxWaves, 2) wide_walk_kernel(WideWa
   }
   if (a.dbg && w == 0 && lane == 0)
     printf("wide_walk wave 0: total %lld | normals %lld | frame product %lld (GEMM itself %lld) | F %lld (ncall %d)\n",
-           (long long)(clock64() - cy_t0), cy_n, cy_m, cy_g, cy_f, ncall);
+           (long long)(WCLK() - cy_t0), cy_n, cy_m, cy_g, cy_f, ncall);
   (void)WIDE_F(a.prob, D, su, sv, lane);  // v of the returned point
   lds_sync();
   if (ghost) return;
@@ -891,6 +906,7 @@ struct WideUnifArgs {
   int wpr, my_mode, run_me;
 };
 
+#undef WCLK
 template <int RNG>
 __global__ void __launch_bounds__(64) wide_unif_kernel(WideUnifArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1535,7 +1551,7 @@ __global__ void __launch_bounds__(kRT) wide_eig_kernel(WideEigArgs a) {
   int* rot = a.rot + (size_t)run * kEigMaxSweeps;
   const double tol2 = (double)D * (2.220446049250313e-16 * 2.220446049250313e-16);
   int nbar = 0;
-  long long tp_ = clock64(), cy_rot = 0, cy_st = 0, cy_bar = 0, cy_ld = 0;
+  long long tp_ = (a.dbg ? clock64() : 0ll), cy_rot = 0, cy_st = 0, cy_bar = 0, cy_ld = 0;
 
   // circle method: the pair of blocks workgroup w holds in round r
   auto pair_of = [&](int r, int& top, int& bot) {
@@ -1597,7 +1613,7 @@ __global__ void __launch_bounds__(kRT) wide_eig_kernel(WideEigArgs a) {
   for (sweep = 0; sweep < kEigMaxSweeps && ok && !converged; ++sweep) {
     for (int r = 0; r < M - 1 && ok; ++r) {
       int nrot = 0;
-      long long c0_ = clock64();
+      long long c0_ = (a.dbg ? clock64() : 0ll);
       if (r == 0) {
         // all pairs among the 2b columns: circle method inside the tile (2b - 1 steps of b pairs)
         const int m2 = 2 * b;
@@ -1624,8 +1640,8 @@ __global__ void __launch_bounds__(kRT) wide_eig_kernel(WideEigArgs a) {
       }
       if (lane == 0 && nrot) atomicAdd(&s_rot, nrot);
       __syncthreads();
-      cy_rot += clock64() - c0_;
-      c0_ = clock64();
+      cy_rot += (a.dbg ? clock64() : 0ll) - c0_;
+      c0_ = (a.dbg ? clock64() : 0ll);
       const bool last_round = r == M - 2;
       if (M > 2) {
         // hand the blocks on
@@ -1643,16 +1659,16 @@ __global__ void __launch_bounds__(kRT) wide_eig_kernel(WideEigArgs a) {
         s_rot = 0;
       }
       __syncthreads();  // (stores drained)
-      cy_st += clock64() - c0_;
-      c0_ = clock64();
+      cy_st += (a.dbg ? clock64() : 0ll) - c0_;
+      c0_ = (a.dbg ? clock64() : 0ll);
       if (B > 1) {
         ++nbar;
         ok = eig_barrier(bar, B * nbar, &s_ok);
       } else {
         __syncthreads();
       }
-      cy_bar += clock64() - c0_;
-      c0_ = clock64();
+      cy_bar += (a.dbg ? clock64() : 0ll) - c0_;
+      c0_ = (a.dbg ? clock64() : 0ll);
       if (last_round) {
         const int total = __hip_atomic_load(rot + sweep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         converged = total == 0;
@@ -1682,12 +1698,12 @@ __global__ void __launch_bounds__(kRT) wide_eig_kernel(WideEigArgs a) {
         parity ^= 1;
         __syncthreads();
       }
-      cy_ld += clock64() - c0_;
+      cy_ld += (a.dbg ? clock64() : 0ll) - c0_;
     }
   }
   if (a.dbg && t == 0 && blockIdx.x == 0)
     printf("wide_eig: D %d, %d workgroups x %d columns, %d sweeps, %lld cycles (rotations %lld, hand-on %lld, barrier %lld, pick-up %lld)\n",
-           D, B, 2 * b, sweep, (long long)(clock64() - tp_), cy_rot, cy_st, cy_bar, cy_ld);
+           D, B, 2 * b, sweep, (long long)((a.dbg ? clock64() : 0ll) - tp_), cy_rot, cy_st, cy_bar, cy_ld);
   // results: the blocks this workgroup holds now (those of the last round it worked on)
   if (ok && converged) {
     int top, bot;
@@ -1729,7 +1745,7 @@ __global__ void __launch_bounds__(kRT) wide_eig2_kernel(WideEigArgs a) {
   int* rot = a.rot + (size_t)run * kEigMaxSweeps;
   const double tol2 = (double)D * (2.220446049250313e-16 * 2.220446049250313e-16);
   int nbar = 0;
-  long long tp_ = clock64(), cy_rot = 0, cy_st = 0, cy_bar = 0, cy_ld = 0, cy_a = 0, cy_b = 0, cy_c = 0;
+  long long tp_ = (a.dbg ? clock64() : 0ll), cy_rot = 0, cy_st = 0, cy_bar = 0, cy_ld = 0, cy_a = 0, cy_b = 0, cy_c = 0;
 
   // circle method: the pair of blocks workgroup w holds in round r
   auto pair_of = [&](int r, int& top, int& bot) {
@@ -1775,7 +1791,7 @@ __global__ void __launch_bounds__(kRT) wide_eig2_kernel(WideEigArgs a) {
   for (sweep = 0; sweep < kEigMaxSweeps && ok && !converged; ++sweep) {
     for (int r = 0; r < M - 1 && ok; ++r) {
       int nrot = 0;
-      long long c0_ = clock64();
+      long long c0_ = (a.dbg ? clock64() : 0ll);
       const int m2 = 2 * b, nt = (m2 + 15) >> 4;
       // (a) Gram matrix of the G parts on the matrix cores: tiles (0,0) (0,1) (1,1) x four slices of
       // the rows, partial tiles summed in slice order
@@ -1811,8 +1827,8 @@ __global__ void __launch_bounds__(kRT) wide_eig2_kernel(WideEigArgs a) {
         jm0[i * kGS + j] = i == j ? 1.0 : 0.0;
       }
       __syncthreads();
-      cy_a += clock64() - c0_;
-      long long c1_ = clock64();
+      cy_a += (a.dbg ? clock64() : 0ll) - c0_;
+      long long c1_ = (a.dbg ? clock64() : 0ll);
       // (b) the round's rotations on the small matrices: angles from the Gram matrix, Gm <- R^T Gm R,
       // J <- J R (element-wise with the partner map: new column = coefa * own + coefb * partner)
       int cur = 0;
@@ -1864,8 +1880,8 @@ __global__ void __launch_bounds__(kRT) wide_eig2_kernel(WideEigArgs a) {
         __syncthreads();
         cur ^= 1;
       }
-      cy_b += clock64() - c1_;
-      c1_ = clock64();
+      cy_b += (a.dbg ? clock64() : 0ll) - c1_;
+      c1_ = (a.dbg ? clock64() : 0ll);
       // (c) the columns (G and V parts) times the accumulated rotation, on the matrix cores; a wave
       // owns 16 rows at a time: all of their operands are in registers before the first write
       {
@@ -1906,11 +1922,11 @@ __global__ void __launch_bounds__(kRT) wide_eig2_kernel(WideEigArgs a) {
         }
       }
       __syncthreads();
-      cy_c += clock64() - c1_;
+      cy_c += (a.dbg ? clock64() : 0ll) - c1_;
       if (nrot) atomicAdd(&s_rot, nrot);
       __syncthreads();
-      cy_rot += clock64() - c0_;
-      c0_ = clock64();
+      cy_rot += (a.dbg ? clock64() : 0ll) - c0_;
+      c0_ = (a.dbg ? clock64() : 0ll);
       const bool last_round = r == M - 2;
       if (M > 2) {
         // hand the blocks on
@@ -1928,16 +1944,16 @@ __global__ void __launch_bounds__(kRT) wide_eig2_kernel(WideEigArgs a) {
         s_rot = 0;
       }
       __syncthreads();  // (stores drained)
-      cy_st += clock64() - c0_;
-      c0_ = clock64();
+      cy_st += (a.dbg ? clock64() : 0ll) - c0_;
+      c0_ = (a.dbg ? clock64() : 0ll);
       if (B > 1) {
         ++nbar;
         ok = eig_barrier(bar, B * nbar, &s_ok);
       } else {
         __syncthreads();
       }
-      cy_bar += clock64() - c0_;
-      c0_ = clock64();
+      cy_bar += (a.dbg ? clock64() : 0ll) - c0_;
+      c0_ = (a.dbg ? clock64() : 0ll);
       if (last_round) {
         const int total = __hip_atomic_load(rot + sweep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         converged = total == 0;
@@ -1967,12 +1983,12 @@ __global__ void __launch_bounds__(kRT) wide_eig2_kernel(WideEigArgs a) {
         parity ^= 1;
         __syncthreads();
       }
-      cy_ld += clock64() - c0_;
+      cy_ld += (a.dbg ? clock64() : 0ll) - c0_;
     }
   }
   if (a.dbg && t == 0 && blockIdx.x == 0)
     printf("wide_eig2: D %d, %d workgroups x %d columns, %d sweeps, %lld cycles (rotations %lld = Gram %lld + steps %lld + apply %lld, hand-on %lld, barrier %lld, pick-up %lld)\n",
-           D, B, 2 * b, sweep, (long long)(clock64() - tp_), cy_rot, cy_a, cy_b, cy_c, cy_st, cy_bar, cy_ld);
+           D, B, 2 * b, sweep, (long long)((a.dbg ? clock64() : 0ll) - tp_), cy_rot, cy_a, cy_b, cy_c, cy_st, cy_bar, cy_ld);
   // results: the blocks this workgroup holds now (those of the last round it worked on)
   if (ok && converged) {
     int top, bot;
