@@ -4162,10 +4162,18 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
   // side stream no longer pays -- measured on the bench shard (tools/r6_env.sh): 64 runs 1.065 ms either way, one run
   // 0.70 -> 0.66 and 128 runs 2.05 -> 2.01 WITHOUT it (two more event waits per level, five 31 KB leaf workgroups per
   // CU beside the level's own) -- so it is off by default; DH_LEAF_SIDE=1 switches it on.
+  // Round 6, second half: the leaves by a light kernel of their own on the MAIN stream (DH_LEAF_MAIN=1; measured and
+  // left off).  A leaf needs neither the axis nor a second tile: k_ell_wave<256> -- the same routines with four
+  // wavefronts, a carve of the tile (4 d - 1 points) and two matrices, 31 KB instead of k_ell's 77 -- in front of the
+  // level's k_ell, which skips what it takes.  The 2 048 leaves of the 64-run bench tree's last busy level are four
+  // rounds of k_ell's two workgroups per CU (112 us); the light kernel took 90 us for them (its wave-by-wave fold, 20
+  // spilled registers at the 168 of three workgroups per CU) and k_ell another 56 for the level's splittable children:
+  // 1.04 -> 1.09 ms per 64 runs.
   int leaf_from = nlev, leaf_cap = 0;
   size_t lds_leaf = 0;
-  if (a.fast && mode == 0 && tail && forked && wave_from >= nlev && d >= 14 &&
-      (getenv("DH_LEAF_SIDE") && atoi(getenv("DH_LEAF_SIDE")) == 1)) {  // (round 6: off unless asked for, see below)
+  const bool leaf_side = getenv("DH_LEAF_SIDE") && atoi(getenv("DH_LEAF_SIDE")) == 1;
+  const bool leaf_main = !leaf_side && getenv("DH_LEAF_MAIN") && atoi(getenv("DH_LEAF_MAIN")) == 1;
+  if (a.fast && mode == 0 && tail && (forked || leaf_main) && wave_from >= nlev && d >= 14 && (leaf_side || leaf_main)) {
     leaf_cap = 4 * d - 1 < 128 ? 4 * d - 1 : 128;
     lds_leaf = wave_lds_bytes(d, leaf_cap, false);
     if (lds_leaf <= 64 * 1024) {
@@ -4210,7 +4218,9 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
       hipLaunchKernelGGL(k_ell_wave<64>, dim3(runs * ge), dim3(64), lds_wave, ctx->stream, a, L, ge,
                          wave_cap, wave_axis, 0);
     const int lc = (leaf_cap > 0 && L >= leaf_from) ? leaf_cap : 0;
-    if (lc && !hip_ok(ctx, hipEventRecord(ctx->ev_leaf, ctx->stream), "hipEventRecord(leaf fork)")) return DH_ERR_HIP;
+    if (lc && leaf_main)
+      hipLaunchKernelGGL(k_ell_wave<256>, dim3(runs * ge), dim3(256), lds_leaf, ctx->stream, a, L, ge, leaf_cap, 0, 1);
+    if (lc && leaf_side && !hip_ok(ctx, hipEventRecord(ctx->ev_leaf, ctx->stream), "hipEventRecord(leaf fork)")) return DH_ERR_HIP;
     // The top levels' children are several 256-point tiles each and few (one workgroup per CU or less): their
     // workgroups stage 512 points at once -- a 1 000-point child is gathered three times instead of seven (covariance
     // pass 2 + Mahalanobis pass 1, the last tile still staged), a 500-point child once instead of three times.  Only
@@ -4228,7 +4238,7 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
     else
       hipLaunchKernelGGL(k_ell<true>, dim3(runs * ge), dim3(kThreads), top ? lds_top : lds, ctx->stream, a, L, ge, 0, 0,
                          top ? 2 * kThreads : kThreads);
-    if (lc) {  // (submitted after the level's k_ell: its few splittable children should get their slots first)
+    if (lc && leaf_side) {  // (submitted after the level's k_ell: its few splittable children should get their slots first)
       if (!hip_ok(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->ev_leaf, 0), "hipStreamWaitEvent(leaf fork)"))
         return DH_ERR_HIP;
       hipLaunchKernelGGL(k_ell_wave<128>, dim3(runs * ge), dim3(128), lds_leaf, ctx->side_stream, a, L, ge,
