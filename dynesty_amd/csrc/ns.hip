@@ -1279,9 +1279,19 @@ __global__ void __launch_bounds__(kT) ns_consume(NsArgs a) {
   double sel_v = INFINITY;  // compact: the threshold value (the (K + 1)-th smallest key) ...
   int sel_extra = 0;        // ... and how many live points OUTSIDE the subset carry it
   if (!compact) {
-    for (int i = t; i < N; i += kT) {
-      skey[i] = a.live_logl[(size_t)run * N + i];
-      src[i] = -1;
+    // (round 6: eight keys of a thread in flight -- one load, one LDS store at a time the 2 000 keys of a C2 run were
+    // eight cold round trips in a row, 11 k cycles of every fill)
+    const double* keys = a.live_logl + (size_t)run * N;
+    for (int i0 = t; i0 < N; i0 += 8 * kT) {
+      double kv[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) kv[q] = keys[i0 + q * kT < N ? i0 + q * kT : 0];
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+        if (i0 + q * kT < N) {
+          skey[i0 + q * kT] = kv[q];
+          src[i0 + q * kT] = -1;
+        }
     }
   } else {
     const double* keys = a.live_logl + (size_t)run * N;
