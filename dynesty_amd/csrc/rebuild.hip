@@ -18,6 +18,7 @@
 #include <stdlib.h>
 
 #include "ctx.h"
+#include <type_traits>
 #include <vector>
 #include "eig_wave.h"
 
@@ -117,6 +118,7 @@ struct RebuildArgs {
   int kp_cap;
   int tq_sleep, tq_nocoh;  // diagnostics (DH_TREE_SLEEP, DH_TREE_NOCOH)
   unsigned epoch;          // rebuild launches of this context so far: part of the tag of the k-means partials
+  int root_run0;           // k_root_parts: first run of this launch (the runs go in chunks that are co-resident)
 };
 
 #ifdef DH_REBUILD_TIMING
@@ -1245,8 +1247,15 @@ template <int NT = kThreads>
 __device__ __forceinline__ bool spd_fast(const Lds& L, const double* cov, int D, bool want_axis, double* logdet,
                                          const double** cov_keep = nullptr, bool prepared = false) {
   const int t = threadIdx.x, LD = L.LD;
-  const int jsh = D <= 32 ? 5 : 6;
-  const int j = t & ((1 << jsh) - 1), i0 = t >> jsh, istep = NT >> jsh;
+  // Thread map of the element-wise passes (round 6): column j = t mod D, rows t / D, t / D + NT / D, ... -- every
+  // thread of the first (NT / D) D has work and a thread's rows are ceil(D / (NT / D)): 3 at D = 25 and 256 threads
+  // where the power-of-two map (column t & 31, 8 row groups) executed 4 row slots for 25 rows, the fourth for the
+  // threads of one group only.  The sweeps are instruction-bound (one instruction per ~10 cycles and wavefront): the
+  // slots executed are their time.  `j` is D for the threads beyond, which every `j < D` below already excludes.
+  const int istep = NT / D > 0 ? NT / D : 1;
+  const int i0 = t / D;
+  const int j = i0 < istep ? t - i0 * D : D;
+  const int jsh = D <= 32 ? 5 : 6;  // (the overlap experiment's 128-thread map)
   // Two sweeps per barrier (round 5): sweep k + 1 needs, of the matrix sweep k produces, row k + 1, column k + 1 and
   // the entry itself -- each of them one fma of entries of the matrix sweep k READS, so a thread forms them on its own
   // (the very expressions sweep k would have stored) and applies both sweeps to its entries before anyone has to
@@ -1284,8 +1293,10 @@ __device__ __forceinline__ bool spd_fast(const Lds& L, const double* cov, int D,
   const int wv = threadIdx.x >> 6;
   const bool ovl = NT == kThreads && want_axis && keep != nullptr && keep == L.AX && D <= 32 && D >= kMfmaMinDim &&
                    !(DH_SPD_OVERLAP == 0);
-  const bool sweeper = !ovl || wv < 2;
-  const int istep_e = ovl ? (128 >> jsh) : istep;
+  const bool sweeper = !ovl || (wv < 2 && i0 < (128 / D > 0 ? 128 / D : 1));
+  const int istep_e = ovl ? (128 / D > 0 ? 128 / D : 1) : istep;
+  const int nslots = (D + istep_e - 1) / istep_e;  // row slots of a thread (uniform)
+  (void)jsh;
   const double s0_o = ldexp(1.0, -(ilogb(tr_cov) + 1));  // (as below: trace of the scaled copy in [1/2, 1))
   const double* sP = L.AX;
   double* sQ = L.V;
@@ -1338,10 +1349,12 @@ __device__ __forceinline__ bool spd_fast(const Lds& L, const double* cov, int D,
       const double cjr = cj * rp;
       const double r1j = (j == k) ? a10 * rp : fma(-a10, cjr, dj);  // sweep k: (row k + 1, column j)
       const double cjr1 = r1j * rp1;
-      for (int ib = i0; ib < D; ib += 4 * istep_e) {
-        double ci[4], ei[4], w[4];
+      // (U row slots of a thread as straight-line code: exactly as many as the map needs -- see above)
+      auto rows = [&](auto Uc, int ib) {
+        constexpr int U = decltype(Uc)::value;
+        double ci[U], ei[U], w[U];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < U; ++u) {
           const int i = ib + u * istep_e;
           const int ic = i < D ? i : k;
           ci[u] = src[ic * LD + k];
@@ -1349,7 +1362,7 @@ __device__ __forceinline__ bool spd_fast(const Lds& L, const double* cov, int D,
           w[u] = src[ic * LD + j];
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < U; ++u) {
           const int i = ib + u * istep_e;
           // sweep k at (i, j) and at (i, k + 1)
           double v = fma(-ci[u], cjr, w[u]);
@@ -1362,7 +1375,15 @@ __device__ __forceinline__ bool spd_fast(const Lds& L, const double* cov, int D,
           val = (i == k1) ? ((j == k1) ? -rp1 : cjr1) : val;
           if (i < D) dst[i * LD + j] = val;
         }
-      }
+      };
+      if (nslots == 1)
+        rows(std::integral_constant<int, 1>{}, i0);
+      else if (nslots == 2)
+        rows(std::integral_constant<int, 2>{}, i0);
+      else if (nslots == 3)
+        rows(std::integral_constant<int, 3>{}, i0);
+      else
+        for (int ib = i0; ib < D; ib += 4 * istep_e) rows(std::integral_constant<int, 4>{}, ib);
     }
     square_issue();
     __syncthreads();
@@ -2433,7 +2454,7 @@ __device__ __forceinline__ void queue_split(const RebuildArgs& a, int run, int l
 __global__ void __launch_bounds__(kThreads, 2) k_root_parts(RebuildArgs a, int rp) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   PH_LEVEL(-1);
-  const int D = a.d, DD = D * D, t = threadIdx.x, run = blockIdx.x / rp, q = blockIdx.x % rp;
+  const int D = a.d, DD = D * D, t = threadIdx.x, run = a.root_run0 + blockIdx.x / rp, q = blockIdx.x % rp;
   const int n = a.n_arr ? a.n_arr[run] : a.n;
   if (a.active && !a.active[run]) return;
   Lds L;
@@ -3829,6 +3850,7 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
     return DH_OK;
   }
   RebuildArgs a;
+  a.root_run0 = 0;
   a.pts = pts;
   a.n = n;
   a.d = d;
@@ -3957,8 +3979,19 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
       if (cap_tree < cap_split) cap_split = cap_tree;  // the parts of a node may be k_tree workgroups
     }
   }
+  // The parts of a run meet at spin waits, so what is launched together must be resident together: when all runs x
+  // parts do not fit, the root goes in chunks of runs that do (round 6; before, 128 runs x 8 parts fell back to the
+  // single-workgroup root, 447 us against 81 us per 64 runs).
   int rp = n > 1 ? (n + kThreads - 1) / kThreads : 1;
-  if ((long long)runs * rp > cap_root) rp = 1;
+  if (rp > cap_root || (ctx->coop_launch && (long long)runs * rp > cap_root)) rp = 1;
+  int root_chunk = runs;
+  if (rp > 1 && (long long)runs * rp > cap_root) root_chunk = cap_root / rp;
+  if (getenv("DH_ROOT_ONE_LAUNCH") && atoi(getenv("DH_ROOT_ONE_LAUNCH")) == 1 && !ctx->coop_launch)
+    root_chunk = runs;  // experiment: one launch, run-major ids, relying on in-order dispatch as k_split's chunks do
+  if (getenv("DH_ROOT_CHUNK") && atoi(getenv("DH_ROOT_CHUNK")) == 0) {  // diagnostic: the form before
+    root_chunk = runs;
+    if ((long long)runs * rp > cap_root) rp = 1;
+  }
   if (mode == 0 && (n + a.tps - 1) / a.tps > cap_split)
     return fail(ctx, DH_ERR_ARG, "rebuild: the %d parts of a %d-point node exceed the %d co-resident workgroups of k_split",
                 (n + a.tps - 1) / a.tps, n, cap_split);
@@ -4105,8 +4138,13 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
     attr_fin = lds_fin;
   }
   if (!hip_ok(ctx, hipMemsetAsync(cnt, 0, b_cnt, ctx->stream), "memset(rebuild counters)")) return DH_ERR_HIP;
-  if (!hip_ok(ctx, launch_all_resident(ctx, k_root_parts, dim3(runs * rp), dim3(kThreads), lds, a, rp), "k_root_parts launch"))
-    return DH_ERR_HIP;
+  for (int r0 = 0; r0 < runs; r0 += root_chunk) {
+    a.root_run0 = r0;
+    const int cr = runs - r0 < root_chunk ? runs - r0 : root_chunk;
+    if (!hip_ok(ctx, launch_all_resident(ctx, k_root_parts, dim3(cr * rp), dim3(kThreads), lds, a, rp), "k_root_parts launch"))
+      return DH_ERR_HIP;
+  }
+  a.root_run0 = 0;
   bool forked = false;
   if (a.fast && !(getenv("DH_ROOT_EIG_SIDE") && atoi(getenv("DH_ROOT_EIG_SIDE")) == 0)) {
     if (!ctx->side_stream) {

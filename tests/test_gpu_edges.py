@@ -368,3 +368,28 @@ def test_leaves_on_the_side_stream_give_the_same_bits(ctx):
         assert a["nells"] == b["nells"]
         for k in a:
             np.testing.assert_array_equal(np.asarray(a[k]), np.asarray(b[k]))
+
+
+def test_root_of_more_runs_than_fit_at_once_goes_in_chunks_with_the_same_bits(ctx):
+    """Round 6: the cooperative root (k_root_parts: ceil(n / 256) workgroups per run that meet at spin waits) needs
+    its workgroups co-resident; 144 runs x 8 parts do not fit the 512 slots, so the runs go in chunks of 64 -- same
+    bits as the single-workgroup root the launcher fell back to before (DH_ROOT_CHUNK=0) and as 144 separate calls'
+    first runs."""
+    import os
+    base = inputs.cloud("c2")
+    sets = [base[np.random.default_rng(r).permutation(len(base))] for r in range(144)]
+    got = ctx.rebuild_many(sets, multi=True)
+    os.environ["DH_ROOT_CHUNK"] = "0"
+    try:
+        ref = ctx.rebuild_many(sets, multi=True)
+    finally:
+        del os.environ["DH_ROOT_CHUNK"]
+    assert len(got) == len(ref) == 144
+    for a, b in zip(ref, got):
+        assert a["nells"] == b["nells"] and a["nells"] >= 1
+        for k in a:
+            np.testing.assert_array_equal(np.asarray(a[k]), np.asarray(b[k]))
+    for r in (0, 63, 64, 143):  # either side of a chunk boundary against the run on its own
+        one = ctx.rebuild(sets[r], multi=True)
+        for k in FIELDS:
+            np.testing.assert_array_equal(np.asarray(one[k]), np.asarray(got[r][k]))
