@@ -4246,14 +4246,30 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
       const int v = e ? atoi(e) : 0;
       return v >= 1 && v <= 100 ? v : 87;
     }();
-    int cr = cap_split_level > 0 ? (int)((long long)cap_split_level * resident_pct / 100) / gp : 1;
+    // (round 6) no more k_ell / k_ell_wave workgroups than a few rounds of the chip: a workgroup takes every ge-th child
+    // of its run (the kernels' own loops).  The bound above is the worst case; a many-mode tree's deep level (eggbox 2-D,
+    // nlive 5 000, 16 runs: 1 065 parts and 1 252 children possible per run, some 200 there) was 20 000 workgroups of
+    // which a fifth found work, and the dispatch of the rest half the level's time.
+    const int grid_cap = getenv("DH_LEVEL_GRID_CAP") ? atoi(getenv("DH_LEVEL_GRID_CAP")) : 1;
+    const int split_room = cap_split_level > 0 ? (int)((long long)cap_split_level * resident_pct / 100) : 1;
+    const int gp_l = gp;  // (k_split keeps the worst case: a loop over parts in it costs registers it does not have --
+                          // 5 spilled VGPRs -- and, where the parts are real, serialises two k-means chains)
+    int ge_l = ge, gw_l = ge;
+    if (grid_cap > 0) {
+      const int cap_ell = 2 * ctx->num_cu;  // (k_ell: two workgroups per CU)
+      const int want_e = 8 * cap_ell / runs > 1 ? 8 * cap_ell / runs : 1;
+      if (want_e < ge_l) ge_l = want_e;
+      const int want_w = 16384 / runs > 1 ? 16384 / runs : 1;
+      if (want_w < gw_l) gw_l = want_w;
+    }
+    int cr = cap_split_level > 0 ? split_room / gp_l : 1;
     cr = cr < 1 ? 1 : (cr > runs ? runs : cr);
     const int nchunk = (runs + cr - 1) / cr;
     cr = (runs + nchunk - 1) / nchunk;  // (chunks of equal size)
-    hipLaunchKernelGGL(k_split, dim3(nchunk * cr * gp), dim3(kThreads), lds_split, ctx->stream, a, L, gp, cr);
+    hipLaunchKernelGGL(k_split, dim3(nchunk * cr * gp_l), dim3(kThreads), lds_split, ctx->stream, a, L, gp_l, cr);
     const int wave = L >= wave_from ? 1 : 0;
     if (L >= wave_from)
-      hipLaunchKernelGGL(k_ell_wave<64>, dim3(runs * ge), dim3(64), lds_wave, ctx->stream, a, L, ge,
+      hipLaunchKernelGGL(k_ell_wave<64>, dim3(runs * gw_l), dim3(64), lds_wave, ctx->stream, a, L, gw_l,
                          wave_cap, wave_axis, 0);
     const int lc = (leaf_cap > 0 && L >= leaf_from) ? leaf_cap : 0;
     if (lc && leaf_main)
@@ -4268,10 +4284,10 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
     static const int top_div = getenv("DH_ELL_TOP_DIV") ? atoi(getenv("DH_ELL_TOP_DIV")) : 2;
     const bool top = lds_top > 0 && (n >> (L + 1)) > kThreads && (long long)runs * ge * (top_div > 0 ? top_div : 1) <= ctx->num_cu;
     if (a.fast && tail && !(getenv("DH_ELL_DEFER") && atoi(getenv("DH_ELL_DEFER")) == 0))
-      hipLaunchKernelGGL((k_ell<false, true>), dim3(runs * ge), dim3(kThreads), top ? lds_top : lds, ctx->stream, a, L, ge, wave, lc,
+      hipLaunchKernelGGL((k_ell<false, true>), dim3(runs * ge_l), dim3(kThreads), top ? lds_top : lds, ctx->stream, a, L, ge_l, wave, lc,
                          top ? 2 * kThreads : kThreads);
     else if (a.fast)
-      hipLaunchKernelGGL(k_ell<false>, dim3(runs * ge), dim3(kThreads), top ? lds_top : lds, ctx->stream, a, L, ge, wave, lc,
+      hipLaunchKernelGGL(k_ell<false>, dim3(runs * ge_l), dim3(kThreads), top ? lds_top : lds, ctx->stream, a, L, ge_l, wave, lc,
                          top ? 2 * kThreads : kThreads);
     else
       hipLaunchKernelGGL(k_ell<true>, dim3(runs * ge), dim3(kThreads), top ? lds_top : lds, ctx->stream, a, L, ge, 0, 0,
