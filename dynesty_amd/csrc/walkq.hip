@@ -1203,9 +1203,12 @@ __global__ void __launch_bounds__(256) rwalkq_kernel(RwalkQArgs a) {
         const uint64_t rem = __ballot(!done);
         if (!rem) break;
         const int cur = __shfl(my_frame, __ffsll((long long)rem) - 1);
-        load_frags<NR, MT>(a.axes + (size_t)cur * n * n, n, j, t, F);
+        // (fragments of its own: loaded into F, the wavefronts of ONE frame -- the common case -- paid 32 register
+        // copies per step for keeping their F intact, round 6)
+        double Fn[MT][NR];
+        load_frags<NR, MT>(a.axes + (size_t)cur * n * n, n, j, t, Fn);
         mfma_acc tmp[MT];
-        frag_matvec<NR, MT>(F, dr, tmp);
+        frag_matvec<NR, MT>(Fn, dr, tmp);
         if (my_frame == cur) {
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) acc[mt] = tmp[mt];

@@ -77,14 +77,16 @@ def test_rwalkq_kernel_keeps_two_wavefronts_per_simd():
     """The four-lanes-per-walker kernel of the bench's launch shape (NR = 7: 25-D; KIND 1 = correlated Normal /
     affine prior): two wavefronts per SIMD is what the form is for; the Normal prior's erfcinv once took it to
     256 VGPRs + 160 spilled (it is excluded from this kernel since)."""
-    res = usage("walkq.hip")
+    # (round 6: walkq.hip is built with the matrix instructions' accumulators in vector registers -- csrc/Makefile
+    # FLAGS_walkq -- so that no v_accvgpr_read stands between a product and its use: AGPRs == 0 pins it)
+    res = usage("walkq.hip", ("-mllvm", "-amdgpu-mfma-vgpr-form"))
     # RNG 0 = PCG64 in the kernel, 1 = hiprand Philox in the kernel, 2 = PCG64 items (the bench's variant),
     # 3 = Philox items (the throughput mode since round 5)
     for rng in ("0", "1", "2", "3"):
         key = [k for k in res if "13rwalkq_kernelILi7ELi1ELi" + rng in k]
         assert len(key) == 1, list(res)
         r = res[key[0]]
-        assert r["VGPRs"] <= 256 and r["Occupancy [waves/SIMD]"] >= 2, r
+        assert r["VGPRs"] <= 256 and r["Occupancy [waves/SIMD]"] >= 2 and r["AGPRs"] == 0, r
         assert r["VGPRs Spill"] == 0, r
         if rng in ("2", "3"):
             assert r["ScratchSize [bytes/lane]"] == 0, r
