@@ -1768,11 +1768,15 @@ __device__ __forceinline__ int node_ellipsoid(const Lds& L, const RebuildArgs& a
       return ellipsoid_store_fast(L, a, es, cov_g, logdet, logvol_out);
     }
     // the eigen-free path does not apply (not positive definite, condition bound >= 1e7, degenerate
-    // leading eigenvalues): the reference's route, right here, with the wave-level solver
+    // leading eigenvalues): the reference's route, right here.  (round 6: with the whole-workgroup solver.  The
+    // wave-level Jacobi used to stand here -- a fraction of the registers, for a "rare" path -- and took 1.8 ms per
+    // node: in a C2 run the deep levels of three early rebuilds produce 16-175 leaves of ~55 points whose covariance
+    // bound is above 1e7, and the work-queue tail those are handed to ran 1.84 ms instead of 5 us: 5.5 ms of the
+    // loop's 135.  The level kernel hands such nodes on (CHILD: kDeferred), so its registers do not pay for this.)
     if constexpr (CHILD) return kDeferred;
     __syncthreads();
     for (int pass = 0; pass < 2; ++pass) {
-      const bool good = regularize<true>(L, cov_g, D);
+      const bool good = regularize<false>(L, cov_g, D);
       const double fmx = node_fmax(L, pts, perm, start, count, D);
       if (pass == 0) ellipsoid_rescale(L, cov_g, D, fmx);
       if (pass == 1 && fmx >= 1.0) return DH_ERR_CONTAIN;
@@ -4318,6 +4322,36 @@ int dh::rebuild_launch_full(dh_ctx* ctx, int runs, const double* pts, int n, int
     if (const char* e = getenv("DH_TREE_G")) G = atoi(e) > 0 ? atoi(e) : G;
     at.tq_sleep = getenv("DH_TREE_SLEEP") ? atoi(getenv("DH_TREE_SLEEP")) : 1;
     at.tq_nocoh = getenv("DH_TREE_NOCOH") ? atoi(getenv("DH_TREE_NOCOH")) : 0;
+    if (getenv("DH_TREE_STATS")) {  // diagnostic: what the level kernels left for the work-queue tail (a sync per rebuild)
+      int q[64];
+      (void)hipStreamSynchronize(ctx->stream);
+      (void)hipMemcpy(q, at.tq_ctl, sizeof q, hipMemcpyDeviceToHost);
+      const int nq = q[16] > 0 ? (q[16] < a.tq_cap ? q[16] : a.tq_cap) : 0;
+      std::vector<unsigned long long> items((size_t)nq + 1);
+      if (nq > 0) (void)hipMemcpy(items.data(), at.tq_items, (size_t)nq * 8, hipMemcpyDeviceToHost);
+      int nsplit = 0, nell = 0;
+      for (int i = 0; i < nq; ++i) (items[i] & kItemSplit ? nsplit : nell) += 1;
+      {  // sizes and depths of the declined nodes
+        std::vector<Node> nd((size_t)runs * a.max_nodes);
+        (void)hipMemcpy(nd.data(), a.nodes, nd.size() * sizeof(Node), hipMemcpyDeviceToHost);
+        int hist_depth[16] = {0}, cmin = 1 << 30, cmax = 0;
+        long long csum = 0;
+        for (int i = 0; i < nq; ++i)
+          if (!(items[i] & kItemSplit)) {
+            const int r = (int)((items[i] >> 40) & 0x3fffff), nn = (int)((items[i] >> 16) & 0xffffff);
+            const Node& x = nd[(size_t)r * a.max_nodes + nn];
+            hist_depth[x.depth < 15 ? x.depth : 15] += 1;
+            cmin = x.count < cmin ? x.count : cmin;
+            cmax = x.count > cmax ? x.count : cmax;
+            csum += x.count;
+          }
+        if (nell)
+          fprintf(stderr, "  declined nodes: count %d .. %d (mean %.0f); by depth 1..6: %d %d %d %d %d %d\n", cmin, cmax, (double)csum / nell,
+                  hist_depth[1], hist_depth[2], hist_depth[3], hist_depth[4], hist_depth[5], hist_depth[6]);
+      }
+      fprintf(stderr, "rebuild tail: %d items queued by the level kernels (%d runs, n %d, d %d, %d levels): %d ellipsoids (declined by the "
+              "eigen-free path) + %d k-means parts (deeper than the level plan)\n", nq, runs, n, d, nlev, nell, nsplit);
+    }
     hipLaunchKernelGGL(k_tree, dim3(G), dim3(kThreads), lds, ctx->stream, at);
   }
   if (forked && !hip_ok(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0), "hipStreamWaitEvent(join)")) return DH_ERR_HIP;
