@@ -108,6 +108,59 @@ __global__ void __launch_bounds__(64)
   }
 }
 
+// The same test with the ellipsoid's centre and precision matrix staged in LDS (round 6), for queues whose length is a
+// multiple of 256 (a workgroup's 256 candidates are of ONE run).  The form above fetches the matrix through the scalar
+// cache: 625 doubles per ellipsoid and wavefront at D = 25, eighty dependent 64-byte scalar loads in front of a chain of
+// 625 multiply-adds -- 26 us per 64 x 512 candidates, 4 % of the C2 loop.  Here the workgroup loads the 5 KB once
+// (coalesced) and every lane reads its operands as LDS broadcasts.  The same multiply-adds in the same order: the same
+// verdicts.
+template <int N>
+__global__ void __launch_bounds__(256)
+    contains_runs_lds_kernel(const double* __restrict__ x, int k, int d, int wpr, const double* __restrict__ ctrs,
+                             const double* __restrict__ ams, const int* __restrict__ nells, int max_ells, int strict,
+                             const int* __restrict__ run_mode, int my_mode, const int* __restrict__ bstatus, int* flag,
+                             int* first) {
+  __shared__ double sA[N * N + N];
+  const int t = threadIdx.x, w = blockIdx.x * 256 + t;
+  const bool live = w < k;
+  const int wi = live ? w : k - 1;
+  const int run = (blockIdx.x * 256) / wpr;  // (wpr % 256 == 0: the same for the whole workgroup)
+  const bool served = (!run_mode || run_mode[run] == my_mode) && (!bstatus || bstatus[run] == 0);
+  if (!served) return;
+  double xx[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) xx[i] = (i < d) ? x[(size_t)wi * d + i] : 0.0;
+  const int m = nells ? nells[run] : 1;
+  bool inside = false;
+  for (int a = 0; a < m; ++a) {
+    const double* __restrict__ c = ctrs + ((size_t)run * max_ells + a) * d;
+    const double* __restrict__ A = ams + ((size_t)run * max_ells + a) * d * d;
+    if (a) __syncthreads();
+    for (int e = t; e < d * d + d; e += 256) sA[e] = e < d * d ? A[e] : c[e - d * d];
+    __syncthreads();
+    double dl[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) dl[i] = (i < d) ? xx[i] - sA[d * d + (i < d ? i : 0)] : 0.0;
+    double q = 0.0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      if (i < d) {
+        double r = 0.0;
+#pragma unroll
+        for (int j = 0; j < N; ++j)
+          if (j < d) r = fma(sA[i * d + j], dl[j], r);
+        q = fma(dl[i], r, q);
+      }
+    }
+    inside = inside || (strict ? (q < 1.0) : (sqrt(q) <= 1.0));
+  }
+  const bool out = live && !inside;
+  if (out) {
+    atomicOr(&flag[run], 1);
+    if (first) atomicMin(&first[run], w - run * wpr);
+  }
+}
+
 // The same test above the register-resident dimensions.  One wavefront per start point re-read the run's precision
 // matrix (320 KB at D = 200) for every point: 109 us per 2 048-walker fill of C4, L2-bandwidth bound.  Now a workgroup of
 // four wavefronts takes P <= 8 start points OF ONE RUN: the points' offsets from the centre sit in LDS, wavefront w
@@ -197,6 +250,19 @@ int contains_runs_launch(dh_ctx* ctx, const double* x, int k, int d, int wpr, co
     const size_t lds = ((size_t)P * d + (size_t)((d + 63) / 64) * P * 64) * 8;
     hipLaunchKernelGGL(contains_runs_wide_kernel, dim3(nruns * bpr), dim3(256), lds, ctx->stream, x, k, d, wpr, P, ctrs, ams,
                        nells, max_ells, strict, run_mode, my_mode, bstatus, flag, first);
+    return hip_ok(ctx, hipGetLastError(), "contains_runs launch") ? DH_OK : DH_ERR_HIP;
+  }
+  const bool lds_form = !(getenv("DH_CONTAINS_LDS") && atoi(getenv("DH_CONTAINS_LDS")) == 0);
+  if (lds_form && d >= 9 && wpr % 256 == 0) {
+    bool hit2 = false;
+#define X(NN)                                                                                                      \
+  if (!hit2 && d <= NN) {                                                                                          \
+    hit2 = true;                                                                                                   \
+    hipLaunchKernelGGL(contains_runs_lds_kernel<NN>, dim3((k + 255) / 256), dim3(256), 0, ctx->stream, x, k, d, wpr, ctrs, \
+                       ams, nells, max_ells, strict, run_mode, my_mode, bstatus, flag, first);                      \
+  }
+    DH_DIM_LIST(X)
+#undef X
     return hip_ok(ctx, hipGetLastError(), "contains_runs launch") ? DH_OK : DH_ERR_HIP;
   }
   const dim3 grid((k + 63) / 64), block(64);

@@ -109,3 +109,29 @@ def test_class_contains_scalar_and_batch_golden(ctx, name, golden_bounding):
         np.testing.assert_array_equal(got_one, g[f"{name}/single/contains"])
     finally:
         backend.set_backend(None)
+
+
+def test_membership_test_of_the_resident_loop_lds_form_equals_scalar_form():
+    """Round 6: the start points' membership test of the resident loop (contains_runs_kernel) with the ellipsoid staged in
+    LDS by the workgroup -- for queues of a multiple of 256 entries at D >= 9 -- against the form that fetches it
+    through the scalar cache (DH_CONTAINS_LDS=0): the same multiply-adds in the same order, so whole runs are the same,
+    iteration for iteration: every record field bit for bit (multi and single bounds, two dimensions)."""
+    import os
+    import inputs
+    from dynesty_amd import _lib, problems
+    c = _lib.Context(0)
+    for prob, bound, K in ((problems.gauss_corr(13, 0.4, 5.0, "corr13"), "multi", 256),
+                           (inputs.problem("C2"), "single", 512), (inputs.problem("C2"), "multi", 256)):
+        outs = []
+        for v in ("1", "0"):
+            os.environ["DH_CONTAINS_LDS"] = v
+            try:
+                outs.append(c.ns_ensemble(prob, 6, 600, K, walks=25, bound=bound, entropy=[5], want_dead_logl=True))
+            finally:
+                del os.environ["DH_CONTAINS_LDS"]
+        a, b = outs
+        assert int(a["nbound"].sum()) > 6
+        for k in ("logz", "logzerr", "niter", "ncall", "nbound"):
+            np.testing.assert_array_equal(np.asarray(a[k]), np.asarray(b[k]), err_msg=k)
+        for r, n in enumerate(a["niter"]):  # (the store is only written up to the run's length)
+            np.testing.assert_array_equal(a["dead_logl"][r][:n], b["dead_logl"][r][:n])
