@@ -81,6 +81,15 @@ struct dh_ctx {
   // buffer, launches larger than the budget go in chunks of walkers
   int rwalk_items = 1;
   int itemgen_blocks_per_cu = 0;  // occupancy of itemgen_kernel on this context's device, asked once (walkq.hip)
+  // A request of the resident loop to the NEXT generator pass (round 6): `runs` extra workgroups in front of
+  // itemgen_kernel's grid sort each run's n live log-likelihoods by (value, slot) into out[run * stride ...] -- the
+  // order ns_consume needs for the same fill, formed in the shadow of the walk instead of at the head of the consumption.
+  // Cleared by the launch that serves it (done = 1); a launch that cannot (chunked, another generator) leaves done = 0.
+  struct PresortReq {
+    const double* keys = nullptr;  // runs x n
+    unsigned short* out = nullptr;
+    int n = 0, runs = 0, stride = 0, done = 0;
+  } presort;
   double* items = nullptr;
   size_t items_cap = 0;
   size_t items_budget = (size_t)1 << 30;

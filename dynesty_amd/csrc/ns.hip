@@ -26,6 +26,7 @@
 #include <cmath>
 
 #include "ctx.h"
+#include "ns_sort.h"
 #include "rng_pcg64.h"
 
 using namespace dh;
@@ -72,6 +73,10 @@ struct NsArgs {
   int overlap;       // 1: a run whose bound is being rebuilt sits the fill out (its rebuild runs beside the others' walk)
   int rebuild_fill;  // 1: this fill builds bounds; 0: a run that is due waits (idle) for the next fill that does
   int serial_walk;   // diagnostic (DH_NS_SERIAL=1): ns_consume walks every queue with the one-wavefront routine
+  // (round 6) the slot order of every run's live points for THIS fill, sorted by the generator pass's presort workgroups
+  // beside the walk (dh_ctx::PresortReq); presorted = 1: ns_consume reads it instead of sorting
+  const unsigned short* presort;
+  int presort_stride, presorted;
   NsRun* st;
   double* live_u;
   double* live_v;
@@ -689,12 +694,6 @@ struct WorstKey {
   int slot;
 };
 __device__ __forceinline__ bool key_before(double ka, int sa, double kb, int sb) { return ka < kb || (ka == kb && sa < sb); }
-// the same without short-circuit evaluation (the compiler turns || and && on lane values into exec-mask branches:
-// a dozen scalar branches per compare-exchange of the sort)
-__device__ __forceinline__ int key_before_nb(double ka, int sa, double kb, int sb) {
-  const int lt = ka < kb ? 1 : 0, eq = ka == kb ? 1 : 0, sl = sa < sb ? 1 : 0;
-  return lt | (eq & sl);
-}
 
 __device__ __forceinline__ int consume_sorted(const double* skey, const unsigned short* sidx, int* src, const double* ql,
                                               double* dcur, int* dj, int* dslot, int* dsrc, double* bkey, int* bslot,
@@ -801,102 +800,9 @@ __device__ __forceinline__ int consume_sorted(const double* skey, const unsigned
   return ndead;
 }
 
-// Bitonic sort of a run's slots by (log-likelihood, slot) with the elements in REGISTERS: thread t holds the SPT
-// consecutive positions t * SPT .. of the P = SPT * kT, so a compare-exchange at distance jj is inside the thread
-// (jj < SPT), a lane exchange inside the wavefront (jj < 64 SPT: __shfl_xor), and only the two or three widest
-// distances go through LDS (the slots travel, the keys are looked up again).  The version that kept the order in
-// LDS and read every key through its slot paid two dependent LDS round trips and a workgroup barrier for each of
-// the 66 stages of 2048 elements: 55 us of the 150 us of a C2 queue consumption.
-// sidx: max(P, kT) entries; padding = slot 0xFFFF / key +inf sorts to the end.
-template <int SPT>
-__device__ __attribute__((noinline)) void sort_slots(const double* skey, unsigned short* sidx, int N, int nsidx) {
-  constexpr int P = SPT * kT;
-  const int t = threadIdx.x, lane = t & 63, g0 = t * SPT;
-  double k[SPT];
-  int sl[SPT];
-#pragma unroll
-  for (int e = 0; e < SPT; ++e) {
-    const int g = g0 + e;
-    sl[e] = g < N ? g : 0xFFFF;
-    k[e] = g < N ? skey[g] : INFINITY;
-  }
-  for (int kk = 2; kk <= P; kk <<= 1) {
-    int jj = kk >> 1;
-    // distances between wavefronts: through LDS
-    for (; jj >= 64 * SPT; jj >>= 1) {
-#pragma unroll
-      for (int e = 0; e < SPT; ++e)
-        if (g0 + e < nsidx) sidx[g0 + e] = (unsigned short)sl[e];
-      __syncthreads();
-      int ps[SPT];
-      double pk[SPT];
-#pragma unroll
-      for (int e = 0; e < SPT; ++e) {
-        const int gp = (g0 + e) ^ jj;
-        ps[e] = gp < nsidx ? (int)sidx[gp] : 0xFFFF;
-      }
-#pragma unroll
-      for (int e = 0; e < SPT; ++e) pk[e] = ps[e] == 0xFFFF ? INFINITY : skey[ps[e]];
-#pragma unroll
-      for (int e = 0; e < SPT; ++e) {
-        const int g = g0 + e;
-        const int keep_min = (((g & jj) == 0) == ((g & kk) == 0)) ? 1 : 0;
-        // (a strict total order: "partner first" decides both directions; identical paddings swap harmlessly)
-        const bool take = key_before_nb(pk[e], ps[e], k[e], sl[e]) == keep_min;
-        k[e] = take ? pk[e] : k[e];
-        sl[e] = take ? ps[e] : sl[e];
-      }
-      __syncthreads();
-    }
-    // distances between lanes
-    for (; jj >= SPT; jj >>= 1) {
-      const int m = jj / SPT;
-      const bool lower = (lane & m) == 0;
-      // (all exchanges issued before the first comparison: one LDS-crossbar latency per stage, not per element)
-      int plo[SPT], phi[SPT], ps[SPT];
-      const int src_lane = (lane ^ m) << 2;
-#pragma unroll
-      for (int e = 0; e < SPT; ++e) {
-        const long long bits = __double_as_longlong(k[e]);
-        plo[e] = __builtin_amdgcn_ds_bpermute(src_lane, (int)(unsigned)bits);
-        phi[e] = __builtin_amdgcn_ds_bpermute(src_lane, (int)(unsigned)(bits >> 32));
-        ps[e] = __builtin_amdgcn_ds_bpermute(src_lane, sl[e]);
-      }
-#pragma unroll
-      for (int e = 0; e < SPT; ++e) {
-        const double pk = __longlong_as_double(((long long)phi[e] << 32) | (unsigned)plo[e]);
-        const int keep_min = (lower == (((g0 + e) & kk) == 0)) ? 1 : 0;
-        const bool take = key_before_nb(pk, ps[e], k[e], sl[e]) == keep_min;
-        k[e] = take ? pk : k[e];
-        sl[e] = take ? ps[e] : sl[e];
-      }
-    }
-    // distances inside the thread
-#pragma unroll
-    for (int J = SPT / 2; J >= 1; J >>= 1) {
-      if (J <= (kk >> 1)) {
-#pragma unroll
-        for (int e = 0; e < SPT; ++e) {
-          if ((e & J) == 0) {
-            const int e2 = e | J;
-            const int asc = (((g0 + e) & kk) == 0) ? 1 : 0;
-            const bool sw = key_before_nb(k[e2], sl[e2], k[e], sl[e]) == asc;
-            const double ka = k[e], kb = k[e2];
-            const int sa = sl[e], sb = sl[e2];
-            k[e] = sw ? kb : ka;
-            k[e2] = sw ? ka : kb;
-            sl[e] = sw ? sb : sa;
-            sl[e2] = sw ? sa : sb;
-          }
-        }
-      }
-    }
-  }
-#pragma unroll
-  for (int e = 0; e < SPT; ++e)
-    if (g0 + e < nsidx) sidx[g0 + e] = (unsigned short)sl[e];
-  __syncthreads();
-}
+// (sort_slots: ns_sort.h)
+using dh_sort::key_before_nb;
+using dh_sort::sort_slots;
 
 // The same walk without the serial chain, by the whole workgroup.  Let U_j = the run's live values at the start of
 // the fill plus the proposals accepted before entry j, dead or alive; c_j = the deaths before j.  Entry j is
@@ -1417,7 +1323,19 @@ __global__ void __launch_bounds__(kT) ns_consume(NsArgs a) {
   auto real_slot = [&](int sl) -> int { return compact ? (int)cslot[sl] : sl; };
   __syncthreads();
   NS_PROF(16);
-  {
+  if (a.presorted && !compact) {
+    const int nsidx = P > kT ? P : kT;
+    const unsigned short* pre = a.presort + (size_t)run * a.presort_stride;
+    for (int i0 = t; i0 < nsidx; i0 += 8 * kT) {
+      unsigned short sv[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) sv[q] = pre[i0 + q * kT < nsidx ? i0 + q * kT : 0];
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+        if (i0 + q * kT < nsidx) sidx[i0 + q * kT] = sv[q];
+    }
+    __syncthreads();
+  } else {
     const int nsidx = P > kT ? P : kT;
     switch (nsidx / kT) {
       case 1: sort_slots<1>(skey, sidx, NC, nsidx); break;
@@ -2148,6 +2066,9 @@ int dh_ns_consume(dh_ctx* ctx, int runs, int nlive, int queue_size, double dlogz
   a.add_live = 1;
   a.forced_exact = 0;
   a.force_first = nullptr;
+  a.presort = nullptr;
+  a.presort_stride = 0;
+  a.presorted = 0;
   a.sel_ent = nullptr;
   a.undo_u = nullptr;
   a.undo_slot = nullptr;
@@ -2335,6 +2256,9 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
   a.add_live = 1;
   a.forced_exact = 0;
   a.force_first = nullptr;
+  a.presort = nullptr;
+  a.presort_stride = 0;
+  a.presorted = 0;
   a.sel_ent = nullptr;
   a.undo_u = nullptr;
   a.undo_slot = nullptr;
@@ -2436,7 +2360,8 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
                o_fk = take((size_t)R * 4), o_pmk = take((size_t)R * 4),
                o_boot = take(bootstrap > 0 ? bootstrap_ws_bytes(R, N, D, me, bootstrap) : 8),
                o_lit = take(want_pt ? (size_t)R * N * 4 : 8), o_pid = take(want_pt ? (size_t)R * a.cap * 4 : 8),
-               o_pit = take(want_pt ? (size_t)R * a.cap * 4 : 8), o_pnc = take(want_pt ? (size_t)R * a.cap * 4 : 8);
+               o_pit = take(want_pt ? (size_t)R * a.cap * 4 : 8), o_pnc = take(want_pt ? (size_t)R * a.cap * 4 : 8),
+               o_pso = take((size_t)R * 2048 * 2);
   char* base = nullptr;
   (void)hipSetDevice(ctx->device);
   if (!hip_ok(ctx, hipMalloc((void**)&base, off), "hipMalloc(ns state)")) return DH_ERR_NOMEM;
@@ -2496,6 +2421,9 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
   a.boot_ent = (uint64_t*)(base + o_be);
   a.run_shift = (double*)(base + o_rs);
   a.force_first = (int*)(base + o_ff);
+  a.presort = (const unsigned short*)(base + o_pso);
+  a.presort_stride = 2048;
+  a.presorted = 0;
   a.sel_ent = a.forced_exact ? (uint64_t*)(base + o_se) : nullptr;
   a.undo_u = a.forced_exact ? (double*)(base + o_uu) : nullptr;
   a.undo_slot = a.forced_exact ? (int*)(base + o_us) : nullptr;
@@ -2577,6 +2505,8 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
     return rc;
   };
   const int n_frames = R * me * (a.forced_exact ? 2 : 1);
+  const bool presort_ok = sampler == 0 && N <= 2048 && !ns_consume_compact(N, K) && !a.overlap &&
+                          !(getenv("DH_NS_PRESORT") && atoi(getenv("DH_NS_PRESORT")) == 0);
   while (fill < fills_cap && ndone < R) {
     for (int burst = 0; burst < 8 && fill < fills_cap; ++burst, ++fill) {
       if (a.overlap && fill > 0 && !hip_ok(ctx, hipStreamWaitEvent(s, ev_rb, 0), "hipStreamWaitEvent(rebuild)"))
@@ -2684,9 +2614,21 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
         // 32-bit draws one walker consumes per fill: per step hiprand_normal4 x ceil(D / 4) and one
         // hiprand_uniform_double (2 draws; padded to 4 so that a fill's block stays 4-aligned)
         key.offset = (unsigned long long)fill * (unsigned long long)walks * (unsigned long long)(4 * ((D + 3) / 4) + 4);
+        // the slot order ns_consume needs, sorted in front of the generator pass's grid (beside the walk) where the
+        // whole live set is sorted (not the compact form) and fits the generator's LDS
+        if (presort_ok) {
+          ctx->presort.keys = a.live_logl;
+          ctx->presort.out = (unsigned short*)(base + o_pso);
+          ctx->presort.n = N;
+          ctx->presort.runs = R;
+          ctx->presort.stride = a.presort_stride;
+          ctx->presort.done = 0;
+        }
         rc = rwalk_launch_runs(ctx, problem, R * K, D, D, a.q_u0, a.b_axes, n_frames, a.q_frame, 1.0, 0.0, walks,
                                d_bc, a.q_rng, a.r_u, a.r_v, a.r_logl, a.r_a, a.r_b, a.q_rng_out,
                                a.run_loglstar, a.run_scale, a.run_mode, K, MODE_BOUND, philox ? &key : nullptr);
+        a.presorted = presort_ok && ctx->presort.done ? 1 : 0;
+        ctx->presort = dh_ctx::PresortReq();
       }
       else
         rc = slice_launch_runs(ctx, problem, R * K, D, sampler - 1, a.q_u0, a.b_axes, n_frames, a.q_frame, 1.0,
@@ -2695,6 +2637,7 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
                                MODE_BOUND, philox ? &key_slice : nullptr);
       if (rc) return cleanup(rc);
       hipLaunchKernelGGL(ns_consume, dim3(R), dim3(kT), lds_cons, s, a);
+      a.presorted = 0;
     }
     if (!hip_ok(ctx, hipMemcpyAsync(h_state, a.ndone, 8, hipMemcpyDeviceToHost, s), "D2H ndone") ||
         !hip_ok(ctx, hipStreamSynchronize(s), "sync"))

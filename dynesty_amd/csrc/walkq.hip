@@ -29,6 +29,7 @@
 #include <hiprand/hiprand_kernel.h>
 
 #include "ctx.h"
+#include "ns_sort.h"
 #include "rng_pcg64.h"
 
 using namespace dh;
@@ -426,6 +427,10 @@ struct ItemGenArgs {
   const uint64_t* pcg_jump;
   const int* run_mode;
   int k, n, walks, wpr, my_mode, wbase;
+  // presort workgroups (dh_ctx::PresortReq): the first ps_runs workgroups of the grid
+  const double* ps_keys;
+  unsigned short* ps_out;
+  int ps_n, ps_runs, ps_stride;
 };
 
 __device__ __forceinline__ uint64_t mad_u64_u32_s(uint32_t a, uint32_t b_uniform, uint64_t c) {
@@ -558,9 +563,48 @@ __device__ __forceinline__ void sub128_limbs(const uint32_t (&A)[4], const uint3
   R[3] = (uint32_t)(r >> 96);
 }
 
+// the slot order of one run's live points for ns_consume (see dh_ctx::PresortReq): keys into LDS, the register sort of
+// ns_sort.h, the order out to global memory.  n <= 2048.
+__device__ __attribute__((noinline)) void itemgen_presort(const double* keys, unsigned short* out, int n, unsigned char* smem) {
+  double* skey = (double*)smem;                           // n
+  unsigned short* sidx = (unsigned short*)(skey + 2048);  // P
+  const int t = threadIdx.x;
+  int P = 256;
+  while (P < n) P <<= 1;
+  for (int i0 = t; i0 < n; i0 += 8 * 256) {
+    double kv[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) kv[q] = keys[i0 + q * 256 < n ? i0 + q * 256 : 0];
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      if (i0 + q * 256 < n) skey[i0 + q * 256] = kv[q];
+  }
+  __syncthreads();
+  switch (P / 256) {
+    case 1: dh_sort::sort_slots<1>(skey, sidx, n, P); break;
+    case 2: dh_sort::sort_slots<2>(skey, sidx, n, P); break;
+    case 4: dh_sort::sort_slots<4>(skey, sidx, n, P); break;
+    default: dh_sort::sort_slots<8>(skey, sidx, n, P); break;
+  }
+  for (int i = t; i < P; i += 256) out[i] = sidx[i];
+}
+
+constexpr int kPresortLds = 2048 * 8 + 2048 * 2;
+// PRESORT: the form with presort workgroups in front of the grid (launched only when the resident loop has asked: the
+// plain form keeps its 6 KB of LDS and its 64 bytes of scratch -- with the sort's 20 KB and call frames in it the pass
+// was 3 us slower for everybody)
+template <bool PRESORT>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) itemgen_kernel(ItemGenArgs a) {
 #pragma clang fp contract(off)
-  __shared__ ZigQ zig;
+  // (one buffer: a presort workgroup never touches the ziggurat tables)
+  __shared__ __attribute__((aligned(16))) unsigned char ig_smem[!PRESORT || sizeof(ZigQ) > kPresortLds ? sizeof(ZigQ) : kPresortLds];
+  if constexpr (PRESORT) {
+    if ((int)blockIdx.x < a.ps_runs) {
+      itemgen_presort(a.ps_keys + (size_t)blockIdx.x * a.ps_n, a.ps_out + (size_t)blockIdx.x * a.ps_stride, a.ps_n, ig_smem);
+      return;
+    }
+  }
+  ZigQ& zig = *reinterpret_cast<ZigQ*>(ig_smem);
   const int tid = threadIdx.x, lane = tid & 63, wave = (int)sfirst((uint32_t)(tid >> 6));
   {
     const int i = tid;
@@ -577,8 +621,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))
   const uint32_t magic_n1 = (uint32_t)(0x100000000ull / (uint32_t)n1) + 1u;
   uint64_t U0 = 0;
   for (int b = 0; b < 64; b += n1) U0 |= 1ull << b;
-  const int nwaves = gridDim.x * 4;
-  for (int w = blockIdx.x * 4 + wave; w < a.k; w += nwaves) {
+  const int ps_runs = PRESORT ? a.ps_runs : 0;
+  const int nwaves = ((int)gridDim.x - ps_runs) * 4;
+  for (int w = ((int)blockIdx.x - ps_runs) * 4 + wave; w < a.k; w += nwaves) {
     if (a.run_mode && a.run_mode[(a.wbase + w) / a.wpr] != a.my_mode) continue;
     const uint64_t* p = a.rng_in + (size_t)w * 4;
     const U128 S00 = {p[0], p[1]};
@@ -1426,7 +1471,7 @@ int rwalkq_launch(dh_ctx* ctx, const ProblemDev& prob, int k, int ndim, const do
       int& per_cu = ctx->itemgen_blocks_per_cu;  // (per context: the library keeps no process-global state)
       if (per_cu == 0) {
         int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, itemgen_kernel, 256, 0) != hipSuccess || nb < 1) nb = 6;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, itemgen_kernel<false>, 256, 0) != hipSuccess || nb < 1) nb = 6;
         if (const char* e = getenv("DH_ITEMGEN_BLOCKS_PER_CU")) {
           const int v = atoi(e);
           if (v >= 1 && v <= 16) nb = v;
@@ -1435,7 +1480,26 @@ int rwalkq_launch(dh_ctx* ctx, const ProblemDev& prob, int k, int ndim, const do
       }
       const int gmax = ctx->num_cu * per_cu;
       if (gblocks > gmax) gblocks = gmax;
-      hipLaunchKernelGGL(itemgen_kernel, dim3(gblocks), block, 0, ctx->stream, g);
+      // the resident loop's presort request rides in front of the generator's grid (the generator's wavefronts loop
+      // over the walkers, so the `runs` slots it gives up cost it runs / grid of its time)
+      g.ps_keys = nullptr;
+      g.ps_out = nullptr;
+      g.ps_n = g.ps_runs = g.ps_stride = 0;
+      dh_ctx::PresortReq& pr = ctx->presort;
+      if (pr.keys && pr.runs > 0 && pr.n <= 2048 && first == 0 && kc == k && gblocks > 4 * pr.runs) {
+        g.ps_keys = pr.keys;
+        g.ps_out = pr.out;
+        g.ps_n = pr.n;
+        g.ps_runs = pr.runs;
+        g.ps_stride = pr.stride;
+        pr.done = 1;
+        if (gblocks + pr.runs <= gmax) gblocks += pr.runs;  // (room left: the generator keeps all its workgroups)
+      }
+      pr.keys = nullptr;
+      if (g.ps_runs > 0)
+        hipLaunchKernelGGL(itemgen_kernel<true>, dim3(gblocks), block, 0, ctx->stream, g);
+      else
+        hipLaunchKernelGGL(itemgen_kernel<false>, dim3(gblocks), block, 0, ctx->stream, g);
       a.items = ctx->items;
       a.rng_in = rng + first * 4;
     }
