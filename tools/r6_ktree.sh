@@ -20,4 +20,5 @@ for n, i in enumerate(roots):
     kf = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in seg if "k_finish" in r["Kernel_Name"]]
     print("rebuild %2d: %7.1f us root..k_out_eig, k_tree %7.1f, k_finish %6.1f" % (n, tot, sum(kt), sum(kf)))
 PY
+python tools/r6_first_rebuild.py $O | tee $O/first_rebuild.txt
 find $O -name "*.csv" -delete
