@@ -862,6 +862,10 @@ struct PhiloxItemArgs {
   const int* run_mode;
   int k, n, walks, wpr, my_mode, wbase;
   int gmagic;  // floor(1024 / (nb + 2)) + 1: lane / (nb + 2) = (lane * gmagic) >> 10 for lane < 64
+  // presort workgroups (dh_ctx::PresortReq): the first ps_runs workgroups of the grid (PRESORT form only)
+  const double* ps_keys;
+  unsigned short* ps_out;
+  int ps_n, ps_runs, ps_stride;
 };
 
 __device__ __forceinline__ uint4 philox_round(uint4 c, uint32_t k0, uint32_t k1) {
@@ -878,12 +882,23 @@ __device__ __forceinline__ uint4 philox_block(uint4 c, uint32_t k0, uint32_t k1)
   return c;
 }
 
-__global__ void __launch_bounds__(256) philox_items_kernel(PhiloxItemArgs a) {
+template <bool PRESORT>
+// (waves_per_eu: the presort's sort is a call shared with itemgen_kernel<true>; its registers are bounded by the tightest caller)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) philox_items_kernel(PhiloxItemArgs a) {
+  int block = (int)blockIdx.x;
+  if constexpr (PRESORT) {
+    __shared__ __attribute__((aligned(16))) unsigned char ps_smem[kPresortLds];
+    if (block < a.ps_runs) {
+      itemgen_presort(a.ps_keys + (size_t)block * a.ps_n, a.ps_out + (size_t)block * a.ps_stride, a.ps_n, ps_smem);
+      return;
+    }
+    block -= a.ps_runs;
+  }
   const int nb = (a.n + 3) >> 2, G = nb + 2, gpw = 64 / G, rs = 4 * (nb + 1);
   const int lane = threadIdx.x & 63;
   // (walker, step) of the wavefront's first group by scalar arithmetic, of this lane's group by a few adds: no
   // per-lane division (k walks < 2^31: the launcher's chunks see to it)
-  const int wv = (int)sfirst(blockIdx.x * 4 + (threadIdx.x >> 6));
+  const int wv = (int)sfirst(block * 4 + (threadIdx.x >> 6));
   const int gi = (lane * a.gmagic) >> 10, q = lane - gi * G;  // lane / G for lane < 64 (host-checked magic)
   const int total = a.k * a.walks;
   const int ws0 = wv * gpw;
@@ -1444,7 +1459,23 @@ int rwalkq_launch(dh_ctx* ctx, const ProblemDev& prob, int k, int ndim, const do
       const long long gpw = 64 / (nr + 2), nws = (long long)kc * walks;
       if (nws >= (1ll << 31) - 64) return fail(ctx, DH_ERR_ARG, "rwalkq: %lld walker-steps in one generator launch", nws);
       const long long gwaves = (nws + gpw - 1) / gpw;
-      hipLaunchKernelGGL(philox_items_kernel, dim3((unsigned)((gwaves + 3) / 4)), block, 0, ctx->stream, g);
+      g.ps_keys = nullptr;
+      g.ps_out = nullptr;
+      g.ps_n = g.ps_runs = g.ps_stride = 0;
+      dh_ctx::PresortReq& pr = ctx->presort;  // (as in front of the PCG64 pass below)
+      if (pr.keys && pr.runs > 0 && pr.n <= 2048 && first == 0 && kc == k && gwaves > 64ll * pr.runs) {
+        g.ps_keys = pr.keys;
+        g.ps_out = pr.out;
+        g.ps_n = pr.n;
+        g.ps_runs = pr.runs;
+        g.ps_stride = pr.stride;
+        pr.done = 1;
+      }
+      pr.keys = nullptr;
+      if (g.ps_runs > 0)
+        hipLaunchKernelGGL(philox_items_kernel<true>, dim3((unsigned)((gwaves + 3) / 4) + g.ps_runs), block, 0, ctx->stream, g);
+      else
+        hipLaunchKernelGGL(philox_items_kernel<false>, dim3((unsigned)((gwaves + 3) / 4)), block, 0, ctx->stream, g);
       a.items32 = reinterpret_cast<const float*>(ctx->items);
       a.ph_seq0 = philox->seq0 + first;
     } else {
