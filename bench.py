@@ -895,8 +895,8 @@ def reference_logz_gate():
 
 
 def _profile_path(name):
-    """The newest committed record of that name (profiles/r06, else r05, else r04)."""
-    for rnd in ("r06", "r05", "r04"):
+    """The newest committed record of that name (profiles/r06/final = the round's last code, else r06, r05, r04)."""
+    for rnd in (os.path.join("r06", "final"), "r06", "r05", "r04"):
         p = os.path.join(ROOT, "profiles", rnd, name)
         if os.path.exists(p):
             return p
