@@ -3617,16 +3617,14 @@ __global__ void __launch_bounds__(64)
 // The eigen-system of cov is taken from the stored principal axes
 // (v = axes / axlens, l = axlens^2) instead of a fresh eigh(cov).
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(1024)
-    scale_logvol_kernel(int m, int D, double* covs, double* ams, double* axes, double* axlens,
-                        double* logvols, const double* __restrict__ targets, double shift,
-                        const int* __restrict__ nells, int stride, const int* __restrict__ active,
-                        const double* __restrict__ run_shift) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+__device__ __forceinline__ void scale_logvol_one(int e, int m, int D, double* covs, double* ams, double* axes, double* axlens,
+                                                 double* logvols, const double* __restrict__ targets, double shift,
+                                                 const int* __restrict__ nells, int stride, const int* __restrict__ active,
+                                                 const double* __restrict__ run_shift, unsigned char* smem) {
   double* fax = (double*)smem;  // D
   double* lax = fax + D;        // D  log axlens
   int* iso = (int*)(lax + D);
-  const int e = blockIdx.x, lane = threadIdx.x, nt = blockDim.x;  // nt = 64 (one wavefront) or more at wide D
+  const int lane = threadIdx.x, nt = blockDim.x;  // nt = 64 (one wavefront) or more at wide D
   auto sync = [&]() {
     if (nt > 64)
       __syncthreads();
@@ -3722,6 +3720,26 @@ __global__ void __launch_bounds__(1024)
   }
   if (lane == 0) logvols[e] = target;
 }
+// G = 0: workgroup e takes ellipsoid e.  G > 0 (the batched forms, round 6): workgroup (run, g) takes slots g, g + G, ...
+// of its run -- the resident loop's enlarge launched runs x max_ells workgroups (64 x 40) for the one to three
+// ellipsoids a run holds, 38 us of dispatch per rebuild.
+__global__ void __launch_bounds__(1024)
+    scale_logvol_kernel(int m, int D, double* covs, double* ams, double* axes, double* axlens,
+                        double* logvols, const double* __restrict__ targets, double shift,
+                        const int* __restrict__ nells, int stride, const int* __restrict__ active,
+                        const double* __restrict__ run_shift, int G) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  if (G <= 0) {
+    scale_logvol_one((int)blockIdx.x, m, D, covs, ams, axes, axlens, logvols, targets, shift, nells, stride, active, run_shift, smem);
+    return;
+  }
+  const int run = (int)blockIdx.x / G;
+  const int cnt = nells ? min(nells[run], stride) : stride;
+  for (int slot = (int)blockIdx.x % G; slot < cnt; slot += G) {
+    scale_logvol_one(run * stride + slot, m, D, covs, ams, axes, axlens, logvols, targets, shift, nells, stride, active, run_shift, smem);
+    __syncthreads();
+  }
+}
 
 size_t rebuild_lds_bytes(int D, int TP = kThreads) {
   const size_t base = rebuild_lds_base_bytes(D, TP);
@@ -3791,9 +3809,10 @@ int dh::enlarge_launch_masked(dh_ctx* ctx, int runs, int max_ells, const int32_t
                               double* ams, double* axes, double* axlens, double* logvols,
                               double log_enlarge, const int* active, const double* run_shift) {
   const int m = runs * max_ells;
-  hipLaunchKernelGGL(scale_logvol_kernel, dim3(m), dim3(d > 64 ? 1024 : 256), (size_t)2 * d * 8 + 64, ctx->stream, m, d,
+  const int G = nells ? (max_ells < 4 ? max_ells : 4) : 0;
+  hipLaunchKernelGGL(scale_logvol_kernel, dim3(G > 0 ? runs * G : m), dim3(d > 64 ? 1024 : 256), (size_t)2 * d * 8 + 64, ctx->stream, m, d,
                      covs, ams, axes, axlens, logvols, (const double*)nullptr, log_enlarge, nells, max_ells,
-                     active, run_shift);
+                     active, run_shift, G);
   return hip_ok(ctx, hipGetLastError(), "enlarge launch") ? DH_OK : DH_ERR_HIP;
 }
 
@@ -4506,9 +4525,10 @@ int dh_enlarge_batch_dev(dh_ctx* ctx, int runs, int max_ells, const int32_t* nel
   if (!nells || !covs || !ams || !axes || !axlens || !logvols || d < 1 || max_ells < 1)
     return fail(ctx, DH_ERR_ARG, "enlarge: bad arguments");
   const int m = runs * max_ells;
-  hipLaunchKernelGGL(scale_logvol_kernel, dim3(m), dim3(d > 64 ? 1024 : 256), (size_t)2 * d * 8 + 64, ctx->stream, m, d,
+  const int G = max_ells < 4 ? max_ells : 4;
+  hipLaunchKernelGGL(scale_logvol_kernel, dim3(runs * G), dim3(d > 64 ? 1024 : 256), (size_t)2 * d * 8 + 64, ctx->stream, m, d,
                      covs, ams, axes, axlens, logvols, (const double*)nullptr, log_enlarge, nells,
-                     max_ells, (const int*)nullptr, (const double*)nullptr);
+                     max_ells, (const int*)nullptr, (const double*)nullptr, G);
   return hip_ok(ctx, hipGetLastError(), "enlarge launch") ? DH_OK : DH_ERR_HIP;
 }
 
@@ -4531,7 +4551,7 @@ int dh_scale_to_logvol(dh_ctx* ctx, int m, int d, double* covs, double* ams, dou
   if (!d_c || !d_p || !d_x || !d_al || !d_lv || !d_t) return DH_ERR_NOMEM;
   hipLaunchKernelGGL(scale_logvol_kernel, dim3(m), dim3(d > 64 ? 1024 : 256), (size_t)2 * d * 8 + 64, ctx->stream, m, d,
                      d_c, d_p, d_x, d_al, d_lv, d_t, 0.0, (const int*)nullptr, 1, (const int*)nullptr,
-                     (const double*)nullptr);
+                     (const double*)nullptr, 0);
   if (!hip_ok(ctx, hipGetLastError(), "scale_to_logvol launch")) return DH_ERR_HIP;
   if (!down(ctx, covs, d_c, (size_t)m * dd) || !down(ctx, ams, d_p, (size_t)m * dd) ||
       !down(ctx, axes, d_x, (size_t)m * dd) || !down(ctx, axlens, d_al, (size_t)m * d) ||
