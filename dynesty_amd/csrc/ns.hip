@@ -632,7 +632,10 @@ __global__ void __launch_bounds__(kT) ns_reselect(NsArgs a) {
     }                                                            \
   } while (0)
 
-constexpr int kEPT = 8;  // deaths per lane in the scan phase: K <= kEPT * kT
+constexpr int kEPTMax = 8;  // deaths per lane in the scan phases: K <= kEPTMax * kT
+// (round 6) ns_consume and its parallel walk are compiled for kEPT = 1, 2, 4, 8 deaths per lane and launched for the
+// smallest that holds the queue: with one form for all, a queue of 512 carried eight-element register arrays and
+// eight-trip loops of which two trips did anything.
 
 // LDS of ns_consume: keys and slot sources by slot, the sorted slot order (padded to a power of two), the queue's
 // arrays and the buffer of low replacements
@@ -821,6 +824,7 @@ using dh_sort::sort_slots;
 // (rwalk handing back its start point), and when the dead-point store runs out, this routine changes nothing and
 // returns 0 -- the serial walk takes the fill.  All threads call it; cj = K ints of scratch (c_j of every entry);
 // sh = 4 shared ints; on success *ndead_out / *newmin as consume_sorted.
+template <int kEPT>
 __device__ int consume_parallel(const double* skey, const unsigned short* sidx, int* src, const double* ql, double* dcur,
                                 int* dj, int* dslot, int* dsrc, double* bkey, int* bqs, int* cj, int N, int K,
                                 long long room, int* sh, int* ndead_out, double* newmin, long long* prof) {
@@ -1141,6 +1145,7 @@ __device__ int consume_parallel(const double* skey, const unsigned short* sidx, 
   return 1;
 }
 
+template <int kEPT>
 __global__ void __launch_bounds__(kT) ns_consume(NsArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int run = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
@@ -1396,7 +1401,7 @@ __global__ void __launch_bounds__(kT) ns_consume(NsArgs a) {
   const long long room = a.dead_rel ? (long long)K + 1 : a.cap - it0;
   int walked = 0;
   if (!a.serial_walk) {
-    walked = consume_parallel(skey, sidx, src, ql, dcur, dj, dslot, dsrc, bkey, bslot, qborn, NC, K, room, &misc[4],
+    walked = consume_parallel<kEPT>(skey, sidx, src, ql, dcur, dj, dslot, dsrc, bkey, bslot, qborn, NC, K, room, &misc[4],
                               &misc[0], &bcast[2], run == 0 ? a.prof : nullptr);
     if (walked && t == 0) misc[1] = -1;
     if (a.prof && run == 0 && t == 0 && !walked) atomicAdd((unsigned long long*)&a.prof[10], 1ull);
@@ -2032,6 +2037,15 @@ __global__ void __launch_bounds__(kT) ns_finish(NsArgs a) {
 
 }  // namespace
 
+namespace {
+// the instance of ns_consume for a queue of K entries (kEPT = 1, 2, 4 or 8 deaths per lane)
+typedef void (*NsConsumeFn)(NsArgs);
+inline NsConsumeFn ns_consume_for(int K) {
+  const int ept = (K + kT - 1) / kT;
+  return ept <= 1 ? ns_consume<1> : ept <= 2 ? ns_consume<2> : ept <= 4 ? ns_consume<4> : ns_consume<8>;
+}
+}  // namespace
+
 extern "C" {
 
 // see include/dynhip.h
@@ -2047,7 +2061,7 @@ int dh_ns_consume(dh_ctx* ctx, int runs, int nlive, int queue_size, double dlogz
       !dead_slot || !dead_src || !ndead || !stopped)
     return fail(ctx, DH_ERR_ARG, "ns_consume: bad arguments");
   const int R = runs, N = nlive, K = queue_size;
-  if (K > kEPT * kT) return fail(ctx, DH_ERR_ARG, "ns_consume: queue_size %d > %d", K, kEPT * kT);
+  if (K > kEPTMax * kT) return fail(ctx, DH_ERR_ARG, "ns_consume: queue_size %d > %d", K, kEPTMax * kT);
   // slots travel as 16-bit indices; beyond the register sort's 32 keys per thread (or the LDS) the consumption works on
   // the K + 1 smallest live points (ns_consume_compact)
   if (N > 65535) return fail(ctx, DH_ERR_ARG, "ns_consume: nlive %d > 65535", N);
@@ -2121,11 +2135,11 @@ int dh_ns_consume(dh_ctx* ctx, int runs, int nlive, int queue_size, double dlogz
       !hip_ok(ctx, hipMemsetAsync(a.bstatus, 0, (size_t)R * 4, s), "memset") ||
       !hip_ok(ctx, hipMemsetAsync(a.trace_n, 0, (size_t)R * 8, s), "memset"))
     return DH_ERR_HIP;
-  if (!hip_ok(ctx, hipFuncSetAttribute((const void*)ns_consume, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max), "hipFuncSetAttribute(ns_consume)") ||
+  if (!hip_ok(ctx, hipFuncSetAttribute((const void*)ns_consume_for(K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max), "hipFuncSetAttribute(ns_consume)") ||
       !hip_ok(ctx, hipFuncSetAttribute((const void*)ns_start, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max), "hipFuncSetAttribute(ns_start)"))
     return DH_ERR_HIP;
   hipLaunchKernelGGL(ns_start, dim3(R), dim3(kT), 0, s, a);  // loglstar = min, lmax = max of live_logl
-  hipLaunchKernelGGL(ns_consume, dim3(R), dim3(kT), lds_max, s, a);
+  hipLaunchKernelGGL(ns_consume_for(K), dim3(R), dim3(kT), lds_max, s, a);
   if (!hip_ok(ctx, hipGetLastError(), "ns_consume launch")) return DH_ERR_HIP;
   std::vector<int> tn((size_t)R * 2);
   if (!down(ctx, st.data(), a.st, (size_t)R) || !down(ctx, live_logl, a.live_logl, (size_t)R * N) ||
@@ -2466,13 +2480,13 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
     lds_fin += (size_t)N * 16 + (Pf > 256 ? Pf : 256) * 2;
   }
   const size_t lds_cons = ns_consume_lds(N, K);
-  if (K > kEPT * kT) return cleanup(fail(ctx, DH_ERR_ARG, "ns_ensemble: queue_size %d > %d", K, kEPT * kT));
+  if (K > kEPTMax * kT) return cleanup(fail(ctx, DH_ERR_ARG, "ns_ensemble: queue_size %d > %d", K, kEPTMax * kT));
   if (lds_cons > 150 * 1024) return cleanup(fail(ctx, DH_ERR_ARG, "ns_ensemble: nlive/queue too large for LDS"));
   const size_t lds_max = lds_cons > lds_fin ? lds_cons : lds_fin;
   if (lds_max > 150 * 1024) return cleanup(fail(ctx, DH_ERR_ARG, "ns_ensemble: nlive/queue too large for LDS"));
   if (me > kMaxCum) return cleanup(fail(ctx, DH_ERR_ARG, "ns_ensemble: nlive/(2 ndim) = %d ellipsoids > %d", me, kMaxCum));
   // the attribute is per device (and the call is cheap): set it on every call, on this context's device
-  if (!hip_ok(ctx, hipFuncSetAttribute((const void*)ns_consume, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max), "hipFuncSetAttribute(ns_consume)") ||
+  if (!hip_ok(ctx, hipFuncSetAttribute((const void*)ns_consume_for(K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max), "hipFuncSetAttribute(ns_consume)") ||
       !hip_ok(ctx, hipFuncSetAttribute((const void*)ns_start, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max), "hipFuncSetAttribute(ns_start)") ||
       !hip_ok(ctx, hipFuncSetAttribute((const void*)ns_finish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max), "hipFuncSetAttribute(ns_finish)"))
     return cleanup(DH_ERR_HIP);
@@ -2636,7 +2650,7 @@ int dh_ns_ensemble(dh_ctx* ctx, int problem, int runs, int nlive, int ndim, int 
                                a.q_rng_out, a.run_loglstar, a.run_scale, a.run_mode, a.run_doubling, K,
                                MODE_BOUND, philox ? &key_slice : nullptr);
       if (rc) return cleanup(rc);
-      hipLaunchKernelGGL(ns_consume, dim3(R), dim3(kT), lds_cons, s, a);
+      hipLaunchKernelGGL(ns_consume_for(K), dim3(R), dim3(kT), lds_cons, s, a);
       a.presorted = 0;
     }
     if (!hip_ok(ctx, hipMemcpyAsync(h_state, a.ndone, 8, hipMemcpyDeviceToHost, s), "D2H ndone") ||
