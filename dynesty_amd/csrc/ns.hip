@@ -1832,13 +1832,15 @@ __global__ void __launch_bounds__(kT) ns_consume(NsArgs a) {
     double* lv = a.live_v + (size_t)run * N * D;
     const double* ru = a.r_u + (size_t)run * K * D;
     const double* rv = a.r_v + (size_t)run * K * D;
-    // (eight elements per thread in flight: one at a time the loop ran at one global round trip per element)
+    // (sixteen elements per thread in flight -- one at a time the loop ran at one global round trip per element, with
+    // eight it was still five dependent trips per C2 fill: 20 k of the kernel's 108 k cycles)
     const int tot = nrep * D;
-    for (int e0 = t; e0 < tot; e0 += 8 * kT) {
-      size_t to[8];
-      double xu[8], xv[8];
+    constexpr int LS = 16;
+    for (int e0 = t; e0 < tot; e0 += LS * kT) {
+      size_t to[LS];
+      double xu[LS], xv[LS];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
+      for (int q = 0; q < LS; ++q) {
         const int e = e0 + q * kT;
         const int ec = e < tot ? e : 0;
         const int c = ec / D, j = ec - c * D;
@@ -1848,7 +1850,7 @@ __global__ void __launch_bounds__(kT) ns_consume(NsArgs a) {
         xv[q] = rv[from];
       }
 #pragma unroll
-      for (int q = 0; q < 8; ++q)
+      for (int q = 0; q < LS; ++q)
         if (e0 + q * kT < tot) {
           lu[to[q]] = xu[q];
           lv[to[q]] = xv[q];
