@@ -654,8 +654,12 @@ __host__ __device__ inline size_t ns_consume_lds_full(int N, int K) {
 // runs the same consumption on that subset; the slots of the death list and of the replacements are translated back
 // when they are stored.  Same deaths, same replacements, same evidence as the full arrays would give
 // (tests/test_gpu_ns_consume.py holds the two paths to each other and to the oracle).
+// (round 6) ... and where the register sort of all slots costs more than the selection: at C3 (nlive 5 000, K = 1 024)
+// the sort of 8 192 padded slots was 144 k of the kernel's 230 k cycles per fill; selected first, 1 025 of them are
+// sorted.  Taken from nlive > 4 096 (the sort's 16 and 32 elements per lane) when the queue is a quarter of the live
+// set or less.
 __host__ __device__ inline bool ns_consume_compact(int N, int K) {
-  return K + 1 < N && (N > 32 * kT || ns_consume_lds_full(N, K) > (size_t)150 * 1024);
+  return K + 1 < N && (N > 32 * kT || ns_consume_lds_full(N, K) > (size_t)150 * 1024 || (N > 4096 && 4 * (K + 1) <= N + 4));
 }
 __host__ __device__ inline bool ns_finish_big(int N) {  // ns_finish: keys by slot, keys in order, sorted slots in LDS?
   size_t P = 1;
