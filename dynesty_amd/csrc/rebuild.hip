@@ -3322,35 +3322,40 @@ __global__ void __launch_bounds__(kThreads) k_finish(RebuildArgs a) {
     double* o_ax = a.axes + (size_t)run * a.max_ells * DD;
     double* o_al = a.axlens + (size_t)run * a.max_ells * D;
     double* o_lv = a.logvols + (size_t)run * a.max_ells;
+    // (round 6) the records of ALL M ellipsoids in flight together: one ellipsoid after the other, each with its own
+    // cold reads, the copy of a 15-ellipsoid list (eggbox) was 15 round trips in a row -- half of this kernel at C3
+    for (int x = t; x < M * D; x += kThreads) {
+      const int m = x / D, e = x - m * D;
+      const double* es = estore + (size_t)reslist[rs0 + m] * NS;
+      o_ctr[x] = es[e];
+      o_al[x] = es[D + 3 * DD + e];
+    }
+    // (every load of a thread first, then its stores: the compiler cannot move a load of the record above a store to
+    // an output it may alias, and a serial chain of cold round trips was most of this phase)
+    for (int x0 = t; x0 < M * DD; x0 += 4 * kThreads) {
+      double c[4], p[4], xx[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int x = x0 + u * kThreads, xc = x < M * DD ? x : 0;
+        const int m = xc / DD, ec = xc - m * DD;
+        const double* es = estore + (size_t)reslist[rs0 + m] * NS;
+        c[u] = es[D + ec];
+        p[u] = es[D + DD + ec];
+        xx[u] = es[D + 2 * DD + ec];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int x = x0 + u * kThreads;
+        if (x < M * DD) {
+          o_cov[x] = c[u];
+          o_am[x] = p[u];
+          o_ax[x] = xx[u];
+        }
+      }
+    }
+    __syncthreads();  // (the root's side-stream eigen-system below overwrites what other threads have just copied)
     for (int m = 0; m < M; ++m) {
       const int ni = reslist[rs0 + m];
-      const double* es = estore + (size_t)ni * NS;
-      for (int e = t; e < D; e += kThreads) {
-        const double c0 = es[e], a0 = es[D + 3 * DD + e];
-        o_ctr[m * D + e] = c0;
-        o_al[m * D + e] = a0;
-      }
-      // (every load of a thread first, then its stores: the compiler cannot move a load of the record above a store to
-      // an output it may alias, and a serial chain of cold round trips was most of this phase)
-      for (int e0 = t; e0 < DD; e0 += 4 * kThreads) {
-        double c[4], p[4], x[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int e = e0 + u * kThreads, ec = e < DD ? e : 0;
-          c[u] = es[D + ec];
-          p[u] = es[D + DD + ec];
-          x[u] = es[D + 2 * DD + ec];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int e = e0 + u * kThreads;
-          if (e < DD) {
-            o_cov[(size_t)m * DD + e] = c[u];
-            o_am[(size_t)m * DD + e] = p[u];
-            o_ax[(size_t)m * DD + e] = x[u];
-          }
-        }
-      }
       int need_eig = nodes[ni].fast;
       if (need_eig && ni == 0 && a.root_eig) {
         // the root's eigen-system was solved on the side stream (k_root_eig)
