@@ -393,3 +393,25 @@ def test_root_of_more_runs_than_fit_at_once_goes_in_chunks_with_the_same_bits(ct
         one = ctx.rebuild(sets[r], multi=True)
         for k in FIELDS:
             np.testing.assert_array_equal(np.asarray(one[k]), np.asarray(got[r][k]))
+
+
+def test_capped_level_grids_give_the_same_bits(ctx):
+    """Round 6: k_ell / k_ell_wave are launched with at most a few rounds of the chip's workgroup slots and loop over
+    their run's children (DH_LEVEL_GRID_CAP=0: the worst-case grids).  A many-mode cloud in two dimensions -- hundreds of
+    small nodes per level, the shape the cap is for -- in a batch large enough for the cap to bind: every output the same."""
+    import os
+    rng = np.random.default_rng(21)
+    ctrs = rng.uniform(0.1, 0.9, (40, 2))
+    base = np.concatenate([c + 0.004 * rng.standard_normal((60, 2)) for c in ctrs])
+    sets = [base[np.random.default_rng(r).permutation(len(base))] for r in range(48)]
+    got = ctx.rebuild_many(sets, multi=True)
+    os.environ["DH_LEVEL_GRID_CAP"] = "0"
+    try:
+        ref = ctx.rebuild_many(sets, multi=True)
+    finally:
+        del os.environ["DH_LEVEL_GRID_CAP"]
+    assert max(g["nells"] for g in got) >= 10
+    for a, b in zip(ref, got):
+        assert a["nells"] == b["nells"]
+        for k in a:
+            np.testing.assert_array_equal(np.asarray(a[k]), np.asarray(b[k]))

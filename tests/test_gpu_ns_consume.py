@@ -275,3 +275,27 @@ def test_replay_of_the_whole_real_run_with_its_plateaus(ctx):
     # the volumes did leave the constant ladder
     dlv = np.log((nlive + 1.0) / nlive)
     assert abs(state[0, 0] + niter * dlv) > 1e-7
+
+
+def test_presorted_slot_order_equals_the_sort_in_place():
+    """Round 6: in an rwalk fill the live points' slot order comes from presort workgroups in front of the generator pass
+    (PCG64 items and Philox rows alike) and ns_consume reads it; DH_NS_PRESORT=0 keeps the sort inside ns_consume.  The
+    same order either way: whole runs iteration for iteration, both RNG modes, nlive at and off the sort's power of two."""
+    import os
+    from dynesty_amd import _lib, problems
+    c = _lib.Context(0)
+    prob = problems.gauss_corr(10, 0.4, 5.0, "corr10")
+    for nlive, K, rng in ((512, 128, "pcg64"), (700, 256, "pcg64"), (2000, 512, "philox")):
+        outs = []
+        for v in ("1", "0"):
+            os.environ["DH_NS_PRESORT"] = v
+            try:
+                outs.append(c.ns_ensemble(prob, 5, nlive, K, walks=20, bound="multi", entropy=[9], want_dead_logl=True, rng=rng))
+            finally:
+                del os.environ["DH_NS_PRESORT"]
+        a, b = outs
+        assert (a["status"] == 0).all() and int(a["niter"].min()) > nlive
+        for k in ("logz", "logzerr", "niter", "ncall", "nbound"):
+            np.testing.assert_array_equal(np.asarray(a[k]), np.asarray(b[k]), err_msg=k)
+        for r, n in enumerate(a["niter"]):
+            np.testing.assert_array_equal(a["dead_logl"][r][:n], b["dead_logl"][r][:n])
