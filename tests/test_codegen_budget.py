@@ -119,9 +119,10 @@ def test_ns_consume_does_not_spill_vector_registers():
     made the same code 2.6x slower); neither may spill vector registers."""
     res = usage("ns.hip")
     key = [k for k in res if "10ns_consume" in k]
-    assert len(key) == 1, list(res)
-    # (the call ABI's save area is scratch: 368 B per lane measured)
-    assert res[key[0]]["VGPRs Spill"] == 0 and res[key[0]]["ScratchSize [bytes/lane]"] <= 1024, res[key[0]]
+    assert len(key) == 4, list(res)  # (round 6: one instance per deaths-per-lane, 1 / 2 / 4 / 8)
+    for kk in key:
+        # (the call ABI's save area is scratch: 368 B per lane measured)
+        assert res[kk]["VGPRs Spill"] == 0 and res[kk]["ScratchSize [bytes/lane]"] <= 1024, res[kk]
     sorts = [k for k in res if "sort_slots" in k]
     for k in sorts:
         assert res[k]["VGPRs Spill"] == 0, (k, res[k])
