@@ -951,20 +951,24 @@ __device__ __forceinline__ void load_frags(const double* M, int n, int j, int t,
     }
 }
 
-template <int NR, int MT>
+// KS: the K steps taken by matrix instructions (NR, or NR - 1 in the R1 form of rwalkq_kernel, which adds the last
+// column by vector instructions)
+template <int NR, int MT, int KS = NR>
 __device__ __forceinline__ void frag_matvec(const double (&F)[MT][NR], const double (&x)[NR], mfma_acc (&acc)[MT]) {
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) acc[mt] = (mfma_acc){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-  for (int s = 0; s < NR; ++s)
+  for (int s = 0; s < KS; ++s)
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[mt] = DH_MFMA_F64(F[mt][s], x[s], acc[mt]);
 }
 
 // log-likelihood of the walker's v (quarter vector per sub-lane); every sub-lane returns the same bits
-template <int NR, int MT, int KIND>
+// R1 (n = 4 (NR - 1) + 1): the last K step holds ONE live column; it is added as w[row] += P[row][n - 1] v[n - 1] by
+// vector instructions (Cp: this lane's rows of that column) instead of a whole matrix instruction per row block
+template <int NR, int MT, int KIND, bool R1 = false>
 __device__ __forceinline__ double loglike_quad(const ProblemDev& P, int n, int t, const double (&v)[NR],
-                                               const double* sprec, int lane) {
+                                               const double* sprec, int lane, const double (&Cp)[NR]) {
   cdptr lp = as_const(P.like_par);
   const int lid = like_of<KIND>(P);
   if (lid == LIKE_GAUSS_PREC) {
@@ -973,9 +977,14 @@ __device__ __forceinline__ double loglike_quad(const ProblemDev& P, int n, int t
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) w[mt] = (mfma_acc){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int s = 0; s < NR; ++s)
+    for (int s = 0; s < (R1 ? NR - 1 : NR); ++s)
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) w[mt] = DH_MFMA_F64(sprec[(mt * NR + s) * 64 + lane], v[s], w[mt]);
+    if constexpr (R1) {
+      const double vb = __shfl(v[NR - 1], lane & 15);  // element n - 1 of the walker: sub-lane 0's last register
+#pragma unroll
+      for (int r = 0; r < NR; ++r) w[r >> 2][r & 3] = fma(Cp[r], vb, w[r >> 2][r & 3]);
+    }
     double q0 = 0.0, q1 = 0.0;
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
@@ -1065,7 +1074,12 @@ __device__ __forceinline__ double root_n(double ur, int n, double inv_n) {
 }
 
 // generic_random_walk (internal_samplers.py:866-986) for ndim == ncdim: four lanes per walker.  Workgroup = 4 wavefronts = 64 walkers.
-template <int NR, int KIND, int RNG>
+// R1 (round 6): n = 4 (NR - 1) + 1 -- the headline's D = 25 -- leaves ONE live column in the last K step of both
+// products; a matrix instruction per row block (2 x 86 cycles of the pipe) for it is replaced by NR multiply-adds and a
+// lane broadcast.  A matrix instruction's K steps are fused multiply-adds onto the accumulator and the padded products
+// are exact zeros, so fma(column, x, acc) is what the last instruction computed: the same bits
+// (tests/test_gpu_rwalkq.py::test_last_column_by_vector_instructions_equals_the_matrix_form).
+template <int NR, int KIND, int RNG, bool R1 = false>
 __global__ void __launch_bounds__(256) rwalkq_kernel(RwalkQArgs a) {
   constexpr int MT = (4 * NR + 15) / 16;
   constexpr int STRIDE = RingGeom<NR>::stride;
@@ -1171,6 +1185,19 @@ __global__ void __launch_bounds__(256) rwalkq_kernel(RwalkQArgs a) {
   const bool uni = __all(my_frame == f0);
   double F[MT][NR];
   load_frags<NR, MT>(a.axes + (size_t)f0 * n * n, n, j, t, F);
+  // R1: this lane's rows 4 r + t of the last column of the frame and of the precision matrix
+  double Cf[NR], Cp[NR];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    Cf[r] = Cp[r] = 0.0;
+    if constexpr (R1) {
+      const int row = 4 * r + t;
+      if (row < n) {
+        Cf[r] = a.axes[(size_t)f0 * n * n + (size_t)row * n + (n - 1)];
+        if (like_of<KIND>(a.prob) == LIKE_GAUSS_PREC) Cp[r] = a.prob.like_par[1 + (size_t)row * n + (n - 1)];
+      }
+    }
+  }
 
   int nacc = 0, nrej = 0;
   double logl_cur = 0.0;
@@ -1254,7 +1281,12 @@ __global__ void __launch_bounds__(256) rwalkq_kernel(RwalkQArgs a) {
     // du = axes @ dr on the matrix cores; walkers of a wave on different frames: one product per frame
     mfma_acc acc[MT];
     if (uni) {
-      frag_matvec<NR, MT>(F, dr, acc);
+      frag_matvec<NR, MT, R1 ? NR - 1 : NR>(F, dr, acc);
+      if constexpr (R1) {
+        const double xb = __shfl(dr[NR - 1], j);
+#pragma unroll
+        for (int r = 0; r < NR; ++r) acc[r >> 2][r & 3] = fma(Cf[r], xb, acc[r >> 2][r & 3]);
+      }
     } else {
       bool done = false;
 #pragma unroll
@@ -1306,7 +1338,7 @@ __global__ void __launch_bounds__(256) rwalkq_kernel(RwalkQArgs a) {
     // a proposal outside the cube is counted as a call and a reject, no likelihood evaluated; here the
     // evaluation runs anyway (the matrix instruction serves the whole wave) and its verdict is ignored
     prior_quad<NR, KIND>(a.prob, n, t, up, vv);
-    const double ll = loglike_quad<NR, MT, KIND>(a.prob, n, t, vv, sprec, lane);
+    const double ll = loglike_quad<NR, MT, KIND, R1>(a.prob, n, t, vv, sprec, lane, Cp);
     if (inside && ll > loglstar) {
 #pragma unroll
       for (int r = 0; r < NR; ++r) u[r] = up[r];
@@ -1318,7 +1350,7 @@ __global__ void __launch_bounds__(256) rwalkq_kernel(RwalkQArgs a) {
   }
   // v of the returned point; logl is re-evaluated when nothing was accepted (internal_samplers.py:970-975)
   prior_quad<NR, KIND>(a.prob, n, t, u, vv);
-  const double ll0 = loglike_quad<NR, MT, KIND>(a.prob, n, t, vv, sprec, lane);
+  const double ll0 = loglike_quad<NR, MT, KIND, R1>(a.prob, n, t, vv, sprec, lane, Cp);
   if (nacc == 0) logl_cur = ll0;
   if (live && on) {
 #pragma unroll
@@ -1398,12 +1430,19 @@ int rwalkq_launch(dh_ctx* ctx, const ProblemDev& prob, int k, int ndim, const do
   const dim3 block(256);
   const int kind = problem_kind(prob.like_id, prob.prior_id) == KIND_PREC_AFFINE ? KIND_PREC_AFFINE : KIND_GENERIC;
   const int nr = (ndim + 3) / 4;  // 2 <= ndim <= 32: 1 .. 8
+  // the last column by vector instructions where it is the only live one of its K step (DH_RWALKQ_R1=0: the matrix form)
+  const bool r1 = ndim % 4 == 1 && ndim >= 5 && !(getenv("DH_RWALKQ_R1") && atoi(getenv("DH_RWALKQ_R1")) == 0);
 #define L(NRR, KK, GRID)                                                                               \
   do {                                                                                                 \
-    if (a.items32)                                                                                     \
+    constexpr bool R1K = KK == KIND_PREC_AFFINE && NRR >= 2;                                            \
+    if (a.items32 && r1 && R1K)                                                                        \
+      hipLaunchKernelGGL((rwalkq_kernel<NRR, KK, RNGQ_ITEMS32, R1K>), GRID, block, 0, ctx->stream, a); \
+    else if (a.items32)                                                                                \
       hipLaunchKernelGGL((rwalkq_kernel<NRR, KK, RNGQ_ITEMS32>), GRID, block, 0, ctx->stream, a);      \
     else if (philox)                                                                                   \
       hipLaunchKernelGGL((rwalkq_kernel<NRR, KK, RNGQ_PHILOX>), GRID, block, 0, ctx->stream, a);       \
+    else if (a.items && r1 && R1K)                                                                     \
+      hipLaunchKernelGGL((rwalkq_kernel<NRR, KK, RNGQ_ITEMS, R1K>), GRID, block, 0, ctx->stream, a);   \
     else if (a.items)                                                                                  \
       hipLaunchKernelGGL((rwalkq_kernel<NRR, KK, RNGQ_ITEMS>), GRID, block, 0, ctx->stream, a);        \
     else                                                                                               \

@@ -242,3 +242,43 @@ def test_quad_periodic_and_reflective_coordinates(ctx, d):
     quad_ph = ctx.rwalk_batch_philox(prob, u0, axes, 1.0, loglstar, 20, 99, bc=bc)
     np.testing.assert_array_equal(quad_ph["accept"], lane_ph["accept"])
     np.testing.assert_allclose(quad_ph["u"], lane_ph["u"], rtol=0, atol=1e-13)
+
+
+@pytest.mark.parametrize("d", [5, 9, 13, 17, 21, 25, 29])
+def test_last_column_by_vector_instructions_equals_the_matrix_form(ctx, d):
+    """Round 6: at n = 4 (NR - 1) + 1 the last K step of the frame product and of the Gaussian quadratic form holds one
+    live column; the R1 instance of rwalkq_kernel adds it as fma(column, x, acc) by vector instructions instead of a
+    matrix instruction per row block (DH_RWALKQ_R1=0 keeps the matrix form).  The matrix instruction's K steps are fused
+    multiply-adds and the padded products exact zeros, so every bit must agree: u, v, ln L, counts, generator states --
+    PCG64 items and Philox rows, one frame and mixed frames, a batch off every granularity."""
+    import os
+    prob = problems.gauss_corr(d, 0.4, 5.0, f"corr{d}")
+    case = make_case(prob, 5200, 700 + d)
+    u0 = case["u0"][:4099]
+    k = len(u0)
+    a = case["axes"]
+    axes3 = np.stack([a, 0.5 * a[::-1, ::-1].copy(), 0.8 * a.T.copy()])
+    idx = ((np.arange(k) // 40) % 3).astype(np.int32)
+    st = ctx.seed_children([d, 3], 1, k)
+    ctx.set_rwalk_form(2)
+    ctx.set_rwalk_items(True, 1 << 30)
+
+    def both(fn):
+        out = []
+        for v in ("1", "0"):
+            os.environ["DH_RWALKQ_R1"] = v
+            try:
+                out.append(fn())
+            finally:
+                del os.environ["DH_RWALKQ_R1"]
+        return out
+    r1, mat = both(lambda: ctx.rwalk_batch(prob, u0, a, case["scale"], case["loglstar"], 45, st))
+    for key in ("u", "v", "logl", "accept", "reject", "rng_out"):
+        np.testing.assert_array_equal(r1[key], mat[key], err_msg=key)
+    assert r1["accept"].sum() > 0 and r1["reject"].sum() > 0
+    r1, mat = both(lambda: ctx.rwalk_batch(prob, u0, axes3, case["scale"], case["loglstar"], 30, st, axes_idx=idx))
+    for key in ("u", "v", "logl", "accept", "reject", "rng_out"):
+        np.testing.assert_array_equal(r1[key], mat[key], err_msg=key)
+    r1, mat = both(lambda: ctx.rwalk_batch_philox(prob, u0, a, case["scale"], case["loglstar"], 45, 4321, sequence0=3))
+    for key in ("u", "v", "logl", "accept", "reject"):
+        np.testing.assert_array_equal(r1[key], mat[key], err_msg=key)
