@@ -282,3 +282,9 @@ def test_last_column_by_vector_instructions_equals_the_matrix_form(ctx, d):
     r1, mat = both(lambda: ctx.rwalk_batch_philox(prob, u0, a, case["scale"], case["loglstar"], 45, 4321, sequence0=3))
     for key in ("u", "v", "logl", "accept", "reject"):
         np.testing.assert_array_equal(r1[key], mat[key], err_msg=key)
+    # periodic and reflective coordinates beside hard ones (a wide proposal so that wraps happen)
+    bc = (np.arange(d) % 3).astype(np.int8)
+    r1, mat = both(lambda: ctx.rwalk_batch(prob, u0, 6.0 * a, case["scale"], case["loglstar"] - 50.0, 20, st, bc=bc))
+    for key in ("u", "v", "logl", "accept", "reject", "rng_out"):
+        np.testing.assert_array_equal(r1[key], mat[key], err_msg=key)
+    assert r1["accept"].sum() > 0
